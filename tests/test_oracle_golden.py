@@ -1,0 +1,248 @@
+"""Pin the CPU oracle (oracle/cpu_ref.py) against the golden vectors produced by the reference.
+
+CPU-only (`-m "not gpu"`).  Tolerances: the oracle is float64 like the reference, so agreement is
+to rounding (1e-10) except where an optimiser (fminbound) sits in the loop (1e-6 on lambda)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+from oracle import cpu_ref as O
+
+def lam_close(ours, ref, rtol):
+    """lambda histories agree; where GCV sits on its flat floor near the fminbound lower limit
+    (1e-9) the minimiser's position is rounding noise, so only its order of magnitude is compared."""
+    ours, ref = np.asarray(ours, dtype=float), np.asarray(ref, dtype=float)
+    if ours.shape != ref.shape:
+        return False
+    floor = ref < 1e-7
+    ok_big = np.allclose(ours[~floor], ref[~floor], rtol=rtol, atol=1e-12)
+    ok_floor = np.all(ours[floor] < 1e-7)
+    return bool(ok_big and ok_floor)
+
+
+BLUR_GAUSS = [("g9x9_s3_32x32", (9, 9), (3, 3)), ("g5x7_s1-2_24x40", (5, 7), (1, 2)),
+              ("g10x10_s2_16x16", (10, 10), (2, 2)), ("g9x9_s3_64x64", (9, 9), (3, 3)),
+              ("g3x3_s1_7x5", (3, 3), (1, 1)), ("g9x9_s3_6x6", (9, 9), (3, 3))]
+
+
+@pytest.mark.parametrize("name,dim,spread", BLUR_GAUSS)
+@pytest.mark.parametrize("use_scipy", [True, False])
+def test_blur_gauss(name, dim, spread, use_scipy):
+    g = load_golden("blur2d_" + name)
+    psf, center = O.gauss_psf(dim, spread)
+    assert np.allclose(psf, g["psf"], rtol=0, atol=1e-15)
+    assert np.array_equal(center, g["center"])
+    A = O.Blur2D(psf, int(g["nx"]), int(g["ny"]), use_scipy=use_scipy)
+    assert relerr(A @ g["x"], g["fwd"]) < 1e-13
+    assert relerr(A.T @ g["y"], g["bwd"]) < 1e-13
+    out3 = A @ g["X3"]
+    assert out3.shape == g["fwd3"].shape and relerr(out3, g["fwd3"]) < 1e-13
+    assert (A @ g["x"].reshape(-1, 1)).shape == (A.shape[0], 1)
+
+
+@pytest.mark.parametrize("name", ["asym7x5_20x28", "asym4x6_33x17"])
+@pytest.mark.parametrize("use_scipy", [True, False])
+def test_blur_asymmetric(name, use_scipy):
+    g = load_golden("blur2d_" + name)
+    A = O.Blur2D(g["psf"], int(g["nx"]), int(g["ny"]), use_scipy=use_scipy)
+    assert relerr(A @ g["x"], g["fwd"]) < 1e-13
+    assert relerr(A.T @ g["y"], g["bwd"]) < 1e-13
+
+
+def test_blur_adjoint_identity_symmetric_odd_psf():
+    psf, _ = O.gauss_psf((9, 9), (3, 3))
+    A = O.Blur2D(psf, 20, 24)
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(480), rng.standard_normal(480)
+    assert abs(np.dot(A @ x, y) - np.dot(x, A.T @ y)) < 1e-12 * np.linalg.norm(x) * np.linalg.norm(y)
+
+
+@pytest.mark.parametrize("name", ["cgls_blur64_x0zero", "cgls_blur64_x0ATb", "cgls_blur64_tol"])
+def test_cgls(name):
+    g = load_golden(name)
+    N = int(g["N"])
+    A = O.Blur2D(g["psf"], N, N)
+    xt = g["x_true"] if "x_true" in g else None
+    x, info = O.cgls(A, g["b"], g["x0"], int(g["max_iter"]), float(g["tol"]), x_true=xt)
+    assert info["its"] == int(g["its"])
+    assert relerr(x, g["x"]) < 1e-10
+    assert np.allclose(info["relResidual"], g["relResidual"], rtol=1e-9)
+    if xt is not None:
+        assert np.allclose(info["relError"], g["relError"], rtol=1e-9)
+    if "x_it10" in g:
+        assert relerr(info["xHistory"][9], g["x_it10"]) < 1e-10
+    assert len(info["xHistory"]) == info["its"] and info["regParam"] == []
+
+
+def test_deblur1d_cgls_config_c1():
+    g = load_golden("deblur1d_cgls_n256")
+    n = int(g["n"])
+    assert np.allclose(O.gauss_psf_1d(n, 3), g["psf"], atol=1e-16)
+    for use_scipy in (True, False):
+        A = O.Blur1D(g["psf"], use_scipy=use_scipy)
+        assert relerr(A @ g["x_true"], g["b_true"]) < 1e-13
+        assert relerr(A.T @ g["b"], g["ATb"]) < 1e-13
+    x, info = O.cgls(A, g["b"], np.zeros((n, 1)), int(g["max_iter"]), float(g["tol"]), x_true=g["x_true"])
+    assert info["its"] == int(g["its"])
+    assert np.allclose(info["relError"][:30], g["relError"][:30], rtol=1e-6)
+    assert relerr(x, g["x"]) < 1e-5     # 50 CG steps on a numerically rank-deficient 1-D blur amplify rounding
+
+
+def test_golub_kahan_update_and_arnoldi_update():
+    g = load_golden("gk_update_blur32")
+    N = int(g["N"])
+    A = O.Blur2D(g["psf"], N, N)
+    b = g["b"].reshape(-1)
+    U, B, V = (b / np.linalg.norm(b))[:, None], None, None
+    for _ in range(int(g["steps"])):
+        U, B, V = O.golub_kahan_update(A, U, B, V)
+    assert B.shape == g["B"].shape and np.allclose(B, g["B"], rtol=1e-10, atol=1e-14)
+    assert relerr(U, g["U"]) < 1e-9 and relerr(V, g["V"]) < 1e-9
+    g = load_golden("arnoldi_update_blur32")
+    Vq, H = (b / np.linalg.norm(b))[:, None], None
+    for _ in range(int(g["steps"])):
+        Vq, H = O.arnoldi_update(A, Vq, H)
+    assert H.shape == g["H"].shape and np.allclose(H, g["H"], rtol=1e-9, atol=1e-13)
+    assert relerr(Vq, g["V"]) < 1e-9
+
+
+@pytest.mark.parametrize("d", [3, 8])
+def test_golub_kahan(d):
+    g = load_golden(f"golub_kahan_blur32_d{d}")
+    N = int(g["N"])
+    A = O.Blur2D(g["psf"], N, N)
+    U, S, V = O.golub_kahan(A, g["b"], d)
+    assert S.shape == g["S"].shape and np.allclose(S, g["S"], rtol=1e-10, atol=1e-14)
+    assert relerr(U, g["U"]) < 1e-9 and relerr(V, g["V"]) < 1e-9
+
+
+def test_arnoldi():
+    g = load_golden("arnoldi_blur32_d6")
+    N = int(g["N"])
+    A = O.Blur2D(g["psf"], N, N)
+    Q, H = O.arnoldi(A, g["b"], int(g["n_iter"]))
+    assert H.shape == g["H"].shape and np.allclose(H, g["H"], rtol=1e-9, atol=1e-13)
+    assert relerr(Q, g["Q"]) < 1e-9
+
+
+@pytest.mark.parametrize("tag", ["lam1e-2", "gcv", "dp"])
+@pytest.mark.parametrize("solver", ["hybrid_lsqr", "hybrid_gmres"])
+def test_hybrid(solver, tag):
+    g = load_golden(f"{solver}_blur32_{tag}")
+    N = int(g["N"])
+    A = O.Blur2D(g["psf"], N, N)
+    rp = {"lam1e-2": 1e-2, "gcv": "gcv", "dp": "dp"}[tag]
+    fn = getattr(O, solver)
+    x, info = fn(A, g["b"], int(g["n_iter"]), rp, g["x_true"], delta=float(g["delta"]))
+    assert info["its"] == int(g["its"]) and len(info["xHistory"]) == int(g["n_hist"])
+    assert lam_close(info["regParam_history"], g["regParam_history"], 1e-3 if tag == "gcv" else 1e-6)
+    assert np.allclose(info["relError"], g["relError"], rtol=1e-6)
+    assert relerr(x, g["x"]) < 1e-6
+    assert relerr(info["xHistory"][0], g["x_it1"]) < 1e-8
+    if solver == "hybrid_gmres":
+        assert np.allclose(info["relResidual"], g["relResidual"], rtol=1e-6, atol=1e-12)
+
+
+@pytest.mark.parametrize("tag", ["lam1e-2", "gcv", "dp"])
+def test_gks(tag):
+    g = load_golden(f"gks_blur32_{tag}")
+    N = int(g["N"])
+    A = O.Blur2D(g["psf"], N, N)
+    rp = {"lam1e-2": 1e-2, "gcv": "gcv", "dp": "dp"}[tag]
+    for L in (O.FirstDerivative2D(N), O.MatrixOp(O.first_derivative_2d(N, N))):
+        x, info = O.gks(A, g["b"], L, int(g["projection_dim"]), int(g["n_iter"]), rp, g["x_true"], delta=float(g["delta"]))
+        assert info["its"] == int(g["its"])
+        assert lam_close(info["regParam_history"], g["regParam_history"], 1e-3 if tag == "gcv" else 1e-6)
+        assert np.allclose(info["relError"], g["relError"], rtol=1e-5)
+        assert np.allclose(info["Residual"], g["Residual"], rtol=1e-4)
+        assert relerr(x, g["x"]) < 1e-5
+
+
+@pytest.mark.parametrize("tag,p,q,rp,eps", [("p2q1_lam1e-2", 2, 1, 1e-2, 0.1), ("p2q1_gcv", 2, 1, "gcv", 0.1),
+                                            ("p1q1_lam1e-2", 1, 1, 1e-2, 0.1),
+                                            ("p2q0.5_eps0.01_lam1e-3", 2, 0.5, 1e-3, 0.01)])
+def test_mmgks(tag, p, q, rp, eps):
+    g = load_golden("mmgks_blur32_" + tag)
+    N = int(g["N"])
+    assert float(g["epsilon"]) == eps
+    A = O.Blur2D(g["psf"], N, N)
+    x, info = O.mmgks(A, g["b"], O.FirstDerivative2D(N), p, q, int(g["projection_dim"]), int(g["n_iter"]), rp,
+                      g["x_true"], epsilon=eps)
+    assert info["its"] == int(g["its"])
+    assert lam_close(info["regParam_history"], g["regParam_history"], 1e-3 if rp == "gcv" else 1e-6)
+    assert np.allclose(info["relError"], g["relError"], rtol=1e-5)
+    assert np.allclose(info["Residual"], g["Residual"], rtol=1e-4)
+    assert relerr(x, g["x"]) < 1e-5
+
+
+def test_dynamic_blockdiag_spacetime():
+    g = load_golden("gks_dyn3x16_lam1e-2")
+    N, nt = int(g["N"]), int(g["nt"])
+    F = O.BlockDiag([O.Blur2D(g["psfs"][t], N, N) for t in range(nt)])
+    L = O.SpaceTimeDerivative(N, nt)
+    x, info = O.gks(F, g["b"], L, 3, int(g["n_iter"]), 1e-2, g["x_true"])
+    assert np.allclose(info["relError"], g["relError"], rtol=1e-6) and relerr(x, g["x"]) < 1e-6
+    g = load_golden("mmgks_dyn3x16_p2q1_lam1e-2")
+    x, info = O.mmgks(F, g["b"], L, 2, 1, 3, int(g["n_iter"]), 1e-2, g["x_true"])
+    assert np.allclose(info["relError"], g["relError"], rtol=1e-6) and relerr(x, g["x"]) < 1e-6
+    assert np.allclose(info["Residual"], g["Residual"], rtol=1e-5)
+
+
+def test_derivative_operators_and_weights():
+    g = load_golden("deriv_ops")
+    for n in (4, 5):
+        assert np.array_equal(O.first_derivative_1d(n).toarray(), g[f"D1_{n}"])
+        assert np.array_equal(O.first_derivative_2d(n, n).toarray(), g[f"D2_{n}"])
+        assert np.array_equal(O.FirstDerivative2D(n).todense(), g[f"D2_{n}"])
+        assert np.array_equal(O.FirstDerivative2D(n).T.todense(), g[f"D2_{n}"].T)
+    for (N, nt) in ((4, 3), (3, 2)):
+        assert np.array_equal(O.spacetime_derivative(N, N, nt).toarray(), g[f"Dst_{N}_{nt}"])
+        assert np.array_equal(O.SpaceTimeDerivative(N, nt).todense(), g[f"Dst_{N}_{nt}"])
+        assert np.array_equal(O.SpaceTimeDerivative(N, nt).T.todense(), g[f"Dst_{N}_{nt}"].T)
+    u = g["holder_u"]
+    assert np.allclose(O.smoothed_holder_weights(u, 0.1, 1), g["holder_eps0.1_p1"], rtol=1e-15)
+    assert np.allclose(O.smoothed_holder_weights(u, 0.01, 0.5), g["holder_eps0.01_p0.5"], rtol=1e-15)
+    assert np.allclose(O.smoothed_holder_weights(u, 0.1, 2), g["holder_eps0.1_p2"], rtol=1e-15)
+
+
+def test_regparam_functions():
+    g = load_golden("regparam_fn")
+    Q_A, R_A, R_L, b = g["Q_A"], g["R_A"], g["R_L"], g["b"]
+    for i, lam in enumerate(g["lams"]):
+        assert np.isclose(O.gcv_numerator(lam, Q_A, R_A, R_L, b), g["gcv_num"][i], rtol=1e-9)
+        assert np.isclose(O.gcv_denominator(lam, R_A, R_L), g["gcv_den"][i], rtol=1e-9)
+        assert np.isclose(O.lcurve_curvature(lam, R_A, R_L, Q_A.T @ b), g["curvature"][i], rtol=1e-6)
+    assert np.isclose(O.gcv_choose(Q_A, R_A, R_L, b), float(g["lam_gcv"]), rtol=1e-6)
+    assert np.isclose(O.discrepancy_choose(Q_A, R_A, R_L, b, float(g["delta"])), float(g["lam_dp"]), rtol=1e-8)
+    assert np.isclose(O.discrepancy_choose(Q_A, R_A, R_L, b, float(g["delta"]), eta=1.2), float(g["lam_dp_eta12"]), rtol=1e-8)
+    assert np.isclose(O.lcurve_choose(R_A, R_L, Q_A.T @ b), float(g["lam_lcurve"]), rtol=1e-5)
+    import scipy.linalg as sla
+    Qb, s, _ = sla.svd(g["B"], full_matrices=False)
+    k = g["B"].shape[1]
+    for i, lam in enumerate(g["lams"]):
+        assert np.isclose(O.gcv_numerator(lam, Qb, np.diag(s), np.eye(k), g["bhat"], variant="modified"), g["gcv_num_mod"][i], rtol=1e-9)
+        assert np.isclose(O.gcv_denominator(lam, np.diag(s), np.eye(k), "modified", int(g["fullsize"])), g["gcv_den_mod"][i], rtol=1e-9)
+    assert np.isclose(O.gcv_choose(Qb, np.diag(s), np.eye(k), g["bhat"], "modified", int(g["fullsize"])), float(g["lam_gcv_mod"]), rtol=1e-6)
+
+
+# ------------------------------------------------------------------ Radon: parity unpinned -> invariants
+def test_radon_oracle_invariants():
+    N = 32
+    ang = np.linspace(0, np.pi, 12, endpoint=False)
+    R = O.Radon2D(N, ang)
+    rng = np.random.default_rng(1)
+    x, y = rng.standard_normal(R.shape[1]), rng.standard_normal(R.shape[0])
+    assert abs(np.dot(R @ x, y) - np.dot(x, R.T @ y)) < 1e-12 * np.linalg.norm(R @ x) * np.linalg.norm(y)
+    img = rng.random((N, N))
+    sino = (R @ img.reshape(-1)).reshape(len(ang), N) * N
+    # axis-aligned views: angle 0 integrates along y (column sums), pi/2 along x (row sums)
+    assert np.allclose(sino[0], img.sum(axis=0), rtol=1e-12)
+    assert np.allclose(sino[6], img.sum(axis=1)[::-1], rtol=1e-9) or np.allclose(sino[6], img.sum(axis=1), rtol=1e-9)
+    # total mass is conserved for every view whose rays all stay inside the detector
+    disc = np.zeros((N, N))
+    ii, jj = np.meshgrid(np.arange(N) - (N - 1) / 2, np.arange(N) - (N - 1) / 2, indexing="ij")
+    disc[ii ** 2 + jj ** 2 <= 10 ** 2] = 1.0
+    sd = (R @ disc.reshape(-1)).reshape(len(ang), N) * N
+    assert np.allclose(sd.sum(axis=1), disc.sum(), rtol=2e-2)
+    # central ray of a centred disc of radius 10 is ~ its diameter
+    assert np.all(np.abs(sd[:, N // 2 - 1:N // 2 + 1].mean(axis=1) - 20.0) < 1.0)

@@ -1,0 +1,331 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by RUNNING THE REFERENCE in this container.
+
+TEST TOOLING, NOT PRODUCT.  Run only where /root/reference exists (the build
+container):
+
+    python tools/make_goldens.py
+
+It puts tools/oracle_shim (our stand-ins for the absent pylops / astra / h5py /
+resizeimage packages) and /root/reference on sys.path, imports the reference's
+own modules, runs them on small seeded inputs and stores plain arrays / scalars
+(inputs and expected outputs) as .npz.  No reference source, bytecode or pickled
+reference object is written anywhere — only numbers.
+
+Fixture families:
+  G1 blur2d_*            Deblurring2D.Gauss + forward_Op  (Deblurring2D.py:48-73), fwd & bwd
+  G2 cgls_*              CGLS                              (CGLS.py:16-86)
+  G3 gk_update, arnoldi_update, golub_kahan, arnoldi      (decompositions.py:20-255)
+  G4 hybrid_lsqr_*, hybrid_gmres_*                        (Hybrid_LSQR.py:25, Hybrid_GMRES.py:23)
+  G5 gks_*, mmgks_*                                       (GKS.py:27, MMGKS.py:28)
+  G6 deriv_ops                                            (operators.py:24-45)
+  G7 regparam_fn                                          (gcv.py, discrepancy_principle.py, l_curve.py)
+  G8 deblur1d_cgls                                        (Deblurring1D.py + CGLS: BASELINE config C1)
+"""
+import io
+import os
+import sys
+import contextlib
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+REF = os.environ.get("TRIPS_REFERENCE", "/root/reference")
+sys.path.insert(0, os.path.join(HERE, "oracle_shim"))
+sys.path.insert(0, REF)
+
+import numpy as np
+
+np.int0 = np.intp  # removed in NumPy 2; Deblurring1D.py:68,72 still uses it
+
+from scipy.ndimage import convolve  # noqa: E402
+from trips.solvers.CGLS import CGLS  # noqa: E402
+from trips.solvers.GKS import GKS  # noqa: E402
+from trips.solvers.MMGKS import MMGKS  # noqa: E402
+from trips.solvers.Hybrid_LSQR import Hybrid_LSQR  # noqa: E402
+from trips.solvers.Hybrid_GMRES import Hybrid_GMRES  # noqa: E402
+from trips.test_problems.Deblurring2D import Deblurring2D  # noqa: E402
+from trips.test_problems.Deblurring1D import Deblurring1D  # noqa: E402
+from trips.utilities import decompositions as dec  # noqa: E402
+from trips.utilities import operators as refops  # noqa: E402
+from trips.utilities.weights import smoothed_holder_weights  # noqa: E402
+from trips.utilities.reg_param.gcv import generalized_crossvalidation, gcv_numerator, gcv_denominator  # noqa: E402
+from trips.utilities.reg_param.discrepancy_principle import discrepancy_principle  # noqa: E402
+from trips.utilities.reg_param.l_curve import l_curve, curvature  # noqa: E402
+import scipy.linalg as la  # noqa: E402
+
+OUT = os.path.join(REPO, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+
+
+def quiet(fn, *a, **k):
+    """tqdm / print noise of the reference goes nowhere."""
+    with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+        return fn(*a, **k)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrays.items()})
+    print(f"  {name}.npz  {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def test_image(nx, ny, seed):
+    """Piecewise-constant rectangles + smooth bump + a little texture (seeded)."""
+    rng = np.random.default_rng(seed)
+    img = np.zeros((nx, ny))
+    for _ in range(4):
+        i0, j0 = rng.integers(0, nx - 2), rng.integers(0, ny - 2)
+        h, w = rng.integers(2, max(3, nx // 2)), rng.integers(2, max(3, ny // 2))
+        img[i0:i0 + h, j0:j0 + w] += rng.uniform(0.3, 1.0)
+    ii, jj = np.meshgrid(np.arange(nx), np.arange(ny), indexing="ij")
+    img += 0.5 * np.exp(-((ii - nx / 3) ** 2 + (jj - ny / 2) ** 2) / (0.05 * nx * ny))
+    img += 0.1 * rng.random((nx, ny))
+    return img
+
+
+def blur_problem(N, seed, noise=0.01, dim=(9, 9), spread=(3, 3)):
+    D = Deblurring2D(CommitCrime=True)
+    A = D.forward_Op(dim, spread, N, N)
+    PSF, center = D.Gauss(dim, spread)
+    x_true = test_image(N, N, seed).reshape(-1, 1)
+    b_true = A @ x_true
+    rng = np.random.default_rng(seed + 1000)
+    e = rng.standard_normal(b_true.shape)
+    e *= noise * np.linalg.norm(b_true) / np.linalg.norm(e)   # recipe of Deblurring2D.py:142-146, seeded
+    b = b_true + e
+    return A, PSF, x_true, b, float(np.linalg.norm(e))
+
+
+# ----------------------------------------------------------------------------------------- G1
+def g1_blur():
+    print("G1 blur")
+    cases = [
+        ("g9x9_s3_32x32", (9, 9), (3, 3), 32, 32),
+        ("g5x7_s1-2_24x40", (5, 7), (1, 2), 24, 40),
+        ("g10x10_s2_16x16", (10, 10), (2, 2), 16, 16),
+        ("g9x9_s3_64x64", (9, 9), (3, 3), 64, 64),
+        ("g3x3_s1_7x5", (3, 3), (1, 1), 7, 5),        # image smaller than tile, odd sizes
+        ("g9x9_s3_6x6", (9, 9), (3, 3), 6, 6),        # PSF larger than image: repeated reflection
+    ]
+    for name, dim, spread, nx, ny in cases:
+        D = Deblurring2D(CommitCrime=True)
+        A = D.forward_Op(dim, spread, nx, ny)
+        PSF, center = D.Gauss(dim, spread)
+        x = test_image(nx, ny, 7).reshape(-1)
+        y = test_image(nx, ny, 8).reshape(-1)
+        fwd = np.asarray(A @ x.reshape(-1, 1)).reshape(-1)
+        bwd = np.asarray(A.T @ y.reshape(-1, 1)).reshape(-1)
+        # multi-column operand (GKS.py:37 `A@V`)
+        X3 = np.stack([x, y, x - y], axis=1)
+        fwd3 = np.asarray(A @ X3)
+        save("blur2d_" + name, psf=PSF, center=center, nx=nx, ny=ny, x=x, y=y, fwd=fwd, bwd=bwd, X3=X3, fwd3=fwd3)
+    # non-separable, asymmetric PSF through the reference's exact scipy call (Deblurring2D.py:70-71)
+    rng = np.random.default_rng(3)
+    for name, kh, kw, nx, ny in [("asym7x5_20x28", 7, 5, 20, 28), ("asym4x6_33x17", 4, 6, 33, 17)]:
+        PSF = rng.random((kh, kw))
+        PSF /= PSF.sum()
+        x = test_image(nx, ny, 9)
+        y = test_image(nx, ny, 10)
+        fwd = convolve(x.reshape([nx, ny]), PSF, mode="reflect").reshape(-1)
+        bwd = convolve(y.reshape([nx, ny]), np.flipud(np.fliplr(PSF)), mode="reflect").reshape(-1)
+        save("blur2d_" + name, psf=PSF, nx=nx, ny=ny, x=x.reshape(-1), y=y.reshape(-1), fwd=fwd, bwd=bwd)
+
+
+# ----------------------------------------------------------------------------------------- G2
+def g2_cgls():
+    print("G2 CGLS")
+    N = 64
+    A, PSF, x_true, b, delta = blur_problem(N, 11)
+    n = N * N
+    x, info = quiet(CGLS, A, b, np.zeros((n, 1)), 20, 0, x_true=x_true)
+    save("cgls_blur64_x0zero", psf=PSF, N=N, b=b, x_true=x_true, x0=np.zeros((n, 1)), max_iter=20, tol=0.0,
+         x=x, relResidual=info["relResidual"], relError=info["relError"], its=info["its"],
+         x_it1=info["xHistory"][0], x_it10=info["xHistory"][9])
+    x0 = np.asarray(A.T @ b).reshape(-1, 1)
+    x, info = quiet(CGLS, A, b, x0, 20, 0, x_true=x_true)
+    save("cgls_blur64_x0ATb", psf=PSF, N=N, b=b, x_true=x_true, x0=x0, max_iter=20, tol=0.0,
+         x=x, relResidual=info["relResidual"], relError=info["relError"], its=info["its"])
+    # early stop through tol (CGLS.py:73-75)
+    for tol in (2e-2, 1e-2, 5e-3, 2e-3, 1e-3):
+        x, info = quiet(CGLS, A, b, np.zeros((n, 1)), 50, tol)
+        if 5 <= info["its"] < 40:
+            break
+    save("cgls_blur64_tol", psf=PSF, N=N, b=b, x0=np.zeros((n, 1)), max_iter=50, tol=tol,
+         x=x, relResidual=info["relResidual"], its=info["its"])
+
+
+# ----------------------------------------------------------------------------------------- G3
+def g3_decomp():
+    print("G3 decompositions")
+    N = 32
+    A, PSF, x_true, b, delta = blur_problem(N, 21)
+    # golub_kahan_update x10 exactly as Hybrid_LSQR drives it (Hybrid_LSQR.py:63-74)
+    beta = np.linalg.norm(b)
+    U = b.reshape((-1, 1)) / beta
+    B = np.empty(1)
+    V = np.empty((N * N, 1))
+    for _ in range(10):
+        U, B, V = dec.golub_kahan_update(A, U, B, V)
+    save("gk_update_blur32", psf=PSF, N=N, b=b, steps=10, U=U, B=B, V=V)
+    # arnoldi_update x10 as Hybrid_GMRES drives it (Hybrid_GMRES.py:41-47)
+    Vq = b.reshape((-1, 1)) / beta
+    H = np.empty(1)
+    for _ in range(10):
+        Vq, H = dec.arnoldi_update(A, Vq, H)
+    save("arnoldi_update_blur32", psf=PSF, N=N, b=b, steps=10, V=Vq, H=H)
+    U, S, V = quiet(dec.golub_kahan, A, b, 3)
+    save("golub_kahan_blur32_d3", psf=PSF, N=N, b=b, n_iter=3, U=U, S=S, V=V)
+    U, S, V = quiet(dec.golub_kahan, A, b, 8)
+    save("golub_kahan_blur32_d8", psf=PSF, N=N, b=b, n_iter=8, U=U, S=S, V=V)
+    Q, H = quiet(dec.arnoldi, A, b, 6)
+    save("arnoldi_blur32_d6", psf=PSF, N=N, b=b, n_iter=6, Q=Q, H=H)
+
+
+# ----------------------------------------------------------------------------------------- G4
+def g4_hybrid():
+    print("G4 hybrid")
+    N = 32
+    A, PSF, x_true, b0, delta0 = blur_problem(N, 31)
+    _, _, _, b1, delta1 = blur_problem(N, 31, noise=0.1)
+    for tag, rp, kw in [("lam1e-2", 1e-2, {}), ("gcv", "gcv", {}), ("dp", "dp", {"delta": delta1})]:
+        b, delta = (b1, delta1) if tag == "dp" else (b0, delta0)
+        x, info = quiet(Hybrid_LSQR, A, b, 12, rp, x_true, **kw)
+        save("hybrid_lsqr_blur32_" + tag, psf=PSF, N=N, b=b, x_true=x_true, n_iter=12, delta=delta,
+             x=x, regParam=info["regParam"], regParam_history=np.array(info["regParam_history"], dtype=float),
+             relError=info["relError"], its=info["its"], n_hist=len(info["xHistory"]), x_it1=info["xHistory"][0])
+        x, info = quiet(Hybrid_GMRES, A, b, 12, rp, x_true, **kw)
+        save("hybrid_gmres_blur32_" + tag, psf=PSF, N=N, b=b, x_true=x_true, n_iter=12, delta=delta,
+             x=x, regParam=info["regParam"], regParam_history=np.array(info["regParam_history"], dtype=float),
+             relError=info["relError"], relResidual=info["relResidual"], its=info["its"],
+             n_hist=len(info["xHistory"]), x_it1=info["xHistory"][0])
+
+
+# ----------------------------------------------------------------------------------------- G5
+def g5_gks():
+    print("G5 GKS / MMGKS")
+    N = 32
+    A, PSF, x_true, b0, delta0 = blur_problem(N, 41)
+    _, _, _, b1, delta1 = blur_problem(N, 41, noise=0.1)
+    L = refops.gen_first_derivative_operator_2D(N, N)
+    for tag, rp, kw in [("lam1e-2", 1e-2, {}), ("gcv", "gcv", {}), ("dp", "dp", {"delta": delta1})]:
+        b, delta = (b1, delta1) if tag == "dp" else (b0, delta0)
+        x, info = quiet(GKS, A, b, L, 3, 10, rp, x_true, **kw)
+        save("gks_blur32_" + tag, psf=PSF, N=N, b=b, x_true=x_true, projection_dim=3, n_iter=10, delta=delta,
+             x=x, regParam=info["regParam"], regParam_history=np.array(info["regParam_history"], dtype=float),
+             relError=info["relError"], Residual=info["Residual"], its=info["its"], x_it1=info["xHistory"][0])
+    for tag, p, q, rp, kw in [("p2q1_lam1e-2", 2, 1, 1e-2, {}),
+                              ("p2q1_gcv", 2, 1, "gcv", {}),
+                              ("p1q1_lam1e-2", 1, 1, 1e-2, {}),
+                              ("p2q0.5_eps0.01_lam1e-3", 2, 0.5, 1e-3, {"epsilon": 0.01})]:
+        b, delta = b0, delta0
+        x, info = quiet(MMGKS, A, b, L, p, q, 3, 10, rp, x_true, **kw)
+        save("mmgks_blur32_" + tag, psf=PSF, N=N, b=b, x_true=x_true, pnorm=p, qnorm=q, projection_dim=3, n_iter=10,
+             epsilon=kw.get("epsilon", 0.1),
+             x=x, regParam=info["regParam"], regParam_history=np.array(info["regParam_history"], dtype=float),
+             relError=info["relError"], Residual=info["Residual"], its=info["its"], x_it1=info["xHistory"][0])
+    # a dynamic (frame-major, block-diagonal) problem with the space-time derivative (config C5 shape, tiny)
+    nt, Nf = 3, 16
+    Ds = [Deblurring2D(CommitCrime=True) for _ in range(nt)]
+    spreads = [(1.0, 1.0), (1.5, 1.0), (2.0, 2.0)]
+    ops = [Ds[t].forward_Op((5, 5), spreads[t], Nf, Nf) for t in range(nt)]
+    psfs = np.stack([Ds[t].Gauss((5, 5), spreads[t])[0] for t in range(nt)])
+    import pylops
+    F = pylops.BlockDiag(ops)
+    xt = np.concatenate([test_image(Nf, Nf, 50 + t).reshape(-1) for t in range(nt)]).reshape(-1, 1)
+    bt = np.asarray(F @ xt).reshape(-1, 1)
+    rng = np.random.default_rng(77)
+    e = rng.standard_normal(bt.shape)
+    bt = bt + 0.01 * np.linalg.norm(bt) / np.linalg.norm(e) * e
+    Lst = refops.gen_spacetime_derivative_operator(Nf, Nf, nt)
+    x, info = quiet(GKS, F, bt, Lst, 3, 8, 1e-2, xt)
+    save("gks_dyn3x16_lam1e-2", psfs=psfs, N=Nf, nt=nt, b=bt, x_true=xt, projection_dim=3, n_iter=8,
+         x=x, regParam_history=np.array(info["regParam_history"], dtype=float),
+         relError=info["relError"], Residual=info["Residual"], its=info["its"])
+    x, info = quiet(MMGKS, F, bt, Lst, 2, 1, 3, 8, 1e-2, xt)
+    save("mmgks_dyn3x16_p2q1_lam1e-2", psfs=psfs, N=Nf, nt=nt, b=bt, x_true=xt, pnorm=2, qnorm=1, projection_dim=3,
+         n_iter=8, epsilon=0.1, x=x, regParam_history=np.array(info["regParam_history"], dtype=float),
+         relError=info["relError"], Residual=info["Residual"], its=info["its"])
+
+
+# ----------------------------------------------------------------------------------------- G6
+def g6_derivs():
+    print("G6 derivative operators")
+    out = {}
+    for n in (4, 5):
+        out[f"D1_{n}"] = refops.gen_first_derivative_operator(n).toarray()
+        out[f"D2_{n}"] = refops.gen_first_derivative_operator_2D(n, n).toarray()
+    out["Dst_4_3"] = refops.gen_spacetime_derivative_operator(4, 4, 3).toarray()
+    out["Dst_3_2"] = refops.gen_spacetime_derivative_operator(3, 3, 2).toarray()
+    rng = np.random.default_rng(5)
+    u = rng.standard_normal(50)
+    out["holder_u"] = u
+    out["holder_eps0.1_p1"] = smoothed_holder_weights(u, epsilon=0.1, p=1)
+    out["holder_eps0.01_p0.5"] = smoothed_holder_weights(u, epsilon=0.01, p=0.5)
+    out["holder_eps0.1_p2"] = smoothed_holder_weights(u, epsilon=0.1, p=2)
+    save("deriv_ops", **out)
+
+
+# ----------------------------------------------------------------------------------------- G7
+def g7_regparam():
+    print("G7 reg-param functions")
+    rng = np.random.default_rng(6)
+    m, k = 60, 6
+    AV = rng.standard_normal((m, k)) @ np.diag(np.logspace(0, -3, k))
+    LV = rng.standard_normal((80, k))
+    b = AV @ rng.standard_normal((k, 1)) + 0.05 * rng.standard_normal((m, 1))
+    Q_A, R_A = la.qr(AV, mode="economic")
+    _, R_L = la.qr(LV, mode="economic")
+    lams = np.array([1e-8, 1e-4, 1e-2, 1.0, 50.0])
+    num = np.array([gcv_numerator(l, Q_A, R_A, R_L, b) for l in lams])
+    den = np.array([gcv_denominator(l, R_A, R_L, b) for l in lams])
+    lam_gcv = generalized_crossvalidation(Q_A, R_A, R_L, b)
+    delta = 0.05 * np.sqrt(m)
+    lam_dp = discrepancy_principle(Q_A, R_A, R_L, b, delta=float(delta))
+    lam_dp_eta = discrepancy_principle(Q_A, R_A, R_L, b, delta=float(delta), eta=1.2)
+    curv = np.array([curvature(l, R_A, R_L, Q_A.T @ b) for l in lams])
+    lam_lc = l_curve(R_A, R_L, Q_A.T @ b)
+    # hybrid flavour: bidiagonal B, 'modified' GCV with fullsize (Hybrid_LSQR.py:81-84)
+    kk = 7
+    B = np.zeros((kk + 1, kk))
+    B[np.arange(kk), np.arange(kk)] = np.logspace(0, -2, kk)
+    B[np.arange(1, kk + 1), np.arange(kk)] = 0.5 * np.logspace(0, -2, kk)
+    bhat = np.zeros(kk + 1)
+    bhat[0] = 3.7
+    Qb, sb, _ = la.svd(B, full_matrices=False)
+    Rb = np.diag(sb)
+    num_mod = np.array([gcv_numerator(l, Qb, Rb, np.eye(kk), bhat, variant="modified") for l in lams])
+    den_mod = np.array([gcv_denominator(l, Rb, np.eye(kk), bhat, variant="modified", fullsize=500) for l in lams])
+    lam_gcv_mod = generalized_crossvalidation(Qb, Rb, np.eye(kk), bhat, variant="modified", fullsize=500)
+    save("regparam_fn", AV=AV, LV=LV, b=b, Q_A=Q_A, R_A=R_A, R_L=R_L, lams=lams, gcv_num=num, gcv_den=den,
+         lam_gcv=lam_gcv, delta=delta, lam_dp=lam_dp, lam_dp_eta12=lam_dp_eta, curvature=curv, lam_lcurve=lam_lc,
+         B=B, bhat=bhat, gcv_num_mod=num_mod, gcv_den_mod=den_mod, lam_gcv_mod=lam_gcv_mod, fullsize=500)
+
+
+# ----------------------------------------------------------------------------------------- G8
+def g8_deblur1d():
+    print("G8 1-D deblurring (BASELINE config C1)")
+    n = 256
+    D1 = Deblurring1D(CommitCrime=True)
+    A = D1.forward_Op_1D(parameter=3, nx=n)
+    x_true = D1.gen_xtrue(n, "curve0").reshape(-1, 1)
+    b_true = np.asarray(A @ x_true).reshape(-1, 1)
+    rng = np.random.default_rng(81)
+    e = rng.standard_normal(b_true.shape)
+    e *= 0.01 * np.linalg.norm(b_true) / np.linalg.norm(e)
+    b = b_true + e
+    x, info = quiet(CGLS, A, b, np.zeros((n, 1)), 50, 0, x_true=x_true)
+    ATb = np.asarray(A.T @ b).reshape(-1)
+    save("deblur1d_cgls_n256", psf=D1.PSF, n=n, x_true=x_true, b_true=b_true, b=b, ATb=ATb, max_iter=50, tol=0.0,
+         x=x, relResidual=info["relResidual"], relError=info["relError"], its=info["its"])
+
+
+if __name__ == "__main__":
+    g1_blur()
+    g2_cgls()
+    g3_decomp()
+    g4_hybrid()
+    g5_gks()
+    g6_derivs()
+    g7_regparam()
+    g8_deblur1d()
+    print("done ->", OUT)
