@@ -1,0 +1,153 @@
+/*
+ * trk.h — C ABI of libtrk.so, the MI355X (gfx950) engine behind TRIPs-Py's Krylov hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, `extern "C"`, no torch / numpy types.
+ * TRIPs-Py has no FFI today (pure NumPy/SciPy, duck-typed operators); every entry point below
+ * names the reference code (path:line under /root/reference) whose arithmetic it replaces, and
+ * INTEGRATION.md shows the ctypes binding a TRIPs-Py maintainer would add.
+ *
+ * Conventions
+ *   - every function returns int: 0 = TRK_OK, negative = error; `trk_last_error()` returns a
+ *     thread-local description of the last failure on the calling thread.
+ *   - all vectors are CALLER-OWNED DEVICE buffers of float (fp32 storage); every reduction is
+ *     accumulated in double and delivered to a CALLER-OWNED DEVICE double.  The library never
+ *     frees or retains user buffers past the call.  Its only allocations are the opaque operator
+ *     handles and a small per-stream scratch area for block partial sums.
+ *   - all work is enqueued on the caller's `stream` (a hipStream_t passed as void*; 0 = default
+ *     stream).  No entry point synchronises the device or the stream.
+ *   - "basis" arguments are ROW-PER-VECTOR: vector j of a basis V is the contiguous run
+ *     V[j*ld .. j*ld+n).  (The reference stores n x k column-major-by-NumPy-view matrices and
+ *     re-copies them with hstack/column_stack every iteration: decompositions.py:243-254,
+ *     GKS.py:91-96.)
+ *   - a COEFFICIENT is given by four arguments (double c, const double* num, const double* den,
+ *     int flags) and means  c * f(*num) / g(*den)  evaluated ON THE DEVICE when the kernel runs:
+ *     num/den may be NULL (=1); TRK_SQRT_NUM / TRK_SQRT_DEN apply sqrt() to the loaded value.
+ *     This is how alpha = ||v||, beta = gamma/delta ... stay on the GPU between kernels
+ *     (CGLS.py:61-72, decompositions.py:235-242) without a host round trip.
+ */
+#ifndef TRK_H
+#define TRK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TRK_OK 0
+#define TRK_EINVAL (-1)       /* bad argument (NULL, size, shape)            */
+#define TRK_EHIP (-2)         /* a HIP runtime call failed                    */
+#define TRK_ENOMEM (-3)       /* device / host allocation failed              */
+#define TRK_EUNSUPPORTED (-4) /* valid request this build cannot serve        */
+
+#define TRK_SQRT_NUM 1
+#define TRK_SQRT_DEN 2
+
+typedef struct trk_op trk_op; /* opaque linear operator (immutable after create) */
+typedef void* trk_stream;     /* hipStream_t */
+
+/* ---------------------------------------------------------------- library ------------- */
+int trk_version(void);                 /* 10000*major + 100*minor + patch */
+const char* trk_last_error(void);      /* thread-local, never NULL */
+/* device facts the host sizes launches / rooflines with (CU count, LDS per CU, ...). */
+int trk_device_info(int* cu_count, int* wavefront, int64_t* lds_per_cu, int64_t* hbm_bytes);
+
+/* ---------------------------------------------------------------- operators ----------- */
+/* 2-D blur, reflective boundary.  Replaces scipy.ndimage.convolve(X.reshape(nx,ny), PSF,
+ * mode='reflect') (forward) and the same with flipud(fliplr(PSF)) (the reference's "transpose"),
+ * trips/test_problems/Deblurring2D.py:66-73.  psf_host: kh x kw row-major doubles on the HOST
+ * (copied).  Rank-1 PSFs (every Deblurring2D.Gauss PSF, :48-64) take a separable LDS-tiled path.
+ * A kh x 1 PSF on an nx x 1 image is the 1-D blur of Deblurring1D.py:56-62. */
+int trk_blur2d_create(const double* psf_host, int kh, int kw, int nx, int ny, trk_op** out);
+
+/* Parallel-beam Radon transform, Joseph / linear-interpolation projector, matched adjoint.
+ * Replaces astra.OpTomo over create_proj_geom('parallel', 1, N, theta) + 'linear' projector and
+ * the /N scaling of trips/utilities/io.py:392-399.  Image N x N row-major; sinogram
+ * (n_ang, n_det) row-major.  PARITY UNPINNED (astra-toolbox is absent; see oracle/cpu_ref.py). */
+int trk_radon2d_create(int N, int n_det, const double* angles_host, int n_ang, double scale, trk_op** out);
+
+/* First-difference regularisers, matrix-free.  Replace the scipy.sparse matrices of
+ * trips/utilities/operators.py:24-36 (2-D: rows x[i,j]-x[i,j+1] then x[i,j]-x[i+1,j]) and :39-45
+ * (space-time: nt copies of the 2-D operator, then temporal rows x_t - x_{t+1}).
+ * For a time-sharded problem a rank creates the operator over its LOCAL frames and passes the
+ * first frame of the next rank via trk_spacetime_set_halo before each forward apply (and adds
+ * the returned halo contribution after each transpose apply). */
+int trk_deriv2d_create(int N, trk_op** out);
+int trk_spacetime_create(int N, int nt_local, int has_next, int has_prev, trk_op** out);
+/* forward: x_next = first frame of the next rank (N*N floats) ; transpose: y_prev = last
+ * temporal block of the previous rank's output rows (N*N floats).  Either may be NULL. */
+int trk_spacetime_set_halo(trk_op* op, const float* x_next_dev, const float* y_prev_dev);
+
+/* Block-diagonal operator over frames (pylops.BlockDiag at io.py:420; sparse slicing :223-225).
+ * The handle borrows `ops` (they must outlive it). x and y are frame-major. */
+int trk_blockdiag_create(trk_op* const* ops, int count, trk_op** out);
+
+int trk_op_shape(const trk_op* op, int64_t* rows, int64_t* cols);
+/* y = A x (transpose=0) or y = A^T y (transpose=1) for `batch` vectors, vector b at x + b*ldx,
+ * y + b*ldy.  If sumsq_dev != NULL it additionally receives sum(y*y) over all batch outputs,
+ * fp64-accumulated (the ||w||^2, ||t||^2 of CGLS.py:61,69-70 fused into the producing kernel). */
+int trk_op_apply(trk_op* op, int transpose, const float* x_dev, int64_t ldx, float* y_dev, int64_t ldy,
+                 int batch, double* sumsq_dev, trk_stream stream);
+int trk_op_destroy(trk_op* op);
+
+/* ---------------------------------------------------------------- kernel timing -------- */
+/* Measurement aid (bench.py's roofline leg): a timer holds `capacity` hipEvent pairs.  While a timer is attached to
+ * an operator, every apply in the selected direction (0 forward, 1 transpose, 2 both) records one pair tightly around
+ * its MAIN kernel, on the stream of the apply (not around the reduction finalize).  trk_timer_read synchronises on
+ * the recorded events and returns the elapsed milliseconds of each pair.  Detach with timer = NULL. */
+typedef struct trk_timer trk_timer;
+int trk_timer_create(int capacity, trk_timer** out);
+int trk_timer_reset(trk_timer* t);
+int trk_timer_read(trk_timer* t, float* ms_out, int max_out, int* count_out);
+int trk_timer_destroy(trk_timer* t);
+int trk_op_set_timer(trk_op* op, trk_timer* t, int which);
+
+/* ---------------------------------------------------------------- reductions ---------- */
+/* out = sum x*y ; out = sum x*x ; out = sum (x-y)^2      (np.dot / np.linalg.norm call sites:
+ * CGLS.py:49-50,61,70,73,76,79; decompositions.py:92,97,178,182,217,225,238,241; GKS.py:89-90) */
+int trk_dot(const float* x, const float* y, int64_t n, double* out_dev, trk_stream stream);
+int trk_nrm2sq(const float* x, int64_t n, double* out_dev, trk_stream stream);
+int trk_diff_nrm2sq(const float* x, const float* y, int64_t n, double* out_dev, trk_stream stream);
+
+/* ---------------------------------------------------------------- axpy family --------- */
+/* out = A*x + B*y, A and B device-evaluated coefficients; y may be NULL (then out = A*x);
+ * out may alias x or y.  If sumsq_dev != NULL it receives sum(out*out).
+ * (CGLS.py:65,67,72; decompositions.py:94,177,181,218,237-242) */
+int trk_axpby(int64_t n, double ca, const double* a_num, const double* a_den, int a_flags, const float* x,
+              double cb, const double* b_num, const double* b_den, int b_flags, const float* y, float* out,
+              double* sumsq_dev, trk_stream stream);
+/* out = x * y (element-wise; MMGKS.py:114,116 `wf * (...)`, `wr * (...)`). */
+int trk_mul(int64_t n, const float* x, const float* y, float* out, trk_stream stream);
+/* out = (v*v + eps*eps)^(p/2 - 1) with v = x - y (y may be NULL): the smoothed-Holder MM weights of
+ * trips/utilities/weights.py:66-68 applied to the residual A x - b (MMGKS.py:56-57) or to L x (:60,93). */
+int trk_mm_weights(int64_t n, const float* x, const float* y, double eps, double p, float* out, trk_stream stream);
+
+/* One fused CGLS vector update (CGLS.py:64-67):  step = *gamma / *delta ;
+ *   x_new = x + step*p ; r = r - step*w ;  sums_dev[0] = ||x_new||^2, sums_dev[1] = ||step*p||^2
+ *   (= ||x_new - x_old||^2, :76), sums_dev[2] = ||x_new - x_true||^2 if x_true != NULL (:79).
+ * x_new may alias x (in place) or be the next slot of an on-device history (xHistory, :66). */
+int trk_cgls_update_xr(int64_t n, int64_t m, const double* gamma_dev, const double* delta_dev, const float* x,
+                       const float* p, float* x_new, float* r, const float* w, const float* x_true,
+                       double* sums_dev, trk_stream stream);
+
+/* ---------------------------------------------------------------- tall-skinny basis ops */
+/* h[j] = sum_i w2[i] * V[j][i] * r[i], j < k  (w2 may be NULL = 1).  One pass over V.
+ * (V^T r of the (re)orthogonalisation: decompositions.py:90-94,216-218; GKS.py:86-88; MMGKS.py:119-120;
+ *  one row of a weighted Gram matrix.) */
+int trk_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* w2, double* h_dev,
+               trk_stream stream);
+/* out = a*base + s * sum_j y[j]*V[j]   (y: k device doubles; base may be NULL; out may alias base).
+ * (x = V@y: Hybrid_LSQR.py:105, Hybrid_GMRES.py:77, GKS.py:76; r -= V h: GKS.py:86-88) */
+int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y_dev, double a, const float* base,
+               double s, float* out, double* sumsq_dev, trk_stream stream);
+/* G[a][b] = sum_i w[i]^2 * W[a][i] * W[b][i]  (k x k, fp64, full symmetric; w may be NULL), and, if
+ * b1 != NULL, c1[a] = sum_i w[i]*W[a][i]*b1[i], c2[a] = sum_i w[i]^2*W[a][i]*b1[i].
+ * Replaces the from-scratch economic QR of AV*wf / LV*wr (MMGKS.py:58-59,94-95; GKS.py:54-56): the host
+ * takes R = chol(G) and Q^T b = R^-T c. */
+int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G_dev,
+              double* c1_dev, double* c2_dev, trk_stream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TRK_H */

@@ -1,0 +1,69 @@
+"""GPU parity of trips_py_amd.solvers.CGLS with the reference CGLS outputs (tests/golden/cgls_*.npz) and the oracle.
+Bar: final x <= 1e-5 relative (fp32 engine vs fp64 reference), identical `its`, info lists to 1e-4."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name", ["cgls_blur64_x0zero", "cgls_blur64_x0ATb", "cgls_blur64_tol"])
+def test_cgls_golden(name):
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.solvers import CGLS
+    g = load_golden(name)
+    N = int(g["N"])
+    A = Blur2D(g["psf"], N, N)
+    xt = g["x_true"] if "x_true" in g else None
+    x, info = CGLS(A, g["b"], g["x0"], int(g["max_iter"]), float(g["tol"]), x_true=xt)
+    assert info["its"] == int(g["its"])
+    assert isinstance(x, np.ndarray) and x.shape == (N * N, 1)
+    assert relerr(x, g["x"]) < 1e-5, relerr(x, g["x"])
+    assert np.allclose(info["relResidual"], g["relResidual"], rtol=1e-4)
+    assert len(info["xHistory"]) == info["its"] and info["regParam"] == []
+    if xt is not None:
+        assert np.allclose(info["relError"], g["relError"], rtol=1e-4)
+    if "x_it10" in g:
+        assert relerr(info["xHistory"][9], g["x_it10"]) < 1e-5
+        assert relerr(info["xHistory"][0], g["x_it1"]) < 1e-5
+
+
+def test_cgls_config_c1_deblur1d():
+    """BASELINE config C1 (1-D Gaussian deblur n=256, CGLS 50 its) through the engine."""
+    from trips_py_amd.operators import Blur1D
+    from trips_py_amd.solvers import CGLS
+    g = load_golden("deblur1d_cgls_n256")
+    n = int(g["n"])
+    A = Blur1D(g["psf"])
+    x, info = CGLS(A, g["b"], np.zeros((n, 1)), int(g["max_iter"]), float(g["tol"]), x_true=g["x_true"])
+    assert info["its"] == int(g["its"])
+    # the 1-D problem is numerically rank deficient: late CG iterates amplify fp32 rounding; early ones must agree
+    assert np.allclose(info["relError"][:15], g["relError"][:15], rtol=1e-3)
+    assert info["relError"][-1] < 2 * g["relError"][-1] + 1e-3
+
+
+def test_cgls_config_c2_512_against_oracle_and_history_off():
+    """BASELINE config C2 (blur 512^2 fp32, CGLS 100 its) vs the float64 oracle on identical inputs."""
+    from oracle import cpu_ref as O
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import add_noise, gauss_psf, synthetic_image
+    from trips_py_amd.solvers import CGLS
+    N, its = 512, 100
+    psf, _ = gauss_psf((9, 9), (3, 3))
+    xt = synthetic_image(N, 0).reshape(-1, 1)
+    Ao = O.Blur2D(psf, N, N)
+    b, _ = add_noise(Ao @ xt, 0.01, 1)
+    xo, io = O.cgls(Ao, b, np.zeros((N * N, 1)), its, 0, x_true=xt)
+    A = Blur2D(psf, N, N)
+    x, info = CGLS(A, b, np.zeros((N * N, 1)), its, 0, x_true=xt, history=False)
+    assert info["its"] == its and info["xHistory"] == []
+    assert relerr(x, xo) < 1e-5, relerr(x, xo)
+    assert np.allclose(info["relError"], io["relError"], rtol=1e-4)
+    assert np.allclose(info["relResidual"], io["relResidual"], rtol=1e-3)
+    # torch in -> torch out
+    bt = torch.from_numpy(b.astype(np.float32)).to(A.engine.device)
+    x2, info2 = CGLS(A, bt, torch.zeros(N * N, device=A.engine.device), 10, 0)
+    assert isinstance(x2, torch.Tensor) and x2.shape == (N * N, 1) and len(info2["xHistory"]) == 10
+    assert relerr(x2.cpu().numpy(), io["xHistory"][9]) < 1e-5

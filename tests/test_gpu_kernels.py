@@ -1,0 +1,163 @@
+"""GPU parity of the vector kernels against NumPy float64 on the same seeded inputs.
+All calls go through the C ABI (libtrk.so) via HipEngine.  fp32 storage / fp64 accumulation: tolerances are stated per test."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from trips_py_amd.engine import default_engine
+    return default_engine()
+
+
+def dev(eng, a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(eng.device)
+
+
+def f32(a):
+    return np.asarray(a, dtype=np.float32).astype(np.float64)
+
+
+SIZES = [1, 3, 64, 1000, 4097, 262144, 1_000_003]
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_dot_nrm2_diff(eng, n):
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    dx, dy = dev(eng, x), dev(eng, y)
+    S = eng.scalars(3)
+    eng.dot(dx, dy, S[0:1])
+    eng.nrm2sq(dx, S[1:2])
+    eng.diff_nrm2sq(dx, dy, S[2:3])
+    got = eng.to_host(S)
+    x32, y32 = f32(x), f32(y)
+    # fp64 accumulation of fp32 products: agreement with NumPy float64 on the same fp32 inputs to ~1e-13
+    assert np.isclose(got[0], np.dot(x32, y32), rtol=1e-11, atol=1e-9)
+    assert np.isclose(got[1], np.dot(x32, x32), rtol=1e-12)
+    assert np.isclose(got[2], np.sum((x32 - y32) ** 2), rtol=1e-12)
+
+
+def test_reductions_misaligned_and_empty(eng):
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(10_001)
+    big = dev(eng, x)
+    S = eng.scalars(2)
+    v = big[1:]                               # 4-byte aligned only -> scalar path
+    eng.nrm2sq(v, S[0:1])
+    eng.dot(v, v, S[1:2])
+    got = eng.to_host(S)
+    ref = np.dot(f32(x)[1:], f32(x)[1:])
+    assert np.isclose(got[0], ref, rtol=1e-12) and np.isclose(got[1], ref, rtol=1e-12)
+    e = eng.empty(0)
+    eng.nrm2sq(e, S[0:1])
+    assert eng.to_host(S)[0] == 0.0
+
+
+@pytest.mark.parametrize("n", [5, 4096, 100_003])
+def test_axpby_with_device_coefficients(eng, n):
+    from trips_py_amd.engine import Coef
+    rng = np.random.default_rng(n)
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    dx, dy, out = dev(eng, x), dev(eng, y), eng.empty(n)
+    S = eng.scalars(4)
+    S[0], S[1] = 9.0, 4.0
+    # out = (2 * sqrt(S0) / S1) x + (-1/sqrt(S1)) y
+    eng.axpby(Coef(2.0, num=S[0:1], den=S[1:2], sqrt_num=True), dx, Coef(-1.0, den=S[1:2], sqrt_den=True), dy, out, sumsq=S[2:3])
+    ref = (f32(x) * np.float32(1.5) + f32(y) * np.float32(-0.5)).astype(np.float32)
+    assert np.allclose(out.cpu().numpy(), ref, rtol=2e-7, atol=1e-7)
+    assert np.isclose(eng.to_host(S)[2], np.sum(out.cpu().numpy().astype(np.float64) ** 2), rtol=1e-12)
+    # in place, y = None (scaling)
+    eng.scale(Coef(1.0, den=S[0:1], sqrt_den=True), dx, dx)
+    assert np.allclose(dx.cpu().numpy(), f32(x) / 3.0, rtol=2e-7)
+    # aliasing out == y
+    eng.axpby(1.0, out, 2.0, dy, dy)
+    assert np.allclose(dy.cpu().numpy(), ref + 2 * f32(y), rtol=3e-7, atol=1e-6)
+
+
+@pytest.mark.parametrize("p,eps", [(1.0, 0.1), (2.0, 0.1), (0.5, 0.01), (1.5, 0.3)])
+def test_mm_weights_and_mul(eng, p, eps):
+    rng = np.random.default_rng(3)
+    n = 50_001
+    x, y = rng.standard_normal(n), rng.standard_normal(n)
+    dx, dy, out = dev(eng, x), dev(eng, y), eng.empty(n)
+    eng.mm_weights(dx, dy, eps, p, out)
+    v = (f32(x) - f32(y)).astype(np.float32).astype(np.float64)
+    ref = (v ** 2 + eps ** 2) ** (p / 2 - 1)                        # weights.py:66-68
+    assert np.allclose(out.cpu().numpy(), ref, rtol=5e-6)          # powf / rsqrt in fp32
+    eng.mm_weights(dx, None, eps, p, out)
+    assert np.allclose(out.cpu().numpy(), (f32(x) ** 2 + eps ** 2) ** (p / 2 - 1), rtol=5e-6)
+    eng.mul(dx, dy, out)
+    assert np.allclose(out.cpu().numpy(), (f32(x) * f32(y)).astype(np.float32), rtol=1e-7)
+
+
+@pytest.mark.parametrize("n,m", [(1000, 1000), (4099, 777), (262144, 92160)])
+def test_cgls_update(eng, n, m):
+    rng = np.random.default_rng(n + m)
+    x, p, xt = rng.standard_normal(n), rng.standard_normal(n), rng.standard_normal(n)
+    r, w = rng.standard_normal(m), rng.standard_normal(m)
+    dx, dp, dxt, dr, dw = (dev(eng, a) for a in (x, p, xt, r, w))
+    xn = eng.empty(n)
+    S = eng.scalars(5)
+    S[0], S[1] = 3.0, 7.0
+    eng.cgls_update(S[0:1], S[1:2], dx, dp, xn, dr, dw, dxt, S[2:5])
+    step = np.float32(3.0 / 7.0)
+    d = (step * f32(p).astype(np.float32)).astype(np.float32)
+    xr = (f32(x).astype(np.float32) + d).astype(np.float32)
+    assert np.allclose(xn.cpu().numpy(), xr, rtol=1e-6, atol=1e-7)
+    assert np.allclose(dr.cpu().numpy(), f32(r) - step * f32(w), rtol=1e-6, atol=1e-6)
+    got = eng.to_host(S)[2:5]
+    xn64 = xn.cpu().numpy().astype(np.float64)
+    assert np.isclose(got[0], np.sum(xn64 ** 2), rtol=1e-12)
+    assert np.isclose(got[1], np.sum(d.astype(np.float64) ** 2), rtol=1e-6)
+    assert np.isclose(got[2], np.sum((xn64 - f32(xt)) ** 2), rtol=1e-12)
+
+
+@pytest.mark.parametrize("k,n", [(1, 100), (3, 4096), (8, 10_001), (13, 65_536), (37, 30_000)])
+def test_gemv_t_and_gemv_n(eng, k, n):
+    rng = np.random.default_rng(k * n)
+    V = rng.standard_normal((k + 2, n))
+    r, w2 = rng.standard_normal(n), rng.random(n)
+    dV, dr, dw = dev(eng, V), dev(eng, r), dev(eng, w2)
+    H = eng.scalars(2 * k)
+    eng.gemv_t(dV, k, dr, H[0:k])
+    eng.gemv_t(dV, k, dr, H[k:2 * k], w2=dw)
+    got = eng.to_host(H)
+    V32, r32, w32 = f32(V)[:k], f32(r), f32(w2)
+    assert np.allclose(got[:k], V32 @ r32, rtol=1e-10, atol=1e-8)
+    assert np.allclose(got[k:], V32 @ (r32 * w32).astype(np.float32).astype(np.float64), rtol=1e-10, atol=1e-8)
+    # gemv_n: out = a*base + s*sum y_j V_j
+    y = rng.standard_normal(k)
+    Y = eng.scalars(k + 1)
+    Y[:k] = torch.from_numpy(y).to(eng.device)
+    base, out = dev(eng, r), eng.empty(n)
+    eng.gemv_n(dV, k, Y[0:k], out, a=0.5, base=base, s=-2.0, sumsq=Y[k:k + 1])
+    ref = 0.5 * r32 - 2.0 * (y @ V32)
+    assert np.allclose(out.cpu().numpy(), ref, rtol=1e-6, atol=1e-6)
+    assert np.isclose(eng.to_host(Y)[k], np.sum(out.cpu().numpy().astype(np.float64) ** 2), rtol=1e-12)
+    eng.gemv_n(dV, k, Y[0:k], out)                       # x = V@y form
+    assert np.allclose(out.cpu().numpy(), y @ V32, rtol=1e-6, atol=1e-6)
+    # in place: r -= V h  (GKS.py:86-88)
+    eng.gemv_n(dV, k, Y[0:k], base, a=1.0, base=base, s=-1.0)
+    assert np.allclose(base.cpu().numpy(), r32 - y @ V32, rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("k,m", [(1, 64), (3, 5000), (4, 4096), (7, 10_001), (13, 33_000)])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_wgram(eng, k, m, weighted):
+    rng = np.random.default_rng(k + m)
+    W = rng.standard_normal((k + 1, m))
+    w, b = rng.random(m) + 0.5, rng.standard_normal(m)
+    dW, dw, db = dev(eng, W), dev(eng, w), dev(eng, b)
+    G = eng.scalars(k * k + 2 * k)
+    eng.wgram(dW, k, dw if weighted else None, db, G[0:k * k], G[k * k:k * k + k], G[k * k + k:])
+    got = eng.to_host(G)
+    W32, w32, b32 = f32(W)[:k], (f32(w) if weighted else np.ones(m)), f32(b)
+    Gref = (W32 * w32 ** 2) @ W32.T
+    assert np.allclose(got[:k * k].reshape(k, k), Gref, rtol=2e-6, atol=1e-6 * np.abs(Gref).max())
+    assert np.allclose(got[:k * k].reshape(k, k), got[:k * k].reshape(k, k).T)
+    assert np.allclose(got[k * k:k * k + k], W32 @ (w32 * b32), rtol=1e-6, atol=1e-6 * m ** 0.5)
+    assert np.allclose(got[k * k + k:], W32 @ (w32 ** 2 * b32), rtol=1e-6, atol=1e-6 * m ** 0.5)

@@ -1,0 +1,149 @@
+"""Build + load libtrk.so (the C-ABI engine, include/trk.h) through ctypes.
+
+There is NO CPU fallback: if the shared library is missing or cannot be loaded, or no GPU is
+visible when a kernel is requested, the product path raises.  `build()` cross-compiles for gfx950
+with hipcc (no GPU needed) into trips_py_amd/csrc/libtrk.so, in-tree, so the built library
+travels with the source snapshot.
+"""
+import ctypes
+import os
+import shutil
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+INCLUDE = os.path.join(os.path.dirname(HERE), "include")
+LIB_PATH = os.path.join(CSRC, "libtrk.so")
+SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip"]
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
+
+
+class TrkError(RuntimeError):
+    pass
+
+
+def _hipcc():
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise TrkError("hipcc not found: cannot build libtrk.so (ROCm toolchain required)")
+    return exe
+
+
+def _stale():
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(INCLUDE, "trk.h")]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link libtrk.so.  Returns the library path."""
+    if not force and not _stale():
+        return LIB_PATH
+    hipcc = _hipcc()
+    srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+    def cc(src):
+        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+        if not force and os.path.exists(obj):
+            newest = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
+            newest = max(newest, os.path.getmtime(os.path.join(CSRC, src)), os.path.getmtime(os.path.join(INCLUDE, "trk.h")))
+            if os.path.getmtime(obj) > newest:
+                return obj
+        cmd = [hipcc] + HIPCC_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise TrkError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
+        objs = list(ex.map(cc, srcs))
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise TrkError(f"link of libtrk.so failed:\n{r.stdout}\n{r.stderr}")
+    return LIB_PATH
+
+
+# ----------------------------------------------------------------------------- ctypes signatures
+c_f32p = ctypes.c_void_p     # device pointers travel as integers (tensor.data_ptr())
+c_f64p = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_dbl = ctypes.c_double
+c_op = ctypes.c_void_p
+c_stream = ctypes.c_void_p
+
+SIGNATURES = {
+    "trk_version": (c_int, []),
+    "trk_last_error": (ctypes.c_char_p, []),
+    "trk_device_info": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "trk_blur2d_create": (c_int, [ctypes.POINTER(c_dbl), c_int, c_int, c_int, c_int, ctypes.POINTER(c_op)]),
+    "trk_radon2d_create": (c_int, [c_int, c_int, ctypes.POINTER(c_dbl), c_int, c_dbl, ctypes.POINTER(c_op)]),
+    "trk_deriv2d_create": (c_int, [c_int, ctypes.POINTER(c_op)]),
+    "trk_spacetime_create": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_op)]),
+    "trk_spacetime_set_halo": (c_int, [c_op, c_f32p, c_f32p]),
+    "trk_blockdiag_create": (c_int, [ctypes.POINTER(c_op), c_int, ctypes.POINTER(c_op)]),
+    "trk_op_shape": (c_int, [c_op, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
+    "trk_op_apply": (c_int, [c_op, c_int, c_f32p, c_i64, c_f32p, c_i64, c_int, c_f64p, c_stream]),
+    "trk_op_destroy": (c_int, [c_op]),
+    "trk_timer_create": (c_int, [c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "trk_timer_reset": (c_int, [ctypes.c_void_p]),
+    "trk_timer_read": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), c_int, ctypes.POINTER(c_int)]),
+    "trk_timer_destroy": (c_int, [ctypes.c_void_p]),
+    "trk_op_set_timer": (c_int, [c_op, ctypes.c_void_p, c_int]),
+    "trk_dot": (c_int, [c_f32p, c_f32p, c_i64, c_f64p, c_stream]),
+    "trk_nrm2sq": (c_int, [c_f32p, c_i64, c_f64p, c_stream]),
+    "trk_diff_nrm2sq": (c_int, [c_f32p, c_f32p, c_i64, c_f64p, c_stream]),
+    "trk_axpby": (c_int, [c_i64, c_dbl, c_f64p, c_f64p, c_int, c_f32p, c_dbl, c_f64p, c_f64p, c_int, c_f32p, c_f32p, c_f64p, c_stream]),
+    "trk_mul": (c_int, [c_i64, c_f32p, c_f32p, c_f32p, c_stream]),
+    "trk_mm_weights": (c_int, [c_i64, c_f32p, c_f32p, c_dbl, c_dbl, c_f32p, c_stream]),
+    "trk_cgls_update_xr": (c_int, [c_i64, c_i64, c_f64p, c_f64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_stream]),
+    "trk_gemv_t": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_stream]),
+    "trk_gemv_n": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_dbl, c_f32p, c_dbl, c_f32p, c_f64p, c_stream]),
+    "trk_wgram": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_stream]),
+}
+
+_lib = None
+
+
+def lib_path():
+    return LIB_PATH
+
+
+def load():
+    """dlopen libtrk.so (building it first if hipcc is present and the library is stale/missing)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch first: its bundled libamdhip64.so (same SONAME as ROCm's) must be the HIP runtime of the
+    # process, so that torch's streams / allocations and libtrk's kernels live in one runtime.
+    import torch  # noqa: F401
+    if _stale():
+        try:
+            build()
+        except TrkError:
+            if not os.path.exists(LIB_PATH):
+                raise
+    if not os.path.exists(LIB_PATH):
+        raise TrkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+                       "There is no CPU fallback for the engine.")
+    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = header / library mismatch: fail loudly
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = load().trk_last_error().decode("utf-8", "replace")
+        exc = ValueError if rc == -1 else (NotImplementedError if rc == -4 else TrkError)
+        raise exc(f"{what}: trk error {rc}: {msg}")

@@ -1,0 +1,236 @@
+// core.hip — library plumbing: error strings, per-stream scratch, the fixed-order finalize kernel,
+// operator-handle dispatch and the block-diagonal (frame-major) composite.
+#include "trk_internal.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <map>
+#include <mutex>
+#include <vector>
+
+namespace trk {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+// ---------------------------------------------------------------- scratch
+struct Scratch {
+  double* ptr = nullptr;
+  size_t cap = 0;
+};
+static std::mutex g_mu;
+static std::map<std::pair<int, hipStream_t>, Scratch> g_scratch;
+static std::vector<double*> g_retired;  // outgrown buffers stay alive: work enqueued earlier may still use them
+
+int scratch_doubles(hipStream_t s, size_t count, double** out) {
+  int dev = 0;
+  TRK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  Scratch& sc = g_scratch[{dev, s}];
+  if (sc.cap < count) {
+    size_t cap = sc.cap ? sc.cap : (size_t)1 << 16;
+    while (cap < count) cap *= 2;
+    double* p = nullptr;
+    hipError_t e = hipMalloc(&p, cap * sizeof(double));
+    if (e != hipSuccess) return fail(TRK_ENOMEM, "hipMalloc(%zu B) for reduction scratch: %s", cap * sizeof(double), hipGetErrorString(e));
+    if (sc.ptr) g_retired.push_back(sc.ptr);
+    sc.ptr = p;
+    sc.cap = cap;
+  }
+  *out = sc.ptr;
+  return TRK_OK;
+}
+
+// ---------------------------------------------------------------- finalize: fixed-order sum of block partials
+__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partials, int nblocks, int stride,
+                                                  double* __restrict__ out) {
+  __shared__ double lds[4];
+  const int o = blockIdx.x;
+  double v = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) v += partials[(size_t)b * stride + o];
+  v = block_sum<256>(v, lds);
+  if (threadIdx.x == 0) out[o] = v;
+}
+
+int finalize_sums(const double* partials, int nblocks, int stride, int nout, double* out_dev, hipStream_t s) {
+  if (nout <= 0) return TRK_OK;
+  hipLaunchKernelGGL(k_finalize, dim3(nout), dim3(256), 0, s, partials, nblocks, stride, out_dev);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t p;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+// ---------------------------------------------------------------- block-diagonal composite (frames)
+struct BlockDiagImpl {
+  std::vector<trk_op*> ops;
+  std::vector<int64_t> roff, coff;
+  double* frame_sums = nullptr;  // one double per frame for the fused sum(y*y); owned by the handle
+};
+
+static int blockdiag_apply(trk_op* op, int transpose, const float* x, int64_t ldx, float* y, int64_t ldy, int batch,
+                           double* sumsq_dev, hipStream_t s) {
+  auto* im = static_cast<BlockDiagImpl*>(op->impl);
+  const size_t nf = im->ops.size();
+  // sum(y*y) over all frames: every frame writes its own double, one finalize adds them in frame order
+  // (the handle-owned buffer makes the fused-norm form non-reentrant across streams for composites)
+  double* parts = sumsq_dev ? im->frame_sums : nullptr;
+  for (size_t f = 0; f < nf; ++f) {
+    const int64_t xo = transpose ? im->roff[f] : im->coff[f];
+    const int64_t yo = transpose ? im->coff[f] : im->roff[f];
+    int rc = im->ops[f]->apply(im->ops[f], transpose, x + xo, ldx, y + yo, ldy, batch, sumsq_dev ? parts + f : nullptr, s);
+    if (rc) return rc;
+  }
+  if (sumsq_dev) return finalize_sums(parts, (int)nf, 1, 1, sumsq_dev, s);
+  return TRK_OK;
+}
+
+static void blockdiag_destroy(trk_op* op) {
+  auto* im = static_cast<BlockDiagImpl*>(op->impl);
+  if (im->frame_sums) (void)hipFree(im->frame_sums);
+  delete im;
+}
+
+}  // namespace trk
+
+using namespace trk;
+
+extern "C" {
+
+int trk_version(void) { return 100; /* 0.1.0 */ }
+
+const char* trk_last_error(void) { return g_err; }
+
+int trk_device_info(int* cu, int* wavefront, int64_t* lds_per_cu, int64_t* hbm_bytes) {
+  int dev = 0;
+  TRK_HIP(hipGetDevice(&dev));
+  hipDeviceProp_t p;
+  TRK_HIP(hipGetDeviceProperties(&p, dev));
+  if (cu) *cu = p.multiProcessorCount;
+  if (wavefront) *wavefront = p.warpSize;
+  if (lds_per_cu) *lds_per_cu = (int64_t)p.maxSharedMemoryPerMultiProcessor;
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  return TRK_OK;
+}
+
+int trk_blockdiag_create(trk_op* const* ops, int count, trk_op** out) {
+  TRK_REQUIRE(ops && out && count > 0, "trk_blockdiag_create: ops/out NULL or count <= 0");
+  auto* im = new BlockDiagImpl();
+  int64_t r = 0, c = 0;
+  for (int i = 0; i < count; ++i) {
+    if (!ops[i]) {
+      delete im;
+      return fail(TRK_EINVAL, "trk_blockdiag_create: ops[%d] is NULL", i);
+    }
+    im->ops.push_back(ops[i]);
+    im->roff.push_back(r);
+    im->coff.push_back(c);
+    r += ops[i]->rows;
+    c += ops[i]->cols;
+  }
+  if (hipMalloc(&im->frame_sums, sizeof(double) * (size_t)count) != hipSuccess) {
+    delete im;
+    return fail(TRK_ENOMEM, "trk_blockdiag_create: hipMalloc of %d frame sums failed", count);
+  }
+  auto* op = new trk_op{5, r, c, im, blockdiag_apply, blockdiag_destroy, nullptr, 0};
+  *out = op;
+  return TRK_OK;
+}
+
+int trk_op_shape(const trk_op* op, int64_t* rows, int64_t* cols) {
+  TRK_REQUIRE(op, "trk_op_shape: op is NULL");
+  if (rows) *rows = op->rows;
+  if (cols) *cols = op->cols;
+  return TRK_OK;
+}
+
+int trk_op_apply(trk_op* op, int transpose, const float* x, int64_t ldx, float* y, int64_t ldy, int batch,
+                 double* sumsq_dev, trk_stream stream) {
+  TRK_REQUIRE(op && x && y, "trk_op_apply: NULL argument");
+  TRK_REQUIRE(batch >= 1, "trk_op_apply: batch must be >= 1 (got %d)", batch);
+  const int64_t nin = transpose ? op->rows : op->cols, nout = transpose ? op->cols : op->rows;
+  TRK_REQUIRE(batch == 1 || (ldx >= nin && ldy >= nout), "trk_op_apply: ldx/ldy smaller than the vector length");
+  TRK_REQUIRE(x != y, "trk_op_apply: in-place apply is not supported");
+  return op->apply(op, transpose ? 1 : 0, x, ldx, y, ldy, batch, sumsq_dev, (hipStream_t)stream);
+}
+
+int trk_timer_create(int capacity, trk_timer** out) {
+  TRK_REQUIRE(out && capacity > 0 && capacity <= (1 << 20), "trk_timer_create: bad capacity");
+  auto* t = new trk_timer{new hipEvent_t[2 * (size_t)capacity], capacity, 0};
+  for (int i = 0; i < 2 * capacity; ++i) {
+    hipError_t e = hipEventCreate(&t->ev[i]);
+    if (e != hipSuccess) {
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy(t->ev[j]);
+      delete[] t->ev;
+      delete t;
+      return fail(TRK_EHIP, "hipEventCreate: %s", hipGetErrorString(e));
+    }
+  }
+  *out = t;
+  return TRK_OK;
+}
+
+int trk_timer_reset(trk_timer* t) {
+  TRK_REQUIRE(t, "trk_timer_reset: NULL");
+  t->used = 0;
+  return TRK_OK;
+}
+
+int trk_timer_read(trk_timer* t, float* ms_out, int max_out, int* count_out) {
+  TRK_REQUIRE(t && ms_out && count_out, "trk_timer_read: NULL argument");
+  const int n = t->used < max_out ? t->used : max_out;
+  for (int i = 0; i < n; ++i) {
+    TRK_HIP(hipEventSynchronize(t->ev[2 * i + 1]));
+    TRK_HIP(hipEventElapsedTime(&ms_out[i], t->ev[2 * i], t->ev[2 * i + 1]));
+  }
+  *count_out = n;
+  return TRK_OK;
+}
+
+int trk_timer_destroy(trk_timer* t) {
+  if (!t) return TRK_OK;
+  for (int i = 0; i < 2 * t->cap; ++i) (void)hipEventDestroy(t->ev[i]);
+  delete[] t->ev;
+  delete t;
+  return TRK_OK;
+}
+
+int trk_op_set_timer(trk_op* op, trk_timer* t, int which) {
+  TRK_REQUIRE(op, "trk_op_set_timer: op is NULL");
+  TRK_REQUIRE(which >= 0 && which <= 2, "trk_op_set_timer: which must be 0, 1 or 2");
+  op->timer = t;
+  op->timer_which = which;
+  return TRK_OK;
+}
+
+int trk_op_destroy(trk_op* op) {
+  if (!op) return TRK_OK;
+  if (op->destroy) op->destroy(op);
+  delete op;
+  return TRK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,128 @@
+// trk_internal.h — shared host/device helpers of libtrk.so (gfx950 only; wave = 64 lanes).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+#include "trk.h"
+
+namespace trk {
+
+// ------------------------------------------------------------------ errors (thread-local string)
+void set_error(const char* fmt, ...) __attribute__((format(printf, 1, 2)));
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+#define TRK_HIP(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t e_ = (expr);                                                                   \
+    if (e_ != hipSuccess) return ::trk::fail(TRK_EHIP, "%s -> %s (%s:%d)", #expr,             \
+                                             hipGetErrorString(e_), __FILE__, __LINE__);      \
+  } while (0)
+
+#define TRK_REQUIRE(cond, ...)                                  \
+  do {                                                          \
+    if (!(cond)) return ::trk::fail(TRK_EINVAL, __VA_ARGS__);   \
+  } while (0)
+
+#define TRK_LAUNCH_CHECK() TRK_HIP(hipGetLastError())
+
+// ------------------------------------------------------------------ per-stream scratch (block partial sums)
+// Partials of a reduction are written by the producing kernel and summed, in a fixed order, by a
+// one-block finalize kernel on the same stream: deterministic, no atomics, no fences.
+constexpr int kMaxPartialBlocks = 1024;
+int scratch_doubles(hipStream_t s, size_t count, double** out);  // grows, never shrinks
+
+// out[o] = sum_{b < nblocks} partials[b*stride + o]   for o < nout   (fixed summation order)
+int finalize_sums(const double* partials, int nblocks, int stride, int nout, double* out_dev, hipStream_t s);
+
+// device facts (cached)
+int cu_count();
+
+// ------------------------------------------------------------------ device-evaluated coefficient
+struct Coef {
+  double c;
+  const double* num;
+  const double* den;
+  int flags;
+};
+
+__device__ __forceinline__ double coef_eval(const Coef& k) {
+  double v = k.c;
+  if (k.num) {
+    double t = *k.num;
+    v *= (k.flags & TRK_SQRT_NUM) ? sqrt(t) : t;
+  }
+  if (k.den) {
+    double t = *k.den;
+    v /= (k.flags & TRK_SQRT_DEN) ? sqrt(t) : t;
+  }
+  return v;
+}
+
+// ------------------------------------------------------------------ wave64 / block reductions (fp64)
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return v;  // lane 0 holds the wave total
+}
+
+// Sum over a block of NT threads (NT multiple of 64).  `lds` holds NT/64 doubles.  Result valid in thread 0.
+template <int NT>
+__device__ __forceinline__ double block_sum(double v, double* lds) {
+  constexpr int NW = NT / 64;
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  __syncthreads();  // protect lds reuse between consecutive calls
+  if (lane == 0) lds[wid] = v;
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x == 0) {
+#pragma unroll
+    for (int w = 0; w < NW; ++w) t += lds[w];
+  }
+  return t;
+}
+
+inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+}  // namespace trk
+
+// ------------------------------------------------------------------ kernel timer (hipEvent pairs)
+struct trk_timer {
+  hipEvent_t* ev;  // 2*cap events
+  int cap, used;
+};
+
+namespace trk {
+// record the start / stop event of the next pair if a timer is attached for this direction
+struct TimerScope {
+  trk_timer* t;
+  hipStream_t s;
+  TimerScope(trk_timer* timer, int which, int transpose, hipStream_t st) : t(nullptr), s(st) {
+    if (timer && (which == 2 || which == transpose) && timer->used < timer->cap) {
+      t = timer;
+      (void)hipEventRecord(t->ev[2 * t->used], s);
+    }
+  }
+  void stop() {
+    if (t) {
+      (void)hipEventRecord(t->ev[2 * t->used + 1], s);
+      ++t->used;
+      t = nullptr;
+    }
+  }
+};
+}  // namespace trk
+
+// ------------------------------------------------------------------ operator handle
+struct trk_op {
+  int kind;  // 1 blur2d, 2 radon2d, 3 deriv2d, 4 spacetime, 5 blockdiag
+  int64_t rows, cols;
+  void* impl;
+  int (*apply)(trk_op*, int transpose, const float* x, int64_t ldx, float* y, int64_t ldy, int batch,
+               double* sumsq_dev, hipStream_t s);
+  void (*destroy)(trk_op*);
+  trk_timer* timer = nullptr;
+  int timer_which = 0;
+};

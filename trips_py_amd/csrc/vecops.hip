@@ -1,0 +1,606 @@
+// vecops.hip — the vector algebra inside the Krylov loops, HBM-bound streaming kernels:
+// 16-byte-per-lane coalesced loads, grid-stride, fp32 storage, fp64 accumulation, wave64 __shfl reductions,
+// one double of block partial per workgroup, summed in a fixed order by core.hip's finalize kernel.
+#include "trk_internal.h"
+
+using namespace trk;
+
+namespace {
+
+constexpr int NT = 256;
+
+// grid for a streaming kernel over n floats: one float4 per thread until the chip is covered 4x (<= kMaxPartialBlocks
+// blocks so a reduction leaves at most that many partials), then grid-stride
+inline int stream_grid(int64_t n) {
+  int64_t want = (n + (int64_t)NT * 4 - 1) / ((int64_t)NT * 4);
+  int64_t cap = (int64_t)cu_count() * 4;
+  if (cap > kMaxPartialBlocks) cap = kMaxPartialBlocks;
+  if (want > cap) want = cap;
+  if (want < 1) want = 1;
+  return (int)want;
+}
+
+__device__ __forceinline__ float4 ld4(const float* p, int64_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
+__device__ __forceinline__ void st4(float* p, int64_t i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
+
+// ------------------------------------------------------------------ dot / nrm2 / diff-nrm2
+// MODE 0: sum x*y   1: sum x*x   2: sum (x-y)^2
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(NT) void k_reduce2(const float* __restrict__ x, const float* __restrict__ y, int64_t n,
+                                                double* __restrict__ partials) {
+  __shared__ double lds[NT / 64];
+  double acc = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      float4 a = ld4(x, i);
+      if (MODE == 1) {
+        acc += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+      } else {
+        float4 b = ld4(y, i);
+        if (MODE == 0) {
+          acc += (double)a.x * b.x + (double)a.y * b.y + (double)a.z * b.z + (double)a.w * b.w;
+        } else {
+          double d0 = (double)a.x - b.x, d1 = (double)a.y - b.y, d2 = (double)a.z - b.z, d3 = (double)a.w - b.w;
+          acc += d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3;
+        }
+      }
+    }
+    for (int64_t i = (n4 << 2) + tid; i < n; i += nth) {
+      double a = x[i], b = (MODE == 1) ? a : (double)y[i];
+      acc += (MODE == 2) ? (a - b) * (a - b) : a * b;
+    }
+  } else {
+    for (int64_t i = tid; i < n; i += nth) {
+      double a = x[i], b = (MODE == 1) ? a : (double)y[i];
+      acc += (MODE == 2) ? (a - b) * (a - b) : a * b;
+    }
+  }
+  acc = block_sum<NT>(acc, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
+template <int MODE>
+int launch_reduce2(const float* x, const float* y, int64_t n, double* out, hipStream_t s) {
+  const int grid = stream_grid(n);
+  double* part = nullptr;
+  if (int rc = scratch_doubles(s, grid, &part)) return rc;
+  const bool vec = aligned16(x) && (MODE == 1 || aligned16(y));
+  if (vec)
+    hipLaunchKernelGGL((k_reduce2<MODE, true>), dim3(grid), dim3(NT), 0, s, x, y, n, part);
+  else
+    hipLaunchKernelGGL((k_reduce2<MODE, false>), dim3(grid), dim3(NT), 0, s, x, y, n, part);
+  TRK_LAUNCH_CHECK();
+  return finalize_sums(part, grid, 1, 1, out, s);
+}
+
+// ------------------------------------------------------------------ out = A*x + B*y (+ sum out^2)
+template <bool HAS_Y, bool SUMSQ, bool VEC>
+__global__ __launch_bounds__(NT) void k_axpby(int64_t n, Coef ca, const float* x, Coef cb, const float* y, float* out,
+                                              double* __restrict__ partials) {
+  __shared__ double lds[NT / 64];
+  const float a = (float)coef_eval(ca);
+  const float b = HAS_Y ? (float)coef_eval(cb) : 0.f;
+  double acc = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      float4 v = ld4(x, i), o;
+      if (HAS_Y) {
+        float4 w = ld4(y, i);
+        o.x = fmaf(a, v.x, b * w.x);
+        o.y = fmaf(a, v.y, b * w.y);
+        o.z = fmaf(a, v.z, b * w.z);
+        o.w = fmaf(a, v.w, b * w.w);
+      } else {
+        o.x = a * v.x;
+        o.y = a * v.y;
+        o.z = a * v.z;
+        o.w = a * v.w;
+      }
+      st4(out, i, o);
+      if (SUMSQ) acc += (double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z + (double)o.w * o.w;
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) {
+    float o = HAS_Y ? fmaf(a, x[i], b * y[i]) : a * x[i];
+    out[i] = o;
+    if (SUMSQ) acc += (double)o * o;
+  }
+  if (SUMSQ) {
+    acc = block_sum<NT>(acc, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+  }
+}
+
+// ------------------------------------------------------------------ out = x*y ; MM weights
+template <bool VEC>
+__global__ __launch_bounds__(NT) void k_mul(int64_t n, const float* x, const float* y, float* out) {
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      float4 a = ld4(x, i), b = ld4(y, i);
+      st4(out, i, make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w));
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) out[i] = x[i] * y[i];
+}
+
+// w = (v^2 + eps^2)^(e), e = p/2 - 1.  e == -0.5 (q = 1, the TV case) is an rsqrt; e == 0 is 1.
+__device__ __forceinline__ float mm_w(float v, float eps2, float e, int special) {
+  const float t = fmaf(v, v, eps2);
+  if (special == 1) return 1.0f;
+  if (special == 2) return 1.0f / sqrtf(t);
+  return powf(t, e);
+}
+
+template <bool HAS_Y, bool VEC>
+__global__ __launch_bounds__(NT) void k_mm_weights(int64_t n, const float* x, const float* y, float eps2, float e,
+                                                   int special, float* out) {
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      float4 a = ld4(x, i);
+      if (HAS_Y) {
+        float4 b = ld4(y, i);
+        a.x -= b.x;
+        a.y -= b.y;
+        a.z -= b.z;
+        a.w -= b.w;
+      }
+      st4(out, i, make_float4(mm_w(a.x, eps2, e, special), mm_w(a.y, eps2, e, special), mm_w(a.z, eps2, e, special),
+                              mm_w(a.w, eps2, e, special)));
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) {
+    float v = HAS_Y ? x[i] - y[i] : x[i];
+    out[i] = mm_w(v, eps2, e, special);
+  }
+}
+
+// ------------------------------------------------------------------ fused CGLS update (CGLS.py:64-67,76,79)
+// partials layout: [block][3] = ||x_new||^2, ||step*p||^2, ||x_new - x_true||^2
+template <bool HAS_XT, bool VEC>
+__global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, const double* gamma, const double* delta,
+                                                    const float* x, const float* p, float* x_new, float* r,
+                                                    const float* w, const float* x_true, double* __restrict__ partials) {
+  __shared__ double lds[NT / 64];
+  const float step = (float)(*gamma / *delta);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t ntail = 0, mtail = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2, m4 = m >> 2;
+    ntail = n4 << 2;
+    mtail = m4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      const float4 xv = ld4(x, i), pv = ld4(p, i);
+      const float4 d = make_float4(step * pv.x, step * pv.y, step * pv.z, step * pv.w);
+      const float4 xn = make_float4(xv.x + d.x, xv.y + d.y, xv.z + d.z, xv.w + d.w);
+      st4(x_new, i, xn);
+      s0 += (double)xn.x * xn.x + (double)xn.y * xn.y + (double)xn.z * xn.z + (double)xn.w * xn.w;
+      s1 += (double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z + (double)d.w * d.w;
+      if (HAS_XT) {
+        const float4 t = ld4(x_true, i);
+        const double e0 = (double)xn.x - t.x, e1 = (double)xn.y - t.y, e2 = (double)xn.z - t.z, e3 = (double)xn.w - t.w;
+        s2 += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+      }
+    }
+    for (int64_t i = tid; i < m4; i += nth) {
+      float4 rv = ld4(r, i);
+      const float4 wv = ld4(w, i);
+      rv.x = fmaf(-step, wv.x, rv.x);
+      rv.y = fmaf(-step, wv.y, rv.y);
+      rv.z = fmaf(-step, wv.z, rv.z);
+      rv.w = fmaf(-step, wv.w, rv.w);
+      st4(r, i, rv);
+    }
+  }
+  for (int64_t i = ntail + tid; i < n; i += nth) {
+    const float d = step * p[i];
+    const float xn = x[i] + d;
+    x_new[i] = xn;
+    s0 += (double)xn * xn;
+    s1 += (double)d * d;
+    if (HAS_XT) {
+      const double e = (double)xn - x_true[i];
+      s2 += e * e;
+    }
+  }
+  for (int64_t i = mtail + tid; i < m; i += nth) r[i] = fmaf(-step, w[i], r[i]);
+  s0 = block_sum<NT>(s0, lds);
+  s1 = block_sum<NT>(s1, lds);
+  if (HAS_XT) s2 = block_sum<NT>(s2, lds);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x * 3 + 0] = s0;
+    partials[blockIdx.x * 3 + 1] = s1;
+    partials[blockIdx.x * 3 + 2] = HAS_XT ? s2 : 0.0;
+  }
+}
+
+// ------------------------------------------------------------------ h[j] = sum_i wt(i) V[j][i] r[i]   (k dots, one pass)
+// grid = (bx, ceil(k/JT)); a block sweeps its share of i for JT rows; partials [bx][k].
+// WPOW: 0 no weight, 1 multiply by w, 2 multiply by w^2.
+constexpr int JT = 8;
+
+template <int WPOW, bool VEC>
+__global__ __launch_bounds__(NT) void k_gemv_t(const float* __restrict__ V, int64_t ld, int k, int64_t n,
+                                               const float* __restrict__ r, const float* __restrict__ w,
+                                               double* __restrict__ partials) {
+  __shared__ double lds[NT / 64];
+  const int j0 = blockIdx.y * JT;
+  const int jn = (k - j0 < JT) ? (k - j0) : JT;
+  double acc[JT];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) acc[j] = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      float4 rv = ld4(r, i);
+      if (WPOW) {
+        float4 wv = ld4(w, i);
+        if (WPOW == 2) {
+          wv.x *= wv.x;
+          wv.y *= wv.y;
+          wv.z *= wv.z;
+          wv.w *= wv.w;
+        }
+        rv.x *= wv.x;
+        rv.y *= wv.y;
+        rv.z *= wv.z;
+        rv.w *= wv.w;
+      }
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        if (j < jn) {
+          float4 v = ld4(V + (int64_t)(j0 + j) * ld, i);
+          acc[j] += (double)v.x * rv.x + (double)v.y * rv.y + (double)v.z * rv.z + (double)v.w * rv.w;
+        }
+      }
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) {
+    float rv = r[i];
+    if (WPOW) {
+      float wv = w[i];
+      rv *= (WPOW == 2) ? wv * wv : wv;
+    }
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+      if (j < jn) acc[j] += (double)V[(int64_t)(j0 + j) * ld + i] * rv;
+  }
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    double t = block_sum<NT>(acc[j], lds);
+    if (threadIdx.x == 0 && j < jn) partials[(size_t)blockIdx.x * k + j0 + j] = t;
+  }
+}
+
+int launch_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* w, int wpow, double* h,
+                  hipStream_t s) {
+  const int ntile = ceil_div(k, JT);
+  int bx = stream_grid(n);
+  // spread over the chip even when there are many row tiles
+  const int cap = (cu_count() * 8 + ntile - 1) / ntile;
+  if (bx > cap) bx = cap < 1 ? 1 : cap;
+  double* part = nullptr;
+  if (int rc = scratch_doubles(s, (size_t)bx * k, &part)) return rc;
+  const bool vec = aligned16(V) && aligned16(r) && (ld % 4 == 0) && (!wpow || aligned16(w));
+  dim3 grid(bx, ntile);
+#define GT(WP, VC) hipLaunchKernelGGL((k_gemv_t<WP, VC>), grid, dim3(NT), 0, s, V, ld, k, n, r, w, part)
+  if (wpow == 0) { if (vec) GT(0, true); else GT(0, false); }
+  else if (wpow == 1) { if (vec) GT(1, true); else GT(1, false); }
+  else { if (vec) GT(2, true); else GT(2, false); }
+#undef GT
+  TRK_LAUNCH_CHECK();
+  return finalize_sums(part, bx, k, k, h, s);
+}
+
+// ------------------------------------------------------------------ out = a*base + s * sum_j y[j] V[j]   (+ sum out^2)
+constexpr int KMAX_LDS = 1024;  // coefficients staged in LDS as doubles
+
+template <bool HAS_BASE, bool SUMSQ, bool VEC>
+__global__ __launch_bounds__(NT) void k_gemv_n(const float* __restrict__ V, int64_t ld, int k, int64_t n,
+                                               const double* __restrict__ y, double a, const float* base, double sc,
+                                               float* out, double* __restrict__ partials) {
+  __shared__ double ys[KMAX_LDS];
+  __shared__ double lds[NT / 64];
+  for (int j = threadIdx.x; j < k; j += NT) ys[j] = sc * y[j];
+  __syncthreads();
+  double acc2 = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+      if (HAS_BASE) {
+        float4 b = ld4(base, i);
+        o0 = a * b.x;
+        o1 = a * b.y;
+        o2 = a * b.z;
+        o3 = a * b.w;
+      }
+#pragma unroll 4
+      for (int j = 0; j < k; ++j) {
+        const float4 v = ld4(V + (int64_t)j * ld, i);
+        const double c = ys[j];
+        o0 = fma(c, (double)v.x, o0);
+        o1 = fma(c, (double)v.y, o1);
+        o2 = fma(c, (double)v.z, o2);
+        o3 = fma(c, (double)v.w, o3);
+      }
+      float4 o = make_float4((float)o0, (float)o1, (float)o2, (float)o3);
+      st4(out, i, o);
+      if (SUMSQ) acc2 += (double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z + (double)o.w * o.w;
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) {
+    double o = HAS_BASE ? a * base[i] : 0.0;
+    for (int j = 0; j < k; ++j) o = fma(ys[j], (double)V[(int64_t)j * ld + i], o);
+    const float of = (float)o;
+    out[i] = of;
+    if (SUMSQ) acc2 += (double)of * of;
+  }
+  if (SUMSQ) {
+    acc2 = block_sum<NT>(acc2, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc2;
+  }
+}
+
+// ------------------------------------------------------------------ weighted Gram, tile pairs (TG x TG)
+// G[a][b] = sum_i w_i^2 W[a][i] W[b][i].  grid = (bx, npairs): pair p -> (ta <= tb).  partials [bx][k*k] (upper blocks).
+constexpr int TG = 4;
+
+template <bool HAS_W, bool VEC>
+__global__ __launch_bounds__(NT) void k_wgram(const float* __restrict__ W, int64_t ld, int k, int64_t m,
+                                              const float* __restrict__ w, int ntile,
+                                              double* __restrict__ partials) {
+  __shared__ double lds[NT / 64];
+  // blockIdx.y enumerates tile pairs (ta <= tb) row by row
+  int ta = 0, rem = blockIdx.y;
+  while (rem >= ntile - ta) {
+    rem -= ntile - ta;
+    ++ta;
+  }
+  const int a0 = ta * TG, b0 = (ta + rem) * TG;
+  double acc[TG][TG];
+#pragma unroll
+  for (int a = 0; a < TG; ++a)
+#pragma unroll
+    for (int b = 0; b < TG; ++b) acc[a][b] = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t m4 = m >> 2;
+    tail0 = m4 << 2;
+    for (int64_t i = tid; i < m4; i += nth) {
+      float4 ra[TG], rb[TG];
+      float4 ww = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (HAS_W) {
+        ww = ld4(w, i);
+        ww.x *= ww.x;
+        ww.y *= ww.y;
+        ww.z *= ww.z;
+        ww.w *= ww.w;
+      }
+#pragma unroll
+      for (int a = 0; a < TG; ++a) {
+        const int ja = (a0 + a < k) ? a0 + a : k - 1;  // clamp: out-of-range rows are computed and discarded
+        ra[a] = ld4(W + (int64_t)ja * ld, i);
+        if (HAS_W) {
+          ra[a].x *= ww.x;
+          ra[a].y *= ww.y;
+          ra[a].z *= ww.z;
+          ra[a].w *= ww.w;
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < TG; ++b) {
+        const int jb = (b0 + b < k) ? b0 + b : k - 1;
+        rb[b] = ld4(W + (int64_t)jb * ld, i);
+      }
+#pragma unroll
+      for (int a = 0; a < TG; ++a)
+#pragma unroll
+        for (int b = 0; b < TG; ++b)
+          acc[a][b] += (double)ra[a].x * rb[b].x + (double)ra[a].y * rb[b].y + (double)ra[a].z * rb[b].z +
+                       (double)ra[a].w * rb[b].w;
+    }
+  }
+  for (int64_t i = tail0 + tid; i < m; i += nth) {
+    float ww = 1.f;
+    if (HAS_W) {
+      ww = w[i];
+      ww *= ww;
+    }
+#pragma unroll
+    for (int a = 0; a < TG; ++a) {
+      const int ja = (a0 + a < k) ? a0 + a : k - 1;
+      const float va = W[(int64_t)ja * ld + i] * ww;
+#pragma unroll
+      for (int b = 0; b < TG; ++b) {
+        const int jb = (b0 + b < k) ? b0 + b : k - 1;
+        acc[a][b] += (double)va * W[(int64_t)jb * ld + i];
+      }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < TG; ++a)
+#pragma unroll
+    for (int b = 0; b < TG; ++b) {
+      double t = block_sum<NT>(acc[a][b], lds);
+      if (threadIdx.x == 0 && a0 + a < k && b0 + b < k) {
+        partials[(size_t)blockIdx.x * k * k + (size_t)(a0 + a) * k + (b0 + b)] = t;
+        partials[(size_t)blockIdx.x * k * k + (size_t)(b0 + b) * k + (a0 + a)] = t;
+      }
+    }
+}
+
+}  // namespace
+
+// ======================================================================================= C ABI
+extern "C" {
+
+int trk_dot(const float* x, const float* y, int64_t n, double* out, trk_stream st) {
+  TRK_REQUIRE(x && y && out && n >= 0, "trk_dot: NULL argument or n < 0");
+  return launch_reduce2<0>(x, y, n, out, (hipStream_t)st);
+}
+
+int trk_nrm2sq(const float* x, int64_t n, double* out, trk_stream st) {
+  TRK_REQUIRE(x && out && n >= 0, "trk_nrm2sq: NULL argument or n < 0");
+  return launch_reduce2<1>(x, x, n, out, (hipStream_t)st);
+}
+
+int trk_diff_nrm2sq(const float* x, const float* y, int64_t n, double* out, trk_stream st) {
+  TRK_REQUIRE(x && y && out && n >= 0, "trk_diff_nrm2sq: NULL argument or n < 0");
+  return launch_reduce2<2>(x, y, n, out, (hipStream_t)st);
+}
+
+int trk_axpby(int64_t n, double ca, const double* a_num, const double* a_den, int a_flags, const float* x, double cb,
+              const double* b_num, const double* b_den, int b_flags, const float* y, float* out, double* sumsq,
+              trk_stream st) {
+  TRK_REQUIRE(x && out && n >= 0, "trk_axpby: NULL x/out or n < 0");
+  hipStream_t s = (hipStream_t)st;
+  const Coef A{ca, a_num, a_den, a_flags}, B{cb, b_num, b_den, b_flags};
+  const int grid = stream_grid(n);
+  double* part = nullptr;
+  if (sumsq)
+    if (int rc = scratch_doubles(s, grid, &part)) return rc;
+  const bool vec = aligned16(x) && aligned16(out) && (!y || aligned16(y));
+#define AX(HY, SS, VC) hipLaunchKernelGGL((k_axpby<HY, SS, VC>), dim3(grid), dim3(NT), 0, s, n, A, x, B, y, out, part)
+  if (y) {
+    if (sumsq) { if (vec) AX(true, true, true); else AX(true, true, false); }
+    else       { if (vec) AX(true, false, true); else AX(true, false, false); }
+  } else {
+    if (sumsq) { if (vec) AX(false, true, true); else AX(false, true, false); }
+    else       { if (vec) AX(false, false, true); else AX(false, false, false); }
+  }
+#undef AX
+  TRK_LAUNCH_CHECK();
+  if (sumsq) return finalize_sums(part, grid, 1, 1, sumsq, s);
+  return TRK_OK;
+}
+
+int trk_mul(int64_t n, const float* x, const float* y, float* out, trk_stream st) {
+  TRK_REQUIRE(x && y && out && n >= 0, "trk_mul: NULL argument or n < 0");
+  const int grid = stream_grid(n);
+  if (aligned16(x) && aligned16(y) && aligned16(out))
+    hipLaunchKernelGGL((k_mul<true>), dim3(grid), dim3(NT), 0, (hipStream_t)st, n, x, y, out);
+  else
+    hipLaunchKernelGGL((k_mul<false>), dim3(grid), dim3(NT), 0, (hipStream_t)st, n, x, y, out);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_mm_weights(int64_t n, const float* x, const float* y, double eps, double p, float* out, trk_stream st) {
+  TRK_REQUIRE(x && out && n >= 0, "trk_mm_weights: NULL argument or n < 0");
+  const float e = (float)(p / 2.0 - 1.0), eps2 = (float)(eps * eps);
+  const int special = (p == 2.0) ? 1 : (p == 1.0) ? 2 : 0;
+  const int grid = stream_grid(n);
+  const bool vec = aligned16(x) && aligned16(out) && (!y || aligned16(y));
+  hipStream_t s = (hipStream_t)st;
+#define MW(HY, VC) hipLaunchKernelGGL((k_mm_weights<HY, VC>), dim3(grid), dim3(NT), 0, s, n, x, y, eps2, e, special, out)
+  if (y) { if (vec) MW(true, true); else MW(true, false); }
+  else   { if (vec) MW(false, true); else MW(false, false); }
+#undef MW
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_cgls_update_xr(int64_t n, int64_t m, const double* gamma, const double* delta, const float* x, const float* p,
+                       float* x_new, float* r, const float* w, const float* x_true, double* sums, trk_stream st) {
+  TRK_REQUIRE(gamma && delta && x && p && x_new && r && w && sums, "trk_cgls_update_xr: NULL argument");
+  TRK_REQUIRE(n >= 0 && m >= 0, "trk_cgls_update_xr: negative size");
+  hipStream_t s = (hipStream_t)st;
+  const int grid = stream_grid(n > m ? n : m);
+  double* part = nullptr;
+  if (int rc = scratch_doubles(s, (size_t)grid * 3, &part)) return rc;
+  const bool vec = aligned16(x) && aligned16(p) && aligned16(x_new) && aligned16(r) && aligned16(w) &&
+                   (!x_true || aligned16(x_true));
+#define CU(XT, VC) hipLaunchKernelGGL((k_cgls_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, gamma, delta, x, p, x_new, r, w, x_true, part)
+  if (x_true) { if (vec) CU(true, true); else CU(true, false); }
+  else        { if (vec) CU(false, true); else CU(false, false); }
+#undef CU
+  TRK_LAUNCH_CHECK();
+  return finalize_sums(part, grid, 3, 3, sums, s);
+}
+
+int trk_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* w2, double* h, trk_stream st) {
+  TRK_REQUIRE(V && r && h, "trk_gemv_t: NULL argument");
+  TRK_REQUIRE(k >= 1 && n >= 0 && ld >= n, "trk_gemv_t: need k >= 1, n >= 0, ld >= n");
+  return launch_gemv_t(V, ld, k, n, r, w2, w2 ? 1 : 0, h, (hipStream_t)st);
+}
+
+int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, double a, const float* base, double sc,
+               float* out, double* sumsq, trk_stream st) {
+  TRK_REQUIRE(V && y && out, "trk_gemv_n: NULL argument");
+  TRK_REQUIRE(k >= 1 && k <= KMAX_LDS && n >= 0 && ld >= n, "trk_gemv_n: need 1 <= k <= %d, n >= 0, ld >= n", KMAX_LDS);
+  hipStream_t s = (hipStream_t)st;
+  const int grid = stream_grid(n);
+  double* part = nullptr;
+  if (sumsq)
+    if (int rc = scratch_doubles(s, grid, &part)) return rc;
+  const bool vec = aligned16(V) && aligned16(out) && (ld % 4 == 0) && (!base || aligned16(base));
+#define GN(HB, SS, VC) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, y, a, base, sc, out, part)
+  if (base) {
+    if (sumsq) { if (vec) GN(true, true, true); else GN(true, true, false); }
+    else       { if (vec) GN(true, false, true); else GN(true, false, false); }
+  } else {
+    if (sumsq) { if (vec) GN(false, true, true); else GN(false, true, false); }
+    else       { if (vec) GN(false, false, true); else GN(false, false, false); }
+  }
+#undef GN
+  TRK_LAUNCH_CHECK();
+  if (sumsq) return finalize_sums(part, grid, 1, 1, sumsq, s);
+  return TRK_OK;
+}
+
+int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G, double* c1,
+              double* c2, trk_stream st) {
+  TRK_REQUIRE(W && G, "trk_wgram: NULL argument");
+  TRK_REQUIRE(k >= 1 && k <= 512 && m >= 0 && ld >= m, "trk_wgram: need 1 <= k <= 512, m >= 0, ld >= m");
+  TRK_REQUIRE(!b1 || (c1 && c2), "trk_wgram: b1 given but c1/c2 NULL");
+  hipStream_t s = (hipStream_t)st;
+  const int nt = ceil_div(k, TG);
+  const int npairs = nt * (nt + 1) / 2;
+  int bx = stream_grid(m);
+  const int cap = (cu_count() * 8 + npairs - 1) / npairs;
+  if (bx > cap) bx = cap < 1 ? 1 : cap;
+  double* part = nullptr;  // [bx][k*k] partials
+  if (int rc = scratch_doubles(s, (size_t)bx * k * k, &part)) return rc;
+  const bool vec = aligned16(W) && (ld % 4 == 0) && (!w || aligned16(w));
+  dim3 grid(bx, npairs);
+#define WG(HW, VC) hipLaunchKernelGGL((k_wgram<HW, VC>), grid, dim3(NT), 0, s, W, ld, k, m, w, nt, part)
+  if (w) { if (vec) WG(true, true); else WG(true, false); }
+  else   { if (vec) WG(false, true); else WG(false, false); }
+#undef WG
+  TRK_LAUNCH_CHECK();
+  if (int rc = finalize_sums(part, bx, k * k, k * k, G, s)) return rc;
+  if (b1) {
+    if (w) {
+      if (int rc = launch_gemv_t(W, ld, k, m, b1, w, 1, c1, s)) return rc;
+      if (int rc = launch_gemv_t(W, ld, k, m, b1, w, 2, c2, s)) return rc;
+    } else {
+      if (int rc = launch_gemv_t(W, ld, k, m, b1, nullptr, 0, c1, s)) return rc;
+      TRK_HIP(hipMemcpyAsync(c2, c1, sizeof(double) * k, hipMemcpyDeviceToDevice, s));
+    }
+  }
+  return TRK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,183 @@
+"""HipEngine — the Python face of libtrk.so: device vectors are fp32 torch tensors, device scalars are
+float64 torch tensors, every call goes through the C ABI (include/trk.h) on torch's current HIP stream.
+
+PyTorch is plumbing here (device memory, streams, torch.distributed); all arithmetic on vectors is done by the
+hand-written HIP kernels.  There is no CPU fallback: constructing a HipEngine without a visible GPU or without
+libtrk.so raises.
+
+Reductions leave LOCAL sums in device doubles; `allreduce()` turns them into global sums when the problem is
+sharded across ranks (one process per GPU, RCCL through torch.distributed), and is a no-op otherwise.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+
+SQRT_NUM = 1
+SQRT_DEN = 2
+
+
+class Coef:
+    """A coefficient evaluated ON THE DEVICE when the kernel runs:  c * f(num) / g(den).
+
+    `num` / `den` are one-element views of a float64 device tensor (or None = 1); sqrt_* apply a square root to the
+    loaded value (norms are stored squared)."""
+
+    __slots__ = ("c", "num", "den", "flags", "_keep")
+
+    def __init__(self, c=1.0, num=None, den=None, sqrt_num=False, sqrt_den=False):
+        self.c = float(c)
+        self.num = _ptr(num)
+        self.den = _ptr(den)
+        self.flags = (SQRT_NUM if sqrt_num else 0) | (SQRT_DEN if sqrt_den else 0)
+        self._keep = (num, den)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if isinstance(t, int):
+        return t
+    return t.data_ptr()
+
+
+def _as_coef(a):
+    return a if isinstance(a, Coef) else Coef(a)
+
+
+class HipEngine:
+    """One per (device, communicator).  All methods enqueue on torch's current stream and return immediately."""
+
+    is_native = True
+
+    def __init__(self, device=None, comm=None):
+        if not torch.cuda.is_available():
+            raise _lib.TrkError("HipEngine needs a visible GPU (torch.cuda.is_available() is False); "
+                                "the engine has no CPU fallback")
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.comm = comm
+        self.world = 1 if comm is None else comm.world
+        self.rank = 0 if comm is None else comm.rank
+
+    # ------------------------------------------------------------------ memory
+    def empty(self, n):
+        return torch.empty(int(n), dtype=torch.float32, device=self.device)
+
+    def zeros(self, n):
+        return torch.zeros(int(n), dtype=torch.float32, device=self.device)
+
+    def empty_basis(self, k, n):
+        """Row-per-vector basis storage [k, n] (a new vector is a write, never a re-copy)."""
+        return torch.empty((int(k), int(n)), dtype=torch.float32, device=self.device)
+
+    def scalars(self, n):
+        return torch.zeros(int(n), dtype=torch.float64, device=self.device)
+
+    def to_vec(self, a, n=None):
+        """numpy / torch, shape (n,), (n,1) -> contiguous fp32 device vector (a copy unless already one)."""
+        if isinstance(a, torch.Tensor):
+            t = a.detach().reshape(-1).to(device=self.device, dtype=torch.float32).contiguous()
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1))).to(self.device)
+        if n is not None and t.numel() != n:
+            raise ValueError(f"vector has {t.numel()} entries, expected {n}")
+        return t
+
+    def to_host(self, t):
+        """Device doubles -> numpy float64 (synchronises the current stream)."""
+        return t.detach().to("cpu").numpy().astype(np.float64, copy=False)
+
+    def stream(self):
+        return torch.cuda.current_stream(self.device).cuda_stream
+
+    def synchronize(self):
+        torch.cuda.current_stream(self.device).synchronize()
+
+    # ------------------------------------------------------------------ collectives
+    def allreduce(self, scal):
+        """Sum a (view of a) float64 device tensor over all ranks, in place.  No-op for a single rank."""
+        if self.comm is not None and self.world > 1:
+            self.comm.allreduce_sum_(scal)
+        return scal
+
+    # ------------------------------------------------------------------ operators
+    def op_apply(self, handle, transpose, x, y, batch=1, ldx=0, ldy=0, sumsq=None):
+        rc = self.lib.trk_op_apply(handle, int(bool(transpose)), x.data_ptr(), int(ldx), y.data_ptr(), int(ldy),
+                                   int(batch), _ptr(sumsq), self.stream())
+        _lib.check(rc, "trk_op_apply")
+
+    # ------------------------------------------------------------------ reductions (local sums)
+    def dot(self, x, y, out):
+        _lib.check(self.lib.trk_dot(x.data_ptr(), y.data_ptr(), x.numel(), _ptr(out), self.stream()), "trk_dot")
+
+    def nrm2sq(self, x, out):
+        _lib.check(self.lib.trk_nrm2sq(x.data_ptr(), x.numel(), _ptr(out), self.stream()), "trk_nrm2sq")
+
+    def diff_nrm2sq(self, x, y, out):
+        _lib.check(self.lib.trk_diff_nrm2sq(x.data_ptr(), y.data_ptr(), x.numel(), _ptr(out), self.stream()),
+                   "trk_diff_nrm2sq")
+
+    # ------------------------------------------------------------------ axpy family
+    def axpby(self, a, x, b, y, out, sumsq=None):
+        """out = a*x + b*y  (a, b: float or Coef; y may be None)."""
+        a, b = _as_coef(a), _as_coef(b)
+        rc = self.lib.trk_axpby(x.numel(), a.c, a.num, a.den, a.flags, x.data_ptr(), b.c, b.num, b.den, b.flags,
+                                None if y is None else y.data_ptr(), out.data_ptr(), _ptr(sumsq), self.stream())
+        _lib.check(rc, "trk_axpby")
+
+    def scale(self, a, x, out, sumsq=None):
+        self.axpby(a, x, 0.0, None, out, sumsq)
+
+    def copy(self, x, out):
+        out.copy_(x)
+
+    def mul(self, x, y, out):
+        _lib.check(self.lib.trk_mul(x.numel(), x.data_ptr(), y.data_ptr(), out.data_ptr(), self.stream()), "trk_mul")
+
+    def mm_weights(self, x, y, eps, p, out):
+        """out = ((x - y)^2 + eps^2)^(p/2 - 1); y may be None."""
+        rc = self.lib.trk_mm_weights(x.numel(), x.data_ptr(), None if y is None else y.data_ptr(), float(eps), float(p),
+                                     out.data_ptr(), self.stream())
+        _lib.check(rc, "trk_mm_weights")
+
+    def cgls_update(self, gamma, delta, x, p, x_new, r, w, x_true, sums):
+        rc = self.lib.trk_cgls_update_xr(x.numel(), r.numel(), _ptr(gamma), _ptr(delta), x.data_ptr(), p.data_ptr(),
+                                         x_new.data_ptr(), r.data_ptr(), w.data_ptr(),
+                                         None if x_true is None else x_true.data_ptr(), _ptr(sums), self.stream())
+        _lib.check(rc, "trk_cgls_update_xr")
+
+    # ------------------------------------------------------------------ tall-skinny basis ops (row-per-vector V[k_max, n])
+    def gemv_t(self, V, k, r, out_h, w2=None):
+        """out_h[j] = sum_i w2[i] V[j,i] r[i]  for j < k (local sums)."""
+        rc = self.lib.trk_gemv_t(V.data_ptr(), V.stride(0), int(k), r.numel(), r.data_ptr(),
+                                 None if w2 is None else w2.data_ptr(), _ptr(out_h), self.stream())
+        _lib.check(rc, "trk_gemv_t")
+
+    def gemv_n(self, V, k, y, out, a=0.0, base=None, s=1.0, sumsq=None):
+        """out = a*base + s * sum_j y[j] V[j]   (y: k device doubles)."""
+        rc = self.lib.trk_gemv_n(V.data_ptr(), V.stride(0), int(k), out.numel(), _ptr(y), float(a),
+                                 None if base is None else base.data_ptr(), float(s), out.data_ptr(), _ptr(sumsq),
+                                 self.stream())
+        _lib.check(rc, "trk_gemv_n")
+
+    def wgram(self, W, k, w, b1, G, c1=None, c2=None):
+        """G = W diag(w^2) W^T (k x k), c1 = W (w*b1), c2 = W (w^2*b1)  (local sums; w may be None)."""
+        rc = self.lib.trk_wgram(W.data_ptr(), W.stride(0), int(k), W.shape[1], None if w is None else w.data_ptr(),
+                                None if b1 is None else b1.data_ptr(), _ptr(G), _ptr(c1), _ptr(c2), self.stream())
+        _lib.check(rc, "trk_wgram")
+
+
+_default_engines = {}
+
+
+def default_engine(comm=None):
+    """The process-wide engine of the current device (created on first use; raises without GPU / library)."""
+    if not torch.cuda.is_available():
+        raise _lib.TrkError("no GPU visible: trips_py_amd runs only on the HIP engine (no CPU fallback)")
+    key = (torch.cuda.current_device(), id(comm))
+    if key not in _default_engines:
+        _default_engines[key] = HipEngine(comm=comm)
+    return _default_engines[key]

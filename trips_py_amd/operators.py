@@ -1,0 +1,288 @@
+"""Linear operators with the PyLops `LinearOperator` surface the reference's solvers rely on
+(`A.shape`, `A @ x`, `A * x`, `A.T @ y`, operands (n,), (n,1), (n,k)), backed by libtrk.so.
+
+  Blur2D(psf, nx, ny)                <- Deblurring2D.forward_Op            trips/test_problems/Deblurring2D.py:66-73
+  Blur1D(psf)                        <- Deblurring1D.forward_Op_1D         trips/test_problems/Deblurring1D.py:93-102
+  Radon2DParallel(N, angles, ...)    <- parallel-beam OpTomo wrapper       trips/utilities/io.py:392-400
+  BlockDiagOp([A_0, ..])             <- pylops.BlockDiag / frame slicing    trips/utilities/io.py:420, :223-225
+  FirstDerivative2D(N)               <- gen_first_derivative_operator_2D   trips/utilities/operators.py:30-36
+  SpaceTimeDerivative(N, nt)         <- gen_spacetime_derivative_operator  trips/utilities/operators.py:39-45
+  Identity(n)                        <- pylops.Identity                    trips/solvers/Hybrid_LSQR.py:76
+
+NumPy in -> NumPy (float64) out, so the unmodified reference solvers can be handed one of these; torch device
+tensors in -> torch device tensors out.  The engine's own solvers use `apply()` on fp32 device vectors and
+row-per-vector bases and never leave the GPU.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import default_engine
+
+
+class LinearOperator:
+    """Base class: subclasses provide `_apply(x2d, y2d, transpose, sumsq)` on [batch, n] fp32 device tensors."""
+
+    dtype = np.dtype("float32")
+
+    def __init__(self, shape, engine=None):
+        self.shape = (int(shape[0]), int(shape[1]))
+        self.engine = engine if engine is not None else default_engine()
+
+    # ---- engine-native entry point -----------------------------------------------------------
+    def apply(self, x, out=None, transpose=False, sumsq=None):
+        """y = A x (or A^T x) for a 1-D fp32 device vector, or a [batch, n] row-per-vector block.
+        `sumsq` (1-element float64 device view) receives the LOCAL sum(y*y) fused into the kernel."""
+        nin = self.shape[0] if transpose else self.shape[1]
+        nout = self.shape[1] if transpose else self.shape[0]
+        one = x.dim() == 1
+        x2 = x.reshape(1, -1) if one else x
+        if x2.shape[1] != nin:
+            raise ValueError(f"dimension mismatch: operator expects {nin}, got {x2.shape[1]}")
+        if out is None:
+            out = torch.empty((x2.shape[0], nout), dtype=torch.float32, device=x.device)
+        o2 = out.reshape(1, -1) if out.dim() == 1 else out
+        if x2.stride(1) != 1 or o2.stride(1) != 1:
+            raise ValueError("apply() needs unit-stride vectors")
+        self._apply(x2, o2, bool(transpose), sumsq)
+        return o2[0] if one else o2
+
+    def _apply(self, x2, y2, transpose, sumsq):
+        raise NotImplementedError
+
+    # ---- PyLops-style surface ----------------------------------------------------------------
+    def _dot(self, x, transpose):
+        nin = self.shape[0] if transpose else self.shape[1]
+        is_np = not isinstance(x, torch.Tensor)
+        if is_np:
+            xa = np.asarray(x)
+            if xa.ndim not in (1, 2) or xa.shape[0] != nin:
+                raise ValueError(f"dimension mismatch: operator is {self.shape}, operand is {xa.shape}")
+            t = torch.from_numpy(np.ascontiguousarray(xa.reshape(nin, -1).T, dtype=np.float32)).to(self.engine.device)
+            y = self.apply(t, transpose=transpose)                       # [k, nout]
+            out = y.T.to("cpu").numpy().astype(np.float64)
+            return out.reshape(-1) if xa.ndim == 1 else out
+        if x.dim() not in (1, 2) or x.shape[0] != nin:
+            raise ValueError(f"dimension mismatch: operator is {self.shape}, operand is {tuple(x.shape)}")
+        t = x.to(device=self.engine.device, dtype=torch.float32)
+        rows = t.reshape(nin, -1).T.contiguous()                         # (n,k) column view -> row-per-vector
+        y = self.apply(rows, transpose=transpose).T
+        return y.reshape(-1) if x.dim() == 1 else y
+
+    def matvec(self, x):
+        return self._dot(x, False)
+
+    def rmatvec(self, y):
+        return self._dot(y, True)
+
+    matmat = matvec
+    rmatmat = rmatvec
+
+    def dot(self, x):
+        return self._dot(x, False)
+
+    def __matmul__(self, x):
+        return self._dot(x, False)
+
+    def __mul__(self, x):          # `L * v` means matvec in the reference (GKS.py:95, MMGKS.py:127)
+        return self._dot(x, False)
+
+    def __call__(self, x):
+        return self._dot(x, False)
+
+    @property
+    def T(self):
+        return _Transposed(self)
+
+    H = T
+
+    def adjoint(self):
+        return _Transposed(self)
+
+    transpose = adjoint
+
+    def todense(self):
+        """Dense float64 matrix (small operators only; Tikhonov.py:20, demo_1D_deblurring)."""
+        n = self.shape[1]
+        if n > 1 << 14:
+            raise MemoryError("todense() is for small operators")
+        return self._dot(np.eye(n), False)
+
+    def __repr__(self):
+        return f"<{self.shape[0]}x{self.shape[1]} {type(self).__name__} on {self.engine.device}>"
+
+
+class _Transposed(LinearOperator):
+    def __init__(self, op):
+        self.op = op
+        self.shape = (op.shape[1], op.shape[0])
+        self.engine = op.engine
+
+    def apply(self, x, out=None, transpose=False, sumsq=None):
+        return self.op.apply(x, out, not transpose, sumsq)
+
+    def _dot(self, x, transpose):
+        return self.op._dot(x, not transpose)
+
+    @property
+    def T(self):
+        return self.op
+
+    H = T
+
+
+class _HandleOperator(LinearOperator):
+    """An operator that owns a trk_op handle."""
+
+    def __init__(self, handle, engine):
+        self._h = handle
+        rows, cols = ctypes.c_int64(), ctypes.c_int64()
+        _lib.check(engine.lib.trk_op_shape(handle, ctypes.byref(rows), ctypes.byref(cols)), "trk_op_shape")
+        super().__init__((rows.value, cols.value), engine)
+
+    def _apply(self, x2, y2, transpose, sumsq):
+        self.engine.op_apply(self._h, transpose, x2, y2, batch=x2.shape[0], ldx=x2.stride(0), ldy=y2.stride(0), sumsq=sumsq)
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self.engine.lib.trk_op_destroy(h)
+            except Exception:
+                pass
+
+
+def _dbl_array(a):
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+    return a, a.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+
+
+class Blur2D(_HandleOperator):
+    """y = scipy.ndimage.convolve(x.reshape(nx,ny), psf, mode='reflect'); `.T` = the same with the flipped PSF."""
+
+    def __init__(self, psf, nx, ny, engine=None):
+        engine = engine if engine is not None else default_engine()
+        psf = np.asarray(psf, dtype=np.float64)
+        if psf.ndim != 2:
+            raise ValueError("psf must be 2-D")
+        self.psf, self.nx, self.ny = psf, int(nx), int(ny)
+        arr, p = _dbl_array(psf)
+        h = ctypes.c_void_p()
+        _lib.check(engine.lib.trk_blur2d_create(p, psf.shape[0], psf.shape[1], self.nx, self.ny, ctypes.byref(h)), "trk_blur2d_create")
+        super().__init__(h, engine)
+
+
+class Blur1D(Blur2D):
+    """1-D blur with a (possibly length-n) PSF: an n x 1 image and a k x 1 PSF."""
+
+    def __init__(self, psf, n=None, engine=None):
+        psf = np.asarray(psf, dtype=np.float64).reshape(-1)
+        n = len(psf) if n is None else int(n)
+        super().__init__(psf.reshape(-1, 1), n, 1, engine)
+
+
+class Radon2DParallel(_HandleOperator):
+    """Parallel-beam Joseph projector; sinogram (n_ang, n_det) row-major; scale defaults to 1/N (io.py:397-399)."""
+
+    def __init__(self, N, angles, n_det=None, scale=None, engine=None):
+        engine = engine if engine is not None else default_engine()
+        self.N = int(N)
+        self.angles = np.asarray(angles, dtype=np.float64).reshape(-1)
+        self.n_det = self.N if n_det is None else int(n_det)
+        self.scale = 1.0 / self.N if scale is None else float(scale)
+        arr, p = _dbl_array(self.angles)
+        h = ctypes.c_void_p()
+        _lib.check(engine.lib.trk_radon2d_create(self.N, self.n_det, p, len(self.angles), self.scale, ctypes.byref(h)), "trk_radon2d_create")
+        super().__init__(h, engine)
+
+
+class FirstDerivative2D(_HandleOperator):
+    def __init__(self, N, engine=None):
+        engine = engine if engine is not None else default_engine()
+        self.N = int(N)
+        h = ctypes.c_void_p()
+        _lib.check(engine.lib.trk_deriv2d_create(self.N, ctypes.byref(h)), "trk_deriv2d_create")
+        super().__init__(h, engine)
+
+
+class SpaceTimeDerivative(_HandleOperator):
+    """Space-time first differences over this rank's `nt_local` frames.  With a sharded time axis the engine's
+    communicator moves one frame to the neighbour before each apply (forward: first frame of the next rank;
+    transpose: last temporal block of the previous rank)."""
+
+    def __init__(self, N, nt, engine=None):
+        engine = engine if engine is not None else default_engine()
+        self.N, self.nt_global = int(N), int(nt)
+        w, r = engine.world, engine.rank
+        if self.nt_global % w:
+            raise ValueError(f"{nt} frames do not shard evenly over {w} ranks")
+        self.nt_local = self.nt_global // w
+        self.has_next, self.has_prev = r < w - 1, r > 0
+        h = ctypes.c_void_p()
+        _lib.check(engine.lib.trk_spacetime_create(self.N, self.nt_local, int(self.has_next), int(self.has_prev), ctypes.byref(h)),
+                   "trk_spacetime_create")
+        super().__init__(h, engine)
+        npix = self.N * self.N
+        self._halo_next = engine.empty(npix) if self.has_next else None
+        self._halo_prev = engine.empty(npix) if self.has_prev else None
+        self._ps = 2 * self.N * (self.N - 1)
+
+    def _apply(self, x2, y2, transpose, sumsq):
+        eng, npix = self.engine, self.N * self.N
+        if eng.world > 1:
+            if x2.shape[0] != 1:
+                raise NotImplementedError("sharded space-time operator applies one vector at a time")
+            if not transpose:
+                # my first frame -> previous rank ; receive the next rank's first frame
+                eng.comm.shift(send=x2[0, :npix] if self.has_prev else None, send_to=eng.rank - 1,
+                               recv=self._halo_next, recv_from=eng.rank + 1 if self.has_next else None)
+            else:
+                # my last temporal block -> next rank ; receive the previous rank's last temporal block
+                last = x2[0, self.nt_local * self._ps + (self.nt_local - 1) * npix:] if self.has_next else None
+                eng.comm.shift(send=last, send_to=eng.rank + 1,
+                               recv=self._halo_prev, recv_from=eng.rank - 1 if self.has_prev else None)
+            _lib.check(eng.lib.trk_spacetime_set_halo(self._h, None if self._halo_next is None else self._halo_next.data_ptr(),
+                                                      None if self._halo_prev is None else self._halo_prev.data_ptr()),
+                       "trk_spacetime_set_halo")
+        super()._apply(x2, y2, transpose, sumsq)
+
+
+class BlockDiagOp(_HandleOperator):
+    """F = blkdiag(A_0 .. A_{T-1}) over THIS RANK's frames; x and b are frame-major."""
+
+    def __init__(self, ops, engine=None):
+        engine = engine if engine is not None else ops[0].engine
+        self.ops = list(ops)
+        arr = (ctypes.c_void_p * len(self.ops))(*[o._h for o in self.ops])
+        h = ctypes.c_void_p()
+        _lib.check(engine.lib.trk_blockdiag_create(arr, len(self.ops), ctypes.byref(h)), "trk_blockdiag_create")
+        super().__init__(h, engine)
+
+
+class Identity(LinearOperator):
+    def __init__(self, n, engine=None):
+        super().__init__((n, n), engine)
+
+    def _apply(self, x2, y2, transpose, sumsq):
+        y2.copy_(x2)
+        if sumsq is not None:
+            self.engine.nrm2sq(y2.reshape(-1), sumsq)
+
+
+def is_identity(A):
+    """Host predicate selecting the L = I branch (trips/utilities/utils.py:47-62)."""
+    if isinstance(A, Identity):
+        return True
+    if isinstance(A, LinearOperator):
+        return False
+    if hasattr(A, "shape") and len(A.shape) == 2 and A.shape[0] == A.shape[1]:
+        try:
+            import scipy.sparse as sp
+            if sp.issparse(A):
+                return abs((A - sp.eye(A.shape[0])).sum()) < 1e-6
+            return bool(np.allclose(np.asarray(A), np.eye(A.shape[0])))
+        except Exception:
+            return False
+    return False
