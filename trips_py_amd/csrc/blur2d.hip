@@ -7,13 +7,17 @@
 //     c[a',b'] = PSF[kh-1-a', kw-1-b'],  T = kh-1-kh/2,  L = kw-1-kw/2.
 //
 // Kernel plan (HBM-bound: 8 bytes of traffic per pixel):
-//   * k_blur_tile<KH,KW,SEP>: one workgroup (256 threads = 4 waves) per 32 x 128 output tile.  The tile plus halo is
-//     staged in LDS with 16-byte coalesced row loads (scalar reflect path only on border tiles).  Rank-1 PSFs (every
-//     Gaussian PSF) run a separable row pass LDS->LDS then a column pass; general PSFs run the direct KH*KW form.  Each
-//     thread owns a 4 x 4 register block of outputs and reads LDS only with 16-byte ds_read_b128.  Stores are 16-byte
-//     coalesced.  Optionally the tile's sum(y^2) is reduced (wave64 shuffles, fp64) into one partial per workgroup.
-//   * workgroup -> tile map is XCD-aware: ids are dealt round-robin over the 8 XCDs, so id%8 picks one of 8 contiguous
-//     bands of tiles and vertically adjacent tiles (which share halo rows) stay in one XCD's L2.
+//   * k_blur_strip<KH,KW,SEP>: a workgroup (256 threads = 4 waves) owns a 128-column strip of a band of rows and SLIDES
+//     DOWN it in steps of 32 rows.  The KH-1 halo rows shared by consecutive steps stay in an LDS ring of 32+KH-1 rows,
+//     so every input row is fetched once per strip (no vertical re-reads); only the KW-1 halo columns between
+//     neighbouring strips are read twice (6 % at 9x9, served by L2).  While a step is being computed from LDS, the 32
+//     new rows of the next step are already in flight from HBM into registers (16-byte coalesced loads) and are written
+//     to the ring after the step's barrier: loads overlap compute, 2 barriers per step, 22 KB of LDS per workgroup.
+//     Each thread owns a 4 x 4 register block of outputs; per staged row it reads 12 floats (3 x ds_read_b128), forms the
+//     row-filtered values in registers and scatters them into its 4 output rows (separable PSFs: 9+... FMAs; general
+//     PSFs: the direct KH*KW form from the same 12 floats).  Stores are 16-byte coalesced.  Optionally sum(y^2) is
+//     accumulated per thread in fp64 over all steps and reduced once per workgroup (wave64 shuffles).
+//   * grid = strips x row bands, sized to ~4 workgroups per CU so that a 4096^2 image is split evenly (no tail).
 //   * k_blur_generic: any PSF size (even, rectangular, longer than the image: repeated reflection), no tiling.
 #include "trk_internal.h"
 
@@ -28,10 +32,13 @@ constexpr int NT = 256;
 constexpr int TW = 128;  // output tile width  (32 lanes x float4)
 constexpr int TH = 32;   // output tile height (8 thread rows x 4)
 
+typedef float f4 __attribute__((ext_vector_type(4)));  // one 16-byte register quad: keeps loads/stores as b128
+
 __host__ __device__ constexpr int rup4(int v) { return (v + 3) & ~3; }
 
 __device__ __forceinline__ int reflect(int i, int n) {
-  // half-sample symmetric extension, any distance
+  // half-sample symmetric extension, any distance; in-range indices (the common case) skip the division
+  if ((unsigned)i < (unsigned)n) return i;
   const int p = 2 * n;
   i %= p;
   if (i < 0) i += p;
@@ -41,159 +48,332 @@ __device__ __forceinline__ int reflect(int i, int n) {
 struct BlurImpl {
   int nx, ny, kh, kw;
   bool separable;
-  bool tiled;          // a k_blur_tile instantiation exists for (kh,kw)
+  bool tiled;          // a k_blur_strip instantiation exists for (kh,kw)
   float* w_dev[2];     // [kh*kw] correlation weights: 0 forward, 1 "transpose" (flipped PSF)
   float* sep_dev[2];   // [kw row weights | kh column weights]
 };
 
-// ------------------------------------------------------------------------------------------------ tiled kernel
+// ------------------------------------------------------------------------------------------------ strip kernel
+// min waves per SIMD asked of the register allocator: 4 (= 4 workgroups per CU) for the separable kernels up to 9x9,
+// 2 for the register-hungry direct / large-PSF forms
 template <int KH, int KW, bool SEP, bool SUMSQ>
-__global__ __launch_bounds__(NT) void k_blur_tile(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
-                                                  int64_t ldy, int nx, int ny, const float* __restrict__ wts,
-                                                  double* __restrict__ partials, int tiles_x, int tiles_y) {
+__global__ __launch_bounds__(NT, (SEP && KH <= 9) ? 4 : 2) void k_blur_strip(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                   int64_t ldy, int nx, int ny, const float* __restrict__ wts,
+                                                   double* __restrict__ partials, int strips_x, int rows_per_band) {
   constexpr int T = KH - 1 - KH / 2;   // halo above
   constexpr int L = KW - 1 - KW / 2;   // halo left
   constexpr int R = KW / 2;            // halo right
   constexpr int LP = rup4(L), RP = rup4(R);
   constexpr int SW = TW + LP + RP;     // staged row length (floats, multiple of 4)
-  constexpr int SH = TH + KH - 1;      // staged rows
+  constexpr int RING = TH + KH - 1;    // staged rows per step
   constexpr int OFF = LP - L;          // first needed column inside the 16-byte aligned read
   constexpr int NV = (OFF + KW + 3 + 3) / 4;  // float4s covering 4 outputs' taps
   constexpr int SW4 = SW / 4;
+  constexpr int NPF = (TH * SW4 + NT - 1) / NT;  // float4 prefetched per thread per step
 
-  __shared__ __attribute__((aligned(16))) float S[SH * SW];
-  __shared__ __attribute__((aligned(16))) float H[SEP ? SH * TW : 4];
+  __shared__ f4 S4[RING * SW4];
+  float* const S = reinterpret_cast<float*>(S4);
   __shared__ double red[NT / 64];
 
-  // XCD-aware tile id
-  const int ntile = tiles_x * tiles_y;
-  int bid = blockIdx.x;
-  if ((ntile & 7) == 0) bid = (bid & 7) * (ntile >> 3) + (bid >> 3);
-  const int ti = bid / tiles_x, tj = bid - ti * tiles_x;
-  const int i0 = ti * TH, j0 = tj * TW;
+  const int sj = blockIdx.x % strips_x, band = blockIdx.x / strips_x;
+  const int j0 = sj * TW;
+  const int i_begin = band * rows_per_band;
+  const int i_end = (i_begin + rows_per_band < nx) ? i_begin + rows_per_band : nx;
   x += (int64_t)blockIdx.y * ldx;
   y += (int64_t)blockIdx.y * ldy;
 
-  // ---- stage tile + halo
-  const bool interior = (i0 - T >= 0) && (i0 + TH + KH / 2 <= nx) && (j0 - LP >= 0) && (j0 + TW + RP <= ny) &&
-                        ((ny & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
-  if (interior) {
-    const float* src = x + (int64_t)(i0 - T) * ny + (j0 - LP);
-    for (int idx = threadIdx.x; idx < SH * SW4; idx += NT) {
+  // staged row `rel` is image row (i_begin - T + rel), reflected; it lives in ring slot rel % RING.
+  // With ny % 4 == 0 and an aligned base every 4-column group of a staged row is either wholly inside the image
+  // (one 16-byte load) or wholly outside (halo of the first / last strip: four reflected scalar loads).
+  const bool fast = ((ny & 3) == 0) && ((reinterpret_cast<uintptr_t>(x) & 15u) == 0);
+
+  auto load_group = [&](int rel, int c4) -> f4 {   // 4 staged columns of staged row `rel`
+    const int gi = reflect(i_begin - T + rel, nx);
+    const int gc = j0 - LP + 4 * c4;
+    const float* row = x + (int64_t)gi * ny;
+    if (fast && gc >= 0 && gc + 3 < ny) return *reinterpret_cast<const f4*>(row + gc);
+    return (f4){row[reflect(gc, ny)], row[reflect(gc + 1, ny)], row[reflect(gc + 2, ny)], row[reflect(gc + 3, ny)]};
+  };
+
+  auto load_direct = [&](int rel0, int count) {   // global -> LDS, rows rel0 .. rel0+count-1
+    for (int idx = threadIdx.x; idx < count * SW4; idx += NT) {
       const int r = idx / SW4, c4 = idx - r * SW4;
-      const float4 v = *reinterpret_cast<const float4*>(src + (int64_t)r * ny + 4 * c4);
-      *reinterpret_cast<float4*>(&S[r * SW + 4 * c4]) = v;
+      S4[((rel0 + r) % RING) * SW4 + c4] = load_group(rel0 + r, c4);
     }
-  } else {
-    for (int idx = threadIdx.x; idx < SH * SW; idx += NT) {
-      const int r = idx / SW, c = idx - r * SW;
-      const int gi = reflect(i0 - T + r, nx), gj = reflect(j0 - LP + c, ny);
-      S[idx] = x[(int64_t)gi * ny + gj];
-    }
-  }
-  __syncthreads();
+  };
 
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads; thread block of 4 rows x 4 cols
-  float acc[4][4];
-#pragma unroll
-  for (int rr = 0; rr < 4; ++rr)
-#pragma unroll
-    for (int c = 0; c < 4; ++c) acc[rr][c] = 0.f;
-
+  float wr[SEP ? KW : 1], wc[SEP ? KH : 1];
   if (SEP) {
-    // row pass: H[r][c] = sum_b wr[b] * S[r][c + OFF + b]
-    float wr[KW];
 #pragma unroll
     for (int b = 0; b < KW; ++b) wr[b] = wts[b];
-    for (int r = ty; r < SH; r += 8) {
-      float v[NV * 4];
-#pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        const float4 t = *reinterpret_cast<const float4*>(&S[r * SW + 4 * tx + 4 * q]);
-        v[4 * q] = t.x;
-        v[4 * q + 1] = t.y;
-        v[4 * q + 2] = t.z;
-        v[4 * q + 3] = t.w;
-      }
-      float h[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int b = 0; b < KW; ++b)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) h[c] = fmaf(wr[b], v[OFF + c + b], h[c]);
-      *reinterpret_cast<float4*>(&H[r * TW + 4 * tx]) = make_float4(h[0], h[1], h[2], h[3]);
-    }
-    __syncthreads();
-    // column pass
-    float wc[KH];
 #pragma unroll
     for (int a = 0; a < KH; ++a) wc[a] = wts[KW + a];
+  }
+
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8 threads; thread block of 4 rows x 4 cols
+  const int gj = j0 + 4 * tx;
+  // block-uniform: every thread's 4 columns are inside the image and 16-byte aligned
+  const bool vec_ok = ((ny & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15u) == 0) && (j0 + TW <= ny);
+  double ss = 0.0;
+
+  load_direct(0, RING);
+  int rb = 0;  // ring slot of the step's first staged row
+  for (int i0 = i_begin; i0 < i_end; i0 += TH) {
+    const int rel_base = i0 - i_begin;
+    const bool has_next = (i0 + TH < i_end);
+    __syncthreads();  // the step's RING rows are in LDS
+
+    // ---- next step's 32 new rows: HBM -> registers, in flight during the compute below
+    f4 pf[NPF];
 #pragma unroll
-    for (int a = 0; a < KH + 3; ++a) {
-      const float4 hv = *reinterpret_cast<const float4*>(&H[(4 * ty + a) * TW + 4 * tx]);
+    for (int q = 0; q < NPF; ++q) pf[q] = (f4){0.f, 0.f, 0.f, 0.f};
+    if (has_next) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        if (a - rr >= 0 && a - rr < KH) {
-          const float w = wc[a - rr];
-          acc[rr][0] = fmaf(w, hv.x, acc[rr][0]);
-          acc[rr][1] = fmaf(w, hv.y, acc[rr][1]);
-          acc[rr][2] = fmaf(w, hv.z, acc[rr][2]);
-          acc[rr][3] = fmaf(w, hv.w, acc[rr][3]);
+      for (int q = 0; q < NPF; ++q) {
+        const int idx = threadIdx.x + q * NT;
+        if (idx < TH * SW4) {
+          const int r = idx / SW4, c4 = idx - r * SW4;
+          pf[q] = load_group(rel_base + RING + r, c4);
         }
       }
     }
-  } else {
+
+    // ---- compute the 4 x 4 output block from LDS
+    float acc[4][4];
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[rr][c] = 0.f;
 #pragma unroll
     for (int a = 0; a < KH + 3; ++a) {
+      int slot = rb + 4 * ty + a;
+      if (slot >= RING) slot -= RING;
       float v[NV * 4];
 #pragma unroll
       for (int q = 0; q < NV; ++q) {
-        const float4 t = *reinterpret_cast<const float4*>(&S[(4 * ty + a) * SW + 4 * tx + 4 * q]);
-        v[4 * q] = t.x;
-        v[4 * q + 1] = t.y;
-        v[4 * q + 2] = t.z;
-        v[4 * q + 3] = t.w;
+        const f4 t = S4[slot * SW4 + tx + q];
+        v[4 * q] = t[0];
+        v[4 * q + 1] = t[1];
+        v[4 * q + 2] = t[2];
+        v[4 * q + 3] = t[3];
       }
+      if (SEP) {
+        float h[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        if (a - rr >= 0 && a - rr < KH) {
+        for (int b = 0; b < KW; ++b)
 #pragma unroll
-          for (int b = 0; b < KW; ++b) {
-            const float w = wts[(a - rr) * KW + b];
+          for (int c = 0; c < 4; ++c) h[c] = fmaf(wr[b], v[OFF + c + b], h[c]);
 #pragma unroll
-            for (int c = 0; c < 4; ++c) acc[rr][c] = fmaf(w, v[OFF + c + b], acc[rr][c]);
+        for (int rr = 0; rr < 4; ++rr) {
+          if (a - rr >= 0 && a - rr < KH) {
+            const float w = wc[a - rr];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[rr][c] = fmaf(w, h[c], acc[rr][c]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) {
+          if (a - rr >= 0 && a - rr < KH) {
+#pragma unroll
+            for (int b = 0; b < KW; ++b) {
+              const float w = wts[(a - rr) * KW + b];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[rr][c] = fmaf(w, v[OFF + c + b], acc[rr][c]);
+            }
           }
         }
       }
     }
-  }
 
-  // ---- store (16-byte coalesced when the row is aligned and fully inside)
-  double ss = 0.0;
-  const int gj = j0 + 4 * tx;
-  const bool vec_ok = ((ny & 3) == 0) && ((reinterpret_cast<uintptr_t>(y) & 15u) == 0) && (gj + 3 < ny);
+    // ---- store (16-byte coalesced when the strip is aligned and fully inside: a block-uniform branch)
+    if (vec_ok) {
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int gi = i0 + 4 * ty + rr;
-    if (gi < nx) {
-      float* dst = y + (int64_t)gi * ny + gj;
-      if (vec_ok) {
-        *reinterpret_cast<float4*>(dst) = make_float4(acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]);
-        if (SUMSQ)
-          ss += (double)acc[rr][0] * acc[rr][0] + (double)acc[rr][1] * acc[rr][1] + (double)acc[rr][2] * acc[rr][2] +
-                (double)acc[rr][3] * acc[rr][3];
-      } else {
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          if (gj + c < ny) {
-            dst[c] = acc[rr][c];
-            if (SUMSQ) ss += (double)acc[rr][c] * acc[rr][c];
-          }
+      for (int rr = 0; rr < 4; ++rr) {
+        const int gi = i0 + 4 * ty + rr;
+        if (gi < i_end) {
+          *reinterpret_cast<f4*>(y + (int64_t)gi * ny + gj) = (f4){acc[rr][0], acc[rr][1], acc[rr][2], acc[rr][3]};
+          if (SUMSQ)
+            ss += (double)acc[rr][0] * acc[rr][0] + (double)acc[rr][1] * acc[rr][1] +
+                  (double)acc[rr][2] * acc[rr][2] + (double)acc[rr][3] * acc[rr][3];
+        }
       }
+    } else {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int gi = i0 + 4 * ty + rr;
+        if (gi < i_end) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            if (gj + c < ny) {
+              y[(int64_t)gi * ny + gj + c] = acc[rr][c];
+              if (SUMSQ) ss += (double)acc[rr][c] * acc[rr][c];
+            }
+        }
+      }
+    }
+
+    if (has_next) {
+      __syncthreads();  // every wave is done reading the rows about to be overwritten
+#pragma unroll
+      for (int q = 0; q < NPF; ++q) {
+        const int idx = threadIdx.x + q * NT;
+        if (idx < TH * SW4) {
+          const int r = idx / SW4, c4 = idx - r * SW4;
+          S4[((rel_base + RING + r) % RING) * SW4 + c4] = pf[q];
+        }
+      }
+      rb += TH;
+      if (rb >= RING) rb -= RING;
     }
   }
   if (SUMSQ) {
     ss = block_sum<NT>(ss, red);
     if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ss;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ sliding kernel
+// Separable PSFs with halos <= 4 columns (KW <= 9): no LDS, no barriers.  One wave owns a 256-column span (4 columns
+// per lane) of a band of rows and marches down it.  Per staged row a lane issues three 16-byte buffer loads (its own
+// 4 columns and the 4 to the left / right: L1/L2 hits of the neighbour lanes' lines), D rows ahead of use; the row is
+// filtered horizontally in registers (KW taps from the 12 values), and the result is scattered with packed FMAs into
+// KH rolling output-row accumulators (output o += wc[a] * h[o+a]); the oldest accumulator is complete and is stored
+// with one 16-byte coalesced store.  Row addresses are wave-uniform (SGPR soffset of the buffer instruction), column
+// offsets are per-lane constants: the inner loop has no address arithmetic in VALU.  The loop is unrolled by
+// U = lcm(KH, D) so that every ring index is a compile-time constant (registers, not scratch).
+typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+__host__ __device__ constexpr int gcd_c(int a, int b) { return b == 0 ? a : gcd_c(b, a % b); }
+__host__ __device__ constexpr int lcm_c(int a, int b) { return a / gcd_c(a, b) * b; }
+__host__ __device__ constexpr int pmod(int a, int m) { return ((a % m) + m) % m; }
+
+constexpr int SPAN = 256;  // columns per wave
+
+template <int KH, int KW, int D, bool SUMSQ>
+__global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                   int64_t ldy, int nx, int ny, const float* __restrict__ wts,
+                                                   double* __restrict__ partials, int spans_x, int nbands,
+                                                   int rows_per_band) {
+  constexpr int T = KH - 1 - KH / 2;
+  constexpr int Lh = KW - 1 - KW / 2;
+  constexpr int OFFC = 4 - Lh;          // v[] index of tap 0 of output column 0
+  constexpr int U = lcm_c(KH, D);
+  static_assert(Lh <= 4 && KW / 2 <= 4, "sliding kernel handles halos of at most one 4-column group");
+
+  // XCD-aware placement: ids are dealt round-robin over the 8 XCDs; give each XCD a contiguous block of bands so that
+  // horizontally and vertically adjacent waves (which share halo lines) share an L2.
+  int band, span;
+  {
+    const int id = blockIdx.x;
+    if ((nbands & 7) == 0) {
+      const int xcd = id & 7, local = id >> 3, bpx = nbands >> 3;
+      band = xcd * bpx + local / spans_x;
+      span = local % spans_x;
+    } else {
+      band = id / spans_x;
+      span = id % spans_x;
+    }
+  }
+  x += (int64_t)blockIdx.y * ldx;
+  y += (int64_t)blockIdx.y * ldy;
+  const int i_begin = band * rows_per_band;
+  const int i_end = (i_begin + rows_per_band < nx) ? i_begin + rows_per_band : nx;
+  const int lane = threadIdx.x;
+  const int c0 = span * SPAN + 4 * lane;
+  const bool active = c0 < ny;
+  const int cc = active ? c0 : ny - 4;                 // clamped: every load address is valid
+  const int cl = (cc >= 4) ? cc - 4 : 0;
+  const int cr = (cc + 8 <= ny) ? cc + 4 : ny - 4;
+  const bool ledge = (c0 == 0), redge = (c0 + 4 == ny);
+  const bool edge_span = (span == 0) || ((span + 1) * SPAN >= ny);   // wave-uniform
+
+  const unsigned img_bytes = (unsigned)nx * (unsigned)ny * 4u;
+  const auto rin = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, img_bytes, 0x00020000);
+  const auto rout = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, img_bytes, 0x00020000);
+  const int vl = cl * 4, vc = cc * 4, vr = cr * 4;
+  const int vst = c0 * 4;
+
+  float wr[KW], wc[KH];
+#pragma unroll
+  for (int b = 0; b < KW; ++b) wr[b] = wts[b];
+#pragma unroll
+  for (int a = 0; a < KH; ++a) wc[a] = wts[KW + a];
+
+  const int band_rows = i_end - i_begin;
+  const int total = ((band_rows + KH - 1 + U - 1) / U) * U;   // staged rows processed (multiple of U)
+
+  f4 pL[D], pC[D], pR[D];
+  auto issue = [&](int t, int slot) {
+    const int gi = reflect(i_begin - T + t, nx);
+    const int so = gi * ny * 4;
+    pL[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, vl, so, 0));
+    pC[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, vc, so, 0));
+    pR[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, vr, so, 0));
+  };
+#pragma unroll
+  for (int d = 0; d < D; ++d) issue(d, d);
+
+  f2 acc[KH][2];
+  double ss = 0.0;
+  for (int t0 = 0; t0 < total; t0 += U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int t = t0 + u;
+      constexpr int dummy = 0;
+      (void)dummy;
+      const int slot = u % D;
+      f4 Lv = pL[slot], Cv = pC[slot], Rv = pR[slot];
+      if (t + D < total) issue(t + D, slot);           // uniform branch: refill the slot D rows ahead
+      if (edge_span) {                                  // reflect across the image's left / right border
+        const f4 rev = (f4){Cv[3], Cv[2], Cv[1], Cv[0]};
+        if (ledge) Lv = rev;
+        if (redge) Rv = rev;
+      }
+      const float v[12] = {Lv[0], Lv[1], Lv[2], Lv[3], Cv[0], Cv[1], Cv[2], Cv[3], Rv[0], Rv[1], Rv[2], Rv[3]};
+      float h0 = 0.f, h1 = 0.f, h2 = 0.f, h3 = 0.f;
+#pragma unroll
+      for (int b = 0; b < KW; ++b) {
+        h0 = fmaf(wr[b], v[OFFC + b], h0);
+        h1 = fmaf(wr[b], v[OFFC + b + 1], h1);
+        h2 = fmaf(wr[b], v[OFFC + b + 2], h2);
+        h3 = fmaf(wr[b], v[OFFC + b + 3], h3);
+      }
+      const f2 hlo = {h0, h1}, hhi = {h2, h3};
+      // scatter into the rolling accumulators: output o = t - a gets wc[a] * h_t
+#pragma unroll
+      for (int a = 0; a < KH; ++a) {
+        const int k = pmod(u - a, KH);
+        if (a == 0) {
+          acc[k][0] = wc[0] * hlo;
+          acc[k][1] = wc[0] * hhi;
+        } else {
+          acc[k][0] = wc[a] * hlo + acc[k][0];
+          acc[k][1] = wc[a] * hhi + acc[k][1];
+        }
+      }
+      // output o = t - (KH-1) is complete
+      const int o = t - (KH - 1);
+      if (o >= 0 && o < band_rows) {                   // uniform branch
+        const int kd = pmod(u - (KH - 1), KH);
+        const f4 out = (f4){acc[kd][0][0], acc[kd][0][1], acc[kd][1][0], acc[kd][1][1]};
+        // NOTE the row offset goes into the VGPR offset, not the SGPR soffset: with an SGPR soffset hipcc (ROCm 7.2)
+        // emits no wait state between a >64-bit buffer store and a VALU overwrite of its data registers, and on
+        // gfx950 the last dword of the store was then observed corrupted (lanes 12-15 of each row of 16).
+        if (active) {
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, out), rout, vst + (i_begin + o) * ny * 4, 0, 0);
+          if (SUMSQ) {
+            const float q = fmaf(out[0], out[0], fmaf(out[1], out[1], fmaf(out[2], out[2], out[3] * out[3])));
+            ss += (double)q;
+          }
+        }
+      }
+    }
+  }
+  if (SUMSQ) {
+    ss = wave_sum(ss);
+    if (lane == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ss;
   }
 }
 
@@ -226,13 +406,25 @@ __global__ __launch_bounds__(NT) void k_blur_generic(const float* __restrict__ x
 }
 
 // ------------------------------------------------------------------------------------------------ dispatch
+// strips x row bands: about 4 workgroups per CU, bands a whole number of 32-row steps
+inline void strip_grid(int nx, int ny, int batch, int* strips_x, int* rows_per_band, int* nband) {
+  const int sx = ceil_div(ny, TW), steps = ceil_div(nx, TH);
+  int want = (4 * cu_count()) / (sx * (batch > 0 ? batch : 1));
+  if (want < 1) want = 1;
+  if (want > steps) want = steps;
+  const int steps_per_band = ceil_div(steps, want);
+  *strips_x = sx;
+  *rows_per_band = steps_per_band * TH;
+  *nband = ceil_div(nx, *rows_per_band);
+}
+
 template <int K>
-int launch_tile(const BlurImpl* im, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch,
-                double* part, int tiles_x, int tiles_y, hipStream_t s) {
-  dim3 grid(tiles_x * tiles_y, batch), block(NT);
+int launch_strip(const BlurImpl* im, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch,
+                 double* part, int strips_x, int rows_per_band, int nband, hipStream_t s) {
+  dim3 grid(strips_x * nband, batch), block(NT);
   const float* w = im->separable ? im->sep_dev[tr] : im->w_dev[tr];
 #define BL(SEP, SS) \
-  hipLaunchKernelGGL((k_blur_tile<K, K, SEP, SS>), grid, block, 0, s, x, ldx, y, ldy, im->nx, im->ny, w, part, tiles_x, tiles_y)
+  hipLaunchKernelGGL((k_blur_strip<K, K, SEP, SS>), grid, block, 0, s, x, ldx, y, ldy, im->nx, im->ny, w, part, strips_x, rows_per_band)
   if (im->separable) { if (part) BL(true, true); else BL(true, false); }
   else               { if (part) BL(false, true); else BL(false, false); }
 #undef BL
@@ -240,28 +432,84 @@ int launch_tile(const BlurImpl* im, int tr, const float* x, int64_t ldx, float* 
   return TRK_OK;
 }
 
+template <int K, int D>
+int launch_slide(const BlurImpl* im, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch,
+                 double* part, int spans_x, int nbands, int rows_per_band, hipStream_t s) {
+  dim3 grid(spans_x * nbands, batch), block(64);
+  const float* w = im->sep_dev[tr];
+  if (part)
+    hipLaunchKernelGGL((k_blur_slide<K, K, D, true>), grid, block, 0, s, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band);
+  else
+    hipLaunchKernelGGL((k_blur_slide<K, K, D, false>), grid, block, 0, s, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+// bands for the sliding kernel: about 2 waves per SIMD over the chip, a multiple of 8 bands when possible (XCD map)
+inline void slide_grid(int nx, int ny, int batch, int* spans_x, int* nbands, int* rows_per_band) {
+  const int sx = ceil_div(ny, SPAN);
+  int want = (8 * cu_count()) / (sx * (batch > 0 ? batch : 1));   // 2 waves x 4 SIMDs per CU
+  if (want < 1) want = 1;
+  int rpb = ceil_div(nx, want);
+  if (rpb < 16) rpb = 16;                                         // keep the halo overhead (KH-1 rows) bounded
+  int nb = ceil_div(nx, rpb);
+  if (nb > 8 && (nb & 7)) {                                       // round the band count to a multiple of 8
+    nb = (nb + 7) & ~7;
+    rpb = ceil_div(nx, nb);
+    nb = ceil_div(nx, rpb);
+  }
+  *spans_x = sx;
+  *nbands = nb;
+  *rows_per_band = rpb;
+}
+
 int blur_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
                hipStream_t s) {
   auto* im = static_cast<BlurImpl*>(op->impl);
   double* part = nullptr;
   int nblk;
-  TimerScope tm(op->timer, op->timer_which, tr, s);
-  if (im->tiled) {
-    const int tiles_x = ceil_div(im->ny, TW), tiles_y = ceil_div(im->nx, TH);
-    nblk = tiles_x * tiles_y;
+  const bool slide_ok = im->separable && im->kh == im->kw && (im->kh & 1) && im->kh >= 3 && im->kh <= 9 &&
+                        (im->ny & 3) == 0 && im->ny >= 8 && aligned16(x) && aligned16(y) &&
+                        (batch == 1 || ((ldx & 3) == 0 && (ldy & 3) == 0)) &&
+                        (int64_t)im->nx * im->ny < ((int64_t)1 << 30);
+  if (slide_ok) {
+    int spans_x, nbands, rpb;
+    slide_grid(im->nx, im->ny, batch, &spans_x, &nbands, &rpb);
+    nblk = spans_x * nbands;
     if (sumsq)
       if (int rc = scratch_doubles(s, (size_t)nblk * batch, &part)) return rc;
+    TimerScope tm(op->timer, op->timer_which, tr, s);
     int rc;
     switch (im->kh) {
-      case 3: rc = launch_tile<3>(im, tr, x, ldx, y, ldy, batch, part, tiles_x, tiles_y, s); break;
-      case 5: rc = launch_tile<5>(im, tr, x, ldx, y, ldy, batch, part, tiles_x, tiles_y, s); break;
-      case 7: rc = launch_tile<7>(im, tr, x, ldx, y, ldy, batch, part, tiles_x, tiles_y, s); break;
-      case 9: rc = launch_tile<9>(im, tr, x, ldx, y, ldy, batch, part, tiles_x, tiles_y, s); break;
-      case 11: rc = launch_tile<11>(im, tr, x, ldx, y, ldy, batch, part, tiles_x, tiles_y, s); break;
-      case 13: rc = launch_tile<13>(im, tr, x, ldx, y, ldy, batch, part, tiles_x, tiles_y, s); break;
-      case 15: rc = launch_tile<15>(im, tr, x, ldx, y, ldy, batch, part, tiles_x, tiles_y, s); break;
-      default: return fail(TRK_EUNSUPPORTED, "blur2d: no tiled kernel for %dx%d", im->kh, im->kw);
+      case 3: rc = launch_slide<3, 6>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s); break;
+      case 5: rc = launch_slide<5, 5>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s); break;
+      case 7: rc = launch_slide<7, 7>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s); break;
+      default: rc = launch_slide<9, 6>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s); break;
     }
+    tm.stop();
+    if (rc) return rc;
+    if (sumsq) return finalize_sums(part, nblk * batch, 1, 1, sumsq, s);
+    return TRK_OK;
+  }
+  if (im->tiled) {
+    int strips_x, rows_per_band, nband;
+    strip_grid(im->nx, im->ny, batch, &strips_x, &rows_per_band, &nband);
+    nblk = strips_x * nband;
+    if (sumsq)
+      if (int rc = scratch_doubles(s, (size_t)nblk * batch, &part)) return rc;
+    TimerScope tm(op->timer, op->timer_which, tr, s);
+    int rc;
+    switch (im->kh) {
+      case 3: rc = launch_strip<3>(im, tr, x, ldx, y, ldy, batch, part, strips_x, rows_per_band, nband, s); break;
+      case 5: rc = launch_strip<5>(im, tr, x, ldx, y, ldy, batch, part, strips_x, rows_per_band, nband, s); break;
+      case 7: rc = launch_strip<7>(im, tr, x, ldx, y, ldy, batch, part, strips_x, rows_per_band, nband, s); break;
+      case 9: rc = launch_strip<9>(im, tr, x, ldx, y, ldy, batch, part, strips_x, rows_per_band, nband, s); break;
+      case 11: rc = launch_strip<11>(im, tr, x, ldx, y, ldy, batch, part, strips_x, rows_per_band, nband, s); break;
+      case 13: rc = launch_strip<13>(im, tr, x, ldx, y, ldy, batch, part, strips_x, rows_per_band, nband, s); break;
+      case 15: rc = launch_strip<15>(im, tr, x, ldx, y, ldy, batch, part, strips_x, rows_per_band, nband, s); break;
+      default: return fail(TRK_EUNSUPPORTED, "blur2d: no strip kernel for %dx%d", im->kh, im->kw);
+    }
+    tm.stop();
     if (rc) return rc;
   } else {
     const int64_t npix = (int64_t)im->nx * im->ny;
@@ -271,13 +519,14 @@ int blur_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_
     if (sumsq)
       if (int rc = scratch_doubles(s, (size_t)nblk * batch, &part)) return rc;
     dim3 grid(nblk, batch);
+    TimerScope tm(op->timer, op->timer_which, tr, s);
     if (part)
       hipLaunchKernelGGL((k_blur_generic<true>), grid, dim3(NT), 0, s, x, ldx, y, ldy, im->nx, im->ny, im->kh, im->kw, im->w_dev[tr], part);
     else
       hipLaunchKernelGGL((k_blur_generic<false>), grid, dim3(NT), 0, s, x, ldx, y, ldy, im->nx, im->ny, im->kh, im->kw, im->w_dev[tr], part);
+    tm.stop();
     TRK_LAUNCH_CHECK();
   }
-  tm.stop();
   if (sumsq) return finalize_sums(part, nblk * batch, 1, 1, sumsq, s);
   return TRK_OK;
 }

@@ -56,13 +56,23 @@ int scratch_doubles(hipStream_t s, size_t count, double** out) {
 }
 
 // ---------------------------------------------------------------- finalize: fixed-order sum of block partials
+// One workgroup per output.  Four independent accumulators keep four loads in flight per thread; the association of
+// the sum is a fixed function of (nblocks, thread id), hence bitwise reproducible run to run.
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partials, int nblocks, int stride,
                                                   double* __restrict__ out) {
   __shared__ double lds[4];
   const int o = blockIdx.x;
-  double v = 0.0;
-  for (int b = threadIdx.x; b < nblocks; b += 256) v += partials[(size_t)b * stride + o];
-  v = block_sum<256>(v, lds);
+  const double* __restrict__ p = partials + o;
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  int b = threadIdx.x;
+  for (; b + 768 < nblocks; b += 1024) {
+    v0 += p[(size_t)b * stride];
+    v1 += p[(size_t)(b + 256) * stride];
+    v2 += p[(size_t)(b + 512) * stride];
+    v3 += p[(size_t)(b + 768) * stride];
+  }
+  for (; b < nblocks; b += 256) v0 += p[(size_t)b * stride];
+  double v = block_sum<256>((v0 + v1) + (v2 + v3), lds);
   if (threadIdx.x == 0) out[o] = v;
 }
 

@@ -457,17 +457,17 @@ __global__ __launch_bounds__(NT) void k_wgram(const float* __restrict__ W, int64
 extern "C" {
 
 int trk_dot(const float* x, const float* y, int64_t n, double* out, trk_stream st) {
-  TRK_REQUIRE(x && y && out && n >= 0, "trk_dot: NULL argument or n < 0");
+  TRK_REQUIRE(out && n >= 0 && ((x && y) || n == 0), "trk_dot: NULL argument or n < 0");
   return launch_reduce2<0>(x, y, n, out, (hipStream_t)st);
 }
 
 int trk_nrm2sq(const float* x, int64_t n, double* out, trk_stream st) {
-  TRK_REQUIRE(x && out && n >= 0, "trk_nrm2sq: NULL argument or n < 0");
+  TRK_REQUIRE(out && n >= 0 && (x || n == 0), "trk_nrm2sq: NULL argument or n < 0");
   return launch_reduce2<1>(x, x, n, out, (hipStream_t)st);
 }
 
 int trk_diff_nrm2sq(const float* x, const float* y, int64_t n, double* out, trk_stream st) {
-  TRK_REQUIRE(x && y && out && n >= 0, "trk_diff_nrm2sq: NULL argument or n < 0");
+  TRK_REQUIRE(out && n >= 0 && ((x && y) || n == 0), "trk_diff_nrm2sq: NULL argument or n < 0");
   return launch_reduce2<2>(x, y, n, out, (hipStream_t)st);
 }
 
