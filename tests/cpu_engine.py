@@ -1,0 +1,176 @@
+"""TEST-ONLY engine: the HipEngine interface re-implemented with NumPy / torch-CPU so that the solvers' HOST LOGIC
+(iteration structure, projected problems, lambda selection, info dictionaries, the distributed reduction points) can be
+exercised without a GPU (`-m "not gpu"`), including world_size-2 runs over gloo.
+
+It is never importable from the product (it lives under tests/), and it is not a fallback: trips_py_amd's default engine
+raises without a GPU.  Arithmetic mimics the device: fp32 vector storage, float64 reductions.  Operators are adapters
+over the oracle's operators (oracle/cpu_ref.py)."""
+import numpy as np
+import torch
+
+from trips_py_amd.engine import SQRT_DEN, SQRT_NUM, Coef
+from trips_py_amd.operators import LinearOperator
+
+
+class CpuScalars:
+    def __init__(self, n):
+        self.a = np.zeros(int(n), dtype=np.float64)
+
+    def ref(self, i):
+        return (self, int(i))
+
+    def view(self, i=0, j=None):
+        return torch.from_numpy(self.a)[i:j]      # shares memory: collectives act in place
+
+    def host(self, i=0, j=None):
+        return self.a[i:j].copy()
+
+    def set(self, i, values):
+        v = np.atleast_1d(np.asarray(values, dtype=np.float64))
+        self.a[i:i + v.size] = v
+
+    def __len__(self):
+        return self.a.size
+
+
+def _put(ref, vals):
+    s, i = ref
+    vals = np.atleast_1d(np.asarray(vals, dtype=np.float64))
+    s.a[i:i + vals.size] = vals
+
+
+def _get(ref, n=1):
+    s, i = ref
+    return s.a[i:i + n] if n > 1 else s.a[i]
+
+
+def _coef(c):
+    if not isinstance(c, Coef):
+        return float(c)
+    v = c.c
+    if c.num is not None:
+        t = _get(c.num)
+        v *= np.sqrt(t) if c.flags & SQRT_NUM else t
+    if c.den is not None:
+        t = _get(c.den)
+        v /= np.sqrt(t) if c.flags & SQRT_DEN else t
+    return float(v)
+
+
+def _d(t):
+    return t.detach().numpy().astype(np.float64)
+
+
+class CpuEngine:
+    is_native = False
+
+    def __init__(self, comm=None):
+        self.device = torch.device("cpu")
+        self.comm = comm
+        self.world = 1 if comm is None else comm.world
+        self.rank = 0 if comm is None else comm.rank
+
+    def empty(self, n):
+        return torch.zeros(int(n), dtype=torch.float32)
+
+    zeros = empty
+
+    def empty_basis(self, k, n):
+        return torch.zeros((int(k), int(n)), dtype=torch.float32)
+
+    def scalars(self, n):
+        return CpuScalars(n)
+
+    def to_vec(self, a, n=None):
+        t = a.detach().reshape(-1).to(torch.float32).clone() if isinstance(a, torch.Tensor) else \
+            torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=np.float32).reshape(-1)))
+        if n is not None and t.numel() != n:
+            raise ValueError(f"vector has {t.numel()} entries, expected {n}")
+        return t
+
+    def to_host(self, s):
+        return s.host() if isinstance(s, CpuScalars) else s.detach().numpy().astype(np.float64)
+
+    def synchronize(self):
+        pass
+
+    def allreduce(self, scal, i=0, j=None):
+        if self.comm is not None and self.world > 1:
+            self.comm.allreduce_sum_(scal.view(i, j))
+        return scal
+
+    # reductions
+    def dot(self, x, y, out):
+        _put(out, np.dot(_d(x), _d(y)))
+
+    def nrm2sq(self, x, out):
+        _put(out, np.dot(_d(x), _d(x)))
+
+    def diff_nrm2sq(self, x, y, out):
+        d = _d(x) - _d(y)
+        _put(out, np.dot(d, d))
+
+    # axpy family
+    def axpby(self, a, x, b, y, out, sumsq=None):
+        r = np.float32(_coef(a)) * x.numpy()
+        if y is not None:
+            r = r + np.float32(_coef(b)) * y.numpy()
+        out.copy_(torch.from_numpy(np.asarray(r, dtype=np.float32)))
+        if sumsq is not None:
+            _put(sumsq, np.dot(_d(out), _d(out)))
+
+    def scale(self, a, x, out, sumsq=None):
+        self.axpby(a, x, 0.0, None, out, sumsq)
+
+    def mul(self, x, y, out):
+        out.copy_(x * y)
+
+    def mm_weights(self, x, y, eps, p, out):
+        v = _d(x) - (0 if y is None else _d(y))
+        out.copy_(torch.from_numpy(((v ** 2 + eps ** 2) ** (p / 2 - 1)).astype(np.float32)))
+
+    def cgls_update(self, gamma, delta, x, p, x_new, r, w, x_true, sums):
+        step = np.float32(_get(gamma) / _get(delta))
+        d = step * p.numpy()
+        xn = x.numpy() + d
+        x_new.copy_(torch.from_numpy(xn))
+        r.copy_(torch.from_numpy(r.numpy() - step * w.numpy()))
+        xn64 = xn.astype(np.float64)
+        e = 0.0 if x_true is None else np.sum((xn64 - _d(x_true)) ** 2)
+        _put(sums, [np.dot(xn64, xn64), np.dot(d.astype(np.float64), d.astype(np.float64)), e])
+
+    # tall-skinny
+    def gemv_t(self, V, k, r, out_h, w2=None):
+        rr = _d(r) if w2 is None else (r.numpy() * w2.numpy()).astype(np.float64)
+        _put(out_h, _d(V[:k]) @ rr)
+
+    def gemv_n(self, V, k, y, out, a=0.0, base=None, s=1.0, sumsq=None):
+        o = s * (np.asarray(_get(y, k)).reshape(-1) @ _d(V[:k]))
+        if base is not None:
+            o = o + a * _d(base)
+        out.copy_(torch.from_numpy(o.astype(np.float32)))
+        if sumsq is not None:
+            _put(sumsq, np.dot(_d(out), _d(out)))
+
+    def wgram(self, W, k, w, b1, G, c1=None, c2=None):
+        Wk = _d(W[:k])
+        ww = np.ones(Wk.shape[1]) if w is None else _d(w)
+        _put(G, ((Wk * ww ** 2) @ Wk.T).reshape(-1))
+        if b1 is not None:
+            _put(c1, Wk @ (ww * _d(b1)))
+            _put(c2, Wk @ (ww ** 2 * _d(b1)))
+
+
+class OracleOp(LinearOperator):
+    """Adapter: an oracle operator behind the engine-native `apply()` protocol (torch CPU fp32 in / out)."""
+
+    def __init__(self, oracle_op, engine):
+        self.o = oracle_op
+        super().__init__(oracle_op.shape, engine)
+
+    def _apply(self, x2, y2, transpose, sumsq):
+        fn = self.o._adj if transpose else self.o._fwd
+        for b in range(x2.shape[0]):
+            y2[b].copy_(torch.from_numpy(fn(x2[b].numpy().astype(np.float64)).astype(np.float32)))
+        if sumsq is not None:
+            _put(sumsq, float((y2.double() ** 2).sum()))

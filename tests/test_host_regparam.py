@@ -1,0 +1,49 @@
+"""Host-side (product) regularisation-parameter selectors against the reference's own values (tests/golden/regparam_fn.npz).
+These take only k-sized inputs; the m-length contractions they replace are fed here from NumPy."""
+import numpy as np
+import scipy.linalg as sla
+
+from conftest import load_golden
+from trips_py_amd.reg_param import (discrepancy_principle, gcv_function, generalized_crossvalidation, l_curve,
+                                    l_curve_curvature)
+
+
+def test_gcv_dp_lcurve_on_reduced_inputs():
+    g = load_golden("regparam_fn")
+    Q_A, R_A, R_L, b = g["Q_A"], g["R_A"], g["R_L"], g["b"]
+    rhs = (Q_A.T @ b).reshape(-1)
+    resid2 = float(np.linalg.norm(b) ** 2 - np.linalg.norm(rhs) ** 2)
+    for i, lam in enumerate(g["lams"]):
+        assert np.isclose(gcv_function(lam, R_A, R_L, rhs), g["gcv_num"][i] / g["gcv_den"][i], rtol=1e-9)
+        assert np.isclose(l_curve_curvature(lam, R_A, R_L, rhs), g["curvature"][i], rtol=1e-6)
+    assert np.isclose(generalized_crossvalidation(R_A, R_L, rhs), float(g["lam_gcv"]), rtol=1e-6)
+    assert np.isclose(discrepancy_principle(R_A, R_L, rhs, resid2, delta=float(g["delta"])), float(g["lam_dp"]), rtol=1e-8)
+    assert np.isclose(discrepancy_principle(R_A, R_L, rhs, resid2, delta=float(g["delta"]), eta=1.2), float(g["lam_dp_eta12"]), rtol=1e-8)
+    assert np.isclose(l_curve(R_A, R_L, rhs), float(g["lam_lcurve"]), rtol=1e-5)
+
+
+def test_same_answers_from_gram_cholesky_factors():
+    """What the engine feeds: R = chol(Gram) instead of Householder-QR factors (signs / rotations differ, values must not)."""
+    g = load_golden("regparam_fn")
+    AV, LV, b = g["AV"], g["LV"], g["b"]
+    R_A = sla.cholesky(AV.T @ AV)
+    R_L = sla.cholesky(LV.T @ LV)
+    rhs = sla.solve_triangular(R_A, AV.T @ b, trans="T").reshape(-1)
+    resid2 = float(np.linalg.norm(b) ** 2 - np.linalg.norm(rhs) ** 2)
+    assert np.isclose(generalized_crossvalidation(R_A, R_L, rhs), float(g["lam_gcv"]), rtol=1e-5)
+    assert np.isclose(discrepancy_principle(R_A, R_L, rhs, resid2, delta=float(g["delta"])), float(g["lam_dp"]), rtol=1e-7)
+    for i, lam in enumerate(g["lams"]):
+        assert np.isclose(gcv_function(lam, R_A, R_L, rhs), g["gcv_num"][i] / g["gcv_den"][i], rtol=1e-7)
+
+
+def test_hybrid_modified_gcv():
+    g = load_golden("regparam_fn")
+    B, bhat, m = g["B"], g["bhat"], int(g["fullsize"])
+    Qb, s, _ = sla.svd(B, full_matrices=False)
+    k = B.shape[1]
+    rhs = Qb.T @ bhat
+    # the reference's numerator is ALWAYS the standard one (kwargs are not forwarded, gcv.py:94)
+    std_num = np.array([np.linalg.norm(np.diag(s) @ sla.solve(np.diag(s ** 2) + l * np.eye(k), np.diag(s) @ rhs) - rhs) ** 2 for l in g["lams"]])
+    for i, lam in enumerate(g["lams"]):
+        assert np.isclose(gcv_function(lam, np.diag(s), np.eye(k), rhs, "modified", m), std_num[i] / g["gcv_den_mod"][i], rtol=1e-9)
+    assert np.isclose(generalized_crossvalidation(np.diag(s), np.eye(k), rhs, "modified", m), float(g["lam_gcv_mod"]), rtol=1e-6)

@@ -37,6 +37,8 @@ class Formatter:
 
 def history_fits(engine, count, n, what):
     """Refuse (loudly) an on-device history that cannot fit; the reference keeps every iterate (CGLS.py:66)."""
+    if engine.device.type != "cuda":
+        return
     need = int(count) * int(n) * 4
     free, _total = torch.cuda.mem_get_info(engine.device)
     if need > 0.8 * free:

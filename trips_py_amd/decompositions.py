@@ -1,0 +1,134 @@
+"""Krylov factorisations with the reference's names and return shapes (trips/utilities/decompositions.py:20-255),
+computed by the engine (trips_py_amd/krylov.py).
+
+    golub_kahan(A, b, n_iter)        -> (U  m x (n_iter+1),  S  (n_iter+1) x n_iter,  V  n x n_iter)      (:118-205)
+    arnoldi(A, b, n_iter)            -> (Q  n x (n_iter+1),  H  (n_iter+1) x n_iter)                       (:20-116)
+    golub_kahan_update(A, U, S, V)   -> one more GK step                                                    (:230-255)
+    arnoldi_update(A, V, H)          -> one more Arnoldi step                                               (:207-228)
+
+The `*_update` functions accept either the reference's arrays (NumPy, n x k) — then the bases are uploaded, one step is
+taken and NumPy arrays come back, O(k n) traffic like the reference's own hstack — or the handles they returned the
+previous time (`KrylovArrays`), in which case the bases stay on the GPU and the step costs two operator applies.
+"""
+import numpy as np
+import torch
+
+from ._io import as_operator
+from .engine import Coef
+from .krylov import ArnoldiState, DeviceBasis, GKState, orthogonalize
+
+
+def _fmt_like(b):
+    return not isinstance(b, torch.Tensor)
+
+
+def golub_kahan(A, b, n_iter, dp_stop=False, **kwargs):
+    if dp_stop:
+        raise NotImplementedError("golub_kahan(dp_stop=True) (decompositions.py:185-195) is not implemented on the engine yet")
+    A = as_operator(A)
+    gk = GKState(A, b, int(n_iter))
+    for _ in range(int(n_iter)):
+        gk.step()
+    if _fmt_like(b):
+        return gk.U.numpy(), gk.B(), gk.V.numpy()
+    return gk.U.torch_cols(), gk.B(), gk.V.torch_cols()
+
+
+def arnoldi(A, b, n_iter, dp_stop=False, **kwargs):
+    """NOTE the reference's arnoldi (unlike arnoldi_update) orthogonalises step ii only against Q[:, :ii] — the newest
+    vector Q[:, ii] is skipped and H[ii, ii] stays 0 (decompositions.py:88-94, `range(0, iterations)`).  Reproduced."""
+    if dp_stop:
+        raise NotImplementedError("arnoldi(dp_stop=True) (decompositions.py:104-112) is not implemented on the engine yet")
+    A = as_operator(A)
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Arnoldi can not be used. The operator is not square")
+    eng, n, n_iter = A.engine, A.shape[0], int(n_iter)
+    Q = DeviceBasis(eng, n, n_iter + 1)
+    S = eng.scalars(2 * n_iter + 2)
+    H = np.zeros((n_iter + 1, n_iter))
+    bv = eng.to_vec(b, n)
+    eng.nrm2sq(bv, S.ref(0))
+    eng.allreduce(S, 0, 1)
+    eng.scale(Coef(1.0, den=S.ref(0), sqrt_den=True), bv, Q.next_slot())
+    Q.commit()
+    w = eng.empty(n)
+    for ii in range(n_iter):
+        A.apply(Q[ii], out=w)
+        # literal modified Gram-Schmidt against Q[:, :ii] only: with the newest vector skipped the basis is not
+        # orthonormal, so block (classical) Gram-Schmidt would NOT give the same numbers
+        for jj in range(ii):
+            eng.dot(Q[jj], w, S.ref(1 + jj))
+            eng.allreduce(S, 1 + jj, 2 + jj)
+            eng.axpby(1.0, w, Coef(-1.0, num=S.ref(1 + jj)), Q[jj], w)
+        eng.nrm2sq(w, S.ref(0))
+        eng.allreduce(S, 0, 1)
+        h = S.host(0, 1 + ii)
+        H[:ii, ii] = h[1:1 + ii]
+        H[ii + 1, ii] = np.sqrt(h[0])
+        if H[ii + 1, ii] == 0:
+            break
+        eng.scale(Coef(1.0, den=S.ref(0), sqrt_den=True), w, Q.next_slot())
+        Q.commit()
+    k = Q.k
+    Hh = H[:k, :k - 1] if k < n_iter + 1 else H
+    return (Q.numpy() if _fmt_like(b) else Q.torch_cols()), Hh
+
+
+class KrylovArrays(np.ndarray):
+    """A NumPy array (the reference's n x k layout) that remembers the device state it was downloaded from, so that a
+    chain of *_update calls keeps working on the GPU."""
+
+    def __new__(cls, arr, state):
+        obj = np.asarray(arr).view(cls)
+        obj._trk_state = state
+        return obj
+
+    def __array_finalize__(self, obj):
+        self._trk_state = getattr(obj, "_trk_state", None)
+
+
+def golub_kahan_update(A, U, S, V):
+    A = as_operator(A)
+    st = getattr(U, "_trk_state", None)
+    if not isinstance(st, GKState) or st.A is not A or st.V.k != (0 if np.ndim(S) < 2 else np.shape(S)[1]):
+        # cold start from the reference's arrays: upload what the step needs (U[:, -1], V[:, -1], last beta)
+        U = np.asarray(U, dtype=np.float64)
+        k = 0 if np.ndim(S) < 2 else np.shape(S)[1]
+        st = GKState.__new__(GKState)
+        st.A, st.eng = A, A.engine
+        eng = A.engine
+        m, n = A.shape
+        st.U, st.V = DeviceBasis(eng, m, k + 2), DeviceBasis(eng, n, k + 1)
+        for j in range(U.shape[1]):
+            st.U.next_slot().copy_(eng.to_vec(U[:, j], m))
+            st.U.commit()
+        for j in range(k):
+            st.V.next_slot().copy_(eng.to_vec(np.asarray(V)[:, j], n))
+            st.V.commit()
+        st.tmp_n, st.tmp_m, st.S = eng.empty(n), eng.empty(m), eng.scalars(4)
+        Sm = np.asarray(S, dtype=np.float64)
+        st.alphas = [] if k == 0 else list(np.diag(Sm[:k, :k]))
+        st.betas = [] if k == 0 else list(np.diag(Sm[1:, :k]))
+        st.beta0 = None
+    st.step()
+    return KrylovArrays(st.U.numpy(), st), st.B(), KrylovArrays(st.V.numpy(), st)
+
+
+def arnoldi_update(A, V, H):
+    A = as_operator(A)
+    st = getattr(V, "_trk_state", None)
+    if not isinstance(st, ArnoldiState) or st.A is not A or st.V.k != np.shape(V)[1]:
+        Vn = np.asarray(V, dtype=np.float64)
+        st = ArnoldiState.__new__(ArnoldiState)
+        st.A, st.eng = A, A.engine
+        eng, n = A.engine, A.shape[0]
+        st.V = DeviceBasis(eng, n, Vn.shape[1] + 1)
+        for j in range(Vn.shape[1]):
+            st.V.next_slot().copy_(eng.to_vec(Vn[:, j], n))
+            st.V.commit()
+        st.w, st.S = eng.empty(n), eng.scalars(2 * (Vn.shape[1] + 1) + 2)
+        Hm = np.asarray(H, dtype=np.float64)
+        st.Hcols = [] if Hm.ndim < 2 else [Hm[:j + 2, j].copy() for j in range(Hm.shape[1])]
+        st.beta0 = None
+    st.step()
+    return KrylovArrays(st.V.numpy(), st), st.H()

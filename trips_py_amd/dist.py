@@ -1,0 +1,47 @@
+"""Multi-GPU plumbing: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI on ROCm; "gloo" in the
+CPU tests).  The hot path has exactly two kinds of exchange when a dynamic problem is sharded by time frames:
+
+  * all-reduce(sum) of a handful of float64 scalars (inner products, Gram rows): latency-bound, so reductions of one
+    synchronisation point share one call;
+  * a one-frame halo shift between time-neighbours for the temporal rows of the space-time regulariser.
+
+Everything else (operator applies, axpys, weights) is local to a rank's frames.
+"""
+import torch
+import torch.distributed as dist
+
+
+class TorchComm:
+    def __init__(self, group=None):
+        if not dist.is_initialized():
+            raise RuntimeError("torch.distributed is not initialised")
+        self.group = group
+        self.world = dist.get_world_size(group)
+        self.rank = dist.get_rank(group)
+
+    def allreduce_sum_(self, t):
+        """In-place sum over ranks of a float64 tensor (device tensor under nccl, CPU tensor under gloo)."""
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        return t
+
+    def shift(self, send, send_to, recv, recv_from):
+        """Send `send` to rank `send_to` and receive into `recv` from rank `recv_from` (either side may be None)."""
+        ops = []
+        if send is not None and 0 <= send_to < self.world:
+            ops.append(dist.P2POp(dist.isend, send.contiguous(), send_to, self.group))
+        if recv is not None and recv_from is not None and 0 <= recv_from < self.world:
+            ops.append(dist.P2POp(dist.irecv, recv, recv_from, self.group))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+
+def frame_range(n_frames, world, rank):
+    """Frames [lo, hi) owned by `rank` (contiguous, frame-major layout of x and b: io.py:223-225)."""
+    if n_frames % world:
+        raise ValueError(f"{n_frames} frames do not shard evenly over {world} ranks")
+    per = n_frames // world
+    return rank * per, (rank + 1) * per

@@ -40,7 +40,47 @@ def _ptr(t):
         return None
     if isinstance(t, int):
         return t
-    return t.data_ptr()
+    if hasattr(t, "data_ptr"):
+        return t.data_ptr()
+    return t          # an opaque scalar reference of another engine implementation
+
+
+class DevScalars:
+    """A block of float64 device scalars.  `ref(i)` is the opaque handle kernels take for scalar i (here: its device
+    address as a plain int, so the hot loops create no tensor views); `view(i, j)` is a tensor view for collectives
+    and downloads."""
+
+    __slots__ = ("t", "base")
+
+    def __init__(self, t):
+        self.t = t
+        self.base = t.data_ptr()
+
+    def ref(self, i):
+        return self.base + 8 * i
+
+    def view(self, i=0, j=None):
+        return self.t[i:j]
+
+    def host(self, i=0, j=None):
+        return self.t[i:j].detach().to("cpu").numpy().astype(np.float64, copy=False)
+
+    def set(self, i, values):
+        v = torch.as_tensor(np.atleast_1d(np.asarray(values, dtype=np.float64)))
+        self.t[i:i + v.numel()].copy_(v, non_blocking=False)
+
+    def __len__(self):
+        return self.t.numel()
+
+    # tensor-like conveniences used by tests
+    def __getitem__(self, k):
+        return self.t[k]
+
+    def __setitem__(self, k, v):
+        self.t[k] = v
+
+    def data_ptr(self):
+        return self.base
 
 
 def _as_coef(a):
@@ -74,7 +114,7 @@ class HipEngine:
         return torch.empty((int(k), int(n)), dtype=torch.float32, device=self.device)
 
     def scalars(self, n):
-        return torch.zeros(int(n), dtype=torch.float64, device=self.device)
+        return DevScalars(torch.zeros(int(n), dtype=torch.float64, device=self.device))
 
     def to_vec(self, a, n=None):
         """numpy / torch, shape (n,), (n,1) -> contiguous fp32 device vector (a copy unless already one)."""
@@ -88,6 +128,8 @@ class HipEngine:
 
     def to_host(self, t):
         """Device doubles -> numpy float64 (synchronises the current stream)."""
+        if isinstance(t, DevScalars):
+            return t.host()
         return t.detach().to("cpu").numpy().astype(np.float64, copy=False)
 
     def stream(self):
@@ -97,10 +139,11 @@ class HipEngine:
         torch.cuda.current_stream(self.device).synchronize()
 
     # ------------------------------------------------------------------ collectives
-    def allreduce(self, scal):
-        """Sum a (view of a) float64 device tensor over all ranks, in place.  No-op for a single rank."""
+    def allreduce(self, scal, i=0, j=None):
+        """Sum scalars [i, j) of a DevScalars block (or a float64 tensor view) over all ranks, in place.
+        No-op for a single rank."""
         if self.comm is not None and self.world > 1:
-            self.comm.allreduce_sum_(scal)
+            self.comm.allreduce_sum_(scal.view(i, j) if isinstance(scal, DevScalars) else scal)
         return scal
 
     # ------------------------------------------------------------------ operators

@@ -1,0 +1,173 @@
+"""Engine-level Krylov building blocks: a growable row-per-vector device basis and the Golub-Kahan / Arnoldi steps
+(reference: trips/utilities/decompositions.py:207-255) expressed in libtrk kernels.
+
+Scalars produced by a step (alpha^2, beta^2, the Gram-Schmidt coefficients) stay in device doubles and are consumed by
+the next kernel through device-evaluated coefficients; the host reads them once per step (it needs them for the
+projected problem anyway).  Sharded problems all-reduce the same doubles (`engine.allreduce`).
+"""
+import numpy as np
+import torch
+
+from .engine import Coef
+
+
+class DeviceBasis:
+    """k vectors of length n stored row-per-vector in one [capacity, n] fp32 device tensor.
+
+    Appending is a write into the next row (the reference re-copies the whole basis with hstack / column_stack / pad at
+    every step: decompositions.py:172-175,243-254; GKS.py:91-96).  `.shape` is the reference's (n, k)."""
+
+    def __init__(self, engine, n, capacity):
+        self.engine, self.n = engine, int(n)
+        self.data = engine.empty_basis(max(1, int(capacity)), n)
+        self.k = 0
+
+    @property
+    def shape(self):
+        return (self.n, self.k)
+
+    def reserve(self, capacity):
+        if capacity > self.data.shape[0]:
+            new = self.engine.empty_basis(max(capacity, 2 * self.data.shape[0]), self.n)
+            new[:self.k].copy_(self.data[:self.k])
+            self.data = new
+
+    def next_slot(self):
+        """The row the next vector will be written into (not yet counted)."""
+        self.reserve(self.k + 1)
+        return self.data[self.k]
+
+    def commit(self):
+        self.k += 1
+
+    def __getitem__(self, j):
+        if j < 0:
+            j += self.k
+        if not 0 <= j < self.k:
+            raise IndexError(j)
+        return self.data[j]
+
+    def rows(self, k=None):
+        return self.data[:self.k if k is None else k]
+
+    def numpy(self, k=None):
+        """(n, k) float64 array, the reference's layout."""
+        return self.rows(k).detach().to("cpu").numpy().astype(np.float64).T.copy()
+
+    def torch_cols(self, k=None):
+        return self.rows(k).T
+
+
+# --------------------------------------------------------------------------------------------------------------------
+class GKState:
+    """Golub-Kahan bidiagonalisation A V_k = U_{k+1} B_k, one step at a time (decompositions.py:230-255, no
+    reorthogonalisation).  `alphas`, `betas` live on the host (float64); U, V on the device."""
+
+    def __init__(self, A, b, capacity):
+        self.A, self.eng = A, A.engine
+        m, n = A.shape
+        eng = self.eng
+        self.U = DeviceBasis(eng, m, capacity + 1)
+        self.V = DeviceBasis(eng, n, capacity)
+        self.tmp_n, self.tmp_m = eng.empty(n), eng.empty(m)
+        self.S = eng.scalars(4)
+        self.alphas, self.betas = [], []
+        bv = eng.to_vec(b, m)
+        eng.nrm2sq(bv, self.S.ref(0))
+        eng.allreduce(self.S, 0, 1)
+        eng.scale(Coef(1.0, den=self.S.ref(0), sqrt_den=True), bv, self.U.next_slot())
+        self.U.commit()
+        self.beta0 = float(np.sqrt(self.S.host(0, 1)[0]))
+
+    def step(self):
+        A, eng, S = self.A, self.eng, self.S
+        k = self.V.k
+        u = self.U[k]
+        a2, b2 = S.ref(1), S.ref(2)
+        # v = A^T u_k - beta_{k-1} v_{k-1} ; alpha = ||v||
+        if k == 0:
+            A.apply(u, out=self.tmp_n, transpose=True, sumsq=a2)
+        else:
+            A.apply(u, out=self.tmp_n, transpose=True)
+            eng.axpby(1.0, self.tmp_n, -self.betas[-1], self.V[k - 1], self.tmp_n, sumsq=a2)
+        eng.allreduce(S, 1, 2)
+        v = self.V.next_slot()
+        eng.scale(Coef(1.0, den=a2, sqrt_den=True), self.tmp_n, v)
+        self.V.commit()
+        # u' = A v_k - alpha u_k ; beta = ||u'||
+        A.apply(v, out=self.tmp_m)
+        eng.axpby(1.0, self.tmp_m, Coef(-1.0, num=a2, sqrt_num=True), u, self.tmp_m, sumsq=b2)
+        eng.allreduce(S, 2, 3)
+        eng.scale(Coef(1.0, den=b2, sqrt_den=True), self.tmp_m, self.U.next_slot())
+        self.U.commit()
+        h = S.host(1, 3)
+        alpha, beta = float(np.sqrt(h[0])), float(np.sqrt(h[1]))
+        self.alphas.append(alpha)
+        self.betas.append(beta)
+        return alpha, beta
+
+    def B(self):
+        """(k+1) x k lower-bidiagonal projected matrix."""
+        k = len(self.alphas)
+        B = np.zeros((k + 1, k))
+        B[np.arange(k), np.arange(k)] = self.alphas
+        B[np.arange(1, k + 1), np.arange(k)] = self.betas
+        return B
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def orthogonalize(eng, V, k, w, H, off, passes=2):
+    """w <- w - V_k (V_k^T w), `passes` times (block classical Gram-Schmidt; GKS.py:86-88 uses 3 passes, MMGKS.py:119-120
+    two; for Arnoldi two passes of CGS match the reference's modified Gram-Schmidt to rounding).
+    Pass p leaves its k coefficients in H[off + p*k : off + (p+1)*k] (device doubles, all-reduced)."""
+    for p in range(passes):
+        lo = off + p * k
+        eng.gemv_t(V.data, k, w, H.ref(lo))
+        eng.allreduce(H, lo, lo + k)
+        eng.gemv_n(V.data, k, H.ref(lo), w, a=1.0, base=w, s=-1.0)
+
+
+class ArnoldiState:
+    """Arnoldi A V_k = V_{k+1} H_k (decompositions.py:207-228): orthogonalisation against ALL previous vectors."""
+
+    def __init__(self, A, b, capacity):
+        self.A, self.eng = A, A.engine
+        m, n = A.shape
+        if m != n:
+            raise ValueError("Arnoldi can not be used. The operator is not square")
+        eng = self.eng
+        self.V = DeviceBasis(eng, n, capacity + 1)
+        self.w = eng.empty(n)
+        self.S = eng.scalars(2 * (capacity + 1) + 2)
+        self.Hcols = []
+        bv = eng.to_vec(b, n)
+        eng.nrm2sq(bv, self.S.ref(0))
+        eng.allreduce(self.S, 0, 1)
+        eng.scale(Coef(1.0, den=self.S.ref(0), sqrt_den=True), bv, self.V.next_slot())
+        self.V.commit()
+        self.beta0 = float(np.sqrt(self.S.host(0, 1)[0]))
+
+    def step(self):
+        A, eng, S, V = self.A, self.eng, self.S, self.V
+        k = V.k
+        if len(S) < 2 * k + 2:
+            self.S = S = eng.scalars(4 * k + 2)
+        A.apply(V[k - 1], out=self.w)
+        orthogonalize(eng, V, k, self.w, S, 1, passes=2)
+        eng.nrm2sq(self.w, S.ref(0))
+        eng.allreduce(S, 0, 1)
+        eng.scale(Coef(1.0, den=S.ref(0), sqrt_den=True), self.w, V.next_slot())
+        V.commit()
+        h = S.host(0, 1 + 2 * k)
+        col = np.zeros(k + 1)
+        col[:k] = h[1:1 + k] + h[1 + k:1 + 2 * k]
+        col[k] = np.sqrt(h[0])
+        self.Hcols.append(col)
+        return col
+
+    def H(self):
+        k = len(self.Hcols)
+        H = np.zeros((k + 1, k))
+        for j, c in enumerate(self.Hcols):
+            H[:j + 2, j] = c
+        return H

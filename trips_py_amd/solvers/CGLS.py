@@ -34,15 +34,14 @@ class CGLSRun:
             self.X = eng.empty_basis(2, n)
         self.r, self.t, self.w, self.p = eng.empty(m), eng.empty(n), eng.empty(m), eng.empty(n)
         # scalar layout: S[0] = gamma_0 = ||t_0||^2 ; row k (1-based) at 5k: [delta, gamma, ||x||^2, ||dx||^2, ||x-xt||^2]
-        self.S = eng.scalars(5 * (max_iter + 1))
-        self.S0 = self.S.data_ptr()        # device-scalar addresses as plain ints: no tensor views in the hot loop
+        self.S = S = eng.scalars(5 * (max_iter + 1))
         self.dist = eng.world > 1
         self.k = 0
         # r = b - A x0 ; t = A^T r ; p = t                                                (CGLS.py:45-47)
         A.apply(x_start, out=self.r)
         eng.axpby(1.0, self.bv, -1.0, self.r, self.r)
-        A.apply(self.r, out=self.t, transpose=True, sumsq=self.S0)
-        eng.allreduce(self.S[0:1])
+        A.apply(self.r, out=self.t, transpose=True, sumsq=S.ref(0))
+        eng.allreduce(S, 0, 1)
         self.p.copy_(self.t)
         self.x_cur = x_start
 
@@ -53,25 +52,26 @@ class CGLSRun:
         eng, A, S = self.eng, self.A, self.S
         self.k += 1
         k = self.k
-        base = self.S0 + 40 * k            # row k: delta, gamma, ||x||^2, ||dx||^2, ||x-xt||^2
-        gamma_old = self.S0 if k == 1 else base - 32
+        b = 5 * k                          # row k: delta, gamma, ||x||^2, ||dx||^2, ||x-xt||^2
+        delta, gamma = S.ref(b), S.ref(b + 1)
+        gamma_old = S.ref(0) if k == 1 else S.ref(b - 4)
         x_new = self.slot(k - 1)
-        A.apply(self.p, out=self.w, sumsq=base)
+        A.apply(self.p, out=self.w, sumsq=delta)
         if self.dist:
-            eng.allreduce(S[5 * k:5 * k + 1])
-        eng.cgls_update(gamma_old, base, self.x_cur, self.p, x_new, self.r, self.w, self.xt, base + 16)
-        A.apply(self.r, out=self.t, transpose=True, sumsq=base + 8)
+            eng.allreduce(S, b, b + 1)
+        eng.cgls_update(gamma_old, delta, self.x_cur, self.p, x_new, self.r, self.w, self.xt, S.ref(b + 2))
+        A.apply(self.r, out=self.t, transpose=True, sumsq=gamma)
         if self.dist:
-            eng.allreduce(S[5 * k + 1:5 * k + 5])
-        eng.axpby(1.0, self.t, Coef(1.0, num=base + 8, den=gamma_old), self.p, self.p)
+            eng.allreduce(S, b + 1, b + 5)
+        eng.axpby(1.0, self.t, Coef(1.0, num=gamma, den=gamma_old), self.p, self.p)
         self.x_cur = x_new
 
     def row(self, k):
         """[delta, gamma, ||x||^2, ||dx||^2, ||x-xt||^2] of iteration k (host sync)."""
-        return self.eng.to_host(self.S[5 * k:5 * k + 5])
+        return self.S.host(5 * k, 5 * k + 5)
 
     def rows(self):
-        Sh = self.eng.to_host(self.S)
+        Sh = self.S.host()
         return Sh[0], Sh[5:5 * (self.k + 1)].reshape(self.k, 5)
 
 
@@ -94,7 +94,7 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
         run.step()
         if sync_each:
             if nt0 is None:
-                nt0 = float(np.sqrt(run.eng.to_host(run.S[0:1])[0]))
+                nt0 = float(np.sqrt(run.S.host(0, 1)[0]))
             h = run.row(run.k)
             stop = (np.sqrt(h[1]) <= nt0 * tol) or (np.sqrt(h[2]) * tol >= 1)            # (:73-75)
     _g0, rows = run.rows()

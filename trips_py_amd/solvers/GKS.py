@@ -1,0 +1,129 @@
+"""Generalized Krylov Subspace method on the HIP engine — signature and `info` of trips/solvers/GKS.py:27-105.
+
+    min ||A x - b||^2 + lambda ||L x||^2   over   x in span(V_k),   V grown by the normalised normal-equation residual.
+
+What moved where
+  * V, AV = A V, LV = L V live on the GPU as row-per-vector bases; a new column is a write (GKS.py:91-96 re-copies all).
+  * The from-scratch economic QRs of AV and LV (:54-56) are replaced by their Gram matrices, kept INCREMENTALLY:
+    one tall-skinny GEMV-T per new column (k+1 fp64-accumulated dots), then R = chol(G) on the host (k x k).
+    Q_A^T b = R_A^{-T} (AV)^T b, ||b - Q_A Q_A^T b||^2 = ||b||^2 - ||Q_A^T b||^2.
+  * residual r = A^T(AV y - b) + lambda L^T(LV y) and its 3 re-orthogonalisation passes (:81-88) run on the device with
+    device-resident coefficients; the host sees k-sized data only.
+"""
+import numpy as np
+
+from .._io import Formatter, as_operator, history_fits
+from ..engine import Coef
+from ..krylov import DeviceBasis, GKState, orthogonalize
+from ..operators import is_identity
+from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq
+
+
+class _ProjectedBases:
+    """V, AV, LV and the incrementally maintained Gram data  G_A = AV AV^T, G_L = LV LV^T, c = AV b."""
+
+    def __init__(self, A, L, bv, V0, kmax):
+        self.A, self.L, self.eng, self.bv = A, L, A.engine, bv
+        eng = self.eng
+        m, n = A.shape
+        p = L.shape[0]
+        self.V = V0
+        self.V.reserve(kmax)
+        self.AV = DeviceBasis(eng, m, kmax)
+        self.LV = DeviceBasis(eng, p, kmax)
+        self.GA = np.zeros((kmax, kmax))
+        self.GL = np.zeros((kmax, kmax))
+        self.c = np.zeros(kmax)
+        self.S = eng.scalars(2 * kmax + 2)
+        for j in range(V0.k):
+            self._push_images(j)
+
+    def _push_images(self, j):
+        """AV[j] = A V[j], LV[j] = L V[j], and row/column j of the Gram data (k+1 dots each, one pass over the basis)."""
+        eng, S = self.eng, self.S
+        av, lv = self.AV.next_slot(), self.LV.next_slot()
+        self.A.apply(self.V[j], out=av)
+        self.L.apply(self.V[j], out=lv)
+        self.AV.commit()
+        self.LV.commit()
+        k = j + 1
+        eng.gemv_t(self.AV.data, k, av, S.ref(0))
+        eng.gemv_t(self.LV.data, k, lv, S.ref(k))
+        eng.dot(av, self.bv, S.ref(2 * k))
+        eng.allreduce(S, 0, 2 * k + 1)
+        h = S.host(0, 2 * k + 1)
+        self.GA[j, :k] = self.GA[:k, j] = h[:k]
+        self.GL[j, :k] = self.GL[:k, j] = h[k:2 * k]
+        self.c[j] = h[2 * k]
+
+    def append(self):
+        """The caller has written the new basis vector into V.next_slot() and committed it."""
+        self._push_images(self.V.k - 1)
+
+
+def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwargs):
+    """Returns (x, info); info keys xHistory, regParam, regParam_history, relError (if x_true), Residual, its (= n_iter-1).
+    Engine-only kwarg: history=True."""
+    A, L = as_operator(A), as_operator(L, "L")
+    check_delta(regparam, kwargs)
+    if is_identity(L):
+        raise NotImplementedError("GKS with L = Identity (the SVD branch, GKS.py:44-50) is not implemented on the engine")
+    eng = A.engine
+    m, n = A.shape
+    n_iter, d = int(n_iter), int(projection_dim)
+    keep = bool(kwargs.get("history", True))
+    fmt = Formatter(b)
+    bv = eng.to_vec(b, m)
+    xt = None if x_true is None else eng.to_vec(x_true, n)
+    kmax = d + n_iter
+
+    gk = GKState(A, bv, d)
+    for _ in range(d):
+        gk.step()
+    pb = _ProjectedBases(A, L, bv, gk.V, kmax)
+    if keep:
+        history_fits(eng, n_iter, n, "GKS xHistory")
+    X = eng.empty_basis(n_iter if keep else 1, n)
+    Y = eng.scalars(kmax)
+    H = eng.scalars(3 * kmax)
+    E = eng.scalars(n_iter + 3)             # E[0] = ||x_true||^2, E[1] = ||b||^2, E[2+i] = ||x_i - x_true||^2
+    R = eng.scalars(n_iter + 1)             # ||r_i||^2
+    tm, tp, r, rb = eng.empty(m), eng.empty(L.shape[0]), eng.empty(n), eng.empty(n)
+    eng.nrm2sq(bv, E.ref(1))
+    if xt is not None:
+        eng.nrm2sq(xt, E.ref(0))
+    eng.allreduce(E, 0, 2)
+    b2 = float(E.host(1, 2)[0])
+
+    lams, lam, x_dev = [], None, None
+    for ii in range(n_iter):
+        k = pb.V.k
+        R_A, R_L = gram_factor(pb.GA[:k, :k]), gram_factor(pb.GL[:k, :k])
+        rhs = project_rhs(R_A, pb.c[:k])
+        lam = choose_lambda(regparam, R_A, R_L, rhs, max(b2 - float(rhs @ rhs), 0.0), kwargs)
+        lams.append(lam)
+        y = tikhonov_lstsq(R_A, R_L, lam, rhs)
+        Y.set(0, y)
+        x_dev = X[ii] if keep else X[0]
+        eng.gemv_n(pb.V.data, k, Y.ref(0), x_dev)                                   # x = V y (:76)
+        if xt is not None:
+            eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
+        # r = A^T (AV y - b) + lam L^T (LV y)                                          (:81-85)
+        eng.gemv_n(pb.AV.data, k, Y.ref(0), tm, a=-1.0, base=bv, s=1.0)
+        A.apply(tm, out=r, transpose=True)
+        eng.gemv_n(pb.LV.data, k, Y.ref(0), tp)
+        L.apply(tp, out=rb, transpose=True)
+        eng.axpby(1.0, r, float(lam), rb, r)
+        orthogonalize(eng, pb.V, k, r, H, 0, passes=3)                               # (:86-88)
+        eng.nrm2sq(r, R.ref(ii))
+        eng.allreduce(R, ii, ii + 1)
+        eng.scale(Coef(1.0, den=R.ref(ii), sqrt_den=True), r, pb.V.next_slot())     # vn = r/||r|| (:89-91)
+        pb.V.commit()
+        pb.append()                                                                  # AV, LV, Gram rows (:92-96)
+    info = {"xHistory": fmt.hist(X, n_iter) if keep else [], "regParam": lam, "regParam_history": lams,
+            "Residual": list(np.sqrt(R.host(0, n_iter))), "its": n_iter - 1}
+    if xt is not None:
+        eng.allreduce(E, 2, 2 + n_iter)
+        e = E.host(0, 2 + n_iter)
+        info["relError"] = list(np.sqrt(e[2:] / e[0]))
+    return fmt.vec(x_dev), info

@@ -1,0 +1,75 @@
+"""Hybrid GMRES on the HIP engine — signature, iteration structure and `info` of trips/solvers/Hybrid_GMRES.py:23-87.
+
+Device: Arnoldi steps (1 operator apply + two passes of block Gram-Schmidt against the whole basis = 2 tall-skinny
+GEMV-T / GEMV-N pairs), x = V_k y.  Host: H_k, lambda selection, stacked Tikhonov solve."""
+import numpy as np
+import scipy.linalg as sla
+
+from .._io import Formatter, as_operator, history_fits
+from ..krylov import ArnoldiState
+from ._common import check_delta, choose_lambda, tikhonov_lstsq
+
+
+def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
+    """Returns (x, info); info keys: xHistory (n_iter iterates), regParam, regParam_history (first entry 0),
+    relError (if x_true), relResidual, its (= n_iter-1).  Engine-only kwarg: history=True."""
+    A = as_operator(A)
+    delta = check_delta(regparam, kwargs)
+    eng = A.engine
+    m, n = A.shape
+    if m != n:
+        raise Exception("Please check the size of the matrx A: it should be square in order to apply hybrid GMRES")
+    n_iter = int(n_iter)
+    keep = bool(kwargs.get("history", True))
+    fmt = Formatter(b)
+    xt = None if x_true is None else eng.to_vec(x_true, n)
+
+    ar = ArnoldiState(A, b, n_iter)
+    bv = eng.to_vec(b, m) if (isinstance(regparam, str) and regparam == "dp") else None
+    if keep:
+        history_fits(eng, n_iter, n, "Hybrid_GMRES xHistory")
+    X = eng.empty_basis(max(1, n_iter) if keep else 1, n)
+    Y = eng.scalars(max(1, n_iter))
+    E = eng.scalars(max(1, n_iter) + 1)
+    P = eng.scalars(n_iter + 2)
+    if xt is not None:
+        eng.nrm2sq(xt, E.ref(0))
+        eng.allreduce(E, 0, 1)
+
+    lams, res, lam, x_dev = [], [], 0, None
+    for ii in range(n_iter):
+        ar.step()
+        k = ii + 1
+        H = ar.H()
+        bhat = np.zeros(k + 1)
+        bhat[0] = ar.beta0
+        if ii == 0:
+            lam = 0
+        elif isinstance(regparam, str) and regparam in ("gcv", "l_curve"):
+            Qh, s, _ = sla.svd(H, full_matrices=False)
+            lam = choose_lambda(regparam, np.diag(s), np.eye(k), Qh.T @ bhat, 0.0, kwargs)   # 'standard' GCV here (:58)
+        elif isinstance(regparam, str) and regparam == "dp":
+            eng.gemv_t(ar.V.data, k + 1, bv, P.ref(0))
+            eng.allreduce(P, 0, k + 1)
+            lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=H, dp_bproj=P.host(0, k + 1))
+        else:
+            lam = regparam
+        lams.append(lam)
+        y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
+        Y.set(0, y)
+        x_dev = X[ii] if keep else X[0]
+        eng.gemv_n(ar.V.data, k, Y.ref(0), x_dev)                      # x = V[:, :-1] @ y (:77)
+        # reference quirk (:80): `bhat - H@y` broadcasts a (k+1,) against a (k+1,1) -> Frobenius norm of a matrix
+        hy = (H @ y).reshape(-1, 1)
+        res.append(float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
+        if xt is not None:
+            eng.diff_nrm2sq(x_dev, xt, E.ref(ii + 1))
+    if x_dev is None:
+        raise UnboundLocalError("Hybrid_GMRES with n_iter < 1 forms no iterate")
+    info = {"xHistory": fmt.hist(X, n_iter) if keep else [], "regParam": lam, "regParam_history": lams,
+            "relResidual": res, "its": n_iter - 1}
+    if xt is not None:
+        eng.allreduce(E, 1, n_iter + 1)
+        e = E.host(0, n_iter + 1)
+        info["relError"] = list(np.sqrt(e[1:] / e[0]))
+    return fmt.vec(x_dev), info

@@ -1,0 +1,76 @@
+"""Hybrid LSQR on the HIP engine — signature, iteration structure and `info` of trips/solvers/Hybrid_LSQR.py:25-114.
+
+Device: Golub-Kahan steps (2 operator applies + fused axpby/norm kernels), x = V y (one tall-skinny GEMV over the
+row-per-vector basis), ||x - x_true||.  Host (float64, k-sized): B_k, lambda selection, the stacked Tikhonov solve.
+"""
+import numpy as np
+import scipy.linalg as sla
+
+from .._io import Formatter, as_operator, history_fits
+from ..krylov import GKState
+from ._common import check_delta, choose_lambda, tikhonov_lstsq
+
+
+def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
+    """Returns (x, info); info keys: xHistory (n_iter-1 iterates: none is formed at the first step, :77-78), regParam,
+    regParam_history, relError (if x_true), relResidual (empty list, as in the reference), its (= n_iter-1).
+    Engine-only kwarg: history=True."""
+    A = as_operator(A)
+    delta = check_delta(regparam, kwargs)
+    eng = A.engine
+    m, n = A.shape
+    n_iter = int(n_iter)
+    keep = bool(kwargs.get("history", True))
+    fmt = Formatter(b)
+    xt = None if x_true is None else eng.to_vec(x_true, n)
+
+    gk = GKState(A, b, n_iter)
+    bv = eng.to_vec(b, m) if (isinstance(regparam, str) and regparam == "dp") else None
+    if keep:
+        history_fits(eng, n_iter, n, "Hybrid_LSQR xHistory")
+    X = eng.empty_basis(max(1, n_iter - 1) if keep else 1, n)
+    Y = eng.scalars(max(1, n_iter))          # projected solution, uploaded each iteration
+    E = eng.scalars(max(1, n_iter) + 1)      # E[0] = ||x_true||^2, E[i] = ||x_i - x_true||^2
+    P = eng.scalars(n_iter + 2)              # U^T b for the discrepancy principle
+    if xt is not None:
+        eng.nrm2sq(xt, E.ref(0))
+        eng.allreduce(E, 0, 1)
+
+    lams, lam, nx_done, x_dev = [], 0, 0, None
+    for ii in range(n_iter):
+        gk.step()
+        k = ii + 1
+        B = gk.B()
+        bhat = np.zeros(k + 1)
+        bhat[0] = gk.beta0
+        if ii == 0:
+            lam = 0
+            continue
+        if isinstance(regparam, str) and regparam in ("gcv", "l_curve"):
+            Qb, s, _ = sla.svd(B, full_matrices=False)
+            lam = choose_lambda(regparam, np.diag(s), np.eye(k), Qb.T @ bhat, 0.0, kwargs, variant="modified", fullsize=m)
+        elif isinstance(regparam, str) and regparam == "dp":
+            # discrepancy_principle(U, B, L, b): projects b on the (no longer exactly orthonormal) computed U (:86)
+            eng.gemv_t(gk.U.data, k + 1, bv, P.ref(0))
+            eng.allreduce(P, 0, k + 1)
+            lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=B, dp_bproj=P.host(0, k + 1))
+        else:
+            lam = regparam
+        lams.append(lam)
+        y = tikhonov_lstsq(B, np.eye(k), lam, bhat)
+        Y.set(0, y)
+        x_dev = X[nx_done] if keep else X[0]
+        eng.gemv_n(gk.V.data, k, Y.ref(0), x_dev)
+        nx_done += 1
+        if xt is not None:
+            eng.diff_nrm2sq(x_dev, xt, E.ref(nx_done))
+    if x_dev is None:
+        raise UnboundLocalError("Hybrid_LSQR with n_iter < 2 forms no iterate (the reference fails the same way, "
+                                "Hybrid_LSQR.py:114)")
+    info = {"xHistory": fmt.hist(X, nx_done) if keep else [], "regParam": lam, "regParam_history": lams,
+            "relResidual": [], "its": n_iter - 1}
+    if xt is not None:
+        eng.allreduce(E, 1, nx_done + 1)
+        e = E.host(0, nx_done + 1)
+        info["relError"] = list(np.sqrt(e[1:] / e[0]))
+    return fmt.vec(x_dev), info

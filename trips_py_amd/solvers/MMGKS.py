@@ -1,0 +1,134 @@
+"""Majorization-Minimization GKS on the HIP engine — signature and `info` of trips/solvers/MMGKS.py:28-137
+(plain smoothed-Holder weights branch, :93; the isoTV and group-sparsity weight branches are SURVEY §8f rank 3).
+
+    min ||A x - b||_p^p + lambda ||L x||_q^q   by iteratively re-weighted least squares in a growing subspace.
+
+Every iteration re-weights AV by wf = ((A x - b)^2 + eps^2)^(p/2-1) and LV by wr = ((L x)^2 + eps^2)^(q/2-1) and the
+reference re-factorises both m x k / p x k weighted matrices by QR (:58-59,94-95).  Here one kernel forms each
+WEIGHTED Gram matrix  W diag(w^2) W^T  (k x k, fp64) together with the two projected right-hand sides the reference
+uses: (AV*wf)^T b for the least-squares solve (sic: unweighted b, :106) and (AV*wf)^T (wf*b) for the lambda selector
+(:97-99); the host factors k x k matrices.
+"""
+import numpy as np
+
+from .._io import Formatter, as_operator, history_fits
+from ..engine import Coef
+from ..krylov import DeviceBasis, GKState, orthogonalize
+from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq
+
+
+def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv", x_true=None, **kwargs):
+    """Returns (x, info); info keys xHistory, regParam, regParam_history, relError (if x_true), Residual, its.
+    Engine-only kwarg: history=True."""
+    A, L = as_operator(A), as_operator(L, "L")
+    check_delta(regparam, kwargs)
+    for opt in ("isoTV", "GS"):
+        if kwargs.get(opt, False):
+            raise NotImplementedError(f"MMGKS {opt} weights (MMGKS.py:61-91) are not implemented on the engine yet")
+    epsilon = kwargs.get("epsilon", 0.1)
+    eng = A.engine
+    m, n = A.shape
+    p_rows = L.shape[0]
+    n_iter, d = int(n_iter), int(projection_dim)
+    keep = bool(kwargs.get("history", True))
+    fmt = Formatter(b)
+    bv = eng.to_vec(b, m)
+    xt = None if x_true is None else eng.to_vec(x_true, n)
+    kmax = d + n_iter
+
+    gk = GKState(A, bv, d)
+    for _ in range(d):
+        gk.step()
+    V = gk.V
+    V.reserve(kmax)
+    AV, LV = DeviceBasis(eng, m, kmax), DeviceBasis(eng, p_rows, kmax)
+
+    def push_images(j):
+        A.apply(V[j], out=AV.next_slot())
+        L.apply(V[j], out=LV.next_slot())
+        AV.commit()
+        LV.commit()
+
+    for j in range(V.k):
+        push_images(j)
+    if keep:
+        history_fits(eng, n_iter, n, "MMGKS xHistory")
+    X = eng.empty_basis(n_iter if keep else 1, n)
+    x_cur = eng.empty(n)
+    A.apply(bv, out=x_cur, transpose=True)                                            # x = A^T b (:43)
+    G = eng.scalars(2 * kmax * kmax + 2 * kmax + 2)
+    Y = eng.scalars(kmax)
+    H = eng.scalars(2 * kmax)
+    E = eng.scalars(n_iter + 3)
+    Rn = eng.scalars(n_iter + 1)
+    tm, wf = eng.empty(m), eng.empty(m)
+    tp, wr = eng.empty(p_rows), eng.empty(p_rows)
+    r, rb = eng.empty(n), eng.empty(n)
+    if xt is not None:
+        eng.nrm2sq(xt, E.ref(0))
+        eng.allreduce(E, 0, 1)
+    need_wb2 = isinstance(regparam, str) and regparam == "dp"
+
+    lams, res, lam, x_dev, its = [], [], None, None, 0
+    for ii in range(n_iter):
+        its = ii
+        k = V.k
+        kk = k * k
+        # weights from the current iterate (:56-57, :60, :93)
+        A.apply(x_cur, out=tm)
+        eng.mm_weights(tm, bv, epsilon, pnorm, wf)
+        L.apply(x_cur, out=tp)
+        eng.mm_weights(tp, None, epsilon, qnorm, wr)
+        # weighted Gram matrices and projected right-hand sides
+        eng.wgram(AV.data, k, wf, bv, G.ref(0), G.ref(2 * kk), G.ref(2 * kk + k))
+        eng.wgram(LV.data, k, wr, None, G.ref(kk))
+        nred = 2 * kk + 2 * k
+        if need_wb2:                                                                   # ||wf*b||^2 for the discrepancy test
+            eng.mul(wf, bv, tm)
+            eng.nrm2sq(tm, G.ref(nred))
+            nred += 1
+        eng.allreduce(G, 0, nred)
+        g = G.host(0, nred)
+        R_A, R_L = gram_factor(g[:kk].reshape(k, k)), gram_factor(g[kk:2 * kk].reshape(k, k))
+        rhs_b = project_rhs(R_A, g[2 * kk:2 * kk + k])            # Q_A^T b          (:106)
+        rhs_wb = project_rhs(R_A, g[2 * kk + k:2 * kk + 2 * k])   # Q_A^T (wf*b)     (:97-99)
+        resid2 = max(float(g[-1]) - float(rhs_wb @ rhs_wb), 0.0) if need_wb2 else 0.0
+        if isinstance(regparam, str) and regparam == "l_curve":
+            lam = choose_lambda("l_curve", R_A, R_L, rhs_b, 0.0, kwargs)               # l_curve(R_A, R_L, Q_A.T@b) (:101)
+        else:
+            lam = choose_lambda(regparam, R_A, R_L, rhs_wb, resid2, kwargs)
+        lams.append(lam)
+        y = tikhonov_lstsq(R_A, R_L, lam, rhs_b)
+        Y.set(0, y)
+        x_dev = X[ii] if keep else X[0]
+        eng.gemv_n(V.data, k, Y.ref(0), x_dev)                                        # x = V y (:107)
+        x_cur = x_dev if keep else x_cur
+        if not keep:
+            x_cur.copy_(x_dev)
+        if xt is not None:
+            eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
+        if ii >= R_L.shape[0]:                                                        # (:109-110)
+            break
+        # r = A^T (wf * (AV y - b)) + lam L^T (wr * (LV y))                            (:114-118)
+        eng.gemv_n(AV.data, k, Y.ref(0), tm, a=-1.0, base=bv, s=1.0)
+        eng.mul(wf, tm, tm)
+        A.apply(tm, out=r, transpose=True)
+        eng.gemv_n(LV.data, k, Y.ref(0), tp)
+        eng.mul(wr, tp, tp)
+        L.apply(tp, out=rb, transpose=True)
+        eng.axpby(1.0, r, float(lam), rb, r)
+        orthogonalize(eng, V, k, r, H, 0, passes=2)                                   # (:119-120)
+        eng.nrm2sq(r, Rn.ref(ii))
+        eng.allreduce(Rn, ii, ii + 1)
+        eng.scale(Coef(1.0, den=Rn.ref(ii), sqrt_den=True), r, V.next_slot())
+        V.commit()
+        push_images(V.k - 1)
+        res.append(ii)
+    nres = len(res)
+    info = {"xHistory": fmt.hist(X, its + 1) if keep else [], "regParam": lam, "regParam_history": lams,
+            "Residual": list(np.sqrt(Rn.host(0, nres))), "its": its}
+    if xt is not None:
+        eng.allreduce(E, 2, 3 + its)
+        e = E.host(0, 3 + its)
+        info["relError"] = list(np.sqrt(e[2:] / e[0]))
+    return fmt.vec(x_dev), info

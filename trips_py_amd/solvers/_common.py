@@ -1,0 +1,63 @@
+"""Pieces shared by the projection solvers (host side, float64): stacked Tikhonov least squares, Gram -> triangular
+factor, and the lambda dispatcher with the reference's keyword names."""
+import numpy as np
+import scipy.linalg as sla
+
+from ..reg_param import discrepancy_principle, generalized_crossvalidation, l_curve
+
+NO_DELTA_MSG = ("A value for the noise level delta was not provided and the discrepancy principle cannot be applied. \n"
+                "                    Please supply a value of delta based on the estimated noise level of the problem, or choose "
+                "the regularization parameter according to gcv or a different stopping criterion.")
+
+
+def check_delta(regparam, kwargs):
+    """Same precondition (and exception type) as Hybrid_LSQR.py:55-61, Hybrid_GMRES.py:25-31, GKS.py:29-34."""
+    delta = kwargs.get("delta", None)
+    dp_stop = kwargs.get("dp_stop", False)
+    if (isinstance(regparam, str) and regparam == "dp" or dp_stop is not False) and delta is None:
+        raise Exception(NO_DELTA_MSG)
+    if dp_stop:
+        raise NotImplementedError("dp_stop=True is not implemented on the engine yet (SURVEY §8f rank 2)")
+    return delta
+
+
+def tikhonov_lstsq(M, L, lam, rhs):
+    """argmin ||M y - rhs||^2 + lam ||L y||^2 through the stacked least-squares problem, as the reference does
+    (Hybrid_LSQR.py:104, Hybrid_GMRES.py:76, GKS.py:74, MMGKS.py:106)."""
+    top = np.asarray(rhs, dtype=np.float64).reshape(-1, 1)
+    stack = np.vstack((M, np.sqrt(lam) * L))
+    return np.linalg.lstsq(stack, np.vstack((top, np.zeros((L.shape[0], 1)))), rcond=None)[0].reshape(-1)
+
+
+def gram_factor(G):
+    """Upper-triangular R with R^T R = G (G symmetric positive definite up to rounding).  Replaces the economic QR of
+    the m x k matrix (GKS.py:54-56, MMGKS.py:58-59,94-95): R differs from the Householder R by row signs only, which no
+    downstream formula sees.  Falls back to a symmetric eigen-factor when G is numerically semi-definite."""
+    G = 0.5 * (G + G.T)
+    try:
+        return sla.cholesky(G, lower=False)
+    except sla.LinAlgError:
+        w, Q = sla.eigh(G)
+        w = np.maximum(w, w.max() * 1e-15)
+        return np.sqrt(w)[:, None] * Q.T
+
+
+def project_rhs(R, c):
+    """Q^T b = R^{-T} (W^T b) for Q R = W."""
+    return sla.solve(R.T, np.asarray(c, dtype=np.float64).reshape(-1))
+
+
+def choose_lambda(regparam, R_A, R_L, rhs, resid2, kwargs, variant="standard", fullsize=None, L_is_identity=False,
+                  dp_A=None, dp_bproj=None):
+    """regparam in {'gcv','dp','l_curve', number}  ->  lambda  (branches of GKS.py:60-70 / Hybrid_LSQR.py:80-100)."""
+    if isinstance(regparam, str):
+        if regparam == "gcv":
+            return generalized_crossvalidation(R_A, R_L, rhs, variant=variant, fullsize=fullsize)
+        if regparam == "dp":
+            extra = {k: kwargs[k] for k in ("eta", "explicitProj") if k in kwargs}
+            return discrepancy_principle(R_A if dp_A is None else dp_A, R_L, rhs if dp_bproj is None else dp_bproj, resid2,
+                                         delta=kwargs.get("delta"), L_is_identity=L_is_identity, **extra)
+        if regparam == "l_curve":
+            return l_curve(R_A, R_L, rhs)
+        raise ValueError(f"unknown regparam {regparam!r}")
+    return regparam
