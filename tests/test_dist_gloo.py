@@ -1,0 +1,159 @@
+"""world_size = 2 runs over gloo (CPU): the sharded dynamic problem of BASELINE config C5 in miniature.
+
+Frames are sharded over ranks (frame-major x, b; block-diagonal forward operator), every inner product is all-reduced
+through trips_py_amd.dist.TorchComm (the same class that drives RCCL on GPUs), and the temporal rows of the space-time
+regulariser exchange one frame with the time-neighbour (trips_py_amd.operators.spacetime_halo_exchange).  The vector
+arithmetic runs on the test-only CPU engine; what is under test is the product's distributed host logic: the solvers'
+reduction points, TorchComm, the halo exchange and frame partitioning.  Each rank's slice of the result must equal the
+single-process solve."""
+import os
+import socket
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(HERE)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _problem(nt=4, N=12):
+    from oracle import cpu_ref as O
+    psfs = [O.gauss_psf((5, 5), (1.0 + 0.25 * t, 1.2))[0] for t in range(nt)]
+    rng = np.random.default_rng(3)
+    frames = []
+    for t in range(nt):
+        img = np.zeros((N, N))
+        img[2 + t // 2:7 + t // 2, 3:8] = 1.0
+        img[8:11, 1 + t:4 + t] = 0.5
+        frames.append(img + 0.05 * rng.random((N, N)))
+    x_true = np.concatenate([f.reshape(-1) for f in frames])
+    F = O.BlockDiag([O.Blur2D(p, N, N) for p in psfs])
+    b = F @ x_true
+    e = rng.standard_normal(b.shape)
+    b = b + 0.01 * np.linalg.norm(b) / np.linalg.norm(e) * e
+    return psfs, x_true, b, nt, N
+
+
+class ShardedSpaceTime:
+    """Test adapter: the oracle's space-time operator restricted to this rank's frames, with the product's halo exchange."""
+
+    def __init__(self, N, nt, eng):
+        from oracle import cpu_ref as O
+        from trips_py_amd.dist import frame_range
+        self.N, self.eng = N, eng
+        lo, hi = frame_range(nt, eng.world, eng.rank)
+        self.ntl = hi - lo
+        self.has_next, self.has_prev = eng.rank < eng.world - 1, eng.rank > 0
+        self.D2 = O.FirstDerivative2D(N)
+        npix, ps = N * N, self.D2.shape[0]
+        self.ps, self.npix = ps, npix
+        self.ntemp = self.ntl - 1 + (1 if self.has_next else 0)
+        self.shape = (self.ntl * ps + self.ntemp * npix, self.ntl * npix)
+        self.halo_next = torch.zeros(npix, dtype=torch.float32) if self.has_next else None
+        self.halo_prev = torch.zeros(npix, dtype=torch.float32) if self.has_prev else None
+
+    def fwd(self, x):
+        from trips_py_amd.operators import spacetime_halo_exchange
+        xt = torch.from_numpy(x.astype(np.float32))
+        if self.eng.world > 1:
+            spacetime_halo_exchange(self.eng, xt, False, self.N, self.ntl, self.halo_next, self.halo_prev)
+        X = x.reshape(self.ntl, self.npix)
+        spat = np.concatenate([self.D2._fwd(X[t]) for t in range(self.ntl)])
+        Xe = np.vstack([X, self.halo_next.numpy().astype(np.float64)[None]]) if self.has_next else X
+        return np.concatenate((spat, (Xe[:-1] - Xe[1:]).reshape(-1)))
+
+    def adj(self, y):
+        from trips_py_amd.operators import spacetime_halo_exchange
+        yt = torch.from_numpy(y.astype(np.float32))
+        if self.eng.world > 1:
+            spacetime_halo_exchange(self.eng, yt, True, self.N, self.ntl, self.halo_next, self.halo_prev)
+        out = np.stack([self.D2._adj(y[t * self.ps:(t + 1) * self.ps]) for t in range(self.ntl)])
+        Tm = y[self.ntl * self.ps:].reshape(self.ntemp, self.npix)
+        out[:self.ntemp] += Tm
+        out[1:] -= Tm[:self.ntl - 1]
+        if self.has_prev:
+            out[0] -= self.halo_prev.numpy().astype(np.float64)
+        return out.reshape(-1)
+
+
+def _solve_all(eng):
+    """CGLS, GKS and MMGKS on this rank's shard; returns the local slices of the three solutions + info scalars."""
+    from cpu_engine import OracleOp
+    from oracle import cpu_ref as O
+    from trips_py_amd import solvers as S
+    from trips_py_amd.dist import frame_range
+    psfs, x_true, b, nt, N = _problem()
+    lo, hi = frame_range(nt, eng.world, eng.rank)
+    npix = N * N
+    F = OracleOp(O.BlockDiag([O.Blur2D(psfs[t], N, N) for t in range(lo, hi)]), eng)
+    st = ShardedSpaceTime(N, nt, eng)
+
+    class _L:                                           # minimal oracle-like wrapper for OracleOp
+        shape = st.shape
+        _fwd = staticmethod(st.fwd)
+        _adj = staticmethod(st.adj)
+    L = OracleOp(_L, eng)
+    bl, xl = b[lo * npix:hi * npix], x_true[lo * npix:hi * npix]
+    out = {}
+    x, info = S.CGLS(F, bl, np.zeros(F.shape[1]), 12, 0, x_true=xl)
+    out["cgls"] = (x.reshape(-1), np.array(info["relResidual"]))
+    x, info = S.GKS(F, bl, L, 3, 6, 1e-2, xl)
+    out["gks"] = (x.reshape(-1), np.array(info["Residual"]))
+    x, info = S.MMGKS(F, bl, L, 2, 1, 3, 6, 1e-2, xl)
+    out["mmgks"] = (x.reshape(-1), np.array(info["Residual"]))
+    x, info = S.Hybrid_LSQR(F, bl, 8, 1e-2, xl)
+    out["lsqr"] = (x.reshape(-1), np.array(info["regParam_history"], dtype=float))
+    return out, (lo, hi, npix)
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, REPO)
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from cpu_engine import CpuEngine
+        from trips_py_amd.dist import TorchComm
+        eng = CpuEngine(comm=TorchComm())
+        out, (lo, hi, npix) = _solve_all(eng)
+        np.savez(os.path.join(outdir, f"rank{rank}.npz"), lo=lo, hi=hi, npix=npix,
+                 **{f"{k}_x": v[0] for k, v in out.items()}, **{f"{k}_s": v[1] for k, v in out.items()})
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_solvers_match_single_process():
+    sys.path.insert(0, HERE)
+    from cpu_engine import CpuEngine
+    ref, _ = _solve_all(CpuEngine())                     # single process, all frames
+    world = 2
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        parts = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
+    for key in ("cgls", "gks", "mmgks", "lsqr"):
+        x = np.concatenate([p[f"{key}_x"] for p in parts])
+        rx = ref[key][0]
+        err = np.linalg.norm(x - rx) / np.linalg.norm(rx)
+        assert err < 2e-5, (key, err)
+        for p in parts:                                  # global scalars are identical on every rank
+            assert np.allclose(p[f"{key}_s"], ref[key][1], rtol=1e-4), key
+
+
+def test_frame_range_and_comm_validation():
+    from trips_py_amd.dist import frame_range
+    assert frame_range(32, 8, 3) == (12, 16)
+    with pytest.raises(ValueError):
+        frame_range(30, 8, 0)

@@ -230,23 +230,35 @@ class SpaceTimeDerivative(_HandleOperator):
         self._ps = 2 * self.N * (self.N - 1)
 
     def _apply(self, x2, y2, transpose, sumsq):
-        eng, npix = self.engine, self.N * self.N
+        eng = self.engine
         if eng.world > 1:
             if x2.shape[0] != 1:
                 raise NotImplementedError("sharded space-time operator applies one vector at a time")
-            if not transpose:
-                # my first frame -> previous rank ; receive the next rank's first frame
-                eng.comm.shift(send=x2[0, :npix] if self.has_prev else None, send_to=eng.rank - 1,
-                               recv=self._halo_next, recv_from=eng.rank + 1 if self.has_next else None)
-            else:
-                # my last temporal block -> next rank ; receive the previous rank's last temporal block
-                last = x2[0, self.nt_local * self._ps + (self.nt_local - 1) * npix:] if self.has_next else None
-                eng.comm.shift(send=last, send_to=eng.rank + 1,
-                               recv=self._halo_prev, recv_from=eng.rank - 1 if self.has_prev else None)
+            spacetime_halo_exchange(eng, x2[0], transpose, self.N, self.nt_local, self._halo_next, self._halo_prev)
             _lib.check(eng.lib.trk_spacetime_set_halo(self._h, None if self._halo_next is None else self._halo_next.data_ptr(),
                                                       None if self._halo_prev is None else self._halo_prev.data_ptr()),
                        "trk_spacetime_set_halo")
         super()._apply(x2, y2, transpose, sumsq)
+
+
+def spacetime_halo_exchange(eng, x, transpose, N, nt_local, halo_next, halo_prev):
+    """The one-frame neighbour exchange of the time-sharded space-time regulariser (operators.py:39-45 of the reference
+    couples frame t with t+1 through the rows x_t - x_{t+1}).
+
+    forward  : every rank but the first sends its FIRST frame to the previous rank (which owns the row coupling its
+               last frame to it) and receives the next rank's first frame into `halo_next`.
+    transpose: every rank but the last sends its LAST temporal block (the row it owns on behalf of the boundary) to the
+               next rank and receives the previous rank's into `halo_prev`.
+    x is the rank-local operand (frame-major image block for forward; [spatial rows | temporal rows] for transpose)."""
+    npix, ps = N * N, 2 * N * (N - 1)
+    has_next, has_prev = eng.rank < eng.world - 1, eng.rank > 0
+    if not transpose:
+        eng.comm.shift(send=x[:npix] if has_prev else None, send_to=eng.rank - 1,
+                       recv=halo_next, recv_from=eng.rank + 1 if has_next else None)
+    else:
+        last = x[nt_local * ps + (nt_local - 1) * npix:nt_local * ps + nt_local * npix] if has_next else None
+        eng.comm.shift(send=last, send_to=eng.rank + 1,
+                       recv=halo_prev, recv_from=eng.rank - 1 if has_prev else None)
 
 
 class BlockDiagOp(_HandleOperator):
