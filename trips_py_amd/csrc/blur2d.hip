@@ -22,6 +22,8 @@
 #include "trk_internal.h"
 
 #include <cmath>
+#include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 using namespace trk;
@@ -292,22 +294,42 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
   const unsigned img_bytes = (unsigned)nx * (unsigned)ny * 4u;
   const auto rin = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, img_bytes, 0x00020000);
   const auto rout = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, img_bytes, 0x00020000);
-  const int vl = cl * 4, vc = cc * 4, vr = cr * 4;
+  int vl = cl * 4, vr = cr * 4;
+  const int vc = cc * 4;
+#ifdef TRK_EXPERIMENT_NOLR
+  vl = vc; vr = vc;   // timing experiment only (wrong results): price of the left/right neighbour loads
+#endif
   const int vst = c0 * 4;
 
+  // Odd bands march UPWARD (from their bottom halo to their top), even bands downward: the halo rows two neighbouring
+  // bands share are then read by both at (nearly) the same time, at the start or at the end of their marches, and
+  // the second reader hits in the XCD's L2 instead of fetching the rows again (measured fabric reads 1.13x -> ~1.0x
+  // of the image at 64-row bands).  Marching up = the same recurrence on the reversed row sequence with the column
+  // weights reversed.
+  const bool up = (band & 1) != 0;                     // wave-uniform
   float wr[KW], wc[KH];
 #pragma unroll
   for (int b = 0; b < KW; ++b) wr[b] = wts[b];
 #pragma unroll
-  for (int a = 0; a < KH; ++a) wc[a] = wts[KW + a];
+  for (int a = 0; a < KH; ++a) wc[a] = up ? wts[KW + KH - 1 - a] : wts[KW + a];
 
   const int band_rows = i_end - i_begin;
   const int total = ((band_rows + KH - 1 + U - 1) / U) * U;   // staged rows processed (multiple of U)
+  const int rowbytes = ny * 4;
+  // a band whose staged rows all lie inside the image needs no row reflection: the row offset is linear in t
+  // staged row t is image row  first + dir*t  (down: from i_begin - T ; up: from i_end - 1 + KH/2)
+  const int dir = up ? -1 : 1;
+  const int first = up ? (i_end - 1 + KH / 2) : (i_begin - T);
+  const int last = first + dir * (total - 1);
+  const bool interior = (first >= 0) && (first < nx) && (last >= 0) && (last < nx);   // wave-uniform
+  // finished output o (counted in marching order) is image row  ofirst + dir*o
+  const int ofirst = up ? (i_end - 1) : i_begin;
 
   f4 pL[D], pC[D], pR[D];
   auto issue = [&](int t, int slot) {
-    const int gi = reflect(i_begin - T + t, nx);
-    const int so = gi * ny * 4;
+    int gi = first + dir * t;
+    if (!interior) gi = reflect(gi, nx);
+    const int so = gi * rowbytes;
     pL[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, vl, so, 0));
     pC[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, vc, so, 0));
     pR[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, vr, so, 0));
@@ -317,15 +339,18 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
 
   f2 acc[KH][2];
   double ss = 0.0;
-  for (int t0 = 0; t0 < total; t0 += U) {
+  float qacc = 0.f;
+
+  // One block of U staged rows.  GUARD = false is the steady state: every row refills its prefetch slot and stores one
+  // finished output row, with no bounds tests (see the loop split below).
+  auto block = [&](int t0, auto guard_tag) {
+    constexpr bool GUARD = decltype(guard_tag)::value;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int t = t0 + u;
-      constexpr int dummy = 0;
-      (void)dummy;
       const int slot = u % D;
       f4 Lv = pL[slot], Cv = pC[slot], Rv = pR[slot];
-      if (t + D < total) issue(t + D, slot);           // uniform branch: refill the slot D rows ahead
+      if (!GUARD || t + D < total) issue(t + D, slot);  // refill the slot D rows ahead
       if (edge_span) {                                  // reflect across the image's left / right border
         const f4 rev = (f4){Cv[3], Cv[2], Cv[1], Cv[0]};
         if (ledge) Lv = rev;
@@ -355,22 +380,30 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
       }
       // output o = t - (KH-1) is complete
       const int o = t - (KH - 1);
-      if (o >= 0 && o < band_rows) {                   // uniform branch
+      if (!GUARD || (o >= 0 && o < band_rows)) {        // uniform
         const int kd = pmod(u - (KH - 1), KH);
         const f4 out = (f4){acc[kd][0][0], acc[kd][0][1], acc[kd][1][0], acc[kd][1][1]};
         // NOTE the row offset goes into the VGPR offset, not the SGPR soffset: with an SGPR soffset hipcc (ROCm 7.2)
         // emits no wait state between a >64-bit buffer store and a VALU overwrite of its data registers, and on
         // gfx950 the last dword of the store was then observed corrupted (lanes 12-15 of each row of 16).
         if (active) {
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, out), rout, vst + (i_begin + o) * ny * 4, 0, 0);
-          if (SUMSQ) {
-            const float q = fmaf(out[0], out[0], fmaf(out[1], out[1], fmaf(out[2], out[2], out[3] * out[3])));
-            ss += (double)q;
-          }
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, out), rout, vst + (ofirst + dir * o) * rowbytes, 0, 0);
+          if (SUMSQ) qacc = fmaf(out[0], out[0], fmaf(out[1], out[1], fmaf(out[2], out[2], fmaf(out[3], out[3], qacc))));
         }
       }
+      if (SUMSQ && (u & 3) == 3) {                      // fp32 partial of <= 16 squares, then into the fp64 sum
+        ss += (double)qacc;
+        qacc = 0.f;
+      }
     }
-  }
+  };
+  // first block (outputs start after KH-1 rows) and last block (prefetch stops) are guarded; the middle is not:
+  // for t < total - U:  t + D < total  and  o = t - (KH-1) < band_rows  hold by construction, o >= 0 after block 0.
+  block(0, std::true_type{});
+  int t0 = U;
+  for (; t0 + U < total; t0 += U) block(t0, std::false_type{});
+  if (t0 < total) block(t0, std::true_type{});
+  if (SUMSQ) ss += (double)qacc;
   if (SUMSQ) {
     ss = wave_sum(ss);
     if (lane == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ss;
@@ -445,21 +478,23 @@ int launch_slide(const BlurImpl* im, int tr, const float* x, int64_t ldx, float*
   return TRK_OK;
 }
 
-// bands for the sliding kernel: about 2 waves per SIMD over the chip, a multiple of 8 bands when possible (XCD map)
-inline void slide_grid(int nx, int ny, int batch, int* spans_x, int* nbands, int* rows_per_band) {
+// Bands for the sliding kernel.  A wave processes roundup(rows_per_band + KH-1, U) staged rows, so band heights of the
+// form j*U - (KH-1) waste nothing; the smallest such height that needs no more than ~1.25 waves per SIMD is taken
+// (measured at 4096^2, 9x9: 64-row bands / one wave per SIMD 24.4 us; 32-row bands / two waves 30.4 us — the KH-1 halo
+// rows every band re-reads outweigh the second wave).  Band count is rounded to a multiple of 8 when it costs nothing,
+// for the XCD-aware placement.
+inline void slide_grid(int nx, int ny, int batch, int kh, int U, int* spans_x, int* nbands, int* rows_per_band) {
   const int sx = ceil_div(ny, SPAN);
-  int want = (8 * cu_count()) / (sx * (batch > 0 ? batch : 1));   // 2 waves x 4 SIMDs per CU
-  if (want < 1) want = 1;
-  int rpb = ceil_div(nx, want);
-  if (rpb < 16) rpb = 16;                                         // keep the halo overhead (KH-1 rows) bounded
-  int nb = ceil_div(nx, rpb);
-  if (nb > 8 && (nb & 7)) {                                       // round the band count to a multiple of 8
-    nb = (nb + 7) & ~7;
-    rpb = ceil_div(nx, nb);
-    nb = ceil_div(nx, rpb);
+  const int64_t max_waves = (int64_t)5 * cu_count();              // 1.25 waves per SIMD
+  int rpb = U - (kh - 1);
+  while (rpb < 1) rpb += U;
+  while ((int64_t)sx * ceil_div(nx, rpb) * (batch > 0 ? batch : 1) > max_waves && rpb < nx) rpb += U;
+  if (const char* e = getenv("TRK_BLUR_RPB")) {                   // tuning knob (rows per band)
+    const int v = atoi(e);
+    if (v > 0) rpb = v;
   }
   *spans_x = sx;
-  *nbands = nb;
+  *nbands = ceil_div(nx, rpb);
   *rows_per_band = rpb;
 }
 
@@ -474,7 +509,8 @@ int blur_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_
                         (int64_t)im->nx * im->ny < ((int64_t)1 << 30);
   if (slide_ok) {
     int spans_x, nbands, rpb;
-    slide_grid(im->nx, im->ny, batch, &spans_x, &nbands, &rpb);
+    const int Usel = (im->kh == 9) ? 18 : (im->kh == 7) ? 7 : (im->kh == 5) ? 5 : 6;   // lcm(KH, D) of the instantiations below
+    slide_grid(im->nx, im->ny, batch, im->kh, Usel, &spans_x, &nbands, &rpb);
     nblk = spans_x * nbands;
     if (sumsq)
       if (int rc = scratch_doubles(s, (size_t)nblk * batch, &part)) return rc;
