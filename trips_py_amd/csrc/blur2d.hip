@@ -20,6 +20,7 @@
 //   * grid = strips x row bands, sized to ~4 workgroups per CU so that a 4096^2 image is split evenly (no tail).
 //   * k_blur_generic: any PSF size (even, rectangular, longer than the image: repeated reflection), no tiling.
 #include "trk_internal.h"
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdlib>
@@ -467,13 +468,15 @@ int launch_strip(const BlurImpl* im, int tr, const float* x, int64_t ldx, float*
 
 template <int K, int D>
 int launch_slide(const BlurImpl* im, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch,
-                 double* part, int spans_x, int nbands, int rows_per_band, hipStream_t s) {
+                 double* part, int spans_x, int nbands, int rows_per_band, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
   dim3 grid(spans_x * nbands, batch), block(64);
   const float* w = im->sep_dev[tr];
+  // hipExtLaunchKernelGGL attaches the (optional) events to the dispatch itself: their timestamps are the kernel's own
+  // begin / end, the same quantity rocprofv3's kernel trace reports.
   if (part)
-    hipLaunchKernelGGL((k_blur_slide<K, K, D, true>), grid, block, 0, s, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band);
+    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, true>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band);
   else
-    hipLaunchKernelGGL((k_blur_slide<K, K, D, false>), grid, block, 0, s, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band);
+    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, false>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }
@@ -514,15 +517,20 @@ int blur_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_
     nblk = spans_x * nbands;
     if (sumsq)
       if (int rc = scratch_doubles(s, (size_t)nblk * batch, &part)) return rc;
-    TimerScope tm(op->timer, op->timer_which, tr, s);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (trk_timer* t = op->timer)
+      if ((op->timer_which == 2 || op->timer_which == tr) && t->used < t->cap) {
+        ev0 = t->ev[2 * t->used];
+        ev1 = t->ev[2 * t->used + 1];
+        ++t->used;
+      }
     int rc;
     switch (im->kh) {
-      case 3: rc = launch_slide<3, 6>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s); break;
-      case 5: rc = launch_slide<5, 5>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s); break;
-      case 7: rc = launch_slide<7, 7>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s); break;
-      default: rc = launch_slide<9, 6>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s); break;
+      case 3: rc = launch_slide<3, 6>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1); break;
+      case 5: rc = launch_slide<5, 5>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1); break;
+      case 7: rc = launch_slide<7, 7>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1); break;
+      default: rc = launch_slide<9, 6>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1); break;
     }
-    tm.stop();
     if (rc) return rc;
     if (sumsq) return finalize_sums(part, nblk * batch, 1, 1, sumsq, s);
     return TRK_OK;
