@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--size", type=int, default=4096, help="image side of the blur workload")
     ap.add_argument("--workload", default="blur_cgls", choices=["blur_cgls"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the C4 (MMGKS) and C5 (sharded dynamic tomo) legs")
     ap.add_argument("--cpu-iters", type=int, default=3, help="CPU-baseline sample: CGLS iterations timed on the host")
     return ap.parse_args()
 
@@ -48,8 +49,14 @@ def dist_setup(args):
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("TRK_DIST_BACKEND", "nccl")          # "gloo": single-GPU debugging of the N > 1 path
+        if os.environ.get("TRK_SINGLE_DEVICE"):
+            local = 0
         torch.cuda.set_device(local)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
     if world != args.gpus and rank == 0:
@@ -68,7 +75,7 @@ def max_over_ranks(v, world):
     if world == 1:
         return v
     import torch.distributed as dist
-    t = torch.tensor([v], dtype=torch.float64, device="cuda")
+    t = torch.tensor([v], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
 
@@ -185,7 +192,80 @@ def run_blur_cgls(args, rank, world):
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         res["cpu_baseline"] = cpu_baseline_cgls(psf, N, b, args.cpu_iters)
+    del run
+    torch.cuda.empty_cache()
+    if not args.no_extras:
+        # secondary measurements (never `value`): each guarded so that the main line is always printed
+        for name, fn in (("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world)),
+                         ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world))):
+            try:
+                res["extra"][name] = fn()
+            except Exception as exc:          # noqa: BLE001
+                res["extra"][name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+            barrier(world)
     return res
+
+
+def extra_c4_mmgks(A, b, N, world):
+    """BASELINE config C4: blur 4096^2, MMGKS + TV (pnorm=2, qnorm=1, projection_dim=3, n_iter=30, lambda=1e-2).
+    Replicas across ranks (a static image does not shard)."""
+    from trips_py_amd.operators import FirstDerivative2D
+    from trips_py_amd.solvers import MMGKS
+    L = FirstDerivative2D(N)
+    MMGKS(A, b, L, 2, 1, 3, 4, 1e-2, history=False)          # warm-up (allocations, kernels)
+    barrier(world)
+    t0 = time.perf_counter()
+    x, info = MMGKS(A, b, L, 2, 1, 3, 30, 1e-2, history=False)
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    return {"solver": "MMGKS(pnorm=2,qnorm=1,projection_dim=3,n_iter=30,regparam=1e-2,epsilon=0.1), L = 2-D first derivative",
+            "iters_per_sec_all_ranks": round(world * 30 / dt, 2), "seconds_per_solve": round(dt, 4), "its": int(info["its"]) + 1,
+            "parallelism": "replicas" if world > 1 else "single"}
+
+
+def extra_c5_dynamic(rank, world):
+    """BASELINE config C5 (dynamic parallel-beam tomography, 256^2 frames, 15 angles per frame shifted by 1 degree per
+    frame, space-time derivative): frames sharded over ranks, 4 frames per rank (weak; 8 ranks = the 32-frame config),
+    global inner products all-reduced over RCCL, one-frame halo exchange for the temporal rows."""
+    from trips_py_amd.dist import TorchComm, frame_range
+    from trips_py_amd.engine import HipEngine
+    from trips_py_amd.operators import BlockDiagOp, Radon2DParallel, SpaceTimeDerivative
+    from trips_py_amd.solvers import CGLS, GKS
+    Nf, per_rank, na = 256, 4, 15
+    nt = per_rank * world
+    eng = HipEngine(comm=TorchComm()) if world > 1 else HipEngine()
+    lo, hi = frame_range(nt, world, rank)
+    ops = [Radon2DParallel(Nf, np.deg2rad(t + 12.0 * np.arange(na)), engine=eng) for t in range(lo, hi)]
+    F = BlockDiagOp(ops, engine=eng)
+    L = SpaceTimeDerivative(Nf, nt, engine=eng)
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    frames = []
+    for t in range(nt):                                        # two bars drifting linearly in t (every rank builds all, keeps its own)
+        img = torch.zeros((Nf, Nf))
+        img[60 + 2 * t:100 + 2 * t, 40:200] = 1.0
+        img[150:190, 30 + 3 * t:90 + 3 * t] = 0.6
+        frames.append(img + 0.05 * torch.rand((Nf, Nf), generator=g))
+    xt = torch.cat([f.reshape(-1) for f in frames[lo:hi]]).to(eng.device)
+    bl = F.apply(xt)
+    e = torch.randn(bl.numel(), device=eng.device, generator=torch.Generator(device=eng.device).manual_seed(77 + rank))
+    bl = bl + e * (0.01 * torch.linalg.norm(bl) / torch.linalg.norm(e))
+    x0 = torch.zeros(F.shape[1], device=eng.device)
+    out = {"frames_total": nt, "frames_per_rank": per_rank, "frame": f"{Nf}x{Nf}", "angles_per_frame": na}
+    CGLS(F, bl, x0, 5, 0, history=False)
+    barrier(world)
+    t0 = time.perf_counter()
+    CGLS(F, bl, x0, 100, 0, history=False)
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    out["cgls_iters_per_sec"] = round(100 / dt, 1)
+    GKS(F, bl, L, 3, 3, 1e-2, history=False)
+    barrier(world)
+    t0 = time.perf_counter()
+    GKS(F, bl, L, 3, 50, 1e-2, history=False)
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    out["gks_iters_per_sec"] = round(50 / dt, 1)
+    return out
 
 
 def cpu_baseline_cgls(psf, N, b_dev, iters):

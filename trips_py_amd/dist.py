@@ -18,22 +18,36 @@ class TorchComm:
         self.group = group
         self.world = dist.get_world_size(group)
         self.rank = dist.get_rank(group)
+        # gloo cannot move device tensors point-to-point: stage through the host (debug / CPU-test backend only)
+        self.host_staging = dist.get_backend(group) == "gloo"
 
     def allreduce_sum_(self, t):
         """In-place sum over ranks of a float64 tensor (device tensor under nccl, CPU tensor under gloo)."""
+        if self.host_staging and t.is_cuda:
+            h = t.detach().to("cpu")
+            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return t
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
         return t
 
     def shift(self, send, send_to, recv, recv_from):
         """Send `send` to rank `send_to` and receive into `recv` from rank `recv_from` (either side may be None)."""
+        do_send = send is not None and 0 <= send_to < self.world
+        do_recv = recv is not None and recv_from is not None and 0 <= recv_from < self.world
+        stage = self.host_staging and ((do_send and send.is_cuda) or (do_recv and recv.is_cuda))
+        sbuf = (send.detach().to("cpu") if stage else send.contiguous()) if do_send else None
+        rbuf = (torch.empty(recv.shape, dtype=recv.dtype) if stage else recv) if do_recv else None
         ops = []
-        if send is not None and 0 <= send_to < self.world:
-            ops.append(dist.P2POp(dist.isend, send.contiguous(), send_to, self.group))
-        if recv is not None and recv_from is not None and 0 <= recv_from < self.world:
-            ops.append(dist.P2POp(dist.irecv, recv, recv_from, self.group))
+        if do_send:
+            ops.append(dist.P2POp(dist.isend, sbuf, send_to, self.group))
+        if do_recv:
+            ops.append(dist.P2POp(dist.irecv, rbuf, recv_from, self.group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+        if do_recv and stage:
+            recv.copy_(rbuf)
 
     def barrier(self):
         dist.barrier(group=self.group)
