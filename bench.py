@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--size", type=int, default=4096, help="image side of the blur workload")
     ap.add_argument("--workload", default="blur_cgls", choices=["blur_cgls"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--unfused", action="store_true", help="force the generic seven-launch CGLS iteration")
     ap.add_argument("--no-extras", action="store_true", help="skip the C4 (MMGKS) and C5 (sharded dynamic tomo) legs")
     ap.add_argument("--cpu-iters", type=int, default=3, help="CPU-baseline sample: CGLS iterations timed on the host")
     return ap.parse_args()
@@ -119,7 +120,7 @@ def load_traffic(kernel_key):
 def run_blur_cgls(args, rank, world):
     from trips_py_amd.operators import Blur2D
     from trips_py_amd.problems import gauss_psf
-    from trips_py_amd.solvers import CGLSRun
+    from trips_py_amd.solvers import CGLSRun, CGLSRunFused
 
     N, K, W = args.size, args.steps, args.warmup
     n = N * N
@@ -141,7 +142,9 @@ def run_blur_cgls(args, rank, world):
     b = b + e * (0.01 * torch.linalg.norm(b) / torch.linalg.norm(e))
     x0 = torch.zeros(n, dtype=torch.float32, device=eng.device)
 
-    run = CGLSRun(A, b, x0, W + K, x_true=None, history=False)    # reference call without x_true (CGLS.py:16)
+    # the class trips_py_amd.solvers.CGLS itself picks for this operator (tol = 0, single rank per problem)
+    Run = CGLSRunFused if (CGLSRunFused.usable(A, eng) and not args.unfused) else CGLSRun
+    run = Run(A, b, x0, W + K, x_true=None, history=False)        # reference call without x_true (CGLS.py:16)
     for _ in range(W):
         run.step()
     tfwd = KernelTimer(A, K + 4, 0)
@@ -184,6 +187,7 @@ def run_blur_cgls(args, rank, world):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"blur{N}_cgls", "image": f"{N}x{N} fp32", "psf": "Gaussian 9x9 sigma=(3,3), reflect",
                       "solver": "CGLS (trips.solvers.CGLS semantics, tol=0)", "noise": "1% Gaussian",
+                      "iteration": "fused: 3 launches (blur+p-update, x-update, blur^T+r-update)" if Run is CGLSRunFused else "generic: 7 launches",
                       "parallelism": "replicas" if world > 1 else "single"},
            "roofline": roofline,
            "extra": {"relError_after_timed_iters": float(torch.linalg.norm(run.x_cur - x_true) / torch.linalg.norm(x_true)),

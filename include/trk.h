@@ -130,6 +130,27 @@ int trk_cgls_update_xr(int64_t n, int64_t m, const double* gamma_dev, const doub
                        const float* p, float* x_new, float* r, const float* w, const float* x_true,
                        double* sums_dev, trk_stream stream);
 
+/* ---------------------------------------------------------------- fused CGLS fast path --- */
+/* For operators whose kernel can combine two inputs on load (the blur): one CGLS iteration becomes three launches with no
+ * reduction-finalize launches in between.  A "scalar source" (const double* p, int n) is the constant 1 (n = 0), a
+ * finished device scalar (n = 1) or n block partials still to be added (summed by the CONSUMER, always in the same order).
+ *   y = Op(x1 + cb*x2), cb = sign * S(num)/S(den); the combined operand is also written to comb_out (must not alias
+ *   x1/x2); sum(y*y) is left as *n_partials raw block partials in ysq_partials (capacity given).
+ *     forward : x1 = t, x2 = p_old, cb = +gamma_k/gamma_{k-1}  -> comb = p_new (CGLS.py:72), y = w = A p_new (:60), ||w||^2 (:61)
+ *     adjoint : x1 = r_old, x2 = w, cb = -gamma/delta          -> comb = r_new (:67),       y = t = A^T r_new (:68), ||t||^2 (:70) */
+int trk_op_fused_caps(const trk_op* op, int* can_fuse);
+int trk_op_apply_fused(trk_op* op, int transpose, const float* x1, const float* x2, double sign, const double* num,
+                       int num_n, const double* den, int den_n, float* comb_out, float* y, double* ysq_partials,
+                       int capacity, int* n_partials, trk_stream stream);
+/* x_new = x + (S(gamma)/S(delta)) p (CGLS.py:64-65); block 0 stores the two finished scalars to publish_* (may be NULL);
+ * [||x_new||^2, ||step*p||^2, ||x_new - x_true||^2] are left as *n_blocks x 3 raw partials (:76-80). */
+int trk_cgls_x_update(int64_t n, const double* gamma, int gamma_n, const double* delta, int delta_n, const float* x,
+                      const float* p, float* x_new, const float* x_true, double* publish_delta, double* publish_gamma,
+                      double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
+/* out[b*out_stride + v] = sum_j partials[(b*nblocks + j)*nvals + v]  for b < batches, v < nvals (fixed order). */
+int trk_finalize_batched(const double* partials, int nblocks, int nvals, int batches, double* out, int out_stride,
+                         trk_stream stream);
+
 /* ---------------------------------------------------------------- tall-skinny basis ops */
 /* h[j] = sum_i w2[i] * V[j][i] * r[i], j < k  (w2 may be NULL = 1).  One pass over V.
  * (V^T r of the (re)orthogonalisation: decompositions.py:90-94,216-218; GKS.py:86-88; MMGKS.py:119-120;

@@ -67,3 +67,28 @@ def test_cgls_config_c2_512_against_oracle_and_history_off():
     x2, info2 = CGLS(A, bt, torch.zeros(N * N, device=A.engine.device), 10, 0)
     assert isinstance(x2, torch.Tensor) and x2.shape == (N * N, 1) and len(info2["xHistory"]) == 10
     assert relerr(x2.cpu().numpy(), io["xHistory"][9]) < 1e-5
+
+
+@pytest.mark.parametrize("N", [64, 256, 1000])
+def test_fused_and_unfused_cgls_agree(N):
+    """The three-launch fused path (trk_op_apply_fused / trk_cgls_x_update) against the generic seven-launch path."""
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import add_noise, gauss_psf, synthetic_image
+    from trips_py_amd.solvers import CGLS, CGLSRunFused
+    psf, _ = gauss_psf((9, 9), (3, 3))
+    A = Blur2D(psf, N, N)
+    assert CGLSRunFused.usable(A, A.engine)
+    xt = synthetic_image(N, 3).reshape(-1, 1)
+    b, _ = add_noise(A @ xt, 0.01, 4)
+    x0 = np.zeros((N * N, 1))
+    xf, inf_f = CGLS(A, b, x0, 25, 0, x_true=xt)
+    xu, inf_u = CGLS(A, b, x0, 25, 0, x_true=xt, fused=False)
+    assert relerr(xf, xu) < 2e-6
+    assert np.allclose(inf_f["relResidual"], inf_u["relResidual"], rtol=1e-5)
+    assert np.allclose(inf_f["relError"], inf_u["relError"], rtol=1e-5)
+    assert relerr(inf_f["xHistory"][4], inf_u["xHistory"][4]) < 1e-6
+    # non-zero start and no x_true, history off
+    xs = A.T @ b
+    xf, _ = CGLS(A, b, xs, 8, 0, history=False)
+    xu, _ = CGLS(A, b, xs, 8, 0, history=False, fused=False)
+    assert relerr(xf, xu) < 2e-6

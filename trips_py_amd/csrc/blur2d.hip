@@ -254,11 +254,22 @@ __host__ __device__ constexpr int pmod(int a, int m) { return ((a % m) + m) % m;
 
 constexpr int SPAN = 256;  // columns per wave
 
-template <int KH, int KW, int D, bool SUMSQ>
+// FUSE: the operand is formed on load as  comb = x + cb * x2,  cb = sign * S(num) / S(den)  (device scalars, possibly
+// still block partials), and the rows a band OWNS are also written to `comb` (never aliasing x / x2: neighbouring bands
+// read each other's halo rows).  This is how CGLS's  p = t + (gamma/gamma_old) p  and  r = r - beta w  ride along with
+// the blur that consumes them (CGLS.py:67-68,72 + :60) instead of being separate passes over memory.
+struct SlideFuse {
+  const float* x2;
+  float* comb;
+  double sign;
+  ScalarSrc num, den;
+};
+
+template <int KH, int KW, int D, bool SUMSQ, bool FUSE>
 __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
                                                    int64_t ldy, int nx, int ny, const float* __restrict__ wts,
                                                    double* __restrict__ partials, int spans_x, int nbands,
-                                                   int rows_per_band) {
+                                                   int rows_per_band, SlideFuse fz) {
   constexpr int T = KH - 1 - KH / 2;
   constexpr int Lh = KW - 1 - KW / 2;
   constexpr int OFFC = 4 - Lh;          // v[] index of tap 0 of output column 0
@@ -295,6 +306,10 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
   const unsigned img_bytes = (unsigned)nx * (unsigned)ny * 4u;
   const auto rin = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, img_bytes, 0x00020000);
   const auto rout = __builtin_amdgcn_make_buffer_rsrc((void*)y, 0, img_bytes, 0x00020000);
+  const auto rin2 = __builtin_amdgcn_make_buffer_rsrc((void*)(FUSE ? fz.x2 : x), 0, img_bytes, 0x00020000);
+  const auto rcomb = __builtin_amdgcn_make_buffer_rsrc((void*)(FUSE ? fz.comb : y), 0, img_bytes, 0x00020000);
+  float cb = 0.f;
+  if (FUSE) cb = (fz.sign == 0.0) ? 0.f : (float)(fz.sign * scalar_from_wave(fz.num, threadIdx.x) / scalar_from_wave(fz.den, threadIdx.x));
   int vl = cl * 4, vr = cr * 4;
   const int vc = cc * 4;
 #ifdef TRK_EXPERIMENT_NOLR
@@ -327,6 +342,7 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
   const int ofirst = up ? (i_end - 1) : i_begin;
 
   f4 pL[D], pC[D], pR[D];
+  f4 qL[FUSE ? D : 1], qC[FUSE ? D : 1], qR[FUSE ? D : 1];
   auto issue = [&](int t, int slot) {
     int gi = first + dir * t;
     if (!interior) gi = reflect(gi, nx);
@@ -334,6 +350,11 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
     pL[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, vl, so, 0));
     pC[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, vc, so, 0));
     pR[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin, vr, so, 0));
+    if (FUSE) {
+      qL[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin2, vl, so, 0));
+      qC[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin2, vc, so, 0));
+      qR[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rin2, vr, so, 0));
+    }
   };
 #pragma unroll
   for (int d = 0; d < D; ++d) issue(d, d);
@@ -351,6 +372,15 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
       const int t = t0 + u;
       const int slot = u % D;
       f4 Lv = pL[slot], Cv = pC[slot], Rv = pR[slot];
+      if (FUSE) {
+        Lv = Lv + cb * qL[slot];
+        Cv = Cv + cb * qC[slot];
+        Rv = Rv + cb * qR[slot];
+        // the combined operand of the rows this band owns goes back to memory (16-byte coalesced)
+        const int graw = first + dir * t;
+        if (graw >= i_begin && graw < i_end && active)                                   // first test is wave-uniform
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, Cv), rcomb, vst + graw * rowbytes, 0, 0);
+      }
       if (!GUARD || t + D < total) issue(t + D, slot);  // refill the slot D rows ahead
       if (edge_span) {                                  // reflect across the image's left / right border
         const f4 rev = (f4){Cv[3], Cv[2], Cv[1], Cv[0]};
@@ -468,15 +498,22 @@ int launch_strip(const BlurImpl* im, int tr, const float* x, int64_t ldx, float*
 
 template <int K, int D>
 int launch_slide(const BlurImpl* im, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch,
-                 double* part, int spans_x, int nbands, int rows_per_band, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1) {
+                 double* part, int spans_x, int nbands, int rows_per_band, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
+                 const SlideFuse* fuse = nullptr) {
   dim3 grid(spans_x * nbands, batch), block(64);
   const float* w = im->sep_dev[tr];
+  if (fuse) {   // fused-operand form: always with the sum of squares (raw partials)
+    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, true, true>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band, *fuse);
+    TRK_LAUNCH_CHECK();
+    return TRK_OK;
+  }
+  const SlideFuse nofuse{nullptr, nullptr, 0.0, {nullptr, 0}, {nullptr, 0}};
   // hipExtLaunchKernelGGL attaches the (optional) events to the dispatch itself: their timestamps are the kernel's own
   // begin / end, the same quantity rocprofv3's kernel trace reports.
   if (part)
-    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, true>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band);
+    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, true, false>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band, nofuse);
   else
-    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, false>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band);
+    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, false, false>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band, nofuse);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }
@@ -501,15 +538,47 @@ inline void slide_grid(int nx, int ny, int batch, int kh, int U, int* spans_x, i
   *rows_per_band = rpb;
 }
 
+inline bool slide_shape_ok(const BlurImpl* im) {
+  return im->separable && im->kh == im->kw && (im->kh & 1) && im->kh >= 3 && im->kh <= 9 && (im->ny & 3) == 0 &&
+         im->ny >= 8 && (int64_t)im->nx * im->ny < ((int64_t)1 << 30);
+}
+
+// y = A (x1 + cb * x2), comb written out, sum(y^2) as raw partials (CGLS fast path; 9x9-class separable PSFs only)
+int blur_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, double sign, ScalarSrc num, ScalarSrc den,
+                     float* comb, float* y, double* partials, int cap, int* n_partials, hipStream_t s) {
+  auto* im = static_cast<BlurImpl*>(op->impl);
+  if (!slide_shape_ok(im) || !aligned16(x1) || !aligned16(x2) || !aligned16(comb) || !aligned16(y))
+    return fail(TRK_EUNSUPPORTED, "blur2d fused apply: needs a separable odd PSF <= 9x9, ny %% 4 == 0, 16-byte aligned buffers");
+  if (comb == x1 || comb == x2) return fail(TRK_EINVAL, "blur2d fused apply: comb must not alias an input (halo rows are shared)");
+  int spans_x, nbands, rpb;
+  const int Usel = (im->kh == 9) ? 18 : (im->kh == 7) ? 7 : (im->kh == 5) ? 5 : 6;
+  slide_grid(im->nx, im->ny, 1, im->kh, Usel, &spans_x, &nbands, &rpb);
+  const int nblk = spans_x * nbands;
+  if (nblk > cap) return fail(TRK_EINVAL, "blur2d fused apply: partial buffer holds %d doubles, %d needed", cap, nblk);
+  *n_partials = nblk;
+  const SlideFuse fz{x2, comb, sign, num, den};
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (trk_timer* t = op->timer)
+    if ((op->timer_which == 2 || op->timer_which == tr) && t->used < t->cap) {
+      ev0 = t->ev[2 * t->used];
+      ev1 = t->ev[2 * t->used + 1];
+      ++t->used;
+    }
+  switch (im->kh) {
+    case 3: return launch_slide<3, 6>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
+    case 5: return launch_slide<5, 5>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
+    case 7: return launch_slide<7, 7>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
+    default: return launch_slide<9, 6>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
+  }
+}
+
 int blur_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
                hipStream_t s) {
   auto* im = static_cast<BlurImpl*>(op->impl);
   double* part = nullptr;
   int nblk;
-  const bool slide_ok = im->separable && im->kh == im->kw && (im->kh & 1) && im->kh >= 3 && im->kh <= 9 &&
-                        (im->ny & 3) == 0 && im->ny >= 8 && aligned16(x) && aligned16(y) &&
-                        (batch == 1 || ((ldx & 3) == 0 && (ldy & 3) == 0)) &&
-                        (int64_t)im->nx * im->ny < ((int64_t)1 << 30);
+  const bool slide_ok = slide_shape_ok(im) && aligned16(x) && aligned16(y) &&
+                        (batch == 1 || ((ldx & 3) == 0 && (ldy & 3) == 0));
   if (slide_ok) {
     int spans_x, nbands, rpb;
     const int Usel = (im->kh == 9) ? 18 : (im->kh == 7) ? 7 : (im->kh == 5) ? 5 : 6;   // lcm(KH, D) of the instantiations below
@@ -652,6 +721,8 @@ extern "C" int trk_blur2d_create(const double* psf, int kh, int kw, int nx, int 
     return rc;
   }
   const int64_t n = (int64_t)nx * ny;
-  *out = new trk_op{1, n, n, im, blur_apply, blur_destroy, nullptr, 0};
+  auto* op = new trk_op{1, n, n, im, blur_apply, blur_destroy, nullptr, 0};
+  if (slide_shape_ok(im)) op->apply_fused = blur_apply_fused;
+  *out = op;
   return TRK_OK;
 }

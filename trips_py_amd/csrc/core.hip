@@ -83,6 +83,19 @@ int finalize_sums(const double* partials, int nblocks, int stride, int nout, dou
   return TRK_OK;
 }
 
+// out[batch*out_stride + o] = sum_b partials[batch*batch_stride + b*stride + o]
+__global__ __launch_bounds__(256) void k_finalize_batched(const double* __restrict__ partials, int nblocks, int stride,
+                                                          size_t batch_stride, int nvals, double* __restrict__ out,
+                                                          int out_stride) {
+  __shared__ double lds[4];
+  const int o = blockIdx.x % nvals, bt = blockIdx.x / nvals;
+  const double* __restrict__ p = partials + (size_t)bt * batch_stride + o;
+  double v = 0.0;
+  for (int b = threadIdx.x; b < nblocks; b += 256) v += p[(size_t)b * stride];
+  v = block_sum<256>(v, lds);
+  if (threadIdx.x == 0) out[(size_t)bt * out_stride + o] = v;
+}
+
 int cu_count() {
   static int n = 0;
   if (n == 0) {
@@ -185,6 +198,32 @@ int trk_op_apply(trk_op* op, int transpose, const float* x, int64_t ldx, float* 
   TRK_REQUIRE(batch == 1 || (ldx >= nin && ldy >= nout), "trk_op_apply: ldx/ldy smaller than the vector length");
   TRK_REQUIRE(x != y, "trk_op_apply: in-place apply is not supported");
   return op->apply(op, transpose ? 1 : 0, x, ldx, y, ldy, batch, sumsq_dev, (hipStream_t)stream);
+}
+
+int trk_op_fused_caps(const trk_op* op, int* can_fuse) {
+  TRK_REQUIRE(op && can_fuse, "trk_op_fused_caps: NULL argument");
+  *can_fuse = op->apply_fused ? 1 : 0;
+  return TRK_OK;
+}
+
+int trk_op_apply_fused(trk_op* op, int transpose, const float* x1, const float* x2, double sign, const double* num,
+                       int num_n, const double* den, int den_n, float* comb_out, float* y, double* ysq_partials,
+                       int capacity, int* n_partials, trk_stream stream) {
+  TRK_REQUIRE(op && x1 && x2 && comb_out && y && ysq_partials && n_partials, "trk_op_apply_fused: NULL argument");
+  TRK_REQUIRE(num_n >= 0 && den_n >= 0 && (num_n == 0 || num) && (den_n == 0 || den), "trk_op_apply_fused: bad scalar source");
+  if (!op->apply_fused) return fail(TRK_EUNSUPPORTED, "trk_op_apply_fused: this operator has no fused form");
+  return op->apply_fused(op, transpose ? 1 : 0, x1, x2, sign, ScalarSrc{num, num_n}, ScalarSrc{den, den_n}, comb_out, y,
+                         ysq_partials, capacity, n_partials, (hipStream_t)stream);
+}
+
+int trk_finalize_batched(const double* partials, int nblocks, int nvals, int batches, double* out, int out_stride,
+                         trk_stream stream) {
+  TRK_REQUIRE(partials && out && nblocks >= 1 && nvals >= 1 && batches >= 0, "trk_finalize_batched: bad argument");
+  if (batches == 0) return TRK_OK;
+  hipLaunchKernelGGL(k_finalize_batched, dim3(nvals * batches), dim3(256), 0, (hipStream_t)stream, partials, nblocks, nvals,
+                     (size_t)nblocks * nvals, nvals, out, out_stride);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
 }
 
 int trk_timer_create(int capacity, trk_timer** out) {

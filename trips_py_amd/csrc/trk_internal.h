@@ -82,6 +82,33 @@ __device__ __forceinline__ double block_sum(double v, double* lds) {
   return t;
 }
 
+// ------------------------------------------------------------------ a scalar that may still be block partials
+// n == 0: the constant 1 ; n == 1: *p ; n > 1: the sum of n block partials.  The sum is always formed the same way
+// (lane l of one wave adds p[l], p[l+64], ... then a wave64 tree), so every kernel that consumes the same partials
+// gets the bitwise same value, and no separate finalize launch is needed between producer and consumer.
+struct ScalarSrc {
+  const double* p;
+  int n;
+};
+
+__device__ __forceinline__ double wave_sum_all(double v) {   // total in every lane
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// called by ONE full wave (64 lanes); returns the value in every lane
+__device__ __forceinline__ double scalar_from_wave(const ScalarSrc s, int lane) {
+  if (s.n == 0) return 1.0;
+  if (s.n == 1) return *s.p;
+  double v = 0.0;
+  for (int i = lane; i < s.n; i += 64) v += s.p[i];
+  // fixed tree: shfl_down order so that the association does not depend on the caller
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  return __shfl(v, 0, 64);
+}
+
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -125,4 +152,9 @@ struct trk_op {
   void (*destroy)(trk_op*);
   trk_timer* timer = nullptr;
   int timer_which = 0;
+  // optional: y = Op(x1 + cb*x2) with the combined operand written to `comb`, cb = sign*S(num)/S(den); the sum of y^2
+  // is left as raw block partials (count returned on the host) for the consumer kernel to add up
+  int (*apply_fused)(trk_op*, int transpose, const float* x1, const float* x2, double sign, trk::ScalarSrc num,
+                     trk::ScalarSrc den, float* comb, float* y, double* partials, int cap, int* n_partials,
+                     hipStream_t s) = nullptr;
 };

@@ -228,6 +228,66 @@ __global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, const 
   }
 }
 
+// ------------------------------------------------------------------ CGLS x-update of the fused fast path
+// x_new = x + (gamma/delta) p with gamma, delta possibly still block partials of the producing blur kernels; block 0
+// publishes the two finished scalars; the three norms are left as raw partials [block][3] (summed once, after the solve).
+template <bool HAS_XT>
+__global__ __launch_bounds__(NT) void k_cgls_x_update(int64_t n, ScalarSrc gamma, ScalarSrc delta, const float* __restrict__ x,
+                                                      const float* __restrict__ p, float* __restrict__ x_new,
+                                                      const float* __restrict__ x_true, double* pub_delta,
+                                                      double* pub_gamma, double* __restrict__ partials) {
+  __shared__ double lds[NT / 64];
+  __shared__ double bc[2];
+  if (threadIdx.x < 64) {                          // one wave evaluates both scalars (fixed summation order)
+    const double g = scalar_from_wave(gamma, threadIdx.x), d = scalar_from_wave(delta, threadIdx.x);
+    if (threadIdx.x == 0) {
+      bc[0] = g;
+      bc[1] = d;
+      if (blockIdx.x == 0) {
+        if (pub_gamma) *pub_gamma = g;
+        if (pub_delta) *pub_delta = d;
+      }
+    }
+  }
+  __syncthreads();
+  const float step = (float)(bc[0] / bc[1]);
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = tid; i < n4; i += nth) {
+    const float4 xv = ld4(x, i), pv = ld4(p, i);
+    const float4 d = make_float4(step * pv.x, step * pv.y, step * pv.z, step * pv.w);
+    const float4 xn = make_float4(xv.x + d.x, xv.y + d.y, xv.z + d.z, xv.w + d.w);
+    st4(x_new, i, xn);
+    s0 += (double)xn.x * xn.x + (double)xn.y * xn.y + (double)xn.z * xn.z + (double)xn.w * xn.w;
+    s1 += (double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z + (double)d.w * d.w;
+    if (HAS_XT) {
+      const float4 t = ld4(x_true, i);
+      const double e0 = (double)xn.x - t.x, e1 = (double)xn.y - t.y, e2 = (double)xn.z - t.z, e3 = (double)xn.w - t.w;
+      s2 += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+    }
+  }
+  for (int64_t i = (n4 << 2) + tid; i < n; i += nth) {
+    const float d = step * p[i];
+    const float xn = x[i] + d;
+    x_new[i] = xn;
+    s0 += (double)xn * xn;
+    s1 += (double)d * d;
+    if (HAS_XT) {
+      const double e = (double)xn - x_true[i];
+      s2 += e * e;
+    }
+  }
+  s0 = block_sum<NT>(s0, lds);
+  s1 = block_sum<NT>(s1, lds);
+  if (HAS_XT) s2 = block_sum<NT>(s2, lds);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x * 3 + 0] = s0;
+    partials[blockIdx.x * 3 + 1] = s1;
+    partials[blockIdx.x * 3 + 2] = HAS_XT ? s2 : 0.0;
+  }
+}
+
 // ------------------------------------------------------------------ h[j] = sum_i wt(i) V[j][i] r[i]   (k dots, one pass)
 // grid = (bx, ceil(k/JT)); a block sweeps its share of i for JT rows; partials [bx][k].
 // WPOW: 0 no weight, 1 multiply by w, 2 multiply by w^2.
@@ -538,6 +598,26 @@ int trk_cgls_update_xr(int64_t n, int64_t m, const double* gamma, const double* 
 #undef CU
   TRK_LAUNCH_CHECK();
   return finalize_sums(part, grid, 3, 3, sums, s);
+}
+
+int trk_cgls_x_update(int64_t n, const double* gamma, int gamma_n, const double* delta, int delta_n, const float* x,
+                      const float* p, float* x_new, const float* x_true, double* publish_delta, double* publish_gamma,
+                      double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream st) {
+  TRK_REQUIRE(gamma && delta && gamma_n >= 1 && delta_n >= 1 && x && p && x_new && norm_partials && n_blocks,
+              "trk_cgls_x_update: NULL argument");
+  TRK_REQUIRE(aligned16(x) && aligned16(p) && aligned16(x_new) && (!x_true || aligned16(x_true)),
+              "trk_cgls_x_update: vectors must be 16-byte aligned");
+  const int grid = stream_grid(n);
+  TRK_REQUIRE(grid <= capacity_blocks, "trk_cgls_x_update: partial buffer too small (%d blocks needed)", grid);
+  *n_blocks = grid;
+  const ScalarSrc g{gamma, gamma_n}, d{delta, delta_n};
+  hipStream_t s = (hipStream_t)st;
+  if (x_true)
+    hipLaunchKernelGGL((k_cgls_x_update<true>), dim3(grid), dim3(NT), 0, s, n, g, d, x, p, x_new, x_true, publish_delta, publish_gamma, norm_partials);
+  else
+    hipLaunchKernelGGL((k_cgls_x_update<false>), dim3(grid), dim3(NT), 0, s, n, g, d, x, p, x_new, x_true, publish_delta, publish_gamma, norm_partials);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
 }
 
 int trk_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* w2, double* h, trk_stream st) {

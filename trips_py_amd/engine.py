@@ -192,6 +192,34 @@ class HipEngine:
                                          None if x_true is None else x_true.data_ptr(), _ptr(sums), self.stream())
         _lib.check(rc, "trk_cgls_update_xr")
 
+    # ------------------------------------------------------------------ fused CGLS fast path (include/trk.h)
+    def op_can_fuse(self, handle):
+        can = ctypes.c_int(0)
+        _lib.check(self.lib.trk_op_fused_caps(handle, ctypes.byref(can)), "trk_op_fused_caps")
+        return bool(can.value)
+
+    def op_apply_fused(self, handle, transpose, x1, x2, sign, num, num_n, den, den_n, comb, y, partials, capacity):
+        n = ctypes.c_int(0)
+        rc = self.lib.trk_op_apply_fused(handle, int(bool(transpose)), x1.data_ptr(), x2.data_ptr(), float(sign), _ptr(num),
+                                         int(num_n), _ptr(den), int(den_n), comb.data_ptr(), y.data_ptr(), _ptr(partials),
+                                         int(capacity), ctypes.byref(n), self.stream())
+        _lib.check(rc, "trk_op_apply_fused")
+        return n.value
+
+    def cgls_x_update(self, gamma, gamma_n, delta, delta_n, x, p, x_new, x_true, pub_delta, pub_gamma, partials, capacity):
+        n = ctypes.c_int(0)
+        rc = self.lib.trk_cgls_x_update(x.numel(), _ptr(gamma), int(gamma_n), _ptr(delta), int(delta_n), x.data_ptr(),
+                                        p.data_ptr(), x_new.data_ptr(), None if x_true is None else x_true.data_ptr(),
+                                        _ptr(pub_delta), _ptr(pub_gamma), _ptr(partials), int(capacity), ctypes.byref(n),
+                                        self.stream())
+        _lib.check(rc, "trk_cgls_x_update")
+        return n.value
+
+    def finalize_batched(self, partials, nblocks, nvals, batches, out, out_stride):
+        rc = self.lib.trk_finalize_batched(_ptr(partials), int(nblocks), int(nvals), int(batches), _ptr(out), int(out_stride),
+                                           self.stream())
+        _lib.check(rc, "trk_finalize_batched")
+
     # ------------------------------------------------------------------ tall-skinny basis ops (row-per-vector V[k_max, n])
     def gemv_t(self, V, k, r, out_h, w2=None):
         """out_h[j] = sum_i w2[i] V[j,i] r[i]  for j < k (local sums)."""

@@ -75,6 +75,96 @@ class CGLSRun:
         return Sh[0], Sh[5:5 * (self.k + 1)].reshape(self.k, 5)
 
 
+class CGLSRunFused(CGLSRun):
+    """The same recurrence in three launches per iteration and no reduction-finalize launches, for operators with a
+    fused apply (trk_op_apply_fused: the separable blur):
+
+        K1  w = A (t + (gamma_k/gamma_{k-1}) p_old)  [p_new written out]   + ||w||^2 partials
+        K2  x += (gamma/delta) p_new                                        + norm partials; publishes delta, gamma
+        K3  t = A^T (r_old - (gamma/delta) w)        [r_new written out]   + ||t||^2 partials
+
+    p and r are double-buffered (a band of the blur kernel reads its neighbours' halo rows of the old vector while they
+    write the new one).  11 vector passes per iteration instead of 13, 3 launches instead of 7.  Single rank, tol = 0
+    (nothing visits the host until the end)."""
+
+    PCAP = 4096                            # room for the producers' block partials
+
+    @staticmethod
+    def usable(A, eng):
+        return (getattr(eng, "is_native", False) and eng.world == 1 and hasattr(A, "_h") and A.shape[0] == A.shape[1]
+                and eng.op_can_fuse(A._h))
+
+    def __init__(self, A, b, x0, max_iter, x_true=None, history=True):
+        self.A = A = as_operator(A)
+        self.eng = eng = A.engine
+        m, n = A.shape
+        self.max_iter = max_iter = int(max_iter)
+        self.keep = bool(history)
+        self.bv = eng.to_vec(b, m)
+        self.xt = None if x_true is None else eng.to_vec(x_true, n)
+        x_start = eng.to_vec(x0, n)
+        if self.keep:
+            history_fits(eng, max_iter, n, "CGLS xHistory")
+            self.X = eng.empty_basis(max_iter, n)
+        else:
+            self.X = eng.empty_basis(2, n)
+        self.R = eng.empty_basis(2, m)     # r ping-pong
+        self.P = eng.empty_basis(2, n)     # p ping-pong
+        self.P.zero_()                     # the first K1 multiplies p_old by 0: it must be finite
+        self.t, self.w = eng.empty(n), eng.empty(m)
+        self.S = S = eng.scalars(5 * (max_iter + 1))
+        self.PG = eng.scalars(self.PCAP)   # ||t||^2 partials (gamma)
+        self.PD = eng.scalars(self.PCAP)   # ||w||^2 partials (delta)
+        self.NP = eng.scalars(3 * 1024 * max_iter)   # norm partials of every iteration, summed once at the end
+        self.dist = False
+        self.k = 0
+        self.n_g = self.n_np = 0
+        # r0 = b - A x0 ; t0 = A^T r0 with raw ||t0||^2 partials: K3 form with x1 = b, x2 = A x0, cb = -1
+        A.apply(x_start, out=self.w)
+        self.n_g = eng.op_apply_fused(A._h, True, self.bv, self.w, -1.0, None, 0, None, 0, self.R[0], self.t,
+                                      self.PG.ref(0), self.PCAP)
+        self.x_cur = x_start
+        self._final = False
+
+    def step(self):
+        eng, A, S = self.eng, self.A, self.S
+        self.k += 1
+        k = self.k
+        b = 5 * k
+        p_old, p_new = self.P[(k - 1) & 1], self.P[k & 1]
+        r_old, r_new = self.R[(k - 1) & 1], self.R[k & 1]
+        gprev = S.ref(0) if k <= 2 else S.ref(5 * (k - 2) + 1)     # gamma_{k-2}, published by K2 of iteration k-1
+        # K1: p_k = t + (gamma_{k-1}/gamma_{k-2}) p_{k-1} ; w = A p_k
+        n_d = eng.op_apply_fused(A._h, False, self.t, p_old, 0.0 if k == 1 else 1.0, self.PG.ref(0), self.n_g, gprev, 1,
+                                 p_new, self.w, self.PD.ref(0), self.PCAP)
+        # K2: x_k = x_{k-1} + (gamma_{k-1}/delta_k) p_k ; publishes delta_k -> S[5k], gamma_{k-1} -> S[5(k-1)+1] (S[0] for k = 1)
+        x_new = self.slot(k - 1)
+        gpub = S.ref(0) if k == 1 else S.ref(b - 4)
+        self.n_np = eng.cgls_x_update(self.PG.ref(0), self.n_g, self.PD.ref(0), n_d, self.x_cur, p_new, x_new, self.xt,
+                                      S.ref(b), gpub, self.NP.ref(3 * self.n_np * (k - 1)), 1024)
+        # K3: r_k = r_{k-1} - (gamma_{k-1}/delta_k) w ; t = A^T r_k ; ||t||^2 partials = gamma_k
+        self.n_g = eng.op_apply_fused(A._h, True, r_old, self.w, -1.0, gpub, 1, S.ref(b), 1, r_new, self.t,
+                                      self.PG.ref(0), self.PCAP)
+        self.x_cur = x_new
+
+    def _finish(self):
+        """Sum the norm partials of all iterations (one launch) and the last gamma (one launch)."""
+        if self.k == 0 or self._final == self.k:
+            return
+        eng, S, k = self.eng, self.S, self.k
+        eng.finalize_batched(self.NP.ref(0), self.n_np, 3, k, S.ref(7), 5)        # -> S[5i+2 .. 5i+4], i = 1..k
+        eng.finalize_batched(self.PG.ref(0), self.n_g, 1, 1, S.ref(5 * k + 1), 1)  # gamma_k
+        self._final = k
+
+    def row(self, k):
+        raise RuntimeError("the fused CGLS path publishes its norms after the solve (tol = 0 only)")
+
+    def rows(self):
+        self._finish()
+        Sh = self.S.host()
+        return Sh[0], Sh[5:5 * (self.k + 1)].reshape(self.k, 5)
+
+
 def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
     """Conjugate Gradient Least Squares.
 
@@ -86,8 +176,10 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
         # the reference would fail at `shrink = norm_x/xmax` (:84) with norm_x undefined
         raise UnboundLocalError("CGLS with max_iter <= 0: the reference leaves norm_x undefined (CGLS.py:84)")
     fmt = Formatter(b)
-    run = CGLSRun(A, b, x0, max_iter, x_true, kwargs.get("history", True))
+    A = as_operator(A)
     sync_each = (tol != 0)
+    fused = (not sync_each) and kwargs.get("fused", True) and CGLSRunFused.usable(A, A.engine)
+    run = (CGLSRunFused if fused else CGLSRun)(A, b, x0, max_iter, x_true, kwargs.get("history", True))
     nt0 = None
     stop = False
     while run.k < run.max_iter and not stop:
