@@ -65,6 +65,11 @@ int trk_blur2d_create(const double* psf_host, int kh, int kw, int nx, int ny, tr
  * the /N scaling of trips/utilities/io.py:392-399.  Image N x N row-major; sinogram
  * (n_ang, n_det) row-major.  PARITY UNPINNED (astra-toolbox is absent; see oracle/cpu_ref.py). */
 int trk_radon2d_create(int N, int n_det, const double* angles_host, int n_ang, double scale, trk_op** out);
+/* The same projector for a DYNAMIC problem: n_frames time frames of N x N, frame t seen under its own n_ang_per_frame
+ * angles (angles_host frame-major).  Equals pylops.BlockDiag of the per-frame operators (io.py:391-420) but runs every
+ * frame in one launch.  x: frame-major images; y: (frame, angle, detector). */
+int trk_radon2d_dynamic_create(int N, int n_det, const double* angles_host, int n_frames, int n_ang_per_frame,
+                               double scale, trk_op** out);
 
 /* First-difference regularisers, matrix-free.  Replace the scipy.sparse matrices of
  * trips/utilities/operators.py:24-36 (2-D: rows x[i,j]-x[i,j+1] then x[i,j]-x[i+1,j]) and :39-45

@@ -124,3 +124,23 @@ def test_radon_invariants(N, na):
     sd = (R @ disc.reshape(-1)).reshape(na, N) * N
     assert np.allclose(sd.sum(axis=1), disc.sum(), rtol=2e-2)
     assert np.all(np.abs(sd[:, N // 2 - 1:N // 2 + 1].mean(axis=1) - 2 * rad) < 1.5)
+
+
+def test_dynamic_radon_equals_blockdiag_of_frames():
+    """BlockDiagOp of same-geometry Radon frames runs as ONE handle (trk_radon2d_dynamic_create): identical to applying the
+    per-frame operators one by one, and to the oracle's block-diagonal operator."""
+    from oracle import cpu_ref as O
+    from trips_py_amd.operators import BlockDiagOp, Radon2DParallel
+    N, nt, na = 48, 5, 9
+    angs = [np.deg2rad(t + 20.0 * np.arange(na)) for t in range(nt)]
+    frames = [Radon2DParallel(N, a) for a in angs]
+    F = BlockDiagOp(frames)
+    rng = np.random.default_rng(3)
+    x = rng.random(nt * N * N)
+    y = rng.standard_normal(F.shape[0])
+    per_f = np.concatenate([frames[t] @ x[t * N * N:(t + 1) * N * N] for t in range(nt)])
+    per_a = np.concatenate([frames[t].T @ y[t * na * N:(t + 1) * na * N] for t in range(nt)])
+    assert np.array_equal(F @ x, per_f) and np.array_equal(F.T @ y, per_a)
+    Fo = O.BlockDiag([O.Radon2D(N, a) for a in angs])
+    f = lambda v: v.astype(np.float32).astype(np.float64)
+    assert relerr(F @ x, Fo @ f(x)) < 2e-5 and relerr(F.T @ y, Fo.T @ f(y)) < 2e-5

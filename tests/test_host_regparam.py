@@ -47,3 +47,17 @@ def test_hybrid_modified_gcv():
     for i, lam in enumerate(g["lams"]):
         assert np.isclose(gcv_function(lam, np.diag(s), np.eye(k), rhs, "modified", m), std_num[i] / g["gcv_den_mod"][i], rtol=1e-9)
     assert np.isclose(generalized_crossvalidation(np.diag(s), np.eye(k), rhs, "modified", m), float(g["lam_gcv_mod"]), rtol=1e-6)
+
+
+def test_diagonal_fast_path_equals_general_gcv():
+    import numpy as np
+    from trips_py_amd.reg_param.gcv import gcv_function, gcv_function_diag
+    rng = np.random.default_rng(0)
+    k = 9
+    s = np.sort(rng.random(k))[::-1] + 0.01
+    rhs = rng.standard_normal(k)
+    for lam in (1e-9, 1e-5, 1e-2, 3.0):
+        for variant, m in (("standard", None), ("modified", 400)):
+            a = gcv_function(lam, np.diag(s), np.eye(k), rhs, variant, m)
+            b = gcv_function_diag(lam, s, rhs, variant, m)
+            assert np.isclose(a, b, rtol=1e-10)

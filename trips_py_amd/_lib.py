@@ -85,6 +85,7 @@ SIGNATURES = {
     "trk_device_info": (c_int, [ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "trk_blur2d_create": (c_int, [ctypes.POINTER(c_dbl), c_int, c_int, c_int, c_int, ctypes.POINTER(c_op)]),
     "trk_radon2d_create": (c_int, [c_int, c_int, ctypes.POINTER(c_dbl), c_int, c_dbl, ctypes.POINTER(c_op)]),
+    "trk_radon2d_dynamic_create": (c_int, [c_int, c_int, ctypes.POINTER(c_dbl), c_int, c_int, c_dbl, ctypes.POINTER(c_op)]),
     "trk_deriv2d_create": (c_int, [c_int, ctypes.POINTER(c_op)]),
     "trk_spacetime_create": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_op)]),
     "trk_spacetime_set_halo": (c_int, [c_op, c_f32p, c_f32p]),

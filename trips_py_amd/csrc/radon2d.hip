@@ -36,15 +36,18 @@ struct AngleParam {
 };
 
 struct RadonImpl {
-  int N, nd, na;
-  AngleParam* ang_dev;
-  float* xT;  // N*N transposed image (forward, mode-1 angles); owned by the handle (non-reentrant across streams)
+  int N, nd, na;   // na = angles PER FRAME
+  int nt;          // time frames sharing one launch (block-diagonal dynamic operator, io.py:391-420); 1 = static
+  AngleParam* ang_dev;   // nt*na entries, frame-major
+  float* xT;  // nt*N*N transposed images (forward, mode-1 angles); owned by the handle (non-reentrant across streams)
   int n_mode1;
 };
 
 // ---------------------------------------------------------------------------------------- transpose (LDS tile 32x33)
 __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in, float* __restrict__ out, int N) {
   __shared__ float tile[32][33];
+  in += (int64_t)blockIdx.z * N * N;
+  out += (int64_t)blockIdx.z * N * N;
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
   for (int r = ty; r < 32; r += 8) {
@@ -62,11 +65,12 @@ __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in,
 // grid = (ceil(nd/64), n_ang, batch) ; block = 256 = 64 detectors x 4 marching quarters
 __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img, const float* __restrict__ imgT,
                                                    int64_t ld_img, float* __restrict__ sino, int64_t ld_sino, int N,
-                                                   int nd, const AngleParam* __restrict__ ang) {
+                                                   int nd, const AngleParam* __restrict__ ang, int na_per_frame) {
   __shared__ float part[4][64];
-  const int a = blockIdx.y;
+  const int a = blockIdx.y;                       // global angle index (frame-major)
   const AngleParam p = ang[a];
-  const float* __restrict__ I = (p.mode ? imgT : img) + (int64_t)blockIdx.z * ld_img;
+  const int frame = a / na_per_frame;
+  const float* __restrict__ I = (p.mode ? imgT : img) + (int64_t)blockIdx.z * ld_img + (int64_t)frame * N * N;
   const int lane = threadIdx.x & 63, q4 = threadIdx.x >> 6;
   const int d = blockIdx.x * 64 + lane;
   const float s = (float)d - 0.5f * (float)(nd - 1);
@@ -105,7 +109,9 @@ __global__ __launch_bounds__(256) void k_radon_adj(const float* __restrict__ sin
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)N * N) return;
   const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
-  const float* __restrict__ S = sino + (int64_t)blockIdx.y * ld_sino;
+  const int frame = blockIdx.y;                   // blockIdx.y = time frame, blockIdx.z = batch vector
+  const float* __restrict__ S = sino + (int64_t)blockIdx.z * ld_sino + (int64_t)frame * na * nd;
+  ang += (int64_t)frame * na;
   const float sdh = 0.5f * (float)(nd - 1);
   float acc = 0.f;
   for (int a = 0; a < na; ++a) {
@@ -133,35 +139,35 @@ __global__ __launch_bounds__(256) void k_radon_adj(const float* __restrict__ sin
     }
     acc = fmaf(p.wgt, sum, acc);
   }
-  img[(int64_t)blockIdx.y * ld_img + idx] = acc;
+  img[(int64_t)blockIdx.z * ld_img + (int64_t)frame * N * N + idx] = acc;
 }
 
 int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
                 hipStream_t s) {
   auto* im = static_cast<RadonImpl*>(op->impl);
-  const int N = im->N, nd = im->nd, na = im->na;
+  const int N = im->N, nd = im->nd, na = im->na, nt = im->nt;
   TimerScope tm(op->timer, op->timer_which, tr, s);
   if (!tr) {
     for (int b = 0; b < batch; ++b) {  // the transposed copy is per vector
       const float* xb = x + (int64_t)b * ldx;
       if (im->n_mode1 > 0) {
-        dim3 g(ceil_div(N, 32), ceil_div(N, 32));
+        dim3 g(ceil_div(N, 32), ceil_div(N, 32), nt);
         hipLaunchKernelGGL(k_transpose, g, dim3(256), 0, s, xb, im->xT, N);
       }
-      dim3 grid(ceil_div(nd, 64), na, 1);
-      hipLaunchKernelGGL(k_radon_fwd, grid, dim3(256), 0, s, xb, im->xT, (int64_t)0, y + (int64_t)b * ldy, (int64_t)0, N, nd, im->ang_dev);
+      dim3 grid(ceil_div(nd, 64), nt * na, 1);
+      hipLaunchKernelGGL(k_radon_fwd, grid, dim3(256), 0, s, xb, im->xT, (int64_t)0, y + (int64_t)b * ldy, (int64_t)0, N, nd, im->ang_dev, na);
       TRK_LAUNCH_CHECK();
     }
   } else {
-    dim3 grid(ceil_div((int64_t)N * N, 256), batch);
+    dim3 grid(ceil_div((int64_t)N * N, 256), nt, batch);
     hipLaunchKernelGGL(k_radon_adj, grid, dim3(256), 0, s, x, ldx, y, ldy, N, nd, na, im->ang_dev);
     TRK_LAUNCH_CHECK();
   }
   tm.stop();
   if (sumsq) {
     // the output is small next to the tap work: one extra streaming pass for the fused norm
-    const int64_t nout = tr ? (int64_t)N * N : (int64_t)na * nd;
-    if (batch == 1 || (tr ? ldy == nout : ldy == nout)) return trk_nrm2sq(y, nout * batch, sumsq, (trk_stream)s);
+    const int64_t nout = tr ? (int64_t)nt * N * N : (int64_t)nt * na * nd;
+    if (batch == 1 || ldy == nout) return trk_nrm2sq(y, nout * batch, sumsq, (trk_stream)s);
     return fail(TRK_EUNSUPPORTED, "radon: fused sum of squares needs contiguous batch outputs");
   }
   return TRK_OK;
@@ -176,9 +182,8 @@ void radon_destroy(trk_op* op) {
 
 }  // namespace
 
-extern "C" int trk_radon2d_create(int N, int n_det, const double* angles, int n_ang, double scale, trk_op** out) {
-  TRK_REQUIRE(out && angles, "trk_radon2d_create: NULL argument");
-  TRK_REQUIRE(N >= 1 && n_det >= 1 && n_ang >= 1, "trk_radon2d_create: sizes must be >= 1");
+static int radon_create_impl(int N, int n_det, const double* angles, int nt, int na, double scale, trk_op** out) {
+  const int n_ang = nt * na;
   std::vector<AngleParam> h(n_ang);
   const double half = 0.5 * (N - 1);
   int n1 = 0;
@@ -201,15 +206,28 @@ extern "C" int trk_radon2d_create(int N, int n_det, const double* angles, int n_
     }
     h[a] = p;
   }
-  auto* im = new RadonImpl{N, n_det, n_ang, nullptr, nullptr, n1};
+  auto* im = new RadonImpl{N, n_det, na, nt, nullptr, nullptr, n1};
   hipError_t e = hipMalloc(&im->ang_dev, sizeof(AngleParam) * n_ang);
   if (e == hipSuccess) e = hipMemcpy(im->ang_dev, h.data(), sizeof(AngleParam) * n_ang, hipMemcpyHostToDevice);
-  if (e == hipSuccess && n1 > 0) e = hipMalloc(&im->xT, sizeof(float) * (size_t)N * N);
+  if (e == hipSuccess && n1 > 0) e = hipMalloc(&im->xT, sizeof(float) * (size_t)nt * N * N);
   if (e != hipSuccess) {
     trk_op tmp{2, 0, 0, im, nullptr, nullptr, nullptr, 0};
     radon_destroy(&tmp);
     return fail(TRK_EHIP, "trk_radon2d_create: %s", hipGetErrorString(e));
   }
-  *out = new trk_op{2, (int64_t)n_ang * n_det, (int64_t)N * N, im, radon_apply, radon_destroy, nullptr, 0};
+  *out = new trk_op{2, (int64_t)n_ang * n_det, (int64_t)nt * N * N, im, radon_apply, radon_destroy, nullptr, 0};
   return TRK_OK;
+}
+
+extern "C" int trk_radon2d_create(int N, int n_det, const double* angles, int n_ang, double scale, trk_op** out) {
+  TRK_REQUIRE(out && angles, "trk_radon2d_create: NULL argument");
+  TRK_REQUIRE(N >= 1 && n_det >= 1 && n_ang >= 1, "trk_radon2d_create: sizes must be >= 1");
+  return radon_create_impl(N, n_det, angles, 1, n_ang, scale, out);
+}
+
+extern "C" int trk_radon2d_dynamic_create(int N, int n_det, const double* angles, int n_frames, int n_ang_per_frame,
+                                          double scale, trk_op** out) {
+  TRK_REQUIRE(out && angles, "trk_radon2d_dynamic_create: NULL argument");
+  TRK_REQUIRE(N >= 1 && n_det >= 1 && n_frames >= 1 && n_ang_per_frame >= 1, "trk_radon2d_dynamic_create: sizes must be >= 1");
+  return radon_create_impl(N, n_det, angles, n_frames, n_ang_per_frame, scale, out);
 }

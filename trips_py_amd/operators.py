@@ -267,9 +267,19 @@ class BlockDiagOp(_HandleOperator):
     def __init__(self, ops, engine=None):
         engine = engine if engine is not None else ops[0].engine
         self.ops = list(ops)
-        arr = (ctypes.c_void_p * len(self.ops))(*[o._h for o in self.ops])
         h = ctypes.c_void_p()
-        _lib.check(engine.lib.trk_blockdiag_create(arr, len(self.ops), ctypes.byref(h)), "trk_blockdiag_create")
+        first = self.ops[0]
+        same_radon = all(isinstance(o, Radon2DParallel) and o.N == first.N and o.n_det == first.n_det
+                         and o.scale == first.scale and len(o.angles) == len(first.angles) for o in self.ops)
+        if same_radon and len(self.ops) > 1:
+            # frames of one dynamic tomography problem: a single handle runs all frames per launch
+            ang = np.concatenate([o.angles for o in self.ops])
+            arr, p = _dbl_array(ang)
+            _lib.check(engine.lib.trk_radon2d_dynamic_create(first.N, first.n_det, p, len(self.ops), len(first.angles),
+                                                             first.scale, ctypes.byref(h)), "trk_radon2d_dynamic_create")
+        else:
+            arr = (ctypes.c_void_p * len(self.ops))(*[o._h for o in self.ops])
+            _lib.check(engine.lib.trk_blockdiag_create(arr, len(self.ops), ctypes.byref(h)), "trk_blockdiag_create")
         super().__init__(h, engine)
 
 

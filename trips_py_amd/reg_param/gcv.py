@@ -18,8 +18,25 @@ def gcv_function(lam, R_A, R_L, rhs, variant="standard", fullsize=None):
     return num / (m_eff - np.trace(R_A @ inv)) ** 2
 
 
+def gcv_function_diag(lam, s, rhs, variant="standard", fullsize=None):
+    """The same G(lambda) when R_A = diag(s) (k values, possibly fewer than len(rhs)) and R_L = I — the hybrid solvers'
+    case (SVD of the projected matrix, Hybrid_LSQR.py:81-84, Hybrid_GMRES.py:55-58): O(k) instead of a k x k solve.
+        x_l = s*rhs/(s^2+lam)  ->  R_A x_l - rhs = -lam/(s^2+lam) * rhs ;  trace = sum s^2/(s^2+lam)."""
+    f = s * s / (s * s + lam)
+    num = float(np.sum(((1.0 - f) * rhs) ** 2))
+    m_eff = fullsize if variant == "modified" else len(s)
+    return num / (m_eff - float(np.sum(f))) ** 2
+
+
 def generalized_crossvalidation(R_A, R_L, rhs, variant="standard", fullsize=None, **_ignored):
     """lambda = argmin G over [1e-9, 1e2] by scipy's bounded Brent search, same settings as gcv.py:94-95."""
     rhs = np.asarray(rhs, dtype=np.float64).reshape(-1)
-    fun = lambda lam: gcv_function(lam, R_A, R_L, rhs, variant, fullsize)
+    R_A, R_L = np.asarray(R_A), np.asarray(R_L)
+    k = R_A.shape[0]
+    if (R_A.shape == (k, k) and R_L.shape == (k, k) and not np.any(R_A - np.diag(np.diag(R_A)))
+            and not np.any(R_L - np.eye(k))):
+        s = np.diag(R_A).copy()
+        fun = lambda lam: gcv_function_diag(lam, s, rhs, variant, fullsize)
+    else:
+        fun = lambda lam: gcv_function(lam, R_A, R_L, rhs, variant, fullsize)
     return sopt.fminbound(fun, 1e-9, 1e2, xtol=1e-12, maxfun=1000, disp=0)
