@@ -2,6 +2,7 @@
 // 16-byte-per-lane coalesced loads, grid-stride, fp32 storage, fp64 accumulation, wave64 __shfl reductions,
 // one double of block partial per workgroup, summed in a fixed order by core.hip's finalize kernel.
 #include "trk_internal.h"
+#include <cstdlib>
 
 using namespace trk;
 
@@ -511,6 +512,106 @@ __global__ __launch_bounds__(NT) void k_wgram(const float* __restrict__ W, int64
     }
 }
 
+// ------------------------------------------------------------------ weighted Gram, LDS-staged (every row read once)
+// Rows of the augmented matrix  [ w*W_0 ; ... ; w*W_{k-1} ; b ; w*b ]  for a chunk of CH elements are staged in LDS (fp32),
+// then every thread owns one 4x4 tile of row pairs (upper triangle) and a residue class of the chunk's elements and
+// accumulates 16 fp64 FMAs per element.  One pass gives G = W diag(w^2) W^T, c1 = W (w*b), c2 = W (w^2*b) and ||w*b||^2.
+// HBM traffic 4*m*(k+2) bytes; LDS rows are padded by one float (row stride CH+1) so that the 8 row reads of a wave's
+// different tiles fall on different banks.  Partials: [block][KA*KA] (KA = k + 2 when b is given).
+constexpr int WG_TILE = 4;
+
+template <bool HAS_W, bool HAS_B>
+__global__ __launch_bounds__(NT) void k_wgram2(const float* __restrict__ W, int64_t ld, int k, int64_t m,
+                                               const float* __restrict__ w, const float* __restrict__ bvec, int CH,
+                                               double* __restrict__ partials) {
+  extern __shared__ float smem[];
+  const int KA = k + (HAS_B ? 2 : 0);
+  const int nt = (KA + WG_TILE - 1) / WG_TILE, KP = nt * WG_TILE;
+  const int ntu = nt * (nt + 1) / 2;
+  const int RS = CH + 1;                                  // padded row stride (floats)
+  const int nslice = NT / ntu;                            // >= 1 (host guarantees ntu <= NT)
+  const int pair = threadIdx.x % ntu, slice = threadIdx.x / ntu;
+  const bool worker = slice < nslice;
+  int ta = 0, rem = pair;
+  while (rem >= nt - ta) {
+    rem -= nt - ta;
+    ++ta;
+  }
+  const int a0 = ta * WG_TILE, b0 = (ta + rem) * WG_TILE;
+  double acc[WG_TILE][WG_TILE];
+#pragma unroll
+  for (int a = 0; a < WG_TILE; ++a)
+#pragma unroll
+    for (int b = 0; b < WG_TILE; ++b) acc[a][b] = 0.0;
+
+  const int64_t nchunk = (m + CH - 1) / CH;
+  for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+    const int64_t e0 = c * CH;
+    const int len = (int)((m - e0 < CH) ? (m - e0) : CH);
+    // stage: row r, element e  ->  smem[r*RS + e]
+    for (int idx = threadIdx.x; idx < KP * CH; idx += NT) {
+      const int r = idx / CH, e = idx - r * CH;
+      float v = 0.f;
+      if (e < len && r < KA) {
+        const float wv = HAS_W ? w[e0 + e] : 1.f;
+        if (r < k) v = W[(int64_t)r * ld + e0 + e] * wv;
+        else if (r == k) v = bvec[e0 + e];
+        else v = bvec[e0 + e] * wv;
+      }
+      smem[r * RS + e] = v;
+    }
+    __syncthreads();
+    if (worker) {
+      for (int e = slice; e < len; e += nslice) {
+        double av[WG_TILE], bw[WG_TILE];
+#pragma unroll
+        for (int a = 0; a < WG_TILE; ++a) av[a] = (double)smem[(a0 + a) * RS + e];
+#pragma unroll
+        for (int b = 0; b < WG_TILE; ++b) bw[b] = (double)smem[(b0 + b) * RS + e];
+#pragma unroll
+        for (int a = 0; a < WG_TILE; ++a)
+#pragma unroll
+          for (int b = 0; b < WG_TILE; ++b) acc[a][b] = fma(av[a], bw[b], acc[a][b]);
+      }
+    }
+    __syncthreads();
+  }
+  // reduce the slices of each tile pair in a fixed order through LDS (reusing the staging area), then write the block partial
+  double* red = reinterpret_cast<double*>(smem);          // [NT][16]
+#pragma unroll
+  for (int a = 0; a < WG_TILE; ++a)
+#pragma unroll
+    for (int b = 0; b < WG_TILE; ++b) red[threadIdx.x * 16 + a * WG_TILE + b] = worker ? acc[a][b] : 0.0;
+  __syncthreads();
+  double* __restrict__ out = partials + (size_t)blockIdx.x * KA * KA;
+  for (int idx = threadIdx.x; idx < ntu * 16; idx += NT) {
+    const int pr = idx / 16, q = idx - pr * 16;
+    double t = 0.0;
+    for (int sl = 0; sl < nslice; ++sl) t += red[(sl * ntu + pr) * 16 + q];
+    int pta = 0, prem = pr;
+    while (prem >= nt - pta) {
+      prem -= nt - pta;
+      ++pta;
+    }
+    const int ra = pta * WG_TILE + q / WG_TILE, rb = (pta + prem) * WG_TILE + (q % WG_TILE);
+    if (ra < KA && rb < KA) {
+      out[(size_t)ra * KA + rb] = t;
+      out[(size_t)rb * KA + ra] = t;
+    }
+  }
+}
+
+// scatter the augmented Gram [KA x KA] into G (k x k), c1, c2 (and optionally ||w b||^2)
+__global__ void k_wgram_unpack(const double* __restrict__ Ga, int k, int KA, double* __restrict__ G, double* __restrict__ c1,
+                               double* __restrict__ c2) {
+  for (int idx = threadIdx.x; idx < k * k; idx += blockDim.x) G[idx] = Ga[(size_t)(idx / k) * KA + (idx % k)];
+  if (KA > k)
+    for (int a = threadIdx.x; a < k; a += blockDim.x) {
+      c1[a] = Ga[(size_t)a * KA + k];
+      c2[a] = Ga[(size_t)a * KA + k + 1];
+    }
+}
+
 }  // namespace
 
 // ======================================================================================= C ABI
@@ -656,6 +757,36 @@ int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, cons
   TRK_REQUIRE(k >= 1 && k <= 512 && m >= 0 && ld >= m, "trk_wgram: need 1 <= k <= 512, m >= 0, ld >= m");
   TRK_REQUIRE(!b1 || (c1 && c2), "trk_wgram: b1 given but c1/c2 NULL");
   hipStream_t s = (hipStream_t)st;
+  const int KA = k + (b1 ? 2 : 0);
+  const int nt2 = ceil_div(KA, WG_TILE), ntu = nt2 * (nt2 + 1) / 2;
+  // The LDS-staged single-pass kernel reads every row once but is instruction-bound (8 ds_read + 8 cvt per 16 fp64 FMAs):
+  // measured slower than the tile-pair kernel at 4096^2 (k = 3..33: 3.2 ms vs 1.7 ms average), so it is opt-in.
+  static const bool use_lds = getenv("TRK_WGRAM_LDS") != nullptr;
+  if (use_lds && ntu <= NT) {
+    // LDS-staged single pass
+    const int KP = nt2 * WG_TILE;
+    int CH = (KP <= 40) ? 256 : (KP <= 80) ? 128 : 64;
+    size_t lds = (size_t)KP * (CH + 1) * sizeof(float);
+    const size_t red = (size_t)NT * 16 * sizeof(double);
+    if (lds < red) lds = red;
+    int64_t nchunk = (m + CH - 1) / CH;
+    int bx = (int)(nchunk < (int64_t)cu_count() * 2 ? (nchunk > 0 ? nchunk : 1) : (int64_t)cu_count() * 2);
+    if (bx > kMaxPartialBlocks) bx = kMaxPartialBlocks;
+    double* part = nullptr;  // [bx][KA*KA] partials, then the finished augmented Gram
+    const size_t npart = (size_t)bx * KA * KA;
+    if (int rc = scratch_doubles(s, npart + (size_t)KA * KA, &part)) return rc;
+    double* Ga = part + npart;
+#define WG2(HW, HB) hipLaunchKernelGGL((k_wgram2<HW, HB>), dim3(bx), dim3(NT), lds, s, W, ld, k, m, w, b1, CH, part)
+    if (w) { if (b1) WG2(true, true); else WG2(true, false); }
+    else   { if (b1) WG2(false, true); else WG2(false, false); }
+#undef WG2
+    TRK_LAUNCH_CHECK();
+    if (int rc = finalize_sums(part, bx, KA * KA, KA * KA, Ga, s)) return rc;
+    hipLaunchKernelGGL(k_wgram_unpack, dim3(1), dim3(256), 0, s, Ga, k, KA, G, c1, c2);
+    TRK_LAUNCH_CHECK();
+    return TRK_OK;
+  }
+  // many rows: tile-pair form (re-reads W once per tile pair)
   const int nt = ceil_div(k, TG);
   const int npairs = nt * (nt + 1) / 2;
   int bx = stream_grid(m);
