@@ -757,3 +757,56 @@ def mmgks(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     if x_true is not None:
         info["relError"] = _rre(hist, x_true)
     return x, info
+
+
+# =====================================================================================
+# SURVEY §8f rank 2 — one-shot projection solvers
+# =====================================================================================
+def golub_kahan_tikhonov(A, b, n_iter=3, regparam="gcv", delta=None, eta=1.01):
+    """trips/solvers/GK_Tikhonov.py:23-76.  NOTE the reference ignores n_iter: golub_kahan(A, b, n_iter=3) (:60)."""
+    b = np.asarray(b, dtype=np.float64).reshape(-1, 1)
+    U, B, V = golub_kahan(A, b, 3)
+    bhat = U.T @ b
+    k = B.shape[1]
+    if regparam == "gcv":
+        Qb, s, _ = sla.svd(B, full_matrices=False)
+        lam = gcv_choose(Qb, np.diag(s), np.eye(k), bhat, variant="modified", fullsize=A.shape[0])
+    elif regparam == "dp":
+        lam = discrepancy_choose(U, B, np.eye(k), b, delta, eta, L_is_identity=True)
+    else:
+        lam = regparam
+    y = _tik_lstsq(B, np.eye(k), lam, bhat)
+    return V @ y, lam
+
+
+def arnoldi_tikhonov(A, b, n_iter=3, regparam="gcv", delta=None, eta=1.01):
+    """trips/solvers/A_Tikhonov.py:23-97 (uses the quirky `arnoldi`, decompositions.py:20-116)."""
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("The observation matrix A must be square for this method.")
+    b = np.asarray(b, dtype=np.float64).reshape(-1, 1)
+    Q, H = arnoldi(A, b, n_iter)
+    bhat = Q.T @ b
+    k = H.shape[1]
+    if regparam == "gcv":
+        Qh, s, _ = sla.svd(H, full_matrices=False)
+        lam = gcv_choose(Qh, np.diag(s), np.eye(k), bhat)
+        y = sla.solve(H.T @ H + lam * np.eye(k), H.T @ bhat)
+    elif regparam == "dp":
+        lam = discrepancy_choose(Q, H, np.eye(k), b, delta, eta, L_is_identity=True)
+        y = _tik_lstsq(H, np.eye(k), lam, bhat)
+    else:
+        lam = regparam
+        y = sla.solve(H.T @ H + lam * np.eye(k), H.T @ bhat)
+    return Q[:, :-1] @ y, lam
+
+
+def gmres(A, b, n_iter=3):
+    """trips/solvers/GMRES.py:19-51.  NOTE the reference ignores n_iter (arnoldi(A, b_vec, n_iter=5), :46) and solves
+    lstsq(H.T, H.T @ bhat), i.e. the minimum-norm y in R^{k+1}, then x = V_{k+1} y (:49-50)."""
+    if A.shape[0] != A.shape[1]:
+        raise ValueError("Arnoldi can not be used. The operator is not square")
+    b = np.asarray(b, dtype=np.float64).reshape(-1, 1)
+    Q, H = arnoldi(A, b, 5)
+    bhat = Q.T @ b
+    y = np.linalg.lstsq(H.T, H.T @ bhat, rcond=None)[0]
+    return Q @ y

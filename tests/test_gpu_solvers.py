@@ -131,3 +131,16 @@ def test_history_off_and_torch_io():
     gh = load_golden("hybrid_lsqr_blur32_lam1e-2")
     x, info = S.Hybrid_LSQR(blur(gh), torch.from_numpy(gh["b"].astype(np.float32)).to(dev), 12, 1e-2, history=False)
     assert relerr(x.cpu().numpy(), gh["x"]) < TOL
+
+
+def test_oneshot_solvers():
+    """Golub_Kahan_Tikhonov, Arnoldi_Tikhonov, GMRES vs the reference's outputs."""
+    from trips_py_amd import solvers as S
+    g = load_golden("oneshot_blur32")
+    A = blur(g)
+    for tag, rp, bb, kw in [("lam", 1e-2, g["b"], {}), ("gcv", "gcv", g["b"], {}), ("dp", "dp", g["b_dp"], {"delta": float(g["delta_dp"])})]:
+        x, lam = S.Golub_Kahan_Tikhonov(A, bb, 3, rp, **kw)
+        assert lam_close([lam], [float(g[f"gkt_{tag}_lam"])], 5e-3) and relerr(x, g[f"gkt_{tag}_x"]) < (TOL if tag == "lam" else 1e-4)
+        x, lam = S.Arnoldi_Tikhonov(A, bb, 6, rp, **kw)
+        assert lam_close([lam], [float(g[f"at_{tag}_lam"])], 5e-2) and relerr(x, g[f"at_{tag}_x"]) < (TOL if tag == "lam" else 2e-3)
+    assert relerr(S.GMRES(A, g["b"], 5), g["gmres_x"]) < 1e-4

@@ -138,3 +138,14 @@ def test_reference_error_behaviour(eng):
         S.Hybrid_GMRES(rect, np.ones(rect.shape[0]), 3, 1e-2)
     with pytest.raises(TypeError):
         S.CGLS(np.eye(4), np.ones(4), np.zeros(4), 3, 0)
+
+
+def test_oneshot_solvers(eng):
+    g = load_golden("oneshot_blur32")
+    A = blur(eng, g)
+    for tag, rp, bb, kw in [("lam", 1e-2, g["b"], {}), ("gcv", "gcv", g["b"], {}), ("dp", "dp", g["b_dp"], {"delta": float(g["delta_dp"])})]:
+        x, lam = S.Golub_Kahan_Tikhonov(A, bb, 3, rp, **kw)
+        assert lam_close([lam], [float(g[f"gkt_{tag}_lam"])], 5e-3) and relerr(x, g[f"gkt_{tag}_x"]) < 1e-4
+        x, lam = S.Arnoldi_Tikhonov(A, bb, 6, rp, **kw)
+        assert lam_close([lam], [float(g[f"at_{tag}_lam"])], 5e-2) and relerr(x, g[f"at_{tag}_x"]) < (2e-3 if tag != "lam" else 1e-4)
+    assert relerr(S.GMRES(A, g["b"], 5), g["gmres_x"]) < 1e-4

@@ -246,3 +246,15 @@ def test_radon_oracle_invariants():
     assert np.allclose(sd.sum(axis=1), disc.sum(), rtol=2e-2)
     # central ray of a centred disc of radius 10 is ~ its diameter
     assert np.all(np.abs(sd[:, N // 2 - 1:N // 2 + 1].mean(axis=1) - 20.0) < 1.0)
+
+
+def test_oneshot_solvers():
+    g = load_golden("oneshot_blur32")
+    N = int(g["N"])
+    A = O.Blur2D(g["psf"], N, N)
+    for tag, rp, bb, kw in [("lam", 1e-2, g["b"], {}), ("gcv", "gcv", g["b"], {}), ("dp", "dp", g["b_dp"], {"delta": float(g["delta_dp"])})]:
+        x, lam = O.golub_kahan_tikhonov(A, bb, 3, rp, **kw)
+        assert lam_close([lam], [float(g[f"gkt_{tag}_lam"])], 2e-3) and relerr(x, g[f"gkt_{tag}_x"]) < 1e-7
+        x, lam = O.arnoldi_tikhonov(A, bb, 6, rp, **kw)
+        assert lam_close([lam], [float(g[f"at_{tag}_lam"])], 2e-3) and relerr(x, g[f"at_{tag}_x"]) < (1e-4 if tag == "gcv" else 1e-6)
+    assert relerr(O.gmres(A, g["b"], 5), g["gmres_x"]) < 1e-8

@@ -43,6 +43,9 @@ from trips.solvers.GKS import GKS  # noqa: E402
 from trips.solvers.MMGKS import MMGKS  # noqa: E402
 from trips.solvers.Hybrid_LSQR import Hybrid_LSQR  # noqa: E402
 from trips.solvers.Hybrid_GMRES import Hybrid_GMRES  # noqa: E402
+from trips.solvers.GK_Tikhonov import Golub_Kahan_Tikhonov  # noqa: E402
+from trips.solvers.A_Tikhonov import Arnoldi_Tikhonov  # noqa: E402
+from trips.solvers.GMRES import GMRES  # noqa: E402
 from trips.test_problems.Deblurring2D import Deblurring2D  # noqa: E402
 from trips.test_problems.Deblurring1D import Deblurring1D  # noqa: E402
 from trips.utilities import decompositions as dec  # noqa: E402
@@ -200,6 +203,25 @@ def g4_hybrid():
              n_hist=len(info["xHistory"]), x_it1=info["xHistory"][0])
 
 
+# ----------------------------------------------------------------------------------------- G4b
+def g4b_oneshot():
+    print("G4b one-shot solvers")
+    N = 32
+    A, PSF, x_true, b, delta = blur_problem(N, 61)
+    _, _, _, b1, delta1 = blur_problem(N, 61, noise=0.2)
+    out = {"psf": PSF, "N": N, "b": b, "b_dp": b1, "delta_dp": delta1}
+    for tag, rp, kw, bb in [("lam", 1e-2, {}, b), ("gcv", "gcv", {}, b), ("dp", "dp", {"delta": delta1}, b1)]:
+        x, lam = quiet(Golub_Kahan_Tikhonov, A, bb, 3, rp, **kw)
+        out[f"gkt_{tag}_x"], out[f"gkt_{tag}_lam"] = x, lam
+        x, lam = quiet(Arnoldi_Tikhonov, A, bb, 6, rp, **kw)
+        out[f"at_{tag}_x"], out[f"at_{tag}_lam"] = x, lam
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        out["gmres_x"] = quiet(GMRES, A, b, 5)
+    save("oneshot_blur32", **out)
+
+
 # ----------------------------------------------------------------------------------------- G5
 def g5_gks():
     print("G5 GKS / MMGKS")
@@ -324,6 +346,7 @@ if __name__ == "__main__":
     g2_cgls()
     g3_decomp()
     g4_hybrid()
+    g4b_oneshot()
     g5_gks()
     g6_derivs()
     g7_regparam()

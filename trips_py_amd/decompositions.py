@@ -34,11 +34,10 @@ def golub_kahan(A, b, n_iter, dp_stop=False, **kwargs):
     return gk.U.torch_cols(), gk.B(), gk.V.torch_cols()
 
 
-def arnoldi(A, b, n_iter, dp_stop=False, **kwargs):
-    """NOTE the reference's arnoldi (unlike arnoldi_update) orthogonalises step ii only against Q[:, :ii] — the newest
-    vector Q[:, ii] is skipped and H[ii, ii] stays 0 (decompositions.py:88-94, `range(0, iterations)`).  Reproduced."""
-    if dp_stop:
-        raise NotImplementedError("arnoldi(dp_stop=True) (decompositions.py:104-112) is not implemented on the engine yet")
+def arnoldi_device(A, b, n_iter):
+    """The reference's `arnoldi` on the device: returns (DeviceBasis Q with k+1 vectors, H (k+1) x k host float64).
+    NOTE the reference (unlike arnoldi_update) orthogonalises step ii only against Q[:, :ii] — the newest vector
+    Q[:, ii] is skipped and H[ii, ii] stays 0 (decompositions.py:88-94, `range(0, iterations)`).  Reproduced."""
     A = as_operator(A)
     if A.shape[0] != A.shape[1]:
         raise ValueError("Arnoldi can not be used. The operator is not square")
@@ -70,8 +69,14 @@ def arnoldi(A, b, n_iter, dp_stop=False, **kwargs):
         eng.scale(Coef(1.0, den=S.ref(0), sqrt_den=True), w, Q.next_slot())
         Q.commit()
     k = Q.k
-    Hh = H[:k, :k - 1] if k < n_iter + 1 else H
-    return (Q.numpy() if _fmt_like(b) else Q.torch_cols()), Hh
+    return Q, (H[:k, :k - 1] if k < n_iter + 1 else H)
+
+
+def arnoldi(A, b, n_iter, dp_stop=False, **kwargs):
+    if dp_stop:
+        raise NotImplementedError("arnoldi(dp_stop=True) (decompositions.py:104-112) is not implemented on the engine yet")
+    Q, H = arnoldi_device(A, b, n_iter)
+    return (Q.numpy() if _fmt_like(b) else Q.torch_cols()), H
 
 
 class KrylovArrays(np.ndarray):
