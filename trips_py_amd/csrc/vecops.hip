@@ -601,6 +601,116 @@ __global__ __launch_bounds__(NT) void k_wgram2(const float* __restrict__ W, int6
   }
 }
 
+// ------------------------------------------------------------------ weighted Gram on the matrix cores
+// The one GEMM-shaped contraction of the path (SYRK: G = R R^T, R = the <= 64 augmented rows, m up to 3e7 long) runs on
+// v_mfma_f32_32x32x2_f32: a wave feeds lane l with R[row l&31][element slot l>>5] as BOTH operands (A[i][k] = R_i[e_k],
+// B[k][j] = R_j[e_k]), so one instruction adds two elements to a full 32 x 32 tile of G.  Products are exact fp32 FMAs;
+// the fp32 tile is flushed into fp64 accumulators after every 32 elements (per wave), so the long sum is fp64.
+// Rows are staged per 128-element chunk through LDS with coalesced 16-byte loads (row stride 129 floats: the 32 rows a
+// wave reads at one element fall on 32 different banks).  NTILE = 1: KA <= 32 rows (1 tile); NTILE = 2: KA <= 64 (3 tiles).
+typedef float f16v __attribute__((ext_vector_type(16)));
+
+template <int NTILE, bool HAS_W, bool HAS_B>
+__global__ __launch_bounds__(NT) void k_wgram_mfma(const float* __restrict__ W, int64_t ld, int k, int64_t m,
+                                                   const float* __restrict__ w, const float* __restrict__ bvec,
+                                                   double* __restrict__ partials) {
+  constexpr int KP = 32 * NTILE, CH = 128, RS = CH + 1, CH4 = CH / 4;
+  constexpr int NPAIR = NTILE * (NTILE + 1) / 2;
+  __shared__ float tile[KP * RS];
+  __shared__ double red[3][16][64];
+  const int KA = k + (HAS_B ? 2 : 0);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 31, h = lane >> 5;
+  double accd[NPAIR][16];
+#pragma unroll
+  for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) accd[p][q] = 0.0;
+  const bool vec_ok = ((ld & 3) == 0) && ((reinterpret_cast<uintptr_t>(W) & 15u) == 0) &&
+                      (!HAS_W || (reinterpret_cast<uintptr_t>(w) & 15u) == 0) &&
+                      (!HAS_B || (reinterpret_cast<uintptr_t>(bvec) & 15u) == 0);
+  const int64_t nchunk = (m + CH - 1) / CH;
+  for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+    const int64_t e0 = c * CH;
+    const bool full = vec_ok && (e0 + CH <= m);
+    if (full) {
+      for (int idx = threadIdx.x; idx < KP * CH4; idx += NT) {
+        const int row = idx / CH4, q = idx - row * CH4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row < KA) {
+          float4 wv = make_float4(1.f, 1.f, 1.f, 1.f);
+          if (HAS_W && row != k) wv = ld4(w + e0, q);
+          if (row < k) v = ld4(W + (int64_t)row * ld + e0, q);
+          else v = ld4(bvec + e0, q);
+          v.x *= wv.x;
+          v.y *= wv.y;
+          v.z *= wv.z;
+          v.w *= wv.w;
+        }
+        float* d = &tile[row * RS + 4 * q];
+        d[0] = v.x;
+        d[1] = v.y;
+        d[2] = v.z;
+        d[3] = v.w;
+      }
+    } else {
+      for (int idx = threadIdx.x; idx < KP * CH; idx += NT) {
+        const int row = idx / CH, e = idx - row * CH;
+        float v = 0.f;
+        if (row < KA && e0 + e < m) {
+          const float wv = (HAS_W && row != k) ? w[e0 + e] : 1.f;
+          v = ((row < k) ? W[(int64_t)row * ld + e0 + e] : bvec[e0 + e]) * wv;
+        }
+        tile[row * RS + e] = v;
+      }
+    }
+    __syncthreads();
+    f16v acc[NPAIR];
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[p][q] = 0.f;
+    const int ebase = wave * 32 + h * 16;       // this wave's 32 elements: slot h takes one half
+#pragma unroll 4
+    for (int sidx = 0; sidx < 16; ++sidx) {
+      const float a0 = tile[r * RS + ebase + sidx];
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a0, acc[0], 0, 0, 0);
+      if (NTILE == 2) {
+        const float a1 = tile[(32 + r) * RS + ebase + sidx];
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, a1, acc[1], 0, 0, 0);   // rows of tile 0 x rows of tile 1
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, a1, acc[2], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < NPAIR; ++p)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) accd[p][q] += (double)acc[p][q];
+    __syncthreads();
+  }
+  // combine the 4 waves (fixed order) and write the block partial in matrix order
+  double* __restrict__ out = partials + (size_t)blockIdx.x * KA * KA;
+#pragma unroll
+  for (int p = 0; p < NPAIR; ++p) {
+    if (wave > 0) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) red[wave - 1][q][lane] = accd[p][q];
+    }
+    __syncthreads();
+    if (wave == 0) {
+      const int ti = (p == 2) ? 1 : 0, tj = (p == 0) ? 0 : 1;     // pair 0: (0,0)  1: (0,1)  2: (1,1)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const double t = ((accd[p][q] + red[0][q][lane]) + red[1][q][lane]) + red[2][q][lane];
+        const int row = ti * 32 + (q & 3) + 8 * (q >> 2) + 4 * h, col = tj * 32 + r;   // MFMA 32x32 C/D map
+        if (row < KA && col < KA) {
+          out[(size_t)row * KA + col] = t;
+          if (ti != tj) out[(size_t)col * KA + row] = t;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 // scatter the augmented Gram [KA x KA] into G (k x k), c1, c2 (and optionally ||w b||^2)
 __global__ void k_wgram_unpack(const double* __restrict__ Ga, int k, int KA, double* __restrict__ G, double* __restrict__ c1,
                                double* __restrict__ c2) {
@@ -759,6 +869,30 @@ int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, cons
   hipStream_t s = (hipStream_t)st;
   const int KA = k + (b1 ? 2 : 0);
   const int nt2 = ceil_div(KA, WG_TILE), ntu = nt2 * (nt2 + 1) / 2;
+  if (KA <= 64 && !getenv("TRK_WGRAM_NO_MFMA")) {
+    // matrix-core single pass (every row read once)
+    int64_t nchunk = (m + 127) / 128;
+    int bx = (int)(nchunk < (int64_t)cu_count() * 3 ? (nchunk > 0 ? nchunk : 1) : (int64_t)cu_count() * 3);
+    if (bx > kMaxPartialBlocks) bx = kMaxPartialBlocks;
+    double* part = nullptr;
+    const size_t npart = (size_t)bx * KA * KA;
+    if (int rc = scratch_doubles(s, npart + (size_t)KA * KA, &part)) return rc;
+    double* Ga = part + npart;
+#define WM(NTI, HW, HB) hipLaunchKernelGGL((k_wgram_mfma<NTI, HW, HB>), dim3(bx), dim3(NT), 0, s, W, ld, k, m, w, b1, part)
+    if (KA <= 32) {
+      if (w) { if (b1) WM(1, true, true); else WM(1, true, false); }
+      else   { if (b1) WM(1, false, true); else WM(1, false, false); }
+    } else {
+      if (w) { if (b1) WM(2, true, true); else WM(2, true, false); }
+      else   { if (b1) WM(2, false, true); else WM(2, false, false); }
+    }
+#undef WM
+    TRK_LAUNCH_CHECK();
+    if (int rc = finalize_sums(part, bx, KA * KA, KA * KA, Ga, s)) return rc;
+    hipLaunchKernelGGL(k_wgram_unpack, dim3(1), dim3(256), 0, s, Ga, k, KA, G, c1, c2);
+    TRK_LAUNCH_CHECK();
+    return TRK_OK;
+  }
   // The LDS-staged single-pass kernel reads every row once but is instruction-bound (8 ds_read + 8 cvt per 16 fp64 FMAs):
   // measured slower than the tile-pair kernel at 4096^2 (k = 3..33: 3.2 ms vs 1.7 ms average), so it is opt-in.
   static const bool use_lds = getenv("TRK_WGRAM_LDS") != nullptr;
