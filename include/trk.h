@@ -83,6 +83,14 @@ int trk_spacetime_create(int N, int nt_local, int has_next, int has_prev, trk_op
  * temporal block of the previous rank's output rows (N*N floats).  Either may be NULL. */
 int trk_spacetime_set_halo(trk_op* op, const float* x_next_dev, const float* y_prev_dev);
 
+/* General sparse operator from host CSR arrays of A (nrows x ncols) and of A^T (built by the caller, e.g. scipy's
+ * `.T.tocsr()`); all six arrays are copied to the device.  Serves operators the reference holds as scipy.sparse matrices:
+ * the derivative regularisers (operators.py:24-45), the framelet analysis operators (:50-113) and the precomputed
+ * forward matrices of the real dynamic data sets sliced per frame (io.py:132-135,197-229). */
+int trk_csr_create(int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* indptr_host, const int* indices_host,
+                   const float* values_host, const int64_t* t_indptr_host, const int* t_indices_host,
+                   const float* t_values_host, trk_op** out);
+
 /* Block-diagonal operator over frames (pylops.BlockDiag at io.py:420; sparse slicing :223-225).
  * The handle borrows `ops` (they must outlive it). x and y are frame-major. */
 int trk_blockdiag_create(trk_op* const* ops, int count, trk_op** out);

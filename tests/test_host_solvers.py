@@ -149,3 +149,28 @@ def test_oneshot_solvers(eng):
         x, lam = S.Arnoldi_Tikhonov(A, bb, 6, rp, **kw)
         assert lam_close([lam], [float(g[f"at_{tag}_lam"])], 5e-2) and relerr(x, g[f"at_{tag}_x"]) < (2e-3 if tag != "lam" else 1e-4)
     assert relerr(S.GMRES(A, g["b"], 5), g["gmres_x"]) < 1e-4
+
+
+def test_framelet_matrix_matches_reference_without_gpu():
+    """The host-side construction of the framelet analysis matrix (the device only does the SpMV)."""
+    import scipy.sparse as sp
+    import trips_py_amd.operators as ops
+
+    captured = {}
+
+    class FakeSparseOp:
+        def __init__(self, M, engine=None):
+            captured["M"] = sp.csr_matrix(M)
+    orig = ops.SparseOp
+    ops.SparseOp = FakeSparseOp
+    try:
+        g = load_golden("framelet_ops")
+        ops.create_framelet_operator(8, 6, 2)
+        assert np.allclose(captured["M"].toarray(), g["dense_8_6_2"], atol=1e-14)
+        for (n, m, l) in ((12, 12, 1), (16, 10, 3)):
+            ops.create_framelet_operator(n, m, l)
+            M = captured["M"]
+            assert relerr(M @ g[f"x_{n}_{m}_{l}"], g[f"Wx_{n}_{m}_{l}"]) < 1e-13
+            assert relerr(M.T @ g[f"y_{n}_{m}_{l}"], g[f"WTy_{n}_{m}_{l}"]) < 1e-13
+    finally:
+        ops.SparseOp = orig

@@ -36,6 +36,10 @@ sys.path.insert(0, REF)
 import numpy as np
 
 np.int0 = np.intp  # removed in NumPy 2; Deblurring1D.py:68,72 still uses it
+import scipy.sparse as _sps  # noqa: E402
+for _cls in (_sps.csr_matrix, _sps.csc_matrix, _sps.coo_matrix, _sps.lil_matrix):
+    if not hasattr(_cls, "H"):   # removed from SciPy sparse matrices; create_framelet_operator (operators.py:107,109) uses it
+        _cls.H = property(lambda self: self.conj().T)
 
 from scipy.ndimage import convolve  # noqa: E402
 from trips.solvers.CGLS import CGLS  # noqa: E402
@@ -285,6 +289,18 @@ def g6_derivs():
     out["holder_eps0.01_p0.5"] = smoothed_holder_weights(u, epsilon=0.01, p=0.5)
     out["holder_eps0.1_p2"] = smoothed_holder_weights(u, epsilon=0.1, p=2)
     save("deriv_ops", **out)
+    # framelet analysis operator (operators.py:50-113): action on seeded vectors + a small dense matrix
+    fr = {}
+    for (n, m, l) in ((8, 6, 2), (12, 12, 1), (16, 10, 3)):
+        Wf = refops.create_framelet_operator(n, m, l)
+        rng2 = np.random.default_rng(n * 100 + m * 10 + l)
+        x = rng2.standard_normal(n * m)
+        y = rng2.standard_normal(Wf.shape[0])
+        fr[f"x_{n}_{m}_{l}"], fr[f"y_{n}_{m}_{l}"] = x, y
+        fr[f"Wx_{n}_{m}_{l}"] = np.asarray(Wf @ x).reshape(-1)
+        fr[f"WTy_{n}_{m}_{l}"] = np.asarray(Wf.T @ y).reshape(-1)
+    fr["dense_8_6_2"] = np.asarray(refops.create_framelet_operator(8, 6, 2).todense())
+    save("framelet_ops", **fr)
 
 
 # ----------------------------------------------------------------------------------------- G7

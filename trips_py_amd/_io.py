@@ -11,6 +11,14 @@ from .operators import LinearOperator
 def as_operator(A, role="A"):
     if isinstance(A, LinearOperator):
         return A
+    try:
+        import scipy.sparse as sp
+        if sp.issparse(A):
+            # a matrix the reference built with scipy.sparse (e.g. gen_first_derivative_operator_2D): device CSR SpMV
+            from .operators import SparseOp
+            return SparseOp(A)
+    except ImportError:        # pragma: no cover
+        pass
     raise TypeError(f"{role} must be a trips_py_amd LinearOperator (Blur2D, Radon2DParallel, BlockDiagOp, "
                     f"FirstDerivative2D, ...); got {type(A).__name__}.  The engine has no host/NumPy operator path.")
 

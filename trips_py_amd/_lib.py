@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libtrk.so")
-SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip"]
+SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip", "spmv.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
 
@@ -89,6 +89,8 @@ SIGNATURES = {
     "trk_deriv2d_create": (c_int, [c_int, ctypes.POINTER(c_op)]),
     "trk_spacetime_create": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_op)]),
     "trk_spacetime_set_halo": (c_int, [c_op, c_f32p, c_f32p]),
+    "trk_csr_create": (c_int, [c_i64, c_i64, c_i64, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                               ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(c_op)]),
     "trk_blockdiag_create": (c_int, [ctypes.POINTER(c_op), c_int, ctypes.POINTER(c_op)]),
     "trk_op_shape": (c_int, [c_op, ctypes.POINTER(c_i64), ctypes.POINTER(c_i64)]),
     "trk_op_apply": (c_int, [c_op, c_int, c_f32p, c_i64, c_f32p, c_i64, c_int, c_f64p, c_stream]),

@@ -283,6 +283,62 @@ class BlockDiagOp(_HandleOperator):
         super().__init__(h, engine)
 
 
+class SparseOp(_HandleOperator):
+    """An operator given as a (scipy.sparse or small dense) matrix: CSR SpMV on the device, both directions as gathers.
+    This is what a reference-built regulariser (`gen_first_derivative_operator_2D`, `gen_spacetime_derivative_operator`,
+    the framelet analysis matrices: trips/utilities/operators.py) or a precomputed sparse forward matrix
+    (io.py:197-229) becomes when handed to the engine's solvers."""
+
+    def __init__(self, M, engine=None):
+        import scipy.sparse as sp
+        engine = engine if engine is not None else default_engine()
+        A = sp.csr_matrix(M)
+        A.sum_duplicates()
+        At = A.T.tocsr()
+        At.sum_duplicates()
+        self.matrix = A
+
+        def arrs(C):
+            return (np.ascontiguousarray(C.indptr, dtype=np.int64), np.ascontiguousarray(C.indices, dtype=np.int32),
+                    np.ascontiguousarray(C.data, dtype=np.float32))
+        ip, ix, dv = arrs(A)
+        tp, tx, tv = arrs(At)
+        h = ctypes.c_void_p()
+        _lib.check(engine.lib.trk_csr_create(A.shape[0], A.shape[1], A.nnz, ip.ctypes.data, ix.ctypes.data, dv.ctypes.data,
+                                             tp.ctypes.data, tx.ctypes.data, tv.ctypes.data, ctypes.byref(h)), "trk_csr_create")
+        super().__init__(h, engine)
+
+
+def create_framelet_operator(n, m, l, engine=None):
+    """The reference's framelet analysis operator (trips/utilities/operators.py:50-113) as ONE sparse matrix on the device:
+    vec_F(W_n X W_m^H) = kron(W_m, W_n) vec_F(X) for the reference's column-major reshapes (:106-108); rows
+    n(2l+1) * m(2l+1), columns n*m."""
+    import scipy.sparse as sp
+
+    def construct_H(lev, nn):                       # operators.py:50-85
+        e = np.ones((nn,))
+        H0 = (sp.spdiags(e, -lev, nn, nn) + sp.spdiags(2 * e, 0, nn, nn) + sp.spdiags(e, lev, nn, nn)).tolil()
+        H1 = (sp.spdiags(-e, -lev, nn, nn) + sp.spdiags(e, lev, nn, nn)).tolil()
+        H2 = (sp.spdiags(-e, -lev, nn, nn) + sp.spdiags(2 * e, 0, nn, nn) + sp.spdiags(-e, lev, nn, nn)).tolil()
+        for jj in range(lev):
+            H0[jj, lev - jj - 1] += 1
+            H0[-jj - 1, -lev + jj] += 1
+            H1[jj, lev - jj - 1] -= 1
+            H1[-jj - 1, -lev + jj] += 1
+            H2[jj, lev - jj - 1] -= 1
+            H2[-jj - 1, -lev + jj] -= 1
+        return H0.tocsr() / 4, H1.tocsr() * (np.sqrt(2) / 4), H2.tocsr() / 4
+
+    def analysis(nn, level, w):                     # operators.py:88-103
+        if level == l:
+            return sp.vstack(construct_H(level, nn))
+        H0, H1, H2 = construct_H(level, nn)
+        return sp.vstack((analysis(nn, level + 1, H0), H1, H2)) * w
+
+    W_n, W_m = analysis(n, 1, 1), analysis(m, 1, 1)
+    return SparseOp(sp.kron(W_m, W_n, format="csr"), engine=engine)
+
+
 class Identity(LinearOperator):
     def __init__(self, n, engine=None):
         super().__init__((n, n), engine)
