@@ -62,7 +62,12 @@ __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in,
 }
 
 // ---------------------------------------------------------------------------------------- forward
-// grid = (ceil(nd/64), n_ang, batch) ; block = 256 = 64 detectors x 4 marching quarters
+// grid = (ceil(nd/64), n_ang_total, batch) ; block = 256 = 64 detectors x 4 marching quarters.
+// Both taps of a step come from ONE 8-byte buffer load at (row, floor(q)); out-of-range taps get weight 0 (the buffer
+// range check returns 0 for the two addresses that fall outside the image allocation).
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+
 __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img, const float* __restrict__ imgT,
                                                    int64_t ld_img, float* __restrict__ sino, int64_t ld_sino, int N,
                                                    int nd, const AngleParam* __restrict__ ang, int na_per_frame) {
@@ -71,6 +76,7 @@ __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img
   const AngleParam p = ang[a];
   const int frame = a / na_per_frame;
   const float* __restrict__ I = (p.mode ? imgT : img) + (int64_t)blockIdx.z * ld_img + (int64_t)frame * N * N;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)I, 0, (unsigned)N * (unsigned)N * 4u, 0x00020000);
   const int lane = threadIdx.x & 63, q4 = threadIdx.x >> 6;
   const int d = blockIdx.x * 64 + lane;
   const float s = (float)d - 0.5f * (float)(nd - 1);
@@ -81,14 +87,22 @@ __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img
     for (int tb = t0; tb < t1; tb += 64) {
       const int te = (tb + 64 < t1) ? tb + 64 : t1;
       float acc = 0.f;
+#pragma unroll 8
       for (int tt = tb; tt < te; ++tt) {
         const float q = fmaf((float)tt, p.dq, base);
         const float qf = floorf(q);
         const float f = q - qf;
         const int c = (int)qf;
-        const float* row = I + (int64_t)tt * N;
-        if (c >= 0 && c < N) acc = fmaf(1.0f - f, row[c], acc);
-        if (c + 1 >= 0 && c + 1 < N) acc = fmaf(f, row[c + 1], acc);
+        // c == -1: only the right tap (column 0) is inside; start the 8-byte load at column 0 instead (an access that
+        // STARTS below the buffer is dropped whole by the range check — measured on gfx950 — while one that runs off
+        // the end returns its in-range dword)
+        const bool neg1 = (c == -1);
+        const int cl = neg1 ? 0 : c;
+        const f2v v = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (tt * N + cl) * 4, 0, 0));
+        const float w0 = neg1 ? f : (((unsigned)c < (unsigned)N) ? 1.0f - f : 0.f);
+        const float w1 = neg1 ? 0.f : (((unsigned)(c + 1) < (unsigned)N) ? f : 0.f);
+        acc = fmaf(w0, v[0], acc);
+        acc = fmaf(w1, v[1], acc);
       }
       total += (double)acc;
     }
@@ -102,7 +116,11 @@ __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img
 }
 
 // ---------------------------------------------------------------------------------------- adjoint (gather)
-// one thread per pixel; grid = (ceil(N*N/256), batch)
+// One thread per pixel; grid = (ceil(N*N/256), n_frames, batch).  The forward weights of ray d on its two taps are
+// (1-f, f) with f = q - floor(q), i.e. hat(q - col) = max(0, 1 - |q - col|) on pixel `col`; the gather evaluates exactly
+// that for the three detectors nearest to the pixel's inverse image d* (every ray with |q - col| < 1 is among them,
+// because |dq/dd| = 1/|cos| >= 1), with q computed by the SAME float expression as the forward kernel.  The weights are
+// bit-identical to the forward ones (the subtractions involved are exact), so this is the exact transpose.
 __global__ __launch_bounds__(256) void k_radon_adj(const float* __restrict__ sino, int64_t ld_sino,
                                                    float* __restrict__ img, int64_t ld_img, int N, int nd, int na,
                                                    const AngleParam* __restrict__ ang) {
@@ -113,29 +131,26 @@ __global__ __launch_bounds__(256) void k_radon_adj(const float* __restrict__ sin
   const float* __restrict__ S = sino + (int64_t)blockIdx.z * ld_sino + (int64_t)frame * na * nd;
   ang += (int64_t)frame * na;
   const float sdh = 0.5f * (float)(nd - 1);
+  const float fi = (float)i, fj = (float)j;
   float acc = 0.f;
+#pragma unroll 2
   for (int a = 0; a < na; ++a) {
     const AngleParam p = ang[a];
-    const int tt = p.mode ? j : i;          // marching index
-    const int col = p.mode ? i : j;         // interpolated coordinate this pixel sits on
-    const float off = fmaf((float)tt, p.dq, p.k0);
-    // q(d) = (d - sdh)*inv + off ;  |q - col| < 1  <=>  d within 1/|inv| (<= 1) of dstar
-    const float dstar = ((float)col - off) / p.inv + sdh;
-    const int dlo = (int)floorf(dstar) - 1;
+    const float ftt = p.mode ? fj : fi;       // marching index
+    const float fcol = p.mode ? fi : fj;      // interpolated coordinate this pixel sits on
+    const float off = fmaf(ftt, p.dq, p.k0);
+    const float dstar = (fcol - off) / p.inv + sdh;
+    const int d0 = (int)rintf(dstar);
     const float* __restrict__ Sa = S + (int64_t)a * nd;
     float sum = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int d = dlo + e;
-      if (d >= 0 && d < nd) {
-        const float s = (float)d - sdh;
-        const float q = fmaf((float)tt, p.dq, fmaf(s, p.inv, p.k0));
-        const float qf = floorf(q);
-        const float f = q - qf;
-        const int c = (int)qf;
-        if (c == col) sum = fmaf(1.0f - f, Sa[d], sum);
-        else if (c + 1 == col) sum = fmaf(f, Sa[d], sum);
-      }
+    for (int e = -1; e <= 1; ++e) {
+      const int d = d0 + e;
+      const float sd = (float)d - sdh;
+      const float q = fmaf(ftt, p.dq, fmaf(sd, p.inv, p.k0));
+      const float wgt = fmaxf(1.0f - fabsf(q - fcol), 0.f);
+      const float sv = ((unsigned)d < (unsigned)nd) ? Sa[(unsigned)d < (unsigned)nd ? d : 0] : 0.f;
+      sum = fmaf(wgt, sv, sum);
     }
     acc = fmaf(p.wgt, sum, acc);
   }
