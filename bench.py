@@ -38,6 +38,7 @@ def parse():
     ap.add_argument("--workload", default="blur_cgls", choices=["blur_cgls"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--unfused", action="store_true", help="force the generic seven-launch CGLS iteration")
+    ap.add_argument("--fused", action="store_true", help="force the fused three-launch CGLS iteration")
     ap.add_argument("--no-extras", action="store_true", help="skip the C4 (MMGKS) and C5 (sharded dynamic tomo) legs")
     ap.add_argument("--cpu-iters", type=int, default=3, help="CPU-baseline sample: CGLS iterations timed on the host")
     return ap.parse_args()
@@ -143,7 +144,8 @@ def run_blur_cgls(args, rank, world):
     x0 = torch.zeros(n, dtype=torch.float32, device=eng.device)
 
     # the class trips_py_amd.solvers.CGLS itself picks for this operator (tol = 0, single rank per problem)
-    Run = CGLSRunFused if (CGLSRunFused.usable(A, eng) and not args.unfused) else CGLSRun
+    fused = CGLSRunFused.usable(A, eng) and not args.unfused and (args.fused or n <= CGLSRunFused.AUTO_MAX_N)
+    Run = CGLSRunFused if fused else CGLSRun
     run = Run(A, b, x0, W + K, x_true=None, history=False)        # reference call without x_true (CGLS.py:16)
     for _ in range(W):
         run.step()
@@ -171,16 +173,20 @@ def run_blur_cgls(args, rank, world):
     tadj.detach()
     ms_adj = tadj.read()
 
-    alg_bytes = 8.0 * n                                   # read x once + write y once
+    # algorithmic bytes of the forward-blur launch: plain matvec reads x and writes y (8 n); the fused form also reads
+    # p_old and writes p_new (16 n) — SURVEY §8d's own accounting of a fused update + matvec
+    alg_bytes = (16.0 if fused else 8.0) * n
     t_kernel = float(np.mean(ms_fwd)) * 1e-3
     achieved = alg_bytes / t_kernel / 1e9
-    roofline = {"bound": "hbm", "kernel": "k_blur_slide<9,9,D=6,sumsq> (forward blur matvec, fused ||Ap||^2)",
+    kname = ("k_blur_slide<9,9,D=6,sumsq,fuse> (p = t + ratio*p fused into w = A p, + ||w||^2)" if fused
+             else "k_blur_slide<9,9,D=6,sumsq> (forward blur matvec w = A p, fused ||w||^2)")
+    roofline = {"bound": "hbm", "kernel": kname,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": load_traffic("k_blur_slide_fwd"),
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None if fused else load_traffic("k_blur_slide_fwd"),
                 "alg_bytes_per_launch": alg_bytes, "avg_kernel_us": round(t_kernel * 1e6, 2),
                 "min_kernel_us": round(float(np.min(ms_fwd)) * 1e3, 2), "launches_timed": int(len(ms_fwd)),
-                "adjoint_avg_kernel_us": round(float(np.mean(ms_adj[2:])) * 1e3, 2),
-                "adjoint_GBps": round(alg_bytes / (float(np.mean(ms_adj[2:])) * 1e-3) / 1e9, 1)}
+                "adjoint_matvec_avg_kernel_us": round(float(np.mean(ms_adj[2:])) * 1e3, 2),
+                "adjoint_matvec_GBps": round(8.0 * n / (float(np.mean(ms_adj[2:])) * 1e-3) / 1e9, 1)}
 
     res = {"metric": "krylov_iters_per_sec", "value": round(world * K / elapsed, 3), "unit": "iters/s",
            "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
@@ -200,7 +206,8 @@ def run_blur_cgls(args, rank, world):
     torch.cuda.empty_cache()
     if not args.no_extras:
         # secondary measurements (never `value`): each guarded so that the main line is always printed
-        for name, fn in (("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world)),
+        for name, fn in (("c3_tomo512_hybrid_lsqr", lambda: extra_c3_tomo(world)),
+                         ("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world)),
                          ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world))):
             try:
                 res["extra"][name] = fn()
@@ -208,6 +215,47 @@ def run_blur_cgls(args, rank, world):
                 res["extra"][name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             barrier(world)
     return res
+
+
+def extra_c3_tomo(world):
+    """BASELINE config C3: parallel-beam tomography 512^2, 180 angles, Hybrid-LSQR 100 iterations (lambda = 1e-2), plus
+    the Radon matvec rates.  The Radon operator is gather/ALU-bound, not HBM-bound: taps/s is the honest
+    rate, algorithmic GB/s is reported for completeness.  Replicas across ranks."""
+    from trips_py_amd.operators import Radon2DParallel
+    from trips_py_amd.solvers import Hybrid_LSQR
+    Nt, na = 512, 180
+    R = Radon2DParallel(Nt, np.linspace(0, np.pi, na, endpoint=False))
+    eng = R.engine
+    ii, jj = torch.meshgrid(torch.arange(Nt), torch.arange(Nt), indexing="ij")
+    ph = ((((ii - 256) / 180.0) ** 2 + ((jj - 256) / 230.0) ** 2) < 1).float() + 0.5 * ((((ii - 300) / 60.0) ** 2 + ((jj - 200) / 40.0) ** 2) < 1).float()
+    xt = ph.reshape(-1).to(eng.device)
+    bt = R.apply(xt)
+    e = torch.randn(bt.numel(), device=eng.device, generator=torch.Generator(device=eng.device).manual_seed(5))
+    bt = bt + e * (0.01 * torch.linalg.norm(bt) / torch.linalg.norm(e))
+    out = {"geometry": f"{Nt}x{Nt}, {na} angles, {Nt} detectors", "taps_per_apply": 2.0 * Nt * Nt * na,
+           "alg_bytes_per_apply": 4.0 * (Nt * Nt + na * Nt)}
+    y, z = torch.empty_like(bt), torch.empty_like(xt)
+    for name, fn in (("fwd", lambda: R.apply(xt, out=y)), ("adj", lambda: R.apply(bt, out=z, transpose=True))):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / 20
+        out[f"radon_{name}_us"] = round(ms * 1e3, 1)
+        out[f"radon_{name}_Gtaps_per_s"] = round(out["taps_per_apply"] / ms / 1e6, 1)
+        out[f"radon_{name}_alg_GBps"] = round(out["alg_bytes_per_apply"] / ms / 1e6, 2)
+    Hybrid_LSQR(R, bt, 5, 1e-2, history=False)
+    barrier(world)
+    t0 = time.perf_counter()
+    Hybrid_LSQR(R, bt, 100, 1e-2, history=False)
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    out["hybrid_lsqr_iters_per_sec_all_ranks"] = round(world * 100 / dt, 1)
+    return out
 
 
 def extra_c4_mmgks(A, b, N, world):

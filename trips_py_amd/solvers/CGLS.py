@@ -88,6 +88,10 @@ class CGLSRunFused(CGLSRun):
     (nothing visits the host until the end)."""
 
     PCAP = 4096                            # room for the producers' block partials
+    # measured crossover (MI355X, 9x9 blur): the fused iteration wins up to 2048^2 (launch-bound: 27.5k vs 16.3k it/s at
+    # 1024^2, 17.4k vs 15.6k at 2048^2) and loses 5 % from 3072^2 up (the single-wave-per-SIMD blur kernel with two
+    # operands is latency-bound), so CGLS() picks it below this many unknowns unless told otherwise
+    AUTO_MAX_N = 6 * 2 ** 20
 
     @staticmethod
     def usable(A, eng):
@@ -178,7 +182,9 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
     fmt = Formatter(b)
     A = as_operator(A)
     sync_each = (tol != 0)
-    fused = (not sync_each) and kwargs.get("fused", True) and CGLSRunFused.usable(A, A.engine)
+    want = kwargs.get("fused", None)          # None: automatic by size; True / False: forced
+    fused = (not sync_each) and CGLSRunFused.usable(A, A.engine) and \
+        (want if want is not None else A.shape[1] <= CGLSRunFused.AUTO_MAX_N)
     run = (CGLSRunFused if fused else CGLSRun)(A, b, x0, max_iter, x_true, kwargs.get("history", True))
     nt0 = None
     stop = False
