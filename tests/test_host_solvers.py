@@ -174,3 +174,11 @@ def test_framelet_matrix_matches_reference_without_gpu():
             assert relerr(M.T @ g[f"y_{n}_{m}_{l}"], g[f"WTy_{n}_{m}_{l}"]) < 1e-13
     finally:
         ops.SparseOp = orig
+
+
+def test_golub_kahan_dp_stop(eng):
+    g = load_golden("golub_kahan_blur32_dpstop")
+    A = blur(eng, g)
+    U, Sm, V = golub_kahan(A, g["b"], int(g["n_iter"]), True, gk_eta=float(g["gk_eta"]), gk_delta=float(g["gk_delta"]))
+    assert Sm.shape == g["S"].shape and V.shape == g["V"].shape          # stops at the same step as the reference
+    assert np.allclose(Sm, g["S"], rtol=1e-4, atol=1e-7) and relerr(V[:, :4], g["V"][:, :4]) < 1e-4

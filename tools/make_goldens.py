@@ -186,6 +186,10 @@ def g3_decomp():
     save("golub_kahan_blur32_d8", psf=PSF, N=N, b=b, n_iter=8, U=U, S=S, V=V)
     Q, H = quiet(dec.arnoldi, A, b, 6)
     save("arnoldi_blur32_d6", psf=PSF, N=N, b=b, n_iter=6, Q=Q, H=H)
+    # discrepancy-principle stopping inside golub_kahan (decompositions.py:167-195): gk_delta chosen so that it stops early
+    _, _, _, bn, dn = blur_problem(N, 21, noise=0.1)
+    U, S, V = quiet(dec.golub_kahan, A, bn, 12, True, gk_eta=1.001, gk_delta=dn)
+    save("golub_kahan_blur32_dpstop", psf=PSF, N=N, b=bn, n_iter=12, gk_eta=1.001, gk_delta=dn, U=U, S=S, V=V)
 
 
 # ----------------------------------------------------------------------------------------- G4

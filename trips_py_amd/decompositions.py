@@ -22,13 +22,45 @@ def _fmt_like(b):
     return not isinstance(b, torch.Tensor)
 
 
-def golub_kahan(A, b, n_iter, dp_stop=False, **kwargs):
-    if dp_stop:
-        raise NotImplementedError("golub_kahan(dp_stop=True) (decompositions.py:185-195) is not implemented on the engine yet")
+def golub_kahan_device(A, b, n_iter, dp_stop=False, **kwargs):
+    """`golub_kahan` on the device -> GKState.  With dp_stop the factorisation halts once the projected least-squares
+    solution meets the discrepancy principle ||A x_k - b|| <= gk_eta * gk_delta (decompositions.py:148-149,167-195;
+    defaults 1.001 and 0.001 — NOT the solvers' `delta`)."""
     A = as_operator(A)
-    gk = GKState(A, b, int(n_iter))
-    for _ in range(int(n_iter)):
+    n_iter = int(n_iter)
+    gk = GKState(A, b, n_iter)
+    if not dp_stop:
+        for _ in range(n_iter):
+            gk.step()
+        return gk
+    eta = kwargs.get("gk_eta", 1.001)
+    delta = kwargs.get("gk_delta", 0.001)
+    eng = A.engine
+    m, n = A.shape
+    bv = eng.to_vec(b, m)
+    P, Y, R = eng.scalars(n_iter + 2), eng.scalars(n_iter + 1), eng.scalars(1)
+    x, ax = eng.empty(n), eng.empty(m)
+    res_norm = np.inf
+    for _ in range(n_iter):
+        if res_norm <= eta * delta:
+            print("discrepancy principle satisfied, halting early.")
+            break
         gk.step()
+        k = gk.V.k
+        eng.gemv_t(gk.U.data, k + 1, bv, P.ref(0))                  # bhat = U.T @ b (:189)
+        eng.allreduce(P, 0, k + 1)
+        y = np.linalg.lstsq(gk.B(), P.host(0, k + 1).reshape(-1, 1), rcond=None)[0].reshape(-1)
+        Y.set(0, y)
+        eng.gemv_n(gk.V.data, k, Y.ref(0), x)                       # x = V @ y (:193)
+        A.apply(x, out=ax)
+        eng.diff_nrm2sq(ax, bv, R.ref(0))                           # ||A x - b|| (:195)
+        eng.allreduce(R, 0, 1)
+        res_norm = float(np.sqrt(R.host(0, 1)[0]))
+    return gk
+
+
+def golub_kahan(A, b, n_iter, dp_stop=False, **kwargs):
+    gk = golub_kahan_device(A, b, n_iter, dp_stop, **kwargs)
     if _fmt_like(b):
         return gk.U.numpy(), gk.B(), gk.V.numpy()
     return gk.U.torch_cols(), gk.B(), gk.V.torch_cols()

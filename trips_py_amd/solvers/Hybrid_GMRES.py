@@ -15,6 +15,9 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
     relError (if x_true), relResidual, its (= n_iter-1).  Engine-only kwarg: history=True."""
     A = as_operator(A)
     delta = check_delta(regparam, kwargs)
+    if kwargs.get("dp_stop", False):
+        # the reference's dp_stop branch multiplies V[:, :-1] (k-1 columns) by a k-vector and raises (:87-93 / :60-66)
+        raise NotImplementedError("dp_stop=True: the reference branch is shape-inconsistent; not reproduced")
     eng = A.engine
     m, n = A.shape
     if m != n:

@@ -13,7 +13,8 @@ import numpy as np
 
 from .._io import Formatter, as_operator, history_fits
 from ..engine import Coef
-from ..krylov import DeviceBasis, GKState, orthogonalize
+from ..decompositions import golub_kahan_device
+from ..krylov import DeviceBasis, orthogonalize
 from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq
 
 
@@ -34,11 +35,10 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     fmt = Formatter(b)
     bv = eng.to_vec(b, m)
     xt = None if x_true is None else eng.to_vec(x_true, n)
-    kmax = d + n_iter
+    kmax = d + n_iter + 1
 
-    gk = GKState(A, bv, d)
-    for _ in range(d):
-        gk.step()
+    gk = golub_kahan_device(A, bv, d, kwargs.get("dp_stop", False),                 # GKS.py:36 / MMGKS.py:37
+                            **{k_: v_ for k_, v_ in kwargs.items() if k_ in ("gk_eta", "gk_delta")})
     V = gk.V
     V.reserve(kmax)
     AV, LV = DeviceBasis(eng, m, kmax), DeviceBasis(eng, p_rows, kmax)

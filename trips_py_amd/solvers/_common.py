@@ -16,8 +16,6 @@ def check_delta(regparam, kwargs):
     dp_stop = kwargs.get("dp_stop", False)
     if (isinstance(regparam, str) and regparam == "dp" or dp_stop is not False) and delta is None:
         raise Exception(NO_DELTA_MSG)
-    if dp_stop:
-        raise NotImplementedError("dp_stop=True is not implemented on the engine yet (SURVEY §8f rank 2)")
     return delta
 
 
