@@ -248,6 +248,30 @@ def extra_c3_tomo(world):
         out[f"radon_{name}_us"] = round(ms * 1e3, 1)
         out[f"radon_{name}_Gtaps_per_s"] = round(out["taps_per_apply"] / ms / 1e6, 1)
         out[f"radon_{name}_alg_GBps"] = round(out["alg_bytes_per_apply"] / ms / 1e6, 2)
+    # the north_star's second roofline point: the Radon matvec at 4096^2 x 180 angles (6.04 G taps per apply)
+    try:
+        Nb = 4096
+        Rb = Radon2DParallel(Nb, np.linspace(0, np.pi, na, endpoint=False))
+        xb = torch.rand(Nb * Nb, device=eng.device)
+        yb, zb = torch.empty(Rb.shape[0], device=eng.device), torch.empty(Nb * Nb, device=eng.device)
+        big = {"taps_per_apply": 2.0 * Nb * Nb * na, "alg_bytes_per_apply": 4.0 * (Nb * Nb + na * Nb)}
+        for name, fn in (("fwd", lambda: Rb.apply(xb, out=yb)), ("adj", lambda: Rb.apply(yb, out=zb, transpose=True))):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(3):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / 3
+            big[f"{name}_ms"] = round(ms, 3)
+            big[f"{name}_Gtaps_per_s"] = round(big["taps_per_apply"] / ms / 1e6, 1)
+            big[f"{name}_alg_GBps"] = round(big["alg_bytes_per_apply"] / ms / 1e6, 2)
+        out["radon_4096x180"] = big
+        del Rb, xb, yb, zb
+    except Exception as exc:      # noqa: BLE001
+        out["radon_4096x180"] = {"error": str(exc)[:200]}
     Hybrid_LSQR(R, bt, 5, 1e-2, history=False)
     barrier(world)
     t0 = time.perf_counter()

@@ -22,6 +22,6 @@ for name, sub, mult in (("FETCH_SIZE", "pmc_fetch", 2.0), ("WRITE_SIZE", "pmc_wr
         traffic.setdefault(k, {})[name] = mean * 1024 * mult
 print("== traffic per launch (bytes) for the blur kernel")
 for k, d in traffic.items():
-    if "k_blur_slide<9, 9, 6, true>" in k:
+    if "k_blur_slide<9, 9, 6, true, false>" in k:
         tot = d.get("FETCH_SIZE", 0) + d.get("WRITE_SIZE", 0)
         print(json.dumps({"k_blur_slide_fwd": tot, "read": d.get("FETCH_SIZE"), "write": d.get("WRITE_SIZE")}))
