@@ -71,6 +71,12 @@ int trk_radon2d_create(int N, int n_det, const double* angles_host, int n_ang, d
 int trk_radon2d_dynamic_create(int N, int n_det, const double* angles_host, int n_frames, int n_ang_per_frame,
                                double scale, trk_op** out);
 
+/* Fan-beam (flat detector) line projector and matched adjoint: astra 'fanflat' geometry + 'line_fanflat' projector of
+ * trips/test_problems/Tomography.py:53-88 (p = int(sqrt(2) nx) detector pixels of pitch (SOD+ODD)/SOD, SOD = 3 nx,
+ * ODD = nx).  Weights = ray / pixel intersection lengths.  Sinogram (n_ang, n_det) row-major.  PARITY UNPINNED. */
+int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double source_origin, double origin_detector,
+                         const double* angles_host, int n_ang, trk_op** out);
+
 /* First-difference regularisers, matrix-free.  Replace the scipy.sparse matrices of
  * trips/utilities/operators.py:24-36 (2-D: rows x[i,j]-x[i,j+1] then x[i,j]-x[i+1,j]) and :39-45
  * (space-time: nt copies of the 2-D operator, then temporal rows x_t - x_{t+1}).

@@ -810,3 +810,62 @@ def gmres(A, b, n_iter=3):
     bhat = Q.T @ b
     y = np.linalg.lstsq(H.T, H.T @ bhat, rcond=None)[0]
     return Q @ y
+
+
+# =====================================================================================
+# SURVEY §8f rank 1 — fan-beam line projector (PARITY UNPINNED, like Radon2D)
+# =====================================================================================
+class FanBeam2D(_Op):
+    """astra 'fanflat' + 'line_fanflat' of trips/test_problems/Tomography.py:53-88, restated by brute force: the weight of
+    pixel (r,c) for ray (angle a, detector d) is the length of the segment source -> detector-pixel centre inside the
+    pixel square, obtained by clipping the ray against EVERY pixel (no traversal logic to get wrong).  Convention as in
+    csrc/fanbeam2d.hip: source (SOD sin t, -SOD cos t), detector centre (-ODD sin t, ODD cos t), detector axis (cos t, sin t)."""
+
+    def __init__(self, N, angles, n_det=None, sod=None, odd=None, pitch=None):
+        self.N = int(N)
+        self.angles = np.asarray(angles, dtype=np.float64).reshape(-1)
+        self.nd = int(np.sqrt(2) * self.N) if n_det is None else int(n_det)
+        self.sod = 3.0 * self.N if sod is None else float(sod)
+        self.odd = 1.0 * self.N if odd is None else float(odd)
+        self.pitch = (self.sod + self.odd) / self.sod if pitch is None else float(pitch)
+        self.shape = (len(self.angles) * self.nd, self.N * self.N)
+        self._M = None
+
+    def matrix(self):
+        if self._M is None:
+            N, nd, half = self.N, self.nd, 0.5 * self.N
+            rr, cc = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+            x0, x1 = (cc - half).reshape(-1), (cc + 1 - half).reshape(-1)
+            y1 = (half - rr).reshape(-1)
+            y0 = y1 - 1.0
+            rows, cols, vals = [], [], []
+            for a, th in enumerate(self.angles):
+                ct, st = np.cos(th), np.sin(th)
+                sx, sy = self.sod * st, -self.sod * ct
+                for d in range(nd):
+                    off = (d - 0.5 * (nd - 1)) * self.pitch
+                    ex, ey = -self.odd * st + off * ct, self.odd * ct + off * st
+                    dx, dy = ex - sx, ey - sy
+                    L = np.hypot(dx, dy)
+                    t0 = np.zeros(N * N)
+                    t1 = np.ones(N * N)
+                    for (lo, hi, s0, dd) in ((x0, x1, sx, dx), (y0, y1, sy, dy)):
+                        if abs(dd) > 1e-14:
+                            ta, tb = (lo - s0) / dd, (hi - s0) / dd
+                            t0 = np.maximum(t0, np.minimum(ta, tb))
+                            t1 = np.minimum(t1, np.maximum(ta, tb))
+                        else:
+                            t1 = np.where((s0 < lo) | (s0 > hi), -1.0, t1)
+                    ln = (t1 - t0) * L
+                    nz = np.nonzero(ln > 1e-12)[0]
+                    rows.append(np.full(nz.size, a * nd + d))
+                    cols.append(nz)
+                    vals.append(ln[nz])
+            self._M = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=self.shape).tocsr()
+        return self._M
+
+    def _fwd(self, x):
+        return self.matrix() @ x
+
+    def _adj(self, y):
+        return self.matrix().T @ y

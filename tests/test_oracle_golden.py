@@ -258,3 +258,17 @@ def test_oneshot_solvers():
         x, lam = O.arnoldi_tikhonov(A, bb, 6, rp, **kw)
         assert lam_close([lam], [float(g[f"at_{tag}_lam"])], 2e-3) and relerr(x, g[f"at_{tag}_x"]) < (1e-4 if tag == "gcv" else 1e-6)
     assert relerr(O.gmres(A, g["b"], 5), g["gmres_x"]) < 1e-8
+
+
+def test_fanbeam_oracle_invariants():
+    """Fan-beam oracle (parity unpinned): exact adjoint by construction; every ray's weights sum to its chord through the
+    image square; geometry defaults of Tomography.define_proj_id (Tomography.py:48-60)."""
+    N = 16
+    A = O.FanBeam2D(N, np.linspace(0, np.pi, 6, endpoint=False))
+    assert A.nd == int(np.sqrt(2) * N) and A.sod == 3 * N and A.odd == N and abs(A.pitch - 4 / 3) < 1e-15
+    M = A.matrix()
+    chord = np.asarray(M.sum(axis=1)).reshape(6, A.nd)
+    assert chord.max() <= np.sqrt(2) * N + 1e-9 and np.all(chord[:, A.nd // 2 - 1:A.nd // 2 + 1] >= N - 1e-9)
+    rng = np.random.default_rng(0)
+    x, y = rng.standard_normal(N * N), rng.standard_normal(M.shape[0])
+    assert abs(np.dot(A @ x, y) - np.dot(x, A.T @ y)) < 1e-12 * np.linalg.norm(x) * np.linalg.norm(y) * N

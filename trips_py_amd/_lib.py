@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libtrk.so")
-SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip", "spmv.hip"]
+SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip", "spmv.hip", "fanbeam2d.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
 
@@ -86,6 +86,7 @@ SIGNATURES = {
     "trk_blur2d_create": (c_int, [ctypes.POINTER(c_dbl), c_int, c_int, c_int, c_int, ctypes.POINTER(c_op)]),
     "trk_radon2d_create": (c_int, [c_int, c_int, ctypes.POINTER(c_dbl), c_int, c_dbl, ctypes.POINTER(c_op)]),
     "trk_radon2d_dynamic_create": (c_int, [c_int, c_int, ctypes.POINTER(c_dbl), c_int, c_int, c_dbl, ctypes.POINTER(c_op)]),
+    "trk_fanbeam2d_create": (c_int, [c_int, c_int, c_dbl, c_dbl, c_dbl, ctypes.POINTER(c_dbl), c_int, ctypes.POINTER(c_op)]),
     "trk_deriv2d_create": (c_int, [c_int, ctypes.POINTER(c_op)]),
     "trk_spacetime_create": (c_int, [c_int, c_int, c_int, c_int, ctypes.POINTER(c_op)]),
     "trk_spacetime_set_halo": (c_int, [c_op, c_f32p, c_f32p]),

@@ -198,6 +198,28 @@ class Radon2DParallel(_HandleOperator):
         super().__init__(h, engine)
 
 
+class FanBeam2D(_HandleOperator):
+    """Fan-beam flat-detector line projector with the geometry defaults of Tomography.define_proj_id
+    (trips/test_problems/Tomography.py:48-67): p = int(sqrt(2) N) detector pixels, source-origin 3N, origin-detector N,
+    detector pitch (SOD+ODD)/SOD, theta = linspace(0, pi, views, endpoint=False)."""
+
+    def __init__(self, N, views=None, angles=None, n_det=None, source_origin=None, origin_detector=None, det_pitch=None,
+                 engine=None):
+        engine = engine if engine is not None else default_engine()
+        self.N = int(N)
+        self.angles = (np.linspace(0, np.pi, int(views), endpoint=False) if angles is None
+                       else np.asarray(angles, dtype=np.float64).reshape(-1))
+        self.n_det = int(np.sqrt(2) * self.N) if n_det is None else int(n_det)
+        self.sod = 3.0 * self.N if source_origin is None else float(source_origin)
+        self.odd = 1.0 * self.N if origin_detector is None else float(origin_detector)
+        self.pitch = (self.sod + self.odd) / self.sod if det_pitch is None else float(det_pitch)
+        arr, p = _dbl_array(self.angles)
+        h = ctypes.c_void_p()
+        _lib.check(engine.lib.trk_fanbeam2d_create(self.N, self.n_det, self.pitch, self.sod, self.odd, p, len(self.angles),
+                                                   ctypes.byref(h)), "trk_fanbeam2d_create")
+        super().__init__(h, engine)
+
+
 class FirstDerivative2D(_HandleOperator):
     def __init__(self, N, engine=None):
         engine = engine if engine is not None else default_engine()

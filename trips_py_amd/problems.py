@@ -8,7 +8,7 @@
 """
 import numpy as np
 
-from .operators import Blur1D, Blur2D, BlockDiagOp, Radon2DParallel
+from .operators import Blur1D, Blur2D, BlockDiagOp, FanBeam2D, Radon2DParallel
 
 
 def gauss_psf(dim, spread):
@@ -59,6 +59,25 @@ class Deblurring1D:
             raise NotImplementedError("only the 'reflect' boundary is implemented on the engine")
         self.PSF = gauss_psf_1d(nx, parameter)
         return Blur1D(self.PSF, nx, engine=engine)
+
+
+class Tomography:
+    """Operator-constructor subset of trips.test_problems.Tomography (same method name and return convention)."""
+
+    def __init__(self, **kwargs):
+        self.nx = self.ny = None
+        self.CommitCrime = kwargs.get("CommitCrime", False)
+
+    def forward_Op(self, nx, ny, views, engine=None):
+        """Fan-beam operator of Tomography.py:78-88.  With CommitCrime=False the reference also returns a second operator
+        whose angles are shifted by 1e-8 (:61-65); the same triple / pair is returned here."""
+        self.nx, self.ny, self.q = nx, ny, views
+        self.p = int(np.sqrt(2) * nx)
+        A = FanBeam2D(nx, views=views, engine=engine)
+        if not self.CommitCrime:
+            A_mis = FanBeam2D(nx, angles=A.angles + 1e-8, engine=engine)
+            return A, A, A_mis
+        return A, A
 
 
 def parallel_beam_frames(N, angle_sets, engine=None):
