@@ -146,7 +146,9 @@ def run_blur_cgls(args, rank, world):
     # the class trips_py_amd.solvers.CGLS itself picks for this operator (tol = 0, single rank per problem)
     fused = CGLSRunFused.usable(A, eng) and not args.unfused and (args.fused or n <= CGLSRunFused.AUTO_MAX_N)
     Run = CGLSRunFused if fused else CGLSRun
-    run = Run(A, b, x0, W + K, x_true=None, history=False)        # reference call without x_true (CGLS.py:16)
+    # reference call without x_true (CGLS.py:16); norms deferred exactly as CGLS() does for tol = 0 on one rank
+    run = Run(A, b, x0, W + K, x_true=None, history=False) if fused else \
+        Run(A, b, x0, W + K, x_true=None, history=False, defer_norms=True)
     for _ in range(W):
         run.step()
     tfwd = KernelTimer(A, K + 4, 0)

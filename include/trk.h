@@ -149,6 +149,13 @@ int trk_cgls_update_xr(int64_t n, int64_t m, const double* gamma_dev, const doub
                        const float* p, float* x_new, float* r, const float* w, const float* x_true,
                        double* sums_dev, trk_stream stream);
 
+/* The same update with the three norms left as *n_blocks x 3 raw block partials (summed once after the solve with
+ * trk_finalize_batched) — saves one reduction-finalize launch per iteration when nothing needs the norms on the fly
+ * (tol = 0, single rank). */
+int trk_cgls_update_xr_deferred(int64_t n, int64_t m, const double* gamma_dev, const double* delta_dev, const float* x,
+                                const float* p, float* x_new, float* r, const float* w, const float* x_true,
+                                double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
+
 /* ---------------------------------------------------------------- fused CGLS fast path --- */
 /* For operators whose kernel can combine two inputs on load (the blur): one CGLS iteration becomes three launches with no
  * reduction-finalize launches in between.  A "scalar source" (const double* p, int n) is the constant 1 (n = 0), a

@@ -112,6 +112,7 @@ SIGNATURES = {
     "trk_op_apply_fused": (c_int, [c_op, c_int, c_f32p, c_f32p, c_dbl, c_f64p, c_int, c_f64p, c_int, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
     "trk_cgls_x_update": (c_int, [c_i64, c_f64p, c_int, c_f64p, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
     "trk_finalize_batched": (c_int, [c_f64p, c_int, c_int, c_int, c_f64p, c_int, c_stream]),
+    "trk_cgls_update_xr_deferred": (c_int, [c_i64, c_i64, c_f64p, c_f64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
     "trk_gemv_t": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_gemv_n": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_dbl, c_f32p, c_dbl, c_f32p, c_f64p, c_stream]),
     "trk_wgram": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_stream]),

@@ -811,6 +811,25 @@ int trk_cgls_update_xr(int64_t n, int64_t m, const double* gamma, const double* 
   return finalize_sums(part, grid, 3, 3, sums, s);
 }
 
+int trk_cgls_update_xr_deferred(int64_t n, int64_t m, const double* gamma, const double* delta, const float* x,
+                                const float* p, float* x_new, float* r, const float* w, const float* x_true,
+                                double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream st) {
+  TRK_REQUIRE(gamma && delta && x && p && x_new && r && w && norm_partials && n_blocks, "trk_cgls_update_xr_deferred: NULL argument");
+  TRK_REQUIRE(n >= 0 && m >= 0, "trk_cgls_update_xr_deferred: negative size");
+  hipStream_t s = (hipStream_t)st;
+  const int grid = stream_grid(n > m ? n : m);
+  TRK_REQUIRE(grid <= capacity_blocks, "trk_cgls_update_xr_deferred: partial buffer too small (%d blocks needed)", grid);
+  *n_blocks = grid;
+  const bool vec = aligned16(x) && aligned16(p) && aligned16(x_new) && aligned16(r) && aligned16(w) &&
+                   (!x_true || aligned16(x_true));
+#define CU(XT, VC) hipLaunchKernelGGL((k_cgls_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, gamma, delta, x, p, x_new, r, w, x_true, norm_partials)
+  if (x_true) { if (vec) CU(true, true); else CU(true, false); }
+  else        { if (vec) CU(false, true); else CU(false, false); }
+#undef CU
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
 int trk_cgls_x_update(int64_t n, const double* gamma, int gamma_n, const double* delta, int delta_n, const float* x,
                       const float* p, float* x_new, const float* x_true, double* publish_delta, double* publish_gamma,
                       double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream st) {

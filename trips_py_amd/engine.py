@@ -192,6 +192,15 @@ class HipEngine:
                                          None if x_true is None else x_true.data_ptr(), _ptr(sums), self.stream())
         _lib.check(rc, "trk_cgls_update_xr")
 
+    def cgls_update_deferred(self, gamma, delta, x, p, x_new, r, w, x_true, partials, capacity):
+        n = ctypes.c_int(0)
+        rc = self.lib.trk_cgls_update_xr_deferred(x.numel(), r.numel(), _ptr(gamma), _ptr(delta), x.data_ptr(), p.data_ptr(),
+                                                  x_new.data_ptr(), r.data_ptr(), w.data_ptr(),
+                                                  None if x_true is None else x_true.data_ptr(), _ptr(partials),
+                                                  int(capacity), ctypes.byref(n), self.stream())
+        _lib.check(rc, "trk_cgls_update_xr_deferred")
+        return n.value
+
     # ------------------------------------------------------------------ fused CGLS fast path (include/trk.h)
     def op_can_fuse(self, handle):
         can = ctypes.c_int(0)

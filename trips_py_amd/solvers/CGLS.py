@@ -18,7 +18,7 @@ class CGLSRun:
     """The CGLS recurrence as an object: `step()` enqueues one iteration (no host sync), `rows()` downloads the
     per-iteration scalars.  `CGLS()` below and bench.py both drive this one implementation."""
 
-    def __init__(self, A, b, x0, max_iter, x_true=None, history=True):
+    def __init__(self, A, b, x0, max_iter, x_true=None, history=True, defer_norms=False):
         self.A = A = as_operator(A)
         self.eng = eng = A.engine
         m, n = A.shape
@@ -32,6 +32,12 @@ class CGLSRun:
             self.X = eng.empty_basis(max_iter, n)
         else:
             self.X = eng.empty_basis(2, n)
+        # tol = 0 on a single rank: nothing needs ||x||, ||dx||, ||x-x_true|| before the end -> keep them as block
+        # partials and sum all iterations in one launch afterwards (one reduction-finalize launch less per iteration)
+        self.defer = bool(defer_norms) and eng.world == 1 and hasattr(eng, "cgls_update_deferred")
+        self.NP = eng.scalars(3 * 1024 * max_iter) if self.defer else None
+        self.n_np = 0
+        self._final = 0
         self.r, self.t, self.w, self.p = eng.empty(m), eng.empty(n), eng.empty(m), eng.empty(n)
         # scalar layout: S[0] = gamma_0 = ||t_0||^2 ; row k (1-based) at 5k: [delta, gamma, ||x||^2, ||dx||^2, ||x-xt||^2]
         self.S = S = eng.scalars(5 * (max_iter + 1))
@@ -59,7 +65,11 @@ class CGLSRun:
         A.apply(self.p, out=self.w, sumsq=delta)
         if self.dist:
             eng.allreduce(S, b, b + 1)
-        eng.cgls_update(gamma_old, delta, self.x_cur, self.p, x_new, self.r, self.w, self.xt, S.ref(b + 2))
+        if self.defer:
+            self.n_np = eng.cgls_update_deferred(gamma_old, delta, self.x_cur, self.p, x_new, self.r, self.w, self.xt,
+                                                 self.NP.ref(3 * self.n_np * (k - 1)), 1024)
+        else:
+            eng.cgls_update(gamma_old, delta, self.x_cur, self.p, x_new, self.r, self.w, self.xt, S.ref(b + 2))
         A.apply(self.r, out=self.t, transpose=True, sumsq=gamma)
         if self.dist:
             eng.allreduce(S, b + 1, b + 5)
@@ -71,6 +81,9 @@ class CGLSRun:
         return self.S.host(5 * k, 5 * k + 5)
 
     def rows(self):
+        if self.defer and self._final != self.k and self.k > 0:
+            self.eng.finalize_batched(self.NP.ref(0), self.n_np, 3, self.k, self.S.ref(7), 5)
+            self._final = self.k
         Sh = self.S.host()
         return Sh[0], Sh[5:5 * (self.k + 1)].reshape(self.k, 5)
 
@@ -185,7 +198,10 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
     want = kwargs.get("fused", None)          # None: automatic by size; True / False: forced
     fused = (not sync_each) and CGLSRunFused.usable(A, A.engine) and \
         (want if want is not None else A.shape[1] <= CGLSRunFused.AUTO_MAX_N)
-    run = (CGLSRunFused if fused else CGLSRun)(A, b, x0, max_iter, x_true, kwargs.get("history", True))
+    if fused:
+        run = CGLSRunFused(A, b, x0, max_iter, x_true, kwargs.get("history", True))
+    else:
+        run = CGLSRun(A, b, x0, max_iter, x_true, kwargs.get("history", True), defer_norms=not sync_each)
     nt0 = None
     stop = False
     while run.k < run.max_iter and not stop:
