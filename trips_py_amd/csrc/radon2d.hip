@@ -14,8 +14,8 @@
 // bit-identical matrix entries (exact transpose; only the summation order differs).
 //
 // Forward: mode-1 angles read a transposed copy of the image so that both modes read ROWS: the 64 adjacent detectors of
-// a wave touch 64..90 contiguous floats per marching step (coalesced, L1/L2-resident bands).  A workgroup is 64
-// detectors x 4 row-quarters of one angle; the quarters are combined through LDS.
+// a wave touch 64..90 contiguous floats per marching step.  The grid runs over bands of 128 marching rows (see
+// k_radon_fwd); a workgroup is 64 detectors x 4 neighbouring angles.
 // Adjoint: gather form, one thread per pixel, no atomics: for each angle the <= 3 detectors whose ray passes within one
 // pixel are found from the inverse of q and re-evaluated exactly.
 //
@@ -24,6 +24,7 @@
 #include "trk_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 using namespace trk;
@@ -33,6 +34,7 @@ namespace {
 struct AngleParam {
   float inv, dq, k0, wgt;
   int mode;
+  float rinv;   // ~1/inv: only used to LOCATE the adjoint's candidate rays, never in a weight
 };
 
 struct RadonImpl {
@@ -41,6 +43,8 @@ struct RadonImpl {
   AngleParam* ang_dev;   // nt*na entries, frame-major
   float* xT;  // nt*N*N transposed images (forward, mode-1 angles); owned by the handle (non-reentrant across streams)
   int n_mode1;
+  float* part;  // [n_bands][nt*na][nd] forward band partial sums (n_bands > 1 only); owned by the handle
+  int n_bands, band;
 };
 
 // ---------------------------------------------------------------------------------------- transpose (LDS tile 32x33)
@@ -62,57 +66,128 @@ __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in,
 }
 
 // ---------------------------------------------------------------------------------------- forward
-// grid = (ceil(nd/64), n_ang_total, batch) ; block = 256 = 64 detectors x 4 marching quarters.
 // Both taps of a step come from ONE 8-byte buffer load at (row, floor(q)); out-of-range taps get weight 0 (the buffer
 // range check returns 0 for the two addresses that fall outside the image allocation).
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned int u2v __attribute__((ext_vector_type(2)));
 
+// One marching step of one ray with full edge handling: offset of the 8-byte load and the two tap weights (taps outside
+// the image, steps outside [.., te) and rays outside the detector weigh 0).
+__device__ __forceinline__ int radon_edge_tap(int tt, int te, bool live, int N, float dq, float base, f2v& w) {
+  const bool valid = live && tt < te;
+  const int tr = tt < te ? tt : te - 1;
+  const float q = fmaf((float)tr, dq, base);
+  const float qf = floorf(q);
+  const float f = q - qf;
+  const int c = (int)qf;
+  // c == -1: only the right tap (column 0) is inside; start the 8-byte load at column 0 instead (an access that
+  // STARTS below the buffer is dropped whole by the range check — measured on gfx950 — while one that runs off
+  // the end returns its in-range dword)
+  const bool neg1 = (c == -1);
+  const int cl = neg1 ? 0 : c;
+  const float w0 = neg1 ? f : (((unsigned)c < (unsigned)N) ? 1.0f - f : 0.f);
+  const float w1 = neg1 ? 0.f : (((unsigned)(c + 1) < (unsigned)N) ? f : 0.f);
+  w[0] = valid ? w0 : 0.f;
+  w[1] = valid ? w1 : 0.f;
+  return (tr * N + cl) * 4;
+}
+
+// Forward kernel.  grid = (ceil(nd/64) * n_angle_groups, n_bands); block = 256 = 4 waves = 4 CONSECUTIVE ANGLES of one
+// frame x 64 detectors, marching the RADON_BAND image rows (mode 1: columns, through the transposed copy) of band
+// blockIdx.y.  Why this shape (measured at 4096^2 x 180, MI355X): a wave marching the whole image touches 3-4 new
+// cache lines per step and never returns to them, and every angle sweeps the whole 67 MB image, so the first version
+// (one wave = a quarter of the image) moved ~12 GB through the fabric per apply and was bound by L2 misses (2.15 ms;
+// halving its VALU work changed nothing).  With row bands the grid runs band by band (blockIdx.x is the fast index),
+// the 2 MB band stays in every XCD's 4 MB L2 while all angles and detectors pass over it, and the four waves of a
+// workgroup - neighbouring angles, same detectors, same rows at the same time - share most of their L1 lines.
+// Band partial sums go to a scratch array [band][angle][detector] that k_radon_bands_sum adds up in a fixed order.
+//
+// Marching steps are taken in chunks of RADON_CHUNK.  A chunk whose taps are inside the image for EVERY ray of the wave
+// (q is monotone in tt, so its two end steps decide) runs without any edge logic: the row offset is a wave-uniform
+// SGPR, both taps and both weights sit in register pairs and one packed FMA accumulates them.
+#define RADON_CHUNK 32
+#define RADON_BAND 128
+
+template <bool FINAL>
 __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img, const float* __restrict__ imgT,
-                                                   int64_t ld_img, float* __restrict__ sino, int64_t ld_sino, int N,
-                                                   int nd, const AngleParam* __restrict__ ang, int na_per_frame) {
-  __shared__ float part[4][64];
-  const int a = blockIdx.y;                       // global angle index (frame-major)
+                                                   float* __restrict__ out, int N, int nd,
+                                                   const AngleParam* __restrict__ ang, int na_per_frame, int ngrp_per_frame,
+                                                   int ndblk, int64_t band_stride, int bh) {
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int grp = blockIdx.x / ndblk, dblk = blockIdx.x - grp * ndblk;
+  const int frame = grp / ngrp_per_frame;
+  const int af = (grp - frame * ngrp_per_frame) * 4 + wv;        // angle within the frame
+  if (af >= na_per_frame) return;
+  const int a = frame * na_per_frame + af;                         // global angle index (frame-major)
   const AngleParam p = ang[a];
-  const int frame = a / na_per_frame;
-  const float* __restrict__ I = (p.mode ? imgT : img) + (int64_t)blockIdx.z * ld_img + (int64_t)frame * N * N;
+  const float* __restrict__ I = (p.mode ? imgT : img) + (int64_t)frame * N * N;
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)I, 0, (unsigned)N * (unsigned)N * 4u, 0x00020000);
-  const int lane = threadIdx.x & 63, q4 = threadIdx.x >> 6;
-  const int d = blockIdx.x * 64 + lane;
+  const int d = dblk * 64 + lane;
   const float s = (float)d - 0.5f * (float)(nd - 1);
   const float base = fmaf(s, p.inv, p.k0);
-  const int t0 = (int)(((int64_t)N * q4) >> 2), t1 = (int)(((int64_t)N * (q4 + 1)) >> 2);
+  const int t0 = blockIdx.y * bh, t1 = (t0 + bh < N) ? t0 + bh : N;
+  const float qmax = (float)(N - 1);
+  const bool live = d < nd;
   double total = 0.0;
-  if (d < nd) {
-    for (int tb = t0; tb < t1; tb += 64) {
-      const int te = (tb + 64 < t1) ? tb + 64 : t1;
-      float acc = 0.f;
-#pragma unroll 8
-      for (int tt = tb; tt < te; ++tt) {
-        const float q = fmaf((float)tt, p.dq, base);
-        const float qf = floorf(q);
-        const float f = q - qf;
-        const int c = (int)qf;
-        // c == -1: only the right tap (column 0) is inside; start the 8-byte load at column 0 instead (an access that
-        // STARTS below the buffer is dropped whole by the range check — measured on gfx950 — while one that runs off
-        // the end returns its in-range dword)
-        const bool neg1 = (c == -1);
-        const int cl = neg1 ? 0 : c;
-        const f2v v = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (tt * N + cl) * 4, 0, 0));
-        const float w0 = neg1 ? f : (((unsigned)c < (unsigned)N) ? 1.0f - f : 0.f);
-        const float w1 = neg1 ? 0.f : (((unsigned)(c + 1) < (unsigned)N) ? f : 0.f);
-        acc = fmaf(w0, v[0], acc);
-        acc = fmaf(w1, v[1], acc);
+  for (int tb = t0; tb < t1; tb += RADON_CHUNK) {
+    const int te = (tb + RADON_CHUNK < t1) ? tb + RADON_CHUNK : t1;
+    const float qa = fmaf((float)tb, p.dq, base), qb = fmaf((float)(te - 1), p.dq, base);
+    const bool inside = !live || (fminf(qa, qb) >= 0.f && fmaxf(qa, qb) < qmax);
+    if (te - tb == RADON_CHUNK && __builtin_amdgcn_ballot_w64(inside) == ~0ull) {
+      f2v acc2 = {0.f, 0.f};
+      // two batches of 8 steps in flight: the loads of batch k+1 are issued before batch k is accumulated
+      f2v w[2][8], v[2][8];
+      auto issue = [&](int k) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int tt = tb + 8 * k + u;
+          const float q = fmaf((float)tt, p.dq, base);
+          const float qf = floorf(q);
+          w[k & 1][u][1] = q - qf;
+          w[k & 1][u][0] = 1.0f - w[k & 1][u][1];
+          v[k & 1][u] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)qf << 2, (unsigned)tt * (unsigned)N * 4u, 0));
+        }
+      };
+      issue(0);
+#pragma unroll
+      for (int k = 0; k < RADON_CHUNK / 8; ++k) {
+        if (k + 1 < RADON_CHUNK / 8) issue(k + 1);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc2 = __builtin_elementwise_fma(w[k & 1][u], v[k & 1][u], acc2);
       }
-      total += (double)acc;
+      total += (double)(acc2[0] + acc2[1]);
+    } else {
+      // edge chunk (or the short last one): same batching, weights carry the edge logic
+      f2v acc2 = {0.f, 0.f};
+#pragma unroll 1
+      for (int k = 0; k < RADON_CHUNK / 8 && tb + 8 * k < te; ++k) {
+        f2v w[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int off = radon_edge_tap(tb + 8 * k + u, te, live, N, p.dq, base, w[u]);
+          v[u] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc2 = __builtin_elementwise_fma(w[u], v[u], acc2);
+      }
+      total += (double)(acc2[0] + acc2[1]);
     }
   }
-  part[q4][lane] = (float)total;
-  __syncthreads();
-  if (q4 == 0 && d < nd) {
-    const float v = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
-    sino[(int64_t)blockIdx.z * ld_sino + (int64_t)a * nd + d] = p.wgt * v;
+  if (live) {
+    if (FINAL) out[(int64_t)a * nd + d] = p.wgt * (float)total;
+    else out[(int64_t)blockIdx.y * band_stride + (int64_t)a * nd + d] = (float)total;
   }
+}
+
+// sino[a][d] = wgt_a * sum over bands (fixed order, fp64) of the band partial sums
+__global__ __launch_bounds__(256) void k_radon_bands_sum(const float* __restrict__ part, int nb, int64_t band_stride,
+                                                         float* __restrict__ sino, int nd,
+                                                         const AngleParam* __restrict__ ang) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= band_stride) return;
+  double t = 0.0;
+  for (int b = 0; b < nb; ++b) t += (double)part[(int64_t)b * band_stride + idx];
+  sino[idx] = ang[idx / nd].wgt * (float)t;
 }
 
 // ---------------------------------------------------------------------------------------- adjoint (gather)
@@ -133,27 +208,39 @@ __global__ __launch_bounds__(256) void k_radon_adj(const float* __restrict__ sin
   const float sdh = 0.5f * (float)(nd - 1);
   const float fi = (float)i, fj = (float)j;
   float acc = 0.f;
-#pragma unroll 2
-  for (int a = 0; a < na; ++a) {
-    const AngleParam p = ang[a];
-    const float ftt = p.mode ? fj : fi;       // marching index
-    const float fcol = p.mode ? fi : fj;      // interpolated coordinate this pixel sits on
+  // One angle: ftt = marching index, fcol = interpolated coordinate this pixel sits on.  The sinogram row is read
+  // through its own buffer descriptor, so candidates d < 0 or d >= nd return 0 without any VALU bounds logic (single
+  // dwords: the range check applies per access).
+  auto one_angle = [&](const AngleParam p, const __amdgpu_buffer_rsrc_t row, float ftt, float fcol) {
     const float off = fmaf(ftt, p.dq, p.k0);
-    const float dstar = (fcol - off) / p.inv + sdh;
-    const int d0 = (int)rintf(dstar);
-    const float* __restrict__ Sa = S + (int64_t)a * nd;
+    const float d0f = rintf(fmaf(fcol - off, p.rinv, sdh));
+    const int d0 = (int)d0f;
+    const float sd0 = d0f - sdh;                  // exact, == (float)d0 - sdh of the forward kernel
     float sum = 0.f;
 #pragma unroll
     for (int e = -1; e <= 1; ++e) {
-      const int d = d0 + e;
-      const float sd = (float)d - sdh;
-      const float q = fmaf(ftt, p.dq, fmaf(sd, p.inv, p.k0));
+      const float q = fmaf(ftt, p.dq, fmaf(sd0 + (float)e, p.inv, p.k0));
       const float wgt = fmaxf(1.0f - fabsf(q - fcol), 0.f);
-      const float sv = ((unsigned)d < (unsigned)nd) ? Sa[(unsigned)d < (unsigned)nd ? d : 0] : 0.f;
+      // the empty asm hides that the three offsets are adjacent: merged into one wider load, a candidate pair that
+      // STARTS at d = -1 would be dropped whole by the range check and lose its in-range element d = 0
+      int voff = (d0 + e) << 2;
+      asm("" : "+v"(voff));
+      const float sv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(row, voff, 0, 0));
       sum = fmaf(wgt, sv, sum);
     }
     acc = fmaf(p.wgt, sum, acc);
+  };
+  auto angle = [&](int a) {
+    const AngleParam p = ang[a];
+    const auto row = __builtin_amdgcn_make_buffer_rsrc((void*)(S + (int64_t)a * nd), 0, (unsigned)nd * 4u, 0x00020000);
+    one_angle(p, row, p.mode ? fj : fi, p.mode ? fi : fj);
+  };
+  int a = 0;
+  for (; a + 4 <= na; a += 4) {   // unrolled by hand: loops holding inline asm are not runtime-unrolled by the compiler
+#pragma unroll
+    for (int u = 0; u < 4; ++u) angle(a + u);
   }
+  for (; a < na; ++a) angle(a);
   img[(int64_t)blockIdx.z * ld_img + (int64_t)frame * N * N + idx] = acc;
 }
 
@@ -169,8 +256,16 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
         dim3 g(ceil_div(N, 32), ceil_div(N, 32), nt);
         hipLaunchKernelGGL(k_transpose, g, dim3(256), 0, s, xb, im->xT, N);
       }
-      dim3 grid(ceil_div(nd, 64), nt * na, 1);
-      hipLaunchKernelGGL(k_radon_fwd, grid, dim3(256), 0, s, xb, im->xT, (int64_t)0, y + (int64_t)b * ldy, (int64_t)0, N, nd, im->ang_dev, na);
+      const int ndblk = ceil_div(nd, 64), ngrp = ceil_div(na, 4), nb = im->n_bands;
+      const int64_t bs = (int64_t)nt * na * nd;
+      dim3 grid(ndblk * ngrp * nt, nb, 1);
+      float* yb = y + (int64_t)b * ldy;
+      if (nb == 1) {
+        hipLaunchKernelGGL(k_radon_fwd<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band);
+      } else {
+        hipLaunchKernelGGL(k_radon_fwd<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band);
+        hipLaunchKernelGGL(k_radon_bands_sum, dim3(ceil_div(bs, 256)), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev);
+      }
       TRK_LAUNCH_CHECK();
     }
   } else {
@@ -192,6 +287,7 @@ void radon_destroy(trk_op* op) {
   auto* im = static_cast<RadonImpl*>(op->impl);
   if (im->ang_dev) (void)hipFree(im->ang_dev);
   if (im->xT) (void)hipFree(im->xT);
+  if (im->part) (void)hipFree(im->part);
   delete im;
 }
 
@@ -211,20 +307,25 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
       p.dq = (float)(st / ct);
       p.k0 = (float)(half - half * st / ct);
       p.wgt = (float)(scale / std::fabs(ct));
+      p.rinv = (float)ct;
     } else {
       p.mode = 1;
       p.inv = (float)(-1.0 / st);
       p.dq = (float)(ct / st);
       p.k0 = (float)(half - half * ct / st);
       p.wgt = (float)(scale / std::fabs(st));
+      p.rinv = (float)(-st);
       ++n1;
     }
     h[a] = p;
   }
-  auto* im = new RadonImpl{N, n_det, na, nt, nullptr, nullptr, n1};
+  const int band = getenv("TRK_RADON_BAND") ? atoi(getenv("TRK_RADON_BAND")) : RADON_BAND;   // multiple of RADON_CHUNK
+  const int nb = (N + band - 1) / band;
+  auto* im = new RadonImpl{N, n_det, na, nt, nullptr, nullptr, n1, nullptr, nb, band};
   hipError_t e = hipMalloc(&im->ang_dev, sizeof(AngleParam) * n_ang);
   if (e == hipSuccess) e = hipMemcpy(im->ang_dev, h.data(), sizeof(AngleParam) * n_ang, hipMemcpyHostToDevice);
   if (e == hipSuccess && n1 > 0) e = hipMalloc(&im->xT, sizeof(float) * (size_t)nt * N * N);
+  if (e == hipSuccess && nb > 1) e = hipMalloc(&im->part, sizeof(float) * (size_t)nb * n_ang * n_det);
   if (e != hipSuccess) {
     trk_op tmp{2, 0, 0, im, nullptr, nullptr, nullptr, 0};
     radon_destroy(&tmp);
