@@ -173,6 +173,14 @@ int trk_op_apply_fused(trk_op* op, int transpose, const float* x1, const float* 
 int trk_cgls_x_update(int64_t n, const double* gamma, int gamma_n, const double* delta, int delta_n, const float* x,
                       const float* p, float* x_new, const float* x_true, double* publish_delta, double* publish_gamma,
                       double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
+/* The projected Tikhonov problem of the Golub-Kahan hybrid solvers on the device (Hybrid_LSQR.py:104, GK_Tikhonov.py:60):
+ *   y = argmin || B_k y - beta0 e1 ||^2 + mu^2 || y ||^2 ,  B_k lower bidiagonal (k+1) x k with diagonal alpha_j and
+ *   sub-diagonal beta_{j+1}, given as the SQUARED norms the Golub-Kahan kernels leave in device doubles:
+ *   alpha_j^2 = alpha_sq[j*alpha_stride], beta_{j+1}^2 = beta_sq[j*beta_stride] (j < k), beta0^2 = *beta0_sq.
+ *   mu = sqrt(lam) of the reference's stacked system.  Writes y[0..k).  1 <= k <= 4096. */
+int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride, const double* beta_sq, int64_t beta_stride, int k,
+                        double mu, const double* beta0_sq, double* y, trk_stream stream);
+
 /* out[b*out_stride + v] = sum_j partials[(b*nblocks + j)*nvals + v]  for b < batches, v < nvals (fixed order). */
 int trk_finalize_batched(const double* partials, int nblocks, int nvals, int batches, double* out, int out_stride,
                          trk_stream stream);

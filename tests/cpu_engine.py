@@ -152,6 +152,17 @@ class CpuEngine:
         if sumsq is not None:
             _put(sumsq, np.dot(_d(out), _d(out)))
 
+    def bidiag_tikhonov(self, alpha_sq, alpha_stride, beta_sq, beta_stride, k, mu, beta0_sq, y):
+        (sa, ia), (sb, ib) = alpha_sq, beta_sq
+        al = np.sqrt(sa.a[ia:ia + alpha_stride * k:alpha_stride])
+        be = np.sqrt(sb.a[ib:ib + beta_stride * k:beta_stride])
+        B = np.zeros((k + 1, k))
+        B[np.arange(k), np.arange(k)] = al
+        B[np.arange(1, k + 1), np.arange(k)] = be
+        rhs = np.zeros(2 * k + 1)
+        rhs[0] = np.sqrt(_get(beta0_sq))
+        _put(y, np.linalg.lstsq(np.vstack((B, mu * np.eye(k))), rhs, rcond=None)[0])
+
     def wgram(self, W, k, w, b1, G, c1=None, c2=None):
         Wk = _d(W[:k])
         ww = np.ones(Wk.shape[1]) if w is None else _d(w)

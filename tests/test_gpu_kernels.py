@@ -161,3 +161,27 @@ def test_wgram(eng, k, m, weighted):
     assert np.allclose(got[:k * k].reshape(k, k), got[:k * k].reshape(k, k).T)
     assert np.allclose(got[k * k:k * k + k], W32 @ (w32 * b32), rtol=1e-6, atol=1e-6 * m ** 0.5)
     assert np.allclose(got[k * k + k:], W32 @ (w32 ** 2 * b32), rtol=1e-6, atol=1e-6 * m ** 0.5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,mu", [(1, 0.3), (2, 0.0), (7, 1e-2), (100, 1e-3), (1000, 0.5)])
+def test_bidiag_tikhonov_matches_stacked_lstsq(k, mu):
+    """trk_bidiag_tikhonov against the reference's formulation (Hybrid_LSQR.py:104): lstsq on [B; mu I], [beta0 e1; 0]."""
+    from trips_py_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(k)
+    al, be, b0 = rng.random(k) + 0.05, rng.random(k) + 0.05, 1.7
+    AB = eng.scalars(2 * k + 1)
+    ab = np.zeros(2 * k + 1)
+    ab[0], ab[1::2], ab[2::2] = b0 ** 2, al ** 2, be ** 2
+    AB.set(0, ab)
+    Y = eng.scalars(k)
+    eng.bidiag_tikhonov(AB.ref(1), 2, AB.ref(2), 2, k, mu, AB.ref(0), Y.ref(0))
+    B = np.zeros((k + 1, k))
+    B[np.arange(k), np.arange(k)] = al
+    B[np.arange(1, k + 1), np.arange(k)] = be
+    rhs = np.zeros(2 * k + 1)
+    rhs[0] = b0
+    want = np.linalg.lstsq(np.vstack((B, mu * np.eye(k))), rhs, rcond=None)[0]
+    got = Y.host()
+    assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max()) * np.linalg.cond(np.vstack((B, mu * np.eye(k))))

@@ -31,7 +31,7 @@ def golub_kahan_device(A, b, n_iter, dp_stop=False, **kwargs):
     gk = GKState(A, b, n_iter)
     if not dp_stop:
         for _ in range(n_iter):
-            gk.step()
+            gk.step(sync=False)                 # B_k is downloaded once, when the caller asks for it
         return gk
     eta = kwargs.get("gk_eta", 1.001)
     delta = kwargs.get("gk_delta", 0.001)
@@ -128,25 +128,12 @@ def golub_kahan_update(A, U, S, V):
     A = as_operator(A)
     st = getattr(U, "_trk_state", None)
     if not isinstance(st, GKState) or st.A is not A or st.V.k != (0 if np.ndim(S) < 2 else np.shape(S)[1]):
-        # cold start from the reference's arrays: upload what the step needs (U[:, -1], V[:, -1], last beta)
+        # cold start from the reference's arrays: upload the vectors and the bidiagonal
         U = np.asarray(U, dtype=np.float64)
         k = 0 if np.ndim(S) < 2 else np.shape(S)[1]
-        st = GKState.__new__(GKState)
-        st.A, st.eng = A, A.engine
-        eng = A.engine
-        m, n = A.shape
-        st.U, st.V = DeviceBasis(eng, m, k + 2), DeviceBasis(eng, n, k + 1)
-        for j in range(U.shape[1]):
-            st.U.next_slot().copy_(eng.to_vec(U[:, j], m))
-            st.U.commit()
-        for j in range(k):
-            st.V.next_slot().copy_(eng.to_vec(np.asarray(V)[:, j], n))
-            st.V.commit()
-        st.tmp_n, st.tmp_m, st.S = eng.empty(n), eng.empty(m), eng.scalars(4)
         Sm = np.asarray(S, dtype=np.float64)
-        st.alphas = [] if k == 0 else list(np.diag(Sm[:k, :k]))
-        st.betas = [] if k == 0 else list(np.diag(Sm[1:, :k]))
-        st.beta0 = None
+        st = GKState.resume(A, [U[:, j] for j in range(U.shape[1])], [np.asarray(V)[:, j] for j in range(k)],
+                            [] if k == 0 else list(np.diag(Sm[:k, :k])), [] if k == 0 else list(np.diag(Sm[1:, :k])))
     st.step()
     return KrylovArrays(st.U.numpy(), st), st.B(), KrylovArrays(st.V.numpy(), st)
 

@@ -61,7 +61,10 @@ class DeviceBasis:
 # --------------------------------------------------------------------------------------------------------------------
 class GKState:
     """Golub-Kahan bidiagonalisation A V_k = U_{k+1} B_k, one step at a time (decompositions.py:230-255, no
-    reorthogonalisation).  `alphas`, `betas` live on the host (float64); U, V on the device."""
+    reorthogonalisation).  U, V live on the device, and so do the squared norms that define B_k:
+    AB[0] = beta0^2 = ||b||^2, AB[2j+1] = alpha_j^2, AB[2j+2] = beta_{j+1}^2 (global sums after `allreduce`).
+    `alphas`, `betas` are their host copies; `step(sync=False)` skips the download, so a caller that needs B_k only
+    on the device (fixed-lambda Hybrid_LSQR: trk_bidiag_tikhonov) never synchronises."""
 
     def __init__(self, A, b, capacity):
         self.A, self.eng = A, A.engine
@@ -70,48 +73,109 @@ class GKState:
         self.U = DeviceBasis(eng, m, capacity + 1)
         self.V = DeviceBasis(eng, n, capacity)
         self.tmp_n, self.tmp_m = eng.empty(n), eng.empty(m)
-        self.S = eng.scalars(4)
-        self.alphas, self.betas = [], []
+        self.AB = eng.scalars(2 * max(1, capacity) + 1)
+        self._alphas, self._betas = [], []
         bv = eng.to_vec(b, m)
-        eng.nrm2sq(bv, self.S.ref(0))
-        eng.allreduce(self.S, 0, 1)
-        eng.scale(Coef(1.0, den=self.S.ref(0), sqrt_den=True), bv, self.U.next_slot())
+        eng.nrm2sq(bv, self.AB.ref(0))
+        eng.allreduce(self.AB, 0, 1)
+        eng.scale(Coef(1.0, den=self.AB.ref(0), sqrt_den=True), bv, self.U.next_slot())
         self.U.commit()
-        self.beta0 = float(np.sqrt(self.S.host(0, 1)[0]))
+        self._beta0 = None
 
-    def step(self):
-        A, eng, S = self.A, self.eng, self.S
+    @classmethod
+    def resume(cls, A, U_cols, V_cols, alphas, betas):
+        """Cold start from host arrays (golub_kahan_update handed the reference's U, S, V): upload the vectors and the
+        bidiagonal so that the next step continues the factorisation."""
+        st = cls.__new__(cls)
+        st.A, st.eng = A, A.engine
+        eng = A.engine
+        m, n = A.shape
+        k = len(alphas)
+        st.U, st.V = DeviceBasis(eng, m, k + 2), DeviceBasis(eng, n, k + 1)
+        for u in U_cols:
+            st.U.next_slot().copy_(eng.to_vec(u, m))
+            st.U.commit()
+        for v in V_cols:
+            st.V.next_slot().copy_(eng.to_vec(v, n))
+            st.V.commit()
+        st.tmp_n, st.tmp_m = eng.empty(n), eng.empty(m)
+        st.AB = eng.scalars(2 * (k + 1) + 1)
+        if k:
+            ab = np.zeros(2 * k + 1)
+            ab[1::2], ab[2::2] = np.square(alphas), np.square(betas)
+            st.AB.set(0, ab)
+        st._alphas, st._betas = [float(a) for a in alphas], [float(b) for b in betas]
+        st._beta0 = float("nan")                # unknown: the reference's arrays do not carry ||b||
+        return st
+
+    # host copies, downloaded on demand
+    def _sync(self):
         k = self.V.k
+        if len(self._alphas) < k:
+            h = self.AB.host(0, 2 * k + 1)
+            if self._beta0 is None:
+                self._beta0 = float(np.sqrt(h[0]))
+            self._alphas, self._betas = list(np.sqrt(h[1::2])), list(np.sqrt(h[2::2]))
+
+    @property
+    def alphas(self):
+        self._sync()
+        return self._alphas
+
+    @property
+    def betas(self):
+        self._sync()
+        return self._betas
+
+    @property
+    def beta0(self):
+        if self._beta0 is None:
+            self._beta0 = float(np.sqrt(self.AB.host(0, 1)[0]))
+        return self._beta0
+
+    def step(self, sync=True):
+        A, eng = self.A, self.eng
+        k = self.V.k
+        if len(self.AB) < 2 * k + 3:
+            new = eng.scalars(4 * k + 8)
+            new.view(0, 2 * k + 1).copy_(self.AB.view(0, 2 * k + 1))
+            self.AB = new
+        AB = self.AB
         u = self.U[k]
-        a2, b2 = S.ref(1), S.ref(2)
-        # v = A^T u_k - beta_{k-1} v_{k-1} ; alpha = ||v||
+        a2, b2 = AB.ref(2 * k + 1), AB.ref(2 * k + 2)
+        # v = A^T u_k - beta_k v_{k-1} ; alpha = ||v||        (beta_k^2 sits in AB[2k])
         if k == 0:
             A.apply(u, out=self.tmp_n, transpose=True, sumsq=a2)
         else:
             A.apply(u, out=self.tmp_n, transpose=True)
-            eng.axpby(1.0, self.tmp_n, -self.betas[-1], self.V[k - 1], self.tmp_n, sumsq=a2)
-        eng.allreduce(S, 1, 2)
+            eng.axpby(1.0, self.tmp_n, Coef(-1.0, num=AB.ref(2 * k), sqrt_num=True), self.V[k - 1], self.tmp_n, sumsq=a2)
+        eng.allreduce(AB, 2 * k + 1, 2 * k + 2)
         v = self.V.next_slot()
         eng.scale(Coef(1.0, den=a2, sqrt_den=True), self.tmp_n, v)
         self.V.commit()
         # u' = A v_k - alpha u_k ; beta = ||u'||
         A.apply(v, out=self.tmp_m)
         eng.axpby(1.0, self.tmp_m, Coef(-1.0, num=a2, sqrt_num=True), u, self.tmp_m, sumsq=b2)
-        eng.allreduce(S, 2, 3)
+        eng.allreduce(AB, 2 * k + 2, 2 * k + 3)
         eng.scale(Coef(1.0, den=b2, sqrt_den=True), self.tmp_m, self.U.next_slot())
         self.U.commit()
-        h = S.host(1, 3)
-        alpha, beta = float(np.sqrt(h[0])), float(np.sqrt(h[1]))
-        self.alphas.append(alpha)
-        self.betas.append(beta)
-        return alpha, beta
+        if not sync:
+            return None
+        h = np.sqrt(AB.host(2 * k + 1, 2 * k + 3))
+        if len(self._alphas) == k:
+            self._alphas.append(float(h[0]))
+            self._betas.append(float(h[1]))
+        else:
+            self._sync()
+        return float(h[0]), float(h[1])
 
     def B(self):
         """(k+1) x k lower-bidiagonal projected matrix."""
-        k = len(self.alphas)
+        alphas, betas = self.alphas, self.betas
+        k = len(alphas)
         B = np.zeros((k + 1, k))
-        B[np.arange(k), np.arange(k)] = self.alphas
-        B[np.arange(1, k + 1), np.arange(k)] = self.betas
+        B[np.arange(k), np.arange(k)] = alphas
+        B[np.arange(1, k + 1), np.arange(k)] = betas
         return B
 
 

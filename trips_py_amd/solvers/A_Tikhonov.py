@@ -4,9 +4,10 @@ import scipy.linalg as sla
 
 from .._io import Formatter, as_operator
 from ..decompositions import arnoldi_device
-from ._common import check_delta, choose_lambda, tikhonov_lstsq
+from ._common import check_delta, choose_lambda, tikhonov_lstsq, small_host_blas
 
 
+@small_host_blas
 def Arnoldi_Tikhonov(A, b, n_iter=3, regparam="gcv", **kwargs):
     """Returns (x, lambda).  Built on the reference's `arnoldi` (with its skipped-newest-vector quirk)."""
     A = as_operator(A)

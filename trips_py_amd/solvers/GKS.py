@@ -17,7 +17,7 @@ from ..engine import Coef
 from ..decompositions import golub_kahan_device
 from ..krylov import DeviceBasis, orthogonalize
 from ..operators import is_identity
-from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq
+from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq, small_host_blas
 
 
 class _ProjectedBases:
@@ -62,6 +62,7 @@ class _ProjectedBases:
         self._push_images(self.V.k - 1)
 
 
+@small_host_blas
 def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys xHistory, regParam, regParam_history, relError (if x_true), Residual, its (= n_iter-1).
     Engine-only kwarg: history=True."""

@@ -4,9 +4,10 @@ import scipy.linalg as sla
 
 from .._io import Formatter, as_operator
 from ..krylov import GKState
-from ._common import check_delta, choose_lambda, tikhonov_lstsq
+from ._common import check_delta, choose_lambda, tikhonov_lstsq, small_host_blas
 
 
+@small_host_blas
 def Golub_Kahan_Tikhonov(A, b, n_iter=3, regparam="gcv", **kwargs):
     """Returns (x, lambda).  NOTE the reference ignores `n_iter` and always takes 3 Golub-Kahan steps
     (`golub_kahan(A, b, n_iter=3, dp_stop=0)`, :60); reproduced."""

@@ -3,8 +3,10 @@ import numpy as np
 
 from .._io import Formatter, as_operator
 from ..decompositions import arnoldi_device
+from ._common import small_host_blas
 
 
+@small_host_blas
 def GMRES(A, b, n_iter=3, dp_stop=0, **kwargs):
     """Returns x.  NOTE the reference ignores `n_iter` (`arnoldi(A, b_vec, n_iter=5)`, :46) and solves
     `lstsq(H.T, H.T @ bhat)` — the minimum-norm y in R^{k+1} — then x = V_{k+1} y (:49-50); reproduced."""

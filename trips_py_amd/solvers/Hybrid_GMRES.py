@@ -7,9 +7,10 @@ import scipy.linalg as sla
 
 from .._io import Formatter, as_operator, history_fits
 from ..krylov import ArnoldiState
-from ._common import check_delta, choose_lambda, tikhonov_lstsq
+from ._common import check_delta, choose_lambda, tikhonov_lstsq, small_host_blas
 
 
+@small_host_blas
 def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys: xHistory (n_iter iterates), regParam, regParam_history (first entry 0),
     relError (if x_true), relResidual, its (= n_iter-1).  Engine-only kwarg: history=True."""

@@ -1,16 +1,19 @@
 """Hybrid LSQR on the HIP engine — signature, iteration structure and `info` of trips/solvers/Hybrid_LSQR.py:25-114.
 
-Device: Golub-Kahan steps (2 operator applies + fused axpby/norm kernels), x = V y (one tall-skinny GEMV over the
-row-per-vector basis), ||x - x_true||.  Host (float64, k-sized): B_k, lambda selection, the stacked Tikhonov solve.
+Device: Golub-Kahan steps (2 operator applies + fused axpby/norm kernels), the projected Tikhonov solve on the
+bidiagonal (trk_bidiag_tikhonov), x = V y (one tall-skinny GEMV over the row-per-vector basis), ||x - x_true||.
+Host (float64, k-sized): lambda selection only.  With a numeric `regparam` nothing is read back inside the loop: the
+whole solve is enqueued asynchronously.
 """
 import numpy as np
 import scipy.linalg as sla
 
 from .._io import Formatter, as_operator, history_fits
 from ..krylov import GKState
-from ._common import check_delta, choose_lambda, tikhonov_lstsq
+from ._common import check_delta, choose_lambda, small_host_blas
 
 
+@small_host_blas
 def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys: xHistory (n_iter-1 iterates: none is formed at the first step, :77-78), regParam,
     regParam_history, relError (if x_true), relResidual (empty list, as in the reference), its (= n_iter-1).
@@ -40,15 +43,17 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         eng.allreduce(E, 0, 1)
 
     lams, lam, nx_done, x_dev = [], 0, 0, None
+    on_host = isinstance(regparam, str)          # lambda selection needs B_k on the host
     for ii in range(n_iter):
-        gk.step()
+        gk.step(sync=on_host)
         k = ii + 1
-        B = gk.B()
-        bhat = np.zeros(k + 1)
-        bhat[0] = gk.beta0
         if ii == 0:
             lam = 0
             continue
+        if on_host:
+            B = gk.B()
+            bhat = np.zeros(k + 1)
+            bhat[0] = gk.beta0
         if isinstance(regparam, str) and regparam in ("gcv", "l_curve"):
             Qb, s, _ = sla.svd(B, full_matrices=False)
             lam = choose_lambda(regparam, np.diag(s), np.eye(k), Qb.T @ bhat, 0.0, kwargs, variant="modified", fullsize=m)
@@ -60,8 +65,8 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         else:
             lam = regparam
         lams.append(lam)
-        y = tikhonov_lstsq(B, np.eye(k), lam, bhat)
-        Y.set(0, y)
+        # y = lstsq([B; sqrt(lam) I], [beta0 e1; 0]) (:104), on the device from the squared norms in gk.AB
+        eng.bidiag_tikhonov(gk.AB.ref(1), 2, gk.AB.ref(2), 2, k, np.sqrt(lam), gk.AB.ref(0), Y.ref(0))
         x_dev = X[nx_done] if keep else X[0]
         eng.gemv_n(gk.V.data, k, Y.ref(0), x_dev)
         nx_done += 1

@@ -15,9 +15,10 @@ from .._io import Formatter, as_operator, history_fits
 from ..engine import Coef
 from ..decompositions import golub_kahan_device
 from ..krylov import DeviceBasis, orthogonalize
-from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq
+from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq, small_host_blas
 
 
+@small_host_blas
 def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys xHistory, regParam, regParam_history, relError (if x_true), Residual, its.
     Engine-only kwarg: history=True."""
