@@ -181,6 +181,14 @@ int trk_cgls_x_update(int64_t n, const double* gamma, int gamma_n, const double*
 int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride, const double* beta_sq, int64_t beta_stride, int k,
                         double mu, const double* beta0_sq, double* y, trk_stream stream);
 
+/* HOST function (no device work, no stream): lambda = argmin over [x1, x2] of the GCV function of a diagonalised
+ * projected problem,  G(lam) = sum_i ((1 - f_i) rhs_i)^2 / (m_eff - sum_i f_i)^2,  f_i = s_i^2 / (s_i^2 + lam),
+ * by the bounded Brent search of scipy.optimize.fminbound restated step for step — what
+ * trips/utilities/reg_param/gcv.py:94-95 runs every iteration (objective :25-78; x1 = 1e-9, x2 = 1e2, xtol = 1e-12,
+ * maxfun = 1000 there).  s, rhs: k host doubles.  fval_out / nfev_out may be NULL. */
+int trk_host_gcv_fminbound(const double* s, const double* rhs, int k, double m_eff, double x1, double x2, double xatol,
+                           int maxfun, double* lam_out, double* fval_out, int* nfev_out);
+
 /* out[b*out_stride + v] = sum_j partials[(b*nblocks + j)*nvals + v]  for b < batches, v < nvals (fixed order). */
 int trk_finalize_batched(const double* partials, int nblocks, int nvals, int batches, double* out, int out_stride,
                          trk_stream stream);

@@ -61,3 +61,40 @@ def test_diagonal_fast_path_equals_general_gcv():
             a = gcv_function(lam, np.diag(s), np.eye(k), rhs, variant, m)
             b = gcv_function_diag(lam, s, rhs, variant, m)
             assert np.isclose(a, b, rtol=1e-10)
+
+
+def test_host_gcv_minimiser_equals_scipy_fminbound():
+    """libtrk's host-side bounded Brent search (trk_host_gcv_fminbound) restates scipy.optimize.fminbound and NumPy's
+    summation order: on the diagonal GCV objective it returns the same lambda as the scipy path, bit for bit."""
+    import scipy.optimize as sopt
+    from trips_py_amd.reg_param import gcv as G
+    assert G._host_lib() is not None, "libtrk.so must be built for this test"
+    rng = np.random.default_rng(7)
+    for _ in range(60):
+        k = int(rng.integers(1, 300))
+        s = np.sort(rng.random(k) * 10 ** rng.uniform(-6, 1, k))[::-1].copy()
+        rhs = rng.standard_normal(k) * 10 ** rng.uniform(-3, 0, k)
+        m = k + int(rng.integers(0, 5000))
+        want = sopt.fminbound(lambda lam: G.gcv_function_diag(lam, s, rhs, "modified", m), 1e-9, 1e2, xtol=1e-12,
+                              maxfun=1000, disp=0)
+        assert G.fminbound_gcv_diag(s, rhs, m) == want
+
+
+def test_gcv_pair_reduction_keeps_the_minimiser():
+    """(R_A, R_L) -> (diag(s), I) by z = R_L y leaves G(lambda) unchanged: same lambda as minimising the k x k form."""
+    import scipy.optimize as sopt
+    from trips_py_amd.reg_param import gcv as G
+    rng = np.random.default_rng(3)
+    for k in (4, 17, 40):
+        RA = np.triu(rng.standard_normal((k, k))) * np.logspace(0, -3, k)[:, None]
+        RL = np.triu(rng.standard_normal((k, k))) + 3 * np.eye(k)
+        rhs = rng.standard_normal(k)
+        for lam in (1e-6, 1e-2, 3.0):
+            s, r2 = G._diagonalise(RA, RL, rhs)
+            assert np.isclose(G.gcv_function(lam, RA, RL, rhs), G.gcv_function_diag(lam, s, r2), rtol=1e-9)
+        direct = sopt.fminbound(lambda lam: G.gcv_function(lam, RA, RL, rhs), 1e-9, 1e2, xtol=1e-12, maxfun=1000, disp=0)
+        assert np.isclose(G.generalized_crossvalidation(RA, RL, rhs), direct, rtol=1e-6)
+    # singular R_L: falls back to the k x k form instead of dividing by zero
+    RL0 = np.triu(rng.standard_normal((5, 5)))
+    RL0[2, 2] = 0.0
+    assert G._diagonalise(np.eye(5), RL0, np.ones(5)) is None

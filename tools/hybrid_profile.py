@@ -14,7 +14,7 @@ its = int(sys.argv[4]) if len(sys.argv) > 4 else 100
 if which in ("lsqr",):
     A = Radon2DParallel(N, np.linspace(0, np.pi, 180, endpoint=False))
 else:
-    A = Blur2D(gauss_psf((9, 9), (3, 3)), N, N)
+    A = Blur2D(gauss_psf((9, 9), (3, 3))[0], N, N)
 eng = A.engine
 x = torch.rand(N * N, device=eng.device)
 b = A.apply(x)

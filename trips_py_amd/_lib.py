@@ -114,6 +114,7 @@ SIGNATURES = {
     "trk_finalize_batched": (c_int, [c_f64p, c_int, c_int, c_int, c_f64p, c_int, c_stream]),
     "trk_cgls_update_xr_deferred": (c_int, [c_i64, c_i64, c_f64p, c_f64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
     "trk_bidiag_tikhonov": (c_int, [c_f64p, c_i64, c_f64p, c_i64, c_int, c_dbl, c_f64p, c_f64p, c_stream]),
+    "trk_host_gcv_fminbound": (c_int, [c_f64p, c_f64p, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
     "trk_gemv_t": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_gemv_n": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_dbl, c_f32p, c_dbl, c_f32p, c_f64p, c_stream]),
     "trk_wgram": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_stream]),

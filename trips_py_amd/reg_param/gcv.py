@@ -28,15 +28,71 @@ def gcv_function_diag(lam, s, rhs, variant="standard", fullsize=None):
     return num / (m_eff - float(np.sum(f))) ** 2
 
 
-def generalized_crossvalidation(R_A, R_L, rhs, variant="standard", fullsize=None, **_ignored):
-    """lambda = argmin G over [1e-9, 1e2] by scipy's bounded Brent search, same settings as gcv.py:94-95."""
-    rhs = np.asarray(rhs, dtype=np.float64).reshape(-1)
-    R_A, R_L = np.asarray(R_A), np.asarray(R_L)
+_host = None
+
+
+def _host_lib():
+    """libtrk.so's host-side minimiser (trk_host_gcv_fminbound); None when the library cannot be loaded, in which case
+    the same search runs through scipy.optimize (identical algorithm, ~100x slower)."""
+    global _host
+    if _host is None:
+        try:
+            from .. import _lib
+            _host = _lib.load()
+        except Exception:
+            _host = False
+    return _host or None
+
+
+def fminbound_gcv_diag(s, rhs, m_eff, x1=1e-9, x2=1e2, xtol=1e-12, maxfun=1000):
+    """argmin of gcv_function_diag over [x1, x2] — bounded Brent search with the settings of gcv.py:94-95."""
+    s = np.ascontiguousarray(s, dtype=np.float64)
+    rhs = np.ascontiguousarray(rhs, dtype=np.float64)
+    lib = _host_lib()
+    if lib is None or s.size == 0:
+        return sopt.fminbound(lambda lam: gcv_function_diag(lam, s, rhs, "modified", m_eff), x1, x2, xtol=xtol,
+                              maxfun=maxfun, disp=0)
+    import ctypes
+    lam = ctypes.c_double(0.0)
+    rc = lib.trk_host_gcv_fminbound(s.ctypes.data, rhs.ctypes.data, int(s.size), float(m_eff), float(x1), float(x2),
+                                    float(xtol), int(maxfun), ctypes.byref(lam), None, None)
+    if rc != 0:
+        raise RuntimeError("trk_host_gcv_fminbound failed")
+    return lam.value
+
+
+def _diagonalise(R_A, R_L, rhs):
+    """(R_A, R_L) -> (s, U^T rhs) with G unchanged: substitute z = R_L y, M = R_A R_L^-1 = U diag(s) W^T; then
+    R_A (R_A^T R_A + lam R_L^T R_L)^-1 R_A^T = U diag(s^2/(s^2+lam)) U^T.  None if R_L is (numerically) singular."""
     k = R_A.shape[0]
+    if R_A.shape != (k, k) or R_L.shape != (k, k) or rhs.size != k:
+        return None
+    d = np.abs(np.diag(R_L))
+    tri = not np.any(np.tril(R_L, -1))
+    if tri and (d.min() <= 1e-12 * d.max()):
+        return None
+    try:
+        M = sla.solve_triangular(R_L, R_A.T, trans="T", lower=False).T if tri else sla.solve(R_L.T, R_A.T).T
+        U, sig, _ = sla.svd(M)
+    except (sla.LinAlgError, ValueError):
+        return None
+    if not np.all(np.isfinite(sig)):
+        return None
+    return sig, U.T @ rhs
+
+
+def generalized_crossvalidation(R_A, R_L, rhs, variant="standard", fullsize=None, **_ignored):
+    """lambda = argmin G over [1e-9, 1e2] by bounded Brent search, same settings as gcv.py:94-95.  The pair is first
+    brought to (diag(s), I) — it already is in the hybrid solvers — so that every one of the ~60 evaluations is O(k)."""
+    rhs = np.asarray(rhs, dtype=np.float64).reshape(-1)
+    R_A, R_L = np.asarray(R_A, dtype=np.float64), np.asarray(R_L, dtype=np.float64)
+    k = R_A.shape[0]
+    m_eff = fullsize if variant == "modified" else R_A.shape[0]
     if (R_A.shape == (k, k) and R_L.shape == (k, k) and not np.any(R_A - np.diag(np.diag(R_A)))
             and not np.any(R_L - np.eye(k))):
-        s = np.diag(R_A).copy()
-        fun = lambda lam: gcv_function_diag(lam, s, rhs, variant, fullsize)
-    else:
-        fun = lambda lam: gcv_function(lam, R_A, R_L, rhs, variant, fullsize)
+        return fminbound_gcv_diag(np.diag(R_A).copy(), rhs, m_eff)
+    red = _diagonalise(R_A, R_L, rhs)
+    if red is not None:
+        return fminbound_gcv_diag(red[0], red[1], m_eff)
+    fun = lambda lam: gcv_function(lam, R_A, R_L, rhs, variant, fullsize)
     return sopt.fminbound(fun, 1e-9, 1e2, xtol=1e-12, maxfun=1000, disp=0)
