@@ -26,6 +26,7 @@ import torch
 REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
+EXTRAS_BUDGET_S = 420
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -207,7 +208,20 @@ def run_blur_cgls(args, rank, world):
     del run
     torch.cuda.empty_cache()
     if not args.no_extras:
-        # secondary measurements (never `value`): each guarded so that the main line is always printed
+        # secondary measurements (never `value`): each guarded so that the main line is always printed — against
+        # exceptions by try/except, against a hang (e.g. one rank failing inside a collective) by a watchdog that prints
+        # the line with whatever is measured so far and ends the process
+        import threading
+
+        def give_up():
+            res["extra"]["extras_watchdog"] = f"secondary measurements exceeded {EXTRAS_BUDGET_S} s; abandoned"
+            if rank == 0:
+                print(json.dumps(res), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(EXTRAS_BUDGET_S, give_up)
+        watchdog.daemon = True
+        watchdog.start()
         for name, fn in (("c3_tomo512_hybrid_lsqr", lambda: extra_c3_tomo(world)),
                          ("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world)),
                          ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world))):
@@ -216,6 +230,7 @@ def run_blur_cgls(args, rank, world):
             except Exception as exc:          # noqa: BLE001
                 res["extra"][name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             barrier(world)
+        watchdog.cancel()
     return res
 
 
@@ -281,6 +296,13 @@ def extra_c3_tomo(world):
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     out["hybrid_lsqr_iters_per_sec_all_ranks"] = round(world * 100 / dt, 1)
+    Hybrid_LSQR(R, bt, 5, "gcv", history=False)
+    barrier(world)
+    t0 = time.perf_counter()
+    Hybrid_LSQR(R, bt, 100, "gcv", history=False)
+    barrier(world)
+    dt = max_over_ranks(time.perf_counter() - t0, world)
+    out["hybrid_lsqr_gcv_iters_per_sec_all_ranks"] = round(world * 100 / dt, 1)
     return out
 
 

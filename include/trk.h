@@ -137,6 +137,8 @@ int trk_axpby(int64_t n, double ca, const double* a_num, const double* a_den, in
               double* sumsq_dev, trk_stream stream);
 /* out = x * y (element-wise; MMGKS.py:114,116 `wf * (...)`, `wr * (...)`). */
 int trk_mul(int64_t n, const float* x, const float* y, float* out, trk_stream stream);
+/* out = w * (x - y) in one pass (the weighted residual `wf * (AV@y - b)` of MMGKS.py:114); out may alias any input. */
+int trk_mul_diff(int64_t n, const float* w, const float* x, const float* y, float* out, trk_stream stream);
 /* out = (v*v + eps*eps)^(p/2 - 1) with v = x - y (y may be NULL): the smoothed-Holder MM weights of
  * trips/utilities/weights.py:66-68 applied to the residual A x - b (MMGKS.py:56-57) or to L x (:60,93). */
 int trk_mm_weights(int64_t n, const float* x, const float* y, double eps, double p, float* out, trk_stream stream);

@@ -125,6 +125,9 @@ class CpuEngine:
     def mul(self, x, y, out):
         out.copy_(x * y)
 
+    def mul_diff(self, w, x, y, out):
+        out.copy_(w * (x - y))
+
     def mm_weights(self, x, y, eps, p, out):
         v = _d(x) - (0 if y is None else _d(y))
         out.copy_(torch.from_numpy(((v ** 2 + eps ** 2) ** (p / 2 - 1)).astype(np.float32)))

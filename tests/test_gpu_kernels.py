@@ -145,7 +145,8 @@ def test_gemv_t_and_gemv_n(eng, k, n):
     assert np.allclose(base.cpu().numpy(), r32 - y @ V32, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize("k,m", [(1, 64), (3, 5000), (4, 4096), (7, 10_001), (13, 33_000), (33, 70_001), (61, 20_000), (90, 9_000)])
+@pytest.mark.parametrize("k,m", [(1, 64), (3, 5000), (4, 4096), (7, 10_001), (13, 33_000), (14, 96), (20, 40_004), (30, 8_200),
+                                 (31, 4_100), (33, 70_001), (45, 12_004), (61, 20_000), (90, 9_000)])
 @pytest.mark.parametrize("weighted", [False, True])
 def test_wgram(eng, k, m, weighted):
     rng = np.random.default_rng(k + m)

@@ -79,14 +79,18 @@ def test_hybrid(eng, solver, tag):
         assert info["relResidual"] == []
 
 
+@pytest.mark.parametrize("streaming", [False, True])
 @pytest.mark.parametrize("tag", ["lam1e-2", "gcv", "dp"])
-def test_gks(eng, tag):
+def test_gks(eng, tag, streaming):
+    """`streaming` operators form A x, L x directly instead of (AV) y, (LV) y: same iterates to rounding."""
     g = load_golden(f"gks_blur32_{tag}")
     N = int(g["N"])
     rp = {"lam1e-2": 1e-2, "gcv": "gcv", "dp": "dp"}[tag]
     kw = {"delta": float(g["delta"])} if tag == "dp" else {}
     L = OracleOp(O.FirstDerivative2D(N), eng)
-    x, info = S.GKS(blur(eng, g), g["b"], L, int(g["projection_dim"]), int(g["n_iter"]), rp, g["x_true"], **kw)
+    A = blur(eng, g)
+    A.streaming = L.streaming = streaming
+    x, info = S.GKS(A, g["b"], L, int(g["projection_dim"]), int(g["n_iter"]), rp, g["x_true"], **kw)
     assert info["its"] == int(g["its"]) and len(info["xHistory"]) == int(g["n_iter"])
     if tag == "lam1e-2":
         assert relerr(x, g["x"]) < TOL
@@ -100,11 +104,14 @@ def test_gks(eng, tag):
 
 @pytest.mark.parametrize("tag,p,q,rp,eps", [("p2q1_lam1e-2", 2, 1, 1e-2, 0.1), ("p1q1_lam1e-2", 1, 1, 1e-2, 0.1),
                                             ("p2q0.5_eps0.01_lam1e-3", 2, 0.5, 1e-3, 0.01), ("p2q1_gcv", 2, 1, "gcv", 0.1)])
-def test_mmgks(eng, tag, p, q, rp, eps):
+@pytest.mark.parametrize("streaming", [False, True])
+def test_mmgks(eng, tag, p, q, rp, eps, streaming):
     g = load_golden("mmgks_blur32_" + tag)
     N = int(g["N"])
     L = OracleOp(O.FirstDerivative2D(N), eng)
-    x, info = S.MMGKS(blur(eng, g), g["b"], L, p, q, int(g["projection_dim"]), int(g["n_iter"]), rp, g["x_true"], epsilon=eps)
+    A = blur(eng, g)
+    A.streaming = L.streaming = streaming
+    x, info = S.MMGKS(A, g["b"], L, p, q, int(g["projection_dim"]), int(g["n_iter"]), rp, g["x_true"], epsilon=eps)
     assert info["its"] == int(g["its"]) and len(info["xHistory"]) == int(g["n_iter"])
     if rp != "gcv":
         assert relerr(x, g["x"]) < 5e-5

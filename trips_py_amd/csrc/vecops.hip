@@ -134,6 +134,22 @@ __global__ __launch_bounds__(NT) void k_mul(int64_t n, const float* x, const flo
   for (int64_t i = tail0 + tid; i < n; i += nth) out[i] = x[i] * y[i];
 }
 
+// out = w * (x - y)
+template <bool VEC>
+__global__ __launch_bounds__(NT) void k_mul_diff(int64_t n, const float* w, const float* x, const float* y, float* out) {
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      float4 c = ld4(w, i), a = ld4(x, i), b = ld4(y, i);
+      st4(out, i, make_float4(c.x * (a.x - b.x), c.y * (a.y - b.y), c.z * (a.z - b.z), c.w * (a.w - b.w)));
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) out[i] = w[i] * (x[i] - y[i]);
+}
+
 // w = (v^2 + eps^2)^(e), e = p/2 - 1.  e == -0.5 (q = 1, the TV case) is an rsqrt; e == 0 is 1.
 __device__ __forceinline__ float mm_w(float v, float eps2, float e, int special) {
   const float t = fmaf(v, v, eps2);
@@ -711,6 +727,150 @@ __global__ __launch_bounds__(NT) void k_wgram_mfma(const float* __restrict__ W, 
   }
 }
 
+// Register-direct variant on v_mfma_f32_16x16x4_f32 for KA <= 64 and 16-byte aligned rows: no LDS staging, no block
+// barriers inside the stream, and only the T(T+1)/2 upper 16 x 16 tiles of the symmetric Gram are computed (T = ceil(KA/16)).
+// Why: the 32 x 32 kernel above is bound by the fp32 matrix pipe, not by HBM — 64 cycles per instruction = 16 B/clk/CU of
+// input (measured 0.97 ms per pass over 33.5 M elements whatever k <= 30 is); one 32 x 32 tile costs 128 cycles per 4
+// elements, the 16 x 16 tiles cost 32 (T = 1), 96 (T = 2), 192 (T = 3), 320 (T = 4), which puts the pipe at or above
+// the HBM rate for every KA <= 64.
+// A wave owns groups of 32 U consecutive elements (U = 1).  Lane (r = l & 15, s = l >> 4) loads, for
+// each 16-row tile t, 2 U float4 of row 16 t + r at element offsets 16 j + 4 s (j < 2 U): the four s-lanes of a row read 64 contiguous bytes per
+// instruction.  Component c of float4 j feeds MFMA number 4 j + c of every tile pair (element slots s = 0..3 then hold
+// elements 16 j + 4 s + c).  The next group's loads are issued before the current group's MFMAs; the fp32 tiles are
+// flushed into fp64 accumulators after every group, so the long sum is fp64.
+typedef float f4v __attribute__((ext_vector_type(4)));
+
+template <int T, bool HAS_W, bool HAS_B>
+__global__ __launch_bounds__(NT, 2) void k_wgram_t16(const float* __restrict__ W, int64_t ld, int k, int64_t m,
+                                                  const float* __restrict__ w, const float* __restrict__ bvec,
+                                                  double* __restrict__ partials) {
+  constexpr int NP = T * (T + 1) / 2;
+  constexpr int U = 1;                                         // a group is 32 U elements: 2 U float4 per lane and tile (U = 4, 2 measured slower)
+  constexpr int GE = 32 * U;
+  __shared__ double red[3][4][64];
+  const int KA = k + (HAS_B ? 2 : 0);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, sl = lane >> 4;
+  // every lane loads unconditionally (no divergent branches, so all loads of a group are in flight together): lanes
+  // beyond the last row read row 0 and multiply by 0; `one[t]` is the factor of an unweighted live row
+  const float* rowp[T];
+  bool live[T], wtd[T];
+  float one[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int rr = 16 * t + r;
+    live[t] = rr < KA;
+    wtd[t] = HAS_W && live[t] && rr != k;                      // row k is the plain b; rows < k and row k+1 carry w
+    one[t] = live[t] ? 1.f : 0.f;
+    rowp[t] = (rr < k) ? W + (int64_t)rr * ld : (HAS_B && live[t] ? bvec : W);
+  }
+  double accd[NP][4];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accd[p][q] = 0.0;
+  const int64_t ngroup = m / GE;                               // full groups; the tail (< GE elements) is done below
+  const int64_t g0 = (int64_t)blockIdx.x * (NT / 64) + wave, gs = (int64_t)gridDim.x * (NT / 64);
+  float4 v[2][T][2 * U];
+  auto load = [&](int buf, int64_t g) {
+    const int64_t e = g * GE + 4 * sl;
+#pragma unroll
+    for (int j = 0; j < 2 * U; ++j) {
+      float4 wv = make_float4(1.f, 1.f, 1.f, 1.f);
+      if (HAS_W) wv = *reinterpret_cast<const float4*>(w + e + 16 * j);
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        float4 x = *reinterpret_cast<const float4*>(rowp[t] + e + 16 * j);
+        x.x *= wtd[t] ? wv.x : one[t];
+        x.y *= wtd[t] ? wv.y : one[t];
+        x.z *= wtd[t] ? wv.z : one[t];
+        x.w *= wtd[t] ? wv.w : one[t];
+        v[buf][t][j] = x;
+      }
+    }
+  };
+  auto consume = [&](int buf) {
+    int p = 0;
+#pragma unroll
+    for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+      for (int tb = ta; tb < T; ++tb, ++p) {
+        f4v acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2 * U; ++j) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[buf][ta][j].x, v[buf][tb][j].x, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[buf][ta][j].y, v[buf][tb][j].y, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[buf][ta][j].z, v[buf][tb][j].z, acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(v[buf][ta][j].w, v[buf][tb][j].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) accd[p][q] += (double)acc[q];
+      }
+  };
+  if (g0 < ngroup) {
+    load(0, g0);
+    int64_t g = g0;
+    for (; g + 2 * gs < ngroup; g += 2 * gs) {                 // two groups per trip: buffer indices stay compile-time
+      load(1, g + gs);
+      consume(0);
+      load(0, g + 2 * gs);
+      consume(1);
+    }
+    if (g + gs < ngroup) {
+      load(1, g + gs);
+      consume(0);
+      consume(1);
+    } else {
+      consume(0);
+    }
+  }
+  // tail elements [GE * ngroup, m): one wave, scalar predicated loads; element slot sl of step i holds element 4 i + sl
+  if (blockIdx.x == 0 && wave == 0 && (m % GE)) {
+    const int64_t e0 = ngroup * GE;
+    for (int i = 0; i < 8 * U; ++i) {
+      const int64_t e = e0 + 4 * i + sl;
+      float a[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) a[t] = (live[t] && e < m) ? rowp[t][e] * (wtd[t] ? w[e] : 1.f) : 0.f;
+      int p = 0;
+#pragma unroll
+      for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+        for (int tb = ta; tb < T; ++tb, ++p) {
+          f4v acc = {0.f, 0.f, 0.f, 0.f};
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ta], a[tb], acc, 0, 0, 0);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) accd[p][q] += (double)acc[q];
+        }
+    }
+  }
+  // combine the 4 waves (fixed order) and write the block partial in matrix order (16x16 C/D map: lane (r, sl), register q
+  // holds D[4 sl + q][r])
+  double* __restrict__ out = partials + (size_t)blockIdx.x * KA * KA;
+  int p = 0;
+#pragma unroll
+  for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+    for (int tb = ta; tb < T; ++tb, ++p) {
+      if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave - 1][q][lane] = accd[p][q];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double t = ((accd[p][q] + red[0][q][lane]) + red[1][q][lane]) + red[2][q][lane];
+          const int row = 16 * ta + 4 * sl + q, col = 16 * tb + r;
+          if (row < KA && col < KA) {
+            out[(size_t)row * KA + col] = t;
+            if (ta != tb) out[(size_t)col * KA + row] = t;
+          }
+        }
+      }
+      __syncthreads();
+    }
+}
+
 // scatter the augmented Gram [KA x KA] into G (k x k), c1, c2 (and optionally ||w b||^2)
 __global__ void k_wgram_unpack(const double* __restrict__ Ga, int k, int KA, double* __restrict__ G, double* __restrict__ c1,
                                double* __restrict__ c2) {
@@ -774,6 +934,17 @@ int trk_mul(int64_t n, const float* x, const float* y, float* out, trk_stream st
     hipLaunchKernelGGL((k_mul<true>), dim3(grid), dim3(NT), 0, (hipStream_t)st, n, x, y, out);
   else
     hipLaunchKernelGGL((k_mul<false>), dim3(grid), dim3(NT), 0, (hipStream_t)st, n, x, y, out);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_mul_diff(int64_t n, const float* w, const float* x, const float* y, float* out, trk_stream st) {
+  TRK_REQUIRE(w && x && y && out && n >= 0, "trk_mul_diff: NULL argument or n < 0");
+  const int grid = stream_grid(n);
+  if (aligned16(w) && aligned16(x) && aligned16(y) && aligned16(out))
+    hipLaunchKernelGGL((k_mul_diff<true>), dim3(grid), dim3(NT), 0, (hipStream_t)st, n, w, x, y, out);
+  else
+    hipLaunchKernelGGL((k_mul_diff<false>), dim3(grid), dim3(NT), 0, (hipStream_t)st, n, w, x, y, out);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }
@@ -890,15 +1061,29 @@ int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, cons
   const int nt2 = ceil_div(KA, WG_TILE), ntu = nt2 * (nt2 + 1) / 2;
   if (KA <= 64 && !getenv("TRK_WGRAM_NO_MFMA")) {
     // matrix-core single pass (every row read once)
+    static const bool no_direct = getenv("TRK_WGRAM_NO_DIRECT") != nullptr;
+    const bool al16 = (ld % 4 == 0) && aligned16(W) && (!w || aligned16(w)) && (!b1 || aligned16(b1));
+    const bool direct = al16 && !no_direct && KA <= 48;   // T = 4 does not fit the register file: 49..64 rows stay on the 32x32 kernel
+    const int T16 = (KA + 15) / 16;
+    // blocks per CU = what the register budget of the variant lets be resident (8 / 4 / 2 waves per SIMD for T = 1 / 2 / 3)
+    static const int per_cu_env = getenv("TRK_WGRAM_PER_CU") ? atoi(getenv("TRK_WGRAM_PER_CU")) : 0;
+    const int per_cu = per_cu_env ? per_cu_env : direct ? (T16 == 1 ? 8 : T16 == 2 ? 4 : 2) : 3;
     int64_t nchunk = (m + 127) / 128;
-    int bx = (int)(nchunk < (int64_t)cu_count() * 3 ? (nchunk > 0 ? nchunk : 1) : (int64_t)cu_count() * 3);
-    if (bx > kMaxPartialBlocks) bx = kMaxPartialBlocks;
+    int bx = (int)(nchunk < (int64_t)cu_count() * per_cu ? (nchunk > 0 ? nchunk : 1) : (int64_t)cu_count() * per_cu);
+    if (bx > 2 * kMaxPartialBlocks) bx = 2 * kMaxPartialBlocks;
     double* part = nullptr;
     const size_t npart = (size_t)bx * KA * KA;
     if (int rc = scratch_doubles(s, npart + (size_t)KA * KA, &part)) return rc;
     double* Ga = part + npart;
 #define WM(NTI, HW, HB) hipLaunchKernelGGL((k_wgram_mfma<NTI, HW, HB>), dim3(bx), dim3(NT), 0, s, W, ld, k, m, w, b1, part)
-    if (KA <= 32) {
+    if (direct) {
+#define WD(TT, HW, HB) hipLaunchKernelGGL((k_wgram_t16<TT, HW, HB>), dim3(bx), dim3(NT), 0, s, W, ld, k, m, w, b1, part)
+#define WDT(TT) do { if (w) { if (b1) WD(TT, true, true); else WD(TT, true, false); } \
+                     else   { if (b1) WD(TT, false, true); else WD(TT, false, false); } } while (0)
+      if (T16 == 1) WDT(1); else if (T16 == 2) WDT(2); else WDT(3);
+#undef WDT
+#undef WD
+    } else if (KA <= 32) {
       if (w) { if (b1) WM(1, true, true); else WM(1, true, false); }
       else   { if (b1) WM(1, false, true); else WM(1, false, false); }
     } else {

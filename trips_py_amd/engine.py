@@ -191,6 +191,11 @@ class HipEngine:
     def mul(self, x, y, out):
         _lib.check(self.lib.trk_mul(x.numel(), x.data_ptr(), y.data_ptr(), out.data_ptr(), self.stream()), "trk_mul")
 
+    def mul_diff(self, w, x, y, out):
+        """out = w * (x - y)."""
+        _lib.check(self.lib.trk_mul_diff(x.numel(), w.data_ptr(), x.data_ptr(), y.data_ptr(), out.data_ptr(), self.stream()),
+                   "trk_mul_diff")
+
     def mm_weights(self, x, y, eps, p, out):
         """out = ((x - y)^2 + eps^2)^(p/2 - 1); y may be None."""
         rc = self.lib.trk_mm_weights(x.numel(), x.data_ptr(), None if y is None else y.data_ptr(), float(eps), float(p),

@@ -180,15 +180,19 @@ class GKState:
 
 
 # --------------------------------------------------------------------------------------------------------------------
-def orthogonalize(eng, V, k, w, H, off, passes=2):
+def orthogonalize(eng, V, k, w, H, off, passes=2, out=None, sumsq=None):
     """w <- w - V_k (V_k^T w), `passes` times (block classical Gram-Schmidt; GKS.py:86-88 uses 3 passes, MMGKS.py:119-120
     two; for Arnoldi two passes of CGS match the reference's modified Gram-Schmidt to rounding).
-    Pass p leaves its k coefficients in H[off + p*k : off + (p+1)*k] (device doubles, all-reduced)."""
+    Pass p leaves its k coefficients in H[off + p*k : off + (p+1)*k] (device doubles, all-reduced).
+    The last pass may write its result to `out` instead of `w` (e.g. straight into the next basis slot) and leave the
+    LOCAL sum of its squares in `sumsq` — fused into that kernel, no extra pass."""
     for p in range(passes):
         lo = off + p * k
+        last = p == passes - 1
         eng.gemv_t(V.data, k, w, H.ref(lo))
         eng.allreduce(H, lo, lo + k)
-        eng.gemv_n(V.data, k, H.ref(lo), w, a=1.0, base=w, s=-1.0)
+        eng.gemv_n(V.data, k, H.ref(lo), out if (last and out is not None) else w, a=1.0, base=w, s=-1.0,
+                   sumsq=sumsq if last else None)
 
 
 class ArnoldiState:

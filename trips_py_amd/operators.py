@@ -26,6 +26,9 @@ class LinearOperator:
     """Base class: subclasses provide `_apply(x2d, y2d, transpose, sumsq)` on [batch, n] fp32 device tensors."""
 
     dtype = np.dtype("float32")
+    # True when one apply moves about as many bytes as reading two or three vectors (stencils): the projection solvers
+    # then form A x / L x directly instead of (AV) y / (LV) y, which reads k basis vectors
+    streaming = False
 
     def __init__(self, shape, engine=None):
         self.shape = (int(shape[0]), int(shape[1]))
@@ -172,6 +175,7 @@ class Blur2D(_HandleOperator):
         h = ctypes.c_void_p()
         _lib.check(engine.lib.trk_blur2d_create(p, psf.shape[0], psf.shape[1], self.nx, self.ny, ctypes.byref(h)), "trk_blur2d_create")
         super().__init__(h, engine)
+        self.streaming = max(psf.shape) <= 15          # the sliding-window / LDS-strip kernels (csrc/blur2d.hip)
 
 
 class Blur1D(Blur2D):
@@ -227,6 +231,7 @@ class FirstDerivative2D(_HandleOperator):
         h = ctypes.c_void_p()
         _lib.check(engine.lib.trk_deriv2d_create(self.N, ctypes.byref(h)), "trk_deriv2d_create")
         super().__init__(h, engine)
+        self.streaming = True
 
 
 class SpaceTimeDerivative(_HandleOperator):
@@ -250,6 +255,7 @@ class SpaceTimeDerivative(_HandleOperator):
         self._halo_next = engine.empty(npix) if self.has_next else None
         self._halo_prev = engine.empty(npix) if self.has_prev else None
         self._ps = 2 * self.N * (self.N - 1)
+        self.streaming = w == 1                        # sharded: every apply also pays a halo exchange
 
     def _apply(self, x2, y2, transpose, sumsq):
         eng = self.engine

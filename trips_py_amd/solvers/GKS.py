@@ -96,6 +96,7 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     eng.allreduce(E, 0, 2)
     b2 = float(E.host(1, 2)[0])
 
+    dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
     lams, lam, x_dev = [], None, None
     for ii in range(n_iter):
         k = pb.V.k
@@ -109,16 +110,24 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         eng.gemv_n(pb.V.data, k, Y.ref(0), x_dev)                                   # x = V y (:76)
         if xt is not None:
             eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
-        # r = A^T (AV y - b) + lam L^T (LV y)                                          (:81-85)
-        eng.gemv_n(pb.AV.data, k, Y.ref(0), tm, a=-1.0, base=bv, s=1.0)
+        # r = A^T (A x - b) + lam L^T (L x), A x = (AV) y and L x = (LV) y in the reference (:81-85); stencil operators
+        # form them directly from x (8n-12n bytes instead of k basis vectors)
+        if dA:
+            A.apply(x_dev, out=tm)
+            eng.axpby(1.0, tm, -1.0, bv, tm)
+        else:
+            eng.gemv_n(pb.AV.data, k, Y.ref(0), tm, a=-1.0, base=bv, s=1.0)
         A.apply(tm, out=r, transpose=True)
-        eng.gemv_n(pb.LV.data, k, Y.ref(0), tp)
+        if dL:
+            L.apply(x_dev, out=tp)
+        else:
+            eng.gemv_n(pb.LV.data, k, Y.ref(0), tp)
         L.apply(tp, out=rb, transpose=True)
         eng.axpby(1.0, r, float(lam), rb, r)
-        orthogonalize(eng, pb.V, k, r, H, 0, passes=3)                               # (:86-88)
-        eng.nrm2sq(r, R.ref(ii))
+        vn = pb.V.next_slot()
+        orthogonalize(eng, pb.V, k, r, H, 0, passes=3, out=vn, sumsq=R.ref(ii))      # (:86-88), ||r||^2 fused
         eng.allreduce(R, ii, ii + 1)
-        eng.scale(Coef(1.0, den=R.ref(ii), sqrt_den=True), r, pb.V.next_slot())     # vn = r/||r|| (:89-91)
+        eng.scale(Coef(1.0, den=R.ref(ii), sqrt_den=True), vn, vn)                   # vn = r/||r|| (:89-91)
         pb.V.commit()
         pb.append()                                                                  # AV, LV, Gram rows (:92-96)
     info = {"xHistory": fmt.hist(X, n_iter) if keep else [], "regParam": lam, "regParam_history": lams,

@@ -62,24 +62,28 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     H = eng.scalars(2 * kmax)
     E = eng.scalars(n_iter + 3)
     Rn = eng.scalars(n_iter + 1)
-    tm, wf = eng.empty(m), eng.empty(m)
-    tp, wr = eng.empty(p_rows), eng.empty(p_rows)
+    ax, tm, wf = eng.empty(m), eng.empty(m), eng.empty(m)
+    lx, tp, wr = eng.empty(p_rows), eng.empty(p_rows), eng.empty(p_rows)
     r, rb = eng.empty(n), eng.empty(n)
     if xt is not None:
         eng.nrm2sq(xt, E.ref(0))
         eng.allreduce(E, 0, 1)
     need_wb2 = isinstance(regparam, str) and regparam == "dp"
+    # A x and L x of the iterate are needed twice: in the residual of this iteration (the reference forms them as
+    # (AV) y and (LV) y, :114-116) and in the weights of the next (A @ x, L @ x, :56,:60).  A stencil operator forms them
+    # once, directly — 8n-12n bytes instead of reading k basis vectors; others keep the basis products.
+    dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
+    A.apply(x_cur, out=ax)
+    L.apply(x_cur, out=lx)
 
     lams, res, lam, x_dev, its = [], [], None, None, 0
     for ii in range(n_iter):
         its = ii
         k = V.k
         kk = k * k
-        # weights from the current iterate (:56-57, :60, :93)
-        A.apply(x_cur, out=tm)
-        eng.mm_weights(tm, bv, epsilon, pnorm, wf)
-        L.apply(x_cur, out=tp)
-        eng.mm_weights(tp, None, epsilon, qnorm, wr)
+        # weights from the current iterate (:56-57, :60, :93); ax = A x, lx = L x of it
+        eng.mm_weights(ax, bv, epsilon, pnorm, wf)
+        eng.mm_weights(lx, None, epsilon, qnorm, wr)
         # weighted Gram matrices and projected right-hand sides
         eng.wgram(AV.data, k, wf, bv, G.ref(0), G.ref(2 * kk), G.ref(2 * kk + k))
         eng.wgram(LV.data, k, wr, None, G.ref(kk))
@@ -103,25 +107,37 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         Y.set(0, y)
         x_dev = X[ii] if keep else X[0]
         eng.gemv_n(V.data, k, Y.ref(0), x_dev)                                        # x = V y (:107)
-        x_cur = x_dev if keep else x_cur
-        if not keep:
-            x_cur.copy_(x_dev)
         if xt is not None:
             eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
         if ii >= R_L.shape[0]:                                                        # (:109-110)
             break
-        # r = A^T (wf * (AV y - b)) + lam L^T (wr * (LV y))                            (:114-118)
-        eng.gemv_n(AV.data, k, Y.ref(0), tm, a=-1.0, base=bv, s=1.0)
-        eng.mul(wf, tm, tm)
+        last = ii == n_iter - 1
+        # r = A^T (wf * (A x - b)) + lam L^T (wr * (L x))                              (:114-118)
+        if dA:
+            A.apply(x_dev, out=ax)
+            res_a = ax
+        else:
+            eng.gemv_n(AV.data, k, Y.ref(0), tm)
+            res_a = tm
+            if not last:
+                A.apply(x_dev, out=ax)                                                # for the next weights (:56)
+        eng.mul_diff(wf, res_a, bv, tm)
         A.apply(tm, out=r, transpose=True)
-        eng.gemv_n(LV.data, k, Y.ref(0), tp)
-        eng.mul(wr, tp, tp)
+        if dL:
+            L.apply(x_dev, out=lx)
+            res_l = lx
+        else:
+            eng.gemv_n(LV.data, k, Y.ref(0), tp)
+            res_l = tp
+            if not last:
+                L.apply(x_dev, out=lx)                                                # for the next weights (:60)
+        eng.mul(wr, res_l, tp)
         L.apply(tp, out=rb, transpose=True)
         eng.axpby(1.0, r, float(lam), rb, r)
-        orthogonalize(eng, V, k, r, H, 0, passes=2)                                   # (:119-120)
-        eng.nrm2sq(r, Rn.ref(ii))
+        vn = V.next_slot()
+        orthogonalize(eng, V, k, r, H, 0, passes=2, out=vn, sumsq=Rn.ref(ii))       # (:119-120), ||r||^2 fused
         eng.allreduce(Rn, ii, ii + 1)
-        eng.scale(Coef(1.0, den=Rn.ref(ii), sqrt_den=True), r, V.next_slot())
+        eng.scale(Coef(1.0, den=Rn.ref(ii), sqrt_den=True), vn, vn)                  # vn = r / ||r|| (:121-123)
         V.commit()
         push_images(V.k - 1)
         res.append(ii)
