@@ -150,14 +150,12 @@ def run_blur_cgls(args, rank, world):
     # reference call without x_true (CGLS.py:16); norms deferred exactly as CGLS() does for tol = 0 on one rank
     run = Run(A, b, x0, W + K, x_true=None, history=False) if fused else \
         Run(A, b, x0, W + K, x_true=None, history=False, defer_norms=True)
-    for _ in range(W):
-        run.step()
+    run.run(W)
     tfwd = KernelTimer(A, K + 4, 0)
     tfwd.attach()
     barrier(world)
     t0 = time.perf_counter()
-    for _ in range(K):
-        run.step()
+    run.run(K)                                  # K iterations, enqueued by one library call (trk_cgls_iterate*)
     barrier(world)
     t1 = time.perf_counter()
     tfwd.detach()

@@ -191,6 +191,24 @@ int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride, const doub
 int trk_host_gcv_fminbound(const double* s, const double* rhs, int k, double m_eff, double x1, double x2, double xatol,
                            int maxfun, double* lam_out, double* fval_out, int* nfev_out);
 
+/* n_iters consecutive CGLS iterations (numbers k_first .. k_first + n_iters - 1, 1-based) enqueued by one call: the loop
+ * body of trips/solvers/CGLS.py:56-80 with tol = 0, i.e. nothing is read back between iterations.  Same kernels, scalar
+ * layout and results as calling trk_op_apply / trk_cgls_update_xr_deferred / trk_op_apply / trk_axpby per iteration:
+ *   S[0] = gamma_0 = ||t_0||^2 (set up by the caller, with r, t, p = t);  S[5k .. 5k+4] = [delta_k, gamma_k, (norms)]
+ *   X: iterate slots, row stride x_ld; iteration k writes slot k-1 (keep_history) or (k-1) & 1;  x_prev = x_{k_first-1}
+ *   NP: >= 3 * np_capacity_blocks * (iterations so far) doubles of norm partials (trk_finalize_batched sums them);
+ *   *n_np_inout: partial blocks per iteration (0 before the first iteration; constant afterwards). */
+int trk_cgls_iterate(trk_op* A, int k_first, int n_iters, float* p, float* r, float* t, float* w, float* X, int64_t x_ld,
+                     int keep_history, const float* x_prev, const float* x_true, double* S, double* NP,
+                     int np_capacity_blocks, int* n_np_inout, trk_stream stream);
+/* The same for operators with a fused apply (trk_op_fused_caps): three launches per iteration.  P, R: ping-pong pairs
+ * [2][p_ld], [2][r_ld] (iteration k reads index (k-1) & 1, writes k & 1); PG / PD: gamma / delta block partials with
+ * `pcap` doubles each; *n_g_inout: number of valid gamma partials in PG (set by the caller's r0/t0 setup). */
+int trk_cgls_iterate_fused(trk_op* A, int k_first, int n_iters, float* P, int64_t p_ld, float* R, int64_t r_ld, float* t,
+                           float* w, float* X, int64_t x_ld, int keep_history, const float* x_prev, const float* x_true,
+                           double* S, double* PG, double* PD, int pcap, double* NP, int np_capacity_blocks,
+                           int* n_g_inout, int* n_np_inout, trk_stream stream);
+
 /* out[b*out_stride + v] = sum_j partials[(b*nblocks + j)*nvals + v]  for b < batches, v < nvals (fixed order). */
 int trk_finalize_batched(const double* partials, int nblocks, int nvals, int batches, double* out, int out_stride,
                          trk_stream stream);

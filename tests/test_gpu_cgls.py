@@ -92,3 +92,36 @@ def test_fused_and_unfused_cgls_agree(N):
     xf, _ = CGLS(A, b, xs, 8, 0, history=False)
     xu, _ = CGLS(A, b, xs, 8, 0, history=False, fused=False)
     assert relerr(xf, xu) < 2e-6
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("history", [False, True])
+def test_c_loop_equals_stepwise(fused, history):
+    """trk_cgls_iterate / trk_cgls_iterate_fused (a stretch of iterations driven from C) enqueue exactly the launches of
+    step(): iterates and scalar rows are bit-identical, also when a stretch continues a stepwise start."""
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import gauss_psf
+    from trips_py_amd.solvers import CGLSRun, CGLSRunFused
+    N, iters = 96, 12
+    A = Blur2D(gauss_psf((9, 9), (3, 3))[0], N, N)
+    rng = np.random.default_rng(5)
+    b, x0, xt = rng.standard_normal(N * N), np.zeros(N * N), rng.standard_normal(N * N)
+
+    def make():
+        return (CGLSRunFused(A, b, x0, iters, xt, history) if fused
+                else CGLSRun(A, b, x0, iters, xt, history, defer_norms=True))
+    r1 = make()
+    for _ in range(iters):
+        r1.step()
+    r2 = make()
+    r2.step()
+    r2.step()
+    r2.run(4)
+    r2.run(1000)                                   # clipped to max_iter
+    assert r2.k == r1.k == iters
+    g1, rows1 = r1.rows()
+    g2, rows2 = r2.rows()
+    assert g1 == g2 and np.array_equal(rows1, rows2)
+    assert torch.equal(r1.x_cur, r2.x_cur)
+    if history:
+        assert torch.equal(r1.X, r2.X)

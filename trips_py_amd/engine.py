@@ -240,6 +240,28 @@ class HipEngine:
         _lib.check(rc, "trk_cgls_x_update")
         return n.value
 
+    def cgls_iterate(self, handle, k_first, n_iters, p, r, t, w, X, keep, x_prev, x_true, S, NP, np_cap, n_np):
+        """n_iters generic CGLS iterations in one library call; returns the partial-block count."""
+        c = ctypes.c_int(int(n_np))
+        rc = self.lib.trk_cgls_iterate(handle, int(k_first), int(n_iters), p.data_ptr(), r.data_ptr(), t.data_ptr(),
+                                       w.data_ptr(), X.data_ptr(), X.stride(0), int(bool(keep)), x_prev.data_ptr(),
+                                       None if x_true is None else x_true.data_ptr(), _ptr(S), _ptr(NP), int(np_cap),
+                                       ctypes.byref(c), self.stream())
+        _lib.check(rc, "trk_cgls_iterate")
+        return c.value
+
+    def cgls_iterate_fused(self, handle, k_first, n_iters, P, R, t, w, X, keep, x_prev, x_true, S, PG, PD, pcap, NP, np_cap,
+                           n_g, n_np):
+        """n_iters fused (3-launch) CGLS iterations in one library call; returns (n_g, n_np)."""
+        cg, cn = ctypes.c_int(int(n_g)), ctypes.c_int(int(n_np))
+        rc = self.lib.trk_cgls_iterate_fused(handle, int(k_first), int(n_iters), P.data_ptr(), P.stride(0), R.data_ptr(),
+                                             R.stride(0), t.data_ptr(), w.data_ptr(), X.data_ptr(), X.stride(0),
+                                             int(bool(keep)), x_prev.data_ptr(), None if x_true is None else x_true.data_ptr(),
+                                             _ptr(S), _ptr(PG), _ptr(PD), int(pcap), _ptr(NP), int(np_cap), ctypes.byref(cg),
+                                             ctypes.byref(cn), self.stream())
+        _lib.check(rc, "trk_cgls_iterate_fused")
+        return cg.value, cn.value
+
     def finalize_batched(self, partials, nblocks, nvals, batches, out, out_stride):
         rc = self.lib.trk_finalize_batched(_ptr(partials), int(nblocks), int(nvals), int(batches), _ptr(out), int(out_stride),
                                            self.stream())

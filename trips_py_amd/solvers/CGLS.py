@@ -76,6 +76,22 @@ class CGLSRun:
         eng.axpby(1.0, self.t, Coef(1.0, num=gamma, den=gamma_old), self.p, self.p)
         self.x_cur = x_new
 
+    def run(self, n_steps):
+        """Enqueue `n_steps` iterations.  With deferred norms on the HIP engine the whole stretch is one library call
+        (trk_cgls_iterate: the same launches as `step()`, driven from C instead of the interpreter)."""
+        n_steps = min(int(n_steps), self.max_iter - self.k)
+        if n_steps <= 0:
+            return
+        eng = self.eng
+        if self.defer and not self.dist and hasattr(self.A, "_h") and hasattr(eng, "cgls_iterate"):
+            self.n_np = eng.cgls_iterate(self.A._h, self.k + 1, n_steps, self.p, self.r, self.t, self.w, self.X, self.keep,
+                                         self.x_cur, self.xt, self.S.ref(0), self.NP.ref(0), 1024, self.n_np)
+            self.k += n_steps
+            self.x_cur = self.slot(self.k - 1)
+        else:
+            for _ in range(n_steps):
+                self.step()
+
     def row(self, k):
         """[delta, gamma, ||x||^2, ||dx||^2, ||x-xt||^2] of iteration k (host sync)."""
         return self.S.host(5 * k, 5 * k + 5)
@@ -164,6 +180,18 @@ class CGLSRunFused(CGLSRun):
                                       self.PG.ref(0), self.PCAP)
         self.x_cur = x_new
 
+    def run(self, n_steps):
+        """Enqueue `n_steps` iterations in one library call (trk_cgls_iterate_fused)."""
+        n_steps = min(int(n_steps), self.max_iter - self.k)
+        if n_steps <= 0:
+            return
+        self.n_g, self.n_np = self.eng.cgls_iterate_fused(self.A._h, self.k + 1, n_steps, self.P, self.R, self.t, self.w,
+                                                          self.X, self.keep, self.x_cur, self.xt, self.S.ref(0),
+                                                          self.PG.ref(0), self.PD.ref(0), self.PCAP, self.NP.ref(0), 1024,
+                                                          self.n_g, self.n_np)
+        self.k += n_steps
+        self.x_cur = self.slot(self.k - 1)
+
     def _finish(self):
         """Sum the norm partials of all iterations (one launch) and the last gamma (one launch)."""
         if self.k == 0 or self._final == self.k:
@@ -204,6 +232,8 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
         run = CGLSRun(A, b, x0, max_iter, x_true, kwargs.get("history", True), defer_norms=not sync_each)
     nt0 = None
     stop = False
+    if not sync_each:
+        run.run(run.max_iter)                   # tol = 0: nothing is read back inside the loop -> one enqueue
     while run.k < run.max_iter and not stop:
         run.step()
         if sync_each:
