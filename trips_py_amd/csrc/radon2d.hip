@@ -319,7 +319,11 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     }
     h[a] = p;
   }
-  const int band = getenv("TRK_RADON_BAND") ? atoi(getenv("TRK_RADON_BAND")) : RADON_BAND;   // multiple of RADON_CHUNK
+  int band = RADON_BAND;
+  if (const char* e = getenv("TRK_RADON_BAND")) {               // tuning knob; kept a positive multiple of RADON_CHUNK
+    band = atoi(e);
+    band = band < RADON_CHUNK ? RADON_CHUNK : (band / RADON_CHUNK) * RADON_CHUNK;
+  }
   const int nb = (N + band - 1) / band;
   auto* im = new RadonImpl{N, n_det, na, nt, nullptr, nullptr, n1, nullptr, nb, band};
   hipError_t e = hipMalloc(&im->ang_dev, sizeof(AngleParam) * n_ang);
