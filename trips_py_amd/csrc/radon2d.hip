@@ -191,11 +191,13 @@ __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img
 // with one ds_read2_b32 (the 32 lanes of a half-wave hit distinct banks: the rays' columns are strictly increasing and
 // span < 64 floats).  Columns outside the image are staged as zeros (out-of-range buffer offsets), so the marching loop
 // carries no edge logic at all.  The tile is private to its wave: no workgroup barrier, LDS operations of one wave
-// execute in order.
+// execute in order.  DMA = true (default): the 7 loads go straight into LDS (buffer_load_dwordx4 ... lds — lane l of load i
+// lands at float4 64 i + l of the tile, which is exactly the staging order; out-of-range lanes store zeros), which takes
+// the texture-data -> register -> LDS detour out of the path.
 #define LDS_R 16
 #define LDS_W 112
 
-template <bool FINAL>
+template <bool FINAL, bool DMA = false>
 __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__ img, const float* __restrict__ imgT,
                                                        float* __restrict__ out, int N, int nd,
                                                        const AngleParam* __restrict__ ang, int na_per_frame,
@@ -255,10 +257,17 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
         bool ok = (unsigned)col < (unsigned)N;
         if (!full) ok = ok && (tb + (lane + 64 * i) / (LDS_W / 4) < te);
         const int voff = ok ? (col << 2) + srowN4[i] : (int)img_bytes;          // out of range: returns 0, fetches nothing
-        v[i] = __builtin_bit_cast(f4r, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, rowbase, 0));
+        if (DMA)   // straight into LDS (buffer_load_dwordx4 ... lds: lane l of load i lands at float4 64 i + l of the tile)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(T + 256 * i), 16, voff, rowbase, 0, 0);
+        else
+          v[i] = __builtin_bit_cast(f4r, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, rowbase, 0));
       }
+      if (DMA) {
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): the tile is in LDS
+      } else {
 #pragma unroll
-      for (int i = 0; i < 7; ++i) *reinterpret_cast<f4r*>(&T[slds[i]]) = v[i];
+        for (int i = 0; i < 7; ++i) *reinterpret_cast<f4r*>(&T[slds[i]]) = v[i];
+      }
       __builtin_amdgcn_wave_barrier();
       // march.  (float) of the wave-uniform row number comes from a table through the scalar cache (fidx[i] = (float) i): the
       // SAME value the adjoint's (float) i conversion gives, without a vector instruction per step.
@@ -395,12 +404,16 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
       dim3 grid(ndblk * ngrp * nt, nb, 1);
       float* yb = y + (int64_t)b * ldy;
       static const bool no_lds = getenv("TRK_RADON_NO_LDS") != nullptr;
+      // global -> LDS directly (buffer_load_dwordx4 ... lds, new on gfx950) instead of through registers: 1.30 -> 1.11 ms at 4096^2
+      static const bool dma = getenv("TRK_RADON_NO_DMA") == nullptr;
       const bool lds = !no_lds && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15u) == 0);
       if (nb == 1) {
-        if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
+        if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<true, true>), grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
+        else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
         else hipLaunchKernelGGL(k_radon_fwd<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band);
       } else {
-        if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
+        if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<false, true>), grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
+        else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
         else hipLaunchKernelGGL(k_radon_fwd<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band);
         hipLaunchKernelGGL(k_radon_bands_sum, dim3(ceil_div(bs, 256)), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev);
       }
