@@ -96,6 +96,39 @@ def test_radon_vs_oracle_convention(N, na, nd):
     assert relerr(R.T @ y, Ro.T @ f(y)) < 2e-5, relerr(R.T @ y, Ro.T @ f(y))
 
 
+@pytest.mark.parametrize("case", ["fan7", "scattered", "wide_detector", "narrow_detector", "near45"])
+def test_radon_shared_window_forward_vs_oracle(case):
+    """N >= 1024 runs the window-sharing forward kernel (4 neighbouring angles stage one LDS window; rays are owned by
+    their column at the band's top row).  Against the oracle's sparse Joseph matrix, including what the kernel special-
+    cases: a last group of fewer than 4 angles, groups mixing row- and column-driven angles, angles in scattered order
+    (the union window does not fit -> direct gathers), detectors wider / narrower than the image."""
+    from oracle import cpu_ref as O
+    from trips_py_amd.operators import Radon2DParallel
+    N = 1024
+    ang = {"fan7": np.linspace(0, np.pi, 7, endpoint=False),
+           "scattered": np.array([0.1, 2.0, 0.8, 2.9, 1.3, 0.05]),
+           "wide_detector": np.deg2rad([10.0, 11.0, 12.0, 13.0, 100.0, 101.0]),
+           "narrow_detector": np.deg2rad([30.0, 31.0, 32.0, 33.0, 34.0]),
+           "near45": np.deg2rad([43.0, 44.0, 45.0, 46.0, 133.0, 134.0, 135.0, 136.0])}[case]
+    nd = {"wide_detector": 1500, "narrow_detector": 700}.get(case, N)
+    R, Ro = Radon2DParallel(N, ang, n_det=nd), O.Radon2D(N, ang, n_det=nd)
+    rng = np.random.default_rng(11)
+    ii, jj = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+    x = (np.exp(-((ii - N / 2.5) ** 2 + (jj - N / 1.7) ** 2) / (0.02 * N * N)) + 0.05 * rng.random((N, N))).reshape(-1)
+    f = lambda v: v.astype(np.float32).astype(np.float64)
+    assert relerr(R @ x, Ro @ f(x)) < 5e-5, relerr(R @ x, Ro @ f(x))
+    # exact-adjoint identity with the gather adjoint
+    eng = R.engine
+    xd = torch.from_numpy(rng.standard_normal(N * N).astype(np.float32)).to(eng.device)
+    yd = torch.from_numpy(rng.standard_normal(R.shape[0]).astype(np.float32)).to(eng.device)
+    Rx, RTy = R.apply(xd), R.apply(yd, transpose=True)
+    S = eng.scalars(2)
+    eng.dot(Rx, yd, S.ref(0))
+    eng.dot(xd, RTy, S.ref(1))
+    dd = S.host()
+    assert abs(dd[0] - dd[1]) <= 1e-6 * float(torch.linalg.norm(Rx.double()) * torch.linalg.norm(yd.double()))
+
+
 @pytest.mark.parametrize("N,na", [(64, 20), (512, 180), (1500, 24)])
 def test_radon_invariants(N, na):
     """What pins the Radon operator: exact-adjoint identity, axis-aligned views = column / row sums, mass conservation,
@@ -144,6 +177,18 @@ def test_dynamic_radon_equals_blockdiag_of_frames():
     Fo = O.BlockDiag([O.Radon2D(N, a) for a in angs])
     f = lambda v: v.astype(np.float32).astype(np.float64)
     assert relerr(F @ x, Fo @ f(x)) < 2e-5 and relerr(F.T @ y, Fo.T @ f(y)) < 2e-5
+
+
+def test_dynamic_radon_large_frames_use_the_shared_window_kernel():
+    """Frames of 1024^2 (window-sharing forward kernel, frame-major angle groups): one dynamic handle == per-frame handles."""
+    from trips_py_amd.operators import BlockDiagOp, Radon2DParallel
+    N, nt, na = 1024, 2, 5
+    angs = [np.deg2rad(3.0 * t + 36.0 * np.arange(na)) for t in range(nt)]
+    frames = [Radon2DParallel(N, a) for a in angs]
+    F = BlockDiagOp(frames)
+    x = np.random.default_rng(4).random(nt * N * N)
+    per_f = np.concatenate([frames[t] @ x[t * N * N:(t + 1) * N * N] for t in range(nt)])
+    assert np.array_equal(F @ x, per_f)
 
 
 def test_sparse_operator_and_reference_built_regularisers():

@@ -322,6 +322,175 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
   }
 }
 
+// Window-sharing forward kernel (N % 4 == 0, more than one band).  In k_radon_fwd_lds every wave fetches its own window: the
+// texture path moves 7 KB per wave and 16 steps and is saturated (PMC: TD 98 % busy, VALU 54 %).  Rays of NEIGHBOURING ANGLES
+// that cross the same columns need the same window, so here a workgroup is 4 consecutive angles x ONE image window:
+//   * within a band, a ray belongs to the window its column at the band's TOP row falls into:
+//         jj = floor((q(d, t0) + OFFS) / WO),   WO = floor(61 min_w |inv_w|) columns  (<= 61 rays of any of the 4 angles);
+//     a wave takes the 64 detectors around the window's pre-image and keeps those whose q(d, t0) — the very float the
+//     march uses — lies in it, so every ray has exactly one owner per band;
+//   * per chunk of 16 rows the union of the 4 waves' column ranges (a few columns wider than one wave's: angles 1 degree apart
+//     drift < 12 columns over a 128-row band) is staged ONCE, 2 direct-to-LDS 16-byte loads per thread into a double-buffered
+//     16 x 128 tile, one workgroup barrier per chunk; the march is that of k_radon_fwd_lds.
+// If the four angles are not neighbours (arbitrary angle order), or the group mixes row- and column-driven angles, the
+// union does not fit / the images differ: those chunks (groups) fall back to direct gathers — slower, same result.
+// Rays that cannot touch the image inside a band are owned by no window: the band partials are zeroed before the launch.
+#define WIN_R 16
+#define WIN_W 128
+#define WIN_MAXCH 32
+
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__ img, const float* __restrict__ imgT,
+                                                       float* __restrict__ out, int N, int nd,
+                                                       const AngleParam* __restrict__ ang, int na_per_frame,
+                                                       int ngrp_per_frame, int nwin, int64_t band_stride, int bh,
+                                                       const float* __restrict__ fidx) {
+  __shared__ __attribute__((aligned(16))) float tile[2][WIN_R * WIN_W];
+  __shared__ float ext[4][WIN_MAXCH][2];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int grp = blockIdx.x / nwin, jj = blockIdx.x - grp * nwin;
+  const int frame = grp / ngrp_per_frame;
+  const int af0 = (grp - frame * ngrp_per_frame) * 4;            // first angle of the group within the frame
+  const int nval = (na_per_frame - af0 < 4) ? na_per_frame - af0 : 4;   // valid waves: 0 .. nval-1
+  const AngleParam* __restrict__ ag = ang + (int64_t)frame * na_per_frame + af0;
+  // group-wide quantities (every wave computes the same scalars)
+  float invmin = fabsf(ag[0].inv);
+  bool mixed = false;
+  for (int w = 1; w < nval; ++w) {
+    invmin = fminf(invmin, fabsf(ag[w].inv));
+    mixed = mixed || (ag[w].mode != ag[0].mode);
+  }
+  const int WO = (int)floorf(61.0f * invmin);
+  const int OFFS = bh + 4;
+  const int t0 = blockIdx.y * bh, t1 = (t0 + bh < N) ? t0 + bh : N;
+  if ((int64_t)jj * WO - OFFS > (int64_t)N + bh + 4) return;     // window beyond every ray that can touch the band (uniform)
+  const bool valid = wv < nval;
+  const AngleParam p = ag[valid ? wv : 0];
+  const int a = frame * na_per_frame + af0 + wv;
+  const float* __restrict__ I = (p.mode ? imgT : img) + (int64_t)frame * N * N;
+  const unsigned img_bytes = (unsigned)N * (unsigned)N * 4u;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)I, 0, img_bytes, 0x00020000);
+  const float sdh = 0.5f * (float)(nd - 1);
+  // candidate detectors: the 64 around the pre-image of the window [qa, qb) at row t0
+  const float qa = (float)(jj * WO - OFFS), qb = (float)((jj + 1) * WO - OFFS);
+  const float t0f = fidx[t0];
+  const float offs = fmaf(t0f, p.dq, p.k0);
+  const float dA = (qa - offs) * p.rinv + sdh, dB = (qb - offs) * p.rinv + sdh;
+  const int dstart = (int)floorf(fminf(dA, dB)) - 1;
+  const int d = dstart + lane;
+  const float base = fmaf((float)d - sdh, p.inv, p.k0);
+  const float qtop = fmaf(t0f, p.dq, base);
+  const bool owned = valid && (unsigned)d < (unsigned)nd && qtop >= qa && qtop < qb;
+  const unsigned long long omask = __builtin_amdgcn_ballot_w64(owned);
+  const bool any = omask != 0ull;
+  const int l_first = any ? __builtin_ctzll(omask) : 0, l_last = any ? 63 - __builtin_clzll(omask) : 0;
+  const float b_first = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, base), l_first));
+  const float b_last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, base), l_last));
+  const float blo = fminf(b_first, b_last), bhi = fmaxf(b_first, b_last);
+  const float base_m = owned ? base : b_first;                   // lanes without a ray follow an owned one: always inside the tile
+  double total = 0.0;
+
+  if (mixed) {
+    // the group straddles the 45-degree switch of the marching axis: no common image, every wave gathers for itself
+    if (any) {
+      for (int tb = t0; tb < t1; tb += 8) {
+        f2v w[8], v[8], acc2 = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int off = radon_edge_tap(tb + u, t1, owned, N, p.dq, base, w[u]);
+          v[u] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc2 = __builtin_elementwise_fma(w[u], v[u], acc2);
+        total += (double)(acc2[0] + acc2[1]);
+      }
+    }
+  } else {
+    // column range of every chunk, per wave -> LDS -> every wave knows the union (one barrier for the whole band)
+    const int nch = (t1 - t0 + WIN_R - 1) / WIN_R;
+    if (lane < nch) {
+      const int tb = t0 + lane * WIN_R, te = (tb + WIN_R < t1) ? tb + WIN_R : t1;
+      const float ta = (float)tb * p.dq, tz = (float)(te - 1) * p.dq;
+      ext[wv][lane][0] = any ? blo + fminf(ta, tz) : 3.0e38f;
+      ext[wv][lane][1] = any ? bhi + fmaxf(ta, tz) : -3.0e38f;
+    }
+    __syncthreads();
+    // staging slots of this thread: float4 numbers t and t + 256 of the 16 x 32 tile
+    int sc4[2], srowN4[2], srow[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = (int)threadIdx.x + 256 * i;
+      srow[i] = idx / (WIN_W / 4);
+      sc4[i] = (idx - srow[i] * (WIN_W / 4)) * 4;
+      srowN4[i] = srow[i] * N * 4;
+    }
+    for (int ch = 0; ch < nch; ++ch) {
+      const int tb = t0 + ch * WIN_R, te = (tb + WIN_R < t1) ? tb + WIN_R : t1;
+      const int buf = ch & 1;
+      float* __restrict__ T = tile[buf];
+      const float ulo = fminf(fminf(ext[0][ch][0], ext[1][ch][0]), fminf(ext[2][ch][0], ext[3][ch][0]));
+      const float uhi = fmaxf(fmaxf(ext[0][ch][1], ext[1][ch][1]), fmaxf(ext[2][ch][1], ext[3][ch][1]));
+      const bool nobody = ulo > uhi;                             // no wave owns a ray in this window (uniform over the workgroup)
+      const int cs = __builtin_amdgcn_readfirstlane(nobody ? 0 : (((int)floorf(ulo) - 1) & ~3));
+      const bool fits = !nobody && (__builtin_amdgcn_readfirstlane((int)floorf(nobody ? 0.f : uhi)) + 2 - cs) < WIN_W;
+      const bool full = (te - tb == WIN_R);
+      f2v acc2 = {0.f, 0.f};
+      if (fits) {
+        const unsigned rowbase = (unsigned)tb * (unsigned)N * 4u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int col = cs + sc4[i];
+          const bool ok = ((unsigned)col < (unsigned)N) && (tb + srow[i] < te);
+          const int voff = ok ? (col << 2) + srowN4[i] : (int)img_bytes;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(T + (wv * 64 + 256 * i) * 4), 16,
+                                                   voff, rowbase, 0, 0);
+        }
+        __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this wave's part of the tile is in LDS
+      }
+      __syncthreads();                                           // tile complete; also: everyone is done with the other buffer
+      if (fits && any) {
+        const float* __restrict__ ftt = fidx + tb;
+        auto march = [&](auto full_tag) {
+          constexpr bool FULL = decltype(full_tag)::value;
+          f2v w[WIN_R], t2[WIN_R];
+#pragma unroll
+          for (int u = 0; u < WIN_R; ++u) {
+            const float q = fmaf(ftt[FULL ? u : (tb + u < te ? u : 0)], p.dq, base_m);
+            const float qf = floorf(q);
+            const float f = q - qf;
+            w[u][1] = (FULL || tb + u < te) ? f : 0.f;
+            w[u][0] = (FULL || tb + u < te) ? 1.0f - f : 0.f;
+            const int c = (int)qf;
+            int rowoff4 = (u * WIN_W - cs) * 4;
+            asm("" : "+s"(rowoff4));
+            const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(T) + rowoff4 + (c << 2));
+            t2[u] = (f2v){tp[0], tp[1]};
+          }
+#pragma unroll
+          for (int u = 0; u < WIN_R; ++u) acc2 = __builtin_elementwise_fma(w[u], t2[u], acc2);
+        };
+        if (full) march(std::true_type{});
+        else march(std::false_type{});
+      } else if (!fits && any) {
+        // the four angles are too far apart for one window: direct gathers for this chunk
+#pragma unroll 1
+        for (int k = 0; k < WIN_R / 8 && tb + 8 * k < te; ++k) {
+          f2v w[8], v[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int off = radon_edge_tap(tb + 8 * k + u, te, owned, N, p.dq, base, w[u]);
+            v[u] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) acc2 = __builtin_elementwise_fma(w[u], v[u], acc2);
+        }
+      }
+      total += (double)(acc2[0] + acc2[1]);
+    }
+  }
+  if (owned) out[(int64_t)blockIdx.y * band_stride + (int64_t)a * nd + d] = (float)total;
+}
+
 // sino[a][d] = wgt_a * sum over bands (fixed order, fp64) of the band partial sums
 __global__ __launch_bounds__(256) void k_radon_bands_sum(const float* __restrict__ part, int nb, int64_t band_stride,
                                                          float* __restrict__ sino, int nd,
@@ -407,7 +576,16 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
       // global -> LDS directly (buffer_load_dwordx4 ... lds, new on gfx950) instead of through registers: 1.30 -> 1.11 ms at 4096^2
       static const bool dma = getenv("TRK_RADON_NO_DMA") == nullptr;
       const bool lds = !no_lds && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15u) == 0);
-      if (nb == 1) {
+      static const bool no_win = getenv("TRK_RADON_NO_WIN") != nullptr;
+      // measured: 512^2 35 us (shared) vs 32 us (per-wave windows); 2048^2 0.256 vs 0.277 ms; 4096^2 0.96 vs 1.11 ms
+      if (nb > 1 && N >= 1024 && lds && dma && !no_win && im->band <= WIN_R * WIN_MAXCH) {
+        // window-sharing kernel: band partials of rays no window owns must read as zero
+        if (hipMemsetAsync(im->part, 0, sizeof(float) * (size_t)nb * bs, s) != hipSuccess) return fail(TRK_EHIP, "radon: hipMemsetAsync failed");
+        const int nwin = ceil_div(N + 2 * im->band + 16, 61);
+        dim3 gw(nwin * ngrp * nt, nb, 1);
+        hipLaunchKernelGGL(k_radon_fwd_win<0>, gw, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, nwin, bs, im->band, im->fidx);
+        hipLaunchKernelGGL(k_radon_bands_sum, dim3(ceil_div(bs, 256)), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev);
+      } else if (nb == 1) {
         if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<true, true>), grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
         else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
         else hipLaunchKernelGGL(k_radon_fwd<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band);
