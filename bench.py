@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--unfused", action="store_true", help="force the generic seven-launch CGLS iteration")
     ap.add_argument("--fused", action="store_true", help="force the fused three-launch CGLS iteration")
     ap.add_argument("--no-extras", action="store_true", help="skip the C4 (MMGKS) and C5 (sharded dynamic tomo) legs")
-    ap.add_argument("--cpu-iters", type=int, default=3, help="CPU-baseline sample: CGLS iterations timed on the host")
+    ap.add_argument("--cpu-iters", type=int, default=8, help="CPU-baseline sample: CGLS iterations timed on the host")
     return ap.parse_args()
 
 
