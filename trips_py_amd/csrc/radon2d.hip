@@ -24,6 +24,7 @@
 #include "trk_internal.h"
 
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <type_traits>
 #include <vector>
@@ -624,6 +625,10 @@ void radon_destroy(trk_op* op) {
 }  // namespace
 
 static int radon_create_impl(int N, int n_det, const double* angles, int nt, int na, double scale, trk_op** out) {
+  // the kernels address a frame through one buffer descriptor with 32-bit byte offsets
+  if ((int64_t)N * N >= ((int64_t)1 << 29) || (int64_t)n_det >= ((int64_t)1 << 29))
+    return fail(TRK_EUNSUPPORTED, "radon2d: frames of %d x %d pixels / %d detectors exceed the 2 GiB per-frame addressing of the kernels", N, N, n_det);
+  if ((int64_t)nt * na > (int64_t)INT32_MAX / 4) return fail(TRK_EUNSUPPORTED, "radon2d: too many angles");
   const int n_ang = nt * na;
   std::vector<AngleParam> h(n_ang);
   const double half = 0.5 * (N - 1);
