@@ -504,14 +504,23 @@ __global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__
 }
 
 // sino[a][d] = wgt_a * sum over bands (fixed order, fp64) of the band partial sums
+// ssq_part != NULL: also leaves sum(sino^2) of this block's 256 outputs in ssq_part[blockIdx.x] (the fused norm of the apply)
 __global__ __launch_bounds__(256) void k_radon_bands_sum(const float* __restrict__ part, int nb, int64_t band_stride,
                                                          float* __restrict__ sino, int nd,
-                                                         const AngleParam* __restrict__ ang) {
+                                                         const AngleParam* __restrict__ ang, double* __restrict__ ssq_part) {
+  __shared__ double lds[4];
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= band_stride) return;
-  double t = 0.0;
-  for (int b = 0; b < nb; ++b) t += (double)part[(int64_t)b * band_stride + idx];
-  sino[idx] = ang[idx / nd].wgt * (float)t;
+  float o = 0.f;
+  if (idx < band_stride) {
+    double t = 0.0;
+    for (int b = 0; b < nb; ++b) t += (double)part[(int64_t)b * band_stride + idx];
+    o = ang[idx / nd].wgt * (float)t;
+    sino[idx] = o;
+  }
+  if (ssq_part) {                                                 // uniform over the grid
+    const double q = block_sum<256>((double)o * o, lds);
+    if (threadIdx.x == 0) ssq_part[blockIdx.x] = q;
+  }
 }
 
 // ---------------------------------------------------------------------------------------- adjoint (gather)
@@ -593,9 +602,12 @@ __global__ __launch_bounds__(256) void k_radon_adj_prep(const float* __restrict_
 }
 
 __global__ __launch_bounds__(256) void k_radon_adj2(const float* __restrict__ sp, float* __restrict__ img, int N, int nd, int na,
-                                                    const AdjAngle* __restrict__ ang, const int* __restrict__ n_mode0) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)N * N) return;
+                                                    const AdjAngle* __restrict__ ang, const int* __restrict__ n_mode0,
+                                                    double* __restrict__ ssq_part) {
+  __shared__ double lds[4];
+  const int64_t idx_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool inside = idx_raw < (int64_t)N * N;
+  const int64_t idx = inside ? idx_raw : (int64_t)N * N - 1;        // lanes past the image repeat the last pixel (no store)
   const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
   const int frame = blockIdx.y;
   const int ndp = nd + ADJ_PAD;
@@ -631,7 +643,12 @@ __global__ __launch_bounds__(256) void k_radon_adj2(const float* __restrict__ sp
     for (int u = 0; u < 4; ++u) one_angle(a + u, fj, fi);
   }
   for (; a < na; ++a) one_angle(a, fj, fi);
-  img[(int64_t)frame * N * N + idx] = (accm + accp) + acc0;
+  const float o = (accm + accp) + acc0;
+  if (inside) img[(int64_t)frame * N * N + idx] = o;
+  if (ssq_part) {                                                 // uniform over the grid
+    const double q = block_sum<256>(inside ? (double)o * o : 0.0, lds);
+    if (threadIdx.x == 0) ssq_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = q;
+  }
 }
 
 int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
@@ -639,6 +656,13 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
   auto* im = static_cast<RadonImpl*>(op->impl);
   const int N = im->N, nd = im->nd, na = im->na, nt = im->nt;
   TimerScope tm(op->timer, op->timer_which, tr, s);
+  // fused ||y||^2 (batch 1): block partials from the kernel that writes y (band reduction / gather), then one finalize
+  double* ssq_part = nullptr;
+  const bool fuse_ssq = sumsq && batch == 1 && (tr ? getenv("TRK_RADON_ADJ_V1") == nullptr : im->n_bands > 1);
+  if (fuse_ssq) {
+    const int64_t nblk = tr ? (int64_t)ceil_div((int64_t)N * N, 256) * nt : (int64_t)ceil_div((int64_t)nt * na * nd, 256);
+    if (int rc = scratch_doubles(s, (size_t)nblk, &ssq_part)) return rc;
+  }
   if (!tr) {
     for (int b = 0; b < batch; ++b) {  // the transposed copy is per vector
       const float* xb = x + (int64_t)b * ldx;
@@ -662,7 +686,7 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
         const int nwin = ceil_div(N + 2 * im->band + 16, 61);
         dim3 gw(nwin * ngrp * nt, nb, 1);
         hipLaunchKernelGGL(k_radon_fwd_win<0>, gw, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, nwin, bs, im->band, im->fidx);
-        hipLaunchKernelGGL(k_radon_bands_sum, dim3(ceil_div(bs, 256)), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev);
+        hipLaunchKernelGGL(k_radon_bands_sum, dim3(ceil_div(bs, 256)), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev, ssq_part);
       } else if (nb == 1) {
         if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<true, true>), grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
         else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
@@ -671,9 +695,13 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
         if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<false, true>), grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
         else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
         else hipLaunchKernelGGL(k_radon_fwd<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band);
-        hipLaunchKernelGGL(k_radon_bands_sum, dim3(ceil_div(bs, 256)), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev);
+        hipLaunchKernelGGL(k_radon_bands_sum, dim3(ceil_div(bs, 256)), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev, ssq_part);
       }
       TRK_LAUNCH_CHECK();
+    }
+    if (ssq_part) {
+      tm.stop();
+      return finalize_sums(ssq_part, ceil_div((int64_t)nt * na * nd, 256), 1, 1, sumsq, s);
     }
   } else {
     static const bool adj_v1 = getenv("TRK_RADON_ADJ_V1") != nullptr;
@@ -687,8 +715,12 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
         hipLaunchKernelGGL(k_radon_adj_prep, dim3(ceil_div((int64_t)na * ndp, 256), nt), dim3(256), 0, s, x + (int64_t)b * ldx,
                            im->sino_pad, nd, na, im->adj_orig, im->adj_wgt);
         hipLaunchKernelGGL(k_radon_adj2, dim3(ceil_div((int64_t)N * N, 256), nt), dim3(256), 0, s, im->sino_pad,
-                           y + (int64_t)b * ldy, N, nd, na, im->adj_ang, im->adj_n0);
+                           y + (int64_t)b * ldy, N, nd, na, im->adj_ang, im->adj_n0, ssq_part);
         TRK_LAUNCH_CHECK();
+      }
+      if (ssq_part) {
+        tm.stop();
+        return finalize_sums(ssq_part, ceil_div((int64_t)N * N, 256) * nt, 1, 1, sumsq, s);
       }
     }
   }
