@@ -69,7 +69,8 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     A, L = as_operator(A), as_operator(L, "L")
     check_delta(regparam, kwargs)
     if is_identity(L):
-        raise NotImplementedError("GKS with L = Identity (the SVD branch, GKS.py:44-50) is not implemented on the engine")
+        raise NotImplementedError("GKS with L = Identity: the reference's SVD branch (GKS.py:44-50) sets R_L to a pylops Identity and then "
+                                  "fails in np.concatenate((R_A, sqrt(lam) * R_L)) (:74); not reproduced — use Hybrid_LSQR for L = I")
     eng = A.engine
     m, n = A.shape
     n_iter, d = int(n_iter), int(projection_dim)
