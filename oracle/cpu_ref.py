@@ -417,24 +417,38 @@ def arnoldi_update(A, V, H):
     return np.hstack((V, (w / h[k])[:, None])), Hn
 
 
-def arnoldi(A, b, n_iter):
-    """decompositions.py:20-116 (dp_stop=False).  NOTE the reference orthogonalises step ii only
-    against the first `ii` vectors... which is all of them but the newest (jj < iterations == ii):
-    H[ii,ii] is never written and the new vector is not orthogonalised against Q[:,ii]."""
+def arnoldi(A, b, n_iter, dp_stop=False, gk_eta=1.001, gk_delta=0.001):
+    """decompositions.py:20-116.  NOTE the reference orthogonalises step ii only against the first `ii` vectors... which
+    is all of them but the newest (jj < iterations == ii): H[ii,ii] is never written and the new vector is not
+    orthogonalised against Q[:,ii].  dp_stop (:104-112): after every step the NORMALISED b is projected, y solves
+    (H_k^T H_k) y = Q_k^T b with the square top block H_k of H, and the factorisation halts before the next step once
+    ||A Q_k y - b/||b|| || <= gk_eta * gk_delta (defaults 1.001, 0.001; not the solvers' delta)."""
     b = _col(b)
     n = b.shape[0]
-    Q = np.zeros((n, n_iter + 1))
-    H = np.zeros((n_iter + 1, n_iter))
-    Q[:, 0] = b / np.linalg.norm(b)
+    bn = b / np.linalg.norm(b)
+    Q = np.zeros((n, 2))
+    H = np.zeros((2, 1))
+    Q[:, 0] = bn
+    res_norm = np.inf
     for ii in range(n_iter):
+        if dp_stop and res_norm <= gk_eta * gk_delta:
+            break
+        if ii != 0:
+            Q = np.pad(Q, ((0, 0), (0, 1)))
+            H = np.pad(H, ((0, 1), (0, 1)))
         w = _col(A @ Q[:, ii])
         for jj in range(ii):
             H[jj, ii] = np.dot(Q[:, jj], w)
             w = w - H[jj, ii] * Q[:, jj]
         H[ii + 1, ii] = np.linalg.norm(w)
         if H[ii + 1, ii] == 0:
-            return Q[:, :ii + 2], H[:ii + 2, :ii + 1]
+            return Q, H
         Q[:, ii + 1] = w / H[ii + 1, ii]
+        if dp_stop:
+            bhat = Q[:, :-1].T @ bn
+            Hk = H[:-1, :]
+            y = np.linalg.lstsq(Hk.T @ Hk, bhat, rcond=None)[0]
+            res_norm = np.linalg.norm(_col(A @ (Q[:, :-1] @ y)) - bn)
     return Q, H
 
 
@@ -780,7 +794,8 @@ def golub_kahan_tikhonov(A, b, n_iter=3, regparam="gcv", delta=None, eta=1.01):
 
 
 def arnoldi_tikhonov(A, b, n_iter=3, regparam="gcv", delta=None, eta=1.01):
-    """trips/solvers/A_Tikhonov.py:23-97 (uses the quirky `arnoldi`, decompositions.py:20-116)."""
+    """trips/solvers/A_Tikhonov.py:23-97 (uses the quirky `arnoldi`, decompositions.py:20-116).  dp_stop=True is not
+    restated: the reference call `arnoldi(A, b, n_iter, dp_stop, **kwargs)` (:70) then raises TypeError."""
     if A.shape[0] != A.shape[1]:
         raise ValueError("The observation matrix A must be square for this method.")
     b = np.asarray(b, dtype=np.float64).reshape(-1, 1)

@@ -42,6 +42,10 @@ def test_decompositions():
     g = load_golden("arnoldi_blur32_d6")
     Q, H = arnoldi(A, g["b"], int(g["n_iter"]))
     assert H.shape == g["H"].shape and np.allclose(H, g["H"], rtol=1e-3, atol=1e-5)
+    for tag in ("stop1", "never"):                                    # dp_stop inside arnoldi (decompositions.py:104-112)
+        g = load_golden("arnoldi_blur32_dpstop_" + tag)
+        Q, H = arnoldi(blur(g), g["b"], int(g["n_iter"]), True, gk_eta=float(g["gk_eta"]), gk_delta=float(g["gk_delta"]))
+        assert Q.shape == g["Q"].shape and H.shape == g["H"].shape and np.allclose(H, g["H"], rtol=1e-3, atol=1e-5)
 
 
 @pytest.mark.parametrize("tag", ["lam1e-2", "gcv", "dp"])

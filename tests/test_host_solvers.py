@@ -189,3 +189,18 @@ def test_golub_kahan_dp_stop(eng):
     U, Sm, V = golub_kahan(A, g["b"], int(g["n_iter"]), True, gk_eta=float(g["gk_eta"]), gk_delta=float(g["gk_delta"]))
     assert Sm.shape == g["S"].shape and V.shape == g["V"].shape          # stops at the same step as the reference
     assert np.allclose(Sm, g["S"], rtol=1e-4, atol=1e-7) and relerr(V[:, :4], g["V"][:, :4]) < 1e-4
+
+
+@pytest.mark.parametrize("tag", ["stop1", "never"])
+def test_arnoldi_dp_stop(eng, tag):
+    g = load_golden("arnoldi_blur32_dpstop_" + tag)
+    A = blur(eng, g)
+    Q, H = arnoldi(A, g["b"], int(g["n_iter"]), True, gk_eta=float(g["gk_eta"]), gk_delta=float(g["gk_delta"]))
+    assert Q.shape == g["Q"].shape and H.shape == g["H"].shape            # stops at the same step as the reference
+    assert np.allclose(H, g["H"], rtol=1e-4, atol=1e-6) and relerr(Q[:, :2], g["Q"][:, :2]) < 1e-4
+
+
+def test_arnoldi_tikhonov_dp_stop_fails_like_the_reference(eng):
+    g = load_golden("oneshot_blur32")
+    with pytest.raises(TypeError):
+        S.Arnoldi_Tikhonov(blur(eng, g), g["b"], 3, 1e-2, dp_stop=True)

@@ -125,6 +125,17 @@ def test_arnoldi():
     assert relerr(Q, g["Q"]) < 1e-9
 
 
+@pytest.mark.parametrize("tag", ["stop1", "never"])
+def test_arnoldi_dp_stop(tag):
+    """decompositions.py:104-112: halts after the first step for gk_delta = 1, never for 0.5 (its residual stays ~0.95)."""
+    g = load_golden("arnoldi_blur32_dpstop_" + tag)
+    N = int(g["N"])
+    A = O.Blur2D(g["psf"], N, N)
+    Q, H = O.arnoldi(A, g["b"], int(g["n_iter"]), True, float(g["gk_eta"]), float(g["gk_delta"]))
+    assert Q.shape == g["Q"].shape and H.shape == g["H"].shape
+    assert np.allclose(H, g["H"], rtol=1e-9, atol=1e-13) and relerr(Q, g["Q"]) < 1e-9
+
+
 @pytest.mark.parametrize("tag", ["lam1e-2", "gcv", "dp"])
 @pytest.mark.parametrize("solver", ["hybrid_lsqr", "hybrid_gmres"])
 def test_hybrid(solver, tag):

@@ -190,6 +190,13 @@ def g3_decomp():
     _, _, _, bn, dn = blur_problem(N, 21, noise=0.1)
     U, S, V = quiet(dec.golub_kahan, A, bn, 12, True, gk_eta=1.001, gk_delta=dn)
     save("golub_kahan_blur32_dpstop", psf=PSF, N=N, b=bn, n_iter=12, gk_eta=1.001, gk_delta=dn, U=U, S=S, V=V)
+    # the same switch in arnoldi (decompositions.py:104-112).  Its residual (normal equations of the square block of H, the
+    # normalised b) stays between 0.9 and 1 on this problem: gk_delta = 1 halts after the first step, 0.5 never halts
+    for tag, gd in (("stop1", 1.0), ("never", 0.5)):
+        Q, H = quiet(dec.arnoldi, A, bn, 7, True, gk_eta=1.001, gk_delta=gd)
+        save("arnoldi_blur32_dpstop_" + tag, psf=PSF, N=N, b=bn, n_iter=7, gk_eta=1.001, gk_delta=gd, Q=Q, H=H)
+    # (Arnoldi_Tikhonov(dp_stop=True) cannot be pinned: A_Tikhonov.py:70 passes dp_stop both positionally and inside
+    #  **kwargs and raises TypeError)
 
 
 # ----------------------------------------------------------------------------------------- G4

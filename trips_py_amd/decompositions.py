@@ -66,14 +66,18 @@ def golub_kahan(A, b, n_iter, dp_stop=False, **kwargs):
     return gk.U.torch_cols(), gk.B(), gk.V.torch_cols()
 
 
-def arnoldi_device(A, b, n_iter):
+def arnoldi_device(A, b, n_iter, dp_stop=False, **kwargs):
     """The reference's `arnoldi` on the device: returns (DeviceBasis Q with k+1 vectors, H (k+1) x k host float64).
     NOTE the reference (unlike arnoldi_update) orthogonalises step ii only against Q[:, :ii] — the newest vector
-    Q[:, ii] is skipped and H[ii, ii] stays 0 (decompositions.py:88-94, `range(0, iterations)`).  Reproduced."""
+    Q[:, ii] is skipped and H[ii, ii] stays 0 (decompositions.py:88-94, `range(0, iterations)`).  Reproduced.
+    dp_stop (:104-112): after every step y solves (H_k^T H_k) y = Q_k^T b^ with the square top block of H and the
+    NORMALISED b^, and the factorisation halts before the next step once ||A Q_k y - b^|| <= gk_eta * gk_delta
+    (defaults 1.001 / 0.001 — not the solvers' delta)."""
     A = as_operator(A)
     if A.shape[0] != A.shape[1]:
         raise ValueError("Arnoldi can not be used. The operator is not square")
     eng, n, n_iter = A.engine, A.shape[0], int(n_iter)
+    eta, delta = kwargs.get("gk_eta", 1.001), kwargs.get("gk_delta", 0.001)
     Q = DeviceBasis(eng, n, n_iter + 1)
     S = eng.scalars(2 * n_iter + 2)
     H = np.zeros((n_iter + 1, n_iter))
@@ -83,7 +87,14 @@ def arnoldi_device(A, b, n_iter):
     eng.scale(Coef(1.0, den=S.ref(0), sqrt_den=True), bv, Q.next_slot())
     Q.commit()
     w = eng.empty(n)
+    if dp_stop:
+        P, Y, R = eng.scalars(n_iter + 1), eng.scalars(n_iter + 1), eng.scalars(1)
+        x, ax = eng.empty(n), eng.empty(n)
+    res_norm, done = np.inf, 0
     for ii in range(n_iter):
+        if dp_stop and res_norm <= eta * delta:
+            print("discrepancy principle satisfied, stopping early.")
+            break
         A.apply(Q[ii], out=w)
         # literal modified Gram-Schmidt against Q[:, :ii] only: with the newest vector skipped the basis is not
         # orthonormal, so block (classical) Gram-Schmidt would NOT give the same numbers
@@ -96,18 +107,28 @@ def arnoldi_device(A, b, n_iter):
         h = S.host(0, 1 + ii)
         H[:ii, ii] = h[1:1 + ii]
         H[ii + 1, ii] = np.sqrt(h[0])
+        done = ii + 1
         if H[ii + 1, ii] == 0:
             break
         eng.scale(Coef(1.0, den=S.ref(0), sqrt_den=True), w, Q.next_slot())
         Q.commit()
-    k = Q.k
-    return Q, (H[:k, :k - 1] if k < n_iter + 1 else H)
+        if dp_stop:
+            k = ii + 1
+            eng.gemv_t(Q.data, k, Q[0], P.ref(0))                     # bhat = Q[:, :-1].T @ (b / ||b||)   (:106)
+            eng.allreduce(P, 0, k)
+            Hk = H[:k, :k]
+            y = np.linalg.lstsq(Hk.T @ Hk, P.host(0, k), rcond=None)[0]   # (:108)
+            Y.set(0, y)
+            eng.gemv_n(Q.data, k, Y.ref(0), x)                        # x = Q[:, :-1] @ y                  (:110)
+            A.apply(x, out=ax)
+            eng.diff_nrm2sq(ax, Q[0], R.ref(0))                       # ||A x - b^||                       (:112)
+            eng.allreduce(R, 0, 1)
+            res_norm = float(np.sqrt(R.host(0, 1)[0]))
+    return Q, H[:done + 1, :done]
 
 
 def arnoldi(A, b, n_iter, dp_stop=False, **kwargs):
-    if dp_stop:
-        raise NotImplementedError("arnoldi(dp_stop=True) (decompositions.py:104-112) is not implemented on the engine yet")
-    Q, H = arnoldi_device(A, b, n_iter)
+    Q, H = arnoldi_device(A, b, n_iter, dp_stop, **{k_: v_ for k_, v_ in kwargs.items() if k_ in ("gk_eta", "gk_delta")})
     return (Q.numpy() if _fmt_like(b) else Q.torch_cols()), H
 
 

@@ -13,8 +13,9 @@ def Arnoldi_Tikhonov(A, b, n_iter=3, regparam="gcv", **kwargs):
     A = as_operator(A)
     if A.shape[0] != A.shape[1]:
         raise ValueError("The observation matrix A must be square for this method.")
-    if kwargs.get("dp_stop", False):
-        raise NotImplementedError("Arnoldi_Tikhonov(dp_stop=True) is not implemented on the engine yet")
+    if "dp_stop" in kwargs:
+        # the reference passes dp_stop positionally AND inside **kwargs (A_Tikhonov.py:69-70) and fails the same way
+        raise TypeError("arnoldi() got multiple values for argument 'dp_stop'")
     if isinstance(regparam, str) and regparam == "dp" and kwargs.get("delta") is None:
         check_delta(regparam, kwargs)
     eng = A.engine
