@@ -590,13 +590,11 @@ typedef float f3v __attribute__((ext_vector_type(3)));
 __global__ __launch_bounds__(256) void k_radon_adj_prep(const float* __restrict__ sino, float* __restrict__ sp, int nd, int na,
                                                         const int* __restrict__ orig, const float* __restrict__ wgt) {
   const int ndp = nd + ADJ_PAD;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over (frame*na + sorted angle) x ndp
-  const int64_t rows = (int64_t)gridDim.y * na;                      // gridDim.y = frames
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over (sorted angle of the frame) x ndp; blockIdx.y = frame
   const int64_t r = idx / ndp;
   if (r >= (int64_t)na) return;
   const int e = (int)(idx - r * ndp);
   const int64_t rs = (int64_t)blockIdx.y * na + r;                   // sorted row (frame-major)
-  (void)rows;
   const int d = e - ADJ_PAD;
   sp[rs * ndp + e] = d < 0 ? 0.f : wgt[rs] * sino[((int64_t)blockIdx.y * na + orig[rs]) * nd + d];
 }
