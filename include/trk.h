@@ -219,6 +219,11 @@ int trk_finalize_batched(const double* partials, int nblocks, int nvals, int bat
  *  one row of a weighted Gram matrix.) */
 int trk_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* w2, double* h_dev,
                trk_stream stream);
+/* One fused step of repeated classical Gram-Schmidt (GKS.py:86-88, MMGKS.py:119-120; Arnoldi with reorthogonalisation):
+ *   w_out = w_in - sum_j h[j] V[j]   and   g[j] = sum_i V[j][i] w_out[i]   (j < k <= 16)   with ONE pass over V.
+ * w_out may alias w_in; h and g are k device doubles (g must not alias h). */
+int trk_gemv_nt(const float* V, int64_t ld, int k, int64_t n, const double* h_dev, const float* w_in, float* w_out,
+                double* g_dev, trk_stream stream);
 /* out = a*base + s * sum_j y[j]*V[j]   (y: k device doubles; base may be NULL; out may alias base).
  * (x = V@y: Hybrid_LSQR.py:105, Hybrid_GMRES.py:77, GKS.py:76; r -= V h: GKS.py:86-88) */
 int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y_dev, double a, const float* base,

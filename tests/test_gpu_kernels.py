@@ -186,3 +186,26 @@ def test_bidiag_tikhonov_matches_stacked_lstsq(k, mu):
     want = np.linalg.lstsq(np.vstack((B, mu * np.eye(k))), rhs, rcond=None)[0]
     got = Y.host()
     assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max()) * np.linalg.cond(np.vstack((B, mu * np.eye(k))))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n", [(1, 100), (3, 4097), (8, 10_000), (9, 65_536), (12, 50_000), (16, 30_001)])
+def test_gemv_nt_fused_gram_schmidt_step(k, n):
+    """trk_gemv_nt: w_out = w - V^T-combination with the old coefficients AND the new dot products in one pass."""
+    from trips_py_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(k * 7 + n)
+    V, w, h = rng.standard_normal((k, n)), rng.standard_normal(n), rng.standard_normal(k) * 0.3
+    dV = torch.from_numpy(V.astype(np.float32)).to(eng.device)
+    dw = eng.to_vec(w)
+    H = eng.scalars(2 * k)
+    H.set(0, h)
+    out = eng.empty(n)
+    eng.gemv_nt(dV, k, H.ref(0), dw, out, H.ref(k))
+    V32, w32 = V.astype(np.float32).astype(np.float64), w.astype(np.float32).astype(np.float64)
+    want = w32 - h @ V32
+    got = out.cpu().numpy().astype(np.float64)
+    assert np.allclose(got, want, rtol=1e-6, atol=1e-6)
+    assert np.allclose(H.host(k, 2 * k), V32 @ got, rtol=1e-10, atol=1e-9)
+    eng.gemv_nt(dV, k, H.ref(0), dw, dw, H.ref(k))                 # in place
+    assert torch.equal(dw, out)

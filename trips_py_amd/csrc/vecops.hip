@@ -439,6 +439,74 @@ __global__ __launch_bounds__(NT) void k_gemv_n(const float* __restrict__ V, int6
   }
 }
 
+// ------------------------------------------------------------------ fused reorthogonalisation step
+// w_out = w_in - sum_j h[j] V[j]   AND   g[j] = sum_i V[j][i] w_out[i]   with ONE pass over the k basis rows:
+// the middle step of repeated classical Gram-Schmidt  r -= V (V^T r)  (GKS.py:86-88 three times, MMGKS.py:119-120 twice,
+// Arnoldi): the update with the previous pass's coefficients and the next pass's dot products read the same rows, so a
+// thread keeps its k float4 of a column group in registers between the two uses (k <= KB = 8 / 16).
+// Element formulas are those of k_gemv_n (fp64 accumulation of the combination, rounded once) and k_gemv_t.
+template <int KB, bool VEC>
+__global__ __launch_bounds__(NT, 2) void k_gemv_nt(const float* __restrict__ V, int64_t ld, int k, int64_t n,
+                                                   const double* __restrict__ h, const float* w_in, float* w_out,
+                                                   double* __restrict__ partials) {
+  __shared__ double hs[KB];
+  __shared__ double lds[NT / 64];
+  if (threadIdx.x < KB) hs[threadIdx.x] = threadIdx.x < k ? h[threadIdx.x] : 0.0;
+  __syncthreads();
+  double acc[KB];
+#pragma unroll
+  for (int j = 0; j < KB; ++j) acc[j] = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      const float4 wv = ld4(w_in, i);
+      float4 v[KB];
+#pragma unroll
+      for (int j = 0; j < KB; ++j) v[j] = (j < k) ? ld4(V + (int64_t)j * ld, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      double o0 = (double)wv.x, o1 = (double)wv.y, o2 = (double)wv.z, o3 = (double)wv.w;
+#pragma unroll
+      for (int j = 0; j < KB; ++j) {
+        if (j < k) {
+          const double c = -hs[j];
+          o0 = fma(c, (double)v[j].x, o0);
+          o1 = fma(c, (double)v[j].y, o1);
+          o2 = fma(c, (double)v[j].z, o2);
+          o3 = fma(c, (double)v[j].w, o3);
+        }
+      }
+      const float4 o = make_float4((float)o0, (float)o1, (float)o2, (float)o3);
+      st4(w_out, i, o);
+#pragma unroll
+      for (int j = 0; j < KB; ++j)
+        if (j < k) acc[j] += (double)v[j].x * o.x + (double)v[j].y * o.y + (double)v[j].z * o.z + (double)v[j].w * o.w;
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) {
+    float v[KB];
+#pragma unroll
+    for (int j = 0; j < KB; ++j) v[j] = (j < k) ? V[(int64_t)j * ld + i] : 0.f;
+    double o0 = (double)w_in[i];
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+      if (j < k) o0 = fma(-hs[j], (double)v[j], o0);
+    const float o = (float)o0;
+    w_out[i] = o;
+#pragma unroll
+    for (int j = 0; j < KB; ++j)
+      if (j < k) acc[j] += (double)v[j] * o;
+  }
+#pragma unroll
+  for (int j = 0; j < KB; ++j) {
+    if (j < k) {                                                // uniform
+      const double t = block_sum<NT>(acc[j], lds);
+      if (threadIdx.x == 0) partials[(size_t)blockIdx.x * k + j] = t;
+    }
+  }
+}
+
 // ------------------------------------------------------------------ weighted Gram, tile pairs (TG x TG)
 // G[a][b] = sum_i w_i^2 W[a][i] W[b][i].  grid = (bx, npairs): pair p -> (ta <= tb).  partials [bx][k*k] (upper blocks).
 constexpr int TG = 4;
@@ -1049,6 +1117,23 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, do
   TRK_LAUNCH_CHECK();
   if (sumsq) return finalize_sums(part, grid, 1, 1, sumsq, s);
   return TRK_OK;
+}
+
+int trk_gemv_nt(const float* V, int64_t ld, int k, int64_t n, const double* h, const float* w_in, float* w_out,
+                double* g, trk_stream st) {
+  TRK_REQUIRE(V && h && w_in && w_out && g, "trk_gemv_nt: NULL argument");
+  TRK_REQUIRE(k >= 1 && k <= 16 && n >= 0 && ld >= n, "trk_gemv_nt: need 1 <= k <= 16, n >= 0, ld >= n");
+  hipStream_t s = (hipStream_t)st;
+  int bx = stream_grid(n);
+  double* part = nullptr;
+  if (int rc = scratch_doubles(s, (size_t)bx * k, &part)) return rc;
+  const bool vec = aligned16(V) && aligned16(w_in) && aligned16(w_out) && (ld % 4 == 0);
+#define NTK(KBB, VC) hipLaunchKernelGGL((k_gemv_nt<KBB, VC>), dim3(bx), dim3(NT), 0, s, V, ld, k, n, h, w_in, w_out, part)
+  if (k <= 8) { if (vec) NTK(8, true); else NTK(8, false); }
+  else        { if (vec) NTK(16, true); else NTK(16, false); }
+#undef NTK
+  TRK_LAUNCH_CHECK();
+  return finalize_sums(part, bx, k, k, g, s);
 }
 
 int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G, double* c1,

@@ -274,6 +274,14 @@ class HipEngine:
                                  None if w2 is None else w2.data_ptr(), _ptr(out_h), self.stream())
         _lib.check(rc, "trk_gemv_t")
 
+    GEMV_NT_MAX_K = 16
+
+    def gemv_nt(self, V, k, h, w_in, w_out, g):
+        """w_out = w_in - sum_j h[j] V[j] and g[j] = V[j] . w_out (local sums), one pass over V; k <= GEMV_NT_MAX_K."""
+        rc = self.lib.trk_gemv_nt(V.data_ptr(), V.stride(0), int(k), w_in.numel(), _ptr(h), w_in.data_ptr(), w_out.data_ptr(),
+                                  _ptr(g), self.stream())
+        _lib.check(rc, "trk_gemv_nt")
+
     def gemv_n(self, V, k, y, out, a=0.0, base=None, s=1.0, sumsq=None):
         """out = a*base + s * sum_j y[j] V[j]   (y: k device doubles)."""
         rc = self.lib.trk_gemv_n(V.data_ptr(), V.stride(0), int(k), out.numel(), _ptr(y), float(a),

@@ -186,6 +186,18 @@ def orthogonalize(eng, V, k, w, H, off, passes=2, out=None, sumsq=None):
     Pass p leaves its k coefficients in H[off + p*k : off + (p+1)*k] (device doubles, all-reduced).
     The last pass may write its result to `out` instead of `w` (e.g. straight into the next basis slot) and leave the
     LOCAL sum of its squares in `sumsq` — fused into that kernel, no extra pass."""
+    fuse = passes >= 2 and k <= getattr(eng, "GEMV_NT_MAX_K", 0) and hasattr(eng, "gemv_nt")
+    if fuse:
+        # pass p's update and pass p+1's dot products read the same rows of V: one sweep (trk_gemv_nt) instead of two
+        eng.gemv_t(V.data, k, w, H.ref(off))
+        eng.allreduce(H, off, off + k)
+        for p in range(passes - 1):
+            lo, nx = off + p * k, off + (p + 1) * k
+            eng.gemv_nt(V.data, k, H.ref(lo), w, w, H.ref(nx))
+            eng.allreduce(H, nx, nx + k)
+        lo = off + (passes - 1) * k
+        eng.gemv_n(V.data, k, H.ref(lo), out if out is not None else w, a=1.0, base=w, s=-1.0, sumsq=sumsq)
+        return
     for p in range(passes):
         lo = off + p * k
         last = p == passes - 1
