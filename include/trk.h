@@ -179,9 +179,12 @@ int trk_cgls_x_update(int64_t n, const double* gamma, int gamma_n, const double*
  *   y = argmin || B_k y - beta0 e1 ||^2 + mu^2 || y ||^2 ,  B_k lower bidiagonal (k+1) x k with diagonal alpha_j and
  *   sub-diagonal beta_{j+1}, given as the SQUARED norms the Golub-Kahan kernels leave in device doubles:
  *   alpha_j^2 = alpha_sq[j*alpha_stride], beta_{j+1}^2 = beta_sq[j*beta_stride] (j < k), beta0^2 = *beta0_sq.
- *   mu = sqrt(lam) of the reference's stacked system.  Writes y[0..k).  1 <= k <= 4096. */
+ *   mu = sqrt(lam) of the reference's stacked system.  Writes y[0..k).  1 <= k <= 2048.
+ *   work (may be NULL): >= 3 (k_max + 1) + 4 device doubles, zero-initialised by the caller, kept between calls: when mu is
+ *   unchanged and columns were only appended since the last call (the fixed-lambda hybrid iteration) only the new
+ *   columns are rotated; anything else restarts from the first column. */
 int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride, const double* beta_sq, int64_t beta_stride, int k,
-                        double mu, const double* beta0_sq, double* y, trk_stream stream);
+                        double mu, const double* beta0_sq, double* y, double* work, int work_doubles, trk_stream stream);
 
 /* HOST function (no device work, no stream): lambda = argmin over [x1, x2] of the GCV function of a diagonalised
  * projected problem,  G(lam) = sum_i ((1 - f_i) rhs_i)^2 / (m_eff - sum_i f_i)^2,  f_i = s_i^2 / (s_i^2 + lam),

@@ -155,7 +155,7 @@ class CpuEngine:
         if sumsq is not None:
             _put(sumsq, np.dot(_d(out), _d(out)))
 
-    def bidiag_tikhonov(self, alpha_sq, alpha_stride, beta_sq, beta_stride, k, mu, beta0_sq, y):
+    def bidiag_tikhonov(self, alpha_sq, alpha_stride, beta_sq, beta_stride, k, mu, beta0_sq, y, work=None):
         (sa, ia), (sb, ib) = alpha_sq, beta_sq
         al = np.sqrt(sa.a[ia:ia + alpha_stride * k:alpha_stride])
         be = np.sqrt(sb.a[ib:ib + beta_stride * k:beta_stride])

@@ -186,6 +186,16 @@ def test_bidiag_tikhonov_matches_stacked_lstsq(k, mu):
     want = np.linalg.lstsq(np.vstack((B, mu * np.eye(k))), rhs, rcond=None)[0]
     got = Y.host()
     assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max()) * np.linalg.cond(np.vstack((B, mu * np.eye(k))))
+    # resumable form: growing k with the same mu (one column or several at a time), then a change of mu, then a smaller k
+    W = eng.scalars(3 * (k + 1) + 4)
+    for kk, m in [(max(1, k // 3), mu), (max(1, k // 3) + 1 if k > 3 else k, mu), (k, mu), (k, mu + 0.25), (max(1, k - 1), mu + 0.25)]:
+        kk = min(kk, k)
+        eng.bidiag_tikhonov(AB.ref(1), 2, AB.ref(2), 2, kk, m, AB.ref(0), Y.ref(0), W)
+        Bk = B[:kk + 1, :kk]
+        rk = np.zeros(2 * kk + 1)
+        rk[0] = b0
+        wk = np.linalg.lstsq(np.vstack((Bk, m * np.eye(kk))), rk, rcond=None)[0]
+        assert np.abs(Y.host(0, kk) - wk).max() <= 1e-10 * max(1.0, np.abs(wk).max()) * np.linalg.cond(np.vstack((Bk, m * np.eye(kk)))), (kk, m)
 
 
 @pytest.mark.gpu

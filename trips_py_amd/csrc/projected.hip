@@ -5,7 +5,7 @@
 // (and GK_Tikhonov.py:60) for the lower-bidiagonal B_k of Golub-Kahan: the stacked matrix is reduced to an upper
 // bidiagonal R by 2k Givens rotations (the damped-LSQR elimination of Paige & Saunders 1982, §2 of "LSQR: an algorithm
 // for sparse linear equations and sparse least squares"), then R y = phi is back-substituted.  O(k), backward stable,
-// float64 throughout; one lane does the (inherently sequential) recurrence: ~4 us at k = 100.
+// float64 throughout; one lane does the (inherently sequential) recurrence.
 #include "trk_internal.h"
 
 #include <cmath>
@@ -15,39 +15,90 @@ using namespace trk;
 
 namespace {
 
-constexpr int BIDIAG_MAX_K = 4096;   // rho, theta in LDS (64 KB)
+constexpr int BIDIAG_MAX_K = 2048;   // the back substitution stages 3 k doubles in LDS
 
+// One workgroup of 64 lanes.  Square roots of the new columns' squared norms are taken in parallel; lane 0 then runs the
+// rotation recurrence — per column two square roots and two reciprocals (r^2 = abar^2 + mu^2 + beta^2 needs no second
+// hypot); a second small kernel does the back substitution (multiplications by the stored 1/rho).  With a `work` array the recurrence state
+// survives between calls: when mu is unchanged and one column was appended (the fixed-lambda hybrid iteration) only that
+// column is rotated, O(1) instead of O(k) expensive operations; any other change restarts from column 0.
+// work: [0] columns done, [1] mu, [2] abar, [3] phibar, then invrho[cap], theta[cap], phi[cap].
 __global__ __launch_bounds__(64) void k_bidiag_tikhonov(const double* __restrict__ alpha_sq, int64_t a_stride,
                                                         const double* __restrict__ beta_sq, int64_t b_stride, int k,
                                                         double mu, const double* __restrict__ beta0_sq,
-                                                        double* __restrict__ y) {
-  extern __shared__ double lds[];
+                                                        double* __restrict__ y, double* __restrict__ work, int cap,
+                                                        double* __restrict__ scratch) {
+  __shared__ double sh_start;
+  double* st = work ? work : scratch;                          // scratch: same layout, always restarted
+  double* invrho = st + 4;
+  double* theta = invrho + cap;
+  double* phi = theta + cap;
+  if (threadIdx.x == 0) {
+    const bool resume = work && st[1] == mu && st[0] >= 1.0 && (int)st[0] < k;
+    sh_start = resume ? st[0] : 0.0;
+  }
+  __syncthreads();
+  const int j0 = (int)sh_start;
+  // al[j], be[j] of the columns to process, through y (as scratch) — y[j] is overwritten by the back substitution later
+  double* al = y;                                               // al[j] for j in [j0, k)
+  for (int j = j0 + (int)threadIdx.x; j < k; j += 64) al[j] = sqrt(alpha_sq[(int64_t)j * a_stride]);
+  __syncthreads();
   if (threadIdx.x != 0) return;
-  double* rho = lds;
-  double* theta = lds + k;
-  double abar = sqrt(alpha_sq[0]);
-  double phibar = sqrt(*beta0_sq);
-  for (int j = 0; j < k; ++j) {
-    const double bj = sqrt(beta_sq[(int64_t)j * b_stride]);   // B[j+1, j]
-    // rotate the damping row (mu in column j) into abar
-    const double rhat = hypot(abar, mu);
+  const double mu2 = mu * mu;
+  double abar, phibar;
+  if (j0 == 0) {
+    abar = al[0];
+    phibar = sqrt(*beta0_sq);
+  } else {
+    abar = st[2];
+    phibar = st[3];
+    // st[2] holds -c2 of the previous last column (its alpha_{j0} factor was not known then)
+    abar *= al[j0];
+    theta[j0] *= al[j0];
+  }
+  for (int j = j0; j < k; ++j) {
+    const double bj2 = beta_sq[(int64_t)j * b_stride];         // B[j+1, j]^2
+    const double rhat2 = abar * abar + mu2, r2 = rhat2 + bj2;
+    const double rhat = sqrt(rhat2), r = sqrt(r2), bj = sqrt(bj2);
+    const double ir = 1.0 / r;
     const double phihat = (abar / rhat) * phibar;
-    // rotate the sub-diagonal entry into rhat
-    const double r = hypot(rhat, bj);
-    const double c2 = rhat / r, s2 = bj / r;
-    rho[j] = r;
-    y[j] = c2 * phihat;                                        // phi_j, overwritten by the back substitution
+    const double c2 = rhat * ir, s2 = bj * ir;
+    invrho[j] = ir;
+    phi[j] = c2 * phihat;
     if (j + 1 < k) {
-      const double an = sqrt(alpha_sq[(int64_t)(j + 1) * a_stride]);
-      theta[j + 1] = s2 * an;
-      abar = -c2 * an;
+      theta[j + 1] = s2 * al[j + 1];
+      abar = -c2 * al[j + 1];
+    } else {
+      theta[j + 1] = s2;                                        // completed with alpha_{j+1} on resume (cap >= k + 1)
+      abar = -c2;
     }
     phibar = s2 * phihat;
   }
-  double yn = y[k - 1] / rho[k - 1];
+  st[0] = (double)k;
+  st[1] = mu;
+  st[2] = abar;
+  st[3] = phibar;
+}
+
+// Back substitution R y = phi for the upper-bidiagonal R kept as (1/rho, theta): the three arrays are first copied to
+// LDS by all lanes (the dependent chain then waits ~60 cycles per step on LDS instead of an L2 round trip).
+__global__ __launch_bounds__(64) void k_bidiag_backsub(const double* __restrict__ st, int cap, int k, double* __restrict__ y) {
+  extern __shared__ double sm[];
+  const double* invrho = st + 4;
+  const double* theta = invrho + cap;
+  const double* phi = theta + cap;
+  double *s_ir = sm, *s_th = sm + k, *s_ph = sm + 2 * k;
+  for (int j = threadIdx.x; j < k; j += 64) {
+    s_ir[j] = invrho[j];
+    s_th[j] = theta[j];
+    s_ph[j] = phi[j];
+  }
+  __syncthreads();
+  if (threadIdx.x != 0) return;
+  double yn = s_ph[k - 1] * s_ir[k - 1];
   y[k - 1] = yn;
   for (int j = k - 2; j >= 0; --j) {
-    yn = (y[j] - theta[j + 1] * yn) / rho[j];
+    yn = (s_ph[j] - s_th[j + 1] * yn) * s_ir[j];
     y[j] = yn;
   }
 }
@@ -56,12 +107,22 @@ __global__ __launch_bounds__(64) void k_bidiag_tikhonov(const double* __restrict
 
 extern "C" int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride, const double* beta_sq,
                                    int64_t beta_stride, int k, double mu, const double* beta0_sq, double* y,
-                                   trk_stream stream) {
+                                   double* work, int work_doubles, trk_stream stream) {
   TRK_REQUIRE(alpha_sq && beta_sq && beta0_sq && y, "trk_bidiag_tikhonov: NULL argument");
-  TRK_REQUIRE(k >= 1 && k <= BIDIAG_MAX_K, "trk_bidiag_tikhonov: k must be in [1, 4096]");
+  TRK_REQUIRE(k >= 1 && k <= BIDIAG_MAX_K, "trk_bidiag_tikhonov: k must be in [1, 2048]");
   TRK_REQUIRE(mu >= 0.0, "trk_bidiag_tikhonov: mu must be >= 0");
-  hipLaunchKernelGGL(k_bidiag_tikhonov, dim3(1), dim3(64), 2 * sizeof(double) * (size_t)k, (hipStream_t)stream, alpha_sq,
-                     alpha_stride, beta_sq, beta_stride, k, mu, beta0_sq, y);
+  hipStream_t s = (hipStream_t)stream;
+  int cap = k + 1;
+  double* scratch = nullptr;
+  if (work) {
+    cap = (work_doubles - 4) / 3;
+    TRK_REQUIRE(cap >= k + 1, "trk_bidiag_tikhonov: work holds %d doubles, %d needed", work_doubles, 3 * (k + 1) + 4);
+  } else {
+    if (int rc = scratch_doubles(s, (size_t)3 * cap + 4, &scratch)) return rc;
+  }
+  hipLaunchKernelGGL(k_bidiag_tikhonov, dim3(1), dim3(64), 0, s, alpha_sq, alpha_stride, beta_sq, beta_stride, k, mu,
+                     beta0_sq, y, work, cap, scratch);
+  hipLaunchKernelGGL(k_bidiag_backsub, dim3(1), dim3(64), 3 * sizeof(double) * (size_t)k, s, work ? work : scratch, cap, k, y);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }

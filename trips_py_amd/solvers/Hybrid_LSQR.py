@@ -35,7 +35,8 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     if keep:
         history_fits(eng, n_iter, n, "Hybrid_LSQR xHistory")
     X = eng.empty_basis(max(1, n_iter - 1) if keep else 1, n)
-    Y = eng.scalars(max(1, n_iter))          # projected solution, uploaded each iteration
+    Y = eng.scalars(max(1, n_iter))          # projected solution
+    W = eng.scalars(3 * (n_iter + 1) + 4)    # rotation state of the projected solve, resumed while lambda stays the same
     E = eng.scalars(max(1, n_iter) + 1)      # E[0] = ||x_true||^2, E[i] = ||x_i - x_true||^2
     P = eng.scalars(n_iter + 2)              # U^T b for the discrepancy principle
     if xt is not None:
@@ -66,7 +67,7 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             lam = regparam
         lams.append(lam)
         # y = lstsq([B; sqrt(lam) I], [beta0 e1; 0]) (:104), on the device from the squared norms in gk.AB
-        eng.bidiag_tikhonov(gk.AB.ref(1), 2, gk.AB.ref(2), 2, k, np.sqrt(lam), gk.AB.ref(0), Y.ref(0))
+        eng.bidiag_tikhonov(gk.AB.ref(1), 2, gk.AB.ref(2), 2, k, np.sqrt(lam), gk.AB.ref(0), Y.ref(0), W)
         x_dev = X[nx_done] if keep else X[0]
         eng.gemv_n(gk.V.data, k, Y.ref(0), x_dev)
         nx_done += 1
