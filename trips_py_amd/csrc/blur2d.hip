@@ -543,6 +543,27 @@ inline bool slide_shape_ok(const BlurImpl* im) {
          im->ny >= 8 && (int64_t)im->nx * im->ny < ((int64_t)1 << 30);
 }
 
+// 9x9 exists with prefetch depth 6 (band heights 18 j - 8) and depth 9 (9 j - 8): the finer quantisation is used when it fills
+// the chip better — estimated time = wave generations x rows per wave; the depth-9 loop is ~4 % slower per row at equal shape
+// (4096^2: 26.8 vs 25.8 us), so it must win by more than that.  Measured: 2048^2 12.1 -> 9.4 us, 3072^2 18.7 -> 16.6 us.
+inline bool slide_pick_depth9(const BlurImpl* im, int batch, int* spans_x, int* nbands, int* rpb) {
+  if (im->kh != 9 || getenv("TRK_BLUR_RPB")) return false;
+  int sx9, nb9, rpb9;
+  slide_grid(im->nx, im->ny, batch, im->kh, 9, &sx9, &nb9, &rpb9);
+  const int64_t slots = (int64_t)4 * cu_count();
+  auto est = [&](int sx, int nb, int r) {
+    const int64_t waves = (int64_t)sx * nb * (batch > 0 ? batch : 1);
+    return (double)((waves + slots - 1) / slots) * (double)(r + im->kh - 1);
+  };
+  if (est(sx9, nb9, rpb9) * 1.07 < est(*spans_x, *nbands, *rpb)) {
+    *spans_x = sx9;
+    *nbands = nb9;
+    *rpb = rpb9;
+    return true;
+  }
+  return false;
+}
+
 // y = A (x1 + cb * x2), comb written out, sum(y^2) as raw partials (CGLS fast path; 9x9-class separable PSFs only)
 int blur_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, double sign, ScalarSrc num, ScalarSrc den,
                      float* comb, float* y, double* partials, int cap, int* n_partials, hipStream_t s) {
@@ -553,6 +574,7 @@ int blur_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, doubl
   int spans_x, nbands, rpb;
   const int Usel = (im->kh == 9) ? 18 : (im->kh == 7) ? 7 : (im->kh == 5) ? 5 : 6;
   slide_grid(im->nx, im->ny, 1, im->kh, Usel, &spans_x, &nbands, &rpb);
+  const bool depth9 = slide_pick_depth9(im, 1, &spans_x, &nbands, &rpb);
   const int nblk = spans_x * nbands;
   if (nblk > cap) return fail(TRK_EINVAL, "blur2d fused apply: partial buffer holds %d doubles, %d needed", cap, nblk);
   *n_partials = nblk;
@@ -568,7 +590,9 @@ int blur_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, doubl
     case 3: return launch_slide<3, 6>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
     case 5: return launch_slide<5, 5>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
     case 7: return launch_slide<7, 7>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
-    default: return launch_slide<9, 6>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
+    default:
+      return depth9 ? launch_slide<9, 9>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz)
+                    : launch_slide<9, 6>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
   }
 }
 
@@ -583,6 +607,7 @@ int blur_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_
     int spans_x, nbands, rpb;
     const int Usel = (im->kh == 9) ? 18 : (im->kh == 7) ? 7 : (im->kh == 5) ? 5 : 6;   // lcm(KH, D) of the instantiations below
     slide_grid(im->nx, im->ny, batch, im->kh, Usel, &spans_x, &nbands, &rpb);
+    const bool depth9 = slide_pick_depth9(im, batch, &spans_x, &nbands, &rpb);
     nblk = spans_x * nbands;
     if (sumsq)
       if (int rc = scratch_doubles(s, (size_t)nblk * batch, &part)) return rc;
@@ -598,7 +623,10 @@ int blur_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_
       case 3: rc = launch_slide<3, 6>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1); break;
       case 5: rc = launch_slide<5, 5>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1); break;
       case 7: rc = launch_slide<7, 7>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1); break;
-      default: rc = launch_slide<9, 6>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1); break;
+      default:
+        rc = depth9 ? launch_slide<9, 9>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1)
+                    : launch_slide<9, 6>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1);
+        break;
     }
     if (rc) return rc;
     if (sumsq) return finalize_sums(part, nblk * batch, 1, 1, sumsq, s);
