@@ -1,0 +1,31 @@
+"""Host-side data helpers of trips_py_amd.problems (the demos' gen_data / add_noise, Deblurring2D.py:123-159): no GPU."""
+import numpy as np
+from scipy.ndimage import convolve
+
+from trips_py_amd import problems as P
+
+
+def test_gen_data_and_add_noise_follow_the_reference_recipe():
+    nx, ny = 24, 20
+    rng = np.random.default_rng(0)
+    x = rng.random(nx * ny)
+    for crime in (False, True):
+        D = P.Deblurring2D(CommitCrime=crime)
+        D.nx, D.ny = nx, ny                                   # what forward_Op records (it needs the GPU engine)
+        psf, centre = D.Gauss((7, 7), (2, 3))
+        assert np.isclose(psf.sum(), 1.0) and tuple(centre) == (3, 3)
+        b = D.gen_data(x)
+        assert b.shape == (nx * ny, 1)
+        if crime:
+            want = convolve(x.reshape(nx, ny), psf, mode="reflect")
+        else:
+            big = np.zeros((2 * nx, 2 * ny))
+            big[nx // 2:nx // 2 + nx, ny // 2:ny // 2 + ny] = x.reshape(nx, ny)
+            want = convolve(big, psf, mode="constant")[nx // 2:nx // 2 + nx, ny // 2:ny // 2 + ny]
+        assert np.array_equal(b.reshape(nx, ny), want)
+    np.random.seed(5)
+    bm, delta = D.add_noise(b, "Gaussian", 0.02)
+    assert bm.shape == (nx, ny)
+    assert np.isclose(np.linalg.norm(bm.reshape(-1, 1) - b), delta) and np.isclose(delta / np.linalg.norm(b), 0.02)
+    bm, delta = D.add_noise(b, "Poisson", 0.0)
+    assert bm.shape == (nx, ny) and delta == 0.0

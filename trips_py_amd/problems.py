@@ -49,6 +49,41 @@ class Deblurring2D:
         psf, _ = self.Gauss(dim, spread)
         return Blur2D(psf, nx, ny, engine=engine)
 
+    # The two data-generation helpers of the demos, on the HOST (one-time data preparation, not the hot path): same
+    # arithmetic as Deblurring2D.py:123-159 so that a demo keeps working with this class swapped in.  Images come from the
+    # caller (the reference's gen_true reads ./data/image_data/*.mat: dataset handling is out of scope).
+    def gen_data(self, x):
+        """b = blurred x.  CommitCrime=False (:125-137): blur on a zero-padded 2nx x 2ny canvas with 'constant' boundary and cut
+        the centre out (the data then do not come from the reflective operator); True: the operator's own convolution."""
+        from scipy.ndimage import convolve
+        psf, _ = gauss_psf(self.dim, self.spread)
+        im = np.asarray(x, dtype=np.float64).reshape((self.nx, self.ny))
+        if self.CommitCrime is False:
+            big = np.zeros((2 * self.nx, 2 * self.ny))
+            i0, j0 = self.nx // 2, self.ny // 2
+            big[i0:i0 + self.nx, j0:j0 + self.ny] = im
+            b = convolve(big, psf, mode="constant")[i0:i0 + self.nx, j0:j0 + self.ny]
+        else:
+            b = convolve(im, psf, mode="reflect")
+        return b.reshape((-1, 1))
+
+    def add_noise(self, b_true, opt, noise_level):
+        """(b_meas as an nx x ny image, delta) — :141-159 (unseeded, like the reference; seeded variant: problems.add_noise)."""
+        b_true = np.asarray(b_true, dtype=np.float64)
+        if opt == "Gaussian":
+            e = np.random.randn(self.nx * self.ny, 1)
+            sig = noise_level * np.linalg.norm(b_true) / np.linalg.norm(e)
+            b_meas, delta = b_true + sig * e, np.linalg.norm(sig * e)
+        elif opt == "Poisson":
+            b_meas, delta = np.random.poisson(lam=b_true + 1), 0.0
+        elif opt == "Laplace":
+            e = np.random.laplace(self.nx * self.ny, 1)
+            sig = noise_level * np.linalg.norm(b_true) / np.linalg.norm(e)
+            b_meas, delta = b_true + sig * e, np.linalg.norm(sig * e)
+        else:
+            raise ValueError(f"unknown noise option {opt!r}")
+        return np.asarray(b_meas).reshape((self.nx, self.ny)), delta
+
 
 class Deblurring1D:
     def __init__(self, **kwargs):
