@@ -114,6 +114,31 @@ class Tomography:
             return A, A, A_mis
         return A, A
 
+    def gen_data(self, x, nx, ny, views, engine=None):
+        """(A, b, p, q, AforMatrixOperation) of Tomography.py:153-168: b from the angle-shifted operator unless CommitCrime;
+        NOTE the reference then overwrites p with `views` and q with rows / views (:166-167); reproduced."""
+        ops = self.forward_Op(nx, ny, views, engine=engine)
+        xv = np.asarray(x, dtype=np.float64).reshape(-1)
+        b = np.asarray((ops[2] if not self.CommitCrime else ops[0]) @ xv).reshape((-1, 1))
+        self.p = views
+        self.q = int(b.shape[0] / views)
+        return ops[0], b, self.p, self.q, ops[1]
+
+    def add_noise(self, b_true, opt, noise_level):
+        """(b_meas as a p x q array, delta) — Tomography.py:203-227 (unseeded like the reference)."""
+        b_true = np.asarray(b_true, dtype=np.float64)
+        if opt == "Gaussian":
+            noise = np.random.randn(b_true.shape[0]).reshape((-1, 1))
+            e = noise_level * np.linalg.norm(b_true) / np.linalg.norm(noise) * noise
+            b_meas, delta = b_true.reshape((-1, 1)) + e, np.linalg.norm(e)
+        elif opt == "Poisson":
+            b_meas, delta = np.random.poisson(lam=b_true + 1), 0
+        else:
+            e = np.random.laplace(self.p * self.q)
+            sig = noise_level * np.linalg.norm(b_true) / np.linalg.norm(e)
+            b_meas, delta = b_true + sig * e, np.linalg.norm(sig * e)
+        return np.asarray(b_meas).reshape((self.p, self.q)), delta
+
 
 def parallel_beam_frames(N, angle_sets, engine=None):
     """One Radon2DParallel per time frame (io.py:391-420), combined frame-major with BlockDiagOp."""
