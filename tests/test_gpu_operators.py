@@ -271,3 +271,14 @@ def test_fanbeam_invariants_and_problem_class():
     assert np.all(np.abs(mid - 2 * R) < 1.5)
     # the 1e-8-shifted operator of the non-inverse-crime setup is the same operator to rounding
     assert relerr(A_mis @ disc.reshape(-1), sd.reshape(-1)) < 1e-4
+    Ac, Ac2 = Tomography(CommitCrime=True).forward_Op(N, N, views)
+    assert Ac.shape == A.shape and Ac2 is Ac
+    # the demos' data helpers (Tomography.py:153-168, 203-227)
+    T = Tomography(CommitCrime=False)
+    xr = rng.random(N * N)
+    Aop, b, p, q, Amat = T.gen_data(xr, N, N, views)
+    assert b.shape == (A.shape[0], 1) and (p, q) == (views, A.shape[0] // views) and Amat is Aop
+    assert relerr(b.reshape(-1), A_mis @ xr) < 1e-6
+    np.random.seed(2)
+    bm, delta = T.add_noise(b, "Gaussian", 0.01)
+    assert bm.shape == (p, q) and np.isclose(delta / np.linalg.norm(b), 0.01)
