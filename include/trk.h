@@ -12,7 +12,10 @@
  *   - all vectors are CALLER-OWNED DEVICE buffers of float (fp32 storage); every reduction is
  *     accumulated in double and delivered to a CALLER-OWNED DEVICE double.  The library never
  *     frees or retains user buffers past the call.  Its only allocations are the opaque operator
- *     handles and a small per-stream scratch area for block partial sums.
+ *     handles (including, for the projectors, handle-owned work buffers: a transposed image copy,
+ *     band partial sums, a padded sinogram copy) and a small per-stream scratch area for block
+ *     partial sums.  Consequence: blur / derivative / CSR handles may be applied from several
+ *     streams at once; ONE projector handle must be applied from one stream at a time.
  *   - all work is enqueued on the caller's `stream` (a hipStream_t passed as void*; 0 = default
  *     stream).  No entry point synchronises the device or the stream.
  *   - "basis" arguments are ROW-PER-VECTOR: vector j of a basis V is the contiguous run
@@ -43,7 +46,7 @@ extern "C" {
 #define TRK_SQRT_NUM 1
 #define TRK_SQRT_DEN 2
 
-typedef struct trk_op trk_op; /* opaque linear operator (immutable after create) */
+typedef struct trk_op trk_op; /* opaque linear operator (geometry immutable after create) */
 typedef void* trk_stream;     /* hipStream_t */
 
 /* ---------------------------------------------------------------- library ------------- */
