@@ -529,10 +529,8 @@ inline void slide_grid(int nx, int ny, int batch, int kh, int U, int* spans_x, i
   int rpb = U - (kh - 1);
   while (rpb < 1) rpb += U;
   while ((int64_t)sx * ceil_div(nx, rpb) * (batch > 0 ? batch : 1) > max_waves && rpb < nx) rpb += U;
-  if (const char* e = getenv("TRK_BLUR_RPB")) {                   // tuning knob (rows per band)
-    const int v = atoi(e);
-    if (v > 0) rpb = v;
-  }
+  static const int rpb_env = getenv("TRK_BLUR_RPB") ? atoi(getenv("TRK_BLUR_RPB")) : 0;   // tuning knob (rows per band)
+  if (rpb_env > 0) rpb = rpb_env;
   *spans_x = sx;
   *nbands = ceil_div(nx, rpb);
   *rows_per_band = rpb;
@@ -547,7 +545,8 @@ inline bool slide_shape_ok(const BlurImpl* im) {
 // the chip better — estimated time = wave generations x rows per wave; the depth-9 loop is ~4 % slower per row at equal shape
 // (4096^2: 26.8 vs 25.8 us), so it must win by more than that.  Measured: 2048^2 12.1 -> 9.4 us, 3072^2 18.7 -> 16.6 us.
 inline bool slide_pick_depth9(const BlurImpl* im, int batch, int* spans_x, int* nbands, int* rpb) {
-  if (im->kh != 9 || getenv("TRK_BLUR_RPB")) return false;
+  static const bool rpb_forced = getenv("TRK_BLUR_RPB") != nullptr;
+  if (im->kh != 9 || rpb_forced) return false;
   int sx9, nb9, rpb9;
   slide_grid(im->nx, im->ny, batch, im->kh, 9, &sx9, &nb9, &rpb9);
   const int64_t slots = (int64_t)4 * cu_count();

@@ -656,7 +656,8 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
   TimerScope tm(op->timer, op->timer_which, tr, s);
   // fused ||y||^2 (batch 1): block partials from the kernel that writes y (band reduction / gather), then one finalize
   double* ssq_part = nullptr;
-  const bool fuse_ssq = sumsq && batch == 1 && (tr ? getenv("TRK_RADON_ADJ_V1") == nullptr : im->n_bands > 1);
+  static const bool adj_first_form = getenv("TRK_RADON_ADJ_V1") != nullptr;
+  const bool fuse_ssq = sumsq && batch == 1 && (tr ? !adj_first_form : im->n_bands > 1);
   if (fuse_ssq) {
     const int64_t nblk = tr ? (int64_t)ceil_div((int64_t)N * N, 256) * nt : (int64_t)ceil_div((int64_t)nt * na * nd, 256);
     if (int rc = scratch_doubles(s, (size_t)nblk, &ssq_part)) return rc;
@@ -702,8 +703,7 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
       return finalize_sums(ssq_part, ceil_div((int64_t)nt * na * nd, 256), 1, 1, sumsq, s);
     }
   } else {
-    static const bool adj_v1 = getenv("TRK_RADON_ADJ_V1") != nullptr;
-    if (adj_v1) {
+    if (adj_first_form) {
       dim3 grid(ceil_div((int64_t)N * N, 256), nt, batch);
       hipLaunchKernelGGL(k_radon_adj, grid, dim3(256), 0, s, x, ldx, y, ldy, N, nd, na, im->ang_dev);
       TRK_LAUNCH_CHECK();

@@ -1144,7 +1144,8 @@ int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, cons
   hipStream_t s = (hipStream_t)st;
   const int KA = k + (b1 ? 2 : 0);
   const int nt2 = ceil_div(KA, WG_TILE), ntu = nt2 * (nt2 + 1) / 2;
-  if (KA <= 64 && !getenv("TRK_WGRAM_NO_MFMA")) {
+  static const bool no_mfma = getenv("TRK_WGRAM_NO_MFMA") != nullptr;
+  if (KA <= 64 && !no_mfma) {
     // matrix-core single pass (every row read once)
     static const bool no_direct = getenv("TRK_WGRAM_NO_DIRECT") != nullptr;
     const bool al16 = (ld % 4 == 0) && aligned16(W) && (!w || aligned16(w)) && (!b1 || aligned16(b1));
