@@ -31,18 +31,49 @@ def _hipcc():
     return exe
 
 
+STAMP_PATH = LIB_PATH + ".stamp"
+
+
+def _source_hash():
+    """Hash of everything the library is built from.  Staleness is decided by content, not by modification times: a copied
+    tree (the GPU box receives a snapshot) must not trigger rebuilds, least of all from eight ranks at once."""
+    import hashlib
+    h = hashlib.sha256(" ".join(HIPCC_FLAGS[:-2] + SOURCES).encode())
+    deps = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    for path in [os.path.join(CSRC, f) for f in deps] + [os.path.join(INCLUDE, "trk.h")]:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _stale():
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(LIB_PATH) or not os.path.exists(STAMP_PATH):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))] + [os.path.join(INCLUDE, "trk.h")]
-    return any(os.path.getmtime(d) > t for d in deps)
+    try:
+        with open(STAMP_PATH) as fh:
+            return fh.read().strip() != _source_hash()
+    except OSError:
+        return True
 
 
 def build(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link libtrk.so.  Returns the library path."""
     if not force and not _stale():
         return LIB_PATH
+    # one builder at a time (several ranks may import the package together)
+    import fcntl
+    with open(os.path.join(CSRC, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not _stale():
+                return LIB_PATH
+            return _build_locked(force, verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(force, verbose):
     hipcc = _hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
@@ -67,6 +98,8 @@ def build(force=False, verbose=False):
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise TrkError(f"link of libtrk.so failed:\n{r.stdout}\n{r.stderr}")
+    with open(STAMP_PATH, "w") as fh:
+        fh.write(_source_hash() + "\n")
     return LIB_PATH
 
 
