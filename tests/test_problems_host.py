@@ -29,3 +29,22 @@ def test_gen_data_and_add_noise_follow_the_reference_recipe():
     assert np.isclose(np.linalg.norm(bm.reshape(-1, 1) - b), delta) and np.isclose(delta / np.linalg.norm(b), 0.02)
     bm, delta = D.add_noise(b, "Poisson", 0.0)
     assert bm.shape == (nx, ny) and delta == 0.0
+
+
+def test_deblurring1d_helpers_reproduce_config_c1_inputs():
+    """Deblurring1D.gen_xtrue / gen_data (Deblurring1D.py:104-197) against the golden of BASELINE config C1, which was produced
+    by the reference itself (n = 256, 'curve0', sigma = 3, inverse crime)."""
+    from conftest import load_golden
+    g = load_golden("deblur1d_cgls_n256")
+    n = int(g["n"])
+    D = P.Deblurring1D(CommitCrime=True)
+    x = D.gen_xtrue(n, "curve0")
+    assert np.array_equal(x, g["x_true"].reshape(-1))
+    b = D.gen_data(x, parameter=3.0)
+    assert np.allclose(b.reshape(-1), g["b_true"].reshape(-1), rtol=0, atol=1e-15)
+    assert np.allclose(D.PSF, g["psf"].reshape(-1))
+    for test, shape in (("sigma", (n,)), ("piecewise", (n,)), ("curve1", (n, 1)), ("curve2", (n, 1)), ("curve3", (n, 1))):
+        assert D.gen_xtrue(n, test).shape == shape
+    np.random.seed(0)
+    bm, delta = D.add_noise(b, "Gaussian", 0.05)
+    assert np.isclose(delta / np.linalg.norm(b), 0.05) and bm.shape == b.shape

@@ -86,14 +86,85 @@ class Deblurring2D:
 
 
 class Deblurring1D:
+    """trips.test_problems.Deblurring1D: the operator constructor on the engine plus the demo's host-side data helpers
+    (Deblurring1D.py:63-69, 104-143, 144-197, 199-216) — BASELINE config C1 (n = 256, 'curve0', sigma = 3)."""
+
     def __init__(self, **kwargs):
+        self.grid_points = self.ny = self.parameter = self.boundary_condition = None
         self.CommitCrime = kwargs.get("CommitCrime", False)
+
+    def Gauss1D(self, grid_points, parameter):
+        self.grid_points = grid_points
+        psf = gauss_psf_1d(grid_points, parameter)
+        return psf, int(np.where(psf == psf.max())[0][0])
 
     def forward_Op_1D(self, parameter, nx, boundary_condition="reflect", engine=None):
         if boundary_condition != "reflect":
             raise NotImplementedError("only the 'reflect' boundary is implemented on the engine")
-        self.PSF = gauss_psf_1d(nx, parameter)
+        self.parameter, self.boundary_condition = parameter, boundary_condition
+        self.PSF, self.center = self.Gauss1D(nx, parameter)
         return Blur1D(self.PSF, nx, engine=engine)
+
+    def gen_xtrue(self, N, test):
+        """The test signals of :144-197."""
+        self.grid_points, self.ny = N, 1
+        if test == "sigma":
+            x = np.linspace(-2.5, 2.5, N)
+            return np.piecewise(x, [x < 0, x >= 0], [-1, 1])
+        if test == "piecewise":
+            xx = np.linspace(0, 1, N)
+            edges = [0, 0.10, 0.15, 0.20, 0.25, 0.35, 0.38, 0.45, 0.55, 0.75, 0.8]
+            values = [0, 1, 0, 0, 0, 0, 0, 0.25, 0, 1, 0]
+            conds = [(edges[i] <= xx) & (xx < edges[i + 1]) for i in range(10)] + [(0.8 <= xx) & (xx <= 1)]
+            return np.piecewise(xx, conds, values)
+        if test == "curve0":
+            h = np.pi / N
+            t = -np.pi / 2 + np.arange(0.5, N, 1) * h
+            return 2 * np.exp(-6 * (t - 0.8) ** 2) + np.exp(-2 * (t + 0.5) ** 2)
+        h = 1.0 / N
+        sqh = np.sqrt(h)
+        i = np.arange(N, dtype=np.float64)
+        if test == "curve1":
+            return (h * sqh * (i + 0.5)).reshape(-1, 1)
+        if test == "curve2":
+            return ((np.exp((i + 1) * h) - np.exp(i * h)) / sqh).reshape(-1, 1)
+        if test == "curve3":
+            d = (((i + 1) * h) ** 2 - (i * h) ** 2) / 2
+            first = np.arange(N) < int(N / 2 + 1)
+            return (np.where(first, d, h - d) / sqh).reshape(-1, 1)
+        raise ValueError(f"unknown test signal {test!r}")
+
+    def gen_data(self, x, **kwargs):
+        """b = blurred x (:104-143): on a zero-padded 2N grid unless CommitCrime; parameter defaults to 0.3 as in the reference."""
+        from scipy.ndimage import convolve1d
+        if "parameter" in kwargs:
+            self.parameter, self.boundary_condition = kwargs["parameter"], "reflect"
+        elif self.parameter is None:
+            self.parameter = 0.3
+            self.boundary_condition = kwargs.get("boundary_condition", self.boundary_condition or "reflect")
+        n = self.grid_points
+        self.PSF, self.center = self.Gauss1D(n, self.parameter)
+        if self.CommitCrime is False:
+            pad = np.zeros((2 * n, 1))
+            pad[n // 2:n // 2 + n, :] = np.asarray(x, dtype=np.float64).reshape((n, 1))
+            b = convolve1d(pad, self.PSF, mode=self.boundary_condition)      # (axis -1 of an (2n, 1) array, as the reference)
+            return b[n // 2:n // 2 + n, :].reshape((-1, 1))
+        return convolve1d(np.asarray(x, dtype=np.float64), self.PSF, mode=self.boundary_condition).reshape((-1, 1))
+
+    def add_noise(self, b_true, opt, noise_level):
+        """(b_meas, delta) — :199-216 (unseeded, like the reference)."""
+        b_true = np.asarray(b_true, dtype=np.float64)
+        if opt == "Gaussian":
+            e = np.random.randn(self.grid_points, 1)
+            sig = noise_level * np.linalg.norm(b_true) / np.linalg.norm(e)
+            return b_true + sig * e, np.linalg.norm(sig * e)
+        if opt == "Poisson":
+            return np.random.poisson(lam=b_true + 1), 0
+        if opt == "Laplace":
+            e = np.random.laplace(self.grid_points)
+            sig = noise_level * np.linalg.norm(b_true) / np.linalg.norm(e)
+            return b_true + sig * e, np.linalg.norm(sig * e)
+        raise ValueError(f"unknown noise option {opt!r}")
 
 
 class Tomography:
