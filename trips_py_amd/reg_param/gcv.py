@@ -28,31 +28,22 @@ def gcv_function_diag(lam, s, rhs, variant="standard", fullsize=None):
     return num / (m_eff - float(np.sum(f))) ** 2
 
 
-_host = None
-
-
 def _host_lib():
-    """libtrk.so's host-side minimiser (trk_host_gcv_fminbound); None when the library cannot be loaded, in which case
-    the same search runs through scipy.optimize (identical algorithm, ~100x slower)."""
-    global _host
-    if _host is None:
-        try:
-            from .. import _lib
-            _host = _lib.load()
-        except Exception:
-            _host = False
-    return _host or None
+    """libtrk.so's host-side minimiser (trk_host_gcv_fminbound).  Loading failures propagate: there is no second
+    implementation behind it."""
+    from .. import _lib
+    return _lib.load()
 
 
 def fminbound_gcv_diag(s, rhs, m_eff, x1=1e-9, x2=1e2, xtol=1e-12, maxfun=1000):
     """argmin of gcv_function_diag over [x1, x2] — bounded Brent search with the settings of gcv.py:94-95."""
     s = np.ascontiguousarray(s, dtype=np.float64)
     rhs = np.ascontiguousarray(rhs, dtype=np.float64)
-    lib = _host_lib()
-    if lib is None or s.size == 0:
+    if s.size == 0:
         return sopt.fminbound(lambda lam: gcv_function_diag(lam, s, rhs, "modified", m_eff), x1, x2, xtol=xtol,
                               maxfun=maxfun, disp=0)
     import ctypes
+    lib = _host_lib()
     lam = ctypes.c_double(0.0)
     rc = lib.trk_host_gcv_fminbound(s.ctypes.data, rhs.ctypes.data, int(s.size), float(m_eff), float(x1), float(x2),
                                     float(xtol), int(maxfun), ctypes.byref(lam), None, None)
