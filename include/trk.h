@@ -183,11 +183,14 @@ int trk_cgls_x_update(int64_t n, const double* gamma, int gamma_n, const double*
  *   sub-diagonal beta_{j+1}, given as the SQUARED norms the Golub-Kahan kernels leave in device doubles:
  *   alpha_j^2 = alpha_sq[j*alpha_stride], beta_{j+1}^2 = beta_sq[j*beta_stride] (j < k), beta0^2 = *beta0_sq.
  *   mu = sqrt(lam) of the reference's stacked system.  Writes y[0..k).  1 <= k <= 2048.
+ *   y_over_alpha != 0: y_j / alpha_j is written instead — the coefficients of x = V y with respect to basis vectors
+ *   stored un-normalised (alpha_j v_j), as the Golub-Kahan recurrence produces them before its division.
  *   work (may be NULL): >= 3 (k_max + 1) + 4 device doubles, zero-initialised by the caller, kept between calls: when mu is
  *   unchanged and columns were only appended since the last call (the fixed-lambda hybrid iteration) only the new
  *   columns are rotated; anything else restarts from the first column. */
 int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride, const double* beta_sq, int64_t beta_stride, int k,
-                        double mu, const double* beta0_sq, double* y, double* work, int work_doubles, trk_stream stream);
+                        double mu, const double* beta0_sq, double* y, int y_over_alpha, double* work, int work_doubles,
+                        trk_stream stream);
 
 /* HOST function (no device work, no stream): lambda = argmin over [x1, x2] of the GCV function of a diagonalised
  * projected problem,  G(lam) = sum_i ((1 - f_i) rhs_i)^2 / (m_eff - sum_i f_i)^2,  f_i = s_i^2 / (s_i^2 + lam),

@@ -155,7 +155,8 @@ class CpuEngine:
         if sumsq is not None:
             _put(sumsq, np.dot(_d(out), _d(out)))
 
-    def bidiag_tikhonov(self, alpha_sq, alpha_stride, beta_sq, beta_stride, k, mu, beta0_sq, y, work=None):
+    def bidiag_tikhonov(self, alpha_sq, alpha_stride, beta_sq, beta_stride, k, mu, beta0_sq, y, work=None,
+                        y_over_alpha=False):
         (sa, ia), (sb, ib) = alpha_sq, beta_sq
         al = np.sqrt(sa.a[ia:ia + alpha_stride * k:alpha_stride])
         be = np.sqrt(sb.a[ib:ib + beta_stride * k:beta_stride])
@@ -164,7 +165,8 @@ class CpuEngine:
         B[np.arange(1, k + 1), np.arange(k)] = be
         rhs = np.zeros(2 * k + 1)
         rhs[0] = np.sqrt(_get(beta0_sq))
-        _put(y, np.linalg.lstsq(np.vstack((B, mu * np.eye(k))), rhs, rcond=None)[0])
+        sol = np.linalg.lstsq(np.vstack((B, mu * np.eye(k))), rhs, rcond=None)[0]
+        _put(y, sol / al if y_over_alpha else sol)
 
     def wgram(self, W, k, w, b1, G, c1=None, c2=None):
         Wk = _d(W[:k])

@@ -186,6 +186,9 @@ def test_bidiag_tikhonov_matches_stacked_lstsq(k, mu):
     want = np.linalg.lstsq(np.vstack((B, mu * np.eye(k))), rhs, rcond=None)[0]
     got = Y.host()
     assert np.abs(got - want).max() <= 1e-10 * max(1.0, np.abs(want).max()) * np.linalg.cond(np.vstack((B, mu * np.eye(k))))
+    # coefficients of un-normalised basis vectors alpha_j v_j
+    eng.bidiag_tikhonov(AB.ref(1), 2, AB.ref(2), 2, k, mu, AB.ref(0), Y.ref(0), y_over_alpha=True)
+    assert np.allclose(Y.host() * al, got, rtol=1e-13, atol=0)
     # resumable form: growing k with the same mu (one column or several at a time), then a change of mu, then a smaller k
     W = eng.scalars(3 * (k + 1) + 4)
     for kk, m in [(max(1, k // 3), mu), (max(1, k // 3) + 1 if k > 3 else k, mu), (k, mu), (k, mu + 0.25), (max(1, k - 1), mu + 0.25)]:
@@ -219,3 +222,26 @@ def test_gemv_nt_fused_gram_schmidt_step(k, n):
     assert np.allclose(H.host(k, 2 * k), V32 @ got, rtol=1e-10, atol=1e-9)
     eng.gemv_nt(dV, k, H.ref(0), dw, dw, H.ref(k))                 # in place
     assert torch.equal(dw, out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(64, 64), (96, 40)])
+def test_golub_kahan_unnormalised_storage_is_the_same_factorisation(shape):
+    """GKState(normalized=False) keeps beta_j u_j / alpha_j v_j: same alpha, beta, and the same vectors after division."""
+    import torch
+    from trips_py_amd.krylov import GKState
+    from trips_py_amd.operators import Blur2D
+    from oracle import cpu_ref as O
+    rng = np.random.default_rng(5)
+    A = Blur2D(O.gauss_psf((7, 7), 1.2)[0], shape[0], shape[1])
+    b = rng.standard_normal(A.shape[0]).astype(np.float32)
+    g1, g2 = GKState(A, b, 12), GKState(A, b, 12, normalized=False)
+    for _ in range(12):
+        g1.step()
+        g2.step(sync=False)
+    assert np.allclose(g2.alphas, g1.alphas, rtol=2e-5) and np.allclose(g2.betas, g1.betas, rtol=2e-5)
+    assert abs(g2.beta0 - g1.beta0) <= 1e-6 * g1.beta0
+    V1, V2 = g1.V.numpy(), g2.V.numpy() / np.asarray(g2.alphas)
+    U1, U2 = g1.U.numpy(), g2.U.numpy() / np.concatenate(([g2.beta0], g2.betas))
+    assert np.abs(V1 - V2).max() <= 2e-4 * np.abs(V1).max() and np.abs(U1 - U2).max() <= 2e-4 * np.abs(U1).max()
+

@@ -22,10 +22,14 @@ b = b + 0.01 * torch.linalg.norm(b) / np.sqrt(b.numel()) * torch.randn_like(b)
 L = FirstDerivative2D(N)
 kw = {"delta": float(0.01 * torch.linalg.norm(b))} if reg == "dp" else {}
 def run(n):
-    if which == "lsqr": return Hybrid_LSQR(A, b, n, reg, history=False, **kw)
+    if which in ("lsqr", "lsqrb"): return Hybrid_LSQR(A, b, n, reg, history=False, **kw)
     if which == "gmres": return Hybrid_GMRES(A, b, n, reg, history=False, **kw)
     if which == "gks": return GKS(A, b, L, 3, n, reg, history=False, **kw)
     if which == "mmgks": return MMGKS(A, b, L, 2, 1, 3, n, reg, history=False, **kw)
+if os.environ.get("GK_NORMALIZED"):      # timing comparison only (y is then scaled wrongly): the older normalised storage
+    H = sys.modules["trips_py_amd.solvers.Hybrid_LSQR"]
+    from trips_py_amd.krylov import GKState
+    H.GKState = lambda A, b, n, normalized=False: GKState(A, b, n)
 run(5); torch.cuda.synchronize()
 t0 = time.perf_counter(); run(its); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"{which} reg={reg} N={N}: {its} iterations in {dt*1e3:.1f} ms = {its/dt:.0f} it/s")

@@ -82,7 +82,8 @@ __global__ __launch_bounds__(64) void k_bidiag_tikhonov(const double* __restrict
 
 // Back substitution R y = phi for the upper-bidiagonal R kept as (1/rho, theta): the three arrays are first copied to
 // LDS by all lanes (the dependent chain then waits ~60 cycles per step on LDS instead of an L2 round trip).
-__global__ __launch_bounds__(64) void k_bidiag_backsub(const double* __restrict__ st, int cap, int k, double* __restrict__ y) {
+__global__ __launch_bounds__(64) void k_bidiag_backsub(const double* __restrict__ st, int cap, int k, double* __restrict__ y,
+                                                        const double* __restrict__ alpha_sq, int64_t alpha_stride) {
   extern __shared__ double sm[];
   const double* invrho = st + 4;
   const double* theta = invrho + cap;
@@ -94,20 +95,24 @@ __global__ __launch_bounds__(64) void k_bidiag_backsub(const double* __restrict_
     s_ph[j] = phi[j];
   }
   __syncthreads();
-  if (threadIdx.x != 0) return;
-  double yn = s_ph[k - 1] * s_ir[k - 1];
-  y[k - 1] = yn;
-  for (int j = k - 2; j >= 0; --j) {
-    yn = (s_ph[j] - s_th[j + 1] * yn) * s_ir[j];
-    y[j] = yn;
+  if (threadIdx.x == 0) {
+    double yn = s_ph[k - 1] * s_ir[k - 1];
+    s_ph[k - 1] = yn;
+    for (int j = k - 2; j >= 0; --j) {
+      yn = (s_ph[j] - s_th[j + 1] * yn) * s_ir[j];
+      s_ph[j] = yn;
+    }
   }
+  __syncthreads();
+  // alpha_sq != NULL: coefficients with respect to the un-normalised vectors alpha_j v_j
+  for (int j = threadIdx.x; j < k; j += 64) y[j] = alpha_sq ? s_ph[j] / sqrt(alpha_sq[j * alpha_stride]) : s_ph[j];
 }
 
 }  // namespace
 
 extern "C" int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride, const double* beta_sq,
                                    int64_t beta_stride, int k, double mu, const double* beta0_sq, double* y,
-                                   double* work, int work_doubles, trk_stream stream) {
+                                   int y_over_alpha, double* work, int work_doubles, trk_stream stream) {
   TRK_REQUIRE(alpha_sq && beta_sq && beta0_sq && y, "trk_bidiag_tikhonov: NULL argument");
   TRK_REQUIRE(k >= 1 && k <= BIDIAG_MAX_K, "trk_bidiag_tikhonov: k must be in [1, 2048]");
   TRK_REQUIRE(mu >= 0.0, "trk_bidiag_tikhonov: mu must be >= 0");
@@ -122,7 +127,8 @@ extern "C" int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride,
   }
   hipLaunchKernelGGL(k_bidiag_tikhonov, dim3(1), dim3(64), 0, s, alpha_sq, alpha_stride, beta_sq, beta_stride, k, mu,
                      beta0_sq, y, work, cap, scratch);
-  hipLaunchKernelGGL(k_bidiag_backsub, dim3(1), dim3(64), 3 * sizeof(double) * (size_t)k, s, work ? work : scratch, cap, k, y);
+  hipLaunchKernelGGL(k_bidiag_backsub, dim3(1), dim3(64), 3 * sizeof(double) * (size_t)k, s, work ? work : scratch, cap, k, y,
+                     y_over_alpha ? alpha_sq : nullptr, alpha_stride);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }

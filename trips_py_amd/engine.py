@@ -289,12 +289,14 @@ class HipEngine:
                                  self.stream())
         _lib.check(rc, "trk_gemv_n")
 
-    def bidiag_tikhonov(self, alpha_sq, alpha_stride, beta_sq, beta_stride, k, mu, beta0_sq, y, work=None):
+    def bidiag_tikhonov(self, alpha_sq, alpha_stride, beta_sq, beta_stride, k, mu, beta0_sq, y, work=None,
+                        y_over_alpha=False):
         """y = argmin ||B_k y - beta0 e1||^2 + mu^2 ||y||^2 for the Golub-Kahan bidiagonal given as squared device norms.
         work: a zero-initialised DevScalars block kept between calls (resumes the rotation recurrence when only columns
-        were appended and mu is unchanged)."""
+        were appended and mu is unchanged).  y_over_alpha: write y_j / alpha_j (coefficients of un-normalised vectors)."""
         rc = self.lib.trk_bidiag_tikhonov(_ptr(alpha_sq), int(alpha_stride), _ptr(beta_sq), int(beta_stride), int(k),
-                                          float(mu), _ptr(beta0_sq), _ptr(y), None if work is None else work.ref(0),
+                                          float(mu), _ptr(beta0_sq), _ptr(y), int(bool(y_over_alpha)),
+                                          None if work is None else work.ref(0),
                                           0 if work is None else len(work), self.stream())
         _lib.check(rc, "trk_bidiag_tikhonov")
 

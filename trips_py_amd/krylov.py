@@ -64,10 +64,18 @@ class GKState:
     reorthogonalisation).  U, V live on the device, and so do the squared norms that define B_k:
     AB[0] = beta0^2 = ||b||^2, AB[2j+1] = alpha_j^2, AB[2j+2] = beta_{j+1}^2 (global sums after `allreduce`).
     `alphas`, `betas` are their host copies; `step(sync=False)` skips the download, so a caller that needs B_k only
-    on the device (fixed-lambda Hybrid_LSQR: trk_bidiag_tikhonov) never synchronises."""
+    on the device (fixed-lambda Hybrid_LSQR: trk_bidiag_tikhonov) never synchronises.
 
-    def __init__(self, A, b, capacity):
+    normalized=False keeps the vectors as the recurrence produces them, U[j] = beta_j u_j (beta_0 := beta0, U[0] = b)
+    and V[j] = alpha_j v_j, and folds the divisions into the coefficients of the next step:
+        V[k]   = (1/beta_k)  A^T U[k] - (beta_k/alpha_{k-1}) V[k-1]        ||V[k]||   = alpha_k
+        U[k+1] = (1/alpha_k) A V[k]   - (alpha_k/beta_k)     U[k]          ||U[k+1]|| = beta_{k+1}
+    (same alpha, beta; one rounding less per element) — two kernels and 8 (n + m) bytes less per step.  Consumers
+    divide by the norms themselves: x = V y takes y_j / alpha_j, U^T b gives beta_j (u_j . b)."""
+
+    def __init__(self, A, b, capacity, normalized=True):
         self.A, self.eng = A, A.engine
+        self.normalized = bool(normalized)
         m, n = A.shape
         eng = self.eng
         self.U = DeviceBasis(eng, m, capacity + 1)
@@ -78,7 +86,10 @@ class GKState:
         bv = eng.to_vec(b, m)
         eng.nrm2sq(bv, self.AB.ref(0))
         eng.allreduce(self.AB, 0, 1)
-        eng.scale(Coef(1.0, den=self.AB.ref(0), sqrt_den=True), bv, self.U.next_slot())
+        if self.normalized:
+            eng.scale(Coef(1.0, den=self.AB.ref(0), sqrt_den=True), bv, self.U.next_slot())
+        else:
+            self.U.next_slot().copy_(bv)
         self.U.commit()
         self._beta0 = None
 
@@ -88,6 +99,7 @@ class GKState:
         bidiagonal so that the next step continues the factorisation."""
         st = cls.__new__(cls)
         st.A, st.eng = A, A.engine
+        st.normalized = True
         eng = A.engine
         m, n = A.shape
         k = len(alphas)
@@ -143,6 +155,23 @@ class GKState:
         AB = self.AB
         u = self.U[k]
         a2, b2 = AB.ref(2 * k + 1), AB.ref(2 * k + 2)
+        if not self.normalized:
+            bk2 = AB.ref(2 * k)                                     # ||U[k]||^2
+            A.apply(u, out=self.tmp_n, transpose=True)
+            v = self.V.next_slot()
+            if k == 0:
+                eng.scale(Coef(1.0, den=bk2, sqrt_den=True), self.tmp_n, v, sumsq=a2)
+            else:
+                eng.axpby(Coef(1.0, den=bk2, sqrt_den=True), self.tmp_n,
+                          Coef(-1.0, num=bk2, den=AB.ref(2 * k - 1), sqrt_num=True, sqrt_den=True), self.V[k - 1], v, sumsq=a2)
+            eng.allreduce(AB, 2 * k + 1, 2 * k + 2)
+            self.V.commit()
+            A.apply(v, out=self.tmp_m)
+            eng.axpby(Coef(1.0, den=a2, sqrt_den=True), self.tmp_m,
+                      Coef(-1.0, num=a2, den=bk2, sqrt_num=True, sqrt_den=True), u, self.U.next_slot(), sumsq=b2)
+            eng.allreduce(AB, 2 * k + 2, 2 * k + 3)
+            self.U.commit()
+            return self._finish_step(k, sync)
         # v = A^T u_k - beta_k v_{k-1} ; alpha = ||v||        (beta_k^2 sits in AB[2k])
         if k == 0:
             A.apply(u, out=self.tmp_n, transpose=True, sumsq=a2)
@@ -159,9 +188,12 @@ class GKState:
         eng.allreduce(AB, 2 * k + 2, 2 * k + 3)
         eng.scale(Coef(1.0, den=b2, sqrt_den=True), self.tmp_m, self.U.next_slot())
         self.U.commit()
+        return self._finish_step(k, sync)
+
+    def _finish_step(self, k, sync):
         if not sync:
             return None
-        h = np.sqrt(AB.host(2 * k + 1, 2 * k + 3))
+        h = np.sqrt(self.AB.host(2 * k + 1, 2 * k + 3))
         if len(self._alphas) == k:
             self._alphas.append(float(h[0]))
             self._betas.append(float(h[1]))

@@ -30,7 +30,7 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     fmt = Formatter(b)
     xt = None if x_true is None else eng.to_vec(x_true, n)
 
-    gk = GKState(A, b, n_iter)
+    gk = GKState(A, b, n_iter, normalized=False)     # U[j] = beta_j u_j, V[j] = alpha_j v_j (krylov.GKState)
     bv = eng.to_vec(b, m) if (isinstance(regparam, str) and regparam == "dp") else None
     if keep:
         history_fits(eng, n_iter, n, "Hybrid_LSQR xHistory")
@@ -62,12 +62,16 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             # discrepancy_principle(U, B, L, b): projects b on the (no longer exactly orthonormal) computed U (:86)
             eng.gemv_t(gk.U.data, k + 1, bv, P.ref(0))
             eng.allreduce(P, 0, k + 1)
-            lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=B, dp_bproj=P.host(0, k + 1))
+            bproj = P.host(0, k + 1) / np.concatenate(([gk.beta0], gk.betas[:k]))          # rows of U are beta_j u_j
+            lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=B, dp_bproj=bproj)
         else:
             lam = regparam
         lams.append(lam)
+        if not keep and xt is None and ii < n_iter - 1:
+            continue                         # nobody looks at this iterate (history=False, no x_true)
         # y = lstsq([B; sqrt(lam) I], [beta0 e1; 0]) (:104), on the device from the squared norms in gk.AB
-        eng.bidiag_tikhonov(gk.AB.ref(1), 2, gk.AB.ref(2), 2, k, np.sqrt(lam), gk.AB.ref(0), Y.ref(0), W)
+        # (as y_j / alpha_j: the rows of V are alpha_j v_j)
+        eng.bidiag_tikhonov(gk.AB.ref(1), 2, gk.AB.ref(2), 2, k, np.sqrt(lam), gk.AB.ref(0), Y.ref(0), W, y_over_alpha=True)
         x_dev = X[nx_done] if keep else X[0]
         eng.gemv_n(gk.V.data, k, Y.ref(0), x_dev)
         nx_done += 1
