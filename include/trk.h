@@ -199,6 +199,12 @@ int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride, const doub
  * maxfun = 1000 there).  s, rhs: k host doubles.  fval_out / nfev_out may be NULL. */
 int trk_host_gcv_fminbound(const double* s, const double* rhs, int k, double m_eff, double x1, double x2, double xatol,
                            int maxfun, double* lam_out, double* fval_out, int* nfev_out);
+/* HOST function: the Newton iteration of the discrepancy principle (discrepancy_principle.py:80-99, 'tikhonov'):
+ * solves || bhat / (sv*beta + 1) ||^2 + extra = target for beta = 1/alpha from beta = 1e-8 with the reference's
+ * stopping rule.  sv: squared singular values padded with zeros to n, bhat: U^T b (n host doubles).  *alpha_set = 0
+ * when the reference would return its unassigned value (converged at the very first step). */
+int trk_host_dp_newton(const double* sv, const double* bhat, int n, double target, double extra, double* alpha_out,
+                       int* alpha_set, int* iters_out);
 
 /* n_iters consecutive CGLS iterations (numbers k_first .. k_first + n_iters - 1, 1-based) enqueued by one call: the loop
  * body of trips/solvers/CGLS.py:56-80 with tol = 0, i.e. nothing is read back between iterations.  Same kernels, scalar

@@ -25,6 +25,14 @@ class CpuScalars:
     def host(self, i=0, j=None):
         return self.a[i:j].copy()
 
+    def host_later(self, i, j):
+        vals = self.a[i:j].copy()
+
+        class _Now:
+            def get(self):
+                return vals
+        return _Now()
+
     def set(self, i, values):
         v = np.atleast_1d(np.asarray(values, dtype=np.float64))
         self.a[i:i + v.size] = v

@@ -1,6 +1,7 @@
 """Host-side (product) regularisation-parameter selectors against the reference's own values (tests/golden/regparam_fn.npz).
 These take only k-sized inputs; the m-length contractions they replace are fed here from NumPy."""
 import numpy as np
+import pytest
 import scipy.linalg as sla
 
 from conftest import load_golden
@@ -98,3 +99,19 @@ def test_gcv_pair_reduction_keeps_the_minimiser():
     RL0 = np.triu(rng.standard_normal((5, 5)))
     RL0[2, 2] = 0.0
     assert G._diagonalise(np.eye(5), RL0, np.ones(5)) is None
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 40, 150])
+def test_bidiag_svd_first_row_matches_dense_svd(k):
+    """What Hybrid_LSQR's GCV takes from svd(B_k) (Hybrid_LSQR.py:81-84): singular values and |first row of U|."""
+    import scipy.linalg as sla
+    from trips_py_amd.reg_param._bidiag import bidiag_svd_first_row
+    rng = np.random.default_rng(k)
+    al, be = rng.random(k) + 0.01, rng.random(k) + 0.01
+    B = np.zeros((k + 1, k))
+    B[np.arange(k), np.arange(k)] = al
+    B[np.arange(1, k + 1), np.arange(k)] = be
+    U, s, _ = sla.svd(B, full_matrices=False)
+    s2, u0 = bidiag_svd_first_row(al, be)
+    assert np.allclose(s2, s, rtol=1e-12, atol=1e-14 * s.max())
+    assert np.allclose(np.abs(u0), np.abs(U[0]), rtol=0, atol=1e-11)

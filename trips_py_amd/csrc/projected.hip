@@ -262,3 +262,39 @@ extern "C" int trk_host_gcv_fminbound(const double* s, const double* rhs, int k,
   if (nfev_out) *nfev_out = num;
   return TRK_OK;
 }
+
+// HOST: the Newton iteration of the discrepancy principle on beta = 1/alpha
+// (trips/utilities/reg_param/discrepancy_principle.py:80-99, dptype 'tikhonov'):
+//   f(beta) = || bhat / (sv*beta + 1) ||^2 + extra - target,  beta_0 = 1e-8, at least 30 steps unless the update falls
+//   below 1e-12*beta.  *alpha_set = 0 when the loop ended before alpha was assigned (the reference then returns None).
+extern "C" int trk_host_dp_newton(const double* sv, const double* bhat, int n, double target, double extra,
+                                  double* alpha_out, int* alpha_set, int* iters_out) {
+  TRK_REQUIRE(sv && bhat && alpha_out && alpha_set, "trk_host_dp_newton: NULL argument");
+  TRK_REQUIRE(n >= 1, "trk_host_dp_newton: n must be >= 1");
+  double beta = 1e-8, alpha = 0.0;
+  int it = 0, have = 0;
+  while (it < 30 || (it <= 100 && std::fabs(alpha) < 1e-16)) {
+    double zz = 0.0, zwz = 0.0;
+    for (int i = 0; i < n; ++i) {
+      const double den = sv[i] * beta + 1.0;
+      const double z = bhat[i] / den;
+      const double w = z / den;
+      zz += z * z;
+      zwz += z * (w - z);
+    }
+    const double nz = std::sqrt(zz);
+    const double f = nz * nz + extra - target;
+    const double fp = 2.0 / beta * zwz;
+    const double beta_new = beta - f / fp;
+    if (std::fabs(beta_new - beta) < 1e-12 * beta) break;
+    beta = beta_new;
+    alpha = 1.0 / beta_new;
+    have = 1;
+    ++it;
+  }
+  *alpha_out = alpha;
+  *alpha_set = have;
+  if (iters_out) *iters_out = it;
+  return TRK_OK;
+}
+

@@ -58,11 +58,12 @@ class DevScalars:
     address as a plain int, so the hot loops create no tensor views); `view(i, j)` is a tensor view for collectives
     and downloads."""
 
-    __slots__ = ("t", "base")
+    __slots__ = ("t", "base", "_pin")
 
     def __init__(self, t):
         self.t = t
         self.base = t.data_ptr()
+        self._pin = None
 
     def ref(self, i):
         return self.base + 8 * i
@@ -72,6 +73,16 @@ class DevScalars:
 
     def host(self, i=0, j=None):
         return self.t[i:j].detach().to("cpu").numpy().astype(np.float64, copy=False)
+
+    def host_later(self, i, j):
+        """Start the download of scalars [i, j) at this point of the stream and return a handle; `get()` waits for THAT
+        copy only, so work enqueued in between overlaps with whatever the host does before it asks."""
+        if self._pin is None:
+            self._pin = torch.empty(self.t.numel(), dtype=torch.float64, pin_memory=True)
+        self._pin[i:j].copy_(self.t[i:j], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return _Pending(ev, self._pin, i, j)
 
     def set(self, i, values):
         v = torch.as_tensor(np.atleast_1d(np.asarray(values, dtype=np.float64)))
@@ -89,6 +100,17 @@ class DevScalars:
 
     def data_ptr(self):
         return self.base
+
+
+class _Pending:
+    __slots__ = ("ev", "pin", "i", "j")
+
+    def __init__(self, ev, pin, i, j):
+        self.ev, self.pin, self.i, self.j = ev, pin, i, j
+
+    def get(self):
+        self.ev.synchronize()
+        return self.pin[self.i:self.j].numpy().copy()
 
 
 def _as_coef(a):

@@ -121,9 +121,10 @@ class GKState:
         return st
 
     # host copies, downloaded on demand
-    def _sync(self):
-        k = self.V.k
+    def _sync(self, need=None):
+        k = self.V.k if need is None else need
         if len(self._alphas) < k:
+            k = self.V.k
             h = self.AB.host(0, 2 * k + 1)
             if self._beta0 is None:
                 self._beta0 = float(np.sqrt(h[0]))
@@ -144,6 +145,26 @@ class GKState:
         if self._beta0 is None:
             self._beta0 = float(np.sqrt(self.AB.host(0, 1)[0]))
         return self._beta0
+
+    def step_prefetch(self):
+        """One step, enqueued, plus the start of the download of its two norms: `absorb()` later waits for that copy
+        only, so a caller can enqueue the NEXT step before it looks at this one's numbers (the hybrid solvers choose
+        lambda_k on the host while the device already runs step k+1, which does not depend on it)."""
+        k = self.V.k
+        self.step(sync=False)
+        lo = 0 if self._beta0 is None else 2 * k + 1
+        return k, lo, self.AB.host_later(lo, 2 * k + 3)
+
+    def absorb(self, pending):
+        k, lo, handle = pending
+        if len(self._alphas) > k:
+            return                                  # a full download overtook it
+        v = np.sqrt(handle.get())
+        if lo == 0:
+            self._beta0 = float(v[0])
+            v = v[2 * k + 1:]
+        self._alphas.append(float(v[0]))
+        self._betas.append(float(v[1]))
 
     def step(self, sync=True):
         A, eng = self.A, self.eng
@@ -201,10 +222,11 @@ class GKState:
             self._sync()
         return float(h[0]), float(h[1])
 
-    def B(self):
-        """(k+1) x k lower-bidiagonal projected matrix."""
-        alphas, betas = self.alphas, self.betas
-        k = len(alphas)
+    def B(self, k=None):
+        """(k+1) x k lower-bidiagonal projected matrix (k: leading part, host copies permitting without a download)."""
+        self._sync(k)
+        k = len(self._alphas) if k is None else k
+        alphas, betas = self._alphas[:k], self._betas[:k]
         B = np.zeros((k + 1, k))
         B[np.arange(k), np.arange(k)] = alphas
         B[np.arange(1, k + 1), np.arange(k)] = betas

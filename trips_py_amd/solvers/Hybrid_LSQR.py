@@ -10,6 +10,9 @@ import scipy.linalg as sla
 
 from .._io import Formatter, as_operator, history_fits
 from ..krylov import GKState
+from ..reg_param._bidiag import bidiag_svd_first_row, bidiag_svd_project
+from ..reg_param.discrepancy_principle import discrepancy_principle
+from ..reg_param.gcv import fminbound_gcv_diag
 from ._common import check_delta, choose_lambda, small_host_blas
 
 
@@ -45,25 +48,37 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
 
     lams, lam, nx_done, x_dev = [], 0, 0, None
     on_host = isinstance(regparam, str)          # lambda selection needs B_k on the host
+    pend = gk.step_prefetch() if on_host else None
     for ii in range(n_iter):
-        gk.step(sync=on_host)
         k = ii + 1
+        if on_host:
+            gk.absorb(pend)                  # alpha_k, beta_{k+1}; step k+1 runs while the host chooses lambda_k
+            pend = gk.step_prefetch() if k < n_iter else None
+        else:
+            gk.step(sync=False)
         if ii == 0:
             lam = 0
             continue
         if on_host:
-            B = gk.B()
+            B = gk.B(k)
             bhat = np.zeros(k + 1)
             bhat[0] = gk.beta0
-        if isinstance(regparam, str) and regparam in ("gcv", "l_curve"):
+        if isinstance(regparam, str) and regparam == "gcv":
+            # svd(B) (:81) enters GCV through s and Q_A^T bhat = beta0 * (first row of the left vectors) only
+            s, u0 = bidiag_svd_first_row(gk._alphas[:k], gk._betas[:k])
+            lam = fminbound_gcv_diag(s, gk.beta0 * u0, m)              # variant 'modified', fullsize = m (:84)
+        elif isinstance(regparam, str) and regparam == "l_curve":
             Qb, s, _ = sla.svd(B, full_matrices=False)
             lam = choose_lambda(regparam, np.diag(s), np.eye(k), Qb.T @ bhat, 0.0, kwargs, variant="modified", fullsize=m)
         elif isinstance(regparam, str) and regparam == "dp":
             # discrepancy_principle(U, B, L, b): projects b on the (no longer exactly orthonormal) computed U (:86)
             eng.gemv_t(gk.U.data, k + 1, bv, P.ref(0))
             eng.allreduce(P, 0, k + 1)
-            bproj = P.host(0, k + 1) / np.concatenate(([gk.beta0], gk.betas[:k]))          # rows of U are beta_j u_j
-            lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=B, dp_bproj=bproj)
+            bproj = P.host(0, k + 1) / np.concatenate(([gk.beta0], gk._betas[:k]))          # rows of U are beta_j u_j
+            s, proj = bidiag_svd_project(gk._alphas[:k], gk._betas[:k], bproj)       # svd(B_k), U^T bproj (dp :68-70)
+            extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
+            lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
+                                        spectrum=(s, proj, (k + 1, k)), **extra)
         else:
             lam = regparam
         lams.append(lam)
