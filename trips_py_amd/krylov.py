@@ -281,23 +281,40 @@ class ArnoldiState:
         self.V.commit()
         self.beta0 = float(np.sqrt(self.S.host(0, 1)[0]))
 
-    def step(self):
+    def _enqueue(self):
         A, eng, S, V = self.A, self.eng, self.S, self.V
         k = V.k
         if len(S) < 2 * k + 2:
             self.S = S = eng.scalars(4 * k + 2)
         A.apply(V[k - 1], out=self.w)
-        orthogonalize(eng, V, k, self.w, S, 1, passes=2)
-        eng.nrm2sq(self.w, S.ref(0))
+        slot = V.next_slot()
+        # the second Gram-Schmidt pass writes straight into the next slot and leaves ||.||^2 in S[0]
+        orthogonalize(eng, V, k, self.w, S, 1, passes=2, out=slot, sumsq=S.ref(0))
         eng.allreduce(S, 0, 1)
-        eng.scale(Coef(1.0, den=S.ref(0), sqrt_den=True), self.w, V.next_slot())
+        eng.scale(Coef(1.0, den=S.ref(0), sqrt_den=True), slot, slot)
         V.commit()
-        h = S.host(0, 1 + 2 * k)
+        return k
+
+    def _column(self, k, h):
         col = np.zeros(k + 1)
         col[:k] = h[1:1 + k] + h[1 + k:1 + 2 * k]
         col[k] = np.sqrt(h[0])
         self.Hcols.append(col)
         return col
+
+    def step(self):
+        k = self._enqueue()
+        return self._column(k, self.S.host(0, 1 + 2 * k))
+
+    def step_prefetch(self):
+        """The step enqueued and the download of its column of H started; `absorb()` waits for that copy only (see
+        GKState.step_prefetch).  Absorb a pending step before prefetching the next: both use the same scalars."""
+        k = self._enqueue()
+        return k, self.S.host_later(0, 1 + 2 * k)
+
+    def absorb(self, pending):
+        k, handle = pending
+        return self._column(k, handle.get())
 
     def H(self):
         k = len(self.Hcols)

@@ -41,10 +41,12 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
         eng.allreduce(E, 0, 1)
 
     lams, res, lam, x_dev = [], [], 0, None
+    pend = ar.step_prefetch() if n_iter > 0 else None
     for ii in range(n_iter):
-        ar.step()
         k = ii + 1
-        H = ar.H()
+        ar.absorb(pend)                      # column k of H; step k+1 runs while the host works on the projected problem
+        pend = ar.step_prefetch() if k < n_iter else None
+        H = ar.H()[:k + 1, :k]
         bhat = np.zeros(k + 1)
         bhat[0] = ar.beta0
         if ii == 0:

@@ -48,7 +48,7 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
 
     lams, lam, nx_done, x_dev = [], 0, 0, None
     on_host = isinstance(regparam, str)          # lambda selection needs B_k on the host
-    pend = gk.step_prefetch() if on_host else None
+    pend = gk.step_prefetch() if (on_host and n_iter > 0) else None
     for ii in range(n_iter):
         k = ii + 1
         if on_host:
