@@ -545,10 +545,16 @@ inline bool slide_shape_ok(const BlurImpl* im) {
 // the chip better — estimated time = wave generations x rows per wave; the depth-9 loop is ~4 % slower per row at equal shape
 // (4096^2: 26.8 vs 25.8 us), so it must win by more than that.  Measured: 2048^2 12.1 -> 9.4 us, 3072^2 18.7 -> 16.6 us.
 inline bool slide_pick_depth9(const BlurImpl* im, int batch, int* spans_x, int* nbands, int* rpb) {
-  static const bool rpb_forced = getenv("TRK_BLUR_RPB") != nullptr;
+  static const bool rpb_forced = getenv("TRK_BLUR_RPB") != nullptr || getenv("TRK_BLUR_NO_D9") != nullptr;
   if (im->kh != 9 || rpb_forced) return false;
   int sx9, nb9, rpb9;
   slide_grid(im->nx, im->ny, batch, im->kh, 9, &sx9, &nb9, &rpb9);
+  // one-row bands (j = 1) are never worth it: on a small image they only multiply the waves and the block partials every
+  // consumer sums (512^2 CGLS: 36.1 k it/s with 1-row bands, 41.2 k with the 10-row bands of the depth-6 form)
+  if (rpb9 < 10) {
+    rpb9 = 10;
+    nb9 = ceil_div(im->nx, rpb9);
+  }
   const int64_t slots = (int64_t)4 * cu_count();
   auto est = [&](int sx, int nb, int r) {
     const int64_t waves = (int64_t)sx * nb * (batch > 0 ? batch : 1);
