@@ -179,8 +179,8 @@ def run_blur_cgls(args, rank, world):
     alg_bytes = (16.0 if fused else 8.0) * n
     t_kernel = float(np.mean(ms_fwd)) * 1e-3
     achieved = alg_bytes / t_kernel / 1e9
-    kname = ("k_blur_slide<9,9,D=6,sumsq,fuse> (p = t + ratio*p fused into w = A p, + ||w||^2)" if fused
-             else "k_blur_slide<9,9,D=6,sumsq> (forward blur matvec w = A p, fused ||w||^2)")
+    kname = ("k_blur_slide<9,9,D=9,sumsq,fuse> (p = t + ratio*p fused into w = A p, + ||w||^2)" if fused
+             else "k_blur_slide<9,9,D=9,sumsq> (forward blur matvec w = A p, fused ||w||^2)")
     roofline = {"bound": "hbm", "kernel": kname,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None if fused else load_traffic("k_blur_slide_fwd"),

@@ -5,7 +5,8 @@ import torch
 from trips_py_amd.operators import Blur2D
 from trips_py_amd.problems import gauss_psf
 psf = gauss_psf((9, 9), (3, 3))[0]
-for N in (1024, 1536, 2048, 2560, 3072, 3584, 3840, 4000, 4096, 4160, 4224, 4352, 5120, 8192):
+SIZES = [int(a) for a in sys.argv[1:]] or (1024, 1536, 2048, 2560, 3072, 3584, 3840, 4000, 4096, 4160, 4224, 4352, 5120, 8192)
+for N in SIZES:
     A = Blur2D(psf, N, N)
     x = torch.randn(N * N, device="cuda"); y = torch.empty_like(x)
     def t(fn, R=40):

@@ -280,15 +280,13 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
   // horizontally and vertically adjacent waves (which share halo lines) share an L2.
   int band, span;
   {
-    const int id = blockIdx.x;
-    if ((nbands & 7) == 0) {
-      const int xcd = id & 7, local = id >> 3, bpx = nbands >> 3;
-      band = xcd * bpx + local / spans_x;
-      span = local % spans_x;
-    } else {
-      band = id / spans_x;
-      span = id % spans_x;
-    }
+    // XCD x receives the ids congruent to x mod 8 — (total - x + 7) / 8 of them; it takes that many consecutive tiles of
+    // the row-major (band, span) order, starting where the lower XCDs' shares end (any band count, no remainder rule)
+    const int id = blockIdx.x, total = nbands * spans_x;
+    const int xcd = id & 7, local = id >> 3;
+    const int t = xcd * (total >> 3) + min(xcd, total & 7) + local;
+    band = t / spans_x;
+    span = t - band * spans_x;
   }
   x += (int64_t)blockIdx.y * ldx;
   y += (int64_t)blockIdx.y * ldy;
@@ -519,16 +517,36 @@ int launch_slide(const BlurImpl* im, int tr, const float* x, int64_t ldx, float*
 }
 
 // Bands for the sliding kernel.  A wave processes roundup(rows_per_band + KH-1, U) staged rows, so band heights of the
-// form j*U - (KH-1) waste nothing; the smallest such height that needs no more than ~1.25 waves per SIMD is taken
-// (measured at 4096^2, 9x9: 64-row bands / one wave per SIMD 24.4 us; 32-row bands / two waves 30.4 us — the KH-1 halo
-// rows every band re-reads outweigh the second wave).  Band count is rounded to a multiple of 8 when it costs nothing,
-// for the XCD-aware placement.
+// form j*U - (KH-1) waste nothing.  Which j: a sweep over band heights at 2560^2 ... 5120^2 (tools/blur_band_sweep.sh,
+// DESIGN.md §4.1) shows the time following  staged rows per wave x G(x),  x = waves / (4 x CUs) the waves per SIMD:
+//     G = 1                                        x <= 1   (fewer waves than SIMDs do not help: the rows per wave rule)
+//     G = 1 + 0.3 (ceil(x) - 1) + 0.37 (x - 1)     x >  1   (a second wave on a SIMD costs 1.3x at once, then little
+//                                                            more until the next SIMD-filling multiple)
+// so the best grids fill the SIMDs once (x just below 1) or nearly twice (x = 1.7 .. 1.9) and the worst sit just above a
+// multiple (4096^2, 9x9: 37-row bands, x = 1.73: 22.6 us; 64-row bands, x = 1: 23.5 us; 46-row bands, x = 1.41: 24.5 us).
+// The candidate with the smallest predicted time is taken; bands shorter than KH + 1 rows are never used (on a small
+// image they only multiply the waves and the block partials every consumer sums).
 inline void slide_grid(int nx, int ny, int batch, int kh, int U, int* spans_x, int* nbands, int* rows_per_band) {
   const int sx = ceil_div(ny, SPAN);
-  const int64_t max_waves = (int64_t)5 * cu_count();              // 1.25 waves per SIMD
-  int rpb = U - (kh - 1);
-  while (rpb < 1) rpb += U;
-  while ((int64_t)sx * ceil_div(nx, rpb) * (batch > 0 ? batch : 1) > max_waves && rpb < nx) rpb += U;
+  const double slots = 4.0 * cu_count();
+  const int nb = batch > 0 ? batch : 1;
+  int rows = U;
+  while (rows - (kh - 1) < kh + 1) rows += U;
+  int rpb = rows - (kh - 1);
+  double best = 1e300;
+  for (;; rows += U) {
+    const int r = rows - (kh - 1);
+    const double x = (double)sx * ceil_div(nx, r) * nb / slots;
+    const double g = x <= 1.0 ? 1.0 : 1.0 + 0.3 * (ceil(x) - 1.0) + 0.37 * (x - 1.0);
+    const bool last = x <= 1.0 || r >= nx;   // taller bands only add rows per wave from here on
+    // more than 3.75 waves per SIMD are not considered: one block partial per wave, and the callers' partial buffers
+    // (CGLS: 4096 doubles) are sized for that
+    if ((x <= 3.75 || last) && rows * g < best) {
+      best = rows * g;
+      rpb = r;
+    }
+    if (last) break;
+  }
   static const int rpb_env = getenv("TRK_BLUR_RPB") ? atoi(getenv("TRK_BLUR_RPB")) : 0;   // tuning knob (rows per band)
   if (rpb_env > 0) rpb = rpb_env;
   *spans_x = sx;
@@ -541,34 +559,6 @@ inline bool slide_shape_ok(const BlurImpl* im) {
          im->ny >= 8 && (int64_t)im->nx * im->ny < ((int64_t)1 << 30);
 }
 
-// 9x9 exists with prefetch depth 6 (band heights 18 j - 8) and depth 9 (9 j - 8): the finer quantisation is used when it fills
-// the chip better — estimated time = wave generations x rows per wave; the depth-9 loop is ~4 % slower per row at equal shape
-// (4096^2: 26.8 vs 25.8 us), so it must win by more than that.  Measured: 2048^2 12.1 -> 9.4 us, 3072^2 18.7 -> 16.6 us.
-inline bool slide_pick_depth9(const BlurImpl* im, int batch, int* spans_x, int* nbands, int* rpb) {
-  static const bool rpb_forced = getenv("TRK_BLUR_RPB") != nullptr || getenv("TRK_BLUR_NO_D9") != nullptr;
-  if (im->kh != 9 || rpb_forced) return false;
-  int sx9, nb9, rpb9;
-  slide_grid(im->nx, im->ny, batch, im->kh, 9, &sx9, &nb9, &rpb9);
-  // one-row bands (j = 1) are never worth it: on a small image they only multiply the waves and the block partials every
-  // consumer sums (512^2 CGLS: 36.1 k it/s with 1-row bands, 41.2 k with the 10-row bands of the depth-6 form)
-  if (rpb9 < 10) {
-    rpb9 = 10;
-    nb9 = ceil_div(im->nx, rpb9);
-  }
-  const int64_t slots = (int64_t)4 * cu_count();
-  auto est = [&](int sx, int nb, int r) {
-    const int64_t waves = (int64_t)sx * nb * (batch > 0 ? batch : 1);
-    return (double)((waves + slots - 1) / slots) * (double)(r + im->kh - 1);
-  };
-  if (est(sx9, nb9, rpb9) * 1.07 < est(*spans_x, *nbands, *rpb)) {
-    *spans_x = sx9;
-    *nbands = nb9;
-    *rpb = rpb9;
-    return true;
-  }
-  return false;
-}
-
 // y = A (x1 + cb * x2), comb written out, sum(y^2) as raw partials (CGLS fast path; 9x9-class separable PSFs only)
 int blur_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, double sign, ScalarSrc num, ScalarSrc den,
                      float* comb, float* y, double* partials, int cap, int* n_partials, hipStream_t s) {
@@ -577,9 +567,8 @@ int blur_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, doubl
     return fail(TRK_EUNSUPPORTED, "blur2d fused apply: needs a separable odd PSF <= 9x9, ny %% 4 == 0, 16-byte aligned buffers");
   if (comb == x1 || comb == x2) return fail(TRK_EINVAL, "blur2d fused apply: comb must not alias an input (halo rows are shared)");
   int spans_x, nbands, rpb;
-  const int Usel = (im->kh == 9) ? 18 : (im->kh == 7) ? 7 : (im->kh == 5) ? 5 : 6;
+  const int Usel = (im->kh == 9) ? 9 : (im->kh == 7) ? 7 : (im->kh == 5) ? 5 : 6;      // lcm(KH, D) of the instantiations below
   slide_grid(im->nx, im->ny, 1, im->kh, Usel, &spans_x, &nbands, &rpb);
-  const bool depth9 = slide_pick_depth9(im, 1, &spans_x, &nbands, &rpb);
   const int nblk = spans_x * nbands;
   if (nblk > cap) return fail(TRK_EINVAL, "blur2d fused apply: partial buffer holds %d doubles, %d needed", cap, nblk);
   *n_partials = nblk;
@@ -596,8 +585,7 @@ int blur_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, doubl
     case 5: return launch_slide<5, 5>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
     case 7: return launch_slide<7, 7>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
     default:
-      return depth9 ? launch_slide<9, 9>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz)
-                    : launch_slide<9, 6>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
+      return launch_slide<9, 9>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
   }
 }
 
@@ -610,9 +598,8 @@ int blur_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_
                         (batch == 1 || ((ldx & 3) == 0 && (ldy & 3) == 0));
   if (slide_ok) {
     int spans_x, nbands, rpb;
-    const int Usel = (im->kh == 9) ? 18 : (im->kh == 7) ? 7 : (im->kh == 5) ? 5 : 6;   // lcm(KH, D) of the instantiations below
+    const int Usel = (im->kh == 9) ? 9 : (im->kh == 7) ? 7 : (im->kh == 5) ? 5 : 6;   // lcm(KH, D) of the instantiations below
     slide_grid(im->nx, im->ny, batch, im->kh, Usel, &spans_x, &nbands, &rpb);
-    const bool depth9 = slide_pick_depth9(im, batch, &spans_x, &nbands, &rpb);
     nblk = spans_x * nbands;
     if (sumsq)
       if (int rc = scratch_doubles(s, (size_t)nblk * batch, &part)) return rc;
@@ -629,8 +616,7 @@ int blur_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_
       case 5: rc = launch_slide<5, 5>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1); break;
       case 7: rc = launch_slide<7, 7>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1); break;
       default:
-        rc = depth9 ? launch_slide<9, 9>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1)
-                    : launch_slide<9, 6>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1);
+        rc = launch_slide<9, 9>(im, tr, x, ldx, y, ldy, batch, part, spans_x, nbands, rpb, s, ev0, ev1);
         break;
     }
     if (rc) return rc;
