@@ -517,15 +517,18 @@ int launch_slide(const BlurImpl* im, int tr, const float* x, int64_t ldx, float*
 }
 
 // Bands for the sliding kernel.  A wave processes roundup(rows_per_band + KH-1, U) staged rows, so band heights of the
-// form j*U - (KH-1) waste nothing.  Which j: a sweep over band heights at 2560^2 ... 5120^2 (tools/blur_band_sweep.sh,
-// DESIGN.md §4.1) shows the time following  staged rows per wave x G(x),  x = waves / (4 x CUs) the waves per SIMD:
+// form j*U - (KH-1) waste nothing.  Which j: band-height sweeps INSIDE the CGLS loop at 3072^2 ... 5120^2
+// (tools/bench_rpb_sweep.sh) show the kernel time following  staged rows per wave x G(x),
+// x = waves / (4 x CUs) the waves per SIMD:
 //     G = 1                                        x <= 1   (fewer waves than SIMDs do not help: the rows per wave rule)
-//     G = 1 + 0.3 (ceil(x) - 1) + 0.37 (x - 1)     x >  1   (a second wave on a SIMD costs 1.3x at once, then little
-//                                                            more until the next SIMD-filling multiple)
-// so the best grids fill the SIMDs once (x just below 1) or nearly twice (x = 1.7 .. 1.9) and the worst sit just above a
-// multiple (4096^2, 9x9: 37-row bands, x = 1.73: 22.6 us; 64-row bands, x = 1: 23.5 us; 46-row bands, x = 1.41: 24.5 us).
-// The candidate with the smallest predicted time is taken; bands shorter than KH + 1 rows are never used (on a small
-// image they only multiply the waves and the block partials every consumer sums).
+//     G = 0.6 + 0.45 x + 0.5 (ceil(x) - 1)         x >  1   (a second wave on a SIMD costs ~1.6x at once: both stream
+//                                                            from HBM, neither hides the other's latency)
+// i.e. the best grid is the shortest band that still gives every SIMD at most one wave, and the worst sit just above a
+// multiple (4096^2, 9x9, forward matvec inside CGLS: 64-row bands, x = 1: 24.9 us; 55-row bands, x = 1.17: 34.0 us;
+// 37-row bands, x = 1.73: 28.3 us).  Back-to-back launches on the same two buffers, which the 256 MB memory-side cache
+// then holds, behave differently (37-row bands 22.5 us, 64-row bands 23.5 us): the rule follows the solver loop.
+// Bands shorter than KH + 1 rows are never used (on a small image they only multiply the waves and the block
+// partials every consumer sums).
 inline void slide_grid(int nx, int ny, int batch, int kh, int U, int* spans_x, int* nbands, int* rows_per_band) {
   const int sx = ceil_div(ny, SPAN);
   const double slots = 4.0 * cu_count();
@@ -537,7 +540,7 @@ inline void slide_grid(int nx, int ny, int batch, int kh, int U, int* spans_x, i
   for (;; rows += U) {
     const int r = rows - (kh - 1);
     const double x = (double)sx * ceil_div(nx, r) * nb / slots;
-    const double g = x <= 1.0 ? 1.0 : 1.0 + 0.3 * (ceil(x) - 1.0) + 0.37 * (x - 1.0);
+    const double g = x <= 1.0 ? 1.0 : 0.6 + 0.45 * x + 0.5 * (ceil(x) - 1.0);
     const bool last = x <= 1.0 || r >= nx;   // taller bands only add rows per wave from here on
     // more than 3.75 waves per SIMD are not considered: one block partial per wave, and the callers' partial buffers
     // (CGLS: 4096 doubles) are sized for that
