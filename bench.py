@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--size", type=int, default=4096, help="image side of the blur workload")
     ap.add_argument("--workload", default="blur_cgls", choices=["blur_cgls"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--unfused", action="store_true", help="force the generic seven-launch CGLS iteration")
+    ap.add_argument("--unfused", action="store_true", help="force the generic (unfused-operand) CGLS iteration")
     ap.add_argument("--fused", action="store_true", help="force the fused three-launch CGLS iteration")
     ap.add_argument("--no-extras", action="store_true", help="skip the C4 (MMGKS) and C5 (sharded dynamic tomo) legs")
     ap.add_argument("--cpu-iters", type=int, default=8, help="CPU-baseline sample: CGLS iterations timed on the host")
@@ -194,7 +194,7 @@ def run_blur_cgls(args, rank, world):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"blur{N}_cgls", "image": f"{N}x{N} fp32", "psf": "Gaussian 9x9 sigma=(3,3), reflect",
                       "solver": "CGLS (trips.solvers.CGLS semantics, tol=0)", "noise": "1% Gaussian",
-                      "iteration": "fused: 3 launches (blur+p-update, x-update, blur^T+r-update)" if Run is CGLSRunFused else "generic: 7 launches",
+                      "iteration": "fused: 3 launches (blur+p-update, x-update, blur^T+r-update)" if Run is CGLSRunFused else ("4 launches (blur, x/r update, blur^T, p update; consumers add the block partials)" if getattr(run, "raw", False) else "generic: 6 launches"),
                       "parallelism": "replicas" if world > 1 else "single"},
            "roofline": roofline,
            "extra": {"relError_after_timed_iters": float(torch.linalg.norm(run.x_cur - x_true) / torch.linalg.norm(x_true)),

@@ -160,6 +160,16 @@ int trk_cgls_update_xr(int64_t n, int64_t m, const double* gamma_dev, const doub
 int trk_cgls_update_xr_deferred(int64_t n, int64_t m, const double* gamma_dev, const double* delta_dev, const float* x,
                                 const float* p, float* x_new, float* r, const float* w, const float* x_true,
                                 double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
+/* The same with gamma / delta given as scalar sources (a finished scalar, n = 1, or n block partials of the kernel that
+ * produced them — see the fused fast path below); block 0 stores the finished delta to *publish_delta (may be NULL). */
+int trk_cgls_update_xr_src(int64_t n, int64_t m, const double* gamma, int gamma_n, const double* delta, int delta_n,
+                           const float* x, const float* p, float* x_new, float* r, const float* w, const float* x_true,
+                           double* publish_delta, double* norm_partials, int capacity_blocks, int* n_blocks,
+                           trk_stream stream);
+/* p = t + (S(gamma_new) / *gamma_old) p  (CGLS.py:72; same arithmetic as trk_axpby) with gamma_new a scalar source; block 0
+ * stores the finished gamma_new to *publish_gamma (may be NULL). */
+int trk_cgls_p_update(int64_t n, const float* t, float* p, const double* gamma_new, int gamma_new_n, const double* gamma_old,
+                      double* publish_gamma, trk_stream stream);
 
 /* ---------------------------------------------------------------- fused CGLS fast path --- */
 /* For operators whose kernel can combine two inputs on load (the blur): one CGLS iteration becomes three launches with no
@@ -168,7 +178,8 @@ int trk_cgls_update_xr_deferred(int64_t n, int64_t m, const double* gamma_dev, c
  *   y = Op(x1 + cb*x2), cb = sign * S(num)/S(den); the combined operand is also written to comb_out (must not alias
  *   x1/x2); sum(y*y) is left as *n_partials raw block partials in ysq_partials (capacity given).
  *     forward : x1 = t, x2 = p_old, cb = +gamma_k/gamma_{k-1}  -> comb = p_new (CGLS.py:72), y = w = A p_new (:60), ||w||^2 (:61)
- *     adjoint : x1 = r_old, x2 = w, cb = -gamma/delta          -> comb = r_new (:67),       y = t = A^T r_new (:68), ||t||^2 (:70) */
+ *     adjoint : x1 = r_old, x2 = w, cb = -gamma/delta          -> comb = r_new (:67),       y = t = A^T r_new (:68), ||t||^2 (:70)
+ *   x2 = NULL: y = Op(x1) by the plain one-operand kernel (sign, num, den, comb_out ignored), sum(y*y) still left raw. */
 int trk_op_fused_caps(const trk_op* op, int* can_fuse);
 int trk_op_apply_fused(trk_op* op, int transpose, const float* x1, const float* x2, double sign, const double* num,
                        int num_n, const double* den, int den_n, float* comb_out, float* y, double* ysq_partials,
@@ -212,10 +223,13 @@ int trk_host_dp_newton(const double* sv, const double* bhat, int n, double targe
  *   S[0] = gamma_0 = ||t_0||^2 (set up by the caller, with r, t, p = t);  S[5k .. 5k+4] = [delta_k, gamma_k, (norms)]
  *   X: iterate slots, row stride x_ld; iteration k writes slot k-1 (keep_history) or (k-1) & 1;  x_prev = x_{k_first-1}
  *   NP: >= 3 * np_capacity_blocks * (iterations so far) doubles of norm partials (trk_finalize_batched sums them);
- *   *n_np_inout: partial blocks per iteration (0 before the first iteration; constant afterwards). */
+ *   *n_np_inout: partial blocks per iteration (0 before the first iteration; constant afterwards).
+ *   PG, PD (may be NULL): `pcap` doubles each.  Given them and an operator with a fused apply (trk_op_fused_caps), the
+ *   operator leaves ||t||^2 / ||w||^2 as raw block partials there (trk_op_apply_fused with x2 = NULL) and the consumers
+ *   (trk_cgls_update_xr_src, trk_cgls_p_update) add them up: four launches per iteration instead of six. */
 int trk_cgls_iterate(trk_op* A, int k_first, int n_iters, float* p, float* r, float* t, float* w, float* X, int64_t x_ld,
                      int keep_history, const float* x_prev, const float* x_true, double* S, double* NP,
-                     int np_capacity_blocks, int* n_np_inout, trk_stream stream);
+                     int np_capacity_blocks, int* n_np_inout, double* PG, double* PD, int pcap, trk_stream stream);
 /* The same for operators with a fused apply (trk_op_fused_caps): three launches per iteration.  P, R: ping-pong pairs
  * [2][p_ld], [2][r_ld] (iteration k reads index (k-1) & 1, writes k & 1); PG / PD: gamma / delta block partials with
  * `pcap` doubles each; *n_g_inout: number of valid gamma partials in PG (set by the caller's r0/t0 setup). */

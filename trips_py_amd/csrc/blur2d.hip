@@ -566,9 +566,10 @@ inline bool slide_shape_ok(const BlurImpl* im) {
 int blur_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, double sign, ScalarSrc num, ScalarSrc den,
                      float* comb, float* y, double* partials, int cap, int* n_partials, hipStream_t s) {
   auto* im = static_cast<BlurImpl*>(op->impl);
-  if (!slide_shape_ok(im) || !aligned16(x1) || !aligned16(x2) || !aligned16(comb) || !aligned16(y))
+  if (!slide_shape_ok(im) || !aligned16(x1) || !aligned16(y) || (x2 && (!aligned16(x2) || !aligned16(comb))))
     return fail(TRK_EUNSUPPORTED, "blur2d fused apply: needs a separable odd PSF <= 9x9, ny %% 4 == 0, 16-byte aligned buffers");
-  if (comb == x1 || comb == x2) return fail(TRK_EINVAL, "blur2d fused apply: comb must not alias an input (halo rows are shared)");
+  if (x2 && (comb == x1 || comb == x2))
+    return fail(TRK_EINVAL, "blur2d fused apply: comb must not alias an input (halo rows are shared)");
   int spans_x, nbands, rpb;
   const int Usel = (im->kh == 9) ? 9 : (im->kh == 7) ? 7 : (im->kh == 5) ? 5 : 6;      // lcm(KH, D) of the instantiations below
   slide_grid(im->nx, im->ny, 1, im->kh, Usel, &spans_x, &nbands, &rpb);
@@ -576,6 +577,7 @@ int blur_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, doubl
   if (nblk > cap) return fail(TRK_EINVAL, "blur2d fused apply: partial buffer holds %d doubles, %d needed", cap, nblk);
   *n_partials = nblk;
   const SlideFuse fz{x2, comb, sign, num, den};
+  const SlideFuse* fzp = x2 ? &fz : nullptr;      // x2 == NULL: the plain one-operand kernel, partials left raw
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   if (trk_timer* t = op->timer)
     if ((op->timer_which == 2 || op->timer_which == tr) && t->used < t->cap) {
@@ -584,11 +586,11 @@ int blur_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, doubl
       ++t->used;
     }
   switch (im->kh) {
-    case 3: return launch_slide<3, 6>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
-    case 5: return launch_slide<5, 5>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
-    case 7: return launch_slide<7, 7>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
+    case 3: return launch_slide<3, 6>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, fzp);
+    case 5: return launch_slide<5, 5>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, fzp);
+    case 7: return launch_slide<7, 7>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, fzp);
     default:
-      return launch_slide<9, 9>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, &fz);
+      return launch_slide<9, 9>(im, tr, x1, 0, y, 0, 1, partials, spans_x, nbands, rpb, s, ev0, ev1, fzp);
   }
 }
 

@@ -13,17 +13,35 @@ extern "C" {
 
 int trk_cgls_iterate(trk_op* A, int k_first, int n_iters, float* p, float* r, float* t, float* w, float* X, int64_t x_ld,
                      int keep_history, const float* x_prev, const float* x_true, double* S, double* NP,
-                     int np_capacity_blocks, int* n_np_inout, trk_stream stream) {
+                     int np_capacity_blocks, int* n_np_inout, double* PG, double* PD, int pcap, trk_stream stream) {
   TRK_REQUIRE(A && p && r && t && w && X && x_prev && S && NP && n_np_inout, "trk_cgls_iterate: NULL argument");
   TRK_REQUIRE(k_first >= 1 && n_iters >= 0, "trk_cgls_iterate: need k_first >= 1, n_iters >= 0");
   const int64_t m = A->rows, n = A->cols;
   int n_np = *n_np_inout;
+  // raw-partials form: the operator leaves ||w||^2, ||t||^2 as block partials and the consumers add them up —
+  // four launches per iteration instead of six (no reduction-finalize launches)
+  const bool raw = PG && PD && pcap > 0 && A->apply_fused;
   for (int k = k_first; k < k_first + n_iters; ++k) {
     double* row = S + 5 * (int64_t)k;                       // [delta, gamma, ||x||^2, ||dx||^2, ||x-xt||^2]
     double *delta = row, *gamma = row + 1;
     const double* gamma_old = (k == 1) ? S : row - 4;
     float* x_new = X + (int64_t)(keep_history ? (k - 1) : ((k - 1) & 1)) * x_ld;
-    int rc = trk_op_apply(A, 0, p, 0, w, 0, 1, delta, stream);                                  // w = A p, ||w||^2   (:60-61)
+    int rc;
+    if (raw) {
+      int n_d = 0, n_g = 0;
+      rc = trk_op_apply_fused(A, 0, p, nullptr, 0.0, nullptr, 0, nullptr, 0, nullptr, w, PD, pcap, &n_d, stream);
+      if (rc) return rc;
+      rc = trk_cgls_update_xr_src(n, m, gamma_old, 1, PD, n_d, x_prev, p, x_new, r, w, x_true, delta,
+                                  NP + 3 * (int64_t)n_np * (k - 1), np_capacity_blocks, &n_np, stream);
+      if (rc) return rc;
+      rc = trk_op_apply_fused(A, 1, r, nullptr, 0.0, nullptr, 0, nullptr, 0, nullptr, t, PG, pcap, &n_g, stream);
+      if (rc) return rc;
+      rc = trk_cgls_p_update(n, t, p, PG, n_g, gamma_old, gamma, stream);
+      if (rc) return rc;
+      x_prev = x_new;
+      continue;
+    }
+    rc = trk_op_apply(A, 0, p, 0, w, 0, 1, delta, stream);                                      // w = A p, ||w||^2   (:60-61)
     if (rc) return rc;
     rc = trk_cgls_update_xr_deferred(n, m, gamma_old, delta, x_prev, p, x_new, r, w, x_true,      // x, r updates   (:64-67)
                                      NP + 3 * (int64_t)n_np * (k - 1), np_capacity_blocks, &n_np, stream);

@@ -209,7 +209,7 @@ int trk_op_fused_caps(const trk_op* op, int* can_fuse) {
 int trk_op_apply_fused(trk_op* op, int transpose, const float* x1, const float* x2, double sign, const double* num,
                        int num_n, const double* den, int den_n, float* comb_out, float* y, double* ysq_partials,
                        int capacity, int* n_partials, trk_stream stream) {
-  TRK_REQUIRE(op && x1 && x2 && comb_out && y && ysq_partials && n_partials, "trk_op_apply_fused: NULL argument");
+  TRK_REQUIRE(op && x1 && y && ysq_partials && n_partials && (!x2 || comb_out), "trk_op_apply_fused: NULL argument");
   TRK_REQUIRE(num_n >= 0 && den_n >= 0 && (num_n == 0 || num) && (den_n == 0 || den), "trk_op_apply_fused: bad scalar source");
   if (!op->apply_fused) return fail(TRK_EUNSUPPORTED, "trk_op_apply_fused: this operator has no fused form");
   return op->apply_fused(op, transpose ? 1 : 0, x1, x2, sign, ScalarSrc{num, num_n}, ScalarSrc{den, den_n}, comb_out, y,

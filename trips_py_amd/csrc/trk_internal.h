@@ -101,8 +101,28 @@ __device__ __forceinline__ double wave_sum_all(double v) {   // total in every l
 __device__ __forceinline__ double scalar_from_wave(const ScalarSrc s, int lane) {
   if (s.n == 0) return 1.0;
   if (s.n == 1) return *s.p;
-  double v = 0.0;
-  for (int i = lane; i < s.n; i += 64) v += s.p[i];
+  // eight independent accumulators: the loads of a round are in flight together (the partials were written by the
+  // previous kernel, possibly through another XCD's L2 — each one is a trip to the memory side)
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, a4 = 0.0, a5 = 0.0, a6 = 0.0, a7 = 0.0;
+  int i = lane;
+  for (; i + 448 < s.n; i += 512) {
+    a0 += s.p[i];
+    a1 += s.p[i + 64];
+    a2 += s.p[i + 128];
+    a3 += s.p[i + 192];
+    a4 += s.p[i + 256];
+    a5 += s.p[i + 320];
+    a6 += s.p[i + 384];
+    a7 += s.p[i + 448];
+  }
+  if (i < s.n) a0 += s.p[i];
+  if (i + 64 < s.n) a1 += s.p[i + 64];
+  if (i + 128 < s.n) a2 += s.p[i + 128];
+  if (i + 192 < s.n) a3 += s.p[i + 192];
+  if (i + 256 < s.n) a4 += s.p[i + 256];
+  if (i + 320 < s.n) a5 += s.p[i + 320];
+  if (i + 384 < s.n) a6 += s.p[i + 384];
+  double v = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
   // fixed tree: shfl_down order so that the association does not depend on the caller
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);

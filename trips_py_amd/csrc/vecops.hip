@@ -188,11 +188,26 @@ __global__ __launch_bounds__(NT) void k_mm_weights(int64_t n, const float* x, co
 // ------------------------------------------------------------------ fused CGLS update (CGLS.py:64-67,76,79)
 // partials layout: [block][3] = ||x_new||^2, ||step*p||^2, ||x_new - x_true||^2
 template <bool HAS_XT, bool VEC>
-__global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, const double* gamma, const double* delta,
+__global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, ScalarSrc gamma, ScalarSrc delta,
                                                     const float* x, const float* p, float* x_new, float* r,
-                                                    const float* w, const float* x_true, double* __restrict__ partials) {
+                                                    const float* w, const float* x_true, double* __restrict__ partials,
+                                                    double* pub_delta) {
   __shared__ double lds[NT / 64];
-  const float step = (float)(*gamma / *delta);
+  __shared__ double bc;
+  float step;
+  if (gamma.n == 1 && delta.n == 1) {                // finished scalars (grid-uniform)
+    step = (float)(*gamma.p / *delta.p);
+  } else {                                           // block partials of the producing kernel: one wave sums them
+    if (threadIdx.x < 64) {
+      const double g = scalar_from_wave(gamma, threadIdx.x), d = scalar_from_wave(delta, threadIdx.x);
+      if (threadIdx.x == 0) {
+        bc = g / d;
+        if (blockIdx.x == 0 && pub_delta) *pub_delta = d;
+      }
+    }
+    __syncthreads();
+    step = (float)bc;
+  }
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
   int64_t ntail = 0, mtail = 0;
@@ -243,6 +258,40 @@ __global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, const 
     partials[blockIdx.x * 3 + 1] = s1;
     partials[blockIdx.x * 3 + 2] = HAS_XT ? s2 : 0.0;
   }
+}
+
+// ------------------------------------------------------------------ CGLS direction update (CGLS.py:72)
+// p = t + (gamma_new / gamma_old) p with gamma_new possibly still the block partials of the adjoint kernel that produced
+// t; block 0 publishes the finished gamma_new.  Same arithmetic as trk_axpby(1, t, gamma_new/gamma_old, p).
+template <bool VEC>
+__global__ __launch_bounds__(NT) void k_cgls_p_update(int64_t n, const float* __restrict__ t, float* p, ScalarSrc gnew,
+                                                      const double* gold, double* pub_gamma) {
+  __shared__ double bc;
+  if (threadIdx.x < 64) {
+    const double g = scalar_from_wave(gnew, threadIdx.x);
+    if (threadIdx.x == 0) {
+      bc = g / *gold;
+      if (blockIdx.x == 0 && pub_gamma) *pub_gamma = g;
+    }
+  }
+  __syncthreads();
+  const float b = (float)bc;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      const float4 v = ld4(t, i), w = ld4(p, i);
+      float4 o;
+      o.x = fmaf(1.f, v.x, b * w.x);
+      o.y = fmaf(1.f, v.y, b * w.y);
+      o.z = fmaf(1.f, v.z, b * w.z);
+      o.w = fmaf(1.f, v.w, b * w.w);
+      st4(p, i, o);
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) p[i] = fmaf(1.f, t[i], b * p[i]);
 }
 
 // ------------------------------------------------------------------ CGLS x-update of the fused fast path
@@ -1042,7 +1091,7 @@ int trk_cgls_update_xr(int64_t n, int64_t m, const double* gamma, const double* 
   if (int rc = scratch_doubles(s, (size_t)grid * 3, &part)) return rc;
   const bool vec = aligned16(x) && aligned16(p) && aligned16(x_new) && aligned16(r) && aligned16(w) &&
                    (!x_true || aligned16(x_true));
-#define CU(XT, VC) hipLaunchKernelGGL((k_cgls_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, gamma, delta, x, p, x_new, r, w, x_true, part)
+#define CU(XT, VC) hipLaunchKernelGGL((k_cgls_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, ScalarSrc{gamma, 1}, ScalarSrc{delta, 1}, x, p, x_new, r, w, x_true, part, (double*)nullptr)
   if (x_true) { if (vec) CU(true, true); else CU(true, false); }
   else        { if (vec) CU(false, true); else CU(false, false); }
 #undef CU
@@ -1050,21 +1099,45 @@ int trk_cgls_update_xr(int64_t n, int64_t m, const double* gamma, const double* 
   return finalize_sums(part, grid, 3, 3, sums, s);
 }
 
-int trk_cgls_update_xr_deferred(int64_t n, int64_t m, const double* gamma, const double* delta, const float* x,
-                                const float* p, float* x_new, float* r, const float* w, const float* x_true,
-                                double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream st) {
-  TRK_REQUIRE(gamma && delta && x && p && x_new && r && w && norm_partials && n_blocks, "trk_cgls_update_xr_deferred: NULL argument");
-  TRK_REQUIRE(n >= 0 && m >= 0, "trk_cgls_update_xr_deferred: negative size");
+int trk_cgls_update_xr_src(int64_t n, int64_t m, const double* gamma, int gamma_n, const double* delta, int delta_n,
+                           const float* x, const float* p, float* x_new, float* r, const float* w, const float* x_true,
+                           double* publish_delta, double* norm_partials, int capacity_blocks, int* n_blocks,
+                           trk_stream st) {
+  TRK_REQUIRE(gamma && delta && gamma_n >= 1 && delta_n >= 1 && x && p && x_new && r && w && norm_partials && n_blocks,
+              "trk_cgls_update_xr_src: NULL argument");
+  TRK_REQUIRE(n >= 0 && m >= 0, "trk_cgls_update_xr_src: negative size");
   hipStream_t s = (hipStream_t)st;
   const int grid = stream_grid(n > m ? n : m);
-  TRK_REQUIRE(grid <= capacity_blocks, "trk_cgls_update_xr_deferred: partial buffer too small (%d blocks needed)", grid);
+  TRK_REQUIRE(grid <= capacity_blocks, "trk_cgls_update_xr_src: partial buffer too small (%d blocks needed)", grid);
   *n_blocks = grid;
   const bool vec = aligned16(x) && aligned16(p) && aligned16(x_new) && aligned16(r) && aligned16(w) &&
                    (!x_true || aligned16(x_true));
-#define CU(XT, VC) hipLaunchKernelGGL((k_cgls_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, gamma, delta, x, p, x_new, r, w, x_true, norm_partials)
+  const ScalarSrc g{gamma, gamma_n}, d{delta, delta_n};
+#define CU(XT, VC) hipLaunchKernelGGL((k_cgls_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, g, d, x, p, x_new, r, w, x_true, norm_partials, publish_delta)
   if (x_true) { if (vec) CU(true, true); else CU(true, false); }
   else        { if (vec) CU(false, true); else CU(false, false); }
 #undef CU
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_cgls_update_xr_deferred(int64_t n, int64_t m, const double* gamma, const double* delta, const float* x,
+                                const float* p, float* x_new, float* r, const float* w, const float* x_true,
+                                double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream st) {
+  return trk_cgls_update_xr_src(n, m, gamma, 1, delta, 1, x, p, x_new, r, w, x_true, nullptr, norm_partials,
+                                capacity_blocks, n_blocks, st);
+}
+
+int trk_cgls_p_update(int64_t n, const float* t, float* p, const double* gamma_new, int gamma_new_n,
+                      const double* gamma_old, double* publish_gamma, trk_stream st) {
+  TRK_REQUIRE(t && p && gamma_new && gamma_new_n >= 1 && gamma_old && n >= 0, "trk_cgls_p_update: bad argument");
+  const int grid = stream_grid(n);
+  const ScalarSrc g{gamma_new, gamma_new_n};
+  hipStream_t s = (hipStream_t)st;
+  if (aligned16(t) && aligned16(p))
+    hipLaunchKernelGGL((k_cgls_p_update<true>), dim3(grid), dim3(NT), 0, s, n, t, p, g, gamma_old, publish_gamma);
+  else
+    hipLaunchKernelGGL((k_cgls_p_update<false>), dim3(grid), dim3(NT), 0, s, n, t, p, g, gamma_old, publish_gamma);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }

@@ -246,12 +246,28 @@ class HipEngine:
         return bool(can.value)
 
     def op_apply_fused(self, handle, transpose, x1, x2, sign, num, num_n, den, den_n, comb, y, partials, capacity):
+        """x2 = None: the plain one-operand apply with ||y||^2 left as raw block partials."""
         n = ctypes.c_int(0)
-        rc = self.lib.trk_op_apply_fused(handle, int(bool(transpose)), x1.data_ptr(), x2.data_ptr(), float(sign), _ptr(num),
-                                         int(num_n), _ptr(den), int(den_n), comb.data_ptr(), y.data_ptr(), _ptr(partials),
+        rc = self.lib.trk_op_apply_fused(handle, int(bool(transpose)), x1.data_ptr(), None if x2 is None else x2.data_ptr(),
+                                         float(sign), _ptr(num), int(num_n), _ptr(den), int(den_n),
+                                         None if comb is None else comb.data_ptr(), y.data_ptr(), _ptr(partials),
                                          int(capacity), ctypes.byref(n), self.stream())
         _lib.check(rc, "trk_op_apply_fused")
         return n.value
+
+    def cgls_update_src(self, gamma, gamma_n, delta, delta_n, x, p, x_new, r, w, x_true, pub_delta, partials, capacity):
+        n = ctypes.c_int(0)
+        rc = self.lib.trk_cgls_update_xr_src(x.numel(), r.numel(), _ptr(gamma), int(gamma_n), _ptr(delta), int(delta_n),
+                                             x.data_ptr(), p.data_ptr(), x_new.data_ptr(), r.data_ptr(), w.data_ptr(),
+                                             None if x_true is None else x_true.data_ptr(), _ptr(pub_delta), _ptr(partials),
+                                             int(capacity), ctypes.byref(n), self.stream())
+        _lib.check(rc, "trk_cgls_update_xr_src")
+        return n.value
+
+    def cgls_p_update(self, t, p, gamma_new, gamma_new_n, gamma_old, pub_gamma):
+        rc = self.lib.trk_cgls_p_update(p.numel(), t.data_ptr(), p.data_ptr(), _ptr(gamma_new), int(gamma_new_n),
+                                        _ptr(gamma_old), _ptr(pub_gamma), self.stream())
+        _lib.check(rc, "trk_cgls_p_update")
 
     def cgls_x_update(self, gamma, gamma_n, delta, delta_n, x, p, x_new, x_true, pub_delta, pub_gamma, partials, capacity):
         n = ctypes.c_int(0)
@@ -262,13 +278,15 @@ class HipEngine:
         _lib.check(rc, "trk_cgls_x_update")
         return n.value
 
-    def cgls_iterate(self, handle, k_first, n_iters, p, r, t, w, X, keep, x_prev, x_true, S, NP, np_cap, n_np):
-        """n_iters generic CGLS iterations in one library call; returns the partial-block count."""
+    def cgls_iterate(self, handle, k_first, n_iters, p, r, t, w, X, keep, x_prev, x_true, S, NP, np_cap, n_np,
+                     PG=None, PD=None, pcap=0):
+        """n_iters generic CGLS iterations in one library call; returns the partial-block count.  PG / PD: buffers for the
+        operator's raw ||t||^2 / ||w||^2 block partials (four launches per iteration instead of six)."""
         c = ctypes.c_int(int(n_np))
         rc = self.lib.trk_cgls_iterate(handle, int(k_first), int(n_iters), p.data_ptr(), r.data_ptr(), t.data_ptr(),
                                        w.data_ptr(), X.data_ptr(), X.stride(0), int(bool(keep)), x_prev.data_ptr(),
                                        None if x_true is None else x_true.data_ptr(), _ptr(S), _ptr(NP), int(np_cap),
-                                       ctypes.byref(c), self.stream())
+                                       ctypes.byref(c), _ptr(PG), _ptr(PD), int(pcap), self.stream())
         _lib.check(rc, "trk_cgls_iterate")
         return c.value
 

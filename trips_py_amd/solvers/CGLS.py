@@ -18,6 +18,8 @@ class CGLSRun:
     """The CGLS recurrence as an object: `step()` enqueues one iteration (no host sync), `rows()` downloads the
     per-iteration scalars.  `CGLS()` below and bench.py both drive this one implementation."""
 
+    PCAP = 4096                            # room for an operator's raw block partials
+
     def __init__(self, A, b, x0, max_iter, x_true=None, history=True, defer_norms=False):
         self.A = A = as_operator(A)
         self.eng = eng = A.engine
@@ -37,6 +39,11 @@ class CGLSRun:
         self.defer = bool(defer_norms) and eng.world == 1 and hasattr(eng, "cgls_update_deferred")
         self.NP = eng.scalars(3 * 1024 * max_iter) if self.defer else None
         self.n_np = 0
+        # operators that can leave ||A p||^2 / ||A^T r||^2 as raw block partials (the blur): the consumers add them up and
+        # the two reduction-finalize launches of the iteration disappear (six launches -> four)
+        self.raw = (self.defer and hasattr(eng, "cgls_p_update") and hasattr(A, "_h") and eng.op_can_fuse(A._h))
+        self.PG = eng.scalars(self.PCAP) if self.raw else None
+        self.PD = eng.scalars(self.PCAP) if self.raw else None
         self._final = 0
         self.r, self.t, self.w, self.p = eng.empty(m), eng.empty(n), eng.empty(m), eng.empty(n)
         # scalar layout: S[0] = gamma_0 = ||t_0||^2 ; row k (1-based) at 5k: [delta, gamma, ||x||^2, ||dx||^2, ||x-xt||^2]
@@ -62,6 +69,14 @@ class CGLSRun:
         delta, gamma = S.ref(b), S.ref(b + 1)
         gamma_old = S.ref(0) if k == 1 else S.ref(b - 4)
         x_new = self.slot(k - 1)
+        if self.raw:
+            n_d = eng.op_apply_fused(A._h, False, self.p, None, 0.0, None, 0, None, 0, None, self.w, self.PD.ref(0), self.PCAP)
+            self.n_np = eng.cgls_update_src(gamma_old, 1, self.PD.ref(0), n_d, self.x_cur, self.p, x_new, self.r, self.w,
+                                            self.xt, delta, self.NP.ref(3 * self.n_np * (k - 1)), 1024)
+            n_g = eng.op_apply_fused(A._h, True, self.r, None, 0.0, None, 0, None, 0, None, self.t, self.PG.ref(0), self.PCAP)
+            eng.cgls_p_update(self.t, self.p, self.PG.ref(0), n_g, gamma_old, gamma)
+            self.x_cur = x_new
+            return
         A.apply(self.p, out=self.w, sumsq=delta)
         if self.dist:
             eng.allreduce(S, b, b + 1)
@@ -85,7 +100,9 @@ class CGLSRun:
         eng = self.eng
         if self.defer and not self.dist and hasattr(self.A, "_h") and hasattr(eng, "cgls_iterate"):
             self.n_np = eng.cgls_iterate(self.A._h, self.k + 1, n_steps, self.p, self.r, self.t, self.w, self.X, self.keep,
-                                         self.x_cur, self.xt, self.S.ref(0), self.NP.ref(0), 1024, self.n_np)
+                                         self.x_cur, self.xt, self.S.ref(0), self.NP.ref(0), 1024, self.n_np,
+                                         None if not self.raw else self.PG.ref(0), None if not self.raw else self.PD.ref(0),
+                                         self.PCAP if self.raw else 0)
             self.k += n_steps
             self.x_cur = self.slot(self.k - 1)
         else:
