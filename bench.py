@@ -145,7 +145,7 @@ def run_blur_cgls(args, rank, world):
     x0 = torch.zeros(n, dtype=torch.float32, device=eng.device)
 
     # the class trips_py_amd.solvers.CGLS itself picks for this operator (tol = 0, single rank per problem)
-    fused = CGLSRunFused.usable(A, eng) and not args.unfused and (args.fused or n <= CGLSRunFused.AUTO_MAX_N)
+    fused = CGLSRunFused.usable(A, eng) and not args.unfused and (args.fused or CGLSRunFused.auto(n))
     Run = CGLSRunFused if fused else CGLSRun
     # reference call without x_true (CGLS.py:16); norms deferred exactly as CGLS() does for tol = 0 on one rank
     run = Run(A, b, x0, W + K, x_true=None, history=False) if fused else \

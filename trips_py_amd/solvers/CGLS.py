@@ -134,10 +134,16 @@ class CGLSRunFused(CGLSRun):
     (nothing visits the host until the end)."""
 
     PCAP = 4096                            # room for the producers' block partials
-    # measured crossover (MI355X, 9x9 blur): the fused iteration wins up to 2048^2 (launch-bound: 27.5k vs 16.3k it/s at
-    # 1024^2, 17.4k vs 15.6k at 2048^2) and loses 5 % from 3072^2 up (the single-wave-per-SIMD blur kernel with two
-    # operands is latency-bound), so CGLS() picks it below this many unknowns unless told otherwise
-    AUTO_MAX_N = 6 * 2 ** 20
+    # measured (MI355X, 9x9 blur, iterations/s fused vs the four-launch generic form whose consumers add up the block
+    # partials): 512^2 36.3 k vs 40.2 k, 1024^2 28.3 k vs 30.0 k, 1536^2 21.9 k vs 24.2 k | 1792^2 21.5 k vs 20.8 k,
+    # 2048^2 18.7 k vs 18.1 k, 2560^2 14.7 k vs 13.9 k | 2816^2 11.9 k vs 12.3 k, 3072^2 10.3 k vs 10.7 k, 4096^2 6.2 k vs
+    # 6.9 k: the two-operand blur kernel pays only in the middle range, so CGLS() picks it there unless told otherwise
+    AUTO_MIN_N = 3 * 2 ** 20
+    AUTO_MAX_N = 7 * 2 ** 20
+
+    @classmethod
+    def auto(cls, n):
+        return cls.AUTO_MIN_N <= n <= cls.AUTO_MAX_N
 
     @staticmethod
     def usable(A, eng):
@@ -242,7 +248,7 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
     sync_each = (tol != 0)
     want = kwargs.get("fused", None)          # None: automatic by size; True / False: forced
     fused = (not sync_each) and CGLSRunFused.usable(A, A.engine) and \
-        (want if want is not None else A.shape[1] <= CGLSRunFused.AUTO_MAX_N)
+        (want if want is not None else CGLSRunFused.auto(A.shape[1]))
     if fused:
         run = CGLSRunFused(A, b, x0, max_iter, x_true, kwargs.get("history", True))
     else:
