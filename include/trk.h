@@ -257,6 +257,11 @@ int trk_gemv_nt(const float* V, int64_t ld, int k, int64_t n, const double* h_de
  * (x = V@y: Hybrid_LSQR.py:105, Hybrid_GMRES.py:77, GKS.py:76; r -= V h: GKS.py:86-88) */
 int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y_dev, double a, const float* base,
                double s, float* out, double* sumsq_dev, trk_stream stream);
+/* out = V^T-combination sum_j y[j] V[j] as trk_gemv_n (a = 0, scale 1) with sum (out - ref)^2 left as *n_blocks raw block
+ * partials (the relError numerator ||x_k - x_true||^2 of the solvers' loops: summed once per solve with
+ * trk_finalize_batched instead of one reduction-finalize launch per iterate). */
+int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y, float* out, const float* ref,
+                   double* err_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
 /* G[a][b] = sum_i w[i]^2 * W[a][i] * W[b][i]  (k x k, fp64, full symmetric; w may be NULL), and, if
  * b1 != NULL, c1[a] = sum_i w[i]*W[a][i]*b1[i], c2[a] = sum_i w[i]^2*W[a][i]*b1[i].
  * Replaces the from-scratch economic QR of AV*wf / LV*wr (MMGKS.py:58-59,94-95; GKS.py:54-56): the host

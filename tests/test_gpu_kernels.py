@@ -245,3 +245,31 @@ def test_golub_kahan_unnormalised_storage_is_the_same_factorisation(shape):
     U1, U2 = g1.U.numpy(), g2.U.numpy() / np.concatenate(([g2.beta0], g2.betas))
     assert np.abs(V1 - V2).max() <= 2e-4 * np.abs(V1).max() and np.abs(U1 - U2).max() <= 2e-4 * np.abs(U1).max()
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,n", [(1, 1000), (5, 4099), (40, 65_536)])
+def test_gemv_n_err_partials(k, n):
+    """trk_gemv_n_err: x = V y and the raw partials of ||x - ref||^2, summed later by trk_finalize_batched."""
+    import torch
+    from trips_py_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(k)
+    V = eng.empty_basis(k + 1, n)
+    Vh = rng.standard_normal((k, n)).astype(np.float32)
+    V[:k].copy_(torch.from_numpy(Vh))
+    yh = rng.standard_normal(k)
+    Y = eng.scalars(k)
+    Y.set(0, yh)
+    ref = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(eng.device)
+    out, out2 = eng.empty(n), eng.empty(n)
+    EP, E = eng.scalars(2 * 1024), eng.scalars(2)
+    nb = eng.gemv_n_err(V, k, Y.ref(0), out, ref, EP.ref(0), 1024)
+    nb2 = eng.gemv_n_err(V, k, Y.ref(0), out, ref, EP.ref(nb), 1024)
+    assert nb == nb2 and 1 <= nb <= 1024
+    eng.finalize_batched(EP.ref(0), nb, 1, 2, E.ref(0), 1)
+    eng.gemv_n(V, k, Y.ref(0), out2)
+    assert torch.equal(out, out2)
+    want = float(np.sum((out.cpu().numpy().astype(np.float64) - ref.cpu().numpy().astype(np.float64)) ** 2))
+    got = E.host()
+    assert abs(got[0] - want) <= 1e-12 * want and got[0] == got[1]

@@ -19,16 +19,20 @@ constexpr int BIDIAG_MAX_K = 2048;   // the back substitution stages 3 k doubles
 
 // One workgroup of 64 lanes.  Square roots of the new columns' squared norms are taken in parallel; lane 0 then runs the
 // rotation recurrence — per column two square roots and two reciprocals (r^2 = abar^2 + mu^2 + beta^2 needs no second
-// hypot); a second small kernel does the back substitution (multiplications by the stored 1/rho).  With a `work` array the recurrence state
-// survives between calls: when mu is unchanged and one column was appended (the fixed-lambda hybrid iteration) only that
-// column is rotated, O(1) instead of O(k) expensive operations; any other change restarts from column 0.
+// hypot) — and the back substitution R y = phi (multiplications by the stored 1/rho) out of LDS, where the dependent chain
+// waits ~60 cycles per step instead of an L2 round trip.  With a `work` array the recurrence state survives between
+// calls: when mu is unchanged and one column was appended (the fixed-lambda hybrid iteration) only that column is rotated,
+// O(1) instead of O(k) expensive operations; any other change restarts from column 0.
 // work: [0] columns done, [1] mu, [2] abar, [3] phibar, then invrho[cap], theta[cap], phi[cap].
+// y_over_alpha: y_j / alpha_j is written (coefficients with respect to the un-normalised vectors alpha_j v_j).
 __global__ __launch_bounds__(64) void k_bidiag_tikhonov(const double* __restrict__ alpha_sq, int64_t a_stride,
                                                         const double* __restrict__ beta_sq, int64_t b_stride, int k,
                                                         double mu, const double* __restrict__ beta0_sq,
                                                         double* __restrict__ y, double* __restrict__ work, int cap,
-                                                        double* __restrict__ scratch) {
+                                                        double* __restrict__ scratch, int y_over_alpha) {
+  extern __shared__ double sm[];
   __shared__ double sh_start;
+  double *s_ir = sm, *s_th = sm + k, *s_ph = sm + 2 * k;
   double* st = work ? work : scratch;                          // scratch: same layout, always restarted
   double* invrho = st + 4;
   double* theta = invrho + cap;
@@ -39,63 +43,59 @@ __global__ __launch_bounds__(64) void k_bidiag_tikhonov(const double* __restrict
   }
   __syncthreads();
   const int j0 = (int)sh_start;
-  // al[j], be[j] of the columns to process, through y (as scratch) — y[j] is overwritten by the back substitution later
+  // al[j] of the columns to process, through y (as scratch) — y is written last
   double* al = y;                                               // al[j] for j in [j0, k)
   for (int j = j0 + (int)threadIdx.x; j < k; j += 64) al[j] = sqrt(alpha_sq[(int64_t)j * a_stride]);
-  __syncthreads();
-  if (threadIdx.x != 0) return;
-  const double mu2 = mu * mu;
-  double abar, phibar;
-  if (j0 == 0) {
-    abar = al[0];
-    phibar = sqrt(*beta0_sq);
-  } else {
-    abar = st[2];
-    phibar = st[3];
-    // st[2] holds -c2 of the previous last column (its alpha_{j0} factor was not known then)
-    abar *= al[j0];
-    theta[j0] *= al[j0];
-  }
-  for (int j = j0; j < k; ++j) {
-    const double bj2 = beta_sq[(int64_t)j * b_stride];         // B[j+1, j]^2
-    const double rhat2 = abar * abar + mu2, r2 = rhat2 + bj2;
-    const double rhat = sqrt(rhat2), r = sqrt(r2), bj = sqrt(bj2);
-    const double ir = 1.0 / r;
-    const double phihat = (abar / rhat) * phibar;
-    const double c2 = rhat * ir, s2 = bj * ir;
-    invrho[j] = ir;
-    phi[j] = c2 * phihat;
-    if (j + 1 < k) {
-      theta[j + 1] = s2 * al[j + 1];
-      abar = -c2 * al[j + 1];
-    } else {
-      theta[j + 1] = s2;                                        // completed with alpha_{j+1} on resume (cap >= k + 1)
-      abar = -c2;
-    }
-    phibar = s2 * phihat;
-  }
-  st[0] = (double)k;
-  st[1] = mu;
-  st[2] = abar;
-  st[3] = phibar;
-}
-
-// Back substitution R y = phi for the upper-bidiagonal R kept as (1/rho, theta): the three arrays are first copied to
-// LDS by all lanes (the dependent chain then waits ~60 cycles per step on LDS instead of an L2 round trip).
-__global__ __launch_bounds__(64) void k_bidiag_backsub(const double* __restrict__ st, int cap, int k, double* __restrict__ y,
-                                                        const double* __restrict__ alpha_sq, int64_t alpha_stride) {
-  extern __shared__ double sm[];
-  const double* invrho = st + 4;
-  const double* theta = invrho + cap;
-  const double* phi = theta + cap;
-  double *s_ir = sm, *s_th = sm + k, *s_ph = sm + 2 * k;
-  for (int j = threadIdx.x; j < k; j += 64) {
+  // columns rotated by earlier launches: their factors go to LDS for the back substitution
+  for (int j = threadIdx.x; j < j0; j += 64) {
     s_ir[j] = invrho[j];
     s_th[j] = theta[j];
     s_ph[j] = phi[j];
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    const double mu2 = mu * mu;
+    double abar, phibar;
+    if (j0 == 0) {
+      abar = al[0];
+      phibar = sqrt(*beta0_sq);
+    } else {
+      abar = st[2];
+      phibar = st[3];
+      // st[2] holds -c2 of the previous last column (its alpha_{j0} factor was not known then)
+      abar *= al[j0];
+      const double t = theta[j0] * al[j0];
+      theta[j0] = t;
+      s_th[j0] = t;
+    }
+    for (int j = j0; j < k; ++j) {
+      const double bj2 = beta_sq[(int64_t)j * b_stride];         // B[j+1, j]^2
+      const double rhat2 = abar * abar + mu2, r2 = rhat2 + bj2;
+      const double rhat = sqrt(rhat2), r = sqrt(r2), bj = sqrt(bj2);
+      const double ir = 1.0 / r;
+      const double phihat = (abar / rhat) * phibar;
+      const double c2 = rhat * ir, s2 = bj * ir;
+      invrho[j] = ir;
+      s_ir[j] = ir;
+      const double ph = c2 * phihat;
+      phi[j] = ph;
+      s_ph[j] = ph;
+      if (j + 1 < k) {
+        const double th = s2 * al[j + 1];
+        theta[j + 1] = th;
+        s_th[j + 1] = th;
+        abar = -c2 * al[j + 1];
+      } else {
+        theta[j + 1] = s2;                                        // completed with alpha_{j+1} on resume (cap >= k + 1)
+        abar = -c2;
+      }
+      phibar = s2 * phihat;
+    }
+    st[0] = (double)k;
+    st[1] = mu;
+    st[2] = abar;
+    st[3] = phibar;
+    // back substitution, the solution left in s_ph
     double yn = s_ph[k - 1] * s_ir[k - 1];
     s_ph[k - 1] = yn;
     for (int j = k - 2; j >= 0; --j) {
@@ -104,8 +104,8 @@ __global__ __launch_bounds__(64) void k_bidiag_backsub(const double* __restrict_
     }
   }
   __syncthreads();
-  // alpha_sq != NULL: coefficients with respect to the un-normalised vectors alpha_j v_j
-  for (int j = threadIdx.x; j < k; j += 64) y[j] = alpha_sq ? s_ph[j] / sqrt(alpha_sq[j * alpha_stride]) : s_ph[j];
+  for (int j = threadIdx.x; j < k; j += 64)
+    y[j] = y_over_alpha ? s_ph[j] / sqrt(alpha_sq[(int64_t)j * a_stride]) : s_ph[j];
 }
 
 }  // namespace
@@ -125,10 +125,8 @@ extern "C" int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride,
   } else {
     if (int rc = scratch_doubles(s, (size_t)3 * cap + 4, &scratch)) return rc;
   }
-  hipLaunchKernelGGL(k_bidiag_tikhonov, dim3(1), dim3(64), 0, s, alpha_sq, alpha_stride, beta_sq, beta_stride, k, mu,
-                     beta0_sq, y, work, cap, scratch);
-  hipLaunchKernelGGL(k_bidiag_backsub, dim3(1), dim3(64), 3 * sizeof(double) * (size_t)k, s, work ? work : scratch, cap, k, y,
-                     y_over_alpha ? alpha_sq : nullptr, alpha_stride);
+  hipLaunchKernelGGL(k_bidiag_tikhonov, dim3(1), dim3(64), 3 * sizeof(double) * (size_t)k, s, alpha_sq, alpha_stride, beta_sq,
+                     beta_stride, k, mu, beta0_sq, y, work, cap, scratch, y_over_alpha);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }

@@ -438,10 +438,12 @@ int launch_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, 
 // ------------------------------------------------------------------ out = a*base + s * sum_j y[j] V[j]   (+ sum out^2)
 constexpr int KMAX_LDS = 1024;  // coefficients staged in LDS as doubles
 
-template <bool HAS_BASE, bool SUMSQ, bool VEC>
+// HAS_REF: the partials are those of sum (out - ref)^2 instead of sum out^2 (the error norm against x_true)
+template <bool HAS_BASE, bool SUMSQ, bool VEC, bool HAS_REF = false>
 __global__ __launch_bounds__(NT) void k_gemv_n(const float* __restrict__ V, int64_t ld, int k, int64_t n,
                                                const double* __restrict__ y, double a, const float* base, double sc,
-                                               float* out, double* __restrict__ partials) {
+                                               float* out, double* __restrict__ partials,
+                                               const float* __restrict__ ref = nullptr) {
   __shared__ double ys[KMAX_LDS];
   __shared__ double lds[NT / 64];
   for (int j = threadIdx.x; j < k; j += NT) ys[j] = sc * y[j];
@@ -472,7 +474,13 @@ __global__ __launch_bounds__(NT) void k_gemv_n(const float* __restrict__ V, int6
       }
       float4 o = make_float4((float)o0, (float)o1, (float)o2, (float)o3);
       st4(out, i, o);
-      if (SUMSQ) acc2 += (double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z + (double)o.w * o.w;
+      if (SUMSQ && HAS_REF) {
+        const float4 t = ld4(ref, i);
+        const double e0 = (double)o.x - t.x, e1 = (double)o.y - t.y, e2 = (double)o.z - t.z, e3 = (double)o.w - t.w;
+        acc2 += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+      } else if (SUMSQ) {
+        acc2 += (double)o.x * o.x + (double)o.y * o.y + (double)o.z * o.z + (double)o.w * o.w;
+      }
     }
   }
   for (int64_t i = tail0 + tid; i < n; i += nth) {
@@ -480,7 +488,12 @@ __global__ __launch_bounds__(NT) void k_gemv_n(const float* __restrict__ V, int6
     for (int j = 0; j < k; ++j) o = fma(ys[j], (double)V[(int64_t)j * ld + i], o);
     const float of = (float)o;
     out[i] = of;
-    if (SUMSQ) acc2 += (double)of * of;
+    if (SUMSQ && HAS_REF) {
+      const double e = (double)of - ref[i];
+      acc2 += e * e;
+    } else if (SUMSQ) {
+      acc2 += (double)of * of;
+    }
   }
   if (SUMSQ) {
     acc2 = block_sum<NT>(acc2, lds);
@@ -1189,6 +1202,23 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, do
 #undef GN
   TRK_LAUNCH_CHECK();
   if (sumsq) return finalize_sums(part, grid, 1, 1, sumsq, s);
+  return TRK_OK;
+}
+
+int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y, float* out, const float* ref,
+                   double* err_partials, int capacity_blocks, int* n_blocks, trk_stream st) {
+  TRK_REQUIRE(V && y && out && ref && err_partials && n_blocks, "trk_gemv_n_err: NULL argument");
+  TRK_REQUIRE(k >= 1 && k <= KMAX_LDS && n >= 0 && ld >= n, "trk_gemv_n_err: need 1 <= k <= %d, n >= 0, ld >= n", KMAX_LDS);
+  const int grid = stream_grid(n);
+  TRK_REQUIRE(grid <= capacity_blocks, "trk_gemv_n_err: partial buffer too small (%d blocks needed)", grid);
+  *n_blocks = grid;
+  hipStream_t s = (hipStream_t)st;
+  const float* nobase = nullptr;
+  if (aligned16(V) && aligned16(out) && aligned16(ref) && (ld % 4 == 0))
+    hipLaunchKernelGGL((k_gemv_n<false, true, true, true>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, y, 1.0, nobase, 1.0, out, err_partials, ref);
+  else
+    hipLaunchKernelGGL((k_gemv_n<false, true, false, true>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, y, 1.0, nobase, 1.0, out, err_partials, ref);
+  TRK_LAUNCH_CHECK();
   return TRK_OK;
 }
 

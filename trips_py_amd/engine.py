@@ -316,6 +316,14 @@ class HipEngine:
 
     GEMV_NT_MAX_K = 16
 
+    def gemv_n_err(self, V, k, y, out, ref, partials, capacity):
+        """out = sum_j y[j] V[j]; raw block partials of ||out - ref||^2 into `partials`; returns their count."""
+        n = ctypes.c_int(0)
+        rc = self.lib.trk_gemv_n_err(V.data_ptr(), V.stride(0), int(k), out.numel(), _ptr(y), out.data_ptr(), ref.data_ptr(),
+                                     _ptr(partials), int(capacity), ctypes.byref(n), self.stream())
+        _lib.check(rc, "trk_gemv_n_err")
+        return n.value
+
     def gemv_nt(self, V, k, h, w_in, w_out, g):
         """w_out = w_in - sum_j h[j] V[j] and g[j] = V[j] . w_out (local sums), one pass over V; k <= GEMV_NT_MAX_K."""
         rc = self.lib.trk_gemv_nt(V.data_ptr(), V.stride(0), int(k), w_in.numel(), _ptr(h), w_in.data_ptr(), w_out.data_ptr(),

@@ -39,6 +39,10 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
     if xt is not None:
         eng.nrm2sq(xt, E.ref(0))
         eng.allreduce(E, 0, 1)
+    # ||x_i - x_true||^2 as raw block partials of the kernel that forms x_i, summed once after the loop
+    err_fused = xt is not None and hasattr(eng, "gemv_n_err")
+    EP = eng.scalars(1024 * max(1, n_iter)) if err_fused else None
+    n_ep = 0
 
     lams, res, lam, x_dev = [], [], 0, None
     pend = ar.step_prefetch() if n_iter > 0 else None
@@ -64,17 +68,22 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
         y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
         Y.set(0, y)
         x_dev = X[ii] if keep else X[0]
-        eng.gemv_n(ar.V.data, k, Y.ref(0), x_dev)                      # x = V[:, :-1] @ y (:77)
+        if err_fused:
+            n_ep = eng.gemv_n_err(ar.V.data, k, Y.ref(0), x_dev, xt, EP.ref(n_ep * ii), 1024)
+        else:
+            eng.gemv_n(ar.V.data, k, Y.ref(0), x_dev)                  # x = V[:, :-1] @ y (:77)
         # reference quirk (:80): `bhat - H@y` broadcasts a (k+1,) against a (k+1,1) -> Frobenius norm of a matrix
         hy = (H @ y).reshape(-1, 1)
         res.append(float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
-        if xt is not None:
+        if xt is not None and not err_fused:
             eng.diff_nrm2sq(x_dev, xt, E.ref(ii + 1))
     if x_dev is None:
         raise UnboundLocalError("Hybrid_GMRES with n_iter < 1 forms no iterate")
     info = {"xHistory": fmt.hist(X, n_iter) if keep else [], "regParam": lam, "regParam_history": lams,
             "relResidual": res, "its": n_iter - 1}
     if xt is not None:
+        if err_fused:
+            eng.finalize_batched(EP.ref(0), n_ep, 1, n_iter, E.ref(1), 1)
         eng.allreduce(E, 1, n_iter + 1)
         e = E.host(0, n_iter + 1)
         info["relError"] = list(np.sqrt(e[1:] / e[0]))

@@ -45,6 +45,10 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     if xt is not None:
         eng.nrm2sq(xt, E.ref(0))
         eng.allreduce(E, 0, 1)
+    # ||x_i - x_true||^2 as raw block partials of the kernel that forms x_i, summed once after the loop
+    err_fused = xt is not None and hasattr(eng, "gemv_n_err")
+    EP = eng.scalars(1024 * max(1, n_iter)) if err_fused else None
+    n_ep = 0
 
     lams, lam, nx_done, x_dev = [], 0, 0, None
     on_host = isinstance(regparam, str)          # lambda selection needs B_k on the host
@@ -88,9 +92,12 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         # (as y_j / alpha_j: the rows of V are alpha_j v_j)
         eng.bidiag_tikhonov(gk.AB.ref(1), 2, gk.AB.ref(2), 2, k, np.sqrt(lam), gk.AB.ref(0), Y.ref(0), W, y_over_alpha=True)
         x_dev = X[nx_done] if keep else X[0]
-        eng.gemv_n(gk.V.data, k, Y.ref(0), x_dev)
+        if err_fused:
+            n_ep = eng.gemv_n_err(gk.V.data, k, Y.ref(0), x_dev, xt, EP.ref(n_ep * nx_done), 1024)
+        else:
+            eng.gemv_n(gk.V.data, k, Y.ref(0), x_dev)
         nx_done += 1
-        if xt is not None:
+        if xt is not None and not err_fused:
             eng.diff_nrm2sq(x_dev, xt, E.ref(nx_done))
     if x_dev is None:
         raise UnboundLocalError("Hybrid_LSQR with n_iter < 2 forms no iterate (the reference fails the same way, "
@@ -98,6 +105,8 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     info = {"xHistory": fmt.hist(X, nx_done) if keep else [], "regParam": lam, "regParam_history": lams,
             "relResidual": [], "its": n_iter - 1}
     if xt is not None:
+        if err_fused:
+            eng.finalize_batched(EP.ref(0), n_ep, 1, nx_done, E.ref(1), 1)
         eng.allreduce(E, 1, nx_done + 1)
         e = E.host(0, nx_done + 1)
         info["relError"] = list(np.sqrt(e[1:] / e[0]))
