@@ -125,3 +125,27 @@ def test_c_loop_equals_stepwise(fused, history):
     assert torch.equal(r1.x_cur, r2.x_cur)
     if history:
         assert torch.equal(r1.X, r2.X)
+
+
+@pytest.mark.parametrize("N", [64, 520])
+def test_raw_partials_form_equals_finalized_form(N):
+    """CGLSRun with the operator's norms left as block partials (trk_op_apply_fused(x2=NULL), trk_cgls_update_xr_src,
+    trk_cgls_p_update: 4 launches) against the same recurrence with finished scalars (6 launches + norms on the fly)."""
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import gauss_psf
+    from trips_py_amd.solvers import CGLSRun
+    A = Blur2D(gauss_psf((9, 9), (3, 3))[0], N, N)
+    rng = np.random.default_rng(N)
+    b, x0, xt = rng.standard_normal(N * N), np.zeros(N * N), rng.standard_normal(N * N)
+    raw = CGLSRun(A, b, x0, 15, x_true=xt, history=True, defer_norms=True)
+    fin = CGLSRun(A, b, x0, 15, x_true=xt, history=True, defer_norms=False)
+    assert raw.raw and not fin.raw
+    raw.run(15)
+    for _ in range(15):
+        fin.step()
+    g0r, Rr = raw.rows()
+    g0f, Rf = fin.rows()
+    assert g0r == g0f
+    assert np.allclose(Rr, Rf, rtol=2e-6, atol=0)
+    xr, xf = raw.X[14].cpu().numpy(), fin.X[14].cpu().numpy()
+    assert relerr(xr, xf) < 2e-6
