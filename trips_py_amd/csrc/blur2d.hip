@@ -542,9 +542,9 @@ inline void slide_grid(int nx, int ny, int batch, int kh, int U, int* spans_x, i
     const double x = (double)sx * ceil_div(nx, r) * nb / slots;
     const double g = x <= 1.0 ? 1.0 : 0.6 + 0.45 * x + 0.5 * (ceil(x) - 1.0);
     const bool last = x <= 1.0 || r >= nx;   // taller bands only add rows per wave from here on
-    // more than 3.75 waves per SIMD are not considered: one block partial per wave, and the callers' partial buffers
-    // (CGLS: 4096 doubles) are sized for that
-    if ((x <= 3.75 || last) && rows * g < best) {
+    // more than 3840 waves (3.75 per SIMD on 256 CUs) are not considered: one block partial per wave, and the callers'
+    // partial buffers (CGLS: 4096 doubles) are sized for that
+    if ((x * slots <= 3840.0 || last) && rows * g < best) {
       best = rows * g;
       rpb = r;
     }
