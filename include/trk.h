@@ -145,6 +145,10 @@ int trk_mul_diff(int64_t n, const float* w, const float* x, const float* y, floa
 /* out = (v*v + eps*eps)^(p/2 - 1) with v = x - y (y may be NULL): the smoothed-Holder MM weights of
  * trips/utilities/weights.py:66-68 applied to the residual A x - b (MMGKS.py:56-57) or to L x (:60,93). */
 int trk_mm_weights(int64_t n, const float* x, const float* y, double eps, double p, float* out, trk_stream stream);
+/* Group-sparsity weights of MMGKS (MMGKS.py:86-90): out[c*groups + i] = (sum_{t < group_len} d[i*group_len + t]^2 + add)^expo,
+ * c < copies — one weight per group of consecutive entries, tiled `copies` times. */
+int trk_group_weights(const float* d, int64_t groups, int group_len, double add, double expo, int copies, float* out,
+                      trk_stream stream);
 
 /* One fused CGLS vector update (CGLS.py:64-67):  step = *gamma / *delta ;
  *   x_new = x + step*p ; r = r - step*w ;  sums_dev[0] = ||x_new||^2, sums_dev[1] = ||step*p||^2

@@ -734,13 +734,42 @@ def gks(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, delta
 
 
 # =====================================================================================
-# a12 MMGKS (plain smoothed-Holder weights branch)               trips/solvers/MMGKS.py:28-137
+# a12 MMGKS (plain smoothed-Holder weights and group-sparsity branches)   trips/solvers/MMGKS.py:28-137
 # =====================================================================================
+def old_first_derivative_matrix(n):
+    """trips/utilities/operators_old.py:66-72: rows 0..n-2 of I - subdiag(1), i.e. row 0 = x[0], row i = x[i] - x[i-1]."""
+    import scipy.sparse as sp
+    D = sp.spdiags(np.ones(n - 1), -1, n, n)
+    return (sp.identity(n) - D).tocsr()[0:-1, :]
+
+
+def old_first_derivative_2d_matrix(nx, ny):
+    """operators_old.py:75-85: vstack(kron(I_nx, D_nx), kron(D_ny, I_ny))."""
+    import scipy.sparse as sp
+    Dx, Dy = old_first_derivative_matrix(nx), old_first_derivative_matrix(ny)
+    return sp.vstack((sp.kron(sp.identity(nx), Dx), sp.kron(Dy, sp.identity(ny)))).tocsr()
+
+
+def group_sparsity_weights(x, Ls, nx, ny, qnorm):
+    """MMGKS.py:78-91 (GS branch), literally: the frame-major iterate is reshaped (nx*ny, nt) in C order (:85), the
+    smoothing constant is exp(2) (:87), one weight per row of Ls over its nt entries, tiled nt times (:90)."""
+    nt = int(x.reshape(-1, 1).shape[0] / (nx * ny))
+    D = Ls.dot(np.reshape(x, (nx * ny, nt)))
+    wr = (np.linalg.norm(D[:2 * nx * (ny - 1), :], axis=1) ** 2 + np.exp(2)) ** (qnorm / 2 - 1)
+    return np.kron(np.ones((nt, 1)), wr.reshape(-1, 1))
+
+
 def mmgks(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv", x_true=None,
-          epsilon=0.1, delta=None, eta=1.01):
+          epsilon=0.1, delta=None, eta=1.01, GS=False, prob_dims=None):
     b = np.asarray(b, dtype=np.float64).reshape(-1, 1)
     _, _, V = golub_kahan(A, b, projection_dim)
     x = A.T @ b                                                  # :43
+    Ls = None
+    if GS:                                                       # :45-52: L is REPLACED by kron(I_nt, Ls)
+        import scipy.sparse as sp
+        nx, ny, nt = prob_dims
+        Ls = old_first_derivative_2d_matrix(nx, ny)
+        L = MatrixOp(sp.kron(sp.identity(nt), Ls).tocsr())
     AV, LV = A @ V, L @ V
     hist, lams, res = [], [], []
     lam = None
@@ -749,7 +778,10 @@ def mmgks(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         its = ii
         wf = smoothed_holder_weights(A @ x - b, epsilon, pnorm)          # :56-57
         Q_A, R_A = sla.qr(AV * wf, mode="economic")
-        wr = smoothed_holder_weights(L @ x, epsilon, qnorm).reshape(-1, 1)   # :60,93
+        if GS:
+            wr = group_sparsity_weights(x, Ls, prob_dims[0], prob_dims[1], qnorm)   # :78-91
+        else:
+            wr = smoothed_holder_weights(L @ x, epsilon, qnorm).reshape(-1, 1)   # :60,93
         _, R_L = sla.qr(LV * wr, mode="economic")
         lam = _select_lambda(regparam, Q_A, R_A, R_L, wf * b, delta, eta)    # weighted b for the selector (:97-99)
         lams.append(lam)

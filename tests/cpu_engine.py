@@ -140,6 +140,15 @@ class CpuEngine:
         v = _d(x) - (0 if y is None else _d(y))
         out.copy_(torch.from_numpy(((v ** 2 + eps ** 2) ** (p / 2 - 1)).astype(np.float32)))
 
+    def group_weights(self, d, groups, group_len, add, expo, copies, out):
+        D = _d(d)[:groups * group_len].reshape(groups, group_len)
+        w = ((D ** 2).sum(axis=1) + add) ** expo
+        out.copy_(torch.from_numpy(np.tile(w, copies).astype(np.float32)))
+
+    def sparse_operator(self, M):
+        from oracle import cpu_ref as O
+        return OracleOp(O.MatrixOp(M), self)
+
     def cgls_update(self, gamma, delta, x, p, x_new, r, w, x_true, sums):
         step = np.float32(_get(gamma) / _get(delta))
         d = step * p.numpy()

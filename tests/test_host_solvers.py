@@ -133,6 +133,23 @@ def test_dynamic_blockdiag_spacetime(eng):
     assert relerr(x, g["x"]) < 5e-5 and np.allclose(info["relError"], g["relError"], rtol=2e-4)
 
 
+@pytest.mark.parametrize("tag,q,rp", [("q1_lam1e-2", 1, 1e-2), ("q0.5_lam1e-3", 0.5, 1e-3), ("q1_gcv", 1, "gcv")])
+def test_mmgks_group_sparsity_branch(eng, tag, q, rp):
+    g = load_golden("mmgks_dyn3x16_gs_" + tag)
+    N, nt = int(g["N"]), int(g["nt"])
+    F = OracleOp(O.BlockDiag([O.Blur2D(g["psfs"][t], N, N) for t in range(nt)]), eng)
+    L = OracleOp(O.SpaceTimeDerivative(N, nt), eng)
+    x, info = S.MMGKS(F, g["b"], L, 2, q, 3, int(g["n_iter"]), rp, g["x_true"], GS="GS", prob_dims=(N, N, nt))
+    assert info["its"] == int(g["its"])
+    if rp != "gcv":
+        assert relerr(x, g["x"]) < 5e-5 and np.allclose(info["relError"], g["relError"], rtol=2e-4)
+        assert np.allclose(info["Residual"], g["Residual"], rtol=2e-3)
+    else:
+        assert np.allclose(info["relError"], g["relError"], rtol=5e-2) and relerr(x, g["x"]) < 5e-2
+    with pytest.raises(TypeError):
+        S.MMGKS(F, g["b"], L, 2, q, 3, 2, 1e-2, GS="GS")
+
+
 def test_reference_error_behaviour(eng):
     g = load_golden("gks_blur32_lam1e-2")
     A = blur(eng, g)

@@ -4,7 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from trips_py_amd.operators import Blur2D
 from trips_py_amd.problems import gauss_psf
-psf = gauss_psf((9, 9), (3, 3))[0]
+K = int(os.environ.get("PSF", "9"))               # PSF side (3, 5, 7, 9: sliding kernel; 11..15: strip kernel)
+psf = gauss_psf((K, K), (K / 3.0, K / 3.0))[0]
 SIZES = [int(a) for a in sys.argv[1:]] or (1024, 1536, 2048, 2560, 3072, 3584, 3840, 4000, 4096, 4160, 4224, 4352, 5120, 8192)
 for N in SIZES:
     A = Blur2D(psf, N, N)

@@ -282,6 +282,12 @@ def g5_gks():
     save("mmgks_dyn3x16_p2q1_lam1e-2", psfs=psfs, N=Nf, nt=nt, b=bt, x_true=xt, pnorm=2, qnorm=1, projection_dim=3,
          n_iter=8, epsilon=0.1, x=x, regParam_history=np.array(info["regParam_history"], dtype=float),
          relError=info["relError"], Residual=info["Residual"], its=info["its"])
+    # group-sparsity weights branch (MMGKS.py:45-52,78-91): L is replaced by kron(I_nt, old first-derivative matrix)
+    for tag, q, rp in (("q1_lam1e-2", 1, 1e-2), ("q0.5_lam1e-3", 0.5, 1e-3), ("q1_gcv", 1, "gcv")):
+        x, info = quiet(MMGKS, F, bt, Lst, 2, q, 3, 8, rp, xt, GS="GS", prob_dims=(Nf, Nf, nt))
+        save("mmgks_dyn3x16_gs_" + tag, psfs=psfs, N=Nf, nt=nt, b=bt, x_true=xt, pnorm=2, qnorm=q, projection_dim=3,
+             n_iter=8, epsilon=0.1, x=x, regParam_history=np.array(info["regParam_history"], dtype=float),
+             relError=info["relError"], Residual=info["Residual"], its=info["its"])
 
 
 # ----------------------------------------------------------------------------------------- G6

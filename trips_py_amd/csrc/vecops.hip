@@ -185,6 +185,20 @@ __global__ __launch_bounds__(NT) void k_mm_weights(int64_t n, const float* x, co
   }
 }
 
+// ------------------------------------------------------------------ group-sparsity weights (MMGKS.py:86-90)
+// out[c*groups + i] = (sum_t d[i*len + t]^2 + add)^expo for c < copies: one weight per group of `len` consecutive
+// entries (the nt entries of a row of Ls X), repeated `copies` times (np.kron(ones(nt), wr)).
+__global__ __launch_bounds__(NT) void k_group_weights(const float* __restrict__ d, int64_t groups, int len, double add,
+                                                      double expo, int copies, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * NT + threadIdx.x;
+  if (i >= groups) return;
+  const float* g = d + i * len;
+  double s = 0.0;
+  for (int t = 0; t < len; ++t) s += (double)g[t] * (double)g[t];
+  const float w = (float)pow(s + add, expo);
+  for (int c = 0; c < copies; ++c) out[(int64_t)c * groups + i] = w;
+}
+
 // ------------------------------------------------------------------ fused CGLS update (CGLS.py:64-67,76,79)
 // partials layout: [block][3] = ||x_new||^2, ||step*p||^2, ||x_new - x_true||^2
 template <bool HAS_XT, bool VEC>
@@ -1090,6 +1104,16 @@ int trk_mm_weights(int64_t n, const float* x, const float* y, double eps, double
   if (y) { if (vec) MW(true, true); else MW(true, false); }
   else   { if (vec) MW(false, true); else MW(false, false); }
 #undef MW
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_group_weights(const float* d, int64_t groups, int group_len, double add, double expo, int copies, float* out,
+                      trk_stream st) {
+  TRK_REQUIRE(d && out && groups >= 0 && group_len >= 1 && copies >= 1, "trk_group_weights: bad argument");
+  if (groups == 0) return TRK_OK;
+  hipLaunchKernelGGL(k_group_weights, dim3(ceil_div(groups, NT)), dim3(NT), 0, (hipStream_t)st, d, groups, group_len, add, expo,
+                     copies, out);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }

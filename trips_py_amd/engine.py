@@ -224,6 +224,17 @@ class HipEngine:
                                      out.data_ptr(), self.stream())
         _lib.check(rc, "trk_mm_weights")
 
+    def group_weights(self, d, groups, group_len, add, expo, copies, out):
+        """out[c*groups + i] = (sum_t d[i*group_len + t]^2 + add)^expo, c < copies (MMGKS group-sparsity weights)."""
+        rc = self.lib.trk_group_weights(d.data_ptr(), int(groups), int(group_len), float(add), float(expo), int(copies),
+                                        out.data_ptr(), self.stream())
+        _lib.check(rc, "trk_group_weights")
+
+    def sparse_operator(self, M):
+        """A scipy.sparse matrix as an operator of this engine (device CSR SpMV)."""
+        from .operators import SparseOp
+        return SparseOp(M, engine=self)
+
     def cgls_update(self, gamma, delta, x, p, x_new, r, w, x_true, sums):
         rc = self.lib.trk_cgls_update_xr(x.numel(), r.numel(), _ptr(gamma), _ptr(delta), x.data_ptr(), p.data_ptr(),
                                          x_new.data_ptr(), r.data_ptr(), w.data_ptr(),

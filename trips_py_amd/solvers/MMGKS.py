@@ -1,5 +1,6 @@
 """Majorization-Minimization GKS on the HIP engine — signature and `info` of trips/solvers/MMGKS.py:28-137
-(plain smoothed-Holder weights branch, :93; the isoTV and group-sparsity weight branches are SURVEY §8f rank 3).
+(plain smoothed-Holder weights, :93, and the group-sparsity weights branch, :45-52 / :78-91; the isoTV branch, :61-77, goes
+through PyLops' FirstDerivative, whose arithmetic is not pinned here — SURVEY §8f rank 3).
 
     min ||A x - b||_p^p + lambda ||L x||_q^q   by iteratively re-weighted least squares in a growing subspace.
 
@@ -18,18 +19,52 @@ from ..krylov import DeviceBasis, orthogonalize
 from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq, small_host_blas
 
 
+def _old_first_derivative_2d_matrix(nx, ny):
+    """trips/utilities/operators_old.py:66-85, built the same way: D_n = rows 0..n-2 of (I - subdiagonal of ones), i.e.
+    row 0 = x[0], row i = x[i] - x[i-1];  Ls = vstack(kron(I_nx, D_nx), kron(D_ny, I_ny))."""
+    import scipy.sparse as sp
+
+    def d1(n):
+        return (sp.identity(n) - sp.spdiags(np.ones(n - 1), -1, n, n)).tocsr()[0:-1, :]
+    return sp.vstack((sp.kron(sp.identity(nx), d1(nx)), sp.kron(d1(ny), sp.identity(ny)))).tocsr()
+
+
 @small_host_blas
 def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys xHistory, regParam, regParam_history, relError (if x_true), Residual, its.
     Engine-only kwarg: history=True."""
-    A, L = as_operator(A), as_operator(L, "L")
+    A = as_operator(A)
     check_delta(regparam, kwargs)
-    for opt in ("isoTV", "GS"):
-        if kwargs.get(opt, False):
-            raise NotImplementedError(f"MMGKS {opt} weights (MMGKS.py:61-91) are not implemented on the engine yet")
+    if kwargs.get("isoTV", False) in ("isoTV", "ISOTV", "IsoTV"):
+        raise NotImplementedError("MMGKS isoTV weights (MMGKS.py:61-77) apply pylops.FirstDerivative (operators_old.py:31); "
+                                  "its arithmetic is not available to pin: not implemented on the engine")
     epsilon = kwargs.get("epsilon", 0.1)
     eng = A.engine
     m, n = A.shape
+    gs = kwargs.get("GS", False) in ("GS", "gs", "Gs")
+    if gs:
+        # group sparsity (:45-52): the caller's L is REPLACED by kron(I_nt, Ls), Ls the 2-D first-derivative matrix of
+        # operators_old.py:66-85; the weights couple the nt entries of every row of Ls X (:83-90)
+        prob_dims = kwargs.get("prob_dims", False)
+        if prob_dims is False:                      # the reference fails with a TypeError as well (indexing False, :46)
+            raise TypeError("For Isotropic Group Sparsity you must enter the dimension of the dynamic problem. (x_mmgks, "
+                            "info_mmgks) = MMGKS(A, data_vec, L, pnorm=2, qnorm=1, projection_dim=2, n_iter =3, regparam = "
+                            "'gcv', x_true = None, GS = 'GS', prob_dims = (nx,ny, nt))")
+        gs_nx, gs_ny, gs_nt = (int(v) for v in prob_dims[:3])
+        Ls = _old_first_derivative_2d_matrix(gs_nx, gs_ny)
+        import scipy.sparse as sp
+        L = eng.sparse_operator(sp.kron(sp.identity(gs_nt), Ls).tocsr())
+        # Ls applied to x.reshape(nx*ny, nt) (C order, :85), as one sparse product on the flat iterate
+        gs_nt_x = n // (gs_nx * gs_ny)                                # nt as the reference re-derives it (:84)
+        gs_rows = 2 * gs_nx * (gs_ny - 1)                             # the rows the reference loops over (:88)
+        gs_op = eng.sparse_operator(sp.kron(Ls[:gs_rows], sp.identity(gs_nt_x)).tocsr())
+        gs_d = eng.empty(gs_rows * gs_nt_x)
+        if getattr(eng, "world", 1) > 1:
+            raise NotImplementedError("MMGKS group-sparsity weights couple all frames of a pixel: single rank only")
+        if gs_rows * gs_nt_x != L.shape[0]:          # the reference's LV * wr (:94) does not broadcast either
+            raise ValueError(f"MMGKS GS: prob_dims {tuple(prob_dims)} do not match a square nx x ny x nt iterate of length {n}")
+    else:
+        L = as_operator(L, "L")
     p_rows = L.shape[0]
     n_iter, d = int(n_iter), int(projection_dim)
     keep = bool(kwargs.get("history", True))
@@ -83,7 +118,11 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         kk = k * k
         # weights from the current iterate (:56-57, :60, :93); ax = A x, lx = L x of it
         eng.mm_weights(ax, bv, epsilon, pnorm, wf)
-        eng.mm_weights(lx, None, epsilon, qnorm, wr)
+        if gs:
+            gs_op.apply(x_cur if x_dev is None else x_dev, out=gs_d)
+            eng.group_weights(gs_d, gs_rows, gs_nt_x, float(np.exp(2)), qnorm / 2 - 1, gs_nt_x, wr)   # exp(2): sic (:87)
+        else:
+            eng.mm_weights(lx, None, epsilon, qnorm, wr)
         # weighted Gram matrices and projected right-hand sides
         eng.wgram(AV.data, k, wf, bv, G.ref(0), G.ref(2 * kk), G.ref(2 * kk + k))
         eng.wgram(LV.data, k, wr, None, G.ref(kk))
