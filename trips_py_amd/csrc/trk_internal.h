@@ -86,6 +86,8 @@ __device__ __forceinline__ double block_sum(double v, double* lds) {
 // n == 0: the constant 1 ; n == 1: *p ; n > 1: the sum of n block partials.  The sum is always formed the same way
 // (lane l of one wave adds p[l], p[l+64], ... then a wave64 tree), so every kernel that consumes the same partials
 // gets the bitwise same value, and no separate finalize launch is needed between producer and consumer.
+constexpr int64_t kNontemporalMinFloats = (int64_t)11 << 20;   // see stream_nontemporal()
+
 struct ScalarSrc {
   const double* p;
   int n;
@@ -130,6 +132,15 @@ __device__ __forceinline__ double scalar_from_wave(const ScalarSrc s, int lane) 
 }
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+
+// Non-temporal stores for streamed outputs of n floats?  Below the threshold the next kernel finds them in L2 / the
+// 256 MB memory-side cache and ordinary stores are faster (2048^2 CGLS: 18.7 k vs 16.6 k iterations/s); above it they only
+// evict what the next kernel needs (5120^2: 4.0 k -> 4.5 k).  TRK_NT=0/1 overrides (tuning).
+inline int stream_nontemporal(int64_t n) {
+  static const int env = getenv("TRK_NT") ? atoi(getenv("TRK_NT")) : -1;
+  if (env >= 0) return env != 0;
+  return n >= kNontemporalMinFloats;
+}
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 

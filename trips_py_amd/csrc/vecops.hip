@@ -23,6 +23,13 @@ inline int stream_grid(int64_t n) {
 
 __device__ __forceinline__ float4 ld4(const float* p, int64_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
 __device__ __forceinline__ void st4(float* p, int64_t i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
+// non-temporal store for outputs the same kernel never re-reads (CGLS x / r / p updates: -1 us of 61 / 31 us at n = 16.8 M;
+// non-temporal LOADS of the streamed inputs made the next blur kernel 6 us slower: its operand no longer sat in the
+// memory-side cache)
+typedef float f4nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_nt(float* p, int64_t i4, float4 v) {
+  __builtin_nontemporal_store((f4nt){v.x, v.y, v.z, v.w}, reinterpret_cast<f4nt*>(p) + i4);
+}
 
 // ------------------------------------------------------------------ dot / nrm2 / diff-nrm2
 // MODE 0: sum x*y   1: sum x*x   2: sum (x-y)^2
@@ -205,7 +212,7 @@ template <bool HAS_XT, bool VEC>
 __global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, ScalarSrc gamma, ScalarSrc delta,
                                                     const float* x, const float* p, float* x_new, float* r,
                                                     const float* w, const float* x_true, double* __restrict__ partials,
-                                                    double* pub_delta) {
+                                                    double* pub_delta, int nt) {
   __shared__ double lds[NT / 64];
   __shared__ double bc;
   float step;
@@ -233,7 +240,7 @@ __global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, Scalar
       const float4 xv = ld4(x, i), pv = ld4(p, i);
       const float4 d = make_float4(step * pv.x, step * pv.y, step * pv.z, step * pv.w);
       const float4 xn = make_float4(xv.x + d.x, xv.y + d.y, xv.z + d.z, xv.w + d.w);
-      st4(x_new, i, xn);
+      if (nt) st4_nt(x_new, i, xn); else st4(x_new, i, xn);
       s0 += (double)xn.x * xn.x + (double)xn.y * xn.y + (double)xn.z * xn.z + (double)xn.w * xn.w;
       s1 += (double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z + (double)d.w * d.w;
       if (HAS_XT) {
@@ -249,7 +256,7 @@ __global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, Scalar
       rv.y = fmaf(-step, wv.y, rv.y);
       rv.z = fmaf(-step, wv.z, rv.z);
       rv.w = fmaf(-step, wv.w, rv.w);
-      st4(r, i, rv);
+      if (nt) st4_nt(r, i, rv); else st4(r, i, rv);
     }
   }
   for (int64_t i = ntail + tid; i < n; i += nth) {
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, Scalar
 // t; block 0 publishes the finished gamma_new.  Same arithmetic as trk_axpby(1, t, gamma_new/gamma_old, p).
 template <bool VEC>
 __global__ __launch_bounds__(NT) void k_cgls_p_update(int64_t n, const float* __restrict__ t, float* p, ScalarSrc gnew,
-                                                      const double* gold, double* pub_gamma) {
+                                                      const double* gold, double* pub_gamma, int nt) {
   __shared__ double bc;
   if (threadIdx.x < 64) {
     const double g = scalar_from_wave(gnew, threadIdx.x);
@@ -302,7 +309,7 @@ __global__ __launch_bounds__(NT) void k_cgls_p_update(int64_t n, const float* __
       o.y = fmaf(1.f, v.y, b * w.y);
       o.z = fmaf(1.f, v.z, b * w.z);
       o.w = fmaf(1.f, v.w, b * w.w);
-      st4(p, i, o);
+      if (nt) st4_nt(p, i, o); else st4(p, i, o);
     }
   }
   for (int64_t i = tail0 + tid; i < n; i += nth) p[i] = fmaf(1.f, t[i], b * p[i]);
@@ -1128,7 +1135,7 @@ int trk_cgls_update_xr(int64_t n, int64_t m, const double* gamma, const double* 
   if (int rc = scratch_doubles(s, (size_t)grid * 3, &part)) return rc;
   const bool vec = aligned16(x) && aligned16(p) && aligned16(x_new) && aligned16(r) && aligned16(w) &&
                    (!x_true || aligned16(x_true));
-#define CU(XT, VC) hipLaunchKernelGGL((k_cgls_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, ScalarSrc{gamma, 1}, ScalarSrc{delta, 1}, x, p, x_new, r, w, x_true, part, (double*)nullptr)
+#define CU(XT, VC) hipLaunchKernelGGL((k_cgls_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, ScalarSrc{gamma, 1}, ScalarSrc{delta, 1}, x, p, x_new, r, w, x_true, part, (double*)nullptr, stream_nontemporal(n))
   if (x_true) { if (vec) CU(true, true); else CU(true, false); }
   else        { if (vec) CU(false, true); else CU(false, false); }
 #undef CU
@@ -1150,7 +1157,7 @@ int trk_cgls_update_xr_src(int64_t n, int64_t m, const double* gamma, int gamma_
   const bool vec = aligned16(x) && aligned16(p) && aligned16(x_new) && aligned16(r) && aligned16(w) &&
                    (!x_true || aligned16(x_true));
   const ScalarSrc g{gamma, gamma_n}, d{delta, delta_n};
-#define CU(XT, VC) hipLaunchKernelGGL((k_cgls_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, g, d, x, p, x_new, r, w, x_true, norm_partials, publish_delta)
+#define CU(XT, VC) hipLaunchKernelGGL((k_cgls_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, g, d, x, p, x_new, r, w, x_true, norm_partials, publish_delta, stream_nontemporal(n))
   if (x_true) { if (vec) CU(true, true); else CU(true, false); }
   else        { if (vec) CU(false, true); else CU(false, false); }
 #undef CU
@@ -1172,9 +1179,9 @@ int trk_cgls_p_update(int64_t n, const float* t, float* p, const double* gamma_n
   const ScalarSrc g{gamma_new, gamma_new_n};
   hipStream_t s = (hipStream_t)st;
   if (aligned16(t) && aligned16(p))
-    hipLaunchKernelGGL((k_cgls_p_update<true>), dim3(grid), dim3(NT), 0, s, n, t, p, g, gamma_old, publish_gamma);
+    hipLaunchKernelGGL((k_cgls_p_update<true>), dim3(grid), dim3(NT), 0, s, n, t, p, g, gamma_old, publish_gamma, stream_nontemporal(n));
   else
-    hipLaunchKernelGGL((k_cgls_p_update<false>), dim3(grid), dim3(NT), 0, s, n, t, p, g, gamma_old, publish_gamma);
+    hipLaunchKernelGGL((k_cgls_p_update<false>), dim3(grid), dim3(NT), 0, s, n, t, p, g, gamma_old, publish_gamma, stream_nontemporal(n));
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }
