@@ -418,7 +418,7 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
         if (active) {
           // aux = 2: non-temporal store, for images too large for the next kernel to find the output cached
           // (stream_nontemporal(); 4096^2: 23.9 -> 23.2 us in the CGLS loop); nt_store is grid-uniform
-          if (nt_store)
+          if (nt_store & 1)
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, out), rout, vst + (ofirst + dir * o) * rowbytes, 0, 2);
           else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, out), rout, vst + (ofirst + dir * o) * rowbytes, 0, 0);

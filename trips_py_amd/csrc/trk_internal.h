@@ -133,13 +133,16 @@ __device__ __forceinline__ double scalar_from_wave(const ScalarSrc s, int lane) 
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// Non-temporal stores for streamed outputs of n floats?  Below the threshold the next kernel finds them in L2 / the
-// 256 MB memory-side cache and ordinary stores are faster (2048^2 CGLS: 18.7 k vs 16.6 k iterations/s); above it they only
-// evict what the next kernel needs (5120^2: 4.0 k -> 4.5 k).  TRK_NT=0/1 overrides (tuning).
+// Which streamed outputs of n floats are stored non-temporally: bit 0 the blur kernel's output, bit 1 the new CGLS
+// iterate (bits 2, 3: the residual and the direction — measured, no gain).  Below the threshold the next kernel finds
+// the data in L2 / the 256 MB memory-side cache and ordinary stores are faster (2048^2 CGLS: 18.7 k vs 16.6 k
+// iterations/s with all four); above it they evict what the next kernels need.  4096^2: 6.68 k (none) / 6.73 k (blur) /
+// 6.81 k (iterate) / 6.87 k (both) / 6.84 k (all four) iterations/s; 5120^2: 3.93 k / 4.26 k / 3.93 k / 4.45 k / 4.45 k.
+// Crossover between 3072^2 (-1 %) and 3584^2 (+2 %).  TRK_NT=<mask> overrides (tuning).
 inline int stream_nontemporal(int64_t n) {
   static const int env = getenv("TRK_NT") ? atoi(getenv("TRK_NT")) : -1;
-  if (env >= 0) return env != 0;
-  return n >= kNontemporalMinFloats;
+  if (env >= 0) return env;
+  return n >= kNontemporalMinFloats ? 3 : 0;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, Scalar
       const float4 xv = ld4(x, i), pv = ld4(p, i);
       const float4 d = make_float4(step * pv.x, step * pv.y, step * pv.z, step * pv.w);
       const float4 xn = make_float4(xv.x + d.x, xv.y + d.y, xv.z + d.z, xv.w + d.w);
-      if (nt) st4_nt(x_new, i, xn); else st4(x_new, i, xn);
+      if (nt & 2) st4_nt(x_new, i, xn); else st4(x_new, i, xn);
       s0 += (double)xn.x * xn.x + (double)xn.y * xn.y + (double)xn.z * xn.z + (double)xn.w * xn.w;
       s1 += (double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z + (double)d.w * d.w;
       if (HAS_XT) {
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, Scalar
       rv.y = fmaf(-step, wv.y, rv.y);
       rv.z = fmaf(-step, wv.z, rv.z);
       rv.w = fmaf(-step, wv.w, rv.w);
-      if (nt) st4_nt(r, i, rv); else st4(r, i, rv);
+      if (nt & 4) st4_nt(r, i, rv); else st4(r, i, rv);
     }
   }
   for (int64_t i = ntail + tid; i < n; i += nth) {
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(NT) void k_cgls_p_update(int64_t n, const float* __
       o.y = fmaf(1.f, v.y, b * w.y);
       o.z = fmaf(1.f, v.z, b * w.z);
       o.w = fmaf(1.f, v.w, b * w.w);
-      if (nt) st4_nt(p, i, o); else st4(p, i, o);
+      if (nt & 8) st4_nt(p, i, o); else st4(p, i, o);
     }
   }
   for (int64_t i = tail0 + tid; i < n; i += nth) p[i] = fmaf(1.f, t[i], b * p[i]);
