@@ -194,7 +194,10 @@ def run_blur_cgls(args, rank, world):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"blur{N}_cgls", "image": f"{N}x{N} fp32", "psf": "Gaussian 9x9 sigma=(3,3), reflect",
                       "solver": "CGLS (trips.solvers.CGLS semantics, tol=0)", "noise": "1% Gaussian",
-                      "iteration": "fused: 3 launches (blur+p-update, x-update, blur^T+r-update)" if Run is CGLSRunFused else ("4 launches (blur, x/r update, blur^T, p update; consumers add the block partials)" if getattr(run, "raw", False) else "generic: 6 launches"),
+                      "iteration": "fused: 3 launches (blur+p-update, x-update, blur^T+r-update)" if Run is CGLSRunFused else (("4 launches (blur, r update, blur^T, x/p update in one pass over p; consumers add the block partials)"
+                                     if getattr(run, "grouping", 0) == 1 else
+                                     "4 launches (blur, x/r update, blur^T, p update; consumers add the block partials)")
+                                    if getattr(run, "raw", False) else "generic: 6 launches"),
                       "parallelism": "replicas" if world > 1 else "single"},
            "roofline": roofline,
            "extra": {"relError_after_timed_iters": float(torch.linalg.norm(run.x_cur - x_true) / torch.linalg.norm(x_true)),

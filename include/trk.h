@@ -174,6 +174,15 @@ int trk_cgls_update_xr_src(int64_t n, int64_t m, const double* gamma, int gamma_
  * stores the finished gamma_new to *publish_gamma (may be NULL). */
 int trk_cgls_p_update(int64_t n, const float* t, float* p, const double* gamma_new, int gamma_new_n, const double* gamma_old,
                       double* publish_gamma, trk_stream stream);
+/* The two halves of the update regrouped so that p is read once: r -= (*gamma_old / S(delta)) w (block 0 publishes delta),
+ * and, after t = A^T r: x_new = x + (*gamma_old / *delta) p together with p = t + (S(gamma_new) / *gamma_old) p (block 0
+ * publishes gamma_new; norms as trk_cgls_update_xr_deferred). */
+int trk_cgls_update_grouping(int64_t n);   /* 1: trk_cgls_iterate uses the r / xp grouping for vectors of n floats (measured rule) */
+int trk_cgls_r_update(int64_t m, const double* gamma_old, const double* delta, int delta_n, float* r, const float* w,
+                      double* publish_delta, trk_stream stream);
+int trk_cgls_xp_update(int64_t n, const double* gamma_old, const double* delta, const double* gamma_new, int gamma_new_n,
+                       const float* x, float* p, const float* t, float* x_new, const float* x_true, double* publish_gamma,
+                       double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
 
 /* ---------------------------------------------------------------- fused CGLS fast path --- */
 /* For operators whose kernel can combine two inputs on load (the blur): one CGLS iteration becomes three launches with no
@@ -230,10 +239,13 @@ int trk_host_dp_newton(const double* sv, const double* bhat, int n, double targe
  *   *n_np_inout: partial blocks per iteration (0 before the first iteration; constant afterwards).
  *   PG, PD (may be NULL): `pcap` doubles each.  Given them and an operator with a fused apply (trk_op_fused_caps), the
  *   operator leaves ||t||^2 / ||w||^2 as raw block partials there (trk_op_apply_fused with x2 = NULL) and the consumers
- *   (trk_cgls_update_xr_src, trk_cgls_p_update) add them up: four launches per iteration instead of six. */
+ *   (trk_cgls_update_xr_src, trk_cgls_p_update) add them up: four launches per iteration instead of six.
+ *   grouping: 0 = [x, r] / [p] updates, 1 = [r] / [x, p] (trk_cgls_r_update, trk_cgls_xp_update), -1 = by size
+ *   (trk_cgls_update_grouping); same results either way. */
 int trk_cgls_iterate(trk_op* A, int k_first, int n_iters, float* p, float* r, float* t, float* w, float* X, int64_t x_ld,
                      int keep_history, const float* x_prev, const float* x_true, double* S, double* NP,
-                     int np_capacity_blocks, int* n_np_inout, double* PG, double* PD, int pcap, trk_stream stream);
+                     int np_capacity_blocks, int* n_np_inout, double* PG, double* PD, int pcap, int grouping,
+                     trk_stream stream);
 /* The same for operators with a fused apply (trk_op_fused_caps): three launches per iteration.  P, R: ping-pong pairs
  * [2][p_ld], [2][r_ld] (iteration k reads index (k-1) & 1, writes k & 1); PG / PD: gamma / delta block partials with
  * `pcap` doubles each; *n_g_inout: number of valid gamma partials in PG (set by the caller's r0/t0 setup). */

@@ -127,8 +127,9 @@ def test_c_loop_equals_stepwise(fused, history):
         assert torch.equal(r1.X, r2.X)
 
 
+@pytest.mark.parametrize("grouping", [0, 1])
 @pytest.mark.parametrize("N", [64, 520])
-def test_raw_partials_form_equals_finalized_form(N):
+def test_raw_partials_form_equals_finalized_form(N, grouping):
     """CGLSRun with the operator's norms left as block partials (trk_op_apply_fused(x2=NULL), trk_cgls_update_xr_src,
     trk_cgls_p_update: 4 launches) against the same recurrence with finished scalars (6 launches + norms on the fly)."""
     from trips_py_amd.operators import Blur2D
@@ -137,10 +138,15 @@ def test_raw_partials_form_equals_finalized_form(N):
     A = Blur2D(gauss_psf((9, 9), (3, 3))[0], N, N)
     rng = np.random.default_rng(N)
     b, x0, xt = rng.standard_normal(N * N), np.zeros(N * N), rng.standard_normal(N * N)
-    raw = CGLSRun(A, b, x0, 15, x_true=xt, history=True, defer_norms=True)
+    raw = CGLSRun(A, b, x0, 15, x_true=xt, history=True, defer_norms=True, grouping=grouping)
     fin = CGLSRun(A, b, x0, 15, x_true=xt, history=True, defer_norms=False)
-    assert raw.raw and not fin.raw
+    assert raw.raw and raw.grouping == grouping and not fin.raw
+    # the C loop and the stepwise driver enqueue the same launches: identical bits
+    twin = CGLSRun(A, b, x0, 15, x_true=xt, history=True, defer_norms=True, grouping=grouping)
+    for _ in range(15):
+        twin.step()
     raw.run(15)
+    assert np.array_equal(raw.rows()[1], twin.rows()[1]) and bool((raw.X[14] == twin.X[14]).all())
     for _ in range(15):
         fin.step()
     g0r, Rr = raw.rows()

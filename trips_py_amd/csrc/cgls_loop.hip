@@ -11,9 +11,24 @@ using namespace trk;
 
 extern "C" {
 
+// Which pair of kernels carries the updates between the operator applies of the raw-partials iteration:
+//   0: [x' = x + a p ; r -= a w] after A p, [p = t + b p] after A^T r           (36n bytes; trk_cgls_update_xr_src, trk_cgls_p_update)
+//   1: [r -= a w] after A p, [x' = x + a p ; p = t + b p] after A^T r            (32n bytes: p is read once; trk_cgls_r_update,
+//                                                                                 trk_cgls_xp_update)
+// Measured (iterations/s, 0 vs 1): 512^2 39.1 k vs 38.3 k, 1536^2 23.7 k vs 23.4 k | 3072^2 10.6 k vs 11.1 k, 3584^2 8.30 k vs
+// 8.72 k, 4096^2 6.85 k vs 7.26 k, 4608^2 5.48 k vs 5.70 k, 5120^2 4.45 k vs 4.36 k, 6144^2 2.82 k vs 2.74 k, 8192^2 1.53 k vs
+// 1.64 k: the saved pass pays from ~8 M unknowns on (small images are launch-bound and the five-stream kernel is the
+// slower one per byte).  TRK_CGLS_XP=0/1 overrides (tuning).
+int trk_cgls_update_grouping(int64_t n) {
+  static const int env = getenv("TRK_CGLS_XP") ? atoi(getenv("TRK_CGLS_XP")) : -1;
+  if (env >= 0) return env != 0;
+  return n >= ((int64_t)8 << 20) ? 1 : 0;
+}
+
 int trk_cgls_iterate(trk_op* A, int k_first, int n_iters, float* p, float* r, float* t, float* w, float* X, int64_t x_ld,
                      int keep_history, const float* x_prev, const float* x_true, double* S, double* NP,
-                     int np_capacity_blocks, int* n_np_inout, double* PG, double* PD, int pcap, trk_stream stream) {
+                     int np_capacity_blocks, int* n_np_inout, double* PG, double* PD, int pcap, int grouping,
+                     trk_stream stream) {
   TRK_REQUIRE(A && p && r && t && w && X && x_prev && S && NP && n_np_inout, "trk_cgls_iterate: NULL argument");
   TRK_REQUIRE(k_first >= 1 && n_iters >= 0, "trk_cgls_iterate: need k_first >= 1, n_iters >= 0");
   const int64_t m = A->rows, n = A->cols;
@@ -21,12 +36,27 @@ int trk_cgls_iterate(trk_op* A, int k_first, int n_iters, float* p, float* r, fl
   // raw-partials form: the operator leaves ||w||^2, ||t||^2 as block partials and the consumers add them up —
   // four launches per iteration instead of six (no reduction-finalize launches)
   const bool raw = PG && PD && pcap > 0 && A->apply_fused;
+  const bool xp_form = (grouping < 0 ? trk_cgls_update_grouping(n) : grouping) == 1;
   for (int k = k_first; k < k_first + n_iters; ++k) {
     double* row = S + 5 * (int64_t)k;                       // [delta, gamma, ||x||^2, ||dx||^2, ||x-xt||^2]
     double *delta = row, *gamma = row + 1;
     const double* gamma_old = (k == 1) ? S : row - 4;
     float* x_new = X + (int64_t)(keep_history ? (k - 1) : ((k - 1) & 1)) * x_ld;
     int rc;
+    if (raw && xp_form) {
+      int n_d = 0, n_g = 0;
+      rc = trk_op_apply_fused(A, 0, p, nullptr, 0.0, nullptr, 0, nullptr, 0, nullptr, w, PD, pcap, &n_d, stream);
+      if (rc) return rc;
+      rc = trk_cgls_r_update(m, gamma_old, PD, n_d, r, w, delta, stream);
+      if (rc) return rc;
+      rc = trk_op_apply_fused(A, 1, r, nullptr, 0.0, nullptr, 0, nullptr, 0, nullptr, t, PG, pcap, &n_g, stream);
+      if (rc) return rc;
+      rc = trk_cgls_xp_update(n, gamma_old, delta, PG, n_g, x_prev, p, t, x_new, x_true, gamma,
+                              NP + 3 * (int64_t)n_np * (k - 1), np_capacity_blocks, &n_np, stream);
+      if (rc) return rc;
+      x_prev = x_new;
+      continue;
+    }
     if (raw) {
       int n_d = 0, n_g = 0;
       rc = trk_op_apply_fused(A, 0, p, nullptr, 0.0, nullptr, 0, nullptr, 0, nullptr, w, PD, pcap, &n_d, stream);

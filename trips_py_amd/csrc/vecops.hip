@@ -315,6 +315,104 @@ __global__ __launch_bounds__(NT) void k_cgls_p_update(int64_t n, const float* __
   for (int64_t i = tail0 + tid; i < n; i += nth) p[i] = fmaf(1.f, t[i], b * p[i]);
 }
 
+// ------------------------------------------------------------------ CGLS residual update alone (CGLS.py:67)
+// r -= (gamma_old / S(delta)) w with delta possibly still the block partials of the forward kernel; block 0 publishes it.
+template <bool VEC>
+__global__ __launch_bounds__(NT) void k_cgls_r_update(int64_t m, const double* gold, ScalarSrc delta, float* r,
+                                                      const float* __restrict__ w, double* pub_delta, int nt) {
+  __shared__ double bc;
+  if (threadIdx.x < 64) {
+    const double d = scalar_from_wave(delta, threadIdx.x);
+    if (threadIdx.x == 0) {
+      bc = *gold / d;
+      if (blockIdx.x == 0 && pub_delta) *pub_delta = d;
+    }
+  }
+  __syncthreads();
+  const float step = (float)bc;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t m4 = m >> 2;
+    tail0 = m4 << 2;
+    for (int64_t i = tid; i < m4; i += nth) {
+      float4 rv = ld4(r, i);
+      const float4 wv = ld4(w, i);
+      rv.x = fmaf(-step, wv.x, rv.x);
+      rv.y = fmaf(-step, wv.y, rv.y);
+      rv.z = fmaf(-step, wv.z, rv.z);
+      rv.w = fmaf(-step, wv.w, rv.w);
+      if (nt & 4) st4_nt(r, i, rv); else st4(r, i, rv);
+    }
+  }
+  for (int64_t i = tail0 + tid; i < m; i += nth) r[i] = fmaf(-step, w[i], r[i]);
+}
+
+// ------------------------------------------------------------------ CGLS iterate + direction update in one pass over p
+// x_new = x + (gamma_old/delta) p (CGLS.py:64-65) and p = t + (S(gamma_new)/gamma_old) p (:72): p is read once for both
+// (20n bytes instead of 12n + 12n); norms as k_cgls_update: [block][3] raw partials; block 0 publishes gamma_new.
+template <bool HAS_XT>
+__global__ __launch_bounds__(NT) void k_cgls_xp_update(int64_t n, const double* gold, const double* delta, ScalarSrc gnew,
+                                                       const float* __restrict__ x, float* p, const float* __restrict__ t,
+                                                       float* __restrict__ x_new, const float* __restrict__ x_true,
+                                                       double* pub_gamma, double* __restrict__ partials, int nt) {
+  __shared__ double lds[NT / 64];
+  __shared__ double bc[2];
+  if (threadIdx.x < 64) {
+    const double g = scalar_from_wave(gnew, threadIdx.x);
+    if (threadIdx.x == 0) {
+      bc[0] = *gold / *delta;
+      bc[1] = g / *gold;
+      if (blockIdx.x == 0 && pub_gamma) *pub_gamma = g;
+    }
+  }
+  __syncthreads();
+  const float step = (float)bc[0], b = (float)bc[1];
+  double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  const int64_t n4 = n >> 2;
+  for (int64_t i = tid; i < n4; i += nth) {
+    const float4 xv = ld4(x, i), pv = ld4(p, i), tv = ld4(t, i);
+    const float4 d = make_float4(step * pv.x, step * pv.y, step * pv.z, step * pv.w);
+    const float4 xn = make_float4(xv.x + d.x, xv.y + d.y, xv.z + d.z, xv.w + d.w);
+    if (nt & 2) st4_nt(x_new, i, xn); else st4(x_new, i, xn);
+    float4 o;
+    o.x = fmaf(1.f, tv.x, b * pv.x);
+    o.y = fmaf(1.f, tv.y, b * pv.y);
+    o.z = fmaf(1.f, tv.z, b * pv.z);
+    o.w = fmaf(1.f, tv.w, b * pv.w);
+    if (nt & 8) st4_nt(p, i, o); else st4(p, i, o);
+    s0 += (double)xn.x * xn.x + (double)xn.y * xn.y + (double)xn.z * xn.z + (double)xn.w * xn.w;
+    s1 += (double)d.x * d.x + (double)d.y * d.y + (double)d.z * d.z + (double)d.w * d.w;
+    if (HAS_XT) {
+      const float4 tt = ld4(x_true, i);
+      const double e0 = (double)xn.x - tt.x, e1 = (double)xn.y - tt.y, e2 = (double)xn.z - tt.z, e3 = (double)xn.w - tt.w;
+      s2 += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+    }
+  }
+  for (int64_t i = (n4 << 2) + tid; i < n; i += nth) {
+    const float pv = p[i];
+    const float d = step * pv;
+    const float xn = x[i] + d;
+    x_new[i] = xn;
+    p[i] = fmaf(1.f, t[i], b * pv);
+    s0 += (double)xn * xn;
+    s1 += (double)d * d;
+    if (HAS_XT) {
+      const double e = (double)xn - x_true[i];
+      s2 += e * e;
+    }
+  }
+  s0 = block_sum<NT>(s0, lds);
+  s1 = block_sum<NT>(s1, lds);
+  if (HAS_XT) s2 = block_sum<NT>(s2, lds);
+  if (threadIdx.x == 0) {
+    partials[blockIdx.x * 3 + 0] = s0;
+    partials[blockIdx.x * 3 + 1] = s1;
+    partials[blockIdx.x * 3 + 2] = HAS_XT ? s2 : 0.0;
+  }
+}
+
 // ------------------------------------------------------------------ CGLS x-update of the fused fast path
 // x_new = x + (gamma/delta) p with gamma, delta possibly still block partials of the producing blur kernels; block 0
 // publishes the two finished scalars; the three norms are left as raw partials [block][3] (summed once, after the solve).
@@ -1170,6 +1268,40 @@ int trk_cgls_update_xr_deferred(int64_t n, int64_t m, const double* gamma, const
                                 double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream st) {
   return trk_cgls_update_xr_src(n, m, gamma, 1, delta, 1, x, p, x_new, r, w, x_true, nullptr, norm_partials,
                                 capacity_blocks, n_blocks, st);
+}
+
+int trk_cgls_r_update(int64_t m, const double* gamma_old, const double* delta, int delta_n, float* r, const float* w,
+                      double* publish_delta, trk_stream st) {
+  TRK_REQUIRE(gamma_old && delta && delta_n >= 1 && r && w && m >= 0, "trk_cgls_r_update: bad argument");
+  const int grid = stream_grid(m);
+  const ScalarSrc d{delta, delta_n};
+  hipStream_t s = (hipStream_t)st;
+  if (aligned16(r) && aligned16(w))
+    hipLaunchKernelGGL((k_cgls_r_update<true>), dim3(grid), dim3(NT), 0, s, m, gamma_old, d, r, w, publish_delta, stream_nontemporal(m));
+  else
+    hipLaunchKernelGGL((k_cgls_r_update<false>), dim3(grid), dim3(NT), 0, s, m, gamma_old, d, r, w, publish_delta, stream_nontemporal(m));
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_cgls_xp_update(int64_t n, const double* gamma_old, const double* delta, const double* gamma_new, int gamma_new_n,
+                       const float* x, float* p, const float* t, float* x_new, const float* x_true, double* publish_gamma,
+                       double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream st) {
+  TRK_REQUIRE(gamma_old && delta && gamma_new && gamma_new_n >= 1 && x && p && t && x_new && norm_partials && n_blocks && n >= 0,
+              "trk_cgls_xp_update: bad argument");
+  TRK_REQUIRE(aligned16(x) && aligned16(p) && aligned16(t) && aligned16(x_new) && (!x_true || aligned16(x_true)),
+              "trk_cgls_xp_update: vectors must be 16-byte aligned");
+  const int grid = stream_grid(n);
+  TRK_REQUIRE(grid <= capacity_blocks, "trk_cgls_xp_update: partial buffer too small (%d blocks needed)", grid);
+  *n_blocks = grid;
+  const ScalarSrc g{gamma_new, gamma_new_n};
+  hipStream_t s = (hipStream_t)st;
+  if (x_true)
+    hipLaunchKernelGGL((k_cgls_xp_update<true>), dim3(grid), dim3(NT), 0, s, n, gamma_old, delta, g, x, p, t, x_new, x_true, publish_gamma, norm_partials, stream_nontemporal(n));
+  else
+    hipLaunchKernelGGL((k_cgls_xp_update<false>), dim3(grid), dim3(NT), 0, s, n, gamma_old, delta, g, x, p, t, x_new, x_true, publish_gamma, norm_partials, stream_nontemporal(n));
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
 }
 
 int trk_cgls_p_update(int64_t n, const float* t, float* p, const double* gamma_new, int gamma_new_n,

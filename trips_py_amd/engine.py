@@ -275,6 +275,24 @@ class HipEngine:
         _lib.check(rc, "trk_cgls_update_xr_src")
         return n.value
 
+    def cgls_update_grouping(self, n):
+        """1: the raw-partials CGLS iteration regroups its updates as [r] / [x, p] (p read once) for vectors of n floats."""
+        return int(self.lib.trk_cgls_update_grouping(int(n)))
+
+    def cgls_r_update(self, gamma_old, delta, delta_n, r, w, pub_delta):
+        rc = self.lib.trk_cgls_r_update(r.numel(), _ptr(gamma_old), _ptr(delta), int(delta_n), r.data_ptr(), w.data_ptr(),
+                                        _ptr(pub_delta), self.stream())
+        _lib.check(rc, "trk_cgls_r_update")
+
+    def cgls_xp_update(self, gamma_old, delta, gamma_new, gamma_new_n, x, p, t, x_new, x_true, pub_gamma, partials, capacity):
+        n = ctypes.c_int(0)
+        rc = self.lib.trk_cgls_xp_update(x.numel(), _ptr(gamma_old), _ptr(delta), _ptr(gamma_new), int(gamma_new_n),
+                                         x.data_ptr(), p.data_ptr(), t.data_ptr(), x_new.data_ptr(),
+                                         None if x_true is None else x_true.data_ptr(), _ptr(pub_gamma), _ptr(partials),
+                                         int(capacity), ctypes.byref(n), self.stream())
+        _lib.check(rc, "trk_cgls_xp_update")
+        return n.value
+
     def cgls_p_update(self, t, p, gamma_new, gamma_new_n, gamma_old, pub_gamma):
         rc = self.lib.trk_cgls_p_update(p.numel(), t.data_ptr(), p.data_ptr(), _ptr(gamma_new), int(gamma_new_n),
                                         _ptr(gamma_old), _ptr(pub_gamma), self.stream())
@@ -290,14 +308,14 @@ class HipEngine:
         return n.value
 
     def cgls_iterate(self, handle, k_first, n_iters, p, r, t, w, X, keep, x_prev, x_true, S, NP, np_cap, n_np,
-                     PG=None, PD=None, pcap=0):
+                     PG=None, PD=None, pcap=0, grouping=-1):
         """n_iters generic CGLS iterations in one library call; returns the partial-block count.  PG / PD: buffers for the
         operator's raw ||t||^2 / ||w||^2 block partials (four launches per iteration instead of six)."""
         c = ctypes.c_int(int(n_np))
         rc = self.lib.trk_cgls_iterate(handle, int(k_first), int(n_iters), p.data_ptr(), r.data_ptr(), t.data_ptr(),
                                        w.data_ptr(), X.data_ptr(), X.stride(0), int(bool(keep)), x_prev.data_ptr(),
                                        None if x_true is None else x_true.data_ptr(), _ptr(S), _ptr(NP), int(np_cap),
-                                       ctypes.byref(c), _ptr(PG), _ptr(PD), int(pcap), self.stream())
+                                       ctypes.byref(c), _ptr(PG), _ptr(PD), int(pcap), int(grouping), self.stream())
         _lib.check(rc, "trk_cgls_iterate")
         return c.value
 

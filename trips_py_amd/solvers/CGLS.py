@@ -20,7 +20,7 @@ class CGLSRun:
 
     PCAP = 4096                            # room for an operator's raw block partials
 
-    def __init__(self, A, b, x0, max_iter, x_true=None, history=True, defer_norms=False):
+    def __init__(self, A, b, x0, max_iter, x_true=None, history=True, defer_norms=False, grouping=None):
         self.A = A = as_operator(A)
         self.eng = eng = A.engine
         m, n = A.shape
@@ -44,6 +44,8 @@ class CGLSRun:
         self.raw = (self.defer and hasattr(eng, "cgls_p_update") and hasattr(A, "_h") and eng.op_can_fuse(A._h))
         self.PG = eng.scalars(self.PCAP) if self.raw else None
         self.PD = eng.scalars(self.PCAP) if self.raw else None
+        # raw form only: 0 = [x, r] / [p] update kernels, 1 = [r] / [x, p] (p read once); None: the library's rule by size
+        self.grouping = (int(grouping) if grouping is not None else eng.cgls_update_grouping(n)) if self.raw else 0
         self._final = 0
         self.r, self.t, self.w, self.p = eng.empty(m), eng.empty(n), eng.empty(m), eng.empty(n)
         # scalar layout: S[0] = gamma_0 = ||t_0||^2 ; row k (1-based) at 5k: [delta, gamma, ||x||^2, ||dx||^2, ||x-xt||^2]
@@ -69,6 +71,15 @@ class CGLSRun:
         delta, gamma = S.ref(b), S.ref(b + 1)
         gamma_old = S.ref(0) if k == 1 else S.ref(b - 4)
         x_new = self.slot(k - 1)
+        if self.raw and self.grouping == 1:
+            # [r] after A p, [x, p] after A^T r: p is read once (trk_cgls_update_grouping: measured rule by size)
+            n_d = eng.op_apply_fused(A._h, False, self.p, None, 0.0, None, 0, None, 0, None, self.w, self.PD.ref(0), self.PCAP)
+            eng.cgls_r_update(gamma_old, self.PD.ref(0), n_d, self.r, self.w, delta)
+            n_g = eng.op_apply_fused(A._h, True, self.r, None, 0.0, None, 0, None, 0, None, self.t, self.PG.ref(0), self.PCAP)
+            self.n_np = eng.cgls_xp_update(gamma_old, delta, self.PG.ref(0), n_g, self.x_cur, self.p, self.t, x_new, self.xt,
+                                           gamma, self.NP.ref(3 * self.n_np * (k - 1)), 1024)
+            self.x_cur = x_new
+            return
         if self.raw:
             n_d = eng.op_apply_fused(A._h, False, self.p, None, 0.0, None, 0, None, 0, None, self.w, self.PD.ref(0), self.PCAP)
             self.n_np = eng.cgls_update_src(gamma_old, 1, self.PD.ref(0), n_d, self.x_cur, self.p, x_new, self.r, self.w,
@@ -102,7 +113,7 @@ class CGLSRun:
             self.n_np = eng.cgls_iterate(self.A._h, self.k + 1, n_steps, self.p, self.r, self.t, self.w, self.X, self.keep,
                                          self.x_cur, self.xt, self.S.ref(0), self.NP.ref(0), 1024, self.n_np,
                                          None if not self.raw else self.PG.ref(0), None if not self.raw else self.PD.ref(0),
-                                         self.PCAP if self.raw else 0)
+                                         self.PCAP if self.raw else 0, self.grouping)
             self.k += n_steps
             self.x_cur = self.slot(self.k - 1)
         else:
