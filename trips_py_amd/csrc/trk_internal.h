@@ -86,7 +86,8 @@ __device__ __forceinline__ double block_sum(double v, double* lds) {
 // n == 0: the constant 1 ; n == 1: *p ; n > 1: the sum of n block partials.  The sum is always formed the same way
 // (lane l of one wave adds p[l], p[l+64], ... then a wave64 tree), so every kernel that consumes the same partials
 // gets the bitwise same value, and no separate finalize launch is needed between producer and consumer.
-constexpr int64_t kNontemporalMinFloats = (int64_t)11 << 20;   // see stream_nontemporal()
+constexpr int64_t kNontemporalMinFloats = (int64_t)11 << 20;        // see stream_nontemporal()
+constexpr int64_t kNontemporalLoadsMinFloats = (int64_t)20 << 20;
 
 struct ScalarSrc {
   const double* p;
@@ -133,15 +134,20 @@ __device__ __forceinline__ double scalar_from_wave(const ScalarSrc s, int lane) 
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 
-// Which streamed outputs of n floats are stored non-temporally: bit 0 the blur kernel's output, bit 1 the new CGLS
-// iterate (bits 2, 3: the residual and the direction — measured, no gain).  Below the threshold the next kernel finds
-// the data in L2 / the 256 MB memory-side cache and ordinary stores are faster (2048^2 CGLS: 18.7 k vs 16.6 k
-// iterations/s with all four); above it they evict what the next kernels need.  4096^2: 6.68 k (none) / 6.73 k (blur) /
-// 6.81 k (iterate) / 6.87 k (both) / 6.84 k (all four) iterations/s; 5120^2: 3.93 k / 4.26 k / 3.93 k / 4.45 k / 4.45 k.
-// Crossover between 3072^2 (-1 %) and 3584^2 (+2 %).  TRK_NT=<mask> overrides (tuning).
+// Cache hints for the streamed vectors of the large-image CGLS loop, as a mask: stores — bit 0 the blur kernel's output,
+// bit 1 the new iterate x' (bits 2, 3: the residual and the direction: measured, no gain); loads in the [x, p] update —
+// bit 4 the old iterate x, bit 5 t = A^T r (both read exactly once).  What a kernel finds in the 256 MB memory-side
+// cache decides its speed, and everything that is not re-read soon only evicts what is:
+//   below ~11.5 M floats the next kernel finds plain-stored data cached and hints lose (2048^2: 18.7 k vs 16.6 k
+//   iterations/s with stores hinted; crossover between 3072^2, -1 %, and 3584^2, +2 %);
+//   4096^2: 6.68 k (none) / 6.73 k (blur) / 6.81 k (x') / 6.87 k (both) / 6.84 k (all four stores); load hints +-0;
+//   5120^2 (regrouped updates): 4.36 k (mask 3) -> 4.76 k (+x load) -> 4.77 k (+t load), the forward blur launch in the
+//   loop 51 -> 36 us; 6144^2: 2.78 k -> 3.01 k (79 -> 50 us); 8192^2: 1.59 k -> 1.70 k; 4608^2: 5.60 k -> 5.71 k.
+// TRK_NT=<mask> overrides (tuning).
 inline int stream_nontemporal(int64_t n) {
   static const int env = getenv("TRK_NT") ? atoi(getenv("TRK_NT")) : -1;
   if (env >= 0) return env;
+  if (n >= kNontemporalLoadsMinFloats) return 51;
   return n >= kNontemporalMinFloats ? 3 : 0;
 }
 

@@ -23,10 +23,12 @@ inline int stream_grid(int64_t n) {
 
 __device__ __forceinline__ float4 ld4(const float* p, int64_t i4) { return reinterpret_cast<const float4*>(p)[i4]; }
 __device__ __forceinline__ void st4(float* p, int64_t i4, float4 v) { reinterpret_cast<float4*>(p)[i4] = v; }
-// non-temporal store for outputs the same kernel never re-reads (CGLS x / r / p updates: -1 us of 61 / 31 us at n = 16.8 M;
-// non-temporal LOADS of the streamed inputs made the next blur kernel 6 us slower: its operand no longer sat in the
-// memory-side cache)
+// non-temporal accesses for vectors that are not re-read soon (which ones and from which size: stream_nontemporal())
 typedef float f4nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4_nt(const float* p, int64_t i4) {
+  const f4nt v = __builtin_nontemporal_load(reinterpret_cast<const f4nt*>(p) + i4);
+  return make_float4(v[0], v[1], v[2], v[3]);
+}
 __device__ __forceinline__ void st4_nt(float* p, int64_t i4, float4 v) {
   __builtin_nontemporal_store((f4nt){v.x, v.y, v.z, v.w}, reinterpret_cast<f4nt*>(p) + i4);
 }
@@ -372,7 +374,7 @@ __global__ __launch_bounds__(NT) void k_cgls_xp_update(int64_t n, const double* 
   const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
   const int64_t n4 = n >> 2;
   for (int64_t i = tid; i < n4; i += nth) {
-    const float4 xv = ld4(x, i), pv = ld4(p, i), tv = ld4(t, i);
+    const float4 xv = (nt & 16) ? ld4_nt(x, i) : ld4(x, i), pv = ld4(p, i), tv = (nt & 32) ? ld4_nt(t, i) : ld4(t, i);
     const float4 d = make_float4(step * pv.x, step * pv.y, step * pv.z, step * pv.w);
     const float4 xn = make_float4(xv.x + d.x, xv.y + d.y, xv.z + d.z, xv.w + d.w);
     if (nt & 2) st4_nt(x_new, i, xn); else st4(x_new, i, xn);
