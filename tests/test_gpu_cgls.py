@@ -71,7 +71,7 @@ def test_cgls_config_c2_512_against_oracle_and_history_off():
 
 @pytest.mark.parametrize("N", [64, 256, 1000])
 def test_fused_and_unfused_cgls_agree(N):
-    """The three-launch fused path (trk_op_apply_fused / trk_cgls_x_update) against the generic seven-launch path."""
+    """The three-launch fused path (trk_op_apply_fused / trk_cgls_x_update) against the generic path (four launches with raw partials)."""
     from trips_py_amd.operators import Blur2D
     from trips_py_amd.problems import add_noise, gauss_psf, synthetic_image
     from trips_py_amd.solvers import CGLS, CGLSRunFused

@@ -1,7 +1,7 @@
 // cgls_loop.hip — whole stretches of CGLS iterations enqueued by ONE library call.
 //
 // With tol = 0 the recurrence of trips/solvers/CGLS.py:56-80 never needs a value on the host, so nothing but call
-// overhead separates consecutive kernels.  Driving the 3-7 launches of an iteration from Python costs ~10 us of
+// overhead separates consecutive kernels.  Driving the 3-6 launches of an iteration from Python costs ~10 us of
 // interpreter + ctypes time per launch — more than the kernels themselves for images up to ~1024^2 (a 512^2 blur runs in
 // 3 us).  These two entry points run the same launch sequence as trips_py_amd.solvers.CGLS.CGLSRun.step /
 // CGLSRunFused.step in a C loop (same kernels, same scalar layout, bit-identical results), leaving one call per solve.
