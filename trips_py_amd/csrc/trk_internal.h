@@ -143,12 +143,14 @@ inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 //   4096^2: 6.68 k (none) / 6.73 k (blur) / 6.81 k (x') / 6.87 k (both) / 6.84 k (all four stores); load hints +-0;
 //   5120^2 (regrouped updates): 4.36 k (mask 3) -> 4.76 k (+x load) -> 4.77 k (+t load), the forward blur launch in the
 //   loop 51 -> 36 us; 6144^2: 2.78 k -> 3.01 k (79 -> 50 us); 8192^2: 1.59 k -> 1.70 k; 4608^2: 5.60 k -> 5.71 k.
+// Bits 6, 7: the basis rows read by k_gemv_t / k_gemv_n (k x 4n bytes streamed once per kernel; hinted, they stop evicting
+// the vector every row tile re-reads): 4096^2 GKS 343 -> 372, Hybrid-GMRES 907 -> 1001, MMGKS 331 -> 342 iterations/s.
 // TRK_NT=<mask> overrides (tuning).
 inline int stream_nontemporal(int64_t n) {
   static const int env = getenv("TRK_NT") ? atoi(getenv("TRK_NT")) : -1;
   if (env >= 0) return env;
-  if (n >= kNontemporalLoadsMinFloats) return 51;
-  return n >= kNontemporalMinFloats ? 3 : 0;
+  if (n >= kNontemporalLoadsMinFloats) return 51 | 192;
+  return n >= kNontemporalMinFloats ? (3 | 192) : 0;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

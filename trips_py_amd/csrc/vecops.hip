@@ -483,7 +483,7 @@ constexpr int JT = 8;
 template <int WPOW, bool VEC>
 __global__ __launch_bounds__(NT) void k_gemv_t(const float* __restrict__ V, int64_t ld, int k, int64_t n,
                                                const float* __restrict__ r, const float* __restrict__ w,
-                                               double* __restrict__ partials) {
+                                               double* __restrict__ partials, int nt) {
   __shared__ double lds[NT / 64];
   const int j0 = blockIdx.y * JT;
   const int jn = (k - j0 < JT) ? (k - j0) : JT;
@@ -513,7 +513,7 @@ __global__ __launch_bounds__(NT) void k_gemv_t(const float* __restrict__ V, int6
 #pragma unroll
       for (int j = 0; j < JT; ++j) {
         if (j < jn) {
-          float4 v = ld4(V + (int64_t)(j0 + j) * ld, i);
+          float4 v = (nt & 64) ? ld4_nt(V + (int64_t)(j0 + j) * ld, i) : ld4(V + (int64_t)(j0 + j) * ld, i);
           acc[j] += (double)v.x * rv.x + (double)v.y * rv.y + (double)v.z * rv.z + (double)v.w * rv.w;
         }
       }
@@ -547,7 +547,7 @@ int launch_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, 
   if (int rc = scratch_doubles(s, (size_t)bx * k, &part)) return rc;
   const bool vec = aligned16(V) && aligned16(r) && (ld % 4 == 0) && (!wpow || aligned16(w));
   dim3 grid(bx, ntile);
-#define GT(WP, VC) hipLaunchKernelGGL((k_gemv_t<WP, VC>), grid, dim3(NT), 0, s, V, ld, k, n, r, w, part)
+#define GT(WP, VC) hipLaunchKernelGGL((k_gemv_t<WP, VC>), grid, dim3(NT), 0, s, V, ld, k, n, r, w, part, stream_nontemporal(n))
   if (wpow == 0) { if (vec) GT(0, true); else GT(0, false); }
   else if (wpow == 1) { if (vec) GT(1, true); else GT(1, false); }
   else { if (vec) GT(2, true); else GT(2, false); }
@@ -564,7 +564,7 @@ template <bool HAS_BASE, bool SUMSQ, bool VEC, bool HAS_REF = false>
 __global__ __launch_bounds__(NT) void k_gemv_n(const float* __restrict__ V, int64_t ld, int k, int64_t n,
                                                const double* __restrict__ y, double a, const float* base, double sc,
                                                float* out, double* __restrict__ partials,
-                                               const float* __restrict__ ref = nullptr) {
+                                               const float* __restrict__ ref = nullptr, int nt = 0) {
   __shared__ double ys[KMAX_LDS];
   __shared__ double lds[NT / 64];
   for (int j = threadIdx.x; j < k; j += NT) ys[j] = sc * y[j];
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(NT) void k_gemv_n(const float* __restrict__ V, int6
       }
 #pragma unroll 4
       for (int j = 0; j < k; ++j) {
-        const float4 v = ld4(V + (int64_t)j * ld, i);
+        const float4 v = (nt & 128) ? ld4_nt(V + (int64_t)j * ld, i) : ld4(V + (int64_t)j * ld, i);
         const double c = ys[j];
         o0 = fma(c, (double)v.x, o0);
         o1 = fma(c, (double)v.y, o1);
@@ -1356,7 +1356,7 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, do
   if (sumsq)
     if (int rc = scratch_doubles(s, grid, &part)) return rc;
   const bool vec = aligned16(V) && aligned16(out) && (ld % 4 == 0) && (!base || aligned16(base));
-#define GN(HB, SS, VC) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, y, a, base, sc, out, part)
+#define GN(HB, SS, VC) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, y, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n))
   if (base) {
     if (sumsq) { if (vec) GN(true, true, true); else GN(true, true, false); }
     else       { if (vec) GN(true, false, true); else GN(true, false, false); }
