@@ -273,3 +273,58 @@ def test_gemv_n_err_partials(k, n):
     want = float(np.sum((out.cpu().numpy().astype(np.float64) - ref.cpu().numpy().astype(np.float64)) ** 2))
     got = E.host()
     assert abs(got[0] - want) <= 1e-12 * want and got[0] == got[1]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("groups,glen,copies,expo", [(1, 1, 1, -0.5), (37, 3, 3, -0.5), (1000, 7, 2, -0.75), (5000, 32, 1, 0.0)])
+def test_group_weights(groups, glen, copies, expo):
+    """trk_group_weights: (sum of squares over each group of consecutive entries + add)^expo, tiled `copies` times."""
+    import torch
+    from trips_py_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(groups + glen)
+    d = rng.standard_normal(groups * glen).astype(np.float32)
+    dd = torch.from_numpy(d).to(eng.device)
+    out = eng.empty(groups * copies)
+    add = float(np.exp(2))
+    eng.group_weights(dd, groups, glen, add, expo, copies, out)
+    want = np.tile(((d.astype(np.float64).reshape(groups, glen) ** 2).sum(axis=1) + add) ** expo, copies)
+    assert np.allclose(out.cpu().numpy(), want, rtol=2e-7, atol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,with_xt", [(8, False), (4099 * 4, True), (100_000, True)])
+def test_cgls_regrouped_update_kernels(n, with_xt):
+    """trk_cgls_r_update and trk_cgls_xp_update against the formulas of CGLS.py:64-72 (scalars as block partials)."""
+    import torch
+    from trips_py_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(n)
+    f = lambda: torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(eng.device)
+    x, p, t, r, w, xt = f(), f(), f(), f(), f(), f()
+    x_new = eng.empty(n)
+    S = eng.scalars(8)                      # [gamma_old, delta_pub, gamma_pub]
+    parts = rng.random(5) + 0.1             # block partials of delta / gamma_new
+    PD, PG = eng.scalars(5), eng.scalars(5)
+    PD.set(0, parts)
+    PG.set(0, parts[::-1] * 2.0)
+    S.set(0, [1.7])
+    delta, gnew, gold = parts.sum(), (parts[::-1] * 2.0).sum(), 1.7
+    r0, p0 = r.cpu().numpy().copy(), p.cpu().numpy().copy()
+    eng.cgls_r_update(S.ref(0), PD.ref(0), 5, r, w, S.ref(1))
+    step = np.float32(gold / delta)
+    assert np.allclose(r.cpu().numpy(), r0 - step * w.cpu().numpy(), rtol=1e-6, atol=1e-6)
+    NP = eng.scalars(3 * 1024)
+    nb = eng.cgls_xp_update(S.ref(0), S.ref(1), PG.ref(0), 5, x, p, t, x_new, xt if with_xt else None, S.ref(2), NP.ref(0), 1024)
+    sh = S.host(0, 3)
+    assert abs(sh[1] - delta) <= 1e-14 * delta and abs(sh[2] - gnew) <= 1e-14 * gnew
+    xn = x.cpu().numpy() + step * p0
+    assert np.allclose(x_new.cpu().numpy(), xn, rtol=1e-6, atol=1e-6)
+    beta = np.float32(gnew / gold)
+    assert np.allclose(p.cpu().numpy(), t.cpu().numpy() + beta * p0, rtol=1e-6, atol=1e-6)
+    sums = NP.host(0, 3 * nb).reshape(nb, 3).sum(axis=0)
+    xn64 = x_new.cpu().numpy().astype(np.float64)
+    assert abs(sums[0] - (xn64 ** 2).sum()) <= 1e-10 * (xn64 ** 2).sum()
+    if with_xt:
+        e = ((xn64 - xt.cpu().numpy()) ** 2).sum()
+        assert abs(sums[2] - e) <= 1e-10 * e
