@@ -2,7 +2,11 @@
 """bench.py — Krylov iterations/second on the 4096 x 4096 blur, with the blur-matvec HBM roofline and a same-box
 CPU baseline, as one JSON line (driver contract).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Either a launcher started the ranks (`python -m torch.distributed.run --nproc-per-node N ...
+bench.py --gpus N`: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment), or — plain `python bench.py --gpus N`
+— this process starts them itself as child processes of torch.distributed.run before anything has touched the GPU.
 
 A "step" is one Krylov iteration of the workload's solver on one batch of synthetic input (generated on the GPU,
 resident in HBM before the timed region).  Static single-image problems do not shard (replicas only):
@@ -45,6 +49,31 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` (N > 1) outside a torch.distributed launcher: start the N ranks as CHILD processes of
+    torch.distributed.run and leave with their exit code.  Nothing in this process has touched the GPU yet (no
+    torch.cuda call that initialises HIP, libtrk not loaded), and the launcher is a child, never an exec."""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    import socket
+    import subprocess
+    single = bool(os.environ.get("TRK_SINGLE_DEVICE"))
+    have = torch.cuda.device_count()                  # counts devices without initialising the runtime
+    if have < args.gpus and not single:
+        print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible "
+              "(TRK_SINGLE_DEVICE=1 TRK_DIST_BACKEND=gloo runs all ranks on one GPU for debugging)", file=sys.stderr)
+        sys.exit(2)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def dist_setup(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -62,9 +91,31 @@ def dist_setup(args):
             dist.init_process_group(backend=backend)
     else:
         torch.cuda.set_device(0)
-    if world != args.gpus and rank == 0:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     return rank, world
+
+
+def comm_check(rank, world):
+    """What the communicator really is: the rank count torch.distributed reports and one all-reduced double
+    (sum of rank + 1 over ranks = world (world + 1) / 2) over the backend in use (nccl = RCCL over xGMI)."""
+    if world == 1:
+        return {"ranks_seen": 1, "backend": None, "allreduce_check": 1.0, "allreduce_expected": 1.0}
+    import torch.distributed as dist
+    nccl = dist.get_backend() == "nccl"
+    t = torch.tensor([rank + 1.0], dtype=torch.float64, device="cuda" if nccl else "cpu")
+    dist.all_reduce(t)
+    out = {"ranks_seen": dist.get_world_size(), "backend": "rccl (torch nccl)" if nccl else dist.get_backend(),
+           "allreduce_check": float(t.item()), "allreduce_expected": world * (world + 1) / 2.0}
+    if nccl:                                           # latency of the one-double all-reduce the sharded solvers issue
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(200):
+            dist.all_reduce(t)
+        torch.cuda.synchronize()
+        out["allreduce_1double_us"] = round((time.perf_counter() - t0) / 200 * 1e6, 2)
+    return out
 
 
 def barrier(world):
@@ -200,7 +251,8 @@ def run_blur_cgls(args, rank, world):
                                     if getattr(run, "raw", False) else "generic: 6 launches"),
                       "parallelism": "replicas" if world > 1 else "single"},
            "roofline": roofline,
-           "extra": {"relError_after_timed_iters": float(torch.linalg.norm(run.x_cur - x_true) / torch.linalg.norm(x_true)),
+           "extra": {"comm": comm_check(rank, world),
+                     "relError_after_timed_iters": float(torch.linalg.norm(run.x_cur - x_true) / torch.linalg.norm(x_true)),
                      "cgls_alg_bytes_per_iter": 44.0 * n,
                      "cgls_effective_GBps": round(44.0 * n * K / elapsed / 1e9, 1)}}
 
@@ -352,14 +404,17 @@ def extra_c4_mmgks(A, b, N, world):
 
 def extra_c5_dynamic(rank, world):
     """BASELINE config C5 (dynamic parallel-beam tomography, 256^2 frames, 15 angles per frame shifted by 1 degree per
-    frame, space-time derivative): frames sharded over ranks, 4 frames per rank (weak; 8 ranks = the 32-frame config),
-    global inner products all-reduced over RCCL, one-frame halo exchange for the temporal rows."""
+    frame, space-time derivative) at its BASELINE size: 32 frames in all, 32 / world per rank (STRONG scaling: the same
+    problem at every N, also N = 1), global inner products all-reduced over RCCL, one-frame halo exchange for the temporal
+    rows of the regulariser."""
     from trips_py_amd.dist import TorchComm, frame_range
     from trips_py_amd.engine import HipEngine
     from trips_py_amd.operators import BlockDiagOp, Radon2DParallel, SpaceTimeDerivative
     from trips_py_amd.solvers import CGLS, GKS
-    Nf, per_rank, na = 256, 4, 15
-    nt = per_rank * world
+    Nf, nt, na = 256, 32, 15
+    if nt % world:
+        return {"skipped": f"32 frames do not divide over {world} ranks"}
+    per_rank = nt // world
     eng = HipEngine(comm=TorchComm()) if world > 1 else HipEngine()
     lo, hi = frame_range(nt, world, rank)
     ops = [Radon2DParallel(Nf, np.deg2rad(t + 12.0 * np.arange(na)), engine=eng) for t in range(lo, hi)]
@@ -377,7 +432,8 @@ def extra_c5_dynamic(rank, world):
     e = torch.randn(bl.numel(), device=eng.device, generator=torch.Generator(device=eng.device).manual_seed(77 + rank))
     bl = bl + e * (0.01 * torch.linalg.norm(bl) / torch.linalg.norm(e))
     x0 = torch.zeros(F.shape[1], device=eng.device)
-    out = {"frames_total": nt, "frames_per_rank": per_rank, "frame": f"{Nf}x{Nf}", "angles_per_frame": na}
+    out = {"frames_total": nt, "frames_per_rank": per_rank, "frame": f"{Nf}x{Nf}", "angles_per_frame": na,
+           "scaling": "strong", "ranks": world}
     CGLS(F, bl, x0, 5, 0, history=False)
     barrier(world)
     t0 = time.perf_counter()
@@ -427,6 +483,7 @@ def cpu_baseline_cgls(psf, N, b_dev, iters):
 
 def main():
     args = parse()
+    spawn_ranks_if_needed(args)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the engine has no CPU fallback)", file=sys.stderr)
         sys.exit(2)

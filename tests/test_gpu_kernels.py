@@ -94,6 +94,19 @@ def test_mm_weights_and_mul(eng, p, eps):
     assert np.allclose(out.cpu().numpy(), (f32(x) * f32(y)).astype(np.float32), rtol=1e-7)
 
 
+@pytest.mark.parametrize("key,eps,p", [("holder_eps0.1_p1", 0.1, 1.0), ("holder_eps0.01_p0.5", 0.01, 0.5),
+                                       ("holder_eps0.1_p2", 0.1, 2.0)])
+def test_mm_weights_reference_golden(eng, key, eps, p):
+    """The reference's own smoothed_holder_weights values (weights.py:66-68), tests/golden/deriv_ops.npz."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "deriv_ops.npz"))
+    u = g["holder_u"]
+    du, out = dev(eng, u), eng.empty(u.size)
+    eng.mm_weights(du, None, eps, p, out)
+    # the kernel sees u rounded to fp32: the weight's sensitivity to that rounding is part of the bar
+    assert np.allclose(out.cpu().numpy(), g[key], rtol=1e-5)
+
+
 @pytest.mark.parametrize("n,m", [(1000, 1000), (4099, 777), (262144, 92160)])
 def test_cgls_update(eng, n, m):
     rng = np.random.default_rng(n + m)

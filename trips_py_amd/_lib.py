@@ -73,27 +73,46 @@ def build(force=False, verbose=False):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
+def _file_hash(paths, extra=""):
+    import hashlib
+    h = hashlib.sha256(extra.encode())
+    for path in paths:
+        h.update(os.path.basename(path).encode())
+        with open(path, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
+
+
 def _build_locked(force, verbose):
     hipcc = _hipcc()
     srcs = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + [os.path.join(INCLUDE, "trk.h")]
 
     def cc(src):
+        # an object is reused only if the CONTENT of its source, of every header and the flags are what it was built
+        # from (modification times mean nothing in a copied tree)
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
-        if not force and os.path.exists(obj):
-            newest = max(os.path.getmtime(os.path.join(CSRC, f)) for f in os.listdir(CSRC) if f.endswith(".h"))
-            newest = max(newest, os.path.getmtime(os.path.join(CSRC, src)), os.path.getmtime(os.path.join(INCLUDE, "trk.h")))
-            if os.path.getmtime(obj) > newest:
-                return obj
+        key = _file_hash([os.path.join(CSRC, src)] + headers, " ".join(HIPCC_FLAGS[:-2]))
+        if not force and os.path.exists(obj) and os.path.exists(obj + ".stamp"):
+            with open(obj + ".stamp") as fh:
+                if fh.read().strip() == key:
+                    return obj
         cmd = [hipcc] + HIPCC_FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
+        if os.path.exists(obj + ".stamp"):
+            os.unlink(obj + ".stamp")
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise TrkError(f"hipcc failed on {src}:\n{r.stdout}\n{r.stderr}")
+        with open(obj + ".stamp", "w") as fh:
+            fh.write(key + "\n")
         return obj
 
     with ThreadPoolExecutor(max_workers=min(4, len(srcs))) as ex:
         objs = list(ex.map(cc, srcs))
+    if os.path.exists(STAMP_PATH):
+        os.unlink(STAMP_PATH)
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
@@ -188,11 +207,14 @@ def load():
     # process, so that torch's streams / allocations and libtrk's kernels live in one runtime.
     import torch  # noqa: F401
     if _stale():
+        # a stale library is never loaded silently: either the rebuild succeeds or the caller hears about it
+        # (TRK_ALLOW_STALE=1: load what is there, with a warning - for boxes without hipcc)
         try:
             build()
-        except TrkError:
-            if not os.path.exists(LIB_PATH):
-                raise
+        except TrkError as exc:
+            if not os.path.exists(LIB_PATH) or os.environ.get("TRK_ALLOW_STALE", "0") != "1":
+                raise TrkError(f"libtrk.so is out of date with its sources and could not be rebuilt: {exc}") from exc
+            print(f"trips_py_amd: WARNING: loading a STALE libtrk.so (TRK_ALLOW_STALE=1): {exc}", file=sys.stderr)
     if not os.path.exists(LIB_PATH):
         raise TrkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
                        "There is no CPU fallback for the engine.")

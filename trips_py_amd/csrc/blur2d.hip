@@ -308,11 +308,8 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
   const auto rcomb = __builtin_amdgcn_make_buffer_rsrc((void*)(FUSE ? fz.comb : y), 0, img_bytes, 0x00020000);
   float cb = 0.f;
   if (FUSE) cb = (fz.sign == 0.0) ? 0.f : (float)(fz.sign * scalar_from_wave(fz.num, threadIdx.x) / scalar_from_wave(fz.den, threadIdx.x));
-  int vl = cl * 4, vr = cr * 4;
+  const int vl = cl * 4, vr = cr * 4;
   const int vc = cc * 4;
-#ifdef TRK_EXPERIMENT_NOLR
-  vl = vc; vr = vc;   // timing experiment only (wrong results): price of the left/right neighbour loads
-#endif
   const int vst = c0 * 4;
 
   // Odd bands march UPWARD (from their bottom halo to their top), even bands downward: the halo rows two neighbouring
@@ -565,7 +562,7 @@ inline void slide_grid(int nx, int ny, int batch, int kh, int U, int* spans_x, i
 
 inline bool slide_shape_ok(const BlurImpl* im) {
   return im->separable && im->kh == im->kw && (im->kh & 1) && im->kh >= 3 && im->kh <= 9 && (im->ny & 3) == 0 &&
-         im->ny >= 8 && (int64_t)im->nx * im->ny < ((int64_t)1 << 30);
+         im->ny >= 8 && (int64_t)im->nx * im->ny < ((int64_t)1 << 29);   // byte offsets are 32-bit signed ints in the kernel
 }
 
 // y = A (x1 + cb * x2), comb written out, sum(y^2) as raw partials (CGLS fast path; 9x9-class separable PSFs only)

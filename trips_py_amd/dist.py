@@ -39,15 +39,19 @@ class TorchComm:
         sbuf = (send.detach().to("cpu") if stage else send.contiguous()) if do_send else None
         rbuf = (torch.empty(recv.shape, dtype=recv.dtype) if stage else recv) if do_recv else None
         ops = []
+        # P2POp peers are GLOBAL ranks; send_to / recv_from are ranks of this communicator's group
         if do_send:
-            ops.append(dist.P2POp(dist.isend, sbuf, send_to, self.group))
+            ops.append(dist.P2POp(dist.isend, sbuf, self._global(send_to), self.group))
         if do_recv:
-            ops.append(dist.P2POp(dist.irecv, rbuf, recv_from, self.group))
+            ops.append(dist.P2POp(dist.irecv, rbuf, self._global(recv_from), self.group))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
         if do_recv and stage:
             recv.copy_(rbuf)
+
+    def _global(self, group_rank):
+        return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
 
     def barrier(self):
         dist.barrier(group=self.group)

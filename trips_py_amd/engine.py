@@ -129,6 +129,11 @@ class HipEngine:
         self.lib = _lib.load()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if self.device.type != "cuda" or self._dev_index != torch.cuda.current_device():
+            # libtrk allocates operator tables / scratch on the process's CURRENT device (one process per GPU is the
+            # deployment model): an engine on any other device would put them on the wrong GPU
+            raise ValueError(f"HipEngine(device={self.device}) must be the current device "
+                             f"(cuda:{torch.cuda.current_device()}); call torch.cuda.set_device() first")
         self.comm = comm
         self.world = 1 if comm is None else comm.world
         self.rank = 0 if comm is None else comm.rank
