@@ -149,6 +149,13 @@ int trk_mm_weights(int64_t n, const float* x, const float* y, double eps, double
  * c < copies — one weight per group of consecutive entries, tiled `copies` times. */
 int trk_group_weights(const float* d, int64_t groups, int group_len, double add, double expo, int copies, float* out,
                       trk_stream stream);
+/* Isotropic-TV weights of MMGKS (MMGKS.py:61-77 = trips/utilities/weights.py:29-40).  x: the flat iterate, viewed as
+ * X[N][N][nt] (t fastest: `x.reshape(nx**2, nt)`, :71); g1, g2: the centered first derivatives of operators_old.py:22-45
+ * (pylops.FirstDerivative, zero first/last row) along j and i.  out[idx] = out[N*N*nt + idx] =
+ * (g1^2 + g2^2 + eps^2)^((q-2)/4) (:75-76), then out[2*N*N*nt + k] = (u_tail[k]^2 + eps^2)^((q-2)/4) for the n_tail temporal
+ * rows of L x (:77).  out: 2*N*N*nt + n_tail floats. */
+int trk_isotv_weights(const float* x, int N, int nt, const float* u_tail, int64_t n_tail, double eps, double q, float* out,
+                      trk_stream stream);
 
 /* One fused CGLS vector update (CGLS.py:64-67):  step = *gamma / *delta ;
  *   x_new = x + step*p ; r = r - step*w ;  sums_dev[0] = ||x_new||^2, sums_dev[1] = ||step*p||^2

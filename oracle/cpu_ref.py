@@ -22,6 +22,11 @@ Pinning status
     reproducible output at that boundary).  `Radon2D` follows the call-site contract
     of trips/utilities/io.py:392-399 with a Joseph (linear-interpolation) projector;
     it is pinned only by the adjoint identity and analytic line integrals.
+  * MMGKS isoTV weights (MMGKS.py:61-77): PARITY UNPINNED in the one piece that lives in
+    PyLops (un-pinned, setup.py:6; absent): `pylops.FirstDerivative`'s centered stencil is
+    restated from its published definition.  Everything around it (reshape, exponent,
+    weight layout, solver loop) is checked against goldens made by running the reference's
+    own MMGKS.py / operators_old.py over that same restatement (tools/oracle_shim).
 
 Every function cites the reference lines it follows (paths relative to /root/reference).
 """
@@ -734,7 +739,7 @@ def gks(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, delta
 
 
 # =====================================================================================
-# a12 MMGKS (plain smoothed-Holder weights and group-sparsity branches)   trips/solvers/MMGKS.py:28-137
+# a12 MMGKS (plain smoothed-Holder weights, group-sparsity and isoTV branches)   trips/solvers/MMGKS.py:28-137
 # =====================================================================================
 def old_first_derivative_matrix(n):
     """trips/utilities/operators_old.py:66-72: rows 0..n-2 of I - subdiag(1), i.e. row 0 = x[0], row i = x[i] - x[i-1]."""
@@ -759,8 +764,59 @@ def group_sparsity_weights(x, Ls, nx, ny, qnorm):
     return np.kron(np.ones((nt, 1)), wr.reshape(-1, 1))
 
 
+# ---- isoTV branch (MMGKS.py:61-77).  PARITY UNPINNED: its spatial operator is operators_old.py:22-45, built from
+# pylops.FirstDerivative / Kronecker / VStack; PyLops is an un-pinned dependency of the reference (setup.py:6) that is
+# absent from /root/reference and not installable here.  What follows restates PyLops' PUBLISHED semantics:
+# FirstDerivative(n) default = centered 3-point stencil, y[i] = (x[i+1] - x[i-1]) / 2 for 1 <= i <= n-2, first and last
+# row zero (edge=False); Kronecker(A, B) = kron(A, B); VStack = row stacking.  (PyLops creates FirstDerivative's output
+# in the operator's dtype, float32 at operators_old.py:31; the restatement stays in float64 — a 6e-8 relative rounding
+# of the products with L that is part of the stated tolerance.)
+def pylops_first_derivative_matrix(n):
+    import scipy.sparse as sp
+    D = sp.lil_matrix((n, n))
+    for i in range(1, n - 1):
+        D[i, i - 1], D[i, i + 1] = -0.5, 0.5
+    return D.tocsr()
+
+
+def old_first_derivative_operator_2d(nx, ny):
+    """operators_old.py:35-45: VStack(Kronecker(I_nx, D_nx), Kronecker(D_ny, I_ny)) — (nx^2 + ny^2) x nx^2, needs nx = ny."""
+    import scipy.sparse as sp
+    Dx, Dy = pylops_first_derivative_matrix(nx), pylops_first_derivative_matrix(ny)
+    return sp.vstack((sp.kron(sp.identity(nx), Dx), sp.kron(Dy, sp.identity(ny)))).tocsr()
+
+
+def old_spatial_derivative_operator(nx, ny, nt):
+    """operators_old.py:47-53: Kronecker(I_nt, D_spatial)."""
+    import scipy.sparse as sp
+    return sp.kron(sp.identity(nt), old_first_derivative_operator_2d(nx, ny)).tocsr()
+
+
+def old_time_derivative_operator(nx, ny, nt):
+    """operators_old.py:55-61: Kronecker(D_nt, I_{nx^2})."""
+    import scipy.sparse as sp
+    return sp.kron(pylops_first_derivative_matrix(nt), sp.identity(nx ** 2)).tocsr()
+
+
+def iso_tv_weights(x, u, nx, ny, epsilon, qnorm):
+    """MMGKS.py:61-77 (= weights.py:29-40), literally: the frame-major iterate is reshaped (nx^2, nt) in C order (:71), the
+    two directional derivatives of that array share one weight (LsX1^2 + LsX2^2 + eps^2)^((q-2)/4) (:75: exponent (q-2)/4,
+    sic), laid out as [weightx.flatten(); weightx.flatten()] (:76) in front of the temporal weights of u[2*spacen*nt:]
+    (:77) — whatever row order the caller's L has."""
+    x = np.asarray(x, dtype=np.float64)
+    nt = int(x.reshape(-1, 1).shape[0] / (nx * ny))
+    Ls = old_first_derivative_operator_2d(nx, ny)
+    spacen = int(Ls.shape[0] / 2)
+    spacent = spacen * nt
+    LsX = Ls @ x.reshape(nx ** 2, nt)
+    wx = (LsX[:spacen, :] ** 2 + LsX[spacen:2 * spacen, :] ** 2 + epsilon ** 2) ** ((qnorm - 2) / 4)
+    wx = np.concatenate((wx.flatten(), wx.flatten()))
+    wt = (np.asarray(u, dtype=np.float64).reshape(-1, 1)[2 * spacent:] ** 2 + epsilon ** 2) ** ((qnorm - 2) / 4)
+    return np.concatenate((wx.reshape(-1, 1), wt))
+
+
 def mmgks(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv", x_true=None,
-          epsilon=0.1, delta=None, eta=1.01, GS=False, prob_dims=None):
+          epsilon=0.1, delta=None, eta=1.01, GS=False, prob_dims=None, isoTV=False):
     b = np.asarray(b, dtype=np.float64).reshape(-1, 1)
     _, _, V = golub_kahan(A, b, projection_dim)
     x = A.T @ b                                                  # :43
@@ -778,7 +834,9 @@ def mmgks(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         its = ii
         wf = smoothed_holder_weights(A @ x - b, epsilon, pnorm)          # :56-57
         Q_A, R_A = sla.qr(AV * wf, mode="economic")
-        if GS:
+        if isoTV:                                                # tested BEFORE the GS option (:61 / :78)
+            wr = iso_tv_weights(x, L @ x, prob_dims[0], prob_dims[1], epsilon, qnorm)
+        elif GS:
             wr = group_sparsity_weights(x, Ls, prob_dims[0], prob_dims[1], qnorm)   # :78-91
         else:
             wr = smoothed_holder_weights(L @ x, epsilon, qnorm).reshape(-1, 1)   # :60,93

@@ -145,6 +145,18 @@ class CpuEngine:
         w = ((D ** 2).sum(axis=1) + add) ** expo
         out.copy_(torch.from_numpy(np.tile(w, copies).astype(np.float32)))
 
+    def isotv_weights(self, x, N, nt, u_tail, eps, q, out):
+        X = _d(x)[:N * N * nt].reshape(N, N, nt)
+        g1, g2 = np.zeros_like(X), np.zeros_like(X)
+        g1[:, 1:-1, :] = 0.5 * X[:, 2:, :] - 0.5 * X[:, :-2, :]
+        g2[1:-1, :, :] = 0.5 * X[2:, :, :] - 0.5 * X[:-2, :, :]
+        e = (q - 2.0) / 4.0
+        w = ((g1 ** 2 + g2 ** 2 + eps ** 2) ** e).reshape(-1)
+        parts = [w, w]
+        if u_tail is not None and u_tail.numel():
+            parts.append((_d(u_tail) ** 2 + eps ** 2) ** e)
+        out.copy_(torch.from_numpy(np.concatenate(parts).astype(np.float32)))
+
     def sparse_operator(self, M):
         from oracle import cpu_ref as O
         return OracleOp(O.MatrixOp(M), self)

@@ -150,6 +150,27 @@ def test_mmgks_group_sparsity_branch(eng, tag, q, rp):
         S.MMGKS(F, g["b"], L, 2, q, 3, 2, 1e-2, GS="GS")
 
 
+@pytest.mark.parametrize("tag,q,rp", [("q1_lam1e-2", 1, 1e-2), ("q0.5_lam1e-3", 0.5, 1e-3), ("q1_gcv", 1, "gcv")])
+def test_mmgks_isotv_branch(eng, tag, q, rp):
+    import scipy.sparse as sp
+    g = load_golden("mmgks_dyn3x16_isotv_" + tag)
+    N, nt = int(g["N"]), int(g["nt"])
+    F = OracleOp(O.BlockDiag([O.Blur2D(g["psfs"][t], N, N) for t in range(nt)]), eng)
+    Lm = sp.csr_matrix((g["L_data"], g["L_indices"], g["L_indptr"]), shape=tuple(g["L_shape"]))
+    L = OracleOp(O.MatrixOp(Lm), eng)
+    x, info = S.MMGKS(F, g["b"], L, 2, q, 3, int(g["n_iter"]), rp, g["x_true"], isoTV="isoTV", prob_dims=(N, N, nt))
+    assert info["its"] == int(g["its"])
+    if rp != "gcv":
+        assert relerr(x, g["x"]) < 5e-5 and np.allclose(info["relError"], g["relError"], rtol=2e-4)
+        assert np.allclose(info["Residual"], g["Residual"], rtol=2e-3)
+    else:
+        assert np.allclose(info["relError"], g["relError"], rtol=5e-2) and relerr(x, g["x"]) < 5e-2
+    with pytest.raises(TypeError):
+        S.MMGKS(F, g["b"], L, 2, q, 3, 2, 1e-2, isoTV="isoTV")
+    with pytest.raises(ValueError):
+        S.MMGKS(F, g["b"], L, 2, q, 3, 2, 1e-2, isoTV="isoTV", prob_dims=(N, N + 1, nt))
+
+
 def test_reference_error_behaviour(eng):
     g = load_golden("gks_blur32_lam1e-2")
     A = blur(eng, g)

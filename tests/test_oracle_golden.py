@@ -215,6 +215,38 @@ def test_mmgks_group_sparsity_branch(tag, q, rp):
     assert np.allclose(info["Residual"], g["Residual"], rtol=1e-4)
 
 
+def _isotv_L(g):
+    import scipy.sparse as sp
+    return sp.csr_matrix((g["L_data"], g["L_indices"], g["L_indptr"]), shape=tuple(g["L_shape"]))
+
+
+@pytest.mark.parametrize("tag,q,rp", [("q1_lam1e-2", 1, 1e-2), ("q0.5_lam1e-3", 0.5, 1e-3), ("q1_gcv", 1, "gcv")])
+def test_mmgks_isotv_branch(tag, q, rp):
+    """MMGKS(..., isoTV='isoTV', prob_dims=...) (MMGKS.py:61-77) as run by the reference's own MMGKS.py and
+    operators_old.py over tools/oracle_shim's restatement of pylops.FirstDerivative (parity unpinned for that stencil)."""
+    import scipy.sparse as sp
+    g = load_golden("mmgks_dyn3x16_isotv_" + tag)
+    assert int(g["pylops_first_derivative_is_shim"]) == 1
+    N, nt = int(g["N"]), int(g["nt"])
+    Lm = sp.vstack((O.old_spatial_derivative_operator(N, N, nt), O.old_time_derivative_operator(N, N, nt))).tocsr()
+    assert abs(Lm - _isotv_L(g)).max() == 0.0             # operators_old.py:35-61 as the reference assembled them
+    F = O.BlockDiag([O.Blur2D(g["psfs"][t], N, N) for t in range(nt)])
+    x, info = O.mmgks(F, g["b"], O.MatrixOp(Lm), 2, q, 3, int(g["n_iter"]), rp, g["x_true"], isoTV=True, prob_dims=(N, N, nt))
+    assert info["its"] == int(g["its"])
+    lam, lam_ref = np.asarray(info["regParam_history"], dtype=float), np.asarray(g["regParam_history"], dtype=float)
+    big = lam_ref > 1e-5
+    assert np.allclose(lam[big], lam_ref[big], rtol=1e-4 if rp == "gcv" else 0) and np.all(lam[~big] < 1e-5)
+    # the reference's PyLops operators round their products to float32 (operators_old.py:31 dtype), the oracle does not
+    assert np.allclose(info["relError"], g["relError"], rtol=1e-5) and relerr(x, g["x"]) < 1e-5
+    assert np.allclose(info["Residual"], g["Residual"], rtol=1e-4)
+
+
+def test_isotv_weights_function():
+    g = load_golden("isotv_weights_16x3")                 # weights.py:29-40
+    w = O.iso_tv_weights(g["x"], g["u"], int(g["nx"]), int(g["ny"]), float(g["eps"]), float(g["q"]))
+    assert w.shape == g["wr"].shape and np.allclose(w, g["wr"], rtol=1e-6)
+
+
 def test_derivative_operators_and_weights():
     g = load_golden("deriv_ops")
     for n in (4, 5):

@@ -18,6 +18,7 @@ Fixture families:
   G3 gk_update, arnoldi_update, golub_kahan, arnoldi      (decompositions.py:20-255)
   G4 hybrid_lsqr_*, hybrid_gmres_*                        (Hybrid_LSQR.py:25, Hybrid_GMRES.py:23)
   G5 gks_*, mmgks_*                                       (GKS.py:27, MMGKS.py:28)
+  G5b mmgks_*_isotv_*, isotv_weights                     (MMGKS.py:61-77 over the shim's FirstDerivative)
   G6 deriv_ops                                            (operators.py:24-45)
   G7 regparam_fn                                          (gcv.py, discrepancy_principle.py, l_curve.py)
   G8 deblur1d_cgls                                        (Deblurring1D.py + CGLS: BASELINE config C1)
@@ -290,6 +291,42 @@ def g5_gks():
              relError=info["relError"], Residual=info["Residual"], its=info["its"])
 
 
+# ----------------------------------------------------------------------------------------- G5b
+def g5b_isotv():
+    """MMGKS isoTV branch (MMGKS.py:61-77) with the operators_old.py PyLops-built regulariser.  NOTE: PyLops is absent, so
+    `pylops.FirstDerivative / Kronecker / VStack` here are tools/oracle_shim's restatement of their published semantics:
+    these fixtures pin MMGKS.py's and operators_old.py's own logic, not PyLops' arithmetic (parity unpinned there)."""
+    print("G5b MMGKS isoTV (reference code over the shim's FirstDerivative)")
+    import pylops
+    from trips.utilities import operators_old as oo
+    nt, Nf = 3, 16
+    Ds = [Deblurring2D(CommitCrime=True) for _ in range(nt)]
+    spreads = [(1.0, 1.0), (1.5, 1.0), (2.0, 2.0)]
+    ops = [Ds[t].forward_Op((5, 5), spreads[t], Nf, Nf) for t in range(nt)]
+    psfs = np.stack([Ds[t].Gauss((5, 5), spreads[t])[0] for t in range(nt)])
+    F = pylops.BlockDiag(ops)
+    xt = np.concatenate([test_image(Nf, Nf, 50 + t).reshape(-1) for t in range(nt)]).reshape(-1, 1)
+    bt = np.asarray(F @ xt).reshape(-1, 1)
+    rng = np.random.default_rng(77)
+    e = rng.standard_normal(bt.shape)
+    bt = bt + 0.01 * np.linalg.norm(bt) / np.linalg.norm(e) * e
+    L = pylops.VStack((oo.spatial_derivative_operator(Nf, Nf, nt), oo.time_derivative_operator(Nf, Nf, nt)))
+    Ld = _sps.csr_matrix(np.asarray(L.todense(), dtype=np.float64))
+    for tag, q, rp in (("q1_lam1e-2", 1, 1e-2), ("q0.5_lam1e-3", 0.5, 1e-3), ("q1_gcv", 1, "gcv")):
+        x, info = quiet(MMGKS, F, bt, L, 2, q, 3, 8, rp, xt, isoTV="isoTV", prob_dims=(Nf, Nf, nt))
+        save("mmgks_dyn3x16_isotv_" + tag, psfs=psfs, N=Nf, nt=nt, b=bt, x_true=xt, pnorm=2, qnorm=q, projection_dim=3,
+             n_iter=8, epsilon=0.1, x=x, regParam_history=np.array(info["regParam_history"], dtype=float),
+             relError=info["relError"], Residual=info["Residual"], its=info["its"], x_it1=info["xHistory"][0],
+             L_data=Ld.data, L_indices=Ld.indices, L_indptr=Ld.indptr, L_shape=np.array(Ld.shape),
+             pylops_first_derivative_is_shim=1)
+    # the weights function on its own (weights.py:29-40)
+    from trips.utilities.weights import iso_TV_weights
+    xs = rng.standard_normal((Nf * Nf * nt, 1))
+    us = np.asarray(L @ xs).reshape(-1, 1)
+    save("isotv_weights_16x3", x=xs, u=us, nx=Nf, ny=Nf, eps=0.1, q=1.0,
+         wr=iso_TV_weights(xs, us, Nf, Nf, 0.1, 1.0), pylops_first_derivative_is_shim=1)
+
+
 # ----------------------------------------------------------------------------------------- G6
 def g6_derivs():
     print("G6 derivative operators")
@@ -375,12 +412,18 @@ def g8_deblur1d():
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1:                      # python tools/make_goldens.py g5b_isotv [...]: only the named families
+        for name in sys.argv[1:]:
+            globals()[name]()
+        print("done ->", OUT)
+        sys.exit(0)
     g1_blur()
     g2_cgls()
     g3_decomp()
     g4_hybrid()
     g4b_oneshot()
     g5_gks()
+    g5b_isotv()
     g6_derivs()
     g7_regparam()
     g8_deblur1d()

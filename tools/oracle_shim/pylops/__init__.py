@@ -4,8 +4,9 @@ TEST TOOLING, NOT PRODUCT.  Used only by tools/make_goldens.py, in the build
 container, so that the reference package under /root/reference can be imported
 and *run* to generate golden vectors.  It is our own code: it implements the few
 pieces of the public PyLops >= 2 operator protocol the reference touches
-(LinearOperator algebra, FunctionOperator, Identity, BlockDiag) and nothing of
-the reference.  It never travels to the GPU box as part of the product path.
+(LinearOperator algebra, FunctionOperator, Identity, BlockDiag, and — restated
+from PyLops' published semantics, NOT its code — FirstDerivative, Kronecker,
+VStack) and nothing of the reference.  It never travels to the GPU box as part of the product path.
 
 Behaviour that matters for faithfulness to PyLops >= 2:
   * `Op @ x` / `Op * x` with a 1-D operand -> matvec; with a 2-D operand ->
@@ -227,12 +228,68 @@ class BlockDiag(LinearOperator):
                                for i, o in enumerate(self.ops)])
 
 
-def _absent(name):
-    def ctor(*a, **k):
-        raise NotImplementedError(f"pylops.{name} is not provided by the oracle shim")
-    return ctor
+class FirstDerivative(LinearOperator):
+    """pylops.FirstDerivative(dims, axis=-1, sampling=1.0, kind="centered", edge=False, order=3, dtype=...), 1-D `dims`
+    only — our restatement of PyLops' published 3-point centered stencil (its arithmetic is not available here):
+        y[1:-1] = (0.5 x[2:] - 0.5 x[:-2]) / sampling,   y[0] = y[-1] = 0 (edge=False);
+    adjoint: y[:-2] -= 0.5 x[1:-1] / sampling ; y[2:] += 0.5 x[1:-1] / sampling.
+    The output array is created with the OPERATOR's dtype (float32 for the operators of operators_old.py:31)."""
+
+    def __init__(self, dims, axis=-1, sampling=1.0, kind="centered", edge=False, order=3, dtype="float64", name="F"):
+        if not np.isscalar(dims):
+            raise NotImplementedError("oracle shim: FirstDerivative over a 1-D axis only")
+        if kind != "centered" or order != 3 or edge:
+            raise NotImplementedError("oracle shim: FirstDerivative(kind='centered', order=3, edge=False) only")
+        super().__init__((int(dims), int(dims)), dtype)
+        self.sampling = float(sampling)
+
+    def _matvec(self, x):
+        y = np.zeros(x.shape, self.dtype)
+        y[1:-1] = (0.5 * x[2:] - 0.5 * x[:-2]) / self.sampling
+        return y
+
+    def _rmatvec(self, x):
+        y = np.zeros(x.shape, self.dtype)
+        y[:-2] -= (0.5 * x[1:-1]) / self.sampling
+        y[2:] += (0.5 * x[1:-1]) / self.sampling
+        return y
 
 
-FirstDerivative = _absent("FirstDerivative")
-Kronecker = _absent("Kronecker")
-VStack = _absent("VStack")
+class Kronecker(LinearOperator):
+    """pylops.Kronecker(Op1, Op2): y = kron(Op1, Op2) x, evaluated as Op1 (Op2 X^T)^T on X = x.reshape(m1, m2)."""
+
+    def __init__(self, Op1, Op2, dtype="float64", name="K"):
+        super().__init__((Op1.shape[0] * Op2.shape[0], Op1.shape[1] * Op2.shape[1]), dtype)
+        self.Op1, self.Op2 = Op1, Op2
+
+    def _matvec(self, x):
+        X = x.reshape(self.Op1.shape[1], self.Op2.shape[1])
+        Y = self.Op2.matmat(X.T).T
+        return self.Op1.matmat(Y).ravel()
+
+    def _rmatvec(self, x):
+        X = x.reshape(self.Op1.shape[0], self.Op2.shape[0])
+        Y = self.Op2.rmatmat(X.T).T
+        return self.Op1.rmatmat(Y).ravel()
+
+
+class VStack(LinearOperator):
+    """pylops.VStack(ops): operators stacked by rows; the result arrays carry the common dtype of the operators."""
+
+    def __init__(self, ops, dtype=None):
+        self.ops = list(ops)
+        dt = np.result_type(*[o.dtype for o in self.ops]) if dtype is None else dtype
+        super().__init__((sum(o.shape[0] for o in self.ops), self.ops[0].shape[1]), dt)
+        self._ro = np.cumsum([0] + [o.shape[0] for o in self.ops])
+
+    def _matvec(self, x):
+        y = np.zeros(self.shape[0], dtype=self.dtype)
+        for i, o in enumerate(self.ops):
+            y[self._ro[i]:self._ro[i + 1]] = o.matvec(x)
+        return y
+
+    def _rmatvec(self, x):
+        y = np.zeros(self.shape[1], dtype=self.dtype)
+        for i, o in enumerate(self.ops):
+            y = y + o.rmatvec(x[self._ro[i]:self._ro[i + 1]])
+        return y

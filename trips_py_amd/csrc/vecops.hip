@@ -208,6 +208,34 @@ __global__ __launch_bounds__(NT) void k_group_weights(const float* __restrict__ 
   for (int c = 0; c < copies; ++c) out[(int64_t)c * groups + i] = w;
 }
 
+// ------------------------------------------------------------------ isotropic-TV weights (MMGKS.py:61-77, weights.py:29-40)
+// The flat iterate is viewed as X[i][j][t] (N x N x nt, t fastest: x.reshape(nx**2, nt) in C order, :71).  With the centered
+// 3-point derivative of operators_old.py:22-45 (zero first / last row per axis):
+//   g1 = (X[i][j+1][t] - X[i][j-1][t]) / 2  (0 at j = 0, N-1),   g2 = (X[i+1][j][t] - X[i-1][j][t]) / 2  (0 at i = 0, N-1)
+//   w  = (g1^2 + g2^2 + eps^2)^e,  written to out[idx] and out[N*N*nt + idx]  (:75-76), idx = (i*N + j)*nt + t;
+// behind them the temporal weights  out[2*N*N*nt + k] = (u_tail[k]^2 + eps^2)^e  (:77).  One pass: 4 B read (neighbours hit
+// in L1/L2) + 8 B written per element.
+__global__ __launch_bounds__(NT) void k_isotv_weights(const float* __restrict__ x, int N, int nt, const float* __restrict__ u_tail,
+                                                      int64_t n_tail, float eps2, float e, int special, float* __restrict__ out) {
+  const int64_t ns = (int64_t)N * N * nt;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  const int64_t sj = nt, si = (int64_t)N * nt;
+  for (int64_t idx = tid; idx < ns; idx += nth) {
+    const int64_t r = idx / nt;
+    const int i = (int)(r / N), j = (int)(r - (int64_t)i * N);
+    const float g1 = (j > 0 && j < N - 1) ? 0.5f * x[idx + sj] - 0.5f * x[idx - sj] : 0.f;
+    const float g2 = (i > 0 && i < N - 1) ? 0.5f * x[idx + si] - 0.5f * x[idx - si] : 0.f;
+    const float t = fmaf(g1, g1, fmaf(g2, g2, eps2));
+    const float w = special == 1 ? 1.0f : special == 2 ? 1.0f / sqrtf(t) : special == 3 ? 1.0f / sqrtf(sqrtf(t)) : powf(t, e);
+    out[idx] = w;
+    out[ns + idx] = w;
+  }
+  for (int64_t k = tid; k < n_tail; k += nth) {
+    const float t = fmaf(u_tail[k], u_tail[k], eps2);
+    out[2 * ns + k] = special == 1 ? 1.0f : special == 2 ? 1.0f / sqrtf(t) : special == 3 ? 1.0f / sqrtf(sqrtf(t)) : powf(t, e);
+  }
+}
+
 // ------------------------------------------------------------------ fused CGLS update (CGLS.py:64-67,76,79)
 // partials layout: [block][3] = ||x_new||^2, ||step*p||^2, ||x_new - x_true||^2
 template <bool HAS_XT, bool VEC>
@@ -1221,6 +1249,18 @@ int trk_group_weights(const float* d, int64_t groups, int group_len, double add,
   if (groups == 0) return TRK_OK;
   hipLaunchKernelGGL(k_group_weights, dim3(ceil_div(groups, NT)), dim3(NT), 0, (hipStream_t)st, d, groups, group_len, add, expo,
                      copies, out);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_isotv_weights(const float* x, int N, int nt, const float* u_tail, int64_t n_tail, double eps, double q, float* out,
+                      trk_stream st) {
+  TRK_REQUIRE(x && out && N >= 1 && nt >= 1 && n_tail >= 0 && (u_tail || n_tail == 0), "trk_isotv_weights: bad argument");
+  const double ed = (q - 2.0) / 4.0;                                   // sic: (q-2)/4 (MMGKS.py:75,77)
+  const int special = (ed == 0.0) ? 1 : (ed == -0.5) ? 2 : (ed == -0.25) ? 3 : 0;
+  const int64_t ns = (int64_t)N * N * nt;
+  hipLaunchKernelGGL(k_isotv_weights, dim3(stream_grid(ns > n_tail ? ns : n_tail)), dim3(NT), 0, (hipStream_t)st, x, N, nt,
+                     u_tail, n_tail, (float)(eps * eps), (float)ed, special, out);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }

@@ -235,6 +235,14 @@ class HipEngine:
                                         out.data_ptr(), self.stream())
         _lib.check(rc, "trk_group_weights")
 
+    def isotv_weights(self, x, N, nt, u_tail, eps, q, out):
+        """MMGKS isotropic-TV weights (MMGKS.py:61-77): spatial part from the centered gradient of x viewed as [N][N][nt],
+        written twice, then (u_tail^2 + eps^2)^((q-2)/4); u_tail may be None / empty."""
+        nt_tail = 0 if u_tail is None else u_tail.numel()
+        rc = self.lib.trk_isotv_weights(x.data_ptr(), int(N), int(nt), None if nt_tail == 0 else u_tail.data_ptr(), nt_tail,
+                                        float(eps), float(q), out.data_ptr(), self.stream())
+        _lib.check(rc, "trk_isotv_weights")
+
     def sparse_operator(self, M):
         """A scipy.sparse matrix as an operator of this engine (device CSR SpMV)."""
         from .operators import SparseOp

@@ -8,6 +8,8 @@
   FirstDerivative2D(N)               <- gen_first_derivative_operator_2D   trips/utilities/operators.py:30-36
   SpaceTimeDerivative(N, nt)         <- gen_spacetime_derivative_operator  trips/utilities/operators.py:39-45
   Identity(n)                        <- pylops.Identity                    trips/solvers/Hybrid_LSQR.py:76
+  first_derivative_operator(_2d), spatial_/time_derivative_operator, VStack
+                                     <- the PyLops-built regularisers      trips/utilities/operators_old.py:22-61
 
 NumPy in -> NumPy (float64) out, so the unmodified reference solvers can be handed one of these; torch device
 tensors in -> torch device tensors out.  The engine's own solvers use `apply()` on fp32 device vectors and
@@ -365,6 +367,90 @@ def create_framelet_operator(n, m, l, engine=None):
 
     W_n, W_m = analysis(n, 1, 1), analysis(m, 1, 1)
     return SparseOp(sp.kron(W_m, W_n, format="csr"), engine=engine)
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# The PyLops-built regularisers of trips/utilities/operators_old.py:22-61 (what MMGKS's isoTV branch expects of `L`,
+# MMGKS.py:61-77).  PyLops is an un-pinned, absent dependency of the reference: `pylops.FirstDerivative(n)` is restated
+# here from its published default (kind="centered", 3-point, edge=False): row i = (x[i+1] - x[i-1]) / 2 for
+# 1 <= i <= n-2, first and last row zero — PARITY UNPINNED for that stencil.
+def _centered_first_derivative_matrix(n):
+    import scipy.sparse as sp
+    i = np.arange(1, n - 1)
+    return sp.csr_matrix((np.concatenate((np.full(i.size, -0.5), np.full(i.size, 0.5))),
+                          (np.concatenate((i, i)), np.concatenate((i - 1, i + 1)))), shape=(n, n))
+
+
+def _first_derivative_2d_matrix(nx, ny):
+    import scipy.sparse as sp
+    if nx != ny:      # the reference's VStack of an nx^2- and an ny^2-column operator fails as well (operators_old.py:43)
+        raise ValueError("first_derivative_operator_2d: the reference's operator exists for nx == ny only")
+    return sp.vstack((sp.kron(sp.identity(nx), _centered_first_derivative_matrix(nx)),
+                      sp.kron(_centered_first_derivative_matrix(ny), sp.identity(ny)))).tocsr()
+
+
+def first_derivative_operator(n, engine=None):
+    """operators_old.py:22-33 (`pylops.FirstDerivative(n)`): n x n, centered, zero first/last row."""
+    return SparseOp(_centered_first_derivative_matrix(n), engine=engine)
+
+
+def first_derivative_operator_2d(nx, ny, engine=None):
+    """operators_old.py:35-45: VStack(Kronecker(I_nx, D_nx), Kronecker(D_ny, I_ny)), 2 nx^2 x nx^2."""
+    return SparseOp(_first_derivative_2d_matrix(nx, ny), engine=engine)
+
+
+def spatial_derivative_operator(nx, ny, nt, engine=None):
+    """operators_old.py:47-53: Kronecker(I_nt, first_derivative_operator_2d) on a frame-major vector."""
+    import scipy.sparse as sp
+    return SparseOp(sp.kron(sp.identity(nt), _first_derivative_2d_matrix(nx, ny)).tocsr(), engine=engine)
+
+
+def time_derivative_operator(nx, ny, nt, engine=None):
+    """operators_old.py:55-61: Kronecker(D_nt, I_{nx^2})."""
+    import scipy.sparse as sp
+    return SparseOp(sp.kron(_centered_first_derivative_matrix(nt), sp.identity(nx ** 2)).tocsr(), engine=engine)
+
+
+class VStack(LinearOperator):
+    """pylops.VStack(ops): operators stacked by rows (the way the dynamic demos assemble space + time regularisers).
+    Sparse-matrix operators are merged into one CSR operator; anything else is applied block by block."""
+
+    def __new__(cls, ops, engine=None):
+        ops = list(ops)
+        if ops and all(isinstance(o, SparseOp) for o in ops):
+            import scipy.sparse as sp
+            return SparseOp(sp.vstack([o.matrix for o in ops]).tocsr(), engine=engine if engine is not None else ops[0].engine)
+        return super().__new__(cls)
+
+    def __init__(self, ops, engine=None):
+        self.ops = list(ops)
+        if not self.ops or any(o.shape[1] != self.ops[0].shape[1] for o in self.ops):
+            raise ValueError("VStack: operators must share their column count")
+        super().__init__((sum(o.shape[0] for o in self.ops), self.ops[0].shape[1]),
+                         engine if engine is not None else self.ops[0].engine)
+        self._ro = np.cumsum([0] + [o.shape[0] for o in self.ops])
+        self._tmp = None
+
+    def _apply(self, x2, y2, transpose, sumsq):
+        eng = self.engine
+        for j in range(x2.shape[0]):
+            if not transpose:
+                for i, o in enumerate(self.ops):
+                    o.apply(x2[j], out=y2[j, self._ro[i]:self._ro[i + 1]])
+            else:
+                if self._tmp is None:
+                    self._tmp = eng.empty(self.shape[1])
+                for i, o in enumerate(self.ops):
+                    seg = x2[j, self._ro[i]:self._ro[i + 1]]
+                    if i == 0:
+                        o.apply(seg, out=y2[j], transpose=True)
+                    else:
+                        o.apply(seg, out=self._tmp, transpose=True)
+                        eng.axpby(1.0, y2[j], 1.0, self._tmp, y2[j])
+        if sumsq is not None:
+            if x2.shape[0] != 1:
+                raise ValueError("VStack: fused sum of squares for single vectors only")
+            eng.nrm2sq(y2[0], sumsq)
 
 
 class Identity(LinearOperator):

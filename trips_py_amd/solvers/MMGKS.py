@@ -1,6 +1,6 @@
 """Majorization-Minimization GKS on the HIP engine — signature and `info` of trips/solvers/MMGKS.py:28-137
-(plain smoothed-Holder weights, :93, and the group-sparsity weights branch, :45-52 / :78-91; the isoTV branch, :61-77, goes
-through PyLops' FirstDerivative, whose arithmetic is not pinned here — SURVEY §8f rank 3).
+(plain smoothed-Holder weights, :93; the group-sparsity weights branch, :45-52 / :78-91; the isotropic-TV weights branch,
+:61-77, whose centered first derivative is restated from PyLops' published definition — parity unpinned there).
 
     min ||A x - b||_p^p + lambda ||L x||_q^q   by iteratively re-weighted least squares in a growing subspace.
 
@@ -35,13 +35,30 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     Engine-only kwarg: history=True."""
     A = as_operator(A)
     check_delta(regparam, kwargs)
-    if kwargs.get("isoTV", False) in ("isoTV", "ISOTV", "IsoTV"):
-        raise NotImplementedError("MMGKS isoTV weights (MMGKS.py:61-77) apply pylops.FirstDerivative (operators_old.py:31); "
-                                  "its arithmetic is not available to pin: not implemented on the engine")
+    iso = kwargs.get("isoTV", False) in ("isoTV", "ISOTV", "IsoTV")
     epsilon = kwargs.get("epsilon", 0.1)
     eng = A.engine
     m, n = A.shape
     gs = kwargs.get("GS", False) in ("GS", "gs", "Gs")
+    if iso:
+        # isotropic TV (:61-77): the caller's L stays (its first 2*nx^2*nt rows are taken to be spatial, the rest temporal);
+        # only the WEIGHTS change — one weight for the two directional derivatives of a pixel, from the centered
+        # derivative of operators_old.py:22-45 applied to x.reshape(nx**2, nt) (:71), exponent (q-2)/4 (:75, sic).
+        prob_dims = kwargs.get("prob_dims", False)
+        if prob_dims is False:                                                            # (:62-63)
+            raise TypeError("For Isotropic TV you must enter the dimension of the dynamic problem! Example: (x_mmgks, "
+                            "info_mmgks) = MMGKS(A, data_vec, L, pnorm=2, qnorm=1, projection_dim=2, n_iter =3, regparam = "
+                            "'gcv', x_true = None, isoTV = 'isoTV', prob_dims = (nx,ny, nt))")
+        iso_nx, iso_ny = int(prob_dims[0]), int(prob_dims[1])
+        iso_nt = n // (iso_nx * iso_ny)                                                   # (:69)
+        if iso_nx != iso_ny or iso_nx * iso_nx * iso_nt != n:
+            # first_derivative_operator_2d (operators_old.py:35-45) stacks an nx^2- and an ny^2-column operator and the
+            # iterate is reshaped (nx**2, nt): the reference fails on anything else too
+            raise ValueError(f"MMGKS isoTV: prob_dims {tuple(prob_dims)} do not match a square nx x nx x nt iterate of length {n}")
+        if getattr(eng, "world", 1) > 1:
+            raise NotImplementedError("MMGKS isoTV weights read the iterate across frame boundaries (x.reshape(nx**2, nt)): "
+                                      "single rank only")
+        gs = False                                                                        # isoTV is tested first (:61 / :78)
     if gs:
         # group sparsity (:45-52): the caller's L is REPLACED by kron(I_nt, Ls), Ls the 2-D first-derivative matrix of
         # operators_old.py:66-85; the weights couple the nt entries of every row of Ls X (:83-90)
@@ -66,6 +83,8 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     else:
         L = as_operator(L, "L")
     p_rows = L.shape[0]
+    if iso and p_rows < 2 * n:                       # LV * wr (:94) needs len(wr) = 2 nx^2 nt + (p_rows - 2 nx^2 nt)
+        raise ValueError(f"MMGKS isoTV: L has {p_rows} rows, fewer than the 2*nx*nx*nt = {2 * n} spatial rows the weights assume")
     n_iter, d = int(n_iter), int(projection_dim)
     keep = bool(kwargs.get("history", True))
     fmt = Formatter(b)
@@ -118,7 +137,9 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         kk = k * k
         # weights from the current iterate (:56-57, :60, :93); ax = A x, lx = L x of it
         eng.mm_weights(ax, bv, epsilon, pnorm, wf)
-        if gs:
+        if iso:
+            eng.isotv_weights(x_cur if x_dev is None else x_dev, iso_nx, iso_nt, lx[2 * n:], epsilon, qnorm, wr)
+        elif gs:
             gs_op.apply(x_cur if x_dev is None else x_dev, out=gs_d)
             eng.group_weights(gs_d, gs_rows, gs_nt_x, float(np.exp(2)), qnorm / 2 - 1, gs_nt_x, wr)   # exp(2): sic (:87)
         else:
