@@ -108,6 +108,21 @@ class LinearOperator:
 
     transpose = adjoint
 
+    def __array__(self, *args, **kwargs):
+        # NumPy asking for an array means a caller took this operator for a matrix — in the reference that is
+        # utils.is_identity's `np.allclose(A, np.eye(n))` on any SQUARE operand that is not a pylops LinearOperator
+        # (utils.py:55; an n x n eye).  Fail with the remedy instead of an obscure ufunc error.
+        raise TypeError(f"{type(self).__name__} is a matrix-free operator, not an array; to hand it to code that tests "
+                        "`isinstance(op, pylops.LinearOperator)` (trips/utilities/utils.py:55) pass op.to_pylops()")
+
+    def to_pylops(self):
+        """This operator as a `pylops.FunctionOperator(matvec, rmatvec, nr, nc)` — the wrapper the reference's own test
+        problems build around their callables (Deblurring2D.py:72, Tomography.py:83, io.py:400).  Use it to hand an engine
+        operator to the UNMODIFIED reference solvers: it then passes their `isinstance(.., pylops.LinearOperator)` tests
+        (utils.py:55, gcv.py:33) like the operators it replaces.  Needs PyLops (a dependency of the reference)."""
+        import pylops
+        return pylops.FunctionOperator(self.matvec, self.rmatvec, self.shape[0], self.shape[1])
+
     def todense(self):
         """Dense float64 matrix (small operators only; Tikhonov.py:20, demo_1D_deblurring)."""
         n = self.shape[1]
