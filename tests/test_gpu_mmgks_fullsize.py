@@ -29,6 +29,15 @@ def d2_adj(y, N):
     return out.reshape(-1)
 
 
+def mv(M, y):
+    """M @ y without BLAS (rocBLAS dgemv refuses 16.8 M-row operands)."""
+    return (M * y[None, :]).sum(dim=1)
+
+
+def mtv(M, v):
+    return (M * v[:, None]).sum(dim=0)
+
+
 def mmgks64(psf, N, b, d, n_iter, lam, eps, pnorm, qnorm):
     """MMGKS.py:37-128, plain smoothed-Holder weights, numeric regparam; returns the list of iterates (float64, device)."""
     psf_t = torch.from_numpy(psf).to(b.device, torch.float64)
@@ -61,15 +70,15 @@ def mmgks64(psf, N, b, d, n_iter, lam, eps, pnorm, qnorm):
         _, R_L = torch.linalg.qr(LV * wr[:, None])
         k = R_A.shape[0]
         M = torch.cat([R_A, np.sqrt(lam) * R_L])
-        rhs = torch.cat([Q_A.T @ b, torch.zeros(k, dtype=b.dtype, device=b.device)])   # UNWEIGHTED b (:106)
+        rhs = torch.cat([mtv(Q_A, b), torch.zeros(k, dtype=b.dtype, device=b.device)])   # UNWEIGHTED b (:106)
         y = torch.linalg.lstsq(M, rhs[:, None]).solution[:, 0]
-        x = V @ y
+        x = mv(V, y)
         hist.append(x.clone())
         if ii >= R_L.shape[0]:
             break
-        r = AT(wf * (AV @ y - b)) + lam * d2_adj(wr * (LV @ y), N)            # :114-118
+        r = AT(wf * (mv(AV, y) - b)) + lam * d2_adj(wr * mv(LV, y), N)            # :114-118
         for _ in range(2):
-            r = r - V @ (V.T @ r)
+            r = r - mv(V, mtv(V, r))
         vn = r / torch.linalg.norm(r)
         V = torch.cat([V, vn[:, None]], 1)
         AV = torch.cat([AV, A(vn)[:, None]], 1)

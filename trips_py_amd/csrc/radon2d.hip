@@ -9,18 +9,27 @@
 // (cos t, sin t); rays run along (sin t, -cos t).  Per angle one of two marching modes:
 //   mode 0 (|cos| >= |sin|): march image rows  tt = i, coordinate q = column:  q = s/cos + (h - h tan) + i tan
 //   mode 1 (otherwise)     : march image cols  tt = j, coordinate q = row   :  q = -s/sin + (h - h cot) + j cot
-// Both are   q(d, tt) = fmaf(tt, dq, fmaf(s_d, inv, k0))   with taps at floor(q), floor(q)+1, weights (1-f), f, times
-// wgt = scale/|cos| (or /|sin|).  Forward and adjoint evaluate q with the SAME float expression, so the adjoint uses
-// bit-identical matrix entries (exact transpose; only the summation order differs).
+// i.e.  q(d, tt) = A(d) + B(tt),  A(d) = s_d inv + k0,  B(tt) = tt dq;  taps at floor(q), floor(q)+1, weights (1-f), f,
+// times wgt = scale/|cos| (or /|sin|).
+//
+// FIXED-POINT RAY COORDINATE (round 2).  Evaluated in fp32, q — a number up to N — carries an error of ~6e-8 N, i.e. an
+// interpolation weight off by 2e-4 at N = 4096 (measured 1.9e-4 relative on white noise).  Here the two terms come from
+// TABLES made once per operator in float64 and rounded to 24 fractional bits, A32[a][d] = round(A(d) 2^24) mod 2^32 and
+// B32[a][tt] = round(B(tt) 2^24) mod 2^32, and the kernels add them as INTEGERS:
+//     Q = A32 + B32 (mod 2^32):   column mod 256 = Q >> 24,   f = (Q & 0xFFFFFF) 2^-24   (exact in fp32, as is 1 - f).
+// Every weight is within 2^-24 of its float64 value whatever N; forward and adjoint read the same tables, so the nearest
+// ray's weight in the adjoint is bit-identical to the forward's; the absolute column comes from where the tap is looked
+// for (the LDS window start, the gathering pixel) — 8 integer bits are plenty for that.  The march costs what it did
+// (7 vector instructions per step); measured against the float64 oracle: DESIGN.md §4.4.
 //
 // Forward: mode-1 angles read a transposed copy of the image so that both modes read ROWS: the 64 adjacent detectors of
 // a wave touch 64..90 contiguous floats per marching step.  The grid runs over bands of 128 marching rows (see
 // k_radon_fwd); a workgroup is 64 detectors x 4 neighbouring angles.
-// Adjoint: gather form, one thread per pixel, no atomics: for each angle the <= 3 detectors whose ray passes within one
-// pixel are found from the inverse of q and re-evaluated exactly.
+// Adjoint: gather form, no atomics (k_radon_adj_tile): per pixel and angle the nearest ray d0 and its two neighbours —
+// every ray within one pixel is among them, because |dq/dd| = 1/|cos| >= 1 — from 16-byte records staged in LDS.
 //
 // Roofline note: algorithmic bytes are only 4(N^2 + n_ang n_det) against 2 N n_det n_ang taps, so this
-// operator is bound by L1/L2 gather + fp32 ALU, not HBM; bench.py reports taps/s next to GB/s.
+// operator is bound by LDS reads / vector issue, not HBM; bench.py reports taps/s next to GB/s.
 #include "trk_internal.h"
 
 #include <cmath>
@@ -33,15 +42,20 @@ using namespace trk;
 
 namespace {
 
+constexpr int QF = 24;                          // fractional bits of the fixed-point ray coordinate
+constexpr float QONE = 16777216.0f;             // 2^24
+constexpr int A32_PAD = 2;                      // A32 rows hold d = -2 .. nd+1
+
 struct AngleParam {
-  float inv, dq, k0, wgt;
+  float inv, dq, k0, wgt;   // fp32 copies: only for ESTIMATES (window placement, candidate location); wgt includes 2^-24
   int mode;
-  float rinv;   // ~1/inv: only used to LOCATE the adjoint's candidate rays, never in a weight
+  float rinv;               // ~1/inv
+  float inv24;              // inv * 2^24: distance between neighbouring rays in fixed-point units (adjoint)
 };
 
-#define ADJ_PAD 2
-struct AdjAngle {   // the adjoint's per-angle constants (sorted by marching mode; the weight lives in the padded sinogram)
-  float inv, dq, k0, rinv;
+struct AdjAngle {           // the adjoint's per-angle constants, sorted by marching mode per frame
+  float rinv, inv24, dq, k0;
+  int orig;                 // index of the angle within its frame
 };
 
 struct RadonImpl {
@@ -51,13 +65,16 @@ struct RadonImpl {
   float* xT;  // nt*N*N transposed images (forward, mode-1 angles); owned by the handle (non-reentrant across streams)
   int n_mode1;
   float* part;  // [n_bands][nt*na][nd] forward band partial sums (n_bands > 1 only); owned by the handle
-  float* fidx;  // fidx[i] = (float) i, i < N + 16: the marching index as a float, read through the scalar cache
-  // adjoint, second form: angles sorted by mode per frame, padded + scaled sinogram copy (owned by the handle)
+  float* fidx;  // fidx[i] = (float) i, i < N + 16
+  unsigned* A32;  // [nt*na][nd + 4]
+  unsigned* B32;  // [nt*na][npad]
+  uint2* CB;      // [nt*na][npad]: {C[a][tt] as float bits, B32[a][tt]}, C = the adjoint's locator offset
+  int npad;
+  // adjoint: angles sorted by mode per frame; per apply a record array {w S[d-1], w S[d], w S[d+1], A32[d]}
   AdjAngle* adj_ang;
-  int* adj_orig;
   float* adj_wgt;
   int* adj_n0;
-  float* sino_pad;
+  uint4* rec;
   int n_bands, band;
 };
 
@@ -80,46 +97,50 @@ __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in,
 }
 
 // ---------------------------------------------------------------------------------------- forward
-// Both taps of a step come from ONE 8-byte buffer load at (row, floor(q)); out-of-range taps get weight 0 (the buffer
-// range check returns 0 for the two addresses that fall outside the image allocation).
+// Both taps of a step come from ONE 8-byte load at (row, floor(q)); out-of-range taps get weight 0.
 typedef float f2v __attribute__((ext_vector_type(2)));
 typedef unsigned int u2v __attribute__((ext_vector_type(2)));
 typedef float f4r __attribute__((ext_vector_type(4)));
 
-// One marching step of one ray with full edge handling: offset of the 8-byte load and the two tap weights (taps outside
-// the image, steps outside [.., te) and rays outside the detector weigh 0).
-__device__ __forceinline__ int radon_edge_tap(int tt, int te, bool live, int N, float dq, float base, f2v& w) {
+// Absolute left-tap column of a step: the fixed-point sum Q knows it mod 256, the fp32 estimate of q (off by far less than a
+// column) says which multiple of 256.
+__device__ __forceinline__ int radon_abs_col(unsigned Q, float qest) {
+  const int ce = (int)floorf(qest);
+  const int cm = (int)(Q >> QF);
+  return ce + (((cm - ce + 128) & 255) - 128);
+}
+
+// One marching step of one ray with full edge handling (direct-gather paths): offset of the 8-byte load and the two tap
+// weights in units of 2^-24 (taps outside the image, steps outside [.., te) and rays outside the detector weigh 0).
+__device__ __forceinline__ int radon_edge_tap(int tt, int te, bool live, int N, float dq, float base, unsigned A,
+                                              const unsigned* __restrict__ Brow, f2v& w) {
   const bool valid = live && tt < te;
   const int tr = tt < te ? tt : te - 1;
-  const float q = fmaf((float)tr, dq, base);
-  const float qf = floorf(q);
-  const float f = q - qf;
-  const int c = (int)qf;
+  const unsigned Q = A + Brow[tr];
+  const int c = radon_abs_col(Q, fmaf((float)tr, dq, base));
+  const float f1 = (float)(Q & 0xFFFFFFu), f0 = QONE - f1;
   // c == -1: only the right tap (column 0) is inside; start the 8-byte load at column 0 instead (an access that
   // STARTS below the buffer is dropped whole by the range check — measured on gfx950 — while one that runs off
   // the end returns its in-range dword)
   const bool neg1 = (c == -1);
   const int cl = neg1 ? 0 : c;
-  const float w0 = neg1 ? f : (((unsigned)c < (unsigned)N) ? 1.0f - f : 0.f);
-  const float w1 = neg1 ? 0.f : (((unsigned)(c + 1) < (unsigned)N) ? f : 0.f);
+  const float w0 = neg1 ? f1 : (((unsigned)c < (unsigned)N) ? f0 : 0.f);
+  const float w1 = neg1 ? 0.f : (((unsigned)(c + 1) < (unsigned)N) ? f1 : 0.f);
   w[0] = valid ? w0 : 0.f;
   w[1] = valid ? w1 : 0.f;
-  return (tr * N + cl) * 4;
+  const bool anyin = (unsigned)cl < (unsigned)N;
+  return anyin ? (tr * N + cl) * 4 : 0x7FFFFFF0;                   // far outside: returns 0, fetches nothing
 }
 
-// Forward kernel.  grid = (ceil(nd/64) * n_angle_groups, n_bands); block = 256 = 4 waves = 4 CONSECUTIVE ANGLES of one
-// frame x 64 detectors, marching the RADON_BAND image rows (mode 1: columns, through the transposed copy) of band
-// blockIdx.y.  Why this shape (measured at 4096^2 x 180, MI355X): a wave marching the whole image touches 3-4 new
-// cache lines per step and never returns to them, and every angle sweeps the whole 67 MB image, so the first version
+// Forward kernel (direct gathers; any N).  grid = (ceil(nd/64) * n_angle_groups, n_bands); block = 256 = 4 waves = 4
+// CONSECUTIVE ANGLES of one frame x 64 detectors, marching the RADON_BAND image rows (mode 1: columns, through the transposed
+// copy) of band blockIdx.y.  Why this shape (measured at 4096^2 x 180, MI355X): a wave marching the whole image touches 3-4
+// new cache lines per step and never returns to them, and every angle sweeps the whole 67 MB image, so the first version
 // (one wave = a quarter of the image) moved ~12 GB through the fabric per apply and was bound by L2 misses (2.15 ms;
 // halving its VALU work changed nothing).  With row bands the grid runs band by band (blockIdx.x is the fast index),
 // the 2 MB band stays in every XCD's 4 MB L2 while all angles and detectors pass over it, and the four waves of a
 // workgroup - neighbouring angles, same detectors, same rows at the same time - share most of their L1 lines.
 // Band partial sums go to a scratch array [band][angle][detector] that k_radon_bands_sum adds up in a fixed order.
-//
-// Marching steps are taken in chunks of RADON_CHUNK.  A chunk whose taps are inside the image for EVERY ray of the wave
-// (q is monotone in tt, so its two end steps decide) runs without any edge logic: the row offset is a wave-uniform
-// SGPR, both taps and both weights sit in register pairs and one packed FMA accumulates them.
 #define RADON_CHUNK 32
 #define RADON_BAND 128
 
@@ -127,7 +148,8 @@ template <bool FINAL>
 __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img, const float* __restrict__ imgT,
                                                    float* __restrict__ out, int N, int nd,
                                                    const AngleParam* __restrict__ ang, int na_per_frame, int ngrp_per_frame,
-                                                   int ndblk, int64_t band_stride, int bh) {
+                                                   int ndblk, int64_t band_stride, int bh,
+                                                   const unsigned* __restrict__ A32, const unsigned* __restrict__ B32, int npad) {
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int grp = blockIdx.x / ndblk, dblk = blockIdx.x - grp * ndblk;
   const int frame = grp / ngrp_per_frame;
@@ -138,16 +160,20 @@ __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img
   const float* __restrict__ I = (p.mode ? imgT : img) + (int64_t)frame * N * N;
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)I, 0, (unsigned)N * (unsigned)N * 4u, 0x00020000);
   const int d = dblk * 64 + lane;
+  const bool live = d < nd;
+  const unsigned A = A32[(int64_t)a * (nd + 2 * A32_PAD) + (live ? d : nd - 1) + A32_PAD];
+  const unsigned* __restrict__ Brow = B32 + (int64_t)a * npad;
   const float s = (float)d - 0.5f * (float)(nd - 1);
   const float base = fmaf(s, p.inv, p.k0);
   const int t0 = blockIdx.y * bh, t1 = (t0 + bh < N) ? t0 + bh : N;
-  const float qmax = (float)(N - 1);
-  const bool live = d < nd;
+  const float qmax = (float)(N - 2);
   double total = 0.0;
   for (int tb = t0; tb < t1; tb += RADON_CHUNK) {
     const int te = (tb + RADON_CHUNK < t1) ? tb + RADON_CHUNK : t1;
     const float qa = fmaf((float)tb, p.dq, base), qb = fmaf((float)(te - 1), p.dq, base);
-    const bool inside = !live || (fminf(qa, qb) >= 0.f && fmaxf(qa, qb) < qmax);
+    // a chunk whose taps are inside the image for EVERY ray of the wave (q is monotone in tt; one column of margin for
+    // the estimate) runs without any edge logic
+    const bool inside = !live || (fminf(qa, qb) >= 1.f && fmaxf(qa, qb) < qmax);
     if (te - tb == RADON_CHUNK && __builtin_amdgcn_ballot_w64(inside) == ~0ull) {
       f2v acc2 = {0.f, 0.f};
       // two batches of 8 steps in flight: the loads of batch k+1 are issued before batch k is accumulated
@@ -156,11 +182,11 @@ __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int tt = tb + 8 * k + u;
-          const float q = fmaf((float)tt, p.dq, base);
-          const float qf = floorf(q);
-          w[k & 1][u][1] = q - qf;
-          w[k & 1][u][0] = 1.0f - w[k & 1][u][1];
-          v[k & 1][u] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)qf << 2, (unsigned)tt * (unsigned)N * 4u, 0));
+          const unsigned Q = A + Brow[tt];
+          const int c = radon_abs_col(Q, fmaf((float)tt, p.dq, base));
+          w[k & 1][u][1] = (float)(Q & 0xFFFFFFu);
+          w[k & 1][u][0] = QONE - w[k & 1][u][1];
+          v[k & 1][u] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, c << 2, (unsigned)tt * (unsigned)N * 4u, 0));
         }
       };
       issue(0);
@@ -179,7 +205,7 @@ __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img
         f2v w[8], v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int off = radon_edge_tap(tb + 8 * k + u, te, live, N, p.dq, base, w[u]);
+          const int off = radon_edge_tap(tb + 8 * k + u, te, live, N, p.dq, base, A, Brow, w[u]);
           v[u] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
         }
 #pragma unroll
@@ -206,6 +232,9 @@ __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img
 // execute in order.  DMA = true (default): the 7 loads go straight into LDS (buffer_load_dwordx4 ... lds — lane l of load i
 // lands at float4 64 i + l of the tile, which is exactly the staging order; out-of-range lanes store zeros), which takes
 // the texture-data -> register -> LDS detour out of the path.
+// The march per step (7 vector instructions): Q = A' + B32[tt] (A' = the ray's table entry minus the window start, per chunk;
+// B32[tt] through the scalar cache), column within the window = Q >> 24, weights (float)(Q & 0xFFFFFF) and 2^24 minus that,
+// LDS address, one ds_read2_b32, one packed FMA.
 #define LDS_R 16
 #define LDS_W 112
 
@@ -214,7 +243,7 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
                                                        float* __restrict__ out, int N, int nd,
                                                        const AngleParam* __restrict__ ang, int na_per_frame,
                                                        int ngrp_per_frame, int ndblk, int64_t band_stride, int bh,
-                                                       const float* __restrict__ fidx) {
+                                                       const unsigned* __restrict__ A32, const unsigned* __restrict__ B32, int npad) {
   __shared__ __attribute__((aligned(16))) float tile[4][LDS_R * LDS_W];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int grp = blockIdx.x / ndblk, dblk = blockIdx.x - grp * ndblk;
@@ -232,6 +261,8 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
   const float base = fmaf((float)d - sdh, p.inv, p.k0);
   const int nlive = (nd - dblk * 64 < 64) ? nd - dblk * 64 : 64;   // live lanes are 0 .. nlive-1 (wave-uniform)
   const bool live = lane < nlive;
+  const unsigned A = A32[(int64_t)a * (nd + 2 * A32_PAD) + (live ? d : nd - 1) + A32_PAD];
+  const unsigned* __restrict__ Ball = B32 + (int64_t)a * npad;
   // base is monotone in the lane: the window's column range comes from the first and the last live ray
   const float b0 = fmaf((float)(dblk * 64) - sdh, p.inv, p.k0), b1 = fmaf((float)(dblk * 64 + nlive - 1) - sdh, p.inv, p.k0);
   const float blo = fminf(b0, b1), bhi = fmaxf(b0, b1);
@@ -252,11 +283,11 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
     // column range of all taps of the chunk (q is monotone in tt as well): wave-uniform
     const float ta = (float)tb * p.dq, tz = (float)(te - 1) * p.dq;
     const float qlo = blo + fminf(ta, tz), qhi = bhi + fmaxf(ta, tz);
-    // (readfirstlane: the values are wave-uniform but were computed in vector registers; as scalars they fold into the
-    // LDS base address of each row)
-    const int cs = __builtin_amdgcn_readfirstlane(((int)floorf(qlo) - 1) & ~3);   // one column of slack for the rounding of the two sums
+    // (readfirstlane: the values are wave-uniform but were computed in vector registers)
+    const int cs = __builtin_amdgcn_readfirstlane(((int)floorf(qlo) - 1) & ~3);   // one column of slack for the fp32 estimate
     const bool fits = (__builtin_amdgcn_readfirstlane((int)floorf(qhi)) + 2 - cs) < LDS_W;
     const bool full = (te - tb == LDS_R);
+    const unsigned* __restrict__ Brow = Ball + tb;
     f2v acc2 = {0.f, 0.f};
     if (fits) {
       // stage: rows tb .. tb+15 (beyond te: not fetched), columns cs .. cs+111 (outside the image: zeros); the row part of the
@@ -281,29 +312,19 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
         for (int i = 0; i < 7; ++i) *reinterpret_cast<f4r*>(&T[slds[i]]) = v[i];
       }
       __builtin_amdgcn_wave_barrier();
-      // march.  (float) of the wave-uniform row number comes from a table through the scalar cache (fidx[i] = (float) i): the
-      // SAME value the adjoint's (float) i conversion gives, without a vector instruction per step.
-      const float* __restrict__ ftt = fidx + tb;
+      const unsigned Ac = A - ((unsigned)cs << QF);               // column relative to the window (mod 256)
       auto march = [&](auto full_tag) {
         constexpr bool FULL = decltype(full_tag)::value;         // FULL: 16 rows, all 64 rays live — no guards at all
         f2v w[LDS_R], t2[LDS_R];
 #pragma unroll
         for (int u = 0; u < LDS_R; ++u) {
-          const float q = fmaf(ftt[FULL ? u : (tb + u < te ? u : 0)], p.dq, base);
-          const float qf = floorf(q);
-          const float f = q - qf;
-          w[u][1] = (FULL || tb + u < te) ? f : 0.f;
-          w[u][0] = (FULL || tb + u < te) ? 1.0f - f : 0.f;
-          int c = (int)qf;
-          if (!FULL) {
-            const int lo = cs, hi = cs + LDS_W - 2;              // dead lanes / rows beyond te may point anywhere
-            c = (c < lo) ? lo : (c > hi ? hi : c);
-          }
-          // byte address = (row base - 4 cs) [scalar, opaque to the optimiser so that it is not re-associated into the
-          // lane part] + 4 c [one v_lshl_add]; both taps with one ds_read2_b32
-          int rowoff4 = (u * LDS_W - cs) * 4;
-          asm("" : "+s"(rowoff4));
-          const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(T) + rowoff4 + (c << 2));
+          const unsigned Q = Ac + Brow[u];                       // Brow is padded: rows beyond te read valid table entries
+          const float f1 = (float)(Q & 0xFFFFFFu);
+          w[u][1] = (FULL || tb + u < te) ? f1 : 0.f;
+          w[u][0] = (FULL || tb + u < te) ? QONE - f1 : 0.f;
+          unsigned c = Q >> QF;
+          if (!FULL) c = c > (unsigned)(LDS_W - 2) ? (unsigned)(LDS_W - 2) : c;   // dead lanes / rows beyond te may point anywhere
+          const float* tp = T + u * LDS_W + c;
           t2[u] = (f2v){tp[0], tp[1]};
         }
 #pragma unroll
@@ -319,7 +340,7 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
         f2v w[8], v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int off = radon_edge_tap(tb + 8 * k + u, te, live, N, p.dq, base, w[u]);
+          const int off = radon_edge_tap(tb + 8 * k + u, te, live, N, p.dq, base, A, Ball, w[u]);
           v[u] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
         }
 #pragma unroll
@@ -339,8 +360,8 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
 // that cross the same columns need the same window, so here a workgroup is 4 consecutive angles x ONE image window:
 //   * within a band, a ray belongs to the window its column at the band's TOP row falls into:
 //         jj = floor((q(d, t0) + OFFS) / WO),   WO = floor(61 min_w |inv_w|) columns  (<= 61 rays of any of the 4 angles);
-//     a wave takes the 64 detectors around the window's pre-image and keeps those whose q(d, t0) — the very float the
-//     march uses — lies in it, so every ray has exactly one owner per band;
+//     a wave takes the 64 detectors around the window's pre-image and keeps those whose fp32 estimate of q(d, t0) — one
+//     expression, evaluated identically by every workgroup — lies in it, so every ray has exactly one owner per band;
 //   * per chunk of 16 rows the union of the 4 waves' column ranges (a few columns wider than one wave's: angles 1 degree apart
 //     drift < 12 columns over a 128-row band) is staged ONCE, 2 direct-to-LDS 16-byte loads per thread into a double-buffered
 //     16 x 128 tile, one workgroup barrier per chunk; the march is that of k_radon_fwd_lds.
@@ -356,7 +377,8 @@ __global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__
                                                        float* __restrict__ out, int N, int nd,
                                                        const AngleParam* __restrict__ ang, int na_per_frame,
                                                        int ngrp_per_frame, int nwin, int64_t band_stride, int bh,
-                                                       const float* __restrict__ fidx) {
+                                                       const float* __restrict__ fidx,
+                                                       const unsigned* __restrict__ A32, const unsigned* __restrict__ B32, int npad) {
   __shared__ __attribute__((aligned(16))) float tile[2][WIN_R * WIN_W];
   __shared__ float ext[4][WIN_MAXCH][2];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -378,7 +400,7 @@ __global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__
   if ((int64_t)jj * WO - OFFS > (int64_t)N + bh + 4) return;     // window beyond every ray that can touch the band (uniform)
   const bool valid = wv < nval;
   const AngleParam p = ag[valid ? wv : 0];
-  const int a = frame * na_per_frame + af0 + wv;
+  const int a = frame * na_per_frame + af0 + (valid ? wv : 0);
   const float* __restrict__ I = (p.mode ? imgT : img) + (int64_t)frame * N * N;
   const unsigned img_bytes = (unsigned)N * (unsigned)N * 4u;
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)I, 0, img_bytes, 0x00020000);
@@ -399,7 +421,11 @@ __global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__
   const float b_first = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, base), l_first));
   const float b_last = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, base), l_last));
   const float blo = fminf(b_first, b_last), bhi = fmaxf(b_first, b_last);
-  const float base_m = owned ? base : b_first;                   // lanes without a ray follow an owned one: always inside the tile
+  const int dcl = d < 0 ? 0 : (d >= nd ? nd - 1 : d);
+  const unsigned A = A32[(int64_t)a * (nd + 2 * A32_PAD) + dcl + A32_PAD];
+  const unsigned A_first = (unsigned)__builtin_amdgcn_readlane((int)A, l_first);
+  const unsigned A_m = owned ? A : A_first;                       // lanes without a ray follow an owned one: always inside the tile
+  const unsigned* __restrict__ Ball = B32 + (int64_t)a * npad;
   double total = 0.0;
 
   if (mixed) {
@@ -409,7 +435,7 @@ __global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__
         f2v w[8], v[8], acc2 = {0.f, 0.f};
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-          const int off = radon_edge_tap(tb + u, t1, owned, N, p.dq, base, w[u]);
+          const int off = radon_edge_tap(tb + u, t1, owned, N, p.dq, base, A, Ball, w[u]);
           v[u] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
         }
 #pragma unroll
@@ -446,6 +472,7 @@ __global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__
       const int cs = __builtin_amdgcn_readfirstlane(nobody ? 0 : (((int)floorf(ulo) - 1) & ~3));
       const bool fits = !nobody && (__builtin_amdgcn_readfirstlane((int)floorf(nobody ? 0.f : uhi)) + 2 - cs) < WIN_W;
       const bool full = (te - tb == WIN_R);
+      const unsigned* __restrict__ Brow = Ball + tb;
       f2v acc2 = {0.f, 0.f};
       if (fits) {
         const unsigned rowbase = (unsigned)tb * (unsigned)N * 4u;
@@ -461,21 +488,19 @@ __global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__
       }
       __syncthreads();                                           // tile complete; also: everyone is done with the other buffer
       if (fits && any) {
-        const float* __restrict__ ftt = fidx + tb;
+        const unsigned Ac = A_m - ((unsigned)cs << QF);
         auto march = [&](auto full_tag) {
           constexpr bool FULL = decltype(full_tag)::value;
           f2v w[WIN_R], t2[WIN_R];
 #pragma unroll
           for (int u = 0; u < WIN_R; ++u) {
-            const float q = fmaf(ftt[FULL ? u : (tb + u < te ? u : 0)], p.dq, base_m);
-            const float qf = floorf(q);
-            const float f = q - qf;
-            w[u][1] = (FULL || tb + u < te) ? f : 0.f;
-            w[u][0] = (FULL || tb + u < te) ? 1.0f - f : 0.f;
-            const int c = (int)qf;
-            int rowoff4 = (u * WIN_W - cs) * 4;
-            asm("" : "+s"(rowoff4));
-            const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(T) + rowoff4 + (c << 2));
+            const unsigned Q = Ac + Brow[u];
+            const float f1 = (float)(Q & 0xFFFFFFu);
+            w[u][1] = (FULL || tb + u < te) ? f1 : 0.f;
+            w[u][0] = (FULL || tb + u < te) ? QONE - f1 : 0.f;
+            unsigned c = Q >> QF;
+            if (!FULL) c = c > (unsigned)(WIN_W - 2) ? (unsigned)(WIN_W - 2) : c;
+            const float* tp = T + u * WIN_W + c;
             t2[u] = (f2v){tp[0], tp[1]};
           }
 #pragma unroll
@@ -490,7 +515,7 @@ __global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__
           f2v w[8], v[8];
 #pragma unroll
           for (int u = 0; u < 8; ++u) {
-            const int off = radon_edge_tap(tb + 8 * k + u, te, owned, N, p.dq, base, w[u]);
+            const int off = radon_edge_tap(tb + 8 * k + u, te, owned, N, p.dq, base, A, Ball, w[u]);
             v[u] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off, 0, 0));
           }
 #pragma unroll
