@@ -1,6 +1,9 @@
-"""How far the fp32 ray coordinates put the projector from the float64 oracle: measured bounds, so that a
-regression in the coordinate arithmetic shows up.  The crossing position is one fp32 FMA on values up to N, i.e. an
-interpolation weight is off by up to ~6e-8 N; on a smooth image the errors average out, on white noise they do not."""
+"""The projector against the float64 oracle at the sizes that matter, white noise included.  With fp32 ray
+coordinates (round 1) an interpolation weight was off by ~6e-8 N and white-noise inputs showed it: 2.5e-5 / 7.6e-5 / 1.9e-4 at
+512 / 2048 / 4096.  The fixed-point coordinate (tables A32 + B32, 24 fractional bits) keeps every weight within 2^-24 of its
+float64 value at any N; the bar is north_star's 1e-5, what is measured is the fp32 accumulation."""
+import os
+
 import numpy as np
 import pytest
 
@@ -9,7 +12,7 @@ from conftest import relerr
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("N", [512, 2048])
+@pytest.mark.parametrize("N", [512, 2048, 4096])
 def test_projector_accuracy_against_float64_oracle(N):
     from oracle import cpu_ref as O
     from trips_py_amd.operators import Radon2DParallel
@@ -19,10 +22,51 @@ def test_projector_accuracy_against_float64_oracle(N):
     ii, jj = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
     smooth = (np.exp(-((ii - N / 2.5) ** 2 + (jj - N / 1.7) ** 2) / (0.02 * N * N)) + 0.05 * rng.random((N, N))).reshape(-1)
     f = lambda v: v.astype(np.float32).astype(np.float64)
-    assert relerr(R @ smooth, Ro @ f(smooth)) < 1e-6                       # measured 1.7e-7 (512), 1.8e-7 (2048), 3.3e-7 (4096)
+    e_smooth = relerr(R @ smooth, Ro @ f(smooth))
     noise = rng.standard_normal(Ro.shape[0])
-    e = relerr(R.T @ noise, Ro.T @ f(noise))
-    assert e < 1e-7 * N, e                                                  # measured 2.5e-5 (512), 7.6e-5 (2048), 1.9e-4 (4096)
+    e_adj = relerr(R.T @ noise, Ro.T @ f(noise))
     xn = rng.standard_normal(N * N)
-    e = relerr(R @ xn, Ro @ f(xn))
-    assert e < 1e-7 * N, e
+    e_fwd = relerr(R @ xn, Ro @ f(xn))
+    print(f"N={N}: forward smooth {e_smooth:.2e}, forward noise {e_fwd:.2e}, adjoint noise {e_adj:.2e}")
+    assert e_smooth < 2e-6 and e_fwd < 1e-5 and e_adj < 1e-5, (e_smooth, e_fwd, e_adj)
+
+
+def test_projector_4096x180_against_oracle_rows():
+    """The north_star size: 4096^2 x 180 angles through the window-sharing forward kernel and the tiled adjoint, checked on a
+    subset of the oracle's sparse matrix (9 of the 180 angles: its rows for the forward, its columns for the adjoint of a
+    sinogram that is zero elsewhere)."""
+    from oracle import cpu_ref as O
+    from trips_py_amd.operators import Radon2DParallel
+    N, na = 4096, 180
+    ang = np.linspace(0, np.pi, na, endpoint=False)
+    pick = np.array([0, 1, 44, 45, 46, 90, 133, 135, 179])
+    R, Ro = Radon2DParallel(N, ang), O.Radon2D(N, ang[pick])
+    rng = np.random.default_rng(5)
+    f = lambda v: v.astype(np.float32).astype(np.float64)
+    x = rng.standard_normal(N * N)
+    got = (R @ x).reshape(na, N)[pick].reshape(-1)
+    e_fwd = relerr(got, Ro @ f(x))
+    y = np.zeros((na, N))
+    y[pick] = rng.standard_normal((pick.size, N))
+    e_adj = relerr(R.T @ y.reshape(-1), Ro.T @ f(y[pick].reshape(-1)))
+    print(f"4096^2 x 180: forward {e_fwd:.2e}, adjoint {e_adj:.2e}")
+    assert e_fwd < 1e-5 and e_adj < 1e-5, (e_fwd, e_adj)
+
+
+@pytest.mark.parametrize("N,na,nd", [(96, 7, 96), (257, 33, 301), (1024, 12, 1024)])
+def test_tiled_adjoint_equals_the_plain_gather(N, na, nd):
+    """k_radon_adj_tile (LDS-staged records, 4 pixels per thread) computes what k_radon_adj_simple (one thread per pixel, records
+    from memory) computes: the same records, the same integer t0, the same three weights; only the order of the sum over
+    the angles differs (the tiled kernel adds its row-driven and column-driven angles separately)."""
+    import torch
+    from trips_py_amd.operators import Radon2DParallel
+    ang = np.linspace(0.05, np.pi + 0.05, na, endpoint=False)
+    R = Radon2DParallel(N, ang, n_det=nd)
+    y = torch.randn(R.shape[0], device=R.engine.device, generator=torch.Generator(device=R.engine.device).manual_seed(1))
+    a = R.apply(y, transpose=True).clone()
+    os.environ["TRK_RADON_ADJ_SIMPLE"] = "1"
+    try:
+        b = R.apply(y, transpose=True).clone()
+    finally:
+        del os.environ["TRK_RADON_ADJ_SIMPLE"]
+    assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b)) < 5e-7

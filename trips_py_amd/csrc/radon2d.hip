@@ -43,11 +43,12 @@ using namespace trk;
 namespace {
 
 constexpr int QF = 24;                          // fractional bits of the fixed-point ray coordinate
-constexpr float QONE = 16777216.0f;             // 2^24
+constexpr float QONE = 16777216.0f;             // 2^24: the adjoint's weights are in units of 2^-24
+constexpr float QTWO32 = 4294967296.0f;         // 2^32: the forward's weights are in units of 2^-32 ((float)(Q << 8))
 constexpr int A32_PAD = 2;                      // A32 rows hold d = -2 .. nd+1
 
 struct AngleParam {
-  float inv, dq, k0, wgt;   // fp32 copies: only for ESTIMATES (window placement, candidate location); wgt includes 2^-24
+  float inv, dq, k0, wgt;   // fp32 copies: only for ESTIMATES (window placement, candidate location); wgt includes the forward's 2^-32
   int mode;
   float rinv;               // ~1/inv
   float inv24;              // inv * 2^24: distance between neighbouring rays in fixed-point units (adjoint)
@@ -111,14 +112,14 @@ __device__ __forceinline__ int radon_abs_col(unsigned Q, float qest) {
 }
 
 // One marching step of one ray with full edge handling (direct-gather paths): offset of the 8-byte load and the two tap
-// weights in units of 2^-24 (taps outside the image, steps outside [.., te) and rays outside the detector weigh 0).
+// weights in units of 2^-32 (taps outside the image, steps outside [.., te) and rays outside the detector weigh 0).
 __device__ __forceinline__ int radon_edge_tap(int tt, int te, bool live, int N, float dq, float base, unsigned A,
                                               const unsigned* __restrict__ Brow, f2v& w) {
   const bool valid = live && tt < te;
   const int tr = tt < te ? tt : te - 1;
   const unsigned Q = A + Brow[tr];
   const int c = radon_abs_col(Q, fmaf((float)tr, dq, base));
-  const float f1 = (float)(Q & 0xFFFFFFu), f0 = QONE - f1;
+  const float f1 = (float)(Q << 8), f0 = QTWO32 - f1;              // units of 2^-32, like the staged march
   // c == -1: only the right tap (column 0) is inside; start the 8-byte load at column 0 instead (an access that
   // STARTS below the buffer is dropped whole by the range check — measured on gfx950 — while one that runs off
   // the end returns its in-range dword)
@@ -184,8 +185,8 @@ __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img
           const int tt = tb + 8 * k + u;
           const unsigned Q = A + Brow[tt];
           const int c = radon_abs_col(Q, fmaf((float)tt, p.dq, base));
-          w[k & 1][u][1] = (float)(Q & 0xFFFFFFu);
-          w[k & 1][u][0] = QONE - w[k & 1][u][1];
+          w[k & 1][u][1] = (float)(Q << 8);
+          w[k & 1][u][0] = QTWO32 - w[k & 1][u][1];
           v[k & 1][u] = __builtin_bit_cast(f2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, c << 2, (unsigned)tt * (unsigned)N * 4u, 0));
         }
       };
@@ -263,6 +264,8 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
   const bool live = lane < nlive;
   const unsigned A = A32[(int64_t)a * (nd + 2 * A32_PAD) + (live ? d : nd - 1) + A32_PAD];
   const unsigned* __restrict__ Ball = B32 + (int64_t)a * npad;
+  float two32 = 4294967296.0f;                     // kept in an SGPR (opaque to the optimiser): no 32-bit literal per step
+  asm("" : "+s"(two32));
   // base is monotone in the lane: the window's column range comes from the first and the last live ray
   const float b0 = fmaf((float)(dblk * 64) - sdh, p.inv, p.k0), b1 = fmaf((float)(dblk * 64 + nlive - 1) - sdh, p.inv, p.k0);
   const float blo = fminf(b0, b1), bhi = fmaxf(b0, b1);
@@ -287,7 +290,8 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
     const int cs = __builtin_amdgcn_readfirstlane(((int)floorf(qlo) - 1) & ~3);   // one column of slack for the fp32 estimate
     const bool fits = (__builtin_amdgcn_readfirstlane((int)floorf(qhi)) + 2 - cs) < LDS_W;
     const bool full = (te - tb == LDS_R);
-    const unsigned* __restrict__ Brow = Ball + tb;
+    // 64-byte aligned (rows are padded to multiples of 32 entries, tb is a multiple of 16): one s_load_dwordx16 per chunk
+    const unsigned* __restrict__ Brow = static_cast<const unsigned*>(__builtin_assume_aligned(Ball + tb, 64));
     f2v acc2 = {0.f, 0.f};
     if (fits) {
       // stage: rows tb .. tb+15 (beyond te: not fetched), columns cs .. cs+111 (outside the image: zeros); the row part of the
@@ -319,12 +323,16 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
 #pragma unroll
         for (int u = 0; u < LDS_R; ++u) {
           const unsigned Q = Ac + Brow[u];                       // Brow is padded: rows beyond te read valid table entries
-          const float f1 = (float)(Q & 0xFFFFFFu);
+          const float f1 = (float)(Q << 8);                      // the 24 fraction bits, in units of 2^-32 (exact: 24 significant bits)
           w[u][1] = (FULL || tb + u < te) ? f1 : 0.f;
-          w[u][0] = (FULL || tb + u < te) ? QONE - f1 : 0.f;
+          w[u][0] = (FULL || tb + u < te) ? two32 - f1 : 0.f;
           unsigned c = Q >> QF;
           if (!FULL) c = c > (unsigned)(LDS_W - 2) ? (unsigned)(LDS_W - 2) : c;   // dead lanes / rows beyond te may point anywhere
-          const float* tp = T + u * LDS_W + c;
+          // byte address = row base [scalar, opaque to the optimiser so that it stays a scalar add and is not turned into a
+          // per-lane one] + 4 c [one v_lshl_add]; both taps with one ds_read2_b32
+          int rowoff4 = u * LDS_W * 4;
+          asm("" : "+s"(rowoff4));
+          const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(T) + rowoff4 + (c << 2));
           t2[u] = (f2v){tp[0], tp[1]};
         }
 #pragma unroll
@@ -426,6 +434,8 @@ __global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__
   const unsigned A_first = (unsigned)__builtin_amdgcn_readlane((int)A, l_first);
   const unsigned A_m = owned ? A : A_first;                       // lanes without a ray follow an owned one: always inside the tile
   const unsigned* __restrict__ Ball = B32 + (int64_t)a * npad;
+  float two32 = 4294967296.0f;                     // kept in an SGPR (opaque to the optimiser): no 32-bit literal per step
+  asm("" : "+s"(two32));
   double total = 0.0;
 
   if (mixed) {
@@ -472,7 +482,7 @@ __global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__
       const int cs = __builtin_amdgcn_readfirstlane(nobody ? 0 : (((int)floorf(ulo) - 1) & ~3));
       const bool fits = !nobody && (__builtin_amdgcn_readfirstlane((int)floorf(nobody ? 0.f : uhi)) + 2 - cs) < WIN_W;
       const bool full = (te - tb == WIN_R);
-      const unsigned* __restrict__ Brow = Ball + tb;
+      const unsigned* __restrict__ Brow = static_cast<const unsigned*>(__builtin_assume_aligned(Ball + tb, 64));
       f2v acc2 = {0.f, 0.f};
       if (fits) {
         const unsigned rowbase = (unsigned)tb * (unsigned)N * 4u;
@@ -495,12 +505,14 @@ __global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__
 #pragma unroll
           for (int u = 0; u < WIN_R; ++u) {
             const unsigned Q = Ac + Brow[u];
-            const float f1 = (float)(Q & 0xFFFFFFu);
+            const float f1 = (float)(Q << 8);                    // the 24 fraction bits, in units of 2^-32 (exact)
             w[u][1] = (FULL || tb + u < te) ? f1 : 0.f;
-            w[u][0] = (FULL || tb + u < te) ? QONE - f1 : 0.f;
+            w[u][0] = (FULL || tb + u < te) ? two32 - f1 : 0.f;
             unsigned c = Q >> QF;
             if (!FULL) c = c > (unsigned)(WIN_W - 2) ? (unsigned)(WIN_W - 2) : c;
-            const float* tp = T + u * WIN_W + c;
+            int rowoff4 = u * WIN_W * 4;
+            asm("" : "+s"(rowoff4));
+            const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(T) + rowoff4 + (c << 2));
             t2[u] = (f2v){tp[0], tp[1]};
           }
 #pragma unroll
@@ -549,127 +561,236 @@ __global__ __launch_bounds__(256) void k_radon_bands_sum(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------- adjoint (gather)
-// One thread per pixel; grid = (ceil(N*N/256), n_frames, batch).  The forward weights of ray d on its two taps are
-// (1-f, f) with f = q - floor(q), i.e. hat(q - col) = max(0, 1 - |q - col|) on pixel `col`; the gather evaluates exactly
-// that for the three detectors nearest to the pixel's inverse image d* (every ray with |q - col| < 1 is among them,
-// because |dq/dd| = 1/|cos| >= 1), with q computed by the SAME float expression as the forward kernel.  The weights are
-// bit-identical to the forward ones (the subtractions involved are exact), so this is the exact transpose.
-__global__ __launch_bounds__(256) void k_radon_adj(const float* __restrict__ sino, int64_t ld_sino,
-                                                   float* __restrict__ img, int64_t ld_img, int N, int nd, int na,
-                                                   const AngleParam* __restrict__ ang) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (int64_t)N * N) return;
-  const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
-  const int frame = blockIdx.y;                   // blockIdx.y = time frame, blockIdx.z = batch vector
-  const float* __restrict__ S = sino + (int64_t)blockIdx.z * ld_sino + (int64_t)frame * na * nd;
-  ang += (int64_t)frame * na;
-  const float sdh = 0.5f * (float)(nd - 1);
-  const float fi = (float)i, fj = (float)j;
-  float acc = 0.f;
-  // One angle: ftt = marching index, fcol = interpolated coordinate this pixel sits on.  The sinogram row is read
-  // through its own buffer descriptor, so candidates d < 0 or d >= nd return 0 without any VALU bounds logic (single
-  // dwords: the range check applies per access).
-  auto one_angle = [&](const AngleParam p, const __amdgpu_buffer_rsrc_t row, float ftt, float fcol) {
-    const float off = fmaf(ftt, p.dq, p.k0);
-    const float d0f = rintf(fmaf(fcol - off, p.rinv, sdh));
-    const int d0 = (int)d0f;
-    const float sd0 = d0f - sdh;                  // exact, == (float)d0 - sdh of the forward kernel
-    float sum = 0.f;
-#pragma unroll
-    for (int e = -1; e <= 1; ++e) {
-      const float q = fmaf(ftt, p.dq, fmaf(sd0 + (float)e, p.inv, p.k0));
-      const float wgt = fmaxf(1.0f - fabsf(q - fcol), 0.f);
-      // the empty asm hides that the three offsets are adjacent: merged into one wider load, a candidate pair that
-      // STARTS at d = -1 would be dropped whole by the range check and lose its in-range element d = 0
-      int voff = (d0 + e) << 2;
-      asm("" : "+v"(voff));
-      const float sv = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(row, voff, 0, 0));
-      sum = fmaf(wgt, sv, sum);
-    }
-    acc = fmaf(p.wgt, sum, acc);
-  };
-  auto angle = [&](int a) {
-    const AngleParam p = ang[a];
-    const auto row = __builtin_amdgcn_make_buffer_rsrc((void*)(S + (int64_t)a * nd), 0, (unsigned)nd * 4u, 0x00020000);
-    one_angle(p, row, p.mode ? fj : fi, p.mode ? fi : fj);
-  };
-  int a = 0;
-  for (; a + 4 <= na; a += 4) {   // unrolled by hand: loops holding inline asm are not runtime-unrolled by the compiler
-#pragma unroll
-    for (int u = 0; u < 4; ++u) angle(a + u);
-  }
-  for (; a < na; ++a) angle(a);
-  img[(int64_t)blockIdx.z * ld_img + (int64_t)frame * N * N + idx] = acc;
-}
+// The forward weights of ray d on its two taps are (1-f, f) with f = q - floor(q), i.e. hat(q - col) = max(0, 1 - |q - col|) on
+// pixel `col`.  Per pixel and angle the gather takes the ray d0 nearest to the pixel's inverse image d* (fp32 estimate) and
+// its two neighbours — every ray with |q - col| < 1 is among them because |dq/dd| = 1/|cos| >= 1:
+//   * t0 = q(d0, tt) - col comes from the SAME tables as the forward, as an integer: t_int = A32[d0] + B32[tt] - (col << 24)
+//     (mod 2^32, |t0| <= 0.71 + the estimate's error), so hat(t0) = 2^24 - |t_int| is bit-identical to the forward's weight;
+//   * the neighbours sit at t0 +- inv (one fp32 add each, 1.2e-7 relative to the weights' scale).
+// What is read per pixel and angle is ONE 16-byte record {w S[d0-1], w S[d0], w S[d0+1], A32[d0]} (w = the angle's weight
+// times 2^-24), written per apply by k_radon_adj_prep for the angles sorted by marching mode.
+//
+// k_radon_adj_tile: a workgroup owns a 32 x 32 pixel tile and walks the angles in batches of ADJ_AB.  Per batch it stages,
+// with direct-to-LDS loads, (i) for every angle the 64 records around the tile's inverse image, as a RING indexed by d0 & 63
+// (the tile's footprint is < 48 detectors, so no index arithmetic beyond a mask is needed to read a record), and (ii) the
+// pairs {C[a][tt], B32[a][tt]} of the tile's 32 marching indices (C: the locator offset, d* = col rinv + C).  A thread holds
+// 4 pixels that share the marching index — a run along the row for mode-0 angles, along the column for mode-1 angles — so
+// that pair is read once per angle and thread; the two partial images meet through LDS at the end.  Per pixel and angle:
+// 16 vector instructions and one ds_read_b128 (the first gather form of round 1: 34 instructions and three dword loads on the
+// texture path; the second: 26 and one 12-byte load).
+constexpr int ADJ_T = 32;      // tile edge (pixels)
+constexpr int ADJ_AB = 8;      // angles per staged batch
+constexpr float RND_MAGIC = 12582912.0f;   // 1.5 * 2^23: x + RND_MAGIC has rint(x) in its low mantissa bits (|x| < 2^22)
 
-// Second form of the same gather, 26 instead of 34 vector instructions per pixel and angle (the first form is VALU-bound: PMC
-// 90 % VALU, 95 % texture):
-//   * a pre-pass writes the sinogram rows SORTED by marching mode, scaled by the angle's weight, with two zeros in front
-//     (k_radon_adj_prep); the gather then runs one loop per mode (no per-angle selects), accumulates weight * value
-//     directly (no per-angle scaling) and fetches its three candidates with ONE 12-byte load that can never start below
-//     the row (candidate d0-1 = -2 is padded index 0; a start below that means all three candidates are outside);
-//   * the middle candidate's weight cannot be negative (|d0 - d*| <= 1/2, |inv| <= sqrt 2), so it needs no clamp.
-// Weights are still evaluated with the forward kernel's float expression: the same matrix entries, transposed.
-typedef float f3v __attribute__((ext_vector_type(3)));
-
-__global__ __launch_bounds__(256) void k_radon_adj_prep(const float* __restrict__ sino, float* __restrict__ sp, int nd, int na,
-                                                        const int* __restrict__ orig, const float* __restrict__ wgt) {
-  const int ndp = nd + ADJ_PAD;
+// records of one vector: rec[(frame*na + sorted angle)][e], e = d + 2 in [0, nd + 3]
+__global__ __launch_bounds__(256) void k_radon_adj_prep(const float* __restrict__ sino, uint4* __restrict__ rec, int nd, int na,
+                                                        const AdjAngle* __restrict__ ang, const float* __restrict__ wgt,
+                                                        const unsigned* __restrict__ A32) {
+  const int ndp = nd + 2 * A32_PAD;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over (sorted angle of the frame) x ndp; blockIdx.y = frame
   const int64_t r = idx / ndp;
   if (r >= (int64_t)na) return;
   const int e = (int)(idx - r * ndp);
   const int64_t rs = (int64_t)blockIdx.y * na + r;                   // sorted row (frame-major)
-  const int d = e - ADJ_PAD;
-  sp[rs * ndp + e] = d < 0 ? 0.f : wgt[rs] * sino[((int64_t)blockIdx.y * na + orig[rs]) * nd + d];
+  const int64_t ro = (int64_t)blockIdx.y * na + ang[rs].orig;        // the same angle in the caller's order
+  const int d = e - A32_PAD;
+  const float w = wgt[rs];
+  const float* __restrict__ S = sino + ro * nd;
+  uint4 o;
+  o.x = __builtin_bit_cast(unsigned, (d - 1 >= 0 && d - 1 < nd) ? w * S[d - 1] : 0.f);
+  o.y = __builtin_bit_cast(unsigned, (d >= 0 && d < nd) ? w * S[d] : 0.f);
+  o.z = __builtin_bit_cast(unsigned, (d + 1 >= 0 && d + 1 < nd) ? w * S[d + 1] : 0.f);
+  o.w = A32[ro * ndp + e];
+  rec[rs * ndp + e] = o;
 }
 
-__global__ __launch_bounds__(256) void k_radon_adj2(const float* __restrict__ sp, float* __restrict__ img, int N, int nd, int na,
-                                                    const AdjAngle* __restrict__ ang, const int* __restrict__ n_mode0,
-                                                    double* __restrict__ ssq_part) {
+// LDS by byte offset: the ring slot of detector d0 is (d0 & 63) * 16 behind the ring's base, which is one v_and_b32 and one
+// v_lshl_add_u32 with the (wave-uniform) base in an SGPR — spelled out, or the optimiser turns it into shift + mask + add
+__device__ __forceinline__ unsigned lds_offset(const void* p) {
+  return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+typedef unsigned u4r __attribute__((ext_vector_type(4)));     // a record {w S[d-1], w S[d], w S[d+1], A32[d]}
+__device__ __forceinline__ u4r ring_read(unsigned ring_base, unsigned bits) {
+  unsigned addr;
+  const unsigned slot = bits & 63u;
+  asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(slot), "s"(ring_base));
+  auto* p = reinterpret_cast<__attribute__((address_space(3))) const u4r*>((size_t)addr);
+  p = (decltype(p))__builtin_assume_aligned(p, 16);              // one ds_read_b128 (otherwise split into two 8-byte reads)
+  return *p;
+}
+
+// one pixel, one angle: the record, t0 from the tables, three hat weights
+__device__ __forceinline__ float adj_gather(const u4r r, unsigned B, unsigned negcol24, float inv24, float acc) {
+  // NOTE the elements are copied to scalars first: __builtin_bit_cast(float, r[k]) on an ext-vector ELEMENT reads element 0
+  // whatever k is (hipcc / ROCm 7.2; found the hard way — the adjoint summed (w0 + wp + wm) S[d0-1])
+  const unsigned sm = r[0], s0 = r[1], sp = r[2], a32 = r[3];
+  unsigned ti;                                                   // t_int = A32 + B32 - (col << 24), wrap-around mod 2^32 is the point
+  asm("v_add3_u32 %0, %1, %2, %3" : "=v"(ti) : "v"(a32), "v"(B), "v"(negcol24));
+  const float tf = (float)(int)ti;
+  const float w0 = QONE - fabsf(tf);
+  const float wp = fmaxf(QONE - fabsf(tf + inv24), 0.f);
+  const float wm = fmaxf(QONE - fabsf(tf - inv24), 0.f);
+  acc = fmaf(w0, __builtin_bit_cast(float, s0), acc);
+  acc = fmaf(wp, __builtin_bit_cast(float, sp), acc);
+  return fmaf(wm, __builtin_bit_cast(float, sm), acc);
+}
+
+__global__ __launch_bounds__(256) void k_radon_adj_tile(const uint4* __restrict__ rec, float* __restrict__ img, int N, int nd, int na,
+                                                        const AdjAngle* __restrict__ ang, const int* __restrict__ n_mode0,
+                                                        const uint2* __restrict__ CB, int npad, int tiles_x,
+                                                        double* __restrict__ ssq_part) {
+  __shared__ __attribute__((aligned(16))) uint4 ring[2][ADJ_AB][64];            // 16 KB
+  __shared__ __attribute__((aligned(16))) uint2 cbs[2][ADJ_AB][ADJ_T];          // 4 KB
+  __shared__ float xch[ADJ_T][ADJ_T + 1];
+  __shared__ double lds[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frame = blockIdx.y;
+  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  const int i0 = ty * ADJ_T, j0 = tx * ADJ_T;
+  const int ndp = nd + 2 * A32_PAD;
+  ang += (int64_t)frame * na;
+  rec += (int64_t)frame * na * ndp;
+  CB += (int64_t)frame * na * npad;
+  const int n0 = n_mode0[frame];
+  const float sdh = 0.5f * (float)(nd - 1);
+  const auto rrec = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, (unsigned)((int64_t)na * ndp * 16), 0x00020000);
+  const auto rcb = __builtin_amdgcn_make_buffer_rsrc((void*)CB, 0, (unsigned)((int64_t)na * npad * 8), 0x00020000);
+
+  // thread -> pixels.  mode 0 (marching index = row): row r0, columns c0 .. c0+3;  mode 1 (= column): column c1, rows r1 .. r1+3
+  const int r0 = tid >> 3, c0 = (tid & 7) * 4;
+  const int c1 = tid & 31, r1 = (tid >> 5) * 4;
+  float fcolA[4], fcolB[4];
+  unsigned colA[4], colB[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    fcolA[k] = (float)(j0 + c0 + k);                 // mode 0: interpolated coordinate = column
+    colA[k] = 0u - ((unsigned)(j0 + c0 + k) << QF);   // negated: t_int = A32 + B32 - (col << 24)
+    fcolB[k] = (float)(i0 + r1 + k);                 // mode 1: interpolated coordinate = row
+    colB[k] = 0u - ((unsigned)(i0 + r1 + k) << QF);
+  }
+  float accA[4] = {0.f, 0.f, 0.f, 0.f}, accB[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const int nbatch = (na + ADJ_AB - 1) / ADJ_AB;
+  // staging of batch b into buffer b & 1: wave w brings the rings of angles w and w + 4 of the batch; the first 128 threads
+  // bring the {C, B32} pairs (16 bytes = two marching indices per thread)
+  auto stage = [&](int b) {
+    const int buf = b & 1;
+#pragma unroll
+    for (int h = 0; h < ADJ_AB / 4; ++h) {
+      const int al = wv + 4 * h;
+      int a = b * ADJ_AB + al;
+      a = a < na ? a : na - 1;
+      const AdjAngle p = ang[a];
+      const bool m1 = a >= n0;
+      // inverse image of the tile: d* = col rinv + (sdh - (k0 + tt dq) rinv), extremes at the corners
+      const float tt_lo = (float)(m1 ? j0 : i0), co_lo = (float)(m1 ? i0 : j0);
+      const float dA = fmaf(co_lo - fmaf(tt_lo, p.dq, p.k0), p.rinv, sdh);
+      const float dB = fmaf(co_lo + (float)(ADJ_T - 1) - fmaf(tt_lo, p.dq, p.k0), p.rinv, sdh);
+      const float dC = fmaf(co_lo - fmaf(tt_lo + (float)(ADJ_T - 1), p.dq, p.k0), p.rinv, sdh);
+      const float dD = fmaf(co_lo + (float)(ADJ_T - 1) - fmaf(tt_lo + (float)(ADJ_T - 1), p.dq, p.k0), p.rinv, sdh);
+      const float dmin = fminf(fminf(dA, dB), fminf(dC, dD)), dmax = fmaxf(fmaxf(dA, dB), fmaxf(dC, dD));
+      const int dbase = __builtin_amdgcn_readfirstlane((int)floorf(0.5f * (dmin + dmax))) - 32;   // ring covers dbase .. dbase + 63
+      const int d = dbase + ((lane - dbase) & 63);                   // the detector whose ring slot is this lane
+      int e = d + A32_PAD;
+      e = e < 0 ? 0 : (e > ndp - 1 ? ndp - 1 : e);                   // beyond the detector: the all-zero end records
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rrec, (__attribute__((address_space(3))) void*)&ring[buf][al][0], 16,
+                                               (a * ndp + e) * 16, 0, 0, 0);
+    }
+    if (tid < ADJ_AB * ADJ_T / 2) {
+      const int al = tid / (ADJ_T / 2), pr = tid - al * (ADJ_T / 2);
+      int a = b * ADJ_AB + al;
+      a = a < na ? a : na - 1;
+      const int tt0 = (a >= n0 ? j0 : i0) + 2 * pr;                  // even: 16-byte aligned pairs (npad is even)
+      // (the LDS address of a direct-to-LDS load is wave-uniform base + 16 * lane: wave 1 lands 1 KB behind wave 0)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rcb, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(&cbs[buf][0][0]) + wv * 1024),
+                                               16, (ang[a].orig * npad + tt0) * 8, 0, 0, 0);
+    }
+  };
+
+  stage(0);
+  for (int b = 0; b < nbatch; ++b) {
+    const int buf = b & 1;
+    __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this wave's share of batch b has landed
+    __syncthreads();                                 // batch b complete; everyone is done with the other buffer
+    if (b + 1 < nbatch) stage(b + 1);
+    const int nal = (na - b * ADJ_AB < ADJ_AB) ? na - b * ADJ_AB : ADJ_AB;
+    for (int al = 0; al < nal; ++al) {
+      const int a = b * ADJ_AB + al;
+      const AdjAngle p = ang[a];                     // wave-uniform: scalar loads
+      const unsigned rbase = __builtin_amdgcn_readfirstlane(lds_offset(&ring[buf][al][0]));
+      if (a < n0) {
+        const uint2 cb = cbs[buf][al][r0];
+        const float C = __builtin_bit_cast(float, cb.x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcolA[k], p.rinv, C) + RND_MAGIC);
+          const u4r r = ring_read(rbase, bits);
+          accA[k] = adj_gather(r, cb.y, colA[k], p.inv24, accA[k]);
+        }
+      } else {
+        const uint2 cb = cbs[buf][al][c1];
+        const float C = __builtin_bit_cast(float, cb.x);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcolB[k], p.rinv, C) + RND_MAGIC);
+          const u4r r = ring_read(rbase, bits);
+          accB[k] = adj_gather(r, cb.y, colB[k], p.inv24, accB[k]);
+        }
+      }
+    }
+  }
+  // the two partial images meet: mode-0 sums go through LDS to the thread that holds the pixel in the mode-1 layout
+#pragma unroll
+  for (int k = 0; k < 4; ++k) xch[r0][c0 + k] = accA[k];
+  __syncthreads();
+  double q = 0.0;
+  img += (int64_t)frame * N * N;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int i = i0 + r1 + k, j = j0 + c1;
+    const float o = accB[k] + xch[r1 + k][c1];
+    if (i < N && j < N) {
+      img[(int64_t)i * N + j] = o;
+      q += (double)o * o;
+    }
+  }
+  if (ssq_part) {                                                 // uniform over the grid
+    q = block_sum<256>(q, lds);
+    if (tid == 0) ssq_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = q;
+  }
+}
+
+// The same arithmetic without LDS (one thread per pixel, records and table pairs read from memory): the reference form the
+// tiled kernel is tested against (TRK_RADON_ADJ_SIMPLE=1 selects it) and the path for frames too small to tile.
+__global__ __launch_bounds__(256) void k_radon_adj_simple(const uint4* __restrict__ rec, float* __restrict__ img, int N, int nd, int na,
+                                                          const AdjAngle* __restrict__ ang, const int* __restrict__ n_mode0,
+                                                          const uint2* __restrict__ CB, int npad, double* __restrict__ ssq_part) {
   __shared__ double lds[4];
   const int64_t idx_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const bool inside = idx_raw < (int64_t)N * N;
-  const int64_t idx = inside ? idx_raw : (int64_t)N * N - 1;        // lanes past the image repeat the last pixel (no store)
+  const int64_t idx = inside ? idx_raw : (int64_t)N * N - 1;
   const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
   const int frame = blockIdx.y;
-  const int ndp = nd + ADJ_PAD;
-  const float* __restrict__ S = sp + (int64_t)frame * na * ndp;
+  const int ndp = nd + 2 * A32_PAD;
   ang += (int64_t)frame * na;
+  rec += (int64_t)frame * na * ndp;
+  CB += (int64_t)frame * na * npad;
   const int n0 = n_mode0[frame];
-  const float sdh = 0.5f * (float)(nd - 1);
-  const float fi = (float)i, fj = (float)j;
-  float accm = 0.f, acc0 = 0.f, accp = 0.f;
-  auto one_angle = [&](int a, float ftt, float fcol) {
+  float acc = 0.f;
+  for (int a = 0; a < na; ++a) {
     const AdjAngle p = ang[a];
-    const auto row = __builtin_amdgcn_make_buffer_rsrc((void*)(S + (int64_t)a * ndp), 0, (unsigned)ndp * 4u, 0x00020000);
-    const float off = fmaf(ftt, p.dq, p.k0);
-    const float d0f = rintf(fmaf(fcol - off, p.rinv, sdh));
-    const int d0 = (int)d0f;
-    const float sd0 = d0f - sdh;                  // exact, == (float)d0 - sdh of the forward kernel
-    const f3v v = __builtin_bit_cast(f3v, __builtin_amdgcn_raw_buffer_load_b96(row, (d0 << 2) + 4 * (ADJ_PAD - 1), 0, 0));
-    const float qm = fmaf(ftt, p.dq, fmaf(sd0 - 1.0f, p.inv, p.k0));
-    const float q0 = fmaf(ftt, p.dq, fmaf(sd0, p.inv, p.k0));
-    const float qp = fmaf(ftt, p.dq, fmaf(sd0 + 1.0f, p.inv, p.k0));
-    accm = fmaf(fmaxf(1.0f - fabsf(qm - fcol), 0.f), v[0], accm);
-    acc0 = fmaf(1.0f - fabsf(q0 - fcol), v[1], acc0);
-    accp = fmaf(fmaxf(1.0f - fabsf(qp - fcol), 0.f), v[2], accp);
-  };
-  int a = 0;
-  for (; a + 4 <= n0; a += 4) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) one_angle(a + u, fi, fj);
+    const int tt = a < n0 ? i : j, col = a < n0 ? j : i;
+    const uint2 cb = CB[(int64_t)p.orig * npad + tt];
+    int d0 = (int)rintf(fmaf((float)col, p.rinv, __builtin_bit_cast(float, cb.x)));
+    int e = d0 + A32_PAD;
+    e = e < 0 ? 0 : (e > ndp - 1 ? ndp - 1 : e);
+    const uint4 rr = rec[(int64_t)a * ndp + e];
+    acc = adj_gather((u4r){rr.x, rr.y, rr.z, rr.w}, cb.y, 0u - ((unsigned)col << QF), p.inv24, acc);
   }
-  for (; a < n0; ++a) one_angle(a, fi, fj);
-  for (; a + 4 <= na; a += 4) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) one_angle(a + u, fj, fi);
-  }
-  for (; a < na; ++a) one_angle(a, fj, fi);
-  const float o = (accm + accp) + acc0;
-  if (inside) img[(int64_t)frame * N * N + idx] = o;
-  if (ssq_part) {                                                 // uniform over the grid
-    const double q = block_sum<256>(inside ? (double)o * o : 0.0, lds);
+  if (inside) img[(int64_t)frame * N * N + idx] = acc;
+  if (ssq_part) {
+    const double q = block_sum<256>(inside ? (double)acc * acc : 0.0, lds);
     if (threadIdx.x == 0) ssq_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = q;
   }
 }
@@ -681,10 +802,13 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
   TimerScope tm(op->timer, op->timer_which, tr, s);
   // fused ||y||^2 (batch 1): block partials from the kernel that writes y (band reduction / gather), then one finalize
   double* ssq_part = nullptr;
-  static const bool adj_first_form = getenv("TRK_RADON_ADJ_V1") != nullptr;
-  const bool fuse_ssq = sumsq && batch == 1 && (tr ? !adj_first_form : im->n_bands > 1);
+  const bool adj_simple = getenv("TRK_RADON_ADJ_SIMPLE") != nullptr;   // read per call: tests switch it
+  const bool tile = !adj_simple && N >= ADJ_T;
+  const int tiles_x = ceil_div(N, ADJ_T);
+  const int64_t adj_blocks = tile ? (int64_t)tiles_x * tiles_x : (int64_t)ceil_div((int64_t)N * N, 256);
+  const bool fuse_ssq = sumsq && batch == 1 && (tr || im->n_bands > 1);
   if (fuse_ssq) {
-    const int64_t nblk = tr ? (int64_t)ceil_div((int64_t)N * N, 256) * nt : (int64_t)ceil_div((int64_t)nt * na * nd, 256);
+    const int64_t nblk = tr ? adj_blocks * nt : (int64_t)ceil_div((int64_t)nt * na * nd, 256);
     if (int rc = scratch_doubles(s, (size_t)nblk, &ssq_part)) return rc;
   }
   if (!tr) {
@@ -709,16 +833,16 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
         if (hipMemsetAsync(im->part, 0, sizeof(float) * (size_t)nb * bs, s) != hipSuccess) return fail(TRK_EHIP, "radon: hipMemsetAsync failed");
         const int nwin = ceil_div(N + 2 * im->band + 16, 61);
         dim3 gw(nwin * ngrp * nt, nb, 1);
-        hipLaunchKernelGGL(k_radon_fwd_win<0>, gw, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, nwin, bs, im->band, im->fidx);
+        hipLaunchKernelGGL(k_radon_fwd_win<0>, gw, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, nwin, bs, im->band, im->fidx, im->A32, im->B32, im->npad);
         hipLaunchKernelGGL(k_radon_bands_sum, dim3(ceil_div(bs, 256)), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev, ssq_part);
       } else if (nb == 1) {
-        if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<true, true>), grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
-        else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
-        else hipLaunchKernelGGL(k_radon_fwd<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band);
+        if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<true, true>), grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
+        else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
+        else hipLaunchKernelGGL(k_radon_fwd<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
       } else {
-        if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<false, true>), grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
-        else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->fidx);
-        else hipLaunchKernelGGL(k_radon_fwd<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band);
+        if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<false, true>), grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
+        else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
+        else hipLaunchKernelGGL(k_radon_fwd<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
         hipLaunchKernelGGL(k_radon_bands_sum, dim3(ceil_div(bs, 256)), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev, ssq_part);
       }
       TRK_LAUNCH_CHECK();
@@ -728,23 +852,21 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
       return finalize_sums(ssq_part, ceil_div((int64_t)nt * na * nd, 256), 1, 1, sumsq, s);
     }
   } else {
-    if (adj_first_form) {
-      dim3 grid(ceil_div((int64_t)N * N, 256), nt, batch);
-      hipLaunchKernelGGL(k_radon_adj, grid, dim3(256), 0, s, x, ldx, y, ldy, N, nd, na, im->ang_dev);
+    const int ndp = nd + 2 * A32_PAD;
+    for (int b = 0; b < batch; ++b) {            // the record array is per vector
+      hipLaunchKernelGGL(k_radon_adj_prep, dim3(ceil_div((int64_t)na * ndp, 256), nt), dim3(256), 0, s, x + (int64_t)b * ldx,
+                         im->rec, nd, na, im->adj_ang, im->adj_wgt, im->A32);
+      if (tile)
+        hipLaunchKernelGGL(k_radon_adj_tile, dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
+                           im->adj_ang, im->adj_n0, im->CB, im->npad, tiles_x, ssq_part);
+      else
+        hipLaunchKernelGGL(k_radon_adj_simple, dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
+                           im->adj_ang, im->adj_n0, im->CB, im->npad, ssq_part);
       TRK_LAUNCH_CHECK();
-    } else {
-      const int ndp = nd + ADJ_PAD;
-      for (int b = 0; b < batch; ++b) {            // the padded copy is per vector
-        hipLaunchKernelGGL(k_radon_adj_prep, dim3(ceil_div((int64_t)na * ndp, 256), nt), dim3(256), 0, s, x + (int64_t)b * ldx,
-                           im->sino_pad, nd, na, im->adj_orig, im->adj_wgt);
-        hipLaunchKernelGGL(k_radon_adj2, dim3(ceil_div((int64_t)N * N, 256), nt), dim3(256), 0, s, im->sino_pad,
-                           y + (int64_t)b * ldy, N, nd, na, im->adj_ang, im->adj_n0, ssq_part);
-        TRK_LAUNCH_CHECK();
-      }
-      if (ssq_part) {
-        tm.stop();
-        return finalize_sums(ssq_part, ceil_div((int64_t)N * N, 256) * nt, 1, 1, sumsq, s);
-      }
+    }
+    if (ssq_part) {
+      tm.stop();
+      return finalize_sums(ssq_part, (int)(adj_blocks * nt), 1, 1, sumsq, s);
     }
   }
   tm.stop();
@@ -759,15 +881,9 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
 
 void radon_destroy(trk_op* op) {
   auto* im = static_cast<RadonImpl*>(op->impl);
-  if (im->ang_dev) (void)hipFree(im->ang_dev);
-  if (im->xT) (void)hipFree(im->xT);
-  if (im->part) (void)hipFree(im->part);
-  if (im->fidx) (void)hipFree(im->fidx);
-  if (im->adj_ang) (void)hipFree(im->adj_ang);
-  if (im->adj_orig) (void)hipFree(im->adj_orig);
-  if (im->adj_wgt) (void)hipFree(im->adj_wgt);
-  if (im->adj_n0) (void)hipFree(im->adj_n0);
-  if (im->sino_pad) (void)hipFree(im->sino_pad);
+  void* ptrs[] = {im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec};
+  for (void* q : ptrs)
+    if (q) (void)hipFree(q);
   delete im;
 }
 
@@ -775,33 +891,47 @@ void radon_destroy(trk_op* op) {
 
 static int radon_create_impl(int N, int n_det, const double* angles, int nt, int na, double scale, trk_op** out) {
   // the kernels address a frame through one buffer descriptor with 32-bit byte offsets
-  if ((int64_t)N * N >= ((int64_t)1 << 29) || (int64_t)n_det >= ((int64_t)1 << 29))
-    return fail(TRK_EUNSUPPORTED, "radon2d: frames of %d x %d pixels / %d detectors exceed the 2 GiB per-frame addressing of the kernels", N, N, n_det);
+  if ((int64_t)N * N >= ((int64_t)1 << 29) || (int64_t)n_det >= ((int64_t)1 << 22))
+    return fail(TRK_EUNSUPPORTED, "radon2d: frames of %d x %d pixels / %d detectors exceed the addressing of the kernels", N, N, n_det);
   if ((int64_t)nt * na > (int64_t)INT32_MAX / 4) return fail(TRK_EUNSUPPORTED, "radon2d: too many angles");
   const int n_ang = nt * na;
+  const int ndp = n_det + 2 * A32_PAD;
+  const int npad = ((N + ADJ_T - 1) / ADJ_T) * ADJ_T + 32;         // whole adjoint tiles + the forward's 16-entry scalar reads
+  if ((int64_t)na * ndp * 16 >= ((int64_t)1 << 31) || (int64_t)na * npad * 8 >= ((int64_t)1 << 31))
+    return fail(TRK_EUNSUPPORTED, "radon2d: %d angles x %d detectors per frame exceed the 2 GiB record addressing of the adjoint", na, n_det);
   std::vector<AngleParam> h(n_ang);
-  const double half = 0.5 * (N - 1);
+  std::vector<float> wadj(n_ang);
+  std::vector<unsigned> a32((size_t)n_ang * ndp), b32((size_t)n_ang * npad);
+  std::vector<uint2> cb((size_t)n_ang * npad);
+  const double half = 0.5 * (N - 1), sdh = 0.5 * (n_det - 1), one = (double)(1 << QF);
+  auto fx = [&](double v) -> unsigned {                                   // round(v 2^24) mod 2^32
+    return (unsigned)((uint64_t)(int64_t)std::llrint(v * one) & 0xFFFFFFFFull);
+  };
   int n1 = 0;
   for (int a = 0; a < n_ang; ++a) {
     const double ct = std::cos(angles[a]), st = std::sin(angles[a]);
+    double inv, dq, k0, w, rinv;
     AngleParam p;
     if (std::fabs(ct) >= std::fabs(st)) {
       p.mode = 0;
-      p.inv = (float)(1.0 / ct);
-      p.dq = (float)(st / ct);
-      p.k0 = (float)(half - half * st / ct);
-      p.wgt = (float)(scale / std::fabs(ct));
-      p.rinv = (float)ct;
+      inv = 1.0 / ct; dq = st / ct; k0 = half - half * st / ct; w = scale / std::fabs(ct); rinv = ct;
     } else {
       p.mode = 1;
-      p.inv = (float)(-1.0 / st);
-      p.dq = (float)(ct / st);
-      p.k0 = (float)(half - half * ct / st);
-      p.wgt = (float)(scale / std::fabs(st));
-      p.rinv = (float)(-st);
+      inv = -1.0 / st; dq = ct / st; k0 = half - half * ct / st; w = scale / std::fabs(st); rinv = -st;
       ++n1;
     }
+    p.inv = (float)inv; p.dq = (float)dq; p.k0 = (float)k0; p.rinv = (float)rinv;
+    p.wgt = (float)(w / 4294967296.0);        // the forward kernels' weights are in units of 2^-32
+    p.inv24 = (float)(inv * one);
     h[a] = p;
+    wadj[a] = (float)(w / one);               // the adjoint's in units of 2^-24
+    for (int e = 0; e < ndp; ++e) a32[(size_t)a * ndp + e] = fx(((double)(e - A32_PAD) - sdh) * inv + k0);
+    for (int t = 0; t < npad; ++t) {
+      const unsigned B = fx((double)t * dq);
+      b32[(size_t)a * npad + t] = B;
+      const float C = (float)(sdh - (k0 + (double)t * dq) * rinv);      // d* = col rinv + C
+      cb[(size_t)a * npad + t] = uint2{__builtin_bit_cast(unsigned, C), B};
+    }
   }
   int band = RADON_BAND;
   if (const char* e = getenv("TRK_RADON_BAND")) {               // tuning knob; kept a positive multiple of RADON_CHUNK
@@ -809,21 +939,28 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     band = band < RADON_CHUNK ? RADON_CHUNK : (band / RADON_CHUNK) * RADON_CHUNK;
   }
   const int nb = (N + band - 1) / band;
-  auto* im = new RadonImpl{N, n_det, na, nt, nullptr, nullptr, n1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nb, band};
-  hipError_t e = hipMalloc(&im->ang_dev, sizeof(AngleParam) * n_ang);
-  if (e == hipSuccess) e = hipMemcpy(im->ang_dev, h.data(), sizeof(AngleParam) * n_ang, hipMemcpyHostToDevice);
-  if (e == hipSuccess && n1 > 0) e = hipMalloc(&im->xT, sizeof(float) * (size_t)nt * N * N);
-  if (e == hipSuccess && nb > 1) e = hipMalloc(&im->part, sizeof(float) * (size_t)nb * n_ang * n_det);
-  if (e == hipSuccess) {
+  auto* im = new RadonImpl{};
+  im->N = N; im->nd = n_det; im->na = na; im->nt = nt; im->n_mode1 = n1; im->npad = npad; im->n_bands = nb; im->band = band;
+  hipError_t e = hipSuccess;
+  auto up = [&](void** dst, const void* src, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(dst, bytes);
+    if (e == hipSuccess && src) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
+  };
+  up((void**)&im->ang_dev, h.data(), sizeof(AngleParam) * n_ang);
+  if (n1 > 0) up((void**)&im->xT, nullptr, sizeof(float) * (size_t)nt * N * N);
+  if (nb > 1) up((void**)&im->part, nullptr, sizeof(float) * (size_t)nb * n_ang * n_det);
+  {
     std::vector<float> fi((size_t)N + 16);
     for (size_t i = 0; i < fi.size(); ++i) fi[i] = (float)i;
-    e = hipMalloc(&im->fidx, sizeof(float) * fi.size());
-    if (e == hipSuccess) e = hipMemcpy(im->fidx, fi.data(), sizeof(float) * fi.size(), hipMemcpyHostToDevice);
+    up((void**)&im->fidx, fi.data(), sizeof(float) * fi.size());
   }
-  if (e == hipSuccess) {
+  up((void**)&im->A32, a32.data(), sizeof(unsigned) * a32.size());
+  up((void**)&im->B32, b32.data(), sizeof(unsigned) * b32.size());
+  up((void**)&im->CB, cb.data(), sizeof(uint2) * cb.size());
+  {
     // adjoint tables: per frame, the angles with marching mode 0 first
     std::vector<AdjAngle> aa(n_ang);
-    std::vector<int> orig(n_ang), n0(nt);
+    std::vector<int> n0(nt);
     std::vector<float> wg(n_ang);
     for (int f = 0; f < nt; ++f) {
       int pos = 0;
@@ -831,23 +968,17 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
         for (int a = 0; a < na; ++a) {
           const AngleParam& q = h[(size_t)f * na + a];
           if (q.mode != pass) continue;
-          aa[(size_t)f * na + pos] = AdjAngle{q.inv, q.dq, q.k0, q.rinv};
-          orig[(size_t)f * na + pos] = a;
-          wg[(size_t)f * na + pos] = q.wgt;
+          aa[(size_t)f * na + pos] = AdjAngle{q.rinv, q.inv24, q.dq, q.k0, a};
+          wg[(size_t)f * na + pos] = wadj[(size_t)f * na + a];
           ++pos;
         }
         if (pass == 0) n0[f] = pos;
       }
     }
-    auto up = [&](void** dst, const void* src, size_t bytes) {
-      if (e == hipSuccess) e = hipMalloc(dst, bytes);
-      if (e == hipSuccess) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
-    };
     up((void**)&im->adj_ang, aa.data(), sizeof(AdjAngle) * n_ang);
-    up((void**)&im->adj_orig, orig.data(), sizeof(int) * n_ang);
     up((void**)&im->adj_wgt, wg.data(), sizeof(float) * n_ang);
     up((void**)&im->adj_n0, n0.data(), sizeof(int) * nt);
-    if (e == hipSuccess) e = hipMalloc(&im->sino_pad, sizeof(float) * (size_t)n_ang * (n_det + ADJ_PAD));
+    up((void**)&im->rec, nullptr, sizeof(uint4) * (size_t)n_ang * ndp);
   }
   if (e != hipSuccess) {
     trk_op tmp{2, 0, 0, im, nullptr, nullptr, nullptr, 0};
