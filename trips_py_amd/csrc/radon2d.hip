@@ -51,12 +51,12 @@ struct AngleParam {
   float inv, dq, k0, wgt;   // fp32 copies: only for ESTIMATES (window placement, candidate location); wgt includes the forward's 2^-32
   int mode;
   float rinv;               // ~1/inv
-  float inv24;              // inv * 2^24: distance between neighbouring rays in fixed-point units (adjoint)
 };
 
 struct AdjAngle {           // the adjoint's per-angle constants, sorted by marching mode per frame
-  float rinv, inv24, dq, k0;
+  float rinv, c1, dq, k0;   // c1 = 1 - |inv| (<= 0): a neighbouring ray at distance |inv| weighs clamp(c1 -+ t0)
   int orig;                 // index of the angle within its frame
+  int flip;                 // inv < 0: the ray on the larger-q side is d0 - 1 (the records store neighbours by side)
 };
 
 struct RadonImpl {
@@ -380,8 +380,9 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
 #define WIN_W 128
 #define WIN_MAXCH 32
 
+// (7 waves per SIMD asked of the register allocator: 72 VGPRs, no spills; at the 78 it takes unasked the kernel ran 16 % longer)
 template <int DUMMY = 0>
-__global__ __launch_bounds__(256) void k_radon_fwd_win(const float* __restrict__ img, const float* __restrict__ imgT,
+__global__ __launch_bounds__(256, 7) void k_radon_fwd_win(const float* __restrict__ img, const float* __restrict__ imgT,
                                                        float* __restrict__ out, int N, int nd,
                                                        const AngleParam* __restrict__ ang, int na_per_frame,
                                                        int ngrp_per_frame, int nwin, int64_t band_stride, int bh,
@@ -565,21 +566,25 @@ __global__ __launch_bounds__(256) void k_radon_bands_sum(const float* __restrict
 // pixel `col`.  Per pixel and angle the gather takes the ray d0 nearest to the pixel's inverse image d* (fp32 estimate) and
 // its two neighbours — every ray with |q - col| < 1 is among them because |dq/dd| = 1/|cos| >= 1:
 //   * t0 = q(d0, tt) - col comes from the SAME tables as the forward, as an integer: t_int = A32[d0] + B32[tt] - (col << 24)
-//     (mod 2^32, |t0| <= 0.71 + the estimate's error), so hat(t0) = 2^24 - |t_int| is bit-identical to the forward's weight;
-//   * the neighbours sit at t0 +- inv (one fp32 add each, 1.2e-7 relative to the weights' scale).
-// What is read per pixel and angle is ONE 16-byte record {w S[d0-1], w S[d0], w S[d0+1], A32[d0]} (w = the angle's weight
-// times 2^-24), written per apply by k_radon_adj_prep for the angles sorted by marching mode.
+//     (mod 2^32, |t0| <= 0.71 + the estimate's error), so hat(t0) = 1 - |t_int| 2^-24 is bit-identical to the forward's weight;
+//   * the neighbours sit at t0 +- |inv| >= 1 away on either side, so their weights are clamp(c1 + t0) and clamp(c1 - t0),
+//     c1 = 1 - |inv| <= 0: ONE packed FMA with the hardware clamp to [0, 1] (one fp32 rounding, 6e-8).
+// What is read per pixel and angle is ONE 16-byte record {w S[d0 -], w S[d0 +], w S[d0], A32[d0]} (w = the angle's weight;
+// -/+: the neighbour on the smaller-q / larger-q side, which is d0 -+ 1 or d0 +- 1 by the sign of inv), written per apply by
+// k_radon_adj_prep for the angles sorted by marching mode.
 //
-// k_radon_adj_tile: a workgroup owns a 32 x 32 pixel tile and walks the angles in batches of ADJ_AB.  Per batch it stages,
+// k_radon_adj_tile: a workgroup owns a T x T pixel tile and walks the angles in batches of AB (8 or 16).  Per batch it stages,
 // with direct-to-LDS loads, (i) for every angle the 64 records around the tile's inverse image, as a RING indexed by d0 & 63
 // (the tile's footprint is < 48 detectors, so no index arithmetic beyond a mask is needed to read a record), and (ii) the
-// pairs {C[a][tt], B32[a][tt]} of the tile's 32 marching indices (C: the locator offset, d* = col rinv + C).  A thread holds
-// 4 pixels that share the marching index — a run along the row for mode-0 angles, along the column for mode-1 angles — so
+// pairs {C[a][tt], B32[a][tt]} of the tile's marching indices (C: the locator offset, d* = col rinv + C).  A thread holds
+// PX pixels that share the marching index — a run along the row for mode-0 angles, along the column for mode-1 angles — so
 // that pair is read once per angle and thread; the two partial images meet through LDS at the end.  Per pixel and angle:
-// 16 vector instructions and one ds_read_b128 (the first gather form of round 1: 34 instructions and three dword loads on the
-// texture path; the second: 26 and one 12-byte load).
-constexpr int ADJ_T = 32;      // tile edge (pixels)
-constexpr int ADJ_AB = 8;      // angles per staged batch
+// 9.5 vector instructions and one ds_read_b128 — d* (packed FMA for two pixels), its rounding (a packed add of 1.5 x 2^23:
+// the integer sits in the low mantissa bits), ring address (and, shift-add), t_int (one three-operand add), its conversion,
+// the centre weight (one FMA), both neighbour weights (one packed FMA with clamp), two accumulating FMAs (one packed).  The
+// kernel is bound by vector-instruction issue (4 cycles per wave instruction): the first gather form of round 1 needed 34
+// instructions and three dword loads on the texture path, the second 26 and one 12-byte load, this kernel's first version 15.
+constexpr int ADJ_T = 32;      // tile edge (pixels) of the large-image instantiation; small images: 16 x 16, one pixel per thread
 constexpr float RND_MAGIC = 12582912.0f;   // 1.5 * 2^23: x + RND_MAGIC has rint(x) in its low mantissa bits (|x| < 2^22)
 
 // records of one vector: rec[(frame*na + sorted angle)][e], e = d + 2 in [0, nd + 3]
@@ -596,10 +601,12 @@ __global__ __launch_bounds__(256) void k_radon_adj_prep(const float* __restrict_
   const int d = e - A32_PAD;
   const float w = wgt[rs];
   const float* __restrict__ S = sino + ro * nd;
+  const float sm = (d - 1 >= 0 && d - 1 < nd) ? w * S[d - 1] : 0.f, sp = (d + 1 >= 0 && d + 1 < nd) ? w * S[d + 1] : 0.f;
+  const bool flip = ang[rs].flip != 0;
   uint4 o;
-  o.x = __builtin_bit_cast(unsigned, (d - 1 >= 0 && d - 1 < nd) ? w * S[d - 1] : 0.f);
-  o.y = __builtin_bit_cast(unsigned, (d >= 0 && d < nd) ? w * S[d] : 0.f);
-  o.z = __builtin_bit_cast(unsigned, (d + 1 >= 0 && d + 1 < nd) ? w * S[d + 1] : 0.f);
+  o.x = __builtin_bit_cast(unsigned, flip ? sp : sm);             // the neighbour at t0 - |inv|
+  o.y = __builtin_bit_cast(unsigned, flip ? sm : sp);             // the neighbour at t0 + |inv|
+  o.z = __builtin_bit_cast(unsigned, (d >= 0 && d < nd) ? w * S[d] : 0.f);
   o.w = A32[ro * ndp + e];
   rec[rs * ndp + e] = o;
 }
@@ -609,7 +616,7 @@ __global__ __launch_bounds__(256) void k_radon_adj_prep(const float* __restrict_
 __device__ __forceinline__ unsigned lds_offset(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
-typedef unsigned u4r __attribute__((ext_vector_type(4)));     // a record {w S[d-1], w S[d], w S[d+1], A32[d]}
+typedef unsigned u4r __attribute__((ext_vector_type(4)));     // a record {w S[d0 -], w S[d0 +], w S[d0], A32[d0]}
 __device__ __forceinline__ u4r ring_read(unsigned ring_base, unsigned bits) {
   unsigned addr;
   const unsigned slot = bits & 63u;
@@ -619,35 +626,44 @@ __device__ __forceinline__ u4r ring_read(unsigned ring_base, unsigned bits) {
   return *p;
 }
 
-// one pixel, one angle: the record, t0 from the tables, three hat weights
-__device__ __forceinline__ float adj_gather(const u4r r, unsigned B, unsigned negcol24, float inv24, float acc) {
+// one pixel, one angle: the record, t0 from the tables, three hat weights.  accn: the two neighbour terms (packed), acc0: the centre
+__device__ __forceinline__ void adj_gather(const u4r r, unsigned B, unsigned negcol24, f2v sc2, float nsc, f2v c2, f2v& accn,
+                                           float& acc0) {
   // NOTE the elements are copied to scalars first: __builtin_bit_cast(float, r[k]) on an ext-vector ELEMENT reads element 0
   // whatever k is (hipcc / ROCm 7.2; found the hard way — the adjoint summed (w0 + wp + wm) S[d0-1])
-  const unsigned sm = r[0], s0 = r[1], sp = r[2], a32 = r[3];
+  const unsigned slo = r[0], shi = r[1], s0 = r[2], a32 = r[3];
   unsigned ti;                                                   // t_int = A32 + B32 - (col << 24), wrap-around mod 2^32 is the point
   asm("v_add3_u32 %0, %1, %2, %3" : "=v"(ti) : "v"(a32), "v"(B), "v"(negcol24));
-  const float tf = (float)(int)ti;
-  const float w0 = QONE - fabsf(tf);
-  const float wp = fmaxf(QONE - fabsf(tf + inv24), 0.f);
-  const float wm = fmaxf(QONE - fabsf(tf - inv24), 0.f);
-  acc = fmaf(w0, __builtin_bit_cast(float, s0), acc);
-  acc = fmaf(wp, __builtin_bit_cast(float, sp), acc);
-  return fmaf(wm, __builtin_bit_cast(float, sm), acc);
+  const float tf = (float)(int)ti;                               // t0 in units of 2^-24, exact
+  // {clamp(c1 + t0), clamp(c1 - t0)} in one packed FMA: both lanes read the LOW half of every source (op_sel_hi 0), the high
+  // lane negates the scale 2^-24.  64-bit operands must sit in even-aligned register pairs, hence the two-element carriers
+  // whose high halves are never read.
+  f2v t2;
+  t2[0] = tf;
+  f2v wn;
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,0] neg_hi:[0,1,0] clamp" : "=v"(wn) : "v"(t2), "s"(sc2), "v"(c2));
+  float w0;                                                      // 1 - |t0|: exact (t0 is a multiple of 2^-24)
+  asm("v_fma_f32 %0, |%1|, %2, 1.0" : "=v"(w0) : "v"(tf), "s"(nsc));
+  const f2v sn = {__builtin_bit_cast(float, slo), __builtin_bit_cast(float, shi)};
+  accn = __builtin_elementwise_fma(wn, sn, accn);
+  acc0 = fmaf(w0, __builtin_bit_cast(float, s0), acc0);
 }
 
+template <int T, int PX, int AB>
 __global__ __launch_bounds__(256) void k_radon_adj_tile(const uint4* __restrict__ rec, float* __restrict__ img, int N, int nd, int na,
                                                         const AdjAngle* __restrict__ ang, const int* __restrict__ n_mode0,
                                                         const uint2* __restrict__ CB, int npad, int tiles_x,
                                                         double* __restrict__ ssq_part) {
-  __shared__ __attribute__((aligned(16))) uint4 ring[2][ADJ_AB][64];            // 16 KB
-  __shared__ __attribute__((aligned(16))) uint2 cbs[2][ADJ_AB][ADJ_T];          // 4 KB
-  __shared__ float xch[ADJ_T][ADJ_T + 1];
+  __shared__ __attribute__((aligned(16))) uint4 ring[2][AB][64];            // 16 KB
+  __shared__ __attribute__((aligned(16))) uint2 cbs[2][AB][T];
+  __shared__ float xch[PX > 1 ? T : 1][T + 1];
+  static_assert(T * T == 256 * PX && (T == 16 || T == 32), "256 threads x PX pixels cover the T x T tile");
   __shared__ double lds[4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frame = blockIdx.y;
   const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
-  const int i0 = ty * ADJ_T, j0 = tx * ADJ_T;
+  const int i0 = ty * T, j0 = tx * T;
   const int ndp = nd + 2 * A32_PAD;
   ang += (int64_t)frame * na;
   rec += (int64_t)frame * na * ndp;
@@ -657,38 +673,53 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const uint4* __restrict_
   const auto rrec = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, (unsigned)((int64_t)na * ndp * 16), 0x00020000);
   const auto rcb = __builtin_amdgcn_make_buffer_rsrc((void*)CB, 0, (unsigned)((int64_t)na * npad * 8), 0x00020000);
 
-  // thread -> pixels.  mode 0 (marching index = row): row r0, columns c0 .. c0+3;  mode 1 (= column): column c1, rows r1 .. r1+3
-  const int r0 = tid >> 3, c0 = (tid & 7) * 4;
-  const int c1 = tid & 31, r1 = (tid >> 5) * 4;
-  float fcolA[4], fcolB[4];
-  unsigned colA[4], colB[4];
+  // thread -> pixels.  mode 0 (marching index = row): row r0, columns c0 + k T/PX;  mode 1 (= column): column c1, rows
+  // r1 + k T/PX, k < PX (PX = 1: the same pixel in both).  Neighbouring lanes hold NEIGHBOURING pixels, so the 16 lanes of a
+  // ds_read_b128 group read records at most ~10 detectors apart: distinct LDS banks (a record is 4 banks wide, 16 records fill
+  // the 64) or the same record (a broadcast).  With 4 consecutive pixels per lane instead, neighbouring lanes were up to 4
+  // detectors apart and 35 % of the LDS cycles were bank conflicts (PMC).
+  constexpr int TS = T / PX;                           // threads along the run direction = pixel stride of one thread
+  const int r0 = tid / TS, c0 = tid % TS;
+  const int r1 = PX > 1 ? tid % TS : tid / T, c1 = PX > 1 ? tid / TS : tid % T;   // (mode 1: neighbouring lanes = neighbouring ROWS)
+  float fcolA[PX], fcolB[PX];
+  unsigned colA[PX], colB[PX];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    fcolA[k] = (float)(j0 + c0 + k);                 // mode 0: interpolated coordinate = column
-    colA[k] = 0u - ((unsigned)(j0 + c0 + k) << QF);   // negated: t_int = A32 + B32 - (col << 24)
-    fcolB[k] = (float)(i0 + r1 + k);                 // mode 1: interpolated coordinate = row
-    colB[k] = 0u - ((unsigned)(i0 + r1 + k) << QF);
+  for (int k = 0; k < PX; ++k) {
+    fcolA[k] = (float)(j0 + c0 + k * TS);            // mode 0: interpolated coordinate = column
+    colA[k] = 0u - ((unsigned)(j0 + c0 + k * TS) << QF);   // negated: t_int = A32 + B32 - (col << 24)
+    fcolB[k] = (float)(i0 + r1 + k * TS);            // mode 1: interpolated coordinate = row
+    colB[k] = 0u - ((unsigned)(i0 + r1 + k * TS) << QF);
   }
-  float accA[4] = {0.f, 0.f, 0.f, 0.f}, accB[4] = {0.f, 0.f, 0.f, 0.f};
+  f2v anA[PX], anB[PX];
+  float accA[PX], accB[PX];
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    accA[k] = accB[k] = 0.f;
+    anA[k] = anB[k] = (f2v){0.f, 0.f};
+  }
+  f2v sc2 = {5.9604644775390625e-8f, 5.9604644775390625e-8f};          // 2^-24, kept in an (aligned) SGPR pair
+  float nsc = -5.9604644775390625e-8f;
+  asm("" : "+s"(sc2));
+  asm("" : "+s"(nsc));
 
-  const int nbatch = (na + ADJ_AB - 1) / ADJ_AB;
+  const int nbatch = (na + AB - 1) / AB;
   // staging of batch b into buffer b & 1: wave w brings the rings of angles w and w + 4 of the batch; the first 128 threads
   // bring the {C, B32} pairs (16 bytes = two marching indices per thread)
   auto stage = [&](int b) {
     const int buf = b & 1;
 #pragma unroll
-    for (int h = 0; h < ADJ_AB / 4; ++h) {
+    for (int h = 0; h < AB / 4; ++h) {
       const int al = wv + 4 * h;
-      int a = b * ADJ_AB + al;
+      int a = b * AB + al;
       a = a < na ? a : na - 1;
       const AdjAngle p = ang[a];
       const bool m1 = a >= n0;
       // inverse image of the tile: d* = col rinv + (sdh - (k0 + tt dq) rinv), extremes at the corners
       const float tt_lo = (float)(m1 ? j0 : i0), co_lo = (float)(m1 ? i0 : j0);
       const float dA = fmaf(co_lo - fmaf(tt_lo, p.dq, p.k0), p.rinv, sdh);
-      const float dB = fmaf(co_lo + (float)(ADJ_T - 1) - fmaf(tt_lo, p.dq, p.k0), p.rinv, sdh);
-      const float dC = fmaf(co_lo - fmaf(tt_lo + (float)(ADJ_T - 1), p.dq, p.k0), p.rinv, sdh);
-      const float dD = fmaf(co_lo + (float)(ADJ_T - 1) - fmaf(tt_lo + (float)(ADJ_T - 1), p.dq, p.k0), p.rinv, sdh);
+      const float dB = fmaf(co_lo + (float)(T - 1) - fmaf(tt_lo, p.dq, p.k0), p.rinv, sdh);
+      const float dC = fmaf(co_lo - fmaf(tt_lo + (float)(T - 1), p.dq, p.k0), p.rinv, sdh);
+      const float dD = fmaf(co_lo + (float)(T - 1) - fmaf(tt_lo + (float)(T - 1), p.dq, p.k0), p.rinv, sdh);
       const float dmin = fminf(fminf(dA, dB), fminf(dC, dD)), dmax = fmaxf(fmaxf(dA, dB), fmaxf(dC, dD));
       const int dbase = __builtin_amdgcn_readfirstlane((int)floorf(0.5f * (dmin + dmax))) - 32;   // ring covers dbase .. dbase + 63
       const int d = dbase + ((lane - dbase) & 63);                   // the detector whose ring slot is this lane
@@ -697,9 +728,9 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const uint4* __restrict_
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rrec, (__attribute__((address_space(3))) void*)&ring[buf][al][0], 16,
                                                (a * ndp + e) * 16, 0, 0, 0);
     }
-    if (tid < ADJ_AB * ADJ_T / 2) {
-      const int al = tid / (ADJ_T / 2), pr = tid - al * (ADJ_T / 2);
-      int a = b * ADJ_AB + al;
+    if (tid < AB * T / 2) {
+      const int al = tid / (T / 2), pr = tid - al * (T / 2);
+      int a = b * AB + al;
       a = a < na ? a : na - 1;
       const int tt0 = (a >= n0 ? j0 : i0) + 2 * pr;                  // even: 16-byte aligned pairs (npad is even)
       // (the LDS address of a direct-to-LDS load is wave-uniform base + 16 * lane: wave 1 lands 1 KB behind wave 0)
@@ -714,42 +745,55 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const uint4* __restrict_
     __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this wave's share of batch b has landed
     __syncthreads();                                 // batch b complete; everyone is done with the other buffer
     if (b + 1 < nbatch) stage(b + 1);
-    const int nal = (na - b * ADJ_AB < ADJ_AB) ? na - b * ADJ_AB : ADJ_AB;
-    for (int al = 0; al < nal; ++al) {
-      const int a = b * ADJ_AB + al;
-      const AdjAngle p = ang[a];                     // wave-uniform: scalar loads
-      const unsigned rbase = __builtin_amdgcn_readfirstlane(lds_offset(&ring[buf][al][0]));
-      if (a < n0) {
-        const uint2 cb = cbs[buf][al][r0];
-        const float C = __builtin_bit_cast(float, cb.x);
+    const int nal = (na - b * AB < AB) ? na - b * AB : AB;
+    // the batch's mode-0 angles come first (the angles are sorted by mode): two loops without a mode test inside, unrolled so
+    // that the LDS reads of several angles are in flight together (small images run few waves per SIMD: latency, not issue)
+    const int a0 = b * AB;
+    const int nm0 = (n0 - a0 < 0) ? 0 : (n0 - a0 < nal ? n0 - a0 : nal);
+    const unsigned rbase0 = __builtin_amdgcn_readfirstlane(lds_offset(&ring[buf][0][0]));
+#pragma unroll 2
+    for (int al = 0; al < nm0; ++al) {
+      const AdjAngle p = ang[a0 + al];               // wave-uniform: scalar loads
+      f2v c2;                                        // the packed clamp-FMA takes its addend from a VGPR pair (low half read)
+      c2[0] = p.c1;
+      asm("" : "+v"(c2));
+      const uint2 cb = cbs[buf][al][r0];
+      const float C = __builtin_bit_cast(float, cb.x);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcolA[k], p.rinv, C) + RND_MAGIC);
-          const u4r r = ring_read(rbase, bits);
-          accA[k] = adj_gather(r, cb.y, colA[k], p.inv24, accA[k]);
-        }
-      } else {
-        const uint2 cb = cbs[buf][al][c1];
-        const float C = __builtin_bit_cast(float, cb.x);
+      for (int k = 0; k < PX; ++k) {
+        const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcolA[k], p.rinv, C) + RND_MAGIC);
+        const u4r r = ring_read(rbase0 + al * 1024, bits);
+        adj_gather(r, cb.y, colA[k], sc2, nsc, c2, anA[k], accA[k]);
+      }
+    }
+#pragma unroll 2
+    for (int al = nm0; al < nal; ++al) {
+      const AdjAngle p = ang[a0 + al];
+      f2v c2;
+      c2[0] = p.c1;
+      asm("" : "+v"(c2));
+      const uint2 cb = cbs[buf][al][c1];
+      const float C = __builtin_bit_cast(float, cb.x);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcolB[k], p.rinv, C) + RND_MAGIC);
-          const u4r r = ring_read(rbase, bits);
-          accB[k] = adj_gather(r, cb.y, colB[k], p.inv24, accB[k]);
-        }
+      for (int k = 0; k < PX; ++k) {
+        const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcolB[k], p.rinv, C) + RND_MAGIC);
+        const u4r r = ring_read(rbase0 + al * 1024, bits);
+        adj_gather(r, cb.y, colB[k], sc2, nsc, c2, anB[k], accB[k]);
       }
     }
   }
   // the two partial images meet: mode-0 sums go through LDS to the thread that holds the pixel in the mode-1 layout
+  if (PX > 1) {
 #pragma unroll
-  for (int k = 0; k < 4; ++k) xch[r0][c0 + k] = accA[k];
-  __syncthreads();
+    for (int k = 0; k < PX; ++k) xch[r0][c0 + k * TS] = accA[k] + (anA[k][0] + anA[k][1]);
+    __syncthreads();
+  }
   double q = 0.0;
   img += (int64_t)frame * N * N;
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    const int i = i0 + r1 + k, j = j0 + c1;
-    const float o = accB[k] + xch[r1 + k][c1];
+  for (int k = 0; k < PX; ++k) {
+    const int i = i0 + r1 + k * TS, j = j0 + c1;
+    const float o = (accB[k] + (anB[k][0] + anB[k][1])) + (PX > 1 ? xch[r1 + k * TS][c1] : accA[k] + (anA[k][0] + anA[k][1]));
     if (i < N && j < N) {
       img[(int64_t)i * N + j] = o;
       q += (double)o * o;
@@ -777,7 +821,12 @@ __global__ __launch_bounds__(256) void k_radon_adj_simple(const uint4* __restric
   rec += (int64_t)frame * na * ndp;
   CB += (int64_t)frame * na * npad;
   const int n0 = n_mode0[frame];
-  float acc = 0.f;
+  float acc0 = 0.f;
+  f2v accn = {0.f, 0.f};
+  f2v sc2 = {5.9604644775390625e-8f, 5.9604644775390625e-8f};
+  float nsc = -5.9604644775390625e-8f;
+  asm("" : "+s"(sc2));
+  asm("" : "+s"(nsc));
   for (int a = 0; a < na; ++a) {
     const AdjAngle p = ang[a];
     const int tt = a < n0 ? i : j, col = a < n0 ? j : i;
@@ -786,8 +835,11 @@ __global__ __launch_bounds__(256) void k_radon_adj_simple(const uint4* __restric
     int e = d0 + A32_PAD;
     e = e < 0 ? 0 : (e > ndp - 1 ? ndp - 1 : e);
     const uint4 rr = rec[(int64_t)a * ndp + e];
-    acc = adj_gather((u4r){rr.x, rr.y, rr.z, rr.w}, cb.y, 0u - ((unsigned)col << QF), p.inv24, acc);
+    f2v c2;
+    c2[0] = p.c1;
+    adj_gather((u4r){rr.x, rr.y, rr.z, rr.w}, cb.y, 0u - ((unsigned)col << QF), sc2, nsc, c2, accn, acc0);
   }
+  const float acc = acc0 + (accn[0] + accn[1]);
   if (inside) img[(int64_t)frame * N * N + idx] = acc;
   if (ssq_part) {
     const double q = block_sum<256>(inside ? (double)acc * acc : 0.0, lds);
@@ -803,8 +855,12 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
   // fused ||y||^2 (batch 1): block partials from the kernel that writes y (band reduction / gather), then one finalize
   double* ssq_part = nullptr;
   const bool adj_simple = getenv("TRK_RADON_ADJ_SIMPLE") != nullptr;   // read per call: tests switch it
-  const bool tile = !adj_simple && N >= ADJ_T;
-  const int tiles_x = ceil_div(N, ADJ_T);
+  const bool tile = !adj_simple && N >= 16;
+  // 32 x 32 tiles with 4 pixels per thread (fewest instructions per pixel) need enough tiles to fill the chip; below that
+  // 16 x 16 tiles with one pixel per thread (4 x the waves): 512^2 x 180: 75 -> XX us
+  static const int tile_env = getenv("TRK_RADON_ADJ_TILE") ? atoi(getenv("TRK_RADON_ADJ_TILE")) : 0;
+  const int tile_T = tile_env ? tile_env : (N >= 1024 ? 32 : 16);
+  const int tiles_x = ceil_div(N, tile_T);
   const int64_t adj_blocks = tile ? (int64_t)tiles_x * tiles_x : (int64_t)ceil_div((int64_t)N * N, 256);
   const bool fuse_ssq = sumsq && batch == 1 && (tr || im->n_bands > 1);
   if (fuse_ssq) {
@@ -856,8 +912,11 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
     for (int b = 0; b < batch; ++b) {            // the record array is per vector
       hipLaunchKernelGGL(k_radon_adj_prep, dim3(ceil_div((int64_t)na * ndp, 256), nt), dim3(256), 0, s, x + (int64_t)b * ldx,
                          im->rec, nd, na, im->adj_ang, im->adj_wgt, im->A32);
-      if (tile)
-        hipLaunchKernelGGL(k_radon_adj_tile, dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
+      if (tile && tile_T == 32)
+        hipLaunchKernelGGL((k_radon_adj_tile<32, 4, 8>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
+                           im->adj_ang, im->adj_n0, im->CB, im->npad, tiles_x, ssq_part);
+      else if (tile)
+        hipLaunchKernelGGL((k_radon_adj_tile<16, 1, 16>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
                            im->adj_ang, im->adj_n0, im->CB, im->npad, tiles_x, ssq_part);
       else
         hipLaunchKernelGGL(k_radon_adj_simple, dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
@@ -922,9 +981,8 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     }
     p.inv = (float)inv; p.dq = (float)dq; p.k0 = (float)k0; p.rinv = (float)rinv;
     p.wgt = (float)(w / 4294967296.0);        // the forward kernels' weights are in units of 2^-32
-    p.inv24 = (float)(inv * one);
     h[a] = p;
-    wadj[a] = (float)(w / one);               // the adjoint's in units of 2^-24
+    wadj[a] = (float)w;                       // the adjoint's are plain
     for (int e = 0; e < ndp; ++e) a32[(size_t)a * ndp + e] = fx(((double)(e - A32_PAD) - sdh) * inv + k0);
     for (int t = 0; t < npad; ++t) {
       const unsigned B = fx((double)t * dq);
@@ -968,7 +1026,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
         for (int a = 0; a < na; ++a) {
           const AngleParam& q = h[(size_t)f * na + a];
           if (q.mode != pass) continue;
-          aa[(size_t)f * na + pos] = AdjAngle{q.rinv, q.inv24, q.dq, q.k0, a};
+          aa[(size_t)f * na + pos] = AdjAngle{q.rinv, 1.0f - fabsf(q.inv), q.dq, q.k0, a, q.inv < 0.f ? 1 : 0};
           wg[(size_t)f * na + pos] = wadj[(size_t)f * na + a];
           ++pos;
         }
