@@ -10,8 +10,32 @@ keeping the history costs no extra traffic.  Sharded problems all-reduce 1 + 4 d
 """
 import numpy as np
 
-from .._io import Formatter, as_operator, history_fits
+from .._io import Formatter, History, as_operator
 from ..engine import Coef
+
+
+class _ShiftedRows:
+    """A [rows, n] device block seen `shift` rows further on: what the C iteration loops take when iterate j is to land in
+    ring slot (j + shift) instead of row j (they only ask for the base address and the row stride)."""
+
+    def __init__(self, t, shift):
+        self.t, self.shift = t, int(shift)
+
+    def data_ptr(self):
+        return self.t.data_ptr() + self.shift * self.t.stride(0) * self.t.element_size()
+
+    def stride(self, dim):
+        return self.t.stride(dim)
+
+    def row(self, j):
+        return self.t[j + self.shift]
+
+
+def _row_of(X, j, keep):
+    """Row of the block the C loop wrote iterate j (0-based) to."""
+    if isinstance(X, _ShiftedRows):
+        return X.row(j)
+    return X[j] if keep else X[j & 1]
 
 
 class CGLSRun:
@@ -25,15 +49,12 @@ class CGLSRun:
         self.eng = eng = A.engine
         m, n = A.shape
         self.max_iter = max_iter = int(max_iter)
-        self.keep = bool(history)
         self.bv = eng.to_vec(b, m)
         self.xt = None if x_true is None else eng.to_vec(x_true, n)
         x_start = eng.to_vec(x0, n)
-        if self.keep:
-            history_fits(eng, max_iter, n, "CGLS xHistory")
-            self.X = eng.empty_basis(max_iter, n)
-        else:
-            self.X = eng.empty_basis(2, n)
+        self.hist = History(eng, history, max_iter, n, "CGLS xHistory")       # True / False / stride / 'host' / '<file>.npy'
+        self.keep = self.hist.keeps_any
+        self.X = self.hist.X
         # tol = 0 on a single rank: nothing needs ||x||, ||dx||, ||x-x_true|| before the end -> keep them as block
         # partials and sum all iterations in one launch afterwards (one reduction-finalize launch less per iteration)
         self.defer = bool(defer_norms) and eng.world == 1 and hasattr(eng, "cgls_update_deferred")
@@ -61,16 +82,42 @@ class CGLSRun:
         self.x_cur = x_start
 
     def slot(self, k):
-        return self.X[k] if self.keep else self.X[k & 1]
+        """The device row holding iterate k (0-based)."""
+        return self.X[self.hist.slot(k)]
 
     def step(self):
+        self._step()
+        self.hist.pushed(self.k - 1)
+
+    def _run_c_loop(self, n_steps, call):
+        """`call(k_first, n, X, keep)` enqueues n iterations writing iterate j (1-based) to X + (j-1) rows (keep) — all at
+        once, or, when the history is streamed through a ring of device slots, in chunks that stay inside one half of the
+        ring (the copies of one half drain while the other half is being written)."""
+        h = self.hist
+        if h.mode != "stream":
+            call(self.k + 1, n_steps, self.X, 1 if h.mode == "device" else 0)
+            self.k += n_steps
+        else:
+            while n_steps > 0:
+                k0 = self.k
+                c = min(n_steps, h.R // 2, h.R - k0 % h.R)
+                for j in range(c):
+                    h.row(k0 + j)                                  # the slots' previous copies must be out
+                call(k0 + 1, c, _ShiftedRows(self.X, k0 % h.R - k0), 1)
+                for j in range(c):
+                    h.pushed(k0 + j)
+                self.k += c
+                n_steps -= c
+        self.x_cur = self.slot(self.k - 1)
+
+    def _step(self):
         eng, A, S = self.eng, self.A, self.S
         self.k += 1
         k = self.k
         b = 5 * k                          # row k: delta, gamma, ||x||^2, ||dx||^2, ||x-xt||^2
         delta, gamma = S.ref(b), S.ref(b + 1)
         gamma_old = S.ref(0) if k == 1 else S.ref(b - 4)
-        x_new = self.slot(k - 1)
+        x_new = self.hist.row(k - 1)
         if self.raw and self.grouping == 1:
             # [r] after A p, [x, p] after A^T r: p is read once (trk_cgls_update_grouping: measured rule by size)
             n_d = eng.op_apply_fused(A._h, False, self.p, None, 0.0, None, 0, None, 0, None, self.w, self.PD.ref(0), self.PCAP)
@@ -110,12 +157,13 @@ class CGLSRun:
             return
         eng = self.eng
         if self.defer and not self.dist and hasattr(self.A, "_h") and hasattr(eng, "cgls_iterate"):
-            self.n_np = eng.cgls_iterate(self.A._h, self.k + 1, n_steps, self.p, self.r, self.t, self.w, self.X, self.keep,
-                                         self.x_cur, self.xt, self.S.ref(0), self.NP.ref(0), 1024, self.n_np,
-                                         None if not self.raw else self.PG.ref(0), None if not self.raw else self.PD.ref(0),
-                                         self.PCAP if self.raw else 0, self.grouping)
-            self.k += n_steps
-            self.x_cur = self.slot(self.k - 1)
+            def call(k_first, n, X, keep):
+                self.n_np = eng.cgls_iterate(self.A._h, k_first, n, self.p, self.r, self.t, self.w, X, keep,
+                                             self.x_cur, self.xt, self.S.ref(0), self.NP.ref(0), 1024, self.n_np,
+                                             None if not self.raw else self.PG.ref(0), None if not self.raw else self.PD.ref(0),
+                                             self.PCAP if self.raw else 0, self.grouping)
+                self.x_cur = _row_of(X, k_first + n - 2, keep)
+            self._run_c_loop(n_steps, call)
         else:
             for _ in range(n_steps):
                 self.step()
@@ -166,15 +214,12 @@ class CGLSRunFused(CGLSRun):
         self.eng = eng = A.engine
         m, n = A.shape
         self.max_iter = max_iter = int(max_iter)
-        self.keep = bool(history)
         self.bv = eng.to_vec(b, m)
         self.xt = None if x_true is None else eng.to_vec(x_true, n)
         x_start = eng.to_vec(x0, n)
-        if self.keep:
-            history_fits(eng, max_iter, n, "CGLS xHistory")
-            self.X = eng.empty_basis(max_iter, n)
-        else:
-            self.X = eng.empty_basis(2, n)
+        self.hist = History(eng, history, max_iter, n, "CGLS xHistory")
+        self.keep = self.hist.keeps_any
+        self.X = self.hist.X
         self.R = eng.empty_basis(2, m)     # r ping-pong
         self.P = eng.empty_basis(2, n)     # p ping-pong
         self.P.zero_()                     # the first K1 multiplies p_old by 0: it must be finite
@@ -193,7 +238,7 @@ class CGLSRunFused(CGLSRun):
         self.x_cur = x_start
         self._final = False
 
-    def step(self):
+    def _step(self):
         eng, A, S = self.eng, self.A, self.S
         self.k += 1
         k = self.k
@@ -205,7 +250,7 @@ class CGLSRunFused(CGLSRun):
         n_d = eng.op_apply_fused(A._h, False, self.t, p_old, 0.0 if k == 1 else 1.0, self.PG.ref(0), self.n_g, gprev, 1,
                                  p_new, self.w, self.PD.ref(0), self.PCAP)
         # K2: x_k = x_{k-1} + (gamma_{k-1}/delta_k) p_k ; publishes delta_k -> S[5k], gamma_{k-1} -> S[5(k-1)+1] (S[0] for k = 1)
-        x_new = self.slot(k - 1)
+        x_new = self.hist.row(k - 1)
         gpub = S.ref(0) if k == 1 else S.ref(b - 4)
         self.n_np = eng.cgls_x_update(self.PG.ref(0), self.n_g, self.PD.ref(0), n_d, self.x_cur, p_new, x_new, self.xt,
                                       S.ref(b), gpub, self.NP.ref(3 * self.n_np * (k - 1)), 1024)
@@ -219,12 +264,13 @@ class CGLSRunFused(CGLSRun):
         n_steps = min(int(n_steps), self.max_iter - self.k)
         if n_steps <= 0:
             return
-        self.n_g, self.n_np = self.eng.cgls_iterate_fused(self.A._h, self.k + 1, n_steps, self.P, self.R, self.t, self.w,
-                                                          self.X, self.keep, self.x_cur, self.xt, self.S.ref(0),
-                                                          self.PG.ref(0), self.PD.ref(0), self.PCAP, self.NP.ref(0), 1024,
-                                                          self.n_g, self.n_np)
-        self.k += n_steps
-        self.x_cur = self.slot(self.k - 1)
+        def call(k_first, n, X, keep):
+            self.n_g, self.n_np = self.eng.cgls_iterate_fused(self.A._h, k_first, n, self.P, self.R, self.t, self.w,
+                                                              X, keep, self.x_cur, self.xt, self.S.ref(0),
+                                                              self.PG.ref(0), self.PD.ref(0), self.PCAP, self.NP.ref(0), 1024,
+                                                              self.n_g, self.n_np)
+            self.x_cur = _row_of(X, k_first + n - 2, keep)
+        self._run_c_loop(n_steps, call)
 
     def _finish(self):
         """Sum the norm partials of all iterations (one launch) and the last gamma (one launch)."""
@@ -249,7 +295,9 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
 
     A: LinearOperator; b: (m,) / (m,1); x0: (n,) / (n,1); returns (x, info) with info keys
     xHistory, regParam (empty), relResidual, its and, if x_true is given, relError (sic: divided by ||x||, :79).
-    Engine-only kwarg: history=True (keep every iterate on the device like the reference's x_history).
+    Engine-only kwarg: history — True (every iterate on the device, like the reference's x_history), False, a stride s
+    (every s-th iterate), "host" (every iterate streamed to host memory through a ring of device slots) or a path ending in
+    .npy (the same into a memory-mapped file): trips_py_amd._io.History.
     """
     if int(max_iter) <= 0:
         # the reference would fail at `shrink = norm_x/xmax` (:84) with norm_x undefined
@@ -280,11 +328,16 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
     if not sync_each:
         # tol == 0: the reference stops only when ||t|| is exactly zero (:75); honour that after the fact
         zero = np.nonzero(rows[:, 1] <= 0.0)[0]
-        if zero.size and run.keep:
+        if zero.size and int(zero[0]) + 1 < k:
             k = int(zero[0]) + 1
-            rows, x_fin = rows[:k], run.slot(k - 1)
+            if run.hist.mode == "device":
+                rows, x_fin = rows[:k], run.slot(k - 1)
+            else:
+                # the iterate of the breakdown step is gone (no / streamed history) and everything after it is 0/0: solve
+                # again for exactly k iterations (deterministic: the same iterates)
+                return CGLS(A, b, x0, k, tol, x_true, **kwargs)
     norm_x = np.sqrt(rows[:, 2])
-    info = {"xHistory": fmt.hist(run.X, k) if run.keep else [], "regParam": [],
+    info = {"xHistory": run.hist.collect(fmt, k), "regParam": [],
             "relResidual": list(np.sqrt(rows[:, 3]) / norm_x), "its": k}
     if run.xt is not None:
         info["relError"] = list(np.sqrt(rows[:, 4]) / norm_x)

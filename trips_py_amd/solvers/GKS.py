@@ -12,7 +12,7 @@ What moved where
 """
 import numpy as np
 
-from .._io import Formatter, as_operator, history_fits
+from .._io import Formatter, History, as_operator
 from ..engine import Coef
 from ..decompositions import golub_kahan_device
 from ..krylov import DeviceBasis, orthogonalize
@@ -65,7 +65,7 @@ class _ProjectedBases:
 @small_host_blas
 def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys xHistory, regParam, regParam_history, relError (if x_true), Residual, its (= n_iter-1).
-    Engine-only kwarg: history=True."""
+    Engine-only kwarg: history (True, False, a stride, 'host' or a .npy path: _io.History)."""
     A, L = as_operator(A), as_operator(L, "L")
     check_delta(regparam, kwargs)
     if is_identity(L):
@@ -74,7 +74,6 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     eng = A.engine
     m, n = A.shape
     n_iter, d = int(n_iter), int(projection_dim)
-    keep = bool(kwargs.get("history", True))
     fmt = Formatter(b)
     bv = eng.to_vec(b, m)
     xt = None if x_true is None else eng.to_vec(x_true, n)
@@ -83,9 +82,7 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     gk = golub_kahan_device(A, bv, d, kwargs.get("dp_stop", False),                 # GKS.py:36 / MMGKS.py:37
                             **{k_: v_ for k_, v_ in kwargs.items() if k_ in ("gk_eta", "gk_delta")})
     pb = _ProjectedBases(A, L, bv, gk.V, kmax)
-    if keep:
-        history_fits(eng, n_iter, n, "GKS xHistory")
-    X = eng.empty_basis(n_iter if keep else 1, n)
+    Hs = History(eng, kwargs.get("history", True), n_iter, n, "GKS xHistory")
     Y = eng.scalars(kmax)
     H = eng.scalars(3 * kmax)
     E = eng.scalars(n_iter + 3)             # E[0] = ||x_true||^2, E[1] = ||b||^2, E[2+i] = ||x_i - x_true||^2
@@ -107,8 +104,9 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         lams.append(lam)
         y = tikhonov_lstsq(R_A, R_L, lam, rhs)
         Y.set(0, y)
-        x_dev = X[ii] if keep else X[0]
+        x_dev = Hs.row(ii)
         eng.gemv_n(pb.V.data, k, Y.ref(0), x_dev)                                   # x = V y (:76)
+        Hs.pushed(ii)
         if xt is not None:
             eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
         # r = A^T (A x - b) + lam L^T (L x), A x = (AV) y and L x = (LV) y in the reference (:81-85); stencil operators
@@ -131,7 +129,7 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         eng.scale(Coef(1.0, den=R.ref(ii), sqrt_den=True), vn, vn)                   # vn = r/||r|| (:89-91)
         pb.V.commit()
         pb.append()                                                                  # AV, LV, Gram rows (:92-96)
-    info = {"xHistory": fmt.hist(X, n_iter) if keep else [], "regParam": lam, "regParam_history": lams,
+    info = {"xHistory": Hs.collect(fmt, n_iter), "regParam": lam, "regParam_history": lams,
             "Residual": list(np.sqrt(R.host(0, n_iter))), "its": n_iter - 1}
     if xt is not None:
         eng.allreduce(E, 2, 2 + n_iter)

@@ -5,7 +5,7 @@ GEMV-T / GEMV-N pairs), x = V_k y.  Host: H_k, lambda selection, stacked Tikhono
 import numpy as np
 import scipy.linalg as sla
 
-from .._io import Formatter, as_operator, history_fits
+from .._io import Formatter, History, as_operator
 from ..krylov import ArnoldiState
 from ._common import check_delta, choose_lambda, tikhonov_lstsq, small_host_blas
 
@@ -13,7 +13,7 @@ from ._common import check_delta, choose_lambda, tikhonov_lstsq, small_host_blas
 @small_host_blas
 def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys: xHistory (n_iter iterates), regParam, regParam_history (first entry 0),
-    relError (if x_true), relResidual, its (= n_iter-1).  Engine-only kwarg: history=True."""
+    relError (if x_true), relResidual, its (= n_iter-1).  Engine-only kwarg: history (True, False, a stride, 'host' or a .npy path: _io.History)."""
     A = as_operator(A)
     delta = check_delta(regparam, kwargs)
     if kwargs.get("dp_stop", False):
@@ -24,15 +24,12 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
     if m != n:
         raise Exception("Please check the size of the matrx A: it should be square in order to apply hybrid GMRES")
     n_iter = int(n_iter)
-    keep = bool(kwargs.get("history", True))
     fmt = Formatter(b)
     xt = None if x_true is None else eng.to_vec(x_true, n)
 
     ar = ArnoldiState(A, b, n_iter)
     bv = eng.to_vec(b, m) if (isinstance(regparam, str) and regparam == "dp") else None
-    if keep:
-        history_fits(eng, n_iter, n, "Hybrid_GMRES xHistory")
-    X = eng.empty_basis(max(1, n_iter) if keep else 1, n)
+    Hs = History(eng, kwargs.get("history", True), max(1, n_iter), n, "Hybrid_GMRES xHistory")
     Y = eng.scalars(max(1, n_iter))
     E = eng.scalars(max(1, n_iter) + 1)
     P = eng.scalars(n_iter + 2)
@@ -67,11 +64,12 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
         lams.append(lam)
         y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
         Y.set(0, y)
-        x_dev = X[ii] if keep else X[0]
+        x_dev = Hs.row(ii)
         if err_fused:
             n_ep = eng.gemv_n_err(ar.V.data, k, Y.ref(0), x_dev, xt, EP.ref(n_ep * ii), 1024)
         else:
             eng.gemv_n(ar.V.data, k, Y.ref(0), x_dev)                  # x = V[:, :-1] @ y (:77)
+        Hs.pushed(ii)
         # reference quirk (:80): `bhat - H@y` broadcasts a (k+1,) against a (k+1,1) -> Frobenius norm of a matrix
         hy = (H @ y).reshape(-1, 1)
         res.append(float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
@@ -79,7 +77,7 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             eng.diff_nrm2sq(x_dev, xt, E.ref(ii + 1))
     if x_dev is None:
         raise UnboundLocalError("Hybrid_GMRES with n_iter < 1 forms no iterate")
-    info = {"xHistory": fmt.hist(X, n_iter) if keep else [], "regParam": lam, "regParam_history": lams,
+    info = {"xHistory": Hs.collect(fmt, n_iter), "regParam": lam, "regParam_history": lams,
             "relResidual": res, "its": n_iter - 1}
     if xt is not None:
         if err_fused:

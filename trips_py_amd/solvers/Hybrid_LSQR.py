@@ -8,7 +8,7 @@ whole solve is enqueued asynchronously.
 import numpy as np
 import scipy.linalg as sla
 
-from .._io import Formatter, as_operator, history_fits
+from .._io import Formatter, History, as_operator
 from ..krylov import GKState
 from ..reg_param._bidiag import bidiag_svd_first_row, bidiag_svd_project
 from ..reg_param.discrepancy_principle import discrepancy_principle
@@ -20,7 +20,7 @@ from ._common import check_delta, choose_lambda, small_host_blas
 def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys: xHistory (n_iter-1 iterates: none is formed at the first step, :77-78), regParam,
     regParam_history, relError (if x_true), relResidual (empty list, as in the reference), its (= n_iter-1).
-    Engine-only kwarg: history=True."""
+    Engine-only kwarg: history (True, False, a stride, 'host' or a .npy path: _io.History)."""
     A = as_operator(A)
     delta = check_delta(regparam, kwargs)
     if kwargs.get("dp_stop", False):
@@ -29,15 +29,13 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     eng = A.engine
     m, n = A.shape
     n_iter = int(n_iter)
-    keep = bool(kwargs.get("history", True))
     fmt = Formatter(b)
     xt = None if x_true is None else eng.to_vec(x_true, n)
 
     gk = GKState(A, b, n_iter, normalized=False)     # U[j] = beta_j u_j, V[j] = alpha_j v_j (krylov.GKState)
     bv = eng.to_vec(b, m) if (isinstance(regparam, str) and regparam == "dp") else None
-    if keep:
-        history_fits(eng, n_iter, n, "Hybrid_LSQR xHistory")
-    X = eng.empty_basis(max(1, n_iter - 1) if keep else 1, n)
+    H = History(eng, kwargs.get("history", True), max(1, n_iter - 1), n, "Hybrid_LSQR xHistory")
+    keep = H.keeps_any
     Y = eng.scalars(max(1, n_iter))          # projected solution
     W = eng.scalars(3 * (n_iter + 1) + 4)    # rotation state of the projected solve, resumed while lambda stays the same
     E = eng.scalars(max(1, n_iter) + 1)      # E[0] = ||x_true||^2, E[i] = ||x_i - x_true||^2
@@ -91,18 +89,19 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         # y = lstsq([B; sqrt(lam) I], [beta0 e1; 0]) (:104), on the device from the squared norms in gk.AB
         # (as y_j / alpha_j: the rows of V are alpha_j v_j)
         eng.bidiag_tikhonov(gk.AB.ref(1), 2, gk.AB.ref(2), 2, k, np.sqrt(lam), gk.AB.ref(0), Y.ref(0), W, y_over_alpha=True)
-        x_dev = X[nx_done] if keep else X[0]
+        x_dev = H.row(nx_done)
         if err_fused:
             n_ep = eng.gemv_n_err(gk.V.data, k, Y.ref(0), x_dev, xt, EP.ref(n_ep * nx_done), 1024)
         else:
             eng.gemv_n(gk.V.data, k, Y.ref(0), x_dev)
+        H.pushed(nx_done)
         nx_done += 1
         if xt is not None and not err_fused:
             eng.diff_nrm2sq(x_dev, xt, E.ref(nx_done))
     if x_dev is None:
         raise UnboundLocalError("Hybrid_LSQR with n_iter < 2 forms no iterate (the reference fails the same way, "
                                 "Hybrid_LSQR.py:114)")
-    info = {"xHistory": fmt.hist(X, nx_done) if keep else [], "regParam": lam, "regParam_history": lams,
+    info = {"xHistory": H.collect(fmt, nx_done), "regParam": lam, "regParam_history": lams,
             "relResidual": [], "its": n_iter - 1}
     if xt is not None:
         if err_fused:

@@ -12,7 +12,7 @@ uses: (AV*wf)^T b for the least-squares solve (sic: unweighted b, :106) and (AV*
 """
 import numpy as np
 
-from .._io import Formatter, as_operator, history_fits
+from .._io import Formatter, History, as_operator
 from ..engine import Coef
 from ..decompositions import golub_kahan_device
 from ..krylov import DeviceBasis, orthogonalize
@@ -32,7 +32,7 @@ def _old_first_derivative_2d_matrix(nx, ny):
 @small_host_blas
 def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys xHistory, regParam, regParam_history, relError (if x_true), Residual, its.
-    Engine-only kwarg: history=True."""
+    Engine-only kwarg: history (True, False, a stride, 'host' or a .npy path: _io.History)."""
     A = as_operator(A)
     check_delta(regparam, kwargs)
     iso = kwargs.get("isoTV", False) in ("isoTV", "ISOTV", "IsoTV")
@@ -86,7 +86,6 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     if iso and p_rows < 2 * n:                       # LV * wr (:94) needs len(wr) = 2 nx^2 nt + (p_rows - 2 nx^2 nt)
         raise ValueError(f"MMGKS isoTV: L has {p_rows} rows, fewer than the 2*nx*nx*nt = {2 * n} spatial rows the weights assume")
     n_iter, d = int(n_iter), int(projection_dim)
-    keep = bool(kwargs.get("history", True))
     fmt = Formatter(b)
     bv = eng.to_vec(b, m)
     xt = None if x_true is None else eng.to_vec(x_true, n)
@@ -106,9 +105,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
 
     for j in range(V.k):
         push_images(j)
-    if keep:
-        history_fits(eng, n_iter, n, "MMGKS xHistory")
-    X = eng.empty_basis(n_iter if keep else 1, n)
+    Hs = History(eng, kwargs.get("history", True), n_iter, n, "MMGKS xHistory")
     x_cur = eng.empty(n)
     A.apply(bv, out=x_cur, transpose=True)                                            # x = A^T b (:43)
     G = eng.scalars(2 * kmax * kmax + 2 * kmax + 2)
@@ -165,8 +162,9 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         lams.append(lam)
         y = tikhonov_lstsq(R_A, R_L, lam, rhs_b)
         Y.set(0, y)
-        x_dev = X[ii] if keep else X[0]
+        x_dev = Hs.row(ii)
         eng.gemv_n(V.data, k, Y.ref(0), x_dev)                                        # x = V y (:107)
+        Hs.pushed(ii)
         if xt is not None:
             eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
         if ii >= R_L.shape[0]:                                                        # (:109-110)
@@ -202,7 +200,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         push_images(V.k - 1)
         res.append(ii)
     nres = len(res)
-    info = {"xHistory": fmt.hist(X, its + 1) if keep else [], "regParam": lam, "regParam_history": lams,
+    info = {"xHistory": Hs.collect(fmt, its + 1), "regParam": lam, "regParam_history": lams,
             "Residual": list(np.sqrt(Rn.host(0, nres))), "its": its}
     if xt is not None:
         eng.allreduce(E, 2, 3 + its)
