@@ -276,6 +276,17 @@ int trk_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, con
  * w_out may alias w_in; h and g are k device doubles (g must not alias h). */
 int trk_gemv_nt(const float* V, int64_t ld, int k, int64_t n, const double* h_dev, const float* w_in, float* w_out,
                 double* g_dev, trk_stream stream);
+/* Two inner-product sets in one sweep over the basis: h2k[j] = V[j] . r, h2k[k + j] = V[j] . r2, j < k (local sums).
+ * Serves the Gram-matrix form of the repeated Gram-Schmidt sweeps (trk_cgs_coeffs): r = the direction to orthogonalise,
+ * r2 = the vector appended last (its Gram row). */
+int trk_gemv_t2(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* r2, double* h2k_dev,
+                trk_stream stream);
+/* Coefficients of `passes` classical Gram-Schmidt sweeps at once (GKS.py:86-88, MMGKS.py:119-120, decompositions.py:216-218):
+ * r - V (V^T r) repeated `passes` times equals r - V c with c_0 = 0, c_{p+1} = c_p + (h - G c_p), h = V^T r, G = V^T V
+ * (device doubles, row stride ldg).  g_new != NULL: first install it as row and column k-1 of G (the newest vector).
+ * passes = 0 only installs.  One workgroup; k x k work. */
+int trk_cgs_coeffs(double* G_dev, int ldg, const double* h_dev, const double* g_new_dev, int k, int passes, double* c_dev,
+                   trk_stream stream);
 /* out = a*base + s * sum_j y[j]*V[j]   (y: k device doubles; base may be NULL; out may alias base).
  * (x = V@y: Hybrid_LSQR.py:105, Hybrid_GMRES.py:77, GKS.py:76; r -= V h: GKS.py:86-88) */
 int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y_dev, double a, const float* base,

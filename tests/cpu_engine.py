@@ -176,6 +176,24 @@ class CpuEngine:
         rr = _d(r) if w2 is None else (r.numpy() * w2.numpy()).astype(np.float64)
         _put(out_h, _d(V[:k]) @ rr)
 
+    def gemv_t2(self, V, k, r, r2, out_h2k):
+        Vk = _d(V[:k])
+        _put(out_h2k, np.concatenate((Vk @ _d(r), Vk @ _d(r2))))
+
+    def cgs_coeffs(self, G, ldg, h, g_new, k, passes, c):
+        Gs, g0 = G
+        M = Gs.a[g0:g0 + ldg * ldg].reshape(ldg, ldg)
+        if g_new is not None:
+            gn = np.asarray(_get(g_new, k)).reshape(-1)
+            M[k - 1, :k] = gn
+            M[:k, k - 1] = gn
+        if passes > 0:
+            hh = np.asarray(_get(h, k)).reshape(-1)
+            cc = np.zeros(k)
+            for _ in range(passes):
+                cc = cc + (hh - M[:k, :k] @ cc)
+            _put(c, cc)
+
     def gemv_n(self, V, k, y, out, a=0.0, base=None, s=1.0, sumsq=None):
         o = s * (np.asarray(_get(y, k)).reshape(-1) @ _d(V[:k]))
         if base is not None:

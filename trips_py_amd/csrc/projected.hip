@@ -189,6 +189,50 @@ inline double sign1(double v) { return v > 0.0 ? 1.0 : (v < 0.0 ? -1.0 : 1.0); }
 
 }  // namespace
 
+// ------------------------------------------------------------------------------------------------ repeated Gram-Schmidt by Gram matrix
+// `passes` sweeps of block classical Gram-Schmidt, r <- r - V (V^T r), amount to r - V c with
+//     c_0 = 0,   c_{p+1} = c_p + (h - G c_p),   h = V^T r,  G = V^T V
+// (sweep p+1 projects the result of sweep p: V^T (r - V c_p) = h - G c_p) — any V, orthonormal or not.  With G kept on the
+// device (one new row per appended vector) the sweeps cost ONE pass over the basis for h and one for r - V c, instead of two
+// per sweep (GKS.py:86-88: three sweeps; MMGKS.py:119-120, decompositions.py:216-218: two).  k x k work, one workgroup.
+__global__ __launch_bounds__(256) void k_cgs_coeffs(double* __restrict__ G, int ldg, const double* __restrict__ h,
+                                                    const double* __restrict__ g_new, int k, int passes, double* __restrict__ c) {
+  extern __shared__ double sh[];           // c (k) | t (k)
+  double* cs = sh;
+  double* ts = sh + k;
+  if (g_new) {                             // install the Gram row / column of the newest vector (index k - 1)
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+      G[(size_t)(k - 1) * ldg + j] = g_new[j];
+      G[(size_t)j * ldg + (k - 1)] = g_new[j];
+    }
+    __threadfence_block();
+  }
+  for (int j = threadIdx.x; j < k; j += blockDim.x) cs[j] = 0.0;
+  __syncthreads();
+  for (int p = 0; p < passes; ++p) {
+    for (int j = threadIdx.x; j < k; j += blockDim.x) {
+      double t = h[j];
+      const double* row = G + (size_t)j * ldg;
+      for (int i = 0; i < k; ++i) t -= row[i] * cs[i];
+      ts[j] = t;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += blockDim.x) cs[j] += ts[j];
+    __syncthreads();
+  }
+  if (c)
+    for (int j = threadIdx.x; j < k; j += blockDim.x) c[j] = cs[j];
+}
+
+extern "C" int trk_cgs_coeffs(double* G, int ldg, const double* h, const double* g_new, int k, int passes, double* c,
+                              trk_stream st) {
+  TRK_REQUIRE(G && k >= 1 && ldg >= k && passes >= 0 && (passes == 0 || (h && c)), "trk_cgs_coeffs: bad argument");
+  TRK_REQUIRE(k <= 2048, "trk_cgs_coeffs: k <= 2048");
+  hipLaunchKernelGGL(k_cgs_coeffs, dim3(1), dim3(256), 2 * (size_t)k * sizeof(double), (hipStream_t)st, G, ldg, h, g_new, k, passes, c);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
 extern "C" int trk_host_gcv_fminbound(const double* s, const double* rhs, int k, double m_eff, double x1, double x2,
                                       double xatol, int maxfun, double* lam_out, double* fval_out, int* nfev_out) {
   TRK_REQUIRE(s && rhs && lam_out, "trk_host_gcv_fminbound: NULL argument");

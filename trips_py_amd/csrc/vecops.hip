@@ -564,6 +564,57 @@ __global__ __launch_bounds__(NT) void k_gemv_t(const float* __restrict__ V, int6
   }
 }
 
+// Two right-hand sides in one sweep over the basis: h[j] = V[j] . r and g[j] = V[j] . r2 (partials [bx][2k]).  What the
+// Gram-matrix form of the repeated Gram-Schmidt sweeps needs: the coefficients of the new direction AND the Gram row of the
+// vector appended last time, for the price of reading the basis once.
+template <bool VEC>
+__global__ __launch_bounds__(NT) void k_gemv_t2(const float* __restrict__ V, int64_t ld, int k, int64_t n,
+                                                const float* __restrict__ r, const float* __restrict__ r2,
+                                                double* __restrict__ partials, int nt) {
+  __shared__ double lds[NT / 64];
+  const int j0 = blockIdx.y * JT;
+  const int jn = (k - j0 < JT) ? (k - j0) : JT;
+  double acc[JT], acc2[JT];
+#pragma unroll
+  for (int j = 0; j < JT; ++j) acc[j] = acc2[j] = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      const float4 rv = ld4(r, i), sv = ld4(r2, i);
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        if (j < jn) {
+          float4 v = (nt & 64) ? ld4_nt(V + (int64_t)(j0 + j) * ld, i) : ld4(V + (int64_t)(j0 + j) * ld, i);
+          acc[j] += (double)v.x * rv.x + (double)v.y * rv.y + (double)v.z * rv.z + (double)v.w * rv.w;
+          acc2[j] += (double)v.x * sv.x + (double)v.y * sv.y + (double)v.z * sv.z + (double)v.w * sv.w;
+        }
+      }
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) {
+    const float rv = r[i], sv = r2[i];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+      if (j < jn) {
+        const double v = (double)V[(int64_t)(j0 + j) * ld + i];
+        acc[j] += v * rv;
+        acc2[j] += v * sv;
+      }
+  }
+#pragma unroll
+  for (int j = 0; j < JT; ++j) {
+    const double t = block_sum<NT>(acc[j], lds);
+    const double t2 = block_sum<NT>(acc2[j], lds);
+    if (threadIdx.x == 0 && j < jn) {
+      partials[(size_t)blockIdx.x * 2 * k + j0 + j] = t;
+      partials[(size_t)blockIdx.x * 2 * k + k + j0 + j] = t2;
+    }
+  }
+}
+
 int launch_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* w, int wpow, double* h,
                   hipStream_t s) {
   const int ntile = ceil_div(k, JT);
@@ -1384,6 +1435,24 @@ int trk_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, con
   TRK_REQUIRE(V && r && h, "trk_gemv_t: NULL argument");
   TRK_REQUIRE(k >= 1 && n >= 0 && ld >= n, "trk_gemv_t: need k >= 1, n >= 0, ld >= n");
   return launch_gemv_t(V, ld, k, n, r, w2, w2 ? 1 : 0, h, (hipStream_t)st);
+}
+
+int trk_gemv_t2(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* r2, double* h2k, trk_stream st) {
+  TRK_REQUIRE(V && r && r2 && h2k, "trk_gemv_t2: NULL argument");
+  TRK_REQUIRE(k >= 1 && n >= 0 && ld >= n, "trk_gemv_t2: need k >= 1, n >= 0, ld >= n");
+  hipStream_t s = (hipStream_t)st;
+  const int ntile = ceil_div(k, JT);
+  int bx = stream_grid(n);
+  const int cap = (cu_count() * 8 + ntile - 1) / ntile;
+  if (bx > cap) bx = cap < 1 ? 1 : cap;
+  double* part = nullptr;
+  if (int rc = scratch_doubles(s, (size_t)bx * 2 * k, &part)) return rc;
+  const bool vec = aligned16(V) && aligned16(r) && aligned16(r2) && (ld % 4 == 0);
+  dim3 grid(bx, ntile);
+  if (vec) hipLaunchKernelGGL((k_gemv_t2<true>), grid, dim3(NT), 0, s, V, ld, k, n, r, r2, part, stream_nontemporal(n));
+  else hipLaunchKernelGGL((k_gemv_t2<false>), grid, dim3(NT), 0, s, V, ld, k, n, r, r2, part, stream_nontemporal(n));
+  TRK_LAUNCH_CHECK();
+  return finalize_sums(part, bx, 2 * k, 2 * k, h2k, s);
 }
 
 int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, double a, const float* base, double sc,

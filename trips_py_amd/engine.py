@@ -358,6 +358,18 @@ class HipEngine:
 
     GEMV_NT_MAX_K = 16
 
+    def gemv_t2(self, V, k, r, r2, out_h2k):
+        """out[j] = V[j] . r, out[k + j] = V[j] . r2 for j < k, one pass over V (local sums)."""
+        rc = self.lib.trk_gemv_t2(V.data_ptr(), V.stride(0), int(k), r.numel(), r.data_ptr(), r2.data_ptr(), _ptr(out_h2k),
+                                  self.stream())
+        _lib.check(rc, "trk_gemv_t2")
+
+    def cgs_coeffs(self, G, ldg, h, g_new, k, passes, c):
+        """c = coefficients of `passes` Gram-Schmidt sweeps from h = V^T r and the Gram matrix G (device doubles); g_new: Gram
+        row of the newest vector, installed into G first (None: G is complete)."""
+        rc = self.lib.trk_cgs_coeffs(_ptr(G), int(ldg), _ptr(h), _ptr(g_new), int(k), int(passes), _ptr(c), self.stream())
+        _lib.check(rc, "trk_cgs_coeffs")
+
     def gemv_n_err(self, V, k, y, out, ref, partials, capacity):
         """out = sum_j y[j] V[j]; raw block partials of ||out - ref||^2 into `partials`; returns their count."""
         n = ctypes.c_int(0)

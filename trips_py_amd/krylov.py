@@ -261,6 +261,49 @@ def orthogonalize(eng, V, k, w, H, off, passes=2, out=None, sumsq=None):
                    sumsq=sumsq if last else None)
 
 
+class GramSchmidtByGram:
+    """The repeated classical Gram-Schmidt sweeps of the projection solvers (GKS.py:86-88 three, MMGKS.py:119-120 and
+    decompositions.py:216-218 two) with TWO passes over the basis instead of two per sweep: `passes` sweeps of
+    r <- r - V (V^T r) equal r - V c, c from h = V^T r and the Gram matrix G = V^T V by a k x k recurrence
+    (trk_cgs_coeffs).  G lives on the device and grows by one row per appended vector; that row (V^T v_new) is formed by the
+    SAME sweep that forms the next h (trk_gemv_t2).  Any basis: the d Golub-Kahan start vectors are not re-orthogonalised,
+    G simply says so.
+
+    At 4096^2 a pass over k = 18 basis vectors is 1.2 GB: MMGKS goes from 4 (k > 16) / 3 to 2 passes per iteration for the
+    sweeps, GKS from 6 / 4 to 2."""
+
+    def __init__(self, eng, V, kmax):
+        self.eng, self.V, self.kmax = eng, V, int(kmax)
+        self.G = eng.scalars(self.kmax * self.kmax)
+        self.W = eng.scalars(3 * self.kmax)           # h (k) | g_new (k) | c (k)
+        self.in_G = 0                                 # vectors whose Gram rows are installed
+        for j in range(V.k):                          # the start basis: one sweep per vector (d of them)
+            eng.gemv_t(V.data, j + 1, V[j], self.W.ref(0))
+            eng.allreduce(self.W, 0, j + 1)
+            eng.cgs_coeffs(self.G.ref(0), self.kmax, None, self.W.ref(0), j + 1, 0, None)
+        self.in_G = V.k
+
+    def sweep(self, k, w, passes, out, sumsq=None):
+        """out = w orthogonalised against V[0..k) by `passes` sweeps; LOCAL sum(out^2) into `sumsq` (fused).  Returns the
+        DevScalars reference of the k combined coefficients."""
+        eng, V, W, K = self.eng, self.V, self.W, self.kmax
+        if k > K:
+            raise ValueError("GramSchmidtByGram: basis larger than planned")
+        if self.in_G == k - 1:                        # the newest vector's Gram row rides along with h
+            eng.gemv_t2(V.data, k, w, V[k - 1], W.ref(0))
+            eng.allreduce(W, 0, 2 * k)
+            eng.cgs_coeffs(self.G.ref(0), K, W.ref(0), W.ref(k), k, passes, W.ref(2 * K))
+            self.in_G = k
+        elif self.in_G == k:
+            eng.gemv_t(V.data, k, w, W.ref(0))
+            eng.allreduce(W, 0, k)
+            eng.cgs_coeffs(self.G.ref(0), K, W.ref(0), None, k, passes, W.ref(2 * K))
+        else:
+            raise RuntimeError("GramSchmidtByGram: more than one vector appended since the last sweep")
+        eng.gemv_n(V.data, k, W.ref(2 * K), out, a=1.0, base=w, s=-1.0, sumsq=sumsq)
+        return W.ref(2 * K)
+
+
 class ArnoldiState:
     """Arnoldi A V_k = V_{k+1} H_k (decompositions.py:207-228): orthogonalisation against ALL previous vectors."""
 

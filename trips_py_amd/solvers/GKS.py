@@ -15,7 +15,7 @@ import numpy as np
 from .._io import Formatter, History, as_operator
 from ..engine import Coef
 from ..decompositions import golub_kahan_device
-from ..krylov import DeviceBasis, orthogonalize
+from ..krylov import DeviceBasis, GramSchmidtByGram, orthogonalize
 from ..operators import is_identity
 from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq, small_host_blas
 
@@ -95,6 +95,7 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     b2 = float(E.host(1, 2)[0])
 
     dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
+    gs_gram = GramSchmidtByGram(eng, pb.V, kmax) if (hasattr(eng, "cgs_coeffs") and kwargs.get("gram_sweeps", True)) else None
     lams, lam, x_dev = [], None, None
     for ii in range(n_iter):
         k = pb.V.k
@@ -124,7 +125,10 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         L.apply(tp, out=rb, transpose=True)
         eng.axpby(1.0, r, float(lam), rb, r)
         vn = pb.V.next_slot()
-        orthogonalize(eng, pb.V, k, r, H, 0, passes=3, out=vn, sumsq=R.ref(ii))      # (:86-88), ||r||^2 fused
+        if gs_gram is not None:
+            gs_gram.sweep(k, r, 3, vn, sumsq=R.ref(ii))                              # (:86-88) three sweeps, ||r||^2 fused
+        else:
+            orthogonalize(eng, pb.V, k, r, H, 0, passes=3, out=vn, sumsq=R.ref(ii))
         eng.allreduce(R, ii, ii + 1)
         eng.scale(Coef(1.0, den=R.ref(ii), sqrt_den=True), vn, vn)                   # vn = r/||r|| (:89-91)
         pb.V.commit()

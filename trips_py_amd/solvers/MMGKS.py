@@ -15,7 +15,7 @@ import numpy as np
 from .._io import Formatter, History, as_operator
 from ..engine import Coef
 from ..decompositions import golub_kahan_device
-from ..krylov import DeviceBasis, orthogonalize
+from ..krylov import DeviceBasis, GramSchmidtByGram, orthogonalize
 from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq, small_host_blas
 
 
@@ -127,6 +127,8 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     A.apply(x_cur, out=ax)
     L.apply(x_cur, out=lx)
 
+    # the two Gram-Schmidt sweeps per iteration by Gram matrix (two passes over V instead of three / four)
+    gs_gram = GramSchmidtByGram(eng, V, kmax) if (hasattr(eng, "cgs_coeffs") and kwargs.get("gram_sweeps", True)) else None
     lams, res, lam, x_dev, its = [], [], None, None, 0
     for ii in range(n_iter):
         its = ii
@@ -193,7 +195,10 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         L.apply(tp, out=rb, transpose=True)
         eng.axpby(1.0, r, float(lam), rb, r)
         vn = V.next_slot()
-        orthogonalize(eng, V, k, r, H, 0, passes=2, out=vn, sumsq=Rn.ref(ii))       # (:119-120), ||r||^2 fused
+        if gs_gram is not None:
+            gs_gram.sweep(k, r, 2, vn, sumsq=Rn.ref(ii))                              # (:119-120) two sweeps, ||r||^2 fused
+        else:
+            orthogonalize(eng, V, k, r, H, 0, passes=2, out=vn, sumsq=Rn.ref(ii))
         eng.allreduce(Rn, ii, ii + 1)
         eng.scale(Coef(1.0, den=Rn.ref(ii), sqrt_den=True), vn, vn)                  # vn = r / ||r|| (:121-123)
         V.commit()
