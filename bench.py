@@ -275,7 +275,8 @@ def run_blur_cgls(args, rank, world):
         watchdog = threading.Timer(EXTRAS_BUDGET_S, give_up)
         watchdog.daemon = True
         watchdog.start()
-        for name, fn in (("c2_blur512_cgls", lambda: extra_c2_blur512(world)),
+        for name, fn in (("trk_comm_rccl", lambda: extra_trk_comm(rank, world)),
+                         ("c2_blur512_cgls", lambda: extra_c2_blur512(world)),
                          ("c3_tomo512_hybrid_lsqr", lambda: extra_c3_tomo(world)),
                          ("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world)),
                          ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world))):
@@ -286,6 +287,33 @@ def run_blur_cgls(args, rank, world):
             barrier(world)
         watchdog.cancel()
     return res
+
+
+def extra_trk_comm(rank, world):
+    """libtrk.so's own collectives (trk_comm_init / trk_allreduce_f64 / trk_halo_exchange over RCCL, include/trk.h) next to
+    torch's: sum of rank + 1 over the ranks and a ring shift of one frame-sized buffer."""
+    import torch.distributed as dist
+    if world > 1 and dist.get_backend() != "nccl":
+        return {"skipped": "ranks share one GPU (gloo debugging run): RCCL needs one GPU per rank"}
+    from trips_py_amd.dist import RcclComm
+    c = RcclComm(rank, world)
+    t = torch.tensor([rank + 1.0], dtype=torch.float64, device="cuda")
+    c.allreduce_sum_(t)
+    total = float(t.item())
+    n = 256 * 256
+    a = torch.full((n,), float(rank), device="cuda")
+    b = torch.full((n,), -1.0, device="cuda")
+    c.shift(a, (rank + 1) % world, b, (rank - 1) % world)
+    torch.cuda.synchronize()
+    ok = bool(torch.all(b == float((rank - 1) % world)).item())
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(100):
+        c.allreduce_sum_(t)
+    torch.cuda.synchronize()
+    us = (time.perf_counter() - t0) / 100 * 1e6
+    return {"allreduce_sum": total, "allreduce_expected": world * (world + 1) / 2.0, "halo_shift_ok": ok,
+            "allreduce_1double_us": round(us, 2), "ranks": world}
 
 
 def extra_c2_blur512(world):

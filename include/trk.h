@@ -42,12 +42,14 @@ extern "C" {
 #define TRK_EHIP (-2)         /* a HIP runtime call failed                    */
 #define TRK_ENOMEM (-3)       /* device / host allocation failed              */
 #define TRK_EUNSUPPORTED (-4) /* valid request this build cannot serve        */
+#define TRK_ENCCL (-5)        /* RCCL missing or an RCCL call failed          */
 
 #define TRK_SQRT_NUM 1
 #define TRK_SQRT_DEN 2
 
 typedef struct trk_op trk_op; /* opaque linear operator (geometry immutable after create) */
 typedef void* trk_stream;     /* hipStream_t */
+typedef struct trk_comm trk_comm; /* opaque communicator of the sharded (frames over GPUs) path: one per process */
 
 /* ---------------------------------------------------------------- library ------------- */
 int trk_version(void);                 /* 10000*major + 100*minor + patch */
@@ -302,6 +304,27 @@ int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y
  * takes R = chol(G) and Q^T b = R^-T c. */
 int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G_dev,
               double* c1_dev, double* c2_dev, trk_stream stream);
+
+/* ---------------------------------------------------------------- collectives ----
+ * The sharded path — frames of a dynamic problem over the GPUs of a node, one process per GPU (io.py:420: F = blkdiag(A_t)) —
+ * has two exchanges: the sum over ranks of a few device doubles (what np.dot / np.linalg.norm of the reference's solver loops
+ * become: CGLS.py:61,70; decompositions.py:236-241; GKS.py:86-88) and a one-frame shift between time-neighbours for the
+ * temporal rows of the space-time regulariser (operators.py:39-45).  RCCL over xGMI; resolved at run time, so the library loads
+ * without it.  All calls enqueue on the caller's stream. */
+/* 128 bytes of ncclUniqueId from rank 0, to be handed to every rank by the host's own means (file, MPI, torch store). */
+int trk_comm_unique_id(void* id128_out);
+/* Collective over all `world` ranks: ncclCommInitRank on the calling process's current device. */
+int trk_comm_init(const void* id128, int rank, int world, trk_comm** out);
+/* Wrap a communicator the host already has (an ncclComm_t, e.g. of its framework); not destroyed with the handle. */
+int trk_comm_attach(void* nccl_comm, int rank, int world, trk_comm** out);
+int trk_comm_info(const trk_comm* comm, int* rank, int* world);
+int trk_comm_destroy(trk_comm* comm);
+/* dev[0..count) <- sum over ranks, in place (ncclAllReduce, double); a no-op for world = 1. */
+int trk_allreduce_f64(trk_comm* comm, double* dev, int count, trk_stream stream);
+/* Send `count` floats to rank send_to and receive `count` from rank recv_from in one group (either side is skipped when its
+ * pointer is NULL or its rank outside [0, world): the first / last frame block has one neighbour only). */
+int trk_halo_exchange(trk_comm* comm, const float* send, int send_to, float* recv, int recv_from, int64_t count,
+                      trk_stream stream);
 
 #ifdef __cplusplus
 }

@@ -88,3 +88,21 @@ def test_sharded_hip_path_matches_single_process():
         assert err < 2e-5, (key, err)
         for p in parts:
             assert np.allclose(p[f"{key}_s"], ref[key][1], rtol=1e-4), key
+
+
+def test_libtrk_rccl_entry_points_single_rank():
+    """trk_comm_unique_id / trk_comm_init / trk_allreduce_f64 / trk_halo_exchange (include/trk.h) on a one-rank RCCL
+    communicator: the calls really go through RCCL (a one-GPU box cannot host two ranks of it)."""
+    import torch
+    from trips_py_amd.dist import RcclComm
+    torch.cuda.set_device(0)
+    c = RcclComm(0, 1)
+    t = torch.tensor([1.5, -2.25, 1e300], dtype=torch.float64, device="cuda")
+    c.allreduce_sum_(t)
+    a = torch.arange(4099, dtype=torch.float32, device="cuda")
+    b = torch.zeros_like(a)
+    c.shift(a, 0, b, 0)                       # send to / receive from itself in one group
+    torch.cuda.synchronize()
+    assert t.tolist() == [1.5, -2.25, 1e300] and torch.equal(a, b)
+    c.shift(a, 5, b, None)                    # neighbours outside the communicator: nothing happens
+    del c

@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libtrk.so")
-SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip", "spmv.hip", "fanbeam2d.hip", "projected.hip", "cgls_loop.hip"]
+SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip", "spmv.hip", "fanbeam2d.hip", "projected.hip", "cgls_loop.hip", "comm.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
 
@@ -113,7 +113,7 @@ def _build_locked(force, verbose):
         objs = list(ex.map(cc, srcs))
     if os.path.exists(STAMP_PATH):
         os.unlink(STAMP_PATH)
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + objs + ["-ldl"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise TrkError(f"link of libtrk.so failed:\n{r.stdout}\n{r.stderr}")
@@ -191,6 +191,13 @@ SIGNATURES = {
     "trk_gemv_nt": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_gemv_n_err": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
     "trk_gemv_n": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_dbl, c_f32p, c_dbl, c_f32p, c_f64p, c_stream]),
+    "trk_comm_unique_id": (c_int, [ctypes.c_void_p]),
+    "trk_comm_init": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "trk_comm_attach": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "trk_comm_info": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "trk_comm_destroy": (c_int, [ctypes.c_void_p]),
+    "trk_allreduce_f64": (c_int, [ctypes.c_void_p, c_f64p, c_int, c_stream]),
+    "trk_halo_exchange": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_f32p, c_int, c_i64, c_stream]),
     "trk_wgram": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_stream]),
 }
 
@@ -233,5 +240,5 @@ def load():
 def check(rc, what=""):
     if rc != 0:
         msg = load().trk_last_error().decode("utf-8", "replace")
-        exc = ValueError if rc == -1 else (NotImplementedError if rc == -4 else TrkError)
+        exc = ValueError if rc == -1 else (NotImplementedError if rc == -4 else TrkError)   # -5 (RCCL): TrkError
         raise exc(f"{what}: trk error {rc}: {msg}")

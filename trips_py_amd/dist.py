@@ -57,6 +57,72 @@ class TorchComm:
         dist.barrier(group=self.group)
 
 
+class RcclComm:
+    """The same two exchanges through libtrk.so's own RCCL entry points (trk_comm_init / trk_allreduce_f64 / trk_halo_exchange,
+    include/trk.h) — what a host without PyTorch binds.  Here torch.distributed (any backend) is used once, to hand rank 0's
+    128-byte unique id to the other ranks; world = 1 needs nothing.  Select with TRK_COMM=rccl (`make_comm()`)."""
+
+    host_staging = False
+
+    def __init__(self, rank=None, world=None):
+        import ctypes
+        from . import _lib
+        self.lib = _lib.load()
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank, self.world = int(rank), int(world)
+        idbuf = (ctypes.c_char * 128)()
+        if self.rank == 0:
+            _lib.check(self.lib.trk_comm_unique_id(idbuf), "trk_comm_unique_id")
+        if self.world > 1:
+            box = [bytes(idbuf)]
+            dist.broadcast_object_list(box, src=0)
+            ctypes.memmove(idbuf, box[0], 128)
+        self._h = ctypes.c_void_p()
+        _lib.check(self.lib.trk_comm_init(idbuf, self.rank, self.world, ctypes.byref(self._h)), "trk_comm_init")
+
+    def _stream(self, t):
+        return torch.cuda.current_stream(t.device).cuda_stream
+
+    def allreduce_sum_(self, t):
+        from . import _lib
+        if not (t.is_cuda and t.dtype == torch.float64 and t.is_contiguous()):
+            raise ValueError("RcclComm.allreduce_sum_: contiguous float64 device tensor expected")
+        _lib.check(self.lib.trk_allreduce_f64(self._h, t.data_ptr(), t.numel(), self._stream(t)), "trk_allreduce_f64")
+        return t
+
+    def shift(self, send, send_to, recv, recv_from):
+        from . import _lib
+        ref = send if send is not None else recv
+        if ref is None:
+            return
+        sb = None if send is None else send.contiguous()
+        count = (sb if sb is not None else recv).numel()
+        rc = self.lib.trk_halo_exchange(self._h, None if sb is None else sb.data_ptr(), -1 if send_to is None else int(send_to),
+                                        None if recv is None else recv.data_ptr(), -1 if recv_from is None else int(recv_from),
+                                        count, self._stream(ref))
+        _lib.check(rc, "trk_halo_exchange")
+
+    def barrier(self):
+        if dist.is_initialized():
+            dist.barrier()
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self.lib.trk_comm_destroy(h)
+            except Exception:
+                pass
+
+
+def make_comm():
+    """The communicator of this process: TorchComm (default) or, with TRK_COMM=rccl, libtrk.so's own RCCL communicator."""
+    import os
+    return RcclComm() if os.environ.get("TRK_COMM", "torch") == "rccl" else TorchComm()
+
+
 def frame_range(n_frames, world, rank):
     """Frames [lo, hi) owned by `rank` (contiguous, frame-major layout of x and b: io.py:223-225)."""
     if n_frames % world:
