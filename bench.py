@@ -170,7 +170,12 @@ def load_traffic(kernel_key):
     return None
 
 
-def run_blur_cgls(args, rank, world):
+def emit_json(fd, res):
+    sys.stdout.flush()
+    os.write(fd, (json.dumps(res) + "\n").encode())
+
+
+def run_blur_cgls(args, rank, world, json_fd=1):
     from trips_py_amd.operators import Blur2D
     from trips_py_amd.problems import gauss_psf
     from trips_py_amd.solvers import CGLSRun, CGLSRunFused
@@ -269,7 +274,7 @@ def run_blur_cgls(args, rank, world):
         def give_up():
             res["extra"]["extras_watchdog"] = f"secondary measurements exceeded {EXTRAS_BUDGET_S} s; abandoned"
             if rank == 0:
-                print(json.dumps(res), flush=True)
+                emit_json(json_fd, res)
             os._exit(0)
 
         watchdog = threading.Timer(EXTRAS_BUDGET_S, give_up)
@@ -531,13 +536,18 @@ def cpu_baseline_cgls(psf, N, b_dev, iters):
 def main():
     args = parse()
     spawn_ranks_if_needed(args)
+    # stdout carries exactly ONE line, the JSON: whatever libraries print there while the bench runs (RCCL's version banner
+    # at communicator creation, for one) is sent to stderr — at the file-descriptor level, C code included
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the engine has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
     rank, world = dist_setup(args)
-    res = run_blur_cgls(args, rank, world)
+    res = run_blur_cgls(args, rank, world, json_fd)
     if rank == 0:
-        print(json.dumps(res))
+        emit_json(json_fd, res)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()

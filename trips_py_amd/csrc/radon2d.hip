@@ -856,10 +856,13 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
   double* ssq_part = nullptr;
   const bool adj_simple = getenv("TRK_RADON_ADJ_SIMPLE") != nullptr;   // read per call: tests switch it
   const bool tile = !adj_simple && N >= 16;
-  // 32 x 32 tiles with 4 pixels per thread (fewest instructions per pixel) need enough tiles to fill the chip; below that
-  // 16 x 16 tiles with one pixel per thread (4 x the waves): 512^2 x 180: 75 -> XX us
+  // 32 x 32 tiles with 4 pixels per thread (fewest instructions per pixel) need enough tiles to fill the chip (frames of a
+  // dynamic problem count); below that 16 x 16 tiles with one pixel per thread (4 x the waves)
   static const int tile_env = getenv("TRK_RADON_ADJ_TILE") ? atoi(getenv("TRK_RADON_ADJ_TILE")) : 0;
-  const int tile_T = tile_env ? tile_env : (N >= 1024 ? 32 : 16);
+  // measured: 512^2 x 180 (one frame: 256 / 1024 tiles) 51 vs 42 us; 32 frames x 256^2 x 15 (2048 / 8192 tiles) 21 vs 34 us
+  const int64_t tiles32 = (int64_t)ceil_div(N, 32) * ceil_div(N, 32) * nt;
+  const int tile_T = tile_env ? tile_env : (tiles32 >= 1024 ? 32 : 16);
+  static const int ab_env = getenv("TRK_RADON_ADJ_AB") ? atoi(getenv("TRK_RADON_ADJ_AB")) : 0;
   const int tiles_x = ceil_div(N, tile_T);
   const int64_t adj_blocks = tile ? (int64_t)tiles_x * tiles_x : (int64_t)ceil_div((int64_t)N * N, 256);
   const bool fuse_ssq = sumsq && batch == 1 && (tr || im->n_bands > 1);
@@ -915,8 +918,11 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
       if (tile && tile_T == 32)
         hipLaunchKernelGGL((k_radon_adj_tile<32, 4, 8>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
                            im->adj_ang, im->adj_n0, im->CB, im->npad, tiles_x, ssq_part);
-      else if (tile)
+      else if (tile && (ab_env ? ab_env == 16 : na > 32))
         hipLaunchKernelGGL((k_radon_adj_tile<16, 1, 16>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
+                           im->adj_ang, im->adj_n0, im->CB, im->npad, tiles_x, ssq_part);
+      else if (tile)   // few angles per frame (dynamic problems: 15): short batches, so that staging and gathering still overlap
+        hipLaunchKernelGGL((k_radon_adj_tile<16, 1, 4>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
                            im->adj_ang, im->adj_n0, im->CB, im->npad, tiles_x, ssq_part);
       else
         hipLaunchKernelGGL(k_radon_adj_simple, dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
