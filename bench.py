@@ -440,18 +440,22 @@ def extra_c4_mmgks(A, b, N, world):
     barrier(world)
     dt = max_over_ranks(time.perf_counter() - t0, world)
     # algorithmic bytes of one MMGKS iteration at basis size k (fp32 vectors, m = n, p = 2n rows of L), DESIGN.md §4.2b:
-    #   weighted Grams of AV and LV 4k(m + p) | x = V y 4kn | two re-orthogonalisation sweeps (V^T r, r - V h each) 16kn |
-    #   weights, stencil applies, weighted residuals, axpys on single vectors 192n        ->  (32k + 192) n  bytes
+    #   weighted Grams of AV and LV 4k(m + p) = 12kn | x = V y 4kn | the two re-orthogonalisation sweeps as ONE pair of passes
+    #   (V^T r with the Gram row riding along, r - V c) 8kn | weights, stencil applies, weighted residuals, axpys on single
+    #   vectors 192n        ->  (24k + 192) n  bytes.   (The reference's own sequence of sweeps — two passes each — is 32k.)
     n = N * N
     its = int(info["its"]) + 1
-    alg = sum((32.0 * (3 + i) + 192.0) * n for i in range(its))
+    alg = sum((24.0 * (3 + i) + 192.0) * n for i in range(its))
+    alg_ref = sum((32.0 * (3 + i) + 192.0) * n for i in range(its))
     gbps = alg / dt / 1e9
     return {"solver": "MMGKS(pnorm=2,qnorm=1,projection_dim=3,n_iter=30,regparam=1e-2,epsilon=0.1), L = 2-D first derivative",
             "iters_per_sec_all_ranks": round(world * 30 / dt, 2), "seconds_per_solve": round(dt, 4), "its": its,
             "parallelism": "replicas" if world > 1 else "single",
-            "roofline": {"bound": "hbm", "alg_bytes_per_iter_formula": "(32 k + 192) n, k = 3 + iteration index, n = 4096^2",
+            "roofline": {"bound": "hbm", "alg_bytes_per_iter_formula": "(24 k + 192) n, k = 3 + iteration index, n = 4096^2",
                          "alg_bytes_per_solve": alg, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(gbps / HBM_PEAK_GBPS, 4), "timed": "whole solve, wall clock incl. the host's projected problems"}}
+                         "frac": round(gbps / HBM_PEAK_GBPS, 4),
+                         "frac_counting_the_reference_sweep_passes_32k": round(alg_ref / dt / 1e9 / HBM_PEAK_GBPS, 4),
+                         "timed": "whole solve, wall clock incl. the host's projected problems"}}
 
 
 def extra_c5_dynamic(rank, world):
