@@ -305,6 +305,17 @@ int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y
 int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G_dev,
               double* c1_dev, double* c2_dev, trk_stream stream);
 
+/* CGLS on SMALL blur problems in two launches per iteration (CGLS.py:56-80): a workgroup owns a 32 x 32 tile and recomputes
+ * in LDS what it needs of its neighbours' halo (p = t + beta p and w = A p on tile + halo) instead of waiting for them at a
+ * kernel boundary; same buffers, scalar layout and results (to fp32 rounding of the partial sums' order) as
+ * trk_cgls_iterate_fused (w is never stored).  trk_cgls_tiled_caps: *can = 1 for separable PSFs up to 9 x 9 on images of at
+ * least 16 x 16 whose tile count fits the norm-partial rows (np_capacity_blocks) and the PG / PD buffers (pcap). */
+int trk_cgls_tiled_caps(trk_op* A, int np_capacity_blocks, int pcap, int* can);
+int trk_cgls_iterate_tiled(trk_op* A, int k_first, int n_iters, float* P, int64_t p_ld, float* R, int64_t r_ld, float* t,
+                           float* X, int64_t x_ld, int keep_history, const float* x_prev, const float* x_true, double* S,
+                           double* PG, double* PD, int pcap, double* NP, int np_capacity_blocks, int* n_g_inout,
+                           int* n_np_inout, trk_stream stream);
+
 /* ---------------------------------------------------------------- collectives ----
  * The sharded path — frames of a dynamic problem over the GPUs of a node, one process per GPU (io.py:420: F = blkdiag(A_t)) —
  * has two exchanges: the sum over ranks of a few device doubles (what np.dot / np.linalg.norm of the reference's solver loops

@@ -155,3 +155,42 @@ def test_raw_partials_form_equals_finalized_form(N, grouping):
     assert np.allclose(Rr, Rf, rtol=2e-6, atol=0)
     xr, xf = raw.X[14].cpu().numpy(), fin.X[14].cpu().numpy()
     assert relerr(xr, xf) < 2e-6
+
+
+@pytest.mark.parametrize("nx,ny,dim,spread", [(64, 64, (9, 9), (3, 3)), (96, 80, (9, 9), (3, 3)), (40, 100, (5, 7), (1, 2)),
+                                             (512, 512, (9, 9), (3, 3)), (17, 16, (3, 3), (1, 1)), (1000, 1000, (7, 7), (2, 2))])
+def test_tiled_two_launch_cgls_equals_the_streaming_form(nx, ny, dim, spread):
+    """trk_cgls_iterate_tiled (a workgroup per 32 x 32 tile recomputing its halo, two launches per iteration) against the
+    four-launch streaming form on the same problem: sizes that are not multiples of the tile, non-square images, PSFs
+    smaller than 9 x 9 and rectangular, with and without x_true / history."""
+    import torch
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import gauss_psf
+    from trips_py_amd.solvers import CGLS
+    from trips_py_amd.solvers.CGLS import CGLSRunFused
+    A = Blur2D(gauss_psf(dim, spread)[0], nx, ny)
+    assert CGLSRunFused.tiled_usable(A, A.engine)
+    dev = A.engine.device
+    n = nx * ny
+    xt = torch.rand(n, device=dev, generator=torch.Generator(device=dev).manual_seed(7))
+    b = A.apply(xt)
+    b = b + 0.01 * torch.randn(n, device=dev, generator=torch.Generator(device=dev).manual_seed(8)) * b.norm() / n ** 0.5
+    x0 = torch.zeros(n, device=dev)
+    its = 25
+    xa, ia = CGLS(A, b, x0, its, 0, xt, tiled=False, fused=False)
+    xb, ib = CGLS(A, b, x0, its, 0, xt, tiled=True)
+    for k in range(its):
+        ra, rb = ia["xHistory"][k].reshape(-1), ib["xHistory"][k].reshape(-1)
+        assert float(torch.linalg.norm(ra - rb) / torch.linalg.norm(ra)) < 2e-6, k
+    assert np.allclose(ia["relError"], ib["relError"], rtol=1e-5) and np.allclose(ia["relResidual"], ib["relResidual"], rtol=1e-5)
+    xc, ic = CGLS(A, b, x0, its, 0, tiled=True, history=False)
+    assert float(torch.linalg.norm(xc - xb) / torch.linalg.norm(xb)) == 0.0 and ic["xHistory"] == []
+
+
+def test_tiled_cgls_against_the_reference_golden():
+    from trips_py_amd.solvers import CGLS
+    from trips_py_amd.operators import Blur2D
+    g = load_golden("cgls_blur64_x0zero")
+    A = Blur2D(g["psf"], int(g["N"]), int(g["N"]))
+    x, info = CGLS(A, g["b"], g["x0"], int(g["max_iter"]), 0, g["x_true"], tiled=True)
+    assert relerr(x, g["x"]) < 1e-5 and np.allclose(info["relError"], g["relError"], rtol=1e-4)

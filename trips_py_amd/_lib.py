@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libtrk.so")
-SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip", "spmv.hip", "fanbeam2d.hip", "projected.hip", "cgls_loop.hip", "comm.hip"]
+SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip", "spmv.hip", "fanbeam2d.hip", "projected.hip", "cgls_loop.hip", "comm.hip", "cgls_tiled.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
 
@@ -183,6 +183,10 @@ SIGNATURES = {
                                    c_int, ctypes.POINTER(c_int), c_stream]),
     "trk_cgls_p_update": (c_int, [c_i64, c_f32p, c_f32p, c_f64p, c_int, c_f64p, c_f64p, c_stream]),
     "trk_cgls_iterate_fused": (c_int, [c_op, c_int, c_int, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_f32p, c_i64, c_int,
+                                       c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_int, ctypes.POINTER(c_int),
+                                       ctypes.POINTER(c_int), c_stream]),
+    "trk_cgls_tiled_caps": (c_int, [c_op, c_int, c_int, ctypes.POINTER(c_int)]),
+    "trk_cgls_iterate_tiled": (c_int, [c_op, c_int, c_int, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_int,
                                        c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_int, ctypes.POINTER(c_int),
                                        ctypes.POINTER(c_int), c_stream]),
     "trk_gemv_t": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_stream]),

@@ -682,6 +682,22 @@ void blur_destroy(trk_op* op) {
 
 }  // namespace
 
+// what the tiled small-image CGLS (cgls_tiled.hip) needs of a blur handle: sizes and the separable weights on the device
+namespace trk {
+bool blur_separable_params(trk_op* op, int* nx, int* ny, int* kh, int* kw, const float** sep_fwd, const float** sep_adj) {
+  if (!op || op->kind != 1) return false;
+  auto* im = static_cast<BlurImpl*>(op->impl);
+  if (!im->separable || !im->sep_dev[0] || !im->sep_dev[1]) return false;
+  *nx = im->nx;
+  *ny = im->ny;
+  *kh = im->kh;
+  *kw = im->kw;
+  *sep_fwd = im->sep_dev[0];
+  *sep_adj = im->sep_dev[1];
+  return true;
+}
+}  // namespace trk
+
 extern "C" int trk_blur2d_create(const double* psf, int kh, int kw, int nx, int ny, trk_op** out) {
   TRK_REQUIRE(psf && out, "trk_blur2d_create: NULL argument");
   TRK_REQUIRE(kh >= 1 && kw >= 1 && nx >= 1 && ny >= 1, "trk_blur2d_create: sizes must be >= 1");

@@ -2,6 +2,8 @@
 // operator-handle dispatch and the block-diagonal (frame-major) composite.
 #include "trk_internal.h"
 
+#include <cstdlib>
+
 #include <cstdarg>
 #include <cstdio>
 #include <map>
@@ -278,6 +280,7 @@ int trk_op_set_timer(trk_op* op, trk_timer* t, int which) {
 int trk_op_destroy(trk_op* op) {
   if (!op) return TRK_OK;
   if (op->destroy) op->destroy(op);
+  if (op->aux) free(op->aux);
   delete op;
   return TRK_OK;
 }

@@ -184,6 +184,12 @@ struct TimerScope {
 };
 }  // namespace trk
 
+struct trk_op;
+namespace trk {
+// blur2d.hip: sizes and device pointers to the separable weights [kw row weights | kh column weights] of a blur handle
+bool blur_separable_params(trk_op* op, int* nx, int* ny, int* kh, int* kw, const float** sep_fwd, const float** sep_adj);
+}  // namespace trk
+
 // ------------------------------------------------------------------ operator handle
 struct trk_op {
   int kind;  // 1 blur2d, 2 radon2d, 3 deriv2d, 4 spacetime, 5 blockdiag
@@ -199,4 +205,5 @@ struct trk_op {
   int (*apply_fused)(trk_op*, int transpose, const float* x1, const float* x2, double sign, trk::ScalarSrc num,
                      trk::ScalarSrc den, float* comb, float* y, double* partials, int cap, int* n_partials,
                      hipStream_t s) = nullptr;
+  void* aux = nullptr;   // malloc'ed per-handle cache of a consumer (cgls_tiled.hip: tile geometry + weights); freed with the handle
 };

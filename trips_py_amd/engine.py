@@ -344,6 +344,23 @@ class HipEngine:
         _lib.check(rc, "trk_cgls_iterate_fused")
         return cg.value, cn.value
 
+    def cgls_tiled_caps(self, handle, np_cap, pcap):
+        can = ctypes.c_int(0)
+        _lib.check(self.lib.trk_cgls_tiled_caps(handle, int(np_cap), int(pcap), ctypes.byref(can)), "trk_cgls_tiled_caps")
+        return bool(can.value)
+
+    def cgls_iterate_tiled(self, handle, k_first, n_iters, P, R, t, X, keep, x_prev, x_true, S, PG, PD, pcap, NP, np_cap,
+                           n_g, n_np):
+        """n_iters tiled (2-launch) CGLS iterations on a small blur problem in one library call; returns (n_g, n_np)."""
+        cg, cn = ctypes.c_int(int(n_g)), ctypes.c_int(int(n_np))
+        rc = self.lib.trk_cgls_iterate_tiled(handle, int(k_first), int(n_iters), P.data_ptr(), P.stride(0), R.data_ptr(),
+                                             R.stride(0), t.data_ptr(), X.data_ptr(), X.stride(0), int(bool(keep)),
+                                             x_prev.data_ptr(), None if x_true is None else x_true.data_ptr(), _ptr(S),
+                                             _ptr(PG), _ptr(PD), int(pcap), _ptr(NP), int(np_cap), ctypes.byref(cg),
+                                             ctypes.byref(cn), self.stream())
+        _lib.check(rc, "trk_cgls_iterate_tiled")
+        return cg.value, cn.value
+
     def finalize_batched(self, partials, nblocks, nvals, batches, out, out_stride):
         rc = self.lib.trk_finalize_batched(_ptr(partials), int(nblocks), int(nvals), int(batches), _ptr(out), int(out_stride),
                                            self.stream())

@@ -209,10 +209,21 @@ class CGLSRunFused(CGLSRun):
         return (getattr(eng, "is_native", False) and eng.world == 1 and hasattr(A, "_h") and A.shape[0] == A.shape[1]
                 and eng.op_can_fuse(A._h))
 
-    def __init__(self, A, b, x0, max_iter, x_true=None, history=True):
+    # Small images (tiled = True): the same recurrence in TWO launches per iteration (trk_cgls_iterate_tiled: a workgroup per
+    # 32 x 32 tile recomputes its halo of p and w in LDS instead of waiting for its neighbours at a kernel boundary).
+    # Measured crossover against the streaming forms: see TILED_MAX_N.
+    TILED_MAX_N = 1 << 20
+
+    @classmethod
+    def tiled_usable(cls, A, eng):
+        return (cls.usable(A, eng) and hasattr(eng, "cgls_tiled_caps") and A.shape[1] <= cls.TILED_MAX_N
+                and eng.cgls_tiled_caps(A._h, 1024, cls.PCAP))
+
+    def __init__(self, A, b, x0, max_iter, x_true=None, history=True, tiled=False):
         self.A = A = as_operator(A)
         self.eng = eng = A.engine
         m, n = A.shape
+        self.tiled = bool(tiled)
         self.max_iter = max_iter = int(max_iter)
         self.bv = eng.to_vec(b, m)
         self.xt = None if x_true is None else eng.to_vec(x_true, n)
@@ -240,6 +251,16 @@ class CGLSRunFused(CGLSRun):
 
     def _step(self):
         eng, A, S = self.eng, self.A, self.S
+        if self.tiled:
+            x_new = self.hist.row(self.k)
+            keep = self.hist.mode == "device"
+            X = self.X if self.hist.mode != "stream" else _ShiftedRows(self.X, self.hist.slot(self.k) - self.k)
+            self.n_g, self.n_np = eng.cgls_iterate_tiled(A._h, self.k + 1, 1, self.P, self.R, self.t, X, keep or self.hist.mode == "stream",
+                                                         self.x_cur, self.xt, S.ref(0), self.PG.ref(0), self.PD.ref(0), self.PCAP,
+                                                         self.NP.ref(0), 1024, self.n_g, self.n_np)
+            self.k += 1
+            self.x_cur = x_new
+            return
         self.k += 1
         k = self.k
         b = 5 * k
@@ -265,10 +286,16 @@ class CGLSRunFused(CGLSRun):
         if n_steps <= 0:
             return
         def call(k_first, n, X, keep):
-            self.n_g, self.n_np = self.eng.cgls_iterate_fused(self.A._h, k_first, n, self.P, self.R, self.t, self.w,
-                                                              X, keep, self.x_cur, self.xt, self.S.ref(0),
-                                                              self.PG.ref(0), self.PD.ref(0), self.PCAP, self.NP.ref(0), 1024,
-                                                              self.n_g, self.n_np)
+            if self.tiled:
+                self.n_g, self.n_np = self.eng.cgls_iterate_tiled(self.A._h, k_first, n, self.P, self.R, self.t, X, keep,
+                                                                  self.x_cur, self.xt, self.S.ref(0), self.PG.ref(0),
+                                                                  self.PD.ref(0), self.PCAP, self.NP.ref(0), 1024,
+                                                                  self.n_g, self.n_np)
+            else:
+                self.n_g, self.n_np = self.eng.cgls_iterate_fused(self.A._h, k_first, n, self.P, self.R, self.t, self.w,
+                                                                  X, keep, self.x_cur, self.xt, self.S.ref(0),
+                                                                  self.PG.ref(0), self.PD.ref(0), self.PCAP, self.NP.ref(0), 1024,
+                                                                  self.n_g, self.n_np)
             self.x_cur = _row_of(X, k_first + n - 2, keep)
         self._run_c_loop(n_steps, call)
 
@@ -308,8 +335,9 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
     want = kwargs.get("fused", None)          # None: automatic by size; True / False: forced
     fused = (not sync_each) and CGLSRunFused.usable(A, A.engine) and \
         (want if want is not None else CGLSRunFused.auto(A.shape[1]))
-    if fused:
-        run = CGLSRunFused(A, b, x0, max_iter, x_true, kwargs.get("history", True))
+    tiled = (not sync_each) and want is None and kwargs.get("tiled", True) and CGLSRunFused.tiled_usable(A, A.engine)
+    if tiled or fused:
+        run = CGLSRunFused(A, b, x0, max_iter, x_true, kwargs.get("history", True), tiled=tiled)
     else:
         run = CGLSRun(A, b, x0, max_iter, x_true, kwargs.get("history", True), defer_norms=not sync_each)
     nt0 = None
