@@ -157,7 +157,7 @@ def test_raw_partials_form_equals_finalized_form(N, grouping):
     assert relerr(xr, xf) < 2e-6
 
 
-@pytest.mark.parametrize("nx,ny,dim,spread", [(64, 64, (9, 9), (3, 3)), (96, 80, (9, 9), (3, 3)), (40, 100, (5, 7), (1, 2)),
+@pytest.mark.parametrize("nx,ny,dim,spread", [(64, 64, (9, 9), (3, 3)), (96, 80, (9, 9), (3, 3)), (40, 100, (5, 5), (1, 2)),
                                              (512, 512, (9, 9), (3, 3)), (17, 16, (3, 3), (1, 1)), (1000, 1000, (7, 7), (2, 2))])
 def test_tiled_two_launch_cgls_equals_the_streaming_form(nx, ny, dim, spread):
     """trk_cgls_iterate_tiled (a workgroup per 32 x 32 tile recomputing its halo, two launches per iteration) against the

@@ -12,7 +12,7 @@
 //            r_k = r_{k-1} - alpha w on tile + halo (r ping-pong);  t = A^T r_k on the tile, ||t||^2 partials;
 //            x_k = x_{k-1} + alpha p_k on the tile with the three norms of CGLS.py:76-80 as partials.
 //
-// The blur is cheap next to a dispatch (a separable 9 x 9 on 48 x 48 floats from LDS: ~1 us), so recomputing it on halos costs
+// The blur is cheap next to a dispatch (a separable 9 x 9 on 48 x 48 floats from LDS), so recomputing it on halos costs
 // less than the two launches and ~26 MB of round trips it saves.  Reflective boundaries (scipy.ndimage 'reflect',
 // Deblurring2D.py:70): the operand of a blur is loaded through reflected indices; a vector that is itself an OUTPUT (r on the
 // halo outside the image) takes the value of its mirror pixel, which lies inside the same tile's halo region.
@@ -31,81 +31,175 @@ namespace {
 constexpr int CT = 32, CH = 4;
 constexpr int E1 = CT + 2 * CH;      // 40: tile + halo
 constexpr int E2 = CT + 4 * CH;      // 48: tile + two halos
-constexpr int NT = 256;
+constexpr int NT = 512;          // 8 waves per workgroup: one workgroup per CU at 512^2, so latency is hidden inside it
 
 struct TiledGeom {
   int nx, ny, tiles_x;
   float rwf[9], cwf[9], rwt[9], cwt[9];     // centred 9-tap row / column weights: forward and "transpose" (flipped PSF)
 };
 
+// half-sample symmetric reflection for an overshoot of at most 8 on an axis of at least 16: one fold, no division
 __device__ __forceinline__ int refl(int i, int n) {
-  if ((unsigned)i < (unsigned)n) return i;
-  const int p = 2 * n;
-  i %= p;
-  if (i < 0) i += p;
-  return (i >= n) ? (p - 1 - i) : i;
+  return i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
 }
 
-// out[R][C] (row stride so) = separable 9 x 9 correlation of in[R + 8][C + 8] (row stride si) with row weights rw, column
-// weights cw; tmp holds (R + 8) x C floats (row stride C + 1).  All 256 threads; ends with the result visible (barrier).
-template <int R, int C>
+// out[R][C] (row stride so) = separable 9 x 9 correlation of in[R + 8][C + 8] (row stride si, a multiple of 4: rows are
+// 16-byte aligned) with row weights rw, column weights cw; tmp holds (R + 8) rows of stride C + 4.  Register blocking: an item
+// is FOUR outputs along the filter direction from 12 inputs (3 LDS reads per output instead of 9); with 512 threads every
+// pass of every blur in this file is at most one item per thread.  Ends with the result visible (barrier).
+typedef float f4t __attribute__((ext_vector_type(4)));
+template <int R, int C, bool END_BARRIER = true>
 __device__ __forceinline__ void blur_lds(const float* __restrict__ in, int si, float* __restrict__ tmp, float* __restrict__ out,
                                          int so, const float* rw, const float* cw) {
-  constexpr int ST = C + 1;
-  for (int idx = threadIdx.x; idx < (R + 8) * C; idx += NT) {
-    const int r = idx / C, c = idx - r * C;
-    const float* p = in + r * si + c;
-    float a = 0.f;
+  static_assert(R % 4 == 0 && C % 4 == 0, "blocks of four outputs");
+  constexpr int ST = C + 4;
+  for (int idx = threadIdx.x; idx < (R + 8) * (C / 4); idx += NT) {
+    const int r = idx / (C / 4), c = (idx - r * (C / 4)) * 4;
+    const f4t* p = reinterpret_cast<const f4t*>(in + r * si + c);
+    const f4t v0 = p[0], v1 = p[1], v2 = p[2];
+    const float v[12] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3], v2[0], v2[1], v2[2], v2[3]};
+    f4t a = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int o = 0; o < 9; ++o) a = fmaf(rw[o], p[o], a);
-    tmp[r * ST + c] = a;
+    for (int o = 0; o < 9; ++o) {
+      a[0] = fmaf(rw[o], v[o], a[0]);
+      a[1] = fmaf(rw[o], v[o + 1], a[1]);
+      a[2] = fmaf(rw[o], v[o + 2], a[2]);
+      a[3] = fmaf(rw[o], v[o + 3], a[3]);
+    }
+    *reinterpret_cast<f4t*>(tmp + r * ST + c) = a;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < R * C; idx += NT) {
-    const int r = idx / C, c = idx - r * C;
+  for (int idx = threadIdx.x; idx < (R / 4) * C; idx += NT) {
+    const int r = (idx / C) * 4, c = idx - (idx / C) * C;
     const float* p = tmp + r * ST + c;
-    float a = 0.f;
+    float v[12];
 #pragma unroll
-    for (int o = 0; o < 9; ++o) a = fmaf(cw[o], p[o * ST], a);
-    out[r * so + c] = a;
+    for (int k = 0; k < 12; ++k) v[k] = p[k * ST];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+#pragma unroll
+    for (int o = 0; o < 9; ++o) {
+      a0 = fmaf(cw[o], v[o], a0);
+      a1 = fmaf(cw[o], v[o + 1], a1);
+      a2 = fmaf(cw[o], v[o + 2], a2);
+      a3 = fmaf(cw[o], v[o + 3], a3);
+    }
+    out[r * so + c] = a0;
+    out[(r + 1) * so + c] = a1;
+    out[(r + 2) * so + c] = a2;
+    out[(r + 3) * so + c] = a3;
+  }
+  if (END_BARRIER) __syncthreads();
+}
+
+// A scalar that is still the block partials of the previous kernel: the loads are ISSUED at the top of the kernel (lane l of
+// wave 0 takes p[l], p[l + 64], ...) and SUMMED only where the value is needed, behind the LDS work that does not depend on it
+// — a partial is a trip to the memory side (written through other XCDs' L2), and waiting for it up front cost every wave of
+// the workgroup ~1.5 us at the first barrier.
+constexpr int PMAX = 16;                                   // 64 * 16 = 1024 partials at most
+__device__ __forceinline__ void partials_issue(const ScalarSrc s, double (&v)[PMAX]) {
+#pragma unroll
+  for (int i = 0; i < PMAX; ++i) {
+    const int idx = (int)threadIdx.x + 64 * i;
+    v[i] = (threadIdx.x < 64 && idx < s.n) ? s.p[idx] : 0.0;
+  }
+}
+__device__ __forceinline__ double partials_sum(const double (&v)[PMAX]) {   // wave 0 only; value in every lane
+  double a = 0.0;
+#pragma unroll
+  for (int i = 0; i < PMAX; ++i) a += v[i];
+  return wave_sum_all(a);
+}
+
+// four block sums with one pair of barriers
+__device__ __forceinline__ void block_sum4(double& a, double& b, double& c, double& d, double* lds /* 4 * NT/64 */) {
+  a = wave_sum(a);
+  b = wave_sum(b);
+  c = wave_sum(c);
+  d = wave_sum(d);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) {
+    lds[wid * 4 + 0] = a;
+    lds[wid * 4 + 1] = b;
+    lds[wid * 4 + 2] = c;
+    lds[wid * 4 + 3] = d;
   }
   __syncthreads();
+  if (threadIdx.x == 0) {
+    a = b = c = d = 0.0;
+    for (int w = 0; w < NT / 64; ++w) {
+      a += lds[w * 4 + 0];
+      b += lds[w * 4 + 1];
+      c += lds[w * 4 + 2];
+      d += lds[w * 4 + 3];
+    }
+  }
 }
 
 __global__ __launch_bounds__(NT) void k_cgls_tile_a(TiledGeom g, const float* __restrict__ t, const float* __restrict__ p_old,
                                                     float* __restrict__ p_new, ScalarSrc gam, const double* __restrict__ gprev,
                                                     double* __restrict__ gpub, int first, double* __restrict__ PD) {
-  __shared__ float P1[E1 * (E1 + 1)];
-  __shared__ float tmp[E1 * (CT + 1)];
-  __shared__ float W[CT * (CT + 1)];
+  constexpr int S1 = E1 + 4;                                // LDS row strides: multiples of 4 (16-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) float T1[E1 * S1];
+  __shared__ __attribute__((aligned(16))) float P1[E1 * S1];
+  __shared__ __attribute__((aligned(16))) float tmp[E1 * (CT + 4)];
+  __shared__ __attribute__((aligned(16))) float WA[CT * (CT + 1)];
+  __shared__ __attribute__((aligned(16))) float WB[CT * (CT + 1)];
   __shared__ double red[NT / 64];
   __shared__ float bc;
   const int ty = blockIdx.x / g.tiles_x, tx = blockIdx.x - ty * g.tiles_x;
   const int i0 = ty * CT, j0 = tx * CT;
+  // every global load of the kernel is issued before anything waits: one memory latency
+  constexpr int NL1 = (E1 * E1 + NT - 1) / NT;
+  float tv[NL1], pv[NL1];
+  int gi[NL1];
+#pragma unroll
+  for (int q = 0; q < NL1; ++q) {
+    const int idx = threadIdx.x + q * NT;
+    const int r = idx / E1, c = idx - r * E1;
+    const int i = i0 - CH + r, j = j0 - CH + c;
+    const bool in = idx < E1 * E1;
+    gi[q] = in ? refl(i, g.nx) * g.ny + refl(j, g.ny) : 0;
+    tv[q] = t[gi[q]];
+    pv[q] = p_old[gi[q]];
+  }
+  double part[PMAX];
+  partials_issue(gam, part);
+  const double gp = first ? 1.0 : *gprev;
+#pragma unroll
+  for (int q = 0; q < NL1; ++q) {
+    const int idx = threadIdx.x + q * NT;
+    if (idx < E1 * E1) {
+      const int r = idx / E1, c = idx - r * E1;
+      T1[r * S1 + c] = tv[q];
+      P1[r * S1 + c] = pv[q];
+    }
+  }
+  __syncthreads();
+  // the blur is linear: A (t + beta p) = A t + beta A p — both halves are formed before beta (the previous kernel's partials) is in
+  blur_lds<CT, CT>(T1, S1, tmp, WA, CT + 1, g.rwf, g.cwf);
+  blur_lds<CT, CT, false>(P1, S1, tmp, WB, CT + 1, g.rwf, g.cwf);
   if (threadIdx.x < 64) {                                   // beta = gamma_{k-1} / gamma_{k-2}; block 0 publishes gamma_{k-1}
-    const double gk = scalar_from_wave(gam, threadIdx.x);
+    const double gk = partials_sum(part);
     if (threadIdx.x == 0) {
-      bc = first ? 0.f : (float)(gk / *gprev);
+      bc = first ? 0.f : (float)(gk / gp);
       if (blockIdx.x == 0) *gpub = gk;
     }
   }
   __syncthreads();
   const float beta = bc;
-  for (int idx = threadIdx.x; idx < E1 * E1; idx += NT) {
+#pragma unroll
+  for (int q = 0; q < NL1; ++q) {                            // p = t + beta p on the tile   (CGLS.py:72)
+    const int idx = threadIdx.x + q * NT;
     const int r = idx / E1, c = idx - r * E1;
     const int i = i0 - CH + r, j = j0 - CH + c;
-    const int64_t gidx = (int64_t)refl(i, g.nx) * g.ny + refl(j, g.ny);
-    const float pn = fmaf(beta, p_old[gidx], t[gidx]);       // p = t + beta p   (CGLS.py:72)
-    P1[r * (E1 + 1) + c] = pn;
-    if (r >= CH && r < CH + CT && c >= CH && c < CH + CT && i < g.nx && j < g.ny) p_new[gidx] = pn;
+    if (idx < E1 * E1 && r >= CH && r < CH + CT && c >= CH && c < CH + CT && i < g.nx && j < g.ny)
+      p_new[gi[q]] = fmaf(beta, pv[q], tv[q]);
   }
-  __syncthreads();
-  blur_lds<CT, CT>(P1, E1 + 1, tmp, W, CT + 1, g.rwf, g.cwf);   // w = A p on the tile   (CGLS.py:60)
   double ss = 0.0;
-  for (int idx = threadIdx.x; idx < CT * CT; idx += NT) {
+  for (int idx = threadIdx.x; idx < CT * CT; idx += NT) {    // ||A p||^2 on the tile   (CGLS.py:60-61)
     const int r = idx / CT, c = idx - r * CT;
     if (i0 + r < g.nx && j0 + c < g.ny) {
-      const float w = W[r * (CT + 1) + c];
+      const float w = fmaf(beta, WB[r * (CT + 1) + c], WA[r * (CT + 1) + c]);
       ss += (double)w * w;
     }
   }
@@ -119,37 +213,72 @@ __global__ __launch_bounds__(NT) void k_cgls_tile_b(TiledGeom g, const float* __
                                                     const float* __restrict__ x_old, float* __restrict__ x_new,
                                                     const float* __restrict__ x_true, ScalarSrc del, const double* __restrict__ gamma,
                                                     double* __restrict__ dpub, double* __restrict__ PG, double* __restrict__ NP) {
-  __shared__ float P2[E2 * (E2 + 1)];
-  __shared__ float tmp[E2 * (E1 + 1)];
-  __shared__ float W[E1 * (E1 + 1)];          // w on tile + halo, then r_k there
-  __shared__ float T[CT * (CT + 1)];
-  __shared__ double red[NT / 64];
+  constexpr int S2 = E2 + 4, S1 = E1 + 4;                   // LDS row strides: multiples of 4 (16-byte aligned rows)
+  __shared__ __attribute__((aligned(16))) float P2[E2 * S2];
+  __shared__ __attribute__((aligned(16))) float tmp[E2 * (E1 + 4)];
+  __shared__ __attribute__((aligned(16))) float W[E1 * S1];  // w on tile + halo, then r_k there
+  __shared__ __attribute__((aligned(16))) float T[CT * (CT + 1)];
+  __shared__ double red[4 * (NT / 64)];
   __shared__ float bc;
   const int ty = blockIdx.x / g.tiles_x, tx = blockIdx.x - ty * g.tiles_x;
   const int i0 = ty * CT, j0 = tx * CT;
-  if (threadIdx.x < 64) {                                   // alpha = gamma_{k-1} / ||w||^2; block 0 publishes ||w||^2
-    const double d = scalar_from_wave(del, threadIdx.x);
+  // every global load of the kernel is issued before anything waits: p on tile + 8, r on tile + 4, x (and x_true) on the tile
+  constexpr int NL2 = (E2 * E2 + NT - 1) / NT, NL1 = (E1 * E1 + NT - 1) / NT, NL0 = (CT * CT + NT - 1) / NT;
+  float pv[NL2], rv[NL1], xv[NL0], xtv[NL0];
+#pragma unroll
+  for (int q = 0; q < NL2; ++q) {
+    const int idx = threadIdx.x + q * NT;
+    const int r = idx / E2, c = idx - r * E2;
+    pv[q] = idx < E2 * E2 ? p[refl(i0 - 2 * CH + r, g.nx) * g.ny + refl(j0 - 2 * CH + c, g.ny)] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < NL1; ++q) {
+    const int idx = threadIdx.x + q * NT;
+    const int r = idx / E1, c = idx - r * E1;
+    const int i = i0 - CH + r, j = j0 - CH + c;
+    rv[q] = (idx < E1 * E1 && (unsigned)i < (unsigned)g.nx && (unsigned)j < (unsigned)g.ny) ? r_old[i * g.ny + j] : 0.f;
+  }
+#pragma unroll
+  for (int q = 0; q < NL0; ++q) {
+    const int idx = threadIdx.x + q * NT;
+    const int r = idx / CT, c = idx - r * CT;
+    const int i = i0 + r, j = j0 + c;
+    const bool in = idx < CT * CT && i < g.nx && j < g.ny;
+    xv[q] = in ? x_old[i * g.ny + j] : 0.f;
+    xtv[q] = (HAS_XT && in) ? x_true[i * g.ny + j] : 0.f;
+  }
+  double part[PMAX];
+  partials_issue(del, part);
+  const double gm = *gamma;
+#pragma unroll
+  for (int q = 0; q < NL2; ++q) {
+    const int idx = threadIdx.x + q * NT;
+    if (idx < E2 * E2) {
+      const int r = idx / E2, c = idx - r * E2;
+      P2[r * S2 + c] = pv[q];
+    }
+  }
+  __syncthreads();
+  blur_lds<E1, E1, false>(P2, S2, tmp, W, S1, g.rwf, g.cwf);   // w = A p on tile + halo (positions outside the image: unused)
+  if (threadIdx.x < 64) {                                   // alpha = gamma_{k-1} / ||w||^2, needed only now; block 0 publishes ||w||^2
+    const double d = partials_sum(part);
     if (threadIdx.x == 0) {
-      bc = (float)(*gamma / d);
+      bc = (float)(gm / d);
       if (blockIdx.x == 0) *dpub = d;
     }
   }
-  for (int idx = threadIdx.x; idx < E2 * E2; idx += NT) {
-    const int r = idx / E2, c = idx - r * E2;
-    P2[r * (E2 + 1) + c] = p[(int64_t)refl(i0 - 2 * CH + r, g.nx) * g.ny + refl(j0 - 2 * CH + c, g.ny)];
-  }
   __syncthreads();
   const float alpha = bc;
-  blur_lds<E1, E1>(P2, E2 + 1, tmp, W, E1 + 1, g.rwf, g.cwf);   // w = A p on tile + halo (positions outside the image: unused)
   // r_k = r_{k-1} - alpha w   (CGLS.py:67) where the position is a pixel; its mirror pixel's value where it is not
-  for (int idx = threadIdx.x; idx < E1 * E1; idx += NT) {
+#pragma unroll
+  for (int q = 0; q < NL1; ++q) {
+    const int idx = threadIdx.x + q * NT;
     const int r = idx / E1, c = idx - r * E1;
     const int i = i0 - CH + r, j = j0 - CH + c;
-    if ((unsigned)i < (unsigned)g.nx && (unsigned)j < (unsigned)g.ny) {
-      const int64_t gidx = (int64_t)i * g.ny + j;
-      const float rn = fmaf(-alpha, W[r * (E1 + 1) + c], r_old[gidx]);
-      W[r * (E1 + 1) + c] = rn;
-      if (r >= CH && r < CH + CT && c >= CH && c < CH + CT) r_new[gidx] = rn;
+    if (idx < E1 * E1 && (unsigned)i < (unsigned)g.nx && (unsigned)j < (unsigned)g.ny) {
+      const float rn = fmaf(-alpha, W[r * S1 + c], rv[q]);
+      W[r * S1 + c] = rn;
+      if (r >= CH && r < CH + CT && c >= CH && c < CH + CT) r_new[i * g.ny + j] = rn;
     }
   }
   __syncthreads();
@@ -159,35 +288,34 @@ __global__ __launch_bounds__(NT) void k_cgls_tile_b(TiledGeom g, const float* __
     if (!((unsigned)i < (unsigned)g.nx && (unsigned)j < (unsigned)g.ny)) {
       const int mr = refl(i, g.nx) - (i0 - CH), mc = refl(j, g.ny) - (j0 - CH);
       // the mirror of a halo position that an output of this tile reads lies inside the halo region; others are not read
-      W[r * (E1 + 1) + c] = ((unsigned)mr < (unsigned)E1 && (unsigned)mc < (unsigned)E1) ? W[mr * (E1 + 1) + mc] : 0.f;
+      W[r * S1 + c] = ((unsigned)mr < (unsigned)E1 && (unsigned)mc < (unsigned)E1) ? W[mr * S1 + mc] : 0.f;
     }
   }
   __syncthreads();
-  blur_lds<CT, CT>(W, E1 + 1, tmp, T, CT + 1, g.rwt, g.cwt);    // t = A^T r on the tile   (CGLS.py:68)
+  blur_lds<CT, CT>(W, S1, tmp, T, CT + 1, g.rwt, g.cwt);        // t = A^T r on the tile   (CGLS.py:68)
   double sg = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int idx = threadIdx.x; idx < CT * CT; idx += NT) {
+#pragma unroll
+  for (int q = 0; q < NL0; ++q) {
+    const int idx = threadIdx.x + q * NT;
     const int r = idx / CT, c = idx - r * CT;
     const int i = i0 + r, j = j0 + c;
-    if (i < g.nx && j < g.ny) {
-      const int64_t gidx = (int64_t)i * g.ny + j;
+    if (idx < CT * CT && i < g.nx && j < g.ny) {
+      const int gidx = i * g.ny + j;
       const float tv = T[r * (CT + 1) + c];
       t[gidx] = tv;
       sg += (double)tv * tv;
-      const float d = alpha * P2[(r + 2 * CH) * (E2 + 1) + c + 2 * CH];       // x += alpha p   (CGLS.py:65)
-      const float xn = x_old[gidx] + d;
+      const float d = alpha * P2[(r + 2 * CH) * S2 + c + 2 * CH];             // x += alpha p   (CGLS.py:65)
+      const float xn = xv[q] + d;
       x_new[gidx] = xn;
       s0 += (double)xn * xn;
       s1 += (double)d * d;
       if (HAS_XT) {
-        const double e = (double)xn - (double)x_true[gidx];
+        const double e = (double)xn - (double)xtv[q];
         s2 += e * e;
       }
     }
   }
-  sg = block_sum<NT>(sg, red);
-  s0 = block_sum<NT>(s0, red);
-  s1 = block_sum<NT>(s1, red);
-  if (HAS_XT) s2 = block_sum<NT>(s2, red);
+  block_sum4(sg, s0, s1, s2, red);
   if (threadIdx.x == 0) {
     PG[blockIdx.x] = sg;
     NP[(size_t)blockIdx.x * 3 + 0] = s0;
