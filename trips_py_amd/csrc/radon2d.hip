@@ -649,12 +649,14 @@ __device__ __forceinline__ void adj_gather(const u4r r, unsigned B, unsigned neg
   acc0 = fmaf(w0, __builtin_bit_cast(float, s0), acc0);
 }
 
-template <int T, int PX, int AB>
-__global__ __launch_bounds__(256) void k_radon_adj_tile(const uint4* __restrict__ rec, float* __restrict__ img, int N, int nd, int na,
-                                                        const AdjAngle* __restrict__ ang, const int* __restrict__ n_mode0,
+template <int T, int PX, int AB, bool PREP>
+__global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict__ sino, const uint4* __restrict__ rec,
+                                                        float* __restrict__ img, int N, int nd, int na,
+                                                        const AdjAngle* __restrict__ ang, const float* __restrict__ wgt,
+                                                        const unsigned* __restrict__ A32, const int* __restrict__ n_mode0,
                                                         const uint2* __restrict__ CB, int npad, int tiles_x,
                                                         double* __restrict__ ssq_part) {
-  __shared__ __attribute__((aligned(16))) uint4 ring[2][AB][64];            // 16 KB
+  __shared__ __attribute__((aligned(16))) uint4 ring[2][AB][64];
   __shared__ __attribute__((aligned(16))) uint2 cbs[2][AB][T];
   __shared__ float xch[PX > 1 ? T : 1][T + 1];
   static_assert(T * T == 256 * PX && (T == 16 || T == 32), "256 threads x PX pixels cover the T x T tile");
@@ -666,11 +668,14 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const uint4* __restrict_
   const int i0 = ty * T, j0 = tx * T;
   const int ndp = nd + 2 * A32_PAD;
   ang += (int64_t)frame * na;
+  wgt += (int64_t)frame * na;
+  sino += (int64_t)frame * na * nd;
   rec += (int64_t)frame * na * ndp;
+  A32 += (int64_t)frame * na * ndp;
+  const auto rrec = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, (unsigned)((int64_t)na * ndp * 16), 0x00020000);
   CB += (int64_t)frame * na * npad;
   const int n0 = n_mode0[frame];
   const float sdh = 0.5f * (float)(nd - 1);
-  const auto rrec = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, (unsigned)((int64_t)na * ndp * 16), 0x00020000);
   const auto rcb = __builtin_amdgcn_make_buffer_rsrc((void*)CB, 0, (unsigned)((int64_t)na * npad * 8), 0x00020000);
 
   // thread -> pixels.  mode 0 (marching index = row): row r0, columns c0 + k T/PX;  mode 1 (= column): column c1, rows
@@ -703,10 +708,15 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const uint4* __restrict_
   asm("" : "+s"(nsc));
 
   const int nbatch = (na + AB - 1) / AB;
-  // staging of batch b into buffer b & 1: wave w brings the rings of angles w and w + 4 of the batch; the first 128 threads
-  // bring the {C, B32} pairs (16 bytes = two marching indices per thread)
-  auto stage = [&](int b) {
-    const int buf = b & 1;
+  // Staging of batch b into buffer b & 1: wave w takes the rings of angles w, w + 4, ... of the batch, lane l the detector whose
+  // ring slot is l.  PREP: the records {w S[d -], w S[d +], w S[d], A32[d]} were written by k_radon_adj_prep and go straight
+  // to LDS (one 16-byte direct-to-LDS load per lane and angle).  !PREP: they are made here from the sinogram itself — four
+  // dwords per lane into registers while the previous batch is gathered, written to LDS afterwards — which saves the pre-pass
+  // launch and pays when a frame has few angles (dynamic problems, 15 per frame: 32 frames 21.0 -> 20.0 us, 4 frames 11.0 ->
+  // 8.4 us) but costs more instructions per record (180 angles: 512^2 46 -> 57 us, 4096^2 1.04 -> 1.32 ms).
+  // The {C, B32} pairs of the tile's marching indices always go straight to LDS (16 bytes = two indices per thread).
+  uint4 sreg[AB / 4];
+  auto stage_load = [&](int b) {
 #pragma unroll
     for (int h = 0; h < AB / 4; ++h) {
       const int al = wv + 4 * h;
@@ -724,11 +734,25 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const uint4* __restrict_
       const int dbase = __builtin_amdgcn_readfirstlane((int)floorf(0.5f * (dmin + dmax))) - 32;   // ring covers dbase .. dbase + 63
       const int d = dbase + ((lane - dbase) & 63);                   // the detector whose ring slot is this lane
       int e = d + A32_PAD;
-      e = e < 0 ? 0 : (e > ndp - 1 ? ndp - 1 : e);                   // beyond the detector: the all-zero end records
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rrec, (__attribute__((address_space(3))) void*)&ring[buf][al][0], 16,
-                                               (a * ndp + e) * 16, 0, 0, 0);
+      e = e < 0 ? 0 : (e > ndp - 1 ? ndp - 1 : e);                   // beyond the detector: weightless (S = 0) anyway
+      if (PREP) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rrec, (__attribute__((address_space(3))) void*)&ring[b & 1][al][0], 16,
+                                                 (a * ndp + e) * 16, 0, 0, 0);
+        continue;
+      }
+      const float* __restrict__ S = sino + (int64_t)p.orig * nd;
+      const float w = wgt[a];
+      const int dm = d - 1, dp = d + 1;
+      const float sm = ((unsigned)dm < (unsigned)nd) ? w * S[dm] : 0.f;
+      const float s0 = ((unsigned)d < (unsigned)nd) ? w * S[d] : 0.f;
+      const float sp = ((unsigned)dp < (unsigned)nd) ? w * S[dp] : 0.f;
+      sreg[h].x = __builtin_bit_cast(unsigned, p.flip ? sp : sm);    // the neighbour at t0 - |inv|
+      sreg[h].y = __builtin_bit_cast(unsigned, p.flip ? sm : sp);    // the neighbour at t0 + |inv|
+      sreg[h].z = __builtin_bit_cast(unsigned, s0);
+      sreg[h].w = A32[(int64_t)p.orig * ndp + e];
     }
     if (tid < AB * T / 2) {
+      const int buf = b & 1;
       const int al = tid / (T / 2), pr = tid - al * (T / 2);
       int a = b * AB + al;
       a = a < na ? a : na - 1;
@@ -738,13 +762,19 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const uint4* __restrict_
                                                16, (ang[a].orig * npad + tt0) * 8, 0, 0, 0);
     }
   };
+  auto stage_store = [&](int b) {
+    if (PREP) return;
+#pragma unroll
+    for (int h = 0; h < AB / 4; ++h) ring[b & 1][wv + 4 * h][lane] = sreg[h];
+  };
 
-  stage(0);
+  stage_load(0);
+  stage_store(0);
   for (int b = 0; b < nbatch; ++b) {
     const int buf = b & 1;
     __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this wave's share of batch b has landed
     __syncthreads();                                 // batch b complete; everyone is done with the other buffer
-    if (b + 1 < nbatch) stage(b + 1);
+    if (b + 1 < nbatch) stage_load(b + 1);           // in flight while batch b is gathered
     const int nal = (na - b * AB < AB) ? na - b * AB : AB;
     // the batch's mode-0 angles come first (the angles are sorted by mode): two loops without a mode test inside, unrolled so
     // that the LDS reads of several angles are in flight together (small images run few waves per SIMD: latency, not issue)
@@ -781,6 +811,7 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const uint4* __restrict_
         adj_gather(r, cb.y, colB[k], sc2, nsc, c2, anB[k], accB[k]);
       }
     }
+    if (b + 1 < nbatch) stage_store(b + 1);          // the other buffer: nobody reads it before the next barrier
   }
   // the two partial images meet: mode-0 sums go through LDS to the thread that holds the pixel in the mode-1 layout
   if (PX > 1) {
@@ -913,17 +944,23 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
   } else {
     const int ndp = nd + 2 * A32_PAD;
     for (int b = 0; b < batch; ++b) {            // the record array is per vector
-      hipLaunchKernelGGL(k_radon_adj_prep, dim3(ceil_div((int64_t)na * ndp, 256), nt), dim3(256), 0, s, x + (int64_t)b * ldx,
-                         im->rec, nd, na, im->adj_ang, im->adj_wgt, im->A32);
-      if (tile && tile_T == 32)
-        hipLaunchKernelGGL((k_radon_adj_tile<32, 4, 8>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
-                           im->adj_ang, im->adj_n0, im->CB, im->npad, tiles_x, ssq_part);
-      else if (tile && (ab_env ? ab_env == 16 : na > 32))
-        hipLaunchKernelGGL((k_radon_adj_tile<16, 1, 16>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
-                           im->adj_ang, im->adj_n0, im->CB, im->npad, tiles_x, ssq_part);
-      else if (tile)   // few angles per frame (dynamic problems: 15): short batches, so that staging and gathering still overlap
-        hipLaunchKernelGGL((k_radon_adj_tile<16, 1, 4>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
-                           im->adj_ang, im->adj_n0, im->CB, im->npad, tiles_x, ssq_part);
+      const float* xb = x + (int64_t)b * ldx;
+      const bool prep = !tile || na > 32;            // few angles per frame: the tile kernel makes its records itself
+      if (prep)
+        hipLaunchKernelGGL(k_radon_adj_prep, dim3(ceil_div((int64_t)na * ndp, 256), nt), dim3(256), 0, s, xb, im->rec, nd, na,
+                           im->adj_ang, im->adj_wgt, im->A32);
+#define ADJ_TILE(TT, PP, BB, PR)                                                                                              \
+  hipLaunchKernelGGL((k_radon_adj_tile<TT, PP, BB, PR>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, xb, im->rec,          \
+                     y + (int64_t)b * ldy, N, nd, na, im->adj_ang, im->adj_wgt, im->A32, im->adj_n0, im->CB, im->npad, tiles_x, \
+                     ssq_part)
+      if (tile && tile_T == 32) {
+        if (prep) ADJ_TILE(32, 4, 8, true); else ADJ_TILE(32, 4, 8, false);
+      } else if (tile && (ab_env ? ab_env == 16 : na > 32)) {
+        if (prep) ADJ_TILE(16, 1, 16, true); else ADJ_TILE(16, 1, 16, false);
+      } else if (tile) {   // few angles per frame (dynamic problems: 15): short batches, so that staging and gathering still overlap
+        if (prep) ADJ_TILE(16, 1, 4, true); else ADJ_TILE(16, 1, 4, false);
+      }
+#undef ADJ_TILE
       else
         hipLaunchKernelGGL(k_radon_adj_simple, dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
                            im->adj_ang, im->adj_n0, im->CB, im->npad, ssq_part);
