@@ -202,9 +202,10 @@ def run_blur_cgls(args, rank, world, json_fd=1):
 
     # the class trips_py_amd.solvers.CGLS itself picks for this operator (tol = 0, single rank per problem)
     fused = CGLSRunFused.usable(A, eng) and not args.unfused and (args.fused or CGLSRunFused.auto(n))
-    Run = CGLSRunFused if fused else CGLSRun
+    tiled = not args.unfused and not args.fused and CGLSRunFused.tiled_usable(A, eng)      # small images (--size <= 1024)
+    Run = CGLSRunFused if (fused or tiled) else CGLSRun
     # reference call without x_true (CGLS.py:16); norms deferred exactly as CGLS() does for tol = 0 on one rank
-    run = Run(A, b, x0, W + K, x_true=None, history=False) if fused else \
+    run = Run(A, b, x0, W + K, x_true=None, history=False, tiled=tiled) if (fused or tiled) else \
         Run(A, b, x0, W + K, x_true=None, history=False, defer_norms=True)
     run.run(W)
     tfwd = KernelTimer(A, K + 4, 0)
@@ -233,9 +234,12 @@ def run_blur_cgls(args, rank, world, json_fd=1):
     # algorithmic bytes of the forward-blur launch: plain matvec reads x and writes y (8 n); the fused form also reads
     # p_old and writes p_new (16 n) — SURVEY §8d's own accounting of a fused update + matvec
     alg_bytes = (16.0 if fused else 8.0) * n
+    if tiled:       # two tile kernels per iteration, no separate blur launch: the iteration's 44n bytes over its time
+        alg_bytes, ms_fwd = 44.0 * n, np.array([elapsed / K * 1e3])
     t_kernel = float(np.mean(ms_fwd)) * 1e-3
     achieved = alg_bytes / t_kernel / 1e9
-    kname = ("k_blur_slide<9,9,D=9,sumsq,fuse> (p = t + ratio*p fused into w = A p, + ||w||^2)" if fused
+    kname = ("k_cgls_tile_a + k_cgls_tile_b (whole iteration: two launches, 44n algorithmic bytes)" if tiled else
+             "k_blur_slide<9,9,D=9,sumsq,fuse> (p = t + ratio*p fused into w = A p, + ||w||^2)" if fused
              else "k_blur_slide<9,9,D=9,sumsq> (forward blur matvec w = A p, fused ||w||^2)")
     roofline = {"bound": "hbm", "kernel": kname,
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -250,7 +254,8 @@ def run_blur_cgls(args, rank, world, json_fd=1):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"blur{N}_cgls", "image": f"{N}x{N} fp32", "psf": "Gaussian 9x9 sigma=(3,3), reflect",
                       "solver": "CGLS (trips.solvers.CGLS semantics, tol=0)", "noise": "1% Gaussian",
-                      "iteration": "fused: 3 launches (blur+p-update, x-update, blur^T+r-update)" if Run is CGLSRunFused else (("4 launches (blur, r update, blur^T, x/p update in one pass over p; consumers add the block partials)"
+                      "iteration": "tiled: 2 launches (a workgroup per 32x32 tile recomputes its halo of p and A p in LDS)" if tiled else
+                                   "fused: 3 launches (blur+p-update, x-update, blur^T+r-update)" if Run is CGLSRunFused else (("4 launches (blur, r update, blur^T, x/p update in one pass over p; consumers add the block partials)"
                                      if getattr(run, "grouping", 0) == 1 else
                                      "4 launches (blur, x/r update, blur^T, p update; consumers add the block partials)")
                                     if getattr(run, "raw", False) else "generic: 6 launches"),

@@ -390,6 +390,7 @@ __global__ __launch_bounds__(256, 7) void k_radon_fwd_win(const float* __restric
                                                        const unsigned* __restrict__ A32, const unsigned* __restrict__ B32, int npad) {
   __shared__ __attribute__((aligned(16))) float tile[2][WIN_R * WIN_W];
   __shared__ float ext[4][WIN_MAXCH][2];
+  __shared__ int chinfo[WIN_MAXCH][2];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int grp = blockIdx.x / nwin, jj = blockIdx.x - grp * nwin;
   const int frame = grp / ngrp_per_frame;
@@ -464,6 +465,18 @@ __global__ __launch_bounds__(256, 7) void k_radon_fwd_win(const float* __restric
       ext[wv][lane][1] = any ? bhi + fmaxf(ta, tz) : -3.0e38f;
     }
     __syncthreads();
+    // the union window of every chunk, once per band instead of once per wave and chunk (8 LDS reads, 6 min/max, two floors:
+    // a sixth of the kernel's vector instructions were this bookkeeping): lane ch of wave 0 does chunk ch
+    if (wv == 0 && lane < nch) {
+      const float ulo = fminf(fminf(ext[0][lane][0], ext[1][lane][0]), fminf(ext[2][lane][0], ext[3][lane][0]));
+      const float uhi = fmaxf(fmaxf(ext[0][lane][1], ext[1][lane][1]), fmaxf(ext[2][lane][1], ext[3][lane][1]));
+      const bool nobody = ulo > uhi;                             // no wave owns a ray in this window
+      const int cs = nobody ? 0 : (((int)floorf(ulo) - 1) & ~3);
+      const bool fits = !nobody && ((int)floorf(nobody ? 0.f : uhi) + 2 - cs) < WIN_W;
+      chinfo[lane][0] = cs;
+      chinfo[lane][1] = fits ? 1 : 0;
+    }
+    __syncthreads();
     // staging slots of this thread: float4 numbers t and t + 256 of the 16 x 32 tile
     int sc4[2], srowN4[2], srow[2];
 #pragma unroll
@@ -477,11 +490,8 @@ __global__ __launch_bounds__(256, 7) void k_radon_fwd_win(const float* __restric
       const int tb = t0 + ch * WIN_R, te = (tb + WIN_R < t1) ? tb + WIN_R : t1;
       const int buf = ch & 1;
       float* __restrict__ T = tile[buf];
-      const float ulo = fminf(fminf(ext[0][ch][0], ext[1][ch][0]), fminf(ext[2][ch][0], ext[3][ch][0]));
-      const float uhi = fmaxf(fmaxf(ext[0][ch][1], ext[1][ch][1]), fmaxf(ext[2][ch][1], ext[3][ch][1]));
-      const bool nobody = ulo > uhi;                             // no wave owns a ray in this window (uniform over the workgroup)
-      const int cs = __builtin_amdgcn_readfirstlane(nobody ? 0 : (((int)floorf(ulo) - 1) & ~3));
-      const bool fits = !nobody && (__builtin_amdgcn_readfirstlane((int)floorf(nobody ? 0.f : uhi)) + 2 - cs) < WIN_W;
+      const int cs = __builtin_amdgcn_readfirstlane(chinfo[ch][0]);
+      const bool fits = __builtin_amdgcn_readfirstlane(chinfo[ch][1]) != 0;
       const bool full = (te - tb == WIN_R);
       const unsigned* __restrict__ Brow = static_cast<const unsigned*>(__builtin_assume_aligned(Ball + tb, 64));
       f2v acc2 = {0.f, 0.f};

@@ -248,6 +248,7 @@ __global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, Scalar
   float step;
   if (gamma.n == 1 && delta.n == 1) {                // finished scalars (grid-uniform)
     step = (float)(*gamma.p / *delta.p);
+    if (blockIdx.x == 0 && threadIdx.x == 0 && pub_delta && pub_delta != delta.p) *pub_delta = *delta.p;   // a one-block producer
   } else {                                           // block partials of the producing kernel: one wave sums them
     if (threadIdx.x < 64) {
       const double g = scalar_from_wave(gamma, threadIdx.x), d = scalar_from_wave(delta, threadIdx.x);

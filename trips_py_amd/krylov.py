@@ -283,25 +283,26 @@ class GramSchmidtByGram:
             eng.cgs_coeffs(self.G.ref(0), self.kmax, None, self.W.ref(0), j + 1, 0, None)
         self.in_G = V.k
 
-    def sweep(self, k, w, passes, out, sumsq=None):
+    def sweep(self, k, w, passes, out, sumsq=None, c_out=None):
         """out = w orthogonalised against V[0..k) by `passes` sweeps; LOCAL sum(out^2) into `sumsq` (fused).  Returns the
         DevScalars reference of the k combined coefficients."""
         eng, V, W, K = self.eng, self.V, self.W, self.kmax
         if k > K:
             raise ValueError("GramSchmidtByGram: basis larger than planned")
+        c = W.ref(2 * K) if c_out is None else c_out
         if self.in_G == k - 1:                        # the newest vector's Gram row rides along with h
             eng.gemv_t2(V.data, k, w, V[k - 1], W.ref(0))
             eng.allreduce(W, 0, 2 * k)
-            eng.cgs_coeffs(self.G.ref(0), K, W.ref(0), W.ref(k), k, passes, W.ref(2 * K))
+            eng.cgs_coeffs(self.G.ref(0), K, W.ref(0), W.ref(k), k, passes, c)
             self.in_G = k
         elif self.in_G == k:
             eng.gemv_t(V.data, k, w, W.ref(0))
             eng.allreduce(W, 0, k)
-            eng.cgs_coeffs(self.G.ref(0), K, W.ref(0), None, k, passes, W.ref(2 * K))
+            eng.cgs_coeffs(self.G.ref(0), K, W.ref(0), None, k, passes, c)
         else:
             raise RuntimeError("GramSchmidtByGram: more than one vector appended since the last sweep")
-        eng.gemv_n(V.data, k, W.ref(2 * K), out, a=1.0, base=w, s=-1.0, sumsq=sumsq)
-        return W.ref(2 * K)
+        eng.gemv_n(V.data, k, c, out, a=1.0, base=w, s=-1.0, sumsq=sumsq)
+        return c
 
 
 class ArnoldiState:
@@ -317,6 +318,7 @@ class ArnoldiState:
         self.w = eng.empty(n)
         self.S = eng.scalars(2 * (capacity + 1) + 2)
         self.Hcols = []
+        self.gram, self.capacity = None, int(capacity)
         bv = eng.to_vec(b, n)
         eng.nrm2sq(bv, self.S.ref(0))
         eng.allreduce(self.S, 0, 1)
@@ -331,8 +333,15 @@ class ArnoldiState:
             self.S = S = eng.scalars(4 * k + 2)
         A.apply(V[k - 1], out=self.w)
         slot = V.next_slot()
-        # the second Gram-Schmidt pass writes straight into the next slot and leaves ||.||^2 in S[0]
-        orthogonalize(eng, V, k, self.w, S, 1, passes=2, out=slot, sumsq=S.ref(0))
+        # two Gram-Schmidt sweeps (= the reference's modified Gram-Schmidt to rounding), written straight into the next slot with
+        # ||.||^2 in S[0]: by Gram matrix (two passes over the basis) where the engine has the kernels, else sweep by sweep
+        if self.gram is None and hasattr(eng, "cgs_coeffs") and self.capacity is not None:
+            self.gram = GramSchmidtByGram(eng, V, self.capacity + 1)
+        if self.gram is not None:
+            # the combined coefficients of both sweeps go to S[1 .. 1+k) (column k of H); S[1+k .. 1+2k) stays zero
+            self.gram.sweep(k, self.w, 2, slot, sumsq=S.ref(0), c_out=S.ref(1))
+        else:
+            orthogonalize(eng, V, k, self.w, S, 1, passes=2, out=slot, sumsq=S.ref(0))
         eng.allreduce(S, 0, 1)
         eng.scale(Coef(1.0, den=S.ref(0), sqrt_den=True), slot, slot)
         V.commit()
