@@ -305,6 +305,13 @@ int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y
 int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G_dev,
               double* c1_dev, double* c2_dev, trk_stream stream);
 
+/* y = (G_A + lam G_L)^-1 c on the device (float64, one workgroup, k <= 88): the projected Tikhonov problem of GKS.py:74 /
+ * MMGKS.py:106, `lstsq([R_A; sqrt(lam) R_L], [Q_A^T b; 0])`, from the Gram data G_A = (AV)^T AV, G_L = (LV)^T LV (row strides
+ * lda, ldl) and c = (AV)^T b that trk_gemv_t / trk_wgram leave on the device — a numeric regparam then needs no host round trip
+ * inside the loop. */
+int trk_gram_tikhonov(const double* GA_dev, int lda, const double* GL_dev, int ldl, const double* c_dev, int k, double lam,
+                      double* y_dev, trk_stream stream);
+
 /* CGLS on SMALL blur problems in two launches per iteration (CGLS.py:56-80): a workgroup owns a 32 x 32 tile and recomputes
  * in LDS what it needs of its neighbours' halo (p = t + beta p and w = A p on tile + halo) instead of waiting for them at a
  * kernel boundary; same buffers, scalar layout and results (to fp32 rounding of the partial sums' order) as

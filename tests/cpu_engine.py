@@ -180,6 +180,14 @@ class CpuEngine:
         Vk = _d(V[:k])
         _put(out_h2k, np.concatenate((Vk @ _d(r), Vk @ _d(r2))))
 
+    GRAM_TIKHONOV_MAX_K = 88
+
+    def gram_tikhonov(self, GA, lda, GL, ldl, c, k, lam, y):
+        (sa, ia), (sl, il) = GA, GL
+        A = np.array([sa.a[ia + i * lda: ia + i * lda + k] for i in range(k)])
+        Lm = np.array([sl.a[il + i * ldl: il + i * ldl + k] for i in range(k)])
+        _put(y, np.linalg.solve(A + lam * Lm, np.asarray(_get(c, k)).reshape(-1)))
+
     def cgs_coeffs(self, G, ldg, h, g_new, k, passes, c):
         Gs, g0 = G
         M = Gs.a[g0:g0 + ldg * ldg].reshape(ldg, ldg)

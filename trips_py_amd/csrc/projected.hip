@@ -233,6 +233,69 @@ extern "C" int trk_cgs_coeffs(double* G, int ldg, const double* h, const double*
   return TRK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ projected Tikhonov solve from Gram data
+// y = argmin ||AV y - b||^2 + lam ||LV y||^2 = (G_A + lam G_L)^-1 c  with G_A = (AV)^T AV, G_L = (LV)^T LV, c = (AV)^T b —
+// what `lstsq([R_A; sqrt(lam) R_L], [Q_A^T b; 0])` of GKS.py:74 / MMGKS.py:106 solves (R^T R = G, R_A^T Q_A^T b = c) — on
+// the device, from the Gram data the device already holds: with a NUMERIC regparam no scalar visits the host inside the
+// loop (GKS / MMGKS each paid a download, two k x k Cholesky factorisations, a stacked least-squares solve and an upload per
+// iteration: ~0.15 ms of host time with the GPU idle).  One workgroup; Cholesky in LDS, float64.
+__global__ __launch_bounds__(256) void k_gram_tikhonov(const double* __restrict__ GA, int lda, const double* __restrict__ GL, int ldl,
+                                                       const double* __restrict__ c, int k, double lam, double* __restrict__ y) {
+  extern __shared__ double sm[];              // M (k x (k+1)) | z (k)
+  const int ld = k + 1;
+  double* M = sm;
+  double* z = sm + (size_t)k * ld;
+  for (int idx = threadIdx.x; idx < k * k; idx += blockDim.x) {
+    const int i = idx / k, j = idx - i * k;
+    M[i * ld + j] = GA[(size_t)i * lda + j] + lam * GL[(size_t)i * ldl + j];
+  }
+  for (int i = threadIdx.x; i < k; i += blockDim.x) z[i] = c[i];
+  __syncthreads();
+  // M = C C^T (lower), column by column; a pivot that rounding drove to <= 0 is lifted to a tiny positive number
+  for (int j = 0; j < k; ++j) {
+    if (threadIdx.x == 0) {
+      const double d = M[j * ld + j];
+      M[j * ld + j] = sqrt(d > 0.0 ? d : 1e-300);
+    }
+    __syncthreads();
+    const double djj = M[j * ld + j];
+    for (int i = j + 1 + threadIdx.x; i < k; i += blockDim.x) M[i * ld + j] /= djj;
+    __syncthreads();
+    const int rem = k - j - 1;
+    for (int idx = threadIdx.x; idx < rem * rem; idx += blockDim.x) {
+      const int a = j + 1 + idx / rem, b = j + 1 + idx % rem;
+      if (b <= a) M[a * ld + b] -= M[a * ld + j] * M[b * ld + j];
+    }
+    __syncthreads();
+  }
+  // C z' = c, then C^T y = z'
+  for (int j = 0; j < k; ++j) {
+    if (threadIdx.x == 0) z[j] /= M[j * ld + j];
+    __syncthreads();
+    const double zj = z[j];
+    for (int i = j + 1 + threadIdx.x; i < k; i += blockDim.x) z[i] -= M[i * ld + j] * zj;
+    __syncthreads();
+  }
+  for (int j = k - 1; j >= 0; --j) {
+    if (threadIdx.x == 0) z[j] /= M[j * ld + j];
+    __syncthreads();
+    const double zj = z[j];
+    for (int i = threadIdx.x; i < j; i += blockDim.x) z[i] -= M[j * ld + i] * zj;
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < k; i += blockDim.x) y[i] = z[i];
+}
+
+extern "C" int trk_gram_tikhonov(const double* GA, int lda, const double* GL, int ldl, const double* c, int k, double lam,
+                                 double* y, trk_stream st) {
+  TRK_REQUIRE(GA && GL && c && y && k >= 1 && lda >= k && ldl >= k, "trk_gram_tikhonov: bad argument");
+  TRK_REQUIRE(k <= 88, "trk_gram_tikhonov: k <= 88 (the factor lives in 64 KB of LDS)");
+  const size_t bytes = ((size_t)k * (k + 1) + k) * sizeof(double);
+  hipLaunchKernelGGL(k_gram_tikhonov, dim3(1), dim3(256), bytes, (hipStream_t)st, GA, lda, GL, ldl, c, k, lam, y);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
 extern "C" int trk_host_gcv_fminbound(const double* s, const double* rhs, int k, double m_eff, double x1, double x2,
                                       double xatol, int maxfun, double* lam_out, double* fval_out, int* nfev_out) {
   TRK_REQUIRE(s && rhs && lam_out, "trk_host_gcv_fminbound: NULL argument");

@@ -381,6 +381,13 @@ class HipEngine:
                                   self.stream())
         _lib.check(rc, "trk_gemv_t2")
 
+    GRAM_TIKHONOV_MAX_K = 88
+
+    def gram_tikhonov(self, GA, lda, GL, ldl, c, k, lam, y):
+        """y = (G_A + lam G_L)^-1 c on the device (k <= GRAM_TIKHONOV_MAX_K)."""
+        rc = self.lib.trk_gram_tikhonov(_ptr(GA), int(lda), _ptr(GL), int(ldl), _ptr(c), int(k), float(lam), _ptr(y), self.stream())
+        _lib.check(rc, "trk_gram_tikhonov")
+
     def cgs_coeffs(self, G, ldg, h, g_new, k, passes, c):
         """c = coefficients of `passes` Gram-Schmidt sweeps from h = V^T r and the Gram matrix G (device doubles); g_new: Gram
         row of the newest vector, installed into G first (None: G is complete)."""

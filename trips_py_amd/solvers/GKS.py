@@ -23,9 +23,16 @@ from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikho
 class _ProjectedBases:
     """V, AV, LV and the incrementally maintained Gram data  G_A = AV AV^T, G_L = LV LV^T, c = AV b."""
 
-    def __init__(self, A, L, bv, V0, kmax):
+    def __init__(self, A, L, bv, V0, kmax, on_device=False):
         self.A, self.L, self.eng, self.bv = A, L, A.engine, bv
         eng = self.eng
+        # on_device: the Gram data stays on the device (rows installed by a tiny kernel) and nothing is downloaded — the
+        # projected problem is solved there too (trk_gram_tikhonov: numeric regparam); else host copies for the selectors
+        self.on_device = bool(on_device)
+        self.kmax = int(kmax)
+        if self.on_device:
+            self.GA_d, self.GL_d = eng.scalars(self.kmax * self.kmax), eng.scalars(self.kmax * self.kmax)
+            self.c_d = eng.scalars(self.kmax)
         m, n = A.shape
         p = L.shape[0]
         self.V = V0
@@ -50,6 +57,13 @@ class _ProjectedBases:
         k = j + 1
         eng.gemv_t(self.AV.data, k, av, S.ref(0))
         eng.gemv_t(self.LV.data, k, lv, S.ref(k))
+        if self.on_device:
+            eng.dot(av, self.bv, self.c_d.ref(j))
+            eng.allreduce(S, 0, 2 * k)
+            eng.allreduce(self.c_d, j, j + 1)
+            eng.cgs_coeffs(self.GA_d.ref(0), self.kmax, None, S.ref(0), k, 0, None)     # install row / column j
+            eng.cgs_coeffs(self.GL_d.ref(0), self.kmax, None, S.ref(k), k, 0, None)
+            return
         eng.dot(av, self.bv, S.ref(2 * k))
         eng.allreduce(S, 0, 2 * k + 1)
         h = S.host(0, 2 * k + 1)
@@ -81,7 +95,11 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
 
     gk = golub_kahan_device(A, bv, d, kwargs.get("dp_stop", False),                 # GKS.py:36 / MMGKS.py:37
                             **{k_: v_ for k_, v_ in kwargs.items() if k_ in ("gk_eta", "gk_delta")})
-    pb = _ProjectedBases(A, L, bv, gk.V, kmax)
+    # numeric regparam: the projected problem is solved on the device from device-resident Gram data (no host round trip per
+    # iteration); the automatic selectors need the factors on the host
+    on_dev = (not isinstance(regparam, str)) and hasattr(eng, "gram_tikhonov") and hasattr(eng, "cgs_coeffs") \
+        and kmax <= eng.GRAM_TIKHONOV_MAX_K and kwargs.get("device_solve", True)
+    pb = _ProjectedBases(A, L, bv, gk.V, kmax, on_device=on_dev)
     Hs = History(eng, kwargs.get("history", True), n_iter, n, "GKS xHistory")
     Y = eng.scalars(kmax)
     H = eng.scalars(3 * kmax)
@@ -99,12 +117,17 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     lams, lam, x_dev = [], None, None
     for ii in range(n_iter):
         k = pb.V.k
-        R_A, R_L = gram_factor(pb.GA[:k, :k]), gram_factor(pb.GL[:k, :k])
-        rhs = project_rhs(R_A, pb.c[:k])
-        lam = choose_lambda(regparam, R_A, R_L, rhs, max(b2 - float(rhs @ rhs), 0.0), kwargs)
-        lams.append(lam)
-        y = tikhonov_lstsq(R_A, R_L, lam, rhs)
-        Y.set(0, y)
+        if on_dev:
+            lam = regparam
+            lams.append(lam)
+            eng.gram_tikhonov(pb.GA_d.ref(0), kmax, pb.GL_d.ref(0), kmax, pb.c_d.ref(0), k, lam, Y.ref(0))   # (:74)
+        else:
+            R_A, R_L = gram_factor(pb.GA[:k, :k]), gram_factor(pb.GL[:k, :k])
+            rhs = project_rhs(R_A, pb.c[:k])
+            lam = choose_lambda(regparam, R_A, R_L, rhs, max(b2 - float(rhs @ rhs), 0.0), kwargs)
+            lams.append(lam)
+            y = tikhonov_lstsq(R_A, R_L, lam, rhs)
+            Y.set(0, y)
         x_dev = Hs.row(ii)
         eng.gemv_n(pb.V.data, k, Y.ref(0), x_dev)                                   # x = V y (:76)
         Hs.pushed(ii)

@@ -127,6 +127,8 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     A.apply(x_cur, out=ax)
     L.apply(x_cur, out=lx)
 
+    # numeric regparam: the projected problem is solved on the device (trk_gram_tikhonov), nothing visits the host in the loop
+    on_dev = (not isinstance(regparam, str)) and hasattr(eng, "gram_tikhonov") and kwargs.get("device_solve", True)
     # the two Gram-Schmidt sweeps per iteration by Gram matrix (two passes over V instead of three / four)
     gs_gram = GramSchmidtByGram(eng, V, kmax) if (hasattr(eng, "cgs_coeffs") and kwargs.get("gram_sweeps", True)) else None
     lams, res, lam, x_dev, its = [], [], None, None, 0
@@ -147,29 +149,36 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         eng.wgram(AV.data, k, wf, bv, G.ref(0), G.ref(2 * kk), G.ref(2 * kk + k))
         eng.wgram(LV.data, k, wr, None, G.ref(kk))
         nred = 2 * kk + 2 * k
-        if need_wb2:                                                                   # ||wf*b||^2 for the discrepancy test
-            eng.mul(wf, bv, tm)
-            eng.nrm2sq(tm, G.ref(nred))
-            nred += 1
-        eng.allreduce(G, 0, nred)
-        g = G.host(0, nred)
-        R_A, R_L = gram_factor(g[:kk].reshape(k, k)), gram_factor(g[kk:2 * kk].reshape(k, k))
-        rhs_b = project_rhs(R_A, g[2 * kk:2 * kk + k])            # Q_A^T b          (:106)
-        rhs_wb = project_rhs(R_A, g[2 * kk + k:2 * kk + 2 * k])   # Q_A^T (wf*b)     (:97-99)
-        resid2 = max(float(g[-1]) - float(rhs_wb @ rhs_wb), 0.0) if need_wb2 else 0.0
-        if isinstance(regparam, str) and regparam == "l_curve":
-            lam = choose_lambda("l_curve", R_A, R_L, rhs_b, 0.0, kwargs)               # l_curve(R_A, R_L, Q_A.T@b) (:101)
+        if on_dev and k <= eng.GRAM_TIKHONOV_MAX_K:
+            # numeric regparam: y = (G_A + lam G_L)^-1 (AV wf)^T b on the device (:106; the UNWEIGHTED b, sic) — no host round trip
+            eng.allreduce(G, 0, nred)
+            lam = regparam
+            lams.append(lam)
+            eng.gram_tikhonov(G.ref(0), k, G.ref(kk), k, G.ref(2 * kk), k, lam, Y.ref(0))
         else:
-            lam = choose_lambda(regparam, R_A, R_L, rhs_wb, resid2, kwargs)
-        lams.append(lam)
-        y = tikhonov_lstsq(R_A, R_L, lam, rhs_b)
-        Y.set(0, y)
+            if need_wb2:                                                               # ||wf*b||^2 for the discrepancy test
+                eng.mul(wf, bv, tm)
+                eng.nrm2sq(tm, G.ref(nred))
+                nred += 1
+            eng.allreduce(G, 0, nred)
+            g = G.host(0, nred)
+            R_A, R_L = gram_factor(g[:kk].reshape(k, k)), gram_factor(g[kk:2 * kk].reshape(k, k))
+            rhs_b = project_rhs(R_A, g[2 * kk:2 * kk + k])            # Q_A^T b          (:106)
+            rhs_wb = project_rhs(R_A, g[2 * kk + k:2 * kk + 2 * k])   # Q_A^T (wf*b)     (:97-99)
+            resid2 = max(float(g[-1]) - float(rhs_wb @ rhs_wb), 0.0) if need_wb2 else 0.0
+            if isinstance(regparam, str) and regparam == "l_curve":
+                lam = choose_lambda("l_curve", R_A, R_L, rhs_b, 0.0, kwargs)           # l_curve(R_A, R_L, Q_A.T@b) (:101)
+            else:
+                lam = choose_lambda(regparam, R_A, R_L, rhs_wb, resid2, kwargs)
+            lams.append(lam)
+            y = tikhonov_lstsq(R_A, R_L, lam, rhs_b)
+            Y.set(0, y)
         x_dev = Hs.row(ii)
         eng.gemv_n(V.data, k, Y.ref(0), x_dev)                                        # x = V y (:107)
         Hs.pushed(ii)
         if xt is not None:
             eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
-        if ii >= R_L.shape[0]:                                                        # (:109-110)
+        if ii >= k:                                                                   # `ii >= R_L.shape[0]` (:109-110)
             break
         last = ii == n_iter - 1
         # r = A^T (wf * (A x - b)) + lam L^T (wr * (L x))                              (:114-118)
