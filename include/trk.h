@@ -159,6 +159,15 @@ int trk_group_weights(const float* d, int64_t groups, int group_len, double add,
 int trk_isotv_weights(const float* x, int N, int nt, const float* u_tail, int64_t n_tail, double eps, double q, float* out,
                       trk_stream stream);
 
+/* Fused forms of the 2-D first-difference regulariser (L from trk_deriv2d_create) for the re-weighted solvers; nothing of
+ * length 2N(N-1) is written and read back:
+ *   trk_tv_weights:  w = ((L x)^2 + eps^2)^(q/2-1)                 replaces  L @ x, then the weights of MMGKS.py:60,93
+ *   trk_tv_grad:     out = r_in + lam * L^T (w .* (L x))           replaces  MMGKS.py:116-118 (w .* (L x), L^T, r + lam*rb)
+ * w == NULL: unit weights (lam * L^T L x, the regularisation term of the GKS residual, GKS.py:81-84); r_in == NULL: 0.
+ * out must not alias x or r_in.  Products and sums are rounded as in the separate kernels. */
+int trk_tv_weights(trk_op* L, const float* x, double eps, double q, float* w, trk_stream stream);
+int trk_tv_grad(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, trk_stream stream);
+
 /* One fused CGLS vector update (CGLS.py:64-67):  step = *gamma / *delta ;
  *   x_new = x + step*p ; r = r - step*w ;  sums_dev[0] = ||x_new||^2, sums_dev[1] = ||step*p||^2
  *   (= ||x_new - x_old||^2, :76), sums_dev[2] = ||x_new - x_true||^2 if x_true != NULL (:79).

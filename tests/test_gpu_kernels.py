@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import relerr
+
 pytestmark = pytest.mark.gpu
 
 
@@ -341,3 +343,41 @@ def test_cgls_regrouped_update_kernels(n, with_xt):
     if with_xt:
         e = ((xn64 - xt.cpu().numpy()) ** 2).sum()
         assert abs(sums[2] - e) <= 1e-10 * e
+
+
+@pytest.mark.parametrize("N", [2, 3, 17, 64, 257, 520, 1030])
+@pytest.mark.parametrize("q", [1.0, 0.7, 2.0])
+def test_fused_tv_weights_and_gradient(eng, N, q):
+    """trk_tv_weights / trk_tv_grad (no L x written out) against the separate kernels they replace: L @ x -> weights
+    (MMGKS.py:60,93) bit for bit; w * (L x) -> L^T -> r + lam * rb (MMGKS.py:116-118) to fp32 rounding of the last sum;
+    and against the float64 sparse matrix of the oracle."""
+    from oracle import cpu_ref as O
+    from trips_py_amd.operators import FirstDerivative2D
+    L = FirstDerivative2D(N, engine=eng)
+    g = torch.Generator(device=eng.device).manual_seed(N)
+    x = torch.randn(N * N, device=eng.device, generator=g)
+    r = torch.randn(N * N, device=eng.device, generator=g)
+    lam, eps = 0.37, 0.1
+    lx = L.apply(x)
+    w_ref = eng.empty(L.shape[0])
+    eng.mm_weights(lx, None, eps, q, w_ref)
+    w = eng.empty(L.shape[0])
+    L.tv_weights(x, eps, q, w)
+    assert torch.equal(w, w_ref)
+    tp, rb = eng.empty(L.shape[0]), eng.empty(N * N)
+    eng.mul(w_ref, lx, tp)
+    L.apply(tp, out=rb, transpose=True)
+    want = eng.empty(N * N)
+    eng.axpby(1.0, r, lam, rb, want)
+    got = eng.empty(N * N)
+    L.tv_grad(x, w, r, lam, out=got)
+    assert relerr(got.cpu().numpy(), want.cpu().numpy()) < 3e-7
+    with pytest.raises(ValueError):
+        L.tv_grad(x, w, r, lam, out=r)                       # in place is refused
+    # unit weights, no r_in: lam * L^T L x
+    L.tv_grad(x, None, None, lam, out=got)
+    Lm = O.first_derivative_2d(N, N).astype(np.float64)
+    x64 = x.cpu().numpy().astype(np.float64)
+    assert relerr(got.cpu().numpy(), lam * (Lm.T @ (Lm @ x64))) < 2e-6
+    w64 = ((Lm @ x64) ** 2 + eps ** 2) ** (q / 2 - 1)
+    assert relerr(w.cpu().numpy(), w64) < 2e-6

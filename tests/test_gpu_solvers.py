@@ -215,3 +215,25 @@ def test_oneshot_solvers():
         x, lam = S.Arnoldi_Tikhonov(A, bb, 6, rp, **kw)
         assert lam_close([lam], [float(g[f"at_{tag}_lam"])], 5e-2) and relerr(x, g[f"at_{tag}_x"]) < (TOL if tag == "lam" else 2e-3)
     assert relerr(S.GMRES(A, g["b"], 5), g["gmres_x"]) < 1e-4
+
+
+@pytest.mark.parametrize("solver", ["GKS", "MMGKS"])
+def test_separate_tv_kernels_path_matches_the_golden_too(solver):
+    """fused_tv=False keeps L x / w * (L x) / L^T / axpby as separate launches (the path operators without trk_tv_grad
+    take); both paths meet the reference golden and agree with each other to fp32 rounding."""
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import FirstDerivative2D
+    g = load_golden("gks_blur32_lam1e-2" if solver == "GKS" else "mmgks_blur32_p2q1_lam1e-2")
+    N = int(g["N"])
+    L = FirstDerivative2D(N)
+    out = {}
+    for fused in (True, False):
+        if solver == "GKS":
+            x, info = S.GKS(blur(g), g["b"], L, int(g["projection_dim"]), int(g["n_iter"]), 1e-2, g["x_true"], fused_tv=fused)
+        else:
+            x, info = S.MMGKS(blur(g), g["b"], L, 2, 1, int(g["projection_dim"]), int(g["n_iter"]), 1e-2, g["x_true"],
+                              epsilon=0.1, fused_tv=fused)
+        assert relerr(x, g["x"]) < TOL, (fused, relerr(x, g["x"]))
+        assert np.allclose(info["Residual"], g["Residual"], rtol=2e-3)
+        out[fused] = x
+    assert relerr(out[True], out[False]) < 5e-6

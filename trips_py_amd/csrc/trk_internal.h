@@ -65,6 +65,15 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;  // lane 0 holds the wave total
 }
 
+// MM weight w = (v^2 + eps^2)^(e), e = p/2 - 1 (trips/solvers/MMGKS.py:57,93).  e == -0.5 (q = 1, the TV case) is an
+// rsqrt; e == 0 is 1.
+__device__ __forceinline__ float mm_w(float v, float eps2, float e, int special) {
+  const float t = fmaf(v, v, eps2);
+  if (special == 1) return 1.0f;
+  if (special == 2) return 1.0f / sqrtf(t);
+  return powf(t, e);
+}
+
 // Sum over a block of NT threads (NT multiple of 64).  `lds` holds NT/64 doubles.  Result valid in thread 0.
 template <int NT>
 __device__ __forceinline__ double block_sum(double v, double* lds) {

@@ -17,6 +17,8 @@ using namespace trk;
 namespace {
 
 constexpr int NT = 256;
+constexpr int RB = 4;              // image rows per thread and batch
+constexpr int kTvMaxBlocks = 4096;  // cap on the blocks (= block partials) per frame of the kernels that reduce
 
 inline int grid_for(int64_t n) {
   int64_t want = (n + NT - 1) / NT;
@@ -25,34 +27,69 @@ inline int grid_for(int64_t n) {
   return (int)(want < 1 ? 1 : want);
 }
 
-// blockIdx.y = frame / batch vector
+// The 2-D stencils run one thread per image COLUMN over batches of RB rows: every load of a batch is issued before the
+// first use (the kernels are latency-, then HBM-bound: memory-level parallelism is what fills the pipe), the vertical
+// neighbours of the batch are loaded once, row offsets are running sums (no integer division) and every load/store of a
+// wavefront is one contiguous row segment.  grid = (ceil(N/NT), row batches (grid-strided when capped), frames).
+struct Grid2 {
+  dim3 g;
+  int per_frame;  // blocks (= block partials) per frame
+};
+inline Grid2 grid2(int N, int frames, bool capped) {
+  const int gx = (N + NT - 1) / NT;
+  int gy = (N + RB - 1) / RB;
+  if (capped) {
+    const int cap = kTvMaxBlocks / gx;
+    if (gy > cap) gy = cap < 1 ? 1 : cap;
+  }
+  return {dim3(gx, gy, frames), gx * gy};
+}
+
+// blockIdx.z = frame / batch vector.  WEIGHTS: y = ((L2 x)^2 + eps2)^e instead of L2 x (k_tv_weights below).
+template <bool SUMSQ, bool WEIGHTS>
+__device__ __forceinline__ void d2_fwd_body(const float* __restrict__ x, float* __restrict__ y, int N, float eps2, float e,
+                                            int special, double& ss) {
+  float* __restrict__ yh = y;
+  float* __restrict__ yv = y + (int64_t)N * (N - 1);
+  const int j = blockIdx.x * NT + threadIdx.x;
+  if (j >= N) return;
+  const bool hr = j < N - 1;
+  for (int i0 = blockIdx.y * RB; i0 < N; i0 += gridDim.y * RB) {
+    const int64_t o0 = (int64_t)i0 * N + j;
+    const int64_t h0 = (int64_t)i0 * (N - 1) + j;
+    float xc[RB + 1], xr[RB];
+#pragma unroll
+    for (int t = 0; t <= RB; ++t) xc[t] = (i0 + t < N) ? x[o0 + (int64_t)t * N] : 0.f;
+#pragma unroll
+    for (int t = 0; t < RB; ++t) xr[t] = (hr && i0 + t < N) ? x[o0 + (int64_t)t * N + 1] : 0.f;
+#pragma unroll
+    for (int t = 0; t < RB; ++t) {
+      const int i = i0 + t;
+      if (i < N) {
+        if (hr) {
+          const float h = xc[t] - xr[t];
+          yh[h0 + (int64_t)t * (N - 1)] = WEIGHTS ? mm_w(h, eps2, e, special) : h;
+          if (SUMSQ) ss += (double)h * h;
+        }
+        if (i < N - 1) {
+          const float v = xc[t] - xc[t + 1];
+          yv[o0 + (int64_t)t * N] = WEIGHTS ? mm_w(v, eps2, e, special) : v;
+          if (SUMSQ) ss += (double)v * v;
+        }
+      }
+    }
+  }
+}
+
 template <bool SUMSQ>
 __global__ __launch_bounds__(NT) void k_d2_fwd(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
                                                int64_t ldy, int N, double* __restrict__ partials) {
   __shared__ double red[NT / 64];
-  x += (int64_t)blockIdx.y * ldx;
-  y += (int64_t)blockIdx.y * ldy;
-  const int64_t npix = (int64_t)N * N;
-  float* __restrict__ yh = y;
-  float* __restrict__ yv = y + (int64_t)N * (N - 1);
   double ss = 0.0;
-  for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < npix; idx += (int64_t)gridDim.x * NT) {
-    const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
-    const float c = x[idx];
-    if (j < N - 1) {
-      const float h = c - x[idx + 1];
-      yh[(int64_t)i * (N - 1) + j] = h;
-      if (SUMSQ) ss += (double)h * h;
-    }
-    if (i < N - 1) {
-      const float v = c - x[idx + N];
-      yv[idx] = v;
-      if (SUMSQ) ss += (double)v * v;
-    }
-  }
+  d2_fwd_body<SUMSQ, false>(x + (int64_t)blockIdx.z * ldx, y + (int64_t)blockIdx.z * ldy, N, 0.f, 0.f, 0, ss);
   if (SUMSQ) {
     ss = block_sum<NT>(ss, red);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ss;
+    if (threadIdx.x == 0) partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = ss;
   }
 }
 
@@ -63,39 +100,122 @@ __global__ __launch_bounds__(NT) void k_d2_adj(const float* __restrict__ y, int6
                                                const float* __restrict__ tprev, int first_has_prev, int last_has_cur,
                                                const float* __restrict__ halo_prev, double* __restrict__ partials) {
   __shared__ double red[NT / 64];
-  const int f = blockIdx.y, nf = gridDim.y;
+  const int f = blockIdx.z, nf = gridDim.z;
   y += (int64_t)f * ldy;
   out += (int64_t)f * ldo;
-  const int64_t npix = (int64_t)N * N;
   const float* __restrict__ yh = y;
   const float* __restrict__ yv = y + (int64_t)N * (N - 1);
   // temporal rows: row t = x_t - x_{t+1};  (L^T y)_t += T_t (if row t exists) - T_{t-1} (if row t-1 exists)
-  const float* tc = nullptr;
-  const float* tp = nullptr;
+  const float* __restrict__ tc = nullptr;
+  const float* __restrict__ tp = nullptr;
   if (TEMPORAL) {
     if (f < nf - 1 || last_has_cur) tc = tcur + (int64_t)f * ldt;
     if (f > 0) tp = tprev + (int64_t)(f - 1) * ldt;
     else if (first_has_prev) tp = halo_prev;
   }
+  const int j = blockIdx.x * NT + threadIdx.x;
   double ss = 0.0;
-  for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < npix; idx += (int64_t)gridDim.x * NT) {
-    const int i = (int)(idx / N), j = (int)(idx - (int64_t)i * N);
-    float acc = 0.f;
-    const int64_t hb = (int64_t)i * (N - 1) + j;
-    if (j < N - 1) acc += yh[hb];
-    if (j > 0) acc -= yh[hb - 1];
-    if (i < N - 1) acc += yv[idx];
-    if (i > 0) acc -= yv[idx - N];
-    if (TEMPORAL) {
-      if (tc) acc += tc[idx];
-      if (tp) acc -= tp[idx];
+  if (j < N) {
+    const bool hr = j < N - 1, hl = j > 0;
+    for (int i0 = blockIdx.y * RB; i0 < N; i0 += gridDim.y * RB) {
+      const int64_t o0 = (int64_t)i0 * N + j;
+      const int64_t h0 = (int64_t)i0 * (N - 1) + j;
+      float hc[RB], hp[RB], v[RB + 1], a[RB], b[RB];
+#pragma unroll
+      for (int t = 0; t <= RB; ++t) {      // v[t] = yv[i0 + t - 1][j]
+        const int i = i0 + t - 1;
+        v[t] = (i >= 0 && i < N - 1) ? yv[o0 + (int64_t)(t - 1) * N] : 0.f;
+      }
+#pragma unroll
+      for (int t = 0; t < RB; ++t) {
+        const bool in = i0 + t < N;
+        hc[t] = (in && hr) ? yh[h0 + (int64_t)t * (N - 1)] : 0.f;
+        hp[t] = (in && hl) ? yh[h0 + (int64_t)t * (N - 1) - 1] : 0.f;
+        if (TEMPORAL) {
+          a[t] = (in && tc) ? tc[o0 + (int64_t)t * N] : 0.f;
+          b[t] = (in && tp) ? tp[o0 + (int64_t)t * N] : 0.f;
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < RB; ++t) {
+        const int i = i0 + t;
+        if (i < N) {
+          float acc = 0.f;
+          if (hr) acc += hc[t];
+          if (hl) acc -= hp[t];
+          if (i < N - 1) acc += v[t + 1];
+          if (i > 0) acc -= v[t];
+          if (TEMPORAL) {
+            if (tc) acc += a[t];
+            if (tp) acc -= b[t];
+          }
+          out[o0 + (int64_t)t * N] = acc;
+          if (SUMSQ) ss += (double)acc * acc;
+        }
+      }
     }
-    out[idx] = acc;
-    if (SUMSQ) ss += (double)acc * acc;
   }
   if (SUMSQ) {
     ss = block_sum<NT>(ss, red);
-    if (threadIdx.x == 0) partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = ss;
+    if (threadIdx.x == 0) partials[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = ss;
+  }
+}
+
+// Fused forms for the re-weighted (MM) solvers, nothing of length 2N(N-1) is written or read twice:
+//   k_tv_weights:  w = ((L2 x)^2 + eps^2)^(q/2-1)                      (MMGKS.py:60,93)      4n read, 8n written
+//   k_tv_grad:     out = r_in + lam * L2^T (w .* (L2 x))               (MMGKS.py:116-118)    x, w, r_in read: 16n, 4n written
+// (W = false: unit weights, out = r_in + lam * L2^T L2 x, the GKS residual term GKS.py:81-84.)
+__global__ __launch_bounds__(NT) void k_tv_weights(const float* __restrict__ x, int N, float eps2, float e, int special,
+                                                   float* __restrict__ w) {
+  double unused = 0.0;
+  d2_fwd_body<false, true>(x, w, N, eps2, e, special, unused);
+}
+
+template <bool W, bool RIN>
+__global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, const float* __restrict__ w,
+                                                const float* __restrict__ rin, float lam, float* __restrict__ out, int N) {
+  const float* __restrict__ wh = w;
+  const float* __restrict__ wv = w + (int64_t)N * (N - 1);
+  const int j = blockIdx.x * NT + threadIdx.x;
+  if (j >= N) return;
+  const bool hr = j < N - 1, hl = j > 0;
+  for (int i0 = blockIdx.y * RB; i0 < N; i0 += gridDim.y * RB) {
+    const int64_t o0 = (int64_t)i0 * N + j;
+    const int64_t h0 = (int64_t)i0 * (N - 1) + j;
+    float xc[RB + 2], xl[RB], xr[RB], wc[RB], wp[RB], v[RB + 1], rr[RB];
+#pragma unroll
+    for (int t = 0; t < RB + 2; ++t) {   // xc[t] = x[i0 + t - 1][j]
+      const int i = i0 + t - 1;
+      xc[t] = (i >= 0 && i < N) ? x[o0 + (int64_t)(t - 1) * N] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t <= RB; ++t) {      // v[t] = wv[i0 + t - 1][j]
+      const int i = i0 + t - 1;
+      v[t] = W ? ((i >= 0 && i < N - 1) ? wv[o0 + (int64_t)(t - 1) * N] : 0.f) : 1.f;
+    }
+#pragma unroll
+    for (int t = 0; t < RB; ++t) {
+      const bool in = i0 + t < N;
+      const int64_t o = o0 + (int64_t)t * N, hb = h0 + (int64_t)t * (N - 1);
+      xr[t] = (in && hr) ? x[o + 1] : 0.f;
+      xl[t] = (in && hl) ? x[o - 1] : 0.f;
+      wc[t] = W ? ((in && hr) ? wh[hb] : 0.f) : 1.f;
+      wp[t] = W ? ((in && hl) ? wh[hb - 1] : 0.f) : 1.f;
+      rr[t] = (RIN && in) ? rin[o] : 0.f;
+    }
+#pragma unroll
+    for (int t = 0; t < RB; ++t) {
+      const int i = i0 + t;
+      if (i < N) {
+        const float c = xc[t + 1];
+        float acc = 0.f;
+        if (hr) acc += __fmul_rn(wc[t], c - xr[t]);
+        if (hl) acc -= __fmul_rn(wp[t], xl[t] - c);
+        if (i < N - 1) acc += __fmul_rn(v[t + 1], c - xc[t + 2]);
+        if (i > 0) acc -= __fmul_rn(v[t], xc[t] - c);
+        out[o0 + (int64_t)t * N] = RIN ? rr[t] + lam * acc : lam * acc;
+      }
+    }
   }
 }
 
@@ -129,11 +249,12 @@ struct D2Impl {
 int d2_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
              hipStream_t s) {
   const int N = static_cast<D2Impl*>(op->impl)->N;
-  const int gx = grid_for((int64_t)N * N);
+  const Grid2 g2 = grid2(N, batch, sumsq != nullptr);
+  const int gx = g2.per_frame;
   double* part = nullptr;
   if (sumsq)
     if (int rc = scratch_doubles(s, (size_t)gx * batch, &part)) return rc;
-  dim3 grid(gx, batch);
+  const dim3 grid = g2.g;
   if (!tr) {
     if (sumsq) hipLaunchKernelGGL((k_d2_fwd<true>), grid, dim3(NT), 0, s, x, ldx, y, ldy, N, part);
     else hipLaunchKernelGGL((k_d2_fwd<false>), grid, dim3(NT), 0, s, x, ldx, y, ldy, N, part);
@@ -163,10 +284,12 @@ int st_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t 
   const int ntemp = nt - 1 + (im->has_next ? 1 : 0);
   if (im->has_next && !tr && !im->halo_next) return fail(TRK_EINVAL, "spacetime forward: halo of the next rank not set");
   if (im->has_prev && tr && !im->halo_prev) return fail(TRK_EINVAL, "spacetime transpose: halo of the previous rank not set");
-  const int gx = grid_for(npix);
+  const int gt = grid_for(npix);        // temporal rows: flat streaming kernel
+  const Grid2 gs = grid2(N, nt, sumsq != nullptr);  // spatial rows: column batches, blockIdx.z = frame
+  const int gsp = gs.per_frame;
   double* part = nullptr;
-  // block partials per vector: forward = spatial (gx*nt) + temporal (gx*ntemp) ; transpose = gx*nt
-  const int per_vec = tr ? gx * nt : gx * nt + gx * (ntemp > 0 ? ntemp : 0);
+  // block partials per vector: forward = spatial (gsp*nt) + temporal (gt*ntemp) ; transpose = gsp*nt
+  const int per_vec = tr ? gsp * nt : gsp * nt + gt * (ntemp > 0 ? ntemp : 0);
   if (sumsq)
     if (int rc = scratch_doubles(s, (size_t)per_vec * batch, &part)) return rc;
   for (int b = 0; b < batch; ++b) {
@@ -174,20 +297,18 @@ int st_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t 
     float* yb = y + (int64_t)b * ldy;
     double* pb = part ? part + (size_t)b * per_vec : nullptr;
     if (!tr) {
-      dim3 g1(gx, nt);
-      if (sumsq) hipLaunchKernelGGL((k_d2_fwd<true>), g1, dim3(NT), 0, s, xb, npix, yb, ps, N, pb);
-      else hipLaunchKernelGGL((k_d2_fwd<false>), g1, dim3(NT), 0, s, xb, npix, yb, ps, N, pb);
+      if (sumsq) hipLaunchKernelGGL((k_d2_fwd<true>), gs.g, dim3(NT), 0, s, xb, npix, yb, ps, N, pb);
+      else hipLaunchKernelGGL((k_d2_fwd<false>), gs.g, dim3(NT), 0, s, xb, npix, yb, ps, N, pb);
       if (ntemp > 0) {
-        dim3 g2(gx, ntemp);
+        dim3 g2(gt, ntemp);
         float* T = yb + (int64_t)nt * ps;
-        if (sumsq) hipLaunchKernelGGL((k_time_fwd<true>), g2, dim3(NT), 0, s, xb, T, npix, nt, im->halo_next, pb + (size_t)gx * nt);
+        if (sumsq) hipLaunchKernelGGL((k_time_fwd<true>), g2, dim3(NT), 0, s, xb, T, npix, nt, im->halo_next, pb + (size_t)gsp * nt);
         else hipLaunchKernelGGL((k_time_fwd<false>), g2, dim3(NT), 0, s, xb, T, npix, nt, im->halo_next, pb);
       }
     } else {
-      dim3 g1(gx, nt);
       const float* T = xb + (int64_t)nt * ps;
-      if (sumsq) hipLaunchKernelGGL((k_d2_adj<true, true>), g1, dim3(NT), 0, s, xb, ps, yb, npix, N, T, npix, T, im->has_prev, im->has_next, im->halo_prev, pb);
-      else hipLaunchKernelGGL((k_d2_adj<false, true>), g1, dim3(NT), 0, s, xb, ps, yb, npix, N, T, npix, T, im->has_prev, im->has_next, im->halo_prev, pb);
+      if (sumsq) hipLaunchKernelGGL((k_d2_adj<true, true>), gs.g, dim3(NT), 0, s, xb, ps, yb, npix, N, T, npix, T, im->has_prev, im->has_next, im->halo_prev, pb);
+      else hipLaunchKernelGGL((k_d2_adj<false, true>), gs.g, dim3(NT), 0, s, xb, ps, yb, npix, N, T, npix, T, im->has_prev, im->has_next, im->halo_prev, pb);
     }
     TRK_LAUNCH_CHECK();
   }
@@ -214,6 +335,32 @@ int trk_spacetime_create(int N, int nt_local, int has_next, int has_prev, trk_op
   const int64_t npix = (int64_t)N * N, ps = 2 * (int64_t)N * (N - 1);
   const int ntemp = nt_local - 1 + (has_next ? 1 : 0);
   *out = new trk_op{4, (int64_t)nt_local * ps + (int64_t)ntemp * npix, (int64_t)nt_local * npix, im, st_apply, st_destroy, nullptr, 0};
+  return TRK_OK;
+}
+
+int trk_tv_weights(trk_op* L, const float* x, double eps, double q, float* w, trk_stream st) {
+  TRK_REQUIRE(L && x && w, "trk_tv_weights: NULL argument");
+  TRK_REQUIRE(L->kind == 3, "trk_tv_weights: L must come from trk_deriv2d_create");
+  const int N = static_cast<D2Impl*>(L->impl)->N;
+  const float e = (float)(q / 2.0 - 1.0), eps2 = (float)(eps * eps);
+  const int special = (q == 2.0) ? 1 : (q == 1.0) ? 2 : 0;
+  hipLaunchKernelGGL(k_tv_weights, grid2(N, 1, false).g, dim3(NT), 0, (hipStream_t)st, x, N, eps2, e, special, w);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_tv_grad(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, trk_stream st) {
+  TRK_REQUIRE(L && x && out, "trk_tv_grad: NULL argument");
+  TRK_REQUIRE(L->kind == 3, "trk_tv_grad: L must come from trk_deriv2d_create");
+  TRK_REQUIRE(out != x && out != r_in, "trk_tv_grad: out must not alias x or r_in");
+  const int N = static_cast<D2Impl*>(L->impl)->N;
+  const dim3 g = grid2(N, 1, false).g;
+  hipStream_t s = (hipStream_t)st;
+#define TG(W, R) hipLaunchKernelGGL((k_tv_grad<W, R>), g, dim3(NT), 0, s, x, w, r_in, (float)lam, out, N)
+  if (w) { if (r_in) TG(true, true); else TG(true, false); }
+  else   { if (r_in) TG(false, true); else TG(false, false); }
+#undef TG
+  TRK_LAUNCH_CHECK();
   return TRK_OK;
 }
 

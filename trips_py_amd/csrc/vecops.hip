@@ -159,14 +159,6 @@ __global__ __launch_bounds__(NT) void k_mul_diff(int64_t n, const float* w, cons
   for (int64_t i = tail0 + tid; i < n; i += nth) out[i] = w[i] * (x[i] - y[i]);
 }
 
-// w = (v^2 + eps^2)^(e), e = p/2 - 1.  e == -0.5 (q = 1, the TV case) is an rsqrt; e == 0 is 1.
-__device__ __forceinline__ float mm_w(float v, float eps2, float e, int special) {
-  const float t = fmaf(v, v, eps2);
-  if (special == 1) return 1.0f;
-  if (special == 2) return 1.0f / sqrtf(t);
-  return powf(t, e);
-}
-
 template <bool HAS_Y, bool VEC>
 __global__ __launch_bounds__(NT) void k_mm_weights(int64_t n, const float* x, const float* y, float eps2, float e,
                                                    int special, float* out) {

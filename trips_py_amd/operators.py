@@ -250,6 +250,19 @@ class FirstDerivative2D(_HandleOperator):
         super().__init__(h, engine)
         self.streaming = True
 
+    # fused forms for the re-weighted solvers (trk_tv_weights / trk_tv_grad): no vector of length 2N(N-1) in between
+    def tv_weights(self, x, eps, q, out):
+        """out = ((L x)^2 + eps^2)^(q/2-1) (MMGKS.py:60,93)."""
+        _lib.check(self.engine.lib.trk_tv_weights(self._h, x.data_ptr(), float(eps), float(q), out.data_ptr(),
+                                                  self.engine.stream()), "trk_tv_weights")
+
+    def tv_grad(self, x, w, r_in, lam, out):
+        """out = r_in + lam * L^T (w .* (L x)) (MMGKS.py:116-118); w None: unit weights (GKS.py:81-84); r_in None: 0."""
+        rc = self.engine.lib.trk_tv_grad(self._h, x.data_ptr(), None if w is None else w.data_ptr(),
+                                         None if r_in is None else r_in.data_ptr(), float(lam), out.data_ptr(),
+                                         self.engine.stream())
+        _lib.check(rc, "trk_tv_grad")
+
 
 class SpaceTimeDerivative(_HandleOperator):
     """Space-time first differences over this rank's `nt_local` frames.  With a sharded time axis the engine's

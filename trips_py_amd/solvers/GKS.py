@@ -113,6 +113,7 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     b2 = float(E.host(1, 2)[0])
 
     dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
+    fusedL = dL and hasattr(L, "tv_grad") and kwargs.get("fused_tv", True)
     gs_gram = GramSchmidtByGram(eng, pb.V, kmax) if (hasattr(eng, "cgs_coeffs") and kwargs.get("gram_sweeps", True)) else None
     lams, lam, x_dev = [], None, None
     for ii in range(n_iter):
@@ -141,12 +142,16 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         else:
             eng.gemv_n(pb.AV.data, k, Y.ref(0), tm, a=-1.0, base=bv, s=1.0)
         A.apply(tm, out=r, transpose=True)
-        if dL:
-            L.apply(x_dev, out=tp)
+        if fusedL:
+            L.tv_grad(x_dev, None, r, float(lam), out=rb)                            # r + lam L^T L x in one stencil pass
+            r, rb = rb, r
         else:
-            eng.gemv_n(pb.LV.data, k, Y.ref(0), tp)
-        L.apply(tp, out=rb, transpose=True)
-        eng.axpby(1.0, r, float(lam), rb, r)
+            if dL:
+                L.apply(x_dev, out=tp)
+            else:
+                eng.gemv_n(pb.LV.data, k, Y.ref(0), tp)
+            L.apply(tp, out=rb, transpose=True)
+            eng.axpby(1.0, r, float(lam), rb, r)
         vn = pb.V.next_slot()
         if gs_gram is not None:
             gs_gram.sweep(k, r, 3, vn, sumsq=R.ref(ii))                              # (:86-88) three sweeps, ||r||^2 fused

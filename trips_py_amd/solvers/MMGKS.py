@@ -124,8 +124,11 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     # (AV) y and (LV) y, :114-116) and in the weights of the next (A @ x, L @ x, :56,:60).  A stencil operator forms them
     # once, directly — 8n-12n bytes instead of reading k basis vectors; others keep the basis products.
     dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
+    # the 2-D first-difference L has fused forms (trk_tv_weights / trk_tv_grad): L x is never written out
+    fusedL = dL and hasattr(L, "tv_grad") and not iso and not gs and kwargs.get("fused_tv", True)
     A.apply(x_cur, out=ax)
-    L.apply(x_cur, out=lx)
+    if not fusedL:
+        L.apply(x_cur, out=lx)
 
     # numeric regparam: the projected problem is solved on the device (trk_gram_tikhonov), nothing visits the host in the loop
     on_dev = (not isinstance(regparam, str)) and hasattr(eng, "gram_tikhonov") and kwargs.get("device_solve", True)
@@ -143,6 +146,8 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         elif gs:
             gs_op.apply(x_cur if x_dev is None else x_dev, out=gs_d)
             eng.group_weights(gs_d, gs_rows, gs_nt_x, float(np.exp(2)), qnorm / 2 - 1, gs_nt_x, wr)   # exp(2): sic (:87)
+        elif fusedL:
+            L.tv_weights(x_cur if x_dev is None else x_dev, epsilon, qnorm, wr)
         else:
             eng.mm_weights(lx, None, epsilon, qnorm, wr)
         # weighted Gram matrices and projected right-hand sides
@@ -192,17 +197,21 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
                 A.apply(x_dev, out=ax)                                                # for the next weights (:56)
         eng.mul_diff(wf, res_a, bv, tm)
         A.apply(tm, out=r, transpose=True)
-        if dL:
-            L.apply(x_dev, out=lx)
-            res_l = lx
+        if fusedL:
+            L.tv_grad(x_dev, wr, r, float(lam), out=rb)                               # r + lam L^T (wr * (L x)), one pass
+            r, rb = rb, r
         else:
-            eng.gemv_n(LV.data, k, Y.ref(0), tp)
-            res_l = tp
-            if not last:
-                L.apply(x_dev, out=lx)                                                # for the next weights (:60)
-        eng.mul(wr, res_l, tp)
-        L.apply(tp, out=rb, transpose=True)
-        eng.axpby(1.0, r, float(lam), rb, r)
+            if dL:
+                L.apply(x_dev, out=lx)
+                res_l = lx
+            else:
+                eng.gemv_n(LV.data, k, Y.ref(0), tp)
+                res_l = tp
+                if not last:
+                    L.apply(x_dev, out=lx)                                            # for the next weights (:60)
+            eng.mul(wr, res_l, tp)
+            L.apply(tp, out=rb, transpose=True)
+            eng.axpby(1.0, r, float(lam), rb, r)
         vn = V.next_slot()
         if gs_gram is not None:
             gs_gram.sweep(k, r, 2, vn, sumsq=Rn.ref(ii))                              # (:119-120) two sweeps, ||r||^2 fused
