@@ -168,6 +168,32 @@ int trk_isotv_weights(const float* x, int N, int nt, const float* u_tail, int64_
 int trk_tv_weights(trk_op* L, const float* x, double eps, double q, float* w, trk_stream stream);
 int trk_tv_grad(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, trk_stream stream);
 
+/* One Golub-Kahan half step in the operator's own output pass (decompositions.py:240-252: v = A^T u - beta v_old, u = A v -
+ * alpha u_old, their norms):   out = a * Op(x) + b * z ,  *sumsq = ||out||^2 (if sumsq != NULL)
+ * with the coefficients of trk_axpby (a = ca * [sqrt] *a_num / [sqrt] *a_den, NULL pointers = 1; z = NULL: out = a * Op(x)).
+ * Operators with a native form (trk_op_axpby_caps: the Radon projector — the band reduction of the forward and the tile
+ * gather of the adjoint carry the epilogue and leave the norm as block partials) need no vector kernel; for every other
+ * operator this is trk_op_apply into `out` followed by trk_axpby in place: same result, any operator.
+ * out must not alias x or z.  hints (0 is always right):
+ *   TRK_HINT_OUT_FEEDS_OPPOSITE  the caller promises that the NEXT apply of this operator is the opposite direction, takes
+ *                                `out` as its input, and that `out` is not modified in between: the operator may leave behind
+ *                                what that apply derives from its input first (the adjoint's detector records, the forward's
+ *                                transposed image copy);
+ *   TRK_HINT_INPUT_FROM_OPPOSITE x is such an `out`, unmodified: what was left behind may be used (checked against x);
+ *   TRK_HINT_SUMSQ_DEFERRED      *sumsq may stay unfinished (block partials inside the operator) until the next
+ *                                trk_op_apply_axpby of this operator that carries TRK_HINT_INPUT_FROM_OPPOSITE — whose kernel
+ *                                adds the partials for its own coefficients and stores the finished value — or until
+ *                                trk_op_flush; every other call on the operator finishes it first.  The caller promises
+ *                                not to read *sumsq (host or device) before one of these. */
+#define TRK_HINT_OUT_FEEDS_OPPOSITE 1
+#define TRK_HINT_INPUT_FROM_OPPOSITE 2
+#define TRK_HINT_SUMSQ_DEFERRED 4
+int trk_op_flush(trk_op* op, trk_stream stream);
+int trk_op_axpby_caps(const trk_op* op, int* native);
+int trk_op_apply_axpby(trk_op* op, int transpose, const float* x, double ca, const double* a_num, const double* a_den,
+                       int a_flags, double cb, const double* b_num, const double* b_den, int b_flags, const float* z,
+                       float* out, double* sumsq, int hints, trk_stream stream);
+
 /* One fused CGLS vector update (CGLS.py:64-67):  step = *gamma / *delta ;
  *   x_new = x + step*p ; r = r - step*w ;  sums_dev[0] = ||x_new||^2, sums_dev[1] = ||step*p||^2
  *   (= ||x_new - x_old||^2, :76), sums_dev[2] = ||x_new - x_true||^2 if x_true != NULL (:79).

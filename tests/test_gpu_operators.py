@@ -285,3 +285,135 @@ def test_fanbeam_invariants_and_problem_class():
     np.random.seed(2)
     bm, delta = T.add_noise(b, "Gaussian", 0.01)
     assert bm.shape == (p, q) and np.isclose(delta / np.linalg.norm(b), 0.01)
+
+
+def _radon_case(name):
+    from trips_py_amd.operators import BlockDiagOp, Radon2DParallel
+    if name == "static64":          # 16 x 16 tiles, records from the pre-pass (180 angles), 4 row bands? (N = 64: one band)
+        return Radon2DParallel(64, np.linspace(0, np.pi, 40, endpoint=False))
+    if name == "static512":         # BASELINE C3 shape: banded forward, 16 x 16 tiles, record pre-pass
+        return Radon2DParallel(512, np.linspace(0, np.pi, 180, endpoint=False))
+    if name == "static1030":        # shared-window forward kernel (N >= 1024), 32 x 32 tiles
+        return Radon2DParallel(1030, np.linspace(0, np.pi, 36, endpoint=False), n_det=1100)
+    if name == "dynamic":           # BASELINE C5 structure: frames in one handle, 15 angles per frame (records made in the tile kernel)
+        return BlockDiagOp([Radon2DParallel(128, np.deg2rad(3.0 * t + 12.0 * np.arange(15))) for t in range(6)])
+    if name == "tiny":              # N < 16: no tiled adjoint -> apply + axpby inside the C entry point
+        return Radon2DParallel(12, np.linspace(0, np.pi, 7, endpoint=False))
+    raise KeyError(name)
+
+
+@pytest.mark.parametrize("case", ["static64", "static512", "static1030", "dynamic", "tiny"])
+def test_radon_fused_half_step_equals_apply_then_axpby(case):
+    """trk_op_apply_axpby (out = a Op(x) + b z and ||out||^2 in the projector's own output pass: band reduction of the
+    forward, tile gather of the adjoint; norm finished by the last workgroup) against trk_op_apply + trk_axpby, both
+    directions, device-scalar coefficients as Golub-Kahan uses them, with and without z; then the hinted chain
+    forward -> adjoint -> forward (records / transposed image left behind by the producing apply) against the plain one."""
+    from trips_py_amd.engine import Coef
+    A = _radon_case(case)
+    eng = A.engine
+    assert A.native_axpby
+    m, n = A.shape
+    g = torch.Generator(device=eng.device).manual_seed(11)
+    x, zx = torch.rand(n, device=eng.device, generator=g), torch.randn(n, device=eng.device, generator=g)
+    y, zy = torch.randn(m, device=eng.device, generator=g), torch.randn(m, device=eng.device, generator=g)
+    S = eng.scalars(8)
+    S.set(0, np.array([3.7, 0.61, 0, 0, 0, 0, 0, 0]))
+    ca, cb = Coef(1.0, den=S.ref(0), sqrt_den=True), Coef(-1.0, num=S.ref(0), den=S.ref(1), sqrt_num=True, sqrt_den=True)
+    for tr, xin, z in ((False, x, zy), (True, y, zx)):
+        nout = n if tr else m
+        t, want, got = eng.empty(nout), eng.empty(nout), eng.empty(nout)
+        A.apply(xin, out=t, transpose=tr)
+        for zz, bb in ((z, cb), (None, 0.0)):
+            eng.axpby(ca, t, bb, zz, want, sumsq=S.ref(2))
+            A.apply_axpby(xin, ca, bb, zz, got, transpose=tr, sumsq=S.ref(3))
+            assert torch.equal(got, want), (tr, zz is None)
+            s = S.host(2, 4)
+            assert abs(s[0] - s[1]) <= 1e-12 * s[0]
+            A.apply_axpby(xin, ca, bb, zz, got, transpose=tr, sumsq=S.ref(4))      # run to run: the same bits
+            assert S.host(4, 5)[0] == s[1]
+    # chain with hints: u1 = A x ; v1 = A^T u1 (records from the forward) ; u2 = A v1 (transposed copy from the adjoint)
+    F, T = A.OUT_FEEDS_OPPOSITE, A.INPUT_FROM_OPPOSITE
+    u1, v1, u2 = eng.empty(m), eng.empty(n), eng.empty(m)
+    A.apply_axpby(x, ca, cb, zy, u1, sumsq=S.ref(5), hints=F)
+    A.apply_axpby(u1, ca, cb, zx, v1, transpose=True, sumsq=S.ref(6), hints=F | T)
+    A.apply_axpby(v1, ca, cb, zy, u2, sumsq=S.ref(7), hints=F | T)
+    hinted = S.host(5, 8).copy()
+    u1p, v1p, u2p = eng.empty(m), eng.empty(n), eng.empty(m)
+    A.apply_axpby(x, ca, cb, zy, u1p, sumsq=S.ref(5))
+    A.apply_axpby(u1p, ca, cb, zx, v1p, transpose=True, sumsq=S.ref(6))
+    A.apply_axpby(v1p, ca, cb, zy, u2p, sumsq=S.ref(7))
+    assert torch.equal(u1, u1p) and torch.equal(v1, v1p) and torch.equal(u2, u2p)
+    assert np.array_equal(hinted, S.host(5, 8))
+    # an apply in between takes the side buffers: the promise of the hint is void and the consumer re-derives them
+    A.apply_axpby(x, ca, cb, zy, u1, hints=F)
+    other = A.apply(zy, transpose=True)
+    A.apply_axpby(u1, ca, cb, zx, v1, transpose=True, hints=T)
+    assert torch.equal(v1, v1p) and other.shape[0] == n
+    A.apply_axpby(u1, ca, cb, zx, v1, transpose=True, hints=F)
+    A.apply(x)
+    A.apply_axpby(v1, ca, cb, zy, u2, hints=T)
+    assert torch.equal(u2, u2p)
+
+
+@pytest.mark.parametrize("case", ["static64", "static512", "dynamic"])
+def test_radon_deferred_norm_is_finished_by_the_next_chained_apply_or_flush(case):
+    """TRK_HINT_SUMSQ_DEFERRED: the norm of a fused apply stays block partials inside the operator; the next chained apply
+    adds them for its own coefficients and stores the finished scalar; trk_op_flush or any other call on the operator
+    finishes it too.  Same vectors as the undeferred chain (the scalar to fp64 rounding: another summation order)."""
+    from trips_py_amd.engine import Coef
+    A = _radon_case(case)
+    eng = A.engine
+    m, n = A.shape
+    g = torch.Generator(device=eng.device).manual_seed(5)
+    u0, v0 = torch.randn(m, device=eng.device, generator=g), torch.randn(n, device=eng.device, generator=g)
+    F, T, D = A.OUT_FEEDS_OPPOSITE, A.INPUT_FROM_OPPOSITE, A.SUMSQ_DEFERRED
+
+    def chain(defer):
+        S = eng.scalars(4)
+        S.set(0, np.array([2.5, -1.0, -1.0, -1.0]))
+        v1, u1, v2 = eng.empty(n), eng.empty(m), eng.empty(n)
+        d = D if defer else 0
+        # v1 = A^T u0 / sqrt(S0) - v0 ; S1 = |v1|^2     (deferred)
+        A.apply_axpby(u0, Coef(1.0, den=S.ref(0), sqrt_den=True), -1.0, v0, v1, transpose=True, sumsq=S.ref(1), hints=F | d)
+        # u1 = A v1 / sqrt(S1) - sqrt(S1)/sqrt(S0) u0 ; S2 = |u1|^2   (reads S1: from the partials when deferred)
+        A.apply_axpby(v1, Coef(1.0, den=S.ref(1), sqrt_den=True), Coef(-1.0, num=S.ref(1), den=S.ref(0), sqrt_num=True, sqrt_den=True),
+                      u0, u1, sumsq=S.ref(2), hints=F | T | d)
+        # v2 = A^T u1 / sqrt(S2) - sqrt(S2)/sqrt(S1) v1 ; S3
+        A.apply_axpby(u1, Coef(1.0, den=S.ref(2), sqrt_den=True), Coef(-1.0, num=S.ref(2), den=S.ref(1), sqrt_num=True, sqrt_den=True),
+                      v1, v2, transpose=True, sumsq=S.ref(3), hints=F | T | d)
+        if defer:
+            A.flush_deferred()
+        return S.host(0, 4), v1, u1, v2
+
+    s_ref, v1r, u1r, v2r = chain(False)
+    s_def, v1d, u1d, v2d = chain(True)
+    assert np.all(s_def > 0) and np.allclose(s_def, s_ref, rtol=1e-12)
+    assert torch.equal(v1d, v1r)
+    for a, b in ((u1d, u1r), (v2d, v2r)):
+        assert float(torch.linalg.norm(a - b) / torch.linalg.norm(b)) < 1e-6
+    # a plain apply on the operator finishes a pending norm as well
+    S = eng.scalars(2)
+    S.set(0, np.array([-1.0, -1.0]))
+    t = eng.empty(n)
+    A.apply_axpby(u0, 1.0, 0.0, None, t, transpose=True, sumsq=S.ref(0), hints=D)
+    A.apply(v0)
+    assert abs(S.host(0, 1)[0] - float(torch.sum(t.double() ** 2))) <= 1e-6 * S.host(0, 1)[0]
+
+
+def test_half_step_entry_point_serves_any_operator():
+    """Operators without a native form: trk_op_apply_axpby = apply into `out` + trk_axpby in place."""
+    from trips_py_amd.engine import Coef
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import gauss_psf
+    A = Blur2D(gauss_psf((7, 7), (2, 2))[0], 50, 70)
+    eng = A.engine
+    assert not A.native_axpby
+    x, z = torch.rand(3500, device=eng.device), torch.rand(3500, device=eng.device)
+    S = eng.scalars(3)
+    S.set(0, np.array([2.0, 0, 0]))
+    want, got = eng.empty(3500), eng.empty(3500)
+    eng.axpby(Coef(1.0, den=S.ref(0)), A.apply(x, transpose=True), -0.25, z, want, sumsq=S.ref(1))
+    A.apply_axpby(x, Coef(1.0, den=S.ref(0)), -0.25, z, got, transpose=True, sumsq=S.ref(2))
+    assert torch.equal(got, want) and S.host(1, 2)[0] == S.host(2, 3)[0]
+    with pytest.raises(ValueError):
+        A.apply_axpby(x, 1.0, 1.0, z, x)

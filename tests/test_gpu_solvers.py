@@ -3,6 +3,7 @@ Bars: fixed lambda -> final x <= 1e-5 relative (north_star); automatic lambda (g
 because the selectors' minima are flat (SURVEY §7 hard part 1: the reference itself moves 3e-3 between fp32 and fp64)."""
 import numpy as np
 import pytest
+import torch
 
 from conftest import load_golden, relerr
 from test_oracle_golden import lam_close
@@ -237,3 +238,27 @@ def test_separate_tv_kernels_path_matches_the_golden_too(solver):
         assert np.allclose(info["Residual"], g["Residual"], rtol=2e-3)
         out[fused] = x
     assert relerr(out[True], out[False]) < 5e-6
+
+
+@pytest.mark.parametrize("N,na", [(64, 30), (512, 180)])
+def test_golub_kahan_fused_half_steps_equal_the_separate_kernels(N, na):
+    """GKState on the Radon projector: the three-launch step (forward, band reduction with epilogue + records, tile gather
+    with epilogue + transposed copy) against apply / axpby / reduce as separate launches: same U, V, alpha, beta."""
+    from trips_py_amd.krylov import GKState
+    from trips_py_amd.operators import Radon2DParallel
+    A = Radon2DParallel(N, np.linspace(0, np.pi, na, endpoint=False))
+    b = A.apply(torch.rand(N * N, device=A.engine.device, generator=torch.Generator(device=A.engine.device).manual_seed(2)))
+    st_f, st_s, st_d = (GKState(A, b, 12, normalized=False) for _ in range(3))
+    assert st_f.native_axpby
+    st_s.native_axpby = False
+    for _ in range(12):
+        st_f.step(sync=False)
+        st_s.step(sync=False)
+        st_d.step(sync=False, defer=True)        # beta^2 finished by the next step's adjoint kernel / the flush in _sync
+    assert np.allclose(st_d.alphas, st_f.alphas, rtol=1e-9) and np.allclose(st_d.betas, st_f.betas, rtol=1e-9)
+    assert relerr(st_d.V.data[11].cpu().numpy(), st_f.V.data[11].cpu().numpy()) < 5e-6
+    # (the norms are summed over different workgroup partitions: equal to fp64 rounding, the vectors to fp32 rounding)
+    for k in range(12):
+        assert relerr(st_f.V.data[k].cpu().numpy(), st_s.V.data[k].cpu().numpy()) < 5e-6, k
+        assert relerr(st_f.U.data[k + 1].cpu().numpy(), st_s.U.data[k + 1].cpu().numpy()) < 5e-6, k
+    assert np.allclose(st_f.alphas, st_s.alphas, rtol=1e-6) and np.allclose(st_f.betas, st_s.betas, rtol=1e-6)

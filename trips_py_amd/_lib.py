@@ -166,6 +166,10 @@ SIGNATURES = {
     "trk_mm_weights": (c_int, [c_i64, c_f32p, c_f32p, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_cgls_update_xr": (c_int, [c_i64, c_i64, c_f64p, c_f64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_op_fused_caps": (c_int, [c_op, ctypes.POINTER(c_int)]),
+    "trk_op_axpby_caps": (c_int, [c_op, ctypes.POINTER(c_int)]),
+    "trk_op_flush": (c_int, [c_op, c_stream]),
+    "trk_op_apply_axpby": (c_int, [c_op, c_int, c_f32p, c_dbl, c_f64p, c_f64p, c_int, c_dbl, c_f64p, c_f64p, c_int, c_f32p,
+                                   c_f32p, c_f64p, c_int, c_stream]),
     "trk_op_apply_fused": (c_int, [c_op, c_int, c_f32p, c_f32p, c_dbl, c_f64p, c_int, c_f64p, c_int, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
     "trk_cgls_x_update": (c_int, [c_i64, c_f64p, c_int, c_f64p, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
     "trk_finalize_batched": (c_int, [c_f64p, c_int, c_int, c_int, c_f64p, c_int, c_stream]),

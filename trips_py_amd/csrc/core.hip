@@ -202,6 +202,32 @@ int trk_op_apply(trk_op* op, int transpose, const float* x, int64_t ldx, float* 
   return op->apply(op, transpose ? 1 : 0, x, ldx, y, ldy, batch, sumsq_dev, (hipStream_t)stream);
 }
 
+int trk_op_axpby_caps(const trk_op* op, int* native) {
+  TRK_REQUIRE(op && native, "trk_op_axpby_caps: NULL argument");
+  *native = op->apply_axpby ? 1 : 0;
+  return TRK_OK;
+}
+
+int trk_op_apply_axpby(trk_op* op, int transpose, const float* x, double ca, const double* a_num, const double* a_den,
+                       int a_flags, double cb, const double* b_num, const double* b_den, int b_flags, const float* z,
+                       float* out, double* sumsq, int hints, trk_stream stream) {
+  TRK_REQUIRE(op && x && out, "trk_op_apply_axpby: NULL argument");
+  TRK_REQUIRE(out != x && out != z, "trk_op_apply_axpby: out must not alias x or z");
+  const int tr = transpose ? 1 : 0;
+  if (op->apply_axpby)
+    return op->apply_axpby(op, tr, x, Coef{ca, a_num, a_den, a_flags}, Coef{cb, b_num, b_den, b_flags}, z, out, sumsq, hints,
+                           (hipStream_t)stream);
+  // any operator: the plain apply into `out`, then the vector kernel in place
+  const int64_t nin = tr ? op->rows : op->cols, nout = tr ? op->cols : op->rows;
+  if (int rc = op->apply(op, tr, x, nin, out, nout, 1, nullptr, (hipStream_t)stream)) return rc;
+  return trk_axpby(nout, ca, a_num, a_den, a_flags, out, cb, b_num, b_den, b_flags, z, out, sumsq, stream);
+}
+
+int trk_op_flush(trk_op* op, trk_stream stream) {
+  TRK_REQUIRE(op, "trk_op_flush: NULL operator");
+  return op->flush ? op->flush(op, (hipStream_t)stream) : TRK_OK;
+}
+
 int trk_op_fused_caps(const trk_op* op, int* can_fuse) {
   TRK_REQUIRE(op && can_fuse, "trk_op_fused_caps: NULL argument");
   *can_fuse = op->apply_fused ? 1 : 0;

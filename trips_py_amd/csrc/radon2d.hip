@@ -76,8 +76,72 @@ struct RadonImpl {
   float* adj_wgt;
   int* adj_n0;
   uint4* rec;
+  int* adj_pos;      // [nt*na]: angle row (caller's order) -> its sorted row, the inverse of adj_ang[].orig
   int n_bands, band;
+  // what the side buffers currently hold, when a fused apply left them behind for the next apply of the other direction
+  // (trk_op_apply_axpby hints): rec = the records of the sinogram at rec_src, xT = the transpose of the image at xT_src
+  const float* rec_src;
+  const float* xT_src;
+  // a fused norm left as block partials (TRK_HINT_SUMSQ_DEFERRED): pend_n partials in pend_buf[pend_which ^ 1] belong to
+  // *pend_target; the next chained apply's epilogue kernel finishes it, anything else calls radon_flush first
+  double* pend_buf[2];
+  int64_t pend_cap;
+  int pend_which;
+  double* pend_target;
+  const double* pend_part;
+  int pend_n;
 };
+
+// Optional epilogue of the kernel that writes an apply's output (trk_op_apply_axpby): out = a * Op(x) + b * z.
+struct Epi {
+  int on;            // 0: out = Op(x)
+  Coef a, b;
+  const float* z;    // NULL: out = a * Op(x)
+  // a norm the previous fused apply of this operator left as block partials (TRK_HINT_SUMSQ_DEFERRED): coefficients that
+  // point at pend_target take the sum of the partials instead, and workgroup 0 stores the finished value there
+  double* pend_target;
+  const double* pend_part;
+  int pend_n;
+};
+
+// the sum of the pending partials — the same bits in every workgroup (one wave, fixed order) — in all threads
+__device__ __forceinline__ double pend_total(const Epi& e, double* lds1) {
+  if (threadIdx.x < 64) {
+    double v = 0.0;
+    for (int i = threadIdx.x; i < e.pend_n; i += 64) v += e.pend_part[i];
+    v = wave_sum_all(v);
+    if (threadIdx.x == 0) *lds1 = v;
+  }
+  __syncthreads();
+  return *lds1;
+}
+__device__ __forceinline__ double coef_eval_pend(const Coef& k, const double* target, double total) {
+  double v = k.c;
+  if (k.num) {
+    const double t = (k.num == target) ? total : *k.num;
+    v *= (k.flags & TRK_SQRT_NUM) ? sqrt(t) : t;
+  }
+  if (k.den) {
+    const double t = (k.den == target) ? total : *k.den;
+    v /= (k.flags & TRK_SQRT_DEN) ? sqrt(t) : t;
+  }
+  return v;
+}
+// both coefficients of the epilogue (uniform over the grid; ends with every thread past a barrier when a norm is pending)
+__device__ __forceinline__ void epi_coefs(const Epi& e, bool first_block, double* lds1, float& ca, float& cb) {
+  ca = 1.f;
+  cb = 0.f;
+  if (!e.on) return;
+  if (e.pend_target) {
+    const double total = pend_total(e, lds1);
+    ca = (float)coef_eval_pend(e.a, e.pend_target, total);
+    if (e.z) cb = (float)coef_eval_pend(e.b, e.pend_target, total);
+    if (first_block && threadIdx.x == 0) *e.pend_target = total;
+  } else {
+    ca = (float)coef_eval(e.a);
+    if (e.z) cb = (float)coef_eval(e.b);
+  }
+}
 
 // ---------------------------------------------------------------------------------------- transpose (LDS tile 32x33)
 __global__ __launch_bounds__(256) void k_transpose(const float* __restrict__ in, float* __restrict__ out, int N) {
@@ -551,22 +615,75 @@ __global__ __launch_bounds__(256, 7) void k_radon_fwd_win(const float* __restric
   if (owned) out[(int64_t)blockIdx.y * band_stride + (int64_t)a * nd + d] = (float)total;
 }
 
-// sino[a][d] = wgt_a * sum over bands (fixed order, fp64) of the band partial sums
-// ssq_part != NULL: also leaves sum(sino^2) of this block's 256 outputs in ssq_part[blockIdx.x] (the fused norm of the apply)
-__global__ __launch_bounds__(256) void k_radon_bands_sum(const float* __restrict__ part, int nb, int64_t band_stride,
-                                                         float* __restrict__ sino, int nd,
-                                                         const AngleParam* __restrict__ ang, double* __restrict__ ssq_part) {
+// sino[a][d] = wgt_a * sum over bands (fixed order, fp64) of the band partial sums, then the optional epilogue
+// a * sino + b * z.  One thread per (angle row, e = d + A32_PAD in [0, nd + 4)): the padding positions exist for REC, which
+// also writes the adjoint's record {w S[d -], w S[d +], w S[d], A32[d]} of every position (what k_radon_adj_prep would
+// make from the finished sinogram; the neighbours come through LDS, the two at the block's edges are recomputed).
+// ssq_part != NULL: sum(out^2) of this block's outputs in ssq_part[blockIdx.x].
+template <bool REC>
+__global__ __launch_bounds__(256) void k_radon_bands_post(const float* __restrict__ part, int nb, int64_t band_stride,
+                                                          float* __restrict__ sino, int nd, const AngleParam* __restrict__ ang,
+                                                          Epi epi, double* __restrict__ ssq_part,
+                                                          uint4* __restrict__ rec, const int* __restrict__ adj_pos,
+                                                          const AdjAngle* __restrict__ adj_ang, const float* __restrict__ adj_wgt,
+                                                          const unsigned* __restrict__ A32) {
   __shared__ double lds[4];
+  __shared__ float sv[258];
+  const int ndp = nd + 2 * A32_PAD;
+  const int64_t rows = band_stride / nd;
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  float o = 0.f;
-  if (idx < band_stride) {
+  const int64_t row = idx / ndp;
+  const int e = (int)(idx - row * ndp), d = e - A32_PAD;
+  const bool valid = row < rows;
+  // the loads first, the coefficients (which may wait for the pending partials) after: two latency chains side by side
+  struct Raw { float o, z; };
+  auto raw = [&](int64_t r, int dd) -> Raw {
+    if (dd < 0 || dd >= nd) return Raw{0.f, 0.f};
+    const int64_t k = r * nd + dd;
     double t = 0.0;
-    for (int b = 0; b < nb; ++b) t += (double)part[(int64_t)b * band_stride + idx];
-    o = ang[idx / nd].wgt * (float)t;
-    sino[idx] = o;
+    for (int b = 0; b < nb; ++b) t += (double)part[(int64_t)b * band_stride + k];
+    return Raw{ang[r].wgt * (float)t, (epi.on && epi.z) ? epi.z[k] : 0.f};
+  };
+  const Raw r0 = valid ? raw(row, d) : Raw{0.f, 0.f};
+  Raw rm{0.f, 0.f}, rp{0.f, 0.f};
+  if (REC) {
+    if (threadIdx.x == 0 && valid && e > 0) rm = raw(row, d - 1);
+    if (threadIdx.x == 255 && valid && e < ndp - 1) rp = raw(row, d + 1);
+  }
+  int64_t rs = 0;
+  float w = 0.f;
+  bool flip = false;
+  unsigned a32 = 0u;
+  if (REC && valid) {
+    rs = adj_pos[row];
+    w = adj_wgt[rs];
+    flip = adj_ang[rs].flip != 0;
+    a32 = A32[row * ndp + e];
+  }
+  float ca, cb;
+  epi_coefs(epi, blockIdx.x == 0, &lds[0], ca, cb);
+  auto fin = [&](const Raw& v) -> float { return epi.on ? (epi.z ? fmaf(ca, v.o, cb * v.z) : ca * v.o) : v.o; };
+  const bool inr = valid && d >= 0 && d < nd;
+  const float v0 = inr ? fin(r0) : 0.f;
+  if (inr) sino[row * nd + d] = v0;
+  if (REC) {
+    sv[threadIdx.x + 1] = v0;
+    if (threadIdx.x == 0) sv[0] = (valid && e > 0 && d - 1 >= 0 && d - 1 < nd) ? fin(rm) : 0.f;
+    if (threadIdx.x == 255) sv[257] = (valid && e < ndp - 1 && d + 1 >= 0 && d + 1 < nd) ? fin(rp) : 0.f;
+    __syncthreads();
+    if (valid) {
+      const float vm = e > 0 ? sv[threadIdx.x] : 0.f, vp = e < ndp - 1 ? sv[threadIdx.x + 2] : 0.f;
+      const float sm = w * vm, sp = w * vp;          // (0 outside the detector)
+      uint4 o;
+      o.x = __builtin_bit_cast(unsigned, flip ? sp : sm);
+      o.y = __builtin_bit_cast(unsigned, flip ? sm : sp);
+      o.z = __builtin_bit_cast(unsigned, w * v0);
+      o.w = a32;
+      rec[rs * ndp + e] = o;
+    }
   }
   if (ssq_part) {                                                 // uniform over the grid
-    const double q = block_sum<256>((double)o * o, lds);
+    const double q = block_sum<256>((double)v0 * v0, lds);
     if (threadIdx.x == 0) ssq_part[blockIdx.x] = q;
   }
 }
@@ -665,7 +782,7 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
                                                         const AdjAngle* __restrict__ ang, const float* __restrict__ wgt,
                                                         const unsigned* __restrict__ A32, const int* __restrict__ n_mode0,
                                                         const uint2* __restrict__ CB, int npad, int tiles_x,
-                                                        double* __restrict__ ssq_part) {
+                                                        double* __restrict__ ssq_part, Epi epi, float* __restrict__ xT_out) {
   __shared__ __attribute__((aligned(16))) uint4 ring[2][AB][64];
   __shared__ __attribute__((aligned(16))) uint2 cbs[2][AB][T];
   __shared__ float xch[PX > 1 ? T : 1][T + 1];
@@ -831,12 +948,25 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
   }
   double q = 0.0;
   img += (int64_t)frame * N * N;
+  // epilogue (trk_op_apply_axpby): out = a * (A^T s) + b * z; xT_out: also the transposed image the next forward apply wants
+  // (measured at 512^2: fetching z and the coefficients before the angle loop instead costs 1.6 us — registers)
+  float zv[PX];
 #pragma unroll
   for (int k = 0; k < PX; ++k) {
     const int i = i0 + r1 + k * TS, j = j0 + c1;
-    const float o = (accB[k] + (anB[k][0] + anB[k][1])) + (PX > 1 ? xch[r1 + k * TS][c1] : accA[k] + (anA[k][0] + anA[k][1]));
+    zv[k] = (epi.on && epi.z && i < N && j < N) ? epi.z[((int64_t)frame * N + i) * N + j] : 0.f;
+  }
+  float ca, cb;
+  epi_coefs(epi, blockIdx.x == 0 && blockIdx.y == 0, &lds[0], ca, cb);
+  if (xT_out) xT_out += (int64_t)frame * N * N;
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    const int i = i0 + r1 + k * TS, j = j0 + c1;
+    float o = (accB[k] + (anB[k][0] + anB[k][1])) + (PX > 1 ? xch[r1 + k * TS][c1] : accA[k] + (anA[k][0] + anA[k][1]));
     if (i < N && j < N) {
+      if (epi.on) o = epi.z ? fmaf(ca, o, cb * zv[k]) : ca * o;
       img[(int64_t)i * N + j] = o;
+      if (xT_out) xT_out[(int64_t)j * N + i] = o;
       q += (double)o * o;
     }
   }
@@ -888,12 +1018,39 @@ __global__ __launch_bounds__(256) void k_radon_adj_simple(const uint4* __restric
   }
 }
 
-int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
-                hipStream_t s) {
+constexpr int HINT_OUT_FEEDS_OPPOSITE = 1, HINT_INPUT_FROM_OPPOSITE = 2, HINT_SUMSQ_DEFERRED = 4;   // = TRK_HINT_* (trk.h)
+
+int radon_flush(trk_op* op, hipStream_t s) {
+  auto* im = static_cast<RadonImpl*>(op->impl);
+  if (!im->pend_target) return TRK_OK;
+  double* target = im->pend_target;
+  im->pend_target = nullptr;
+  return finalize_sums(im->pend_part, im->pend_n, 1, 1, target, s);
+}
+
+// Plain apply (epi.on = 0, hints = 0) and the fused form of trk_op_apply_axpby (batch 1) share this.
+int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq, Epi epi,
+              int hints, hipStream_t s) {
   auto* im = static_cast<RadonImpl*>(op->impl);
   const int N = im->N, nd = im->nd, na = im->na, nt = im->nt;
   TimerScope tm(op->timer, op->timer_which, tr, s);
-  // fused ||y||^2 (batch 1): block partials from the kernel that writes y (band reduction / gather), then one finalize
+  // a norm the previous fused apply left unfinished: this apply's epilogue kernel finishes it if the caller chained the two
+  // (it reads the partials for its coefficients), anything else gets it finished first
+  epi.pend_target = nullptr;
+  epi.pend_part = nullptr;
+  epi.pend_n = 0;
+  if (im->pend_target) {
+    if (epi.on && (hints & HINT_INPUT_FROM_OPPOSITE)) {
+      epi.pend_target = im->pend_target;
+      epi.pend_part = im->pend_part;
+      epi.pend_n = im->pend_n;
+      im->pend_target = nullptr;
+    } else if (int rc = radon_flush(op, s)) {
+      return rc;
+    }
+  }
+  // fused ||y||^2 (batch 1): block partials from the kernel that writes y (band reduction / gather), then one finalize —
+  // or none, when the caller lets the next chained apply finish it (TRK_HINT_SUMSQ_DEFERRED)
   double* ssq_part = nullptr;
   const bool adj_simple = getenv("TRK_RADON_ADJ_SIMPLE") != nullptr;   // read per call: tests switch it
   const bool tile = !adj_simple && N >= 16;
@@ -906,17 +1063,41 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
   static const int ab_env = getenv("TRK_RADON_ADJ_AB") ? atoi(getenv("TRK_RADON_ADJ_AB")) : 0;
   const int tiles_x = ceil_div(N, tile_T);
   const int64_t adj_blocks = tile ? (int64_t)tiles_x * tiles_x : (int64_t)ceil_div((int64_t)N * N, 256);
-  const bool fuse_ssq = sumsq && batch == 1 && (tr || im->n_bands > 1);
-  if (fuse_ssq) {
-    const int64_t nblk = tr ? adj_blocks * nt : (int64_t)ceil_div((int64_t)nt * na * nd, 256);
-    if (int rc = scratch_doubles(s, (size_t)nblk, &ssq_part)) return rc;
+  const int ndp = nd + 2 * A32_PAD;
+  const bool adj_prep = !tile || na > 32;            // few angles per frame: the tile kernel makes its records itself
+  if (epi.on && (batch != 1 || (tr && !tile))) return fail(TRK_EUNSUPPORTED, "radon: fused epilogue needs batch 1 and the tiled adjoint");
+  // the forward's band reduction carries the epilogue / the fused norm / the adjoint's records
+  const bool post = epi.on || im->n_bands > 1;
+  const bool fuse_ssq = sumsq && batch == 1 && (tr ? tile : post);
+  const int64_t post_blocks = ceil_div((int64_t)nt * na * ndp, 256);
+  const int64_t n_part = tr ? adj_blocks * nt : post_blocks;
+  const bool defer = fuse_ssq && epi.on && (hints & HINT_SUMSQ_DEFERRED) && n_part <= im->pend_cap;
+  if (defer) {
+    ssq_part = im->pend_buf[im->pend_which];        // not the buffer a pending norm of the previous apply is read from
+    im->pend_which ^= 1;
+  } else if (fuse_ssq) {
+    if (int rc = scratch_doubles(s, (size_t)n_part, &ssq_part)) return rc;
   }
+  auto finish_norm = [&]() -> int {
+    if (defer) {
+      im->pend_target = sumsq;
+      im->pend_part = ssq_part;
+      im->pend_n = (int)n_part;
+      return TRK_OK;
+    }
+    return finalize_sums(ssq_part, (int)n_part, 1, 1, sumsq, s);
+  };
   if (!tr) {
     for (int b = 0; b < batch; ++b) {  // the transposed copy is per vector
       const float* xb = x + (int64_t)b * ldx;
       if (im->n_mode1 > 0) {
-        dim3 g(ceil_div(N, 32), ceil_div(N, 32), nt);
-        hipLaunchKernelGGL(k_transpose, g, dim3(256), 0, s, xb, im->xT, N);
+        if ((hints & HINT_INPUT_FROM_OPPOSITE) && im->xT_src == xb) {
+          // the adjoint that produced xb left its transpose in xT already
+        } else {
+          dim3 g(ceil_div(N, 32), ceil_div(N, 32), nt);
+          hipLaunchKernelGGL(k_transpose, g, dim3(256), 0, s, xb, im->xT, N);
+        }
+        im->xT_src = nullptr;            // holds for this apply only: the caller's promise covers the very next one
       }
       const int ndblk = ceil_div(nd, 64), ngrp = ceil_div(na, 4), nb = im->n_bands;
       const int64_t bs = (int64_t)nt * na * nd;
@@ -927,6 +1108,8 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
       static const bool dma = getenv("TRK_RADON_NO_DMA") == nullptr;
       const bool lds = !no_lds && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15u) == 0);
       static const bool no_win = getenv("TRK_RADON_NO_WIN") != nullptr;
+      static const bool no_rec_out = getenv("TRK_RADON_NO_REC_OUT") != nullptr;     // tuning knobs: the producer side of the hints off
+      const bool want_rec = (hints & HINT_OUT_FEEDS_OPPOSITE) && tile && adj_prep && batch == 1 && !no_rec_out;
       // measured: 512^2 35 us (shared) vs 32 us (per-wave windows); 2048^2 0.256 vs 0.277 ms; 4096^2 0.96 vs 1.11 ms
       if (nb > 1 && N >= 1024 && lds && dma && !no_win && im->band <= WIN_R * WIN_MAXCH) {
         // window-sharing kernel: band partials of rays no window owns must read as zero
@@ -934,8 +1117,7 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
         const int nwin = ceil_div(N + 2 * im->band + 16, 61);
         dim3 gw(nwin * ngrp * nt, nb, 1);
         hipLaunchKernelGGL(k_radon_fwd_win<0>, gw, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, nwin, bs, im->band, im->fidx, im->A32, im->B32, im->npad);
-        hipLaunchKernelGGL(k_radon_bands_sum, dim3(ceil_div(bs, 256)), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev, ssq_part);
-      } else if (nb == 1) {
+      } else if (!post) {
         if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<true, true>), grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
         else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
         else hipLaunchKernelGGL(k_radon_fwd<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
@@ -943,42 +1125,54 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
         if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<false, true>), grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
         else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
         else hipLaunchKernelGGL(k_radon_fwd<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
-        hipLaunchKernelGGL(k_radon_bands_sum, dim3(ceil_div(bs, 256)), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev, ssq_part);
+      }
+      if (post) {
+        if (want_rec)
+          hipLaunchKernelGGL(k_radon_bands_post<true>, dim3((unsigned)post_blocks), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev, epi,
+                             ssq_part, im->rec, im->adj_pos, im->adj_ang, im->adj_wgt, im->A32);
+        else
+          hipLaunchKernelGGL(k_radon_bands_post<false>, dim3((unsigned)post_blocks), dim3(256), 0, s, im->part, nb, bs, yb, nd, im->ang_dev, epi,
+                             ssq_part, im->rec, im->adj_pos, im->adj_ang, im->adj_wgt, im->A32);
+        if (want_rec) im->rec_src = yb;
       }
       TRK_LAUNCH_CHECK();
     }
     if (ssq_part) {
       tm.stop();
-      return finalize_sums(ssq_part, ceil_div((int64_t)nt * na * nd, 256), 1, 1, sumsq, s);
+      return finish_norm();
     }
   } else {
-    const int ndp = nd + 2 * A32_PAD;
     for (int b = 0; b < batch; ++b) {            // the record array is per vector
       const float* xb = x + (int64_t)b * ldx;
-      const bool prep = !tile || na > 32;            // few angles per frame: the tile kernel makes its records itself
-      if (prep)
-        hipLaunchKernelGGL(k_radon_adj_prep, dim3(ceil_div((int64_t)na * ndp, 256), nt), dim3(256), 0, s, xb, im->rec, nd, na,
-                           im->adj_ang, im->adj_wgt, im->A32);
+      if (adj_prep) {
+        if (!((hints & HINT_INPUT_FROM_OPPOSITE) && im->rec_src == xb))   // else: the forward that produced xb left its records
+          hipLaunchKernelGGL(k_radon_adj_prep, dim3(ceil_div((int64_t)na * ndp, 256), nt), dim3(256), 0, s, xb, im->rec, nd, na,
+                             im->adj_ang, im->adj_wgt, im->A32);
+        im->rec_src = nullptr;
+      }
+      static const bool no_xt_out = getenv("TRK_RADON_NO_XT_OUT") != nullptr;
+      float* xT_out = ((hints & HINT_OUT_FEEDS_OPPOSITE) && tile && im->n_mode1 > 0 && batch == 1 && !no_xt_out) ? im->xT : nullptr;
 #define ADJ_TILE(TT, PP, BB, PR)                                                                                              \
   hipLaunchKernelGGL((k_radon_adj_tile<TT, PP, BB, PR>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, xb, im->rec,          \
                      y + (int64_t)b * ldy, N, nd, na, im->adj_ang, im->adj_wgt, im->A32, im->adj_n0, im->CB, im->npad, tiles_x, \
-                     ssq_part)
+                     ssq_part, epi, xT_out)
       if (tile && tile_T == 32) {
-        if (prep) ADJ_TILE(32, 4, 8, true); else ADJ_TILE(32, 4, 8, false);
+        if (adj_prep) ADJ_TILE(32, 4, 8, true); else ADJ_TILE(32, 4, 8, false);
       } else if (tile && (ab_env ? ab_env == 16 : na > 32)) {
-        if (prep) ADJ_TILE(16, 1, 16, true); else ADJ_TILE(16, 1, 16, false);
+        if (adj_prep) ADJ_TILE(16, 1, 16, true); else ADJ_TILE(16, 1, 16, false);
       } else if (tile) {   // few angles per frame (dynamic problems: 15): short batches, so that staging and gathering still overlap
-        if (prep) ADJ_TILE(16, 1, 4, true); else ADJ_TILE(16, 1, 4, false);
+        if (adj_prep) ADJ_TILE(16, 1, 4, true); else ADJ_TILE(16, 1, 4, false);
       }
 #undef ADJ_TILE
       else
         hipLaunchKernelGGL(k_radon_adj_simple, dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, im->rec, y + (int64_t)b * ldy, N, nd, na,
-                           im->adj_ang, im->adj_n0, im->CB, im->npad, ssq_part);
+                           im->adj_ang, im->adj_n0, im->CB, im->npad, (double*)nullptr);
+      if (xT_out) im->xT_src = y + (int64_t)b * ldy;
       TRK_LAUNCH_CHECK();
     }
     if (ssq_part) {
       tm.stop();
-      return finalize_sums(ssq_part, (int)(adj_blocks * nt), 1, 1, sumsq, s);
+      return finish_norm();
     }
   }
   tm.stop();
@@ -991,9 +1185,27 @@ int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64
   return TRK_OK;
 }
 
+int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
+                hipStream_t s) {
+  return radon_run(op, tr, x, ldx, y, ldy, batch, sumsq, Epi{}, 0, s);
+}
+
+// out = a * Op(x) + b * z (+ ||out||^2) inside the kernel that writes the output: the band reduction (forward) or the tile
+// gather (adjoint).  Small frames the tiled adjoint does not take fall back to apply + trk_axpby.
+int radon_apply_axpby(trk_op* op, int tr, const float* x, Coef a, Coef b, const float* z, float* out, double* sumsq, int hints,
+                      hipStream_t s) {
+  auto* im = static_cast<RadonImpl*>(op->impl);
+  const bool tile = getenv("TRK_RADON_ADJ_SIMPLE") == nullptr && im->N >= 16;
+  if (tr && !tile) {
+    if (int rc = radon_run(op, tr, x, op->rows, out, op->cols, 1, nullptr, Epi{}, 0, s)) return rc;
+    return trk_axpby(op->cols, a.c, a.num, a.den, a.flags, out, b.c, b.num, b.den, b.flags, z, out, sumsq, (trk_stream)s);
+  }
+  return radon_run(op, tr, x, tr ? op->rows : op->cols, out, tr ? op->cols : op->rows, 1, sumsq, Epi{1, a, b, z, nullptr, nullptr, 0}, hints, s);
+}
+
 void radon_destroy(trk_op* op) {
   auto* im = static_cast<RadonImpl*>(op->impl);
-  void* ptrs[] = {im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec};
+  void* ptrs[] = {im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec, im->adj_pos, im->pend_buf[0], im->pend_buf[1]};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete im;
@@ -1059,7 +1271,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
   };
   up((void**)&im->ang_dev, h.data(), sizeof(AngleParam) * n_ang);
   if (n1 > 0) up((void**)&im->xT, nullptr, sizeof(float) * (size_t)nt * N * N);
-  if (nb > 1) up((void**)&im->part, nullptr, sizeof(float) * (size_t)nb * n_ang * n_det);
+  up((void**)&im->part, nullptr, sizeof(float) * (size_t)nb * n_ang * n_det);   // nb = 1: used by the fused epilogue form
   {
     std::vector<float> fi((size_t)N + 16);
     for (size_t i = 0; i < fi.size(); ++i) fi[i] = (float)i;
@@ -1073,6 +1285,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     std::vector<AdjAngle> aa(n_ang);
     std::vector<int> n0(nt);
     std::vector<float> wg(n_ang);
+    std::vector<int> pos_of(n_ang);
     for (int f = 0; f < nt; ++f) {
       int pos = 0;
       for (int pass = 0; pass < 2; ++pass) {
@@ -1081,6 +1294,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
           if (q.mode != pass) continue;
           aa[(size_t)f * na + pos] = AdjAngle{q.rinv, 1.0f - fabsf(q.inv), q.dq, q.k0, a, q.inv < 0.f ? 1 : 0};
           wg[(size_t)f * na + pos] = wadj[(size_t)f * na + a];
+          pos_of[(size_t)f * na + a] = f * na + pos;
           ++pos;
         }
         if (pass == 0) n0[f] = pos;
@@ -1090,6 +1304,11 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     up((void**)&im->adj_wgt, wg.data(), sizeof(float) * n_ang);
     up((void**)&im->adj_n0, n0.data(), sizeof(int) * nt);
     up((void**)&im->rec, nullptr, sizeof(uint4) * (size_t)n_ang * ndp);
+    up((void**)&im->adj_pos, pos_of.data(), sizeof(int) * n_ang);
+    const int64_t t16 = (int64_t)ceil_div(N, 16) * ceil_div(N, 16) * nt, pb = ceil_div((int64_t)n_ang * ndp, 256);
+    im->pend_cap = t16 > pb ? t16 : pb;
+    up((void**)&im->pend_buf[0], nullptr, sizeof(double) * (size_t)im->pend_cap);
+    up((void**)&im->pend_buf[1], nullptr, sizeof(double) * (size_t)im->pend_cap);
   }
   if (e != hipSuccess) {
     trk_op tmp{2, 0, 0, im, nullptr, nullptr, nullptr, 0};
@@ -1097,6 +1316,8 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     return fail(TRK_EHIP, "trk_radon2d_create: %s", hipGetErrorString(e));
   }
   *out = new trk_op{2, (int64_t)n_ang * n_det, (int64_t)nt * N * N, im, radon_apply, radon_destroy, nullptr, 0};
+  (*out)->apply_axpby = radon_apply_axpby;
+  (*out)->flush = radon_flush;
   return TRK_OK;
 }
 

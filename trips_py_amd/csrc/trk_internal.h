@@ -214,5 +214,10 @@ struct trk_op {
   int (*apply_fused)(trk_op*, int transpose, const float* x1, const float* x2, double sign, trk::ScalarSrc num,
                      trk::ScalarSrc den, float* comb, float* y, double* partials, int cap, int* n_partials,
                      hipStream_t s) = nullptr;
+  // optional: out = a * Op(x) + b * z (+ ||out||^2) inside the operator's own output pass (trk_op_apply_axpby); hints: TRK_HINT_*
+  int (*apply_axpby)(trk_op*, int transpose, const float* x, trk::Coef a, trk::Coef b, const float* z, float* out,
+                     double* sumsq, int hints, hipStream_t s) = nullptr;
+  // optional: finish what a TRK_HINT_SUMSQ_DEFERRED apply left unfinished (trk_op_flush)
+  int (*flush)(trk_op*, hipStream_t s) = nullptr;
   void* aux = nullptr;   // malloc'ed per-handle cache of a consumer (cgls_tiled.hip: tile geometry + weights); freed with the handle
 };

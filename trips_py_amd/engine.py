@@ -190,6 +190,14 @@ class HipEngine:
                                    int(batch), _ptr(sumsq), self.stream())
         _lib.check(rc, "trk_op_apply")
 
+    def op_apply_axpby(self, handle, transpose, x, a, b, z, out, sumsq=None, hints=0):
+        """out = a * Op(x) + b * z (+ ||out||^2); a, b: float or Coef; z may be None."""
+        a, b = _as_coef(a), _as_coef(b)
+        rc = self.lib.trk_op_apply_axpby(handle, int(bool(transpose)), x.data_ptr(), a.c, a.num, a.den, a.flags, b.c, b.num,
+                                         b.den, b.flags, None if z is None else z.data_ptr(), out.data_ptr(), _ptr(sumsq),
+                                         int(hints), self.stream())
+        _lib.check(rc, "trk_op_apply_axpby")
+
     # ------------------------------------------------------------------ reductions (local sums)
     def dot(self, x, y, out):
         _lib.check(self.lib.trk_dot(x.data_ptr(), y.data_ptr(), x.numel(), _ptr(out), self.stream()), "trk_dot")

@@ -76,6 +76,9 @@ class GKState:
     def __init__(self, A, b, capacity, normalized=True):
         self.A, self.eng = A, A.engine
         self.normalized = bool(normalized)
+        # operators whose own output pass takes the vector update and the norm of a half step (the Radon projector)
+        self.native_axpby = bool(getattr(A, "native_axpby", False)) and not self.normalized
+        self._chained = False                   # U[k] came out of this state's previous fused forward apply
         m, n = A.shape
         eng = self.eng
         self.U = DeviceBasis(eng, m, capacity + 1)
@@ -100,6 +103,7 @@ class GKState:
         st = cls.__new__(cls)
         st.A, st.eng = A, A.engine
         st.normalized = True
+        st.native_axpby, st._chained = False, False
         eng = A.engine
         m, n = A.shape
         k = len(alphas)
@@ -124,6 +128,7 @@ class GKState:
     def _sync(self, need=None):
         k = self.V.k if need is None else need
         if len(self._alphas) < k:
+            self.flush()
             k = self.V.k
             h = self.AB.host(0, 2 * k + 1)
             if self._beta0 is None:
@@ -166,10 +171,19 @@ class GKState:
         self._alphas.append(float(v[0]))
         self._betas.append(float(v[1]))
 
-    def step(self, sync=True):
+    def flush(self):
+        """Finish a norm a `step(defer=True)` left inside the operator (before anything reads AB)."""
+        if self.native_axpby:
+            self.A.flush_deferred()
+
+    def step(self, sync=True, defer=False):
+        """defer=True (with sync=False): beta_{k+1}^2 may stay unfinished inside the operator until the next step or
+        `flush()` — for loops that look at AB only at the end (fixed-lambda Hybrid_LSQR without history)."""
         A, eng = self.A, self.eng
         k = self.V.k
+        defer = bool(defer) and not sync
         if len(self.AB) < 2 * k + 3:
+            self.flush()
             new = eng.scalars(4 * k + 8)
             new.view(0, 2 * k + 1).copy_(self.AB.view(0, 2 * k + 1))
             self.AB = new
@@ -178,18 +192,38 @@ class GKState:
         a2, b2 = AB.ref(2 * k + 1), AB.ref(2 * k + 2)
         if not self.normalized:
             bk2 = AB.ref(2 * k)                                     # ||U[k]||^2
-            A.apply(u, out=self.tmp_n, transpose=True)
             v = self.V.next_slot()
+            ca_v = Coef(1.0, den=bk2, sqrt_den=True)
+            cb_v = None if k == 0 else Coef(-1.0, num=bk2, den=AB.ref(2 * k - 1), sqrt_num=True, sqrt_den=True)
+            ca_u = Coef(1.0, den=a2, sqrt_den=True)
+            cb_u = Coef(-1.0, num=a2, den=bk2, sqrt_num=True, sqrt_den=True)
+            if self.native_axpby:
+                # the operator's output pass carries the vector update and the norm (trk_op_apply_axpby): no vector kernel,
+                # no reduction launch; U[k] / V[k] go from one half step straight into the other, so what the next apply
+                # derives from its input (detector records, transposed image) is left behind by the one that writes it
+                feeds, takes = A.OUT_FEEDS_OPPOSITE, A.INPUT_FROM_OPPOSITE
+                # single rank: alpha_k^2 stays block partials until the forward apply below adds them up for its own
+                # coefficients (no reduction launch); beta_{k+1}^2 likewise until the next step, if the caller allows
+                local = getattr(eng, "world", 1) == 1
+                later = A.SUMSQ_DEFERRED if local else 0
+                A.apply_axpby(u, ca_v, 0.0 if k == 0 else cb_v, None if k == 0 else self.V[k - 1], v, transpose=True,
+                              sumsq=a2, hints=feeds | (takes if self._chained else 0) | later)
+                eng.allreduce(AB, 2 * k + 1, 2 * k + 2)
+                self.V.commit()
+                A.apply_axpby(v, ca_u, cb_u, u, self.U.next_slot(), sumsq=b2, hints=feeds | takes | (later if defer else 0))
+                eng.allreduce(AB, 2 * k + 2, 2 * k + 3)
+                self.U.commit()
+                self._chained = True
+                return self._finish_step(k, sync)
+            A.apply(u, out=self.tmp_n, transpose=True)
             if k == 0:
-                eng.scale(Coef(1.0, den=bk2, sqrt_den=True), self.tmp_n, v, sumsq=a2)
+                eng.scale(ca_v, self.tmp_n, v, sumsq=a2)
             else:
-                eng.axpby(Coef(1.0, den=bk2, sqrt_den=True), self.tmp_n,
-                          Coef(-1.0, num=bk2, den=AB.ref(2 * k - 1), sqrt_num=True, sqrt_den=True), self.V[k - 1], v, sumsq=a2)
+                eng.axpby(ca_v, self.tmp_n, cb_v, self.V[k - 1], v, sumsq=a2)
             eng.allreduce(AB, 2 * k + 1, 2 * k + 2)
             self.V.commit()
             A.apply(v, out=self.tmp_m)
-            eng.axpby(Coef(1.0, den=a2, sqrt_den=True), self.tmp_m,
-                      Coef(-1.0, num=a2, den=bk2, sqrt_num=True, sqrt_den=True), u, self.U.next_slot(), sumsq=b2)
+            eng.axpby(ca_u, self.tmp_m, cb_u, u, self.U.next_slot(), sumsq=b2)
             eng.allreduce(AB, 2 * k + 2, 2 * k + 3)
             self.U.commit()
             return self._finish_step(k, sync)

@@ -165,6 +165,24 @@ class _HandleOperator(LinearOperator):
     def _apply(self, x2, y2, transpose, sumsq):
         self.engine.op_apply(self._h, transpose, x2, y2, batch=x2.shape[0], ldx=x2.stride(0), ldy=y2.stride(0), sumsq=sumsq)
 
+    #: hints of apply_axpby (trk.h TRK_HINT_*)
+    OUT_FEEDS_OPPOSITE, INPUT_FROM_OPPOSITE, SUMSQ_DEFERRED = 1, 2, 4
+
+    def apply_axpby(self, x, a, b, z, out, transpose=False, sumsq=None, hints=0):
+        """out = a * Op(x) + b * z and ||out||^2 in the operator's own output pass (trk_op_apply_axpby: one Golub-Kahan half
+        step; a, b: float or engine.Coef; z may be None).  Operators without a native form run apply + axpby in C."""
+        self.engine.op_apply_axpby(self._h, transpose, x, a, b, z, out, sumsq, hints)
+
+    def flush_deferred(self):
+        """Finish a norm an apply_axpby(..., hints=SUMSQ_DEFERRED) left as block partials (trk_op_flush)."""
+        _lib.check(self.engine.lib.trk_op_flush(self._h, self.engine.stream()), "trk_op_flush")
+
+    @property
+    def native_axpby(self):
+        n = ctypes.c_int(0)
+        _lib.check(self.engine.lib.trk_op_axpby_caps(self._h, ctypes.byref(n)), "trk_op_axpby_caps")
+        return bool(n.value)
+
     def __del__(self):
         h, self._h = getattr(self, "_h", None), None
         if h:

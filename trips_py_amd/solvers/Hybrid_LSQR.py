@@ -57,7 +57,8 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             gk.absorb(pend)                  # alpha_k, beta_{k+1}; step k+1 runs while the host chooses lambda_k
             pend = gk.step_prefetch() if k < n_iter else None
         else:
-            gk.step(sync=False)
+            # nobody reads B_k before the end (fixed lambda, no history, no x_true): the step's last norm may stay inside the operator
+            gk.step(sync=False, defer=(not keep and xt is None and ii < n_iter - 1))
         if ii == 0:
             lam = 0
             continue
@@ -88,6 +89,7 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             continue                         # nobody looks at this iterate (history=False, no x_true)
         # y = lstsq([B; sqrt(lam) I], [beta0 e1; 0]) (:104), on the device from the squared norms in gk.AB
         # (as y_j / alpha_j: the rows of V are alpha_j v_j)
+        gk.flush()
         eng.bidiag_tikhonov(gk.AB.ref(1), 2, gk.AB.ref(2), 2, k, np.sqrt(lam), gk.AB.ref(0), Y.ref(0), W, y_over_alpha=True)
         x_dev = H.row(nx_done)
         if err_fused:
