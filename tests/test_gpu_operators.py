@@ -43,6 +43,33 @@ def test_first_derivative_2d_vs_oracle(N):
     assert relerr(L @ X3, np.stack([Lo @ f(X3[:, j]) for j in range(3)], 1)) < 1e-6
 
 
+def test_first_derivative_2d_large_image_grid_stride_path():
+    """N = 4500: more row batches than the capped grid of the reducing kernels holds (the batches are then grid-strided):
+    L x, L^T y and their fused norms against the same differences formed with torch."""
+    from trips_py_amd.operators import FirstDerivative2D
+    N = 4500
+    L = FirstDerivative2D(N)
+    eng = L.engine
+    g = torch.Generator(device=eng.device).manual_seed(1)
+    X = torch.randn(N, N, device=eng.device, generator=g)
+    S = eng.scalars(2)
+    out = L.apply(X.reshape(-1), sumsq=S.ref(0))
+    H, V = X[:, :-1] - X[:, 1:], X[:-1, :] - X[1:, :]
+    want = torch.cat([H.reshape(-1), V.reshape(-1)])
+    assert torch.equal(out, want)
+    assert torch.equal(L.apply(X.reshape(-1)), want)                          # the uncapped grid of the plain apply
+    back = L.apply(out, transpose=True, sumsq=S.ref(1))
+    Z = torch.zeros(N, N, device=eng.device)
+    Z[:, :-1] += H
+    Z[:, 1:] -= H
+    Z[:-1, :] += V
+    Z[1:, :] -= V
+    assert float(torch.linalg.norm(back - Z.reshape(-1)) / torch.linalg.norm(Z)) < 1e-6
+    s = S.host()
+    assert np.isclose(s[0], float((out.double() ** 2).sum()), rtol=1e-12)
+    assert np.isclose(s[1], float((back.double() ** 2).sum()), rtol=1e-12)
+
+
 @pytest.mark.parametrize("N,nt", [(16, 3), (33, 5), (256, 4)])
 def test_spacetime_vs_oracle(N, nt):
     from oracle import cpu_ref as O
@@ -56,6 +83,8 @@ def test_spacetime_vs_oracle(N, nt):
     S = L.engine.scalars(1)
     out = L.apply(torch.from_numpy(x.astype(np.float32)).to(L.engine.device), sumsq=S.ref(0))
     assert np.isclose(S.host()[0], float((out.double() ** 2).sum()), rtol=1e-12)
+    back = L.apply(out, transpose=True, sumsq=S.ref(0))
+    assert np.isclose(S.host()[0], float((back.double() ** 2).sum()), rtol=1e-12)
 
 
 def test_blockdiag_frames():
