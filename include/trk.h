@@ -340,12 +340,24 @@ int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y
 int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G_dev,
               double* c1_dev, double* c2_dev, trk_stream stream);
 
-/* y = (G_A + lam G_L)^-1 c on the device (float64, one workgroup, k <= 88): the projected Tikhonov problem of GKS.py:74 /
+/* y = (G_A + lam G_L)^-1 c on the device (float64, one workgroup, k <= 139: the factor lives in LDS): the projected Tikhonov problem of GKS.py:74 /
  * MMGKS.py:106, `lstsq([R_A; sqrt(lam) R_L], [Q_A^T b; 0])`, from the Gram data G_A = (AV)^T AV, G_L = (LV)^T LV (row strides
  * lda, ldl) and c = (AV)^T b that trk_gemv_t / trk_wgram leave on the device — a numeric regparam then needs no host round trip
  * inside the loop. */
 int trk_gram_tikhonov(const double* GA_dev, int lda, const double* GL_dev, int ldl, const double* c_dev, int k, double lam,
                       double* y_dev, trk_stream stream);
+/* Hybrid-GMRES's projected problem on the device (Hybrid_GMRES.py:69-77 with a numeric regparam):
+ *   y = argmin || H_k y - beta0 e1 ||^2 + lam || y ||^2 ,  H_k the (k+1) x k Hessenberg matrix of Arnoldi (decompositions.py:207-228).
+ * One call per Arnoldi step k = 1, 2, ...: column k-1 of H is appended from what the orthogonalisation left on the device —
+ * coef[0..k) (+ coef2[0..k) if not NULL: a second sweep's coefficients) above sqrt(*nrm2_sq) — into H_dev (column-major,
+ * column stride ldh >= k+1; the caller keeps it between calls), G_dev = H^T H (row stride ldg >= k; kept between calls) gets its
+ * new row and column, and (G + lam I) y = beta0 H[0,:]^T is solved (float64, one workgroup):
+ *   mode 0  by Cholesky in LDS from scratch (k <= 139; any sequence of lam);
+ *   mode 1  by the bordering update of the inverse kept in Minv_dev (row stride ldg): valid when the previous call (k-1) used
+ *           the same lam > 0 in mode 1 or 2 — O(k^2) instead of O(k^3);
+ *   mode 2  k <= 2: Minv_dev written directly (start of a mode-1 chain; lam may differ from the previous call's). */
+int trk_hess_tikhonov(double* H_dev, int ldh, double* G_dev, double* Minv_dev, int ldg, const double* coef, const double* coef2,
+                      const double* nrm2_sq, double beta0, int k, double lam, int mode, double* y_dev, trk_stream stream);
 
 /* CGLS on SMALL blur problems in two launches per iteration (CGLS.py:56-80): a workgroup owns a 32 x 32 tile and recomputes
  * in LDS what it needs of its neighbours' halo (p = t + beta p and w = A p on tile + halo) instead of waiting for them at a

@@ -180,7 +180,7 @@ class CpuEngine:
         Vk = _d(V[:k])
         _put(out_h2k, np.concatenate((Vk @ _d(r), Vk @ _d(r2))))
 
-    GRAM_TIKHONOV_MAX_K = 88
+    GRAM_TIKHONOV_MAX_K = 139
 
     def gram_tikhonov(self, GA, lda, GL, ldl, c, k, lam, y):
         (sa, ia), (sl, il) = GA, GL

@@ -381,3 +381,36 @@ def test_fused_tv_weights_and_gradient(eng, N, q):
     assert relerr(got.cpu().numpy(), lam * (Lm.T @ (Lm @ x64))) < 2e-6
     w64 = ((Lm @ x64) ** 2 + eps ** 2) ** (q / 2 - 1)
     assert relerr(w.cpu().numpy(), w64) < 2e-6
+
+
+@pytest.mark.parametrize("kmax,lam", [(5, 0.3), (40, 1e-2), (120, 1e-3)])
+def test_hess_tikhonov_modes_against_stacked_lstsq(eng, kmax, lam):
+    """trk_hess_tikhonov: column by column of a random Hessenberg matrix, y = argmin ||H_k y - beta0 e1||^2 + lam ||y||^2
+    (Hybrid_GMRES.py:69-77) by the bordering update of the inverse (mode 1, chain started by mode 2 with lam = 0 at k = 1 as
+    the reference does) and by Cholesky from scratch (mode 0) against numpy's stacked least-squares solve."""
+    rng = np.random.default_rng(kmax)
+    Hm = np.triu(rng.standard_normal((kmax + 1, kmax)), -1)
+    Hm[np.arange(1, kmax + 1), np.arange(kmax)] = np.abs(Hm[np.arange(1, kmax + 1), np.arange(kmax)]) + 0.5
+    beta0 = 2.7
+    Hd, Gd, Mi = eng.scalars((kmax + 1) * kmax), eng.scalars(kmax * kmax), eng.scalars(kmax * kmax)
+    H0, G0 = eng.scalars((kmax + 1) * kmax), eng.scalars(kmax * kmax)
+    S = eng.scalars(2 * kmax + 2)
+    Y, Y0 = eng.scalars(kmax), eng.scalars(kmax)
+    for k in range(1, kmax + 1):
+        col = Hm[:k + 1, k - 1]
+        half = rng.standard_normal(k)                                  # the two sweeps' coefficient sets add up to the column
+        S.set(0, np.concatenate(([col[k] ** 2], half, col[:k] - half)))
+        lk = 0.0 if k == 1 else lam
+        eng.hess_tikhonov(Hd.ref(0), kmax + 1, Gd.ref(0), Mi.ref(0), kmax, S.ref(1), S.ref(1 + k), S.ref(0), beta0, k, lk,
+                          2 if k <= 2 else 1, Y.ref(0))
+        eng.hess_tikhonov(H0.ref(0), kmax + 1, G0.ref(0), None, kmax, S.ref(1), S.ref(1 + k), S.ref(0), beta0, k, lk, 0, Y0.ref(0))
+        if k in (1, 2, 3, kmax // 2, kmax):
+            Hk = Hm[:k + 1, :k]
+            rhs = np.zeros(2 * k + 1)
+            rhs[0] = beta0
+            want = np.linalg.lstsq(np.vstack((Hk, np.sqrt(lk) * np.eye(k))), rhs, rcond=None)[0]
+            # normal equations in float64 on a random (worse than Arnoldi's) H: cond(H^T H + lam I) <= ||H||^2 / lam ~ 1e5 at
+            # k = 120, and the bordered inverse carries k updates — both far below the fp32 vectors the result multiplies
+            assert relerr(Y.host(0, k), want) < 1e-7, (k, "bordering")
+            assert relerr(Y0.host(0, k), want) < 1e-8, (k, "cholesky")
+    assert np.allclose(Hd.host(0, (kmax + 1) * kmax).reshape(kmax, kmax + 1).T, Hm, rtol=1e-12, atol=1e-13)

@@ -262,3 +262,27 @@ def test_golub_kahan_fused_half_steps_equal_the_separate_kernels(N, na):
         assert relerr(st_f.V.data[k].cpu().numpy(), st_s.V.data[k].cpu().numpy()) < 5e-6, k
         assert relerr(st_f.U.data[k + 1].cpu().numpy(), st_s.U.data[k + 1].cpu().numpy()) < 5e-6, k
     assert np.allclose(st_f.alphas, st_s.alphas, rtol=1e-6) and np.allclose(st_f.betas, st_s.betas, rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,its", [(32, 20), (128, 100)])
+def test_hybrid_gmres_device_projected_solve_equals_the_host_one(N, its):
+    """trk_hess_tikhonov (H appended from the sweep's device scalars, (H^T H + lam I) y = beta0 H[0,:]^T by Cholesky in LDS, no
+    host round trip in the loop) against the host path (download of H's column, stacked lstsq): iterates, lambda history,
+    relError and the reference's relResidual quirk — up to k = 100 > 64 KB of LDS."""
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import gauss_psf
+    from trips_py_amd.solvers import Hybrid_GMRES
+    A = Blur2D(gauss_psf((9, 9), (2, 2))[0], N, N)
+    dev = A.engine.device
+    xt = torch.rand(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
+    b = A.apply(xt)
+    b = b + 0.01 * torch.randn(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(4)) * b.norm() / N
+    xd, idv = Hybrid_GMRES(A, b, its, 1e-2, xt)
+    xh, ih = Hybrid_GMRES(A, b, its, 1e-2, xt, device_solve=False)
+    assert float(torch.linalg.norm(xd - xh) / torch.linalg.norm(xh)) < 1e-5
+    assert idv["regParam_history"] == ih["regParam_history"] and idv["its"] == ih["its"]
+    assert np.allclose(idv["relError"], ih["relError"], rtol=1e-5)
+    assert np.allclose(idv["relResidual"], ih["relResidual"], rtol=1e-6)
+    for k in (0, its // 2, its - 1):
+        a, c = idv["xHistory"][k].reshape(-1), ih["xHistory"][k].reshape(-1)
+        assert float(torch.linalg.norm(a - c) / torch.linalg.norm(c)) < 1e-5, k

@@ -8,6 +8,9 @@
 // float64 throughout; one lane does the (inherently sequential) recurrence.
 #include "trk_internal.h"
 
+#include <map>
+#include <mutex>
+
 #include <cmath>
 #include <vector>
 
@@ -239,19 +242,9 @@ extern "C" int trk_cgs_coeffs(double* G, int ldg, const double* h, const double*
 // the device, from the Gram data the device already holds: with a NUMERIC regparam no scalar visits the host inside the
 // loop (GKS / MMGKS each paid a download, two k x k Cholesky factorisations, a stacked least-squares solve and an upload per
 // iteration: ~0.15 ms of host time with the GPU idle).  One workgroup; Cholesky in LDS, float64.
-__global__ __launch_bounds__(256) void k_gram_tikhonov(const double* __restrict__ GA, int lda, const double* __restrict__ GL, int ldl,
-                                                       const double* __restrict__ c, int k, double lam, double* __restrict__ y) {
-  extern __shared__ double sm[];              // M (k x (k+1)) | z (k)
-  const int ld = k + 1;
-  double* M = sm;
-  double* z = sm + (size_t)k * ld;
-  for (int idx = threadIdx.x; idx < k * k; idx += blockDim.x) {
-    const int i = idx / k, j = idx - i * k;
-    M[i * ld + j] = GA[(size_t)i * lda + j] + lam * GL[(size_t)i * ldl + j];
-  }
-  for (int i = threadIdx.x; i < k; i += blockDim.x) z[i] = c[i];
-  __syncthreads();
-  // M = C C^T (lower), column by column; a pivot that rounding drove to <= 0 is lifted to a tiny positive number
+// M (k x k, row stride ld, lower triangle read) z = rhs in LDS: Cholesky M = C C^T in place, then C z' = z, C^T y = z'.
+// A pivot that rounding drove to <= 0 is lifted to a tiny positive number.  All threads of the workgroup call it.
+__device__ __forceinline__ void chol_solve_lds(double* M, int ld, double* z, int k) {
   for (int j = 0; j < k; ++j) {
     if (threadIdx.x == 0) {
       const double d = M[j * ld + j];
@@ -268,7 +261,6 @@ __global__ __launch_bounds__(256) void k_gram_tikhonov(const double* __restrict_
     }
     __syncthreads();
   }
-  // C z' = c, then C^T y = z'
   for (int j = 0; j < k; ++j) {
     if (threadIdx.x == 0) z[j] /= M[j * ld + j];
     __syncthreads();
@@ -283,15 +275,166 @@ __global__ __launch_bounds__(256) void k_gram_tikhonov(const double* __restrict_
     for (int i = threadIdx.x; i < j; i += blockDim.x) z[i] -= M[j * ld + i] * zj;
     __syncthreads();
   }
+}
+
+__global__ __launch_bounds__(256) void k_gram_tikhonov(const double* __restrict__ GA, int lda, const double* __restrict__ GL, int ldl,
+                                                       const double* __restrict__ c, int k, double lam, double* __restrict__ y) {
+  extern __shared__ double sm[];              // M (k x (k+1)) | z (k)
+  const int ld = k + 1;
+  double* M = sm;
+  double* z = sm + (size_t)k * ld;
+  for (int idx = threadIdx.x; idx < k * k; idx += blockDim.x) {
+    const int i = idx / k, j = idx - i * k;
+    M[i * ld + j] = GA[(size_t)i * lda + j] + lam * GL[(size_t)i * ldl + j];
+  }
+  for (int i = threadIdx.x; i < k; i += blockDim.x) z[i] = c[i];
+  __syncthreads();
+  chol_solve_lds(M, ld, z, k);
   for (int i = threadIdx.x; i < k; i += blockDim.x) y[i] = z[i];
+}
+
+// Hybrid-GMRES's projected problem on the device (Hybrid_GMRES.py:69-77 with a numeric regparam):
+//   y = argmin || H_k y - beta0 e1 ||^2 + lam || y ||^2 ,   H_k the (k+1) x k Hessenberg matrix of Arnoldi.
+// One workgroup appends column k-1 of H from the scalars the orthogonalisation sweep left on the device (its k combined
+// Gram-Schmidt coefficients and ||w||^2), extends G = H^T H by its new row/column, and solves (G + lam I) y = beta0 H[0,:]^T.
+// H: column-major, column stride ldh >= k+1; G, Minv: row stride ldg.
+//   mode 0  Cholesky of G + lam I in LDS, from scratch: O(k^3), any k, any history of lam (what the first version always did:
+//           ~50 us per call averaged over k = 1..100 — serial time the host path hides behind the next Arnoldi step);
+//   mode 1  M = G + lam I grew by one row and column since the previous call with the same lam, and Minv holds its previous
+//           inverse: bordering update  u = Minv g, s = gamma - g.u,  Minv <- [[Minv + u u^T / s, -u / s], [-u^T / s, 1 / s]],
+//           then y = Minv c — O(k^2), four barriers, no sequential dependency (cond(M) <= ||G|| / lam: harmless in float64);
+//   mode 2  k <= 2: Minv formed directly (the start of the chain; the reference solves its first problem with lam = 0).
+__global__ __launch_bounds__(256) void k_hess_tikhonov(double* __restrict__ H, int ldh, double* __restrict__ G, double* Minv,
+                                                       int ldg, const double* __restrict__ coef, const double* __restrict__ coef2,
+                                                       const double* __restrict__ nrm2_sq, double beta0, int k, double lam,
+                                                       int mode, double* __restrict__ y) {
+  extern __shared__ double sm[];              // new column (k+1) | g (k) | u (k) | c (k) | [mode 0: M (k x (k+1)) | z (k)]
+  double* hc = sm;
+  double* g = hc + (k + 1);
+  double* u = g + k;
+  double* cv = u + k;
+  __shared__ double red[4];
+  for (int r = threadIdx.x; r <= k; r += blockDim.x) {
+    const double v = r < k ? coef[r] + (coef2 ? coef2[r] : 0.0) : sqrt(*nrm2_sq);
+    hc[r] = v;
+    H[(size_t)(k - 1) * ldh + r] = v;
+  }
+  __syncthreads();
+  // g[i] = G[i][k-1] = sum_r H[r][i] H[r][k-1]; column i of H is non-zero in rows 0 .. i+1
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    double a = 0.0;
+    if (i == k - 1) {
+      for (int r = 0; r <= k; ++r) a += hc[r] * hc[r];
+    } else {
+      const double* col = H + (size_t)i * ldh;
+      for (int r = 0; r <= i + 1; ++r) a += col[r] * hc[r];
+    }
+    g[i] = a;
+    G[(size_t)i * ldg + (k - 1)] = a;
+    G[(size_t)(k - 1) * ldg + i] = a;
+    cv[i] = beta0 * (i == k - 1 ? hc[0] : H[(size_t)i * ldh]);
+  }
+  __syncthreads();                            // (one workgroup: its own global writes are visible to it after the barrier)
+  if (mode == 0) {
+    const int ld = k + 1;
+    double* M = cv + k;
+    double* z = M + (size_t)k * ld;
+    for (int idx = threadIdx.x; idx < k * k; idx += blockDim.x) {
+      const int i = idx / k, j = idx - i * k;
+      M[i * ld + j] = G[(size_t)i * ldg + j] + (i == j ? lam : 0.0);
+    }
+    for (int i = threadIdx.x; i < k; i += blockDim.x) z[i] = cv[i];
+    __syncthreads();
+    chol_solve_lds(M, ld, z, k);
+    for (int i = threadIdx.x; i < k; i += blockDim.x) y[i] = z[i];
+    return;
+  }
+  const double gamma = g[k - 1] + lam;
+  if (mode == 2) {                            // k = 1 or 2: the inverse written out
+    if (threadIdx.x == 0) {
+      if (k == 1) {
+        Minv[0] = 1.0 / gamma;
+      } else {
+        const double a = G[0] + lam, b = g[0], det = a * gamma - b * b;
+        Minv[0] = gamma / det;
+        Minv[1] = Minv[ldg] = -b / det;
+        Minv[ldg + 1] = a / det;
+      }
+    }
+    __syncthreads();
+  } else {
+    const int m = k - 1;
+    // u = Minv g (Minv symmetric: thread i walks column i, consecutive threads read consecutive addresses)
+    double part = 0.0;
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+      double a = 0.0;
+      for (int j = 0; j < m; ++j) a += Minv[(size_t)j * ldg + i] * g[j];
+      u[i] = a;
+      part += a * g[i];
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const double sinv = 1.0 / (gamma - (red[0] + red[1] + red[2] + red[3]));     // Schur complement of the new diagonal entry
+    for (int idx = threadIdx.x; idx < m * m; idx += blockDim.x) {
+      const int i = idx / m, j = idx - i * m;
+      Minv[(size_t)i * ldg + j] += u[i] * u[j] * sinv;
+    }
+    for (int i = threadIdx.x; i < m; i += blockDim.x) {
+      Minv[(size_t)i * ldg + m] = -u[i] * sinv;
+      Minv[(size_t)m * ldg + i] = -u[i] * sinv;
+    }
+    if (threadIdx.x == 0) Minv[(size_t)m * ldg + m] = sinv;
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {                              // y = Minv c
+    double a = 0.0;
+    for (int j = 0; j < k; ++j) a += Minv[(size_t)j * ldg + i] * cv[j];
+    y[i] = a;
+  }
+}
+
+// both kernels keep the k x (k+1) factor in LDS: up to 160 KB per workgroup on gfx950 (opt-in above 64 KB)
+static int tikhonov_lds(const void* kernel, size_t bytes) {
+  constexpr size_t kMaxDyn = 159 * 1024;        // 160 KB per workgroup minus the kernels' few static bytes
+  if (bytes > kMaxDyn) return fail(TRK_EINVAL, "projected Tikhonov solve: k too large for 160 KB of LDS");
+  if (bytes > 64 * 1024) {
+    static std::mutex mu;
+    static std::map<const void*, size_t> granted;
+    std::lock_guard<std::mutex> lk(mu);
+    if (granted[kernel] < bytes) {
+      if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kMaxDyn) != hipSuccess)
+        return fail(TRK_EHIP, "projected Tikhonov solve: cannot raise the dynamic LDS limit");
+      granted[kernel] = kMaxDyn;
+    }
+  }
+  return TRK_OK;
 }
 
 extern "C" int trk_gram_tikhonov(const double* GA, int lda, const double* GL, int ldl, const double* c, int k, double lam,
                                  double* y, trk_stream st) {
   TRK_REQUIRE(GA && GL && c && y && k >= 1 && lda >= k && ldl >= k, "trk_gram_tikhonov: bad argument");
-  TRK_REQUIRE(k <= 88, "trk_gram_tikhonov: k <= 88 (the factor lives in 64 KB of LDS)");
+  TRK_REQUIRE(k <= 139, "trk_gram_tikhonov: k <= 139 (the factor lives in LDS)");
   const size_t bytes = ((size_t)k * (k + 1) + k) * sizeof(double);
+  if (int rc = tikhonov_lds(reinterpret_cast<const void*>(k_gram_tikhonov), bytes)) return rc;
   hipLaunchKernelGGL(k_gram_tikhonov, dim3(1), dim3(256), bytes, (hipStream_t)st, GA, lda, GL, ldl, c, k, lam, y);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+extern "C" int trk_hess_tikhonov(double* H, int ldh, double* G, double* Minv, int ldg, const double* coef, const double* coef2,
+                                 const double* nrm2_sq, double beta0, int k, double lam, int mode, double* y, trk_stream st) {
+  TRK_REQUIRE(H && G && coef && nrm2_sq && y && k >= 1 && ldh >= k + 1 && ldg >= k, "trk_hess_tikhonov: bad argument");
+  TRK_REQUIRE(mode >= 0 && mode <= 2 && (mode == 0 || Minv), "trk_hess_tikhonov: mode 0 (Cholesky), 1 (bordering update), 2 (k <= 2) ; modes 1, 2 need Minv");
+  TRK_REQUIRE(mode != 2 || k <= 2, "trk_hess_tikhonov: mode 2 starts the chain at k <= 2");
+  TRK_REQUIRE(mode != 1 || (k >= 2 && lam > 0.0), "trk_hess_tikhonov: the bordering update needs k >= 2 and lam > 0");
+  TRK_REQUIRE(mode != 0 || k <= 139, "trk_hess_tikhonov: Cholesky mode needs k <= 139 (the factor lives in LDS)");
+  TRK_REQUIRE(lam >= 0.0, "trk_hess_tikhonov: lam must be >= 0");
+  size_t bytes = ((size_t)(k + 1) + 3 * (size_t)k) * sizeof(double);
+  if (mode == 0) bytes += ((size_t)k * (k + 1) + k) * sizeof(double);
+  if (int rc = tikhonov_lds(reinterpret_cast<const void*>(k_hess_tikhonov), bytes)) return rc;
+  hipLaunchKernelGGL(k_hess_tikhonov, dim3(1), dim3(256), bytes, (hipStream_t)st, H, ldh, G, Minv, ldg, coef, coef2, nrm2_sq,
+                     beta0, k, lam, mode, y);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }

@@ -389,12 +389,19 @@ class HipEngine:
                                   self.stream())
         _lib.check(rc, "trk_gemv_t2")
 
-    GRAM_TIKHONOV_MAX_K = 88
+    GRAM_TIKHONOV_MAX_K = 139          # the k x (k+1) factor lives in LDS (160 KB per workgroup on gfx950)
 
     def gram_tikhonov(self, GA, lda, GL, ldl, c, k, lam, y):
         """y = (G_A + lam G_L)^-1 c on the device (k <= GRAM_TIKHONOV_MAX_K)."""
         rc = self.lib.trk_gram_tikhonov(_ptr(GA), int(lda), _ptr(GL), int(ldl), _ptr(c), int(k), float(lam), _ptr(y), self.stream())
         _lib.check(rc, "trk_gram_tikhonov")
+
+    def hess_tikhonov(self, H, ldh, G, Minv, ldg, coef, coef2, nrm2_sq, beta0, k, lam, mode, y):
+        """Arnoldi step k: append column k-1 of H (coef (+ coef2), sqrt(*nrm2_sq)), extend G = H^T H, solve
+        (G + lam I) y = beta0 H[0,:]^T on the device (trk_hess_tikhonov; mode 0 Cholesky, 1 bordering update of Minv, 2 start)."""
+        rc = self.lib.trk_hess_tikhonov(_ptr(H), int(ldh), _ptr(G), _ptr(Minv), int(ldg), _ptr(coef), _ptr(coef2),
+                                        _ptr(nrm2_sq), float(beta0), int(k), float(lam), int(mode), _ptr(y), self.stream())
+        _lib.check(rc, "trk_hess_tikhonov")
 
     def cgs_coeffs(self, G, ldg, h, g_new, k, passes, c):
         """c = coefficients of `passes` Gram-Schmidt sweeps from h = V^T r and the Gram matrix G (device doubles); g_new: Gram

@@ -42,8 +42,45 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
     n_ep = 0
 
     lams, res, lam, x_dev = [], [], 0, None
-    pend = ar.step_prefetch() if n_iter > 0 else None
-    for ii in range(n_iter):
+    # numeric regparam: the projected problem stays on the device (trk_hess_tikhonov appends the new column of H from the
+    # sweep's scalars and solves the k x k normal equations) — nothing visits the host inside the loop; H and every y are
+    # downloaded once at the end for `relResidual`
+    on_dev = (not isinstance(regparam, str)) and hasattr(eng, "hess_tikhonov") and hasattr(eng, "cgs_coeffs") \
+        and 0 < n_iter and (regparam > 0 or n_iter < eng.GRAM_TIKHONOV_MAX_K) and kwargs.get("device_solve", True)
+    if on_dev:
+        kmax = n_iter
+        Hd = eng.scalars((kmax + 1) * kmax)          # column-major, column stride kmax + 1
+        Gd = eng.scalars(kmax * kmax)
+        Mi = eng.scalars(kmax * kmax)                # (H^T H + lam I)^-1, bordered by one row and column per step
+        Yall = eng.scalars(kmax * kmax)              # y of iteration ii in row ii
+        for ii in range(n_iter):
+            k = ar._enqueue()                        # Arnoldi step k = ii + 1: its coefficients sit in ar.S[1 .. 1+2k), ||w||^2 in S[0]
+            second = ar.S.ref(1 + k) if ar.gram is None else None          # sweep-by-sweep form: two coefficient sets
+            lam = 0 if ii == 0 else regparam                                # (:55-56: the first projected problem is unregularised)
+            lams.append(lam)
+            # steps 1 (lam = 0) and 2 start the chain, every later step borders the inverse it inherits (same lam)
+            mode = 2 if k <= 2 else (1 if lam > 0 else 0)
+            eng.hess_tikhonov(Hd.ref(0), kmax + 1, Gd.ref(0), Mi.ref(0), kmax, ar.S.ref(1), second, ar.S.ref(0), ar.beta0, k,
+                              lam, mode, Yall.ref(ii * kmax))
+            x_dev = Hs.row(ii)
+            if err_fused:
+                n_ep = eng.gemv_n_err(ar.V.data, k, Yall.ref(ii * kmax), x_dev, xt, EP.ref(n_ep * ii), 1024)
+            else:
+                eng.gemv_n(ar.V.data, k, Yall.ref(ii * kmax), x_dev)       # x = V[:, :-1] @ y (:77)
+                if xt is not None:
+                    eng.diff_nrm2sq(x_dev, xt, E.ref(ii + 1))
+            Hs.pushed(ii)
+        Hh = Hd.host(0, (kmax + 1) * kmax).reshape(kmax, kmax + 1).T         # (kmax+1) x kmax
+        Yh = Yall.host(0, kmax * kmax).reshape(kmax, kmax)
+        ar.Hcols = [Hh[:j + 2, j].copy() for j in range(n_iter)]
+        for ii in range(n_iter):
+            k = ii + 1
+            bhat = np.zeros(k + 1)
+            bhat[0] = ar.beta0
+            hy = (Hh[:k + 1, :k] @ Yh[ii, :k]).reshape(-1, 1)
+            res.append(float(np.linalg.norm(bhat.reshape(1, -1) - hy)))    # the reference's broadcast quirk (:80), as below
+    pend = ar.step_prefetch() if (n_iter > 0 and not on_dev) else None
+    for ii in range(0 if not on_dev else n_iter, n_iter):
         k = ii + 1
         ar.absorb(pend)                      # column k of H; step k+1 runs while the host works on the projected problem
         pend = ar.step_prefetch() if k < n_iter else None
