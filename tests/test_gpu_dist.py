@@ -55,6 +55,10 @@ def _solve(eng, nt=4, N=32):
         out[f"{tag}_gks"] = (x.reshape(-1).cpu().numpy(), np.array(info["Residual"]))
         x, info = S.MMGKS(F, bl, L, 2, 1, 3, 5, 1e-2)
         out[f"{tag}_mmgks"] = (x.reshape(-1).cpu().numpy(), np.array(info["Residual"]))
+        # Golub-Kahan with the half steps inside the projector's output pass (tomo: trk_op_apply_axpby, norms all-reduced
+        # between the two applies of a step) / by apply + axpby (blur)
+        x, info = S.Hybrid_LSQR(F, bl, 8, 1e-2)
+        out[f"{tag}_lsqr"] = (x.reshape(-1).cpu().numpy(), np.array(info["regParam_history"], dtype=np.float64))
     return out
 
 
