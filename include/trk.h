@@ -236,7 +236,9 @@ int trk_cgls_xp_update(int64_t n, const double* gamma_old, const double* delta, 
  *   x1/x2); sum(y*y) is left as *n_partials raw block partials in ysq_partials (capacity given).
  *     forward : x1 = t, x2 = p_old, cb = +gamma_k/gamma_{k-1}  -> comb = p_new (CGLS.py:72), y = w = A p_new (:60), ||w||^2 (:61)
  *     adjoint : x1 = r_old, x2 = w, cb = -gamma/delta          -> comb = r_new (:67),       y = t = A^T r_new (:68), ||t||^2 (:70)
- *   x2 = NULL: y = Op(x1) by the plain one-operand kernel (sign, num, den, comb_out ignored), sum(y*y) still left raw. */
+ *   x2 = NULL: y = Op(x1) by the plain one-operand kernel (sign, num, den, comb_out ignored), sum(y*y) still left raw.
+ * trk_op_fused_caps: *can_fuse = 0 (no fused apply), 1 (both forms: the separable blur), 2 (only x2 = NULL: the Radon
+ * projector, whose band reduction / tile gather leave the partials; enough for the four-launch CGLS iteration). */
 int trk_op_fused_caps(const trk_op* op, int* can_fuse);
 int trk_op_apply_fused(trk_op* op, int transpose, const float* x1, const float* x2, double sign, const double* num,
                        int num_n, const double* den, int den_n, float* comb_out, float* y, double* ysq_partials,

@@ -194,3 +194,46 @@ def test_tiled_cgls_against_the_reference_golden():
     A = Blur2D(g["psf"], int(g["N"]), int(g["N"]))
     x, info = CGLS(A, g["b"], g["x0"], int(g["max_iter"]), 0, g["x_true"], tiled=True)
     assert relerr(x, g["x"]) < 1e-5 and np.allclose(info["relError"], g["relError"], rtol=1e-4)
+
+
+@pytest.mark.parametrize("case", ["static", "dynamic", "large_tiles"])
+def test_radon_cgls_raw_partials_form_equals_finalized_form(case):
+    """The projector's one-operand fused apply (trk_op_apply_fused with x2 = NULL: ||A p||^2, ||A^T r||^2 left as the block
+    partials of the band reduction / tile gather, added up by the CGLS update kernels — four launches, no reduction launch)
+    against the same recurrence with finished scalars; the C loop against the stepwise driver; trk_op_fused_caps = 2."""
+    from trips_py_amd.operators import BlockDiagOp, Radon2DParallel
+    from trips_py_amd.solvers import CGLSRun
+    from trips_py_amd.solvers.CGLS import CGLSRunFused
+    if case == "static":
+        A = Radon2DParallel(128, np.linspace(0, np.pi, 60, endpoint=False))
+    elif case == "dynamic":
+        A = BlockDiagOp([Radon2DParallel(64, np.deg2rad(5.0 * t + 12.0 * np.arange(15))) for t in range(4)])
+    else:                        # 1100^2: more adjoint tiles than CGLSRun.PCAP partial slots -> one finished value instead
+        A = Radon2DParallel(2200, np.linspace(0, np.pi, 6, endpoint=False))
+    eng = A.engine
+    assert eng.op_can_fuse(A._h) == 2 and not CGLSRunFused.usable(A, eng)
+    m, n = A.shape
+    g = torch.Generator(device=eng.device).manual_seed(9)
+    xt = torch.rand(n, device=eng.device, generator=g)
+    b = A.apply(xt)
+    b = b + 0.02 * torch.randn(m, device=eng.device, generator=g) * b.norm() / m ** 0.5
+    x0 = torch.zeros(n, device=eng.device)
+    its = 12
+    raw = CGLSRun(A, b, x0, its, x_true=xt, history=True, defer_norms=True)
+    fin = CGLSRun(A, b, x0, its, x_true=xt, history=True, defer_norms=False)
+    twin = CGLSRun(A, b, x0, its, x_true=xt, history=True, defer_norms=True)
+    assert raw.raw and not fin.raw
+    raw.run(its)
+    for _ in range(its):
+        fin.step()
+        twin.step()
+    assert np.array_equal(raw.rows()[1], twin.rows()[1]) and torch.equal(raw.X[its - 1], twin.X[its - 1])
+    g0r, Rr = raw.rows()
+    g0f, Rf = fin.rows()
+    # (two fp32 recurrences whose scalars are summed in different orders: every iterate agrees to fp32 rounding; delta, gamma
+    #  and ||dx||^2 can pass through stretches where CG amplifies that rounding to 1e-4 ... 1e-3 of their current — by then tiny —
+    #  values, so the scalar rows are compared where they are well conditioned: the first four iterations)
+    assert np.isclose(g0r, g0f, rtol=1e-12) and np.allclose(Rr[:4], Rf[:4], rtol=1e-6, atol=0)
+    for k in range(its):
+        assert relerr(raw.X[k].cpu().numpy(), fin.X[k].cpu().numpy()) < 5e-6, k
+    assert relerr(raw.X[its - 1].cpu().numpy(), fin.X[its - 1].cpu().numpy()) < 5e-6

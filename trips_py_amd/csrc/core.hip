@@ -230,7 +230,7 @@ int trk_op_flush(trk_op* op, trk_stream stream) {
 
 int trk_op_fused_caps(const trk_op* op, int* can_fuse) {
   TRK_REQUIRE(op && can_fuse, "trk_op_fused_caps: NULL argument");
-  *can_fuse = op->apply_fused ? 1 : 0;
+  *can_fuse = op->apply_fused ? op->fused_caps : 0;
   return TRK_OK;
 }
 

@@ -1029,8 +1029,10 @@ int radon_flush(trk_op* op, hipStream_t s) {
 }
 
 // Plain apply (epi.on = 0, hints = 0) and the fused form of trk_op_apply_axpby (batch 1) share this.
+// ext_part / ext_cap / ext_n (trk_op_apply_fused with x2 = NULL): the fused norm is LEFT as block partials in the caller's buffer
+// (*ext_n of them; one finished value if they do not fit) for a consumer kernel to add up — no finalize launch.
 int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq, Epi epi,
-              int hints, hipStream_t s) {
+              int hints, hipStream_t s, double* ext_part = nullptr, int ext_cap = 0, int* ext_n = nullptr) {
   auto* im = static_cast<RadonImpl*>(op->impl);
   const int N = im->N, nd = im->nd, na = im->na, nt = im->nt;
   TimerScope tm(op->timer, op->timer_which, tr, s);
@@ -1067,18 +1069,24 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   const bool adj_prep = !tile || na > 32;            // few angles per frame: the tile kernel makes its records itself
   if (epi.on && (batch != 1 || (tr && !tile))) return fail(TRK_EUNSUPPORTED, "radon: fused epilogue needs batch 1 and the tiled adjoint");
   // the forward's band reduction carries the epilogue / the fused norm / the adjoint's records
-  const bool post = epi.on || im->n_bands > 1;
+  const bool post = epi.on || im->n_bands > 1 || ext_part;
+  if (ext_part) sumsq = ext_part;          // where a finished value goes when the partials do not fit / no kernel makes any
   const bool fuse_ssq = sumsq && batch == 1 && (tr ? tile : post);
   const int64_t post_blocks = ceil_div((int64_t)nt * na * ndp, 256);
   const int64_t n_part = tr ? adj_blocks * nt : post_blocks;
   const bool defer = fuse_ssq && epi.on && (hints & HINT_SUMSQ_DEFERRED) && n_part <= im->pend_cap;
-  if (defer) {
+  const bool raw_out = ext_part && fuse_ssq && n_part <= ext_cap;
+  if (ext_n) *ext_n = raw_out ? (int)n_part : 1;
+  if (raw_out) {
+    ssq_part = ext_part;
+  } else if (defer) {
     ssq_part = im->pend_buf[im->pend_which];        // not the buffer a pending norm of the previous apply is read from
     im->pend_which ^= 1;
   } else if (fuse_ssq) {
     if (int rc = scratch_doubles(s, (size_t)n_part, &ssq_part)) return rc;
   }
   auto finish_norm = [&]() -> int {
+    if (raw_out) return TRK_OK;
     if (defer) {
       im->pend_target = sumsq;
       im->pend_part = ssq_part;
@@ -1188,6 +1196,17 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
 int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
                 hipStream_t s) {
   return radon_run(op, tr, x, ldx, y, ldy, batch, sumsq, Epi{}, 0, s);
+}
+
+// trk_op_apply_fused for the projector: only its one-operand form (x2 = NULL) — y = Op(x1) with sum(y^2) left as the block
+// partials of the kernel that writes y (band reduction / tile gather), which the CGLS update kernels add up themselves
+// (trk_cgls_update_xr_src, trk_cgls_p_update): the two reduction launches of a CGLS iteration disappear.
+int radon_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, double, ScalarSrc, ScalarSrc, float*, float* y,
+                      double* partials, int cap, int* n_partials, hipStream_t s) {
+  if (x2) return fail(TRK_EUNSUPPORTED, "radon: the two-operand fused apply is not available (trk_op_fused_caps reports 2)");
+  if (cap < 1) return fail(TRK_EINVAL, "radon: fused apply needs room for at least one partial");
+  return radon_run(op, tr, x1, tr ? op->rows : op->cols, y, tr ? op->cols : op->rows, 1, nullptr, Epi{}, 0, s, partials, cap,
+                   n_partials);
 }
 
 // out = a * Op(x) + b * z (+ ||out||^2) inside the kernel that writes the output: the band reduction (forward) or the tile
@@ -1318,6 +1337,8 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
   *out = new trk_op{2, (int64_t)n_ang * n_det, (int64_t)nt * N * N, im, radon_apply, radon_destroy, nullptr, 0};
   (*out)->apply_axpby = radon_apply_axpby;
   (*out)->flush = radon_flush;
+  (*out)->apply_fused = radon_apply_fused;
+  (*out)->fused_caps = 2;                  // raw block partials only, no two-operand form
   return TRK_OK;
 }
 

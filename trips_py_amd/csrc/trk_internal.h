@@ -214,6 +214,7 @@ struct trk_op {
   int (*apply_fused)(trk_op*, int transpose, const float* x1, const float* x2, double sign, trk::ScalarSrc num,
                      trk::ScalarSrc den, float* comb, float* y, double* partials, int cap, int* n_partials,
                      hipStream_t s) = nullptr;
+  int fused_caps = 1;    // what apply_fused can do (trk_op_fused_caps): 1 = everything, 2 = only x2 = NULL (raw block partials)
   // optional: out = a * Op(x) + b * z (+ ||out||^2) inside the operator's own output pass (trk_op_apply_axpby); hints: TRK_HINT_*
   int (*apply_axpby)(trk_op*, int transpose, const float* x, trk::Coef a, trk::Coef b, const float* z, float* out,
                      double* sumsq, int hints, hipStream_t s) = nullptr;

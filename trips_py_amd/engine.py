@@ -275,7 +275,7 @@ class HipEngine:
     def op_can_fuse(self, handle):
         can = ctypes.c_int(0)
         _lib.check(self.lib.trk_op_fused_caps(handle, ctypes.byref(can)), "trk_op_fused_caps")
-        return bool(can.value)
+        return can.value                   # 0: no; 1: two-operand form and raw partials; 2: raw partials only
 
     def op_apply_fused(self, handle, transpose, x1, x2, sign, num, num_n, den, den_n, comb, y, partials, capacity):
         """x2 = None: the plain one-operand apply with ||y||^2 left as raw block partials."""

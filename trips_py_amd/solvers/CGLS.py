@@ -60,9 +60,9 @@ class CGLSRun:
         self.defer = bool(defer_norms) and eng.world == 1 and hasattr(eng, "cgls_update_deferred")
         self.NP = eng.scalars(3 * 1024 * max_iter) if self.defer else None
         self.n_np = 0
-        # operators that can leave ||A p||^2 / ||A^T r||^2 as raw block partials (the blur): the consumers add them up and
+        # operators that can leave ||A p||^2 / ||A^T r||^2 as raw block partials (the blur, the Radon projector): the consumers add them up and
         # the two reduction-finalize launches of the iteration disappear (six launches -> four)
-        self.raw = (self.defer and hasattr(eng, "cgls_p_update") and hasattr(A, "_h") and eng.op_can_fuse(A._h))
+        self.raw = bool(self.defer and hasattr(eng, "cgls_p_update") and hasattr(A, "_h") and eng.op_can_fuse(A._h))
         self.PG = eng.scalars(self.PCAP) if self.raw else None
         self.PD = eng.scalars(self.PCAP) if self.raw else None
         # raw form only: 0 = [x, r] / [p] update kernels, 1 = [r] / [x, p] (p read once); None: the library's rule by size
@@ -207,7 +207,7 @@ class CGLSRunFused(CGLSRun):
     @staticmethod
     def usable(A, eng):
         return (getattr(eng, "is_native", False) and eng.world == 1 and hasattr(A, "_h") and A.shape[0] == A.shape[1]
-                and eng.op_can_fuse(A._h))
+                and eng.op_can_fuse(A._h) == 1)
 
     # Small images (tiled = True): the same recurrence in TWO launches per iteration (trk_cgls_iterate_tiled: a workgroup per
     # 32 x 32 tile recomputes its halo of p and w in LDS instead of waiting for its neighbours at a kernel boundary).
