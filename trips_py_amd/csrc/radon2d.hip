@@ -302,14 +302,16 @@ __global__ __launch_bounds__(256) void k_radon_fwd(const float* __restrict__ img
 // LDS address, one ds_read2_b32, one packed FMA.
 #define LDS_R 16
 #define LDS_W 112
+#define LDS_WT 116    // row stride of a tile staged through the transposing path (direct1)
 
 template <bool FINAL, bool DMA = false>
 __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__ img, const float* __restrict__ imgT,
                                                        float* __restrict__ out, int N, int nd,
                                                        const AngleParam* __restrict__ ang, int na_per_frame,
                                                        int ngrp_per_frame, int ndblk, int64_t band_stride, int bh,
-                                                       const unsigned* __restrict__ A32, const unsigned* __restrict__ B32, int npad) {
-  __shared__ __attribute__((aligned(16))) float tile[4][LDS_R * LDS_W];
+                                                       const unsigned* __restrict__ A32, const unsigned* __restrict__ B32, int npad,
+                                                       int direct1) {
+  __shared__ __attribute__((aligned(16))) float tile[4][LDS_R * LDS_WT];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int grp = blockIdx.x / ndblk, dblk = blockIdx.x - grp * ndblk;
   const int frame = grp / ngrp_per_frame;
@@ -317,7 +319,11 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
   if (af >= na_per_frame) return;
   const int a = frame * na_per_frame + af;                         // global angle index (frame-major)
   const AngleParam p = ang[a];
-  const float* __restrict__ I = (p.mode ? imgT : img) + (int64_t)frame * N * N;
+  // direct1: angles marched along COLUMNS read the image itself and transpose while staging (no transposed copy, no launch
+  // for it): the window is then 112 image rows x 16 columns, a lane's float4 is four marching steps of one row
+  const bool tdir = direct1 && p.mode;                             // wave-uniform
+  const float* __restrict__ I = ((p.mode && !tdir) ? imgT : img) + (int64_t)frame * N * N;
+  const int rs4 = __builtin_amdgcn_readfirstlane((tdir ? LDS_WT : LDS_W) * 4);   // byte stride of a tile row
   const unsigned img_bytes = (unsigned)N * (unsigned)N * 4u;
   const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)I, 0, img_bytes, 0x00020000);
   float* __restrict__ T = tile[wv];
@@ -362,6 +368,27 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
       // address is the wave-uniform soffset, the lane part is chunk-invariant but for the window start cs
       f4r v[7];
       const unsigned rowbase = (unsigned)tb * (unsigned)N * 4u;
+      if (tdir) {
+        // slot idx = lane + 64 i: window coordinate cw = idx / 4 (an image ROW cs + cw), marching steps 4 q .. 4 q + 3, q = idx % 4
+        // (image COLUMNS tb + 4 q ..: inside the row because N % 4 == 0); element e goes to tile row 4 q + e, column cw.  The
+        // transposed tile has row stride LDS_WT = 116: the four q of a row then fall into different banks
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          const int idx = lane + 64 * i;
+          const int cw = idx >> 2, q = idx & 3;
+          const int row = cs + cw;
+          const bool ok = (unsigned)row < (unsigned)N && tb + 4 * q < N;
+          const int voff = ok ? (row * N + tb + 4 * q) * 4 : (int)img_bytes;
+          v[i] = __builtin_bit_cast(f4r, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, 0, 0));
+        }
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+          const int idx = lane + 64 * i;
+          const int cw = idx >> 2, q = idx & 3;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) T[(4 * q + e) * LDS_WT + cw] = v[i][e];
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < 7; ++i) {
         const int col = cs + sc4[i];
@@ -379,6 +406,7 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
 #pragma unroll
         for (int i = 0; i < 7; ++i) *reinterpret_cast<f4r*>(&T[slds[i]]) = v[i];
       }
+      }
       __builtin_amdgcn_wave_barrier();
       const unsigned Ac = A - ((unsigned)cs << QF);               // column relative to the window (mod 256)
       auto march = [&](auto full_tag) {
@@ -394,7 +422,7 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
           if (!FULL) c = c > (unsigned)(LDS_W - 2) ? (unsigned)(LDS_W - 2) : c;   // dead lanes / rows beyond te may point anywhere
           // byte address = row base [scalar, opaque to the optimiser so that it stays a scalar add and is not turned into a
           // per-lane one] + 4 c [one v_lshl_add]; both taps with one ds_read2_b32
-          int rowoff4 = u * LDS_W * 4;
+          int rowoff4 = u * rs4;
           asm("" : "+s"(rowoff4));
           const float* tp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(T) + rowoff4 + (c << 2));
           t2[u] = (f2v){tp[0], tp[1]};
@@ -1018,6 +1046,28 @@ __global__ __launch_bounds__(256) void k_radon_adj_simple(const uint4* __restric
   }
 }
 
+// Which forward kernel an input at `xb` gets: per-wave LDS windows (N % 4 == 0, 16-byte aligned input; DMA = staged by direct-to-LDS
+// loads), the window-sharing kernel from 1024^2 on, else direct gathers.  direct1: the per-wave-window kernel reads the angles
+// marched along columns from the image itself, transposing while it stages — no transposed copy, no launch for it (512^2 x 180:
+// the copy was 5 of the apply's 31 us; 32 frames of 256^2: 5.8 of 23).  The window-sharing kernel keeps the copy (2.6 % at 4096^2).
+struct FwdPath {
+  bool lds, dma, win, direct1;
+};
+FwdPath fwd_path(const RadonImpl* im, const float* xb) {
+  static const bool no_lds = getenv("TRK_RADON_NO_LDS") != nullptr;
+  // global -> LDS directly (buffer_load_dwordx4 ... lds, new on gfx950) instead of through registers: 1.30 -> 1.11 ms at 4096^2
+  static const bool dma = getenv("TRK_RADON_NO_DMA") == nullptr;
+  static const bool no_win = getenv("TRK_RADON_NO_WIN") != nullptr;
+  static const bool no_direct1 = getenv("TRK_RADON_NO_DIRECT1") != nullptr;
+  FwdPath f;
+  f.lds = !no_lds && (im->N % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15u) == 0);
+  f.dma = dma;
+  // measured: 512^2 35 us (shared) vs 32 us (per-wave windows); 2048^2 0.256 vs 0.277 ms; 4096^2 0.96 vs 1.11 ms
+  f.win = im->n_bands > 1 && im->N >= 1024 && f.lds && dma && !no_win && im->band <= WIN_R * WIN_MAXCH;
+  f.direct1 = f.lds && !f.win && !no_direct1;
+  return f;
+}
+
 constexpr int HINT_OUT_FEEDS_OPPOSITE = 1, HINT_INPUT_FROM_OPPOSITE = 2, HINT_SUMSQ_DEFERRED = 4;   // = TRK_HINT_* (trk.h)
 
 int radon_flush(trk_op* op, hipStream_t s) {
@@ -1098,40 +1148,38 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   if (!tr) {
     for (int b = 0; b < batch; ++b) {  // the transposed copy is per vector
       const float* xb = x + (int64_t)b * ldx;
-      if (im->n_mode1 > 0) {
+      const FwdPath fp = fwd_path(im, xb);
+      const bool lds = fp.lds, dma = fp.dma;
+      const int direct1 = fp.direct1 ? 1 : 0;
+      if (im->n_mode1 > 0 && !fp.direct1) {
         if ((hints & HINT_INPUT_FROM_OPPOSITE) && im->xT_src == xb) {
           // the adjoint that produced xb left its transpose in xT already
         } else {
           dim3 g(ceil_div(N, 32), ceil_div(N, 32), nt);
           hipLaunchKernelGGL(k_transpose, g, dim3(256), 0, s, xb, im->xT, N);
         }
-        im->xT_src = nullptr;            // holds for this apply only: the caller's promise covers the very next one
       }
+      im->xT_src = nullptr;              // holds for this apply only: the caller's promise covers the very next one
       const int ndblk = ceil_div(nd, 64), ngrp = ceil_div(na, 4), nb = im->n_bands;
       const int64_t bs = (int64_t)nt * na * nd;
       dim3 grid(ndblk * ngrp * nt, nb, 1);
       float* yb = y + (int64_t)b * ldy;
-      static const bool no_lds = getenv("TRK_RADON_NO_LDS") != nullptr;
-      // global -> LDS directly (buffer_load_dwordx4 ... lds, new on gfx950) instead of through registers: 1.30 -> 1.11 ms at 4096^2
-      static const bool dma = getenv("TRK_RADON_NO_DMA") == nullptr;
-      const bool lds = !no_lds && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15u) == 0);
-      static const bool no_win = getenv("TRK_RADON_NO_WIN") != nullptr;
       static const bool no_rec_out = getenv("TRK_RADON_NO_REC_OUT") != nullptr;     // tuning knobs: the producer side of the hints off
       const bool want_rec = (hints & HINT_OUT_FEEDS_OPPOSITE) && tile && adj_prep && batch == 1 && !no_rec_out;
       // measured: 512^2 35 us (shared) vs 32 us (per-wave windows); 2048^2 0.256 vs 0.277 ms; 4096^2 0.96 vs 1.11 ms
-      if (nb > 1 && N >= 1024 && lds && dma && !no_win && im->band <= WIN_R * WIN_MAXCH) {
+      if (fp.win) {
         // window-sharing kernel: band partials of rays no window owns must read as zero
         if (hipMemsetAsync(im->part, 0, sizeof(float) * (size_t)nb * bs, s) != hipSuccess) return fail(TRK_EHIP, "radon: hipMemsetAsync failed");
         const int nwin = ceil_div(N + 2 * im->band + 16, 61);
         dim3 gw(nwin * ngrp * nt, nb, 1);
         hipLaunchKernelGGL(k_radon_fwd_win<0>, gw, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, nwin, bs, im->band, im->fidx, im->A32, im->B32, im->npad);
       } else if (!post) {
-        if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<true, true>), grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
-        else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
+        if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<true, true>), grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad, direct1);
+        else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad, direct1);
         else hipLaunchKernelGGL(k_radon_fwd<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
       } else {
-        if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<false, true>), grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
-        else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
+        if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<false, true>), grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad, direct1);
+        else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad, direct1);
         else hipLaunchKernelGGL(k_radon_fwd<false>, grid, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad);
       }
       if (post) {
@@ -1159,7 +1207,8 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
         im->rec_src = nullptr;
       }
       static const bool no_xt_out = getenv("TRK_RADON_NO_XT_OUT") != nullptr;
-      float* xT_out = ((hints & HINT_OUT_FEEDS_OPPOSITE) && tile && im->n_mode1 > 0 && batch == 1 && !no_xt_out) ? im->xT : nullptr;
+      float* xT_out = ((hints & HINT_OUT_FEEDS_OPPOSITE) && tile && im->n_mode1 > 0 && batch == 1 && !no_xt_out &&
+                       !fwd_path(im, y + (int64_t)b * ldy).direct1) ? im->xT : nullptr;
 #define ADJ_TILE(TT, PP, BB, PR)                                                                                              \
   hipLaunchKernelGGL((k_radon_adj_tile<TT, PP, BB, PR>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, xb, im->rec,          \
                      y + (int64_t)b * ldy, N, nd, na, im->adj_ang, im->adj_wgt, im->A32, im->adj_n0, im->CB, im->npad, tiles_x, \
