@@ -1325,6 +1325,13 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     }
   }
   int band = RADON_BAND;
+  {
+    // small frames (dynamic problems: 256^2 x 15 angles): 64-row bands double the workgroups of a grid that cannot fill the chip —
+    // measured per apply: 4 frames (one rank's share of 32 on 8 GPUs) 13.2 -> 10.7 us, 8 frames 14.5 -> 11.6, 16 frames 17.7 -> 17.4,
+    // 32 frames 24.6 -> 25.4.  Decided per FRAME, so that a dynamic handle and its frames' own handles sum in the same order.
+    const int64_t wgs128 = (int64_t)((n_det + 63) / 64) * ((na + 3) / 4) * ((N + RADON_BAND - 1) / RADON_BAND);
+    if (wgs128 < 64 && N > 64) band = 64;
+  }
   if (const char* e = getenv("TRK_RADON_BAND")) {               // tuning knob; kept a positive multiple of RADON_CHUNK
     band = atoi(e);
     band = band < RADON_CHUNK ? RADON_CHUNK : (band / RADON_CHUNK) * RADON_CHUNK;
