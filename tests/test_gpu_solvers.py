@@ -286,3 +286,29 @@ def test_hybrid_gmres_device_projected_solve_equals_the_host_one(N, its):
     for k in (0, its // 2, its - 1):
         a, c = idv["xHistory"][k].reshape(-1), ih["xHistory"][k].reshape(-1)
         assert float(torch.linalg.norm(a - c) / torch.linalg.norm(c)) < 1e-5, k
+
+
+def test_gks_gram_rows_from_v_equal_the_stored_images_form():
+    """GKS on stencil operators keeps no AV / LV: G_A, G_L rows come from one sweep over V with A^T A v_new and L^T L v_new
+    (trk_gemv_t2).  Same iterates and lambda history as the stored-images form, on the reference golden and on a 256^2 problem
+    with the automatic selector (the host-side Gram path)."""
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import Blur2D, FirstDerivative2D
+    from trips_py_amd.problems import gauss_psf
+    g = load_golden("gks_blur32_lam1e-2")
+    N = int(g["N"])
+    L = FirstDerivative2D(N)
+    xa, ia = S.GKS(blur(g), g["b"], L, int(g["projection_dim"]), int(g["n_iter"]), 1e-2, g["x_true"])
+    xb, ib = S.GKS(blur(g), g["b"], L, int(g["projection_dim"]), int(g["n_iter"]), 1e-2, g["x_true"], gram_from_v=False)
+    assert relerr(xa, g["x"]) < TOL and relerr(xb, g["x"]) < TOL and relerr(xa, xb) < 5e-6
+    N = 256
+    A = Blur2D(gauss_psf((9, 9), (2, 2))[0], N, N)
+    dev = A.engine.device
+    xt = torch.rand(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    b = A.apply(xt)
+    b = b + 0.01 * torch.randn(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(2)) * b.norm() / N
+    for rp in (1e-2, "gcv"):
+        xa, ia = S.GKS(A, b, FirstDerivative2D(N), 3, 25, rp, xt)
+        xb, ib = S.GKS(A, b, FirstDerivative2D(N), 3, 25, rp, xt, gram_from_v=False)
+        assert float(torch.linalg.norm(xa - xb) / torch.linalg.norm(xb)) < (2e-5 if rp == 1e-2 else 5e-3), rp
+        assert np.allclose(ia["relError"], ib["relError"], rtol=1e-4 if rp == 1e-2 else 1e-2)

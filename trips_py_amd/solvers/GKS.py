@@ -21,9 +21,15 @@ from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikho
 
 
 class _ProjectedBases:
-    """V, AV, LV and the incrementally maintained Gram data  G_A = AV AV^T, G_L = LV LV^T, c = AV b."""
+    """V and the incrementally maintained Gram data  G_A = (AV)^T AV, G_L = (LV)^T LV, c = (AV)^T b.
 
-    def __init__(self, A, L, bv, V0, kmax, on_device=False):
+    from_v_A / from_v_L (stencil operators, whose products with the iterate are formed directly from x): the images AV, LV are
+    never stored.  G_A[i][j] = v_i . (A^T A v_j), so the new row is V^T z_A with z_A = A^T (A v_new) — one pass over V (n floats
+    per vector) instead of one over AV (m) — and likewise G_L from z_L = L^T L v_new instead of a pass over LV (p = 2n .. 3n floats
+    per vector); both right-hand sides share ONE sweep over V (trk_gemv_t2), and c[j] = v_j . (A^T b).  Otherwise (the Radon
+    projector: m is small and the residual wants (AV) y) the images are kept as row-per-vector bases as before."""
+
+    def __init__(self, A, L, bv, V0, kmax, on_device=False, from_v_A=False, from_v_L=False):
         self.A, self.L, self.eng, self.bv = A, L, A.engine, bv
         eng = self.eng
         # on_device: the Gram data stays on the device (rows installed by a tiny kernel) and nothing is downloaded — the
@@ -37,8 +43,15 @@ class _ProjectedBases:
         p = L.shape[0]
         self.V = V0
         self.V.reserve(kmax)
-        self.AV = DeviceBasis(eng, m, kmax)
-        self.LV = DeviceBasis(eng, p, kmax)
+        self.from_v_A, self.from_v_L = bool(from_v_A), bool(from_v_L)
+        self.AV = None if self.from_v_A else DeviceBasis(eng, m, kmax)
+        self.LV = None if self.from_v_L else DeviceBasis(eng, p, kmax)
+        if self.from_v_A:
+            self.tA, self.zA, self.atb = eng.empty(m), eng.empty(n), eng.empty(n)
+            A.apply(bv, out=self.atb, transpose=True)
+        if self.from_v_L:
+            self.zL = eng.empty(n)
+            self.tL = None if hasattr(L, "tv_grad") else eng.empty(p)
         self.GA = np.zeros((kmax, kmax))
         self.GL = np.zeros((kmax, kmax))
         self.c = np.zeros(kmax)
@@ -47,24 +60,47 @@ class _ProjectedBases:
             self._push_images(j)
 
     def _push_images(self, j):
-        """AV[j] = A V[j], LV[j] = L V[j], and row/column j of the Gram data (k+1 dots each, one pass over the basis)."""
+        """Row / column j of the Gram data (and, where they are kept, AV[j] = A V[j], LV[j] = L V[j])."""
         eng, S = self.eng, self.S
-        av, lv = self.AV.next_slot(), self.LV.next_slot()
-        self.A.apply(self.V[j], out=av)
-        self.L.apply(self.V[j], out=lv)
-        self.AV.commit()
-        self.LV.commit()
+        v = self.V[j]
         k = j + 1
-        eng.gemv_t(self.AV.data, k, av, S.ref(0))
-        eng.gemv_t(self.LV.data, k, lv, S.ref(k))
+        c_out = self.c_d.ref(j) if self.on_device else S.ref(2 * k)
+        if self.from_v_A:
+            self.A.apply(v, out=self.tA)
+            self.A.apply(self.tA, out=self.zA, transpose=True)            # z_A = A^T A v
+            eng.dot(v, self.atb, c_out)                                   # c_j = (A v_j) . b = v_j . (A^T b)
+        else:
+            av = self.AV.next_slot()
+            self.A.apply(v, out=av)
+            self.AV.commit()
+            eng.dot(av, self.bv, c_out)
+        if self.from_v_L:
+            if self.tL is None:
+                self.L.tv_grad(v, None, None, 1.0, out=self.zL)           # z_L = L^T L v in one stencil pass
+            else:
+                self.L.apply(v, out=self.tL)
+                self.L.apply(self.tL, out=self.zL, transpose=True)
+        else:
+            lv = self.LV.next_slot()
+            self.L.apply(v, out=lv)
+            self.LV.commit()
+        if self.from_v_A and self.from_v_L:
+            eng.gemv_t2(self.V.data, k, self.zA, self.zL, S.ref(0))       # both Gram rows from one sweep over V
+        else:
+            if self.from_v_A:
+                eng.gemv_t(self.V.data, k, self.zA, S.ref(0))
+            else:
+                eng.gemv_t(self.AV.data, k, av, S.ref(0))
+            if self.from_v_L:
+                eng.gemv_t(self.V.data, k, self.zL, S.ref(k))
+            else:
+                eng.gemv_t(self.LV.data, k, lv, S.ref(k))
         if self.on_device:
-            eng.dot(av, self.bv, self.c_d.ref(j))
             eng.allreduce(S, 0, 2 * k)
             eng.allreduce(self.c_d, j, j + 1)
             eng.cgs_coeffs(self.GA_d.ref(0), self.kmax, None, S.ref(0), k, 0, None)     # install row / column j
             eng.cgs_coeffs(self.GL_d.ref(0), self.kmax, None, S.ref(k), k, 0, None)
             return
-        eng.dot(av, self.bv, S.ref(2 * k))
         eng.allreduce(S, 0, 2 * k + 1)
         h = S.host(0, 2 * k + 1)
         self.GA[j, :k] = self.GA[:k, j] = h[:k]
@@ -99,7 +135,9 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     # iteration); the automatic selectors need the factors on the host
     on_dev = (not isinstance(regparam, str)) and hasattr(eng, "gram_tikhonov") and hasattr(eng, "cgs_coeffs") \
         and kmax <= eng.GRAM_TIKHONOV_MAX_K and kwargs.get("device_solve", True)
-    pb = _ProjectedBases(A, L, bv, gk.V, kmax, on_device=on_dev)
+    dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
+    from_v = hasattr(eng, "gemv_t2") and kwargs.get("gram_from_v", True)
+    pb = _ProjectedBases(A, L, bv, gk.V, kmax, on_device=on_dev, from_v_A=dA and from_v, from_v_L=dL and from_v)
     Hs = History(eng, kwargs.get("history", True), n_iter, n, "GKS xHistory")
     Y = eng.scalars(kmax)
     H = eng.scalars(3 * kmax)
@@ -112,7 +150,6 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     eng.allreduce(E, 0, 2)
     b2 = float(E.host(1, 2)[0])
 
-    dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
     fusedL = dL and hasattr(L, "tv_grad") and kwargs.get("fused_tv", True)
     gs_gram = GramSchmidtByGram(eng, pb.V, kmax) if (hasattr(eng, "cgs_coeffs") and kwargs.get("gram_sweeps", True)) else None
     lams, lam, x_dev = [], None, None
