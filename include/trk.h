@@ -342,12 +342,16 @@ int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y
 int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G_dev,
               double* c1_dev, double* c2_dev, trk_stream stream);
 
-/* y = (G_A + lam G_L)^-1 c on the device (float64, one workgroup, k <= 139: the factor lives in LDS): the projected Tikhonov problem of GKS.py:74 /
- * MMGKS.py:106, `lstsq([R_A; sqrt(lam) R_L], [Q_A^T b; 0])`, from the Gram data G_A = (AV)^T AV, G_L = (LV)^T LV (row strides
- * lda, ldl) and c = (AV)^T b that trk_gemv_t / trk_wgram leave on the device — a numeric regparam then needs no host round trip
- * inside the loop. */
+/* y = (G_A + lam G_L)^-1 c on the device (float64, one workgroup): the projected Tikhonov problem of GKS.py:74 / MMGKS.py:106,
+ * `lstsq([R_A; sqrt(lam) R_L], [Q_A^T b; 0])`, from the Gram data G_A = (AV)^T AV, G_L = (LV)^T LV (row strides lda, ldl) and
+ * c = (AV)^T b that trk_gemv_t / trk_gemv_t2 / trk_wgram leave on the device — a numeric regparam then needs no host round
+ * trip inside the loop.
+ *   Minv_dev == NULL: Cholesky from scratch in LDS, O(k^3), k <= 139 (MMGKS: both Gram matrices change every iteration);
+ *   Minv_dev != NULL (row stride ldm >= k): the inverse of the leading k_from x k_from block of G_A + lam G_L, left there by the
+ *     previous call with the same lam, is bordered by rows k_from .. k-1 — O(k^2) per new row, any k (GKS: the Gram matrices
+ *     only grow).  k_from = 0 builds it from nothing. */
 int trk_gram_tikhonov(const double* GA_dev, int lda, const double* GL_dev, int ldl, const double* c_dev, int k, double lam,
-                      double* y_dev, trk_stream stream);
+                      double* Minv_dev, int ldm, int k_from, double* y_dev, trk_stream stream);
 /* Hybrid-GMRES's projected problem on the device (Hybrid_GMRES.py:69-77 with a numeric regparam):
  *   y = argmin || H_k y - beta0 e1 ||^2 + lam || y ||^2 ,  H_k the (k+1) x k Hessenberg matrix of Arnoldi (decompositions.py:207-228).
  * One call per Arnoldi step k = 1, 2, ...: column k-1 of H is appended from what the orthogonalisation left on the device —

@@ -182,8 +182,8 @@ class CpuEngine:
 
     GRAM_TIKHONOV_MAX_K = 139
 
-    def gram_tikhonov(self, GA, lda, GL, ldl, c, k, lam, y):
-        (sa, ia), (sl, il) = GA, GL
+    def gram_tikhonov(self, GA, lda, GL, ldl, c, k, lam, y, Minv=None, ldm=0, k_from=0):
+        (sa, ia), (sl, il) = GA, GL           # (the bordering form of the HIP engine solves the same system)
         A = np.array([sa.a[ia + i * lda: ia + i * lda + k] for i in range(k)])
         Lm = np.array([sl.a[il + i * ldl: il + i * ldl + k] for i in range(k)])
         _put(y, np.linalg.solve(A + lam * Lm, np.asarray(_get(c, k)).reshape(-1)))

@@ -414,3 +414,29 @@ def test_hess_tikhonov_modes_against_stacked_lstsq(eng, kmax, lam):
             assert relerr(Y.host(0, k), want) < 1e-7, (k, "bordering")
             assert relerr(Y0.host(0, k), want) < 1e-8, (k, "cholesky")
     assert np.allclose(Hd.host(0, (kmax + 1) * kmax).reshape(kmax, kmax + 1).T, Hm, rtol=1e-12, atol=1e-13)
+
+
+@pytest.mark.parametrize("kmax,lam", [(6, 0.5), (60, 1e-2), (150, 1e-2)])
+def test_gram_tikhonov_bordered_inverse_against_solve(eng, kmax, lam):
+    """trk_gram_tikhonov with Minv: G_A, G_L grow by one row and column per call (GKS), the inverse of G_A + lam G_L is
+    bordered — started from a 3 x 3 block as GKS starts from projection_dim = 3, k up to 150 (> the Cholesky form's LDS
+    limit) — against numpy.linalg.solve and, where it applies, against the Cholesky form."""
+    rng = np.random.default_rng(kmax)
+    Wa, Wl = rng.standard_normal((kmax, 2 * kmax + 5)), rng.standard_normal((kmax, 3 * kmax))
+    GA, GL = Wa @ Wa.T, Wl @ Wl.T
+    c = rng.standard_normal(kmax)
+    GA_d, GL_d, c_d = eng.scalars(kmax * kmax), eng.scalars(kmax * kmax), eng.scalars(kmax)
+    GA_d.set(0, GA.reshape(-1))
+    GL_d.set(0, GL.reshape(-1))
+    c_d.set(0, c)
+    Minv, Y, Y0 = eng.scalars(kmax * kmax), eng.scalars(kmax), eng.scalars(kmax)
+    k_inv = 0
+    for k in range(3, kmax + 1):
+        eng.gram_tikhonov(GA_d.ref(0), kmax, GL_d.ref(0), kmax, c_d.ref(0), k, lam, Y.ref(0), Minv=Minv.ref(0), ldm=kmax, k_from=k_inv)
+        k_inv = k
+        if k in (3, 4, kmax // 2, kmax):
+            want = np.linalg.solve(GA[:k, :k] + lam * GL[:k, :k], c[:k])
+            assert relerr(Y.host(0, k), want) < 1e-9, k
+            if k <= eng.GRAM_TIKHONOV_MAX_K:
+                eng.gram_tikhonov(GA_d.ref(0), kmax, GL_d.ref(0), kmax, c_d.ref(0), k, lam, Y0.ref(0))
+                assert relerr(Y0.host(0, k), want) < 1e-9, k

@@ -293,6 +293,50 @@ __global__ __launch_bounds__(256) void k_gram_tikhonov(const double* __restrict_
   for (int i = threadIdx.x; i < k; i += blockDim.x) y[i] = z[i];
 }
 
+// The same solve when M = G_A + lam G_L only GROWS between calls (GKS with a numeric regparam: one basis vector, hence one row
+// and column of both Gram matrices, per iteration; same lam): Minv holds M^-1 of the leading k_from x k_from block from the
+// previous call and is bordered by rows k_from .. k-1 — u = Minv g, s = M[j][j] - g.u, Minv <- [[Minv + u u^T / s, -u / s],
+// [-u^T / s, 1 / s]] — then y = Minv c: O(k^2) per new row instead of the O(k^3) Cholesky from scratch (k = 53: 79 -> ~12 us).
+// k_from = 0 builds the inverse from nothing (the first call, k = projection_dim).
+__global__ __launch_bounds__(256) void k_gram_tikhonov_border(const double* __restrict__ GA, int lda, const double* __restrict__ GL,
+                                                              int ldl, const double* __restrict__ c, int k, int k_from, double lam,
+                                                              double* Minv, int ldm, double* __restrict__ y) {
+  extern __shared__ double sm[];              // g (k) | u (k)
+  double* g = sm;
+  double* u = sm + k;
+  __shared__ double red[4];
+  for (int j = k_from; j < k; ++j) {
+    for (int i = threadIdx.x; i <= j; i += blockDim.x) g[i] = GA[(size_t)j * lda + i] + lam * GL[(size_t)j * ldl + i];
+    __syncthreads();
+    double part = 0.0;
+    for (int i = threadIdx.x; i < j; i += blockDim.x) {       // u = Minv g (Minv symmetric: thread i walks column i)
+      double a = 0.0;
+      for (int q = 0; q < j; ++q) a += Minv[(size_t)q * ldm + i] * g[q];
+      u[i] = a;
+      part += a * g[i];
+    }
+    part = wave_sum(part);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    const double sinv = 1.0 / (g[j] - (red[0] + red[1] + red[2] + red[3]));
+    for (int idx = threadIdx.x; idx < j * j; idx += blockDim.x) {
+      const int a = idx / j, b = idx - a * j;
+      Minv[(size_t)a * ldm + b] += u[a] * u[b] * sinv;
+    }
+    for (int i = threadIdx.x; i < j; i += blockDim.x) {
+      Minv[(size_t)i * ldm + j] = -u[i] * sinv;
+      Minv[(size_t)j * ldm + i] = -u[i] * sinv;
+    }
+    if (threadIdx.x == 0) Minv[(size_t)j * ldm + j] = sinv;
+    __syncthreads();                            // (one workgroup: its global writes are visible to it after the barrier)
+  }
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    double a = 0.0;
+    for (int q = 0; q < k; ++q) a += Minv[(size_t)q * ldm + i] * c[q];
+    y[i] = a;
+  }
+}
+
 // Hybrid-GMRES's projected problem on the device (Hybrid_GMRES.py:69-77 with a numeric regparam):
 //   y = argmin || H_k y - beta0 e1 ||^2 + lam || y ||^2 ,   H_k the (k+1) x k Hessenberg matrix of Arnoldi.
 // One workgroup appends column k-1 of H from the scalars the orthogonalisation sweep left on the device (its k combined
@@ -412,8 +456,15 @@ static int tikhonov_lds(const void* kernel, size_t bytes) {
 }
 
 extern "C" int trk_gram_tikhonov(const double* GA, int lda, const double* GL, int ldl, const double* c, int k, double lam,
-                                 double* y, trk_stream st) {
+                                 double* Minv, int ldm, int k_from, double* y, trk_stream st) {
   TRK_REQUIRE(GA && GL && c && y && k >= 1 && lda >= k && ldl >= k, "trk_gram_tikhonov: bad argument");
+  if (Minv) {
+    TRK_REQUIRE(ldm >= k && k_from >= 0 && k_from <= k, "trk_gram_tikhonov: bordering form needs ldm >= k and 0 <= k_from <= k");
+    hipLaunchKernelGGL(k_gram_tikhonov_border, dim3(1), dim3(256), 2 * (size_t)k * sizeof(double), (hipStream_t)st, GA, lda, GL, ldl,
+                       c, k, k_from, lam, Minv, ldm, y);
+    TRK_LAUNCH_CHECK();
+    return TRK_OK;
+  }
   TRK_REQUIRE(k <= 139, "trk_gram_tikhonov: k <= 139 (the factor lives in LDS)");
   const size_t bytes = ((size_t)k * (k + 1) + k) * sizeof(double);
   if (int rc = tikhonov_lds(reinterpret_cast<const void*>(k_gram_tikhonov), bytes)) return rc;

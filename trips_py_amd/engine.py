@@ -391,9 +391,11 @@ class HipEngine:
 
     GRAM_TIKHONOV_MAX_K = 139          # the k x (k+1) factor lives in LDS (160 KB per workgroup on gfx950)
 
-    def gram_tikhonov(self, GA, lda, GL, ldl, c, k, lam, y):
-        """y = (G_A + lam G_L)^-1 c on the device (k <= GRAM_TIKHONOV_MAX_K)."""
-        rc = self.lib.trk_gram_tikhonov(_ptr(GA), int(lda), _ptr(GL), int(ldl), _ptr(c), int(k), float(lam), _ptr(y), self.stream())
+    def gram_tikhonov(self, GA, lda, GL, ldl, c, k, lam, y, Minv=None, ldm=0, k_from=0):
+        """y = (G_A + lam G_L)^-1 c on the device.  Minv = None: Cholesky from scratch (k <= GRAM_TIKHONOV_MAX_K); else the
+        inverse kept in Minv (valid for the leading k_from rows, same lam) is bordered by rows k_from .. k-1."""
+        rc = self.lib.trk_gram_tikhonov(_ptr(GA), int(lda), _ptr(GL), int(ldl), _ptr(c), int(k), float(lam), _ptr(Minv), int(ldm),
+                                        int(k_from), _ptr(y), self.stream())
         _lib.check(rc, "trk_gram_tikhonov")
 
     def hess_tikhonov(self, H, ldh, G, Minv, ldg, coef, coef2, nrm2_sq, beta0, k, lam, mode, y):

@@ -134,7 +134,7 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     # numeric regparam: the projected problem is solved on the device from device-resident Gram data (no host round trip per
     # iteration); the automatic selectors need the factors on the host
     on_dev = (not isinstance(regparam, str)) and hasattr(eng, "gram_tikhonov") and hasattr(eng, "cgs_coeffs") \
-        and kmax <= eng.GRAM_TIKHONOV_MAX_K and kwargs.get("device_solve", True)
+        and (kmax <= eng.GRAM_TIKHONOV_MAX_K or kwargs.get("border_inverse", True)) and kwargs.get("device_solve", True)
     dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
     from_v = hasattr(eng, "gemv_t2") and kwargs.get("gram_from_v", True)
     pb = _ProjectedBases(A, L, bv, gk.V, kmax, on_device=on_dev, from_v_A=dA and from_v, from_v_L=dL and from_v)
@@ -153,12 +153,16 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     fusedL = dL and hasattr(L, "tv_grad") and kwargs.get("fused_tv", True)
     gs_gram = GramSchmidtByGram(eng, pb.V, kmax) if (hasattr(eng, "cgs_coeffs") and kwargs.get("gram_sweeps", True)) else None
     lams, lam, x_dev = [], None, None
+    Minv, k_inv = (eng.scalars(kmax * kmax) if (on_dev and kwargs.get("border_inverse", True)) else None), 0
     for ii in range(n_iter):
         k = pb.V.k
         if on_dev:
             lam = regparam
             lams.append(lam)
-            eng.gram_tikhonov(pb.GA_d.ref(0), kmax, pb.GL_d.ref(0), kmax, pb.c_d.ref(0), k, lam, Y.ref(0))   # (:74)
+            # (:74) the Gram matrices only grow: the inverse of G_A + lam G_L is bordered by the rows new since the last call
+            eng.gram_tikhonov(pb.GA_d.ref(0), kmax, pb.GL_d.ref(0), kmax, pb.c_d.ref(0), k, lam, Y.ref(0),
+                              Minv=Minv, ldm=kmax, k_from=k_inv)
+            k_inv = k
         else:
             R_A, R_L = gram_factor(pb.GA[:k, :k]), gram_factor(pb.GL[:k, :k])
             rhs = project_rhs(R_A, pb.c[:k])
