@@ -440,3 +440,4 @@ def test_gram_tikhonov_bordered_inverse_against_solve(eng, kmax, lam):
             if k <= eng.GRAM_TIKHONOV_MAX_K:
                 eng.gram_tikhonov(GA_d.ref(0), kmax, GL_d.ref(0), kmax, c_d.ref(0), k, lam, Y0.ref(0))
                 assert relerr(Y0.host(0, k), want) < 1e-9, k
+
