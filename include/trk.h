@@ -342,6 +342,17 @@ int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y
 int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G_dev,
               double* c1_dev, double* c2_dev, trk_stream stream);
 
+/* GKS without a pass over the basis for the Gram rows of a new vector (GKS.py:86-96).  The sweep that orthogonalises the residual r
+ * against V also takes V^T (A^T A r) and V^T (L^T L r) (trk_gemv_tn: 3 or 4 right-hand sides in one pass, out[q*k + j] = V[j] . rhs[q]);
+ * the new vector is v_k = (r - V c) / rho, so row k of G = V^T M V follows from a = V^T (M r), c, s = r . M r and rho^2 = ||r - V c||^2:
+ *   G[i][k] = G[k][i] = (a_i - (G c)_i) / rho ,  G[k][k] = (s - 2 c.a + c.(G c)) / rho^2 ,  rhs_k = (t - c . rhs) / rho  (t = r . A^T b)
+ * (trk_gram_row_from_sweep; ldg >= k+1; rhs / t may be NULL).  c is of rounding size (r is the residual of the projected
+ * normal equations, orthogonal to V), so nothing cancels. */
+int trk_gemv_tn(const float* V, int64_t ld, int k, int64_t n, const float* const* rhs, int n_rhs, double* out_dev,
+                trk_stream stream);
+int trk_gram_row_from_sweep(double* G_dev, int ldg, int k, const double* a_dev, const double* c_dev, const double* s_rr_dev,
+                            const double* rho2_dev, double* rhs_dev, const double* t_dev, trk_stream stream);
+
 /* y = (G_A + lam G_L)^-1 c on the device (float64, one workgroup): the projected Tikhonov problem of GKS.py:74 / MMGKS.py:106,
  * `lstsq([R_A; sqrt(lam) R_L], [Q_A^T b; 0])`, from the Gram data G_A = (AV)^T AV, G_L = (LV)^T LV (row strides lda, ldl) and
  * c = (AV)^T b that trk_gemv_t / trk_gemv_t2 / trk_wgram leave on the device — a numeric regparam then needs no host round

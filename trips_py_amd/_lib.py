@@ -197,6 +197,8 @@ SIGNATURES = {
                                        ctypes.POINTER(c_int), c_stream]),
     "trk_gemv_t": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_gemv_t2": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_stream]),
+    "trk_gemv_tn": (c_int, [c_f32p, c_i64, c_int, c_i64, ctypes.POINTER(ctypes.c_void_p), c_int, c_f64p, c_stream]),
+    "trk_gram_row_from_sweep": (c_int, [c_f64p, c_int, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_stream]),
     "trk_gram_tikhonov": (c_int, [c_f64p, c_int, c_f64p, c_int, c_f64p, c_int, c_dbl, c_f64p, c_int, c_int, c_f64p, c_stream]),
     "trk_hess_tikhonov": (c_int, [c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_dbl, c_int, c_dbl, c_int, c_f64p,
                                   c_stream]),

@@ -337,6 +337,54 @@ __global__ __launch_bounds__(256) void k_gram_tikhonov_border(const double* __re
   }
 }
 
+// GKS: row / column k of a Gram matrix G = V^T M V (M = A^T A or L^T L) for the basis vector v_k = (r - V c) / rho that the sweep
+// has just produced, from what the sweep's own pass over V left behind — a = V^T (M r), the coefficients c, s = r . M r and
+// rho^2 = ||r - V c||^2 — with no further pass over the basis:
+//   G[i][k] = (a_i - (G c)_i) / rho  (i < k),     G[k][k] = (s - 2 c.a + c.(G c)) / rho^2 ;
+// optionally the same for a projected right-hand side  rhs_k = (t - c . rhs[0..k)) / rho  (t = r . (A^T b)).
+// r is the residual of the projected normal equations, so V^T r = 0 but for rounding and c is of rounding size: nothing cancels.
+__global__ __launch_bounds__(256) void k_gram_row_from_sweep(double* G, int ldg, int k, const double* __restrict__ a,
+                                                             const double* __restrict__ c, const double* __restrict__ s_rr,
+                                                             const double* __restrict__ rho2, double* rhs, const double* tb) {
+  __shared__ double red[3][4];
+  const double rho = sqrt(*rho2);
+  double p_ca = 0.0, p_cgc = 0.0, p_cr = 0.0;
+  for (int i = threadIdx.x; i < k; i += blockDim.x) {
+    double gc = 0.0;
+    for (int j = 0; j < k; ++j) gc += G[(size_t)j * ldg + i] * c[j];        // (G symmetric: column i read along rows)
+    const double v = (a[i] - gc) / rho;
+    G[(size_t)i * ldg + k] = v;
+    G[(size_t)k * ldg + i] = v;
+    p_ca += c[i] * a[i];
+    p_cgc += c[i] * gc;
+    if (rhs) p_cr += c[i] * rhs[i];
+  }
+  p_ca = wave_sum(p_ca);
+  p_cgc = wave_sum(p_cgc);
+  p_cr = wave_sum(p_cr);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = p_ca;
+    red[1][threadIdx.x >> 6] = p_cgc;
+    red[2][threadIdx.x >> 6] = p_cr;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double ca = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    const double cgc = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+    G[(size_t)k * ldg + k] = (*s_rr - 2.0 * ca + cgc) / (rho * rho);
+    if (rhs) rhs[k] = (*tb - ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3]))) / rho;
+  }
+}
+
+extern "C" int trk_gram_row_from_sweep(double* G, int ldg, int k, const double* a, const double* c, const double* s_rr,
+                                       const double* rho2, double* rhs, const double* tb, trk_stream st) {
+  TRK_REQUIRE(G && a && c && s_rr && rho2 && k >= 1 && ldg >= k + 1, "trk_gram_row_from_sweep: bad argument");
+  TRK_REQUIRE(!rhs || tb, "trk_gram_row_from_sweep: rhs given without t = r . (A^T b)");
+  hipLaunchKernelGGL(k_gram_row_from_sweep, dim3(1), dim3(256), 0, (hipStream_t)st, G, ldg, k, a, c, s_rr, rho2, rhs, tb);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
 // Hybrid-GMRES's projected problem on the device (Hybrid_GMRES.py:69-77 with a numeric regparam):
 //   y = argmin || H_k y - beta0 e1 ||^2 + lam || y ||^2 ,   H_k the (k+1) x k Hessenberg matrix of Arnoldi.
 // One workgroup appends column k-1 of H from the scalars the orthogonalisation sweep left on the device (its k combined

@@ -608,6 +608,64 @@ __global__ __launch_bounds__(NT) void k_gemv_t2(const float* __restrict__ V, int
   }
 }
 
+// The same with R right-hand sides (R = 3, 4): out[q k + j] = V[j] . rhs[q].  GKS rides the Gram rows of its NEXT basis vector on
+// the sweep that orthogonalises it (krylov.GramSchmidtByGram.sweep, solvers/GKS.py): V^T (A^T A r) and V^T (L^T L r) next to V^T r
+// and the newest vector's row of V^T V — one pass over the basis instead of two.
+struct RhsSet {
+  const float* p[4];
+};
+template <bool VEC, int R>
+__global__ __launch_bounds__(NT) void k_gemv_tr(const float* __restrict__ V, int64_t ld, int k, int64_t n, RhsSet rhs,
+                                                double* __restrict__ partials, int nt) {
+  __shared__ double lds[NT / 64];
+  const int j0 = blockIdx.y * JT;
+  const int jn = (k - j0 < JT) ? (k - j0) : JT;
+  double acc[R][JT];
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int j = 0; j < JT; ++j) acc[q][j] = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      float4 rv[R];
+#pragma unroll
+      for (int q = 0; q < R; ++q) rv[q] = ld4(rhs.p[q], i);
+#pragma unroll
+      for (int j = 0; j < JT; ++j) {
+        if (j < jn) {
+          const float4 v = (nt & 64) ? ld4_nt(V + (int64_t)(j0 + j) * ld, i) : ld4(V + (int64_t)(j0 + j) * ld, i);
+#pragma unroll
+          for (int q = 0; q < R; ++q)
+            acc[q][j] += (double)v.x * rv[q].x + (double)v.y * rv[q].y + (double)v.z * rv[q].z + (double)v.w * rv[q].w;
+        }
+      }
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) {
+    float rv[R];
+#pragma unroll
+    for (int q = 0; q < R; ++q) rv[q] = rhs.p[q][i];
+#pragma unroll
+    for (int j = 0; j < JT; ++j)
+      if (j < jn) {
+        const double v = (double)V[(int64_t)(j0 + j) * ld + i];
+#pragma unroll
+        for (int q = 0; q < R; ++q) acc[q][j] += v * rv[q];
+      }
+  }
+#pragma unroll
+  for (int q = 0; q < R; ++q)
+#pragma unroll
+    for (int j = 0; j < JT; ++j) {
+      const double t = block_sum<NT>(acc[q][j], lds);
+      if (threadIdx.x == 0 && j < jn) partials[(size_t)blockIdx.x * R * k + (size_t)q * k + j0 + j] = t;
+    }
+}
+
 int launch_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* w, int wpow, double* h,
                   hipStream_t s) {
   const int ntile = ceil_div(k, JT);
@@ -1446,6 +1504,34 @@ int trk_gemv_t2(const float* V, int64_t ld, int k, int64_t n, const float* r, co
   else hipLaunchKernelGGL((k_gemv_t2<false>), grid, dim3(NT), 0, s, V, ld, k, n, r, r2, part, stream_nontemporal(n));
   TRK_LAUNCH_CHECK();
   return finalize_sums(part, bx, 2 * k, 2 * k, h2k, s);
+}
+
+int trk_gemv_tn(const float* V, int64_t ld, int k, int64_t n, const float* const* rhs, int n_rhs, double* out, trk_stream st) {
+  TRK_REQUIRE(V && rhs && out, "trk_gemv_tn: NULL argument");
+  TRK_REQUIRE(n_rhs == 3 || n_rhs == 4, "trk_gemv_tn: 3 or 4 right-hand sides (1: trk_gemv_t, 2: trk_gemv_t2)");
+  TRK_REQUIRE(k >= 1 && n >= 0 && ld >= n, "trk_gemv_tn: need k >= 1, n >= 0, ld >= n");
+  RhsSet rs{};
+  bool vec = aligned16(V) && (ld % 4 == 0);
+  for (int q = 0; q < n_rhs; ++q) {
+    TRK_REQUIRE(rhs[q], "trk_gemv_tn: NULL right-hand side");
+    rs.p[q] = rhs[q];
+    vec = vec && aligned16(rhs[q]);
+  }
+  hipStream_t s = (hipStream_t)st;
+  const int ntile = ceil_div(k, JT);
+  int bx = stream_grid(n);
+  const int cap = (cu_count() * 8 + ntile - 1) / ntile;
+  if (bx > cap) bx = cap < 1 ? 1 : cap;
+  double* part = nullptr;
+  if (int rc = scratch_doubles(s, (size_t)bx * n_rhs * k, &part)) return rc;
+  dim3 grid(bx, ntile);
+  const int nt = stream_nontemporal(n);
+#define GR(VC, RR) hipLaunchKernelGGL((k_gemv_tr<VC, RR>), grid, dim3(NT), 0, s, V, ld, k, n, rs, part, nt)
+  if (n_rhs == 3) { if (vec) GR(true, 3); else GR(false, 3); }
+  else            { if (vec) GR(true, 4); else GR(false, 4); }
+#undef GR
+  TRK_LAUNCH_CHECK();
+  return finalize_sums(part, bx, n_rhs * k, n_rhs * k, out, s);
 }
 
 int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, double a, const float* base, double sc,

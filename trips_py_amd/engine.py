@@ -389,6 +389,18 @@ class HipEngine:
                                   self.stream())
         _lib.check(rc, "trk_gemv_t2")
 
+    def gemv_tn(self, V, k, rhs, out):
+        """out[q*k + j] = V[j] . rhs[q] for 3 or 4 right-hand sides, one pass over V (trk_gemv_tn; local sums)."""
+        arr = (ctypes.c_void_p * len(rhs))(*[r.data_ptr() for r in rhs])
+        rc = self.lib.trk_gemv_tn(V.data_ptr(), V.stride(0), int(k), rhs[0].numel(), arr, len(rhs), _ptr(out), self.stream())
+        _lib.check(rc, "trk_gemv_tn")
+
+    def gram_row_from_sweep(self, G, ldg, k, a, c, s_rr, rho2, rhs=None, tb=None):
+        """Row / column k of G = V^T M V for v_k = (r - V c)/rho from a = V^T (M r), c, s = r.M r, rho^2 (trk_gram_row_from_sweep)."""
+        rc = self.lib.trk_gram_row_from_sweep(_ptr(G), int(ldg), int(k), _ptr(a), _ptr(c), _ptr(s_rr), _ptr(rho2), _ptr(rhs),
+                                              _ptr(tb), self.stream())
+        _lib.check(rc, "trk_gram_row_from_sweep")
+
     GRAM_TIKHONOV_MAX_K = 139          # the k x (k+1) factor lives in LDS (160 KB per workgroup on gfx950)
 
     def gram_tikhonov(self, GA, lda, GL, ldl, c, k, lam, y, Minv=None, ldm=0, k_from=0):

@@ -309,7 +309,7 @@ class GramSchmidtByGram:
     def __init__(self, eng, V, kmax):
         self.eng, self.V, self.kmax = eng, V, int(kmax)
         self.G = eng.scalars(self.kmax * self.kmax)
-        self.W = eng.scalars(3 * self.kmax)           # h (k) | g_new (k) | c (k)
+        self.W = eng.scalars(5 * self.kmax)           # h (k) | g_new (k) | [extra products (k each)] ... c at 4 kmax
         self.in_G = 0                                 # vectors whose Gram rows are installed
         for j in range(V.k):                          # the start basis: one sweep per vector (d of them)
             eng.gemv_t(V.data, j + 1, V[j], self.W.ref(0))
@@ -317,14 +317,22 @@ class GramSchmidtByGram:
             eng.cgs_coeffs(self.G.ref(0), self.kmax, None, self.W.ref(0), j + 1, 0, None)
         self.in_G = V.k
 
-    def sweep(self, k, w, passes, out, sumsq=None, c_out=None):
+    def sweep(self, k, w, passes, out, sumsq=None, c_out=None, extra=()):
         """out = w orthogonalised against V[0..k) by `passes` sweeps; LOCAL sum(out^2) into `sumsq` (fused).  Returns the
-        DevScalars reference of the k combined coefficients."""
+        DevScalars reference of the k combined coefficients.  extra: one or two more vectors z whose products V^T z ride on
+        the same pass over the basis (trk_gemv_tn); they are left at `self.extra_ref(q, k)`."""
         eng, V, W, K = self.eng, self.V, self.W, self.kmax
         if k > K:
             raise ValueError("GramSchmidtByGram: basis larger than planned")
-        c = W.ref(2 * K) if c_out is None else c_out
-        if self.in_G == k - 1:                        # the newest vector's Gram row rides along with h
+        c = W.ref(4 * K) if c_out is None else c_out
+        if extra:
+            if self.in_G != k - 1 or len(extra) > 2:
+                raise RuntimeError("GramSchmidtByGram: extra right-hand sides ride on the sweep that installs the newest vector's row")
+            eng.gemv_tn(V.data, k, [w, V[k - 1]] + list(extra), W.ref(0))
+            eng.allreduce(W, 0, (2 + len(extra)) * k)
+            eng.cgs_coeffs(self.G.ref(0), K, W.ref(0), W.ref(k), k, passes, c)
+            self.in_G = k
+        elif self.in_G == k - 1:                      # the newest vector's Gram row rides along with h
             eng.gemv_t2(V.data, k, w, V[k - 1], W.ref(0))
             eng.allreduce(W, 0, 2 * k)
             eng.cgs_coeffs(self.G.ref(0), K, W.ref(0), W.ref(k), k, passes, c)
@@ -337,6 +345,10 @@ class GramSchmidtByGram:
             raise RuntimeError("GramSchmidtByGram: more than one vector appended since the last sweep")
         eng.gemv_n(V.data, k, c, out, a=1.0, base=w, s=-1.0, sumsq=sumsq)
         return c
+
+    def extra_ref(self, q, k):
+        """Where the last sweep over k vectors left V^T extra[q]."""
+        return self.W.ref((2 + q) * k)
 
 
 class ArnoldiState:

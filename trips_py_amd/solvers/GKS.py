@@ -55,7 +55,7 @@ class _ProjectedBases:
         self.GA = np.zeros((kmax, kmax))
         self.GL = np.zeros((kmax, kmax))
         self.c = np.zeros(kmax)
-        self.S = eng.scalars(2 * kmax + 2)
+        self.S = eng.scalars(2 * kmax + 8)
         for j in range(V0.k):
             self._push_images(j)
 
@@ -110,6 +110,49 @@ class _ProjectedBases:
     def append(self):
         """The caller has written the new basis vector into V.next_slot() and committed it."""
         self._push_images(self.V.k - 1)
+
+    # ---- the Gram rows of the next vector WITHOUT a pass over the basis of their own (on_device only) ----
+    # The new vector is v_k = (r - V c)/rho; G[i][k] = v_i . M v_k follows from a = V^T (M r), which rides on the sweep that
+    # orthogonalises r (krylov.GramSchmidtByGram.sweep(extra=...), trk_gemv_tn), and from c, r . M r, rho^2
+    # (trk_gram_row_from_sweep).  Per iteration GKS then passes over V three times (x = V y, the sweep, r - V c), not four.
+    def sweep_operands(self, r):
+        """The vectors whose V^T products the sweep must also take, and the scalars r . M r (and r . A^T b): call before the sweep."""
+        eng, S = self.eng, self.S
+        extra = []
+        if self.from_v_A:
+            self.A.apply(r, out=self.tA, sumsq=S.ref(0))                  # ||A r||^2 = r . A^T A r
+            self.A.apply(self.tA, out=self.zA, transpose=True)
+            eng.dot(r, self.atb, S.ref(2))
+            extra.append(self.zA)
+        if self.from_v_L:
+            if self.tL is None:
+                self.L.tv_grad(r, None, None, 1.0, out=self.zL)
+            else:
+                self.L.apply(r, out=self.tL)
+                self.L.apply(self.tL, out=self.zL, transpose=True)
+            eng.dot(r, self.zL, S.ref(1))                                 # r . L^T L r
+            extra.append(self.zL)
+        eng.allreduce(S, 0, 3)
+        return extra
+
+    def append_from_sweep(self, gs, k, c, rho2):
+        """After the sweep over k vectors (coefficients c, rho^2 = ||r - V c||^2) and the commit of v_k: rows k of the Gram data."""
+        eng, S = self.eng, self.S
+        q = 0
+        if self.from_v_A:
+            eng.gram_row_from_sweep(self.GA_d.ref(0), self.kmax, k, gs.extra_ref(q, k), c, S.ref(0), rho2, rhs=self.c_d.ref(0), tb=S.ref(2))
+            q += 1
+        else:                                                             # the images of A are kept (small m): as in _push_images
+            av = self.AV.next_slot()
+            self.A.apply(self.V[k], out=av)
+            self.AV.commit()
+            eng.dot(av, self.bv, self.c_d.ref(k))
+            eng.gemv_t(self.AV.data, k + 1, av, S.ref(4))
+            eng.allreduce(S, 4, 4 + k + 1)
+            eng.allreduce(self.c_d, k, k + 1)
+            eng.cgs_coeffs(self.GA_d.ref(0), self.kmax, None, S.ref(4), k + 1, 0, None)
+        if self.from_v_L:
+            eng.gram_row_from_sweep(self.GL_d.ref(0), self.kmax, k, gs.extra_ref(q, k), c, S.ref(1), rho2)
 
 
 @small_host_blas
@@ -194,14 +237,22 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
             L.apply(tp, out=rb, transpose=True)
             eng.axpby(1.0, r, float(lam), rb, r)
         vn = pb.V.next_slot()
-        if gs_gram is not None:
+        merged = (on_dev and gs_gram is not None and pb.from_v_L and hasattr(eng, "gram_row_from_sweep")
+                  and gs_gram.in_G == k - 1 and kwargs.get("gram_rows_from_sweep", True))
+        if merged:
+            # the sweep's pass over V also takes V^T (A^T A r), V^T (L^T L r): the next vector's Gram rows need no pass of their own
+            cc = gs_gram.sweep(k, r, 3, vn, sumsq=R.ref(ii), extra=pb.sweep_operands(r))
+        elif gs_gram is not None:
             gs_gram.sweep(k, r, 3, vn, sumsq=R.ref(ii))                              # (:86-88) three sweeps, ||r||^2 fused
         else:
             orthogonalize(eng, pb.V, k, r, H, 0, passes=3, out=vn, sumsq=R.ref(ii))
         eng.allreduce(R, ii, ii + 1)
         eng.scale(Coef(1.0, den=R.ref(ii), sqrt_den=True), vn, vn)                   # vn = r/||r|| (:89-91)
         pb.V.commit()
-        pb.append()                                                                  # AV, LV, Gram rows (:92-96)
+        if merged:
+            pb.append_from_sweep(gs_gram, k, cc, R.ref(ii))
+        else:
+            pb.append()                                                              # AV, LV, Gram rows (:92-96)
     info = {"xHistory": Hs.collect(fmt, n_iter), "regParam": lam, "regParam_history": lams,
             "Residual": list(np.sqrt(R.host(0, n_iter))), "its": n_iter - 1}
     if xt is not None:
