@@ -17,12 +17,23 @@ def small_host_blas(fn):
     """Run a solver with the host BLAS/LAPACK pools limited to one thread.  The host side of these solvers is k-sized
     (k <= a few hundred) SVD / least squares / Cholesky: on a many-core host the threaded OpenBLAS spends ~1 ms per call
     waking its pool for them (measured: 1.3 ms per 100x100 SVD on the MI355X box, 0.1 ms single-threaded).  No-op
-    when threadpoolctl is not installed."""
+    when threadpoolctl is not installed — and when `regparam` is a number: those paths keep the projected problem on the
+    device and call no host BLAS, while resizing a 128-thread pool on the way in and out can cost tens of milliseconds
+    (measured: a 50-iteration GKS of 18 ms took 92 ms right after another NumPy LAPACK call had populated the pool)."""
     import functools
+    import inspect
+    sig = inspect.signature(fn)
 
     @functools.wraps(fn)
     def wrapped(*args, **kwargs):
         global _blas_controller
+        try:
+            bound = sig.bind_partial(*args, **kwargs)
+            rp = bound.arguments.get("regparam", sig.parameters["regparam"].default if "regparam" in sig.parameters else "gcv")
+        except TypeError:
+            rp = "gcv"
+        if not isinstance(rp, str) and kwargs.get("device_solve", True):
+            return fn(*args, **kwargs)
         if _blas_controller is None:
             try:
                 from threadpoolctl import ThreadpoolController
