@@ -16,7 +16,7 @@ from ..reg_param.gcv import fminbound_gcv_diag
 from ._common import check_delta, choose_lambda, small_host_blas
 
 
-@small_host_blas
+@small_host_blas(when=lambda rp: rp == "l_curve")
 def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys: xHistory (n_iter-1 iterates: none is formed at the first step, :77-78), regParam,
     regParam_history, relError (if x_true), relResidual (empty list, as in the reference), its (= n_iter-1).

@@ -13,7 +13,7 @@ NO_DELTA_MSG = ("A value for the noise level delta was not provided and the disc
 _blas_controller = None
 
 
-def small_host_blas(fn):
+def small_host_blas(fn=None, *, when=None):
     """Run a solver with the host BLAS/LAPACK pools limited to one thread.  The host side of these solvers is k-sized
     (k <= a few hundred) SVD / least squares / Cholesky: on a many-core host the threaded OpenBLAS spends ~1 ms per call
     waking its pool for them (measured: 1.3 ms per 100x100 SVD on the MI355X box, 0.1 ms single-threaded).  No-op
@@ -22,7 +22,12 @@ def small_host_blas(fn):
     (measured: a 50-iteration GKS of 18 ms took 92 ms right after another NumPy LAPACK call had populated the pool)."""
     import functools
     import inspect
+    import os
+    if fn is None:                                              # @small_host_blas(when=...)
+        return lambda f: small_host_blas(f, when=when)
     sig = inspect.signature(fn)
+    needs_limit = when if when is not None else (lambda rp: isinstance(rp, str))
+    disabled = os.environ.get("TRK_NO_BLAS_LIMIT") is not None
 
     @functools.wraps(fn)
     def wrapped(*args, **kwargs):
@@ -32,7 +37,10 @@ def small_host_blas(fn):
             rp = bound.arguments.get("regparam", sig.parameters["regparam"].default if "regparam" in sig.parameters else "gcv")
         except TypeError:
             rp = "gcv"
-        if not isinstance(rp, str) and kwargs.get("device_solve", True):
+        # `when`: which regparam values run threaded host LAPACK at all (Hybrid_LSQR: only 'l_curve' — gcv / dp go through
+        # dbdsqr and the C searches); changing the pool size is not free: now and then the next BLAS call re-creates the pool
+        # (74 ms measured on the 64-thread MI355X host), so the limit is set only where it pays
+        if disabled or (not needs_limit(rp) and kwargs.get("device_solve", True)):
             return fn(*args, **kwargs)
         if _blas_controller is None:
             try:
