@@ -79,6 +79,7 @@ class GKState:
         # operators whose own output pass takes the vector update and the norm of a half step (the Radon projector)
         self.native_axpby = bool(getattr(A, "native_axpby", False)) and not self.normalized
         self._chained = False                   # U[k] came out of this state's previous fused forward apply
+        self._UB, self.uproj = None, None       # U^T b, one entry per row of U (step_prefetch(project=b))
         m, n = A.shape
         eng = self.eng
         self.U = DeviceBasis(eng, m, capacity + 1)
@@ -104,6 +105,7 @@ class GKState:
         st.A, st.eng = A, A.engine
         st.normalized = True
         st.native_axpby, st._chained = False, False
+        st._UB, st.uproj = None, None
         eng = A.engine
         m, n = A.shape
         k = len(alphas)
@@ -151,17 +153,34 @@ class GKState:
             self._beta0 = float(np.sqrt(self.AB.host(0, 1)[0]))
         return self._beta0
 
-    def step_prefetch(self):
+    def step_prefetch(self, project=None):
         """One step, enqueued, plus the start of the download of its two norms: `absorb()` later waits for that copy
         only, so a caller can enqueue the NEXT step before it looks at this one's numbers (the hybrid solvers choose
-        lambda_k on the host while the device already runs step k+1, which does not depend on it)."""
+        lambda_k on the host while the device already runs step k+1, which does not depend on it).
+        project: a vector b whose products with the rows of U the caller wants (the discrepancy principle's U^T b):
+        the new row's U[k+1] . b (U[0] . b as well on the first step) is taken right behind the step and downloaded with
+        the norms — `self.uproj` grows by one entry per absorbed step — instead of a pass over all of U and a blocking
+        download per iteration."""
         k = self.V.k
         self.step(sync=False)
         lo = 0 if self._beta0 is None else 2 * k + 1
-        return k, lo, self.AB.host_later(lo, 2 * k + 3)
+        extra = None
+        if project is not None:
+            eng = self.eng
+            if self._UB is None:
+                self._UB = eng.scalars(self.U.data.shape[0] + 1)
+                self.uproj = []
+            j0 = 0 if k == 0 else k + 1
+            for j in range(j0, k + 2):
+                eng.dot(self.U[j], project, self._UB.ref(j))
+            eng.allreduce(self._UB, j0, k + 2)
+            extra = self._UB.host_later(j0, k + 2)
+        return k, lo, self.AB.host_later(lo, 2 * k + 3), extra
 
     def absorb(self, pending):
-        k, lo, handle = pending
+        k, lo, handle, extra = pending
+        if extra is not None:
+            self.uproj.extend(float(t) for t in extra.get())
         if len(self._alphas) > k:
             return                                  # a full download overtook it
         v = np.sqrt(handle.get())

@@ -50,12 +50,13 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
 
     lams, lam, nx_done, x_dev = [], 0, 0, None
     on_host = isinstance(regparam, str)          # lambda selection needs B_k on the host
-    pend = gk.step_prefetch() if (on_host and n_iter > 0) else None
+    ub_vec = bv if (isinstance(regparam, str) and regparam == "dp") else None   # the discrepancy principle wants U^T b
+    pend = gk.step_prefetch(project=ub_vec) if (on_host and n_iter > 0) else None
     for ii in range(n_iter):
         k = ii + 1
         if on_host:
             gk.absorb(pend)                  # alpha_k, beta_{k+1}; step k+1 runs while the host chooses lambda_k
-            pend = gk.step_prefetch() if k < n_iter else None
+            pend = gk.step_prefetch(project=ub_vec) if k < n_iter else None
         else:
             # nobody reads B_k before the end (fixed lambda, no history, no x_true): the step's last norm may stay inside the operator
             gk.step(sync=False, defer=(not keep and xt is None and ii < n_iter - 1))
@@ -75,9 +76,8 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             lam = choose_lambda(regparam, np.diag(s), np.eye(k), Qb.T @ bhat, 0.0, kwargs, variant="modified", fullsize=m)
         elif isinstance(regparam, str) and regparam == "dp":
             # discrepancy_principle(U, B, L, b): projects b on the (no longer exactly orthonormal) computed U (:86)
-            eng.gemv_t(gk.U.data, k + 1, bv, P.ref(0))
-            eng.allreduce(P, 0, k + 1)
-            bproj = P.host(0, k + 1) / np.concatenate(([gk.beta0], gk._betas[:k]))          # rows of U are beta_j u_j
+            # U^T b row by row, downloaded with each step's norms (krylov.GKState.step_prefetch): no pass over U, no blocking copy
+            bproj = np.asarray(gk.uproj[:k + 1]) / np.concatenate(([gk.beta0], gk._betas[:k]))   # rows of U are beta_j u_j
             s, proj = bidiag_svd_project(gk._alphas[:k], gk._betas[:k], bproj)       # svd(B_k), U^T bproj (dp :68-70)
             extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
             lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
