@@ -269,6 +269,12 @@ int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride, const doub
  * maxfun = 1000 there).  s, rhs: k host doubles.  fval_out / nfev_out may be NULL. */
 int trk_host_gcv_fminbound(const double* s, const double* rhs, int k, double m_eff, double x1, double x2, double xatol,
                            int maxfun, double* lam_out, double* fval_out, int* nfev_out);
+/* HOST function: the same search for the hybrid solvers' bidiagonal projected problem (Hybrid_LSQR.py:81-84: svd(B_k), then GCV
+ * on (S, U^T bhat)) WITHOUT the SVD: B_k = lower bidiagonal (k+1) x k with diagonal alpha[0..k) and sub-diagonal beta[0..k),
+ * bhat = beta0 e1.  G(lam) is evaluated through one LDL^T of the k x k tridiagonal R R^T + lam I per lambda (B = Q [R; 0]):
+ * the same function of lam, O(k) per evaluation, no O(k^2) SVD per iteration. */
+int trk_host_gcv_bidiag(const double* alpha, const double* beta, int k, double beta0, double m_eff, double x1, double x2,
+                        double xatol, int maxfun, double* lam_out, double* fval_out, int* nfev_out);
 /* HOST function: the Newton iteration of the discrepancy principle (discrepancy_principle.py:80-99, 'tikhonov'):
  * solves || bhat / (sv*beta + 1) ||^2 + extra = target for beta = 1/alpha from beta = 1e-8 with the reference's
  * stopping rule.  sv: squared singular values padded with zeros to n, bhat: U^T b (n host doubles).  *alpha_set = 0

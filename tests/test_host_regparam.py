@@ -115,3 +115,37 @@ def test_bidiag_svd_first_row_matches_dense_svd(k):
     s2, u0 = bidiag_svd_first_row(al, be)
     assert np.allclose(s2, s, rtol=1e-12, atol=1e-14 * s.max())
     assert np.allclose(np.abs(u0), np.abs(U[0]), rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 40, 120])
+def test_gcv_of_the_bidiagonal_problem_without_its_svd(k):
+    """trk_host_gcv_bidiag (G(lam) through the resolvent of the tridiagonal R R^T, B = Q [R; 0]) against the diagonalised form the
+    reference evaluates (svd(B_k), GCV on (S, U^T bhat), 'modified', fullsize m: Hybrid_LSQR.py:81-84): the same function of
+    lambda — values agree to 1e-10 over the search interval — hence the same minimiser."""
+    import ctypes
+    from trips_py_amd import _lib
+    from trips_py_amd.reg_param.gcv import fminbound_gcv_bidiag, fminbound_gcv_diag, gcv_function_diag
+    rng = np.random.default_rng(k)
+    al = np.abs(rng.standard_normal(k)) * np.logspace(0, -3, k) + 1e-4       # decaying, as Golub-Kahan on an ill-posed problem
+    be = np.abs(rng.standard_normal(k)) * np.logspace(0, -3, k) + 1e-4
+    beta0, m = 3.3, 5000.0
+    B = np.zeros((k + 1, k))
+    B[np.arange(k), np.arange(k)] = al
+    B[np.arange(1, k + 1), np.arange(k)] = be
+    U, s, _ = np.linalg.svd(B)
+    rhs = beta0 * U[0, :k]
+    lib = _lib.load()
+    for lam in (1e-9, 1e-6, 1e-3, 0.1, 7.0, 100.0):
+        # a degenerate search interval returns the objective at that point
+        out, fv = ctypes.c_double(0.0), ctypes.c_double(0.0)
+        rc = lib.trk_host_gcv_bidiag(al.ctypes.data, be.ctypes.data, k, beta0, m, lam, lam, 1e-12, 5, ctypes.byref(out), ctypes.byref(fv), None)
+        assert rc == 0
+        # the diagonalised form with 1 - f written as lam / (s^2 + lam) (gcv_function_diag forms 1 - s^2/(s^2 + lam), which loses
+        # seven digits at lam = 1e-9; the resolvent form does not)
+        want = float(np.sum((lam / (s * s + lam) * rhs) ** 2)) / (m - float(np.sum(s * s / (s * s + lam)))) ** 2
+        assert abs(fv.value - want) <= 1e-9 * abs(want), (lam, fv.value, want)
+        assert abs(fv.value - gcv_function_diag(lam, s, rhs, "modified", m)) <= 1e-6 * abs(want)
+    l1 = fminbound_gcv_bidiag(al, be, beta0, m)
+    l2 = fminbound_gcv_diag(s, rhs, m)
+    g1, g2 = gcv_function_diag(l1, s, rhs, "modified", m), gcv_function_diag(l2, s, rhs, "modified", m)
+    assert abs(g1 - g2) <= 1e-9 * abs(g2) and (abs(l1 - l2) <= 1e-5 * abs(l2) or abs(g1 - g2) <= 1e-12 * abs(g2))

@@ -52,6 +52,24 @@ def fminbound_gcv_diag(s, rhs, m_eff, x1=1e-9, x2=1e2, xtol=1e-12, maxfun=1000):
     return lam.value
 
 
+def fminbound_gcv_bidiag(alphas, betas, beta0, m_eff, x1=1e-9, x2=1e2, xtol=1e-12, maxfun=1000):
+    """The same minimiser for the Golub-Kahan projected problem (B_k lower bidiagonal with diagonal `alphas`, sub-diagonal
+    `betas`; bhat = beta0 e1; 'modified' GCV with fullsize m_eff: Hybrid_LSQR.py:81-84) WITHOUT the SVD of B_k: G(lam) through
+    one LDL^T of a k x k tridiagonal matrix per evaluation (trk_host_gcv_bidiag)."""
+    import ctypes
+    al = np.ascontiguousarray(alphas, dtype=np.float64)
+    be = np.ascontiguousarray(betas, dtype=np.float64)
+    if al.size == 0 or al.size != be.size:
+        raise ValueError("fminbound_gcv_bidiag: need k >= 1 diagonal and k sub-diagonal entries")
+    lib = _host_lib()
+    lam = ctypes.c_double(0.0)
+    rc = lib.trk_host_gcv_bidiag(al.ctypes.data, be.ctypes.data, int(al.size), float(beta0), float(m_eff), float(x1), float(x2),
+                                 float(xtol), int(maxfun), ctypes.byref(lam), None, None)
+    if rc != 0:
+        raise RuntimeError("trk_host_gcv_bidiag failed")
+    return lam.value
+
+
 def _diagonalise(R_A, R_L, rhs):
     """(R_A, R_L) -> (s, U^T rhs) with G unchanged: substitute z = R_L y, M = R_A R_L^-1 = U diag(s) W^T; then
     R_A (R_A^T R_A + lam R_L^T R_L)^-1 R_A^T = U diag(s^2/(s^2+lam)) U^T.  None if R_L is (numerically) singular."""

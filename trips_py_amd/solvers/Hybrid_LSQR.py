@@ -12,7 +12,7 @@ from .._io import Formatter, History, as_operator
 from ..krylov import GKState
 from ..reg_param._bidiag import bidiag_svd_first_row, bidiag_svd_project
 from ..reg_param.discrepancy_principle import discrepancy_principle
-from ..reg_param.gcv import fminbound_gcv_diag
+from ..reg_param.gcv import fminbound_gcv_diag, fminbound_gcv_bidiag
 from ._common import check_delta, choose_lambda, small_host_blas
 
 
@@ -68,9 +68,13 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             bhat = np.zeros(k + 1)
             bhat[0] = gk.beta0
         if isinstance(regparam, str) and regparam == "gcv":
-            # svd(B) (:81) enters GCV through s and Q_A^T bhat = beta0 * (first row of the left vectors) only
-            s, u0 = bidiag_svd_first_row(gk._alphas[:k], gk._betas[:k])
-            lam = fminbound_gcv_diag(s, gk.beta0 * u0, m)              # variant 'modified', fullsize = m (:84)
+            # svd(B) (:81) enters GCV through s and Q_A^T bhat = beta0 * (first row of the left vectors) only — and G(lam) is a
+            # resolvent of the tridiagonal B B^T: evaluated without the SVD (trk_host_gcv_bidiag); variant 'modified', fullsize = m (:84)
+            if kwargs.get("gcv_by_svd", False):
+                s, u0 = bidiag_svd_first_row(gk._alphas[:k], gk._betas[:k])
+                lam = fminbound_gcv_diag(s, gk.beta0 * u0, m)
+            else:
+                lam = fminbound_gcv_bidiag(gk._alphas[:k], gk._betas[:k], gk.beta0, m)
         elif isinstance(regparam, str) and regparam == "l_curve":
             Qb, s, _ = sla.svd(B, full_matrices=False)
             lam = choose_lambda(regparam, np.diag(s), np.eye(k), Qb.T @ bhat, 0.0, kwargs, variant="modified", fullsize=m)
