@@ -282,6 +282,13 @@ int trk_host_gcv_bidiag(const double* alpha, const double* beta, int k, double b
 int trk_host_dp_newton(const double* sv, const double* bhat, int n, double target, double extra, double* alpha_out,
                        int* alpha_set, int* iters_out);
 
+/* HOST function: the same Newton iteration for the hybrid solvers' bidiagonal projected problem (B_k as in trk_host_gcv_bidiag,
+ * bproj = U^T b, k+1 host doubles) without the SVD of B_k: one LDL^T of a k x k tridiagonal matrix and two solves per step.
+ * *alpha_out = 0 with *alpha_set = 1 when the discrepancy cannot be reached yet (testzero >= 0, discrepancy_principle.py:71-76;
+ * *testzero_out, if not NULL, receives that quantity); *alpha_set = 0: the reference's unassigned value. */
+int trk_host_dp_bidiag(const double* alpha, const double* beta_sub, int k, const double* bproj, double target, double extra,
+                       double* alpha_out, int* alpha_set, int* iters_out, double* testzero_out);
+
 /* n_iters consecutive CGLS iterations (numbers k_first .. k_first + n_iters - 1, 1-based) enqueued by one call: the loop
  * body of trips/solvers/CGLS.py:56-80 with tol = 0, i.e. nothing is read back between iterations.  Same kernels, scalar
  * layout and results as calling trk_op_apply / trk_cgls_update_xr_deferred / trk_op_apply / trk_axpby per iteration:

@@ -149,3 +149,28 @@ def test_gcv_of_the_bidiagonal_problem_without_its_svd(k):
     l2 = fminbound_gcv_diag(s, rhs, m)
     g1, g2 = gcv_function_diag(l1, s, rhs, "modified", m), gcv_function_diag(l2, s, rhs, "modified", m)
     assert abs(g1 - g2) <= 1e-9 * abs(g2) and (abs(l1 - l2) <= 1e-5 * abs(l2) or abs(g1 - g2) <= 1e-12 * abs(g2))
+
+
+@pytest.mark.parametrize("k", [1, 3, 25, 90])
+def test_discrepancy_principle_of_the_bidiagonal_problem_without_its_svd(k):
+    """trk_host_dp_bidiag against the SVD route (`discrepancy_principle(spectrum=...)`, the reference's Newton iteration of
+    discrepancy_principle.py:80-99 on svd(B_k)): the same alpha, and the same `0` when the discrepancy cannot be reached."""
+    from trips_py_amd.reg_param._bidiag import bidiag_svd_project
+    from trips_py_amd.reg_param.discrepancy_principle import discrepancy_principle_bidiag
+    rng = np.random.default_rng(100 + k)
+    al = np.abs(rng.standard_normal(k)) * np.logspace(0, -2, k) + 1e-3
+    be = np.abs(rng.standard_normal(k)) * np.logspace(0, -2, k) + 1e-3
+    bproj = rng.standard_normal(k + 1) * np.logspace(0, -3, k + 1) * 5.0
+    s, proj = bidiag_svd_project(al, be, bproj)
+    null = abs(proj[-1])
+    nb = float(np.linalg.norm(bproj))
+    # below the null-vector component: unreachable, alpha = 0; then targets between it and ||b||^2, where a positive alpha exists
+    # (above ||b||^2 none does and the reference's Newton iteration runs into inf - inf: not compared)
+    deltas = [0.5 * null] + [float(np.sqrt(null ** 2 + f * (nb ** 2 - null ** 2))) / 1.01 for f in (0.05, 0.5, 0.95)]
+    for delta in deltas:
+        want = discrepancy_principle(None, None, None, 0.0, delta=float(delta), L_is_identity=True, spectrum=(s, proj, (k + 1, k)))
+        got = discrepancy_principle_bidiag(al, be, bproj, delta=float(delta))
+        if want in (0, None):
+            assert got == want, (delta, got, want)
+        else:
+            assert abs(got - want) <= 1e-8 * abs(want), (delta, got, want)

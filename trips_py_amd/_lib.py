@@ -179,6 +179,8 @@ SIGNATURES = {
     "trk_host_dp_newton": (c_int, [c_f64p, c_f64p, c_int, c_dbl, c_dbl, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int),
                                   ctypes.POINTER(c_int)]),
     "trk_host_gcv_fminbound": (c_int, [c_f64p, c_f64p, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_int, ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
+    "trk_host_dp_bidiag": (c_int, [c_f64p, c_f64p, c_int, c_f64p, c_dbl, c_dbl, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int),
+                                   ctypes.POINTER(c_int), ctypes.POINTER(c_dbl)]),
     "trk_host_gcv_bidiag": (c_int, [c_f64p, c_f64p, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int, ctypes.POINTER(c_dbl),
                                     ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
     "trk_cgls_iterate": (c_int, [c_op, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_int, c_f32p, c_f32p,

@@ -642,6 +642,71 @@ extern "C" int trk_hess_tikhonov(double* H, int ldh, double* G, double* Minv, in
   return TRK_OK;
 }
 
+// The discrepancy principle's Newton iteration (trk_host_dp_newton) for the bidiagonal projected problem without the SVD of B_k:
+// with B = Q [R; 0] and w = Q^T bproj, || bhat / (sv beta + 1) ||^2 = || (beta R R^T + I)^-1 w_{1..k} ||^2 + w_{k+1}^2 — the last entry
+// is the component along the left null vector of B, which the Newton step does not move — so every step is one LDL^T of a
+// k x k tridiagonal matrix and two solves with it.  Same start (beta = 1e-8), same stopping rule, same `testzero` branch
+// (discrepancy_principle.py:68-99).
+extern "C" int trk_host_dp_bidiag(const double* alpha, const double* beta_sub, int k, const double* bproj, double target,
+                                  double extra, double* alpha_out, int* alpha_set, int* iters_out, double* testzero_out) {
+  TRK_REQUIRE(alpha && beta_sub && bproj && alpha_out && alpha_set, "trk_host_dp_bidiag: NULL argument");
+  TRK_REQUIRE(k >= 1, "trk_host_dp_bidiag: k must be >= 1");
+  std::vector<double> wk(7 * (size_t)k + 1);
+  double *md = wk.data(), *mo = md + k, *w = mo + k, *d = w + (k + 1), *z = d + k, *y = z + k, *tmp = y + k;
+  for (int j = 0; j <= k; ++j) w[j] = bproj[j];
+  double diag = alpha[0], t_prev = 0.0;
+  for (int j = 0; j < k; ++j) {                                  // rotation j mixes rows j, j+1 of B and of w
+    const double rr = std::hypot(diag, beta_sub[j]);
+    const double c = rr > 0.0 ? diag / rr : 1.0, sn = rr > 0.0 ? beta_sub[j] / rr : 0.0;
+    const double wj = c * w[j] + sn * w[j + 1], wn = -sn * w[j] + c * w[j + 1];
+    w[j] = wj;
+    w[j + 1] = wn;
+    const double t = (j + 1 < k) ? sn * alpha[j + 1] : 0.0;
+    md[j] = rr * rr + t * t;
+    if (j > 0) mo[j - 1] = t_prev * rr;
+    t_prev = t;
+    diag = (j + 1 < k) ? c * alpha[j + 1] : 0.0;
+  }
+  const double null2 = w[k] * w[k];
+  const double testzero = null2 - target + extra;                // (:71-76) the discrepancy cannot be reached yet
+  if (testzero_out) *testzero_out = testzero;
+  *alpha_out = 0.0;
+  *alpha_set = 1;
+  if (iters_out) *iters_out = 0;
+  if (!(testzero < 0.0)) return TRK_OK;
+  auto solve = [&](double bt, const double* rhs, double* out) {  // (bt M + I) out = rhs with the pivots in d (Thomas)
+    tmp[0] = rhs[0];
+    for (int j = 1; j < k; ++j) tmp[j] = rhs[j] - bt * mo[j - 1] / d[j - 1] * tmp[j - 1];
+    out[k - 1] = tmp[k - 1] / d[k - 1];
+    for (int j = k - 2; j >= 0; --j) out[j] = (tmp[j] - bt * mo[j] * out[j + 1]) / d[j];
+  };
+  double bt = 1e-8, al = 0.0;
+  int it = 0, have = 0;
+  while (it < 30 || (it <= 100 && std::fabs(al) < 1e-16)) {
+    d[0] = bt * md[0] + 1.0;
+    for (int j = 1; j < k; ++j) d[j] = bt * md[j] + 1.0 - (bt * mo[j - 1]) * (bt * mo[j - 1]) / d[j - 1];
+    solve(bt, w, z);
+    solve(bt, z, y);
+    double zz = null2, zwz = 0.0;
+    for (int j = 0; j < k; ++j) {
+      zz += z[j] * z[j];
+      zwz += z[j] * (y[j] - z[j]);
+    }
+    const double f = zz + extra - target;
+    const double fp = 2.0 / bt * zwz;
+    const double bt_new = bt - f / fp;
+    if (std::fabs(bt_new - bt) < 1e-12 * bt) break;
+    bt = bt_new;
+    al = 1.0 / bt_new;
+    have = 1;
+    ++it;
+  }
+  *alpha_out = al;
+  *alpha_set = have;
+  if (iters_out) *iters_out = it;
+  return TRK_OK;
+}
+
 extern "C" int trk_host_gcv_fminbound(const double* s, const double* rhs, int k, double m_eff, double x1, double x2,
                                       double xatol, int maxfun, double* lam_out, double* fval_out, int* nfev_out) {
   TRK_REQUIRE(s && rhs && lam_out, "trk_host_gcv_fminbound: NULL argument");

@@ -1,5 +1,7 @@
 """Discrepancy principle on projected factors (reference: trips/utilities/reg_param/discrepancy_principle.py:19-99,
 dptype='tikhonov')."""
+import ctypes
+
 import numpy as np
 import scipy.linalg as sla
 
@@ -15,6 +17,26 @@ def _newton(sv, bhat, target, extra):
     alpha, have = ctypes.c_double(0.0), ctypes.c_int(0)
     _lib.check(lib.trk_host_dp_newton(sv.ctypes.data, bhat.ctypes.data, int(sv.size), float(target), float(extra),
                                       ctypes.byref(alpha), ctypes.byref(have), None), "trk_host_dp_newton")
+    return alpha.value if have.value else None
+
+
+def discrepancy_principle_bidiag(alphas, betas, bproj, delta=None, eta=1.01, resid2=0.0, explicitProj=False, **_ignored):
+    """`discrepancy_principle` for the Golub-Kahan projected problem (B_k lower bidiagonal: diagonal `alphas`, sub-diagonal `betas`;
+    bproj = U^T b with k+1 entries; L = I) without the SVD of B_k (trk_host_dp_bidiag): same Newton iteration, same branches."""
+    if not isinstance(delta, (float, int)):
+        raise Exception("A value for the noise level delta was not provided and the discrepancy principle cannot be applied. "
+                        "Please supply a value of delta based on the estimated noise level of the problem, or choose the "
+                        "regularization parameter according to gcv.")
+    al = np.ascontiguousarray(alphas, dtype=np.float64)
+    be = np.ascontiguousarray(betas, dtype=np.float64)
+    bp = np.ascontiguousarray(np.asarray(bproj, dtype=np.float64).reshape(-1))
+    if al.size < 1 or be.size != al.size or bp.size != al.size + 1:
+        raise ValueError("discrepancy_principle_bidiag: need k diagonal, k sub-diagonal and k + 1 projected entries")
+    from .. import _lib
+    alpha, have = ctypes.c_double(0.0), ctypes.c_int(0)
+    _lib.check(_lib.load().trk_host_dp_bidiag(al.ctypes.data, be.ctypes.data, int(al.size), bp.ctypes.data, float((eta * delta) ** 2),
+                                              float(resid2 if explicitProj else 0.0), ctypes.byref(alpha), ctypes.byref(have),
+                                              None, None), "trk_host_dp_bidiag")
     return alpha.value if have.value else None
 
 

@@ -11,7 +11,7 @@ import scipy.linalg as sla
 from .._io import Formatter, History, as_operator
 from ..krylov import GKState
 from ..reg_param._bidiag import bidiag_svd_first_row, bidiag_svd_project
-from ..reg_param.discrepancy_principle import discrepancy_principle
+from ..reg_param.discrepancy_principle import discrepancy_principle, discrepancy_principle_bidiag
 from ..reg_param.gcv import fminbound_gcv_diag, fminbound_gcv_bidiag
 from ._common import check_delta, choose_lambda, small_host_blas
 
@@ -82,10 +82,13 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             # discrepancy_principle(U, B, L, b): projects b on the (no longer exactly orthonormal) computed U (:86)
             # U^T b row by row, downloaded with each step's norms (krylov.GKState.step_prefetch): no pass over U, no blocking copy
             bproj = np.asarray(gk.uproj[:k + 1]) / np.concatenate(([gk.beta0], gk._betas[:k]))   # rows of U are beta_j u_j
-            s, proj = bidiag_svd_project(gk._alphas[:k], gk._betas[:k], bproj)       # svd(B_k), U^T bproj (dp :68-70)
             extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
-            lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
-                                        spectrum=(s, proj, (k + 1, k)), **extra)
+            if kwargs.get("dp_by_svd", False):
+                s, proj = bidiag_svd_project(gk._alphas[:k], gk._betas[:k], bproj)       # svd(B_k), U^T bproj (dp :68-70)
+                lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
+                                            spectrum=(s, proj, (k + 1, k)), **extra)
+            else:                                # the same Newton iteration on the tridiagonal resolvent: no SVD of B_k
+                lam = discrepancy_principle_bidiag(gk._alphas[:k], gk._betas[:k], bproj, delta=kwargs.get("delta"), **extra)
         else:
             lam = regparam
         lams.append(lam)
