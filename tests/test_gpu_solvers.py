@@ -342,3 +342,29 @@ def test_gks_gram_rows_from_the_sweep_equal_the_separate_pass(kind):
     for k in (0, 10, 29):
         u, v = ia["xHistory"][k].reshape(-1), ib["xHistory"][k].reshape(-1)
         assert float(torch.linalg.norm(u - v) / torch.linalg.norm(v)) < 1e-5, k
+
+
+def test_mmgks_pnorm2_unweighted_fidelity_gram_kept_incrementally():
+    """MMGKS with pnorm = 2: wf = 1, so (AV)^T AV is unweighted and only grows — kept as in GKS (row k = V^T (A^T A v_k), no images
+    A v_j, no weighted-Gram pass over them) while the L side is re-weighted every iteration.  Same iterates, residual norms and
+    errors as the form that re-forms both weighted Grams, over 25 iterations."""
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import Blur2D, FirstDerivative2D
+    from trips_py_amd.problems import gauss_psf
+    N = 160
+    A = Blur2D(gauss_psf((9, 9), (2, 2))[0], N, N)
+    L = FirstDerivative2D(N)
+    dev = A.engine.device
+    xt = torch.zeros(N, N, device=dev)
+    xt[30:90, 40:120] = 1.0
+    xt[100:140, 20:70] = 0.5
+    xt = xt.reshape(-1)
+    b = A.apply(xt)
+    b = b + 0.01 * torch.randn(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * b.norm() / N
+    xa, ia = S.MMGKS(A, b, L, 2, 1, 3, 25, 1e-2, xt)
+    xb, ib = S.MMGKS(A, b, L, 2, 1, 3, 25, 1e-2, xt, unweighted_fidelity_gram=False)
+    assert float(torch.linalg.norm(xa - xb) / torch.linalg.norm(xb)) < 1e-5
+    assert np.allclose(ia["relError"], ib["relError"], rtol=1e-5) and np.allclose(ia["Residual"], ib["Residual"], rtol=1e-3)
+    for k in (0, 12, 24):
+        u, v = ia["xHistory"][k].reshape(-1), ib["xHistory"][k].reshape(-1)
+        assert float(torch.linalg.norm(u - v) / torch.linalg.norm(v)) < 1e-5, k

@@ -29,7 +29,7 @@ class _ProjectedBases:
     per vector); both right-hand sides share ONE sweep over V (trk_gemv_t2), and c[j] = v_j . (A^T b).  Otherwise (the Radon
     projector: m is small and the residual wants (AV) y) the images are kept as row-per-vector bases as before."""
 
-    def __init__(self, A, L, bv, V0, kmax, on_device=False, from_v_A=False, from_v_L=False):
+    def __init__(self, A, L, bv, V0, kmax, on_device=False, from_v_A=False, from_v_L=False, use_L=True):
         self.A, self.L, self.eng, self.bv = A, L, A.engine, bv
         eng = self.eng
         # on_device: the Gram data stays on the device (rows installed by a tiny kernel) and nothing is downloaded — the
@@ -43,9 +43,11 @@ class _ProjectedBases:
         p = L.shape[0]
         self.V = V0
         self.V.reserve(kmax)
-        self.from_v_A, self.from_v_L = bool(from_v_A), bool(from_v_L)
+        # use_L = False (MMGKS with pnorm = 2: only the A side is unweighted and grows; the caller keeps the weighted L side)
+        self.use_L = bool(use_L)
+        self.from_v_A, self.from_v_L = bool(from_v_A), bool(from_v_L) and self.use_L
         self.AV = None if self.from_v_A else DeviceBasis(eng, m, kmax)
-        self.LV = None if self.from_v_L else DeviceBasis(eng, p, kmax)
+        self.LV = None if (self.from_v_L or not self.use_L) else DeviceBasis(eng, p, kmax)
         if self.from_v_A:
             self.tA, self.zA, self.atb = eng.empty(m), eng.empty(n), eng.empty(n)
             A.apply(bv, out=self.atb, transpose=True)
@@ -74,7 +76,9 @@ class _ProjectedBases:
             self.A.apply(v, out=av)
             self.AV.commit()
             eng.dot(av, self.bv, c_out)
-        if self.from_v_L:
+        if not self.use_L:
+            pass
+        elif self.from_v_L:
             if self.tL is None:
                 self.L.tv_grad(v, None, None, 1.0, out=self.zL)           # z_L = L^T L v in one stencil pass
             else:
@@ -84,7 +88,12 @@ class _ProjectedBases:
             lv = self.LV.next_slot()
             self.L.apply(v, out=lv)
             self.LV.commit()
-        if self.from_v_A and self.from_v_L:
+        if not self.use_L:
+            if self.from_v_A:
+                eng.gemv_t(self.V.data, k, self.zA, S.ref(0))
+            else:
+                eng.gemv_t(self.AV.data, k, av, S.ref(0))
+        elif self.from_v_A and self.from_v_L:
             eng.gemv_t2(self.V.data, k, self.zA, self.zL, S.ref(0))       # both Gram rows from one sweep over V
         else:
             if self.from_v_A:
@@ -99,7 +108,8 @@ class _ProjectedBases:
             eng.allreduce(S, 0, 2 * k)
             eng.allreduce(self.c_d, j, j + 1)
             eng.cgs_coeffs(self.GA_d.ref(0), self.kmax, None, S.ref(0), k, 0, None)     # install row / column j
-            eng.cgs_coeffs(self.GL_d.ref(0), self.kmax, None, S.ref(k), k, 0, None)
+            if self.use_L:
+                eng.cgs_coeffs(self.GL_d.ref(0), self.kmax, None, S.ref(k), k, 0, None)
             return
         eng.allreduce(S, 0, 2 * k + 1)
         h = S.host(0, 2 * k + 1)

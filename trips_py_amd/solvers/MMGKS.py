@@ -95,16 +95,30 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
                             **{k_: v_ for k_, v_ in kwargs.items() if k_ in ("gk_eta", "gk_delta")})
     V = gk.V
     V.reserve(kmax)
-    AV, LV = DeviceBasis(eng, m, kmax), DeviceBasis(eng, p_rows, kmax)
+    dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
+    # numeric regparam: the projected problem is solved on the device (trk_gram_tikhonov), nothing visits the host in the loop
+    on_dev = (not isinstance(regparam, str)) and hasattr(eng, "gram_tikhonov") and kwargs.get("device_solve", True)
+    # pnorm = 2: wf = ((A x - b)^2 + eps^2)^0 = 1, the fidelity Gram (AV)^T AV is UNWEIGHTED and only grows — it is kept as in GKS
+    # (solvers/GKS._ProjectedBases): new row = V^T (A^T A v_new), one pass over V (n floats per vector) instead of the weighted-Gram
+    # pass over the images A v_j, which are not stored; the L side stays re-weighted every iteration (trk_wgram over LV)
+    unit_A = (pnorm == 2 and on_dev and dA and hasattr(eng, "gram_row_from_sweep") and hasattr(eng, "cgs_coeffs")
+              and kmax <= eng.GRAM_TIKHONOV_MAX_K and kwargs.get("gram_sweeps", True) and kwargs.get("unweighted_fidelity_gram", True))
+    AV = None if unit_A else DeviceBasis(eng, m, kmax)
+    LV = DeviceBasis(eng, p_rows, kmax)
 
     def push_images(j):
-        A.apply(V[j], out=AV.next_slot())
+        if AV is not None:
+            A.apply(V[j], out=AV.next_slot())
+            AV.commit()
         L.apply(V[j], out=LV.next_slot())
-        AV.commit()
         LV.commit()
 
     for j in range(V.k):
         push_images(j)
+    pbA = None
+    if unit_A:
+        from .GKS import _ProjectedBases
+        pbA = _ProjectedBases(A, L, bv, V, kmax, on_device=True, from_v_A=True, use_L=False)
     Hs = History(eng, kwargs.get("history", True), n_iter, n, "MMGKS xHistory")
     x_cur = eng.empty(n)
     A.apply(bv, out=x_cur, transpose=True)                                            # x = A^T b (:43)
@@ -123,15 +137,12 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     # A x and L x of the iterate are needed twice: in the residual of this iteration (the reference forms them as
     # (AV) y and (LV) y, :114-116) and in the weights of the next (A @ x, L @ x, :56,:60).  A stencil operator forms them
     # once, directly — 8n-12n bytes instead of reading k basis vectors; others keep the basis products.
-    dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
     # the 2-D first-difference L has fused forms (trk_tv_weights / trk_tv_grad): L x is never written out
     fusedL = dL and hasattr(L, "tv_grad") and not iso and not gs and kwargs.get("fused_tv", True)
     A.apply(x_cur, out=ax)
     if not fusedL:
         L.apply(x_cur, out=lx)
 
-    # numeric regparam: the projected problem is solved on the device (trk_gram_tikhonov), nothing visits the host in the loop
-    on_dev = (not isinstance(regparam, str)) and hasattr(eng, "gram_tikhonov") and kwargs.get("device_solve", True)
     # the two Gram-Schmidt sweeps per iteration by Gram matrix (two passes over V instead of three / four)
     gs_gram = GramSchmidtByGram(eng, V, kmax) if (hasattr(eng, "cgs_coeffs") and kwargs.get("gram_sweeps", True)) else None
     lams, res, lam, x_dev, its = [], [], None, None, 0
@@ -151,10 +162,16 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         else:
             eng.mm_weights(lx, None, epsilon, qnorm, wr)
         # weighted Gram matrices and projected right-hand sides
-        eng.wgram(AV.data, k, wf, bv, G.ref(0), G.ref(2 * kk), G.ref(2 * kk + k))
+        if pbA is None:
+            eng.wgram(AV.data, k, wf, bv, G.ref(0), G.ref(2 * kk), G.ref(2 * kk + k))
         eng.wgram(LV.data, k, wr, None, G.ref(kk))
         nred = 2 * kk + 2 * k
-        if on_dev and k <= eng.GRAM_TIKHONOV_MAX_K:
+        if pbA is not None:
+            eng.allreduce(G, kk, 2 * kk)
+            lam = regparam
+            lams.append(lam)
+            eng.gram_tikhonov(pbA.GA_d.ref(0), kmax, G.ref(kk), k, pbA.c_d.ref(0), k, lam, Y.ref(0))
+        elif on_dev and k <= eng.GRAM_TIKHONOV_MAX_K:
             # numeric regparam: y = (G_A + lam G_L)^-1 (AV wf)^T b on the device (:106; the UNWEIGHTED b, sic) — no host round trip
             eng.allreduce(G, 0, nred)
             lam = regparam
@@ -213,13 +230,23 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             L.apply(tp, out=rb, transpose=True)
             eng.axpby(1.0, r, float(lam), rb, r)
         vn = V.next_slot()
-        if gs_gram is not None:
+        # (GKS takes that row from the sweep's own pass over V; here r is NOT orthogonal to V — the residual carries the weights to
+        #  the first power, the projected problem to the second — so the coefficients c are not small and the row's algebra
+        #  amplifies fp32 rounding: the reference golden went from 2.4e-7 to 1.6e-5.  Opt-in only.)
+        merged = pbA is not None and gs_gram is not None and gs_gram.in_G == k - 1 and kwargs.get("gram_rows_from_sweep", False)
+        if merged:
+            cc = gs_gram.sweep(k, r, 2, vn, sumsq=Rn.ref(ii), extra=pbA.sweep_operands(r))   # ... and V^T (A^T A r) on the same pass
+        elif gs_gram is not None:
             gs_gram.sweep(k, r, 2, vn, sumsq=Rn.ref(ii))                              # (:119-120) two sweeps, ||r||^2 fused
         else:
             orthogonalize(eng, V, k, r, H, 0, passes=2, out=vn, sumsq=Rn.ref(ii))
         eng.allreduce(Rn, ii, ii + 1)
         eng.scale(Coef(1.0, den=Rn.ref(ii), sqrt_den=True), vn, vn)                  # vn = r / ||r|| (:121-123)
         V.commit()
+        if merged:
+            pbA.append_from_sweep(gs_gram, k, cc, Rn.ref(ii))
+        elif pbA is not None:
+            pbA.append()
         push_images(V.k - 1)
         res.append(ii)
     nres = len(res)
