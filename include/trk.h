@@ -159,8 +159,9 @@ int trk_group_weights(const float* d, int64_t groups, int group_len, double add,
 int trk_isotv_weights(const float* x, int N, int nt, const float* u_tail, int64_t n_tail, double eps, double q, float* out,
                       trk_stream stream);
 
-/* Fused forms of the 2-D first-difference regulariser (L from trk_deriv2d_create) for the re-weighted solvers; nothing of
- * length 2N(N-1) is written and read back:
+/* Fused forms of the first-difference regularisers — L from trk_deriv2d_create, or from trk_spacetime_create on a rank that owns
+ * the whole time axis (no halos; weights laid out as the rows of L: per frame the 2N(N-1) spatial rows, then the temporal rows) —
+ * for the re-weighted solvers; nothing of the length of L x is written and read back:
  *   trk_tv_weights:  w = ((L x)^2 + eps^2)^(q/2-1)                 replaces  L @ x, then the weights of MMGKS.py:60,93
  *   trk_tv_grad:     out = r_in + lam * L^T (w .* (L x))           replaces  MMGKS.py:116-118 (w .* (L x), L^T, r + lam*rb)
  * w == NULL: unit weights (lam * L^T L x, the regularisation term of the GKS residual, GKS.py:81-84); r_in == NULL: 0.

@@ -441,3 +441,33 @@ def test_gram_tikhonov_bordered_inverse_against_solve(eng, kmax, lam):
                 eng.gram_tikhonov(GA_d.ref(0), kmax, GL_d.ref(0), kmax, c_d.ref(0), k, lam, Y0.ref(0))
                 assert relerr(Y0.host(0, k), want) < 1e-9, k
 
+
+
+@pytest.mark.parametrize("N,nt", [(16, 3), (33, 2), (64, 5), (256, 4)])
+@pytest.mark.parametrize("q", [1.0, 0.7])
+def test_fused_tv_forms_of_the_spacetime_operator(eng, N, nt, q):
+    """trk_tv_weights / trk_tv_grad on the space-time first-difference operator (one rank owns the time axis): weights bit for
+    bit with L @ x -> trk_mm_weights; the weighted and the unit-weight gradient against w * (L x) -> L^T -> r + lam * rb."""
+    from trips_py_amd.operators import SpaceTimeDerivative
+    L = SpaceTimeDerivative(N, nt, engine=eng)
+    assert L.fused_tv
+    n = N * N * nt
+    g = torch.Generator(device=eng.device).manual_seed(N + nt)
+    x = torch.randn(n, device=eng.device, generator=g)
+    r = torch.randn(n, device=eng.device, generator=g)
+    lam, eps = 0.41, 0.1
+    lx = L.apply(x)
+    w_ref, w = eng.empty(L.shape[0]), eng.empty(L.shape[0])
+    eng.mm_weights(lx, None, eps, q, w_ref)
+    L.tv_weights(x, eps, q, w)
+    assert torch.equal(w, w_ref)
+    tp, rb, want, got = eng.empty(L.shape[0]), eng.empty(n), eng.empty(n), eng.empty(n)
+    for ww in (w_ref, None):
+        if ww is None:
+            tp.copy_(lx)
+        else:
+            eng.mul(ww, lx, tp)
+        L.apply(tp, out=rb, transpose=True)
+        eng.axpby(1.0, r, lam, rb, want)
+        L.tv_grad(x, ww, r, lam, out=got)
+        assert relerr(got.cpu().numpy(), want.cpu().numpy()) < 3e-7, ww is None

@@ -167,26 +167,46 @@ __global__ __launch_bounds__(NT) void k_d2_adj(const float* __restrict__ y, int6
 // (W = false: unit weights, out = r_in + lam * L2^T L2 x, the GKS residual term GKS.py:81-84.)
 __global__ __launch_bounds__(NT) void k_tv_weights(const float* __restrict__ x, int N, float eps2, float e, int special,
                                                    float* __restrict__ w) {
+  // blockIdx.z = frame (space-time operator: frame-major images, per-frame spatial rows; the temporal rows: k_tvt_weights)
+  const int64_t npix = (int64_t)N * N, ps = 2 * (int64_t)N * (N - 1);
   double unused = 0.0;
-  d2_fwd_body<false, true>(x, w, N, eps2, e, special, unused);
+  d2_fwd_body<false, true>(x + blockIdx.z * npix, w + blockIdx.z * ps, N, eps2, e, special, unused);
 }
 
+// temporal rows of the space-time operator: w_t = ((x_t - x_{t+1})^2 + eps^2)^e, t < nt - 1 (blockIdx.y = t)
+__global__ __launch_bounds__(NT) void k_tvt_weights(const float* __restrict__ x, int64_t npix, float eps2, float e, int special,
+                                                    float* __restrict__ wt) {
+  const float* a = x + (int64_t)blockIdx.y * npix;
+  float* o = wt + (int64_t)blockIdx.y * npix;
+  for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < npix; idx += (int64_t)gridDim.x * NT)
+    o[idx] = mm_w(a[idx] - a[idx + npix], eps2, e, special);
+}
+
+// nt > 1: the space-time operator (single rank).  blockIdx.z = frame; w = [nt x 2N(N-1) spatial | (nt-1) x N^2 temporal] as the rows
+// of L; the temporal part adds wt_t (x_t - x_{t+1}) - wt_{t-1} (x_{t-1} - x_t) to frame t.
 template <bool W, bool RIN>
 __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, const float* __restrict__ w,
-                                                const float* __restrict__ rin, float lam, float* __restrict__ out, int N) {
-  const float* __restrict__ wh = w;
-  const float* __restrict__ wv = w + (int64_t)N * (N - 1);
+                                                const float* __restrict__ rin, float lam, float* __restrict__ out, int N, int nt) {
+  const int f = blockIdx.z;
+  const int64_t npix = (int64_t)N * N, ps = 2 * (int64_t)N * (N - 1);
+  const float* __restrict__ xf = x + f * npix;
+  const float* __restrict__ wh = W ? w + f * ps : nullptr;
+  const float* __restrict__ wv = W ? wh + (int64_t)N * (N - 1) : nullptr;
+  const float* __restrict__ wt = (W && nt > 1) ? w + nt * ps : nullptr;      // temporal weights, row t at wt + t npix
+  rin = RIN ? rin + f * npix : rin;
+  out += f * npix;
   const int j = blockIdx.x * NT + threadIdx.x;
   if (j >= N) return;
   const bool hr = j < N - 1, hl = j > 0;
+  const bool tnext = nt > 1 && f < nt - 1, tprev = nt > 1 && f > 0;
   for (int i0 = blockIdx.y * RB; i0 < N; i0 += gridDim.y * RB) {
     const int64_t o0 = (int64_t)i0 * N + j;
     const int64_t h0 = (int64_t)i0 * (N - 1) + j;
-    float xc[RB + 2], xl[RB], xr[RB], wc[RB], wp[RB], v[RB + 1], rr[RB];
+    float xc[RB + 2], xl[RB], xr[RB], wc[RB], wp[RB], v[RB + 1], rr[RB], xn[RB], xp[RB], wn[RB], wq[RB];
 #pragma unroll
     for (int t = 0; t < RB + 2; ++t) {   // xc[t] = x[i0 + t - 1][j]
       const int i = i0 + t - 1;
-      xc[t] = (i >= 0 && i < N) ? x[o0 + (int64_t)(t - 1) * N] : 0.f;
+      xc[t] = (i >= 0 && i < N) ? xf[o0 + (int64_t)(t - 1) * N] : 0.f;
     }
 #pragma unroll
     for (int t = 0; t <= RB; ++t) {      // v[t] = wv[i0 + t - 1][j]
@@ -197,11 +217,15 @@ __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, con
     for (int t = 0; t < RB; ++t) {
       const bool in = i0 + t < N;
       const int64_t o = o0 + (int64_t)t * N, hb = h0 + (int64_t)t * (N - 1);
-      xr[t] = (in && hr) ? x[o + 1] : 0.f;
-      xl[t] = (in && hl) ? x[o - 1] : 0.f;
+      xr[t] = (in && hr) ? xf[o + 1] : 0.f;
+      xl[t] = (in && hl) ? xf[o - 1] : 0.f;
       wc[t] = W ? ((in && hr) ? wh[hb] : 0.f) : 1.f;
       wp[t] = W ? ((in && hl) ? wh[hb - 1] : 0.f) : 1.f;
       rr[t] = (RIN && in) ? rin[o] : 0.f;
+      xn[t] = (in && tnext) ? xf[o + npix] : 0.f;
+      xp[t] = (in && tprev) ? xf[o - npix] : 0.f;
+      wn[t] = W ? ((in && tnext) ? wt[(int64_t)f * npix + o] : 0.f) : 1.f;
+      wq[t] = W ? ((in && tprev) ? wt[(int64_t)(f - 1) * npix + o] : 0.f) : 1.f;
     }
 #pragma unroll
     for (int t = 0; t < RB; ++t) {
@@ -213,6 +237,8 @@ __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, con
         if (hl) acc -= __fmul_rn(wp[t], xl[t] - c);
         if (i < N - 1) acc += __fmul_rn(v[t + 1], c - xc[t + 2]);
         if (i > 0) acc -= __fmul_rn(v[t], xc[t] - c);
+        if (tnext) acc += __fmul_rn(wn[t], c - xn[t]);             // same order as k_d2_adj<TEMPORAL>: + T_t - T_{t-1}
+        if (tprev) acc -= __fmul_rn(wq[t], xp[t] - c);
         out[o0 + (int64_t)t * N] = RIN ? rr[t] + lam * acc : lam * acc;
       }
     }
@@ -338,25 +364,48 @@ int trk_spacetime_create(int N, int nt_local, int has_next, int has_prev, trk_op
   return TRK_OK;
 }
 
+// N and the frame count of a first-difference regulariser the fused TV forms serve: the 2-D operator, or the space-time operator
+// of one rank that owns the whole time axis (no halos)
+static int tv_geometry(trk_op* L, const char* who, int* N, int* nt) {
+  if (L->kind == 3) {
+    *N = static_cast<D2Impl*>(L->impl)->N;
+    *nt = 1;
+    return TRK_OK;
+  }
+  if (L->kind == 4) {
+    auto* im = static_cast<STImpl*>(L->impl);
+    if (im->has_next || im->has_prev) return fail(TRK_EUNSUPPORTED, "%s: the time axis is sharded over ranks (halo rows): use the operator's apply", who);
+    *N = im->N;
+    *nt = im->nt;
+    return TRK_OK;
+  }
+  return fail(TRK_EINVAL, "%s: L must come from trk_deriv2d_create or trk_spacetime_create", who);
+}
+
 int trk_tv_weights(trk_op* L, const float* x, double eps, double q, float* w, trk_stream st) {
   TRK_REQUIRE(L && x && w, "trk_tv_weights: NULL argument");
-  TRK_REQUIRE(L->kind == 3, "trk_tv_weights: L must come from trk_deriv2d_create");
-  const int N = static_cast<D2Impl*>(L->impl)->N;
+  int N = 0, nt = 0;
+  if (int rc = tv_geometry(L, "trk_tv_weights", &N, &nt)) return rc;
   const float e = (float)(q / 2.0 - 1.0), eps2 = (float)(eps * eps);
   const int special = (q == 2.0) ? 1 : (q == 1.0) ? 2 : 0;
-  hipLaunchKernelGGL(k_tv_weights, grid2(N, 1, false).g, dim3(NT), 0, (hipStream_t)st, x, N, eps2, e, special, w);
+  hipLaunchKernelGGL(k_tv_weights, grid2(N, nt, false).g, dim3(NT), 0, (hipStream_t)st, x, N, eps2, e, special, w);
+  if (nt > 1) {
+    const int64_t npix = (int64_t)N * N;
+    hipLaunchKernelGGL(k_tvt_weights, dim3(grid_for(npix), nt - 1), dim3(NT), 0, (hipStream_t)st, x, npix, eps2, e, special,
+                       w + (int64_t)nt * 2 * N * (N - 1));
+  }
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }
 
 int trk_tv_grad(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, trk_stream st) {
   TRK_REQUIRE(L && x && out, "trk_tv_grad: NULL argument");
-  TRK_REQUIRE(L->kind == 3, "trk_tv_grad: L must come from trk_deriv2d_create");
   TRK_REQUIRE(out != x && out != r_in, "trk_tv_grad: out must not alias x or r_in");
-  const int N = static_cast<D2Impl*>(L->impl)->N;
-  const dim3 g = grid2(N, 1, false).g;
+  int N = 0, nt = 0;
+  if (int rc = tv_geometry(L, "trk_tv_grad", &N, &nt)) return rc;
+  const dim3 g = grid2(N, nt, false).g;
   hipStream_t s = (hipStream_t)st;
-#define TG(W, R) hipLaunchKernelGGL((k_tv_grad<W, R>), g, dim3(NT), 0, s, x, w, r_in, (float)lam, out, N)
+#define TG(W, R) hipLaunchKernelGGL((k_tv_grad<W, R>), g, dim3(NT), 0, s, x, w, r_in, (float)lam, out, N, nt)
   if (w) { if (r_in) TG(true, true); else TG(true, false); }
   else   { if (r_in) TG(false, true); else TG(false, false); }
 #undef TG

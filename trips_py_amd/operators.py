@@ -259,16 +259,11 @@ class FanBeam2D(_HandleOperator):
         super().__init__(h, engine)
 
 
-class FirstDerivative2D(_HandleOperator):
-    def __init__(self, N, engine=None):
-        engine = engine if engine is not None else default_engine()
-        self.N = int(N)
-        h = ctypes.c_void_p()
-        _lib.check(engine.lib.trk_deriv2d_create(self.N, ctypes.byref(h)), "trk_deriv2d_create")
-        super().__init__(h, engine)
-        self.streaming = True
+class _FusedTV:
+    """Fused forms of a first-difference regulariser for the re-weighted solvers (trk_tv_weights / trk_tv_grad): no vector of
+    the length of L x in between.  `fused_tv` says whether this operator instance has them."""
+    fused_tv = True
 
-    # fused forms for the re-weighted solvers (trk_tv_weights / trk_tv_grad): no vector of length 2N(N-1) in between
     def tv_weights(self, x, eps, q, out):
         """out = ((L x)^2 + eps^2)^(q/2-1) (MMGKS.py:60,93)."""
         _lib.check(self.engine.lib.trk_tv_weights(self._h, x.data_ptr(), float(eps), float(q), out.data_ptr(),
@@ -282,7 +277,17 @@ class FirstDerivative2D(_HandleOperator):
         _lib.check(rc, "trk_tv_grad")
 
 
-class SpaceTimeDerivative(_HandleOperator):
+class FirstDerivative2D(_FusedTV, _HandleOperator):
+    def __init__(self, N, engine=None):
+        engine = engine if engine is not None else default_engine()
+        self.N = int(N)
+        h = ctypes.c_void_p()
+        _lib.check(engine.lib.trk_deriv2d_create(self.N, ctypes.byref(h)), "trk_deriv2d_create")
+        super().__init__(h, engine)
+        self.streaming = True
+
+
+class SpaceTimeDerivative(_FusedTV, _HandleOperator):
     """Space-time first differences over this rank's `nt_local` frames.  With a sharded time axis the engine's
     communicator moves one frame to the neighbour before each apply (forward: first frame of the next rank;
     transpose: last temporal block of the previous rank)."""
@@ -304,6 +309,7 @@ class SpaceTimeDerivative(_HandleOperator):
         self._halo_prev = engine.empty(npix) if self.has_prev else None
         self._ps = 2 * self.N * (self.N - 1)
         self.streaming = w == 1                        # sharded: every apply also pays a halo exchange
+        self.fused_tv = w == 1                         # ... and the fused forms have no halo rows
 
     def _apply(self, x2, y2, transpose, sumsq):
         eng = self.engine

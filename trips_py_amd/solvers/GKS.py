@@ -53,7 +53,7 @@ class _ProjectedBases:
             A.apply(bv, out=self.atb, transpose=True)
         if self.from_v_L:
             self.zL = eng.empty(n)
-            self.tL = None if hasattr(L, "tv_grad") else eng.empty(p)
+            self.tL = None if getattr(L, "fused_tv", False) else eng.empty(p)
         self.GA = np.zeros((kmax, kmax))
         self.GL = np.zeros((kmax, kmax))
         self.c = np.zeros(kmax)
@@ -203,7 +203,7 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     eng.allreduce(E, 0, 2)
     b2 = float(E.host(1, 2)[0])
 
-    fusedL = dL and hasattr(L, "tv_grad") and kwargs.get("fused_tv", True)
+    fusedL = dL and getattr(L, "fused_tv", False) and kwargs.get("fused_tv", True)
     gs_gram = GramSchmidtByGram(eng, pb.V, kmax) if (hasattr(eng, "cgs_coeffs") and kwargs.get("gram_sweeps", True)) else None
     lams, lam, x_dev = [], None, None
     Minv, k_inv = (eng.scalars(kmax * kmax) if (on_dev and kwargs.get("border_inverse", True)) else None), 0

@@ -138,7 +138,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     # (AV) y and (LV) y, :114-116) and in the weights of the next (A @ x, L @ x, :56,:60).  A stencil operator forms them
     # once, directly — 8n-12n bytes instead of reading k basis vectors; others keep the basis products.
     # the 2-D first-difference L has fused forms (trk_tv_weights / trk_tv_grad): L x is never written out
-    fusedL = dL and hasattr(L, "tv_grad") and not iso and not gs and kwargs.get("fused_tv", True)
+    fusedL = dL and getattr(L, "fused_tv", False) and not iso and not gs and kwargs.get("fused_tv", True)
     A.apply(x_cur, out=ax)
     if not fusedL:
         L.apply(x_cur, out=lx)
