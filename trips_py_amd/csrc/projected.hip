@@ -296,6 +296,31 @@ struct GcvBidiag {
 
 }  // namespace
 
+// (M v)_i, i < k, for a SYMMETRIC k x k matrix in global memory (row stride ld) and v in LDS, by one workgroup: four lanes per
+// row, each walking a quarter of COLUMN i (consecutive rows -> consecutive addresses), the four partial sums met by two lane
+// exchanges.  These k x k kernels are latency-bound — one thread per row meant k dependent-in-order loads per thread (k = 53:
+// 20-30 us per product); a quarter of them per lane, four times the lanes busy.  sink(i, value) is called once per row.
+template <class F>
+__device__ __forceinline__ void symv4(const double* M, int ld, int k, const double* v, F&& sink) {
+  const int part = threadIdx.x & 3;
+  for (int base = 0; base < k; base += (int)blockDim.x / 4) {
+    const int i = base + ((int)threadIdx.x >> 2);
+    double a0 = 0.0, a1 = 0.0;
+    if (i < k) {
+      int j = part;
+      for (; j + 4 < k; j += 8) {
+        a0 += M[(size_t)j * ld + i] * v[j];
+        a1 += M[(size_t)(j + 4) * ld + i] * v[j + 4];
+      }
+      if (j < k) a0 += M[(size_t)j * ld + i] * v[j];
+    }
+    double a = a0 + a1;
+    a += __shfl_xor(a, 1, 64);
+    a += __shfl_xor(a, 2, 64);
+    if (i < k && part == 0) sink(i, a);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ repeated Gram-Schmidt by Gram matrix
 // `passes` sweeps of block classical Gram-Schmidt, r <- r - V (V^T r), amount to r - V c with
 //     c_0 = 0,   c_{p+1} = c_p + (h - G c_p),   h = V^T r,  G = V^T V
@@ -316,12 +341,12 @@ __global__ __launch_bounds__(256) void k_cgs_coeffs(double* __restrict__ G, int 
   }
   for (int j = threadIdx.x; j < k; j += blockDim.x) cs[j] = 0.0;
   __syncthreads();
+  __syncthreads();                         // (the installed row is read below by other threads)
   for (int p = 0; p < passes; ++p) {
-    for (int j = threadIdx.x; j < k; j += blockDim.x) {
-      double t = h[j];
-      const double* row = G + (size_t)j * ldg;
-      for (int i = 0; i < k; ++i) t -= row[i] * cs[i];
-      ts[j] = t;
+    if (p == 0) {                          // c_0 = 0: the first sweep's coefficients are h itself
+      for (int j = threadIdx.x; j < k; j += blockDim.x) ts[j] = h[j];
+    } else {
+      symv4(G, ldg, k, cs, [&](int i, double a) { ts[i] = h[i] - a; });
     }
     __syncthreads();
     for (int j = threadIdx.x; j < k; j += blockDim.x) cs[j] += ts[j];
@@ -405,20 +430,20 @@ __global__ __launch_bounds__(256) void k_gram_tikhonov(const double* __restrict_
 __global__ __launch_bounds__(256) void k_gram_tikhonov_border(const double* __restrict__ GA, int lda, const double* __restrict__ GL,
                                                               int ldl, const double* __restrict__ c, int k, int k_from, double lam,
                                                               double* Minv, int ldm, double* __restrict__ y) {
-  extern __shared__ double sm[];              // g (k) | u (k)
+  extern __shared__ double sm[];              // g (k) | u (k) | c (k)
   double* g = sm;
   double* u = sm + k;
+  double* cl = sm + 2 * k;
   __shared__ double red[4];
+  for (int i = threadIdx.x; i < k; i += blockDim.x) cl[i] = c[i];
   for (int j = k_from; j < k; ++j) {
     for (int i = threadIdx.x; i <= j; i += blockDim.x) g[i] = GA[(size_t)j * lda + i] + lam * GL[(size_t)j * ldl + i];
     __syncthreads();
     double part = 0.0;
-    for (int i = threadIdx.x; i < j; i += blockDim.x) {       // u = Minv g (Minv symmetric: thread i walks column i)
-      double a = 0.0;
-      for (int q = 0; q < j; ++q) a += Minv[(size_t)q * ldm + i] * g[q];
+    symv4(Minv, ldm, j, g, [&](int i, double a) {             // u = Minv g
       u[i] = a;
       part += a * g[i];
-    }
+    });
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
@@ -434,11 +459,8 @@ __global__ __launch_bounds__(256) void k_gram_tikhonov_border(const double* __re
     if (threadIdx.x == 0) Minv[(size_t)j * ldm + j] = sinv;
     __syncthreads();                            // (one workgroup: its global writes are visible to it after the barrier)
   }
-  for (int i = threadIdx.x; i < k; i += blockDim.x) {
-    double a = 0.0;
-    for (int q = 0; q < k; ++q) a += Minv[(size_t)q * ldm + i] * c[q];
-    y[i] = a;
-  }
+  __syncthreads();
+  symv4(Minv, ldm, k, cl, [&](int i, double a) { y[i] = a; });
 }
 
 // GKS: row / column k of a Gram matrix G = V^T M V (M = A^T A or L^T L) for the basis vector v_k = (r - V c) / rho that the sweep
@@ -450,19 +472,20 @@ __global__ __launch_bounds__(256) void k_gram_tikhonov_border(const double* __re
 __global__ __launch_bounds__(256) void k_gram_row_from_sweep(double* G, int ldg, int k, const double* __restrict__ a,
                                                              const double* __restrict__ c, const double* __restrict__ s_rr,
                                                              const double* __restrict__ rho2, double* rhs, const double* tb) {
+  extern __shared__ double cl[];              // c (k)
   __shared__ double red[3][4];
   const double rho = sqrt(*rho2);
+  for (int i = threadIdx.x; i < k; i += blockDim.x) cl[i] = c[i];
+  __syncthreads();
   double p_ca = 0.0, p_cgc = 0.0, p_cr = 0.0;
-  for (int i = threadIdx.x; i < k; i += blockDim.x) {
-    double gc = 0.0;
-    for (int j = 0; j < k; ++j) gc += G[(size_t)j * ldg + i] * c[j];        // (G symmetric: column i read along rows)
+  symv4(G, ldg, k, cl, [&](int i, double gc) {
     const double v = (a[i] - gc) / rho;
-    G[(size_t)i * ldg + k] = v;
+    G[(size_t)i * ldg + k] = v;              // (row / column k: outside what symv4 reads)
     G[(size_t)k * ldg + i] = v;
-    p_ca += c[i] * a[i];
-    p_cgc += c[i] * gc;
-    if (rhs) p_cr += c[i] * rhs[i];
-  }
+    p_ca += cl[i] * a[i];
+    p_cgc += cl[i] * gc;
+    if (rhs) p_cr += cl[i] * rhs[i];
+  });
   p_ca = wave_sum(p_ca);
   p_cgc = wave_sum(p_cgc);
   p_cr = wave_sum(p_cr);
@@ -484,7 +507,7 @@ extern "C" int trk_gram_row_from_sweep(double* G, int ldg, int k, const double* 
                                        const double* rho2, double* rhs, const double* tb, trk_stream st) {
   TRK_REQUIRE(G && a && c && s_rr && rho2 && k >= 1 && ldg >= k + 1, "trk_gram_row_from_sweep: bad argument");
   TRK_REQUIRE(!rhs || tb, "trk_gram_row_from_sweep: rhs given without t = r . (A^T b)");
-  hipLaunchKernelGGL(k_gram_row_from_sweep, dim3(1), dim3(256), 0, (hipStream_t)st, G, ldg, k, a, c, s_rr, rho2, rhs, tb);
+  hipLaunchKernelGGL(k_gram_row_from_sweep, dim3(1), dim3(256), (size_t)k * sizeof(double), (hipStream_t)st, G, ldg, k, a, c, s_rr, rho2, rhs, tb);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }
@@ -562,12 +585,10 @@ __global__ __launch_bounds__(256) void k_hess_tikhonov(double* __restrict__ H, i
     const int m = k - 1;
     // u = Minv g (Minv symmetric: thread i walks column i, consecutive threads read consecutive addresses)
     double part = 0.0;
-    for (int i = threadIdx.x; i < m; i += blockDim.x) {
-      double a = 0.0;
-      for (int j = 0; j < m; ++j) a += Minv[(size_t)j * ldg + i] * g[j];
+    symv4(Minv, ldg, m, g, [&](int i, double a) {
       u[i] = a;
       part += a * g[i];
-    }
+    });
     part = wave_sum(part);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
     __syncthreads();
@@ -583,11 +604,7 @@ __global__ __launch_bounds__(256) void k_hess_tikhonov(double* __restrict__ H, i
     if (threadIdx.x == 0) Minv[(size_t)m * ldg + m] = sinv;
     __syncthreads();
   }
-  for (int i = threadIdx.x; i < k; i += blockDim.x) {                              // y = Minv c
-    double a = 0.0;
-    for (int j = 0; j < k; ++j) a += Minv[(size_t)j * ldg + i] * cv[j];
-    y[i] = a;
-  }
+  symv4(Minv, ldg, k, cv, [&](int i, double a) { y[i] = a; });                    // y = Minv c
 }
 
 // both kernels keep the k x (k+1) factor in LDS: up to 160 KB per workgroup on gfx950 (opt-in above 64 KB)
@@ -612,7 +629,7 @@ extern "C" int trk_gram_tikhonov(const double* GA, int lda, const double* GL, in
   TRK_REQUIRE(GA && GL && c && y && k >= 1 && lda >= k && ldl >= k, "trk_gram_tikhonov: bad argument");
   if (Minv) {
     TRK_REQUIRE(ldm >= k && k_from >= 0 && k_from <= k, "trk_gram_tikhonov: bordering form needs ldm >= k and 0 <= k_from <= k");
-    hipLaunchKernelGGL(k_gram_tikhonov_border, dim3(1), dim3(256), 2 * (size_t)k * sizeof(double), (hipStream_t)st, GA, lda, GL, ldl,
+    hipLaunchKernelGGL(k_gram_tikhonov_border, dim3(1), dim3(256), 3 * (size_t)k * sizeof(double), (hipStream_t)st, GA, lda, GL, ldl,
                        c, k, k_from, lam, Minv, ldm, y);
     TRK_LAUNCH_CHECK();
     return TRK_OK;
