@@ -58,8 +58,14 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             gk.absorb(pend)                  # alpha_k, beta_{k+1}; step k+1 runs while the host chooses lambda_k
             pend = gk.step_prefetch(project=ub_vec) if k < n_iter else None
         else:
-            # nobody reads B_k before the end (fixed lambda, no history, no x_true): the step's last norm may stay inside the operator
-            gk.step(sync=False, defer=(not keep and xt is None and ii < n_iter - 1))
+            # fixed lambda: nothing on the host needs B_k.  Iterates that nobody looks at are not formed and the step's last norm
+            # stays inside the operator (defer); when every iterate IS formed, step k+1 is enqueued BEFORE x_k — its adjoint kernel
+            # finishes beta_{k+1}^2 on the way (GKState.step(defer=True)), which the projected solve of x_k reads — so that no
+            # reduction launch is spent on it
+            if gk.V.k < k:
+                gk.step(sync=False, defer=True)
+            if k < n_iter and (keep or xt is not None):
+                gk.step(sync=False, defer=True)                      # step k+1 ahead of x_k
         if ii == 0:
             lam = 0
             continue
