@@ -936,36 +936,53 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
     const int a0 = b * AB;
     const int nm0 = (n0 - a0 < 0) ? 0 : (n0 - a0 < nal ? n0 - a0 : nal);
     const unsigned rbase0 = __builtin_amdgcn_readfirstlane(lds_offset(&ring[buf][0][0]));
-#pragma unroll 2
-    for (int al = 0; al < nm0; ++al) {
-      const AdjAngle p = ang[a0 + al];               // wave-uniform: scalar loads
-      f2v c2;                                        // the packed clamp-FMA takes its addend from a VGPR pair (low half read)
-      c2[0] = p.c1;
-      asm("" : "+v"(c2));
-      const uint2 cb = cbs[buf][al][r0];
-      const float C = __builtin_bit_cast(float, cb.x);
+    // One pixel per thread (16 x 16 tiles): FOUR angles per trip, written so that their four {C, B32} reads and then their four
+    // record reads are in flight together.  Angle by angle the compiler waited for each LDS read before the next (the requested
+    // unrolling was not done): two exposed LDS round trips per angle and wave, which four waves per SIMD cannot cover — at
+    // 512^2 x 180 the kernel was latency-bound at 36 us with 12 vector instructions per angle, 16 M in all (PMC).
+    auto angles = [&](int al_lo, int al_hi, const float* fcol, const unsigned* ncol, int cbrow, f2v* an, float* ac) {
+      int al = al_lo;
+      if (PX == 1) {
+        for (; al + 4 <= al_hi; al += 4) {
+          AdjAngle p[4];
+          uint2 cb[4];
+          u4r rr[4];
 #pragma unroll
-      for (int k = 0; k < PX; ++k) {
-        const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcolA[k], p.rinv, C) + RND_MAGIC);
-        const u4r r = ring_read(rbase0 + al * 1024, bits);
-        adj_gather(r, cb.y, colA[k], sc2, nsc, c2, anA[k], accA[k]);
-      }
-    }
-#pragma unroll 2
-    for (int al = nm0; al < nal; ++al) {
-      const AdjAngle p = ang[a0 + al];
-      f2v c2;
-      c2[0] = p.c1;
-      asm("" : "+v"(c2));
-      const uint2 cb = cbs[buf][al][c1];
-      const float C = __builtin_bit_cast(float, cb.x);
+          for (int u = 0; u < 4; ++u) p[u] = ang[a0 + al + u];
 #pragma unroll
-      for (int k = 0; k < PX; ++k) {
-        const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcolB[k], p.rinv, C) + RND_MAGIC);
-        const u4r r = ring_read(rbase0 + al * 1024, bits);
-        adj_gather(r, cb.y, colB[k], sc2, nsc, c2, anB[k], accB[k]);
+          for (int u = 0; u < 4; ++u) cb[u] = cbs[buf][al + u][cbrow];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[0], p[u].rinv, __builtin_bit_cast(float, cb[u].x)) + RND_MAGIC);
+            rr[u] = ring_read(rbase0 + (al + u) * 1024, bits);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            f2v c2;                                  // the packed clamp-FMA takes its addend from a VGPR pair (low half read)
+            c2[0] = p[u].c1;
+            asm("" : "+v"(c2));
+            adj_gather(rr[u], cb[u].y, ncol[0], sc2, nsc, c2, an[0], ac[0]);
+          }
+        }
       }
-    }
+#pragma unroll 2
+      for (; al < al_hi; ++al) {
+        const AdjAngle p = ang[a0 + al];             // wave-uniform: scalar loads
+        f2v c2;
+        c2[0] = p.c1;
+        asm("" : "+v"(c2));
+        const uint2 cb = cbs[buf][al][cbrow];
+        const float C = __builtin_bit_cast(float, cb.x);
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+          const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[k], p.rinv, C) + RND_MAGIC);
+          const u4r r = ring_read(rbase0 + al * 1024, bits);
+          adj_gather(r, cb.y, ncol[k], sc2, nsc, c2, an[k], ac[k]);
+        }
+      }
+    };
+    angles(0, nm0, fcolA, colA, r0, anA, accA);
+    angles(nm0, nal, fcolB, colB, c1, anB, accB);
     if (b + 1 < nbatch) stage_store(b + 1);          // the other buffer: nobody reads it before the next barrier
   }
   // the two partial images meet: mode-0 sums go through LDS to the thread that holds the pixel in the mode-1 layout
