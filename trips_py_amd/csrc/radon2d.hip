@@ -54,7 +54,8 @@ struct AngleParam {
 };
 
 struct AdjAngle {           // the adjoint's per-angle constants, sorted by marching mode per frame
-  float rinv, c1, dq, k0;   // c1 = 1 - |inv| (<= 0): a neighbouring ray at distance |inv| weighs clamp(c1 -+ t0)
+  float c1, rinv, dq, k0;   // c1 = 1 - |inv| (<= 0): a neighbouring ray at distance |inv| weighs clamp(c1 -+ t0).  {c1, rinv} is
+                            // read as ONE scalar pair whose low half is the packed FMA's addend (adj_gather)
   int orig;                 // index of the angle within its frame
   int flip;                 // inv < 0: the ray on the larger-q side is d0 - 1 (the records store neighbours by side)
 };
@@ -772,17 +773,24 @@ __device__ __forceinline__ unsigned lds_offset(const void* p) {
   return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
 }
 typedef unsigned u4r __attribute__((ext_vector_type(4)));     // a record {w S[d0 -], w S[d0 +], w S[d0], A32[d0]}
+// The read is issued as inline assembly: written as a C++ load, the compiler orders it after EVERY outstanding direct-to-LDS
+// load (it cannot see that the prefetch of batch b + 1 lands in the other ring buffer) and put s_waitcnt vmcnt(0) in front of each
+// record read — the prefetch issued a few instructions earlier was waited for before the gather of batch b began, twelve exposed
+// L2 round trips per tile at 512^2 x 180.  The counterpart of hiding the read: the CALLER waits (ring_wait) before using r.
 __device__ __forceinline__ u4r ring_read(unsigned ring_base, unsigned bits) {
   unsigned addr;
   const unsigned slot = bits & 63u;
   asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(slot), "s"(ring_base));
-  auto* p = reinterpret_cast<__attribute__((address_space(3))) const u4r*>((size_t)addr);
-  p = (decltype(p))__builtin_assume_aligned(p, 16);              // one ds_read_b128 (otherwise split into two 8-byte reads)
-  return *p;
+  u4r r;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
+  return r;
 }
+// all of this wave's LDS reads have returned; ring_tie makes a record's uses depend on the wait (volatile asm keeps its order)
+__device__ __forceinline__ void ring_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void ring_tie(u4r& r) { asm volatile("" : "+v"(r)); }
 
 // one pixel, one angle: the record, t0 from the tables, three hat weights.  accn: the two neighbour terms (packed), acc0: the centre
-__device__ __forceinline__ void adj_gather(const u4r r, unsigned B, unsigned negcol24, f2v sc2, float nsc, f2v c2, f2v& accn,
+__device__ __forceinline__ void adj_gather(const u4r r, unsigned B, unsigned negcol24, f2v sc2, float nsc, f2v cr, f2v& accn,
                                            float& acc0) {
   // NOTE the elements are copied to scalars first: __builtin_bit_cast(float, r[k]) on an ext-vector ELEMENT reads element 0
   // whatever k is (hipcc / ROCm 7.2; found the hard way — the adjoint summed (w0 + wp + wm) S[d0-1])
@@ -792,11 +800,13 @@ __device__ __forceinline__ void adj_gather(const u4r r, unsigned B, unsigned neg
   const float tf = (float)(int)ti;                               // t0 in units of 2^-24, exact
   // {clamp(c1 + t0), clamp(c1 - t0)} in one packed FMA: both lanes read the LOW half of every source (op_sel_hi 0), the high
   // lane negates the scale 2^-24.  64-bit operands must sit in even-aligned register pairs, hence the two-element carriers
-  // whose high halves are never read.
+  // whose high halves are never read.  The one scalar operand an instruction may have is the angle's {c1, rinv} pair as it came
+  // from the scalar load (the scale, loop-invariant, lives in a vector pair): with c1 as the vector operand every angle paid a
+  // v_mov to get it there, one of its eleven vector instructions.
   f2v t2;
   t2[0] = tf;
   f2v wn;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,0] neg_hi:[0,1,0] clamp" : "=v"(wn) : "v"(t2), "s"(sc2), "v"(c2));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,0] neg_hi:[0,1,0] clamp" : "=v"(wn) : "v"(t2), "v"(sc2), "s"(cr));
   float w0;                                                      // 1 - |t0|: exact (t0 is a multiple of 2^-24)
   asm("v_fma_f32 %0, |%1|, %2, 1.0" : "=v"(w0) : "v"(tf), "s"(nsc));
   const f2v sn = {__builtin_bit_cast(float, slo), __builtin_bit_cast(float, shi)};
@@ -857,9 +867,9 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
     accA[k] = accB[k] = 0.f;
     anA[k] = anB[k] = (f2v){0.f, 0.f};
   }
-  f2v sc2 = {5.9604644775390625e-8f, 5.9604644775390625e-8f};          // 2^-24, kept in an (aligned) SGPR pair
+  f2v sc2 = {5.9604644775390625e-8f, 5.9604644775390625e-8f};          // 2^-24, kept in an (aligned) VGPR pair
   float nsc = -5.9604644775390625e-8f;
-  asm("" : "+s"(sc2));
+  asm("" : "+v"(sc2));
   asm("" : "+s"(nsc));
 
   const int nbatch = (na + AB - 1) / AB;
@@ -871,6 +881,11 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
   // 8.4 us) but costs more instructions per record (180 angles: 512^2 46 -> 57 us, 4096^2 1.04 -> 1.32 ms).
   // The {C, B32} pairs of the tile's marching indices always go straight to LDS (16 bytes = two indices per thread).
   uint4 sreg[AB / 4];
+  int cb_orig = 0;
+  if (tid < AB * T / 2) {
+    const int a = tid / (T / 2);
+    cb_orig = ang[a < na ? a : na - 1].orig;
+  }
   auto stage_load = [&](int b) {
 #pragma unroll
     for (int h = 0; h < AB / 4; ++h) {
@@ -879,14 +894,14 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
       a = a < na ? a : na - 1;
       const AdjAngle p = ang[a];
       const bool m1 = a >= n0;
-      // inverse image of the tile: d* = col rinv + (sdh - (k0 + tt dq) rinv), extremes at the corners
-      const float tt_lo = (float)(m1 ? j0 : i0), co_lo = (float)(m1 ? i0 : j0);
-      const float dA = fmaf(co_lo - fmaf(tt_lo, p.dq, p.k0), p.rinv, sdh);
-      const float dB = fmaf(co_lo + (float)(T - 1) - fmaf(tt_lo, p.dq, p.k0), p.rinv, sdh);
-      const float dC = fmaf(co_lo - fmaf(tt_lo + (float)(T - 1), p.dq, p.k0), p.rinv, sdh);
-      const float dD = fmaf(co_lo + (float)(T - 1) - fmaf(tt_lo + (float)(T - 1), p.dq, p.k0), p.rinv, sdh);
-      const float dmin = fminf(fminf(dA, dB), fminf(dC, dD)), dmax = fmaxf(fmaxf(dA, dB), fmaxf(dC, dD));
-      const int dbase = __builtin_amdgcn_readfirstlane((int)floorf(0.5f * (dmin + dmax))) - 32;   // ring covers dbase .. dbase + 63
+      // inverse image of the tile: d* = col rinv + (sdh - (k0 + tt dq) rinv) is linear, so the tile's d* are centred on the
+      // image of its centre and span at most (T - 1) sqrt(2) detectors (22 / 44 for T = 16 / 32): a 64-slot ring around the centre
+      // holds them and their +-1 neighbours.  (The four corners and their min / max gave the same centre for 4x the instructions —
+      // all of them wave-uniform but vector work, gfx950 has no scalar float unit: staging was 35 vector instructions per ring,
+      // 43 % of the 16 x 16 kernel's VALU count at 512^2 x 180, PMC.)
+      const float tt_c = (float)(m1 ? j0 : i0) + 0.5f * (float)(T - 1), co_c = (float)(m1 ? i0 : j0) + 0.5f * (float)(T - 1);
+      const float dcen = fmaf(co_c - fmaf(tt_c, p.dq, p.k0), p.rinv, sdh);
+      const int dbase = __builtin_amdgcn_readfirstlane((int)floorf(dcen)) - 32;   // ring covers dbase .. dbase + 63
       const int d = dbase + ((lane - dbase) & 63);                   // the detector whose ring slot is this lane
       int e = d + A32_PAD;
       e = e < 0 ? 0 : (e > ndp - 1 ? ndp - 1 : e);                   // beyond the detector: weightless (S = 0) anyway
@@ -914,7 +929,12 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
       const int tt0 = (a >= n0 ? j0 : i0) + 2 * pr;                  // even: 16-byte aligned pairs (npad is even)
       // (the LDS address of a direct-to-LDS load is wave-uniform base + 16 * lane: wave 1 lands 1 KB behind wave 0)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rcb, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(&cbs[buf][0][0]) + wv * 1024),
-                                               16, (ang[a].orig * npad + tt0) * 8, 0, 0, 0);
+                                               16, (cb_orig * npad + tt0) * 8, 0, 0, 0);
+      // the table row of this thread's pair in the batch after: fetched a batch ahead — read here, the load and the vmcnt(0) its
+      // use needs sat between the ring loads and the gather, one exposed L2 round trip per batch for waves 0 and 1
+      int an = (b + 1) * AB + al;
+      an = an < na ? an : na - 1;
+      cb_orig = ang[an].orig;
     }
   };
   auto stage_store = [&](int b) {
@@ -956,28 +976,35 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
             const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[0], p[u].rinv, __builtin_bit_cast(float, cb[u].x)) + RND_MAGIC);
             rr[u] = ring_read(rbase0 + (al + u) * 1024, bits);
           }
+          ring_wait();
+#pragma unroll
+          for (int u = 0; u < 4; ++u) ring_tie(rr[u]);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            f2v c2;                                  // the packed clamp-FMA takes its addend from a VGPR pair (low half read)
-            c2[0] = p[u].c1;
-            asm("" : "+v"(c2));
-            adj_gather(rr[u], cb[u].y, ncol[0], sc2, nsc, c2, an[0], ac[0]);
+            f2v cr = {p[u].c1, p[u].rinv};           // the packed clamp-FMA takes its addend from this scalar pair (low half read)
+            asm("" : "+s"(cr));
+            adj_gather(rr[u], cb[u].y, ncol[0], sc2, nsc, cr, an[0], ac[0]);
           }
         }
       }
 #pragma unroll 2
       for (; al < al_hi; ++al) {
         const AdjAngle p = ang[a0 + al];             // wave-uniform: scalar loads
-        f2v c2;
-        c2[0] = p.c1;
-        asm("" : "+v"(c2));
+        f2v cr = {p.c1, p.rinv};
+        asm("" : "+s"(cr));
         const uint2 cb = cbs[buf][al][cbrow];
         const float C = __builtin_bit_cast(float, cb.x);
+        u4r rr[PX];
 #pragma unroll
         for (int k = 0; k < PX; ++k) {
           const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[k], p.rinv, C) + RND_MAGIC);
-          const u4r r = ring_read(rbase0 + al * 1024, bits);
-          adj_gather(r, cb.y, ncol[k], sc2, nsc, c2, an[k], ac[k]);
+          rr[k] = ring_read(rbase0 + al * 1024, bits);
+        }
+        ring_wait();
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+          ring_tie(rr[k]);
+          adj_gather(rr[k], cb.y, ncol[k], sc2, nsc, cr, an[k], ac[k]);
         }
       }
     };
@@ -1041,7 +1068,7 @@ __global__ __launch_bounds__(256) void k_radon_adj_simple(const uint4* __restric
   f2v accn = {0.f, 0.f};
   f2v sc2 = {5.9604644775390625e-8f, 5.9604644775390625e-8f};
   float nsc = -5.9604644775390625e-8f;
-  asm("" : "+s"(sc2));
+  asm("" : "+v"(sc2));
   asm("" : "+s"(nsc));
   for (int a = 0; a < na; ++a) {
     const AdjAngle p = ang[a];
@@ -1051,9 +1078,9 @@ __global__ __launch_bounds__(256) void k_radon_adj_simple(const uint4* __restric
     int e = d0 + A32_PAD;
     e = e < 0 ? 0 : (e > ndp - 1 ? ndp - 1 : e);
     const uint4 rr = rec[(int64_t)a * ndp + e];
-    f2v c2;
-    c2[0] = p.c1;
-    adj_gather((u4r){rr.x, rr.y, rr.z, rr.w}, cb.y, 0u - ((unsigned)col << QF), sc2, nsc, c2, accn, acc0);
+    f2v cr = {p.c1, p.rinv};
+    asm("" : "+s"(cr));
+    adj_gather((u4r){rr.x, rr.y, rr.z, rr.w}, cb.y, 0u - ((unsigned)col << QF), sc2, nsc, cr, accn, acc0);
   }
   const float acc = acc0 + (accn[0] + accn[1]);
   if (inside) img[(int64_t)frame * N * N + idx] = acc;
@@ -1385,7 +1412,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
         for (int a = 0; a < na; ++a) {
           const AngleParam& q = h[(size_t)f * na + a];
           if (q.mode != pass) continue;
-          aa[(size_t)f * na + pos] = AdjAngle{q.rinv, 1.0f - fabsf(q.inv), q.dq, q.k0, a, q.inv < 0.f ? 1 : 0};
+          aa[(size_t)f * na + pos] = AdjAngle{1.0f - fabsf(q.inv), q.rinv, q.dq, q.k0, a, q.inv < 0.f ? 1 : 0};
           wg[(size_t)f * na + pos] = wadj[(size_t)f * na + a];
           pos_of[(size_t)f * na + a] = f * na + pos;
           ++pos;
