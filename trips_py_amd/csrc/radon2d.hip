@@ -886,30 +886,50 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
     const int a = tid / (T / 2);
     cb_orig = ang[a < na ? a : na - 1].orig;
   }
+  // lane l holds {rinv, dq, k0} of angle l (mod AB) of the batch stage_load is called for next, fetched a batch ahead
+  float nx_rinv, nx_dq, nx_k0;
+  auto fetch_angles = [&](int b) {
+    int a = b * AB + (lane & (AB - 1));
+    a = a < na ? a : na - 1;
+    nx_rinv = ang[a].rinv;
+    nx_dq = ang[a].dq;
+    nx_k0 = ang[a].k0;
+  };
+  fetch_angles(0);
+  int nam1;                                          // na - 1 as a value the vector unit has no copy of, so that the row
+  asm("s_add_i32 %0, %1, -1" : "=s"(nam1) : "s"(na) : "scc");   // offsets below stay scalar arithmetic
   auto stage_load = [&](int b) {
+    // inverse image of the tile: d* = col rinv + (sdh - (k0 + tt dq) rinv) is linear, so the tile's d* are centred on the
+    // image of its centre and span at most (T - 1) sqrt(2) detectors (22 / 44 for T = 16 / 32): a 64-slot ring around the centre
+    // holds them and their +-1 neighbours.  The ring bases of the batch's AB angles are computed by AB LANES, one angle each, and
+    // handed out by v_readlane: the arithmetic is wave-uniform per angle but gfx950 has no scalar float unit — done per ring
+    // (first from the four corners, 35 vector instructions per ring, then from the centre, 20) staging was 43 % / 30 % of the
+    // 16 x 16 kernel's vector instructions at 512^2 x 180 (PMC).
+    int dbase_l;
+    {
+      int a = b * AB + (lane & (AB - 1));
+      a = a < na ? a : na - 1;
+      const bool m1 = a >= n0;
+      const float tt_c = (float)(m1 ? j0 : i0) + 0.5f * (float)(T - 1), co_c = (float)(m1 ? i0 : j0) + 0.5f * (float)(T - 1);
+      dbase_l = (int)floorf(fmaf(co_c - fmaf(tt_c, nx_dq, nx_k0), nx_rinv, sdh)) - 32;
+    }
+    if (b + 1 < nbatch) fetch_angles(b + 1);
 #pragma unroll
     for (int h = 0; h < AB / 4; ++h) {
       const int al = wv + 4 * h;
-      int a = b * AB + al;
-      a = a < na ? a : na - 1;
-      const AdjAngle p = ang[a];
-      const bool m1 = a >= n0;
-      // inverse image of the tile: d* = col rinv + (sdh - (k0 + tt dq) rinv) is linear, so the tile's d* are centred on the
-      // image of its centre and span at most (T - 1) sqrt(2) detectors (22 / 44 for T = 16 / 32): a 64-slot ring around the centre
-      // holds them and their +-1 neighbours.  (The four corners and their min / max gave the same centre for 4x the instructions —
-      // all of them wave-uniform but vector work, gfx950 has no scalar float unit: staging was 35 vector instructions per ring,
-      // 43 % of the 16 x 16 kernel's VALU count at 512^2 x 180, PMC.)
-      const float tt_c = (float)(m1 ? j0 : i0) + 0.5f * (float)(T - 1), co_c = (float)(m1 ? i0 : j0) + 0.5f * (float)(T - 1);
-      const float dcen = fmaf(co_c - fmaf(tt_c, p.dq, p.k0), p.rinv, sdh);
-      const int dbase = __builtin_amdgcn_readfirstlane((int)floorf(dcen)) - 32;   // ring covers dbase .. dbase + 63
+      int a;
+      asm("s_min_i32 %0, %1, %2" : "=s"(a) : "s"(b * AB + al), "s"(nam1) : "scc");
+      const int row = a * ndp;
+      const int dbase = __builtin_amdgcn_readlane(dbase_l, al);      // ring covers dbase .. dbase + 63
       const int d = dbase + ((lane - dbase) & 63);                   // the detector whose ring slot is this lane
-      int e = d + A32_PAD;
-      e = e < 0 ? 0 : (e > ndp - 1 ? ndp - 1 : e);                   // beyond the detector: weightless (S = 0) anyway
+      int e;                                                         // beyond the detector: weightless (S = 0) anyway
+      asm("v_med3_i32 %0, %1, 0, %2" : "=v"(e) : "v"(d + A32_PAD), "s"(ndp - 1));
       if (PREP) {
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rrec, (__attribute__((address_space(3))) void*)&ring[b & 1][al][0], 16,
-                                                 (a * ndp + e) * 16, 0, 0, 0);
+                                                 (row + e) * 16, 0, 0, 0);
         continue;
       }
+      const AdjAngle p = ang[a];
       const float* __restrict__ S = sino + (int64_t)p.orig * nd;
       const float w = wgt[a];
       const int dm = d - 1, dp = d + 1;
