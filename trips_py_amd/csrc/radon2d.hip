@@ -77,7 +77,8 @@ struct RadonImpl {
   float* adj_wgt;
   int* adj_n0;
   uint4* rec;
-  int* adj_pos;      // [nt*na]: angle row (caller's order) -> its sorted row, the inverse of adj_ang[].orig
+  int4* adj_pos;     // [nt*na]: angle row (caller's order) -> {its sorted row (the inverse of adj_ang[].orig), that row's
+                     // adjoint weight (bits), its flip flag, 0}: one load where the record writer chased three
   int n_bands, band;
   // what the side buffers currently hold, when a fused apply left them behind for the next apply of the other direction
   // (trk_op_apply_axpby hints): rec = the records of the sinogram at rec_src, xT = the transpose of the image at xT_src
@@ -108,8 +109,17 @@ struct Epi {
 // the sum of the pending partials — the same bits in every workgroup (one wave, fixed order) — in all threads
 __device__ __forceinline__ double pend_total(const Epi& e, double* lds1) {
   if (threadIdx.x < 64) {
+    // eight loads in flight per trip, added in the order a one-by-one loop would (the convention of trk_internal.h: every
+    // consumer of the same partials gets the same bits); one by one, the 1024 partials of a 512^2 adjoint were 16 dependent
+    // L2 round trips at the head of every workgroup of the kernel that follows
     double v = 0.0;
-    for (int i = threadIdx.x; i < e.pend_n; i += 64) v += e.pend_part[i];
+    for (int i = threadIdx.x; i < e.pend_n; i += 512) {
+      double t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = (i + 64 * u < e.pend_n) ? e.pend_part[i + 64 * u] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
     v = wave_sum_all(v);
     if (threadIdx.x == 0) *lds1 = v;
   }
@@ -653,7 +663,7 @@ template <bool REC>
 __global__ __launch_bounds__(256) void k_radon_bands_post(const float* __restrict__ part, int nb, int64_t band_stride,
                                                           float* __restrict__ sino, int nd, const AngleParam* __restrict__ ang,
                                                           Epi epi, double* __restrict__ ssq_part,
-                                                          uint4* __restrict__ rec, const int* __restrict__ adj_pos,
+                                                          uint4* __restrict__ rec, const int4* __restrict__ adj_pos,
                                                           const AdjAngle* __restrict__ adj_ang, const float* __restrict__ adj_wgt,
                                                           const unsigned* __restrict__ A32) {
   __shared__ double lds[4];
@@ -670,7 +680,13 @@ __global__ __launch_bounds__(256) void k_radon_bands_post(const float* __restric
     if (dd < 0 || dd >= nd) return Raw{0.f, 0.f};
     const int64_t k = r * nd + dd;
     double t = 0.0;
-    for (int b = 0; b < nb; ++b) t += (double)part[(int64_t)b * band_stride + k];
+    for (int b0 = 0; b0 < nb; b0 += 4) {           // four band partials in flight, added in band order
+      float pv[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) pv[u] = (b0 + u < nb) ? part[(int64_t)(b0 + u) * band_stride + k] : 0.f;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) t += (double)pv[u];
+    }
     return Raw{ang[r].wgt * (float)t, (epi.on && epi.z) ? epi.z[k] : 0.f};
   };
   const Raw r0 = valid ? raw(row, d) : Raw{0.f, 0.f};
@@ -684,9 +700,10 @@ __global__ __launch_bounds__(256) void k_radon_bands_post(const float* __restric
   bool flip = false;
   unsigned a32 = 0u;
   if (REC && valid) {
-    rs = adj_pos[row];
-    w = adj_wgt[rs];
-    flip = adj_ang[rs].flip != 0;
+    const int4 rr = adj_pos[row];
+    rs = rr.x;
+    w = __builtin_bit_cast(float, rr.y);
+    flip = rr.z != 0;
     a32 = A32[row * ndp + e];
   }
   float ca, cb;
@@ -1425,7 +1442,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     std::vector<AdjAngle> aa(n_ang);
     std::vector<int> n0(nt);
     std::vector<float> wg(n_ang);
-    std::vector<int> pos_of(n_ang);
+    std::vector<int4> pos_of(n_ang);
     for (int f = 0; f < nt; ++f) {
       int pos = 0;
       for (int pass = 0; pass < 2; ++pass) {
@@ -1434,7 +1451,9 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
           if (q.mode != pass) continue;
           aa[(size_t)f * na + pos] = AdjAngle{1.0f - fabsf(q.inv), q.rinv, q.dq, q.k0, a, q.inv < 0.f ? 1 : 0};
           wg[(size_t)f * na + pos] = wadj[(size_t)f * na + a];
-          pos_of[(size_t)f * na + a] = f * na + pos;
+          const float wa = wadj[(size_t)f * na + a];
+          const int wbits = __builtin_bit_cast(int, wa);
+          pos_of[(size_t)f * na + a] = int4{f * na + pos, wbits, q.inv < 0.f ? 1 : 0, 0};
           ++pos;
         }
         if (pass == 0) n0[f] = pos;
@@ -1444,7 +1463,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     up((void**)&im->adj_wgt, wg.data(), sizeof(float) * n_ang);
     up((void**)&im->adj_n0, n0.data(), sizeof(int) * nt);
     up((void**)&im->rec, nullptr, sizeof(uint4) * (size_t)n_ang * ndp);
-    up((void**)&im->adj_pos, pos_of.data(), sizeof(int) * n_ang);
+    up((void**)&im->adj_pos, pos_of.data(), sizeof(int4) * n_ang);
     const int64_t t16 = (int64_t)ceil_div(N, 16) * ceil_div(N, 16) * nt, pb = ceil_div((int64_t)n_ang * ndp, 256);
     im->pend_cap = t16 > pb ? t16 : pb;
     up((void**)&im->pend_buf[0], nullptr, sizeof(double) * (size_t)im->pend_cap);
