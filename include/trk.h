@@ -349,6 +349,17 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y_dev
  * trk_finalize_batched instead of one reduction-finalize launch per iterate). */
 int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y, float* out, const float* ref,
                    double* err_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
+/* One step of damped LSQR's short recurrence (Paige & Saunders): the iterate x_k = V_k y_k,
+ * y_k = argmin || [B_k; damp I] y - beta_1 e_1 || — what Hybrid_LSQR.py:104-105 computes with lstsq + V @ y when lambda is a
+ * number (damp = sqrt(lambda)) — from the previous one in a single pass:  w <- vk / alpha_k - (theta_k / rho_{k-1}) w  (in
+ * place; first: w <- vk / alpha_1),  x_out = x_in + (phi_k / rho_k) w  (first: x_in may be NULL = 0).  vk = alpha_k v_k,
+ * alpha_sq / beta_next_sq = alpha_k^2 / beta_{k+1}^2 (device doubles), beta0_sq = ||b||^2 (first step only).  state_in /
+ * state_out: 4 device doubles each {cs, sn, rho, phibar}, different slots.  ref != NULL: ||x_out - ref||^2 is left as
+ * *n_blocks raw block partials (trk_finalize_batched sums them), as trk_gemv_n_err does. */
+int trk_lsqr_damped_update(const float* vk, float* w, const float* x_in, float* x_out, int64_t n, const float* ref,
+                           double* err_partials, int capacity_blocks, int* n_blocks, const double* alpha_sq,
+                           const double* beta_next_sq, const double* beta0_sq, double damp, const double* state_in,
+                           double* state_out, int first, trk_stream stream);
 /* G[a][b] = sum_i w[i]^2 * W[a][i] * W[b][i]  (k x k, fp64, full symmetric; w may be NULL), and, if
  * b1 != NULL, c1[a] = sum_i w[i]*W[a][i]*b1[i], c2[a] = sum_i w[i]^2*W[a][i]*b1[i].
  * Replaces the from-scratch economic QR of AV*wf / LV*wr (MMGKS.py:58-59,94-95; GKS.py:54-56): the host

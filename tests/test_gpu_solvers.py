@@ -368,3 +368,32 @@ def test_mmgks_pnorm2_unweighted_fidelity_gram_kept_incrementally():
     for k in (0, 12, 24):
         u, v = ia["xHistory"][k].reshape(-1), ib["xHistory"][k].reshape(-1)
         assert float(torch.linalg.norm(u - v) / torch.linalg.norm(v)) < 1e-5, k
+
+
+@pytest.mark.parametrize("kind,N,its", [("blur", 64, 30), ("radon", 128, 60), ("radon", 96, 100)])
+def test_hybrid_lsqr_recurrence_equals_the_combination(kind, N, its):
+    """Fixed lambda: the damped-LSQR short recurrence (trk_lsqr_damped_update) against x_k = V_k y_k formed from the projected
+    solve (Hybrid_LSQR.py:104-105), every iterate and every relError — the two are the same iterate algebraically."""
+    from trips_py_amd.operators import Blur2D, Radon2DParallel
+    from trips_py_amd.problems import gauss_psf
+    from trips_py_amd.solvers import Hybrid_LSQR
+    rng = np.random.default_rng(N + its)
+    if kind == "blur":
+        A = Blur2D(gauss_psf((9, 9), (2, 2))[0], N, N)
+    else:
+        A = Radon2DParallel(N, np.linspace(0, np.pi, 45, endpoint=False))
+    xt = rng.random(N * N).astype(np.float32)
+    b = A.apply(torch.from_numpy(xt).cuda())
+    b = (b + 0.01 * torch.randn_like(b) * b.norm() / b.numel() ** 0.5).cpu().numpy()
+    for lam in (1e-2, 0.0):
+        x1, i1 = Hybrid_LSQR(A, b, its, lam, xt)
+        x0, i0 = Hybrid_LSQR(A, b, its, lam, xt, x_by_recurrence=False)
+        assert len(i1["xHistory"]) == len(i0["xHistory"]) == its - 1 and i1["regParam_history"] == i0["regParam_history"]
+        assert relerr(x1, x0) < TOL, relerr(x1, x0)
+        for j in (0, 1, its // 2, its - 2):
+            assert relerr(i1["xHistory"][j], i0["xHistory"][j]) < TOL, j
+        assert np.allclose(i1["relError"], i0["relError"], rtol=1e-5)
+    # no x_true, history kept: the same iterates
+    x2, i2 = Hybrid_LSQR(A, b, 12, 1e-2)
+    x3, i3 = Hybrid_LSQR(A, b, 12, 1e-2, x_by_recurrence=False)
+    assert relerr(x2, x3) < TOL and relerr(i2["xHistory"][0], i3["xHistory"][0]) < TOL

@@ -209,6 +209,8 @@ SIGNATURES = {
     "trk_cgs_coeffs": (c_int, [c_f64p, c_int, c_f64p, c_f64p, c_int, c_int, c_f64p, c_stream]),
     "trk_gemv_nt": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_gemv_n_err": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
+    "trk_lsqr_damped_update": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int),
+                                       c_f64p, c_f64p, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_stream]),
     "trk_gemv_n": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_dbl, c_f32p, c_dbl, c_f32p, c_f64p, c_stream]),
     "trk_comm_unique_id": (c_int, [ctypes.c_void_p]),
     "trk_comm_init": (c_int, [ctypes.c_void_p, c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),

@@ -752,6 +752,93 @@ __global__ __launch_bounds__(NT) void k_gemv_n(const float* __restrict__ V, int6
   }
 }
 
+// ------------------------------------------------------------------ damped-LSQR iterate by its short recurrence
+// x_k = V_k y_k with y_k = argmin || [B_k; damp I] y - beta_1 e_1 ||  (Hybrid_LSQR.py:104-105 with a FIXED lambda, damp =
+// sqrt(lambda)) is Paige & Saunders' damped LSQR iterate, which obeys  w_k = v_k - (theta_k / rho_{k-1}) w_{k-1},
+// x_k = x_{k-1} + (phi_k / rho_k) w_k  — an algebraic identity in B_k (no orthogonality of V is used), so the k-term
+// combination per iterate (4 k n bytes) becomes one pass over three vectors.  The plane rotations (two per step: one against
+// the damping, one against beta_{k+1}) are recomputed by thread 0 of every workgroup from alpha_k^2, beta_{k+1}^2 and the
+// four doubles the previous step left in st_in = {cs, sn, rho, phibar}; workgroup 0 leaves this step's in st_out (the caller
+// alternates two slots).  vk is alpha_k v_k as GKState(normalized=False) stores it.
+template <bool VEC>
+__global__ __launch_bounds__(NT) void k_lsqr_damped_update(const float* __restrict__ vk, float* w, const float* x_in, float* x_out,
+                                                           const float* __restrict__ ref, double* __restrict__ err_part, int64_t n,
+                                                           const double* __restrict__ a2, const double* __restrict__ b2,
+                                                           const double* __restrict__ beta0_sq, double damp,
+                                                           const double* __restrict__ st_in, double* __restrict__ st_out, int first) {
+  __shared__ double cf[3];
+  __shared__ double lds[NT / 64];
+  if (threadIdx.x == 0) {
+    const double alpha = sqrt(*a2), beta = sqrt(*b2);
+    double rhobar, phibar, tw = 0.0;
+    if (first) {
+      rhobar = alpha;
+      phibar = sqrt(*beta0_sq);
+    } else {
+      rhobar = -st_in[0] * alpha;
+      tw = st_in[1] * alpha / st_in[2];
+      phibar = st_in[3];
+    }
+    const double rhobar1 = sqrt(rhobar * rhobar + damp * damp);
+    phibar *= rhobar / rhobar1;
+    const double rho = sqrt(rhobar1 * rhobar1 + beta * beta);
+    const double cs = rhobar1 / rho, sn = beta / rho;
+    cf[0] = 1.0 / alpha;
+    cf[1] = tw;
+    cf[2] = cs * phibar / rho;
+    if (blockIdx.x == 0) {
+      st_out[0] = cs;
+      st_out[1] = sn;
+      st_out[2] = rho;
+      st_out[3] = sn * phibar;
+    }
+  }
+  __syncthreads();
+  const double ia = cf[0], tw = cf[1], px = cf[2];
+  double acc = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  auto one = [&](float v, float wo, float xo, float& wn, float& xn) {
+    wn = (float)(ia * (double)v - (first ? 0.0 : tw * (double)wo));
+    xn = (float)((x_in ? (double)xo : 0.0) + px * (double)wn);
+  };
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      const float4 v = ld4(vk, i);
+      const float4 wo = first ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(w, i);
+      const float4 xo = x_in ? ld4(x_in, i) : make_float4(0.f, 0.f, 0.f, 0.f);
+      float4 wn, xn;
+      one(v.x, wo.x, xo.x, wn.x, xn.x);
+      one(v.y, wo.y, xo.y, wn.y, xn.y);
+      one(v.z, wo.z, xo.z, wn.z, xn.z);
+      one(v.w, wo.w, xo.w, wn.w, xn.w);
+      st4(w, i, wn);
+      st4(x_out, i, xn);
+      if (ref) {
+        const float4 t = ld4(ref, i);
+        const double e0 = (double)xn.x - t.x, e1 = (double)xn.y - t.y, e2 = (double)xn.z - t.z, e3 = (double)xn.w - t.w;
+        acc += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+      }
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) {
+    float wn, xn;
+    one(vk[i], first ? 0.f : w[i], x_in ? x_in[i] : 0.f, wn, xn);
+    w[i] = wn;
+    x_out[i] = xn;
+    if (ref) {
+      const double e = (double)xn - ref[i];
+      acc += e * e;
+    }
+  }
+  if (ref) {
+    acc = block_sum<NT>(acc, lds);
+    if (threadIdx.x == 0) err_part[blockIdx.x] = acc;
+  }
+}
+
 // ------------------------------------------------------------------ fused reorthogonalisation step
 // w_out = w_in - sum_j h[j] V[j]   AND   g[j] = sum_i V[j][i] w_out[i]   with ONE pass over the k basis rows:
 // the middle step of repeated classical Gram-Schmidt  r -= V (V^T r)  (GKS.py:86-88 three times, MMGKS.py:119-120 twice,
@@ -1571,6 +1658,32 @@ int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y
     hipLaunchKernelGGL((k_gemv_n<false, true, true, true>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, y, 1.0, nobase, 1.0, out, err_partials, ref);
   else
     hipLaunchKernelGGL((k_gemv_n<false, true, false, true>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, y, 1.0, nobase, 1.0, out, err_partials, ref);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_lsqr_damped_update(const float* vk, float* w, const float* x_in, float* x_out, int64_t n, const float* ref,
+                           double* err_partials, int capacity_blocks, int* n_blocks, const double* alpha_sq,
+                           const double* beta_next_sq, const double* beta0_sq, double damp, const double* state_in,
+                           double* state_out, int first, trk_stream st) {
+  TRK_REQUIRE(vk && w && x_out && alpha_sq && beta_next_sq && state_out, "trk_lsqr_damped_update: NULL argument");
+  TRK_REQUIRE(first ? beta0_sq != nullptr : (state_in != nullptr && x_in != nullptr),
+              "trk_lsqr_damped_update: the first step needs beta0_sq, later ones state_in and x_in");
+  TRK_REQUIRE(!ref || (err_partials && n_blocks), "trk_lsqr_damped_update: ref given but no room for the partials");
+  TRK_REQUIRE(n >= 0 && damp >= 0.0, "trk_lsqr_damped_update: need n >= 0, damp >= 0");
+  const int grid = stream_grid(n);
+  if (ref) {
+    TRK_REQUIRE(grid <= capacity_blocks, "trk_lsqr_damped_update: partial buffer too small (%d blocks needed)", grid);
+    *n_blocks = grid;
+  }
+  hipStream_t s = (hipStream_t)st;
+  const bool vec = aligned16(vk) && aligned16(w) && aligned16(x_out) && (!x_in || aligned16(x_in)) && (!ref || aligned16(ref));
+  if (vec)
+    hipLaunchKernelGGL((k_lsqr_damped_update<true>), dim3(grid), dim3(NT), 0, s, vk, w, x_in, x_out, ref, err_partials, n, alpha_sq,
+                       beta_next_sq, beta0_sq, damp, state_in, state_out, first);
+  else
+    hipLaunchKernelGGL((k_lsqr_damped_update<false>), dim3(grid), dim3(NT), 0, s, vk, w, x_in, x_out, ref, err_partials, n, alpha_sq,
+                       beta_next_sq, beta0_sq, damp, state_in, state_out, first);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }

@@ -431,6 +431,18 @@ class HipEngine:
         _lib.check(rc, "trk_gemv_n_err")
         return n.value
 
+    def lsqr_damped_update(self, vk, w, x_in, x_out, alpha_sq, beta_next_sq, beta0_sq, damp, state_in, state_out, first,
+                           ref=None, partials=None, capacity=0):
+        """One step of damped LSQR's short recurrence (trk_lsqr_damped_update): w and the iterate from the previous ones and
+        vk = alpha_k v_k; with `ref`, raw block partials of ||x_out - ref||^2 go to `partials` and their count is returned."""
+        nb = ctypes.c_int(0)
+        rc = self.lib.trk_lsqr_damped_update(vk.data_ptr(), w.data_ptr(), None if x_in is None else x_in.data_ptr(), x_out.data_ptr(),
+                                             x_out.numel(), None if ref is None else ref.data_ptr(), _ptr(partials), int(capacity),
+                                             ctypes.byref(nb), _ptr(alpha_sq), _ptr(beta_next_sq), _ptr(beta0_sq), float(damp),
+                                             _ptr(state_in), _ptr(state_out), int(bool(first)), self.stream())
+        _lib.check(rc, "trk_lsqr_damped_update")
+        return nb.value
+
     def gemv_nt(self, V, k, h, w_in, w_out, g):
         """w_out = w_in - sum_j h[j] V[j] and g[j] = V[j] . w_out (local sums), one pass over V; k <= GEMV_NT_MAX_K."""
         rc = self.lib.trk_gemv_nt(V.data_ptr(), V.stride(0), int(k), w_in.numel(), _ptr(h), w_in.data_ptr(), w_out.data_ptr(),
