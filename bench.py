@@ -421,13 +421,17 @@ def extra_c3_tomo(world):
     # every iterate is formed and its relError evaluated (x_true given, as the reference's demos do); only the
     # list of host copies of the iterates is skipped (history=False)
     for tag, reg, kw in (("", 1e-2, {}), ("_gcv", "gcv", {}), ("_dp", "dp", {"delta": delta})):
-        Hybrid_LSQR(R, bt, 5, reg, x_true=xt, history=False, **kw)
+        # warm-up: one whole solve of the timed size (as C2 does) — a 100-step solve allocates its two bases (150 MB) the first
+        # time, which a 5-step warm-up left inside the timed region (13.8k against 15.0k it/s from the third solve on)
+        Hybrid_LSQR(R, bt, 100, reg, x_true=xt, history=False, **kw)
         barrier(world)
+        reps = 3
         t0 = time.perf_counter()
-        _, info = Hybrid_LSQR(R, bt, 100, reg, x_true=xt, history=False, **kw)
+        for _ in range(reps):
+            _, info = Hybrid_LSQR(R, bt, 100, reg, x_true=xt, history=False, **kw)
         barrier(world)
         dt = max_over_ranks(time.perf_counter() - t0, world)
-        out[f"hybrid_lsqr{tag}_iters_per_sec_all_ranks"] = round(world * 100 / dt, 1)
+        out[f"hybrid_lsqr{tag}_iters_per_sec_all_ranks"] = round(world * reps * 100 / dt, 1)
         out[f"hybrid_lsqr{tag}_relError_last"] = float(info["relError"][-1])
     return out
 
