@@ -408,9 +408,9 @@ def extra_c3_tomo(world):
         # The projector is bound by vector-instruction issue, not by HBM: a wave64 VALU instruction occupies its
         # SIMD for 4 cycles (MI355X_MICROARCH.md, cycle constants: 'vector-instruction ISSUE cost'), 1024 SIMDs, 2.4 GHz peak
         # clock.  Instructions per unit are read off the ISA of the inner loops: forward 7 per ray and
-        # marching step (N n_det n_ang steps), adjoint 10.5 per pixel and angle (N^2 n_ang).
+        # marching step (N n_det n_ang steps), adjoint 10.25 per pixel and angle (N^2 n_ang: 41 per angle and four pixels).
         steps = float(Nb) * Nb * na
-        for name, ipu in (("fwd", 7.0), ("adj", 10.5)):
+        for name, ipu in (("fwd", 7.0), ("adj", 10.25)):
             floor_ms = steps * ipu / 64.0 * 4.0 / (1024 * 2.4e9) * 1e3
             big[f"{name}_roofline"] = {"bound": "valu_issue", "instr_per_unit": ipu, "units": steps, "floor_ms": round(floor_ms, 4),
                                        "frac": round(floor_ms / big[f"{name}_ms"], 4)}

@@ -1,0 +1,20 @@
+"""Where the host spends an iteration of Hybrid_LSQR with an automatic lambda (cProfile of one 100-step solve, 512^2 x 180)."""
+import sys, os, cProfile, pstats
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from trips_py_amd.operators import Radon2DParallel
+from trips_py_amd.solvers import Hybrid_LSQR
+N = 512
+R = Radon2DParallel(N, np.linspace(0, np.pi, 180, endpoint=False))
+x = torch.rand(N * N, device="cuda"); b = R.apply(x)
+b = b + 0.01 * torch.randn_like(b) * b.norm() / b.numel() ** 0.5
+reg = sys.argv[1] if len(sys.argv) > 1 else "gcv"
+kw = {"delta": float(0.01 * b.norm())} if reg == "dp" else {}
+Hybrid_LSQR(R, b, 100, reg, x_true=x, history=False, **kw)
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+Hybrid_LSQR(R, b, 100, reg, x_true=x, history=False, **kw)
+torch.cuda.synchronize()
+pr.disable()
+pstats.Stats(pr).sort_stats("tottime").print_stats(22)

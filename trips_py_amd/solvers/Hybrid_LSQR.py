@@ -59,12 +59,21 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         lsqr_w, lsqr_x1, lsqr_st = eng.empty(n), eng.empty(n), eng.scalars(8)
         x_prev = None
     ub_vec = bv if (isinstance(regparam, str) and regparam == "dp") else None   # the discrepancy principle wants U^T b
-    pend = gk.step_prefetch(project=ub_vec) if (on_host and n_iter > 0) else None
+    # The Golub-Kahan steps do not depend on lambda: they are enqueued `ahead` steps in front of the iterate the host is choosing
+    # lambda for, each followed by the download of its two norms.  One step ahead, the device idled every iteration between the
+    # kernels of x_k and the enqueue of step k+2, which waited for step k+1's norms (gcv: 115 us per iteration for 75 us of kernels).
+    ahead = max(1, int(kwargs.get("steps_ahead", 3)))
+    pending, n_enq = [], 0
+    while on_host and n_enq < min(ahead, n_iter):
+        pending.append(gk.step_prefetch(project=ub_vec))
+        n_enq += 1
     for ii in range(n_iter):
         k = ii + 1
         if on_host:
-            gk.absorb(pend)                  # alpha_k, beta_{k+1}; step k+1 runs while the host chooses lambda_k
-            pend = gk.step_prefetch(project=ub_vec) if k < n_iter else None
+            gk.absorb(pending.pop(0))        # alpha_k, beta_{k+1}; the steps behind it run while the host chooses lambda_k
+            while n_enq < n_iter and len(pending) < ahead:
+                pending.append(gk.step_prefetch(project=ub_vec))
+                n_enq += 1
         else:
             # fixed lambda: nothing on the host needs B_k.  Iterates that nobody looks at are not formed and the step's last norm
             # stays inside the operator (defer); when every iterate IS formed, step k+1 is enqueued BEFORE x_k — its adjoint kernel
@@ -99,10 +108,6 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         if ii == 0:
             lam = 0
             continue
-        if on_host:
-            B = gk.B(k)
-            bhat = np.zeros(k + 1)
-            bhat[0] = gk.beta0
         if isinstance(regparam, str) and regparam == "gcv":
             # svd(B) (:81) enters GCV through s and Q_A^T bhat = beta0 * (first row of the left vectors) only — and G(lam) is a
             # resolvent of the tridiagonal B B^T: evaluated without the SVD (trk_host_gcv_bidiag); variant 'modified', fullsize = m (:84)
@@ -112,7 +117,9 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             else:
                 lam = fminbound_gcv_bidiag(gk._alphas[:k], gk._betas[:k], gk.beta0, m)
         elif isinstance(regparam, str) and regparam == "l_curve":
-            Qb, s, _ = sla.svd(B, full_matrices=False)
+            bhat = np.zeros(k + 1)
+            bhat[0] = gk.beta0
+            Qb, s, _ = sla.svd(gk.B(k), full_matrices=False)
             lam = choose_lambda(regparam, np.diag(s), np.eye(k), Qb.T @ bhat, 0.0, kwargs, variant="modified", fullsize=m)
         elif isinstance(regparam, str) and regparam == "dp":
             # discrepancy_principle(U, B, L, b): projects b on the (no longer exactly orthonormal) computed U (:86)
