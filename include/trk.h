@@ -195,6 +195,29 @@ int trk_op_apply_axpby(trk_op* op, int transpose, const float* x, double ca, con
                        int a_flags, double cb, const double* b_num, const double* b_den, int b_flags, const float* z,
                        float* out, double* sumsq, int hints, trk_stream stream);
 
+/* Asynchronous downloads of device scalars into one pinned host block ("mailbox"): trk_mailbox_post enqueues the copy of
+ * `count` doubles to host[offset ..] on `stream` and marks `slot` behind it; trk_mailbox_wait blocks until the work posted
+ * under that slot has completed (re-using a slot before waiting on it only makes the wait later, never earlier).  What the
+ * hybrid solvers use to fetch alpha_k, beta_{k+1} (the entries of B_k, Hybrid_LSQR.py:69-75) while later steps are already
+ * running.  The copy is a one-wave kernel writing host-coherent memory and publishing a sequence number the host polls: no
+ * copy-engine operation and no event on the compute stream. */
+typedef struct trk_mailbox trk_mailbox;
+int trk_mailbox_create(int n_doubles, int slots, trk_mailbox** out);
+int trk_mailbox_destroy(trk_mailbox* mb);
+int trk_mailbox_host(trk_mailbox* mb, double** host_out);
+int trk_mailbox_post(trk_mailbox* mb, int slot, const double* src_dev, int offset, int count, trk_stream stream);
+int trk_mailbox_wait(trk_mailbox* mb, int slot);
+
+/* One whole Golub-Kahan step (decompositions.py:230-255) on UNNORMALISED vectors, two trk_op_apply_axpby calls:
+ *   v_k    = (1/beta_k)  A^T u_k - (beta_k/alpha_{k-1}) v_prev ,  AB[2k+1] = ||v_k||^2    = alpha_k^2
+ *   u_next = (1/alpha_k) A v_k   - (alpha_k/beta_k)     u_k    ,  AB[2k+2] = ||u_next||^2 = beta_{k+1}^2
+ * with u_k = beta_k u_k(normalised), v_prev = alpha_{k-1} v_{k-1} (NULL for k = 0), AB[0] = ||b||^2, AB[2j+1] = alpha_j^2,
+ * AB[2j+2] = beta_{j+1}^2 (device doubles).  chained: u_k came out of the previous trk_gk_step on this operator, untouched
+ * (TRK_HINT_INPUT_FROM_OPPOSITE for the first half step); defer_alpha / defer_beta: TRK_HINT_SUMSQ_DEFERRED for the two norms
+ * (single rank: the next chained apply finishes them). */
+int trk_gk_step(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
+                int defer_alpha, int defer_beta, trk_stream stream);
+
 /* One fused CGLS vector update (CGLS.py:64-67):  step = *gamma / *delta ;
  *   x_new = x + step*p ; r = r - step*w ;  sums_dev[0] = ||x_new||^2, sums_dev[1] = ||step*p||^2
  *   (= ||x_new - x_old||^2, :76), sums_dev[2] = ||x_new - x_true||^2 if x_true != NULL (:79).
@@ -289,6 +312,19 @@ int trk_host_dp_newton(const double* sv, const double* bhat, int n, double targe
  * *testzero_out, if not NULL, receives that quantity); *alpha_set = 0: the reference's unassigned value. */
 int trk_host_dp_bidiag(const double* alpha, const double* beta_sub, int k, const double* bproj, double target, double extra,
                        double* alpha_out, int* alpha_set, int* iters_out, double* testzero_out);
+
+/* HOST: a worker thread of the library for the two searches above, so that choosing lambda_k overlaps the host's own
+ * enqueueing (Hybrid_LSQR.py:80-100: at 512^2 the GCV search is 40 % of the host's time per iteration).  One job at a time:
+ * post copies its inputs and returns at once; collect blocks until the posted job has finished and returns its lambda
+ * (*have = 0: the discrepancy principle's "unassigned" case, as trk_host_dp_bidiag's alpha_set) and its return code. */
+typedef struct trk_host_worker trk_host_worker;
+int trk_host_worker_create(trk_host_worker** out);
+int trk_host_worker_destroy(trk_host_worker* w);
+int trk_host_worker_post_gcv_bidiag(trk_host_worker* w, const double* alpha, const double* beta, int k, double beta0,
+                                    double m_eff, double x1, double x2, double xatol, int maxfun);
+int trk_host_worker_post_dp_bidiag(trk_host_worker* w, const double* alpha, const double* beta_sub, int k, const double* bproj,
+                                   double target, double extra);
+int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int* have_out);
 
 /* n_iters consecutive CGLS iterations (numbers k_first .. k_first + n_iters - 1, 1-based) enqueued by one call: the loop
  * body of trips/solvers/CGLS.py:56-80 with tol = 0, i.e. nothing is read back between iterations.  Same kernels, scalar

@@ -209,6 +209,18 @@ SIGNATURES = {
     "trk_cgs_coeffs": (c_int, [c_f64p, c_int, c_f64p, c_f64p, c_int, c_int, c_f64p, c_stream]),
     "trk_gemv_nt": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_gemv_n_err": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
+    "trk_host_worker_create": (c_int, [ctypes.POINTER(ctypes.c_void_p)]),
+    "trk_host_worker_destroy": (c_int, [ctypes.c_void_p]),
+    "trk_host_worker_post_gcv_bidiag": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_int, c_dbl, c_dbl, c_dbl, c_dbl,
+                                                c_dbl, c_int]),
+    "trk_host_worker_post_dp_bidiag": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_int, ctypes.c_void_p, c_dbl, c_dbl]),
+    "trk_host_worker_collect": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
+    "trk_mailbox_create": (c_int, [c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),
+    "trk_mailbox_destroy": (c_int, [ctypes.c_void_p]),
+    "trk_mailbox_host": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
+    "trk_mailbox_post": (c_int, [ctypes.c_void_p, c_int, c_f64p, c_int, c_int, c_stream]),
+    "trk_mailbox_wait": (c_int, [ctypes.c_void_p, c_int]),
+    "trk_gk_step": (c_int, [c_op, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_stream]),
     "trk_lsqr_damped_update": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int),
                                        c_f64p, c_f64p, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_stream]),
     "trk_gemv_n": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_dbl, c_f32p, c_dbl, c_f32p, c_f64p, c_stream]),

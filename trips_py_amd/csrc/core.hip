@@ -1,6 +1,7 @@
 // core.hip — library plumbing: error strings, per-stream scratch, the fixed-order finalize kernel,
 // operator-handle dispatch and the block-diagonal (frame-major) composite.
 #include "trk_internal.h"
+#include <cstring>
 
 #include <cstdlib>
 
@@ -301,6 +302,108 @@ int trk_op_set_timer(trk_op* op, trk_timer* t, int which) {
   op->timer = t;
   op->timer_which = which;
   return TRK_OK;
+}
+
+// ------------------------------------------------------------------ asynchronous scalar downloads
+// A one-wave kernel copies the scalars into pinned, host-coherent memory and then publishes a sequence number there
+// (system-scope fence in between); the host spins on that number.  Against hipMemcpyAsync + hipEventRecord on the compute
+// stream this keeps the copy engine and its ~8 us of stream latency out of a 70 us iteration, and the wait is a load loop.
+struct trk_mailbox {
+  double* host;                        // pinned
+  int n;
+  unsigned long long* seq;             // pinned: the last sequence number published per slot
+  unsigned long long* expect;          // host: the sequence number the newest post of a slot will publish
+  hipStream_t* stream;                 // the stream that post went to (for the error path of wait)
+  unsigned long long counter;
+  int slots;
+};
+
+namespace {
+__global__ void k_mailbox_post(const double* __restrict__ src, double* dst, int count, unsigned long long* seq,
+                               unsigned long long value) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+}  // namespace
+
+int trk_mailbox_create(int n_doubles, int slots, trk_mailbox** out) {
+  TRK_REQUIRE(out && n_doubles > 0 && slots > 0 && slots <= 4096, "trk_mailbox_create: bad argument");
+  auto* mb = new trk_mailbox{nullptr, n_doubles, nullptr, new unsigned long long[slots](), new hipStream_t[slots](), 0, slots};
+  hipError_t e = hipHostMalloc((void**)&mb->host, sizeof(double) * (size_t)n_doubles, hipHostMallocCoherent | hipHostMallocMapped);
+  if (e == hipSuccess) e = hipHostMalloc((void**)&mb->seq, sizeof(unsigned long long) * (size_t)slots, hipHostMallocCoherent | hipHostMallocMapped);
+  if (e != hipSuccess) {
+    trk_mailbox_destroy(mb);
+    return fail(TRK_EHIP, "trk_mailbox_create: %s", hipGetErrorString(e));
+  }
+  memset(mb->host, 0, sizeof(double) * (size_t)n_doubles);
+  memset(mb->seq, 0, sizeof(unsigned long long) * (size_t)slots);
+  *out = mb;
+  return TRK_OK;
+}
+
+int trk_mailbox_destroy(trk_mailbox* mb) {
+  if (!mb) return TRK_OK;
+  if (mb->host) (void)hipHostFree(mb->host);
+  if (mb->seq) (void)hipHostFree(mb->seq);
+  delete[] mb->expect;
+  delete[] mb->stream;
+  delete mb;
+  return TRK_OK;
+}
+
+int trk_mailbox_host(trk_mailbox* mb, double** host_out) {
+  TRK_REQUIRE(mb && host_out, "trk_mailbox_host: NULL argument");
+  *host_out = mb->host;
+  return TRK_OK;
+}
+
+int trk_mailbox_post(trk_mailbox* mb, int slot, const double* src_dev, int offset, int count, trk_stream stream) {
+  TRK_REQUIRE(mb && src_dev && slot >= 0 && slot < mb->slots, "trk_mailbox_post: bad mailbox / slot");
+  TRK_REQUIRE(offset >= 0 && count > 0 && offset + count <= mb->n, "trk_mailbox_post: range outside the mailbox");
+  mb->expect[slot] = ++mb->counter;
+  mb->stream[slot] = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mailbox_post, dim3(1), dim3(64), 0, (hipStream_t)stream, src_dev, mb->host + offset, count, mb->seq + slot,
+                     mb->expect[slot]);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_mailbox_wait(trk_mailbox* mb, int slot) {
+  TRK_REQUIRE(mb && slot >= 0 && slot < mb->slots, "trk_mailbox_wait: bad mailbox / slot");
+  const unsigned long long want = mb->expect[slot];
+  volatile unsigned long long* p = mb->seq + slot;
+  for (unsigned long long spins = 0;; ++spins) {
+    if (__atomic_load_n(p, __ATOMIC_ACQUIRE) >= want) return TRK_OK;
+    if ((spins & 0xFFFFF) == 0xFFFFF) {                        // every ~1 M polls: is the stream still alive?
+      const hipError_t e = hipStreamQuery(mb->stream[slot]);
+      if (e != hipSuccess && e != hipErrorNotReady) return fail(TRK_EHIP, "trk_mailbox_wait: %s", hipGetErrorString(e));
+      if (e == hipSuccess && __atomic_load_n(p, __ATOMIC_ACQUIRE) < want)
+        return fail(TRK_EHIP, "trk_mailbox_wait: the stream drained without the post arriving");
+    }
+  }
+}
+
+// ------------------------------------------------------------------ one Golub-Kahan step on unnormalised vectors
+int trk_gk_step(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
+                int defer_alpha, int defer_beta, trk_stream stream) {
+  TRK_REQUIRE(op && u_k && v_k && u_next && AB && k >= 0 && (k == 0 || v_prev), "trk_gk_step: bad argument");
+  double* bk2 = AB + 2 * k;            // ||U[k]||^2
+  double* a2 = AB + 2 * k + 1;         // ||V[k]||^2, written by the first half step
+  double* b2 = AB + 2 * k + 2;         // ||U[k+1]||^2, written by the second
+  const int feeds = TRK_HINT_OUT_FEEDS_OPPOSITE, takes = TRK_HINT_INPUT_FROM_OPPOSITE, later = TRK_HINT_SUMSQ_DEFERRED;
+  // V[k] = (1/beta_k) A^T U[k] - (beta_k/alpha_{k-1}) V[k-1]
+  if (int rc = trk_op_apply_axpby(op, 1, u_k, 1.0, nullptr, bk2, TRK_SQRT_DEN, k == 0 ? 0.0 : -1.0, k == 0 ? nullptr : bk2,
+                                  k == 0 ? nullptr : AB + 2 * k - 1, k == 0 ? 0 : (TRK_SQRT_NUM | TRK_SQRT_DEN),
+                                  k == 0 ? nullptr : v_prev, v_k, a2, feeds | (chained ? takes : 0) | (defer_alpha ? later : 0),
+                                  stream))
+    return rc;
+  // U[k+1] = (1/alpha_k) A V[k] - (alpha_k/beta_k) U[k]
+  return trk_op_apply_axpby(op, 0, v_k, 1.0, nullptr, a2, TRK_SQRT_DEN, -1.0, a2, bk2, TRK_SQRT_NUM | TRK_SQRT_DEN, u_k, u_next, b2,
+                            feeds | takes | (defer_beta ? later : 0), stream);
 }
 
 int trk_op_destroy(trk_op* op) {

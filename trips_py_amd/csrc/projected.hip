@@ -794,3 +794,124 @@ extern "C" int trk_host_dp_newton(const double* sv, const double* bhat, int n, d
   return TRK_OK;
 }
 
+
+// ------------------------------------------------------------------ lambda searches on a worker thread
+// The hybrid solvers choose lambda_k on the host from B_k while the device runs the steps after k; at 512^2 the bounded Brent
+// search for GCV (a dependent chain of divisions, O(k) per evaluation, ~40 evaluations) is 40 of the ~100 us the host spends per
+// iteration — more than the device needs for it.  A worker thread of the library takes the search: posting and collecting are
+// two cheap calls, the search overlaps the host's enqueueing of the next step.  One job at a time; inputs are copied at post.
+#include <atomic>
+#include <condition_variable>
+#include <thread>
+
+struct trk_host_worker {
+  std::thread th;
+  std::mutex m;
+  std::condition_variable cv;
+  std::atomic<int> state{0};      // 0 idle, 1 posted, 2 done, 3 stop
+  int kind = 0;                   // 0 gcv_bidiag, 1 dp_bidiag
+  std::vector<double> a, b, c;
+  int k = 0;
+  double p[6] = {0, 0, 0, 0, 0, 0};
+  int maxfun = 0;
+  double lam = 0.0;
+  int have = 0, rc = 0;
+};
+
+namespace {
+void host_worker_main(trk_host_worker* w) {
+  for (;;) {
+    // spin briefly (jobs arrive every ~70 us inside a solve), then sleep
+    int spins = 0;
+    while (w->state.load(std::memory_order_acquire) != 1 && w->state.load(std::memory_order_acquire) != 3 && spins < 20000) ++spins;
+    if (w->state.load(std::memory_order_acquire) != 1 && w->state.load(std::memory_order_acquire) != 3) {
+      std::unique_lock<std::mutex> lk(w->m);
+      w->cv.wait(lk, [&] { const int s = w->state.load(std::memory_order_acquire); return s == 1 || s == 3; });
+    }
+    if (w->state.load(std::memory_order_acquire) == 3) return;
+    if (w->kind == 0) {
+      w->have = 1;
+      w->rc = trk_host_gcv_bidiag(w->a.data(), w->b.data(), w->k, w->p[0], w->p[1], w->p[2], w->p[3], w->p[4], w->maxfun, &w->lam,
+                                  nullptr, nullptr);
+    } else {
+      w->rc = trk_host_dp_bidiag(w->a.data(), w->b.data(), w->k, w->c.data(), w->p[0], w->p[1], &w->lam, &w->have, nullptr, nullptr);
+    }
+    {
+      std::lock_guard<std::mutex> lk(w->m);
+      w->state.store(2, std::memory_order_release);
+    }
+    w->cv.notify_all();
+  }
+}
+}  // namespace
+
+extern "C" int trk_host_worker_create(trk_host_worker** out) {
+  TRK_REQUIRE(out, "trk_host_worker_create: NULL argument");
+  auto* w = new trk_host_worker;
+  w->th = std::thread(host_worker_main, w);
+  *out = w;
+  return TRK_OK;
+}
+
+extern "C" int trk_host_worker_destroy(trk_host_worker* w) {
+  if (!w) return TRK_OK;
+  {
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv.wait(lk, [&] { return w->state.load() != 1; });          // a running job finishes first
+    w->state.store(3, std::memory_order_release);
+  }
+  w->cv.notify_all();
+  w->th.join();
+  delete w;
+  return TRK_OK;
+}
+
+static int host_worker_post(trk_host_worker* w, int kind) {
+  {
+    std::lock_guard<std::mutex> lk(w->m);
+    w->kind = kind;
+    w->state.store(1, std::memory_order_release);
+  }
+  w->cv.notify_all();
+  return TRK_OK;
+}
+
+extern "C" int trk_host_worker_post_gcv_bidiag(trk_host_worker* w, const double* alpha, const double* beta, int k, double beta0,
+                                               double m_eff, double x1, double x2, double xatol, int maxfun) {
+  TRK_REQUIRE(w && alpha && beta && k >= 1, "trk_host_worker_post_gcv_bidiag: bad argument");
+  TRK_REQUIRE(w->state.load() != 1, "trk_host_worker_post_gcv_bidiag: a job is still running (collect it first)");
+  w->a.assign(alpha, alpha + k);
+  w->b.assign(beta, beta + k);
+  w->k = k;
+  w->p[0] = beta0; w->p[1] = m_eff; w->p[2] = x1; w->p[3] = x2; w->p[4] = xatol;
+  w->maxfun = maxfun;
+  return host_worker_post(w, 0);
+}
+
+extern "C" int trk_host_worker_post_dp_bidiag(trk_host_worker* w, const double* alpha, const double* beta_sub, int k,
+                                              const double* bproj, double target, double extra) {
+  TRK_REQUIRE(w && alpha && beta_sub && bproj && k >= 1, "trk_host_worker_post_dp_bidiag: bad argument");
+  TRK_REQUIRE(w->state.load() != 1, "trk_host_worker_post_dp_bidiag: a job is still running (collect it first)");
+  w->a.assign(alpha, alpha + k);
+  w->b.assign(beta_sub, beta_sub + k);
+  w->c.assign(bproj, bproj + k + 1);
+  w->k = k;
+  w->p[0] = target; w->p[1] = extra;
+  return host_worker_post(w, 1);
+}
+
+extern "C" int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int* have_out) {
+  TRK_REQUIRE(w && lam_out && have_out, "trk_host_worker_collect: NULL argument");
+  TRK_REQUIRE(w->state.load() != 0, "trk_host_worker_collect: nothing was posted");
+  int spins = 0;
+  while (w->state.load(std::memory_order_acquire) != 2 && spins < 20000) ++spins;
+  if (w->state.load(std::memory_order_acquire) != 2) {
+    std::unique_lock<std::mutex> lk(w->m);
+    w->cv.wait(lk, [&] { return w->state.load(std::memory_order_acquire) == 2; });
+  }
+  *lam_out = w->lam;
+  *have_out = w->have;
+  const int rc = w->rc;
+  w->state.store(0, std::memory_order_release);
+  return rc;
+}

@@ -58,12 +58,15 @@ class DevScalars:
     address as a plain int, so the hot loops create no tensor views); `view(i, j)` is a tensor view for collectives
     and downloads."""
 
-    __slots__ = ("t", "base", "_pin")
+    __slots__ = ("t", "base", "_pin", "_eng", "_mb", "_mb_np", "_mb_slot", "__weakref__")
 
-    def __init__(self, t):
+    MAILBOX_SLOTS = 32
+
+    def __init__(self, t, eng=None):
         self.t = t
         self.base = t.data_ptr()
         self._pin = None
+        self._eng, self._mb, self._mb_np, self._mb_slot = eng, None, None, 0
 
     def ref(self, i):
         return self.base + 8 * i
@@ -77,6 +80,23 @@ class DevScalars:
     def host_later(self, i, j):
         """Start the download of scalars [i, j) at this point of the stream and return a handle; `get()` waits for THAT
         copy only, so work enqueued in between overlaps with whatever the host does before it asks."""
+        eng = self._eng
+        if eng is not None:
+            # trk_mailbox: one hipMemcpyAsync + one hipEventRecord; the tensor-copy + Event-object route below costs the host
+            # ~12 us per download, a tenth of a Hybrid-LSQR iteration at 512^2
+            if self._mb is None:
+                import weakref
+                mb = ctypes.c_void_p()
+                _lib.check(eng.lib.trk_mailbox_create(self.t.numel(), self.MAILBOX_SLOTS, ctypes.byref(mb)), "trk_mailbox_create")
+                hp = ctypes.c_void_p()
+                _lib.check(eng.lib.trk_mailbox_host(mb, ctypes.byref(hp)), "trk_mailbox_host")
+                self._mb = mb
+                self._mb_np = np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ctypes.c_double)), shape=(self.t.numel(),))
+                weakref.finalize(self, eng.lib.trk_mailbox_destroy, mb)
+            slot = self._mb_slot
+            self._mb_slot = (slot + 1) % self.MAILBOX_SLOTS
+            _lib.check(eng.lib.trk_mailbox_post(self._mb, slot, self.base + 8 * i, int(i), int(j - i), eng.stream()), "trk_mailbox_post")
+            return _Posted(eng.lib, self._mb, slot, self._mb_np, i, j)
         if self._pin is None:
             self._pin = torch.empty(self.t.numel(), dtype=torch.float64, pin_memory=True)
         self._pin[i:j].copy_(self.t[i:j], non_blocking=True)
@@ -100,6 +120,17 @@ class DevScalars:
 
     def data_ptr(self):
         return self.base
+
+
+class _Posted:
+    __slots__ = ("lib", "mb", "slot", "host", "i", "j")
+
+    def __init__(self, lib, mb, slot, host, i, j):
+        self.lib, self.mb, self.slot, self.host, self.i, self.j = lib, mb, slot, host, i, j
+
+    def get(self):
+        _lib.check(self.lib.trk_mailbox_wait(self.mb, self.slot), "trk_mailbox_wait")
+        return self.host[self.i:self.j].copy()
 
 
 class _Pending:
@@ -150,7 +181,7 @@ class HipEngine:
         return torch.empty((int(k), int(n)), dtype=torch.float32, device=self.device)
 
     def scalars(self, n):
-        return DevScalars(torch.zeros(int(n), dtype=torch.float64, device=self.device))
+        return DevScalars(torch.zeros(int(n), dtype=torch.float64, device=self.device), self)
 
     def to_vec(self, a, n=None):
         """numpy / torch, shape (n,), (n,1) -> contiguous fp32 device vector (a copy unless already one)."""
@@ -430,6 +461,13 @@ class HipEngine:
                                      _ptr(partials), int(capacity), ctypes.byref(n), self.stream())
         _lib.check(rc, "trk_gemv_n_err")
         return n.value
+
+    def gk_step(self, handle, k, u_k, v_prev, v_k, u_next, AB, chained, defer_alpha, defer_beta):
+        """One Golub-Kahan step on unnormalised vectors in one call (trk_gk_step): both half steps with their norms."""
+        rc = self.lib.trk_gk_step(handle, int(k), u_k.data_ptr(), None if v_prev is None else v_prev.data_ptr(), v_k.data_ptr(),
+                                  u_next.data_ptr(), AB.base, int(bool(chained)), int(bool(defer_alpha)), int(bool(defer_beta)),
+                                  self.stream())
+        _lib.check(rc, "trk_gk_step")
 
     def lsqr_damped_update(self, vk, w, x_in, x_out, alpha_sq, beta_next_sq, beta0_sq, damp, state_in, state_out, first,
                            ref=None, partials=None, capacity=0):

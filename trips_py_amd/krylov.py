@@ -153,18 +153,21 @@ class GKState:
             self._beta0 = float(np.sqrt(self.AB.host(0, 1)[0]))
         return self._beta0
 
-    def step_prefetch(self, project=None):
+    def step_prefetch(self, project=None, more_follow=False):
         """One step, enqueued, plus the start of the download of its two norms: `absorb()` later waits for that copy
         only, so a caller can enqueue the NEXT step before it looks at this one's numbers (the hybrid solvers choose
         lambda_k on the host while the device already runs step k+1, which does not depend on it).
+        Returns the LIST of downloads started by this call, oldest first, each to be handed to `absorb()` in order.
+        more_follow=True: the caller promises another step_prefetch before anything else touches this state — beta_{k+1}^2 then
+        stays inside the operator (step(defer=True)) until the NEXT step's adjoint kernel finishes it, and this step's download
+        is started by that next call (none by this one: the list may be empty); the last call (more_follow=False) starts both.
         project: a vector b whose products with the rows of U the caller wants (the discrepancy principle's U^T b):
         the new row's U[k+1] . b (U[0] . b as well on the first step) is taken right behind the step and downloaded with
         the norms — `self.uproj` grows by one entry per absorbed step — instead of a pass over all of U and a blocking
         download per iteration."""
         k = self.V.k
-        self.step(sync=False)
-        lo = 0 if self._beta0 is None else 2 * k + 1
-        extra = None
+        self.step(sync=False, defer=bool(more_follow))
+        j0 = None
         if project is not None:
             eng = self.eng
             if self._UB is None:
@@ -174,7 +177,21 @@ class GKState:
             for j in range(j0, k + 2):
                 eng.dot(self.U[j], project, self._UB.ref(j))
             eng.allreduce(self._UB, j0, k + 2)
-            extra = self._UB.host_later(j0, k + 2)
+        started = []
+        late, self._late = getattr(self, "_late", None), None
+        if late is not None:
+            started.append(self._post_step(*late))       # the step before: its beta^2 was finished by this step's first kernel
+        if more_follow:
+            self._late = (k, j0)
+        else:
+            started.append(self._post_step(k, j0))
+        return started
+
+    def _post_step(self, k, j0):
+        first = not getattr(self, "_posted_any", False)
+        self._posted_any = True
+        lo = 0 if first else 2 * k + 1
+        extra = None if j0 is None else self._UB.host_later(j0, k + 2)
         return k, lo, self.AB.host_later(lo, 2 * k + 3), extra
 
     def absorb(self, pending):
@@ -224,6 +241,15 @@ class GKState:
                 # single rank: alpha_k^2 stays block partials until the forward apply below adds them up for its own
                 # coefficients (no reduction launch); beta_{k+1}^2 likewise until the next step, if the caller allows
                 local = getattr(eng, "world", 1) == 1
+                if local and hasattr(eng, "gk_step") and getattr(A, "_h", None):
+                    # the whole step in one call of the library (trk_gk_step: the two half steps below, same coefficients,
+                    # same hints) — the Python side of a step was a fifth of a 512^2 Hybrid-LSQR iteration's host time
+                    un = self.U.next_slot()
+                    eng.gk_step(A._h, k, u, None if k == 0 else self.V[k - 1], v, un, AB, self._chained, True, defer)
+                    self.V.commit()
+                    self.U.commit()
+                    self._chained = True
+                    return self._finish_step(k, sync)
                 later = A.SUMSQ_DEFERRED if local else 0
                 A.apply_axpby(u, ca_v, 0.0 if k == 0 else cb_v, None if k == 0 else self.V[k - 1], v, transpose=True,
                               sumsq=a2, hints=feeds | (takes if self._chained else 0) | later)

@@ -16,6 +16,44 @@ from ..reg_param.gcv import fminbound_gcv_diag, fminbound_gcv_bidiag
 from ._common import check_delta, choose_lambda, small_host_blas
 
 
+class _Searcher:
+    """The library's worker thread for the lambda searches (trk_host_worker_*): post copies B_k's entries and returns, collect
+    waits for the result.  One per solve."""
+
+    def __init__(self, lib):
+        import ctypes
+        self._ct, self.lib = ctypes, lib
+        self.h = ctypes.c_void_p()
+        if lib.trk_host_worker_create(ctypes.byref(self.h)) != 0:
+            raise RuntimeError("trk_host_worker_create failed")
+
+    def post_gcv(self, alphas, betas, beta0, m_eff, x1=1e-9, x2=1e2, xtol=1e-12, maxfun=1000):
+        al = np.ascontiguousarray(alphas, dtype=np.float64)
+        be = np.ascontiguousarray(betas, dtype=np.float64)
+        if self.lib.trk_host_worker_post_gcv_bidiag(self.h, al.ctypes.data, be.ctypes.data, int(al.size), float(beta0), float(m_eff),
+                                                    float(x1), float(x2), float(xtol), int(maxfun)) != 0:
+            raise RuntimeError("trk_host_worker_post_gcv_bidiag failed")
+
+    def post_dp(self, alphas, betas, bproj, delta, eta=1.01):
+        al = np.ascontiguousarray(alphas, dtype=np.float64)
+        be = np.ascontiguousarray(betas, dtype=np.float64)
+        bp = np.ascontiguousarray(np.asarray(bproj, dtype=np.float64).reshape(-1))
+        if self.lib.trk_host_worker_post_dp_bidiag(self.h, al.ctypes.data, be.ctypes.data, int(al.size), bp.ctypes.data,
+                                                   float((eta * delta) ** 2), 0.0) != 0:
+            raise RuntimeError("trk_host_worker_post_dp_bidiag failed")
+
+    def collect(self):
+        lam, have = self._ct.c_double(0.0), self._ct.c_int(0)
+        if self.lib.trk_host_worker_collect(self.h, self._ct.byref(lam), self._ct.byref(have)) != 0:
+            raise RuntimeError("lambda search failed on the worker thread")
+        return lam.value if have.value else None
+
+    def close(self):
+        h, self.h = self.h, None
+        if h:
+            self.lib.trk_host_worker_destroy(h)
+
+
 @small_host_blas(when=lambda rp: rp == "l_curve")
 def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys: xHistory (n_iter-1 iterates: none is formed at the first step, :77-78), regParam,
@@ -64,82 +102,27 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     # kernels of x_k and the enqueue of step k+2, which waited for step k+1's norms (gcv: 115 us per iteration for 75 us of kernels).
     ahead = max(1, int(kwargs.get("steps_ahead", 3)))
     pending, n_enq = [], 0
-    while on_host and n_enq < min(ahead, n_iter):
-        pending.append(gk.step_prefetch(project=ub_vec))
-        n_enq += 1
-    for ii in range(n_iter):
-        k = ii + 1
-        if on_host:
-            gk.absorb(pending.pop(0))        # alpha_k, beta_{k+1}; the steps behind it run while the host chooses lambda_k
-            while n_enq < n_iter and len(pending) < ahead:
-                pending.append(gk.step_prefetch(project=ub_vec))
-                n_enq += 1
-        else:
-            # fixed lambda: nothing on the host needs B_k.  Iterates that nobody looks at are not formed and the step's last norm
-            # stays inside the operator (defer); when every iterate IS formed, step k+1 is enqueued BEFORE x_k — its adjoint kernel
-            # finishes beta_{k+1}^2 on the way (GKState.step(defer=True)), which the projected solve of x_k reads — so that no
-            # reduction launch is spent on it
-            if gk.V.k < k:
-                gk.step(sync=False, defer=True)
-            if k < n_iter and (keep or xt is not None):
-                gk.step(sync=False, defer=True)                      # step k+1 ahead of x_k
-        if recur:
-            # step k of the recurrence (the reference reports no iterate for k = 1, the recurrence needs it all the same);
-            # alpha_k^2 = AB[2k-1] and beta_{k+1}^2 = AB[2k] are final: the step enqueued ahead finished the latter
-            if k == n_iter:
-                gk.flush()                       # no step was enqueued ahead of the last iterate
-            x_dev = lsqr_x1 if ii == 0 else H.row(nx_done)
-            got = eng.lsqr_damped_update(gk.V[ii], lsqr_w, x_prev, x_dev, gk.AB.ref(2 * k - 1), gk.AB.ref(2 * k), gk.AB.ref(0),
-                                         np.sqrt(float(regparam)), lsqr_st.ref(4 * ((ii + 1) & 1)), lsqr_st.ref(4 * (ii & 1)), ii == 0,
-                                         ref=None if ii == 0 else xt, partials=None if (ii == 0 or xt is None) else EP.ref(n_ep * nx_done),
-                                         capacity=1024)
-            x_prev = x_dev
-            if ii == 0:
-                lam = 0
-                x_dev = None
-                continue
-            if xt is not None:
-                n_ep = got
-            lam = regparam
-            lams.append(lam)
-            H.pushed(nx_done)
-            nx_done += 1
-            continue
-        if ii == 0:
-            lam = 0
-            continue
-        if isinstance(regparam, str) and regparam == "gcv":
-            # svd(B) (:81) enters GCV through s and Q_A^T bhat = beta0 * (first row of the left vectors) only — and G(lam) is a
-            # resolvent of the tridiagonal B B^T: evaluated without the SVD (trk_host_gcv_bidiag); variant 'modified', fullsize = m (:84)
-            if kwargs.get("gcv_by_svd", False):
-                s, u0 = bidiag_svd_first_row(gk._alphas[:k], gk._betas[:k])
-                lam = fminbound_gcv_diag(s, gk.beta0 * u0, m)
-            else:
-                lam = fminbound_gcv_bidiag(gk._alphas[:k], gk._betas[:k], gk.beta0, m)
-        elif isinstance(regparam, str) and regparam == "l_curve":
-            bhat = np.zeros(k + 1)
-            bhat[0] = gk.beta0
-            Qb, s, _ = sla.svd(gk.B(k), full_matrices=False)
-            lam = choose_lambda(regparam, np.diag(s), np.eye(k), Qb.T @ bhat, 0.0, kwargs, variant="modified", fullsize=m)
-        elif isinstance(regparam, str) and regparam == "dp":
-            # discrepancy_principle(U, B, L, b): projects b on the (no longer exactly orthonormal) computed U (:86)
-            # U^T b row by row, downloaded with each step's norms (krylov.GKState.step_prefetch): no pass over U, no blocking copy
-            bproj = np.asarray(gk.uproj[:k + 1]) / np.concatenate(([gk.beta0], gk._betas[:k]))   # rows of U are beta_j u_j
-            extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
-            if kwargs.get("dp_by_svd", False):
-                s, proj = bidiag_svd_project(gk._alphas[:k], gk._betas[:k], bproj)       # svd(B_k), U^T bproj (dp :68-70)
-                lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
-                                            spectrum=(s, proj, (k + 1, k)), **extra)
-            else:                                # the same Newton iteration on the tridiagonal resolvent: no SVD of B_k
-                lam = discrepancy_principle_bidiag(gk._alphas[:k], gk._betas[:k], bproj, delta=kwargs.get("delta"), **extra)
-        else:
-            lam = regparam
+    while on_host and n_enq < n_iter and len(pending) < ahead:
+        pending.extend(gk.step_prefetch(project=ub_vec, more_follow=n_enq + 1 < n_iter))     # (a step's download starts behind the
+        n_enq += 1                                                                           #  next step: its last norm rides there)
+    # gcv / dp: the search for lambda_k runs on a worker thread of the library (trk_host_worker_*) while this thread enqueues the
+    # next step; the iterate of step k is formed one trip later, when its lambda is collected.  (The searches were 20-45 us of
+    # the ~100 us this loop spent per iteration at 512^2 x 180 — more than the device needs for an iteration's kernels.)
+    searcher = None
+    if (on_host and regparam in ("gcv", "dp") and kwargs.get("async_search", True) and hasattr(eng, "lib")
+            and not kwargs.get("gcv_by_svd", False) and not kwargs.get("dp_by_svd", False) and n_iter > 2):
+        searcher = _Searcher(eng.lib)
+    waiting = None                           # the step whose lambda the worker is looking for
+
+    def form_iterate(k, lam):
+        nonlocal nx_done, n_ep, x_dev
         lams.append(lam)
-        if not keep and xt is None and ii < n_iter - 1:
-            continue                         # nobody looks at this iterate (history=False, no x_true)
+        if not keep and xt is None and k < n_iter:
+            return                           # nobody looks at this iterate (history=False, no x_true)
         # y = lstsq([B; sqrt(lam) I], [beta0 e1; 0]) (:104), on the device from the squared norms in gk.AB
         # (as y_j / alpha_j: the rows of V are alpha_j v_j)
-        gk.flush()
+        if not on_host:
+            gk.flush()                       # (automatic lambda: the norms of step k were downloaded, hence finished, before this)
         eng.bidiag_tikhonov(gk.AB.ref(1), 2, gk.AB.ref(2), 2, k, np.sqrt(lam), gk.AB.ref(0), Y.ref(0), W, y_over_alpha=True)
         x_dev = H.row(nx_done)
         if err_fused:
@@ -150,6 +133,95 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         nx_done += 1
         if xt is not None and not err_fused:
             eng.diff_nrm2sq(x_dev, xt, E.ref(nx_done))
+
+    try:
+        for ii in range(n_iter):
+            k = ii + 1
+            if on_host:
+                gk.absorb(pending.pop(0))        # alpha_k, beta_{k+1}; the steps behind it run while the host chooses lambda_k
+                while n_enq < n_iter and len(pending) < ahead:
+                    pending.extend(gk.step_prefetch(project=ub_vec, more_follow=n_enq + 1 < n_iter))
+                    n_enq += 1
+            else:
+                # fixed lambda: nothing on the host needs B_k.  Iterates that nobody looks at are not formed and the step's last norm
+                # stays inside the operator (defer); when every iterate IS formed, step k+1 is enqueued BEFORE x_k — its adjoint kernel
+                # finishes beta_{k+1}^2 on the way (GKState.step(defer=True)), which the projected solve of x_k reads — so that no
+                # reduction launch is spent on it
+                if gk.V.k < k:
+                    gk.step(sync=False, defer=True)
+                if k < n_iter and (keep or xt is not None):
+                    gk.step(sync=False, defer=True)                      # step k+1 ahead of x_k
+            if recur:
+                # step k of the recurrence (the reference reports no iterate for k = 1, the recurrence needs it all the same);
+                # alpha_k^2 = AB[2k-1] and beta_{k+1}^2 = AB[2k] are final: the step enqueued ahead finished the latter
+                if k == n_iter:
+                    gk.flush()                       # no step was enqueued ahead of the last iterate
+                x_dev = lsqr_x1 if ii == 0 else H.row(nx_done)
+                got = eng.lsqr_damped_update(gk.V[ii], lsqr_w, x_prev, x_dev, gk.AB.ref(2 * k - 1), gk.AB.ref(2 * k), gk.AB.ref(0),
+                                             np.sqrt(float(regparam)), lsqr_st.ref(4 * ((ii + 1) & 1)), lsqr_st.ref(4 * (ii & 1)), ii == 0,
+                                             ref=None if ii == 0 else xt, partials=None if (ii == 0 or xt is None) else EP.ref(n_ep * nx_done),
+                                             capacity=1024)
+                x_prev = x_dev
+                if ii == 0:
+                    lam = 0
+                    x_dev = None
+                    continue
+                if xt is not None:
+                    n_ep = got
+                lam = regparam
+                lams.append(lam)
+                H.pushed(nx_done)
+                nx_done += 1
+                continue
+            if ii == 0:
+                lam = 0
+                continue
+            if searcher is not None:
+                if waiting is not None:
+                    lam = searcher.collect()
+                # post the search for lambda_k first, then form the iterate of the step before it
+                if regparam == "gcv":
+                    searcher.post_gcv(gk._alphas[:k], gk._betas[:k], gk.beta0, m)
+                else:
+                    bproj = np.asarray(gk.uproj[:k + 1]) / np.concatenate(([gk.beta0], gk._betas[:k]))   # rows of U are beta_j u_j
+                    searcher.post_dp(gk._alphas[:k], gk._betas[:k], bproj, kwargs.get("delta"), kwargs.get("eta", 1.01))
+                if waiting is not None:
+                    form_iterate(waiting, lam)
+                waiting = k
+                continue
+            if isinstance(regparam, str) and regparam == "gcv":
+                # svd(B) (:81) enters GCV through s and Q_A^T bhat = beta0 * (first row of the left vectors) only — and G(lam) is a
+                # resolvent of the tridiagonal B B^T: evaluated without the SVD (trk_host_gcv_bidiag); variant 'modified', fullsize = m (:84)
+                if kwargs.get("gcv_by_svd", False):
+                    s, u0 = bidiag_svd_first_row(gk._alphas[:k], gk._betas[:k])
+                    lam = fminbound_gcv_diag(s, gk.beta0 * u0, m)
+                else:
+                    lam = fminbound_gcv_bidiag(gk._alphas[:k], gk._betas[:k], gk.beta0, m)
+            elif isinstance(regparam, str) and regparam == "l_curve":
+                bhat = np.zeros(k + 1)
+                bhat[0] = gk.beta0
+                Qb, s, _ = sla.svd(gk.B(k), full_matrices=False)
+                lam = choose_lambda(regparam, np.diag(s), np.eye(k), Qb.T @ bhat, 0.0, kwargs, variant="modified", fullsize=m)
+            elif isinstance(regparam, str) and regparam == "dp":
+                # discrepancy_principle(U, B, L, b): projects b on the (no longer exactly orthonormal) computed U (:86)
+                # U^T b row by row, downloaded with each step's norms (krylov.GKState.step_prefetch): no pass over U, no blocking copy
+                bproj = np.asarray(gk.uproj[:k + 1]) / np.concatenate(([gk.beta0], gk._betas[:k]))   # rows of U are beta_j u_j
+                extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
+                if kwargs.get("dp_by_svd", False):
+                    s, proj = bidiag_svd_project(gk._alphas[:k], gk._betas[:k], bproj)       # svd(B_k), U^T bproj (dp :68-70)
+                    lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
+                                                spectrum=(s, proj, (k + 1, k)), **extra)
+                else:                                # the same Newton iteration on the tridiagonal resolvent: no SVD of B_k
+                    lam = discrepancy_principle_bidiag(gk._alphas[:k], gk._betas[:k], bproj, delta=kwargs.get("delta"), **extra)
+            else:
+                lam = regparam
+            form_iterate(k, lam)
+        if waiting is not None:
+            lam = searcher.collect()
+            form_iterate(waiting, lam)
+    finally:
+        if searcher is not None:
+            searcher.close()
     if x_dev is None:
         raise UnboundLocalError("Hybrid_LSQR with n_iter < 2 forms no iterate (the reference fails the same way, "
                                 "Hybrid_LSQR.py:114)")
