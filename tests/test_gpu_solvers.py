@@ -397,3 +397,73 @@ def test_hybrid_lsqr_recurrence_equals_the_combination(kind, N, its):
     x2, i2 = Hybrid_LSQR(A, b, 12, 1e-2)
     x3, i3 = Hybrid_LSQR(A, b, 12, 1e-2, x_by_recurrence=False)
     assert relerr(x2, x3) < TOL and relerr(i2["xHistory"][0], i3["xHistory"][0]) < TOL
+
+
+def test_mailbox_downloads_and_one_call_gk_step():
+    """trk_mailbox_*: scalars posted behind kernels arrive (every slot, re-used slots, overlapping ranges); trk_gk_step: one call
+    = the two trk_op_apply_axpby half steps of krylov.GKState (bit-identical vectors and norms), Radon (native epilogue) and blur
+    (generic fallback)."""
+    from trips_py_amd.engine import Coef, default_engine
+    from trips_py_amd.operators import Blur2D, Radon2DParallel
+    from trips_py_amd.problems import gauss_psf
+    eng = default_engine()
+    S = eng.scalars(40)
+    vals = np.arange(40, dtype=np.float64) * 1.5 + 0.25
+    S.set(0, vals)
+    hs = [S.host_later(i, i + 3) for i in range(0, 36)]           # more posts than slots: early handles wait on later posts
+    for i, h in enumerate(hs):
+        assert np.array_equal(h.get(), vals[i:i + 3])
+    x = torch.rand(1 << 20, device=eng.device)
+    eng.nrm2sq(x, S.ref(5))
+    h = S.host_later(5, 6)                                        # behind the kernel that writes it
+    assert abs(h.get()[0] - float((x.double() ** 2).sum())) < 1e-6 * x.numel()
+    for A in (Radon2DParallel(64, np.linspace(0, np.pi, 24, endpoint=False)), Blur2D(gauss_psf((5, 5), (1, 1))[0], 48, 48)):
+        m, n = A.shape
+        g = torch.Generator(device=eng.device).manual_seed(3)
+        b = torch.randn(m, device=eng.device, generator=g)
+        U0, V0 = [b.clone()] + [eng.empty(m) for _ in range(3)], [eng.empty(n) for _ in range(3)]
+        U1, V1 = [b.clone()] + [eng.empty(m) for _ in range(3)], [eng.empty(n) for _ in range(3)]
+        AB0, AB1 = eng.scalars(8), eng.scalars(8)
+        for AB in (AB0, AB1):
+            eng.nrm2sq(b, AB.ref(0))
+        for k in range(3):
+            bk2, a2, b2 = AB0.ref(2 * k), AB0.ref(2 * k + 1), AB0.ref(2 * k + 2)
+            A.apply_axpby(U0[k], Coef(1.0, den=bk2, sqrt_den=True),
+                          0.0 if k == 0 else Coef(-1.0, num=bk2, den=AB0.ref(2 * k - 1), sqrt_num=True, sqrt_den=True),
+                          None if k == 0 else V0[k - 1], V0[k], transpose=True, sumsq=a2)
+            A.apply_axpby(V0[k], Coef(1.0, den=a2, sqrt_den=True), Coef(-1.0, num=a2, den=bk2, sqrt_num=True, sqrt_den=True), U0[k],
+                          U0[k + 1], sumsq=b2)
+            eng.gk_step(A._h, k, U1[k], None if k == 0 else V1[k - 1], V1[k], U1[k + 1], AB1, k > 0, True, k < 2)
+        A.flush_deferred()
+        assert np.array_equal(AB0.host(0, 7), AB1.host(0, 7))
+        for k in range(3):
+            assert torch.equal(V0[k], V1[k]) and torch.equal(U0[k + 1], U1[k + 1])
+
+
+@pytest.mark.parametrize("reg", ["gcv", "dp"])
+def test_hybrid_lsqr_pipelined_loop_equals_the_plain_one(reg):
+    """Automatic lambda: steps enqueued ahead, the search on the worker thread and the iterate formed one trip late give the
+    same lambdas and the same iterates as the loop that does everything in order (Hybrid_LSQR.py:69-110)."""
+    from trips_py_amd.operators import Radon2DParallel
+    from trips_py_amd.solvers import Hybrid_LSQR
+    N = 96
+    A = Radon2DParallel(N, np.linspace(0, np.pi, 40, endpoint=False))
+    rng = np.random.default_rng(9)
+    xt = rng.random(N * N).astype(np.float32)
+    b = A.apply(torch.from_numpy(xt).cuda())
+    e = torch.randn_like(b)
+    delta = 0.02 * float(b.norm())
+    b = (b + e * (delta / e.norm())).cpu().numpy()
+    kw = {"delta": delta} if reg == "dp" else {}
+    for its in (2, 3, 25):
+        x0, i0 = Hybrid_LSQR(A, b, its, reg, xt, async_search=False, steps_ahead=1, **kw)
+        for opts in ({}, {"steps_ahead": 2}, {"async_search": False}, {"steps_ahead": 7}):
+            x1, i1 = Hybrid_LSQR(A, b, its, reg, xt, **opts, **kw)
+            assert i1["regParam_history"] == i0["regParam_history"] and i1["regParam"] == i0["regParam"], opts
+            assert np.array_equal(x1, x0) and np.array_equal(i1["relError"], i0["relError"]), opts
+            assert len(i1["xHistory"]) == len(i0["xHistory"]) == its - 1
+            assert all(np.array_equal(p, q) for p, q in zip(i1["xHistory"], i0["xHistory"]))
+    # nobody looks at the intermediate iterates: only the last is formed
+    x2, i2 = Hybrid_LSQR(A, b, 12, reg, history=False, **kw)
+    x3, i3 = Hybrid_LSQR(A, b, 12, reg, history=False, async_search=False, steps_ahead=1, **kw)
+    assert np.array_equal(x2, x3) and i2["regParam_history"] == i3["regParam_history"]

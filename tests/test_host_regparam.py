@@ -174,3 +174,38 @@ def test_discrepancy_principle_of_the_bidiagonal_problem_without_its_svd(k):
             assert got == want, (delta, got, want)
         else:
             assert abs(got - want) <= 1e-8 * abs(want), (delta, got, want)
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 40, 100])
+def test_worker_thread_searches_equal_the_direct_calls(k):
+    """trk_host_worker_*: the lambda searches of the hybrid solvers (Hybrid_LSQR.py:80-100) posted to the library's worker
+    thread return the very numbers of trk_host_gcv_bidiag / trk_host_dp_bidiag, job after job on one worker."""
+    import ctypes
+    from trips_py_amd import _lib
+    from trips_py_amd.reg_param.discrepancy_principle import discrepancy_principle_bidiag
+    from trips_py_amd.reg_param.gcv import fminbound_gcv_bidiag
+    lib = _lib.load()
+    rng = np.random.default_rng(k)
+    w = ctypes.c_void_p()
+    assert lib.trk_host_worker_create(ctypes.byref(w)) == 0
+    lam, have = ctypes.c_double(0.0), ctypes.c_int(0)
+    try:
+        assert lib.trk_host_worker_collect(w, ctypes.byref(lam), ctypes.byref(have)) != 0      # nothing posted yet
+        for rep in range(3):
+            al, be = rng.random(k) + 0.3, rng.random(k) + 0.05
+            beta0 = float(rng.random() + 1.0)
+            assert lib.trk_host_worker_post_gcv_bidiag(w, al.ctypes.data, be.ctypes.data, k, beta0, 5000.0, 1e-9, 1e2, 1e-12, 1000) == 0
+            al_copy = al.copy()
+            al[:] = -1.0                                        # the inputs were copied at post
+            assert lib.trk_host_worker_collect(w, ctypes.byref(lam), ctypes.byref(have)) == 0
+            assert have.value == 1 and lam.value == fminbound_gcv_bidiag(al_copy, be, beta0, 5000.0)
+            al = al_copy
+            bp = rng.random(k + 1) * beta0
+            nb2 = float(bp @ bp)
+            for delta in (0.02 * nb2 ** 0.5, 0.5 * nb2 ** 0.5):
+                assert lib.trk_host_worker_post_dp_bidiag(w, al.ctypes.data, be.ctypes.data, k, bp.ctypes.data, (1.01 * delta) ** 2, 0.0) == 0
+                assert lib.trk_host_worker_collect(w, ctypes.byref(lam), ctypes.byref(have)) == 0
+                want = discrepancy_principle_bidiag(al, be, bp, delta=float(delta))
+                assert (lam.value if have.value else None) == want
+    finally:
+        assert lib.trk_host_worker_destroy(w) == 0
