@@ -91,6 +91,31 @@ __device__ __forceinline__ double block_sum(double v, double* lds) {
   return t;
 }
 
+// NV block sums with two barriers instead of 2 NV: every value is reduced within its wave, lane 0 of each wave parks its NV
+// sums in LDS, and thread i < NV adds the NT/64 wave sums of value i — in wave order, the order of block_sum, so the bits are
+// the same.  `lds` holds (NT/64) * NV doubles.  The result of value i is valid in thread i.
+template <int NT, int NV>
+__device__ __forceinline__ double block_sum_many(const double (&v)[NV], double* lds) {
+  constexpr int NW = NT / 64;
+  static_assert(NV <= NT, "one thread per value");
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double w[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) w[i] = wave_sum(v[i]);
+  __syncthreads();  // protect lds reuse between consecutive calls
+  if (lane == 0) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) lds[wid * NV + i] = w[i];
+  }
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x < NV) {
+#pragma unroll
+    for (int q = 0; q < NW; ++q) t += lds[q * NV + threadIdx.x];
+  }
+  return t;
+}
+
 // ------------------------------------------------------------------ a scalar that may still be block partials
 // n == 0: the constant 1 ; n == 1: *p ; n > 1: the sum of n block partials.  The sum is always formed the same way
 // (lane l of one wave adds p[l], p[l+64], ... then a wave64 tree), so every kernel that consumes the same partials

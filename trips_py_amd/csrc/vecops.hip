@@ -505,7 +505,7 @@ template <int WPOW, bool VEC>
 __global__ __launch_bounds__(NT) void k_gemv_t(const float* __restrict__ V, int64_t ld, int k, int64_t n,
                                                const float* __restrict__ r, const float* __restrict__ w,
                                                double* __restrict__ partials, int nt) {
-  __shared__ double lds[NT / 64];
+  __shared__ double lds[(NT / 64) * JT];
   const int j0 = blockIdx.y * JT;
   const int jn = (k - j0 < JT) ? (k - j0) : JT;
   double acc[JT];
@@ -550,11 +550,10 @@ __global__ __launch_bounds__(NT) void k_gemv_t(const float* __restrict__ V, int6
     for (int j = 0; j < JT; ++j)
       if (j < jn) acc[j] += (double)V[(int64_t)(j0 + j) * ld + i] * rv;
   }
-#pragma unroll
-  for (int j = 0; j < JT; ++j) {
-    double t = block_sum<NT>(acc[j], lds);
-    if (threadIdx.x == 0 && j < jn) partials[(size_t)blockIdx.x * k + j0 + j] = t;
-  }
+  // (one exchange for the JT sums: with a block_sum each, the 2 JT barriers of a workgroup were a visible part of the kernel on
+  // short vectors — dynamic problems, n = 2 M)
+  const double t = block_sum_many<NT, JT>(acc, lds);
+  if ((int)threadIdx.x < jn) partials[(size_t)blockIdx.x * k + j0 + threadIdx.x] = t;
 }
 
 // Two right-hand sides in one sweep over the basis: h[j] = V[j] . r and g[j] = V[j] . r2 (partials [bx][2k]).  What the
@@ -564,7 +563,7 @@ template <bool VEC>
 __global__ __launch_bounds__(NT) void k_gemv_t2(const float* __restrict__ V, int64_t ld, int k, int64_t n,
                                                 const float* __restrict__ r, const float* __restrict__ r2,
                                                 double* __restrict__ partials, int nt) {
-  __shared__ double lds[NT / 64];
+  __shared__ double lds[(NT / 64) * 2 * JT];
   const int j0 = blockIdx.y * JT;
   const int jn = (k - j0 < JT) ? (k - j0) : JT;
   double acc[JT], acc2[JT];
@@ -597,15 +596,15 @@ __global__ __launch_bounds__(NT) void k_gemv_t2(const float* __restrict__ V, int
         acc2[j] += v * sv;
       }
   }
+  double both[2 * JT];
 #pragma unroll
   for (int j = 0; j < JT; ++j) {
-    const double t = block_sum<NT>(acc[j], lds);
-    const double t2 = block_sum<NT>(acc2[j], lds);
-    if (threadIdx.x == 0 && j < jn) {
-      partials[(size_t)blockIdx.x * 2 * k + j0 + j] = t;
-      partials[(size_t)blockIdx.x * 2 * k + k + j0 + j] = t2;
-    }
+    both[j] = acc[j];
+    both[JT + j] = acc2[j];
   }
+  const double t = block_sum_many<NT, 2 * JT>(both, lds);      // value i in thread i
+  const int q = threadIdx.x / JT, j = threadIdx.x % JT;
+  if (threadIdx.x < 2 * JT && j < jn) partials[(size_t)blockIdx.x * 2 * k + (size_t)q * k + j0 + j] = t;
 }
 
 // The same with R right-hand sides (R = 3, 4): out[q k + j] = V[j] . rhs[q].  GKS rides the Gram rows of its NEXT basis vector on
@@ -617,7 +616,7 @@ struct RhsSet {
 template <bool VEC, int R>
 __global__ __launch_bounds__(NT) void k_gemv_tr(const float* __restrict__ V, int64_t ld, int k, int64_t n, RhsSet rhs,
                                                 double* __restrict__ partials, int nt) {
-  __shared__ double lds[NT / 64];
+  __shared__ double lds[(NT / 64) * R * JT];
   const int j0 = blockIdx.y * JT;
   const int jn = (k - j0 < JT) ? (k - j0) : JT;
   double acc[R][JT];
@@ -657,13 +656,14 @@ __global__ __launch_bounds__(NT) void k_gemv_tr(const float* __restrict__ V, int
         for (int q = 0; q < R; ++q) acc[q][j] += v * rv[q];
       }
   }
+  double all[R * JT];
 #pragma unroll
   for (int q = 0; q < R; ++q)
 #pragma unroll
-    for (int j = 0; j < JT; ++j) {
-      const double t = block_sum<NT>(acc[q][j], lds);
-      if (threadIdx.x == 0 && j < jn) partials[(size_t)blockIdx.x * R * k + (size_t)q * k + j0 + j] = t;
-    }
+    for (int j = 0; j < JT; ++j) all[q * JT + j] = acc[q][j];
+  const double t = block_sum_many<NT, R * JT>(all, lds);        // value i in thread i
+  const int q = threadIdx.x / JT, j = threadIdx.x % JT;
+  if (threadIdx.x < R * JT && j < jn) partials[(size_t)blockIdx.x * R * k + (size_t)q * k + j0 + j] = t;
 }
 
 int launch_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* w, int wpow, double* h,
