@@ -86,13 +86,14 @@ class DevScalars:
             # ~12 us per download, a tenth of a Hybrid-LSQR iteration at 512^2
             if self._mb is None:
                 import weakref
-                mb = ctypes.c_void_p()
-                _lib.check(eng.lib.trk_mailbox_create(self.t.numel(), self.MAILBOX_SLOTS, ctypes.byref(mb)), "trk_mailbox_create")
-                hp = ctypes.c_void_p()
-                _lib.check(eng.lib.trk_mailbox_host(mb, ctypes.byref(hp)), "trk_mailbox_host")
-                self._mb = mb
-                self._mb_np = np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ctypes.c_double)), shape=(self.t.numel(),))
-                weakref.finalize(self, eng.lib.trk_mailbox_destroy, mb)
+                # borrowed from the engine's pool and handed back when this block dies: pinned memory is never freed while the
+                # engine lives (hipHostFree synchronises the device and takes milliseconds — run by the garbage collector in the
+                # middle of somebody else's solve it cost the bench's C5 CGLS 85 ms)
+                cap = 64
+                while cap < self.t.numel():
+                    cap *= 2
+                self._mb, self._mb_np = eng._mailbox_take(cap, self.MAILBOX_SLOTS)
+                weakref.finalize(self, eng._mailbox_give, cap, self._mb, self._mb_np)
             slot = self._mb_slot
             self._mb_slot = (slot + 1) % self.MAILBOX_SLOTS
             _lib.check(eng.lib.trk_mailbox_post(self._mb, slot, self.base + 8 * i, int(i), int(j - i), eng.stream()), "trk_mailbox_post")
@@ -182,6 +183,21 @@ class HipEngine:
 
     def scalars(self, n):
         return DevScalars(torch.zeros(int(n), dtype=torch.float64, device=self.device), self)
+
+    def _mailbox_take(self, cap, slots):
+        """A trk_mailbox of `cap` doubles from the pool (created on demand), with the NumPy view of its pinned block."""
+        pool = self.__dict__.setdefault("_mailbox_pool", {})
+        free = pool.setdefault(cap, [])
+        if free:
+            return free.pop()
+        mb = ctypes.c_void_p()
+        _lib.check(self.lib.trk_mailbox_create(int(cap), int(slots), ctypes.byref(mb)), "trk_mailbox_create")
+        hp = ctypes.c_void_p()
+        _lib.check(self.lib.trk_mailbox_host(mb, ctypes.byref(hp)), "trk_mailbox_host")
+        return mb, np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ctypes.c_double)), shape=(int(cap),))
+
+    def _mailbox_give(self, cap, mb, view):
+        self.__dict__.setdefault("_mailbox_pool", {}).setdefault(cap, []).append((mb, view))
 
     def to_vec(self, a, n=None):
         """numpy / torch, shape (n,), (n,1) -> contiguous fp32 device vector (a copy unless already one)."""
