@@ -149,6 +149,58 @@ def _as_coef(a):
     return a if isinstance(a, Coef) else Coef(a)
 
 
+def host_cpu_budget():
+    """CPUs this process may actually use: its affinity mask, cut down to the cgroup's CPU quota (cpu.max / cfs_quota_us)."""
+    import math
+    import os
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:                                      # pragma: no cover
+        n = os.cpu_count() or 1
+    for quota_file, period_file in (("/sys/fs/cgroup/cpu.max", None),
+                                    ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "/sys/fs/cgroup/cpu/cpu.cfs_period_us")):
+        try:
+            if period_file is None:
+                q, p = open(quota_file).read().split()[:2]
+            else:
+                q, p = open(quota_file).read().strip(), open(period_file).read().strip()
+            if q not in ("max", "-1") and int(p) > 0:
+                n = min(n, max(1, math.ceil(int(q) / int(p))))
+            break
+        except (OSError, ValueError):
+            continue
+    return n
+
+
+_host_pools_checked = False
+
+
+def tame_host_thread_pools():
+    """Once per process: if the host thread pools (torch's intra-op pool, the BLAS behind NumPy) are larger than the CPU quota
+    of the container, shrink them to half of it.  Measured on the MI355X box (256 logical CPUs visible, cgroup quota 16 CPUs per
+    100 ms): any CPU-side tensor op or LAPACK call wakes a 128-thread pool whose idle spinning exhausts the quota, the kernel then
+    parks EVERY thread of the container until the period ends, and a solve that is enqueueing 5-us kernels stops for 70-95 ms
+    (four of twelve C5 solves in `tools/c5_stall_hunt3.py`; none with 8 threads).  TRK_KEEP_HOST_THREADS=1 leaves the pools alone."""
+    global _host_pools_checked
+    import os
+    if _host_pools_checked or os.environ.get("TRK_KEEP_HOST_THREADS"):
+        return
+    _host_pools_checked = True
+    budget = host_cpu_budget()
+    want = max(1, budget // 2)
+    try:
+        if torch.get_num_threads() > budget:
+            torch.set_num_threads(want)
+    except RuntimeError:                                        # pragma: no cover
+        pass
+    try:
+        from threadpoolctl import threadpool_info, threadpool_limits
+        if any(int(p.get("num_threads", 1)) > budget for p in threadpool_info()):
+            threadpool_limits(limits=want)                      # (called, not entered: stays in force)
+    except Exception:                                           # pragma: no cover  (threadpoolctl missing)
+        pass
+
+
 class HipEngine:
     """One per (device, communicator).  All methods enqueue on torch's current stream and return immediately."""
 
@@ -159,6 +211,7 @@ class HipEngine:
             raise _lib.TrkError("HipEngine needs a visible GPU (torch.cuda.is_available() is False); "
                                 "the engine has no CPU fallback")
         self.lib = _lib.load()
+        tame_host_thread_pools()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         if self.device.type != "cuda" or self._dev_index != torch.cuda.current_device():
