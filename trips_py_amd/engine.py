@@ -187,6 +187,11 @@ def tame_host_thread_pools():
         return
     _host_pools_checked = True
     budget = host_cpu_budget()
+    try:
+        ranks_here = max(1, int(os.environ.get("LOCAL_WORLD_SIZE", "1")))       # one process per GPU: the quota is shared
+    except ValueError:
+        ranks_here = 1
+    budget = max(1, budget // ranks_here)
     want = max(1, budget // 2)
     try:
         if torch.get_num_threads() > budget:
