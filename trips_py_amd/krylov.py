@@ -80,6 +80,7 @@ class GKState:
         self.native_axpby = bool(getattr(A, "native_axpby", False)) and not self.normalized
         self._chained = False                   # U[k] came out of this state's previous fused forward apply
         self._UB, self.uproj = None, None       # U^T b, one entry per row of U (step_prefetch(project=b))
+        self._late, self._posted_any = None, False   # step_prefetch: a step whose download waits for the next step
         m, n = A.shape
         eng = self.eng
         self.U = DeviceBasis(eng, m, capacity + 1)
@@ -106,6 +107,7 @@ class GKState:
         st.normalized = True
         st.native_axpby, st._chained = False, False
         st._UB, st.uproj = None, None
+        st._late, st._posted_any = None, False
         eng = A.engine
         m, n = A.shape
         k = len(alphas)
@@ -178,7 +180,7 @@ class GKState:
                 eng.dot(self.U[j], project, self._UB.ref(j))
             eng.allreduce(self._UB, j0, k + 2)
         started = []
-        late, self._late = getattr(self, "_late", None), None
+        late, self._late = self._late, None
         if late is not None:
             started.append(self._post_step(*late))       # the step before: its beta^2 was finished by this step's first kernel
         if more_follow:
@@ -188,7 +190,7 @@ class GKState:
         return started
 
     def _post_step(self, k, j0):
-        first = not getattr(self, "_posted_any", False)
+        first = not self._posted_any
         self._posted_any = True
         lo = 0 if first else 2 * k + 1
         extra = None if j0 is None else self._UB.host_later(j0, k + 2)
