@@ -8,13 +8,23 @@
 // (SOD sin t, -SOD cos t), the detector centre at (-ODD sin t, ODD cos t), detector axis (cos t, sin t); detector pixel d
 // is centred at (d - (p-1)/2) * pitch along it.  Sinogram (n_ang, n_det) row-major.
 //
-// Forward: one thread per ray, Amanatides-Woo grid traversal (<= 2N steps), lengths from successive crossings.
-// Adjoint: gather, one thread per pixel: for every angle the pixel's four corners are projected onto the detector, every
-// detector whose centre ray falls inside that interval is clipped against the pixel square (slab method) and contributes
-// length * sinogram value.  Same matrix as the forward traversal up to fp32 rounding of the lengths (no atomics).
+// Row-march form (source and detector both outside the image's circumscribed circle — the reference's geometry).  A ray is
+// STEEP (|dy| >= |dx|: it crosses every image row once) or shallow (every column once).  In index coordinates a steep ray is
+// X(Y) = X0 + Y M, |M| <= 1: inside row r it runs from Xa = X0 + r M to Xb = Xa + M, a segment of length len = sqrt(1 + M^2)
+// that touches one column, or two neighbouring ones split at the integer between Xa and Xb:
+//     cl = floor(min), ch = floor(max);  ch == cl: weight len on (r, cl);  else f = (ch - min) / |M|: len f on cl, len (1 - f) on ch.
+// (Shallow rays: the same with rows and columns exchanged.)  {X0, M, len, class} per ray is tabulated once per operator in
+// float64 (16 bytes per ray).  Lengths come out of pixel-sized quantities, not out of differences of ray parameters along a
+// ~4N-long segment as in a Siddon traversal: agreement with the brute-force float64 oracle 1e-6 instead of 1e-4.
+// Forward: one thread per ray marches the N rows (columns), two taps per step, shallow rays on a transposed copy of the image.
+// Adjoint: gather, one thread per pixel: per angle the detectors whose rays can touch the pixel (its centre's projection +- the
+// projected half diagonal) are looked up in the table and weighed BY THE FORWARD'S OWN EXPRESSIONS — the same floats, so the pair
+// is matched to summation order — no atomics.
+// General fallback (detector inside the circumscribed circle): the Siddon traversal / slab-clipping pair below, as before.
 #include "trk_internal.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <vector>
 
 using namespace trk;
@@ -28,12 +38,111 @@ struct FanAngle {
   float nx, ny;      // unit normal source -> detector centre
 };
 
+struct FanRay {      // row-march form of one ray (index coordinates; see the header)
+  float X0, M, len;
+  int shallow;       // 1: marches over columns (the roles of rows and columns exchanged)
+};
+
 struct FanImpl {
   int N, nd, na;
   float dsd;         // source-detector distance
   float pitch;
   FanAngle* ang_dev;
+  FanRay* rays;      // [na * nd], NULL: general fallback kernels
+  float* xT;         // transposed image (forward, shallow rays), owned by the handle
+  float reach;       // half width, in detector pixels per unit magnification, of the detector interval a pixel can touch
 };
+
+// one marching step of a ray: columns (rows) cl, cl + 1 and their weights as fractions of the segment length
+__device__ __forceinline__ void fan_step(float tt, float X0, float M, float inv_absM, int& cl, float& w0, float& w1) {
+  const float a = fmaf(tt, M, X0), b = a + M;
+  const float lo = fminf(a, b), hi = fmaxf(a, b);
+  const float fl = floorf(lo), fh = floorf(hi);
+  cl = (int)fl;
+  float f = fminf(fmaxf((fh - lo) * inv_absM, 0.f), 1.f);
+  f = (fh == fl) ? 1.f : f;
+  w0 = f;
+  w1 = 1.f - f;
+}
+
+__global__ __launch_bounds__(256) void k_fan_transpose(const float* __restrict__ in, int64_t ld_in, float* __restrict__ out, int N) {
+  __shared__ float tile[32][33];
+  in += (int64_t)blockIdx.z * ld_in;
+  out += (int64_t)blockIdx.z * N * N;
+  const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int k = ty; k < 32; k += 8)
+    if (by + k < N && bx + tx < N) tile[k][tx] = in[(int64_t)(by + k) * N + bx + tx];
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8)
+    if (bx + k < N && by + tx < N) out[(int64_t)(bx + k) * N + by + tx] = tile[tx][k];
+}
+
+__global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__ img, int64_t ld_img, const float* __restrict__ imgT,
+                                                       float* __restrict__ sino, int64_t ld_sino, int N, int64_t nrays,
+                                                       const FanRay* __restrict__ rays) {
+  const int64_t ray = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ray >= nrays) return;
+  const FanRay g = rays[ray];
+  const float* __restrict__ I = g.shallow ? imgT + (int64_t)blockIdx.y * N * N : img + (int64_t)blockIdx.y * ld_img;
+  const float inv_absM = 1.0f / fmaxf(fabsf(g.M), 1e-30f);
+  float acc = 0.f;
+  for (int t0 = 0; t0 < N; t0 += 8) {
+    float w0[8], w1[8], v0[8], v1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int tt = t0 + u;
+      int cl;
+      fan_step((float)tt, g.X0, g.M, inv_absM, cl, w0[u], w1[u]);
+      const bool row_ok = tt < N;
+      const bool ok0 = row_ok && (unsigned)cl < (unsigned)N, ok1 = row_ok && (unsigned)(cl + 1) < (unsigned)N;
+      const int64_t base = (int64_t)(row_ok ? tt : 0) * N;
+      v0[u] = I[base + (ok0 ? cl : 0)];
+      v1[u] = I[base + (ok1 ? cl + 1 : 0)];
+      w0[u] = ok0 ? w0[u] : 0.f;
+      w1[u] = ok1 ? w1[u] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = fmaf(w0[u], v0[u], fmaf(w1[u], v1[u], acc));
+  }
+  sino[(int64_t)blockIdx.y * ld_sino + ray] = g.len * acc;
+}
+
+__global__ __launch_bounds__(256) void k_fan_adj_march(const float* __restrict__ sino, int64_t ld_sino, float* __restrict__ img,
+                                                       int64_t ld_img, int N, int nd, int na, float dsd, float inv_pitch, float reach,
+                                                       const FanAngle* __restrict__ ang, const FanRay* __restrict__ rays) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)N * N) return;
+  const int r = (int)(idx / N), c = (int)(idx - (int64_t)r * N);
+  const float half = 0.5f * (float)N;
+  const float px = (float)c + 0.5f - half, py = half - (float)r - 0.5f;     // pixel centre
+  const float* __restrict__ S = sino + (int64_t)blockIdx.y * ld_sino;
+  float acc = 0.f;
+  for (int a = 0; a < na; ++a) {
+    const FanAngle g = ang[a];                                              // wave-uniform: scalar loads
+    // detector coordinate of the centre's projection, and how far to either side a ray can still touch the pixel
+    const float vx = px - g.sx, vy = py - g.sy;
+    const float mag = dsd / (vx * g.nx + vy * g.ny);
+    const float hx = g.sx + mag * vx - g.d0x, hy = g.sy + mag * vy - g.d0y;
+    const float uc = (hx * g.ux + hy * g.uy) * inv_pitch * inv_pitch;
+    const float w = fmaf(reach, mag, 0.01f);
+    int dlo = (int)ceilf(uc - w), dhi = (int)floorf(uc + w);
+    dlo = dlo < 0 ? 0 : dlo;
+    dhi = dhi > nd - 1 ? nd - 1 : dhi;
+    const float* __restrict__ Sa = S + (int64_t)a * nd;
+    const FanRay* __restrict__ Ra = rays + (int64_t)a * nd;
+    for (int d = dlo; d <= dhi; ++d) {
+      const FanRay q = Ra[d];
+      const int tt = q.shallow ? c : r, want = q.shallow ? r : c;          // marching index / the index the ray picks per step
+      int cl;
+      float w0, w1;
+      fan_step((float)tt, q.X0, q.M, 1.0f / fmaxf(fabsf(q.M), 1e-30f), cl, w0, w1);
+      const float wt = (want == cl) ? w0 : ((want == cl + 1) ? w1 : 0.f);
+      acc = fmaf(wt * q.len, Sa[d], acc);
+    }
+  }
+  img[(int64_t)blockIdx.y * ld_img + idx] = acc;
+}
+
 
 __global__ __launch_bounds__(256) void k_fan_fwd(const float* __restrict__ img, int64_t ld_img, float* __restrict__ sino,
                                                  int64_t ld_sino, int N, int nd, int na, const FanAngle* __restrict__ ang) {
@@ -145,9 +254,23 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
               hipStream_t s) {
   auto* im = static_cast<FanImpl*>(op->impl);
   TimerScope tm(op->timer, op->timer_which, tr, s);
-  if (!tr) {
+  static const bool siddon = getenv("TRK_FAN_SIDDON") != nullptr;       // the general pair, for comparison
+  const bool march = im->rays && !siddon;
+  if (!tr && march) {
+    const int nb = ceil_div(im->N, 32);
+    dim3 grid(ceil_div((int64_t)im->na * im->nd, 256), 1);
+    for (int b = 0; b < batch; ++b) {                                      // one transposed copy per handle: columns go one by one
+      hipLaunchKernelGGL(k_fan_transpose, dim3(nb, nb, 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->xT, im->N);
+      hipLaunchKernelGGL(k_fan_fwd_march, grid, dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->xT, y + (int64_t)b * ldy, ldy, im->N,
+                         (int64_t)im->na * im->nd, im->rays);
+    }
+  } else if (!tr) {
     dim3 grid(ceil_div((int64_t)im->na * im->nd, 256), batch);
     hipLaunchKernelGGL(k_fan_fwd, grid, dim3(256), 0, s, x, ldx, y, ldy, im->N, im->nd, im->na, im->ang_dev);
+  } else if (march) {
+    dim3 grid(ceil_div((int64_t)im->N * im->N, 256), batch);
+    hipLaunchKernelGGL(k_fan_adj_march, grid, dim3(256), 0, s, x, ldx, y, ldy, im->N, im->nd, im->na, im->dsd, 1.0f / im->pitch,
+                       im->reach, im->ang_dev, im->rays);
   } else {
     dim3 grid(ceil_div((int64_t)im->N * im->N, 256), batch);
     hipLaunchKernelGGL(k_fan_adj, grid, dim3(256), 0, s, x, ldx, y, ldy, im->N, im->nd, im->na, im->dsd, 1.0f / im->pitch, im->ang_dev);
@@ -165,6 +288,8 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
 void fan_destroy(trk_op* op) {
   auto* im = static_cast<FanImpl*>(op->impl);
   if (im->ang_dev) (void)hipFree(im->ang_dev);
+  if (im->rays) (void)hipFree(im->rays);
+  if (im->xT) (void)hipFree(im->xT);
   delete im;
 }
 
@@ -190,9 +315,42 @@ extern "C" int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double s
     g.ny = (float)(ct);
     h[a] = g;
   }
-  auto* im = new FanImpl{N, n_det, n_ang, (float)(sod + odd), (float)det_pitch, nullptr};
+  auto* im = new FanImpl{N, n_det, n_ang, (float)(sod + odd), (float)det_pitch, nullptr, nullptr, nullptr, 0.f};
   hipError_t e = hipMalloc(&im->ang_dev, sizeof(FanAngle) * n_ang);
   if (e == hipSuccess) e = hipMemcpy(im->ang_dev, h.data(), sizeof(FanAngle) * n_ang, hipMemcpyHostToDevice);
+  // row-march table: needs every ray to cross the whole image, i.e. source and detector outside its circumscribed circle
+  if (e == hipSuccess && odd > 0.7072 * N) {
+    const double half = 0.5 * N;
+    std::vector<FanRay> rt((size_t)n_ang * n_det);
+    for (int a = 0; a < n_ang; ++a) {
+      const double ct = std::cos(angles[a]), st = std::sin(angles[a]);
+      const double sx = sod * st, sy = -sod * ct;
+      for (int d = 0; d < n_det; ++d) {
+        const double off = (d - 0.5 * (n_det - 1)) * det_pitch;
+        const double dx = -odd * st + off * ct - sx, dy = odd * ct + off * st - sy;
+        FanRay q;
+        if (std::fabs(dy) >= std::fabs(dx)) {              // steep: X(Y) = X0 + Y M over rows Y = half - y
+          const double k = dx / dy;
+          q.X0 = (float)(sx + half + (half - sy) * k);
+          q.M = (float)(-k);
+          q.shallow = 0;
+        } else {                                           // shallow: Y(X) = Y0 + X My over columns X = x + half
+          const double k = dy / dx;
+          q.X0 = (float)(half - sy + (half + sx) * k);
+          q.M = (float)(-k);
+          q.shallow = 1;
+        }
+        q.len = (float)std::sqrt(1.0 + (double)q.M * (double)q.M);
+        rt[(size_t)a * n_det + d] = q;
+      }
+    }
+    e = hipMalloc(&im->rays, sizeof(FanRay) * rt.size());
+    if (e == hipSuccess) e = hipMemcpy(im->rays, rt.data(), sizeof(FanRay) * rt.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&im->xT, sizeof(float) * (size_t)N * N);
+    // a pixel's half diagonal seen from the source, on a flat detector: (sqrt(2)/2) mag / pitch / cos^2(fan half angle), plus slack
+    const double tan_max = 0.5 * n_det * det_pitch / (sod + odd);
+    im->reach = (float)(0.7072 / det_pitch * (1.0 + tan_max * tan_max) * 1.02);
+  }
   if (e != hipSuccess) {
     trk_op tmp{7, 0, 0, im, nullptr, nullptr, nullptr, 0};
     fan_destroy(&tmp);
