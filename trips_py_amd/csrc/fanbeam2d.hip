@@ -40,7 +40,7 @@ struct FanAngle {
 
 struct FanRay {      // row-march form of one ray (index coordinates; see the header)
   float X0, M, len;
-  int shallow;       // 1: marches over columns (the roles of rows and columns exchanged)
+  float inv;         // 1 / |M| (capped), NEGATIVE for a shallow ray: marches over columns (rows and columns exchanged)
 };
 
 struct FanImpl {
@@ -49,6 +49,7 @@ struct FanImpl {
   float pitch;
   FanAngle* ang_dev;
   FanRay* rays;      // [na * nd], NULL: general fallback kernels
+  FanRay* recs;      // [na * nd] per apply (adjoint): the same with len * sinogram value in place of len
   float* xT;         // transposed image (forward, shallow rays), owned by the handle
   float reach;       // half width, in detector pixels per unit magnification, of the detector interval a pixel can touch
 };
@@ -83,8 +84,8 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
   const int64_t ray = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (ray >= nrays) return;
   const FanRay g = rays[ray];
-  const float* __restrict__ I = g.shallow ? imgT + (int64_t)blockIdx.y * N * N : img + (int64_t)blockIdx.y * ld_img;
-  const float inv_absM = 1.0f / fmaxf(fabsf(g.M), 1e-30f);
+  const float* __restrict__ I = g.inv < 0.f ? imgT + (int64_t)blockIdx.y * N * N : img + (int64_t)blockIdx.y * ld_img;
+  const float inv_absM = fabsf(g.inv);
   float acc = 0.f;
   for (int t0 = 0; t0 < N; t0 += 8) {
     float w0[8], w1[8], v0[8], v1[8];
@@ -107,15 +108,24 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
   sino[(int64_t)blockIdx.y * ld_sino + ray] = g.len * acc;
 }
 
-__global__ __launch_bounds__(256) void k_fan_adj_march(const float* __restrict__ sino, int64_t ld_sino, float* __restrict__ img,
+// records of one apply: the ray table with len * S in place of len (one gather per candidate ray in the adjoint instead of two)
+__global__ __launch_bounds__(256) void k_fan_adj_prep(const float* __restrict__ sino, int64_t ld_sino, const FanRay* __restrict__ rays,
+                                                      FanRay* __restrict__ recs, int64_t nrays) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nrays) return;
+  FanRay q = rays[i];
+  q.len *= sino[(int64_t)blockIdx.y * ld_sino + i];
+  recs[(int64_t)blockIdx.y * nrays + i] = q;
+}
+
+__global__ __launch_bounds__(256) void k_fan_adj_march(float* __restrict__ img,
                                                        int64_t ld_img, int N, int nd, int na, float dsd, float inv_pitch, float reach,
-                                                       const FanAngle* __restrict__ ang, const FanRay* __restrict__ rays) {
+                                                       const FanAngle* __restrict__ ang, const FanRay* __restrict__ recs) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)N * N) return;
   const int r = (int)(idx / N), c = (int)(idx - (int64_t)r * N);
   const float half = 0.5f * (float)N;
   const float px = (float)c + 0.5f - half, py = half - (float)r - 0.5f;     // pixel centre
-  const float* __restrict__ S = sino + (int64_t)blockIdx.y * ld_sino;
   float acc = 0.f;
   for (int a = 0; a < na; ++a) {
     const FanAngle g = ang[a];                                              // wave-uniform: scalar loads
@@ -128,16 +138,16 @@ __global__ __launch_bounds__(256) void k_fan_adj_march(const float* __restrict__
     int dlo = (int)ceilf(uc - w), dhi = (int)floorf(uc + w);
     dlo = dlo < 0 ? 0 : dlo;
     dhi = dhi > nd - 1 ? nd - 1 : dhi;
-    const float* __restrict__ Sa = S + (int64_t)a * nd;
-    const FanRay* __restrict__ Ra = rays + (int64_t)a * nd;
+    const FanRay* __restrict__ Ra = recs + ((int64_t)blockIdx.y * na + a) * nd;
     for (int d = dlo; d <= dhi; ++d) {
-      const FanRay q = Ra[d];
-      const int tt = q.shallow ? c : r, want = q.shallow ? r : c;          // marching index / the index the ray picks per step
+      const FanRay q = Ra[d];                                              // one 16-byte gather: {X0, M, len * S[a][d], +-1/|M|}
+      const bool shallow = q.inv < 0.f;
+      const int tt = shallow ? c : r, want = shallow ? r : c;              // marching index / the index the ray picks per step
       int cl;
       float w0, w1;
-      fan_step((float)tt, q.X0, q.M, 1.0f / fmaxf(fabsf(q.M), 1e-30f), cl, w0, w1);
+      fan_step((float)tt, q.X0, q.M, fabsf(q.inv), cl, w0, w1);
       const float wt = (want == cl) ? w0 : ((want == cl + 1) ? w1 : 0.f);
-      acc = fmaf(wt * q.len, Sa[d], acc);
+      acc = fmaf(wt, q.len, acc);
     }
   }
   img[(int64_t)blockIdx.y * ld_img + idx] = acc;
@@ -268,9 +278,13 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
     dim3 grid(ceil_div((int64_t)im->na * im->nd, 256), batch);
     hipLaunchKernelGGL(k_fan_fwd, grid, dim3(256), 0, s, x, ldx, y, ldy, im->N, im->nd, im->na, im->ang_dev);
   } else if (march) {
-    dim3 grid(ceil_div((int64_t)im->N * im->N, 256), batch);
-    hipLaunchKernelGGL(k_fan_adj_march, grid, dim3(256), 0, s, x, ldx, y, ldy, im->N, im->nd, im->na, im->dsd, 1.0f / im->pitch,
-                       im->reach, im->ang_dev, im->rays);
+    const int64_t nrays = (int64_t)im->na * im->nd;
+    dim3 grid(ceil_div((int64_t)im->N * im->N, 256), 1);
+    for (int b = 0; b < batch; ++b) {                                      // one record array per handle: columns go one by one
+      hipLaunchKernelGGL(k_fan_adj_prep, dim3(ceil_div(nrays, 256), 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->rays, im->recs, nrays);
+      hipLaunchKernelGGL(k_fan_adj_march, grid, dim3(256), 0, s, y + (int64_t)b * ldy, ldy, im->N, im->nd, im->na, im->dsd,
+                         1.0f / im->pitch, im->reach, im->ang_dev, im->recs);
+    }
   } else {
     dim3 grid(ceil_div((int64_t)im->N * im->N, 256), batch);
     hipLaunchKernelGGL(k_fan_adj, grid, dim3(256), 0, s, x, ldx, y, ldy, im->N, im->nd, im->na, im->dsd, 1.0f / im->pitch, im->ang_dev);
@@ -289,6 +303,7 @@ void fan_destroy(trk_op* op) {
   auto* im = static_cast<FanImpl*>(op->impl);
   if (im->ang_dev) (void)hipFree(im->ang_dev);
   if (im->rays) (void)hipFree(im->rays);
+  if (im->recs) (void)hipFree(im->recs);
   if (im->xT) (void)hipFree(im->xT);
   delete im;
 }
@@ -315,7 +330,7 @@ extern "C" int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double s
     g.ny = (float)(ct);
     h[a] = g;
   }
-  auto* im = new FanImpl{N, n_det, n_ang, (float)(sod + odd), (float)det_pitch, nullptr, nullptr, nullptr, 0.f};
+  auto* im = new FanImpl{N, n_det, n_ang, (float)(sod + odd), (float)det_pitch, nullptr, nullptr, nullptr, nullptr, 0.f};
   hipError_t e = hipMalloc(&im->ang_dev, sizeof(FanAngle) * n_ang);
   if (e == hipSuccess) e = hipMemcpy(im->ang_dev, h.data(), sizeof(FanAngle) * n_ang, hipMemcpyHostToDevice);
   // row-march table: needs every ray to cross the whole image, i.e. source and detector outside its circumscribed circle
@@ -333,19 +348,21 @@ extern "C" int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double s
           const double k = dx / dy;
           q.X0 = (float)(sx + half + (half - sy) * k);
           q.M = (float)(-k);
-          q.shallow = 0;
+          q.inv = 1.0f;
         } else {                                           // shallow: Y(X) = Y0 + X My over columns X = x + half
           const double k = dy / dx;
           q.X0 = (float)(half - sy + (half + sx) * k);
           q.M = (float)(-k);
-          q.shallow = 1;
+          q.inv = -1.0f;
         }
+        q.inv *= 1.0f / std::fmax(std::fabs(q.M), 1e-30f);
         q.len = (float)std::sqrt(1.0 + (double)q.M * (double)q.M);
         rt[(size_t)a * n_det + d] = q;
       }
     }
     e = hipMalloc(&im->rays, sizeof(FanRay) * rt.size());
     if (e == hipSuccess) e = hipMemcpy(im->rays, rt.data(), sizeof(FanRay) * rt.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc(&im->recs, sizeof(FanRay) * rt.size());
     if (e == hipSuccess) e = hipMalloc(&im->xT, sizeof(float) * (size_t)N * N);
     // a pixel's half diagonal seen from the source, on a flat detector: (sqrt(2)/2) mag / pitch / cos^2(fan half angle), plus slack
     const double tan_max = 0.5 * n_det * det_pitch / (sod + odd);
