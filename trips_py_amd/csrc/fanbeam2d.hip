@@ -130,10 +130,12 @@ __global__ __launch_bounds__(256) void k_fan_adj_march(float* __restrict__ img,
   for (int a = 0; a < na; ++a) {
     const FanAngle g = ang[a];                                              // wave-uniform: scalar loads
     // detector coordinate of the centre's projection, and how far to either side a ray can still touch the pixel
+    // (only the candidate interval hangs on these numbers — every candidate is then weighed exactly — so the hardware reciprocal
+    // does: 1 ulp against the 2 % + 0.01 of slack in `reach`)
     const float vx = px - g.sx, vy = py - g.sy;
-    const float mag = dsd / (vx * g.nx + vy * g.ny);
-    const float hx = g.sx + mag * vx - g.d0x, hy = g.sy + mag * vy - g.d0y;
-    const float uc = (hx * g.ux + hy * g.uy) * inv_pitch * inv_pitch;
+    const float mag = dsd * __builtin_amdgcn_rcpf(fmaf(vx, g.nx, vy * g.ny));
+    const float hx = fmaf(mag, vx, g.sx - g.d0x), hy = fmaf(mag, vy, g.sy - g.d0y);
+    const float uc = fmaf(hx, g.ux, hy * g.uy) * (inv_pitch * inv_pitch);
     const float w = fmaf(reach, mag, 0.01f);
     int dlo = (int)ceilf(uc - w), dhi = (int)floorf(uc + w);
     dlo = dlo < 0 ? 0 : dlo;
