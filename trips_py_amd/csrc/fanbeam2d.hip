@@ -50,7 +50,7 @@ struct FanImpl {
   FanAngle* ang_dev;
   FanRay* rays;      // [na * nd], NULL: general fallback kernels
   FanRay* recs;      // [na * nd] per apply (adjoint): the same with len * sinogram value in place of len
-  float* xT;         // transposed image (forward, shallow rays), owned by the handle
+  float* xT;         // two padded copies of the image (forward: as it is / transposed), owned by the handle
   float reach;       // half width, in detector pixels per unit magnification, of the detector interval a pixel can touch
 };
 
@@ -66,46 +66,66 @@ __device__ __forceinline__ void fan_step(float tt, float X0, float M, float inv_
   w1 = 1.f - f;
 }
 
-__global__ __launch_bounds__(256) void k_fan_transpose(const float* __restrict__ in, int64_t ld_in, float* __restrict__ out, int N) {
+// Two padded copies of the image per forward apply, rows of N + 4 floats with two zero columns on either side: P0 as it is
+// (steep rays), P1 transposed (shallow rays).  A marching step then takes its two taps with ONE 8-byte load at column
+// clamp(cl, -2, N) + 2 and needs no range test: whatever lies outside the image reads zeros.
+constexpr int FAN_PAD = 2;
+__global__ __launch_bounds__(256) void k_fan_pad_copies(const float* __restrict__ in, int64_t ld_in, float* __restrict__ P0,
+                                                        float* __restrict__ P1, int N) {
   __shared__ float tile[32][33];
-  in += (int64_t)blockIdx.z * ld_in;
-  out += (int64_t)blockIdx.z * N * N;
+  const int W = N + 2 * FAN_PAD;
   const int bx = blockIdx.x * 32, by = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  for (int k = ty; k < 32; k += 8)
-    if (by + k < N && bx + tx < N) tile[k][tx] = in[(int64_t)(by + k) * N + bx + tx];
+  for (int k = ty; k < 32; k += 8) {
+    const bool ok = by + k < N && bx + tx < N;
+    const float v = ok ? in[(int64_t)(by + k) * N + bx + tx] : 0.f;
+    tile[k][tx] = v;
+    if (ok) P0[(int64_t)(by + k) * W + FAN_PAD + bx + tx] = v;
+  }
   __syncthreads();
   for (int k = ty; k < 32; k += 8)
-    if (bx + k < N && by + tx < N) out[(int64_t)(bx + k) * N + by + tx] = tile[tx][k];
+    if (bx + k < N && by + tx < N) P1[(int64_t)(bx + k) * W + FAN_PAD + by + tx] = tile[tx][k];
 }
 
-__global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__ img, int64_t ld_img, const float* __restrict__ imgT,
-                                                       float* __restrict__ sino, int64_t ld_sino, int N, int64_t nrays,
+typedef float fan_f2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__ P0, const float* __restrict__ P1,
+                                                       float* __restrict__ sino, int N, int64_t nrays,
                                                        const FanRay* __restrict__ rays) {
   const int64_t ray = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (ray >= nrays) return;
   const FanRay g = rays[ray];
-  const float* __restrict__ I = g.inv < 0.f ? imgT + (int64_t)blockIdx.y * N * N : img + (int64_t)blockIdx.y * ld_img;
+  const int W = N + 2 * FAN_PAD;
+  const float* __restrict__ I = (g.inv < 0.f ? P1 : P0) + FAN_PAD;
   const float inv_absM = fabsf(g.inv);
-  float acc = 0.f;
-  for (int t0 = 0; t0 < N; t0 += 8) {
-    float w0[8], w1[8], v0[8], v1[8];
+  float acc0 = 0.f, acc1 = 0.f;
+  int t0 = 0;
+  for (; t0 + 8 <= N; t0 += 8) {
+    float w0[8], w1[8];
+    fan_f2 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      const int tt = t0 + u;
       int cl;
-      fan_step((float)tt, g.X0, g.M, inv_absM, cl, w0[u], w1[u]);
-      const bool row_ok = tt < N;
-      const bool ok0 = row_ok && (unsigned)cl < (unsigned)N, ok1 = row_ok && (unsigned)(cl + 1) < (unsigned)N;
-      const int64_t base = (int64_t)(row_ok ? tt : 0) * N;
-      v0[u] = I[base + (ok0 ? cl : 0)];
-      v1[u] = I[base + (ok1 ? cl + 1 : 0)];
-      w0[u] = ok0 ? w0[u] : 0.f;
-      w1[u] = ok1 ? w1[u] : 0.f;
+      fan_step((float)(t0 + u), g.X0, g.M, inv_absM, cl, w0[u], w1[u]);
+      cl = cl < -FAN_PAD ? -FAN_PAD : (cl > N ? N : cl);
+      v[u] = *reinterpret_cast<const fan_f2*>(I + (int64_t)(t0 + u) * W + cl);      // 4-byte aligned 8-byte load
     }
 #pragma unroll
-    for (int u = 0; u < 8; ++u) acc = fmaf(w0[u], v0[u], fmaf(w1[u], v1[u], acc));
+    for (int u = 0; u < 8; ++u) {
+      const float a = v[u][0], b = v[u][1];
+      acc0 = fmaf(w0[u], a, acc0);
+      acc1 = fmaf(w1[u], b, acc1);
+    }
   }
-  sino[(int64_t)blockIdx.y * ld_sino + ray] = g.len * acc;
+  for (; t0 < N; ++t0) {
+    int cl;
+    float w0, w1;
+    fan_step((float)t0, g.X0, g.M, inv_absM, cl, w0, w1);
+    cl = cl < -FAN_PAD ? -FAN_PAD : (cl > N ? N : cl);
+    const float* q = I + (int64_t)t0 * W + cl;
+    acc0 = fmaf(w0, q[0], acc0);
+    acc1 = fmaf(w1, q[1], acc1);
+  }
+  sino[ray] = g.len * (acc0 + acc1);
 }
 
 // records of one apply: the ray table with len * S in place of len (one gather per candidate ray in the adjoint instead of two)
@@ -270,10 +290,11 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   const bool march = im->rays && !siddon;
   if (!tr && march) {
     const int nb = ceil_div(im->N, 32);
+    const int64_t padded = (int64_t)im->N * (im->N + 2 * FAN_PAD);
     dim3 grid(ceil_div((int64_t)im->na * im->nd, 256), 1);
-    for (int b = 0; b < batch; ++b) {                                      // one transposed copy per handle: columns go one by one
-      hipLaunchKernelGGL(k_fan_transpose, dim3(nb, nb, 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->xT, im->N);
-      hipLaunchKernelGGL(k_fan_fwd_march, grid, dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->xT, y + (int64_t)b * ldy, ldy, im->N,
+    for (int b = 0; b < batch; ++b) {                                      // one pair of padded copies per handle: columns go one by one
+      hipLaunchKernelGGL(k_fan_pad_copies, dim3(nb, nb, 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->xT, im->xT + padded, im->N);
+      hipLaunchKernelGGL(k_fan_fwd_march, grid, dim3(256), 0, s, im->xT, im->xT + padded, y + (int64_t)b * ldy, im->N,
                          (int64_t)im->na * im->nd, im->rays);
     }
   } else if (!tr) {
@@ -365,7 +386,9 @@ extern "C" int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double s
     e = hipMalloc(&im->rays, sizeof(FanRay) * rt.size());
     if (e == hipSuccess) e = hipMemcpy(im->rays, rt.data(), sizeof(FanRay) * rt.size(), hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc(&im->recs, sizeof(FanRay) * rt.size());
-    if (e == hipSuccess) e = hipMalloc(&im->xT, sizeof(float) * (size_t)N * N);
+    const size_t padded = (size_t)N * (N + 2 * FAN_PAD);                 // two padded copies; the pad columns stay zero for good
+    if (e == hipSuccess) e = hipMalloc(&im->xT, sizeof(float) * 2 * padded);
+    if (e == hipSuccess) e = hipMemset(im->xT, 0, sizeof(float) * 2 * padded);
     // a pixel's half diagonal seen from the source, on a flat detector: (sqrt(2)/2) mag / pitch / cos^2(fan half angle), plus slack
     const double tan_max = 0.5 * n_det * det_pitch / (sod + odd);
     im->reach = (float)(0.7072 / det_pitch * (1.0 + tan_max * tan_max) * 1.02);
