@@ -259,7 +259,7 @@ def test_framelet_operator_matches_reference():
         assert relerr(W.T @ g[f"y_{n}_{m}_{l}"], g[f"WTy_{n}_{m}_{l}"]) < 1e-6
 
 
-@pytest.mark.parametrize("N,na", [(16, 7), (34, 12), (50, 20)])
+@pytest.mark.parametrize("N,na", [(16, 7), (34, 12), (50, 20), (132, 24)])
 def test_fanbeam_vs_bruteforce_oracle(N, na):
     """Fan-beam line projector (parity unpinned vs ASTRA): the HIP traversal / gather kernels against the
     oracle's brute-force ray-pixel clipping, plus the geometry defaults of Tomography.define_proj_id."""
@@ -272,8 +272,8 @@ def test_fanbeam_vs_bruteforce_oracle(N, na):
     x, y = rng.random(N * N), rng.standard_normal(Ao.shape[0])
     f = lambda a: a.astype(np.float32).astype(np.float64)
     # N chosen so that p = int(sqrt(2) N) is even: no detector ray runs exactly along a pixel boundary (a measure-zero
-    # tie both implementations break arbitrarily).  Intersection lengths are fp32 differences of ray parameters over a
-    # ~4N-long segment: agreement 1e-4 relative (stated; the operator is parity-unpinned anyway).
+    # tie both implementations break arbitrarily).  Row-march form: lengths from pixel-sized quantities, 1e-5 (the Siddon pair
+    # below differences ray parameters over a ~4N-long segment: 1e-4).
     assert int(np.sqrt(2) * N) % 2 == 0
     assert relerr(A @ x, Ao @ f(x)) < 1e-5, relerr(A @ x, Ao @ f(x))
     assert relerr(A.T @ y, Ao.T @ f(y)) < 1e-5, relerr(A.T @ y, Ao.T @ f(y))
