@@ -452,3 +452,34 @@ def test_half_step_entry_point_serves_any_operator():
     assert torch.equal(got, want) and S.host(1, 2)[0] == S.host(2, 3)[0]
     with pytest.raises(ValueError):
         A.apply_axpby(x, 1.0, 1.0, z, x)
+
+
+@pytest.mark.parametrize("N,views", [(256, 90), (512, 180), (1000, 50)])
+def test_fanbeam_matched_pair_at_demo_sizes(N, views):
+    """Row-march fan-beam pair at the sizes the tomography demos use: <A x, y> = <x, A^T y> to fp32 summation error (the adjoint
+    weighs by the forward's own integers), every ray's weights sum to its chord through the image square (a constant image), and
+    the sinogram of a centred disc is the chord through the disc along every central ray."""
+    from trips_py_amd.operators import FanBeam2D
+    A = FanBeam2D(N, views=views)
+    eng = A.engine
+    g = torch.Generator(device=eng.device).manual_seed(N)
+    x = torch.randn(N * N, device=eng.device, generator=g)
+    y = torch.randn(A.shape[0], device=eng.device, generator=g)
+    Ax, ATy = A.apply(x), A.apply(y, transpose=True)
+    lhs, rhs = float(Ax.double() @ y.double()), float(x.double() @ ATy.double())
+    assert abs(lhs - rhs) <= 2e-6 * float(torch.linalg.norm(Ax.double()) * torch.linalg.norm(y.double())), (lhs, rhs)
+    ones = A.apply(torch.ones(N * N, device=eng.device)).double().cpu().numpy().reshape(views, A.n_det)
+    # chord of the ray source -> detector pixel centre through the square [-N/2, N/2]^2, in float64 on the host
+    th = A.angles[:, None]
+    off = (np.arange(A.n_det) - 0.5 * (A.n_det - 1))[None, :] * A.pitch
+    sx, sy = A.sod * np.sin(th), -A.sod * np.cos(th)
+    dx, dy = -A.odd * np.sin(th) + off * np.cos(th) - sx, A.odd * np.cos(th) + off * np.sin(th) - sy
+    h = 0.5 * N
+    with np.errstate(divide="ignore", invalid="ignore"):
+        tx0, tx1 = (-h - sx) / dx, (h - sx) / dx
+        ty0, ty1 = (-h - sy) / dy, (h - sy) / dy
+    t0 = np.maximum(np.minimum(tx0, tx1), np.minimum(ty0, ty1))
+    t1 = np.minimum(np.maximum(tx0, tx1), np.maximum(ty0, ty1))
+    chord = np.clip(t1 - t0, 0.0, None) * np.hypot(dx, dy)
+    assert np.abs(ones - chord).max() <= 2e-4 * N, np.abs(ones - chord).max()
+    assert relerr(ones, chord) < 1e-5
