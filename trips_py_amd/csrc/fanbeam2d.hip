@@ -80,13 +80,16 @@ __device__ __forceinline__ FanRayRegs fan_ray_regs(const FanRay& q) {
   r.inv_absm = __builtin_amdgcn_rcpf((float)(r.absm > 0 ? r.absm : 1));
   return r;
 }
-__device__ __forceinline__ void fan_step(int tt, const FanRayRegs& r, int& cl, float& w0, float& w1) {
-  const long long lo = r.x0 + (long long)tt * (long long)r.m + (long long)r.mneg;     // the smaller end of the step's interval
+// the step whose interval starts at `lo` (= X0 + tt M + min(M, 0), 64-bit fixed point)
+__device__ __forceinline__ void fan_step_at(long long lo, const FanRayRegs& r, int& cl, float& w0, float& w1) {
   cl = (int)(lo >> FAN_Q);
   const int dist = (1 << FAN_Q) - (int)((unsigned)lo & ((1u << FAN_Q) - 1u));         // to the next integer, in (0, 2^30]
   const float f = (r.absm >= dist) ? fminf((float)dist * r.inv_absm, 1.f) : 1.f;      // the interval reaches it: split there
   w0 = f;
   w1 = 1.f - f;
+}
+__device__ __forceinline__ void fan_step(int tt, const FanRayRegs& r, int& cl, float& w0, float& w1) {
+  fan_step_at(r.x0 + (long long)tt * (long long)r.m + (long long)r.mneg, r, cl, w0, w1);
 }
 
 // Two padded copies of the image per forward apply, rows of N + 4 floats with two zero columns on either side: P0 as it is
@@ -122,15 +125,19 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
   const float* __restrict__ I = (g.shallow ? P1 : P0) + FAN_PAD;
   float acc0 = 0.f, acc1 = 0.f;
   int t0 = 0;
+  long long pos = g.x0 + (long long)g.mneg;            // exact integers: stepping by M accumulates nothing (one 64-bit add per step
+  const float* __restrict__ row = I;                   // instead of a 64-bit multiply-add)
   for (; t0 + 8 <= N; t0 += 8) {
     float w0[8], w1[8];
     fan_f2 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       int cl;
-      fan_step(t0 + u, g, cl, w0[u], w1[u]);
+      fan_step_at(pos, g, cl, w0[u], w1[u]);
+      pos += g.m;
       cl = cl < -FAN_PAD ? -FAN_PAD : (cl > N ? N : cl);
-      v[u] = *reinterpret_cast<const fan_f2*>(I + (int64_t)(t0 + u) * W + cl);      // 4-byte aligned 8-byte load
+      v[u] = *reinterpret_cast<const fan_f2*>(row + cl);                             // 4-byte aligned 8-byte load
+      row += W;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
