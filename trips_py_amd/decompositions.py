@@ -15,7 +15,7 @@ import torch
 
 from ._io import as_operator
 from .engine import Coef
-from .krylov import ArnoldiState, DeviceBasis, GKState, orthogonalize
+from .krylov import ArnoldiState, DeviceBasis, GKState
 
 
 def _fmt_like(b):

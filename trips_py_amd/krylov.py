@@ -6,7 +6,6 @@ the next kernel through device-evaluated coefficients; the host reads them once 
 projected problem anyway).  Sharded problems all-reduce the same doubles (`engine.allreduce`).
 """
 import numpy as np
-import torch
 
 from .engine import Coef
 
