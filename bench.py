@@ -31,6 +31,11 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 EXTRAS_BUDGET_S = 420
+# The loop needs ~100 iterations (14 ms) from a cold start before its kernels run at their steady duration (tools/bench_ramp.py on
+# the MI355X box: forward blur 25.1-25.7 us over iterations 0-50, 24.8 over 50-100, 24.1 from 100 on, whatever idle time precedes;
+# profiles/r03/ramp_cold.txt).  `--steps 20 --warmup 5` alone therefore times the ramp, not the loop.  The run-in is untimed, stated
+# in the JSON line ("run_in_iters"), and part of neither `steps` nor `warmup`.
+RUN_IN_ITERS = 400
 HBM_PEAK_GBPS = 8000.0     # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
@@ -46,7 +51,29 @@ def parse():
     ap.add_argument("--fused", action="store_true", help="force the fused three-launch CGLS iteration")
     ap.add_argument("--no-extras", action="store_true", help="skip the C4 (MMGKS) and C5 (sharded dynamic tomo) legs")
     ap.add_argument("--cpu-iters", type=int, default=8, help="CPU-baseline sample: CGLS iterations timed on the host")
+    ap.add_argument("--run-in", type=int, default=RUN_IN_ITERS,
+                    help="untimed iterations of the same loop BEFORE the --warmup ones (clock / cache settling; stated in the line)")
     return ap.parse_args()
+
+
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT touching HIP / HSA (the parent must stay clean so that it can start its ranks as
+    children): KFD topology nodes with SIMDs (/sys/class/kfd/kfd/topology/nodes/*/properties, `simd_count` > 0 = a GPU node;
+    CPU nodes have 0), narrowed by a HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES list if one is set."""
+    import glob
+    n = 0
+    for f in glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties"):
+        try:
+            props = dict(line.split(None, 1) for line in open(f).read().splitlines() if " " in line)
+            n += int(props.get("simd_count", "0").strip()) > 0
+        except OSError:
+            pass
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            listed = len([t for t in v.split(",") if t.strip() != ""])
+            n = min(n, listed) if n else listed
+    return n
 
 
 def spawn_ranks_if_needed(args):
@@ -58,7 +85,7 @@ def spawn_ranks_if_needed(args):
     import socket
     import subprocess
     single = bool(os.environ.get("TRK_SINGLE_DEVICE"))
-    have = torch.cuda.device_count()                  # counts devices without initialising the runtime
+    have = visible_gpu_count()                        # sysfs / environment only: no HIP or HSA call in this process
     if have < args.gpus and not single:
         print(f"bench.py: --gpus {args.gpus} but only {have} GPU(s) are visible "
               "(TRK_SINGLE_DEVICE=1 TRK_DIST_BACKEND=gloo runs all ranks on one GPU for debugging)", file=sys.stderr)
@@ -205,6 +232,14 @@ def run_blur_cgls(args, rank, world, json_fd=1):
     tiled = not args.unfused and not args.fused and CGLSRunFused.tiled_usable(A, eng)      # small images (--size <= 1024)
     Run = CGLSRunFused if (fused or tiled) else CGLSRun
     # reference call without x_true (CGLS.py:16); norms deferred exactly as CGLS() does for tol = 0 on one rank
+    # run-in: a separate, untimed solve of the same problem with the same iteration form (see RUN_IN_ITERS)
+    RI = max(0, args.run_in)
+    if RI:
+        rin = Run(A, b, x0, RI, x_true=None, history=False, tiled=tiled) if (fused or tiled) else \
+            Run(A, b, x0, RI, x_true=None, history=False, defer_norms=True)
+        rin.run(RI)
+        torch.cuda.synchronize()
+        del rin
     run = Run(A, b, x0, W + K, x_true=None, history=False, tiled=tiled) if (fused or tiled) else \
         Run(A, b, x0, W + K, x_true=None, history=False, defer_norms=True)
     run.run(W)
@@ -245,12 +280,15 @@ def run_blur_cgls(args, rank, world, json_fd=1):
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": None if fused else load_traffic("k_blur_slide_fwd"),
                 "alg_bytes_per_launch": alg_bytes, "avg_kernel_us": round(t_kernel * 1e6, 2),
-                "min_kernel_us": round(float(np.min(ms_fwd)) * 1e3, 2), "launches_timed": int(len(ms_fwd)),
+                "min_kernel_us": round(float(np.min(ms_fwd)) * 1e3, 2),
+                "median_kernel_us": round(float(np.median(ms_fwd)) * 1e3, 2),
+                "p90_kernel_us": round(float(np.percentile(ms_fwd, 90)) * 1e3, 2),
+                "max_kernel_us": round(float(np.max(ms_fwd)) * 1e3, 2), "launches_timed": int(len(ms_fwd)),
                 "adjoint_matvec_avg_kernel_us": round(float(np.mean(ms_adj[2:])) * 1e3, 2),
                 "adjoint_matvec_GBps": round(8.0 * n / (float(np.mean(ms_adj[2:])) * 1e-3) / 1e9, 1)}
 
     res = {"metric": "krylov_iters_per_sec", "value": round(world * K / elapsed, 3), "unit": "iters/s",
-           "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(elapsed / K * 1e3, 4),
+           "n_gpus": world, "steps": K, "warmup": W, "run_in_iters": RI, "ms_per_step": round(elapsed / K * 1e3, 4),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"blur{N}_cgls", "image": f"{N}x{N} fp32", "psf": "Gaussian 9x9 sigma=(3,3), reflect",
                       "solver": "CGLS (trips.solvers.CGLS semantics, tol=0)", "noise": "1% Gaussian",
@@ -285,11 +323,12 @@ def run_blur_cgls(args, rank, world, json_fd=1):
         watchdog = threading.Timer(EXTRAS_BUDGET_S, give_up)
         watchdog.daemon = True
         watchdog.start()
+        cpu = rank == 0 and world == 1 and not args.no_cpu_baseline      # host baselines beside every config (rank 0, N = 1)
         for name, fn in (("trk_comm_rccl", lambda: extra_trk_comm(rank, world)),
-                         ("c2_blur512_cgls", lambda: extra_c2_blur512(world)),
-                         ("c3_tomo512_hybrid_lsqr", lambda: extra_c3_tomo(world)),
-                         ("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world)),
-                         ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world))):
+                         ("c2_blur512_cgls", lambda: extra_c2_blur512(world, cpu)),
+                         ("c3_tomo512_hybrid_lsqr", lambda: extra_c3_tomo(world, cpu)),
+                         ("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world, cpu, psf)),
+                         ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world, cpu))):
             try:
                 res["extra"][name] = fn()
             except Exception as exc:          # noqa: BLE001
@@ -326,6 +365,14 @@ def extra_trk_comm(rank, world):
             "allreduce_1double_us": round(us, 2), "ranks": world}
 
 
+def guarded(fn):
+    """A host baseline must never cost the GPU numbers their line."""
+    try:
+        return fn()
+    except Exception as exc:      # noqa: BLE001
+        return {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+
 class no_gc:
     """Timed regions of a few milliseconds run with the cyclic garbage collector off, as `timeit` does: a generation-2 pass over
     a process that holds a few thousand tensors is itself milliseconds."""
@@ -342,7 +389,7 @@ class no_gc:
         return False
 
 
-def extra_c2_blur512(world):
+def extra_c2_blur512(world, cpu=False):
     """BASELINE config C2: 2-D Gaussian blur 512^2 fp32, CGLS 100 iterations (the reference's own demo size; BASELINE.md §2
     measured the reference at 21.7 it/s on this problem).  Whole solves through the public CGLS() call, x_true given as in
     the demo (relError history on).  Replicas across ranks."""
@@ -366,11 +413,14 @@ def extra_c2_blur512(world):
             x, info = CGLS(A, b, x0, 100, 0, x_true=xt, history=False)
         barrier(world)
         dt = max_over_ranks(time.perf_counter() - t0, world)
-    return {"solver": "CGLS(max_iter=100, tol=0, x_true)", "iters_per_sec_all_ranks": round(world * reps * 100 / dt, 1),
-            "ms_per_solve": round(dt / reps * 1e3, 3), "relError_last": float(info["relError"][-1])}
+    out = {"solver": "CGLS(max_iter=100, tol=0, x_true)", "iters_per_sec_all_ranks": round(world * reps * 100 / dt, 1),
+           "ms_per_solve": round(dt / reps * 1e3, 3), "relError_last": float(info["relError"][-1])}
+    if cpu:
+        out["cpu_baseline"] = guarded(lambda: cpu_c2(gauss_psf((9, 9), (3, 3))[0], N, b))
+    return out
 
 
-def extra_c3_tomo(world):
+def extra_c3_tomo(world, cpu=False):
     """BASELINE config C3: parallel-beam tomography 512^2, 180 angles, Hybrid-LSQR 100 iterations (lambda = 1e-2), plus
     the Radon matvec rates.  The Radon operator is gather/ALU-bound, not HBM-bound: taps/s is the honest
     rate, algorithmic GB/s is reported for completeness.  Replicas across ranks."""
@@ -452,10 +502,12 @@ def extra_c3_tomo(world):
             dt = max_over_ranks(time.perf_counter() - t0, world)
         out[f"hybrid_lsqr{tag}_iters_per_sec_all_ranks"] = round(world * reps * 100 / dt, 1)
         out[f"hybrid_lsqr{tag}_relError_last"] = float(info["relError"][-1])
+    if cpu:
+        out["cpu_baseline"] = guarded(lambda: cpu_c3(Nt, np.linspace(0, np.pi, na, endpoint=False), bt))
     return out
 
 
-def extra_c4_mmgks(A, b, N, world):
+def extra_c4_mmgks(A, b, N, world, cpu=False, psf=None):
     """BASELINE config C4: blur 4096^2, MMGKS + TV (pnorm=2, qnorm=1, projection_dim=3, n_iter=30, lambda=1e-2).
     Replicas across ranks (a static image does not shard)."""
     from trips_py_amd.operators import FirstDerivative2D
@@ -476,7 +528,9 @@ def extra_c4_mmgks(A, b, N, world):
     alg = sum((24.0 * (3 + i) + 192.0) * n for i in range(its))
     alg_ref = sum((32.0 * (3 + i) + 192.0) * n for i in range(its))
     gbps = alg / dt / 1e9
-    return {"solver": "MMGKS(pnorm=2,qnorm=1,projection_dim=3,n_iter=30,regparam=1e-2,epsilon=0.1), L = 2-D first derivative",
+    cpu_part = {"cpu_baseline": guarded(lambda: cpu_c4(psf, N, b))} if cpu else {}
+    return {**cpu_part,
+            "solver": "MMGKS(pnorm=2,qnorm=1,projection_dim=3,n_iter=30,regparam=1e-2,epsilon=0.1), L = 2-D first derivative",
             "iters_per_sec_all_ranks": round(world * 30 / dt, 2), "seconds_per_solve": round(dt, 4), "its": its,
             "parallelism": "replicas" if world > 1 else "single",
             "roofline": {"bound": "hbm", "alg_bytes_per_iter_formula": "(24 k + 192) n, k = 3 + iteration index, n = 4096^2",
@@ -486,7 +540,7 @@ def extra_c4_mmgks(A, b, N, world):
                          "timed": "whole solve, wall clock incl. the host's projected problems"}}
 
 
-def extra_c5_dynamic(rank, world):
+def extra_c5_dynamic(rank, world, cpu=False):
     """BASELINE config C5 (dynamic parallel-beam tomography, 256^2 frames, 15 angles per frame shifted by 1 degree per
     frame, space-time derivative) at its BASELINE size: 32 frames in all, 32 / world per rank (STRONG scaling: the same
     problem at every N, also N = 1), global inner products all-reduced over RCCL, one-frame halo exchange for the temporal
@@ -537,7 +591,113 @@ def extra_c5_dynamic(rank, world):
         barrier(world)
         dt = max_over_ranks(time.perf_counter() - t0, world)
     out["gks_iters_per_sec"] = round(reps * 50 / dt, 1)
+    if cpu:
+        both = guarded(lambda: cpu_c5(Nf, [np.deg2rad(t + 12.0 * np.arange(na)) for t in range(nt)], bl, nt))
+        out["cgls_cpu_baseline"], out["gks_cpu_baseline"] = both if isinstance(both, tuple) else (both, both)
     return out
+
+
+def host_threads():
+    try:
+        from threadpoolctl import threadpool_info
+        return max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+    except Exception:      # noqa: BLE001
+        return None
+
+
+def cpu_iteration_rate(op, solve, sample_iters):
+    """Time `sample_iters` iterations of an ORACLE solver loop (oracle/cpu_ref.py: the reference's algorithm, float64, NumPy /
+    SciPy on this box's host cores — the reported baseline, never the thing measured).  Every solver loop of the path applies
+    A^T exactly once per iteration (CGLS.py:68, decompositions.py:235, GKS.py:82, MMGKS.py:117), so the applies of `op._adj` are
+    stamped: `solve` runs sample_iters + 1 iterations and the time between the last sample_iters + 1 stamps is sample_iters
+    whole iterations — set-up (start basis, first products) is outside, as on the GPU side where it is amortised over the solve."""
+    stamps = []
+    orig = op._adj
+
+    def stamped(y):
+        stamps.append(time.perf_counter())
+        return orig(y)
+
+    op._adj = stamped
+    try:
+        solve(sample_iters + 1)
+    finally:
+        op._adj = orig
+    assert len(stamps) >= sample_iters + 1, (len(stamps), sample_iters)
+    t = (stamps[-1] - stamps[-1 - sample_iters]) / sample_iters
+    return 1.0 / t, t
+
+
+def cpu_leg(value, t, sample, cores=1):
+    return {"value": round(value, 4), "unit": "iters/s", "cores": cores, "kind": "port", "seconds_per_iter": round(t, 4),
+            "sample": sample + f"; float64 oracle on the host (NumPy BLAS threads={host_threads()}, {os.cpu_count()} logical cores visible)"}
+
+
+def cpu_c2(psf, N, b_dev, sample=20):
+    """C2 on the host: the oracle's CGLS (CGLS.py:57-80) over scipy.ndimage.convolve (Deblurring2D.py:70-71), same b."""
+    from oracle import cpu_ref as O
+    Ao = O.Blur2D(psf, N, N)
+    bh = b_dev.detach().cpu().numpy().astype(np.float64).reshape(-1, 1)
+    v, t = cpu_iteration_rate(Ao, lambda k: O.cgls(Ao, bh, np.zeros((N * N, 1)), k, 0), sample)
+    return cpu_leg(v, t, f"{sample} CGLS iterations of the same {N}x{N} problem; scipy.ndimage.convolve is single-threaded")
+
+
+def cpu_c3(Nt, angles, b_dev, sample=8):
+    """C3 on the host: the oracle's Hybrid-LSQR (Hybrid_LSQR.py:73-110, lambda = 1e-2) over the oracle's Joseph projector held as a
+    scipy.sparse CSR matrix (ASTRA's CPU projector is not installable; matrix assembly is set-up, outside the sample)."""
+    from oracle import cpu_ref as O
+    Ro = O.Radon2D(Nt, angles)
+    Ro.matrix()
+    bh = b_dev.detach().cpu().numpy().astype(np.float64).reshape(-1, 1)
+    v, t = cpu_iteration_rate(Ro, lambda k: O.hybrid_lsqr(Ro, bh, k, 1e-2), sample)
+    return cpu_leg(v, t, f"iterations 2..{sample + 1} of Hybrid_LSQR(regparam=1e-2) on the same {Nt}x{Nt}, {len(angles)}-angle data "
+                         "(the reference's cost per iteration grows with the basis: V y, hstack copies); SpMV single-threaded")
+
+
+def cpu_c4(psf, N, b_dev):
+    """C4 on the host: the oracle's MMGKS (MMGKS.py:55-128: two economic QRs of the re-weighted m x k and p x k images per
+    iteration) on the same 4096^2 data — ONE iteration (tens of seconds), the first one (basis size 3; the GPU side's rate is the
+    mean over k = 3..32, and the reference's cost grows with k).  Set-up (Golub-Kahan start basis, A V, L V: MMGKS.py:37-44) is
+    outside the sample: A is applied 6 times there (3 Golub-Kahan steps, 3 columns of A V), so the 7th apply is `A @ x` at the top
+    of the first iteration (MMGKS.py:56) and the sample runs from there to the solver's return."""
+    from oracle import cpu_ref as O
+    Ao, Lo = O.Blur2D(psf, N, N), O.FirstDerivative2D(N)
+    bh = b_dev.detach().cpu().numpy().astype(np.float64).reshape(-1, 1)
+    stamps = []
+    orig = Ao._fwd
+
+    def stamped(x):
+        stamps.append(time.perf_counter())
+        return orig(x)
+
+    Ao._fwd = stamped
+    try:
+        O.mmgks(Ao, bh, Lo, 2, 1, 3, 1, 1e-2, epsilon=0.1)
+    finally:
+        Ao._fwd = orig
+    t_end = time.perf_counter()
+    assert len(stamps) == 8, len(stamps)          # 6 in the set-up, A @ x and A @ v_new in the iteration
+    t = t_end - stamps[6]
+    return cpu_leg(1.0 / t, t, f"the first iteration (basis size 3) of MMGKS(pnorm=2, qnorm=1, projection_dim=3, regparam=1e-2) on the "
+                               f"same {N}x{N} problem, set-up excluded; convolution single-threaded, QRs on the BLAS threads",
+                   cores=host_threads() or 1)
+
+
+def cpu_c5(Nf, angle_sets, b_dev, nt, sample_cgls=10, sample_gks=3):
+    """C5 on the host (all 32 frames, one process): the oracle's CGLS and GKS (GKS.py:42-96, space-time L) over the block-diagonal
+    Joseph projector as scipy.sparse matrices."""
+    from oracle import cpu_ref as O
+    Fo = O.BlockDiag([O.Radon2D(Nf, a) for a in angle_sets])
+    for o in Fo.ops:
+        o.matrix()
+    Lo = O.SpaceTimeDerivative(Nf, nt)
+    bh = b_dev.detach().cpu().numpy().astype(np.float64).reshape(-1, 1)
+    v1, t1 = cpu_iteration_rate(Fo, lambda k: O.cgls(Fo, bh, np.zeros((Fo.shape[1], 1)), k, 0), sample_cgls)
+    v2, t2 = cpu_iteration_rate(Fo, lambda k: O.gks(Fo, bh, Lo, 3, k, 1e-2), sample_gks)
+    what = f"the same {nt} x {Nf}x{Nf} data; SpMV single-threaded, QRs on the BLAS threads"
+    return (cpu_leg(v1, t1, f"{sample_cgls} CGLS iterations on " + what),
+            cpu_leg(v2, t2, f"iterations 2..{sample_gks + 1} (basis size 4..{sample_gks + 3}) of GKS(projection_dim=3, regparam=1e-2) on " + what,
+                    cores=host_threads() or 1))
 
 
 def cpu_baseline_cgls(psf, N, b_dev, iters):

@@ -158,7 +158,11 @@ def test_raw_partials_form_equals_finalized_form(N, grouping):
 
 
 @pytest.mark.parametrize("nx,ny,dim,spread", [(64, 64, (9, 9), (3, 3)), (96, 80, (9, 9), (3, 3)), (40, 100, (5, 5), (1, 2)),
-                                             (512, 512, (9, 9), (3, 3)), (17, 16, (3, 3), (1, 1)), (1000, 1000, (7, 7), (2, 2))])
+                                             (512, 512, (9, 9), (3, 3)), (17, 16, (3, 3), (1, 1)), (1000, 1000, (7, 7), (2, 2)),
+                                             # short axes where a partial last tile's halo loads fold past the far edge
+                                             # (n < (i0 + 40) / 2: the fold is clamped, cgls_tiled.hip refl())
+                                             (16, 16, (9, 9), (3, 3)), (19, 16, (9, 9), (3, 3)), (33, 20, (9, 9), (3, 3)),
+                                             (35, 36, (9, 9), (3, 3)), (36, 16, (5, 5), (1, 1))])
 def test_tiled_two_launch_cgls_equals_the_streaming_form(nx, ny, dim, spread):
     """trk_cgls_iterate_tiled (a workgroup per 32 x 32 tile recomputing its halo, two launches per iteration) against the
     four-launch streaming form on the same problem: sizes that are not multiples of the tile, non-square images, PSFs

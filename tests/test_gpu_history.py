@@ -43,8 +43,8 @@ def test_cgls_history_modes(spec, fused, tmp_path, monkeypatch):
     for j, k in enumerate(H.iterations):
         ref = ia["xHistory"][k].reshape(-1)
         got = H[j].reshape(-1)
-        got = got if isinstance(got, torch.Tensor) else torch.from_numpy(np.asarray(got, dtype=np.float32)).to(ref.device)
-        assert torch.equal(ref.float(), got.float()), (j, k)
+        assert isinstance(got, torch.Tensor) and got.dtype == torch.float32      # torch callers read tensors, whatever the sink
+        assert torch.equal(ref.float(), got.to(ref.device)), (j, k)
 
 
 @pytest.mark.parametrize("spec", [2, "host"])
@@ -65,3 +65,36 @@ def test_projection_solvers_history_modes(spec):
         for j, k in enumerate(H.iterations):
             assert np.array_equal(H[j], ia["xHistory"][k]), (name, j, k)
         assert len(H) == (len(ia["xHistory"]) if isinstance(spec, str) else len(H.iterations))
+
+
+@pytest.mark.parametrize("spec", [4, "file", 0, np.int64(1)])
+def test_history_of_a_solve_that_stops_early(spec, tmp_path):
+    """CGLS with tol > 0 stops before max_iter: a strided history still ends with the LAST iterate formed (it is not on the stride),
+    a .npy sink holds exactly the iterates that exist, and 0 / NumPy integers are accepted as strides (0 = False, 1 = True)."""
+    from trips_py_amd.solvers import CGLS
+    A, xt, b = _blur()
+    n = A.shape[1]
+    x0 = torch.zeros(n, device=b.device)
+    xa, ia = CGLS(A, b, x0, 200, 5e-4, xt)
+    its = int(ia["its"])
+    assert 6 < its < 200 and len(ia["xHistory"]) == its
+    path = str(tmp_path / "early.npy")
+    xb, ib = CGLS(A, b, x0, 200, 5e-4, xt, history=path if spec == "file" else spec)
+    assert torch.equal(xa, xb) and int(ib["its"]) == its
+    H = ib["xHistory"]
+    if isinstance(spec, (int, np.integer)) and spec == 0:
+        assert H == []
+    elif isinstance(spec, (int, np.integer)) and spec == 1:
+        assert len(H) == its and torch.equal(H[its - 1].reshape(-1), xa.reshape(-1))
+    elif spec == 4:
+        want = list(range(3, its, 4))
+        want += [] if want and want[-1] == its - 1 else [its - 1]
+        assert H.iterations == want
+        assert torch.equal(H[len(want) - 1].reshape(-1), xa.reshape(-1))
+        for j, k in enumerate(want):
+            assert torch.equal(H[j].reshape(-1), ia["xHistory"][k].reshape(-1))
+    else:
+        assert len(H) == its
+        on_disk = np.load(path)
+        assert on_disk.shape == (its, n) and on_disk.dtype == np.float32
+        assert np.array_equal(on_disk[its - 1], xa.reshape(-1).cpu().numpy())

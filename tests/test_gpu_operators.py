@@ -285,6 +285,33 @@ def test_fanbeam_vs_bruteforce_oracle(N, na):
     assert relerr(B @ x, Bo @ f(x)) < 1e-4 and relerr(B.T @ y[:Bo.shape[0]], Bo.T @ f(y[:Bo.shape[0]])) < 1e-4
 
 
+def test_fanbeam_against_the_astra_outputs_the_reference_holds():
+    """The demo problem itself (tectonic 32^2, 30 views, p = 45: demos/demo_Tomo_small_scale.ipynb) through the HIP projector:
+    against the decoded ASTRA sinogram / matrix images (rotation sense, detector order, layouts, boundary rays — see
+    tests/astra_demo_image.py) and against the oracle INCLUDING the rays that run along a pixel boundary (p odd, N even: the
+    central ray of views 0 and 15), which the image assigns to the larger column / row index."""
+    from astra_demo_image import check_against_demo_images
+    from conftest import load_golden
+    from oracle import cpu_ref as O
+    from trips_py_amd.problems import Tomography
+    g = load_golden("fanbeam_demo_image")
+    N, views = int(g["nx"]), int(g["views"])
+    A, _, A_mis = Tomography(CommitCrime=False).forward_Op(N, N, views)
+    x = g["phantom"].reshape(-1)
+    dense = A @ np.eye(N * N)
+    out = check_against_demo_images(g, A_mis @ x, dense)
+    assert out["sino_corr"] > 0.9998 and out["dense_corr"] > 0.98, out
+    Ao = O.FanBeam2D(N, np.linspace(0, np.pi, views, endpoint=False))
+    Mo = np.asarray(Ao.matrix().todense())
+    assert relerr(dense, Mo) < 1e-5, relerr(dense, Mo)
+    s = (A @ x).reshape(views, -1)
+    assert abs(s[0, 22] - g["phantom"][:, 16].sum()) < 1e-5 and abs(s[15, 22] - g["phantom"][16].sum()) < 1e-5
+    rng = np.random.default_rng(5)
+    xr, yr = rng.random(N * N), rng.standard_normal(Ao.shape[0])
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    assert relerr(A @ xr, Ao @ f(xr)) < 1e-5 and relerr(A.T @ yr, Ao.T @ f(yr)) < 1e-5
+
+
 def test_fanbeam_invariants_and_problem_class():
     from trips_py_amd.problems import Tomography
     N, views = 128, 45

@@ -331,3 +331,20 @@ def test_fanbeam_oracle_invariants():
     rng = np.random.default_rng(0)
     x, y = rng.standard_normal(N * N), rng.standard_normal(M.shape[0])
     assert abs(np.dot(A @ x, y) - np.dot(x, A.T @ y)) < 1e-12 * np.linalg.norm(x) * np.linalg.norm(y) * N
+
+
+def test_fanbeam_oracle_vs_the_astra_outputs_the_reference_holds():
+    """The only ASTRA outputs in the reference tree: the rendered fan-beam matrix `AA` and noisy sinogram `b` of the tectonic
+    32^2, 30-view demo (demos/demo_Tomo_small_scale.ipynb:145,179; geometry Tomography.py:53-88, phantom phantoms.py:67),
+    decoded into tests/golden/fanbeam_demo_image.npz.  They pin — to image precision — the rotation sense, the detector order,
+    the (views, detectors) sinogram layout, the row-major image, and the side a ray running along a pixel boundary belongs to."""
+    from astra_demo_image import check_against_demo_images
+    g = load_golden("fanbeam_demo_image")
+    assert np.abs(g["phantom"] * 255.0 - g["xtrue_grey"]).max() <= 1.0       # the phantom image is the phantom, as oriented
+    A = O.FanBeam2D(int(g["nx"]), np.linspace(0, np.pi, int(g["views"]), endpoint=False))
+    assert A.nd == int(g["n_det"])
+    out = check_against_demo_images(g, A @ g["phantom"].reshape(-1), np.asarray(A.matrix().todense()))
+    assert out["sino_corr"] > 0.9998 and out["dense_corr"] > 0.98, out
+    # view 0 / detector 22 runs along the boundary of pixel columns 15 | 16, view 15 / detector 22 along rows 15 | 16
+    s = (A @ g["phantom"].reshape(-1)).reshape(30, 45)
+    assert abs(s[0, 22] - g["phantom"][:, 16].sum()) < 1e-12 and abs(s[15, 22] - g["phantom"][16].sum()) < 1e-12

@@ -59,9 +59,10 @@ class HistoryView:
     rows of a host array or a memory-mapped .npy file, converted on access — the reference returns a list of such columns
     (CGLS.py:66, GKS.py:77) and the demos index it."""
 
-    def __init__(self, rows, iters=None):
+    def __init__(self, rows, iters=None, torch_out=False):
         self.rows = rows                     # [count, n] float32 (numpy array, np.memmap or torch tensor)
         self.iterations = list(range(len(rows))) if iters is None else list(iters)   # which iterates the rows are
+        self.torch_out = torch_out           # torch callers get (n,1) float32 host TENSORS from host / file rows, not NumPy
 
     def __len__(self):
         return len(self.rows)
@@ -72,6 +73,8 @@ class HistoryView:
         r = self.rows[k]
         if isinstance(r, torch.Tensor):
             return r.reshape(-1, 1)
+        if self.torch_out:
+            return torch.from_numpy(np.array(r, dtype=np.float32)).reshape(-1, 1)
         return np.asarray(r, dtype=np.float64).reshape(-1, 1)
 
     def __iter__(self):
@@ -82,28 +85,36 @@ class History:
     """Where a solver's iterates go (the reference keeps every one of them: CGLS.py:66, GKS.py:77, MMGKS.py:108 — 67 MB each at
     4096^2).  `spec` is the solvers' engine-only `history=` kwarg:
 
-        True            every iterate in an on-device [count, n] block, each written in place into its slot (default)
-        False           none (two scratch slots)
-        int s >= 2      every s-th iterate (s-1, 2s-1, ...) and the last one, on the device
+        True / 1        every iterate in an on-device [count, n] block, each written in place into its slot (default)
+        False / 0 / None  none (two scratch slots)
+        int s >= 2      every s-th iterate (s-1, 2s-1, ...) and the last one the solver formed (also when it stopped early), on
+                        the device
         "host"          every iterate, streamed to host memory while the solver runs ahead: the device holds a ring of
                         `ring` slots only
-        "<path>.npy"    the same, into a memory-mapped .npy file of shape [count, n] float32 (np.load(path, mmap_mode='r'))
+        "<path>.npy"    the same, into a memory-mapped .npy file of shape [count, n] float32 (np.load(path, mmap_mode='r')); a
+                        solver that stops early leaves a file of exactly the iterates it formed (header and length rewritten)
+
+    NumPy callers read (n,1) float64 columns from a streamed history, torch callers (n,1) float32 tensors (host memory for
+    "host" / file, the device for a stride).
 
     Protocol: `row(k)` = the device vector iterate k is to be written into (call it right before enqueuing the kernels that
     write it), `pushed(k)` once they are enqueued, `collect(fmt, count)` at the end."""
 
     def __init__(self, eng, spec, count, n, what, ring=None):
         self.eng, self.count, self.n = eng, int(count), int(n)
+        if isinstance(spec, (np.bool_, np.integer)):
+            spec = spec.item()                    # NumPy scalars as their Python counterparts
         self.mode = "device" if spec is True else "none" if (spec is False or spec is None) else None
         self.stride = 0
         self.dest = None
         self._events = None
+        self._path = None
         if isinstance(spec, bool) or spec is None:
             pass
         elif isinstance(spec, int):
-            if spec < 1:
-                raise ValueError("history=<int>: the stride must be >= 1")
-            self.mode, self.stride = ("device", 0) if spec == 1 else ("stream", int(spec))
+            if spec < 0:
+                raise ValueError("history=<int>: the stride must be >= 0 (0 = keep nothing, 1 = keep everything)")
+            self.mode, self.stride = ("none", 0) if spec == 0 else ("device", 0) if spec == 1 else ("stream", int(spec))
         elif isinstance(spec, str):
             self.mode = "stream"
         else:
@@ -122,8 +133,8 @@ class History:
             self.X = eng.empty_basis(self.R, n)
             if self.stride:                       # kept iterates: s-1, 2s-1, ... and the last one
                 self.kept = sorted(set(list(range(self.stride - 1, self.count, self.stride)) + [self.count - 1]))
-                history_fits(eng, len(self.kept), n, what)
-                self.dest = eng.empty_basis(len(self.kept), n)
+                history_fits(eng, len(self.kept) + 1, n, what)
+                self.dest = eng.empty_basis(len(self.kept) + 1, n)      # + a spare row: the last iterate of an early stop
                 self._index = {k: i for i, k in enumerate(self.kept)}
             else:
                 self.kept = list(range(self.count))
@@ -132,6 +143,7 @@ class History:
                     self.dest = np.empty((self.count, self.n), dtype=np.float32)
                 elif spec.endswith(".npy"):
                     self.dest = np.lib.format.open_memmap(spec, mode="w+", dtype=np.float32, shape=(self.count, self.n))
+                    self._path = spec
                 else:
                     raise ValueError(f"history={spec!r}: expected 'host' or a path ending in .npy")
                 # pinned staging rows, one per ring slot; the copy engine fills them, the host drains them into `dest`
@@ -193,12 +205,35 @@ class History:
             return fmt.hist(self.X, count)
         if self._index is not None:
             idx = [i for i, k in enumerate(self.kept) if k < count]
-            if count - 1 not in self._index and count >= 1:      # a solver that stopped early: its last iterate is still in the ring
-                pass
-            rows = self.dest[:len(idx)]
-            return HistoryView(rows.detach().to("cpu").numpy() if fmt.numpy else rows, [self.kept[i] for i in idx])
+            iters = [self.kept[i] for i in idx]
+            if count >= 1 and count - 1 not in self._index:
+                # a solver that stopped early (CGLS tol > 0, MMGKS break): its last iterate is not on the stride, but it is still
+                # in its ring slot — nothing was written after it — and goes into the row behind the kept ones
+                self.dest[len(idx)].copy_(self.X[(count - 1) % self.R])
+                iters.append(count - 1)
+            rows = self.dest[:len(iters)]
+            return HistoryView(rows.detach().to("cpu").numpy() if fmt.numpy else rows, iters)
         while self._pending:
             self._drain_one()
         if isinstance(self.dest, np.memmap):
             self.dest.flush()
-        return HistoryView(self.dest[:count])
+            if count < self.count:                # early stop: the file holds exactly the iterates that exist
+                self.dest = None
+                _truncate_npy(self._path, count, self.n)
+                self.dest = np.load(self._path, mmap_mode="r+") if count else np.empty((0, self.n), dtype=np.float32)
+        return HistoryView(self.dest[:count], torch_out=not fmt.numpy)
+
+
+def _truncate_npy(path, rows, n):
+    """Shrink a [count, n] float32 .npy file to its first `rows` rows in place: same header length (the shape's text only gets
+    shorter; the padding absorbs it), the data cut behind the last kept row."""
+    with open(path, "r+b") as f:
+        version = np.lib.format.read_magic(f)
+        size = 2 if version == (1, 0) else 4
+        hlen = int.from_bytes(f.read(size), "little")
+        start = f.tell()
+        txt = "{'descr': '<f4', 'fortran_order': False, 'shape': (%d, %d), }" % (rows, n)
+        if len(txt) + 1 > hlen:
+            raise ValueError(f"{path}: header too short to rewrite")
+        f.write((txt + " " * (hlen - len(txt) - 1) + "\n").encode("latin1"))
+        f.truncate(start + hlen + rows * n * 4)

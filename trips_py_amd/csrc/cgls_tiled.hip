@@ -38,9 +38,13 @@ struct TiledGeom {
   float rwf[9], cwf[9], rwt[9], cwt[9];     // centred 9-tap row / column weights: forward and "transpose" (flipped PSF)
 };
 
-// half-sample symmetric reflection for an overshoot of at most 8 on an axis of at least 16: one fold, no division
+// half-sample symmetric reflection: one fold, no division — exact for an overshoot of at most n (any position a blur of an
+// in-image pixel reads: overshoot <= 8 on axes >= 16).  A partial last tile also LOADS positions up to 39 past its origin, i.e.
+// further out than n on short axes (n < (i0 + 40) / 2: 16..19, 33..35); those cells only ever feed out-of-image LDS cells, but
+// the address must stay inside the buffer, so the folded index is clamped.
 __device__ __forceinline__ int refl(int i, int n) {
-  return i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
+  const int f = i < 0 ? -1 - i : (i >= n ? 2 * n - 1 - i : i);
+  return min(max(f, 0), n - 1);
 }
 
 // out[R][C] (row stride so) = separable 9 x 9 correlation of in[R + 8][C + 8] (row stride si, a multiple of 4: rows are

@@ -13,6 +13,7 @@
 
 #include <dlfcn.h>
 
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 
@@ -43,6 +44,7 @@ struct Rccl {
 Rccl g_rccl;
 std::once_flag g_once;
 bool g_ok = false;
+char g_why[256] = "no such library";      // why loading failed: dlerror() is cleared by reading it, so it is saved once, here
 
 void load_rccl() {
   // a copy that is already in the process (PyTorch's) first; then the system's
@@ -51,8 +53,10 @@ void load_rccl() {
   for (const char* n : names)
     if ((h = dlopen(n, RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL))) break;
   if (!h)
-    for (const char* n : names)
+    for (const char* n : names) {
       if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+      if (const char* e = dlerror()) std::snprintf(g_why, sizeof(g_why), "%s", e);      // the last real attempt's message
+    }
   if (!h) return;
   g_rccl.lib = h;
 #define SYM(field, name) *(void**)(&g_rccl.field) = dlsym(h, name)
@@ -68,12 +72,12 @@ void load_rccl() {
 #undef SYM
   g_ok = g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.CommDestroy && g_rccl.AllReduce && g_rccl.Send && g_rccl.Recv &&
          g_rccl.GroupStart && g_rccl.GroupEnd;
+  if (!g_ok) std::snprintf(g_why, sizeof(g_why), "the library lacks part of the NCCL 2 API");
 }
 
 int need_rccl() {
   std::call_once(g_once, load_rccl);
-  if (!g_ok) return fail(TRK_ENCCL, "RCCL is not available (librccl.so could not be loaded or lacks the NCCL 2 API): %s",
-                         dlerror() ? dlerror() : "no such library");
+  if (!g_ok) return fail(TRK_ENCCL, "RCCL is not available (librccl.so could not be loaded or lacks the NCCL 2 API): %s", g_why);
   return TRK_OK;
 }
 
@@ -130,14 +134,17 @@ int trk_comm_info(const trk_comm* c, int* rank, int* world) {
 
 int trk_comm_destroy(trk_comm* c) {
   if (!c) return TRK_OK;
-  if (c->owned && g_ok) (void)g_rccl.CommDestroy(c->comm);
-  delete c;
+  ncclResult_t r = ncclSuccess;
+  if (c->owned && g_ok) r = g_rccl.CommDestroy(c->comm);
+  delete c;                                   // the handle is gone either way; the result of the teardown is reported
+  if (r != ncclSuccess)
+    return fail(TRK_ENCCL, "ncclCommDestroy -> %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "RCCL error");
   return TRK_OK;
 }
 
 int trk_allreduce_f64(trk_comm* c, double* dev, int count, trk_stream st) {
   TRK_REQUIRE(c && dev && count >= 0, "trk_allreduce_f64: bad argument");
-  if (count == 0) return TRK_OK;
+  if (count == 0 || c->world == 1) return TRK_OK;      // one rank: the sum over ranks is the value itself — no RCCL call (trk.h)
   TRK_NCCL(g_rccl.AllReduce(dev, dev, (size_t)count, ncclFloat64, ncclSum, c->comm, (hipStream_t)st));
   return TRK_OK;
 }
@@ -147,9 +154,25 @@ int trk_halo_exchange(trk_comm* c, const float* send, int send_to, float* recv, 
   const bool do_send = send && send_to >= 0 && send_to < c->world, do_recv = recv && recv_from >= 0 && recv_from < c->world;
   if (count == 0 || (!do_send && !do_recv)) return TRK_OK;
   TRK_NCCL(g_rccl.GroupStart());
-  if (do_send) TRK_NCCL(g_rccl.Send(send, (size_t)count, ncclFloat32, send_to, c->comm, (hipStream_t)st));
-  if (do_recv) TRK_NCCL(g_rccl.Recv(recv, (size_t)count, ncclFloat32, recv_from, c->comm, (hipStream_t)st));
-  TRK_NCCL(g_rccl.GroupEnd());
+  // an error inside the group must not leave it open for every later collective of the process: the group is always ended, and
+  // the FIRST failure is the one reported
+  ncclResult_t first = ncclSuccess;
+  const char* what = "";
+  if (do_send) {
+    first = g_rccl.Send(send, (size_t)count, ncclFloat32, send_to, c->comm, (hipStream_t)st);
+    what = "ncclSend";
+  }
+  if (do_recv && first == ncclSuccess) {
+    first = g_rccl.Recv(recv, (size_t)count, ncclFloat32, recv_from, c->comm, (hipStream_t)st);
+    what = "ncclRecv";
+  }
+  const ncclResult_t end = g_rccl.GroupEnd();
+  if (first == ncclSuccess && end != ncclSuccess) {
+    first = end;
+    what = "ncclGroupEnd";
+  }
+  if (first != ncclSuccess)
+    return fail(TRK_ENCCL, "trk_halo_exchange: %s -> %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(first) : "RCCL error");
   return TRK_OK;
 }
 

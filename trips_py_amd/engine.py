@@ -97,7 +97,7 @@ class DevScalars:
             slot = self._mb_slot
             self._mb_slot = (slot + 1) % self.MAILBOX_SLOTS
             _lib.check(eng.lib.trk_mailbox_post(self._mb, slot, self.base + 8 * i, int(i), int(j - i), eng.stream()), "trk_mailbox_post")
-            return _Posted(eng.lib, self._mb, slot, self._mb_np, i, j)
+            return _Posted(eng.lib, self._mb, slot, self._mb_np, i, j, self)
         if self._pin is None:
             self._pin = torch.empty(self.t.numel(), dtype=torch.float64, pin_memory=True)
         self._pin[i:j].copy_(self.t[i:j], non_blocking=True)
@@ -124,10 +124,12 @@ class DevScalars:
 
 
 class _Posted:
-    __slots__ = ("lib", "mb", "slot", "host", "i", "j")
+    # `owner`: the DevScalars whose mailbox this handle reads — kept alive, so that the mailbox cannot go back to the engine's pool
+    # (and be handed to another block) while a posted download is still to be collected
+    __slots__ = ("lib", "mb", "slot", "host", "i", "j", "owner")
 
-    def __init__(self, lib, mb, slot, host, i, j):
-        self.lib, self.mb, self.slot, self.host, self.i, self.j = lib, mb, slot, host, i, j
+    def __init__(self, lib, mb, slot, host, i, j, owner=None):
+        self.lib, self.mb, self.slot, self.host, self.i, self.j, self.owner = lib, mb, slot, host, i, j, owner
 
     def get(self):
         _lib.check(self.lib.trk_mailbox_wait(self.mb, self.slot), "trk_mailbox_wait")
@@ -193,17 +195,27 @@ def tame_host_thread_pools():
         ranks_here = 1
     budget = max(1, budget // ranks_here)
     want = max(1, budget // 2)
+    changed = []
     try:
         if torch.get_num_threads() > budget:
+            changed.append(f"torch intra-op threads {torch.get_num_threads()} -> {want}")
             torch.set_num_threads(want)
     except RuntimeError:                                        # pragma: no cover
         pass
     try:
         from threadpoolctl import threadpool_info, threadpool_limits
-        if any(int(p.get("num_threads", 1)) > budget for p in threadpool_info()):
+        big = [p for p in threadpool_info() if int(p.get("num_threads", 1)) > budget]
+        if big:
+            changed += [f"{p.get('internal_api', p.get('user_api', 'pool'))} threads {p.get('num_threads')} -> {want}" for p in big]
             threadpool_limits(limits=want)                      # (called, not entered: stays in force)
     except Exception:                                           # pragma: no cover  (threadpoolctl missing)
         pass
+    if changed:
+        # a library changing process-wide state says so, once
+        import sys
+        print(f"[trips_py_amd] host thread pools exceed this process's CPU budget ({budget} CPUs: affinity / cgroup quota"
+              f"{', shared by ' + str(ranks_here) + ' local ranks' if ranks_here > 1 else ''}); shrunk for the life of the process: "
+              + "; ".join(changed) + ".  TRK_KEEP_HOST_THREADS=1 leaves them alone (DESIGN.md 6.1).", file=sys.stderr)
 
 
 class HipEngine:
@@ -254,8 +266,17 @@ class HipEngine:
         _lib.check(self.lib.trk_mailbox_host(mb, ctypes.byref(hp)), "trk_mailbox_host")
         return mb, np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ctypes.c_double)), shape=(int(cap),))
 
+    MAILBOX_POOL_MAX = 32          # free mailboxes kept per size (a solver holds 1-3 at a time): beyond that they are destroyed
+
     def _mailbox_give(self, cap, mb, view):
-        self.__dict__.setdefault("_mailbox_pool", {}).setdefault(cap, []).append((mb, view))
+        free = self.__dict__.setdefault("_mailbox_pool", {}).setdefault(cap, [])
+        if len(free) < self.MAILBOX_POOL_MAX:
+            free.append((mb, view))
+        else:                          # bounded pinned memory: pays the hipHostFree the pool exists to avoid, in pathological use only
+            try:
+                self.lib.trk_mailbox_destroy(mb)
+            except Exception:          # noqa: BLE001  (interpreter shutdown)
+                pass
 
     def to_vec(self, a, n=None):
         """numpy / torch, shape (n,), (n,1) -> contiguous fp32 device vector (a copy unless already one)."""
