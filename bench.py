@@ -362,7 +362,9 @@ def extra_trk_comm(rank, world):
     torch.cuda.synchronize()
     us = (time.perf_counter() - t0) / 100 * 1e6
     return {"allreduce_sum": total, "allreduce_expected": world * (world + 1) / 2.0, "halo_shift_ok": ok,
-            "allreduce_1double_us": round(us, 2), "ranks": world}
+            "allreduce_1double_us": round(us, 2), "ranks": world,
+            "note": ("one rank: trk_allreduce_f64 is a no-op by contract; this probe runs with TRK_COMM_FORCE=1 so that the call "
+                     "goes through RCCL all the same" if world == 1 else "trk_allreduce_f64 over RCCL, enqueue + device time per call")}
 
 
 def guarded(fn):
@@ -553,7 +555,23 @@ def extra_c5_dynamic(rank, world, cpu=False):
     if nt % world:
         return {"skipped": f"32 frames do not divide over {world} ranks"}
     per_rank = nt // world
-    eng = HipEngine(comm=TorchComm()) if world > 1 else HipEngine()
+    # world > 1 over RCCL: libtrk's own communicator (trk_allreduce_f64: the sharded CGLS enqueues its all-reduces from C, no
+    # Python dispatch per scalar); torch's if that cannot be created, or for the gloo debugging backend
+    comm_kind = None
+    if world > 1:
+        import torch.distributed as dist
+        comm = None
+        if dist.get_backend() == "nccl" and os.environ.get("TRK_COMM", "rccl") == "rccl":
+            try:
+                from trips_py_amd.dist import RcclComm
+                comm, comm_kind = RcclComm(), "libtrk RCCL communicator (trk_comm_init / trk_allreduce_f64 / trk_halo_exchange)"
+            except Exception as exc:      # noqa: BLE001
+                comm_kind = f"torch.distributed ({type(exc).__name__} from trk_comm_init: {exc})"[:200]
+        if comm is None:
+            comm, comm_kind = TorchComm(), comm_kind or f"torch.distributed ({dist.get_backend()})"
+        eng = HipEngine(comm=comm)
+    else:
+        eng = HipEngine()
     lo, hi = frame_range(nt, world, rank)
     ops = [Radon2DParallel(Nf, np.deg2rad(t + 12.0 * np.arange(na)), engine=eng) for t in range(lo, hi)]
     F = BlockDiagOp(ops, engine=eng)
@@ -571,17 +589,30 @@ def extra_c5_dynamic(rank, world, cpu=False):
     bl = bl + e * (0.01 * torch.linalg.norm(bl) / torch.linalg.norm(e))
     x0 = torch.zeros(F.shape[1], device=eng.device)
     out = {"frames_total": nt, "frames_per_rank": per_rank, "frame": f"{Nf}x{Nf}", "angles_per_frame": na,
-           "scaling": "strong", "ranks": world}
-    CGLS(F, bl, x0, 100, 0, history=False)                   # warm-up: a whole solve of the timed size, as C2 / C3
-    barrier(world)
+           "scaling": "strong", "ranks": world, "communicator": comm_kind}
     reps = 3
-    with no_gc():
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            CGLS(F, bl, x0, 100, 0, history=False)
+    # CGLS in the arrangement CGLS() picks (ranks > 1: ONE all-reduce per iteration, csrc/cgls_sharded.hip; one rank: the
+    # recurrence as written, nothing to exchange) and, beside it, the other one.  "reduction_points_per_iteration" = calls of the
+    # engine's all-reduce per iteration, counted on one rank as well (there they move nothing)
+    default_one = world > 1
+    for key, kw in (("cgls", {}), ("cgls_one_reduction" if not default_one else "cgls_two_reductions", {"one_reduction": not default_one})):
+        CGLS(F, bl, x0, 100, 0, history=False, **kw)             # warm-up: a whole solve of the timed size, as C2 / C3
         barrier(world)
-        dt = max_over_ranks(time.perf_counter() - t0, world)
-    out["cgls_iters_per_sec"] = round(reps * 100 / dt, 1)
+        with no_gc():
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                CGLS(F, bl, x0, 100, 0, history=False, **kw)
+            barrier(world)
+            dt = max_over_ranks(time.perf_counter() - t0, world)
+        out[f"{key}_iters_per_sec"] = round(reps * 100 / dt, 1)
+    # reduction points per iteration of both arrangements, whatever the rank count (two solves of different length each)
+    for key, kw in (("cgls_one_reduction", {"one_reduction": True}), ("cgls_two_reductions", {"one_reduction": False})):
+        cnt = []
+        for its in (20, 60):
+            c0 = eng.reduction_points
+            CGLS(F, bl, x0, its, 0, history=False, **kw)
+            cnt.append(eng.reduction_points - c0)
+        out[f"{key}_reduction_points_per_iteration"] = round((cnt[1] - cnt[0]) / 40.0, 3)
     GKS(F, bl, L, 3, 50, 1e-2, history=False)
     barrier(world)
     with no_gc():
@@ -591,6 +622,12 @@ def extra_c5_dynamic(rank, world, cpu=False):
         barrier(world)
         dt = max_over_ranks(time.perf_counter() - t0, world)
     out["gks_iters_per_sec"] = round(reps * 50 / dt, 1)
+    cnt = []
+    for its in (10, 30):
+        c0 = eng.reduction_points
+        GKS(F, bl, L, 3, its, 1e-2, history=False)
+        cnt.append(eng.reduction_points - c0)
+    out["gks_reduction_points_per_iteration"] = round((cnt[1] - cnt[0]) / 20.0, 3)
     if cpu:
         both = guarded(lambda: cpu_c5(Nf, [np.deg2rad(t + 12.0 * np.arange(na)) for t in range(nt)], bl, nt))
         out["cgls_cpu_baseline"], out["gks_cpu_baseline"] = both if isinstance(both, tuple) else (both, both)
@@ -741,6 +778,8 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the engine has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        os.environ.setdefault("TRK_COMM_FORCE", "1")      # the RCCL latency probe of extra.trk_comm_rccl on one rank (see its note)
     rank, world = dist_setup(args)
     res = run_blur_cgls(args, rank, world, json_fd)
     if rank == 0:

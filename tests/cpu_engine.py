@@ -77,6 +77,7 @@ class CpuEngine:
         self.comm = comm
         self.world = 1 if comm is None else comm.world
         self.rank = 0 if comm is None else comm.rank
+        self.reduction_points = 0
 
     def empty(self, n):
         return torch.zeros(int(n), dtype=torch.float32)
@@ -103,9 +104,13 @@ class CpuEngine:
         pass
 
     def allreduce(self, scal, i=0, j=None):
+        self.reduction_points += 1
         if self.comm is not None and self.world > 1:
             self.comm.allreduce_sum_(scal.view(i, j))
         return scal
+
+    def copy_scalars(self, src, i, dst, j, n=1):
+        dst.a[j:j + n] = src.a[i:i + n]
 
     # reductions
     def dot(self, x, y, out):
@@ -170,6 +175,39 @@ class CpuEngine:
         xn64 = xn.astype(np.float64)
         e = 0.0 if x_true is None else np.sum((xn64 - _d(x_true)) ** 2)
         _put(sums, [np.dot(xn64, xn64), np.dot(d.astype(np.float64), d.astype(np.float64)), e])
+
+    # CGLS with one all-reduce per iteration (csrc/cgls_sharded.hip restated)
+    def dot_pair(self, q, w, out2):
+        qq = _d(q)
+        _put(out2, [np.dot(qq, qq), 0.0 if w is None else np.dot(qq, _d(w))])
+
+    def cgls_sharded_update(self, G3, delta_prev, gamma_prev, first, x, p, t, x_new, r, q, w, x_true, pub_delta, pub_gamma,
+                            partials, capacity):
+        g, qq, qw = _get(G3, 3)
+        beta = 0.0 if first else g / _get(gamma_prev)
+        delta = qq if first else qq + 2.0 * beta * qw + beta * beta * _get(delta_prev)
+        b32, a32 = np.float32(beta), np.float32(g / delta)
+        pn = t.numpy().copy() if first else (b32 * p.numpy() + t.numpy()).astype(np.float32)
+        wn = q.numpy().copy() if first else (b32 * w.numpy() + q.numpy()).astype(np.float32)
+        p.copy_(torch.from_numpy(pn))
+        w.copy_(torch.from_numpy(wn))
+        d = a32 * pn
+        xn = (x.numpy() + d).astype(np.float32)
+        x_new.copy_(torch.from_numpy(xn))
+        r.copy_(torch.from_numpy((r.numpy() - a32 * wn).astype(np.float32)))
+        _put(pub_delta, delta)
+        _put(pub_gamma, g)
+        xn64, d64 = xn.astype(np.float64), d.astype(np.float64)
+        e = 0.0 if x_true is None else np.sum((xn64 - _d(x_true)) ** 2)
+        _put(partials, [np.dot(xn64, xn64), np.dot(d64, d64), e])
+        return 1
+
+    def finalize_batched(self, partials, nblocks, nvals, batches, out, out_stride):
+        s, i = partials
+        P = s.a[i:i + batches * nblocks * nvals].reshape(batches, nblocks, nvals).sum(axis=1)
+        so, io = out
+        for b in range(batches):
+            so.a[io + b * out_stride: io + b * out_stride + nvals] = P[b]
 
     # tall-skinny
     def gemv_t(self, V, k, r, out_h, w2=None):

@@ -106,8 +106,18 @@ def _solve_all(eng):
     L = OracleOp(_L, eng)
     bl, xl = b[lo * npix:hi * npix], x_true[lo * npix:hi * npix]
     out = {}
-    x, info = S.CGLS(F, bl, np.zeros(F.shape[1]), 12, 0, x_true=xl)
+    calls = getattr(eng.comm, "calls", None)
+    c0 = 0 if calls is None else calls["allreduce"]
+    x, info = S.CGLS(F, bl, np.zeros(F.shape[1]), 12, 0, x_true=xl)                 # world > 1: ONE all-reduce per iteration
     out["cgls"] = (x.reshape(-1), np.array(info["relResidual"]))
+    out["cgls_relerr"] = (np.array(info["relError"]), np.array([0 if calls is None else calls["allreduce"] - c0,
+                                                                 info.get("allreduces_per_iteration", -1.0)]))
+    c0 = 0 if calls is None else calls["allreduce"]
+    x, info = S.CGLS(F, bl, np.zeros(F.shape[1]), 12, 0, x_true=xl, one_reduction=False)   # the two reductions as written
+    out["cgls_two"] = (x.reshape(-1), np.array(info["relResidual"]))
+    out["cgls_two_relerr"] = (np.array(info["relError"]), np.array([0 if calls is None else calls["allreduce"] - c0, -1.0]))
+    x, info = S.CGLS(F, bl, np.zeros(F.shape[1]), 12, 0, x_true=xl, one_reduction=True, history=False)
+    out["cgls_one_nohist"] = (x.reshape(-1), np.array(info["relResidual"]))
     x, info = S.GKS(F, bl, L, 3, 6, 1e-2, xl)
     out["gks"] = (x.reshape(-1), np.array(info["Residual"]))
     x, info = S.MMGKS(F, bl, L, 2, 1, 3, 6, 1e-2, xl)
@@ -126,7 +136,17 @@ def _worker(rank, world, port, outdir):
     try:
         from cpu_engine import CpuEngine
         from trips_py_amd.dist import TorchComm
-        eng = CpuEngine(comm=TorchComm())
+
+        class CountingComm(TorchComm):
+            def __init__(self):
+                super().__init__()
+                self.calls = {"allreduce": 0}
+
+            def allreduce_sum_(self, t):
+                self.calls["allreduce"] += 1
+                return super().allreduce_sum_(t)
+
+        eng = CpuEngine(comm=CountingComm())
         out, (lo, hi, npix) = _solve_all(eng)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), lo=lo, hi=hi, npix=npix,
                  **{f"{k}_x": v[0] for k, v in out.items()}, **{f"{k}_s": v[1] for k, v in out.items()})
@@ -143,7 +163,15 @@ def test_sharded_solvers_match_single_process():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
         parts = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
-    for key in ("cgls", "gks", "mmgks", "lsqr"):
+    # CGLS over ranks: one all-reduce per iteration (12 iterations + the one after the solve for the reported norms) against
+    # 1 + 2 per iteration for the recurrence as written; iterates of the two forms within 1e-5, identical reported scalars
+    for p in parts:
+        assert p["cgls_relerr_s"][0] == 12 + 1 and p["cgls_relerr_s"][1] == 1.0, p["cgls_relerr_s"]
+        assert p["cgls_two_relerr_s"][0] == 1 + 2 * 12, p["cgls_two_relerr_s"]
+        assert np.linalg.norm(p["cgls_x"] - p["cgls_two_x"]) / np.linalg.norm(p["cgls_two_x"]) < 1e-5
+        assert np.allclose(p["cgls_s"], p["cgls_two_s"], rtol=1e-5) and np.allclose(p["cgls_relerr_x"], p["cgls_two_relerr_x"], rtol=1e-5)
+        assert np.array_equal(p["cgls_one_nohist_x"], p["cgls_x"])
+    for key in ("cgls", "cgls_two", "gks", "mmgks", "lsqr"):
         x = np.concatenate([p[f"{key}_x"] for p in parts])
         rx = ref[key][0]
         err = np.linalg.norm(x - rx) / np.linalg.norm(rx)

@@ -1,6 +1,12 @@
-"""BASELINE configs C3 and C5 at their FULL sizes against the float64 oracle (the oracle needs ~1 minute for both on the
+"""BASELINE configs C3 and C5 at their FULL sizes against the float64 oracle (the oracle needs ~1.5 minutes for both on the
 box's host; C2 and C4's operator are covered at full size by test_gpu_cgls.py / test_gpu_fullsize.py).
-The projector's fp32 ray coordinates bound the agreement, so the bars are looser than the blur's 1e-5."""
+
+Bars = north_star's 1e-5 on every solution the solvers converge to, with ONE stated exception: iterates 5..19 of Hybrid-LSQR at
+lambda = 1e-2.  There the projected Tikhonov solution x_k = V_k y_k passes through its semi-convergence transient and is
+sensitive to the 6e-8 roundings of ANY fp32-stored iteration: the float64 oracle itself, re-run with nothing changed but its
+operator products rounded to float32 (tools/fp32_floor.py, CPU only), leaves the float64 run by 3.5e-4 at step 9 and returns to
+7.9e-7 by step 20.  The engine: 1.6e-3 at step 7, 2.1e-6 at step 20, <= 8.4e-7 from step 21 on, 1.8e-7 at step 60
+(tools/configs_parity.py on the MI355X, round 3).  The projector itself is within 1e-7 of the oracle (test_gpu_radon_accuracy.py)."""
 import numpy as np
 import pytest
 
@@ -8,9 +14,16 @@ from conftest import relerr
 
 pytestmark = pytest.mark.gpu
 
+# bars: set from measurements on the MI355X (tools/configs_parity.py) and the fp32-storage floor of the oracle itself
+# (tools/fp32_floor.py) — see DESIGN.md section 2
+C3_BAR = 1e-5              # final iterate, every iterate from step 21 on, relError of those (measured 1.8e-7 ... 8.4e-7)
+C3_TRANSIENT_BAR = 5e-3    # iterates 1..20: the reference algorithm's own fp32 sensitivity (floor 3.5e-4, measured 1.6e-3)
+C5_BAR = 1e-5              # measured 6e-8 ... 1.2e-7 on every iterate, relError 3e-9
+C5_RESIDUAL_BAR = 1e-5     # measured 1.9e-7
 
-def test_c3_tomo512_hybrid_lsqr_fullsize():
-    """Parallel-beam 512^2, 180 angles, Hybrid_LSQR (lambda = 1e-2), 20 iterations, 1 % noise."""
+
+def c3_numbers(its=20):
+    """Parallel-beam 512^2, 180 angles, Hybrid_LSQR (lambda = 1e-2), `its` iterations, 1 % noise: engine vs float64 oracle."""
     from oracle import cpu_ref as O
     from trips_py_amd import solvers as S
     from trips_py_amd.operators import Radon2DParallel
@@ -23,18 +36,26 @@ def test_c3_tomo512_hybrid_lsqr_fullsize():
     b = Ro @ xt.reshape(-1)
     e = rng.standard_normal(b.size)
     b = (b + 0.01 * np.linalg.norm(b) / np.linalg.norm(e) * e).astype(np.float32).astype(np.float64)
-    x, info = S.Hybrid_LSQR(R, b, 20, 1e-2, xt.reshape(-1))
-    xo, io = O.hybrid_lsqr(Ro, b.reshape(-1, 1), 20, 1e-2, xt.reshape(-1, 1))
-    assert info["its"] == io["its"]
-    assert relerr(x, xo.reshape(-1)) < 2e-4, relerr(x, xo.reshape(-1))
-    # intermediate iterates of the fp32 Lanczos process wander a little before they meet again (measured 1.5e-3 at step 6)
-    assert np.allclose(info["relError"], io["relError"], rtol=5e-3)
-    assert np.isclose(info["relError"][-1], io["relError"][-1], rtol=2e-4)
+    x, info = S.Hybrid_LSQR(R, b, its, 1e-2, xt.reshape(-1))
+    xo, io = O.hybrid_lsqr(Ro, b.reshape(-1, 1), its, 1e-2, xt.reshape(-1, 1))
+    return {"its": (info["its"], io["its"]), "x": relerr(x, xo.reshape(-1)),
+            "iterates": [relerr(a, c) for a, c in zip(info["xHistory"], io["xHistory"])],
+            "relError": float(np.max(np.abs(np.asarray(info["relError"]) / np.asarray(io["relError"]) - 1))),
+            "relError_last": float(abs(info["relError"][-1] / io["relError"][-1] - 1))}
 
 
-def test_c5_dynamic_32_frames_gks_fullsize():
+def test_c3_tomo512_hybrid_lsqr_fullsize():
+    m = c3_numbers(60)
+    assert m["its"][0] == m["its"][1] == 59
+    assert m["x"] < C3_BAR and m["relError_last"] < C3_BAR, m
+    assert max(m["iterates"][20:]) < C3_BAR, m
+    assert max(m["iterates"][:20]) < C3_TRANSIENT_BAR, m
+    assert m["relError"] < C3_TRANSIENT_BAR, m
+
+
+def c5_numbers(its=8):
     """Dynamic parallel-beam tomography, 32 frames of 256^2, 15 angles per frame shifted by one degree per frame,
-    space-time derivative regulariser, GKS(projection_dim = 3, lambda = 1e-2), 8 iterations — all frames on one GPU."""
+    space-time derivative regulariser, GKS(projection_dim = 3, lambda = 1e-2), `its` iterations — all frames on one GPU."""
     from oracle import cpu_ref as O
     from trips_py_amd import solvers as S
     from trips_py_amd.operators import BlockDiagOp, Radon2DParallel, SpaceTimeDerivative
@@ -54,11 +75,18 @@ def test_c5_dynamic_32_frames_gks_fullsize():
     b = Fo @ xt
     e = rng.standard_normal(b.size)
     b = (b + 0.01 * np.linalg.norm(b) / np.linalg.norm(e) * e).astype(np.float32).astype(np.float64)
-    x, info = S.GKS(F, b, L, 3, 8, 1e-2, xt)
-    xo, io = O.gks(Fo, b.reshape(-1, 1), Lo, 3, 8, 1e-2, xt.reshape(-1, 1))
-    assert relerr(x, xo.reshape(-1)) < 2e-4, relerr(x, xo.reshape(-1))
-    assert np.allclose(info["relError"], io["relError"], rtol=1e-4)
-    assert np.allclose(info["Residual"], io["Residual"], rtol=5e-3)
+    x, info = S.GKS(F, b, L, 3, its, 1e-2, xt)
+    xo, io = O.gks(Fo, b.reshape(-1, 1), Lo, 3, its, 1e-2, xt.reshape(-1, 1))
+    return {"x": relerr(x, xo.reshape(-1)), "iterates": [relerr(a, c) for a, c in zip(info["xHistory"], io["xHistory"])],
+            "relError": float(np.max(np.abs(np.asarray(info["relError"]) / np.asarray(io["relError"]) - 1))),
+            "Residual": float(np.max(np.abs(np.asarray(info["Residual"]) / np.asarray(io["Residual"]) - 1)))}
+
+
+def test_c5_dynamic_32_frames_gks_fullsize():
+    m = c5_numbers()
+    assert m["x"] < C5_BAR and max(m["iterates"]) < C5_BAR, m
+    assert m["relError"] < C5_BAR, m
+    assert m["Residual"] < C5_RESIDUAL_BAR, m
 
 
 def test_c4_mmgks_tv_1024_vs_oracle_and_4096_path_equivalence():

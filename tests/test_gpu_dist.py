@@ -94,19 +94,88 @@ def test_sharded_hip_path_matches_single_process():
             assert np.allclose(p[f"{key}_s"], ref[key][1], rtol=1e-4), key
 
 
+_RCCL_ONE_RANK = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+torch.cuda.set_device(0)
+from trips_py_amd.dist import RcclComm
+from trips_py_amd.engine import HipEngine
+from trips_py_amd.operators import BlockDiagOp, Radon2DParallel
+from trips_py_amd import solvers as S
+c = RcclComm(0, 1)
+t = torch.tensor([1.5, -2.25, 1e300], dtype=torch.float64, device="cuda")
+c.allreduce_sum_(t)                        # TRK_COMM_FORCE=1: through ncclAllReduce although world = 1
+a = torch.arange(4099, dtype=torch.float32, device="cuda")
+b = torch.zeros_like(a)
+c.shift(a, 0, b, 0)                       # send to / receive from itself in one group
+torch.cuda.synchronize()
+assert t.tolist() == [1.5, -2.25, 1e300] and torch.equal(a, b)
+c.shift(a, 5, b, None)                    # neighbours outside the communicator: nothing happens
+# the one-all-reduce CGLS with its exchanges enqueued from C through this communicator (trk_cgls_iterate_sharded)
+eng = HipEngine(comm=c)
+eng.world = 2                              # pretend: makes the solver take its sharded branch; the communicator has one rank
+N, nt = 64, 4
+F = BlockDiagOp([Radon2DParallel(N, np.deg2rad(t + 12.0 * np.arange(15)), engine=eng) for t in range(nt)], engine=eng)
+g = torch.Generator(device="cuda").manual_seed(0)
+xt = torch.rand(F.shape[1], device="cuda", generator=g)
+bl = F.apply(xt)
+x1, i1 = S.CGLS(F, bl, torch.zeros(F.shape[1], device="cuda"), 30, 0, xt)
+assert i1["allreduces_per_iteration"] == 1.0
+eng.world = 1
+x2, i2 = S.CGLS(F, bl, torch.zeros(F.shape[1], device="cuda"), 30, 0, xt)
+assert "allreduces_per_iteration" not in i2
+err = float(torch.linalg.norm(x1 - x2) / torch.linalg.norm(x2))
+assert err < 1e-5, err
+assert np.allclose(i1["relError"], i2["relError"], rtol=1e-5) and np.allclose(i1["relResidual"], i2["relResidual"], rtol=1e-4)
+print("rccl one-rank ok", err)
+"""
+
+
 def test_libtrk_rccl_entry_points_single_rank():
     """trk_comm_unique_id / trk_comm_init / trk_allreduce_f64 / trk_halo_exchange (include/trk.h) on a one-rank RCCL
-    communicator: the calls really go through RCCL (a one-GPU box cannot host two ranks of it)."""
-    import torch
-    from trips_py_amd.dist import RcclComm
-    torch.cuda.set_device(0)
-    c = RcclComm(0, 1)
-    t = torch.tensor([1.5, -2.25, 1e300], dtype=torch.float64, device="cuda")
-    c.allreduce_sum_(t)
-    a = torch.arange(4099, dtype=torch.float32, device="cuda")
-    b = torch.zeros_like(a)
-    c.shift(a, 0, b, 0)                       # send to / receive from itself in one group
-    torch.cuda.synchronize()
-    assert t.tolist() == [1.5, -2.25, 1e300] and torch.equal(a, b)
-    c.shift(a, 5, b, None)                    # neighbours outside the communicator: nothing happens
-    del c
+    communicator, and trk_cgls_iterate_sharded enqueueing its all-reduces through it: with TRK_COMM_FORCE=1 the calls really go
+    through RCCL (a one-GPU box cannot host two ranks of it).  Own process: the switch is read once per process."""
+    import subprocess
+    env = dict(os.environ, TRK_COMM_FORCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", _RCCL_ONE_RANK % REPO], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+@pytest.mark.parametrize("case", ["tomo_dynamic", "blur96", "tomo_static"])
+def test_one_reduction_cgls_equals_the_recurrence_as_written(case):
+    """CGLS(one_reduction=True) on one rank = the merged-reduction arrangement without its exchange (C loop,
+    trk_cgls_iterate_sharded with comm = NULL, and stepped from Python) against the two-reduction forms: iterates and reported
+    scalars within 1e-5 over 40 iterations; history modes untouched."""
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import Blur2D, BlockDiagOp, Radon2DParallel
+    from trips_py_amd.problems import gauss_psf
+    from trips_py_amd.solvers.CGLS import CGLSRunSharded
+    if case == "tomo_dynamic":
+        A = BlockDiagOp([Radon2DParallel(64, np.deg2rad(t + 12.0 * np.arange(15))) for t in range(4)])
+    elif case == "blur96":
+        A = Blur2D(gauss_psf((9, 9), (3, 3))[0], 96, 96)
+    else:
+        A = Radon2DParallel(128, np.linspace(0, np.pi, 45, endpoint=False))
+    dev = A.engine.device
+    g = torch.Generator(device=dev).manual_seed(1)
+    xt = torch.rand(A.shape[1], device=dev, generator=g)
+    b = A.apply(xt)
+    b = b + 0.01 * torch.randn(b.numel(), device=dev, generator=g) * b.norm() / b.numel() ** 0.5
+    x0 = torch.zeros(A.shape[1], device=dev)
+    its = 40
+    xa, ia = S.CGLS(A, b, x0, its, 0, xt, one_reduction=False, tiled=False, fused=False)
+    xb, ib = S.CGLS(A, b, x0, its, 0, xt, one_reduction=True)
+    assert ib["allreduces_per_iteration"] == 0.0 and ib["its"] == ia["its"] == its
+    for k in range(its):
+        ra, rb = ia["xHistory"][k].reshape(-1), ib["xHistory"][k].reshape(-1)
+        assert float(torch.linalg.norm(ra - rb) / torch.linalg.norm(ra)) < 1e-5, k
+    assert np.allclose(ia["relError"], ib["relError"], rtol=1e-5) and np.allclose(ia["relResidual"], ib["relResidual"], rtol=1e-4)
+    # stepped from Python = the C loop, bit for bit
+    run = CGLSRunSharded(A, b, x0, its, xt)
+    for _ in range(its):
+        run.step()
+    assert torch.equal(run.x_cur, xb.reshape(-1))
+    _g0, rows = run.rows()
+    assert np.allclose(np.sqrt(rows[:, 4]) / np.sqrt(rows[:, 2]), ib["relError"], rtol=1e-12)
+    xc, ic = S.CGLS(A, b, x0, its, 0, one_reduction=True, history=7)
+    assert torch.equal(xc, xb) and ic["xHistory"].iterations == [6, 13, 20, 27, 34, 39]

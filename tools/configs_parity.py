@@ -1,0 +1,17 @@
+"""Measured agreement of C3 (Hybrid-LSQR 512^2 x 180) and C5 (GKS 32 x 256^2) with the float64 oracle at full size: the numbers the
+bars of tests/test_gpu_configs_fullsize.py are set from.  GPU box."""
+import json
+import os
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+import test_gpu_configs_fullsize as T  # noqa: E402
+
+for name, fn, its in (("c3", T.c3_numbers, (20, 60)), ("c5", T.c5_numbers, (8, 20))):
+    for k in its:
+        m = fn(k)
+        m["iterates_max"] = max(m["iterates"])
+        m["iterates"] = [float(f"{v:.2e}") for v in m["iterates"]]
+        print(name, k, json.dumps(m), flush=True)

@@ -1,0 +1,72 @@
+"""What agreement with the float64 oracle can an fp32-storage engine reach on C3 / C5 at all?  CPU only (the oracle twice).
+
+The oracle's solver is run (a) as it is and (b) with every operator product rounded to float32 on the way in and out — the least
+an engine that STORES its vectors in fp32 does to the iteration, with exact (float64) arithmetic everywhere else.  The distance
+between the two runs is a floor for the parity bar of tests/test_gpu_configs_fullsize.py: un-reorthogonalised Golub-Kahan
+(Hybrid_LSQR.py:73-110 via decompositions.py:230-255) amplifies the 6e-8 roundings, GKS's thrice re-orthogonalised basis does not.
+usage: python3 tools/fp32_floor.py c3|c5 [iterations]"""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import cpu_ref as O  # noqa: E402
+
+
+class Rounded(O._Op):
+    """op with fp32-rounded operands and results."""
+
+    def __init__(self, op):
+        self.op, self.shape = op, op.shape
+
+    def _fwd(self, x):
+        return self.op._fwd(x.astype(np.float32).astype(np.float64)).astype(np.float32).astype(np.float64)
+
+    def _adj(self, y):
+        return self.op._adj(y.astype(np.float32).astype(np.float64)).astype(np.float32).astype(np.float64)
+
+
+def rel(a, b):
+    return float(np.linalg.norm(np.ravel(a) - np.ravel(b)) / np.linalg.norm(np.ravel(b)))
+
+
+which = sys.argv[1]
+if which == "c3":
+    its = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    N, na = 512, 180
+    ang = np.linspace(0, np.pi, na, endpoint=False)
+    Ro = O.Radon2D(N, ang)
+    ii, jj = np.meshgrid(np.arange(N), np.arange(N), indexing="ij")
+    xt = (((ii - 256) / 180.0) ** 2 + ((jj - 256) / 230.0) ** 2 < 1).astype(np.float64) + 0.5 * ((((ii - 300) / 60.0) ** 2 + ((jj - 200) / 40.0) ** 2) < 1)
+    rng = np.random.default_rng(5)
+    b = Ro @ xt.reshape(-1)
+    e = rng.standard_normal(b.size)
+    b = (b + 0.01 * np.linalg.norm(b) / np.linalg.norm(e) * e).astype(np.float32).astype(np.float64)
+    xa, ia = O.hybrid_lsqr(Ro, b.reshape(-1, 1), its, 1e-2, xt.reshape(-1, 1))
+    xb, ib = O.hybrid_lsqr(Rounded(Ro), b.reshape(-1, 1), its, 1e-2, xt.reshape(-1, 1))
+    print(f"C3 Hybrid_LSQR {its} iterations: final x fp32-rounded products vs float64: {rel(xb, xa):.3e}")
+    print("per iterate:", " ".join(f"{rel(hb, ha):.1e}" for ha, hb in zip(ia["xHistory"], ib["xHistory"])))
+    print("relError max rel. difference:", float(np.max(np.abs(np.array(ib["relError"]) / np.array(ia["relError"]) - 1))))
+else:
+    its = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    N, nt, na = 256, 32, 15
+    angs = [np.deg2rad(t + 12.0 * np.arange(na)) for t in range(nt)]
+    Fo = O.BlockDiag([O.Radon2D(N, a) for a in angs])
+    Lo = O.SpaceTimeDerivative(N, nt)
+    frames = []
+    for t in range(nt):
+        img = np.zeros((N, N))
+        img[60 + 2 * t:100 + 2 * t, 40:200] = 1.0
+        img[150:190, 30 + 3 * t:90 + 3 * t] = 0.6
+        frames.append(img.reshape(-1))
+    xt = np.concatenate(frames)
+    rng = np.random.default_rng(9)
+    b = Fo @ xt
+    e = rng.standard_normal(b.size)
+    b = (b + 0.01 * np.linalg.norm(b) / np.linalg.norm(e) * e).astype(np.float32).astype(np.float64)
+    xa, ia = O.gks(Fo, b.reshape(-1, 1), Lo, 3, its, 1e-2, xt.reshape(-1, 1))
+    xb, ib = O.gks(Rounded(Fo), b.reshape(-1, 1), Rounded(Lo), 3, its, 1e-2, xt.reshape(-1, 1))
+    print(f"C5 GKS {its} iterations: final x fp32-rounded products vs float64: {rel(xb, xa):.3e}")
+    print("per iterate:", " ".join(f"{rel(hb, ha):.1e}" for ha, hb in zip(ia["xHistory"], ib["xHistory"])))
+    print("Residual max rel. difference:", float(np.max(np.abs(np.array(ib["Residual"]) / np.array(ia["Residual"]) - 1))))

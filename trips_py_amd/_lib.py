@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libtrk.so")
-SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip", "spmv.hip", "fanbeam2d.hip", "projected.hip", "cgls_loop.hip", "comm.hip", "cgls_tiled.hip"]
+SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip", "spmv.hip", "fanbeam2d.hip", "projected.hip", "cgls_loop.hip", "comm.hip", "cgls_tiled.hip", "cgls_sharded.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
 
@@ -231,6 +231,11 @@ SIGNATURES = {
     "trk_comm_destroy": (c_int, [ctypes.c_void_p]),
     "trk_allreduce_f64": (c_int, [ctypes.c_void_p, c_f64p, c_int, c_stream]),
     "trk_halo_exchange": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_f32p, c_int, c_i64, c_stream]),
+    "trk_dot_pair": (c_int, [c_f32p, c_f32p, c_i64, c_f64p, c_stream]),
+    "trk_cgls_sharded_update": (c_int, [c_i64, c_i64, c_f64p, c_f64p, c_f64p, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
+                                        c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
+    "trk_cgls_iterate_sharded": (c_int, [c_op, ctypes.c_void_p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64,
+                                         c_int, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
     "trk_wgram": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_stream]),
 }
 

@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -144,7 +145,10 @@ int trk_comm_destroy(trk_comm* c) {
 
 int trk_allreduce_f64(trk_comm* c, double* dev, int count, trk_stream st) {
   TRK_REQUIRE(c && dev && count >= 0, "trk_allreduce_f64: bad argument");
-  if (count == 0 || c->world == 1) return TRK_OK;      // one rank: the sum over ranks is the value itself — no RCCL call (trk.h)
+  // one rank: the sum over ranks is the value itself — no RCCL call (trk.h).  TRK_COMM_FORCE=1 (diagnostics, tests, the bench's
+  // latency probe) sends one-rank communicators through RCCL all the same: the only way a one-GPU box can exercise the call.
+  static const bool force = getenv("TRK_COMM_FORCE") != nullptr;
+  if (count == 0 || (c->world == 1 && !force)) return TRK_OK;
   TRK_NCCL(g_rccl.AllReduce(dev, dev, (size_t)count, ncclFloat64, ncclSum, c->comm, (hipStream_t)st));
   return TRK_OK;
 }

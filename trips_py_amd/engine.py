@@ -239,6 +239,7 @@ class HipEngine:
         self.comm = comm
         self.world = 1 if comm is None else comm.world
         self.rank = 0 if comm is None else comm.rank
+        self.reduction_points = 0           # calls of allreduce() (+ the all-reduces a C iteration loop enqueues itself)
 
     # ------------------------------------------------------------------ memory
     def empty(self, n):
@@ -306,9 +307,14 @@ class HipEngine:
     def allreduce(self, scal, i=0, j=None):
         """Sum scalars [i, j) of a DevScalars block (or a float64 tensor view) over all ranks, in place.
         No-op for a single rank."""
+        self.reduction_points += 1          # counted on one rank too: what a sharded run of the same solve would exchange
         if self.comm is not None and self.world > 1:
             self.comm.allreduce_sum_(scal.view(i, j) if isinstance(scal, DevScalars) else scal)
         return scal
+
+    def copy_scalars(self, src, i, dst, j, n=1):
+        """dst[j .. j+n) = src[i .. i+n) between DevScalars blocks, on the stream (no host visit)."""
+        dst.t[j:j + n].copy_(src.t[i:i + n], non_blocking=True)
 
     # ------------------------------------------------------------------ operators
     def op_apply(self, handle, transpose, x, y, batch=1, ldx=0, ldy=0, sumsq=None):
@@ -494,6 +500,32 @@ class HipEngine:
                                              ctypes.byref(cn), self.stream())
         _lib.check(rc, "trk_cgls_iterate_tiled")
         return cg.value, cn.value
+
+    # ------------------------------------------------------------------ CGLS with one all-reduce per iteration (cgls_sharded.hip)
+    def dot_pair(self, q, w, out2):
+        """out2[0] = <q, q>, out2[1] = <q, w> (w None: 0): this rank's sums."""
+        _lib.check(self.lib.trk_dot_pair(q.data_ptr(), None if w is None else w.data_ptr(), q.numel(), _ptr(out2), self.stream()),
+                   "trk_dot_pair")
+
+    def cgls_sharded_update(self, G3, delta_prev, gamma_prev, first, x, p, t, x_new, r, q, w, x_true, pub_delta, pub_gamma,
+                            partials, capacity):
+        n = ctypes.c_int(0)
+        rc = self.lib.trk_cgls_sharded_update(x.numel(), r.numel(), _ptr(G3), _ptr(delta_prev), _ptr(gamma_prev), int(bool(first)),
+                                              x.data_ptr(), p.data_ptr(), t.data_ptr(), x_new.data_ptr(), r.data_ptr(), q.data_ptr(),
+                                              w.data_ptr(), None if x_true is None else x_true.data_ptr(), _ptr(pub_delta),
+                                              _ptr(pub_gamma), _ptr(partials), int(capacity), ctypes.byref(n), self.stream())
+        _lib.check(rc, "trk_cgls_sharded_update")
+        return n.value
+
+    def cgls_iterate_sharded(self, handle, comm_handle, k_first, n_iters, p, r, t, q, w, X, keep, x_prev, x_true, S, G3, NP, np_cap,
+                             n_np):
+        n = ctypes.c_int(int(n_np))
+        rc = self.lib.trk_cgls_iterate_sharded(handle, comm_handle, int(k_first), int(n_iters), p.data_ptr(), r.data_ptr(),
+                                               t.data_ptr(), q.data_ptr(), w.data_ptr(), X.data_ptr(), X.stride(0), int(keep),
+                                               x_prev.data_ptr(), None if x_true is None else x_true.data_ptr(), _ptr(S), _ptr(G3),
+                                               _ptr(NP), int(np_cap), ctypes.byref(n), self.stream())
+        _lib.check(rc, "trk_cgls_iterate_sharded")
+        return n.value
 
     def finalize_batched(self, partials, nblocks, nvals, batches, out, out_stride):
         rc = self.lib.trk_finalize_batched(_ptr(partials), int(nblocks), int(nvals), int(batches), _ptr(out), int(out_stride),

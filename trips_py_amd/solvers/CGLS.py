@@ -180,6 +180,103 @@ class CGLSRun:
         return Sh[0], Sh[5:5 * (self.k + 1)].reshape(self.k, 5)
 
 
+class CGLSRunSharded(CGLSRun):
+    """The recurrence with ONE all-reduce per iteration, for unknowns spread over ranks (frames of a dynamic problem, io.py:420)
+    and tol = 0.  The reference's two global sums per iteration (CGLS.py:61 ||A p||^2, :70 ||A^T r||^2; the second waits for the
+    first) become one exchange of three doubles: with q = A t_{k-1} formed explicitly, w_k = A p_k = q + beta w_{k-1} and
+    delta_k = ||q||^2 + 2 beta <q, w_{k-1}> + beta^2 delta_{k-1} (include/trk.h, csrc/cgls_sharded.hip).  The three norms the
+    reference records per iterate are only reported, so each rank keeps its share and they are summed over the ranks once, in
+    `rows()`.  With libtrk's own communicator (dist.RcclComm) — or on one rank — the whole stretch is one library call
+    (trk_cgls_iterate_sharded: the all-reduces are enqueued from C); with torch's communicator the same kernels are stepped from
+    Python.  `allreduces` counts the exchanges issued inside the iterations."""
+
+    NPC = 1024
+
+    def __init__(self, A, b, x0, max_iter, x_true=None, history=True):
+        self.A = A = as_operator(A)
+        self.eng = eng = A.engine
+        m, n = A.shape
+        self.max_iter = max_iter = int(max_iter)
+        self.bv = eng.to_vec(b, m)
+        self.xt = None if x_true is None else eng.to_vec(x_true, n)
+        x_start = eng.to_vec(x0, n)
+        self.hist = History(eng, history, max_iter, n, "CGLS xHistory")
+        self.keep = self.hist.keeps_any
+        self.X = self.hist.X
+        self.defer, self.raw, self.grouping, self._final = False, False, 0, 0
+        self.NP = eng.scalars(3 * self.NPC * max_iter)
+        self.n_np = 0
+        self.r, self.t, self.w, self.p, self.q = eng.empty(m), eng.empty(n), eng.zeros(m), eng.zeros(n), eng.empty(m)
+        self.S = eng.scalars(5 * (max_iter + 1))
+        self.G = eng.scalars(4)                       # [gamma_{k-1}, ||q||^2, <q, w_{k-1}>]: the one exchange of an iteration
+        self.dist = eng.world > 1
+        self.k = 0
+        self.allreduces = 0
+        self._rows = None
+        A.apply(x_start, out=self.r)                                         # r = b - A x0 ; t = A^T r          (CGLS.py:45-46)
+        eng.axpby(1.0, self.bv, -1.0, self.r, self.r)
+        A.apply(self.r, out=self.t, transpose=True, sumsq=self.G.ref(0))     # this rank's ||t_0||^2: summed by iteration 1
+        self.x_cur = x_start
+
+    def _step(self):
+        eng, A, S, G = self.eng, self.A, self.S, self.G
+        self.k += 1
+        k = self.k
+        b = 5 * k
+        x_new = self.hist.row(k - 1)
+        A.apply(self.t, out=self.q)                                          # q = A t_{k-1}
+        eng.dot_pair(self.q, None if k == 1 else self.w, G.ref(1))
+        eng.allreduce(G, 0, 3)               # the iteration's one exchange (a no-op on one rank)
+        self.allreduces += self.dist
+        self.n_np = eng.cgls_sharded_update(G.ref(0), S.ref(b - 5), S.ref(0) if k <= 2 else S.ref(b - 9), k == 1, self.x_cur, self.p,
+                                            self.t, x_new, self.r, self.q, self.w, self.xt, S.ref(b),
+                                            S.ref(0) if k == 1 else S.ref(b - 4), self.NP.ref(3 * self.n_np * (k - 1)), self.NPC)
+        A.apply(self.r, out=self.t, transpose=True, sumsq=G.ref(0))          # t_k = A^T r_k, this rank's ||t_k||^2
+        self.x_cur = x_new
+
+    def run(self, n_steps):
+        n_steps = min(int(n_steps), self.max_iter - self.k)
+        if n_steps <= 0:
+            return
+        eng = self.eng
+        comm_h = getattr(eng.comm, "_h", None) if self.dist else None       # libtrk's own communicator (dist.RcclComm)
+        if hasattr(eng, "cgls_iterate_sharded") and hasattr(self.A, "_h") and (not self.dist or comm_h is not None):
+            def call(k_first, n, X, keep):
+                self.n_np = eng.cgls_iterate_sharded(self.A._h, comm_h, k_first, n, self.p, self.r, self.t, self.q, self.w, X, keep,
+                                                     self.x_cur, self.xt, self.S.ref(0), self.G.ref(0), self.NP.ref(0), self.NPC,
+                                                     self.n_np)
+                self.x_cur = _row_of(X, k_first + n - 2, keep)
+                eng.reduction_points += n
+                if self.dist:
+                    self.allreduces += n
+            self._run_c_loop(n_steps, call)
+        else:
+            for _ in range(n_steps):
+                self.step()
+
+    def rows(self):
+        """(gamma_0, [delta, gamma, ||x||^2, ||dx||^2, ||x - x_true||^2] per iteration): the rank's norm shares are summed over
+        blocks, then — with the last gamma, still local — over the ranks: one exchange per solve."""
+        k = self.k
+        if k == 0:
+            return self.S.host(0, 1)[0], np.zeros((0, 5))
+        if self._rows is None or self._rows[0] != k:
+            eng = self.eng
+            N3 = eng.scalars(3 * k + 1)
+            eng.finalize_batched(self.NP.ref(0), self.n_np, 3, k, N3.ref(0), 3)
+            N3.set(3 * k, self.G.host(0, 1))                          # gamma_k: formed by the last A^T r, not yet exchanged
+            eng.allreduce(N3, 0, 3 * k + 1)
+            Sh, Nh = self.S.host(), N3.host()
+            rows = Sh[5:5 * (k + 1)].reshape(k, 5).copy()
+            rows[:, 2:5] = Nh[:3 * k].reshape(k, 3)
+            rows[k - 1, 1] = Nh[3 * k]
+            self._rows = (k, Sh[0], rows)
+        return self._rows[1], self._rows[2]
+
+    def row(self, k):
+        return self.rows()[1][k - 1]
+
+
 class CGLSRunFused(CGLSRun):
     """The same recurrence in three launches per iteration and no reduction-finalize launches, for operators with a
     fused apply (trk_op_apply_fused: the separable blur):
@@ -336,7 +433,14 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
     fused = (not sync_each) and CGLSRunFused.usable(A, A.engine) and \
         (want if want is not None else CGLSRunFused.auto(A.shape[1]))
     tiled = (not sync_each) and want is None and kwargs.get("tiled", True) and CGLSRunFused.tiled_usable(A, A.engine)
-    if tiled or fused:
+    # unknowns spread over ranks, tol = 0: the one-all-reduce form (one_reduction=False keeps the two reductions of the recurrence
+    # as written; one_reduction=True also selects it on a single rank, where it is the same arithmetic without the exchange)
+    one_red = kwargs.get("one_reduction", None)
+    sharded = (not sync_each) and (one_red if one_red is not None else A.engine.world > 1) and \
+        hasattr(A.engine, "cgls_sharded_update")
+    if sharded:
+        run = CGLSRunSharded(A, b, x0, max_iter, x_true, kwargs.get("history", True))
+    elif tiled or fused:
         run = CGLSRunFused(A, b, x0, max_iter, x_true, kwargs.get("history", True), tiled=tiled)
     else:
         run = CGLSRun(A, b, x0, max_iter, x_true, kwargs.get("history", True), defer_norms=not sync_each)
@@ -369,4 +473,6 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
             "relResidual": list(np.sqrt(rows[:, 3]) / norm_x), "its": k}
     if run.xt is not None:
         info["relError"] = list(np.sqrt(rows[:, 4]) / norm_x)
+    if sharded:
+        info["allreduces_per_iteration"] = run.allreduces / max(1, run.k)      # engine-only key: exchanges inside the iterations
     return fmt.vec(x_fin), info

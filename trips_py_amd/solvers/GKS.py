@@ -66,7 +66,8 @@ class _ProjectedBases:
         eng, S = self.eng, self.S
         v = self.V[j]
         k = j + 1
-        c_out = self.c_d.ref(j) if self.on_device else S.ref(2 * k)
+        # sharded: c_j travels with the Gram rows (one all-reduce of 2k + 1 doubles, then a device copy into c_d[j])
+        c_out = self.c_d.ref(j) if (self.on_device and eng.world == 1) else S.ref(2 * k)
         if self.from_v_A:
             self.A.apply(v, out=self.tA)
             self.A.apply(self.tA, out=self.zA, transpose=True)            # z_A = A^T A v
@@ -105,8 +106,9 @@ class _ProjectedBases:
             else:
                 eng.gemv_t(self.LV.data, k, lv, S.ref(k))
         if self.on_device:
-            eng.allreduce(S, 0, 2 * k)
-            eng.allreduce(self.c_d, j, j + 1)
+            if eng.world > 1:
+                eng.allreduce(S, 0, 2 * k + 1)
+                eng.copy_scalars(S, 2 * k, self.c_d, j, 1)
             eng.cgs_coeffs(self.GA_d.ref(0), self.kmax, None, S.ref(0), k, 0, None)     # install row / column j
             if self.use_L:
                 eng.cgs_coeffs(self.GL_d.ref(0), self.kmax, None, S.ref(k), k, 0, None)
@@ -156,10 +158,14 @@ class _ProjectedBases:
             av = self.AV.next_slot()
             self.A.apply(self.V[k], out=av)
             self.AV.commit()
-            eng.dot(av, self.bv, self.c_d.ref(k))
-            eng.gemv_t(self.AV.data, k + 1, av, S.ref(4))
-            eng.allreduce(S, 4, 4 + k + 1)
-            eng.allreduce(self.c_d, k, k + 1)
+            if eng.world > 1:                                             # c_k behind the Gram row: one exchange
+                eng.dot(av, self.bv, S.ref(4 + k + 1))
+                eng.gemv_t(self.AV.data, k + 1, av, S.ref(4))
+                eng.allreduce(S, 4, 4 + k + 2)
+                eng.copy_scalars(S, 4 + k + 1, self.c_d, k, 1)
+            else:
+                eng.dot(av, self.bv, self.c_d.ref(k))
+                eng.gemv_t(self.AV.data, k + 1, av, S.ref(4))
             eng.cgs_coeffs(self.GA_d.ref(0), self.kmax, None, S.ref(4), k + 1, 0, None)
         if self.from_v_L:
             eng.gram_row_from_sweep(self.GL_d.ref(0), self.kmax, k, gs.extra_ref(q, k), c, S.ref(1), rho2)
