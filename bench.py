@@ -304,8 +304,14 @@ def run_blur_cgls(args, rank, world, json_fd=1):
                      "cgls_alg_bytes_per_iter": 44.0 * n,
                      "cgls_effective_GBps": round(44.0 * n * K / elapsed / 1e9, 1)}}
 
+    # Host baselines run AFTER every GPU measurement of this process: NumPy / SciPy work on the host wakes BLAS thread pools whose
+    # idle spinning can exhaust the container's CPU quota, and the kernel then parks every thread for the rest of the period — a
+    # solver loop enqueueing microsecond kernels stops for ~100 ms (seen here as C4 at 170 instead of 540
+    # iterations/s when the C3 host leg ran right before it).
+    cpu_jobs = []          # (where the result goes, closure)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        res["cpu_baseline"] = cpu_baseline_cgls(psf, N, b, args.cpu_iters)
+        b_host = b.detach().to("cpu")
+        cpu_jobs.append((lambda v: res.__setitem__("cpu_baseline", v), lambda: cpu_baseline_cgls(psf, N, b_host, args.cpu_iters)))
     del run
     torch.cuda.empty_cache()
     if not args.no_extras:
@@ -325,16 +331,21 @@ def run_blur_cgls(args, rank, world, json_fd=1):
         watchdog.start()
         cpu = rank == 0 and world == 1 and not args.no_cpu_baseline      # host baselines beside every config (rank 0, N = 1)
         for name, fn in (("trk_comm_rccl", lambda: extra_trk_comm(rank, world)),
-                         ("c2_blur512_cgls", lambda: extra_c2_blur512(world, cpu)),
-                         ("c3_tomo512_hybrid_lsqr", lambda: extra_c3_tomo(world, cpu)),
-                         ("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world, cpu, psf)),
-                         ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world, cpu))):
+                         ("c2_blur512_cgls", lambda: extra_c2_blur512(world, cpu_jobs if cpu else None)),
+                         ("c3_tomo512_hybrid_lsqr", lambda: extra_c3_tomo(world, cpu_jobs if cpu else None)),
+                         ("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world, cpu_jobs if cpu else None, psf)),
+                         ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world, cpu_jobs if cpu else None))):
             try:
                 res["extra"][name] = fn()
             except Exception as exc:          # noqa: BLE001
                 res["extra"][name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             barrier(world)
+        for put, job in cpu_jobs:             # every GPU number is in: now the host legs, each guarded
+            put(guarded(job))
         watchdog.cancel()
+    else:
+        for put, job in cpu_jobs:
+            put(guarded(job))
     return res
 
 
@@ -391,7 +402,7 @@ class no_gc:
         return False
 
 
-def extra_c2_blur512(world, cpu=False):
+def extra_c2_blur512(world, cpu_jobs=None):
     """BASELINE config C2: 2-D Gaussian blur 512^2 fp32, CGLS 100 iterations (the reference's own demo size; BASELINE.md §2
     measured the reference at 21.7 it/s on this problem).  Whole solves through the public CGLS() call, x_true given as in
     the demo (relError history on).  Replicas across ranks."""
@@ -417,12 +428,13 @@ def extra_c2_blur512(world, cpu=False):
         dt = max_over_ranks(time.perf_counter() - t0, world)
     out = {"solver": "CGLS(max_iter=100, tol=0, x_true)", "iters_per_sec_all_ranks": round(world * reps * 100 / dt, 1),
            "ms_per_solve": round(dt / reps * 1e3, 3), "relError_last": float(info["relError"][-1])}
-    if cpu:
-        out["cpu_baseline"] = guarded(lambda: cpu_c2(gauss_psf((9, 9), (3, 3))[0], N, b))
+    if cpu_jobs is not None:
+        bh = b.detach().to("cpu")
+        cpu_jobs.append((lambda v: out.__setitem__("cpu_baseline", v), lambda: cpu_c2(gauss_psf((9, 9), (3, 3))[0], N, bh)))
     return out
 
 
-def extra_c3_tomo(world, cpu=False):
+def extra_c3_tomo(world, cpu_jobs=None):
     """BASELINE config C3: parallel-beam tomography 512^2, 180 angles, Hybrid-LSQR 100 iterations (lambda = 1e-2), plus
     the Radon matvec rates.  The Radon operator is gather/ALU-bound, not HBM-bound: taps/s is the honest
     rate, algorithmic GB/s is reported for completeness.  Replicas across ranks."""
@@ -504,23 +516,28 @@ def extra_c3_tomo(world, cpu=False):
             dt = max_over_ranks(time.perf_counter() - t0, world)
         out[f"hybrid_lsqr{tag}_iters_per_sec_all_ranks"] = round(world * reps * 100 / dt, 1)
         out[f"hybrid_lsqr{tag}_relError_last"] = float(info["relError"][-1])
-    if cpu:
-        out["cpu_baseline"] = guarded(lambda: cpu_c3(Nt, np.linspace(0, np.pi, na, endpoint=False), bt))
+    if cpu_jobs is not None:
+        bh = bt.detach().to("cpu")
+        cpu_jobs.append((lambda v: out.__setitem__("cpu_baseline", v),
+                         lambda: cpu_c3(Nt, np.linspace(0, np.pi, na, endpoint=False), bh)))
     return out
 
 
-def extra_c4_mmgks(A, b, N, world, cpu=False, psf=None):
+def extra_c4_mmgks(A, b, N, world, cpu_jobs=None, psf=None):
     """BASELINE config C4: blur 4096^2, MMGKS + TV (pnorm=2, qnorm=1, projection_dim=3, n_iter=30, lambda=1e-2).
     Replicas across ranks (a static image does not shard)."""
     from trips_py_amd.operators import FirstDerivative2D
     from trips_py_amd.solvers import MMGKS
     L = FirstDerivative2D(N)
     MMGKS(A, b, L, 2, 1, 3, 4, 1e-2, history=False)          # warm-up (allocations, kernels)
+    MMGKS(A, b, L, 2, 1, 3, 30, 1e-2, history=False)         # and one whole solve of the timed size, as C2 / C3 / C5
     barrier(world)
+    reps = 3
     t0 = time.perf_counter()
-    x, info = MMGKS(A, b, L, 2, 1, 3, 30, 1e-2, history=False)
+    for _ in range(reps):
+        x, info = MMGKS(A, b, L, 2, 1, 3, 30, 1e-2, history=False)
     barrier(world)
-    dt = max_over_ranks(time.perf_counter() - t0, world)
+    dt = max_over_ranks(time.perf_counter() - t0, world) / reps          # mean over three solves
     # algorithmic bytes of one MMGKS iteration at basis size k (fp32 vectors, m = n, p = 2n rows of L), DESIGN.md §4.2b:
     #   weighted Grams of AV and LV 4k(m + p) = 12kn | x = V y 4kn | the two re-orthogonalisation sweeps as ONE pair of passes
     #   (V^T r with the Gram row riding along, r - V c) 8kn | weights, stencil applies, weighted residuals, axpys on single
@@ -530,9 +547,7 @@ def extra_c4_mmgks(A, b, N, world, cpu=False, psf=None):
     alg = sum((24.0 * (3 + i) + 192.0) * n for i in range(its))
     alg_ref = sum((32.0 * (3 + i) + 192.0) * n for i in range(its))
     gbps = alg / dt / 1e9
-    cpu_part = {"cpu_baseline": guarded(lambda: cpu_c4(psf, N, b))} if cpu else {}
-    return {**cpu_part,
-            "solver": "MMGKS(pnorm=2,qnorm=1,projection_dim=3,n_iter=30,regparam=1e-2,epsilon=0.1), L = 2-D first derivative",
+    out = {"solver": "MMGKS(pnorm=2,qnorm=1,projection_dim=3,n_iter=30,regparam=1e-2,epsilon=0.1), L = 2-D first derivative",
             "iters_per_sec_all_ranks": round(world * 30 / dt, 2), "seconds_per_solve": round(dt, 4), "its": its,
             "parallelism": "replicas" if world > 1 else "single",
             "roofline": {"bound": "hbm", "alg_bytes_per_iter_formula": "(24 k + 192) n, k = 3 + iteration index, n = 4096^2",
@@ -540,9 +555,13 @@ def extra_c4_mmgks(A, b, N, world, cpu=False, psf=None):
                          "frac": round(gbps / HBM_PEAK_GBPS, 4),
                          "frac_counting_the_reference_sweep_passes_32k": round(alg_ref / dt / 1e9 / HBM_PEAK_GBPS, 4),
                          "timed": "whole solve, wall clock incl. the host's projected problems"}}
+    if cpu_jobs is not None:
+        bh = b.detach().to("cpu")
+        cpu_jobs.append((lambda v: out.__setitem__("cpu_baseline", v), lambda: cpu_c4(psf, N, bh)))
+    return out
 
 
-def extra_c5_dynamic(rank, world, cpu=False):
+def extra_c5_dynamic(rank, world, cpu_jobs=None):
     """BASELINE config C5 (dynamic parallel-beam tomography, 256^2 frames, 15 angles per frame shifted by 1 degree per
     frame, space-time derivative) at its BASELINE size: 32 frames in all, 32 / world per rank (STRONG scaling: the same
     problem at every N, also N = 1), global inner products all-reduced over RCCL, one-frame halo exchange for the temporal
@@ -613,6 +632,8 @@ def extra_c5_dynamic(rank, world, cpu=False):
             CGLS(F, bl, x0, its, 0, history=False, **kw)
             cnt.append(eng.reduction_points - c0)
         out[f"{key}_reduction_points_per_iteration"] = round((cnt[1] - cnt[0]) / 40.0, 3)
+    if world == 1:       # the single-rank form of the recurrence keeps its sums as block partials and never calls the engine's all-reduce
+        out["cgls_two_reductions_reduction_points_per_iteration"] = "2 on ranks > 1 (CGLS.py:61,70); 0 calls on one rank"
     GKS(F, bl, L, 3, 50, 1e-2, history=False)
     barrier(world)
     with no_gc():
@@ -628,9 +649,12 @@ def extra_c5_dynamic(rank, world, cpu=False):
         GKS(F, bl, L, 3, its, 1e-2, history=False)
         cnt.append(eng.reduction_points - c0)
     out["gks_reduction_points_per_iteration"] = round((cnt[1] - cnt[0]) / 20.0, 3)
-    if cpu:
-        both = guarded(lambda: cpu_c5(Nf, [np.deg2rad(t + 12.0 * np.arange(na)) for t in range(nt)], bl, nt))
-        out["cgls_cpu_baseline"], out["gks_cpu_baseline"] = both if isinstance(both, tuple) else (both, both)
+    if cpu_jobs is not None:
+        bh = bl.detach().to("cpu")
+
+        def put(both):
+            out["cgls_cpu_baseline"], out["gks_cpu_baseline"] = both if isinstance(both, tuple) else (both, both)
+        cpu_jobs.append((put, lambda: cpu_c5(Nf, [np.deg2rad(t + 12.0 * np.arange(na)) for t in range(nt)], bh, nt)))
     return out
 
 

@@ -180,13 +180,15 @@ def test_tiled_two_launch_cgls_equals_the_streaming_form(nx, ny, dim, spread):
     b = A.apply(xt)
     b = b + 0.01 * torch.randn(n, device=dev, generator=torch.Generator(device=dev).manual_seed(8)) * b.norm() / n ** 0.5
     x0 = torch.zeros(n, device=dev)
-    its = 25
+    # images of a few hundred pixels under a 9 x 9 blur are so ill-conditioned that fp32 CGLS itself falls apart after a handful
+    # of iterations (16 x 16: the two forms' roundings differ by 3e-6 at iterate 6 and grow ninefold per iteration): what the short
+    # axes are here for — the clamped halo folds — is exercised from the first iteration on, so they run 5
+    its = 25 if n >= 4096 else 5
     xa, ia = CGLS(A, b, x0, its, 0, xt, tiled=False, fused=False)
     xb, ib = CGLS(A, b, x0, its, 0, xt, tiled=True)
     for k in range(its):
         ra, rb = ia["xHistory"][k].reshape(-1), ib["xHistory"][k].reshape(-1)
-        # tiny images (a 9 x 9 blur of 16 x 16 pixels) amplify the two forms' different fp32 roundings: measured 3.2e-6 at 16 x 16
-        assert float(torch.linalg.norm(ra - rb) / torch.linalg.norm(ra)) < (2e-6 if n >= 4096 else 1e-5), k
+        assert float(torch.linalg.norm(ra - rb) / torch.linalg.norm(ra)) < 2e-6, k
     assert np.allclose(ia["relError"], ib["relError"], rtol=1e-5) and np.allclose(ia["relResidual"], ib["relResidual"], rtol=1e-5)
     xc, ic = CGLS(A, b, x0, its, 0, tiled=True, history=False)
     assert float(torch.linalg.norm(xc - xb) / torch.linalg.norm(xb)) == 0.0 and ic["xHistory"] == []

@@ -581,14 +581,16 @@ __global__ __launch_bounds__(256, 7) void k_radon_fwd_win(const float* __restric
     }
     __syncthreads();
     // staging slots of this thread: float4 numbers t and t + 256 of the 16 x 32 tile
-    int sc4[2], srowN4[2], srow[2];
+    int sc4[2], srowN4[1], srow[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int idx = (int)threadIdx.x + 256 * i;
       srow[i] = idx / (WIN_W / 4);
       sc4[i] = (idx - srow[i] * (WIN_W / 4)) * 4;
-      srowN4[i] = srow[i] * N * 4;
     }
+    static_assert(256 / (WIN_W / 4) == 8, "the two staging slots of a thread are 8 tile rows apart");
+    srowN4[0] = srow[0] * N * 4;
+    asm volatile("" : "+v"(srowN4[0]));              // one register, kept: not re-multiplied in every chunk
     for (int ch = 0; ch < nch; ++ch) {
       const int tb = t0 + ch * WIN_R, te = (tb + WIN_R < t1) ? tb + WIN_R : t1;
       const int buf = ch & 1;
@@ -600,13 +602,25 @@ __global__ __launch_bounds__(256, 7) void k_radon_fwd_win(const float* __restric
       f2v acc2 = {0.f, 0.f};
       if (fits) {
         const unsigned rowbase = (unsigned)tb * (unsigned)N * 4u;
+        if (full) {
+          // every row of the chunk is an image row: the thread's two slots are the same columns 8 rows apart, so ONE vector
+          // offset serves both loads and the second row offset rides in the scalar offset (which the range check ignores: the
+          // out-of-image columns are still caught through the vector offset).  4 vector instructions per chunk instead of 14,
+          // two of them quarter-rate 32-bit multiplies the register allocator kept re-deriving.
+          const int col = cs + sc4[0];
+          const int voff = ((unsigned)col < (unsigned)N) ? (col << 2) + srowN4[0] : (int)img_bytes;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(T + (wv * 64) * 4), 16, voff, rowbase, 0, 0);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(T + (wv * 64 + 256) * 4), 16, voff,
+                                                   rowbase + 8u * (unsigned)N * 4u, 0, 0);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int col = cs + sc4[i];
-          const bool ok = ((unsigned)col < (unsigned)N) && (tb + srow[i] < te);
-          const int voff = ok ? (col << 2) + srowN4[i] : (int)img_bytes;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(T + (wv * 64 + 256 * i) * 4), 16,
-                                                   voff, rowbase, 0, 0);
+          for (int i = 0; i < 2; ++i) {
+            const int col = cs + sc4[i];
+            const bool ok = ((unsigned)col < (unsigned)N) && (tb + srow[i] < te);
+            const int voff = ok ? (col << 2) + srow[i] * N * 4 : (int)img_bytes;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (__attribute__((address_space(3))) void*)(T + (wv * 64 + 256 * i) * 4), 16,
+                                                     voff, rowbase, 0, 0);
+          }
         }
         __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): this wave's part of the tile is in LDS
       }

@@ -2,7 +2,9 @@
 // 16-byte-per-lane coalesced loads, grid-stride, fp32 storage, fp64 accumulation, wave64 __shfl reductions,
 // one double of block partial per workgroup, summed in a fixed order by core.hip's finalize kernel.
 #include "trk_internal.h"
+#include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 using namespace trk;
 
@@ -12,6 +14,34 @@ constexpr int NT = 256;
 
 // grid for a streaming kernel over n floats: one float4 per thread until the chip is covered 4x (<= kMaxPartialBlocks
 // blocks so a reduction leaves at most that many partials), then grid-stride
+
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+// Workgroups of `kernel` (NT threads, no dynamic LDS) that one CU holds at a time.
+template <class K>
+inline int resident_blocks_per_cu(K kernel) {
+  int nb = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, NT, 0) != hipSuccess || nb < 1) nb = 4;
+  return nb;
+}
+
+// Grid of the one-pass k-dot kernels (k_gemv_t / _t2 / _tr): x = shares of the vector, y = row tiles.  All workgroups take the
+// same time, so the grid is EXACTLY one resident round — occupancy x CUs workgroups in all, rounded DOWN to whole x-columns.
+// Measured (4096^2, k = 18, three tiles): 683 x 3 = 2049 workgroups, one more than the chip holds, ran 290 us; 1024 x 3 (two
+// rounds) 222 us; a single full round is what every basis size gets now (tools/gemv_micro.py, profiles/r03/gemv_micro.txt).
+inline int tiled_dot_grid_x(int64_t n, int ntile, int blocks_per_cu) {
+  static const int env = env_int("TRK_GEMVT_PER_CU", 0);
+  const int64_t total = (int64_t)cu_count() * (env > 0 ? env : blocks_per_cu);
+  int64_t bx = total / ntile;
+  const int64_t want = (n + (int64_t)NT * 4 - 1) / ((int64_t)NT * 4);
+  if (bx > want) bx = want;
+  if (bx > kMaxPartialBlocks) bx = kMaxPartialBlocks;
+  return bx < 1 ? 1 : (int)bx;
+}
+
 inline int stream_grid(int64_t n) {
   int64_t want = (n + (int64_t)NT * 4 - 1) / ((int64_t)NT * 4);
   int64_t cap = (int64_t)cu_count() * 4;
@@ -506,8 +536,11 @@ __global__ __launch_bounds__(NT) void k_gemv_t(const float* __restrict__ V, int6
                                                const float* __restrict__ r, const float* __restrict__ w,
                                                double* __restrict__ partials, int nt) {
   __shared__ double lds[(NT / 64) * JT];
-  const int j0 = blockIdx.y * JT;
-  const int jn = (k - j0 < JT) ? (k - j0) : JT;
+  // row tiles of equal height: ceil(k / tiles) <= JT rows each (k = 18: 6 + 6 + 6, not 8 + 8 + 2 — the short tile's workgroups
+  // read the right-hand sides for a quarter of the work)
+  const int jb = (k + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int j0 = blockIdx.y * jb;
+  const int jn = (k - j0 < jb) ? (k - j0 < 0 ? 0 : k - j0) : jb;
   double acc[JT];
 #pragma unroll
   for (int j = 0; j < JT; ++j) acc[j] = 0.0;
@@ -564,8 +597,11 @@ __global__ __launch_bounds__(NT) void k_gemv_t2(const float* __restrict__ V, int
                                                 const float* __restrict__ r, const float* __restrict__ r2,
                                                 double* __restrict__ partials, int nt) {
   __shared__ double lds[(NT / 64) * 2 * JT];
-  const int j0 = blockIdx.y * JT;
-  const int jn = (k - j0 < JT) ? (k - j0) : JT;
+  // row tiles of equal height: ceil(k / tiles) <= JT rows each (k = 18: 6 + 6 + 6, not 8 + 8 + 2 — the short tile's workgroups
+  // read the right-hand sides for a quarter of the work)
+  const int jb = (k + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int j0 = blockIdx.y * jb;
+  const int jn = (k - j0 < jb) ? (k - j0 < 0 ? 0 : k - j0) : jb;
   double acc[JT], acc2[JT];
 #pragma unroll
   for (int j = 0; j < JT; ++j) acc[j] = acc2[j] = 0.0;
@@ -617,8 +653,11 @@ template <bool VEC, int R>
 __global__ __launch_bounds__(NT) void k_gemv_tr(const float* __restrict__ V, int64_t ld, int k, int64_t n, RhsSet rhs,
                                                 double* __restrict__ partials, int nt) {
   __shared__ double lds[(NT / 64) * R * JT];
-  const int j0 = blockIdx.y * JT;
-  const int jn = (k - j0 < JT) ? (k - j0) : JT;
+  // row tiles of equal height: ceil(k / tiles) <= JT rows each (k = 18: 6 + 6 + 6, not 8 + 8 + 2 — the short tile's workgroups
+  // read the right-hand sides for a quarter of the work)
+  const int jb = (k + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int j0 = blockIdx.y * jb;
+  const int jn = (k - j0 < jb) ? (k - j0 < 0 ? 0 : k - j0) : jb;
   double acc[R][JT];
 #pragma unroll
   for (int q = 0; q < R; ++q)
@@ -669,10 +708,8 @@ __global__ __launch_bounds__(NT) void k_gemv_tr(const float* __restrict__ V, int
 int launch_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* w, int wpow, double* h,
                   hipStream_t s) {
   const int ntile = ceil_div(k, JT);
-  int bx = stream_grid(n);
-  // spread over the chip even when there are many row tiles
-  const int cap = (cu_count() * 8 + ntile - 1) / ntile;
-  if (bx > cap) bx = cap < 1 ? 1 : cap;
+  static const int occ = resident_blocks_per_cu(k_gemv_t<0, true>);
+  const int bx = tiled_dot_grid_x(n, ntile, occ);
   double* part = nullptr;
   if (int rc = scratch_doubles(s, (size_t)bx * k, &part)) return rc;
   const bool vec = aligned16(V) && aligned16(r) && (ld % 4 == 0) && (!wpow || aligned16(w));
@@ -690,7 +727,7 @@ int launch_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, 
 constexpr int KMAX_LDS = 1024;  // coefficients staged in LDS as doubles
 
 // HAS_REF: the partials are those of sum (out - ref)^2 instead of sum out^2 (the error norm against x_true)
-template <bool HAS_BASE, bool SUMSQ, bool VEC, bool HAS_REF = false>
+template <bool HAS_BASE, bool SUMSQ, bool VEC, bool HAS_REF = false, int U = 8>
 __global__ __launch_bounds__(NT) void k_gemv_n(const float* __restrict__ V, int64_t ld, int k, int64_t n,
                                                const double* __restrict__ y, double a, const float* base, double sc,
                                                float* out, double* __restrict__ partials,
@@ -714,15 +751,28 @@ __global__ __launch_bounds__(NT) void k_gemv_n(const float* __restrict__ V, int6
         o2 = a * b.z;
         o3 = a * b.w;
       }
-#pragma unroll 4
-      for (int j = 0; j < k; ++j) {
-        const float4 v = (nt & 128) ? ld4_nt(V + (int64_t)j * ld, i) : ld4(V + (int64_t)j * ld, i);
-        const double c = ys[j];
-        o0 = fma(c, (double)v.x, o0);
-        o1 = fma(c, (double)v.y, o1);
-        o2 = fma(c, (double)v.z, o2);
-        o3 = fma(c, (double)v.w, o3);
-      }
+      // rows of the basis are requested in groups — U, then 8, then 4 — before the first of a group is used (the compiler's own
+      // unrolling of the plain loop kept 4 in flight; U is the launcher's choice, trk_gemv_n)
+      int j = 0;
+      auto group = [&](auto width) {
+        constexpr int W = decltype(width)::value;
+        float4 v[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) v[u] = (nt & 128) ? ld4_nt(V + (int64_t)(j + u) * ld, i) : ld4(V + (int64_t)(j + u) * ld, i);
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+          const double c = ys[j + u];
+          o0 = fma(c, (double)v[u].x, o0);
+          o1 = fma(c, (double)v[u].y, o1);
+          o2 = fma(c, (double)v[u].z, o2);
+          o3 = fma(c, (double)v[u].w, o3);
+        }
+        j += W;
+      };
+      while (j + U <= k) group(std::integral_constant<int, U>{});
+      if (U > 8 && j + 8 <= k) group(std::integral_constant<int, 8>{});
+      if (U > 4 && j + 4 <= k) group(std::integral_constant<int, 4>{});
+      while (j < k) group(std::integral_constant<int, 1>{});
       float4 o = make_float4((float)o0, (float)o1, (float)o2, (float)o3);
       st4(out, i, o);
       if (SUMSQ && HAS_REF) {
@@ -1580,9 +1630,8 @@ int trk_gemv_t2(const float* V, int64_t ld, int k, int64_t n, const float* r, co
   TRK_REQUIRE(k >= 1 && n >= 0 && ld >= n, "trk_gemv_t2: need k >= 1, n >= 0, ld >= n");
   hipStream_t s = (hipStream_t)st;
   const int ntile = ceil_div(k, JT);
-  int bx = stream_grid(n);
-  const int cap = (cu_count() * 8 + ntile - 1) / ntile;
-  if (bx > cap) bx = cap < 1 ? 1 : cap;
+  static const int occ = resident_blocks_per_cu(k_gemv_t2<true>);
+  const int bx = tiled_dot_grid_x(n, ntile, occ);
   double* part = nullptr;
   if (int rc = scratch_doubles(s, (size_t)bx * 2 * k, &part)) return rc;
   const bool vec = aligned16(V) && aligned16(r) && aligned16(r2) && (ld % 4 == 0);
@@ -1606,9 +1655,8 @@ int trk_gemv_tn(const float* V, int64_t ld, int k, int64_t n, const float* const
   }
   hipStream_t s = (hipStream_t)st;
   const int ntile = ceil_div(k, JT);
-  int bx = stream_grid(n);
-  const int cap = (cu_count() * 8 + ntile - 1) / ntile;
-  if (bx > cap) bx = cap < 1 ? 1 : cap;
+  static const int occ3 = resident_blocks_per_cu(k_gemv_tr<true, 3>), occ4 = resident_blocks_per_cu(k_gemv_tr<true, 4>);
+  const int bx = tiled_dot_grid_x(n, ntile, n_rhs == 3 ? occ3 : occ4);
   double* part = nullptr;
   if (int rc = scratch_doubles(s, (size_t)bx * n_rhs * k, &part)) return rc;
   dim3 grid(bx, ntile);
@@ -1629,9 +1677,17 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, do
   const int grid = stream_grid(n);
   double* part = nullptr;
   if (sumsq)
-    if (int rc = scratch_doubles(s, grid, &part)) return rc;
+    if (int rc = scratch_doubles(s, (size_t)cu_count() * 16, &part)) return rc;
   const bool vec = aligned16(V) && aligned16(out) && (ld % 4 == 0) && (!base || aligned16(base));
-#define GN(HB, SS, VC) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, y, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n))
+  static const int U = env_int("TRK_GEMVN_UNROLL", 8);        // measured, tools/gemv_micro.py: 4 -> 5.4-5.8 TB/s, 8 (+ 8 blocks per CU) -> 6.2-6.4
+  static const int gmul = env_int("TRK_GEMVN_GRID", 8);          // blocks per CU (0: stream_grid's 4)
+  const int grid_n = gmul > 0 ? (int)std::min<int64_t>((n + (int64_t)NT * 4 - 1) / ((int64_t)NT * 4), (int64_t)cu_count() * gmul) : grid;
+#define GN(HB, SS, VC)                                                                                                            \
+  do {                                                                                                                            \
+    if (U >= 16) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC, false, 16>), dim3(grid_n), dim3(NT), 0, s, V, ld, k, n, y, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n)); \
+    else if (U >= 8) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC, false, 8>), dim3(grid_n), dim3(NT), 0, s, V, ld, k, n, y, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n)); \
+    else hipLaunchKernelGGL((k_gemv_n<HB, SS, VC, false, 4>), dim3(grid_n), dim3(NT), 0, s, V, ld, k, n, y, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n)); \
+  } while (0)
   if (base) {
     if (sumsq) { if (vec) GN(true, true, true); else GN(true, true, false); }
     else       { if (vec) GN(true, false, true); else GN(true, false, false); }
@@ -1641,7 +1697,7 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, do
   }
 #undef GN
   TRK_LAUNCH_CHECK();
-  if (sumsq) return finalize_sums(part, grid, 1, 1, sumsq, s);
+  if (sumsq) return finalize_sums(part, grid_n, 1, 1, sumsq, s);
   return TRK_OK;
 }
 

@@ -146,12 +146,17 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     # the two Gram-Schmidt sweeps per iteration by Gram matrix (two passes over V instead of three / four)
     gs_gram = GramSchmidtByGram(eng, V, kmax) if (hasattr(eng, "cgs_coeffs") and kwargs.get("gram_sweeps", True)) else None
     lams, res, lam, x_dev, its = [], [], None, None, 0
+    unit_wf = (pnorm == 2)
+    if unit_wf:
+        wf.fill_(1.0)
     for ii in range(n_iter):
         its = ii
         k = V.k
         kk = k * k
         # weights from the current iterate (:56-57, :60, :93); ax = A x, lx = L x of it
-        eng.mm_weights(ax, bv, epsilon, pnorm, wf)
+        # (pnorm = 2: wf = ((A x - b)^2 + eps^2)^0 is 1.0 exactly in every entry, every iteration — set once, before the loop)
+        if not unit_wf:
+            eng.mm_weights(ax, bv, epsilon, pnorm, wf)
         if iso:
             eng.isotv_weights(x_cur if x_dev is None else x_dev, iso_nx, iso_nt, lx[2 * n:], epsilon, qnorm, wr)
         elif gs:
@@ -212,7 +217,10 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             res_a = tm
             if not last:
                 A.apply(x_dev, out=ax)                                                # for the next weights (:56)
-        eng.mul_diff(wf, res_a, bv, tm)
+        if unit_wf:
+            eng.axpby(1.0, res_a, -1.0, bv, tm)                                       # wf = 1: the same bits as 1.0 * (A x - b)
+        else:
+            eng.mul_diff(wf, res_a, bv, tm)
         A.apply(tm, out=r, transpose=True)
         if fusedL:
             L.tv_grad(x_dev, wr, r, float(lam), out=rb)                               # r + lam L^T (wr * (L x)), one pass
