@@ -473,27 +473,27 @@ int trk_halo_exchange(trk_comm* comm, const float* send, int send_to, float* rec
 /* ---- CGLS with ONE all-reduce per iteration, for unknowns spread over ranks (csrc/cgls_sharded.hip) ----
  * The recurrence of trips/solvers/CGLS.py:56-80 needs two global sums per iteration, ||A p||^2 (:61) and ||A^T r||^2 (:70), the
  * second depending on the first.  With q = A t_{k-1} formed explicitly, w_k = A p_k = q + beta w_{k-1} and
- *   delta_k = ||w_k||^2 = ||q||^2 + 2 beta <q, w_{k-1}> + beta^2 delta_{k-1},   beta = gamma_{k-1} / gamma_{k-2},
- * so G3 = {gamma_{k-1}, ||q||^2, <q, w_{k-1}>} — all from vectors the previous iteration left — is the one exchange, and the rest
- * of the iteration is local.  Same operator applies, same iterates in exact arithmetic.
+ *   delta_k = ||w_k||^2 = ||q||^2 + 2 beta <q, w_{k-1}> + beta^2 ||w_{k-1}||^2,   beta = gamma_{k-1} / gamma_{k-2},
+ * so G4 = {gamma_{k-1}, ||q||^2, <q, w_{k-1}>, ||w_{k-1}||^2} — all from vectors the previous iteration left — is the one
+ * exchange, and the rest of the iteration is local.  Same operator applies, same iterates in exact arithmetic.
  *
- * trk_dot_pair: out2[0] = sum q*q, out2[1] = sum q*w (w may be NULL: 0) — local sums, one pass, fp64 accumulation.
- * trk_cgls_sharded_update: from the all-reduced G3 and *delta_prev, *gamma_prev (= delta_{k-1}, gamma_{k-2}; unused when `first`):
+ * trk_dot_pair: out3[0] = sum q*q, out3[1] = sum q*w, out3[2] = sum w*w (w may be NULL: 0, 0) — local sums, one pass, fp64.
+ * trk_cgls_sharded_update: from the all-reduced G4 and *gamma_prev (= gamma_{k-2}; unused when `first`):
  *   p = t + beta p; w = q + beta w (first: p = t, w = q); x_new = x + alpha p; r -= alpha w, alpha = gamma_{k-1} / delta_k;
  *   *publish_delta = delta_k, *publish_gamma = gamma_{k-1}; the rank's share of ||x_new||^2, ||alpha p||^2, ||x_new - x_true||^2
  *   (CGLS.py:76-80) as *n_blocks x 3 block partials (trk_finalize_batched, then one sum over the ranks after the solve).
- * trk_cgls_iterate_sharded: n_iters iterations enqueued by one call — q = A t; trk_dot_pair; trk_allreduce_f64(comm, G3, 3) (skipped
- *   for comm = NULL); trk_cgls_sharded_update; t = A^T r with the rank's ||t||^2 into G3[0].  Scalar layout as trk_cgls_iterate:
+ * trk_cgls_iterate_sharded: n_iters iterations enqueued by one call — q = A t; trk_dot_pair; trk_allreduce_f64(comm, G4, 4) (skipped
+ *   for comm = NULL); trk_cgls_sharded_update; t = A^T r with the rank's ||t||^2 into G4[0].  Scalar layout as trk_cgls_iterate:
  *   S[0] = gamma_0, S[5k] = delta_k, S[5k+1] = gamma_k (gamma_k is published by iteration k+1: after the last iteration it is
- *   still the LOCAL sum in G3[0]).  Before the first iteration: r = b - A x0, t = A^T r, G3[0] = the rank's ||t||^2. */
-int trk_dot_pair(const float* q, const float* w, int64_t n, double* out2, trk_stream stream);
-int trk_cgls_sharded_update(int64_t n, int64_t m, const double* G3, const double* delta_prev, const double* gamma_prev,
-                            int first, const float* x, float* p, const float* t, float* x_new, float* r, const float* q,
-                            float* w, const float* x_true, double* publish_delta, double* publish_gamma,
-                            double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
+ *   still the LOCAL sum in G4[0]).  Before the first iteration: r = b - A x0, t = A^T r, G4[0] = the rank's ||t||^2. */
+int trk_dot_pair(const float* q, const float* w, int64_t n, double* out3, trk_stream stream);
+int trk_cgls_sharded_update(int64_t n, int64_t m, const double* G4, const double* gamma_prev, int first, const float* x,
+                            float* p, const float* t, float* x_new, float* r, const float* q, float* w, const float* x_true,
+                            double* publish_delta, double* publish_gamma, double* norm_partials, int capacity_blocks,
+                            int* n_blocks, trk_stream stream);
 int trk_cgls_iterate_sharded(trk_op* A, trk_comm* comm, int k_first, int n_iters, float* p, float* r, float* t, float* q,
                              float* w, float* X, int64_t x_ld, int keep_history, const float* x_prev, const float* x_true,
-                             double* S, double* G3, double* NP, int np_capacity_blocks, int* n_np_inout, trk_stream stream);
+                             double* S, double* G4, double* NP, int np_capacity_blocks, int* n_np_inout, trk_stream stream);
 
 #ifdef __cplusplus
 }

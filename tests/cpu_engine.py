@@ -177,15 +177,14 @@ class CpuEngine:
         _put(sums, [np.dot(xn64, xn64), np.dot(d.astype(np.float64), d.astype(np.float64)), e])
 
     # CGLS with one all-reduce per iteration (csrc/cgls_sharded.hip restated)
-    def dot_pair(self, q, w, out2):
+    def dot_pair(self, q, w, out3):
         qq = _d(q)
-        _put(out2, [np.dot(qq, qq), 0.0 if w is None else np.dot(qq, _d(w))])
+        _put(out3, [np.dot(qq, qq), 0.0 if w is None else np.dot(qq, _d(w)), 0.0 if w is None else np.dot(_d(w), _d(w))])
 
-    def cgls_sharded_update(self, G3, delta_prev, gamma_prev, first, x, p, t, x_new, r, q, w, x_true, pub_delta, pub_gamma,
-                            partials, capacity):
-        g, qq, qw = _get(G3, 3)
+    def cgls_sharded_update(self, G4, gamma_prev, first, x, p, t, x_new, r, q, w, x_true, pub_delta, pub_gamma, partials, capacity):
+        g, qq, qw, ww = _get(G4, 4)
         beta = 0.0 if first else g / _get(gamma_prev)
-        delta = qq if first else qq + 2.0 * beta * qw + beta * beta * _get(delta_prev)
+        delta = qq if first else qq + 2.0 * beta * qw + beta * beta * ww
         b32, a32 = np.float32(beta), np.float32(g / delta)
         pn = t.numpy().copy() if first else (b32 * p.numpy() + t.numpy()).astype(np.float32)
         wn = q.numpy().copy() if first else (b32 * w.numpy() + q.numpy()).astype(np.float32)

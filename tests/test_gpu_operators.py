@@ -299,7 +299,15 @@ def test_fanbeam_against_the_astra_outputs_the_reference_holds():
     A, _, A_mis = Tomography(CommitCrime=False).forward_Op(N, N, views)
     x = g["phantom"].reshape(-1)
     dense = A @ np.eye(N * N)
-    out = check_against_demo_images(g, A_mis @ x, dense)
+    # (through A, not A_mis: ASTRA computes in float32, where the reference's 1e-8 angle shift cannot move a ray off a pixel
+    #  boundary — 1.6e-7 pixels at most, under half a float32 spacing at 15.5 — so on the two boundary rays the reference's A_mis IS
+    #  its A, and the image shows the tie rule's value (11.5 and 6.0) on both; the engine resolves 1e-9 pixels and its A_mis splits
+    #  those two rays between the neighbouring columns / rows, 10.75 and 8.0 on this phantom — everywhere else the two agree to 1e-7)
+    out = check_against_demo_images(g, A @ x, dense)
+    s_mis = (A_mis @ x).reshape(views, -1)
+    mask = np.ones_like(s_mis, dtype=bool)
+    mask[0, 22] = mask[15, 22] = False
+    assert relerr(s_mis[mask], (A @ x).reshape(views, -1)[mask]) < 1e-6
     assert out["sino_corr"] > 0.9998 and out["dense_corr"] > 0.98, out
     Ao = O.FanBeam2D(N, np.linspace(0, np.pi, views, endpoint=False))
     Mo = np.asarray(Ao.matrix().todense())

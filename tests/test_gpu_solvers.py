@@ -467,3 +467,39 @@ def test_hybrid_lsqr_pipelined_loop_equals_the_plain_one(reg):
     x2, i2 = Hybrid_LSQR(A, b, 12, reg, history=False, **kw)
     x3, i3 = Hybrid_LSQR(A, b, 12, reg, history=False, async_search=False, steps_ahead=1, **kw)
     assert np.array_equal(x2, x3) and i2["regParam_history"] == i3["regParam_history"]
+
+
+def arnoldi_orthogonality(N=256, steps=100, by_gram=True):
+    """max |V^T V - I| (float64, on the host) after `steps` Arnoldi steps on the 9 x 9 sigma-3 blur of an N x N image, and the
+    smallest h_{k+1,k} / ||A v_k|| met on the way (how much of A v_k the orthogonalisation removed)."""
+    import torch
+    from trips_py_amd.krylov import ArnoldiState
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import gauss_psf
+    A = Blur2D(gauss_psf((9, 9), (3, 3))[0], N, N)
+    dev = A.engine.device
+    g = torch.Generator(device=dev).manual_seed(11)
+    xt = torch.rand(N * N, device=dev, generator=g)
+    b = A.apply(xt)
+    b = b + 0.01 * torch.randn(N * N, device=dev, generator=g) * b.norm() / N
+    ar = ArnoldiState(A, b, steps, by_gram=by_gram)
+    ratio = 1.0
+    for _ in range(steps):
+        col = ar.step()
+        ratio = min(ratio, float(col[-1] / np.linalg.norm(col)))
+    V = ar.V.data[:ar.V.k].double()
+    G = (V @ V.T).cpu().numpy()
+    return float(np.abs(G - np.eye(G.shape[0])).max()), ratio, ar.H()
+
+
+def test_arnoldi_orthogonality_by_gram_vs_sweeps():
+    """Arnoldi's two Gram-Schmidt sweeps as one pair of passes (krylov.GramSchmidtByGram, the default) against sweep by sweep:
+    in exact arithmetic the same vector; in fp32 the second sweep of the literal form also removes the rounding error of the first
+    subtraction, which matters when A v_k lies almost inside the span (strong cancellation).  Measured on the ill-conditioned blur
+    (100 steps, 256^2): both stay far inside north_star's 1e-5, and the Hessenberg matrices agree."""
+    loss_g, ratio_g, Hg = arnoldi_orthogonality(by_gram=True)
+    loss_s, ratio_s, Hs = arnoldi_orthogonality(by_gram=False)
+    print(f"max |V^T V - I|: by Gram {loss_g:.2e} (min h_k+1,k / ||A v_k|| {ratio_g:.3f}), sweep by sweep {loss_s:.2e} ({ratio_s:.3f})")
+    assert loss_s < 2e-6, loss_s
+    assert loss_g < 1e-5, loss_g
+    assert np.abs(Hg - Hs).max() / np.abs(Hs).max() < 1e-5

@@ -4,7 +4,9 @@ The oracle's solver is run (a) as it is and (b) with every operator product roun
 an engine that STORES its vectors in fp32 does to the iteration, with exact (float64) arithmetic everywhere else.  The distance
 between the two runs is a floor for the parity bar of tests/test_gpu_configs_fullsize.py: un-reorthogonalised Golub-Kahan
 (Hybrid_LSQR.py:73-110 via decompositions.py:230-255) amplifies the 6e-8 roundings, GKS's thrice re-orthogonalised basis does not.
-usage: python3 tools/fp32_floor.py c3|c5 [iterations]"""
+`c5cgls`: CGLS (no regularisation) on the C5 data: past semi-convergence (iterate ~25) the recurrence amplifies the roundings by four
+orders of magnitude — what tools/cgls_forms_accuracy.py measures for the engine's two arrangements on the GPU.
+usage: python3 tools/fp32_floor.py c3|c5|c5cgls [iterations]"""
 import os
 import sys
 
@@ -49,7 +51,8 @@ if which == "c3":
     print("per iterate:", " ".join(f"{rel(hb, ha):.1e}" for ha, hb in zip(ia["xHistory"], ib["xHistory"])))
     print("relError max rel. difference:", float(np.max(np.abs(np.array(ib["relError"]) / np.array(ia["relError"]) - 1))))
 else:
-    its = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+    cgls = which == "c5cgls"
+    its = int(sys.argv[2]) if len(sys.argv) > 2 else (60 if cgls else 8)
     N, nt, na = 256, 32, 15
     angs = [np.deg2rad(t + 12.0 * np.arange(na)) for t in range(nt)]
     Fo = O.BlockDiag([O.Radon2D(N, a) for a in angs])
@@ -65,6 +68,13 @@ else:
     b = Fo @ xt
     e = rng.standard_normal(b.size)
     b = (b + 0.01 * np.linalg.norm(b) / np.linalg.norm(e) * e).astype(np.float32).astype(np.float64)
+    if cgls:
+        x0 = np.zeros((Fo.shape[1], 1))
+        xa, ia = O.cgls(Fo, b.reshape(-1, 1), x0, its, 0, xt.reshape(-1, 1))
+        xb, ib = O.cgls(Rounded(Fo), b.reshape(-1, 1), x0, its, 0, xt.reshape(-1, 1))
+        print(f"C5 CGLS {its} iterations: final x fp32-rounded products vs float64: {rel(xb, xa):.3e}")
+        print("per iterate:", " ".join(f"{rel(hb, ha):.1e}" for ha, hb in zip(ia["xHistory"], ib["xHistory"])))
+        sys.exit(0)
     xa, ia = O.gks(Fo, b.reshape(-1, 1), Lo, 3, its, 1e-2, xt.reshape(-1, 1))
     xb, ib = O.gks(Rounded(Fo), b.reshape(-1, 1), Rounded(Lo), 3, its, 1e-2, xt.reshape(-1, 1))
     print(f"C5 GKS {its} iterations: final x fp32-rounded products vs float64: {rel(xb, xa):.3e}")

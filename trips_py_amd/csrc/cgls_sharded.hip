@@ -3,9 +3,10 @@
 //
 // Per rank the work of a C5 iteration is a few microseconds of kernels; what separates them is the latency of the collectives, so
 // the two reductions are merged (the Chronopoulos-Gear arrangement of the same recurrence): with q = A t_{k-1} formed explicitly,
-//     w_k = A p_k = q + beta w_{k-1},      delta_k = ||w_k||^2 = ||q||^2 + 2 beta <q, w_{k-1}> + beta^2 delta_{k-1},
-// so gamma_{k-1} = ||t_{k-1}||^2, ||q||^2 and <q, w_{k-1}> — all formed from vectors iteration k-1 left behind — travel in one
-// all-reduce of three doubles, and everything after it is local:
+//     w_k = A p_k = q + beta w_{k-1},      delta_k = ||w_k||^2 = ||q||^2 + 2 beta <q, w_{k-1}> + beta^2 ||w_{k-1}||^2,
+// so gamma_{k-1} = ||t_{k-1}||^2, ||q||^2, <q, w_{k-1}> and ||w_{k-1}||^2 — all formed from vectors iteration k-1 left behind —
+// travel in one all-reduce of four doubles, and everything after it is local (||w_{k-1}||^2 is summed from the vector itself, not
+// carried over as delta_{k-1}: the expansion is then that of the very w_k the update forms, and no error compounds through beta^2):
 //     beta = gamma_{k-1} / gamma_{k-2} (0 for k = 1);  p_k = t_{k-1} + beta p_{k-1};  w_k = q + beta w_{k-1};
 //     alpha = gamma_{k-1} / delta_k;  x_k = x_{k-1} + alpha p_k;  r_k = r_{k-1} - alpha w_k;  t_k = A^T r_k.
 // Same operator applies per iteration (one A, one A^T), same iterates in exact arithmetic; in floating point w_k carries the
@@ -31,12 +32,12 @@ inline int grid_for(int64_t n) {
   return want < 1 ? 1 : (int)want;
 }
 
-// partials[block][2] = sum q*q, sum q*w  (w == NULL: the second sum is 0)
+// partials[block][3] = sum q*q, sum q*w, sum w*w  (w == NULL: the last two are 0)
 template <bool VEC>
 __global__ __launch_bounds__(NT) void k_dot_pair(const float* __restrict__ q, const float* __restrict__ w, int64_t n,
                                                  double* __restrict__ partials) {
-  __shared__ double lds[(NT / 64) * 2];
-  double acc[2] = {0.0, 0.0};
+  __shared__ double lds[(NT / 64) * 3];
+  double acc[3] = {0.0, 0.0, 0.0};
   const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
   int64_t tail = 0;
   if (VEC) {
@@ -48,32 +49,37 @@ __global__ __launch_bounds__(NT) void k_dot_pair(const float* __restrict__ q, co
       if (w) {
         const float4 b = ld4(w, i);
         acc[1] += (double)a.x * b.x + (double)a.y * b.y + (double)a.z * b.z + (double)a.w * b.w;
+        acc[2] += (double)b.x * b.x + (double)b.y * b.y + (double)b.z * b.z + (double)b.w * b.w;
       }
     }
   }
   for (int64_t i = tail + tid; i < n; i += nth) {
     const double a = q[i];
     acc[0] += a * a;
-    if (w) acc[1] += a * (double)w[i];
+    if (w) {
+      const double b = w[i];
+      acc[1] += a * b;
+      acc[2] += b * b;
+    }
   }
-  const double s = block_sum_many<NT, 2>(acc, lds);
-  if (threadIdx.x < 2) partials[blockIdx.x * 2 + threadIdx.x] = s;
+  const double s = block_sum_many<NT, 3>(acc, lds);
+  if (threadIdx.x < 3) partials[blockIdx.x * 3 + threadIdx.x] = s;
 }
 
-// The local half of the merged iteration.  G = {gamma_{k-1}, ||q||^2, <q, w_{k-1}>} summed over the ranks; dprev = delta_{k-1},
+// The local half of the merged iteration.  G = {gamma_{k-1}, ||q||^2, <q, w_{k-1}>, ||w_{k-1}||^2} summed over the ranks;
 // gprev = gamma_{k-2} (unused when first).  Every thread evaluates the three scalars itself from the same five doubles (grid-
 // uniform loads), block 0 publishes delta_k and gamma_{k-1}.  partials[block][3] = ||x_k||^2, ||alpha p_k||^2, ||x_k - x_true||^2.
 template <bool HAS_XT, bool VEC>
 __global__ __launch_bounds__(NT) void k_cgls_sharded_update(int64_t n, int64_t m, const double* __restrict__ G,
-                                                            const double* dprev, const double* gprev, int first,
+                                                            const double* gprev, int first,
                                                             const float* x, float* p, const float* __restrict__ t, float* x_new,
                                                             float* r, const float* __restrict__ q, float* w,
                                                             const float* __restrict__ x_true, double* pub_delta,
                                                             double* pub_gamma, double* __restrict__ partials) {
   __shared__ double lds[(NT / 64) * 3];
-  const double g = G[0], qq = G[1], qw = G[2];
+  const double g = G[0], qq = G[1], qw = G[2], ww = G[3];
   const double beta_d = first ? 0.0 : g / *gprev;
-  const double delta = first ? qq : qq + 2.0 * beta_d * qw + beta_d * beta_d * *dprev;
+  const double delta = first ? qq : qq + 2.0 * beta_d * qw + beta_d * beta_d * ww;
   const float beta = (float)beta_d, alpha = (float)(g / delta);
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     *pub_delta = delta;
@@ -146,27 +152,26 @@ __global__ __launch_bounds__(NT) void k_cgls_sharded_update(int64_t n, int64_t m
 
 extern "C" {
 
-int trk_dot_pair(const float* q, const float* w, int64_t n, double* out2, trk_stream st) {
-  TRK_REQUIRE(q && out2 && n >= 0, "trk_dot_pair: bad argument");
+int trk_dot_pair(const float* q, const float* w, int64_t n, double* out3, trk_stream st) {
+  TRK_REQUIRE(q && out3 && n >= 0, "trk_dot_pair: bad argument");
   hipStream_t s = (hipStream_t)st;
   const int grid = grid_for(n);
   double* part = nullptr;
-  if (int rc = scratch_doubles(s, (size_t)grid * 2, &part)) return rc;
+  if (int rc = scratch_doubles(s, (size_t)grid * 3, &part)) return rc;
   if (aligned16(q) && (!w || aligned16(w)))
     hipLaunchKernelGGL((k_dot_pair<true>), dim3(grid), dim3(NT), 0, s, q, w, n, part);
   else
     hipLaunchKernelGGL((k_dot_pair<false>), dim3(grid), dim3(NT), 0, s, q, w, n, part);
   TRK_LAUNCH_CHECK();
-  return finalize_sums(part, grid, 2, 2, out2, s);
+  return finalize_sums(part, grid, 3, 3, out3, s);
 }
 
-int trk_cgls_sharded_update(int64_t n, int64_t m, const double* G3, const double* delta_prev, const double* gamma_prev,
-                            int first, const float* x, float* p, const float* t, float* x_new, float* r, const float* q,
+int trk_cgls_sharded_update(int64_t n, int64_t m, const double* G4, const double* gamma_prev, int first, const float* x, float* p, const float* t, float* x_new, float* r, const float* q,
                             float* w, const float* x_true, double* publish_delta, double* publish_gamma,
                             double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream st) {
-  TRK_REQUIRE(G3 && x && p && t && x_new && r && q && w && publish_delta && publish_gamma && norm_partials && n_blocks,
+  TRK_REQUIRE(G4 && x && p && t && x_new && r && q && w && publish_delta && publish_gamma && norm_partials && n_blocks,
               "trk_cgls_sharded_update: NULL argument");
-  TRK_REQUIRE(first || (delta_prev && gamma_prev), "trk_cgls_sharded_update: delta_prev / gamma_prev needed after the first step");
+  TRK_REQUIRE(first || gamma_prev, "trk_cgls_sharded_update: gamma_prev needed after the first step");
   TRK_REQUIRE(n >= 0 && m >= 0, "trk_cgls_sharded_update: negative size");
   TRK_REQUIRE(x_new != p && x_new != t, "trk_cgls_sharded_update: x_new must not alias p or t");
   hipStream_t s = (hipStream_t)st;
@@ -176,7 +181,7 @@ int trk_cgls_sharded_update(int64_t n, int64_t m, const double* G3, const double
   const bool vec = aligned16(x) && aligned16(p) && aligned16(t) && aligned16(x_new) && aligned16(r) && aligned16(q) &&
                    aligned16(w) && (!x_true || aligned16(x_true));
 #define SU(XT, VC)                                                                                                      \
-  hipLaunchKernelGGL((k_cgls_sharded_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, G3, delta_prev, gamma_prev, first, x, \
+  hipLaunchKernelGGL((k_cgls_sharded_update<XT, VC>), dim3(grid), dim3(NT), 0, s, n, m, G4, gamma_prev, first, x, \
                      p, t, x_new, r, q, w, x_true, publish_delta, publish_gamma, norm_partials)
   if (x_true) { if (vec) SU(true, true); else SU(true, false); }
   else        { if (vec) SU(false, true); else SU(false, false); }
@@ -187,8 +192,8 @@ int trk_cgls_sharded_update(int64_t n, int64_t m, const double* G3, const double
 
 int trk_cgls_iterate_sharded(trk_op* A, trk_comm* comm, int k_first, int n_iters, float* p, float* r, float* t, float* q,
                              float* w, float* X, int64_t x_ld, int keep_history, const float* x_prev, const float* x_true,
-                             double* S, double* G3, double* NP, int np_capacity_blocks, int* n_np_inout, trk_stream stream) {
-  TRK_REQUIRE(A && p && r && t && q && w && X && x_prev && S && G3 && NP && n_np_inout,
+                             double* S, double* G4, double* NP, int np_capacity_blocks, int* n_np_inout, trk_stream stream) {
+  TRK_REQUIRE(A && p && r && t && q && w && X && x_prev && S && G4 && NP && n_np_inout,
               "trk_cgls_iterate_sharded: NULL argument");
   TRK_REQUIRE(k_first >= 1 && n_iters >= 0, "trk_cgls_iterate_sharded: need k_first >= 1, n_iters >= 0");
   const int64_t m = A->rows, n = A->cols;
@@ -200,16 +205,16 @@ int trk_cgls_iterate_sharded(trk_op* A, trk_comm* comm, int k_first, int n_iters
     float* x_new = X + (int64_t)(keep_history ? (k - 1) : ((k - 1) & 1)) * x_ld;
     int rc = trk_op_apply(A, 0, t, 0, q, 0, 1, nullptr, stream);                                   // q = A t_{k-1}
     if (rc) return rc;
-    rc = trk_dot_pair(q, k == 1 ? nullptr : w, m, G3 + 1, stream);                                 // ||q||^2, <q, w_{k-1}> (local)
+    rc = trk_dot_pair(q, k == 1 ? nullptr : w, m, G4 + 1, stream);                        // ||q||^2, <q, w_{k-1}>, ||w_{k-1}||^2 (local)
     if (rc) return rc;
     if (comm) {
-      rc = trk_allreduce_f64(comm, G3, 3, stream);                                                 // the iteration's ONE exchange
+      rc = trk_allreduce_f64(comm, G4, 4, stream);                                                 // the iteration's ONE exchange
       if (rc) return rc;
     }
-    rc = trk_cgls_sharded_update(n, m, G3, row - 5, gprev, k == 1, x_prev, p, t, x_new, r, q, w, x_true, row, gpub,
+    rc = trk_cgls_sharded_update(n, m, G4, gprev, k == 1, x_prev, p, t, x_new, r, q, w, x_true, row, gpub,
                                  NP + 3 * (int64_t)n_np * (k - 1), np_capacity_blocks, &n_np, stream);
     if (rc) return rc;
-    rc = trk_op_apply(A, 1, r, 0, t, 0, 1, G3, stream);                                            // t_k = A^T r_k, local ||t_k||^2
+    rc = trk_op_apply(A, 1, r, 0, t, 0, 1, G4, stream);                                            // t_k = A^T r_k, local ||t_k||^2
     if (rc) return rc;
     x_prev = x_new;
   }

@@ -175,6 +175,6 @@ def arnoldi_update(A, V, H):
         Hm = np.asarray(H, dtype=np.float64)
         st.Hcols = [] if Hm.ndim < 2 else [Hm[:j + 2, j].copy() for j in range(Hm.shape[1])]
         st.beta0 = None
-        st.gram, st.capacity = None, None          # a cold start from host arrays: sweep by sweep (the basis may grow)
+        st.gram, st.capacity, st.by_gram = None, None, False   # a cold start from host arrays: sweep by sweep (the basis may grow)
     st.step()
     return KrylovArrays(st.V.numpy(), st), st.H()

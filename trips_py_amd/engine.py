@@ -502,15 +502,14 @@ class HipEngine:
         return cg.value, cn.value
 
     # ------------------------------------------------------------------ CGLS with one all-reduce per iteration (cgls_sharded.hip)
-    def dot_pair(self, q, w, out2):
-        """out2[0] = <q, q>, out2[1] = <q, w> (w None: 0): this rank's sums."""
-        _lib.check(self.lib.trk_dot_pair(q.data_ptr(), None if w is None else w.data_ptr(), q.numel(), _ptr(out2), self.stream()),
+    def dot_pair(self, q, w, out3):
+        """out3[0] = <q, q>, out3[1] = <q, w>, out3[2] = <w, w> (w None: 0, 0): this rank's sums."""
+        _lib.check(self.lib.trk_dot_pair(q.data_ptr(), None if w is None else w.data_ptr(), q.numel(), _ptr(out3), self.stream()),
                    "trk_dot_pair")
 
-    def cgls_sharded_update(self, G3, delta_prev, gamma_prev, first, x, p, t, x_new, r, q, w, x_true, pub_delta, pub_gamma,
-                            partials, capacity):
+    def cgls_sharded_update(self, G4, gamma_prev, first, x, p, t, x_new, r, q, w, x_true, pub_delta, pub_gamma, partials, capacity):
         n = ctypes.c_int(0)
-        rc = self.lib.trk_cgls_sharded_update(x.numel(), r.numel(), _ptr(G3), _ptr(delta_prev), _ptr(gamma_prev), int(bool(first)),
+        rc = self.lib.trk_cgls_sharded_update(x.numel(), r.numel(), _ptr(G4), _ptr(gamma_prev), int(bool(first)),
                                               x.data_ptr(), p.data_ptr(), t.data_ptr(), x_new.data_ptr(), r.data_ptr(), q.data_ptr(),
                                               w.data_ptr(), None if x_true is None else x_true.data_ptr(), _ptr(pub_delta),
                                               _ptr(pub_gamma), _ptr(partials), int(capacity), ctypes.byref(n), self.stream())

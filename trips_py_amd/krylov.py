@@ -400,8 +400,12 @@ class GramSchmidtByGram:
 class ArnoldiState:
     """Arnoldi A V_k = V_{k+1} H_k (decompositions.py:207-228): orthogonalisation against ALL previous vectors."""
 
-    def __init__(self, A, b, capacity):
+    def __init__(self, A, b, capacity, by_gram=True):
+        """by_gram: the two Gram-Schmidt sweeps of a step as ONE pair of passes over the basis (GramSchmidtByGram) where the
+        engine has the kernels; False: sweep by sweep (two pairs of passes; the second sweep then also removes the rounding error
+        of the first subtraction — see tests/test_gpu_solvers.py::test_arnoldi_orthogonality_by_gram_vs_sweeps for what that buys)."""
         self.A, self.eng = A, A.engine
+        self.by_gram = bool(by_gram)
         m, n = A.shape
         if m != n:
             raise ValueError("Arnoldi can not be used. The operator is not square")
@@ -427,7 +431,7 @@ class ArnoldiState:
         slot = V.next_slot()
         # two Gram-Schmidt sweeps (= the reference's modified Gram-Schmidt to rounding), written straight into the next slot with
         # ||.||^2 in S[0]: by Gram matrix (two passes over the basis) where the engine has the kernels, else sweep by sweep
-        if self.gram is None and hasattr(eng, "cgs_coeffs") and self.capacity is not None:
+        if self.gram is None and self.by_gram and hasattr(eng, "cgs_coeffs") and self.capacity is not None:
             self.gram = GramSchmidtByGram(eng, V, self.capacity + 1)
         if self.gram is not None:
             # the combined coefficients of both sweeps go to S[1 .. 1+k) (column k of H); S[1+k .. 1+2k) stays zero

@@ -208,7 +208,7 @@ class CGLSRunSharded(CGLSRun):
         self.n_np = 0
         self.r, self.t, self.w, self.p, self.q = eng.empty(m), eng.empty(n), eng.zeros(m), eng.zeros(n), eng.empty(m)
         self.S = eng.scalars(5 * (max_iter + 1))
-        self.G = eng.scalars(4)                       # [gamma_{k-1}, ||q||^2, <q, w_{k-1}>]: the one exchange of an iteration
+        self.G = eng.scalars(4)                       # [gamma_{k-1}, ||q||^2, <q, w_{k-1}>, ||w_{k-1}||^2]: an iteration's one exchange
         self.dist = eng.world > 1
         self.k = 0
         self.allreduces = 0
@@ -226,9 +226,9 @@ class CGLSRunSharded(CGLSRun):
         x_new = self.hist.row(k - 1)
         A.apply(self.t, out=self.q)                                          # q = A t_{k-1}
         eng.dot_pair(self.q, None if k == 1 else self.w, G.ref(1))
-        eng.allreduce(G, 0, 3)               # the iteration's one exchange (a no-op on one rank)
+        eng.allreduce(G, 0, 4)               # the iteration's one exchange (a no-op on one rank)
         self.allreduces += self.dist
-        self.n_np = eng.cgls_sharded_update(G.ref(0), S.ref(b - 5), S.ref(0) if k <= 2 else S.ref(b - 9), k == 1, self.x_cur, self.p,
+        self.n_np = eng.cgls_sharded_update(G.ref(0), S.ref(0) if k <= 2 else S.ref(b - 9), k == 1, self.x_cur, self.p,
                                             self.t, x_new, self.r, self.q, self.w, self.xt, S.ref(b),
                                             S.ref(0) if k == 1 else S.ref(b - 4), self.NP.ref(3 * self.n_np * (k - 1)), self.NPC)
         A.apply(self.r, out=self.t, transpose=True, sumsq=G.ref(0))          # t_k = A^T r_k, this rank's ||t_k||^2

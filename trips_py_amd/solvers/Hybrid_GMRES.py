@@ -27,7 +27,7 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
     fmt = Formatter(b)
     xt = None if x_true is None else eng.to_vec(x_true, n)
 
-    ar = ArnoldiState(A, b, n_iter)
+    ar = ArnoldiState(A, b, n_iter, by_gram=kwargs.get("gram_sweeps", True))
     bv = eng.to_vec(b, m) if (isinstance(regparam, str) and regparam == "dp") else None
     Hs = History(eng, kwargs.get("history", True), max(1, n_iter), n, "Hybrid_GMRES xHistory")
     Y = eng.scalars(max(1, n_iter))
