@@ -89,6 +89,34 @@ def test_c5_dynamic_32_frames_gks_fullsize():
     assert m["Residual"] < C5_RESIDUAL_BAR, m
 
 
+def test_c5_dynamic_32_frames_cgls_fullsize():
+    """CGLS on the C5 data (what `bench.py` times per rank count), both arrangements — the recurrence as written and the
+    one-all-reduce form of csrc/cgls_sharded.hip — against the float64 oracle at full size: every one of the first 20 iterates
+    within 1e-5 (measured 6e-8 ... 1.1e-6).  Not further: past iterate ~22 un-regularised CGLS on this data amplifies any fp32
+    rounding to 1e-3 — the oracle does it to itself with fp32-rounded products (tools/fp32_floor.py c5cgls, 1.2e-4 at iterate 24,
+    1e-3 from 26 on), and so do both arrangements here (1.8e-3 at iterate 30, tools/cgls_forms_accuracy.py)."""
+    from oracle import cpu_ref as O
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import BlockDiagOp, Radon2DParallel
+    N, nt, na, its = 256, 32, 15, 20
+    angs = [np.deg2rad(t + 12.0 * np.arange(na)) for t in range(nt)]
+    F = BlockDiagOp([Radon2DParallel(N, a) for a in angs])
+    Fo = O.BlockDiag([O.Radon2D(N, a) for a in angs])
+    rng = np.random.default_rng(0)
+    xt = rng.random(F.shape[1])
+    b = Fo @ xt
+    e = rng.standard_normal(b.size)
+    b = (b + 0.01 * np.linalg.norm(b) / np.linalg.norm(e) * e).astype(np.float32).astype(np.float64)
+    x0 = np.zeros(F.shape[1])
+    xo, io = O.cgls(Fo, b.reshape(-1, 1), x0.reshape(-1, 1), its, 0, xt.reshape(-1, 1))
+    for kw in ({"one_reduction": False}, {"one_reduction": True}):
+        x, info = S.CGLS(F, b, x0, its, 0, xt, **kw)
+        d = [relerr(h, ho) for h, ho in zip(info["xHistory"], io["xHistory"])]
+        assert max(d) < 1e-5, (kw, d)
+        # relResidual is the norm of a DIFFERENCE of consecutive iterates over ||x||: it carries the iterates' 1e-6 many times over
+        assert np.allclose(info["relError"], io["relError"], rtol=1e-5) and np.allclose(info["relResidual"], io["relResidual"], rtol=2e-3), kw
+
+
 def test_c4_mmgks_tv_1024_vs_oracle_and_4096_path_equivalence():
     """C4 (blur + MMGKS with the TV-like l2-l1 functional).  The float64 oracle needs minutes at 4096^2 (two economic QRs of
     16.8 M x k per iteration), so parity against it is taken at 1024^2; at the full 4096^2 the two product forms of the
