@@ -42,6 +42,34 @@ __global__ __launch_bounds__(64 * WAVES) void k_band(const float* __restrict__ x
   }
 }
 
+// Round 3: is the band pattern's deficit HBM CHANNEL ALIASING?  64-row bands of a 4096-float pitch start exactly 1 MiB apart, and
+// all of them read their row t at the same time.  Two ways to break that without changing the work: (a) a padded pitch (the image
+// itself cannot have one — contiguous vectors are the ABI — but the probe can); (b) STAGGER: band b starts its march `b * stag`
+// rows into the band and wraps (a copy can; the blur's sliding window could only with re-priming).
+template <int D>
+__global__ __launch_bounds__(64) void k_band_stag(const float* __restrict__ x, float* __restrict__ y, int pitch, int rows, int spans,
+                                                  int stag) {
+  const int lane = threadIdx.x & 63;
+  const int id = blockIdx.x;
+  const int band = id / spans, span = id % spans;
+  const int r0 = band * rows;
+  const int ph = (band * stag) % rows;
+  const size_t col = (size_t)span * 256 + 4 * lane;
+  f4 buf[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) buf[d] = *reinterpret_cast<const f4*>(x + (size_t)(r0 + (ph + d) % rows) * pitch + col);
+  for (int t = 0; t < rows; t += D) {
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int tt = t + d;
+      const int r = r0 + (ph + tt) % rows;
+      const f4 v = buf[d];
+      if (tt + D < rows) buf[d] = *reinterpret_cast<const f4*>(x + (size_t)(r0 + (ph + tt + D) % rows) * pitch + col);
+      *reinterpret_cast<f4*>(y + (size_t)r * pitch + col) = v;
+    }
+  }
+}
+
 template <typename F>
 float timeit(F f, int reps = 30) {
   hipEvent_t a, b;
@@ -81,5 +109,25 @@ int main() {
   BAND(8, false, 1, 16);
   BAND(16, false, 1, 128);
   BAND(8, false, 4, 16);
+  {
+    float *xp, *yp;
+    const int P = N + 64;                      // padded pitch: band starts 1 MiB + 16 KiB apart
+    hipMalloc(&xp, (size_t)P * N * 4);
+    hipMalloc(&yp, (size_t)P * N * 4);
+    hipMemset(xp, 1, (size_t)P * N * 4);
+#define STAG(D, PITCH, XX, YY, STG)                                                                                         \
+  report("band 64 rows D=" #D " pitch=" #PITCH " stagger=" #STG, timeit([&] {                                              \
+           hipLaunchKernelGGL((k_band_stag<D>), dim3((N / 64) * (N / 256)), dim3(64), 0, 0, XX, YY, PITCH, 64, N / 256, STG); \
+         }))
+    STAG(8, N, x, y, 0);
+    STAG(8, N, x, y, 1);
+    STAG(8, N, x, y, 7);
+    STAG(8, N, x, y, 13);
+    STAG(8, P, xp, yp, 0);
+    STAG(8, P, xp, yp, 7);
+    STAG(16, N, x, y, 0);
+    STAG(16, N, x, y, 7);
+    STAG(16, P, xp, yp, 0);
+  }
   return 0;
 }

@@ -27,6 +27,8 @@ prof)
   f=$(ls -t $O/prof_drv/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/bench_driver_flags_kernel_stats.csv
   cat $O/prof_drv.json | head -c 1200; echo
   head -8 $O/bench_driver_flags_kernel_stats.csv ;;
+bench2)
+  TRK_DIST_BACKEND=gloo TRK_SINGLE_DEVICE=1 timeout 900 python bench.py --gpus 2 --steps 50 --no-cpu-baseline > $O/bench_2ranks_one_gpu_gloo.json 2> $O/bench2.err; echo "bench2 rc=$?"; cat $O/bench_2ranks_one_gpu_gloo.json; tail -3 $O/bench2.err ;;
 parity)
   timeout 900 python3 tools/configs_parity.py > $O/configs_parity.txt 2>&1; echo "parity rc=$?"; cut -c1-400 $O/configs_parity.txt ;;
 esac; done
