@@ -490,12 +490,20 @@ def discrepancy_choose(Q, A, L, b, delta, eta=1.01, L_is_identity=False, explici
     nonsingular).  Returns alpha (=lambda); 0 when the discrepancy is not yet reachable."""
     bfull = b
     bp = Q.T @ b
+    bp0 = bp                                                             # the reference's `b` (= Q^T b) where it forms b - Q Q^T b
     if L_is_identity:
         Anew = A
     else:
         _, SL, VL = sla.svd(L)
-        assert L.shape[0] >= L.shape[1] and SL[-1] != 0, "oracle covers the nonsingular-L branch only (:42-44)"
-        Anew = A @ (VL.T @ np.diag(SL ** (-1.0)))
+        if L.shape[0] >= L.shape[1] and SL[-1] != 0:                     # (:42-44)
+            Anew = A @ (VL.T @ np.diag(SL ** (-1.0)))
+        else:                                                            # (:45-66) null space of L: exact zeros / fewer rows
+            W = (VL[np.where(SL == 0), :].reshape((-1, 1)) if L.shape[0] >= L.shape[1] else VL[L.shape[0] - L.shape[1]:, :].T)
+            Q_AW, R_AW = np.linalg.qr(A @ W, mode="reduced")
+            Q_LT, R_LT = np.linalg.qr(L.T, mode="reduced")
+            P = (np.eye(L.shape[1]) - (W @ np.linalg.inv(R_AW) @ Q_AW.T @ A)) @ Q_LT @ np.linalg.inv(R_LT.T)
+            Anew = A @ P
+            bp = bp - A @ (W @ np.linalg.inv(R_AW) @ Q_AW.T @ bp)
     U, S, _ = sla.svd(Anew)
     sv = S ** 2
     bhat = (U.T @ bp).reshape(-1, 1)
@@ -504,14 +512,14 @@ def discrepancy_choose(Q, A, L, b, delta, eta=1.01, L_is_identity=False, explici
         sv = np.append(sv, np.zeros(r - c))
         testzero = np.linalg.norm(bhat[c - r:, :]) ** 2 - (eta * delta) ** 2
         if explicitProj:
-            testzero += np.linalg.norm(bfull - Q @ bp) ** 2
+            testzero += np.linalg.norm(bfull - Q @ bp0) ** 2
     else:
-        testzero = np.linalg.norm(bfull - Q @ bp) ** 2 - (eta * delta) ** 2
+        testzero = np.linalg.norm(bfull - Q @ bp0) ** 2 - (eta * delta) ** 2
     sv = sv.reshape(-1, 1)
     if not testzero < 0:
         return 0
     beta, it, alpha = 1e-8, 0, None
-    extra = np.linalg.norm(bfull - Q @ bp) ** 2 if explicitProj else 0.0
+    extra = np.linalg.norm(bfull - Q @ bp0) ** 2 if explicitProj else 0.0
     while it < 30 or (it <= 100 and abs(alpha) < 1e-16):
         z = bhat / (sv * beta + 1)
         f = np.linalg.norm(z) ** 2 + extra - (eta * delta) ** 2
@@ -523,6 +531,30 @@ def discrepancy_choose(Q, A, L, b, delta, eta=1.01, L_is_identity=False, explici
         beta = beta_new
         alpha = 1 / beta_new[0, 0]
         it += 1
+    return alpha
+
+
+def discrepancy_truncation(Qtb, n, delta, eta=1.01, dptype="tsvd"):
+    """reg_param/discrepancy_principle.py:100-129 (dptype 'tsvd' / 'tgsvd'): truncation index from bhat = Q^T b, n = L.shape[1]."""
+    bhat = np.asarray(Qtb, dtype=np.float64).reshape(-1, 1)
+    m, alpha = bhat.shape[0], n
+    if dptype == "tsvd":
+        f = np.ones((m, 1))
+        for i in range(n):
+            f[n - (i + 1), ] = 0
+            fvar = np.concatenate((1 - f[:n, ], f[n:, ]))
+            if np.sum((fvar * bhat) ** 2) - (eta * delta) ** 2 < 0:
+                alpha = n - (i + 1)
+            else:
+                break
+        return alpha
+    coeff = np.square(bhat)
+    for i in range(n):
+        coeff[n - (i + 1), ] = 0
+        if np.sum(coeff) - (eta * delta) ** 2 >= 0:
+            alpha = i
+        else:
+            break
     return alpha
 
 

@@ -209,3 +209,24 @@ def test_worker_thread_searches_equal_the_direct_calls(k):
                 assert (lam.value if have.value else None) == want
     finally:
         assert lib.trk_host_worker_destroy(w) == 0
+
+
+def test_discrepancy_principle_corner_branches_against_the_reference():
+    """The product's reduced-input form (R_A, L, Q_A^T b, ||b - Q Q^T b||^2) on the branches the iterative solvers never reach:
+    a regulariser with fewer rows than columns (discrepancy_principle.py:56-66), the direct solvers' 'tsvd' / 'tgsvd' truncation
+    indices (:100-129) — values the reference returned (tools/make_goldens.py g7b_dp_corners) — and the exactly-singular
+    regulariser, which ends in numpy's LinAlgError there and here (:45-55)."""
+    g = load_golden("regparam_dp_corners")
+    Q, R, b, delta = g["Q"], g["R"], g["b"], float(g["delta"])
+    bp = Q.T @ b
+    resid2 = float(np.linalg.norm(b - Q @ bp) ** 2)
+    assert np.isclose(discrepancy_principle(R, g["L_wide"], bp, resid2, delta=delta), float(g["lam_wide"]), rtol=1e-9)
+    assert np.isclose(discrepancy_principle(R, g["L_wide"], bp, resid2, delta=delta, eta=1.3), float(g["lam_wide_eta13"]), rtol=1e-9)
+    with pytest.raises(np.linalg.LinAlgError):
+        discrepancy_principle(R, np.diag([1.0, 2, 3, 4, 5, 0.0]), bp, resid2, delta=delta)
+    Qtb = g["U"].T @ b
+    for dpt in ("tsvd", "tgsvd"):
+        for tag, dl in (("", delta), ("_big", 6.0 * delta), ("_small", 0.05 * delta)):
+            assert discrepancy_principle(None, np.eye(6), Qtb, 0.0, delta=float(dl), dptype=dpt) == int(g[f"{dpt}{tag}"]), (dpt, tag)
+    with pytest.raises(UnboundLocalError):
+        discrepancy_principle(R, np.eye(6), bp, resid2, delta=delta, dptype="nonsense")

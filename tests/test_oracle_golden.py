@@ -370,3 +370,19 @@ def test_parallel_beam_convention_is_the_far_source_limit_of_the_pinned_fan_beam
         sf, sr = (F @ img.reshape(-1)).reshape(views, N), (R @ img.reshape(-1)).reshape(views, N)
         assert corr(sf, sr) > c_min and relerr(sf, sr) < d_max, (corr(sf, sr), relerr(sf, sr))
         assert max(corr(sf, sr[:, ::-1]), corr(sf, sr[::-1])) < 0.9
+
+
+def test_discrepancy_principle_corner_branches():
+    """discrepancy_principle.py:56-66 (a projected regulariser with fewer rows than columns) and :100-129 (dptype 'tsvd' / 'tgsvd':
+    the direct solvers' truncation index) against values the reference itself returned; :45-55 (an exactly zero singular value)
+    ends in numpy's LinAlgError in the reference, and here."""
+    g = load_golden("regparam_dp_corners")
+    Q, R, b, delta = g["Q"], g["R"], g["b"], float(g["delta"])
+    assert np.isclose(O.discrepancy_choose(Q, R, g["L_wide"], b, delta), float(g["lam_wide"]), rtol=1e-9)
+    assert np.isclose(O.discrepancy_choose(Q, R, g["L_wide"], b, delta, eta=1.3), float(g["lam_wide_eta13"]), rtol=1e-9)
+    with pytest.raises(np.linalg.LinAlgError):
+        O.discrepancy_choose(Q, R, np.diag([1.0, 2, 3, 4, 5, 0.0]), b, delta)
+    Qtb = g["U"].T @ b
+    for dpt in ("tsvd", "tgsvd"):
+        for tag, dl in (("", delta), ("_big", 6.0 * delta), ("_small", 0.05 * delta)):
+            assert O.discrepancy_truncation(Qtb, 6, dl, dptype=dpt) == int(g[f"{dpt}{tag}"]), (dpt, tag)

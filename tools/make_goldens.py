@@ -393,6 +393,29 @@ def g7_regparam():
          B=B, bhat=bhat, gcv_num_mod=num_mod, gcv_den_mod=den_mod, lam_gcv_mod=lam_gcv_mod, fullsize=500)
 
 
+def g7b_dp_corners():
+    """The discrepancy principle's corner branches (discrepancy_principle.py:45-66 and :100-129): a projected regulariser with
+    fewer rows than columns; the 'tsvd' / 'tgsvd' truncation indices of the direct solvers.  (A regulariser with an exactly zero
+    singular value ends in numpy's LinAlgError in the reference itself — the tests expect the same.)"""
+    print("G7b discrepancy principle: wide L, tsvd / tgsvd")
+    rng = np.random.default_rng(12)
+    m, k = 40, 6
+    A = rng.standard_normal((m, k)) @ np.diag(np.logspace(0, -2, k))
+    Q, R = la.qr(A, mode="economic")
+    b = A @ rng.standard_normal((k, 1)) + 0.05 * rng.standard_normal((m, 1))
+    delta = float(0.05 * np.sqrt(m))
+    Lw = rng.standard_normal((4, k))
+    lam_wide = discrepancy_principle(Q, R, Lw, b, delta=delta)
+    lam_wide_eta = discrepancy_principle(Q, R, Lw, b, delta=delta, eta=1.3)
+    U, _, _ = la.svd(A)
+    out = {}
+    for dpt in ("tsvd", "tgsvd"):
+        for tag, dl in (("", delta), ("_big", 6.0 * delta), ("_small", 0.05 * delta)):
+            out[f"{dpt}{tag}"] = discrepancy_principle(U, A, np.eye(k), b, delta=float(dl), dptype=dpt)
+    save("regparam_dp_corners", A=A, Q=Q, R=R, b=b, delta=delta, L_wide=Lw, lam_wide=lam_wide, lam_wide_eta13=lam_wide_eta, U=U,
+         **out)
+
+
 # ----------------------------------------------------------------------------------------- G8
 def g8_deblur1d():
     print("G8 1-D deblurring (BASELINE config C1)")
@@ -426,5 +449,6 @@ if __name__ == "__main__":
     g5b_isotv()
     g6_derivs()
     g7_regparam()
+    g7b_dp_corners()
     g8_deblur1d()
     print("done ->", OUT)

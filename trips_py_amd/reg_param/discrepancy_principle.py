@@ -40,8 +40,46 @@ def discrepancy_principle_bidiag(alphas, betas, bproj, delta=None, eta=1.01, res
     return alpha.value if have.value else None
 
 
+def _null_space_branch(A, L, bp, W):
+    """discrepancy_principle.py:47-66: A restricted to the A-weighted pseudo-inverse of L, b without its component along the null
+    space W of L (mirrored literally, `np.linalg.inv` of the triangular factors included)."""
+    AW = A @ W
+    Q_AW, R_AW = np.linalg.qr(AW, mode="reduced")
+    Q_LT, R_LT = np.linalg.qr(L.T, mode="reduced")
+    LAwpinv = (np.eye(L.shape[1]) - (W @ np.linalg.inv(R_AW) @ Q_AW.T @ A)) @ Q_LT @ np.linalg.inv(R_LT.T)
+    xnull = W @ np.linalg.inv(R_AW) @ Q_AW.T @ bp
+    return A @ LAwpinv, bp - A @ xnull
+
+
+def _truncation_index(bproj, n, target, dptype):
+    """dptype = 'tsvd' / 'tgsvd' (discrepancy_principle.py:100-129): the truncation index of the direct solvers' filter, from
+    bhat = Q^T b (Q square there) — the two loops as written, quirks included (tgsvd returns the LAST index that still
+    satisfies the discrepancy, counted from the other end)."""
+    bhat = np.asarray(bproj, dtype=np.float64).reshape(-1, 1)
+    m = bhat.shape[0]
+    alpha = n
+    if dptype == "tsvd":
+        f = np.ones((m, 1))
+        for i in range(n):
+            f[n - (i + 1), ] = 0
+            fvar = np.concatenate((1 - f[:n, ], f[n:, ]))
+            if np.sum((fvar * bhat) ** 2) - target < 0:
+                alpha = n - (i + 1)
+            else:
+                break
+        return alpha
+    coeff = np.square(bhat)
+    for i in range(n):
+        coeff[n - (i + 1), ] = 0
+        if np.sum(coeff) - target >= 0:
+            alpha = i
+        else:
+            break
+    return alpha
+
+
 def discrepancy_principle(A, L, bproj, resid2, delta=None, eta=1.01, L_is_identity=False, explicitProj=False,
-                          spectrum=None, **_ignored):
+                          spectrum=None, dptype="tikhonov", **_ignored):
     """alpha with ||A x_alpha - b||^2 = (eta*delta)^2 by the reference's Newton iteration on beta = 1/alpha.
 
     A       projected operator: B_k ((k+1) x k, hybrid solvers) or R_A (k x k, GKS / MMGKS)
@@ -50,11 +88,17 @@ def discrepancy_principle(A, L, bproj, resid2, delta=None, eta=1.01, L_is_identi
     resid2  ||b - Q Q^T b||^2  (used where the reference uses it: square `A`, or explicitProj)
     spectrum (engine-only) = (S, U^T bproj, (rows, cols)) of the matrix the reference would decompose, when the caller
               has it cheaper than a dense SVD (Hybrid_LSQR: the bidiagonal B_k); A and L are then not looked at
+    dptype  'tikhonov' (default: the iterative solvers'), 'tsvd' / 'tgsvd' (the direct solvers' truncation index, :100-129; `bproj`
+            is then Q^T b for the square Q, `L` only gives the column count)
     Returns 0 when the discrepancy cannot be reached yet (:76 `testzero >= 0` branch)."""
     if not isinstance(delta, (float, int)):
         raise Exception("A value for the noise level delta was not provided and the discrepancy principle cannot be applied. "
                         "Please supply a value of delta based on the estimated noise level of the problem, or choose the "
                         "regularization parameter according to gcv.")
+    if dptype in ("tsvd", "tgsvd"):
+        return _truncation_index(bproj, np.shape(L)[1], (eta * delta) ** 2, dptype)
+    if dptype != "tikhonov":
+        raise UnboundLocalError(f"dptype={dptype!r}: the reference leaves alpha unassigned (discrepancy_principle.py:131)")
     if spectrum is not None:
         S, bhat, (r, c) = spectrum
         S, bhat = np.asarray(S, dtype=np.float64), np.asarray(bhat, dtype=np.float64).reshape(-1, 1)
@@ -66,9 +110,16 @@ def discrepancy_principle(A, L, bproj, resid2, delta=None, eta=1.01, L_is_identi
         else:
             L = np.asarray(L, dtype=np.float64)
             _, SL, VL = sla.svd(L)
-            if not (L.shape[0] >= L.shape[1] and SL[-1] != 0):
-                raise NotImplementedError("projected regulariser with a null space (discrepancy_principle.py:45-66)")
-            Anew = A @ (VL.T @ np.diag(SL ** (-1.0)))
+            if L.shape[0] >= L.shape[1] and SL[-1] != 0:
+                Anew = A @ (VL.T @ np.diag(SL ** (-1.0)))
+            elif L.shape[0] >= L.shape[1]:
+                # an exactly zero singular value (:45-55): mirrored as written — like the reference it ends in numpy's LinAlgError,
+                # since R_LT of a rank-deficient (or tall) L is singular (not square)
+                W = VL[np.where(SL == 0), :].reshape((-1, 1))
+                Anew, bp = _null_space_branch(A, L, bp, W)
+            else:                                                       # fewer rows than columns (:56-66)
+                W = VL[L.shape[0] - L.shape[1]:, :].T
+                Anew, bp = _null_space_branch(A, L, bp, W)
         U, S, _ = sla.svd(Anew)
         bhat = U.T @ bp
         r, c = Anew.shape
