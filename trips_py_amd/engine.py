@@ -516,12 +516,12 @@ class HipEngine:
         _lib.check(rc, "trk_cgls_sharded_update")
         return n.value
 
-    def cgls_iterate_sharded(self, handle, comm_handle, k_first, n_iters, p, r, t, q, w, X, keep, x_prev, x_true, S, G3, NP, np_cap,
+    def cgls_iterate_sharded(self, handle, comm_handle, k_first, n_iters, p, r, t, q, w, X, keep, x_prev, x_true, S, G4, NP, np_cap,
                              n_np):
         n = ctypes.c_int(int(n_np))
         rc = self.lib.trk_cgls_iterate_sharded(handle, comm_handle, int(k_first), int(n_iters), p.data_ptr(), r.data_ptr(),
                                                t.data_ptr(), q.data_ptr(), w.data_ptr(), X.data_ptr(), X.stride(0), int(keep),
-                                               x_prev.data_ptr(), None if x_true is None else x_true.data_ptr(), _ptr(S), _ptr(G3),
+                                               x_prev.data_ptr(), None if x_true is None else x_true.data_ptr(), _ptr(S), _ptr(G4),
                                                _ptr(NP), int(np_cap), ctypes.byref(n), self.stream())
         _lib.check(rc, "trk_cgls_iterate_sharded")
         return n.value
