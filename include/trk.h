@@ -482,18 +482,26 @@ int trk_halo_exchange(trk_comm* comm, const float* send, int send_to, float* rec
  *   p = t + beta p; w = q + beta w (first: p = t, w = q); x_new = x + alpha p; r -= alpha w, alpha = gamma_{k-1} / delta_k;
  *   *publish_delta = delta_k, *publish_gamma = gamma_{k-1}; the rank's share of ||x_new||^2, ||alpha p||^2, ||x_new - x_true||^2
  *   (CGLS.py:76-80) as *n_blocks x 3 block partials (trk_finalize_batched, then one sum over the ranks after the solve).
- * trk_cgls_iterate_sharded: n_iters iterations enqueued by one call — q = A t; trk_dot_pair; trk_allreduce_f64(comm, G4, 4) (skipped
- *   for comm = NULL); trk_cgls_sharded_update; t = A^T r with the rank's ||t||^2 into G4[0].  Scalar layout as trk_cgls_iterate:
- *   S[0] = gamma_0, S[5k] = delta_k, S[5k+1] = gamma_k (gamma_k is published by iteration k+1: after the last iteration it is
- *   still the LOCAL sum in G4[0]).  Before the first iteration: r = b - A x0, t = A^T r, G4[0] = the rank's ||t||^2. */
+ * trk_cgls_sharded_scalars: G4[1..3] as trk_dot_pair, and G4[0] = the sum of the n_gamma raw block partials of ||t||^2 the adjoint
+ *   apply left (trk_op_apply_fused with x2 = NULL; n_gamma = 0: G4[0] is finished already) — by ONE workgroup for a rank's share of
+ *   up to 2^19 samples (three launches less per iteration), else by trk_dot_pair + a finalize.
+ * trk_cgls_iterate_sharded: n_iters iterations enqueued by one call — q = A t; trk_cgls_sharded_scalars; trk_allreduce_f64(comm, G4, 4)
+ *   (skipped for comm = NULL); trk_cgls_sharded_update; t = A^T r.  Scalar layout as trk_cgls_iterate: S[0] = gamma_0, S[5k] =
+ *   delta_k, S[5k+1] = gamma_k (gamma_k is published by iteration k+1).  PG / pcap / *n_g_inout (may be NULL / 0 / NULL): with them
+ *   and an operator that has a fused apply, the rank's ||t||^2 stays *n_g_inout raw block partials in PG between the adjoint apply
+ *   and the next iteration's scalars kernel (and after the last iteration); without, it is the finished local sum in G4[0].
+ *   Before the first iteration: r = b - A x0, t = A^T r, and the rank's ||t||^2 in the same form. */
 int trk_dot_pair(const float* q, const float* w, int64_t n, double* out3, trk_stream stream);
+int trk_cgls_sharded_scalars(const float* q, const float* w, int64_t m, const double* gamma_partials, int n_gamma, double* G4,
+                             trk_stream stream);
 int trk_cgls_sharded_update(int64_t n, int64_t m, const double* G4, const double* gamma_prev, int first, const float* x,
                             float* p, const float* t, float* x_new, float* r, const float* q, float* w, const float* x_true,
                             double* publish_delta, double* publish_gamma, double* norm_partials, int capacity_blocks,
                             int* n_blocks, trk_stream stream);
 int trk_cgls_iterate_sharded(trk_op* A, trk_comm* comm, int k_first, int n_iters, float* p, float* r, float* t, float* q,
                              float* w, float* X, int64_t x_ld, int keep_history, const float* x_prev, const float* x_true,
-                             double* S, double* G4, double* NP, int np_capacity_blocks, int* n_np_inout, trk_stream stream);
+                             double* S, double* G4, double* NP, int np_capacity_blocks, int* n_np_inout, double* PG, int pcap,
+                             int* n_g_inout, trk_stream stream);
 
 #ifdef __cplusplus
 }

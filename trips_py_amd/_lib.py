@@ -234,8 +234,10 @@ SIGNATURES = {
     "trk_dot_pair": (c_int, [c_f32p, c_f32p, c_i64, c_f64p, c_stream]),
     "trk_cgls_sharded_update": (c_int, [c_i64, c_i64, c_f64p, c_f64p, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                         c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
+    "trk_cgls_sharded_scalars": (c_int, [c_f32p, c_f32p, c_i64, c_f64p, c_int, c_f64p, c_stream]),
     "trk_cgls_iterate_sharded": (c_int, [c_op, ctypes.c_void_p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64,
-                                         c_int, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
+                                         c_int, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, ctypes.POINTER(c_int), c_f64p, c_int,
+                                         ctypes.POINTER(c_int), c_stream]),
     "trk_wgram": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_stream]),
 }
 

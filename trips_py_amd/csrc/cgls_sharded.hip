@@ -66,6 +66,62 @@ __global__ __launch_bounds__(NT) void k_dot_pair(const float* __restrict__ q, co
   if (threadIdx.x < 3) partials[blockIdx.x * 3 + threadIdx.x] = s;
 }
 
+// Everything the iteration's one exchange carries: G[1..3] = sum q*q, sum q*w, sum w*w, and G[0] = the sum of the n_g raw block
+// partials of ||t||^2 the adjoint kernel left (n_g = 0: G[0] is finished already and stays).  By ONE workgroup for vectors of up to
+// kOneBlockMax floats (one launch instead of partials + finalize + the adjoint's finalize), else by k_dot_pair's partials and ONE
+// finalize launch for all four (k_sharded_finalize).  Measured on the C5 shape (tools/c5_cgls_rate.py): a single workgroup over a
+// rank's 122 880 sinogram samples took longer than the three launches it replaced (CGLS 15.4 k -> 12.0 k iterations/s) — one CU's
+// loads in flight do not stream a megabyte — hence the small limit.  Fixed order: reproducible.
+constexpr int NT1 = 1024;
+constexpr int64_t kOneBlockMax = (int64_t)1 << 14;    // beyond: one workgroup's few loads in flight make it the slowest kernel of the iteration (measured, below)
+template <bool VEC>
+__global__ __launch_bounds__(NT1) void k_sharded_scalars(const float* __restrict__ q, const float* __restrict__ w, int64_t n,
+                                                         const double* __restrict__ pg, int n_g, double* __restrict__ G) {
+  __shared__ double lds[(NT1 / 64) * 4];
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int i = threadIdx.x; i < n_g; i += NT1) acc[0] += pg[i];
+  int64_t tail = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail = n4 << 2;
+    for (int64_t i = threadIdx.x; i < n4; i += NT1) {
+      const float4 a = ld4(q, i);
+      acc[1] += (double)a.x * a.x + (double)a.y * a.y + (double)a.z * a.z + (double)a.w * a.w;
+      if (w) {
+        const float4 b = ld4(w, i);
+        acc[2] += (double)a.x * b.x + (double)a.y * b.y + (double)a.z * b.z + (double)a.w * b.w;
+        acc[3] += (double)b.x * b.x + (double)b.y * b.y + (double)b.z * b.z + (double)b.w * b.w;
+      }
+    }
+  }
+  for (int64_t i = tail + threadIdx.x; i < n; i += NT1) {
+    const double a = q[i];
+    acc[1] += a * a;
+    if (w) {
+      const double b = w[i];
+      acc[2] += a * b;
+      acc[3] += b * b;
+    }
+  }
+  const double s = block_sum_many<NT1, 4>(acc, lds);
+  if (threadIdx.x < 4 && (threadIdx.x > 0 || n_g > 0)) G[threadIdx.x] = s;
+}
+
+// G[0] = sum of pg[0 .. n_g) (skipped for n_g = 0), G[1 + v] = sum over blocks of part[block][v]: one workgroup per output
+__global__ __launch_bounds__(256) void k_sharded_finalize(const double* __restrict__ part, int nblocks, const double* __restrict__ pg,
+                                                          int n_g, double* __restrict__ G) {
+  __shared__ double lds[4];
+  const int o = blockIdx.x;
+  if (o == 0 && n_g == 0) return;
+  double v = 0.0;
+  if (o == 0)
+    for (int i = threadIdx.x; i < n_g; i += 256) v += pg[i];
+  else
+    for (int b = threadIdx.x; b < nblocks; b += 256) v += part[(size_t)b * 3 + (o - 1)];
+  v = block_sum<256>(v, lds);
+  if (threadIdx.x == 0) G[o] = v;
+}
+
 // The local half of the merged iteration.  G = {gamma_{k-1}, ||q||^2, <q, w_{k-1}>, ||w_{k-1}||^2} summed over the ranks;
 // gprev = gamma_{k-2} (unused when first).  Every thread evaluates the three scalars itself from the same five doubles (grid-
 // uniform loads), block 0 publishes delta_k and gamma_{k-1}.  partials[block][3] = ||x_k||^2, ||alpha p_k||^2, ||x_k - x_true||^2.
@@ -166,6 +222,30 @@ int trk_dot_pair(const float* q, const float* w, int64_t n, double* out3, trk_st
   return finalize_sums(part, grid, 3, 3, out3, s);
 }
 
+int trk_cgls_sharded_scalars(const float* q, const float* w, int64_t m, const double* gamma_partials, int n_gamma, double* G4,
+                             trk_stream st) {
+  TRK_REQUIRE(q && G4 && m >= 0 && n_gamma >= 0 && (n_gamma == 0 || gamma_partials), "trk_cgls_sharded_scalars: bad argument");
+  hipStream_t s = (hipStream_t)st;
+  if (m <= kOneBlockMax && n_gamma <= (1 << 16)) {
+    if (aligned16(q) && (!w || aligned16(w)))
+      hipLaunchKernelGGL((k_sharded_scalars<true>), dim3(1), dim3(NT1), 0, s, q, w, m, gamma_partials, n_gamma, G4);
+    else
+      hipLaunchKernelGGL((k_sharded_scalars<false>), dim3(1), dim3(NT1), 0, s, q, w, m, gamma_partials, n_gamma, G4);
+    TRK_LAUNCH_CHECK();
+    return TRK_OK;
+  }
+  const int grid = grid_for(m);
+  double* part = nullptr;
+  if (int rc = scratch_doubles(s, (size_t)grid * 3, &part)) return rc;
+  if (aligned16(q) && (!w || aligned16(w)))
+    hipLaunchKernelGGL((k_dot_pair<true>), dim3(grid), dim3(NT), 0, s, q, w, m, part);
+  else
+    hipLaunchKernelGGL((k_dot_pair<false>), dim3(grid), dim3(NT), 0, s, q, w, m, part);
+  hipLaunchKernelGGL(k_sharded_finalize, dim3(4), dim3(256), 0, s, part, grid, gamma_partials, n_gamma, G4);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
 int trk_cgls_sharded_update(int64_t n, int64_t m, const double* G4, const double* gamma_prev, int first, const float* x, float* p, const float* t, float* x_new, float* r, const float* q,
                             float* w, const float* x_true, double* publish_delta, double* publish_gamma,
                             double* norm_partials, int capacity_blocks, int* n_blocks, trk_stream st) {
@@ -192,12 +272,17 @@ int trk_cgls_sharded_update(int64_t n, int64_t m, const double* G4, const double
 
 int trk_cgls_iterate_sharded(trk_op* A, trk_comm* comm, int k_first, int n_iters, float* p, float* r, float* t, float* q,
                              float* w, float* X, int64_t x_ld, int keep_history, const float* x_prev, const float* x_true,
-                             double* S, double* G4, double* NP, int np_capacity_blocks, int* n_np_inout, trk_stream stream) {
+                             double* S, double* G4, double* NP, int np_capacity_blocks, int* n_np_inout, double* PG, int pcap,
+                             int* n_g_inout, trk_stream stream) {
   TRK_REQUIRE(A && p && r && t && q && w && X && x_prev && S && G4 && NP && n_np_inout,
               "trk_cgls_iterate_sharded: NULL argument");
   TRK_REQUIRE(k_first >= 1 && n_iters >= 0, "trk_cgls_iterate_sharded: need k_first >= 1, n_iters >= 0");
+  TRK_REQUIRE(!PG || (pcap > 0 && n_g_inout), "trk_cgls_iterate_sharded: PG needs its capacity and partial count");
   const int64_t m = A->rows, n = A->cols;
   int n_np = *n_np_inout;
+  // ||t||^2 of the adjoint apply left as raw block partials for the scalars kernel to add up (operators with a fused apply)
+  const bool raw = PG && A->apply_fused;
+  int n_g = raw ? *n_g_inout : 0;
   for (int k = k_first; k < k_first + n_iters; ++k) {
     double* row = S + 5 * (int64_t)k;                          // [delta_k, gamma_k, ||x||^2, ||dx||^2, ||x-xt||^2]
     double* gpub = (k == 1) ? S : row - 4;                     // gamma_{k-1}
@@ -205,7 +290,7 @@ int trk_cgls_iterate_sharded(trk_op* A, trk_comm* comm, int k_first, int n_iters
     float* x_new = X + (int64_t)(keep_history ? (k - 1) : ((k - 1) & 1)) * x_ld;
     int rc = trk_op_apply(A, 0, t, 0, q, 0, 1, nullptr, stream);                                   // q = A t_{k-1}
     if (rc) return rc;
-    rc = trk_dot_pair(q, k == 1 ? nullptr : w, m, G4 + 1, stream);                        // ||q||^2, <q, w_{k-1}>, ||w_{k-1}||^2 (local)
+    rc = trk_cgls_sharded_scalars(q, k == 1 ? nullptr : w, m, PG, n_g, G4, stream);      // gamma_{k-1}, ||q||^2, <q, w>, ||w||^2 (local)
     if (rc) return rc;
     if (comm) {
       rc = trk_allreduce_f64(comm, G4, 4, stream);                                                 // the iteration's ONE exchange
@@ -214,11 +299,15 @@ int trk_cgls_iterate_sharded(trk_op* A, trk_comm* comm, int k_first, int n_iters
     rc = trk_cgls_sharded_update(n, m, G4, gprev, k == 1, x_prev, p, t, x_new, r, q, w, x_true, row, gpub,
                                  NP + 3 * (int64_t)n_np * (k - 1), np_capacity_blocks, &n_np, stream);
     if (rc) return rc;
-    rc = trk_op_apply(A, 1, r, 0, t, 0, 1, G4, stream);                                            // t_k = A^T r_k, local ||t_k||^2
+    if (raw)                                                                                        // t_k = A^T r_k, local ||t_k||^2
+      rc = trk_op_apply_fused(A, 1, r, nullptr, 0.0, nullptr, 0, nullptr, 0, nullptr, t, PG, pcap, &n_g, stream);
+    else
+      rc = trk_op_apply(A, 1, r, 0, t, 0, 1, G4, stream);
     if (rc) return rc;
     x_prev = x_new;
   }
   *n_np_inout = n_np;
+  if (raw) *n_g_inout = n_g;
   return TRK_OK;
 }
 

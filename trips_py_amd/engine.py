@@ -516,15 +516,24 @@ class HipEngine:
         _lib.check(rc, "trk_cgls_sharded_update")
         return n.value
 
+    def cgls_sharded_scalars(self, q, w, gamma_partials, n_gamma, G4):
+        """G4[1..3] = <q,q>, <q,w>, <w,w>; G4[0] = sum of the n_gamma raw partials (n_gamma = 0: left as it is)."""
+        rc = self.lib.trk_cgls_sharded_scalars(q.data_ptr(), None if w is None else w.data_ptr(), q.numel(), _ptr(gamma_partials),
+                                               int(n_gamma), _ptr(G4), self.stream())
+        _lib.check(rc, "trk_cgls_sharded_scalars")
+
     def cgls_iterate_sharded(self, handle, comm_handle, k_first, n_iters, p, r, t, q, w, X, keep, x_prev, x_true, S, G4, NP, np_cap,
-                             n_np):
+                             n_np, PG=None, pcap=0, n_g=0):
+        """Returns (norm-partial blocks per iteration, gamma partials left behind by the last adjoint apply)."""
         n = ctypes.c_int(int(n_np))
+        ng = ctypes.c_int(int(n_g))
         rc = self.lib.trk_cgls_iterate_sharded(handle, comm_handle, int(k_first), int(n_iters), p.data_ptr(), r.data_ptr(),
                                                t.data_ptr(), q.data_ptr(), w.data_ptr(), X.data_ptr(), X.stride(0), int(keep),
                                                x_prev.data_ptr(), None if x_true is None else x_true.data_ptr(), _ptr(S), _ptr(G4),
-                                               _ptr(NP), int(np_cap), ctypes.byref(n), self.stream())
+                                               _ptr(NP), int(np_cap), ctypes.byref(n), _ptr(PG), int(pcap),
+                                               ctypes.byref(ng) if PG is not None else None, self.stream())
         _lib.check(rc, "trk_cgls_iterate_sharded")
-        return n.value
+        return n.value, ng.value
 
     def finalize_batched(self, partials, nblocks, nvals, batches, out, out_stride):
         rc = self.lib.trk_finalize_batched(_ptr(partials), int(nblocks), int(nvals), int(batches), _ptr(out), int(out_stride),

@@ -213,10 +213,23 @@ class CGLSRunSharded(CGLSRun):
         self.k = 0
         self.allreduces = 0
         self._rows = None
+        # operators that can leave ||A^T r||^2 as raw block partials (the Radon projector, the blur): the kernel that forms the
+        # iteration's other sums adds them up too — no reduction-finalize launch behind the adjoint apply (trk_cgls_sharded_scalars)
+        self.rawg = bool(hasattr(eng, "cgls_sharded_scalars") and hasattr(A, "_h") and eng.op_can_fuse(A._h))
+        self.PG = eng.scalars(self.PCAP) if self.rawg else None
+        self.n_g = 0
         A.apply(x_start, out=self.r)                                         # r = b - A x0 ; t = A^T r          (CGLS.py:45-46)
         eng.axpby(1.0, self.bv, -1.0, self.r, self.r)
-        A.apply(self.r, out=self.t, transpose=True, sumsq=self.G.ref(0))     # this rank's ||t_0||^2: summed by iteration 1
+        self._adjoint()                                                      # this rank's ||t_0||^2: summed by iteration 1
         self.x_cur = x_start
+
+    def _adjoint(self):
+        """t = A^T r with this rank's ||t||^2 as raw block partials in PG (n_g of them) or, without a fused apply, finished in G[0]."""
+        if self.rawg:
+            self.n_g = self.eng.op_apply_fused(self.A._h, True, self.r, None, 0.0, None, 0, None, 0, None, self.t, self.PG.ref(0),
+                                               self.PCAP)
+        else:
+            self.A.apply(self.r, out=self.t, transpose=True, sumsq=self.G.ref(0))
 
     def _step(self):
         eng, A, S, G = self.eng, self.A, self.S, self.G
@@ -225,13 +238,16 @@ class CGLSRunSharded(CGLSRun):
         b = 5 * k
         x_new = self.hist.row(k - 1)
         A.apply(self.t, out=self.q)                                          # q = A t_{k-1}
-        eng.dot_pair(self.q, None if k == 1 else self.w, G.ref(1))
+        if self.rawg:
+            eng.cgls_sharded_scalars(self.q, None if k == 1 else self.w, self.PG.ref(0), self.n_g, G.ref(0))
+        else:
+            eng.dot_pair(self.q, None if k == 1 else self.w, G.ref(1))
         eng.allreduce(G, 0, 4)               # the iteration's one exchange (a no-op on one rank)
         self.allreduces += self.dist
         self.n_np = eng.cgls_sharded_update(G.ref(0), S.ref(0) if k <= 2 else S.ref(b - 9), k == 1, self.x_cur, self.p,
                                             self.t, x_new, self.r, self.q, self.w, self.xt, S.ref(b),
                                             S.ref(0) if k == 1 else S.ref(b - 4), self.NP.ref(3 * self.n_np * (k - 1)), self.NPC)
-        A.apply(self.r, out=self.t, transpose=True, sumsq=G.ref(0))          # t_k = A^T r_k, this rank's ||t_k||^2
+        self._adjoint()                                                      # t_k = A^T r_k, this rank's ||t_k||^2
         self.x_cur = x_new
 
     def run(self, n_steps):
@@ -242,9 +258,10 @@ class CGLSRunSharded(CGLSRun):
         comm_h = getattr(eng.comm, "_h", None) if self.dist else None       # libtrk's own communicator (dist.RcclComm)
         if hasattr(eng, "cgls_iterate_sharded") and hasattr(self.A, "_h") and (not self.dist or comm_h is not None):
             def call(k_first, n, X, keep):
-                self.n_np = eng.cgls_iterate_sharded(self.A._h, comm_h, k_first, n, self.p, self.r, self.t, self.q, self.w, X, keep,
-                                                     self.x_cur, self.xt, self.S.ref(0), self.G.ref(0), self.NP.ref(0), self.NPC,
-                                                     self.n_np)
+                self.n_np, self.n_g = eng.cgls_iterate_sharded(self.A._h, comm_h, k_first, n, self.p, self.r, self.t, self.q, self.w, X,
+                                                               keep, self.x_cur, self.xt, self.S.ref(0), self.G.ref(0), self.NP.ref(0),
+                                                               self.NPC, self.n_np, None if not self.rawg else self.PG.ref(0),
+                                                               self.PCAP if self.rawg else 0, self.n_g)
                 self.x_cur = _row_of(X, k_first + n - 2, keep)
                 eng.reduction_points += n
                 if self.dist:
@@ -264,7 +281,10 @@ class CGLSRunSharded(CGLSRun):
             eng = self.eng
             N3 = eng.scalars(3 * k + 1)
             eng.finalize_batched(self.NP.ref(0), self.n_np, 3, k, N3.ref(0), 3)
-            N3.set(3 * k, self.G.host(0, 1))                          # gamma_k: formed by the last A^T r, not yet exchanged
+            if self.rawg:                                             # gamma_k: formed by the last A^T r, not yet summed / exchanged
+                eng.finalize_batched(self.PG.ref(0), self.n_g, 1, 1, N3.ref(3 * k), 1)
+            else:
+                N3.set(3 * k, self.G.host(0, 1))
             eng.allreduce(N3, 0, 3 * k + 1)
             Sh, Nh = self.S.host(), N3.host()
             rows = Sh[5:5 * (k + 1)].reshape(k, 5).copy()
