@@ -230,6 +230,7 @@ def run_blur_cgls(args, rank, world, json_fd=1):
     # the class trips_py_amd.solvers.CGLS itself picks for this operator (tol = 0, single rank per problem)
     fused = CGLSRunFused.usable(A, eng) and not args.unfused and (args.fused or CGLSRunFused.auto(n))
     tiled = not args.unfused and not args.fused and CGLSRunFused.tiled_usable(A, eng)      # small images (--size <= 1024)
+    tiled = CGLSRunFused.TILED_DEFAULT if tiled else 0      # the tiled form CGLS() picks (2: two blurs per iteration)
     Run = CGLSRunFused if (fused or tiled) else CGLSRun
     # reference call without x_true (CGLS.py:16); norms deferred exactly as CGLS() does for tol = 0 on one rank
     # run-in: a separate, untimed solve of the same problem with the same iteration form (see RUN_IN_ITERS)
@@ -273,7 +274,8 @@ def run_blur_cgls(args, rank, world, json_fd=1):
         alg_bytes, ms_fwd = 44.0 * n, np.array([elapsed / K * 1e3])
     t_kernel = float(np.mean(ms_fwd)) * 1e-3
     achieved = alg_bytes / t_kernel / 1e9
-    kname = ("k_cgls_tile_a + k_cgls_tile_b (whole iteration: two launches, 44n algorithmic bytes)" if tiled else
+    kname = ("k_cgls_tile_a2 + k_cgls_tile_b2 (whole iteration: two launches, 44n algorithmic bytes)" if tiled == 2 else
+             "k_cgls_tile_a + k_cgls_tile_b (whole iteration: two launches, 44n algorithmic bytes)" if tiled else
              "k_blur_slide<9,9,D=9,sumsq,fuse> (p = t + ratio*p fused into w = A p, + ||w||^2)" if fused
              else "k_blur_slide<9,9,D=9,sumsq> (forward blur matvec w = A p, fused ||w||^2)")
     roofline = {"bound": "hbm", "kernel": kname,
@@ -292,7 +294,8 @@ def run_blur_cgls(args, rank, world, json_fd=1):
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": f"blur{N}_cgls", "image": f"{N}x{N} fp32", "psf": "Gaussian 9x9 sigma=(3,3), reflect",
                       "solver": "CGLS (trips.solvers.CGLS semantics, tol=0)", "noise": "1% Gaussian",
-                      "iteration": "tiled: 2 launches (a workgroup per 32x32 tile recomputes its halo of p and A p in LDS)" if tiled else
+                      "iteration": "tiled: 2 launches, 2 blurs (a workgroup per 32x32 tile; w = A p advanced as A t + beta w)" if tiled == 2 else
+                                   "tiled: 2 launches (a workgroup per 32x32 tile recomputes its halo of p and A p in LDS)" if tiled else
                                    "fused: 3 launches (blur+p-update, x-update, blur^T+r-update)" if Run is CGLSRunFused else (("4 launches (blur, r update, blur^T, x/p update in one pass over p; consumers add the block partials)"
                                      if getattr(run, "grouping", 0) == 1 else
                                      "4 launches (blur, x/r update, blur^T, p update; consumers add the block partials)")

@@ -448,6 +448,16 @@ int trk_cgls_iterate_tiled(trk_op* A, int k_first, int n_iters, float* P, int64_
                            double* PG, double* PD, int pcap, double* NP, int np_capacity_blocks, int* n_g_inout,
                            int* n_np_inout, trk_stream stream);
 
+/* The same iteration with TWO blurs instead of four: w_k = A p_k is never blurred — it is A t_{k-1} + beta w_{k-1} (csrc/cgls_tiled.hip,
+ * k_cgls_tile_a2 / _b2); ||w_k||^2 is measured on the vector itself.  p, w: n floats each, updated in place (w: any finite content
+ * before the first iteration); R: [2][r_ld] ping-pong pair (iteration k reads index (k-1) & 1, writes k & 1); PG / PD: gamma / delta
+ * block partials, `pcap` doubles each; *n_g_inout: valid gamma partials in PG (set by the caller's t_0 = A^T r_0).  Scalar layout
+ * and everything else as trk_cgls_iterate_tiled. */
+int trk_cgls_iterate_tiled2(trk_op* A, int k_first, int n_iters, float* p, float* w, float* R, int64_t r_ld, float* t, float* X,
+                            int64_t x_ld, int keep_history, const float* x_prev, const float* x_true, double* S, double* PG,
+                            double* PD, int pcap, double* NP, int np_capacity_blocks, int* n_g_inout, int* n_np_inout,
+                            trk_stream stream);
+
 /* ---------------------------------------------------------------- collectives ----
  * The sharded path — frames of a dynamic problem over the GPUs of a node, one process per GPU (io.py:420: F = blkdiag(A_t)) —
  * has two exchanges: the sum over ranks of a few device doubles (what np.dot / np.linalg.norm of the reference's solver loops

@@ -163,10 +163,12 @@ def test_raw_partials_form_equals_finalized_form(N, grouping):
                                              # (n < (i0 + 40) / 2: the fold is clamped, cgls_tiled.hip refl())
                                              (16, 16, (9, 9), (3, 3)), (19, 16, (9, 9), (3, 3)), (33, 20, (9, 9), (3, 3)),
                                              (35, 36, (9, 9), (3, 3)), (36, 16, (5, 5), (1, 1))])
-def test_tiled_two_launch_cgls_equals_the_streaming_form(nx, ny, dim, spread):
-    """trk_cgls_iterate_tiled (a workgroup per 32 x 32 tile recomputing its halo, two launches per iteration) against the
-    four-launch streaming form on the same problem: sizes that are not multiples of the tile, non-square images, PSFs
-    smaller than 9 x 9 and rectangular, with and without x_true / history."""
+@pytest.mark.parametrize("form", [1, 2])
+def test_tiled_two_launch_cgls_equals_the_streaming_form(nx, ny, dim, spread, form):
+    """trk_cgls_iterate_tiled (form 1: a workgroup per 32 x 32 tile recomputing its halo of p and A p, four blurs per iteration) and
+    trk_cgls_iterate_tiled2 (form 2: w = A p kept as a vector and advanced as A t + beta w, two blurs) against the four-launch
+    streaming form on the same problem: sizes that are not multiples of the tile, non-square images, PSFs smaller than 9 x 9 and
+    rectangular, with and without x_true / history, zero and non-zero x0."""
     import torch
     from trips_py_amd.operators import Blur2D
     from trips_py_amd.problems import gauss_psf
@@ -185,21 +187,33 @@ def test_tiled_two_launch_cgls_equals_the_streaming_form(nx, ny, dim, spread):
     # axes are here for — the clamped halo folds — is exercised from the first iteration on, so they run 5
     its = 25 if n >= 4096 else 5
     xa, ia = CGLS(A, b, x0, its, 0, xt, tiled=False, fused=False)
-    xb, ib = CGLS(A, b, x0, its, 0, xt, tiled=True)
+    xb, ib = CGLS(A, b, x0, its, 0, xt, tiled=form)
     for k in range(its):
         ra, rb = ia["xHistory"][k].reshape(-1), ib["xHistory"][k].reshape(-1)
         assert float(torch.linalg.norm(ra - rb) / torch.linalg.norm(ra)) < 2e-6, k
     assert np.allclose(ia["relError"], ib["relError"], rtol=1e-5) and np.allclose(ia["relResidual"], ib["relResidual"], rtol=1e-5)
-    xc, ic = CGLS(A, b, x0, its, 0, tiled=True, history=False)
+    xc, ic = CGLS(A, b, x0, its, 0, tiled=form, history=False)
     assert float(torch.linalg.norm(xc - xb) / torch.linalg.norm(xb)) == 0.0 and ic["xHistory"] == []
+    # a start that is not zero (r0 = b - A x0; form 2's w buffer holds A x0 when the first iteration begins), stepwise driver
+    x1 = 0.5 * torch.rand(n, device=dev, generator=torch.Generator(device=dev).manual_seed(9))
+    xd, idd = CGLS(A, b, x1, 5, 0, xt, tiled=False, fused=False)
+    run = CGLSRunFused(A, b, x1, 5, xt, True, tiled=form)
+    for _ in range(5):
+        run.step()
+    g0, rows = run.rows()
+    assert float(torch.linalg.norm(run.x_cur - xd.reshape(-1)) / torch.linalg.norm(xd)) < 2e-6
+    xe, ie = CGLS(A, b, x1, 5, 0, xt, tiled=form)
+    assert float(torch.linalg.norm(xe.reshape(-1) - run.x_cur) / torch.linalg.norm(xe)) == 0.0      # C loop == stepwise
+    assert np.allclose(idd["relError"], ie["relError"], rtol=1e-5)
 
 
-def test_tiled_cgls_against_the_reference_golden():
+@pytest.mark.parametrize("form", [1, 2])
+def test_tiled_cgls_against_the_reference_golden(form):
     from trips_py_amd.solvers import CGLS
     from trips_py_amd.operators import Blur2D
     g = load_golden("cgls_blur64_x0zero")
     A = Blur2D(g["psf"], int(g["N"]), int(g["N"]))
-    x, info = CGLS(A, g["b"], g["x0"], int(g["max_iter"]), 0, g["x_true"], tiled=True)
+    x, info = CGLS(A, g["b"], g["x0"], int(g["max_iter"]), 0, g["x_true"], tiled=form)
     assert relerr(x, g["x"]) < 1e-5 and np.allclose(info["relError"], g["relError"], rtol=1e-4)
 
 

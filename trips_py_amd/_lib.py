@@ -199,6 +199,9 @@ SIGNATURES = {
     "trk_cgls_iterate_tiled": (c_int, [c_op, c_int, c_int, c_f32p, c_i64, c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_int,
                                        c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_int, ctypes.POINTER(c_int),
                                        ctypes.POINTER(c_int), c_stream]),
+    "trk_cgls_iterate_tiled2": (c_int, [c_op, c_int, c_int, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f32p, c_i64, c_int,
+                                        c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_int, ctypes.POINTER(c_int),
+                                        ctypes.POINTER(c_int), c_stream]),
     "trk_gemv_t": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_gemv_t2": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_gemv_tn": (c_int, [c_f32p, c_i64, c_int, c_i64, ctypes.POINTER(ctypes.c_void_p), c_int, c_f64p, c_stream]),

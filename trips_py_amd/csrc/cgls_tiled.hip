@@ -328,6 +328,187 @@ __global__ __launch_bounds__(NT) void k_cgls_tile_b(TiledGeom g, const float* __
   }
 }
 
+// ------------------------------------------------------------------------------------------------ two launches, TWO blurs
+// The form above blurs four times per iteration (K_A: A t and A p_old on the tile; K_B: A p on tile + halo, A^T r on the tile).
+// Two of them are a linear combination of vectors the iteration already has: w_k = A p_k = A t_{k-1} + beta w_{k-1}.  With w kept as
+// a full image:
+//     K_A2(k)  beta from the gamma partials;  q = A t_{k-1} on the tile (t on tile + 4);  w_k = q + beta w_{k-1},  p_k = t_{k-1} + beta
+//              p_{k-1} on the tile, both in place (only the own tile of either is read);  block partial of ||w_k||^2 (measured on
+//              the vector itself: nothing accumulates from iteration to iteration)
+//     K_B2(k)  alpha = gamma_{k-1} / ||w_k||^2;  r_k = r_{k-1} - alpha w_k on tile + 4 straight from global (w_k is complete: the
+//              previous launch has ended);  t_k = A^T r_k on the tile (+ ||t_k||^2 partial);  x_k = x_{k-1} + alpha p_k on the tile
+// One blur per kernel: K_A2 has 4 barrier-separated LDS phases instead of 7, K_B2 6 instead of 10; the same partial-sum interface
+// (PG, PD) as the four-blur form.
+__global__ __launch_bounds__(NT) void k_cgls_tile_a2(TiledGeom g, const float* __restrict__ t, float* __restrict__ p, float* __restrict__ w,
+                                                     ScalarSrc gam, const double* __restrict__ gprev, double* __restrict__ gpub,
+                                                     int first, double* __restrict__ PD) {
+  constexpr int S1 = E1 + 4;
+  __shared__ __attribute__((aligned(16))) float T1[E1 * S1];
+  __shared__ __attribute__((aligned(16))) float tmp[E1 * (CT + 4)];
+  __shared__ __attribute__((aligned(16))) float WA[CT * (CT + 1)];
+  __shared__ double red[NT / 64];
+  __shared__ float bc;
+  const int ty = blockIdx.x / g.tiles_x, tx = blockIdx.x - ty * g.tiles_x;
+  const int i0 = ty * CT, j0 = tx * CT;
+  constexpr int NL1 = (E1 * E1 + NT - 1) / NT, NL0 = (CT * CT + NT - 1) / NT;
+  float tv[NL1], wv[NL0], pv[NL0];
+#pragma unroll
+  for (int k = 0; k < NL1; ++k) {
+    const int idx = threadIdx.x + k * NT;
+    const int r = idx / E1, c = idx - r * E1;
+    tv[k] = idx < E1 * E1 ? t[refl(i0 - CH + r, g.nx) * g.ny + refl(j0 - CH + c, g.ny)] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < NL0; ++k) {
+    const int idx = threadIdx.x + k * NT;
+    const int r = idx / CT, c = idx - r * CT;
+    const int i = i0 + r, j = j0 + c;
+    const bool in = idx < CT * CT && i < g.nx && j < g.ny;
+    wv[k] = (in && !first) ? w[i * g.ny + j] : 0.f;
+    pv[k] = (in && !first) ? p[i * g.ny + j] : 0.f;
+  }
+  double part[PMAX];
+  partials_issue(gam, part);
+  const double gp = first ? 1.0 : *gprev;
+#pragma unroll
+  for (int k = 0; k < NL1; ++k) {
+    const int idx = threadIdx.x + k * NT;
+    if (idx < E1 * E1) {
+      const int r = idx / E1, c = idx - r * E1;
+      T1[r * S1 + c] = tv[k];
+    }
+  }
+  __syncthreads();
+  blur_lds<CT, CT, false>(T1, S1, tmp, WA, CT + 1, g.rwf, g.cwf);             // q = A t on the tile
+  if (threadIdx.x < 64) {                                   // beta = gamma_{k-1} / gamma_{k-2}; block 0 publishes gamma_{k-1}
+    const double gk = partials_sum(part);
+    if (threadIdx.x == 0) {
+      bc = first ? 0.f : (float)(gk / gp);
+      if (blockIdx.x == 0) *gpub = gk;
+    }
+  }
+  __syncthreads();
+  const float beta = bc;
+  double ss = 0.0;
+#pragma unroll
+  for (int k = 0; k < NL0; ++k) {
+    const int idx = threadIdx.x + k * NT;
+    const int r = idx / CT, c = idx - r * CT;
+    const int i = i0 + r, j = j0 + c;
+    if (idx < CT * CT && i < g.nx && j < g.ny) {
+      const float wn = fmaf(beta, wv[k], WA[r * (CT + 1) + c]);               // w_k = A t + beta w_{k-1}     (= A p_k, CGLS.py:60)
+      w[i * g.ny + j] = wn;
+      p[i * g.ny + j] = fmaf(beta, pv[k], T1[(r + CH) * S1 + c + CH]);        // p_k = t + beta p_{k-1}       (CGLS.py:72)
+      ss += (double)wn * wn;
+    }
+  }
+  ss = block_sum<NT>(ss, red);
+  if (threadIdx.x == 0) PD[blockIdx.x] = ss;
+}
+
+template <bool HAS_XT>
+__global__ __launch_bounds__(NT) void k_cgls_tile_b2(TiledGeom g, const float* __restrict__ w, const float* __restrict__ p,
+                                                     const float* __restrict__ r_old, float* __restrict__ r_new, float* __restrict__ t,
+                                                     const float* __restrict__ x_old, float* __restrict__ x_new,
+                                                     const float* __restrict__ x_true, ScalarSrc del, const double* __restrict__ gamma,
+                                                     double* __restrict__ dpub, double* __restrict__ PG, double* __restrict__ NP) {
+  constexpr int S1 = E1 + 4;
+  __shared__ __attribute__((aligned(16))) float W[E1 * S1];                  // r_k on tile + halo
+  __shared__ __attribute__((aligned(16))) float tmp[E1 * (CT + 4)];
+  __shared__ __attribute__((aligned(16))) float T[CT * (CT + 1)];
+  __shared__ double red[4 * (NT / 64)];
+  __shared__ float bc;
+  const int ty = blockIdx.x / g.tiles_x, tx = blockIdx.x - ty * g.tiles_x;
+  const int i0 = ty * CT, j0 = tx * CT;
+  constexpr int NL1 = (E1 * E1 + NT - 1) / NT, NL0 = (CT * CT + NT - 1) / NT;
+  float wv[NL1], rv[NL1], pv[NL0], xv[NL0], xtv[NL0];
+#pragma unroll
+  for (int k = 0; k < NL1; ++k) {
+    const int idx = threadIdx.x + k * NT;
+    const int r = idx / E1, c = idx - r * E1;
+    const int i = i0 - CH + r, j = j0 - CH + c;
+    const bool in = idx < E1 * E1 && (unsigned)i < (unsigned)g.nx && (unsigned)j < (unsigned)g.ny;
+    const int gi = in ? i * g.ny + j : 0;
+    wv[k] = in ? w[gi] : 0.f;
+    rv[k] = in ? r_old[gi] : 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < NL0; ++k) {
+    const int idx = threadIdx.x + k * NT;
+    const int r = idx / CT, c = idx - r * CT;
+    const int i = i0 + r, j = j0 + c;
+    const bool in = idx < CT * CT && i < g.nx && j < g.ny;
+    const int gi = in ? i * g.ny + j : 0;
+    pv[k] = in ? p[gi] : 0.f;
+    xv[k] = in ? x_old[gi] : 0.f;
+    xtv[k] = (HAS_XT && in) ? x_true[gi] : 0.f;
+  }
+  double part[PMAX];
+  partials_issue(del, part);
+  const double gm = *gamma;
+  if (threadIdx.x < 64) {                                   // alpha = gamma_{k-1} / ||w||^2; block 0 publishes ||w||^2
+    const double d = partials_sum(part);
+    if (threadIdx.x == 0) {
+      bc = (float)(gm / d);
+      if (blockIdx.x == 0) *dpub = d;
+    }
+  }
+  __syncthreads();
+  const float alpha = bc;
+  // r_k = r_{k-1} - alpha w   (CGLS.py:67) where the position is a pixel; its mirror pixel's value where it is not (below)
+#pragma unroll
+  for (int k = 0; k < NL1; ++k) {
+    const int idx = threadIdx.x + k * NT;
+    const int r = idx / E1, c = idx - r * E1;
+    const int i = i0 - CH + r, j = j0 - CH + c;
+    if (idx < E1 * E1 && (unsigned)i < (unsigned)g.nx && (unsigned)j < (unsigned)g.ny) {
+      const float rn = fmaf(-alpha, wv[k], rv[k]);
+      W[r * S1 + c] = rn;
+      if (r >= CH && r < CH + CT && c >= CH && c < CH + CT) r_new[i * g.ny + j] = rn;
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < E1 * E1; idx += NT) {
+    const int r = idx / E1, c = idx - r * E1;
+    const int i = i0 - CH + r, j = j0 - CH + c;
+    if (!((unsigned)i < (unsigned)g.nx && (unsigned)j < (unsigned)g.ny)) {
+      const int mr = refl(i, g.nx) - (i0 - CH), mc = refl(j, g.ny) - (j0 - CH);
+      W[r * S1 + c] = ((unsigned)mr < (unsigned)E1 && (unsigned)mc < (unsigned)E1) ? W[mr * S1 + mc] : 0.f;
+    }
+  }
+  __syncthreads();
+  blur_lds<CT, CT>(W, S1, tmp, T, CT + 1, g.rwt, g.cwt);                      // t_k = A^T r_k on the tile   (CGLS.py:68)
+  double sg = 0.0, s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < NL0; ++k) {
+    const int idx = threadIdx.x + k * NT;
+    const int r = idx / CT, c = idx - r * CT;
+    const int i = i0 + r, j = j0 + c;
+    if (idx < CT * CT && i < g.nx && j < g.ny) {
+      const int gidx = i * g.ny + j;
+      const float tn = T[r * (CT + 1) + c];
+      t[gidx] = tn;
+      sg += (double)tn * tn;
+      const float d = alpha * pv[k];                                           // x += alpha p   (CGLS.py:65)
+      const float xn = xv[k] + d;
+      x_new[gidx] = xn;
+      s0 += (double)xn * xn;
+      s1 += (double)d * d;
+      if (HAS_XT) {
+        const double e = (double)xn - (double)xtv[k];
+        s2 += e * e;
+      }
+    }
+  }
+  block_sum4(sg, s0, s1, s2, red);
+  if (threadIdx.x == 0) {
+    PG[blockIdx.x] = sg;
+    NP[(size_t)blockIdx.x * 3 + 0] = s0;
+    NP[(size_t)blockIdx.x * 3 + 1] = s1;
+    NP[(size_t)blockIdx.x * 3 + 2] = HAS_XT ? s2 : 0.0;
+  }
+}
+
 int tiled_geom(trk_op* A, TiledGeom* g, int* ntiles) {
   int nx, ny, kh, kw;
   const float *sf, *st;
@@ -400,6 +581,49 @@ int trk_cgls_iterate_tiled(trk_op* A, int k_first, int n_iters, float* P, int64_
                          ScalarSrc{PD, ntiles}, gpub, S + b, PG, np);
     else
       hipLaunchKernelGGL(k_cgls_tile_b<false>, dim3(ntiles), dim3(NT), 0, s, g, p_new, r_old, r_new, t, x_prev, x_new, x_true,
+                         ScalarSrc{PD, ntiles}, gpub, S + b, PG, np);
+    TRK_LAUNCH_CHECK();
+    n_g = ntiles;
+    x_prev = x_new;
+  }
+  *n_g_inout = n_g;
+  *n_np_inout = ntiles;
+  return TRK_OK;
+}
+
+int trk_cgls_iterate_tiled2(trk_op* A, int k_first, int n_iters, float* p, float* w, float* R, int64_t r_ld, float* t, float* X,
+                            int64_t x_ld, int keep_history, const float* x_prev, const float* x_true, double* S, double* PG,
+                            double* PD, int pcap, double* NP, int np_capacity_blocks, int* n_g_inout, int* n_np_inout,
+                            trk_stream stream) {
+  TRK_REQUIRE(A && p && w && R && t && X && x_prev && S && PG && PD && NP && n_g_inout && n_np_inout,
+              "trk_cgls_iterate_tiled2: NULL argument");
+  TRK_REQUIRE(k_first >= 1 && n_iters >= 0, "trk_cgls_iterate_tiled2: need k_first >= 1, n_iters >= 0");
+  struct Cache { TiledGeom g; int ntiles; };
+  if (!A->aux) {
+    Cache c;
+    if (!tiled_geom(A, &c.g, &c.ntiles)) return fail(TRK_EUNSUPPORTED, "trk_cgls_iterate_tiled2: needs a separable blur <= 9x9 on an image >= 16x16");
+    A->aux = malloc(sizeof(Cache));
+    if (!A->aux) return fail(TRK_ENOMEM, "trk_cgls_iterate_tiled2: out of memory");
+    memcpy(A->aux, &c, sizeof(Cache));
+  }
+  const TiledGeom g = static_cast<Cache*>(A->aux)->g;
+  const int ntiles = static_cast<Cache*>(A->aux)->ntiles;
+  TRK_REQUIRE(ntiles <= np_capacity_blocks && ntiles <= pcap, "trk_cgls_iterate_tiled2: %d tiles exceed the partial buffers", ntiles);
+  hipStream_t s = (hipStream_t)stream;
+  int n_g = *n_g_inout;
+  for (int k = k_first; k < k_first + n_iters; ++k) {
+    const int64_t b = 5 * (int64_t)k;
+    float *r_old = R + (int64_t)((k - 1) & 1) * r_ld, *r_new = R + (int64_t)(k & 1) * r_ld;
+    const double* gprev = (k <= 2) ? S : S + 5 * (int64_t)(k - 2) + 1;      // gamma_{k-2}
+    double* gpub = (k == 1) ? S : S + b - 4;                                 // gamma_{k-1} goes here
+    float* x_new = X + (int64_t)(keep_history ? (k - 1) : ((k - 1) & 1)) * x_ld;
+    hipLaunchKernelGGL(k_cgls_tile_a2, dim3(ntiles), dim3(NT), 0, s, g, t, p, w, ScalarSrc{PG, n_g}, gprev, gpub, k == 1 ? 1 : 0, PD);
+    double* np = NP + 3 * (int64_t)ntiles * (k - 1);
+    if (x_true)
+      hipLaunchKernelGGL(k_cgls_tile_b2<true>, dim3(ntiles), dim3(NT), 0, s, g, w, p, r_old, r_new, t, x_prev, x_new, x_true,
+                         ScalarSrc{PD, ntiles}, gpub, S + b, PG, np);
+    else
+      hipLaunchKernelGGL(k_cgls_tile_b2<false>, dim3(ntiles), dim3(NT), 0, s, g, w, p, r_old, r_new, t, x_prev, x_new, x_true,
                          ScalarSrc{PD, ntiles}, gpub, S + b, PG, np);
     TRK_LAUNCH_CHECK();
     n_g = ntiles;

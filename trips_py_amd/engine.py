@@ -501,6 +501,16 @@ class HipEngine:
         _lib.check(rc, "trk_cgls_iterate_tiled")
         return cg.value, cn.value
 
+    def cgls_iterate_tiled2(self, handle, k_first, n_iters, p, w, R, t, X, keep, x_prev, x_true, S, PG, PD, pcap, NP, np_cap, n_g, n_np):
+        """The tiled iteration with two blurs instead of four (trk_cgls_iterate_tiled2); returns (n_g, n_np)."""
+        cg, cn = ctypes.c_int(int(n_g)), ctypes.c_int(int(n_np))
+        rc = self.lib.trk_cgls_iterate_tiled2(handle, int(k_first), int(n_iters), p.data_ptr(), w.data_ptr(), R.data_ptr(), R.stride(0),
+                                              t.data_ptr(), X.data_ptr(), X.stride(0), int(bool(keep)), x_prev.data_ptr(),
+                                              None if x_true is None else x_true.data_ptr(), _ptr(S), _ptr(PG), _ptr(PD), int(pcap),
+                                              _ptr(NP), int(np_cap), ctypes.byref(cg), ctypes.byref(cn), self.stream())
+        _lib.check(rc, "trk_cgls_iterate_tiled2")
+        return cg.value, cn.value
+
     # ------------------------------------------------------------------ CGLS with one all-reduce per iteration (cgls_sharded.hip)
     def dot_pair(self, q, w, out3):
         """out3[0] = <q, q>, out3[1] = <q, w>, out3[2] = <w, w> (w None: 0, 0): this rank's sums."""

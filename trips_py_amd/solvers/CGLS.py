@@ -330,6 +330,8 @@ class CGLSRunFused(CGLSRun):
     # 32 x 32 tile recomputes its halo of p and w in LDS instead of waiting for its neighbours at a kernel boundary).
     # Measured crossover against the streaming forms: see TILED_MAX_N.
     TILED_MAX_N = 1 << 20
+    TILED_DEFAULT = 2                      # which tiled form CGLS() picks: 2 (two blurs per iteration, trk_cgls_iterate_tiled2: faster at
+                                           # every size, tools/cgls_small_sizes.py) or 1 (four; trk_cgls_iterate_tiled)
 
     @classmethod
     def tiled_usable(cls, A, eng):
@@ -340,7 +342,7 @@ class CGLSRunFused(CGLSRun):
         self.A = A = as_operator(A)
         self.eng = eng = A.engine
         m, n = A.shape
-        self.tiled = bool(tiled)
+        self.tiled = int(tiled)            # 0: streaming kernels; 1: tiled, four blurs per iteration; 2: tiled, two (w by recurrence)
         self.max_iter = max_iter = int(max_iter)
         self.bv = eng.to_vec(b, m)
         self.xt = None if x_true is None else eng.to_vec(x_true, n)
@@ -372,9 +374,7 @@ class CGLSRunFused(CGLSRun):
             x_new = self.hist.row(self.k)
             keep = self.hist.mode == "device"
             X = self.X if self.hist.mode != "stream" else _ShiftedRows(self.X, self.hist.slot(self.k) - self.k)
-            self.n_g, self.n_np = eng.cgls_iterate_tiled(A._h, self.k + 1, 1, self.P, self.R, self.t, X, keep or self.hist.mode == "stream",
-                                                         self.x_cur, self.xt, S.ref(0), self.PG.ref(0), self.PD.ref(0), self.PCAP,
-                                                         self.NP.ref(0), 1024, self.n_g, self.n_np)
+            self._tiled_call(self.k + 1, 1, X, keep or self.hist.mode == "stream")
             self.k += 1
             self.x_cur = x_new
             return
@@ -397,6 +397,17 @@ class CGLSRunFused(CGLSRun):
                                       self.PG.ref(0), self.PCAP)
         self.x_cur = x_new
 
+    def _tiled_call(self, k_first, n, X, keep):
+        eng = self.eng
+        if self.tiled == 2:
+            self.n_g, self.n_np = eng.cgls_iterate_tiled2(self.A._h, k_first, n, self.P[0], self.w, self.R, self.t, X, keep,
+                                                          self.x_cur, self.xt, self.S.ref(0), self.PG.ref(0), self.PD.ref(0),
+                                                          self.PCAP, self.NP.ref(0), 1024, self.n_g, self.n_np)
+        else:
+            self.n_g, self.n_np = eng.cgls_iterate_tiled(self.A._h, k_first, n, self.P, self.R, self.t, X, keep, self.x_cur, self.xt,
+                                                         self.S.ref(0), self.PG.ref(0), self.PD.ref(0), self.PCAP, self.NP.ref(0),
+                                                         1024, self.n_g, self.n_np)
+
     def run(self, n_steps):
         """Enqueue `n_steps` iterations in one library call (trk_cgls_iterate_fused)."""
         n_steps = min(int(n_steps), self.max_iter - self.k)
@@ -404,10 +415,7 @@ class CGLSRunFused(CGLSRun):
             return
         def call(k_first, n, X, keep):
             if self.tiled:
-                self.n_g, self.n_np = self.eng.cgls_iterate_tiled(self.A._h, k_first, n, self.P, self.R, self.t, X, keep,
-                                                                  self.x_cur, self.xt, self.S.ref(0), self.PG.ref(0),
-                                                                  self.PD.ref(0), self.PCAP, self.NP.ref(0), 1024,
-                                                                  self.n_g, self.n_np)
+                self._tiled_call(k_first, n, X, keep)
             else:
                 self.n_g, self.n_np = self.eng.cgls_iterate_fused(self.A._h, k_first, n, self.P, self.R, self.t, self.w,
                                                                   X, keep, self.x_cur, self.xt, self.S.ref(0),
@@ -453,6 +461,8 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
     fused = (not sync_each) and CGLSRunFused.usable(A, A.engine) and \
         (want if want is not None else CGLSRunFused.auto(A.shape[1]))
     tiled = (not sync_each) and want is None and kwargs.get("tiled", True) and CGLSRunFused.tiled_usable(A, A.engine)
+    if tiled:
+        tiled = int(kwargs.get("tiled", CGLSRunFused.TILED_DEFAULT))       # 1: four blurs per iteration, 2: two (w by recurrence)
     # unknowns spread over ranks, tol = 0: the one-all-reduce form (one_reduction=False keeps the two reductions of the recurrence
     # as written; one_reduction=True also selects it on a single rank, where it is the same arithmetic without the exchange)
     one_red = kwargs.get("one_reduction", None)
