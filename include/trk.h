@@ -207,6 +207,11 @@ int trk_mailbox_destroy(trk_mailbox* mb);
 int trk_mailbox_host(trk_mailbox* mb, double** host_out);
 int trk_mailbox_post(trk_mailbox* mb, int slot, const double* src_dev, int offset, int count, trk_stream stream);
 int trk_mailbox_wait(trk_mailbox* mb, int slot);
+/* trk_mailbox_post plus one more value published with it: the sum of `n_partials` device doubles (block partials of an inner
+ * product some kernel left behind: trk_gk_step_proj), stored at *sum_dev and at host[sum_offset] (outside [offset, offset+count)).
+ * One launch where a reduction launch and a second post stood. */
+int trk_mailbox_post_sum(trk_mailbox* mb, int slot, const double* src_dev, int offset, int count, const double* partials,
+                         int n_partials, double* sum_dev, int sum_offset, trk_stream stream);
 
 /* One whole Golub-Kahan step (decompositions.py:230-255) on UNNORMALISED vectors, two trk_op_apply_axpby calls:
  *   v_k    = (1/beta_k)  A^T u_k - (beta_k/alpha_{k-1}) v_prev ,  AB[2k+1] = ||v_k||^2    = alpha_k^2
@@ -217,6 +222,13 @@ int trk_mailbox_wait(trk_mailbox* mb, int slot);
  * (single rank: the next chained apply finishes them). */
 int trk_gk_step(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
                 int defer_alpha, int defer_beta, trk_stream stream);
+/* trk_gk_step that also leaves <u_next, proj> (proj: op rows floats — the discrepancy principle's U^T b, one new row per step,
+ * discrepancy_principle.py:58) as *n_partials (<= cap) block partials in `partials`: the projector's band reduction forms them
+ * next to the norm it already carries (no pass over u_next, no reduction launch; trk_mailbox_post_sum adds them up on their
+ * way to the host); operators without such a pass get one finished value from trk_dot (*n_partials = 1). */
+int trk_gk_step_proj(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
+                     int defer_alpha, int defer_beta, const float* proj, double* partials, int cap, int* n_partials,
+                     trk_stream stream);
 
 /* One fused CGLS vector update (CGLS.py:64-67):  step = *gamma / *delta ;
  *   x_new = x + step*p ; r = r - step*w ;  sums_dev[0] = ||x_new||^2, sums_dev[1] = ||step*p||^2
@@ -285,6 +297,9 @@ int trk_cgls_x_update(int64_t n, const double* gamma, int gamma_n, const double*
 int trk_bidiag_tikhonov(const double* alpha_sq, int64_t alpha_stride, const double* beta_sq, int64_t beta_stride, int k,
                         double mu, const double* beta0_sq, double* y, int y_over_alpha, double* work, int work_doubles,
                         trk_stream stream);
+/* The same solve on the HOST (float64, same recurrence) for callers that hold B_k there: alpha[k], beta_sub[k] (= B[j+1, j]),
+ * beta0 = ||b||.  Pairs with trk_gemv_n_hosty, which takes the k coefficients from host memory. */
+int trk_host_bidiag_tikhonov(const double* alpha, const double* beta_sub, int k, double beta0, double mu, int y_over_alpha, double* y);
 
 /* HOST function (no device work, no stream): lambda = argmin over [x1, x2] of the GCV function of a diagonalised
  * projected problem,  G(lam) = sum_i ((1 - f_i) rhs_i)^2 / (m_eff - sum_i f_i)^2,  f_i = s_i^2 / (s_i^2 + lam),
@@ -385,6 +400,12 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y_dev
  * trk_finalize_batched instead of one reduction-finalize launch per iterate). */
 int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y, float* out, const float* ref,
                    double* err_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
+/* out = sum_j y_host[j] V[j] with the k coefficients read from HOST memory at the call: they travel in the launch's own arguments
+ * (128 per launch; more rows = more launches adding to `out`), so a projected solution computed on the host (x = V y,
+ * Hybrid_LSQR.py:105) needs neither an upload nor a kernel of its own.  ref != NULL: block partials of ||out - ref||^2 as in
+ * trk_gemv_n_err; ref == NULL: err_partials / n_blocks unused. */
+int trk_gemv_n_hosty(const float* V, int64_t ld, int k, int64_t n, const double* y_host, float* out, const float* ref,
+                     double* err_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
 /* One step of damped LSQR's short recurrence (Paige & Saunders): the iterate x_k = V_k y_k,
  * y_k = argmin || [B_k; damp I] y - beta_1 e_1 || — what Hybrid_LSQR.py:104-105 computes with lstsq + V @ y when lambda is a
  * number (damp = sqrt(lambda)) — from the previous one in a single pass:  w <- vk / alpha_k - (theta_k / rho_{k-1}) w  (in

@@ -440,6 +440,113 @@ def test_mailbox_downloads_and_one_call_gk_step():
             assert torch.equal(V0[k], V1[k]) and torch.equal(U0[k + 1], U1[k + 1])
 
 
+@pytest.mark.parametrize("kind", ["radon", "radon_bands", "blur"])
+def test_gk_projection_rides_the_forward_pass_and_the_post(kind):
+    """krylov.GKState.step_prefetch(project=b): U^T b row by row (the discrepancy principle's projection, discrepancy_principle.py:58).
+    On the projector the forward half step's band reduction leaves <U[k+1], b> as block partials (trk_gk_step_proj) and the post of
+    the step's norms adds them up (trk_mailbox_post_sum); checked against the products of the stored rows in float64, with the
+    norms that travel in the same post, for steps enqueued one and several ahead.  The blur takes the separate-dot path."""
+    from trips_py_amd.krylov import GKState
+    from trips_py_amd.operators import Blur2D, Radon2DParallel
+    from trips_py_amd.problems import gauss_psf
+    if kind == "blur":
+        A = Blur2D(gauss_psf((5, 5), (1, 1))[0], 48, 48)
+    else:
+        N = 64 if kind == "radon" else 600            # 600: several bands
+        A = Radon2DParallel(N, np.linspace(0, np.pi, 24, endpoint=False))
+    m, n = A.shape
+    dev = A.engine.device
+    b = torch.randn(m, device=dev, generator=torch.Generator(device=dev).manual_seed(5)).abs()
+    steps = 9
+    for ahead in (1, 3):
+        gk = GKState(A, b, steps, normalized=False)
+        pending, n_enq = [], 0
+        for k in range(steps):
+            while n_enq < steps and len(pending) < ahead:
+                pending.extend(gk.step_prefetch(project=b, more_follow=n_enq + 1 < steps))
+                n_enq += 1
+            gk.absorb(pending.pop(0))
+            assert len(gk.uproj) == k + 2 and len(gk._alphas) == k + 1
+        assert not pending
+        U = gk.U.data[:steps + 1].double()
+        want = (U @ b.double()).cpu().numpy()
+        assert np.allclose(gk.uproj, want, rtol=1e-6, atol=1e-6 * float(b.norm()) ** 2)
+        ab = gk.AB.host(0, 2 * steps + 1)
+        assert np.allclose(np.square(gk._alphas), ab[1::2], rtol=1e-15) and np.allclose(np.square(gk._betas), ab[2::2], rtol=1e-15)
+        assert np.allclose(ab[2::2], (U[1:] ** 2).sum(1).cpu().numpy(), rtol=1e-5)
+        if kind != "blur":
+            assert gk._UP is not None                               # the merged path ran
+            assert np.array_equal(gk.AB.host(gk._uoff + 2, gk._uoff + steps + 1), np.asarray(gk.uproj[2:]))
+
+
+@pytest.mark.parametrize("k", [1, 5, 128, 129, 300])
+def test_projected_solve_on_the_host_and_coefficients_in_the_launch_arguments(k):
+    """trk_host_bidiag_tikhonov = trk_bidiag_tikhonov (same recurrence, float64) and trk_gemv_n_hosty = trk_gemv_n / trk_gemv_n_err
+    with the coefficients taken from host memory: one launch up to 128 rows, several beyond (one fp32 rounding more per group)."""
+    from trips_py_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(k)
+    n = 70001                                                     # not a multiple of 4: vector body + tail
+    al, be = 0.5 + rng.random(k), 0.1 + rng.random(k)
+    beta0, mu = 3.7, 0.21
+    AB = eng.scalars(2 * k + 1)
+    ab = np.empty(2 * k + 1)
+    ab[0], ab[1::2], ab[2::2] = beta0 ** 2, al ** 2, be ** 2
+    AB.set(0, ab)
+    for over in (False, True):
+        Y = eng.scalars(k)
+        eng.bidiag_tikhonov(AB.ref(1), 2, AB.ref(2), 2, k, mu, AB.ref(0), Y.ref(0), None, y_over_alpha=over)
+        yh = eng.host_bidiag_tikhonov(al, be, beta0, mu, y_over_alpha=over)
+        assert np.allclose(yh, Y.host(0, k), rtol=1e-12, atol=1e-14)
+        # against the definition: argmin || [B; mu I] y - beta0 e1 ||
+        B = np.zeros((k + 1, k))
+        B[np.arange(k), np.arange(k)], B[np.arange(1, k + 1), np.arange(k)] = al, be
+        rhs = np.zeros(2 * k + 1)
+        rhs[0] = beta0
+        yd = np.linalg.lstsq(np.vstack([B, mu * np.eye(k)]), rhs, rcond=None)[0]
+        assert np.allclose(yh * (al if over else 1.0), yd, rtol=1e-9, atol=1e-12)
+    V = torch.randn(k, n + 3, device=eng.device, generator=torch.Generator(device=eng.device).manual_seed(k))[:, :n]
+    ref = torch.randn(n, device=eng.device)
+    Y = eng.scalars(k)
+    Y.set(0, yh)
+    o0, o1, o2 = eng.empty(n), eng.empty(n), eng.empty(n)
+    P0, P1 = eng.scalars(1024), eng.scalars(1024)
+    n0 = eng.gemv_n_err(V, k, Y.ref(0), o0, ref, P0.ref(0), 1024)
+    n1 = eng.gemv_n_hosty(V, k, yh, o1, ref, P1.ref(0), 1024)
+    assert eng.gemv_n_hosty(V, k, yh, o2) == 0
+    assert n0 == n1 and torch.equal(o1, o2)
+    if k <= 128:
+        assert torch.equal(o0, o1) and np.array_equal(P0.host(0, n0), P1.host(0, n1))
+    else:
+        assert float((o0 - o1).norm() / o0.norm()) < 3e-7
+        assert np.allclose(P0.host(0, n0).sum(), P1.host(0, n1).sum(), rtol=1e-6)
+    want = (torch.from_numpy(yh).to(eng.device) @ V.double()).float()
+    assert float((o1 - want).norm() / want.norm()) < 3e-7
+
+
+def test_hybrid_lsqr_host_projected_solve_equals_the_device_one():
+    """Automatic lambda: y_k on the host + coefficients in the launch arguments (the default) against the device solve."""
+    from trips_py_amd.operators import Radon2DParallel
+    from trips_py_amd.solvers import Hybrid_LSQR
+    N = 96
+    A = Radon2DParallel(N, np.linspace(0, np.pi, 40, endpoint=False))
+    rng = np.random.default_rng(10)
+    xt = rng.random(N * N).astype(np.float32)
+    b = A.apply(torch.from_numpy(xt).cuda())
+    e = torch.randn_like(b)
+    delta = 0.02 * float(b.norm())
+    b = (b + e * (delta / e.norm())).cpu().numpy()
+    for reg, kw in (("gcv", {}), ("dp", {"delta": delta})):
+        for xtrue in (xt, None):
+            x0, i0 = Hybrid_LSQR(A, b, 30, reg, xtrue, host_projected_solve=False, **kw)
+            x1, i1 = Hybrid_LSQR(A, b, 30, reg, xtrue, **kw)
+            assert i0["regParam_history"] == i1["regParam_history"]
+            assert relerr(x1, x0) < 1e-6
+            assert all(relerr(p, q) < 1e-6 for p, q in zip(i1["xHistory"], i0["xHistory"]))
+            if xtrue is not None:
+                assert np.allclose(i0["relError"], i1["relError"], rtol=1e-6)
+
+
 @pytest.mark.parametrize("reg", ["gcv", "dp"])
 def test_hybrid_lsqr_pipelined_loop_equals_the_plain_one(reg):
     """Automatic lambda: steps enqueued ahead, the search on the worker thread and the iterate formed one trip late give the

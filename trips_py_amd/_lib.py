@@ -223,6 +223,12 @@ SIGNATURES = {
     "trk_mailbox_host": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),
     "trk_mailbox_post": (c_int, [ctypes.c_void_p, c_int, c_f64p, c_int, c_int, c_stream]),
     "trk_mailbox_wait": (c_int, [ctypes.c_void_p, c_int]),
+    "trk_mailbox_post_sum": (c_int, [ctypes.c_void_p, c_int, c_f64p, c_int, c_int, c_f64p, c_int, c_f64p, c_int, c_stream]),
+    "trk_gk_step_proj": (c_int, [c_op, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_f32p, c_f64p, c_int,
+                                 ctypes.POINTER(c_int), c_stream]),
+    "trk_host_bidiag_tikhonov": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_int, c_dbl, c_dbl, c_int, ctypes.c_void_p]),
+    "trk_gemv_n_hosty": (c_int, [c_f32p, c_i64, c_int, c_i64, ctypes.c_void_p, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int),
+                                 c_stream]),
     "trk_gk_step": (c_int, [c_op, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_stream]),
     "trk_lsqr_damped_update": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int),
                                        c_f64p, c_f64p, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_stream]),

@@ -328,6 +328,22 @@ __global__ void k_mailbox_post(const double* __restrict__ src, double* dst, int 
     __hip_atomic_store(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+// the same with one more value in front of the publication: the sum of n block partials (one wave, the fixed order of
+// trk_internal.h's ScalarSrc), stored on the device (*sum_dev) and in the mailbox (*sum_host)
+__global__ void k_mailbox_post_sum(const double* __restrict__ src, double* dst, int count, const double* __restrict__ part, int n,
+                                   double* sum_dev, double* sum_host, unsigned long long* seq, unsigned long long value) {
+  for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
+  const double t = scalar_from_wave(ScalarSrc{part, n}, threadIdx.x);      // launched with one wave
+  if (threadIdx.x == 0) {
+    *sum_dev = t;
+    *sum_host = t;
+  }
+  __threadfence_system();
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(seq, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
 }  // namespace
 
 int trk_mailbox_create(int n_doubles, int slots, trk_mailbox** out) {
@@ -372,6 +388,20 @@ int trk_mailbox_post(trk_mailbox* mb, int slot, const double* src_dev, int offse
   return TRK_OK;
 }
 
+int trk_mailbox_post_sum(trk_mailbox* mb, int slot, const double* src_dev, int offset, int count, const double* partials,
+                         int n_partials, double* sum_dev, int sum_offset, trk_stream stream) {
+  TRK_REQUIRE(mb && src_dev && partials && sum_dev && slot >= 0 && slot < mb->slots, "trk_mailbox_post_sum: bad mailbox / slot / NULL argument");
+  TRK_REQUIRE(offset >= 0 && count > 0 && offset + count <= mb->n, "trk_mailbox_post_sum: range outside the mailbox");
+  TRK_REQUIRE(n_partials >= 1 && sum_offset >= 0 && sum_offset < mb->n && (sum_offset < offset || sum_offset >= offset + count),
+              "trk_mailbox_post_sum: need n_partials >= 1 and a sum position inside the mailbox, outside the copied range");
+  mb->expect[slot] = ++mb->counter;
+  mb->stream[slot] = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_mailbox_post_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, src_dev, mb->host + offset, count, partials,
+                     n_partials, sum_dev, mb->host + sum_offset, mb->seq + slot, mb->expect[slot]);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
 int trk_mailbox_wait(trk_mailbox* mb, int slot) {
   TRK_REQUIRE(mb && slot >= 0 && slot < mb->slots, "trk_mailbox_wait: bad mailbox / slot");
   const unsigned long long want = mb->expect[slot];
@@ -404,6 +434,28 @@ int trk_gk_step(trk_op* op, int k, const float* u_k, const float* v_prev, float*
   // U[k+1] = (1/alpha_k) A V[k] - (alpha_k/beta_k) U[k]
   return trk_op_apply_axpby(op, 0, v_k, 1.0, nullptr, a2, TRK_SQRT_DEN, -1.0, a2, bk2, TRK_SQRT_NUM | TRK_SQRT_DEN, u_k, u_next, b2,
                             feeds | takes | (defer_beta ? later : 0), stream);
+}
+
+int trk_gk_step_proj(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
+                     int defer_alpha, int defer_beta, const float* proj, double* partials, int cap, int* n_partials,
+                     trk_stream stream) {
+  TRK_REQUIRE(op && proj && partials && n_partials && cap >= 1, "trk_gk_step_proj: bad argument");
+  op->probe_vec = proj;
+  op->probe_part = partials;
+  op->probe_cap = cap;
+  op->probe_n = 0;
+  const int rc = trk_gk_step(op, k, u_k, v_prev, v_k, u_next, AB, chained, defer_alpha, defer_beta, stream);
+  const int n = op->probe_n;
+  op->probe_vec = nullptr;
+  op->probe_part = nullptr;
+  op->probe_cap = op->probe_n = 0;
+  if (rc) return rc;
+  *n_partials = n;
+  if (n == 0) {                       // this operator's output pass carries no dot: one finished value, taken separately
+    *n_partials = 1;
+    return trk_dot(u_next, proj, op->rows, partials, stream);
+  }
+  return TRK_OK;
 }
 
 int trk_op_destroy(trk_op* op) {

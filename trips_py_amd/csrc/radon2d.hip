@@ -104,6 +104,9 @@ struct Epi {
   double* pend_target;
   const double* pend_part;
   int pend_n;
+  // forward only (trk_gk_step_proj): block partials of <out, dotv> next to the fused norm's
+  const float* dotv;
+  double* dot_part;
 };
 
 // the sum of the pending partials — the same bits in every workgroup (one wave, fixed order) — in all threads
@@ -704,6 +707,7 @@ __global__ __launch_bounds__(256) void k_radon_bands_post(const float* __restric
     return Raw{ang[r].wgt * (float)t, (epi.on && epi.z) ? epi.z[k] : 0.f};
   };
   const Raw r0 = valid ? raw(row, d) : Raw{0.f, 0.f};
+  const float dv = (epi.dot_part && valid && d >= 0 && d < nd) ? epi.dotv[row * nd + d] : 0.f;
   Raw rm{0.f, 0.f}, rp{0.f, 0.f};
   if (REC) {
     if (threadIdx.x == 0 && valid && e > 0) rm = raw(row, d - 1);
@@ -745,6 +749,10 @@ __global__ __launch_bounds__(256) void k_radon_bands_post(const float* __restric
   if (ssq_part) {                                                 // uniform over the grid
     const double q = block_sum<256>((double)v0 * v0, lds);
     if (threadIdx.x == 0) ssq_part[blockIdx.x] = q;
+  }
+  if (epi.dot_part) {                                             // uniform over the grid
+    const double q = block_sum<256>((double)v0 * dv, lds);
+    if (threadIdx.x == 0) epi.dot_part[blockIdx.x] = q;
   }
 }
 
@@ -1186,6 +1194,8 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   epi.pend_target = nullptr;
   epi.pend_part = nullptr;
   epi.pend_n = 0;
+  epi.dotv = nullptr;
+  epi.dot_part = nullptr;
   if (im->pend_target) {
     if (epi.on && (hints & HINT_INPUT_FROM_OPPOSITE)) {
       epi.pend_target = im->pend_target;
@@ -1219,6 +1229,11 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   const bool fuse_ssq = sumsq && batch == 1 && (tr ? tile : post);
   const int64_t post_blocks = ceil_div((int64_t)nt * na * ndp, 256);
   const int64_t n_part = tr ? adj_blocks * nt : post_blocks;
+  if (!tr && post && batch == 1 && op->probe_vec && post_blocks <= op->probe_cap) {      // trk_gk_step_proj: <out, probe_vec> partials
+    epi.dotv = op->probe_vec;
+    epi.dot_part = op->probe_part;
+    op->probe_n = (int)post_blocks;
+  }
   const bool defer = fuse_ssq && epi.on && (hints & HINT_SUMSQ_DEFERRED) && n_part <= im->pend_cap;
   const bool raw_out = ext_part && fuse_ssq && n_part <= ext_cap;
   if (ext_n) *ext_n = raw_out ? (int)n_part : 1;

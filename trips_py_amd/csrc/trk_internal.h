@@ -245,5 +245,10 @@ struct trk_op {
                      double* sumsq, int hints, hipStream_t s) = nullptr;
   // optional: finish what a TRK_HINT_SUMSQ_DEFERRED apply left unfinished (trk_op_flush)
   int (*flush)(trk_op*, hipStream_t s) = nullptr;
+  // set for the duration of one trk_gk_step_proj call: the forward half step's output pass also leaves the block partials of
+  // <out, probe_vec> in probe_part and their count in probe_n (0: this operator's pass does not — the caller takes a separate dot)
+  const float* probe_vec = nullptr;
+  double* probe_part = nullptr;
+  int probe_cap = 0, probe_n = 0;
   void* aux = nullptr;   // malloc'ed per-handle cache of a consumer (cgls_tiled.hip: tile geometry + weights); freed with the handle
 };

@@ -727,14 +727,30 @@ int launch_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, 
 constexpr int KMAX_LDS = 1024;  // coefficients staged in LDS as doubles
 
 // HAS_REF: the partials are those of sum (out - ref)^2 instead of sum out^2 (the error norm against x_true)
-template <bool HAS_BASE, bool SUMSQ, bool VEC, bool HAS_REF = false, int U = 8>
-__global__ __launch_bounds__(NT) void k_gemv_n(const float* __restrict__ V, int64_t ld, int k, int64_t n,
-                                               const double* __restrict__ y, double a, const float* base, double sc,
+// where the k coefficients come from: device memory, or the launch's own arguments (values the HOST holds — the projected solution
+// of a hybrid solver whose lambda was chosen there — ride in the dispatch packet: no upload, no kernel that computes them)
+struct YPtr {
+  const double* p;
+  __device__ __forceinline__ double at(int j) const { return p[j]; }
+};
+constexpr int YARG_MAX = 128;
+struct YArg {
+  double v[YARG_MAX];
+  // read where the dispatch put them — the kernel-argument segment, of which this struct is the FIRST member (k_gemv_n) — and not
+  // through `v`: indexing a by-value aggregate with the thread index makes every thread copy all of it to scratch first
+  __device__ __forceinline__ double at(int j) const {
+    return ((const __attribute__((address_space(4))) double*)__builtin_amdgcn_kernarg_segment_ptr())[j];
+  }
+};
+
+template <bool HAS_BASE, bool SUMSQ, bool VEC, bool HAS_REF = false, int U = 8, class YS = YPtr>
+__global__ __launch_bounds__(NT) void k_gemv_n(const YS y, const float* __restrict__ V, int64_t ld, int k, int64_t n,
+                                               double a, const float* base, double sc,
                                                float* out, double* __restrict__ partials,
                                                const float* __restrict__ ref = nullptr, int nt = 0) {
   __shared__ double ys[KMAX_LDS];
   __shared__ double lds[NT / 64];
-  for (int j = threadIdx.x; j < k; j += NT) ys[j] = sc * y[j];
+  for (int j = threadIdx.x; j < k; j += NT) ys[j] = sc * y.at(j);
   __syncthreads();
   double acc2 = 0.0;
   const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
@@ -1684,9 +1700,9 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, do
   const int grid_n = gmul > 0 ? (int)std::min<int64_t>((n + (int64_t)NT * 4 - 1) / ((int64_t)NT * 4), (int64_t)cu_count() * gmul) : grid;
 #define GN(HB, SS, VC)                                                                                                            \
   do {                                                                                                                            \
-    if (U >= 16) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC, false, 16>), dim3(grid_n), dim3(NT), 0, s, V, ld, k, n, y, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n)); \
-    else if (U >= 8) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC, false, 8>), dim3(grid_n), dim3(NT), 0, s, V, ld, k, n, y, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n)); \
-    else hipLaunchKernelGGL((k_gemv_n<HB, SS, VC, false, 4>), dim3(grid_n), dim3(NT), 0, s, V, ld, k, n, y, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n)); \
+    if (U >= 16) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC, false, 16>), dim3(grid_n), dim3(NT), 0, s, YPtr{y}, V, ld, k, n, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n)); \
+    else if (U >= 8) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC, false, 8>), dim3(grid_n), dim3(NT), 0, s, YPtr{y}, V, ld, k, n, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n)); \
+    else hipLaunchKernelGGL((k_gemv_n<HB, SS, VC, false, 4>), dim3(grid_n), dim3(NT), 0, s, YPtr{y}, V, ld, k, n, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n)); \
   } while (0)
   if (base) {
     if (sumsq) { if (vec) GN(true, true, true); else GN(true, true, false); }
@@ -1711,9 +1727,46 @@ int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y
   hipStream_t s = (hipStream_t)st;
   const float* nobase = nullptr;
   if (aligned16(V) && aligned16(out) && aligned16(ref) && (ld % 4 == 0))
-    hipLaunchKernelGGL((k_gemv_n<false, true, true, true>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, y, 1.0, nobase, 1.0, out, err_partials, ref);
+    hipLaunchKernelGGL((k_gemv_n<false, true, true, true>), dim3(grid), dim3(NT), 0, s, YPtr{y}, V, ld, k, n, 1.0, nobase, 1.0, out, err_partials, ref);
   else
-    hipLaunchKernelGGL((k_gemv_n<false, true, false, true>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, y, 1.0, nobase, 1.0, out, err_partials, ref);
+    hipLaunchKernelGGL((k_gemv_n<false, true, false, true>), dim3(grid), dim3(NT), 0, s, YPtr{y}, V, ld, k, n, 1.0, nobase, 1.0, out, err_partials, ref);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_gemv_n_hosty(const float* V, int64_t ld, int k, int64_t n, const double* y_host, float* out, const float* ref,
+                     double* err_partials, int capacity_blocks, int* n_blocks, trk_stream st) {
+  TRK_REQUIRE(V && y_host && out, "trk_gemv_n_hosty: NULL argument");
+  TRK_REQUIRE(!ref || (err_partials && n_blocks), "trk_gemv_n_hosty: ref given but no room for the partials");
+  TRK_REQUIRE(k >= 1 && n >= 0 && ld >= n, "trk_gemv_n_hosty: need k >= 1, n >= 0, ld >= n");
+  const int grid = stream_grid(n);
+  if (ref) {
+    TRK_REQUIRE(grid <= capacity_blocks, "trk_gemv_n_hosty: partial buffer too small (%d blocks needed)", grid);
+    *n_blocks = grid;
+  }
+  hipStream_t s = (hipStream_t)st;
+  const bool vec = aligned16(V) && aligned16(out) && (!ref || aligned16(ref)) && (ld % 4 == 0);
+  // YARG_MAX coefficients per launch; further groups of rows add to what the launches before them left in `out` (rounded to
+  // fp32 in between: one rounding more per 128 terms), the last one carries the error norm
+  for (int j0 = 0; j0 < k; j0 += YARG_MAX) {
+    const int kk = std::min(YARG_MAX, k - j0);
+    const bool last = j0 + kk == k, first = j0 == 0;
+    YArg ya;
+    for (int j = 0; j < kk; ++j) ya.v[j] = y_host[j0 + j];
+    for (int j = kk; j < YARG_MAX; ++j) ya.v[j] = 0.0;
+    const float* Vj = V + (int64_t)j0 * ld;
+    const float* base = first ? nullptr : out;
+    double* part = (last && ref) ? err_partials : nullptr;
+#define GH(HB, SS, VC, HR) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC, HR, 8, YArg>), dim3(grid), dim3(NT), 0, s, ya, Vj, ld, kk, n, 1.0, base, 1.0, out, part, ref, 0)
+    if (first) {
+      if (part) { if (vec) GH(false, true, true, true); else GH(false, true, false, true); }
+      else      { if (vec) GH(false, false, true, false); else GH(false, false, false, false); }
+    } else {
+      if (part) { if (vec) GH(true, true, true, true); else GH(true, true, false, true); }
+      else      { if (vec) GH(true, false, true, false); else GH(true, false, false, false); }
+    }
+#undef GH
+  }
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }

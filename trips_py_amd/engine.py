@@ -105,6 +105,19 @@ class DevScalars:
         ev.record()
         return _Pending(ev, self._pin, i, j)
 
+    def host_later_sum(self, i, j, partials, n_partials, at):
+        """host_later(i, j) that also publishes the sum of `n_partials` block partials (device address `partials`) as scalar `at`
+        of this block (outside [i, j)), on the device and on the host, with the same launch (trk_mailbox_post_sum).
+        Returns two handles: the copied range and the one summed value."""
+        eng = self._eng
+        if self._mb is None:
+            self.host_later(i, j).get()        # (creates the mailbox; the extra post only on the first call)
+        slot = self._mb_slot
+        self._mb_slot = (slot + 1) % self.MAILBOX_SLOTS
+        _lib.check(eng.lib.trk_mailbox_post_sum(self._mb, slot, self.base + 8 * i, int(i), int(j - i), _ptr(partials), int(n_partials),
+                                                self.base + 8 * at, int(at), eng.stream()), "trk_mailbox_post_sum")
+        return (_Posted(eng.lib, self._mb, slot, self._mb_np, i, j, self), _Posted(eng.lib, self._mb, slot, self._mb_np, at, at + 1, self))
+
     def set(self, i, values):
         v = torch.as_tensor(np.atleast_1d(np.asarray(values, dtype=np.float64)))
         self.t[i:i + v.numel()].copy_(v, non_blocking=False)
@@ -607,12 +620,41 @@ class HipEngine:
         _lib.check(rc, "trk_gemv_n_err")
         return n.value
 
+    def host_bidiag_tikhonov(self, alphas, betas, beta0, mu, y_over_alpha=False):
+        """argmin || [B_k; mu I] y - beta0 e_1 || on the host (trk_host_bidiag_tikhonov) from B_k's entries; a float64 array."""
+        al = np.ascontiguousarray(alphas, dtype=np.float64)
+        be = np.ascontiguousarray(betas, dtype=np.float64)
+        y = np.empty(al.size, dtype=np.float64)
+        rc = self.lib.trk_host_bidiag_tikhonov(al.ctypes.data, be.ctypes.data, int(al.size), float(beta0), float(mu),
+                                               int(bool(y_over_alpha)), y.ctypes.data)
+        _lib.check(rc, "trk_host_bidiag_tikhonov")
+        return y
+
+    def gemv_n_hosty(self, V, k, y_host, out, ref=None, partials=None, capacity=0):
+        """out = sum_j y_host[j] V[j], the coefficients a float64 HOST array (they ride in the launch's arguments: trk_gemv_n_hosty);
+        with `ref`, raw block partials of ||out - ref||^2 into `partials` — returns their count (0 without)."""
+        n = ctypes.c_int(0)
+        rc = self.lib.trk_gemv_n_hosty(V.data_ptr(), V.stride(0), int(k), out.numel(), y_host.ctypes.data, out.data_ptr(),
+                                       None if ref is None else ref.data_ptr(), _ptr(partials), int(capacity), ctypes.byref(n),
+                                       self.stream())
+        _lib.check(rc, "trk_gemv_n_hosty")
+        return n.value
+
     def gk_step(self, handle, k, u_k, v_prev, v_k, u_next, AB, chained, defer_alpha, defer_beta):
         """One Golub-Kahan step on unnormalised vectors in one call (trk_gk_step): both half steps with their norms."""
         rc = self.lib.trk_gk_step(handle, int(k), u_k.data_ptr(), None if v_prev is None else v_prev.data_ptr(), v_k.data_ptr(),
                                   u_next.data_ptr(), AB.base, int(bool(chained)), int(bool(defer_alpha)), int(bool(defer_beta)),
                                   self.stream())
         _lib.check(rc, "trk_gk_step")
+
+    def gk_step_proj(self, handle, k, u_k, v_prev, v_k, u_next, AB, chained, defer_alpha, defer_beta, proj, partials, cap):
+        """gk_step that also leaves <u_next, proj> as block partials at `partials` (trk_gk_step_proj); returns their count."""
+        n = ctypes.c_int(0)
+        rc = self.lib.trk_gk_step_proj(handle, int(k), u_k.data_ptr(), None if v_prev is None else v_prev.data_ptr(), v_k.data_ptr(),
+                                       u_next.data_ptr(), AB.base, int(bool(chained)), int(bool(defer_alpha)), int(bool(defer_beta)),
+                                       proj.data_ptr(), _ptr(partials), int(cap), ctypes.byref(n), self.stream())
+        _lib.check(rc, "trk_gk_step_proj")
+        return n.value
 
     def lsqr_damped_update(self, vk, w, x_in, x_out, alpha_sq, beta_next_sq, beta0_sq, damp, state_in, state_out, first,
                            ref=None, partials=None, capacity=0):

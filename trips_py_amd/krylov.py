@@ -72,8 +72,11 @@ class GKState:
     (same alpha, beta; one rounding less per element) — two kernels and 8 (n + m) bytes less per step.  Consumers
     divide by the norms themselves: x = V y takes y_j / alpha_j, U^T b gives beta_j (u_j . b)."""
 
+    PROJ_PARTIALS = 4096            # room for the block partials of <U[k+1], project> (512^2 x 180 angles: 363)
+
     def __init__(self, A, b, capacity, normalized=True):
         self.A, self.eng = A, A.engine
+        self._proj, self._proj_n = None, 0
         self.normalized = bool(normalized)
         # operators whose own output pass takes the vector update and the norm of a half step (the Radon projector)
         self.native_axpby = bool(getattr(A, "native_axpby", False)) and not self.normalized
@@ -85,7 +88,12 @@ class GKState:
         self.U = DeviceBasis(eng, m, capacity + 1)
         self.V = DeviceBasis(eng, n, capacity)
         self.tmp_n, self.tmp_m = eng.empty(n), eng.empty(m)
-        self.AB = eng.scalars(2 * max(1, capacity) + 1)
+        # behind the 2 capacity + 1 squared norms: capacity + 2 places for U^T b (step_prefetch(project=...)), so that one mailbox
+        # post carries a step's norms and its new U^T b entry together
+        self._ab_cap = 2 * max(1, capacity) + 1
+        self._uoff = self._ab_cap
+        self._UP, self._merged = None, False    # block partials of <U[k+1], project>, two halves by step parity
+        self.AB = eng.scalars(self._ab_cap + max(1, capacity) + 2)
         self._alphas, self._betas = [], []
         bv = eng.to_vec(b, m)
         eng.nrm2sq(bv, self.AB.ref(0))
@@ -106,6 +114,7 @@ class GKState:
         st.normalized = True
         st.native_axpby, st._chained = False, False
         st._UB, st.uproj = None, None
+        st._proj, st._proj_n = None, 0
         st._late, st._posted_any = None, False
         eng = A.engine
         m, n = A.shape
@@ -118,7 +127,9 @@ class GKState:
             st.V.next_slot().copy_(eng.to_vec(v, n))
             st.V.commit()
         st.tmp_n, st.tmp_m = eng.empty(n), eng.empty(m)
-        st.AB = eng.scalars(2 * (k + 1) + 1)
+        st._ab_cap = 2 * (k + 1) + 1
+        st._uoff, st._UP, st._merged = None, None, False
+        st.AB = eng.scalars(st._ab_cap)
         if k:
             ab = np.zeros(2 * k + 1)
             ab[1::2], ab[2::2] = np.square(alphas), np.square(betas)
@@ -167,10 +178,25 @@ class GKState:
         the norms — `self.uproj` grows by one entry per absorbed step — instead of a pass over all of U and a blocking
         download per iteration."""
         k = self.V.k
-        self.step(sync=False, defer=bool(more_follow))
+        eng = self.eng
         j0 = None
-        if project is not None:
-            eng = self.eng
+        # one rank, an operator the library steps in one call: the forward half step's own output pass leaves <U[k+1], project> as
+        # block partials (trk_gk_step_proj), and the post of the step's norms adds them up on the way to the host
+        # (trk_mailbox_post_sum) — a dot, its reduction launch and a second post less per step.  The first step (which also owes
+        # U[0] . project) and everything else take the dots separately.
+        merged = (project is not None and k > 0 and hasattr(eng, "gk_step_proj") and getattr(eng, "world", 1) == 1
+                  and self.native_axpby and getattr(self.A, "_h", None) and self._uoff is not None and self._UB is not None
+                  and 2 * k + 3 <= self._ab_cap)
+        if merged:
+            if self._UP is None:
+                self._UP = eng.scalars(2 * self.PROJ_PARTIALS)
+            self._proj = (project, self._UP.ref(self.PROJ_PARTIALS * (k & 1)), self.PROJ_PARTIALS)
+        self.step(sync=False, defer=bool(more_follow))
+        n_part = self._proj_n if merged else 0
+        self._proj = None
+        if merged:
+            j0 = ("merged", self._UP.ref(self.PROJ_PARTIALS * (k & 1)), n_part)
+        elif project is not None:
             if self._UB is None:
                 self._UB = eng.scalars(self.U.data.shape[0] + 1)
                 self.uproj = []
@@ -192,6 +218,11 @@ class GKState:
         first = not self._posted_any
         self._posted_any = True
         lo = 0 if first else 2 * k + 1
+        if isinstance(j0, tuple):                   # the norms and the new U^T b entry (AB[uoff + k + 1]) in one post
+            _, part, n_part = j0
+            at = self._uoff + k + 1
+            handle, extra = self.AB.host_later_sum(lo, 2 * k + 3, part, n_part, at)
+            return k, lo, handle, extra
         extra = None if j0 is None else self._UB.host_later(j0, k + 2)
         return k, lo, self.AB.host_later(lo, 2 * k + 3), extra
 
@@ -219,11 +250,12 @@ class GKState:
         A, eng = self.A, self.eng
         k = self.V.k
         defer = bool(defer) and not sync
-        if len(self.AB) < 2 * k + 3:
+        if self._ab_cap < 2 * k + 3:
             self.flush()
             new = eng.scalars(4 * k + 8)
             new.view(0, 2 * k + 1).copy_(self.AB.view(0, 2 * k + 1))
             self.AB = new
+            self._ab_cap, self._uoff = 4 * k + 8, None       # (no U^T b places behind the regrown block: separate dots from here on)
         AB = self.AB
         u = self.U[k]
         a2, b2 = AB.ref(2 * k + 1), AB.ref(2 * k + 2)
@@ -246,7 +278,10 @@ class GKState:
                     # the whole step in one call of the library (trk_gk_step: the two half steps below, same coefficients,
                     # same hints) — the Python side of a step was a fifth of a 512^2 Hybrid-LSQR iteration's host time
                     un = self.U.next_slot()
-                    eng.gk_step(A._h, k, u, None if k == 0 else self.V[k - 1], v, un, AB, self._chained, True, defer)
+                    if getattr(self, "_proj", None) is not None:
+                        self._proj_n = eng.gk_step_proj(A._h, k, u, self.V[k - 1], v, un, AB, self._chained, True, defer, *self._proj)
+                    else:
+                        eng.gk_step(A._h, k, u, None if k == 0 else self.V[k - 1], v, un, AB, self._chained, True, defer)
                     self.V.commit()
                     self.U.commit()
                     self._chained = True

@@ -83,6 +83,8 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         eng.allreduce(E, 0, 1)
     # ||x_i - x_true||^2 as raw block partials of the kernel that forms x_i, summed once after the loop
     err_fused = xt is not None and hasattr(eng, "gemv_n_err")
+    host_y = (isinstance(regparam, str) and hasattr(eng, "gemv_n_hosty") and kwargs.get("host_projected_solve", True)
+              and (xt is None or err_fused))
     EP = eng.scalars(1024 * max(1, n_iter)) if err_fused else None
     n_ep = 0
 
@@ -121,6 +123,19 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             return                           # nobody looks at this iterate (history=False, no x_true)
         # y = lstsq([B; sqrt(lam) I], [beta0 e1; 0]) (:104), on the device from the squared norms in gk.AB
         # (as y_j / alpha_j: the rows of V are alpha_j v_j)
+        if host_y:
+            # automatic lambda: B_k is on the host already (lambda_k was chosen from it), and so is the projected solve — O(k) on a
+            # CPU core, where one GPU lane spent 5-25 us on the dependent square roots and divisions of a recurrence that restarts
+            # whenever lambda moves; the k coefficients reach the device in the arguments of the launch that forms x_k
+            yk = eng.host_bidiag_tikhonov(gk._alphas[:k], gk._betas[:k], gk.beta0, np.sqrt(lam), y_over_alpha=True)
+            x_dev = H.row(nx_done)
+            if xt is not None:
+                n_ep = eng.gemv_n_hosty(gk.V.data, k, yk, x_dev, xt, EP.ref(n_ep * nx_done), 1024)
+            else:
+                eng.gemv_n_hosty(gk.V.data, k, yk, x_dev)
+            H.pushed(nx_done)
+            nx_done += 1
+            return
         if not on_host:
             gk.flush()                       # (automatic lambda: the norms of step k were downloaded, hence finished, before this)
         eng.bidiag_tikhonov(gk.AB.ref(1), 2, gk.AB.ref(2), 2, k, np.sqrt(lam), gk.AB.ref(0), Y.ref(0), W, y_over_alpha=True)
