@@ -201,6 +201,9 @@ int trk_op_apply_axpby(trk_op* op, int transpose, const float* x, double ca, con
  * hybrid solvers use to fetch alpha_k, beta_{k+1} (the entries of B_k, Hybrid_LSQR.py:69-75) while later steps are already
  * running.  The copy is a one-wave kernel writing host-coherent memory and publishing a sequence number the host polls: no
  * copy-engine operation and no event on the compute stream. */
+/* The other direction: `count` host doubles to device memory, stream-ordered, carried by the launch's own arguments (128 per
+ * launch) — src_host is free when the call returns; no staging copy, no synchronisation. */
+int trk_scalars_put(double* dst_dev, const double* src_host, int count, trk_stream stream);
 typedef struct trk_mailbox trk_mailbox;
 int trk_mailbox_create(int n_doubles, int slots, trk_mailbox** out);
 int trk_mailbox_destroy(trk_mailbox* mb);

@@ -413,6 +413,17 @@ def test_mailbox_downloads_and_one_call_gk_step():
     hs = [S.host_later(i, i + 3) for i in range(0, 36)]           # more posts than slots: early handles wait on later posts
     for i, h in enumerate(hs):
         assert np.array_equal(h.get(), vals[i:i + 3])
+    # the other direction (trk_scalars_put: host doubles in the arguments of a launch), one launch and several, with an offset
+    big = eng.scalars(700)
+    up = np.random.default_rng(0).standard_normal(300 + 131)
+    big.set(7, up[:300])
+    big.set(400, up[300:])
+    big.set(699, 2.5)
+    got = big.host(0, 700)
+    assert np.array_equal(got[7:307], up[:300]) and np.array_equal(got[400:531], up[300:]) and got[699] == 2.5
+    assert not got[:7].any() and not got[307:400].any() and not got[531:699].any()
+    with pytest.raises(IndexError):
+        big.set(650, up[:100])
     x = torch.rand(1 << 20, device=eng.device)
     eng.nrm2sq(x, S.ref(5))
     h = S.host_later(5, 6)                                        # behind the kernel that writes it

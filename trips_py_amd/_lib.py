@@ -218,6 +218,7 @@ SIGNATURES = {
                                                 c_dbl, c_int]),
     "trk_host_worker_post_dp_bidiag": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_int, ctypes.c_void_p, c_dbl, c_dbl]),
     "trk_host_worker_collect": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
+    "trk_scalars_put": (c_int, [c_f64p, ctypes.c_void_p, c_int, c_stream]),
     "trk_mailbox_create": (c_int, [c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "trk_mailbox_destroy": (c_int, [ctypes.c_void_p]),
     "trk_mailbox_host": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p)]),

@@ -1,6 +1,8 @@
 // core.hip — library plumbing: error strings, per-stream scratch, the fixed-order finalize kernel,
 // operator-handle dispatch and the block-diagonal (frame-major) composite.
 #include "trk_internal.h"
+
+#include <algorithm>
 #include <cstring>
 
 #include <cstdlib>
@@ -345,6 +347,31 @@ __global__ void k_mailbox_post_sum(const double* __restrict__ src, double* dst, 
   }
 }
 }  // namespace
+
+// ------------------------------------------------------------------ host doubles -> device, inside a launch
+// The counterpart of the mailbox: up to 128 doubles per launch travel in the kernel's own arguments (read through the
+// kernel-argument segment: the struct is the first parameter) and one wave stores them.  Stream-ordered, the host array is free
+// when the call returns, no staging copy and no synchronisation — what hipMemcpy from pageable memory costs a solver loop that
+// uploads a k-vector per iteration (GKS / MMGKS with automatic lambda: the projected solution).
+namespace {
+struct PutArg { double v[128]; };
+__global__ void k_scalars_put(const PutArg a, double* __restrict__ dst, int count) {
+  const auto* src = (const __attribute__((address_space(4))) double*)__builtin_amdgcn_kernarg_segment_ptr();
+  for (int i = threadIdx.x; i < count; i += blockDim.x) dst[i] = src[i];
+}
+}  // namespace
+
+int trk_scalars_put(double* dst_dev, const double* src_host, int count, trk_stream stream) {
+  TRK_REQUIRE(count >= 0 && (count == 0 || (dst_dev && src_host)), "trk_scalars_put: bad argument");
+  for (int i0 = 0; i0 < count; i0 += 128) {
+    const int c = std::min(128, count - i0);
+    PutArg a;
+    memcpy(a.v, src_host + i0, sizeof(double) * (size_t)c);
+    hipLaunchKernelGGL(k_scalars_put, dim3(1), dim3(64), 0, (hipStream_t)stream, a, dst_dev + i0, c);
+  }
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
 
 int trk_mailbox_create(int n_doubles, int slots, trk_mailbox** out) {
   TRK_REQUIRE(out && n_doubles > 0 && slots > 0 && slots <= 4096, "trk_mailbox_create: bad argument");

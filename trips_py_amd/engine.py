@@ -119,7 +119,16 @@ class DevScalars:
         return (_Posted(eng.lib, self._mb, slot, self._mb_np, i, j, self), _Posted(eng.lib, self._mb, slot, self._mb_np, at, at + 1, self))
 
     def set(self, i, values):
-        v = torch.as_tensor(np.atleast_1d(np.asarray(values, dtype=np.float64)))
+        a = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64)).reshape(-1))
+        eng = self._eng
+        if eng is not None and a.size <= 4096:
+            # in the arguments of a one-wave launch (trk_scalars_put): stream-ordered like the copy below, but no staging of
+            # pageable memory and no synchronisation — GKS / MMGKS with automatic lambda upload a k-vector per iteration
+            if i < 0 or i + a.size > self.t.numel():
+                raise IndexError("DevScalars.set: range outside the block")
+            _lib.check(eng.lib.trk_scalars_put(self.base + 8 * i, a.ctypes.data, int(a.size), eng.stream()), "trk_scalars_put")
+            return
+        v = torch.as_tensor(a)
         self.t[i:i + v.numel()].copy_(v, non_blocking=False)
 
     def __len__(self):
