@@ -383,6 +383,10 @@ int trk_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, con
  * w_out may alias w_in; h and g are k device doubles (g must not alias h). */
 int trk_gemv_nt(const float* V, int64_t ld, int k, int64_t n, const double* h_dev, const float* w_in, float* w_out,
                 double* g_dev, trk_stream stream);
+/* trk_gemv_t with one more row that is not part of the basis: h[j] = V[j] . r (j < k) and *h_x = xrow . r from the same pass
+ * (GKS.py:55: the projected right-hand side c_j = (A v_j) . b next to the Gram row (A V)^T (A v_j) — no dot launch of its own). */
+int trk_gemv_t_x(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* xrow, double* h, double* h_x,
+                 trk_stream stream);
 /* Two inner-product sets in one sweep over the basis: h2k[j] = V[j] . r, h2k[k + j] = V[j] . r2, j < k (local sums).
  * Serves the Gram-matrix form of the repeated Gram-Schmidt sweeps (trk_cgs_coeffs): r = the direction to orthogonalise,
  * r2 = the vector appended last (its Gram row). */
@@ -420,6 +424,12 @@ int trk_lsqr_damped_update(const float* vk, float* w, const float* x_in, float* 
                            double* err_partials, int capacity_blocks, int* n_blocks, const double* alpha_sq,
                            const double* beta_next_sq, const double* beta0_sq, double damp, const double* state_in,
                            double* state_out, int first, trk_stream stream);
+/* The weighted Gram of L V for the 2-D first-difference operator L = [D_h; D_v] of an N x N image, formed from V itself:
+ *   G[a][b] = sum_e w_e^2 (L v_a)_e (L v_b)_e ,   w = [w_h: N rows of N-1 | w_v: N-1 rows of N]  (what trk_tv_weights writes).
+ * Same result as trk_wgram over the stored images L v_j (MMGKS.py:94-95 through its Gram matrix) for half the bytes — n floats per
+ * basis vector instead of 2n — and L V is never stored.  1 <= k <= 48, N a multiple of 32, rows of V 16-byte aligned. */
+int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, double* G, trk_stream stream);
+
 /* G[a][b] = sum_i w[i]^2 * W[a][i] * W[b][i]  (k x k, fp64, full symmetric; w may be NULL), and, if
  * b1 != NULL, c1[a] = sum_i w[i]*W[a][i]*b1[i], c2[a] = sum_i w[i]^2*W[a][i]*b1[i].
  * Replaces the from-scratch economic QR of AV*wf / LV*wr (MMGKS.py:58-59,94-95; GKS.py:54-56): the host

@@ -179,6 +179,37 @@ def test_wgram(eng, k, m, weighted):
     assert np.allclose(got[k * k + k:], W32 @ (w32 ** 2 * b32), rtol=1e-6, atol=1e-6 * m ** 0.5)
 
 
+@pytest.mark.parametrize("N,k", [(32, 1), (32, 5), (64, 16), (64, 17), (96, 7), (96, 32), (160, 33), (128, 48), (512, 20), (1024, 3)])
+def test_wgram_tv_from_v_equals_the_gram_of_the_stored_images(eng, N, k):
+    """trk_wgram_tv (the weighted Gram of L V formed from V, L the 2-D first difference) against (i) the float64 definition on the
+    oracle's L and (ii) trk_wgram over the stored images L v_j: all tile counts, bands that do not divide N, the image's right
+    and bottom edges, weights as trk_tv_weights lays them out."""
+    from trips_py_amd.operators import FirstDerivative2D
+    L = FirstDerivative2D(N, engine=eng)
+    n, p = N * N, 2 * N * (N - 1)
+    g = torch.Generator(device=eng.device).manual_seed(100 * N + k)
+    V = torch.randn(k + 1, n + 4, device=eng.device, generator=g)[:k, :n]      # rows 16-byte aligned, not contiguous
+    w = torch.rand(p, device=eng.device, generator=g) + 0.25
+    LV = torch.empty(k, p, device=eng.device)
+    for j in range(k):
+        L.apply(V[j].contiguous(), out=LV[j])
+    G = eng.scalars(2 * k * k)
+    eng.wgram_tv(V, k, N, w, G[0:k * k])
+    eng.wgram(LV, k, w, None, G[k * k:2 * k * k])
+    got = eng.to_host(G)
+    a, b = got[:k * k].reshape(k, k), got[k * k:].reshape(k, k)
+    ref = ((LV.double() * w.double() ** 2) @ LV.double().T).cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.allclose(a, a.T) and np.allclose(a, ref, rtol=2e-6, atol=1e-6 * scale) and np.allclose(a, b, rtol=2e-6, atol=1e-6 * scale)
+    # and the layout of the differences themselves: the oracle's sparse L
+    if N <= 96:
+        from oracle.cpu_ref import first_derivative_2d
+        Ls = first_derivative_2d(N, N)
+        LVo = (Ls @ V.double().cpu().numpy().T).T
+        refo = (LVo * w.double().cpu().numpy() ** 2) @ LVo.T
+        assert np.allclose(a, refo, rtol=2e-6, atol=1e-6 * scale)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,mu", [(1, 0.3), (2, 0.0), (7, 1e-2), (100, 1e-3), (1000, 0.5)])
 def test_bidiag_tikhonov_matches_stacked_lstsq(k, mu):

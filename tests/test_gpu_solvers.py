@@ -364,10 +364,36 @@ def test_mmgks_pnorm2_unweighted_fidelity_gram_kept_incrementally():
     xa, ia = S.MMGKS(A, b, L, 2, 1, 3, 25, 1e-2, xt)
     xb, ib = S.MMGKS(A, b, L, 2, 1, 3, 25, 1e-2, xt, unweighted_fidelity_gram=False)
     assert float(torch.linalg.norm(xa - xb) / torch.linalg.norm(xb)) < 1e-5
-    assert np.allclose(ia["relError"], ib["relError"], rtol=1e-5) and np.allclose(ia["Residual"], ib["Residual"], rtol=1e-3)
+    # (relError ~ 0.1: iterates 1e-5 apart may move it by 1e-4 of itself)
+    assert np.allclose(ia["relError"], ib["relError"], rtol=1e-4) and np.allclose(ia["Residual"], ib["Residual"], rtol=1e-3)
     for k in (0, 12, 24):
         u, v = ia["xHistory"][k].reshape(-1), ib["xHistory"][k].reshape(-1)
         assert float(torch.linalg.norm(u - v) / torch.linalg.norm(v)) < 1e-5, k
+
+
+@pytest.mark.parametrize("N,its,pq", [(64, 25, (2, 1)), (160, 12, (2, 1)), (96, 20, (1, 1)), (64, 40, (2, 0.5))])
+def test_mmgks_tv_gram_from_v_equals_the_stored_images_form(N, its, pq):
+    """MMGKS with the 2-D first-difference L: the re-weighted Gram of L V formed from V (trk_wgram_tv, the default when N % 32 == 0
+    and the basis stays within 48 vectors) against the form that stores L v_j and reads them back every iteration (MMGKS.py:94-95)."""
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import Blur2D, FirstDerivative2D
+    from trips_py_amd.problems import gauss_psf
+    A = Blur2D(gauss_psf((9, 9), (2, 2))[0], N, N)
+    L = FirstDerivative2D(N)
+    dev = A.engine.device
+    xt = torch.zeros(N, N, device=dev)
+    xt[N // 5:N // 2, N // 4:3 * N // 4] = 1.0
+    xt[5 * N // 8:7 * N // 8, N // 8:N // 2] = 0.5
+    xt = xt.reshape(-1)
+    b = A.apply(xt)
+    b = b + 0.01 * torch.randn(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(3)) * b.norm() / N
+    xa, ia = S.MMGKS(A, b, L, pq[0], pq[1], 3, its, 1e-2, xt)
+    xb, ib = S.MMGKS(A, b, L, pq[0], pq[1], 3, its, 1e-2, xt, tv_gram_from_v=False)
+    assert float(torch.linalg.norm(xa - xb) / torch.linalg.norm(xb)) < 1e-5
+    assert np.allclose(ia["relError"], ib["relError"], rtol=1e-4) and np.allclose(ia["Residual"], ib["Residual"], rtol=2e-3)
+    if its + 4 > 48:                                     # a basis that outgrows the kernel: the stored-images form is chosen, silently
+        xc, ic = S.MMGKS(A, b, L, pq[0], pq[1], 3, 48, 1e-2, xt)
+        assert np.all(np.isfinite(ic["relError"]))
 
 
 @pytest.mark.parametrize("kind,N,its", [("blur", 64, 30), ("radon", 128, 60), ("radon", 96, 100)])

@@ -203,6 +203,7 @@ SIGNATURES = {
                                         c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, c_f64p, c_int, ctypes.POINTER(c_int),
                                         ctypes.POINTER(c_int), c_stream]),
     "trk_gemv_t": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_stream]),
+    "trk_gemv_t_x": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_f64p, c_stream]),
     "trk_gemv_t2": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_gemv_tn": (c_int, [c_f32p, c_i64, c_int, c_i64, ctypes.POINTER(ctypes.c_void_p), c_int, c_f64p, c_stream]),
     "trk_gram_row_from_sweep": (c_int, [c_f64p, c_int, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_stream]),
@@ -248,6 +249,7 @@ SIGNATURES = {
     "trk_cgls_iterate_sharded": (c_int, [c_op, ctypes.c_void_p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64,
                                          c_int, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, ctypes.POINTER(c_int), c_f64p, c_int,
                                          ctypes.POINTER(c_int), c_stream]),
+    "trk_wgram_tv": (c_int, [c_f32p, c_i64, c_int, c_int, c_f32p, c_f64p, c_stream]),
     "trk_wgram": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_stream]),
 }
 

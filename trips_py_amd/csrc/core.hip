@@ -81,6 +81,37 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
   if (threadIdx.x == 0) out[o] = v;
 }
 
+// the same sums with the outputs from index nsplit on stored at out2[o - nsplit] (a value that belongs somewhere else than behind
+// its neighbours: the extra row of trk_gemv_t_x)
+__global__ __launch_bounds__(256) void k_finalize_split(const double* __restrict__ partials, int nblocks, int stride,
+                                                        double* __restrict__ out, int nsplit, double* __restrict__ out2) {
+  __shared__ double lds[4];
+  const int o = blockIdx.x;
+  const double* __restrict__ p = partials + o;
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  int b = threadIdx.x;
+  for (; b + 768 < nblocks; b += 1024) {
+    v0 += p[(size_t)b * stride];
+    v1 += p[(size_t)(b + 256) * stride];
+    v2 += p[(size_t)(b + 512) * stride];
+    v3 += p[(size_t)(b + 768) * stride];
+  }
+  for (; b < nblocks; b += 256) v0 += p[(size_t)b * stride];
+  double v = block_sum<256>((v0 + v1) + (v2 + v3), lds);
+  if (threadIdx.x == 0) {
+    if (o < nsplit) out[o] = v;
+    else out2[o - nsplit] = v;
+  }
+}
+
+int finalize_sums_split(const double* partials, int nblocks, int stride, int nout, double* out_dev, int nsplit, double* out2_dev,
+                        hipStream_t s) {
+  if (nout <= 0) return TRK_OK;
+  hipLaunchKernelGGL(k_finalize_split, dim3(nout), dim3(256), 0, s, partials, nblocks, stride, out_dev, nsplit, out2_dev);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
 int finalize_sums(const double* partials, int nblocks, int stride, int nout, double* out_dev, hipStream_t s) {
   if (nout <= 0) return TRK_OK;
   hipLaunchKernelGGL(k_finalize, dim3(nout), dim3(256), 0, s, partials, nblocks, stride, out_dev);

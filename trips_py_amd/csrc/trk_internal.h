@@ -33,6 +33,8 @@ int scratch_doubles(hipStream_t s, size_t count, double** out);  // grows, never
 
 // out[o] = sum_{b < nblocks} partials[b*stride + o]   for o < nout   (fixed summation order)
 int finalize_sums(const double* partials, int nblocks, int stride, int nout, double* out_dev, hipStream_t s);
+int finalize_sums_split(const double* partials, int nblocks, int stride, int nout, double* out_dev, int nsplit, double* out2_dev,
+                        hipStream_t s);
 
 // device facts (cached)
 int cu_count();
@@ -70,7 +72,10 @@ __device__ __forceinline__ double wave_sum(double v) {
 __device__ __forceinline__ float mm_w(float v, float eps2, float e, int special) {
   const float t = fmaf(v, v, eps2);
   if (special == 1) return 1.0f;
-  if (special == 2) return 1.0f / sqrtf(t);
+  // e = -1/2 (qnorm = 1, the TV weights): the hardware's reciprocal square root (1 ulp) for t in the normal range — t >= eps2, so
+  // the test is uniform; 1/sqrtf costs ~25 instructions per weight with its IEEE square root and division, which made the weights
+  // pass of MMGKS VALU-bound (51 us for 12n bytes at 4096^2 against 36 us for the same pass without them)
+  if (special == 2) return (eps2 >= 1e-30f) ? __builtin_amdgcn_rsqf(t) : 1.0f / sqrtf(t);
   return powf(t, e);
 }
 

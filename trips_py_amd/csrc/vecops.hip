@@ -532,15 +532,18 @@ __global__ __launch_bounds__(NT) void k_cgls_x_update(int64_t n, ScalarSrc gamma
 constexpr int JT = 8;
 
 template <int WPOW, bool VEC>
-__global__ __launch_bounds__(NT) void k_gemv_t(const float* __restrict__ V, int64_t ld, int k, int64_t n,
+__global__ __launch_bounds__(NT) void k_gemv_t(const float* __restrict__ V, int64_t ld, int kv, int64_t n,
                                                const float* __restrict__ r, const float* __restrict__ w,
-                                               double* __restrict__ partials, int nt) {
+                                               double* __restrict__ partials, int nt, const float* __restrict__ xrow = nullptr) {
   __shared__ double lds[(NT / 64) * JT];
+  // xrow: one more row that is not part of the basis (trk_gemv_t_x: the right-hand side b next to the images A v_j), row index kv
+  const int k = kv + (xrow ? 1 : 0);
   // row tiles of equal height: ceil(k / tiles) <= JT rows each (k = 18: 6 + 6 + 6, not 8 + 8 + 2 — the short tile's workgroups
   // read the right-hand sides for a quarter of the work)
   const int jb = (k + (int)gridDim.y - 1) / (int)gridDim.y;
   const int j0 = blockIdx.y * jb;
   const int jn = (k - j0 < jb) ? (k - j0 < 0 ? 0 : k - j0) : jb;
+  auto row = [&](int j) -> const float* { return (j0 + j < kv) ? V + (int64_t)(j0 + j) * ld : xrow; };
   double acc[JT];
 #pragma unroll
   for (int j = 0; j < JT; ++j) acc[j] = 0.0;
@@ -567,7 +570,7 @@ __global__ __launch_bounds__(NT) void k_gemv_t(const float* __restrict__ V, int6
 #pragma unroll
       for (int j = 0; j < JT; ++j) {
         if (j < jn) {
-          float4 v = (nt & 64) ? ld4_nt(V + (int64_t)(j0 + j) * ld, i) : ld4(V + (int64_t)(j0 + j) * ld, i);
+          float4 v = (nt & 64) ? ld4_nt(row(j), i) : ld4(row(j), i);
           acc[j] += (double)v.x * rv.x + (double)v.y * rv.y + (double)v.z * rv.z + (double)v.w * rv.w;
         }
       }
@@ -581,7 +584,7 @@ __global__ __launch_bounds__(NT) void k_gemv_t(const float* __restrict__ V, int6
     }
 #pragma unroll
     for (int j = 0; j < JT; ++j)
-      if (j < jn) acc[j] += (double)V[(int64_t)(j0 + j) * ld + i] * rv;
+      if (j < jn) acc[j] += (double)row(j)[i] * rv;
   }
   // (one exchange for the JT sums: with a block_sum each, the 2 JT barriers of a workgroup were a visible part of the kernel on
   // short vectors — dynamic problems, n = 2 M)
@@ -706,20 +709,22 @@ __global__ __launch_bounds__(NT) void k_gemv_tr(const float* __restrict__ V, int
 }
 
 int launch_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* w, int wpow, double* h,
-                  hipStream_t s) {
-  const int ntile = ceil_div(k, JT);
+                  hipStream_t s, const float* xrow = nullptr, double* h_x = nullptr) {
+  const int kt = k + (xrow ? 1 : 0);
+  const int ntile = ceil_div(kt, JT);
   static const int occ = resident_blocks_per_cu(k_gemv_t<0, true>);
   const int bx = tiled_dot_grid_x(n, ntile, occ);
   double* part = nullptr;
-  if (int rc = scratch_doubles(s, (size_t)bx * k, &part)) return rc;
-  const bool vec = aligned16(V) && aligned16(r) && (ld % 4 == 0) && (!wpow || aligned16(w));
+  if (int rc = scratch_doubles(s, (size_t)bx * kt, &part)) return rc;
+  const bool vec = aligned16(V) && aligned16(r) && (ld % 4 == 0) && (!wpow || aligned16(w)) && (!xrow || aligned16(xrow));
   dim3 grid(bx, ntile);
-#define GT(WP, VC) hipLaunchKernelGGL((k_gemv_t<WP, VC>), grid, dim3(NT), 0, s, V, ld, k, n, r, w, part, stream_nontemporal(n))
+#define GT(WP, VC) hipLaunchKernelGGL((k_gemv_t<WP, VC>), grid, dim3(NT), 0, s, V, ld, k, n, r, w, part, stream_nontemporal(n), xrow)
   if (wpow == 0) { if (vec) GT(0, true); else GT(0, false); }
   else if (wpow == 1) { if (vec) GT(1, true); else GT(1, false); }
   else { if (vec) GT(2, true); else GT(2, false); }
 #undef GT
   TRK_LAUNCH_CHECK();
+  if (xrow) return finalize_sums_split(part, bx, kt, kt, h, k, h_x, s);
   return finalize_sums(part, bx, k, k, h, s);
 }
 
@@ -1405,6 +1410,171 @@ __global__ __launch_bounds__(NT, 2) void k_wgram_t16(const float* __restrict__ W
     }
 }
 
+// ------------------------------------------------------------------ weighted Gram of L V for the 2-D first-difference L, from V
+// G[a][b] = sum over the rows e of L of  w_e^2 (L v_a)_e (L v_b)_e,   L = [D_h; D_v]  (MMGKS.py:94-95: the R factor of wr * (L V)
+// enters the projected problem only through this Gram matrix).  k_wgram_t16 reads the stored images L v_j — 2 n floats
+// per basis vector; here a wave forms them on the fly from V (n floats per vector: HALF the bytes, and L V is never written or
+// kept).  A wave owns a strip of 32 image columns and marches down a band of rows: lane (r = l & 15, sl = l >> 4) holds, per
+// 16-row tile t of V, the 8 pixels at columns 32 strip + 8 sl .. + 7 of row 16 t + r of V, for the current and the next image row
+// — every element of V is loaded ONCE (the row below is the next step's current row).  The pixel right of a lane's eight comes
+// from lane l + 16 (ds_bpermute; the last quarter takes the next strip's first pixel, one dword load per tile and step); the 64
+// weights of a step (32 horizontal, 32 vertical) are ONE coalesced dword load per wave, spread to the lanes through LDS.  (First
+// version: per-lane loads of the weights and of the right neighbours — as many L2 requests again as the rows themselves; 2 TB/s.)
+// Per step 64 weighted differences go through the same v_mfma_f32_16x16x4_f32 tile pairs as in k_wgram_t16, flushed into fp64
+// every step.  Rows are loaded two steps ahead.  w = [w_h: N rows of N-1 | w_v: N-1 rows of N] (trk_tv_weights).  N % 32 == 0.
+template <int T>
+struct TvRow {
+  float4 x[T][2];      // 8 consecutive pixels of the image row, per tile
+  float nx[T];         // the first pixel of the next strip (used by the lanes sl == 3 only)
+  float w;             // lane l < 32: w_h of column 32 strip + l ; l >= 32: w_v of column 32 strip + l - 32
+};
+
+template <int T>
+__global__ __launch_bounds__(NT, 2) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
+                                                    const float* __restrict__ w, int nbands, int band_rows,
+                                                    double* __restrict__ partials) {
+  constexpr int NP = T * (T + 1) / 2;
+  __shared__ double red[3][4][64];
+  __shared__ __attribute__((aligned(16))) float wl[NT / 64][64];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, sl = lane >> 4;
+  const float* __restrict__ wh = w;
+  const float* __restrict__ wv = w + (int64_t)N * (N - 1);
+  const float* rowp[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) {
+    const int rr = 16 * t + r;
+    rowp[t] = V + (int64_t)(rr < k ? rr : 0) * ld;              // rows beyond the basis read row 0: their Gram entries are never stored
+  }
+  double accd[NP][4];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accd[p][q] = 0.0;
+  const int strips = N / 32;
+  const int64_t units = (int64_t)strips * nbands;
+  const int64_t gw = (int64_t)blockIdx.x * (NT / 64) + wave, nw = (int64_t)gridDim.x * (NT / 64);
+  float* __restrict__ my = wl[wave];
+  const int up16 = ((lane + 16) & 63) << 2;                      // ds_bpermute address of lane l + 16
+
+  for (int64_t u = gw; u < units; u += nw) {
+    const int band = (int)(u / strips), strip = (int)(u - (int64_t)band * strips);
+    const int i0 = band * band_rows, i1 = (i0 + band_rows < N) ? i0 + band_rows : N;
+    const int cs = 32 * strip;
+    const int c0 = cs + 8 * sl;
+    const bool last_strip = cs + 32 >= N;                        // (uniform) no pixel right of this strip
+    const int nxo = last_strip ? 31 : 32;                        // clamped: a valid address, met by a zero weight
+
+    // every load is unconditional (clamped addresses, zeroed weights instead of branches): all loads of a row are in flight together
+    auto load = [&](TvRow<T>& P, int i) {
+      const int ic = i < N ? i : N - 1;                          // the row below the image is looked at with a zero weight only
+      const int64_t e = (int64_t)ic * N;
+      const int iv = ic < N - 1 ? ic : N - 2;                    // the last image row has no vertical difference: weight zeroed at use
+      P.w = lane < 32 ? wh[(int64_t)ic * (N - 1) + cs + (lane < 31 || !last_strip ? lane : 30)] : wv[(int64_t)iv * N + cs + lane - 32];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        P.x[t][0] = *reinterpret_cast<const float4*>(rowp[t] + e + c0);
+        P.x[t][1] = *reinterpret_cast<const float4*>(rowp[t] + e + c0 + 4);
+        P.nx[t] = rowp[t][e + cs + nxo];
+      }
+    };
+    auto step = [&](const TvRow<T>& P, const TvRow<T>& Q, int i) {   // P: image row i, Q: the one below
+      // this row's weights to the lanes: h at my[0..31], v at my[32..63]
+      float wk = P.w;
+      if (lane == 31 && last_strip) wk = 0.f;                    // column N - 1 has no right neighbour
+      if (lane >= 32 && i >= N - 1) wk = 0.f;                    // row N - 1 has none below
+      my[lane] = wk;
+      const float4 wh0 = *reinterpret_cast<const float4*>(my + 8 * sl), wh1 = *reinterpret_cast<const float4*>(my + 8 * sl + 4);
+      const float4 wv0 = *reinterpret_cast<const float4*>(my + 32 + 8 * sl), wv1 = *reinterpret_cast<const float4*>(my + 36 + 8 * sl);
+      f4v acc[NP];
+#pragma unroll
+      for (int p = 0; p < NP; ++p) acc[p] = (f4v){0.f, 0.f, 0.f, 0.f};
+      float dh[T][8], dv[T][8];
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float4 a = P.x[t][0], b = P.x[t][1], c = Q.x[t][0], d = Q.x[t][1];
+        // the pixel right of this lane's eight: lane l + 16 holds it as its first, the last quarter takes the next strip's
+        float right = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(up16, __builtin_bit_cast(int, a.x)));
+        right = sl == 3 ? P.nx[t] : right;
+        dh[t][0] = (a.x - a.y) * wh0.x;
+        dh[t][1] = (a.y - a.z) * wh0.y;
+        dh[t][2] = (a.z - a.w) * wh0.z;
+        dh[t][3] = (a.w - b.x) * wh0.w;
+        dh[t][4] = (b.x - b.y) * wh1.x;
+        dh[t][5] = (b.y - b.z) * wh1.y;
+        dh[t][6] = (b.z - b.w) * wh1.z;
+        dh[t][7] = (b.w - right) * wh1.w;
+        dv[t][0] = (a.x - c.x) * wv0.x;
+        dv[t][1] = (a.y - c.y) * wv0.y;
+        dv[t][2] = (a.z - c.z) * wv0.z;
+        dv[t][3] = (a.w - c.w) * wv0.w;
+        dv[t][4] = (b.x - d.x) * wv1.x;
+        dv[t][5] = (b.y - d.y) * wv1.y;
+        dv[t][6] = (b.z - d.z) * wv1.z;
+        dv[t][7] = (b.w - d.w) * wv1.w;
+      }
+      int p = 0;
+#pragma unroll
+      for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+        for (int tb = ta; tb < T; ++tb, ++p) {
+#pragma unroll
+          for (int c = 0; c < 8; ++c) {
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[ta][c], dh[tb][c], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[ta][c], dv[tb][c], acc[p], 0, 0, 0);
+          }
+        }
+#pragma unroll
+      for (int p2 = 0; p2 < NP; ++p2)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) accd[p2][q] += (double)acc[p2][q];
+    };
+
+    TvRow<T> A, B, C;
+    load(A, i0);
+    load(B, i0 + 1);
+    int i = i0;
+    for (; i + 3 <= i1; i += 3) {                                // roles rotate: no register copies
+      load(C, i + 2);
+      step(A, B, i);
+      load(A, i + 3);
+      step(B, C, i + 1);
+      load(B, i + 4);
+      step(C, A, i + 2);
+    }
+    if (i < i1) {                                                // one or two rows left; A = row i, B = row i + 1
+      if (i + 1 < i1) load(C, i + 2);
+      step(A, B, i);
+      if (i + 1 < i1) step(B, C, i + 1);
+    }
+  }
+  // combine the 4 waves (fixed order) and write the block partial in matrix order (16x16 C/D map: lane (r, sl), register q
+  // holds D[4 sl + q][r])
+  double* __restrict__ out = partials + (size_t)blockIdx.x * k * k;
+  int p = 0;
+#pragma unroll
+  for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+    for (int tb = ta; tb < T; ++tb, ++p) {
+      if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[wave - 1][q][lane] = accd[p][q];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const double t = ((accd[p][q] + red[0][q][lane]) + red[1][q][lane]) + red[2][q][lane];
+          const int row = 16 * ta + 4 * sl + q, col = 16 * tb + r;
+          if (row < k && col < k) {
+            out[(size_t)row * k + col] = t;
+            if (ta != tb) out[(size_t)col * k + row] = t;
+          }
+        }
+      }
+      __syncthreads();
+    }
+}
+
 // scatter the augmented Gram [KA x KA] into G (k x k), c1, c2 (and optionally ||w b||^2)
 __global__ void k_wgram_unpack(const double* __restrict__ Ga, int k, int KA, double* __restrict__ G, double* __restrict__ c1,
                                double* __restrict__ c2) {
@@ -1641,6 +1811,13 @@ int trk_gemv_t(const float* V, int64_t ld, int k, int64_t n, const float* r, con
   return launch_gemv_t(V, ld, k, n, r, w2, w2 ? 1 : 0, h, (hipStream_t)st);
 }
 
+int trk_gemv_t_x(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* xrow, double* h, double* h_x,
+                 trk_stream st) {
+  TRK_REQUIRE(V && r && h && xrow && h_x, "trk_gemv_t_x: NULL argument");
+  TRK_REQUIRE(k >= 1 && n >= 0 && ld >= n, "trk_gemv_t_x: need k >= 1, n >= 0, ld >= n");
+  return launch_gemv_t(V, ld, k, n, r, nullptr, 0, h, (hipStream_t)st, xrow, h_x);
+}
+
 int trk_gemv_t2(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* r2, double* h2k, trk_stream st) {
   TRK_REQUIRE(V && r && r2 && h2k, "trk_gemv_t2: NULL argument");
   TRK_REQUIRE(k >= 1 && n >= 0 && ld >= n, "trk_gemv_t2: need k >= 1, n >= 0, ld >= n");
@@ -1721,15 +1898,21 @@ int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y
                    double* err_partials, int capacity_blocks, int* n_blocks, trk_stream st) {
   TRK_REQUIRE(V && y && out && ref && err_partials && n_blocks, "trk_gemv_n_err: NULL argument");
   TRK_REQUIRE(k >= 1 && k <= KMAX_LDS && n >= 0 && ld >= n, "trk_gemv_n_err: need 1 <= k <= %d, n >= 0, ld >= n", KMAX_LDS);
-  const int grid = stream_grid(n);
+  // the launch shape of trk_gemv_n (8 workgroups per CU: tools/gemv_micro.py) when the caller's buffer has room for its partials
+  static const int gmul = env_int("TRK_GEMVN_GRID", 8);
+  int grid = stream_grid(n);
+  if (gmul > 0) {
+    const int g8 = (int)std::min<int64_t>((n + (int64_t)NT * 4 - 1) / ((int64_t)NT * 4), (int64_t)cu_count() * gmul);
+    if (g8 >= 1 && g8 <= capacity_blocks) grid = g8;
+  }
   TRK_REQUIRE(grid <= capacity_blocks, "trk_gemv_n_err: partial buffer too small (%d blocks needed)", grid);
   *n_blocks = grid;
   hipStream_t s = (hipStream_t)st;
   const float* nobase = nullptr;
   if (aligned16(V) && aligned16(out) && aligned16(ref) && (ld % 4 == 0))
-    hipLaunchKernelGGL((k_gemv_n<false, true, true, true>), dim3(grid), dim3(NT), 0, s, YPtr{y}, V, ld, k, n, 1.0, nobase, 1.0, out, err_partials, ref);
+    hipLaunchKernelGGL((k_gemv_n<false, true, true, true>), dim3(grid), dim3(NT), 0, s, YPtr{y}, V, ld, k, n, 1.0, nobase, 1.0, out, err_partials, ref, stream_nontemporal(n));
   else
-    hipLaunchKernelGGL((k_gemv_n<false, true, false, true>), dim3(grid), dim3(NT), 0, s, YPtr{y}, V, ld, k, n, 1.0, nobase, 1.0, out, err_partials, ref);
+    hipLaunchKernelGGL((k_gemv_n<false, true, false, true>), dim3(grid), dim3(NT), 0, s, YPtr{y}, V, ld, k, n, 1.0, nobase, 1.0, out, err_partials, ref, stream_nontemporal(n));
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }
@@ -1812,6 +1995,31 @@ int trk_gemv_nt(const float* V, int64_t ld, int k, int64_t n, const double* h, c
 #undef NTK
   TRK_LAUNCH_CHECK();
   return finalize_sums(part, bx, k, k, g, s);
+}
+
+int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, double* G, trk_stream st) {
+  TRK_REQUIRE(V && w && G, "trk_wgram_tv: NULL argument");
+  TRK_REQUIRE(k >= 1 && k <= 48, "trk_wgram_tv: need 1 <= k <= 48 (trk_wgram over the stored images beyond)");
+  TRK_REQUIRE(N >= 32 && N % 32 == 0 && ld >= (int64_t)N * N && ld % 4 == 0 && aligned16(V) && aligned16(w),
+              "trk_wgram_tv: need N a multiple of 32, 16-byte aligned rows and weights");
+  hipStream_t s = (hipStream_t)st;
+  const int T16 = (k + 15) / 16;
+  const int per_cu = T16 == 1 ? 4 : T16 == 2 ? 3 : 2;          // what the register budget lets be resident (94 / 160 / 248 VGPRs)
+  const int strips = N / 32;
+  int bx = cu_count() * per_cu;
+  // (strip, band) units, band-major: the waves in flight together then work on a few neighbouring image rows of every basis vector
+  static const int band_env = env_int("TRK_WGRAM_TV_BAND", 64);
+  const int band_rows = band_env < N ? (band_env > 0 ? band_env : 16) : N;
+  const int nbands = (N + band_rows - 1) / band_rows;
+  const int64_t units = (int64_t)strips * nbands;
+  if ((int64_t)bx * (NT / 64) > units) bx = (int)((units + NT / 64 - 1) / (NT / 64));
+  double* part = nullptr;
+  if (int rc = scratch_doubles(s, (size_t)bx * k * k, &part)) return rc;
+  if (T16 == 1) hipLaunchKernelGGL((k_wgram_tv<1>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part);
+  else if (T16 == 2) hipLaunchKernelGGL((k_wgram_tv<2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part);
+  else hipLaunchKernelGGL((k_wgram_tv<3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part);
+  TRK_LAUNCH_CHECK();
+  return finalize_sums(part, bx, k * k, k * k, G, s);
 }
 
 int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G, double* c1,

@@ -573,6 +573,12 @@ class HipEngine:
         _lib.check(rc, "trk_finalize_batched")
 
     # ------------------------------------------------------------------ tall-skinny basis ops (row-per-vector V[k_max, n])
+    def gemv_t_x(self, V, k, r, xrow, out_h, out_x):
+        """out_h[j] = V[j] . r for j < k and out_x = xrow . r from the same pass over r (trk_gemv_t_x; local sums)."""
+        rc = self.lib.trk_gemv_t_x(V.data_ptr(), V.stride(0), int(k), r.numel(), r.data_ptr(), xrow.data_ptr(), _ptr(out_h),
+                                   _ptr(out_x), self.stream())
+        _lib.check(rc, "trk_gemv_t_x")
+
     def gemv_t(self, V, k, r, out_h, w2=None):
         """out_h[j] = sum_i w2[i] V[j,i] r[i]  for j < k (local sums)."""
         rc = self.lib.trk_gemv_t(V.data_ptr(), V.stride(0), int(k), r.numel(), r.data_ptr(),
@@ -700,6 +706,14 @@ class HipEngine:
                                           None if work is None else work.ref(0),
                                           0 if work is None else len(work), self.stream())
         _lib.check(rc, "trk_bidiag_tikhonov")
+
+    WGRAM_TV_MAX_K = 48
+
+    def wgram_tv(self, V, k, N, w, G):
+        """G = (L V) diag(w^2) (L V)^T for the 2-D first-difference L of an N x N image, from V itself (trk_wgram_tv: N % 32 == 0,
+        k <= WGRAM_TV_MAX_K; local sums)."""
+        rc = self.lib.trk_wgram_tv(V.data_ptr(), V.stride(0), int(k), int(N), w.data_ptr(), _ptr(G), self.stream())
+        _lib.check(rc, "trk_wgram_tv")
 
     def wgram(self, W, k, w, b1, G, c1=None, c2=None):
         """G = W diag(w^2) W^T (k x k), c1 = W (w*b1), c2 = W (w^2*b1)  (local sums; w may be None)."""

@@ -76,7 +76,10 @@ class _ProjectedBases:
             av = self.AV.next_slot()
             self.A.apply(v, out=av)
             self.AV.commit()
-            eng.dot(av, self.bv, c_out)
+            # c_j = (A v_j) . b: with the Gram row below when the engine can (b as one more row of that pass), else a dot of its own
+            c_with_row = hasattr(eng, "gemv_t_x")
+            if not c_with_row:
+                eng.dot(av, self.bv, c_out)
         if not self.use_L:
             pass
         elif self.from_v_L:
@@ -89,18 +92,23 @@ class _ProjectedBases:
             lv = self.LV.next_slot()
             self.L.apply(v, out=lv)
             self.LV.commit()
+        def a_row_from_images():
+            if c_with_row:
+                eng.gemv_t_x(self.AV.data, k, av, self.bv, S.ref(0), c_out)
+            else:
+                eng.gemv_t(self.AV.data, k, av, S.ref(0))
         if not self.use_L:
             if self.from_v_A:
                 eng.gemv_t(self.V.data, k, self.zA, S.ref(0))
             else:
-                eng.gemv_t(self.AV.data, k, av, S.ref(0))
+                a_row_from_images()
         elif self.from_v_A and self.from_v_L:
             eng.gemv_t2(self.V.data, k, self.zA, self.zL, S.ref(0))       # both Gram rows from one sweep over V
         else:
             if self.from_v_A:
                 eng.gemv_t(self.V.data, k, self.zA, S.ref(0))
             else:
-                eng.gemv_t(self.AV.data, k, av, S.ref(0))
+                a_row_from_images()
             if self.from_v_L:
                 eng.gemv_t(self.V.data, k, self.zL, S.ref(k))
             else:
@@ -158,11 +166,17 @@ class _ProjectedBases:
             av = self.AV.next_slot()
             self.A.apply(self.V[k], out=av)
             self.AV.commit()
+            with_row = hasattr(eng, "gemv_t_x")       # c_k = (A v_k) . b from the Gram row's own pass (b as one more row)
             if eng.world > 1:                                             # c_k behind the Gram row: one exchange
-                eng.dot(av, self.bv, S.ref(4 + k + 1))
-                eng.gemv_t(self.AV.data, k + 1, av, S.ref(4))
+                if with_row:
+                    eng.gemv_t_x(self.AV.data, k + 1, av, self.bv, S.ref(4), S.ref(4 + k + 1))
+                else:
+                    eng.dot(av, self.bv, S.ref(4 + k + 1))
+                    eng.gemv_t(self.AV.data, k + 1, av, S.ref(4))
                 eng.allreduce(S, 4, 4 + k + 2)
                 eng.copy_scalars(S, 4 + k + 1, self.c_d, k, 1)
+            elif with_row:
+                eng.gemv_t_x(self.AV.data, k + 1, av, self.bv, S.ref(4), self.c_d.ref(k))
             else:
                 eng.dot(av, self.bv, self.c_d.ref(k))
                 eng.gemv_t(self.AV.data, k + 1, av, S.ref(4))
@@ -213,6 +227,10 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     gs_gram = GramSchmidtByGram(eng, pb.V, kmax) if (hasattr(eng, "cgs_coeffs") and kwargs.get("gram_sweeps", True)) else None
     lams, lam, x_dev = [], None, None
     Minv, k_inv = (eng.scalars(kmax * kmax) if (on_dev and kwargs.get("border_inverse", True)) else None), 0
+    # ||x_i - x_true||^2 rides the pass that forms x_i = V y (trk_gemv_n_err) as raw block partials
+    err_fused = xt is not None and hasattr(eng, "gemv_n_err") and kwargs.get("fused_error_norm", True)
+    EP_CAP = 2048
+    EP, n_ep = (eng.scalars(EP_CAP * max(1, n_iter)) if err_fused else None), 0
     for ii in range(n_iter):
         k = pb.V.k
         if on_dev:
@@ -230,9 +248,12 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
             y = tikhonov_lstsq(R_A, R_L, lam, rhs)
             Y.set(0, y)
         x_dev = Hs.row(ii)
-        eng.gemv_n(pb.V.data, k, Y.ref(0), x_dev)                                   # x = V y (:76)
+        if err_fused:      # x = V y (:76) with ||x - x_true||^2 as block partials of the same pass, summed once after the loop
+            n_ep = eng.gemv_n_err(pb.V.data, k, Y.ref(0), x_dev, xt, EP.ref(n_ep * ii), EP_CAP)
+        else:
+            eng.gemv_n(pb.V.data, k, Y.ref(0), x_dev)                               # x = V y (:76)
         Hs.pushed(ii)
-        if xt is not None:
+        if xt is not None and not err_fused:
             eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
         # r = A^T (A x - b) + lam L^T (L x), A x = (AV) y and L x = (LV) y in the reference (:81-85); stencil operators
         # form them directly from x (8n-12n bytes instead of k basis vectors)
@@ -272,6 +293,8 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     info = {"xHistory": Hs.collect(fmt, n_iter), "regParam": lam, "regParam_history": lams,
             "Residual": list(np.sqrt(R.host(0, n_iter))), "its": n_iter - 1}
     if xt is not None:
+        if err_fused:
+            eng.finalize_batched(EP.ref(0), n_ep, 1, n_iter, E.ref(2), 1)
         eng.allreduce(E, 2, 2 + n_iter)
         e = E.host(0, 2 + n_iter)
         info["relError"] = list(np.sqrt(e[2:] / e[0]))

@@ -104,14 +104,22 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     unit_A = (pnorm == 2 and on_dev and dA and hasattr(eng, "gram_row_from_sweep") and hasattr(eng, "cgs_coeffs")
               and kmax <= eng.GRAM_TIKHONOV_MAX_K and kwargs.get("gram_sweeps", True) and kwargs.get("unweighted_fidelity_gram", True))
     AV = None if unit_A else DeviceBasis(eng, m, kmax)
-    LV = DeviceBasis(eng, p_rows, kmax)
+    # the 2-D first-difference L has fused forms (trk_tv_weights / trk_tv_grad): L x is never written out
+    fusedL = dL and getattr(L, "fused_tv", False) and not iso and not gs and kwargs.get("fused_tv", True)
+    # ... and its weighted Gram (L V)^T diag(wr^2) (L V) is formed from V itself (trk_wgram_tv): n floats per basis vector per iteration
+    # instead of the 2n of the stored images L v_j, which are then neither computed nor kept (kmax x 2n floats)
+    from ..operators import FirstDerivative2D
+    tv_gram = (fusedL and isinstance(L, FirstDerivative2D) and hasattr(eng, "wgram_tv") and L.N % 32 == 0 and L.N >= 32
+               and kmax <= eng.WGRAM_TV_MAX_K and getattr(eng, "world", 1) == 1 and kwargs.get("tv_gram_from_v", True))
+    LV = None if tv_gram else DeviceBasis(eng, p_rows, kmax)
 
     def push_images(j):
         if AV is not None:
             A.apply(V[j], out=AV.next_slot())
             AV.commit()
-        L.apply(V[j], out=LV.next_slot())
-        LV.commit()
+        if LV is not None:
+            L.apply(V[j], out=LV.next_slot())
+            LV.commit()
 
     for j in range(V.k):
         push_images(j)
@@ -137,8 +145,6 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     # A x and L x of the iterate are needed twice: in the residual of this iteration (the reference forms them as
     # (AV) y and (LV) y, :114-116) and in the weights of the next (A @ x, L @ x, :56,:60).  A stencil operator forms them
     # once, directly — 8n-12n bytes instead of reading k basis vectors; others keep the basis products.
-    # the 2-D first-difference L has fused forms (trk_tv_weights / trk_tv_grad): L x is never written out
-    fusedL = dL and getattr(L, "fused_tv", False) and not iso and not gs and kwargs.get("fused_tv", True)
     A.apply(x_cur, out=ax)
     if not fusedL:
         L.apply(x_cur, out=lx)
@@ -149,6 +155,10 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     unit_wf = (pnorm == 2)
     if unit_wf:
         wf.fill_(1.0)
+    # ||x_i - x_true||^2 rides the pass that forms x_i = V y (trk_gemv_n_err) as raw block partials
+    err_fused = xt is not None and hasattr(eng, "gemv_n_err") and kwargs.get("fused_error_norm", True)
+    EP_CAP = 2048
+    EP, n_ep = (eng.scalars(EP_CAP * max(1, n_iter)) if err_fused else None), 0
     for ii in range(n_iter):
         its = ii
         k = V.k
@@ -169,7 +179,10 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         # weighted Gram matrices and projected right-hand sides
         if pbA is None:
             eng.wgram(AV.data, k, wf, bv, G.ref(0), G.ref(2 * kk), G.ref(2 * kk + k))
-        eng.wgram(LV.data, k, wr, None, G.ref(kk))
+        if tv_gram:
+            eng.wgram_tv(V.data, k, L.N, wr, G.ref(kk))
+        else:
+            eng.wgram(LV.data, k, wr, None, G.ref(kk))
         nred = 2 * kk + 2 * k
         if pbA is not None:
             eng.allreduce(G, kk, 2 * kk)
@@ -201,9 +214,12 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             y = tikhonov_lstsq(R_A, R_L, lam, rhs_b)
             Y.set(0, y)
         x_dev = Hs.row(ii)
-        eng.gemv_n(V.data, k, Y.ref(0), x_dev)                                        # x = V y (:107)
+        if err_fused:      # x = V y (:107) with ||x - x_true||^2 as block partials of the same pass, summed once after the loop
+            n_ep = eng.gemv_n_err(V.data, k, Y.ref(0), x_dev, xt, EP.ref(n_ep * ii), EP_CAP)
+        else:
+            eng.gemv_n(V.data, k, Y.ref(0), x_dev)                                    # x = V y (:107)
         Hs.pushed(ii)
-        if xt is not None:
+        if xt is not None and not err_fused:
             eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
         if ii >= k:                                                                   # `ii >= R_L.shape[0]` (:109-110)
             break
@@ -261,6 +277,8 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     info = {"xHistory": Hs.collect(fmt, its + 1), "regParam": lam, "regParam_history": lams,
             "Residual": list(np.sqrt(Rn.host(0, nres))), "its": its}
     if xt is not None:
+        if err_fused:
+            eng.finalize_batched(EP.ref(0), n_ep, 1, its + 1, E.ref(2), 1)
         eng.allreduce(E, 2, 3 + its)
         e = E.host(0, 3 + its)
         info["relError"] = list(np.sqrt(e[2:] / e[0]))
