@@ -429,6 +429,10 @@ int trk_lsqr_damped_update(const float* vk, float* w, const float* x_in, float* 
  * Same result as trk_wgram over the stored images L v_j (MMGKS.py:94-95 through its Gram matrix) for half the bytes — n floats per
  * basis vector instead of 2n — and L V is never stored.  1 <= k <= 48, N a multiple of 32, rows of V 16-byte aligned. */
 int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, double* G, trk_stream stream);
+/* The same pass also taking h[j] = V[j] . z for one more image z (n floats, 16-byte aligned): MMGKS forms the new Gram row
+ * V^T (A^T A v_new) of the fidelity term (MMGKS.py:58 through its Gram matrix) and the re-weighted Gram of the regulariser for the
+ * next iteration in ONE sweep over the basis. */
+int trk_wgram_tv_z(const float* V, int64_t ld, int k, int N, const float* w, double* G, const float* z, double* h, trk_stream stream);
 
 /* G[a][b] = sum_i w[i]^2 * W[a][i] * W[b][i]  (k x k, fp64, full symmetric; w may be NULL), and, if
  * b1 != NULL, c1[a] = sum_i w[i]*W[a][i]*b1[i], c2[a] = sum_i w[i]^2*W[a][i]*b1[i].

@@ -193,11 +193,17 @@ def test_wgram_tv_from_v_equals_the_gram_of_the_stored_images(eng, N, k):
     LV = torch.empty(k, p, device=eng.device)
     for j in range(k):
         L.apply(V[j].contiguous(), out=LV[j])
-    G = eng.scalars(2 * k * k)
+    G = eng.scalars(3 * k * k + k)
     eng.wgram_tv(V, k, N, w, G[0:k * k])
     eng.wgram(LV, k, w, None, G[k * k:2 * k * k])
+    # ... and with one more image z: the same Gram, and V z from the same pass (trk_wgram_tv_z)
+    z = torch.randn(n, device=eng.device, generator=g)
+    eng.wgram_tv(V, k, N, w, G[2 * k * k:3 * k * k], z=z, h=G[3 * k * k:3 * k * k + k])
     got = eng.to_host(G)
-    a, b = got[:k * k].reshape(k, k), got[k * k:].reshape(k, k)
+    a, b = got[:k * k].reshape(k, k), got[k * k:2 * k * k].reshape(k, k)
+    assert np.array_equal(got[2 * k * k:3 * k * k].reshape(k, k), a)
+    hz = (V.double() @ z.double()).cpu().numpy()
+    assert np.allclose(got[3 * k * k:], hz, rtol=1e-12, atol=1e-12 * float(z.double().norm() * V.double().norm(dim=1).max()))
     ref = ((LV.double() * w.double() ** 2) @ LV.double().T).cpu().numpy()
     scale = np.abs(ref).max()
     assert np.allclose(a, a.T) and np.allclose(a, ref, rtol=2e-6, atol=1e-6 * scale) and np.allclose(a, b, rtol=2e-6, atol=1e-6 * scale)

@@ -249,6 +249,7 @@ SIGNATURES = {
     "trk_cgls_iterate_sharded": (c_int, [c_op, ctypes.c_void_p, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64,
                                          c_int, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, ctypes.POINTER(c_int), c_f64p, c_int,
                                          ctypes.POINTER(c_int), c_stream]),
+    "trk_wgram_tv_z": (c_int, [c_f32p, c_i64, c_int, c_int, c_f32p, c_f64p, c_f32p, c_f64p, c_stream]),
     "trk_wgram_tv": (c_int, [c_f32p, c_i64, c_int, c_int, c_f32p, c_f64p, c_stream]),
     "trk_wgram": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_stream]),
 }

@@ -1427,15 +1427,19 @@ struct TvRow {
   float4 x[T][2];      // 8 consecutive pixels of the image row, per tile
   float nx[T];         // the first pixel of the next strip (used by the lanes sl == 3 only)
   float w;             // lane l < 32: w_h of column 32 strip + l ; l >= 32: w_v of column 32 strip + l - 32
+  float z;             // (Z) lane l: z of column 32 strip + (l & 31)
 };
 
-template <int T>
+// Z: the pass also takes h[j] = V[j] . z for one more image z (MMGKS: the Gram row V^T (A^T A v_new) of the vector appended last,
+// which needs the same sweep over V — trk_wgram_tv_z): fp64 products as in k_gemv_t, z spread to the lanes like the weights.
+// Block partials: [k*k Gram | k dots] per workgroup.
+template <int T, bool Z>
 __global__ __launch_bounds__(NT, 2) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
                                                     const float* __restrict__ w, int nbands, int band_rows,
-                                                    double* __restrict__ partials) {
+                                                    double* __restrict__ partials, const float* __restrict__ z) {
   constexpr int NP = T * (T + 1) / 2;
   __shared__ double red[3][4][64];
-  __shared__ __attribute__((aligned(16))) float wl[NT / 64][64];
+  __shared__ __attribute__((aligned(16))) float wl[NT / 64][Z ? 96 : 64];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, sl = lane >> 4;
   const float* __restrict__ wh = w;
   const float* __restrict__ wv = w + (int64_t)N * (N - 1);
@@ -1450,6 +1454,9 @@ __global__ __launch_bounds__(NT, 2) void k_wgram_tv(const float* __restrict__ V,
   for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int q = 0; q < 4; ++q) accd[p][q] = 0.0;
+  double accz[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) accz[t] = 0.0;
   const int strips = N / 32;
   const int64_t units = (int64_t)strips * nbands;
   const int64_t gw = (int64_t)blockIdx.x * (NT / 64) + wave, nw = (int64_t)gridDim.x * (NT / 64);
@@ -1470,6 +1477,7 @@ __global__ __launch_bounds__(NT, 2) void k_wgram_tv(const float* __restrict__ V,
       const int64_t e = (int64_t)ic * N;
       const int iv = ic < N - 1 ? ic : N - 2;                    // the last image row has no vertical difference: weight zeroed at use
       P.w = lane < 32 ? wh[(int64_t)ic * (N - 1) + cs + (lane < 31 || !last_strip ? lane : 30)] : wv[(int64_t)iv * N + cs + lane - 32];
+      if (Z) P.z = z[e + cs + (lane & 31)];
 #pragma unroll
       for (int t = 0; t < T; ++t) {
         P.x[t][0] = *reinterpret_cast<const float4*>(rowp[t] + e + c0);
@@ -1482,9 +1490,28 @@ __global__ __launch_bounds__(NT, 2) void k_wgram_tv(const float* __restrict__ V,
       float wk = P.w;
       if (lane == 31 && last_strip) wk = 0.f;                    // column N - 1 has no right neighbour
       if (lane >= 32 && i >= N - 1) wk = 0.f;                    // row N - 1 has none below
+      // (the LDS traffic of one wave is in order in hardware; the compiler must not reorder the float stores and the float4 loads
+      //  of the next lines either — it did, across two unrolled steps: fences for the compiler only)
+      __asm__ volatile("" ::: "memory");
       my[lane] = wk;
+      if (Z && lane < 32) my[64 + lane] = P.z;
+      __asm__ volatile("" ::: "memory");
       const float4 wh0 = *reinterpret_cast<const float4*>(my + 8 * sl), wh1 = *reinterpret_cast<const float4*>(my + 8 * sl + 4);
       const float4 wv0 = *reinterpret_cast<const float4*>(my + 32 + 8 * sl), wv1 = *reinterpret_cast<const float4*>(my + 36 + 8 * sl);
+      float4 z0 = make_float4(0.f, 0.f, 0.f, 0.f), z1 = z0;
+      if (Z) {
+        z0 = *reinterpret_cast<const float4*>(my + 64 + 8 * sl);
+        z1 = *reinterpret_cast<const float4*>(my + 68 + 8 * sl);
+      }
+      __asm__ volatile("" ::: "memory");
+      if (Z) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float4 a = P.x[t][0], b = P.x[t][1];
+          accz[t] += (double)a.x * z0.x + (double)a.y * z0.y + (double)a.z * z0.z + (double)a.w * z0.w +
+                     (double)b.x * z1.x + (double)b.y * z1.y + (double)b.z * z1.z + (double)b.w * z1.w;
+        }
+      }
       f4v acc[NP];
 #pragma unroll
       for (int p = 0; p < NP; ++p) acc[p] = (f4v){0.f, 0.f, 0.f, 0.f};
@@ -1549,7 +1576,7 @@ __global__ __launch_bounds__(NT, 2) void k_wgram_tv(const float* __restrict__ V,
   }
   // combine the 4 waves (fixed order) and write the block partial in matrix order (16x16 C/D map: lane (r, sl), register q
   // holds D[4 sl + q][r])
-  double* __restrict__ out = partials + (size_t)blockIdx.x * k * k;
+  double* __restrict__ out = partials + (size_t)blockIdx.x * (k * k + (Z ? k : 0));
   int p = 0;
 #pragma unroll
   for (int ta = 0; ta < T; ++ta)
@@ -1573,6 +1600,22 @@ __global__ __launch_bounds__(NT, 2) void k_wgram_tv(const float* __restrict__ V,
       }
       __syncthreads();
     }
+  if (Z) {
+    // the dots: the four quarter-strip lanes of a row first (fixed order), then the four waves
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      double v = accz[t];
+      const double v1 = __shfl(v, r + 16, 64), v2 = __shfl(v, r + 32, 64), v3 = __shfl(v, r + 48, 64);
+      v = ((__shfl(v, r, 64) + v1) + v2) + v3;
+      if (lane < 16) red[0][wave][16 * (t & 3) + lane] = v;      // [wave][row within a group of 4 tiles]
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 * T) {
+      const int row = threadIdx.x;
+      const double t = ((red[0][0][row] + red[0][1][row]) + red[0][2][row]) + red[0][3][row];
+      if (row < k) out[(size_t)k * k + row] = t;
+    }
+  }
 }
 
 // scatter the augmented Gram [KA x KA] into G (k x k), c1, c2 (and optionally ||w b||^2)
@@ -1997,7 +2040,18 @@ int trk_gemv_nt(const float* V, int64_t ld, int k, int64_t n, const double* h, c
   return finalize_sums(part, bx, k, k, g, s);
 }
 
+static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w, double* G, const float* z, double* h, trk_stream st);
+
 int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, double* G, trk_stream st) {
+  return wgram_tv_run(V, ld, k, N, w, G, nullptr, nullptr, st);
+}
+
+int trk_wgram_tv_z(const float* V, int64_t ld, int k, int N, const float* w, double* G, const float* z, double* h, trk_stream st) {
+  TRK_REQUIRE(z && h && aligned16(z), "trk_wgram_tv_z: z / h NULL or z not 16-byte aligned");
+  return wgram_tv_run(V, ld, k, N, w, G, z, h, st);
+}
+
+static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w, double* G, const float* z, double* h, trk_stream st) {
   TRK_REQUIRE(V && w && G, "trk_wgram_tv: NULL argument");
   TRK_REQUIRE(k >= 1 && k <= 48, "trk_wgram_tv: need 1 <= k <= 48 (trk_wgram over the stored images beyond)");
   TRK_REQUIRE(N >= 32 && N % 32 == 0 && ld >= (int64_t)N * N && ld % 4 == 0 && aligned16(V) && aligned16(w),
@@ -2014,11 +2068,14 @@ int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, doubl
   const int64_t units = (int64_t)strips * nbands;
   if ((int64_t)bx * (NT / 64) > units) bx = (int)((units + NT / 64 - 1) / (NT / 64));
   double* part = nullptr;
-  if (int rc = scratch_doubles(s, (size_t)bx * k * k, &part)) return rc;
-  if (T16 == 1) hipLaunchKernelGGL((k_wgram_tv<1>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part);
-  else if (T16 == 2) hipLaunchKernelGGL((k_wgram_tv<2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part);
-  else hipLaunchKernelGGL((k_wgram_tv<3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part);
+  const int nv = k * k + (z ? k : 0);
+  if (int rc = scratch_doubles(s, (size_t)bx * nv, &part)) return rc;
+#define WTV(TT, ZZ) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z)
+  if (z) { if (T16 == 1) WTV(1, true); else if (T16 == 2) WTV(2, true); else WTV(3, true); }
+  else   { if (T16 == 1) WTV(1, false); else if (T16 == 2) WTV(2, false); else WTV(3, false); }
+#undef WTV
   TRK_LAUNCH_CHECK();
+  if (z) return finalize_sums_split(part, bx, nv, nv, G, k * k, h, s);
   return finalize_sums(part, bx, k * k, k * k, G, s);
 }
 

@@ -709,9 +709,14 @@ class HipEngine:
 
     WGRAM_TV_MAX_K = 48
 
-    def wgram_tv(self, V, k, N, w, G):
+    def wgram_tv(self, V, k, N, w, G, z=None, h=None):
         """G = (L V) diag(w^2) (L V)^T for the 2-D first-difference L of an N x N image, from V itself (trk_wgram_tv: N % 32 == 0,
-        k <= WGRAM_TV_MAX_K; local sums)."""
+        k <= WGRAM_TV_MAX_K; local sums).  With z (an image) the same pass also leaves h[j] = V[j] . z (trk_wgram_tv_z)."""
+        if z is not None:
+            rc = self.lib.trk_wgram_tv_z(V.data_ptr(), V.stride(0), int(k), int(N), w.data_ptr(), _ptr(G), z.data_ptr(), _ptr(h),
+                                         self.stream())
+            _lib.check(rc, "trk_wgram_tv_z")
+            return
         rc = self.lib.trk_wgram_tv(V.data_ptr(), V.stride(0), int(k), int(N), w.data_ptr(), _ptr(G), self.stream())
         _lib.check(rc, "trk_wgram_tv")
 

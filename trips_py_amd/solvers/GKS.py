@@ -61,8 +61,10 @@ class _ProjectedBases:
         for j in range(V0.k):
             self._push_images(j)
 
-    def _push_images(self, j):
-        """Row / column j of the Gram data (and, where they are kept, AV[j] = A V[j], LV[j] = L V[j])."""
+    def _push_images(self, j, v_pass=None):
+        """Row / column j of the Gram data (and, where they are kept, AV[j] = A V[j], LV[j] = L V[j]).
+        v_pass(z, out): a pass over V the caller needs anyway, which also leaves V^T z in `out` (MMGKS: the next iteration's
+        re-weighted Gram, trk_wgram_tv_z) — taken instead of the sweep of V for the A-side Gram row (from_v_A without L)."""
         eng, S = self.eng, self.S
         v = self.V[j]
         k = j + 1
@@ -99,7 +101,10 @@ class _ProjectedBases:
                 eng.gemv_t(self.AV.data, k, av, S.ref(0))
         if not self.use_L:
             if self.from_v_A:
-                eng.gemv_t(self.V.data, k, self.zA, S.ref(0))
+                if v_pass is not None:
+                    v_pass(self.zA, S.ref(0))
+                else:
+                    eng.gemv_t(self.V.data, k, self.zA, S.ref(0))
             else:
                 a_row_from_images()
         elif self.from_v_A and self.from_v_L:
@@ -127,9 +132,10 @@ class _ProjectedBases:
         self.GL[j, :k] = self.GL[:k, j] = h[k:2 * k]
         self.c[j] = h[2 * k]
 
-    def append(self):
+    def append(self, v_pass=None):
         """The caller has written the new basis vector into V.next_slot() and committed it."""
-        self._push_images(self.V.k - 1)
+        self._push_images(self.V.k - 1, v_pass=v_pass if (self.from_v_A and not self.use_L) else None)
+        return v_pass is not None and self.from_v_A and not self.use_L          # whether v_pass ran
 
     # ---- the Gram rows of the next vector WITHOUT a pass over the basis of their own (on_device only) ----
     # The new vector is v_k = (r - V c)/rho; G[i][k] = v_i . M v_k follows from a = V^T (M r), which rides on the sweep that

@@ -156,6 +156,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     if unit_wf:
         wf.fill_(1.0)
     # ||x_i - x_true||^2 rides the pass that forms x_i = V y (trk_gemv_n_err) as raw block partials
+    gram_ahead, fuse_passes = False, bool(kwargs.get("fuse_gram_passes", True))
     err_fused = xt is not None and hasattr(eng, "gemv_n_err") and kwargs.get("fused_error_norm", True)
     EP_CAP = 2048
     EP, n_ep = (eng.scalars(EP_CAP * max(1, n_iter)) if err_fused else None), 0
@@ -173,14 +174,18 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             gs_op.apply(x_cur if x_dev is None else x_dev, out=gs_d)
             eng.group_weights(gs_d, gs_rows, gs_nt_x, float(np.exp(2)), qnorm / 2 - 1, gs_nt_x, wr)   # exp(2): sic (:87)
         elif fusedL:
-            L.tv_weights(x_cur if x_dev is None else x_dev, epsilon, qnorm, wr)
+            if not gram_ahead:
+                L.tv_weights(x_cur if x_dev is None else x_dev, epsilon, qnorm, wr)
         else:
             eng.mm_weights(lx, None, epsilon, qnorm, wr)
         # weighted Gram matrices and projected right-hand sides
         if pbA is None:
             eng.wgram(AV.data, k, wf, bv, G.ref(0), G.ref(2 * kk), G.ref(2 * kk + k))
         if tv_gram:
-            eng.wgram_tv(V.data, k, L.N, wr, G.ref(kk))
+            if gram_ahead:                       # formed at the end of the previous iteration, with the A-side Gram row's sweep
+                gram_ahead = False
+            else:
+                eng.wgram_tv(V.data, k, L.N, wr, G.ref(kk))
         else:
             eng.wgram(LV.data, k, wr, None, G.ref(kk))
         nred = 2 * kk + 2 * k
@@ -270,7 +275,14 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         if merged:
             pbA.append_from_sweep(gs_gram, k, cc, Rn.ref(ii))
         elif pbA is not None:
-            pbA.append()
+            if tv_gram and fuse_passes and not last:
+                # the new Gram row V^T (A^T A v_new) and the NEXT iteration's re-weighted Gram of L V both sweep V (now k + 1 vectors):
+                # one pass (trk_wgram_tv_z).  The weights of the next iteration depend on x_dev only, which is final.
+                L.tv_weights(x_dev, epsilon, qnorm, wr)
+                k1 = V.k
+                gram_ahead = pbA.append(v_pass=lambda zz, out: eng.wgram_tv(V.data, k1, L.N, wr, G.ref(k1 * k1), z=zz, h=out))
+            else:
+                pbA.append()
         push_images(V.k - 1)
         res.append(ii)
     nres = len(res)
