@@ -114,9 +114,11 @@ __global__ __launch_bounds__(256) void k_fan_pad_copies(const float* __restrict_
 
 typedef float fan_f2 __attribute__((ext_vector_type(2)));
 
+// gridDim.y > 1: the march is cut into that many bands of `band` steps, band b leaving its sum (without the ray's length) in
+// part[b][ray] for k_fan_bands_sum — one thread per ray is 2 waves per SIMD at 512^2 x 180 x 724, too few to hide the gathers.
 __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__ P0, const float* __restrict__ P1,
                                                        float* __restrict__ sino, int N, int64_t nrays,
-                                                       const FanRay* __restrict__ rays) {
+                                                       const FanRay* __restrict__ rays, int band, float* __restrict__ part) {
   const int64_t ray = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (ray >= nrays) return;
   const FanRay gq = rays[ray];
@@ -124,9 +126,12 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
   const int W = N + 2 * FAN_PAD;
   const float* __restrict__ I = (g.shallow ? P1 : P0) + FAN_PAD;
   float acc0 = 0.f, acc1 = 0.f;
-  int t0 = 0;
-  long long pos = g.x0 + (long long)g.mneg;            // exact integers: stepping by M accumulates nothing (one 64-bit add per step
-  const float* __restrict__ row = I;                   // instead of a 64-bit multiply-add)
+  int t0 = blockIdx.y * band;
+  const int t_end = (t0 + band < N) ? t0 + band : N;
+  N = t_end;                                             // (the march below runs to N)
+  long long pos = g.x0 + (long long)g.mneg + (long long)t0 * (long long)g.m;   // exact integers: stepping by M accumulates nothing
+  const float* __restrict__ row = I + (int64_t)t0 * W;   // (one 64-bit add per step instead of a 64-bit multiply-add)
+  const int Nimg = W - 2 * FAN_PAD;
   for (; t0 + 8 <= N; t0 += 8) {
     float w0[8], w1[8];
     fan_f2 v[8];
@@ -135,7 +140,7 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
       int cl;
       fan_step_at(pos, g, cl, w0[u], w1[u]);
       pos += g.m;
-      cl = cl < -FAN_PAD ? -FAN_PAD : (cl > N ? N : cl);
+      cl = cl < -FAN_PAD ? -FAN_PAD : (cl > Nimg ? Nimg : cl);
       v[u] = *reinterpret_cast<const fan_f2*>(row + cl);                             // 4-byte aligned 8-byte load
       row += W;
     }
@@ -150,22 +155,49 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
     int cl;
     float w0, w1;
     fan_step(t0, g, cl, w0, w1);
-    cl = cl < -FAN_PAD ? -FAN_PAD : (cl > N ? N : cl);
+    cl = cl < -FAN_PAD ? -FAN_PAD : (cl > Nimg ? Nimg : cl);
     const float* q = I + (int64_t)t0 * W + cl;
     acc0 = fmaf(w0, q[0], acc0);
     acc1 = fmaf(w1, q[1], acc1);
   }
-  sino[ray] = gq.len * (acc0 + acc1);
+  if (gridDim.y == 1) sino[ray] = gq.len * (acc0 + acc1);
+  else part[(int64_t)blockIdx.y * nrays + ray] = acc0 + acc1;
 }
 
-// records of one apply: the ray table with len * S in place of len (one gather per candidate ray in the adjoint instead of two)
+// sino[ray] = len * (the bands' sums, added in band order)
+__global__ __launch_bounds__(256) void k_fan_bands_sum(const float* __restrict__ part, int nb, int64_t nrays,
+                                                       const FanRay* __restrict__ rays, float* __restrict__ sino) {
+  const int64_t ray = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (ray >= nrays) return;
+  float t = 0.f;
+  for (int b = 0; b < nb; ++b) t += part[(int64_t)b * nrays + ray];
+  sino[ray] = rays[ray].len * t;
+}
+
+// records of one apply: the ray table with len * S in place of len (one gather per candidate ray in the adjoint instead of two) and
+// 1/|M| in place of the high word of X0: a pixel weighs a candidate ray by the ray's position RELATIVE to the pixel, which lies
+// within +-1.1 columns for every candidate (the interval is the pixel's half diagonal plus 2 %), so the low 32 bits of the 2^-30
+// fixed-point position — a range of 4 columns — decide it exactly; the 64-bit multiply-add of the forward's absolute position and
+// the reciprocal per candidate were a third of the adjoint's instructions.
+struct FanRec {
+  unsigned x0_lo;    // as FanRay (bit 0: class)
+  float inv_absm;    // the float fan_ray_regs() computes from M — the same bits as the forward uses
+  int m;
+  float len_s;       // len * S[a][d]
+};
+static_assert(sizeof(FanRec) == sizeof(FanRay), "the record array doubles as the forward's band partials: 16 bytes per ray");
+
 __global__ __launch_bounds__(256) void k_fan_adj_prep(const float* __restrict__ sino, int64_t ld_sino, const FanRay* __restrict__ rays,
-                                                      FanRay* __restrict__ recs, int64_t nrays) {
+                                                      FanRec* __restrict__ recs, int64_t nrays) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= nrays) return;
-  FanRay q = rays[i];
-  q.len *= sino[(int64_t)blockIdx.y * ld_sino + i];
-  recs[(int64_t)blockIdx.y * nrays + i] = q;
+  const FanRay q = rays[i];
+  FanRec o;
+  o.x0_lo = q.x0_lo;
+  o.inv_absm = fan_ray_regs(q).inv_absm;
+  o.m = q.m;
+  o.len_s = q.len * sino[(int64_t)blockIdx.y * ld_sino + i];
+  recs[(int64_t)blockIdx.y * nrays + i] = o;
 }
 
 // NC = 2: the geometry admits two candidate rays per pixel and angle nearly everywhere (decided at creation; the reference's: three
@@ -175,7 +207,7 @@ __global__ __launch_bounds__(256) void k_fan_adj_prep(const float* __restrict__ 
 template <int NC>
 __global__ __launch_bounds__(256) void k_fan_adj_march(float* __restrict__ img,
                                                        int64_t ld_img, int N, int nd, int na, float dsd, float inv_pitch, float reach,
-                                                       const FanAngle* __restrict__ ang, const FanRay* __restrict__ recs) {
+                                                       const FanAngle* __restrict__ ang, const FanRec* __restrict__ recs) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)N * N) return;
   const int r = (int)(idx / N), c = (int)(idx - (int64_t)r * N);
@@ -196,26 +228,29 @@ __global__ __launch_bounds__(256) void k_fan_adj_march(float* __restrict__ img,
     dlo = dlo < 0 ? 0 : dlo;
     dhi = dhi > nd - 1 ? nd - 1 : dhi;
   };
-  auto weigh = [&](const FanRay& q) -> float {
-    const FanRayRegs qr = fan_ray_regs(q);
-    const int tt = qr.shallow ? c : r, want = qr.shallow ? r : c;          // marching index / the index the ray picks per step
-    int cl;
-    float w0, w1;
-    fan_step(tt, qr, cl, w0, w1);
-    return ((want == cl) ? w0 : ((want == cl + 1) ? w1 : 0.f)) * q.len;
+  auto weigh = [&](const FanRec& q) -> float {
+    const bool shallow = (q.x0_lo & 1u) != 0u;
+    const unsigned tt = shallow ? c : r, want = shallow ? r : c;           // marching index / the index the ray picks per step
+    // fan_step_at() on the position relative to the pixel, modulo 4 columns: rel = X0 + tt M + min(M, 0) - want   (2^-30 units)
+    const unsigned rel = (q.x0_lo & ~1u) + tt * (unsigned)q.m + (unsigned)(q.m < 0 ? q.m : 0) - (want << FAN_Q);
+    const int sel = (int)rel >> FAN_Q;                                     // cl - want: 0 the ray's first column, -1 its second
+    const int dist = (1 << FAN_Q) - (int)(rel & ((1u << FAN_Q) - 1u));
+    const int absm = q.m < 0 ? -q.m : q.m;
+    const float f = (absm >= dist) ? fminf((float)dist * q.inv_absm, 1.f) : 1.f;
+    return ((sel == 0) ? f : ((sel == -1) ? 1.f - f : 0.f)) * q.len_s;
   };
-  const FanRay* __restrict__ R0 = recs + (int64_t)blockIdx.y * na * nd;
+  const FanRec* __restrict__ R0 = recs + (int64_t)blockIdx.y * na * nd;
   if (NC == 2) {
     constexpr int UA = 4;
     int a = 0;
     for (; a + UA <= na; a += UA) {
-      FanRay q[UA][2];
+      FanRec q[UA][2];
       bool ok[UA][2];
 #pragma unroll
       for (int u = 0; u < UA; ++u) {
         int dlo, dhi;
         interval(ang[a + u], dlo, dhi);
-        const FanRay* __restrict__ Ra = R0 + (int64_t)(a + u) * nd;
+        const FanRec* __restrict__ Ra = R0 + (int64_t)(a + u) * nd;
         ok[u][0] = dlo <= dhi;
         ok[u][1] = dlo + 1 <= dhi;
         q[u][0] = Ra[ok[u][0] ? dlo : 0];
@@ -231,14 +266,14 @@ __global__ __launch_bounds__(256) void k_fan_adj_march(float* __restrict__ img,
     for (; a < na; ++a) {
       int dlo, dhi;
       interval(ang[a], dlo, dhi);
-      const FanRay* __restrict__ Ra = R0 + (int64_t)a * nd;
+      const FanRec* __restrict__ Ra = R0 + (int64_t)a * nd;
       for (int d = dlo; d <= dhi; ++d) acc += weigh(Ra[d]);
     }
   } else {
     for (int a = 0; a < na; ++a) {
       int dlo, dhi;
       interval(ang[a], dlo, dhi);
-      const FanRay* __restrict__ Ra = R0 + (int64_t)a * nd;
+      const FanRec* __restrict__ Ra = R0 + (int64_t)a * nd;
       for (int d = dlo; d <= dhi; ++d) acc += weigh(Ra[d]);                // one 16-byte gather: {X0 (64 bits), M, len * S[a][d]}
     }
   }
@@ -360,11 +395,24 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   if (!tr && march) {
     const int nb = ceil_div(im->N, 32);
     const int64_t padded = (int64_t)im->N * (im->N + 2 * FAN_PAD);
-    dim3 grid(ceil_div((int64_t)im->na * im->nd, 256), 1);
+    const int64_t nrays = (int64_t)im->na * im->nd;
+    // bands of the march: enough waves to hide the gathers (about 8 per SIMD), at most the 4 floats per ray that the adjoint's
+    // record array (unused during a forward apply) has room for, bands of at least 64 steps and a multiple of 8
+    static const int fb_env = getenv("TRK_FAN_FWD_BANDS") ? atoi(getenv("TRK_FAN_FWD_BANDS")) : 0;
+    int nbands = fb_env > 0 ? fb_env : (int)((8 * 4 * (int64_t)cu_count() * 64 + nrays - 1) / nrays);
+    if (nbands > 4) nbands = 4;
+    if (nbands > im->N / 64) nbands = im->N / 64;
+    if (nbands < 1) nbands = 1;
+    const int band = ((im->N + nbands - 1) / nbands + 7) / 8 * 8;
+    nbands = ceil_div(im->N, band);
+    dim3 grid(ceil_div(nrays, 256), nbands);
+    float* part = reinterpret_cast<float*>(im->recs);
     for (int b = 0; b < batch; ++b) {                                      // one pair of padded copies per handle: columns go one by one
       hipLaunchKernelGGL(k_fan_pad_copies, dim3(nb, nb, 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->xT, im->xT + padded, im->N);
       hipLaunchKernelGGL(k_fan_fwd_march, grid, dim3(256), 0, s, im->xT, im->xT + padded, y + (int64_t)b * ldy, im->N,
-                         (int64_t)im->na * im->nd, im->rays);
+                         nrays, im->rays, band, part);
+      if (nbands > 1)
+        hipLaunchKernelGGL(k_fan_bands_sum, dim3(ceil_div(nrays, 256)), dim3(256), 0, s, part, nbands, nrays, im->rays, y + (int64_t)b * ldy);
     }
   } else if (!tr) {
     dim3 grid(ceil_div((int64_t)im->na * im->nd, 256), batch);
@@ -373,13 +421,13 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
     const int64_t nrays = (int64_t)im->na * im->nd;
     dim3 grid(ceil_div((int64_t)im->N * im->N, 256), 1);
     for (int b = 0; b < batch; ++b) {                                      // one record array per handle: columns go one by one
-      hipLaunchKernelGGL(k_fan_adj_prep, dim3(ceil_div(nrays, 256), 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->rays, im->recs, nrays);
+      hipLaunchKernelGGL(k_fan_adj_prep, dim3(ceil_div(nrays, 256), 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->rays, reinterpret_cast<FanRec*>(im->recs), nrays);
       if (im->max_cand <= 3)
         hipLaunchKernelGGL(k_fan_adj_march<2>, grid, dim3(256), 0, s, y + (int64_t)b * ldy, ldy, im->N, im->nd, im->na, im->dsd,
-                           1.0f / im->pitch, im->reach, im->ang_dev, im->recs);
+                           1.0f / im->pitch, im->reach, im->ang_dev, reinterpret_cast<const FanRec*>(im->recs));
       else
         hipLaunchKernelGGL(k_fan_adj_march<0>, grid, dim3(256), 0, s, y + (int64_t)b * ldy, ldy, im->N, im->nd, im->na, im->dsd,
-                           1.0f / im->pitch, im->reach, im->ang_dev, im->recs);
+                           1.0f / im->pitch, im->reach, im->ang_dev, reinterpret_cast<const FanRec*>(im->recs));
     }
   } else {
     dim3 grid(ceil_div((int64_t)im->N * im->N, 256), batch);
