@@ -595,6 +595,11 @@ def extra_c5_dynamic(rank, world, cpu_jobs=None):
                 comm, comm_kind = RcclComm(), "libtrk RCCL communicator (trk_comm_init / trk_allreduce_f64 / trk_halo_exchange)"
             except Exception as exc:      # noqa: BLE001
                 comm_kind = f"torch.distributed ({type(exc).__name__} from trk_comm_init: {exc})"[:200]
+            # every rank must end up on the same communicator: if one could not make its own, all use torch.distributed
+            ok = torch.tensor([1.0 if comm is not None else 0.0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) < 1.0 and comm is not None:
+                comm, comm_kind = None, "torch.distributed (another rank could not create the libtrk communicator)"
         if comm is None:
             comm, comm_kind = TorchComm(), comm_kind or f"torch.distributed ({dist.get_backend()})"
         eng = HipEngine(comm=comm)

@@ -73,12 +73,19 @@ class RcclComm:
             world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank, self.world = int(rank), int(world)
         idbuf = (ctypes.c_char * 128)()
+        why = None
         if self.rank == 0:
-            _lib.check(self.lib.trk_comm_unique_id(idbuf), "trk_comm_unique_id")
+            try:
+                _lib.check(self.lib.trk_comm_unique_id(idbuf), "trk_comm_unique_id")
+            except Exception as exc:      # noqa: BLE001  (the other ranks are waiting in the broadcast: tell them, then raise)
+                why = f"{type(exc).__name__}: {exc}"
         if self.world > 1:
-            box = [bytes(idbuf)]
+            box = [(why, bytes(idbuf))]
             dist.broadcast_object_list(box, src=0)
-            ctypes.memmove(idbuf, box[0], 128)
+            why = box[0][0]
+            ctypes.memmove(idbuf, box[0][1], 128)
+        if why is not None:
+            raise RuntimeError(f"RcclComm: rank 0 could not create the unique id ({why})")
         self._h = ctypes.c_void_p()
         _lib.check(self.lib.trk_comm_init(idbuf, self.rank, self.world, ctypes.byref(self._h)), "trk_comm_init")
 
