@@ -2071,7 +2071,14 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   const int nv = k * k + (z ? k : 0);
   if (int rc = scratch_doubles(s, (size_t)bx * nv, &part)) return rc;
 #define WTV(TT, ZZ) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z)
-  if (z) { if (T16 == 1) WTV(1, true); else if (T16 == 2) WTV(2, true); else WTV(3, true); }
+  if (z && T16 == 3) {
+    // three tiles AND the dots do not fit the register file (108 spilled registers): two passes for 33 <= k <= 48
+    WTV(3, false);
+    TRK_LAUNCH_CHECK();
+    if (int rc = finalize_sums(part, bx, k * k, k * k, G, s)) return rc;
+    return launch_gemv_t(V, ld, k, (int64_t)N * N, z, nullptr, 0, h, s);
+  }
+  if (z) { if (T16 == 1) WTV(1, true); else WTV(2, true); }
   else   { if (T16 == 1) WTV(1, false); else if (T16 == 2) WTV(2, false); else WTV(3, false); }
 #undef WTV
   TRK_LAUNCH_CHECK();

@@ -87,19 +87,38 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
         H = ar.H()[:k + 1, :k]
         bhat = np.zeros(k + 1)
         bhat[0] = ar.beta0
+        svd = None
         if ii == 0:
             lam = 0
         elif isinstance(regparam, str) and regparam in ("gcv", "l_curve"):
-            Qh, s, _ = sla.svd(H, full_matrices=False)
-            lam = choose_lambda(regparam, np.diag(s), np.eye(k), Qh.T @ bhat, 0.0, kwargs)   # 'standard' GCV here (:58)
+            Qh, s, Vh = sla.svd(H, full_matrices=False)
+            qb = Qh.T @ bhat
+            lam = choose_lambda(regparam, np.diag(s), np.eye(k), qb, 0.0, kwargs)   # 'standard' GCV here (:58)
+            svd = (s, Vh, qb)
         elif isinstance(regparam, str) and regparam == "dp":
             eng.gemv_t(ar.V.data, k + 1, bv, P.ref(0))
             eng.allreduce(P, 0, k + 1)
-            lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=H, dp_bproj=P.host(0, k + 1))
+            if kwargs.get("solve_by_svd", True):
+                # the SVD discrepancy_principle() takes of H (discrepancy_principle.py:68-70), taken here so that the Tikhonov
+                # solve below can share it
+                from ..reg_param.discrepancy_principle import discrepancy_principle
+                Uf, s, Vh = sla.svd(H)
+                extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
+                lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
+                                            spectrum=(s, Uf.T @ P.host(0, k + 1).reshape(-1, 1), (k + 1, k)), **extra)
+                svd = (s, Vh, Uf[:, :k].T @ bhat)
+            else:
+                lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=H, dp_bproj=P.host(0, k + 1))
         else:
             lam = regparam
         lams.append(lam)
-        y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
+        if svd is not None and lam > 0 and kwargs.get("solve_by_svd", True):
+            # the Tikhonov minimiser of (:76) from the SVD the selector needed anyway: y = V diag(s / (s^2 + lam)) U^T bhat — O(k^2)
+            # where the stacked least-squares problem is another O(k^3) factorisation per iteration
+            sv, Vh, qb = svd
+            y = Vh.T @ ((sv / (sv * sv + lam)) * qb)
+        else:
+            y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
         Y.set(0, y)
         x_dev = Hs.row(ii)
         if err_fused:
