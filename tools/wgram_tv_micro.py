@@ -14,10 +14,12 @@ LV = torch.empty(kmax, p, device=eng.device)
 for j in range(kmax):
     L.apply(V[j], out=LV[j])
 w = torch.rand(p, device=eng.device) + 0.25
-G = eng.scalars(2 * kmax * kmax)
-for k in (3, 8, 16, 17, 24, 32, 33):
+G = eng.scalars(2 * kmax * kmax + kmax)
+for k in ([int(v) for v in os.environ["KS"].split(",")] if "KS" in os.environ else (3, 8, 16, 17, 24, 32, 33)):
     out = []
-    for f in (lambda: eng.wgram(LV, k, w, None, G[0:k * k]), lambda: eng.wgram_tv(V, k, N, w, G[k * k:2 * k * k])):
+    zz = V[kmax - 1]
+    for f in (lambda: eng.wgram(LV, k, w, None, G[0:k * k]), lambda: eng.wgram_tv(V, k, N, w, G[k * k:2 * k * k]),
+              lambda: eng.wgram_tv(V, k, N, w, G[k * k:2 * k * k], z=zz, h=G[2 * kmax * kmax - kmax:2 * kmax * kmax - kmax + k])):
         f(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):
@@ -26,4 +28,4 @@ for k in (3, 8, 16, 17, 24, 32, 33):
         out.append((time.perf_counter() - t0) / 10 * 1e6)
     g = eng.to_host(G)
     a, b = g[:k * k], g[k * k:2 * k * k]
-    print(f"k={k:2d}: stored images {out[0]:8.1f} us ({(k * p + p) * 4 / out[0] / 1e6:5.2f} TB/s)   from V {out[1]:8.1f} us ({(k * n * 4 + p * 4) / out[1] / 1e6:5.2f} TB/s of its own bytes)   max rel diff {abs(a - b).max() / abs(a).max():.1e}")
+    print(f"k={k:2d}: stored images {out[0]:8.1f} us ({(k * p + p) * 4 / out[0] / 1e6:5.2f} TB/s)   from V {out[1]:8.1f} us ({(k * n * 4 + p * 4) / out[1] / 1e6:5.2f} TB/s of its own bytes)   with V^T z {out[2]:8.1f} us   max rel diff {abs(a - b).max() / abs(a).max():.1e}")

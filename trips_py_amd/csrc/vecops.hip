@@ -2058,7 +2058,14 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
               "trk_wgram_tv: need N a multiple of 32, 16-byte aligned rows and weights");
   hipStream_t s = (hipStream_t)st;
   const int T16 = (k + 15) / 16;
-  const int per_cu = T16 == 1 ? 4 : T16 == 2 ? 3 : 2;          // what the register budget lets be resident (94 / 160 / 248 VGPRs)
+  static const int pc_env = env_int("TRK_WGRAM_TV_PER_CU", 0);
+  // workgroups per CU: what the register budget lets be resident (94 / 160 / 248 VGPRs: 4 / 3 / 2) while the matrix pipe is the
+  // bound, FEWER once the rows' traffic is (k near the top of a tile count): measured at 4096^2, k = 16: 344 / 330 / 319 us with
+  // 4 / 2 / 1 workgroups per CU, k = 32: 762 / 744 / 683 — more waves in flight means more row streams open at once
+  // (with the dots of trk_wgram_tv_z the optimum is flatter: 3 until k = 29 at two tiles)
+  const int per_cu = pc_env > 0 ? pc_env
+                   : z ? (T16 == 1 ? (k <= 14 ? 3 : 2) : T16 == 2 ? (k <= 29 ? 3 : 1) : 2)
+                       : (T16 == 1 ? (k <= 11 ? 4 : k <= 14 ? 2 : 1) : T16 == 2 ? (k <= 25 ? 3 : 1) : 2);
   const int strips = N / 32;
   int bx = cu_count() * per_cu;
   // (strip, band) units, band-major: the waves in flight together then work on a few neighbouring image rows of every basis vector
