@@ -179,6 +179,22 @@ def test_wgram(eng, k, m, weighted):
     assert np.allclose(got[k * k + k:], W32 @ (w32 ** 2 * b32), rtol=1e-6, atol=1e-6 * m ** 0.5)
 
 
+@pytest.mark.parametrize("k,n", [(1, 1000), (7, 10_001), (8, 4096), (9, 70_000), (17, 33_333), (40, 20_000)])
+def test_gemv_t_with_one_more_row(eng, k, n):
+    """trk_gemv_t_x: h = V r and xrow . r from one pass (the row is not part of the basis; tile counts that change with it)."""
+    rng = np.random.default_rng(7 * k + n)
+    V, r, xr = rng.standard_normal((k, n)), rng.standard_normal(n), rng.standard_normal(n)
+    dV, dr, dx = dev(eng, V), dev(eng, r), dev(eng, xr)
+    H = eng.scalars(2 * k + 2)
+    eng.gemv_t_x(dV, k, dr, dx, H[0:k], H[k:k + 1])
+    eng.gemv_t(dV, k, dr, H[k + 1:2 * k + 1])
+    got = eng.to_host(H)
+    V32, r32, x32 = f32(V), f32(r), f32(xr)
+    assert np.allclose(got[:k], V32 @ r32, rtol=1e-12, atol=1e-12 * n ** 0.5)
+    assert np.isclose(got[k], x32 @ r32, rtol=1e-12, atol=1e-12 * n ** 0.5)
+    assert np.allclose(got[k + 1:2 * k + 1], got[:k], rtol=1e-13, atol=1e-13 * n ** 0.5)
+
+
 @pytest.mark.parametrize("N,k", [(32, 1), (32, 5), (64, 16), (64, 17), (96, 7), (96, 32), (160, 33), (128, 48), (512, 20), (1024, 3)])
 def test_wgram_tv_from_v_equals_the_gram_of_the_stored_images(eng, N, k):
     """trk_wgram_tv (the weighted Gram of L V formed from V, L the 2-D first difference) against (i) the float64 definition on the
