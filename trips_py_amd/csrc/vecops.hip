@@ -1433,8 +1433,11 @@ struct TvRow {
 // Z: the pass also takes h[j] = V[j] . z for one more image z (MMGKS: the Gram row V^T (A^T A v_new) of the vector appended last,
 // which needs the same sweep over V — trk_wgram_tv_z): fp64 products as in k_gemv_t, z spread to the lanes like the weights.
 // Block partials: [k*k Gram | k dots] per workgroup.
-template <int T, bool Z>
-__global__ __launch_bounds__(NT, 2) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
+// D: image rows held per wave (the current one, the next, D - 2 in flight).  D = 3 is what is instantiated: with one workgroup per
+// CU and D = 6 (four rows in flight, 320-380 VGPRs) k = 32 went from 689 to 716 us — latency is not what that case waits for; for
+// k <= 24 the kernel sits at the fp32 matrix pipe's rate already (48 MFMAs per 32 pixels at two tiles).
+template <int T, bool Z, int D>
+__global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 2)) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
                                                     const float* __restrict__ w, int nbands, int band_rows,
                                                     double* __restrict__ partials, const float* __restrict__ z) {
   constexpr int NP = T * (T + 1) / 2;
@@ -1556,22 +1559,23 @@ __global__ __launch_bounds__(NT, 2) void k_wgram_tv(const float* __restrict__ V,
         for (int q = 0; q < 4; ++q) accd[p2][q] += (double)acc[p2][q];
     };
 
-    TvRow<T> A, B, C;
-    load(A, i0);
-    load(B, i0 + 1);
+    TvRow<T> P[D];                                               // a ring: row i sits in P[(i - i0) % D]; indices are compile-time below
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) load(P[j], i0 + j);
     int i = i0;
-    for (; i + 3 <= i1; i += 3) {                                // roles rotate: no register copies
-      load(C, i + 2);
-      step(A, B, i);
-      load(A, i + 3);
-      step(B, C, i + 1);
-      load(B, i + 4);
-      step(C, A, i + 2);
+    for (; i + D <= i1; i += D) {                                // roles rotate: no register copies
+#pragma unroll
+      for (int j = 0; j < D; ++j) {
+        load(P[(j + D - 1) % D], i + j + D - 1);
+        step(P[j], P[(j + 1) % D], i + j);
+      }
     }
-    if (i < i1) {                                                // one or two rows left; A = row i, B = row i + 1
-      if (i + 1 < i1) load(C, i + 2);
-      step(A, B, i);
-      if (i + 1 < i1) step(B, C, i + 1);
+#pragma unroll
+    for (int j = 0; j < D - 1; ++j) {                            // fewer than D rows left; P[j] = row i + j
+      if (i + j < i1) {                                          // (uniform)
+        if (i + j + D - 1 <= i1) load(P[(j + D - 1) % D], i + j + D - 1);
+        step(P[j], P[(j + 1) % D], i + j);
+      }
     }
   }
   // combine the 4 waves (fixed order) and write the block partial in matrix order (16x16 C/D map: lane (r, sl), register q
@@ -2064,7 +2068,7 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   // 4 / 2 / 1 workgroups per CU, k = 32: 762 / 744 / 683 — more waves in flight means more row streams open at once
   // (with the dots of trk_wgram_tv_z the optimum is flatter: 3 until k = 29 at two tiles)
   const int per_cu = pc_env > 0 ? pc_env
-                   : z ? (T16 == 1 ? (k <= 14 ? 3 : 2) : T16 == 2 ? (k <= 29 ? 3 : 1) : 2)
+                   : z ? (T16 == 1 ? (k <= 14 ? 3 : 2) : T16 == 2 ? (k <= 29 ? 2 : 1) : 2)
                        : (T16 == 1 ? (k <= 11 ? 4 : k <= 14 ? 2 : 1) : T16 == 2 ? (k <= 25 ? 3 : 1) : 2);
   const int strips = N / 32;
   int bx = cu_count() * per_cu;
@@ -2077,7 +2081,7 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   double* part = nullptr;
   const int nv = k * k + (z ? k : 0);
   if (int rc = scratch_doubles(s, (size_t)bx * nv, &part)) return rc;
-#define WTV(TT, ZZ) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z)
+#define WTV(TT, ZZ) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z)
   if (z && T16 == 3) {
     // three tiles AND the dots do not fit the register file (108 spilled registers): two passes for 33 <= k <= 48
     WTV(3, false);
