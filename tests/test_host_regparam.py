@@ -230,3 +230,26 @@ def test_discrepancy_principle_corner_branches_against_the_reference():
             assert discrepancy_principle(None, np.eye(6), Qtb, 0.0, delta=float(dl), dptype=dpt) == int(g[f"{dpt}{tag}"]), (dpt, tag)
     with pytest.raises(UnboundLocalError):
         discrepancy_principle(R, np.eye(6), bp, resid2, delta=delta, dptype="nonsense")
+
+
+@pytest.mark.parametrize("k", [1, 2, 7, 60, 400])
+def test_host_projected_solve_of_the_bidiagonal_problem(k):
+    """trk_host_bidiag_tikhonov (host, O(k) rotations; Hybrid-LSQR's y_k once lambda was chosen on the host) against the reference's
+    formulation — lstsq on [B_k; mu I], [beta0 e1; 0] (Hybrid_LSQR.py:104) — with and without the division by alpha_j."""
+    import ctypes
+    from trips_py_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(k)
+    al, be, beta0 = 0.2 + rng.random(k), 0.1 + rng.random(k), 2.3
+    B = np.zeros((k + 1, k))
+    B[np.arange(k), np.arange(k)], B[np.arange(1, k + 1), np.arange(k)] = al, be
+    rhs = np.zeros(2 * k + 1)
+    rhs[0] = beta0
+    for mu in (0.0, 1e-3, 0.7):
+        want = np.linalg.lstsq(np.vstack([B, mu * np.eye(k)]), rhs, rcond=None)[0]
+        for over in (0, 1):
+            y = np.empty(k)
+            rc = lib.trk_host_bidiag_tikhonov(al.ctypes.data, be.ctypes.data, k, float(beta0), float(mu), over, y.ctypes.data)
+            assert rc == 0
+            assert np.allclose(y * (al if over else 1.0), want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
+    assert lib.trk_host_bidiag_tikhonov(al.ctypes.data, be.ctypes.data, k, 1.0, -1.0, 0, y.ctypes.data) != 0      # mu < 0
