@@ -428,6 +428,11 @@ def test_hybrid_lsqr_recurrence_equals_the_combination(kind, N, its):
         for j in (0, 1, its // 2, its - 2):
             assert relerr(i1["xHistory"][j], i0["xHistory"][j]) < TOL, j
         assert np.allclose(i1["relError"], i0["relError"], rtol=1e-5)
+        # the update riding the next Golub-Kahan step's adjoint half (trk_gk_step_lsqr: the default on the projector) against the
+        # update in its own launch: the same floats, element by element; the error norms differ in their summation order only
+        x4, i4 = Hybrid_LSQR(A, b, its, lam, xt, update_on_the_step=False)
+        assert np.array_equal(x1, x4) and all(np.array_equal(p, q) for p, q in zip(i1["xHistory"], i4["xHistory"]))
+        assert np.allclose(i1["relError"], i4["relError"], rtol=1e-12)
     # no x_true, history kept: the same iterates
     x2, i2 = Hybrid_LSQR(A, b, 12, 1e-2)
     x3, i3 = Hybrid_LSQR(A, b, 12, 1e-2, x_by_recurrence=False)

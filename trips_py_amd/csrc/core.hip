@@ -516,6 +516,48 @@ int trk_gk_step_proj(trk_op* op, int k, const float* u_k, const float* v_prev, f
   return TRK_OK;
 }
 
+int trk_gk_step_lsqr(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
+                     int defer_alpha, int defer_beta, float* w, const float* x_in, float* x_out, const float* ref,
+                     double* err_partials, int capacity_blocks, int* n_blocks, double damp, const double* state_in,
+                     double* state_out, trk_stream stream) {
+  TRK_REQUIRE(op && k >= 1 && v_prev && w && x_out && state_out && AB, "trk_gk_step_lsqr: bad argument (k >= 1: the update is that of V[k-1])");
+  TRK_REQUIRE(k == 1 || (state_in && x_in), "trk_gk_step_lsqr: steps after the first need state_in and x_in");
+  TRK_REQUIRE(!ref || (err_partials && n_blocks), "trk_gk_step_lsqr: ref given but no room for the partials");
+  LsqrReq q;
+  q.on = 1;
+  q.first = (k == 1);
+  q.w = w;
+  q.x_in = x_in;
+  q.x_out = x_out;
+  q.ref = ref;
+  q.err_part = err_partials;
+  q.err_cap = capacity_blocks;
+  q.a2 = AB + 2 * k - 1;               // alpha_{k-1}^2 = ||V[k-1]||^2 (finished by the forward half of step k-1)
+  q.b2 = AB + 2 * k;                   // beta_k^2 = ||U[k]||^2 (this adjoint's epilogue finishes it if it is still pending)
+  q.beta0_sq = AB;
+  q.damp = damp;
+  q.st_in = state_in;
+  q.st_out = state_out;
+  op->lsqr = q;
+  op->lsqr_blocks = 0;
+  const int rc = trk_gk_step(op, k, u_k, v_prev, v_k, u_next, AB, chained, defer_alpha, defer_beta, stream);
+  const int taken = op->lsqr_blocks;
+  op->lsqr = LsqrReq{};
+  op->lsqr_blocks = 0;
+  if (rc) return rc;
+  if (taken > 0) {
+    if (n_blocks) *n_blocks = taken;
+    return TRK_OK;
+  }
+  // the operator's adjoint pass did not take it (no native epilogue, too many tiles for the partial buffer): the same update in
+  // its own launch, behind the step — the order the caller had before
+  int nb = 0;
+  const int rc2 = trk_lsqr_damped_update(v_prev, w, x_in, x_out, op->cols, ref, err_partials, capacity_blocks, &nb, q.a2, q.b2, AB, damp,
+                                         state_in, state_out, k == 1 ? 1 : 0, stream);
+  if (n_blocks) *n_blocks = nb;
+  return rc2;
+}
+
 int trk_op_destroy(trk_op* op) {
   if (!op) return TRK_OK;
   if (op->destroy) op->destroy(op);

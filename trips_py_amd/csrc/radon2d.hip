@@ -107,6 +107,8 @@ struct Epi {
   // forward only (trk_gk_step_proj): block partials of <out, dotv> next to the fused norm's
   const float* dotv;
   double* dot_part;
+  // adjoint only (trk_gk_step_lsqr): the damped-LSQR update whose vk is this epilogue's z
+  LsqrReq lq;
 };
 
 // the sum of the pending partials — the same bits in every workgroup (one wave, fixed order) — in all threads
@@ -142,12 +144,13 @@ __device__ __forceinline__ double coef_eval_pend(const Coef& k, const double* ta
   return v;
 }
 // both coefficients of the epilogue (uniform over the grid; ends with every thread past a barrier when a norm is pending)
-__device__ __forceinline__ void epi_coefs(const Epi& e, bool first_block, double* lds1, float& ca, float& cb) {
+__device__ __forceinline__ void epi_coefs(const Epi& e, bool first_block, double* lds1, float& ca, float& cb, double* total_out = nullptr) {
   ca = 1.f;
   cb = 0.f;
   if (!e.on) return;
   if (e.pend_target) {
     const double total = pend_total(e, lds1);
+    if (total_out) *total_out = total;
     ca = (float)coef_eval_pend(e.a, e.pend_target, total);
     if (e.z) cb = (float)coef_eval_pend(e.b, e.pend_target, total);
     if (first_block && threadIdx.x == 0) *e.pend_target = total;
@@ -1087,8 +1090,20 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
     const int i = i0 + r1 + k * TS, j = j0 + c1;
     zv[k] = (epi.on && epi.z && i < N && j < N) ? epi.z[((int64_t)frame * N + i) * N + j] : 0.f;
   }
+  // (the operands of the rider below: requested here, so that they travel while the coefficients are worked out)
+  float lw[PX], lx[PX], lr[PX];
+#pragma unroll
+  for (int k = 0; k < PX; ++k) {
+    const int i = i0 + r1 + k * TS, j = j0 + c1;
+    const bool in = epi.lq.on && i < N && j < N;
+    const int64_t g = ((int64_t)frame * N + i) * N + j;
+    lw[k] = (in && !epi.lq.first) ? epi.lq.w[g] : 0.f;
+    lx[k] = (in && epi.lq.x_in) ? epi.lq.x_in[g] : 0.f;
+    lr[k] = (in && epi.lq.ref) ? epi.lq.ref[g] : 0.f;
+  }
   float ca, cb;
-  epi_coefs(epi, blockIdx.x == 0 && blockIdx.y == 0, &lds[0], ca, cb);
+  double pend_sum = 0.0;
+  epi_coefs(epi, blockIdx.x == 0 && blockIdx.y == 0, &lds[0], ca, cb, &pend_sum);
   if (xT_out) xT_out += (int64_t)frame * N * N;
 #pragma unroll
   for (int k = 0; k < PX; ++k) {
@@ -1104,6 +1119,62 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
   if (ssq_part) {                                                 // uniform over the grid
     q = block_sum<256>(q, lds);
     if (tid == 0) ssq_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = q;
+  }
+  if (epi.lq.on) {                                                // uniform over the grid
+    // the damped-LSQR step of the iterate that z = V[k-1] belongs to, on this workgroup's pixels: k_lsqr_damped_update's
+    // arithmetic, expression for expression (vecops.hip) — the same floats whichever kernel forms them
+    const LsqrReq& L = epi.lq;
+    __shared__ double lcf[3];
+    __syncthreads();
+    if (tid == 0) {
+      const double b2v = (epi.pend_target && epi.pend_target == L.b2) ? pend_sum : *L.b2;
+      const double alpha = sqrt(*L.a2), beta = sqrt(b2v);
+      double rhobar, phibar, tw = 0.0;
+      if (L.first) {
+        rhobar = alpha;
+        phibar = sqrt(*L.beta0_sq);
+      } else {
+        rhobar = -L.st_in[0] * alpha;
+        tw = L.st_in[1] * alpha / L.st_in[2];
+        phibar = L.st_in[3];
+      }
+      const double rhobar1 = sqrt(rhobar * rhobar + L.damp * L.damp);
+      phibar *= rhobar / rhobar1;
+      const double rho = sqrt(rhobar1 * rhobar1 + beta * beta);
+      const double cs = rhobar1 / rho, sn = beta / rho;
+      lcf[0] = 1.0 / alpha;
+      lcf[1] = tw;
+      lcf[2] = cs * phibar / rho;
+      if (blockIdx.x == 0 && blockIdx.y == 0) {
+        L.st_out[0] = cs;
+        L.st_out[1] = sn;
+        L.st_out[2] = rho;
+        L.st_out[3] = sn * phibar;
+      }
+    }
+    __syncthreads();
+    const double ia = lcf[0], tw = lcf[1], px = lcf[2];
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+      const int i = i0 + r1 + k * TS, j = j0 + c1;
+      if (i < N && j < N) {
+        const int64_t g = ((int64_t)frame * N + i) * N + j;
+        const float wo = lw[k], xo = lx[k];
+        const float wn = (float)(ia * (double)zv[k] - (L.first ? 0.0 : tw * (double)wo));
+        const float xn = (float)((L.x_in ? (double)xo : 0.0) + px * (double)wn);
+        L.w[g] = wn;
+        L.x_out[g] = xn;
+        if (L.ref) {
+          const double e = (double)xn - lr[k];
+          acc += e * e;
+        }
+      }
+    }
+    if (L.ref) {
+      acc = block_sum<256>(acc, lds);
+      if (tid == 0) L.err_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+    }
   }
 }
 
@@ -1229,6 +1300,11 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   const bool fuse_ssq = sumsq && batch == 1 && (tr ? tile : post);
   const int64_t post_blocks = ceil_div((int64_t)nt * na * ndp, 256);
   const int64_t n_part = tr ? adj_blocks * nt : post_blocks;
+  epi.lq = LsqrReq{};
+  if (tr && tile && batch == 1 && epi.on && epi.z && op->lsqr.on && (!op->lsqr.ref || n_part <= op->lsqr.err_cap)) {
+    epi.lq = op->lsqr;                         // trk_gk_step_lsqr: the iterate's update on the adjoint's pixel pass (z = its vk)
+    op->lsqr_blocks = (int)n_part;
+  }
   if (!tr && post && batch == 1 && op->probe_vec && post_blocks <= op->probe_cap) {      // trk_gk_step_proj: <out, probe_vec> partials
     epi.dotv = op->probe_vec;
     epi.dot_part = op->probe_part;

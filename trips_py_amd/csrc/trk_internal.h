@@ -229,6 +229,26 @@ namespace trk {
 bool blur_separable_params(trk_op* op, int* nx, int* ny, int* kh, int* kw, const float** sep_fwd, const float** sep_adj);
 }  // namespace trk
 
+// One step of damped LSQR's short recurrence (trk_lsqr_damped_update) as a rider on another kernel's pixel pass: the vector vk of
+// that update is the `z` operand of a Golub-Kahan adjoint half step (V[k] = a A^T u + b V[k-1]: z = V[k-1]), so the half step's
+// epilogue can carry the update of the iterate that V[k-1] belongs to (trk_gk_step_lsqr).
+struct LsqrReq {
+  int on = 0;
+  int first = 0;
+  float* w = nullptr;
+  const float* x_in = nullptr;
+  float* x_out = nullptr;
+  const float* ref = nullptr;
+  double* err_part = nullptr;
+  int err_cap = 0;
+  const double* a2 = nullptr;        // alpha^2 of vk (final)
+  const double* b2 = nullptr;        // beta_next^2 (may still be the operator's pending block partials)
+  const double* beta0_sq = nullptr;
+  double damp = 0.0;
+  const double* st_in = nullptr;
+  double* st_out = nullptr;
+};
+
 // ------------------------------------------------------------------ operator handle
 struct trk_op {
   int kind;  // 1 blur2d, 2 radon2d, 3 deriv2d, 4 spacetime, 5 blockdiag
@@ -255,5 +275,9 @@ struct trk_op {
   const float* probe_vec = nullptr;
   double* probe_part = nullptr;
   int probe_cap = 0, probe_n = 0;
+  // set for the duration of one trk_gk_step_lsqr call: the adjoint half step's output pass carries this update if it can and sets
+  // lsqr_blocks to the number of error partials it wrote (>= 1; 0: not taken — the caller runs trk_lsqr_damped_update itself)
+  LsqrReq lsqr;
+  int lsqr_blocks = 0;
   void* aux = nullptr;   // malloc'ed per-handle cache of a consumer (cgls_tiled.hip: tile geometry + weights); freed with the handle
 };

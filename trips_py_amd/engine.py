@@ -662,6 +662,19 @@ class HipEngine:
                                   self.stream())
         _lib.check(rc, "trk_gk_step")
 
+    def gk_step_lsqr(self, handle, k, u_k, v_prev, v_k, u_next, AB, chained, defer_alpha, defer_beta, w, x_in, x_out, ref, partials,
+                     capacity, damp, state_in, state_out):
+        """gk_step (k >= 1) that also advances damped LSQR's iterate by the step of v_prev (trk_gk_step_lsqr): on the projector the
+        update rides the adjoint half step's pixel pass.  Returns the number of error partials written (0 without `ref`)."""
+        n = ctypes.c_int(0)
+        rc = self.lib.trk_gk_step_lsqr(handle, int(k), u_k.data_ptr(), v_prev.data_ptr(), v_k.data_ptr(), u_next.data_ptr(), AB.base,
+                                       int(bool(chained)), int(bool(defer_alpha)), int(bool(defer_beta)), w.data_ptr(),
+                                       None if x_in is None else x_in.data_ptr(), x_out.data_ptr(),
+                                       None if ref is None else ref.data_ptr(), _ptr(partials), int(capacity), ctypes.byref(n),
+                                       float(damp), _ptr(state_in), _ptr(state_out), self.stream())
+        _lib.check(rc, "trk_gk_step_lsqr")
+        return n.value
+
     def gk_step_proj(self, handle, k, u_k, v_prev, v_k, u_next, AB, chained, defer_alpha, defer_beta, proj, partials, cap):
         """gk_step that also leaves <u_next, proj> as block partials at `partials` (trk_gk_step_proj); returns their count."""
         n = ctypes.c_int(0)

@@ -244,11 +244,12 @@ class GKState:
         if self.native_axpby:
             self.A.flush_deferred()
 
-    def step(self, sync=True, defer=False):
+    def step(self, sync=True, defer=False, lsqr=None):
         """defer=True (with sync=False): beta_{k+1}^2 may stay unfinished inside the operator until the next step or
         `flush()` — for loops that look at AB only at the end (fixed-lambda Hybrid_LSQR without history)."""
         A, eng = self.A, self.eng
         k = self.V.k
+        self.lsqr_taken, self.lsqr_blocks = False, 0
         defer = bool(defer) and not sync
         if self._ab_cap < 2 * k + 3:
             self.flush()
@@ -280,6 +281,11 @@ class GKState:
                     un = self.U.next_slot()
                     if getattr(self, "_proj", None) is not None:
                         self._proj_n = eng.gk_step_proj(A._h, k, u, self.V[k - 1], v, un, AB, self._chained, True, defer, *self._proj)
+                    elif lsqr is not None and k >= 1 and hasattr(eng, "gk_step_lsqr"):
+                        # lsqr = (w, x_in, x_out, ref, partials, capacity, damp, state_in, state_out): damped LSQR's update of the
+                        # iterate that V[k-1] belongs to, carried by this step's adjoint half (trk_gk_step_lsqr)
+                        self.lsqr_blocks = eng.gk_step_lsqr(A._h, k, u, self.V[k - 1], v, un, AB, self._chained, True, defer, *lsqr)
+                        self.lsqr_taken = True
                     else:
                         eng.gk_step(A._h, k, u, None if k == 0 else self.V[k - 1], v, un, AB, self._chained, True, defer)
                     self.V.commit()

@@ -98,6 +98,7 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     if recur:
         lsqr_w, lsqr_x1, lsqr_st = eng.empty(n), eng.empty(n), eng.scalars(8)
         x_prev = None
+        fuse_update = bool(kwargs.get("update_on_the_step", True)) and gk.native_axpby and hasattr(eng, "gk_step_lsqr")
     ub_vec = bv if (isinstance(regparam, str) and regparam == "dp") else None   # the discrepancy principle wants U^T b
     # The Golub-Kahan steps do not depend on lambda: they are enqueued `ahead` steps in front of the iterate the host is choosing
     # lambda for, each followed by the download of its two norms.  One step ahead, the device idled every iteration between the
@@ -152,6 +153,7 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     try:
         for ii in range(n_iter):
             k = ii + 1
+            rode = False
             if on_host:
                 gk.absorb(pending.pop(0))        # alpha_k, beta_{k+1}; the steps behind it run while the host chooses lambda_k
                 while n_enq < n_iter and len(pending) < ahead:
@@ -164,9 +166,21 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
                 # reduction launch is spent on it
                 if gk.V.k < k:
                     gk.step(sync=False, defer=True)
+                rode = False
                 if k < n_iter and (keep or xt is not None):
-                    gk.step(sync=False, defer=True)                      # step k+1 ahead of x_k
-            if recur:
+                    # step k+1 ahead of x_k — and x_k's own update on that step's adjoint half, whose second operand is the V[k-1] the
+                    # update needs (trk_gk_step_lsqr: the iteration is three launches on the projector)
+                    req = None
+                    if recur and fuse_update:
+                        x_dev = lsqr_x1 if ii == 0 else H.row(nx_done)
+                        req = (lsqr_w, x_prev, x_dev, None if ii == 0 else xt,
+                               None if (ii == 0 or xt is None) else EP.ref(1024 * nx_done), 1024, np.sqrt(float(regparam)),
+                               lsqr_st.ref(4 * ((ii + 1) & 1)), lsqr_st.ref(4 * (ii & 1)))
+                    gk.step(sync=False, defer=True, lsqr=req)
+                    rode = req is not None and gk.lsqr_taken
+                    if rode:
+                        got = gk.lsqr_blocks
+            if recur and not rode:
                 # step k of the recurrence (the reference reports no iterate for k = 1, the recurrence needs it all the same);
                 # alpha_k^2 = AB[2k-1] and beta_{k+1}^2 = AB[2k] are final: the step enqueued ahead finished the latter
                 if k == n_iter:
@@ -174,8 +188,9 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
                 x_dev = lsqr_x1 if ii == 0 else H.row(nx_done)
                 got = eng.lsqr_damped_update(gk.V[ii], lsqr_w, x_prev, x_dev, gk.AB.ref(2 * k - 1), gk.AB.ref(2 * k), gk.AB.ref(0),
                                              np.sqrt(float(regparam)), lsqr_st.ref(4 * ((ii + 1) & 1)), lsqr_st.ref(4 * (ii & 1)), ii == 0,
-                                             ref=None if ii == 0 else xt, partials=None if (ii == 0 or xt is None) else EP.ref(n_ep * nx_done),
+                                             ref=None if ii == 0 else xt, partials=None if (ii == 0 or xt is None) else EP.ref(1024 * nx_done),
                                              capacity=1024)
+            if recur:
                 x_prev = x_dev
                 if ii == 0:
                     lam = 0
@@ -244,7 +259,9 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             "relResidual": [], "its": n_iter - 1}
     if xt is not None:
         if err_fused:
-            eng.finalize_batched(EP.ref(0), n_ep, 1, nx_done, E.ref(1), 1)
+            # (the recurrence's iterates come from two kernels with different partial counts — the adjoint's tiles or the update's own
+            #  grid: each iterate owns 1024 zero-initialised places, all of them are summed)
+            eng.finalize_batched(EP.ref(0), 1024 if recur else n_ep, 1, nx_done, E.ref(1), 1)
         eng.allreduce(E, 1, nx_done + 1)
         e = E.host(0, nx_done + 1)
         info["relError"] = list(np.sqrt(e[1:] / e[0]))
