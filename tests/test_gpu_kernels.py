@@ -195,7 +195,9 @@ def test_gemv_t_with_one_more_row(eng, k, n):
     assert np.allclose(got[k + 1:2 * k + 1], got[:k], rtol=1e-13, atol=1e-13 * n ** 0.5)
 
 
-@pytest.mark.parametrize("N,k", [(32, 1), (32, 5), (64, 16), (64, 17), (96, 7), (96, 32), (160, 33), (128, 48), (512, 20), (1024, 3)])
+@pytest.mark.parametrize("N,k", [(32, 1), (32, 5), (64, 16), (64, 17), (96, 7), (96, 32), (160, 33), (128, 48), (512, 20), (1024, 3),
+                                 # a multiple of four strips: the workgroup's waves in step, the right-neighbour column through LDS
+                                 (128, 16), (256, 13), (384, 30), (256, 25)])
 def test_wgram_tv_from_v_equals_the_gram_of_the_stored_images(eng, N, k):
     """trk_wgram_tv (the weighted Gram of L V formed from V, L the 2-D first difference) against (i) the float64 definition on the
     oracle's L and (ii) trk_wgram over the stored images L v_j: all tile counts, bands that do not divide N, the image's right

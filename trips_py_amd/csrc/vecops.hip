@@ -1439,10 +1439,17 @@ struct TvRow {
 template <int T, bool Z, int D>
 __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 2)) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
                                                     const float* __restrict__ w, int nbands, int band_rows,
-                                                    double* __restrict__ partials, const float* __restrict__ z) {
+                                                    double* __restrict__ partials, const float* __restrict__ z, int lockstep) {
   constexpr int NP = T * (T + 1) / 2;
   __shared__ double red[3][4][64];
   __shared__ __attribute__((aligned(16))) float wl[NT / 64][Z ? 96 : 64];
+  // lockstep (the launcher's choice when the workgroup's four waves always own four neighbouring strips of one band): the pixel
+  // right of a strip is the first pixel of the next wave's strip, which that wave holds in registers — it is handed over through
+  // LDS, one row ahead, behind the one barrier per image row that keeps the four waves together.  Only the workgroup's last wave
+  // still fetches its neighbour column from memory.  (Every wave fetching it cost 25-40 % more HBM traffic than the operands: the
+  // column is a sector of a line that the neighbouring strip's wave fetches again at some other time;
+  // profiles/r03/traffic_bench_c4.txt.)
+  __shared__ float nxs[2][NT / 64][T][16];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, r = lane & 15, sl = lane >> 4;
   const float* __restrict__ wh = w;
   const float* __restrict__ wv = w + (int64_t)N * (N - 1);
@@ -1473,6 +1480,7 @@ __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 
     const int c0 = cs + 8 * sl;
     const bool last_strip = cs + 32 >= N;                        // (uniform) no pixel right of this strip
     const int nxo = last_strip ? 31 : 32;                        // clamped: a valid address, met by a zero weight
+    const bool need_nx = !lockstep || wave == NT / 64 - 1;       // (uniform per wave)
 
     // every load is unconditional (clamped addresses, zeroed weights instead of branches): all loads of a row are in flight together
     auto load = [&](TvRow<T>& P, int i) {
@@ -1485,10 +1493,27 @@ __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 
       for (int t = 0; t < T; ++t) {
         P.x[t][0] = *reinterpret_cast<const float4*>(rowp[t] + e + c0);
         P.x[t][1] = *reinterpret_cast<const float4*>(rowp[t] + e + c0 + 4);
-        P.nx[t] = rowp[t][e + cs + nxo];
+        P.nx[t] = need_nx ? rowp[t][e + cs + nxo] : 0.f;
+      }
+    };
+    auto publish = [&](const TvRow<T>& R, int i) {               // this wave's first pixel column of image row i, for the wave to its left
+      if (lane < 16) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) nxs[i & 1][wave][t][lane] = R.x[t][0].x;
       }
     };
     auto step = [&](const TvRow<T>& P, const TvRow<T>& Q, int i) {   // P: image row i, Q: the one below
+      float nbr[T];
+#pragma unroll
+      for (int t = 0; t < T; ++t) nbr[t] = P.nx[t];
+      if (lockstep) {                                            // (uniform)
+        __syncthreads();                                         // row i's columns are published; everybody has left row i - 1
+        publish(Q, i + 1);
+        if (wave < NT / 64 - 1) {
+#pragma unroll
+          for (int t = 0; t < T; ++t) nbr[t] = nxs[i & 1][wave + 1][t][r];
+        }
+      }
       // this row's weights to the lanes: h at my[0..31], v at my[32..63]
       float wk = P.w;
       if (lane == 31 && last_strip) wk = 0.f;                    // column N - 1 has no right neighbour
@@ -1524,7 +1549,7 @@ __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 
         const float4 a = P.x[t][0], b = P.x[t][1], c = Q.x[t][0], d = Q.x[t][1];
         // the pixel right of this lane's eight: lane l + 16 holds it as its first, the last quarter takes the next strip's
         float right = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(up16, __builtin_bit_cast(int, a.x)));
-        right = sl == 3 ? P.nx[t] : right;
+        right = sl == 3 ? nbr[t] : right;
         dh[t][0] = (a.x - a.y) * wh0.x;
         dh[t][1] = (a.y - a.z) * wh0.y;
         dh[t][2] = (a.z - a.w) * wh0.z;
@@ -1562,6 +1587,10 @@ __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 
     TvRow<T> P[D];                                               // a ring: row i sits in P[(i - i0) % D]; indices are compile-time below
 #pragma unroll
     for (int j = 0; j < D - 1; ++j) load(P[j], i0 + j);
+    if (lockstep) {
+      __syncthreads();                                           // the previous unit's last exchange has been read
+      publish(P[0], i0);
+    }
     int i = i0;
     for (; i + D <= i1; i += D) {                                // roles rotate: no register copies
 #pragma unroll
@@ -2063,14 +2092,21 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   hipStream_t s = (hipStream_t)st;
   const int T16 = (k + 15) / 16;
   static const int pc_env = env_int("TRK_WGRAM_TV_PER_CU", 0);
-  // workgroups per CU: what the register budget lets be resident (94 / 160 / 248 VGPRs: 4 / 3 / 2) while the matrix pipe is the
-  // bound, FEWER once the rows' traffic is (k near the top of a tile count): measured at 4096^2, k = 16: 344 / 330 / 319 us with
-  // 4 / 2 / 1 workgroups per CU, k = 32: 762 / 744 / 683 — more waves in flight means more row streams open at once
-  // (with the dots of trk_wgram_tv_z the optimum is flatter: 3 until k = 29 at two tiles)
-  const int per_cu = pc_env > 0 ? pc_env
-                   : z ? (T16 == 1 ? (k <= 14 ? 3 : 2) : T16 == 2 ? (k <= 29 ? 2 : 1) : 2)
-                       : (T16 == 1 ? (k <= 11 ? 4 : k <= 14 ? 2 : 1) : T16 == 2 ? (k <= 25 ? 3 : 1) : 2);
   const int strips = N / 32;
+  // The four waves of a workgroup in step (see the kernel: the right-neighbour column handed over through LDS instead of fetched
+  // again — 25-40 % less HBM traffic, one barrier per image row): pays where the rows' traffic is the bound.  Measured at 4096^2
+  // (tools/wgram_tv_micro.py; us, lockstep vs not): plain, two tiles k = 20 / 32: 507 / 620 vs 592 / 831; one tile k = 16: 308 vs
+  // 366, k <= 10 equal; with the dots of _z (218 registers, two workgroups per CU at two tiles): k = 18 / 26 / 32: 640 / 649 / 676 vs
+  // 598 / 666 / 791 — from k = 25 on.
+  static const int ls_env = env_int("TRK_WGRAM_TV_LOCKSTEP", -1);
+  const bool ls_pays = T16 == 1 ? k >= 12 : T16 == 2 ? (z ? k >= 25 : true) : false;
+  const int lock = (strips % (NT / 64) == 0 && (ls_env < 0 ? ls_pays : ls_env != 0)) ? 1 : 0;
+  // workgroups per CU: what the registers let be resident while the matrix pipe is the bound; without the lockstep exchange fewer
+  // once the rows' traffic is (k = 32 plain: 762 / 744 / 683 us with 4 / 2 / 1 — more waves, more row streams open at once)
+  const int per_cu = pc_env > 0 ? pc_env
+                   : lock ? (z ? (T16 == 1 ? 3 : 2) : 3)
+                   : z ? (T16 == 1 ? 3 : T16 == 2 ? 2 : 2)
+                       : (T16 == 1 ? (k <= 11 ? 4 : k <= 14 ? 2 : 1) : T16 == 2 ? (k <= 25 ? 3 : 1) : 2);
   int bx = cu_count() * per_cu;
   // (strip, band) units, band-major: the waves in flight together then work on a few neighbouring image rows of every basis vector
   static const int band_env = env_int("TRK_WGRAM_TV_BAND", 64);
@@ -2081,7 +2117,7 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   double* part = nullptr;
   const int nv = k * k + (z ? k : 0);
   if (int rc = scratch_doubles(s, (size_t)bx * nv, &part)) return rc;
-#define WTV(TT, ZZ) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z)
+#define WTV(TT, ZZ) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock)
   if (z && T16 == 3) {
     // three tiles AND the dots do not fit the register file (108 spilled registers): two passes for 33 <= k <= 48
     WTV(3, false);
