@@ -538,11 +538,24 @@ int tiled_geom(trk_op* A, TiledGeom* g, int* ntiles) {
 
 extern "C" {
 
+// the tile geometry of a handle (two small device-to-host copies: blocking) once per handle, kept in A->aux; ntiles = 0 records
+// "not a separable blur <= 9 x 9 on an image >= 16 x 16" so that the question is not asked of the device again either
+struct TiledCache { TiledGeom g; int ntiles; };
+static const TiledCache* tiled_cache(trk_op* A) {
+  if (!A->aux) {
+    TiledCache c{};
+    if (!tiled_geom(A, &c.g, &c.ntiles)) c.ntiles = 0;
+    A->aux = malloc(sizeof(TiledCache));
+    if (!A->aux) return nullptr;
+    memcpy(A->aux, &c, sizeof(TiledCache));
+  }
+  return static_cast<const TiledCache*>(A->aux);
+}
+
 int trk_cgls_tiled_caps(trk_op* A, int np_capacity_blocks, int pcap, int* can) {
   TRK_REQUIRE(A && can, "trk_cgls_tiled_caps: NULL argument");
-  TiledGeom g;
-  int ntiles = 0;
-  *can = (tiled_geom(A, &g, &ntiles) && ntiles <= np_capacity_blocks && ntiles <= pcap) ? 1 : 0;
+  const TiledCache* c = tiled_cache(A);                    // (asked by every CGLS() call: must not touch the device after the first)
+  *can = (c && c->ntiles > 0 && c->ntiles <= np_capacity_blocks && c->ntiles <= pcap) ? 1 : 0;
   return TRK_OK;
 }
 
@@ -553,16 +566,11 @@ int trk_cgls_iterate_tiled(trk_op* A, int k_first, int n_iters, float* P, int64_
   TRK_REQUIRE(A && P && R && t && X && x_prev && S && PG && PD && NP && n_g_inout && n_np_inout,
               "trk_cgls_iterate_tiled: NULL argument");
   TRK_REQUIRE(k_first >= 1 && n_iters >= 0, "trk_cgls_iterate_tiled: need k_first >= 1, n_iters >= 0");
-  struct Cache { TiledGeom g; int ntiles; };                // the geometry (two small device-to-host copies) once per handle
-  if (!A->aux) {
-    Cache c;
-    if (!tiled_geom(A, &c.g, &c.ntiles)) return fail(TRK_EUNSUPPORTED, "trk_cgls_iterate_tiled: needs a separable blur <= 9x9 on an image >= 16x16");
-    A->aux = malloc(sizeof(Cache));
-    if (!A->aux) return fail(TRK_ENOMEM, "trk_cgls_iterate_tiled: out of memory");
-    memcpy(A->aux, &c, sizeof(Cache));
-  }
-  const TiledGeom g = static_cast<Cache*>(A->aux)->g;
-  const int ntiles = static_cast<Cache*>(A->aux)->ntiles;
+  const TiledCache* tc = tiled_cache(A);
+  if (!tc) return fail(TRK_ENOMEM, "trk_cgls_iterate_tiled: out of memory");
+  if (tc->ntiles <= 0) return fail(TRK_EUNSUPPORTED, "trk_cgls_iterate_tiled: needs a separable blur <= 9x9 on an image >= 16x16");
+  const TiledGeom g = tc->g;
+  const int ntiles = tc->ntiles;
   TRK_REQUIRE(ntiles <= np_capacity_blocks && ntiles <= pcap, "trk_cgls_iterate_tiled: %d tiles exceed the partial buffers", ntiles);
   hipStream_t s = (hipStream_t)stream;
   int n_g = *n_g_inout;
@@ -598,16 +606,11 @@ int trk_cgls_iterate_tiled2(trk_op* A, int k_first, int n_iters, float* p, float
   TRK_REQUIRE(A && p && w && R && t && X && x_prev && S && PG && PD && NP && n_g_inout && n_np_inout,
               "trk_cgls_iterate_tiled2: NULL argument");
   TRK_REQUIRE(k_first >= 1 && n_iters >= 0, "trk_cgls_iterate_tiled2: need k_first >= 1, n_iters >= 0");
-  struct Cache { TiledGeom g; int ntiles; };
-  if (!A->aux) {
-    Cache c;
-    if (!tiled_geom(A, &c.g, &c.ntiles)) return fail(TRK_EUNSUPPORTED, "trk_cgls_iterate_tiled2: needs a separable blur <= 9x9 on an image >= 16x16");
-    A->aux = malloc(sizeof(Cache));
-    if (!A->aux) return fail(TRK_ENOMEM, "trk_cgls_iterate_tiled2: out of memory");
-    memcpy(A->aux, &c, sizeof(Cache));
-  }
-  const TiledGeom g = static_cast<Cache*>(A->aux)->g;
-  const int ntiles = static_cast<Cache*>(A->aux)->ntiles;
+  const TiledCache* tc = tiled_cache(A);
+  if (!tc) return fail(TRK_ENOMEM, "trk_cgls_iterate_tiled2: out of memory");
+  if (tc->ntiles <= 0) return fail(TRK_EUNSUPPORTED, "trk_cgls_iterate_tiled2: needs a separable blur <= 9x9 on an image >= 16x16");
+  const TiledGeom g = tc->g;
+  const int ntiles = tc->ntiles;
   TRK_REQUIRE(ntiles <= np_capacity_blocks && ntiles <= pcap, "trk_cgls_iterate_tiled2: %d tiles exceed the partial buffers", ntiles);
   hipStream_t s = (hipStream_t)stream;
   int n_g = *n_g_inout;

@@ -277,6 +277,10 @@ class HipEngine:
     def scalars(self, n):
         return DevScalars(torch.zeros(int(n), dtype=torch.float64, device=self.device), self)
 
+    def scalars_uninit(self, n):
+        """A block every entry of which is written before it is read (block partials): no zero-fill launch."""
+        return DevScalars(torch.empty(int(n), dtype=torch.float64, device=self.device), self)
+
     def _mailbox_take(self, cap, slots):
         """A trk_mailbox of `cap` doubles from the pool (created on demand), with the NumPy view of its pinned block."""
         pool = self.__dict__.setdefault("_mailbox_pool", {})

@@ -352,12 +352,14 @@ class CGLSRunFused(CGLSRun):
         self.X = self.hist.X
         self.R = eng.empty_basis(2, m)     # r ping-pong
         self.P = eng.empty_basis(2, n)     # p ping-pong
-        self.P.zero_()                     # the first K1 multiplies p_old by 0: it must be finite
+        if self.tiled != 2:                # (the two-blur tiled form does not read p or w in its first iteration)
+            self.P.zero_()                 # the first K1 multiplies p_old by 0: it must be finite
         self.t, self.w = eng.empty(n), eng.empty(m)
         self.S = S = eng.scalars(5 * (max_iter + 1))
-        self.PG = eng.scalars(self.PCAP)   # ||t||^2 partials (gamma)
-        self.PD = eng.scalars(self.PCAP)   # ||w||^2 partials (delta)
-        self.NP = eng.scalars(3 * 1024 * max_iter)   # norm partials of every iteration, summed once at the end
+        uninit = getattr(eng, "scalars_uninit", eng.scalars)
+        self.PG = uninit(self.PCAP)        # ||t||^2 partials (gamma): the counted entries are written before they are read
+        self.PD = uninit(self.PCAP)        # ||w||^2 partials (delta)
+        self.NP = uninit(3 * 1024 * max_iter)        # norm partials of every iteration, summed once at the end
         self.dist = False
         self.k = 0
         self.n_g = self.n_np = 0
