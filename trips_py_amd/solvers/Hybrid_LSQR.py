@@ -16,6 +16,12 @@ from ..reg_param.gcv import fminbound_gcv_diag, fminbound_gcv_bidiag
 from ._common import check_delta, choose_lambda, small_host_blas
 
 
+import atexit
+import threading
+
+_SEARCHER_LOCK = threading.Lock()
+
+
 class _Searcher:
     """The library's worker thread for the lambda searches (trk_host_worker_*): post copies B_k's entries and returns, collect
     waits for the result.  One per solve."""
@@ -52,6 +58,28 @@ class _Searcher:
         h, self.h = self.h, None
         if h:
             self.lib.trk_host_worker_destroy(h)
+
+    # a solve borrows a worker and hands it back: creating and joining a thread per solve was ~0.1 ms of a 7 ms solve
+    _idle = []
+    _idle_max = 4
+
+    @classmethod
+    def borrow(cls, lib):
+        with _SEARCHER_LOCK:
+            while cls._idle:
+                w = cls._idle.pop()
+                if w.h and w.lib is lib:
+                    return w
+        return cls(lib)
+
+    def give_back(self):
+        """After a clean solve (nothing posted and not collected); anything else: close()."""
+        with _SEARCHER_LOCK:
+            keep = bool(self.h) and len(_Searcher._idle) < _Searcher._idle_max
+            if keep:
+                _Searcher._idle.append(self)
+        if not keep:
+            self.close()
 
 
 @small_host_blas(when=lambda rp: rp == "l_curve")
@@ -114,8 +142,9 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     searcher = None
     if (on_host and regparam in ("gcv", "dp") and kwargs.get("async_search", True) and hasattr(eng, "lib")
             and not kwargs.get("gcv_by_svd", False) and not kwargs.get("dp_by_svd", False) and n_iter > 2):
-        searcher = _Searcher(eng.lib)
+        searcher = _Searcher.borrow(eng.lib)
     waiting = None                           # the step whose lambda the worker is looking for
+    clean = False
 
     def form_iterate(k, lam):
         nonlocal nx_done, n_ep, x_dev
@@ -249,9 +278,13 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         if waiting is not None:
             lam = searcher.collect()
             form_iterate(waiting, lam)
+        clean = True
     finally:
         if searcher is not None:
-            searcher.close()
+            if clean:
+                searcher.give_back()
+            else:
+                searcher.close()             # (a job may still be posted: destroy waits for it)
     if x_dev is None:
         raise UnboundLocalError("Hybrid_LSQR with n_iter < 2 forms no iterate (the reference fails the same way, "
                                 "Hybrid_LSQR.py:114)")
@@ -266,3 +299,14 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         e = E.host(0, nx_done + 1)
         info["relError"] = list(np.sqrt(e[1:] / e[0]))
     return fmt.vec(x_dev), info
+
+
+@atexit.register
+def _close_idle_searchers():
+    with _SEARCHER_LOCK:
+        idle, _Searcher._idle = _Searcher._idle, []
+    for w in idle:
+        try:
+            w.close()
+        except Exception:      # noqa: BLE001  (interpreter shutdown)
+            pass
