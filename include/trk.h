@@ -229,7 +229,7 @@ int trk_gk_step(trk_op* op, int k, const float* u_k, const float* v_prev, float*
  * trk_lsqr_damped_update with vk = v_prev, alpha_sq = AB[2k-1], beta_next_sq = AB[2k], beta0_sq = AB[0], first = (k == 1)): on the
  * projector the update rides the adjoint half step's own pixel pass — v_prev is that pass's second operand — so a fixed-lambda
  * Hybrid-LSQR iteration (Hybrid_LSQR.py:69-110) is three launches; any other operator gets the step followed by
- * trk_lsqr_damped_update.  *n_blocks: error partials written (ref != NULL). */
+ * trk_lsqr_damped_update.  *n_blocks: error partials written (ref != NULL).  One trk_gk_step* call at a time per handle. */
 int trk_gk_step_lsqr(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
                      int defer_alpha, int defer_beta, float* w, const float* x_in, float* x_out, const float* ref,
                      double* err_partials, int capacity_blocks, int* n_blocks, double damp, const double* state_in,
@@ -237,7 +237,8 @@ int trk_gk_step_lsqr(trk_op* op, int k, const float* u_k, const float* v_prev, f
 /* trk_gk_step that also leaves <u_next, proj> (proj: op rows floats — the discrepancy principle's U^T b, one new row per step,
  * discrepancy_principle.py:58) as *n_partials (<= cap) block partials in `partials`: the projector's band reduction forms them
  * next to the norm it already carries (no pass over u_next, no reduction launch; trk_mailbox_post_sum adds them up on their
- * way to the host); operators without such a pass get one finished value from trk_dot (*n_partials = 1). */
+ * way to the host); operators without such a pass get one finished value from trk_dot (*n_partials = 1).  Like the deferred norms of
+ * trk_op_apply_axpby, the request travels in the handle for the duration of the call: one trk_gk_step* call at a time per handle. */
 int trk_gk_step_proj(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
                      int defer_alpha, int defer_beta, const float* proj, double* partials, int cap, int* n_partials,
                      trk_stream stream);
