@@ -225,6 +225,16 @@ int trk_mailbox_post_sum(trk_mailbox* mb, int slot, const double* src_dev, int o
  * (single rank: the next chained apply finishes them). */
 int trk_gk_step(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
                 int defer_alpha, int defer_beta, trk_stream stream);
+/* trk_gk_step (optionally with the projection of trk_gk_step_proj: proj != NULL) that also carries a mailbox post — the copy of
+ * `count` (<= 8) device doubles src_dev[0..count) to host[offset ..] of `mb`, optionally the sum of n_sum block partials to *sum_dev and
+ * host[sum_offset], and the publication of `slot` (trk_mailbox_post / trk_mailbox_post_sum): on the projector the first workgroup of
+ * the adjoint half step does it, where the norms of the PREVIOUS step are final (the deferred one is finished by that very
+ * kernel) — the hybrid solvers' per-step download of B_k's new entries (Hybrid_LSQR.py:69-75) without a launch of its own.  Other
+ * operators: the step, then the post in its own launch.  trk_mailbox_wait(mb, slot) as usual. */
+int trk_gk_step_post(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
+                     int defer_alpha, int defer_beta, const float* proj, double* proj_partials, int proj_cap, int* n_proj,
+                     trk_mailbox* mb, int slot, const double* src_dev, int offset, int count, const double* sum_partials,
+                     int n_sum, double* sum_dev, int sum_offset, trk_stream stream);
 /* trk_gk_step for k >= 1 that also advances damped LSQR's iterate by the step belonging to v_prev = V[k-1] (the arguments of
  * trk_lsqr_damped_update with vk = v_prev, alpha_sq = AB[2k-1], beta_next_sq = AB[2k], beta0_sq = AB[0], first = (k == 1)): on the
  * projector the update rides the adjoint half step's own pixel pass — v_prev is that pass's second operand — so a fixed-lambda

@@ -521,8 +521,11 @@ def test_gk_projection_rides_the_forward_pass_and_the_post(kind):
     dev = A.engine.device
     b = torch.randn(m, device=dev, generator=torch.Generator(device=dev).manual_seed(5)).abs()
     steps = 9
-    for ahead in (1, 3):
+    seen = {}
+    for ahead, riders in ((1, True), (3, True), (3, False)):
+        # riders: the post of a step's norms carried by the next step's adjoint kernel (trk_gk_step_post) or launched on its own
         gk = GKState(A, b, steps, normalized=False)
+        gk.rider_posts = riders
         pending, n_enq = [], 0
         for k in range(steps):
             while n_enq < steps and len(pending) < ahead:
@@ -540,6 +543,8 @@ def test_gk_projection_rides_the_forward_pass_and_the_post(kind):
         if kind != "blur":
             assert gk._UP is not None                               # the merged path ran
             assert np.array_equal(gk.AB.host(gk._uoff + 2, gk._uoff + steps + 1), np.asarray(gk.uproj[2:]))
+        seen[(ahead, riders)] = (list(gk._alphas), list(gk._betas), list(gk.uproj), gk.beta0)
+    assert seen[(3, True)] == seen[(3, False)] == seen[(1, True)]   # the same numbers whichever way they travelled
 
 
 @pytest.mark.parametrize("k", [1, 5, 128, 129, 300])

@@ -226,6 +226,9 @@ SIGNATURES = {
     "trk_mailbox_post": (c_int, [ctypes.c_void_p, c_int, c_f64p, c_int, c_int, c_stream]),
     "trk_mailbox_wait": (c_int, [ctypes.c_void_p, c_int]),
     "trk_mailbox_post_sum": (c_int, [ctypes.c_void_p, c_int, c_f64p, c_int, c_int, c_f64p, c_int, c_f64p, c_int, c_stream]),
+    "trk_gk_step_post": (c_int, [c_op, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_f32p, c_f64p, c_int,
+                                 ctypes.POINTER(c_int), ctypes.c_void_p, c_int, c_f64p, c_int, c_int, c_f64p, c_int, c_f64p, c_int,
+                                 c_stream]),
     "trk_gk_step_lsqr": (c_int, [c_op, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_f32p, c_f32p, c_f32p, c_f32p,
                                  c_f64p, c_int, ctypes.POINTER(c_int), c_dbl, c_f64p, c_f64p, c_stream]),
     "trk_gk_step_proj": (c_int, [c_op, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_f32p, c_f64p, c_int,

@@ -516,6 +516,63 @@ int trk_gk_step_proj(trk_op* op, int k, const float* u_k, const float* v_prev, f
   return TRK_OK;
 }
 
+int trk_gk_step_post(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
+                     int defer_alpha, int defer_beta, const float* proj, double* proj_partials, int proj_cap, int* n_proj,
+                     trk_mailbox* mb, int slot, const double* src_dev, int offset, int count, const double* sum_partials,
+                     int n_sum, double* sum_dev, int sum_offset, trk_stream stream) {
+  TRK_REQUIRE(op && mb && src_dev && slot >= 0 && slot < mb->slots, "trk_gk_step_post: bad mailbox / slot / NULL argument");
+  TRK_REQUIRE(offset >= 0 && count > 0 && count <= 8 && offset + count <= mb->n, "trk_gk_step_post: 1..8 doubles inside the mailbox");
+  TRK_REQUIRE(!sum_partials || (n_sum >= 1 && sum_dev && sum_offset >= 0 && sum_offset < mb->n &&
+                                (sum_offset < offset || sum_offset >= offset + count)),
+              "trk_gk_step_post: the sum needs partials, a device place and a mailbox place outside the copied range");
+  TRK_REQUIRE(!proj || (proj_partials && n_proj && proj_cap >= 1), "trk_gk_step_post: proj given but no room for its partials");
+  mb->expect[slot] = ++mb->counter;
+  mb->stream[slot] = (hipStream_t)stream;
+  PostReq q;
+  q.on = 1;
+  q.src = src_dev;
+  q.dst = mb->host + offset;
+  q.count = count;
+  q.part = sum_partials;
+  q.n_part = sum_partials ? n_sum : 0;
+  q.sum_dev = sum_dev;
+  q.sum_host = sum_partials ? mb->host + sum_offset : nullptr;
+  q.seq = mb->seq + slot;
+  q.value = mb->expect[slot];
+  op->post = q;
+  op->post_taken = 0;
+  if (proj) {
+    op->probe_vec = proj;
+    op->probe_part = proj_partials;
+    op->probe_cap = proj_cap;
+    op->probe_n = 0;
+  }
+  const int rc = trk_gk_step(op, k, u_k, v_prev, v_k, u_next, AB, chained, defer_alpha, defer_beta, stream);
+  const int taken = op->post_taken, np = op->probe_n;
+  op->post = PostReq{};
+  op->post_taken = 0;
+  op->probe_vec = nullptr;
+  op->probe_part = nullptr;
+  op->probe_cap = op->probe_n = 0;
+  if (rc) return rc;
+  if (proj) {
+    *n_proj = np;
+    if (np == 0) {
+      *n_proj = 1;
+      if (int rc2 = trk_dot(u_next, proj, op->rows, proj_partials, stream)) return rc2;
+    }
+  }
+  if (!taken) {                        // no kernel of this operator carries posts: the post in its own launch, behind the step
+    if (sum_partials)
+      hipLaunchKernelGGL(k_mailbox_post_sum, dim3(1), dim3(64), 0, (hipStream_t)stream, src_dev, q.dst, count, sum_partials, n_sum,
+                         sum_dev, q.sum_host, q.seq, q.value);
+    else
+      hipLaunchKernelGGL(k_mailbox_post, dim3(1), dim3(64), 0, (hipStream_t)stream, src_dev, q.dst, count, q.seq, q.value);
+    TRK_LAUNCH_CHECK();
+  }
+  return TRK_OK;
+}
+
 int trk_gk_step_lsqr(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
                      int defer_alpha, int defer_beta, float* w, const float* x_in, float* x_out, const float* ref,
                      double* err_partials, int capacity_blocks, int* n_blocks, double damp, const double* state_in,

@@ -109,6 +109,8 @@ struct Epi {
   double* dot_part;
   // adjoint only (trk_gk_step_lsqr): the damped-LSQR update whose vk is this epilogue's z
   LsqrReq lq;
+  // adjoint only (trk_gk_step_post): a mailbox post carried by workgroup 0
+  PostReq pq;
 };
 
 // the sum of the pending partials — the same bits in every workgroup (one wave, fixed order) — in all threads
@@ -1120,6 +1122,25 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
     q = block_sum<256>(q, lds);
     if (tid == 0) ssq_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = q;
   }
+  if (epi.pq.on && blockIdx.x == 0 && blockIdx.y == 0 && tid < 64) {
+    // the mailbox post of the step before (k_mailbox_post / k_mailbox_post_sum, core.hip): its scalars are final here — the
+    // deferred one is `pend_sum`, which this workgroup has just stored — and the host polls the sequence word
+    const PostReq& Q = epi.pq;
+    double sum = 0.0;
+    if (Q.part) sum = scalar_from_wave(ScalarSrc{Q.part, Q.n_part}, tid);
+    if (tid == 0) {
+      for (int c = 0; c < Q.count; ++c) {
+        const double* sp = Q.src + c;
+        Q.dst[c] = (epi.pend_target && sp == epi.pend_target) ? pend_sum : *sp;
+      }
+      if (Q.part) {
+        *Q.sum_dev = sum;
+        *Q.sum_host = sum;
+      }
+      __threadfence_system();
+      __hip_atomic_store(Q.seq, Q.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
   if (epi.lq.on) {                                                // uniform over the grid
     // the damped-LSQR step of the iterate that z = V[k-1] belongs to, on this workgroup's pixels: k_lsqr_damped_update's
     // arithmetic, expression for expression (vecops.hip) — the same floats whichever kernel forms them
@@ -1300,6 +1321,11 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   const bool fuse_ssq = sumsq && batch == 1 && (tr ? tile : post);
   const int64_t post_blocks = ceil_div((int64_t)nt * na * ndp, 256);
   const int64_t n_part = tr ? adj_blocks * nt : post_blocks;
+  epi.pq = PostReq{};
+  if (tr && tile && batch == 1 && epi.on && op->post.on) {
+    epi.pq = op->post;                         // trk_gk_step_post: the mailbox post on the adjoint kernel's first workgroup
+    op->post_taken = 1;
+  }
   epi.lq = LsqrReq{};
   if (tr && tile && batch == 1 && epi.on && epi.z && op->lsqr.on && (!op->lsqr.ref || n_part <= op->lsqr.err_cap)) {
     epi.lq = op->lsqr;                         // trk_gk_step_lsqr: the iterate's update on the adjoint's pixel pass (z = its vk)

@@ -249,6 +249,22 @@ struct LsqrReq {
   double* st_out = nullptr;
 };
 
+// A mailbox post (trk_mailbox_post / _post_sum) as a rider on another kernel: workgroup 0 of a Golub-Kahan adjoint half step copies
+// the scalars the host is waiting for and publishes the slot's sequence number itself (trk_gk_step_post) — the norms of the step
+// before are final exactly there (the adjoint's epilogue finishes the deferred one), so the post needs no launch of its own.
+struct PostReq {
+  int on = 0;
+  const double* src = nullptr;        // device doubles to copy ...
+  double* dst = nullptr;              // ... into pinned host memory (device-visible)
+  int count = 0;
+  const double* part = nullptr;       // optional: n_part block partials, their sum to *sum_dev and *sum_host
+  int n_part = 0;
+  double* sum_dev = nullptr;
+  double* sum_host = nullptr;
+  unsigned long long* seq = nullptr;  // the slot's sequence word (pinned host memory) and the number to publish
+  unsigned long long value = 0;
+};
+
 // ------------------------------------------------------------------ operator handle
 struct trk_op {
   int kind;  // 1 blur2d, 2 radon2d, 3 deriv2d, 4 spacetime, 5 blockdiag
@@ -279,5 +295,8 @@ struct trk_op {
   // lsqr_blocks to the number of error partials it wrote (>= 1; 0: not taken — the caller runs trk_lsqr_damped_update itself)
   LsqrReq lsqr;
   int lsqr_blocks = 0;
+  // likewise for one trk_gk_step_post call: post_taken = 1 when the adjoint half step's kernel carries the post
+  PostReq post;
+  int post_taken = 0;
   void* aux = nullptr;   // malloc'ed per-handle cache of a consumer (cgls_tiled.hip: tile geometry + weights); freed with the handle
 };

@@ -118,6 +118,21 @@ class DevScalars:
                                                 self.base + 8 * at, int(at), eng.stream()), "trk_mailbox_post_sum")
         return (_Posted(eng.lib, self._mb, slot, self._mb_np, i, j, self), _Posted(eng.lib, self._mb, slot, self._mb_np, at, at + 1, self))
 
+    def rider_post(self, i, j, partials=None, n_partials=0, at=None):
+        """The arguments of a post of scalars [i, j) (and, with `partials`, of their sum as scalar `at`) that a kernel is to carry
+        (trk_gk_step_post), and the handles to collect it with: ((mailbox, slot, src, offset, count, partials, n, sum_dev,
+        sum_offset), range handle, sum handle or None)."""
+        eng = self._eng
+        if self._mb is None:
+            self.host_later(i, j).get()        # (creates the mailbox; the extra post only on the first call)
+        slot = self._mb_slot
+        self._mb_slot = (slot + 1) % self.MAILBOX_SLOTS
+        args = (self._mb, slot, self.base + 8 * i, int(i), int(j - i), _ptr(partials), int(n_partials),
+                None if at is None else self.base + 8 * at, 0 if at is None else int(at))
+        h = _Posted(eng.lib, self._mb, slot, self._mb_np, i, j, self)
+        hs = None if at is None else _Posted(eng.lib, self._mb, slot, self._mb_np, at, at + 1, self)
+        return args, h, hs
+
     def set(self, i, values):
         a = np.ascontiguousarray(np.atleast_1d(np.asarray(values, dtype=np.float64)).reshape(-1))
         eng = self._eng
@@ -677,6 +692,18 @@ class HipEngine:
                                        None if ref is None else ref.data_ptr(), _ptr(partials), int(capacity), ctypes.byref(n),
                                        float(damp), _ptr(state_in), _ptr(state_out), self.stream())
         _lib.check(rc, "trk_gk_step_lsqr")
+        return n.value
+
+    def gk_step_post(self, handle, k, u_k, v_prev, v_k, u_next, AB, chained, defer_alpha, defer_beta, post, proj=None):
+        """gk_step (k >= 1) whose adjoint half carries the mailbox post `post` (DevScalars.rider_post()[0]) — trk_gk_step_post; with
+        proj = (vector, partials, capacity) also the projection of gk_step_proj, whose partial count is returned (else 0)."""
+        n = ctypes.c_int(0)
+        pv, pp, pc = (None, None, 0) if proj is None else (proj[0].data_ptr(), _ptr(proj[1]), int(proj[2]))
+        mb, slot, src, off, cnt, sp, sn, sd, so = post
+        rc = self.lib.trk_gk_step_post(handle, int(k), u_k.data_ptr(), v_prev.data_ptr(), v_k.data_ptr(), u_next.data_ptr(), AB.base,
+                                       int(bool(chained)), int(bool(defer_alpha)), int(bool(defer_beta)), pv, pp, pc, ctypes.byref(n),
+                                       mb, int(slot), src, int(off), int(cnt), sp, int(sn), sd, int(so), self.stream())
+        _lib.check(rc, "trk_gk_step_post")
         return n.value
 
     def gk_step_proj(self, handle, k, u_k, v_prev, v_k, u_next, AB, chained, defer_alpha, defer_beta, proj, partials, cap):

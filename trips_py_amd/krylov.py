@@ -83,6 +83,7 @@ class GKState:
         self._chained = False                   # U[k] came out of this state's previous fused forward apply
         self._UB, self.uproj = None, None       # U^T b, one entry per row of U (step_prefetch(project=b))
         self._late, self._posted_any = None, False   # step_prefetch: a step whose download waits for the next step
+        self.rider_posts = True                      # ... and is carried by that step's adjoint kernel where the operator can
         m, n = A.shape
         eng = self.eng
         self.U = DeviceBasis(eng, m, capacity + 1)
@@ -116,6 +117,7 @@ class GKState:
         st._UB, st.uproj = None, None
         st._proj, st._proj_n = None, 0
         st._late, st._posted_any = None, False
+        st.rider_posts = False
         eng = A.engine
         m, n = A.shape
         k = len(alphas)
@@ -191,7 +193,13 @@ class GKState:
             if self._UP is None:
                 self._UP = eng.scalars(2 * self.PROJ_PARTIALS)
             self._proj = (project, self._UP.ref(self.PROJ_PARTIALS * (k & 1)), self.PROJ_PARTIALS)
-        self.step(sync=False, defer=bool(more_follow))
+        # the post of the step before (its last norm is finished by THIS step's adjoint kernel) rides that kernel where it can
+        late, rider = self._late, None
+        late_lo = None if late is None else self._post_lo(late[0])
+        if (late is not None and k >= 1 and self.native_axpby and hasattr(eng, "gk_step_post") and getattr(eng, "world", 1) == 1
+                and getattr(self.A, "_h", None) and (late[1] is None or isinstance(late[1], tuple)) and self.rider_posts):
+            rider = self._post_args(late[0], late[1], late_lo)
+        self.step(sync=False, defer=bool(more_follow), post=None if rider is None else rider[0])
         n_part = self._proj_n if merged else 0
         self._proj = None
         if merged:
@@ -205,19 +213,36 @@ class GKState:
                 eng.dot(self.U[j], project, self._UB.ref(j))
             eng.allreduce(self._UB, j0, k + 2)
         started = []
-        late, self._late = self._late, None
+        self._late = None
         if late is not None:
-            started.append(self._post_step(*late))       # the step before: its beta^2 was finished by this step's first kernel
+            if rider is not None and self.post_taken:
+                started.append(rider[1])
+            else:
+                started.append(self._post_step(late[0], late[1], late_lo))   # the step before: its beta^2 was finished by this step's first kernel
         if more_follow:
             self._late = (k, j0)
         else:
             started.append(self._post_step(k, j0))
         return started
 
-    def _post_step(self, k, j0):
+    def _post_lo(self, k):
+        """Where the post of step k starts: the first one also carries beta0^2."""
         first = not self._posted_any
         self._posted_any = True
-        lo = 0 if first else 2 * k + 1
+        return 0 if first else 2 * k + 1
+
+    def _post_args(self, k, j0, lo):
+        """_post_step as a rider: (arguments for trk_gk_step_post, the (k, lo, handle, extra) tuple absorb() takes)."""
+        if isinstance(j0, tuple):
+            _, part, n_part = j0
+            args, h, hs = self.AB.rider_post(lo, 2 * k + 3, part, n_part, self._uoff + k + 1)
+        else:
+            args, h, hs = self.AB.rider_post(lo, 2 * k + 3)
+        return args, (k, lo, h, hs)
+
+    def _post_step(self, k, j0, lo=None):
+        if lo is None:
+            lo = self._post_lo(k)
         if isinstance(j0, tuple):                   # the norms and the new U^T b entry (AB[uoff + k + 1]) in one post
             _, part, n_part = j0
             at = self._uoff + k + 1
@@ -244,12 +269,12 @@ class GKState:
         if self.native_axpby:
             self.A.flush_deferred()
 
-    def step(self, sync=True, defer=False, lsqr=None):
+    def step(self, sync=True, defer=False, lsqr=None, post=None):
         """defer=True (with sync=False): beta_{k+1}^2 may stay unfinished inside the operator until the next step or
         `flush()` — for loops that look at AB only at the end (fixed-lambda Hybrid_LSQR without history)."""
         A, eng = self.A, self.eng
         k = self.V.k
-        self.lsqr_taken, self.lsqr_blocks = False, 0
+        self.lsqr_taken, self.lsqr_blocks, self.post_taken = False, 0, False
         defer = bool(defer) and not sync
         if self._ab_cap < 2 * k + 3:
             self.flush()
@@ -279,7 +304,14 @@ class GKState:
                     # the whole step in one call of the library (trk_gk_step: the two half steps below, same coefficients,
                     # same hints) — the Python side of a step was a fifth of a 512^2 Hybrid-LSQR iteration's host time
                     un = self.U.next_slot()
-                    if getattr(self, "_proj", None) is not None:
+                    if post is not None and k >= 1 and hasattr(eng, "gk_step_post"):
+                        # the mailbox post of the step before rides this step's adjoint half (trk_gk_step_post)
+                        n_pr = eng.gk_step_post(A._h, k, u, self.V[k - 1], v, un, AB, self._chained, True, defer, post,
+                                                proj=getattr(self, "_proj", None))
+                        if getattr(self, "_proj", None) is not None:
+                            self._proj_n = n_pr
+                        self.post_taken = True
+                    elif getattr(self, "_proj", None) is not None:
                         self._proj_n = eng.gk_step_proj(A._h, k, u, self.V[k - 1], v, un, AB, self._chained, True, defer, *self._proj)
                     elif lsqr is not None and k >= 1 and hasattr(eng, "gk_step_lsqr"):
                         # lsqr = (w, x_in, x_out, ref, partials, capacity, damp, state_in, state_out): damped LSQR's update of the
