@@ -168,6 +168,10 @@ int trk_isotv_weights(const float* x, int N, int nt, const float* u_tail, int64_
  * out must not alias x or r_in.  Products and sums are rounded as in the separate kernels. */
 int trk_tv_weights(trk_op* L, const float* x, double eps, double q, float* w, trk_stream stream);
 int trk_tv_grad(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, trk_stream stream);
+/* trk_tv_grad that also leaves *dot_out = <out, dotv> (dotv: a vector of the image's length): GKS needs r . L^T L r next to
+ * z = L^T L r for the Gram row of the next basis vector (GKS.py:92-96 through the Gram form) — no pass over r and z of its own. */
+int trk_tv_grad_dot(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, const float* dotv,
+                    double* dot_out, trk_stream stream);
 
 /* One Golub-Kahan half step in the operator's own output pass (decompositions.py:240-252: v = A^T u - beta v_old, u = A v -
  * alpha u_old, their norms):   out = a * Op(x) + b * z ,  *sumsq = ||out||^2 (if sumsq != NULL)

@@ -179,6 +179,27 @@ def test_wgram(eng, k, m, weighted):
     assert np.allclose(got[k * k + k:], W32 @ (w32 ** 2 * b32), rtol=1e-6, atol=1e-6 * m ** 0.5)
 
 
+@pytest.mark.parametrize("N,nt", [(16, 1), (100, 1), (257, 1), (512, 1), (48, 5), (64, 3)])
+def test_tv_grad_with_the_dot_of_its_output(eng, N, nt):
+    """trk_tv_grad_dot: the same `out` as trk_tv_grad, and <out, dotv> from the same pass — widths that are not a multiple of the
+    workgroup (threads beyond the image stay for the block sum), with and without weights / r_in, the space-time operator."""
+    from trips_py_amd.operators import FirstDerivative2D, SpaceTimeDerivative
+    L = FirstDerivative2D(N, engine=eng) if nt == 1 else SpaceTimeDerivative(N, nt, engine=eng)
+    n, p = L.shape[1], L.shape[0]
+    g = torch.Generator(device=eng.device).manual_seed(N + nt)
+    x, rin, dv = (torch.randn(n, device=eng.device, generator=g) for _ in range(3))
+    w = torch.rand(p, device=eng.device, generator=g) + 0.5
+    S = eng.scalars(1)
+    for ww in (None, w):
+        for rr in (None, rin):
+            o0, o1 = eng.empty(n), eng.empty(n)
+            L.tv_grad(x, ww, rr, 0.7, o0)
+            L.tv_grad(x, ww, rr, 0.7, o1, dot_with=dv, dot_out=S.ref(0))
+            assert torch.equal(o0, o1)
+            want = float(o0.double() @ dv.double())
+            assert abs(float(eng.to_host(S)[0]) - want) <= 1e-12 * float(o0.double().norm() * dv.double().norm())
+
+
 @pytest.mark.parametrize("k,n", [(1, 1000), (7, 10_001), (8, 4096), (9, 70_000), (17, 33_333), (40, 20_000)])
 def test_gemv_t_with_one_more_row(eng, k, n):
     """trk_gemv_t_x: h = V r and xrow . r from one pass (the row is not part of the basis; tile counts that change with it)."""

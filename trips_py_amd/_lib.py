@@ -163,6 +163,7 @@ SIGNATURES = {
     "trk_isotv_weights": (c_int, [c_f32p, c_int, c_int, c_f32p, c_i64, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_tv_weights": (c_int, [c_op, c_f32p, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_tv_grad": (c_int, [c_op, c_f32p, c_f32p, c_f32p, c_dbl, c_f32p, c_stream]),
+    "trk_tv_grad_dot": (c_int, [c_op, c_f32p, c_f32p, c_f32p, c_dbl, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_mm_weights": (c_int, [c_i64, c_f32p, c_f32p, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_cgls_update_xr": (c_int, [c_i64, c_i64, c_f64p, c_f64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_op_fused_caps": (c_int, [c_op, ctypes.POINTER(c_int)]),

@@ -184,9 +184,15 @@ __global__ __launch_bounds__(NT) void k_tvt_weights(const float* __restrict__ x,
 
 // nt > 1: the space-time operator (single rank).  blockIdx.z = frame; w = [nt x 2N(N-1) spatial | (nt-1) x N^2 temporal] as the rows
 // of L; the temporal part adds wt_t (x_t - x_{t+1}) - wt_{t-1} (x_{t-1} - x_t) to frame t.
-template <bool W, bool RIN>
+// DOT: also the block partial of <out, dotv> (GKS: r . L^T L r for the Gram row of the next basis vector, GKS.py:92-96 through the
+// Gram form — no pass over the two vectors of its own); every thread then stays to the end (the block sum's barriers).
+template <bool W, bool RIN, bool DOT = false>
 __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, const float* __restrict__ w,
-                                                const float* __restrict__ rin, float lam, float* __restrict__ out, int N, int nt) {
+                                                const float* __restrict__ rin, float lam, float* __restrict__ out, int N, int nt,
+                                                const float* __restrict__ dotv = nullptr, double* __restrict__ dot_part = nullptr) {
+#pragma clang fp contract(off)       // products and sums as written (HIP's __fmul_rn is a plain `*`): the same bits in every instantiation
+  __shared__ double dred[DOT ? NT / 64 : 1];
+  double dacc = 0.0;
   const int f = blockIdx.z;
   const int64_t npix = (int64_t)N * N, ps = 2 * (int64_t)N * (N - 1);
   const float* __restrict__ xf = x + f * npix;
@@ -195,8 +201,11 @@ __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, con
   const float* __restrict__ wt = (W && nt > 1) ? w + nt * ps : nullptr;      // temporal weights, row t at wt + t npix
   rin = RIN ? rin + f * npix : rin;
   out += f * npix;
-  const int j = blockIdx.x * NT + threadIdx.x;
-  if (j >= N) return;
+  if (DOT) dotv += f * npix;
+  const int jraw = blockIdx.x * NT + threadIdx.x;
+  const bool live = jraw < N;
+  if (!DOT && !live) return;
+  const int j = live ? jraw : N - 1;                             // (DOT: a thread beyond the image works on the last column, stores nothing)
   const bool hr = j < N - 1, hl = j > 0;
   const bool tnext = nt > 1 && f < nt - 1, tprev = nt > 1 && f > 0;
   for (int i0 = blockIdx.y * RB; i0 < N; i0 += gridDim.y * RB) {
@@ -239,9 +248,15 @@ __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, con
         if (i > 0) acc -= __fmul_rn(v[t], xc[t] - c);
         if (tnext) acc += __fmul_rn(wn[t], c - xn[t]);             // same order as k_d2_adj<TEMPORAL>: + T_t - T_{t-1}
         if (tprev) acc -= __fmul_rn(wq[t], xp[t] - c);
-        out[o0 + (int64_t)t * N] = RIN ? rr[t] + lam * acc : lam * acc;
+        const float ov = RIN ? __fadd_rn(rr[t], __fmul_rn(lam, acc)) : __fmul_rn(lam, acc);   // (no contraction: the same bits with and without DOT)
+        if (!DOT || live) out[o0 + (int64_t)t * N] = ov;
+        if (DOT && live) dacc += (double)ov * (double)dotv[o0 + (int64_t)t * N];
       }
     }
+  }
+  if (DOT) {
+    dacc = block_sum<NT>(dacc, dred);
+    if (threadIdx.x == 0) dot_part[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = dacc;
   }
 }
 
@@ -411,6 +426,25 @@ int trk_tv_grad(trk_op* L, const float* x, const float* w, const float* r_in, do
 #undef TG
   TRK_LAUNCH_CHECK();
   return TRK_OK;
+}
+
+int trk_tv_grad_dot(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, const float* dotv,
+                    double* dot_out, trk_stream st) {
+  TRK_REQUIRE(L && x && out && dotv && dot_out, "trk_tv_grad_dot: NULL argument");
+  TRK_REQUIRE(out != x && out != r_in && out != dotv, "trk_tv_grad_dot: out must not alias x, r_in or dotv");
+  int N = 0, nt = 0;
+  if (int rc = tv_geometry(L, "trk_tv_grad_dot", &N, &nt)) return rc;
+  const Grid2 g2 = grid2(N, nt, true);
+  const int nblk = g2.per_frame * nt;
+  hipStream_t s = (hipStream_t)st;
+  double* part = nullptr;
+  if (int rc = scratch_doubles(s, (size_t)nblk, &part)) return rc;
+#define TGD(W, R) hipLaunchKernelGGL((k_tv_grad<W, R, true>), g2.g, dim3(NT), 0, s, x, w, r_in, (float)lam, out, N, nt, dotv, part)
+  if (w) { if (r_in) TGD(true, true); else TGD(true, false); }
+  else   { if (r_in) TGD(false, true); else TGD(false, false); }
+#undef TGD
+  TRK_LAUNCH_CHECK();
+  return finalize_sums(part, nblk, 1, 1, dot_out, s);
 }
 
 int trk_spacetime_set_halo(trk_op* op, const float* x_next, const float* y_prev) {

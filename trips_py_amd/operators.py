@@ -269,8 +269,16 @@ class _FusedTV:
         _lib.check(self.engine.lib.trk_tv_weights(self._h, x.data_ptr(), float(eps), float(q), out.data_ptr(),
                                                   self.engine.stream()), "trk_tv_weights")
 
-    def tv_grad(self, x, w, r_in, lam, out):
-        """out = r_in + lam * L^T (w .* (L x)) (MMGKS.py:116-118); w None: unit weights (GKS.py:81-84); r_in None: 0."""
+    def tv_grad(self, x, w, r_in, lam, out, dot_with=None, dot_out=None):
+        """out = r_in + lam * L^T (w .* (L x)) (MMGKS.py:116-118); w None: unit weights (GKS.py:81-84); r_in None: 0.
+        dot_with / dot_out: also <out, dot_with> into the device scalar dot_out, from the same pass (trk_tv_grad_dot)."""
+        if dot_with is not None:
+            rc = self.engine.lib.trk_tv_grad_dot(self._h, x.data_ptr(), None if w is None else w.data_ptr(),
+                                                 None if r_in is None else r_in.data_ptr(), float(lam), out.data_ptr(),
+                                                 dot_with.data_ptr(), dot_out if isinstance(dot_out, int) else dot_out.data_ptr(),
+                                                 self.engine.stream())
+            _lib.check(rc, "trk_tv_grad_dot")
+            return
         rc = self.engine.lib.trk_tv_grad(self._h, x.data_ptr(), None if w is None else w.data_ptr(),
                                          None if r_in is None else r_in.data_ptr(), float(lam), out.data_ptr(),
                                          self.engine.stream())

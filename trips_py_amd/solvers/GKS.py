@@ -20,6 +20,10 @@ from ..operators import is_identity
 from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq, small_host_blas
 
 
+import os as _os
+_TVDOT = _os.environ.get("TRK_GKS_TVDOT", "1") != "0"       # r . L^T L r from the pass that forms L^T L r (trk_tv_grad_dot)
+
+
 class _ProjectedBases:
     """V and the incrementally maintained Gram data  G_A = (AV)^T AV, G_L = (LV)^T LV, c = (AV)^T b.
 
@@ -151,12 +155,15 @@ class _ProjectedBases:
             eng.dot(r, self.atb, S.ref(2))
             extra.append(self.zA)
         if self.from_v_L:
-            if self.tL is None:
-                self.L.tv_grad(r, None, None, 1.0, out=self.zL)
+            if self.tL is None and hasattr(getattr(eng, "lib", None), "trk_tv_grad_dot") and _TVDOT:
+                self.L.tv_grad(r, None, None, 1.0, out=self.zL, dot_with=r, dot_out=S.ref(1))   # z_L = L^T L r and r . z_L, one pass
             else:
-                self.L.apply(r, out=self.tL)
-                self.L.apply(self.tL, out=self.zL, transpose=True)
-            eng.dot(r, self.zL, S.ref(1))                                 # r . L^T L r
+                if self.tL is None:
+                    self.L.tv_grad(r, None, None, 1.0, out=self.zL)
+                else:
+                    self.L.apply(r, out=self.tL)
+                    self.L.apply(self.tL, out=self.zL, transpose=True)
+                eng.dot(r, self.zL, S.ref(1))                             # r . L^T L r
             extra.append(self.zL)
         eng.allreduce(S, 0, 3)
         return extra
