@@ -489,15 +489,23 @@ def extra_c3_tomo(world, cpu_jobs=None):
             big[f"{name}_ms"] = round(ms, 3)
             big[f"{name}_Gtaps_per_s"] = round(big["taps_per_apply"] / ms / 1e6, 1)
             big[f"{name}_alg_GBps"] = round(big["alg_bytes_per_apply"] / ms / 1e6, 2)
-        # The projector is bound by vector-instruction issue, not by HBM: a wave64 VALU instruction occupies its
-        # SIMD for 4 cycles (MI355X_MICROARCH.md, cycle constants: 'vector-instruction ISSUE cost'), 1024 SIMDs, 2.4 GHz peak
-        # clock.  Instructions per unit are read off the ISA of the inner loops: forward 7 per ray and
-        # marching step (N n_det n_ang steps), adjoint 10.25 per pixel and angle (N^2 n_ang: 41 per angle and four pixels).
+        # Neither direction is bound by HBM.  What a gfx950 SIMD and the LDS sustain for these instruction streams was
+        # measured on the chip (tools/microbench/issue_rate.hip, profiles/r04/issue_rate.txt): 2.3 cycles per wave64 instruction for
+        # two-source VGPR forms, 4.1-4.2 for an SGPR operand, v_cvt_f32_u32, three-source integer forms and v_pk_fma_f32;
+        # ds_read2_b32 4 LDS cycles per wave when no two lanes of a 32-lane group meet on a bank.
+        #   forward (k_radon_fwd_quad): four symmetric angles share the taps' arithmetic, so a wave-step serves 256
+        #   ray-steps with 4 ds_read2_b32 (16 LDS cycles per CU: the binding pipe, conflict-free by construction) and
+        #   8 shared + 4 packed-FMA vector instructions (38.5 cycles on one of the CU's four SIMDs);
+        #   adjoint (k_radon_adj_tile): 10.25 vector instructions per pixel and angle, its mix at 4 cycles each.
         steps = float(Nb) * Nb * na
-        for name, ipu in (("fwd", 7.0), ("adj", 10.25)):
-            floor_ms = steps * ipu / 64.0 * 4.0 / (1024 * 2.4e9) * 1e3
-            big[f"{name}_roofline"] = {"bound": "valu_issue", "instr_per_unit": ipu, "units": steps, "floor_ms": round(floor_ms, 4),
-                                       "frac": round(floor_ms / big[f"{name}_ms"], 4)}
+        lds_floor_ms = steps / 256.0 * 16.0 / (256 * 2.4e9) * 1e3
+        valu_floor_ms = steps / 256.0 * 38.5 / (1024 * 2.4e9) * 1e3
+        big["fwd_roofline"] = {"bound": "lds_gather", "lds_cycles_per_256_ray_steps": 16.0, "units": steps, "floor_ms": round(lds_floor_ms, 4),
+                               "frac": round(lds_floor_ms / big["fwd_ms"], 4), "valu_floor_ms": round(valu_floor_ms, 4),
+                               "valu_cycles_per_256_ray_steps_per_simd": 38.5}
+        floor_ms = steps * 10.25 / 64.0 * 4.0 / (1024 * 2.4e9) * 1e3
+        big["adj_roofline"] = {"bound": "valu_issue", "instr_per_unit": 10.25, "cycles_per_instr": 4.0, "units": steps,
+                               "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / big["adj_ms"], 4)}
         out["radon_4096x180"] = big
         del Rb, xb, yb, zb
     except Exception as exc:      # noqa: BLE001

@@ -126,7 +126,7 @@ def test_radon_vs_oracle_convention(N, na, nd):
     assert relerr(R.T @ y, Ro.T @ f(y)) < 1e-5, relerr(R.T @ y, Ro.T @ f(y))
 
 
-@pytest.mark.parametrize("case", ["fan7", "scattered", "wide_detector", "narrow_detector", "near45"])
+@pytest.mark.parametrize("case", ["fan7", "scattered", "wide_detector", "narrow_detector", "near45", "quads", "signs", "twice", "deg180"])
 def test_radon_shared_window_forward_vs_oracle(case):
     """N >= 1024 runs the window-sharing forward kernel (4 neighbouring angles stage one LDS window; rays are owned by
     their column at the band's top row).  Against the oracle's sparse Joseph matrix, including what the kernel special-
@@ -139,7 +139,13 @@ def test_radon_shared_window_forward_vs_oracle(case):
            "scattered": np.array([0.1, 2.0, 0.8, 2.9, 1.3, 0.05]),
            "wide_detector": np.deg2rad([10.0, 11.0, 12.0, 13.0, 100.0, 101.0]),
            "narrow_detector": np.deg2rad([30.0, 31.0, 32.0, 33.0, 34.0]),
-           "near45": np.deg2rad([43.0, 44.0, 45.0, 46.0, 133.0, 134.0, 135.0, 136.0])}[case]
+           "near45": np.deg2rad([43.0, 44.0, 45.0, 46.0, 133.0, 134.0, 135.0, 136.0]),
+           # round 4 (k_radon_fwd_quad: the four images of a base angle under the grid's symmetries share a wave): complete quads in
+           # caller order, every sign case of (cos, sin) incl. angles outside [0, pi), an angle given twice, the full 1-degree set
+           "quads": np.deg2rad([10.0, 80.0, 100.0, 170.0, 11.0, 79.0, 101.0, 169.0, 12.0, 78.0, 13.0]),
+           "signs": np.deg2rad([20.0, 160.0, -20.0, 200.0, 70.0, 110.0, -70.0, 250.0, 290.0, 340.0, -160.0, 21.0]),
+           "twice": np.deg2rad([30.0, 30.0, 150.0, 60.0, 30.0, 120.0]),
+           "deg180": np.linspace(0, np.pi, 180, endpoint=False)}[case]
     nd = {"wide_detector": 1500, "narrow_detector": 700}.get(case, N)
     R, Ro = Radon2DParallel(N, ang, n_det=nd), O.Radon2D(N, ang, n_det=nd)
     rng = np.random.default_rng(11)

@@ -32,6 +32,7 @@
 // operator is bound by LDS reads / vector issue, not HBM; bench.py reports taps/s next to GB/s.
 #include "trk_internal.h"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -60,6 +61,8 @@ struct AdjAngle {           // the adjoint's per-angle constants, sorted by marc
   int flip;                 // inv < 0: the ray on the larger-q side is d0 - 1 (the records store neighbours by side)
 };
 
+struct QuadParam;
+
 struct RadonImpl {
   int N, nd, na;   // na = angles PER FRAME
   int nt;          // time frames sharing one launch (block-diagonal dynamic operator, io.py:391-420); 1 = static
@@ -80,6 +83,11 @@ struct RadonImpl {
   int4* adj_pos;     // [nt*na]: angle row (caller's order) -> {its sorted row (the inverse of adj_ang[].orig), that row's
                      // adjoint weight (bits), its flip flag, 0}: one load where the record writer chased three
   int n_bands, band;
+  // quads: groups of up to four symmetric angles served by one wave of k_radon_fwd_quad (nq per frame, padded with empty ones)
+  QuadParam* quad_dev;
+  unsigned* A32q;   // [nt*nq][nd + 4]  base tables
+  unsigned* B32q;   // [nt*nq][npad]
+  int nq;
   // what the side buffers currently hold, when a fused apply left them behind for the next apply of the other direction
   // (trk_op_apply_axpby hints): rec = the records of the sinogram at rec_src, xT = the transpose of the image at xT_src
   const float* rec_src;
@@ -676,6 +684,294 @@ __global__ __launch_bounds__(256, 7) void k_radon_fwd_win(const float* __restric
   if (owned) out[(int64_t)blockIdx.y * band_stride + (int64_t)a * nd + d] = (float)total;
 }
 
+// Quad forward kernel (round 4): FOUR symmetric angles from one set of taps, conflict-free LDS gathers.
+//
+// What bounds k_radon_fwd_win (tools/microbench/issue_rate.hip, profiles/r04/issue_rate.txt): its march is seven vector
+// instructions per ray and row of which five issue at 4 cycles, not 2 (an SGPR operand, v_cvt_f32_u32, three-source integer
+// forms, v_pk_fma_f32): 25-30 cycles per wave and step on the SIMD; and its ds_read2_b32 — 64 rays 1 ... 1.41 columns apart span
+// up to 91 columns, so a 32-lane group meets two addresses per bank — takes 8 LDS cycles instead of 4.  Both pipes level at
+// ~9 cycles per wave-step and CU.  Two changes take each off the critical path:
+//   * SYMMETRY.  With beta in [0, 45 deg], ct = cos(beta), t = tan(beta), q_b(s, i) = s/ct + h(1 - t) + i t  (h = (N-1)/2):
+//       angle beta        rows of x,   q = q_b(s, i)                      slot 0
+//       angle 180 - beta  rows of x,   q = (N-1) - q_b(s, i)              slot 1  (mirrored columns: taps swap their weights)
+//       angle 90 - beta   rows of xT,  q = q_b(-s, j)                     slot 2  (detector index flipped)
+//       angle 90 + beta   rows of xT,  q = (N-1) - q_b(s, j)              slot 3
+//     (all four identities exact; checked against the oracle to 1e-15; the general sign cases are in radon_create_impl).  A wave
+//     computes Q, both weights and the LDS address ONCE per step and uses them for the four members: the window [cs, cs + W) of
+//     x and of xT (region F) and the mirrored window [N - cs - W, N - cs) of both (region M, stored in descending order so that its
+//     address is one constant minus the forward address).  7 shared instructions + 1 (mirror address) + 4 packed FMAs per
+//     256 ray-steps instead of 28: the vector unit drops to ~40 % and the march is bound by its four ds_read2_b32.
+//   * HALF-WAVE WINDOWS.  A 32-lane group (what one LDS cycle serves for ds_read_b32) owns the rays whose column at the band's top
+//     row lies in a 31-column interval: at any row its <= 32 columns are distinct mod 32 — no bank conflicts by construction
+//     (lanes without a ray repeat an owned address: broadcast), at 31 / (32 inv) of the lanes busy.  Measured in isolation:
+//     17.7 cycles per 256 ray-steps and CU against 36.7 for the march above.
+// The member tables A32 / B32 / CB of every angle are DERIVED from its quad's base tables at create time, so the adjoint (which
+// reads the members' tables) still sees bit-identical weights.  Angles without partners run as quads with fewer members.
+// Workgroup = 4 waves = 4 quads of neighbouring beta sharing the staged tiles; chunks of QD_R = 8 rows, double-buffered with a true
+// prefetch (the taps are inline-assembly LDS reads, so the compiler does not drain the direct-to-LDS loads in front of them).
+struct QuadParam {
+  float inv, dq, k0, rinv;   // base geometry: inv = 1/cos(beta) in [1, sqrt 2], dq = tan(beta) in [0, 1], k0 = h (1 - dq), rinv = cos(beta)
+  int am[4];                 // member angle of each slot (index within the frame), -1: none
+  int flip;                  // bit m: member m writes detector nd - 1 - d
+  int mask;                  // bit m: slot m has a member
+  int pad0, pad1;
+};
+#define QD_R 8
+#define QD_W 120                          // window width (floats): 62 owned columns + 8 rows of slope + the drift of 4 neighbouring quads + alignment
+#define QD_MAXCH 32
+#define QD_HALF 31
+#define QD_WO (2 * QD_HALF)
+// LDS layout of a region (F: windows as they are; M: mirrored windows): [row pair p][source: x, xT][row in pair][QD_W] floats.
+//   * one wave-load (60 lanes x 16 bytes = 240 floats) fills the two rows of ONE source: full-width loads with one buffer
+//     resource (half-masked loads per source cost the texture path twice as much per byte: measured, TD 87 % busy);
+//   * the xT window sits QD_SRC = 240 floats behind the x window: inside the 8-bit offsets of ds_read2_b32, so ONE address register
+//     serves both sources;
+//   * region M stores pairs, rows and columns in DESCENDING order: address_M(u, 118 - k) = constant - address_F(u, k).
+#define QD_SRC (2 * QD_W)                 // 240
+#define QD_PAIR (2 * QD_SRC)              // 480
+#define QD_REGION ((QD_R / 2) * QD_PAIR)  // 1920 floats
+
+__device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
+
+template <int DUMMY = 0>
+__global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restrict__ img, const float* __restrict__ imgT,
+                                                        float* __restrict__ out, int N, int nd,
+                                                        const QuadParam* __restrict__ quads, int nq_per_frame, int ngrp_per_frame,
+                                                        int na_per_frame, int nwin, int64_t band_stride, int bh,
+                                                        const float* __restrict__ fidx, const unsigned* __restrict__ A32q,
+                                                        const unsigned* __restrict__ B32q, int npad,
+                                                        const AngleParam* __restrict__ ang, const unsigned* __restrict__ A32,
+                                                        const unsigned* __restrict__ B32) {
+  __shared__ __attribute__((aligned(16))) float tile[2][2 * QD_REGION];
+  __shared__ float ext[4][QD_MAXCH][2];
+  __shared__ int chinfo[QD_MAXCH][2];
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // workgroups b and b + 8 run on the same XCD (round-robin placement: speed only, never correctness): give every XCD one
+  // contiguous eighth of the windows, for all quad groups — its L2 then holds an eighth of the band (and the mirrored eighth)
+  // instead of every fourth window of all of it
+  const int nw8 = (nwin + 7) >> 3;
+  const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+  const int grp = bidx / nw8, jj = xcd * nw8 + (bidx - grp * nw8);
+  if (jj >= nwin) return;
+  const int frame = grp / ngrp_per_frame;
+  const int q0 = (grp - frame * ngrp_per_frame) * 4;
+  const int nval = (nq_per_frame - q0 < 4) ? nq_per_frame - q0 : 4;
+  const QuadParam* __restrict__ qg = quads + (int64_t)frame * nq_per_frame + q0;
+  int smask = 0;                                                    // slots any of the workgroup's quads uses: what gets staged
+  for (int w = 0; w < nval; ++w) smask |= qg[w].mask;
+  const int t0 = blockIdx.y * bh, t1 = (t0 + bh < N) ? t0 + bh : N;
+  const int OFFS = bh + 4;
+  const bool valid = wv < nval;
+  const QuadParam p = qg[valid ? wv : 0];
+  const int qrow = frame * nq_per_frame + q0 + (valid ? wv : 0);
+  const int ndp = nd + 2 * A32_PAD;
+  const unsigned img_bytes = (unsigned)N * (unsigned)N * 4u;
+  const auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)frame * N * N), 0, img_bytes, 0x00020000);
+  const auto rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)((imgT ? imgT : img) + (int64_t)frame * N * N), 0, img_bytes, 0x00020000);
+  const float sdh = 0.5f * (float)(nd - 1);
+  // a half-wave owns the rays whose column at the band's top row lies in [qa, qb), 31 columns: its candidates are the 32
+  // detectors from the first one inside (found exactly: the estimate of the interval's pre-image is good to a small fraction of a
+  // detector, one test decides between its two possible values)
+  const int hw = lane >> 5, li = lane & 31;
+  const float qa = (float)(jj * QD_WO - OFFS + QD_HALF * hw), qb = qa + (float)QD_HALF;
+  const float t0f = fidx[t0];
+  const float offs = fmaf(t0f, p.dq, p.k0);
+  const float dA = (qa - offs) * p.rinv + sdh;
+  const int d0 = (int)ceilf(dA - 0.05f);
+  const float qt0 = fmaf(t0f, p.dq, fmaf((float)d0 - sdh, p.inv, p.k0));
+  const int d = d0 + (qt0 < qa ? 1 : 0) + li;
+  const float base = fmaf((float)d - sdh, p.inv, p.k0);
+  const float qtop = fmaf(t0f, p.dq, base);
+  const bool owned = valid && p.mask != 0 && (unsigned)d < (unsigned)nd && qtop >= qa && qtop < qb;
+  const unsigned long long omask = __builtin_amdgcn_ballot_w64(owned);
+  const bool any = omask != 0ull;
+  const unsigned om_lo = (unsigned)omask, om_hi = (unsigned)(omask >> 32);
+  const int l_first = any ? __builtin_ctzll(omask) : 0, l_last = any ? 63 - __builtin_clzll(omask) : 0;
+  const float blo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, base), l_first));   // inv > 0: increasing
+  const float bhi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, base), l_last));
+  const int dcl = d < 0 ? 0 : (d >= nd ? nd - 1 : d);
+  const unsigned A = A32q[(int64_t)qrow * ndp + dcl + A32_PAD];
+  // lanes without a ray follow the first owned ray of their half (of the other half if theirs owns none): a broadcast, inside the tile
+  const int lf0 = om_lo ? __builtin_ctz(om_lo) : (om_hi ? 32 + __builtin_ctz(om_hi) : 0);
+  const int lf1 = om_hi ? 32 + __builtin_ctz(om_hi) : lf0;
+  const unsigned A_f0 = (unsigned)__builtin_amdgcn_readlane((int)A, lf0), A_f1 = (unsigned)__builtin_amdgcn_readlane((int)A, lf1);
+  const unsigned A_m = owned ? A : (hw ? A_f1 : A_f0);
+  const unsigned* __restrict__ Ball = B32q + (int64_t)qrow * npad;
+  float two32v = 4294967296.0f;                    // in a VECTOR register: an SGPR operand would make the subtraction a 4-cycle issue
+  asm volatile("" : "+v"(two32v));
+  double total[4] = {0.0, 0.0, 0.0, 0.0};
+
+  // column range of every chunk, per wave -> LDS -> the union over the four waves, once per band (dq >= 0: q grows with the row)
+  const int nch = (t1 - t0 + QD_R - 1) / QD_R;
+  if (lane < nch) {
+    const int tb = t0 + lane * QD_R, te = (tb + QD_R < t1) ? tb + QD_R : t1;
+    ext[wv][lane][0] = any ? blo + (float)tb * p.dq : 3.0e38f;
+    ext[wv][lane][1] = any ? bhi + (float)(te - 1) * p.dq : -3.0e38f;
+  }
+  __syncthreads();
+  if (wv == 0 && lane < nch) {
+    const float ulo = fminf(fminf(ext[0][lane][0], ext[1][lane][0]), fminf(ext[2][lane][0], ext[3][lane][0]));
+    const float uhi = fmaxf(fmaxf(ext[0][lane][1], ext[1][lane][1]), fmaxf(ext[2][lane][1], ext[3][lane][1]));
+    const bool nobody = ulo > uhi;
+    const int cs = nobody ? 0 : (((int)floorf(ulo) - 1) & ~3);
+    const bool fits = !nobody && ((int)floorf(nobody ? 0.f : uhi) + 2 - cs) < QD_W;
+    chinfo[lane][0] = cs;
+    chinfo[lane][1] = nobody ? 2 : (fits ? 1 : 0);                // 2: no wave owns a ray here — nothing to stage, nothing to march
+  }
+  __syncthreads();
+
+  // staging: wave wv fills row pair wv of region F and of region M, one load per source (lanes 0-59: row in pair = lane / 30,
+  // four columns from 4 (lane % 30)).  Rows beyond te and columns outside the image arrive as zeros (offset out of range).
+  const int sr = lane >= 30 ? 1 : 0, sk = (lane - 30 * sr) << 2;                   // chunk-invariant
+  const int rowF = (2 * wv + sr) * N * 4, rowM = (2 * (QD_R / 2 - 1 - wv) + 1 - sr) * N * 4;
+  const int uF = 2 * wv + sr, uM = 2 * (QD_R / 2 - 1 - wv) + 1 - sr;
+  auto stage = [&](int ch, int cs) {
+    const int tb = t0 + ch * QD_R, te = (tb + QD_R < t1) ? tb + QD_R : t1;
+    float* __restrict__ T = tile[ch & 1];
+    const unsigned rowbase = (unsigned)tb * (unsigned)N * 4u;
+    const int colF = cs + sk, colM = (N - cs - QD_W) + sk;
+    const bool okF = ((unsigned)colF < (unsigned)N) && (tb + uF < te), okM = ((unsigned)colM < (unsigned)N) && (tb + uM < te);
+    const int voffF = okF ? (colF << 2) + rowF : (int)img_bytes, voffM = okM ? (colM << 2) + rowM : (int)img_bytes;
+    auto* dF = (__attribute__((address_space(3))) void*)(T + wv * QD_PAIR);
+    auto* dFt = (__attribute__((address_space(3))) void*)(T + wv * QD_PAIR + QD_SRC);
+    auto* dM = (__attribute__((address_space(3))) void*)(T + QD_REGION + wv * QD_PAIR);
+    auto* dMt = (__attribute__((address_space(3))) void*)(T + QD_REGION + wv * QD_PAIR + QD_SRC);
+    if (lane < 60) {
+      if (smask & 1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, dF, 16, voffF, rowbase, 0, 0);
+      if (smask & 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, dFt, 16, voffF, rowbase, 0, 0);
+      if (smask & 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, dM, 16, voffM, rowbase, 0, 0);
+      if (smask & 8) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, dMt, 16, voffM, rowbase, 0, 0);
+    }
+  };
+
+  f2v acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  int cs_cur = nch > 0 ? __builtin_amdgcn_readfirstlane(chinfo[0][0]) : 0;
+  int st_cur = nch > 0 ? __builtin_amdgcn_readfirstlane(chinfo[0][1]) : 2;
+  if (st_cur == 1) stage(0, cs_cur);
+  for (int ch = 0; ch < nch; ++ch) {
+    const int tb = t0 + ch * QD_R, te = (tb + QD_R < t1) ? tb + QD_R : t1;
+    const float* __restrict__ T = tile[ch & 1];
+    __syncthreads();                                               // (waits for this wave's loads) chunk ch is in LDS; the other buffer is free
+    const int cs = cs_cur, st = st_cur;
+    if (ch + 1 < nch) {                                            // the next chunk's window: read BEFORE its loads are issued (a C++
+      cs_cur = __builtin_amdgcn_readfirstlane(chinfo[ch + 1][0]);  // LDS read after them would wait for them)
+      st_cur = __builtin_amdgcn_readfirstlane(chinfo[ch + 1][1]);
+      if (st_cur == 1) stage(ch + 1, cs_cur);
+    }
+    const bool full = (te - tb == QD_R);
+    if (st == 1 && any) {
+      const unsigned* __restrict__ Brow = static_cast<const unsigned*>(__builtin_assume_aligned(Ball + tb, 32));
+      const unsigned Ac = A_m - ((unsigned)cs << QF);
+      const unsigned Toff = lds_off(T);
+      unsigned Cm = 2u * Toff + 4u * (unsigned)(QD_REGION + (QD_R / 2 - 1) * QD_PAIR + QD_W + (QD_W - 2));
+      asm volatile("" : "+v"(Cm));
+      auto march = [&](auto full_tag, auto all_tag) {
+        constexpr bool FULL = decltype(full_tag)::value, ALL = decltype(all_tag)::value;
+        f2v w[QD_R];
+        unsigned a0[QD_R], a1[QD_R];
+        // weights and addresses of a step are made three steps ahead of their use, just before its reads are issued: the vector
+        // work of step u + 3 runs while the reads of steps u .. u + 2 are in flight, and few of these registers are live at once
+        auto prep = [&](int u) {
+          const unsigned Q = Ac + Brow[u];
+          float f1 = (float)(Q << 8);                             // the 24 fraction bits, in units of 2^-32 (exact)
+          float f0 = two32v - f1;
+          if (!FULL) {
+            f1 = (tb + u < te) ? f1 : 0.f;
+            f0 = (tb + u < te) ? f0 : 0.f;
+          }
+          w[u] = (f2v){f0, f1};
+          unsigned c = Q >> QF;
+          if (!FULL) c = c > (unsigned)(QD_W - 2) ? (unsigned)(QD_W - 2) : c;
+          int rowoff = (int)Toff + ((u >> 1) * QD_PAIR + (u & 1) * QD_W) * 4;   // a scalar add (opaque to the optimiser, or it becomes a second vector add)
+          asm("" : "+s"(rowoff));
+          a0[u] = (c << 2) + (unsigned)rowoff;
+          a1[u] = Cm - a0[u];
+        };
+        // three steps (12 reads) in flight; LDS returns in order, so "at most 8 outstanding" means step u has arrived
+        f2v tA[QD_R], tB[QD_R], tC[QD_R], tD[QD_R];
+        auto issue = [&](int u) {
+          asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(tA[u]) : "v"(a0[u]));
+          asm volatile("ds_read2_b32 %0, %1 offset0:240 offset1:241" : "=v"(tB[u]) : "v"(a0[u]));
+          asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(tC[u]) : "v"(a1[u]));
+          asm volatile("ds_read2_b32 %0, %1 offset0:240 offset1:241" : "=v"(tD[u]) : "v"(a1[u]));
+          static_assert(QD_SRC == 240, "the offsets above are QD_SRC and QD_SRC + 1");
+        };
+        prep(0);
+        issue(0);
+        prep(1);
+        issue(1);
+        prep(2);
+        issue(2);
+#pragma unroll
+        for (int u = 0; u < QD_R; ++u) {
+          if (u + 3 < QD_R) prep(u + 3);
+          if (u <= QD_R - 3) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+          else if (u == QD_R - 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+          else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          asm volatile("" : "+v"(tA[u]), "+v"(tB[u]), "+v"(tC[u]), "+v"(tD[u]));
+          if (u + 3 < QD_R) issue(u + 3);
+          if (ALL || (p.mask & 1)) acc[0] = __builtin_elementwise_fma(w[u], tA[u], acc[0]);
+          if (ALL || (p.mask & 4)) acc[2] = __builtin_elementwise_fma(w[u], tB[u], acc[2]);
+          // mirrored windows: the pair read at the mirrored address is (tap c+1, tap c): the weights swap halves
+          if (ALL || (p.mask & 2)) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[1]) : "v"(w[u]), "v"(tC[u]));
+          if (ALL || (p.mask & 8)) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[3]) : "v"(w[u]), "v"(tD[u]));
+        }
+      };
+      if (p.mask == 15) {
+        if (full) march(std::true_type{}, std::true_type{});
+        else march(std::false_type{}, std::true_type{});
+      } else {
+        if (full) march(std::true_type{}, std::false_type{});
+        else march(std::false_type{}, std::false_type{});
+      }
+    } else if (st == 0 && any) {
+      // the four quads are too far apart for one window: every member gathers for itself from its own image and tables
+#pragma unroll 1
+      for (int m = 0; m < 4; ++m) {
+        if (!((p.mask >> m) & 1)) continue;
+        const int am_m = m == 0 ? p.am[0] : (m == 1 ? p.am[1] : (m == 2 ? p.am[2] : p.am[3]));   // (no dynamic index into p: it would move to scratch)
+        const int a = frame * na_per_frame + am_m;
+        const AngleParam pm = ang[a];
+        const int dm = ((p.flip >> m) & 1) ? nd - 1 - d : d;
+        const int dmc = dm < 0 ? 0 : (dm >= nd ? nd - 1 : dm);
+        const float base_m = fmaf((float)dm - sdh, pm.inv, pm.k0);
+        const unsigned Amm = A32[(int64_t)a * ndp + dmc + A32_PAD];
+        const unsigned* __restrict__ Bm = B32 + (int64_t)a * npad;
+        f2v w[8], v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int off = radon_edge_tap(tb + u, te, owned, N, pm.dq, base_m, Amm, Bm, w[u]);
+          v[u] = __builtin_bit_cast(f2v, pm.mode ? __builtin_amdgcn_raw_buffer_load_b64(rsrc1, off, 0, 0)
+                                                 : __builtin_amdgcn_raw_buffer_load_b64(rsrc0, off, 0, 0));
+        }
+        f2v am2 = {0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < 8; ++u) am2 = __builtin_elementwise_fma(w[u], v[u], am2);
+        const double tm = (double)(am2[0] + am2[1]);
+        total[0] += m == 0 ? tm : 0.0;
+        total[1] += m == 1 ? tm : 0.0;
+        total[2] += m == 2 ? tm : 0.0;
+        total[3] += m == 3 ? tm : 0.0;
+      }
+    }
+    if ((ch & 1) || ch == nch - 1) {                               // fp32 partial sums over 16 rows, then fp64 (as the other forward kernels)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        total[m] += (double)(acc[m][0] + acc[m][1]);
+        acc[m] = (f2v){0.f, 0.f};
+      }
+    }
+  }
+  if (owned) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (!((p.mask >> m) & 1)) continue;
+      const int dm = ((p.flip >> m) & 1) ? nd - 1 - d : d;
+      out[(int64_t)blockIdx.y * band_stride + ((int64_t)frame * na_per_frame + p.am[m]) * nd + dm] = (float)total[m];
+    }
+  }
+}
+
 // sino[a][d] = wgt_a * sum over bands (fixed order, fp64) of the band partial sums, then the optional epilogue
 // a * sino + b * z.  One thread per (angle row, e = d + A32_PAD in [0, nd + 4)): the padding positions exist for REC, which
 // also writes the adjoint's record {w S[d -], w S[d +], w S[d], A32[d]} of every position (what k_radon_adj_prep would
@@ -1246,7 +1542,7 @@ __global__ __launch_bounds__(256) void k_radon_adj_simple(const uint4* __restric
 // marched along columns from the image itself, transposing while it stages — no transposed copy, no launch for it (512^2 x 180:
 // the copy was 5 of the apply's 31 us; 32 frames of 256^2: 5.8 of 23).  The window-sharing kernel keeps the copy (2.6 % at 4096^2).
 struct FwdPath {
-  bool lds, dma, win, direct1;
+  bool lds, dma, win, direct1, quad;
 };
 FwdPath fwd_path(const RadonImpl* im, const float* xb) {
   static const bool no_lds = getenv("TRK_RADON_NO_LDS") != nullptr;
@@ -1258,8 +1554,12 @@ FwdPath fwd_path(const RadonImpl* im, const float* xb) {
   f.lds = !no_lds && (im->N % 4 == 0) && ((reinterpret_cast<uintptr_t>(xb) & 15u) == 0);
   f.dma = dma;
   // measured: 512^2 35 us (shared) vs 32 us (per-wave windows); 2048^2 0.256 vs 0.277 ms; 4096^2 0.96 vs 1.11 ms
-  f.win = im->n_bands > 1 && im->N >= 1024 && f.lds && dma && !no_win && im->band <= WIN_R * WIN_MAXCH;
+  static const int win_min = getenv("TRK_RADON_WIN_MIN") ? atoi(getenv("TRK_RADON_WIN_MIN")) : 1024;     // tuning knob
+  f.win = im->n_bands > 1 && im->N >= win_min && f.lds && dma && !no_win && im->band <= WIN_R * WIN_MAXCH;
   f.direct1 = f.lds && !f.win && !no_direct1;
+  // four symmetric angles per wave, conflict-free half-wave windows (k_radon_fwd_quad): 4096^2 x 180 0.94 -> see DESIGN.md 4.4
+  static const bool no_quad = getenv("TRK_RADON_NO_QUAD") != nullptr;
+  f.quad = f.win && !no_quad && im->nq > 0 && im->band <= QD_R * QD_MAXCH;
   return f;
 }
 
@@ -1384,9 +1684,16 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
       if (fp.win) {
         // window-sharing kernel: band partials of rays no window owns must read as zero
         if (hipMemsetAsync(im->part, 0, sizeof(float) * (size_t)nb * bs, s) != hipSuccess) return fail(TRK_EHIP, "radon: hipMemsetAsync failed");
-        const int nwin = ceil_div(N + 2 * im->band + 16, 61);
-        dim3 gw(nwin * ngrp * nt, nb, 1);
-        hipLaunchKernelGGL(k_radon_fwd_win<0>, gw, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, nwin, bs, im->band, im->fidx, im->A32, im->B32, im->npad);
+        if (fp.quad) {
+          const int nwq = ceil_div(N + im->band + 4, QD_WO), ngq = ceil_div(im->nq, 4);
+          dim3 gq(8 * ceil_div(nwq, 8) * ngq * nt, nb, 1);           // windows dealt to the XCDs in contiguous eighths (see the kernel)
+          hipLaunchKernelGGL(k_radon_fwd_quad<0>, gq, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->quad_dev, im->nq, ngq, na, nwq, bs, im->band,
+                             im->fidx, im->A32q, im->B32q, im->npad, im->ang_dev, im->A32, im->B32);
+        } else {
+          const int nwin = ceil_div(N + 2 * im->band + 16, 61);
+          dim3 gw(nwin * ngrp * nt, nb, 1);
+          hipLaunchKernelGGL(k_radon_fwd_win<0>, gw, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->ang_dev, na, ngrp, nwin, bs, im->band, im->fidx, im->A32, im->B32, im->npad);
+        }
       } else if (!post) {
         if (lds && dma) hipLaunchKernelGGL((k_radon_fwd_lds<true, true>), grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad, direct1);
         else if (lds) hipLaunchKernelGGL(k_radon_fwd_lds<true>, grid, dim3(256), 0, s, xb, im->xT, yb, N, nd, im->ang_dev, na, ngrp, ndblk, bs, im->band, im->A32, im->B32, im->npad, direct1);
@@ -1486,7 +1793,7 @@ int radon_apply_axpby(trk_op* op, int tr, const float* x, Coef a, Coef b, const 
 
 void radon_destroy(trk_op* op) {
   auto* im = static_cast<RadonImpl*>(op->impl);
-  void* ptrs[] = {im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec, im->adj_pos, im->pend_buf[0], im->pend_buf[1]};
+  void* ptrs[] = {im->quad_dev, im->A32q, im->B32q, im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec, im->adj_pos, im->pend_buf[0], im->pend_buf[1]};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete im;
@@ -1537,6 +1844,103 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
       cb[(size_t)a * npad + t] = uint2{__builtin_bit_cast(unsigned, C), B};
     }
   }
+  // ---- quads (k_radon_fwd_quad): per frame, angles that are images of one base angle beta in [0, 45 deg] under the symmetries of the
+  // square grid share one wave.  With ctb = max(|cos|, |sin|), t = min / max (= tan beta), q_b(s, i) = s / ctb + h (1 - t) + i t:
+  //   marching rows (|cos| >= |sin|):  cos > 0, sin >= 0: q = q_b(s, i)            cos < 0, sin >= 0: q = (N-1) - q_b(s, i)
+  //                                    cos > 0, sin <  0: q = (N-1) - q_b(-s, i)   cos < 0, sin <  0: q = q_b(-s, i)
+  //   marching columns (rows of xT):   sin > 0, cos >= 0: q = q_b(-s, j)           sin > 0, cos <  0: q = (N-1) - q_b(s, j)
+  //                                    sin < 0, cos >= 0: q = (N-1) - q_b(-s, j)   sin < 0, cos <  0: q = q_b(s, j)
+  // slot = 2 [xT] + 1 [mirrored]; -s = the detector index flipped.  The members' tables are then DERIVED from the base's, so that
+  // the forward (base tables) and the adjoint (member tables) weigh every tap with the same bits:
+  //   plain: A_m[e] = A_b[e'], B_m = B_b;   mirrored: A_m[e] = (N-1) 2^24 - A_b[e'], B_m = -B_b   (e' = e, or ndp-1-e when flipped).
+  std::vector<QuadParam> quads;
+  std::vector<unsigned> a32q, b32q;
+  int nq = 0;
+  {
+    struct Cand { double beta, ctb, t; int a, slot, flip; };
+    std::vector<std::vector<QuadParam>> per_frame(nt);
+    std::vector<std::vector<std::pair<double, double>>> geo(nt);          // (ctb, t) of every quad
+    for (int f = 0; f < nt; ++f) {
+      std::vector<Cand> c(na);
+      for (int a = 0; a < na; ++a) {
+        const double ct = std::cos(angles[(size_t)f * na + a]), st = std::sin(angles[(size_t)f * na + a]);
+        Cand k;
+        k.a = a;
+        if (std::fabs(ct) >= std::fabs(st)) {
+          k.ctb = std::fabs(ct); k.t = std::fabs(st) / std::fabs(ct);
+          const bool cp = ct > 0, sp = st >= 0;
+          k.slot = (cp == sp) ? 0 : 1;
+          k.flip = sp ? 0 : 1;
+        } else {
+          k.ctb = std::fabs(st); k.t = std::fabs(ct) / std::fabs(st);
+          const bool sp = st > 0, cp = ct >= 0;
+          k.slot = 2 + ((sp == cp) ? 0 : 1);
+          k.flip = (sp == cp) ? (sp ? 1 : 0) : (sp ? 0 : 1);
+        }
+        k.beta = std::atan2(k.t, 1.0);
+        c[a] = k;
+      }
+      std::stable_sort(c.begin(), c.end(), [](const Cand& x, const Cand& y) { return x.beta < y.beta; });
+      size_t i = 0;
+      while (i < c.size()) {
+        size_t j = i;
+        while (j < c.size() && c[j].beta - c[i].beta <= 1e-12) ++j;
+        // members i .. j-1 share the base; a slot met twice (the same angle given twice) opens another quad of the same base
+        std::vector<char> used(j - i, 0);
+        size_t left = j - i;
+        while (left > 0) {
+          QuadParam q{};
+          q.inv = (float)(1.0 / c[i].ctb); q.dq = (float)c[i].t; q.k0 = (float)(half - half * c[i].t); q.rinv = (float)c[i].ctb;
+          for (int m = 0; m < 4; ++m) q.am[m] = -1;
+          for (size_t k = i; k < j; ++k) {
+            if (used[k - i] || q.am[c[k].slot] >= 0) continue;
+            q.am[c[k].slot] = c[k].a;
+            q.mask |= 1 << c[k].slot;
+            q.flip |= c[k].flip << c[k].slot;
+            used[k - i] = 1;
+            --left;
+          }
+          per_frame[f].push_back(q);
+          geo[f].push_back({c[i].ctb, c[i].t});
+        }
+        i = j;
+      }
+      nq = std::max(nq, (int)per_frame[f].size());
+    }
+    quads.assign((size_t)nt * nq, QuadParam{});
+    a32q.assign((size_t)nt * nq * ndp, 0u);
+    b32q.assign((size_t)nt * nq * npad, 0u);
+    const unsigned KN = (unsigned)(((uint64_t)(N - 1) << QF) & 0xFFFFFFFFull);
+    for (int f = 0; f < nt; ++f) {
+      for (size_t k = 0; k < per_frame[f].size(); ++k) {
+        const size_t qr = (size_t)f * nq + k;
+        quads[qr] = per_frame[f][k];
+        const double ctb = geo[f][k].first, t = geo[f][k].second;
+        const double inv = 1.0 / ctb, k0 = half - half * t;
+        unsigned* Ab = &a32q[qr * ndp];
+        unsigned* Bb = &b32q[qr * npad];
+        for (int e = 0; e < ndp; ++e) Ab[e] = fx(((double)(e - A32_PAD) - sdh) * inv + k0);
+        for (int tt = 0; tt < npad; ++tt) Bb[tt] = fx((double)tt * t);
+        for (int m = 0; m < 4; ++m) {
+          const int am = quads[qr].am[m];
+          if (am < 0) continue;
+          const size_t ar = (size_t)f * na + am;
+          const bool mir = (m & 1) != 0, flp = ((quads[qr].flip >> m) & 1) != 0;
+          for (int e = 0; e < ndp; ++e) {
+            const unsigned v = Ab[flp ? ndp - 1 - e : e];
+            a32[ar * ndp + e] = mir ? KN - v : v;
+          }
+          for (int tt = 0; tt < npad; ++tt) {
+            const unsigned v = mir ? 0u - Bb[tt] : Bb[tt];
+            b32[ar * npad + tt] = v;
+            cb[ar * npad + tt].y = v;
+          }
+        }
+      }
+      for (size_t k = per_frame[f].size(); k < (size_t)nq; ++k)
+        for (int m = 0; m < 4; ++m) quads[(size_t)f * nq + k].am[m] = -1;
+    }
+  }
   int band = RADON_BAND;
   {
     // small frames (dynamic problems: 256^2 x 15 angles): 64-row bands double the workgroups of a grid that cannot fill the chip —
@@ -1568,6 +1972,10 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
   up((void**)&im->A32, a32.data(), sizeof(unsigned) * a32.size());
   up((void**)&im->B32, b32.data(), sizeof(unsigned) * b32.size());
   up((void**)&im->CB, cb.data(), sizeof(uint2) * cb.size());
+  im->nq = nq;
+  up((void**)&im->quad_dev, quads.data(), sizeof(QuadParam) * quads.size());
+  up((void**)&im->A32q, a32q.data(), sizeof(unsigned) * a32q.size());
+  up((void**)&im->B32q, b32q.data(), sizeof(unsigned) * b32q.size());
   {
     // adjoint tables: per frame, the angles with marching mode 0 first
     std::vector<AdjAngle> aa(n_ang);
