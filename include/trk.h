@@ -68,7 +68,9 @@ int trk_blur2d_create(const double* psf_host, int kh, int kw, int nx, int ny, tr
 /* Parallel-beam Radon transform, Joseph / linear-interpolation projector, matched adjoint.
  * Replaces astra.OpTomo over create_proj_geom('parallel', 1, N, theta) + 'linear' projector and
  * the /N scaling of trips/utilities/io.py:392-399.  Image N x N row-major; sinogram
- * (n_ang, n_det) row-major.  PARITY UNPINNED (astra-toolbox is absent; see oracle/cpu_ref.py). */
+ * (n_ang, n_det) row-major.  Parity: astra-toolbox is absent from the build image; the CONVENTION (rotation sense, detector
+ * order, layouts) is pinned to the ASTRA outputs the reference holds as images, through the fan-beam operator's far-source
+ * limit; the interpolation weights follow Joseph's published kernel (oracle/cpu_ref.py, tests/test_oracle_golden.py). */
 int trk_radon2d_create(int N, int n_det, const double* angles_host, int n_ang, double scale, trk_op** out);
 /* The same projector for a DYNAMIC problem: n_frames time frames of N x N, frame t seen under its own n_ang_per_frame
  * angles (angles_host frame-major).  Equals pylops.BlockDiag of the per-frame operators (io.py:391-420) but runs every
@@ -78,7 +80,9 @@ int trk_radon2d_dynamic_create(int N, int n_det, const double* angles_host, int 
 
 /* Fan-beam (flat detector) line projector and matched adjoint: astra 'fanflat' geometry + 'line_fanflat' projector of
  * trips/test_problems/Tomography.py:53-88 (p = int(sqrt(2) nx) detector pixels of pitch (SOD+ODD)/SOD, SOD = 3 nx,
- * ODD = nx).  Weights = ray / pixel intersection lengths.  Sinogram (n_ang, n_det) row-major.  PARITY UNPINNED. */
+ * ODD = nx).  Weights = ray / pixel intersection lengths.  Sinogram (n_ang, n_det) row-major.  Pinned to the two ASTRA outputs of
+ * this geometry the reference holds as rendered images (demos/demo_Tomo_small_scale.ipynb:145,179; tests/golden/
+ * fanbeam_demo_image.npz): correlation 0.9999 with the sinogram, 0.985 with the matrix image, mirrored conventions <= 0.95. */
 int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double source_origin, double origin_detector,
                          const double* angles_host, int n_ang, trk_op** out);
 
@@ -167,6 +171,16 @@ int trk_isotv_weights(const float* x, int N, int nt, const float* u_tail, int64_
  * w == NULL: unit weights (lam * L^T L x, the regularisation term of the GKS residual, GKS.py:81-84); r_in == NULL: 0.
  * out must not alias x or r_in.  Products and sums are rounded as in the separate kernels. */
 int trk_tv_weights(trk_op* L, const float* x, double eps, double q, float* w, trk_stream stream);
+/* Time-sharded space-time operator (trk_spacetime_create with has_next / has_prev): the temporal rows x_t - x_{t+1}
+ * (trips/utilities/operators.py:39-45) couple a rank's first / last frame with ONE frame of each neighbour rank.  Give the NEXT
+ * fused call on this handle (trk_tv_weights / trk_tv_grad / trk_tv_grad_dot) its operand's neighbour frames — the previous rank's
+ * LAST frame and the next rank's FIRST frame of the same vector, N*N floats each, NULL where there is no neighbour — and the rank
+ * forms its own pixels of L^T (w .* L x) completely with the same kernel one rank runs: one two-sided exchange of x
+ * (trk_halo_exchange2) per operand instead of one exchange of rows of L x per direction of L.  The frames must stay valid until
+ * that call has completed on its stream; the call consumes them.  Weight layout of a sharded handle (trk_tv_weights out,
+ * trk_tv_grad in): nt_local * 2N(N-1) spatial | rows 0 .. nt_local-2 | row nt_local-1 (has_next) | the previous rank's boundary
+ * row (has_prev: recomputed from the halo, the same bits as on the rank that owns it), N*N floats each. */
+int trk_tv_halo(trk_op* L, const float* x_prev_last_dev, const float* x_next_first_dev);
 int trk_tv_grad(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, trk_stream stream);
 /* trk_tv_grad that also leaves *dot_out = <out, dotv> (dotv: a vector of the image's length): GKS needs r . L^T L r next to
  * z = L^T L r for the Gram row of the next basis vector (GKS.py:92-96 through the Gram form) — no pass over r and z of its own. */
@@ -541,6 +555,11 @@ int trk_allreduce_f64(trk_comm* comm, double* dev, int count, trk_stream stream)
  * pointer is NULL or its rank outside [0, world): the first / last frame block has one neighbour only). */
 int trk_halo_exchange(trk_comm* comm, const float* send, int send_to, float* recv, int recv_from, int64_t count,
                       trk_stream stream);
+/* Both neighbours in one RCCL group: send_prev -> rank-1 and recv_prev <- rank-1 (rank > 0), send_next -> rank+1 and
+ * recv_next <- rank+1 (rank < world-1), `count` floats each; buffers of a neighbour that does not exist are ignored.  The
+ * exchange behind trk_tv_halo (the boundary frames of a time-sharded vector, operators.py:39-45). */
+int trk_halo_exchange2(trk_comm* comm, const float* send_prev, float* recv_prev, const float* send_next, float* recv_next,
+                       int64_t count, trk_stream stream);
 
 /* ---- CGLS with ONE all-reduce per iteration, for unknowns spread over ranks (csrc/cgls_sharded.hip) ----
  * The recurrence of trips/solvers/CGLS.py:56-80 needs two global sums per iteration, ||A p||^2 (:61) and ||A^T r||^2 (:70), the

@@ -17,11 +17,19 @@ Pinning status
     restates its published algorithm (correlate with the mirrored kernel, origin
     shifted for even sizes, half-sample-symmetric 'reflect' extension) from scratch,
     and the two are checked against each other and against the goldens.
-  * Radon (parallel beam): PARITY UNPINNED.  The arithmetic lives in astra-toolbox
-    (un-pinned, setup.py:11; not installable here; the reference has no test or
-    reproducible output at that boundary).  `Radon2D` follows the call-site contract
-    of trips/utilities/io.py:392-399 with a Joseph (linear-interpolation) projector;
-    it is pinned only by the adjoint identity and analytic line integrals.
+  * Radon (parallel beam): the arithmetic lives in astra-toolbox (un-pinned, setup.py:11;
+    not installable here).  `Radon2D` follows the call-site contract of
+    trips/utilities/io.py:392-399 with a Joseph (linear-interpolation) projector.
+    PINNED: its CONVENTION — rotation sense, detector order, (views, detectors) layout,
+    row-major image — to the two ASTRA outputs the reference holds as rendered images
+    (demos/demo_Tomo_small_scale.ipynb:145,179, decoded into
+    tests/golden/fanbeam_demo_image.npz), through the fan-beam operator whose far-source
+    limit it is (tests/test_oracle_golden.py: correlation 0.9999 with the ASTRA sinogram,
+    every mirrored convention <= 0.95; parallel vs far-source fan: 1e-3, the two
+    interpolation models); the adjoint identity, analytic line integrals and the
+    axis-aligned views.  NOT pinned: the interpolation weights against ASTRA's own
+    numbers (no parallel-beam output exists in the reference) — they follow Joseph's
+    published kernel.
   * MMGKS isoTV weights (MMGKS.py:61-77): PARITY UNPINNED in the one piece that lives in
     PyLops (un-pinned, setup.py:6; absent): `pylops.FirstDerivative`'s centered stencil is
     restated from its published definition.  Everything around it (reshape, exponent,
@@ -204,7 +212,7 @@ def gauss_psf_1d(n, sigma):
 
 # =====================================================================================
 # a3  parallel-beam Radon, Joseph / 'linear'              trips/utilities/io.py:392-400
-#     PARITY UNPINNED (see module docstring)
+#     convention pinned to the reference's ASTRA images, weights = Joseph's published kernel (see module docstring)
 # =====================================================================================
 class Radon2D(_Op):
     """Sinogram (n_ang, n_det) row-major <- image (N, N) row-major, times `scale` (=1/N at io.py:397).
@@ -946,7 +954,7 @@ def gmres(A, b, n_iter=3):
 
 
 # =====================================================================================
-# SURVEY §8f rank 1 — fan-beam line projector (PARITY UNPINNED, like Radon2D)
+# SURVEY §8f rank 1 — fan-beam line projector (pinned to the reference's two rendered ASTRA outputs: tests/test_oracle_golden.py)
 # =====================================================================================
 class FanBeam2D(_Op):
     """astra 'fanflat' + 'line_fanflat' of trips/test_problems/Tomography.py:53-88, restated by brute force: the weight of

@@ -78,6 +78,7 @@ class CpuEngine:
         self.world = 1 if comm is None else comm.world
         self.rank = 0 if comm is None else comm.rank
         self.reduction_points = 0
+        self.halo_exchanges = 0
 
     def empty(self, n):
         return torch.zeros(int(n), dtype=torch.float32)

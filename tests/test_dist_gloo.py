@@ -87,6 +87,94 @@ class ShardedSpaceTime:
         return out.reshape(-1)
 
 
+def _as_fused_operator(fused, plain_op):
+    """An OracleOp (so that as_operator() takes it as it is) carrying the fused surface of `fused`."""
+    for name in ("streaming", "fused_tv", "sharded", "npix", "tv_weights_len", "halo_frames", "tv_weights", "tv_grad", "N"):
+        setattr(plain_op, name, getattr(fused, name))
+    return plain_op
+
+
+class FusedShardedSpaceTime:
+    """Test adapter with the product's FUSED surface for a time-sharded space-time regulariser (operators.SpaceTimeDerivative:
+    streaming / fused_tv / sharded, halo_frames, tv_weights, tv_grad with `halo=`): the stencil itself is the oracle's operator over
+    this rank's frames extended by the neighbour ranks' boundary frames; the exchange is the product's TorchComm.exchange2.  What is
+    under test is the solvers' halo bookkeeping (solvers/GKS._HaloTrack: x = V y and v_new from the basis vectors' halos, ONE
+    exchange per iteration) — the HIP kernel with halos meets the same solves in tests/test_gpu_dist.py."""
+    streaming = True
+    fused_tv = True
+
+    def __init__(self, N, nt, eng, plain):
+        from oracle import cpu_ref as O
+        self.N, self.engine, self.plain = N, eng, plain
+        self.npix = N * N
+        self.ntl, self.has_next, self.has_prev = plain.ntl, plain.has_next, plain.has_prev
+        self.sharded = eng.world > 1
+        self.shape = plain.shape
+        self.tv_weights_len = self.shape[0] + (self.npix if self.has_prev else 0)
+        self.nte = self.ntl + int(self.has_prev) + int(self.has_next)
+        self.Le = O.SpaceTimeDerivative(N, self.nte)
+        self.ps = plain.ps
+        self._xh = torch.zeros(2 * self.npix, dtype=torch.float32)
+
+    # what solvers use of an operator besides the fused forms
+    def apply(self, x, out=None, transpose=False, sumsq=None):
+        return self._op.apply(x, out=out, transpose=transpose, sumsq=sumsq)
+
+    def halo_frames(self, x, out=None):
+        eng, npix = self.engine, self.npix
+        out = self._xh if out is None else out
+        eng.halo_exchanges += 1
+        if eng.world > 1:
+            eng.comm.exchange2(x[:npix], out[:npix], x[(self.ntl - 1) * npix:self.ntl * npix], out[npix:2 * npix])
+        return out
+
+    def _extended(self, x, halo):
+        if self.sharded and halo is None:
+            halo = self.halo_frames(x)
+        parts = ([halo[:self.npix].numpy().astype(np.float64)] if self.has_prev else []) + [x.numpy().astype(np.float64)] \
+            + ([halo[self.npix:].numpy().astype(np.float64)] if self.has_next else [])
+        return np.concatenate(parts)
+
+    def _rows(self, w):
+        """This rank's weight layout [spatial | own temporal rows | previous rank's boundary row] -> the extended operator's rows
+        (the spatial rows of the neighbour frames never reach a local pixel: any weight)."""
+        w = w.numpy().astype(np.float64)
+        npix, ps, ntl = self.npix, self.ps, self.ntl
+        spat, temp = w[:ntl * ps], w[ntl * ps:]
+        own = temp[:(ntl - 1 + int(self.has_next)) * npix]
+        prev_row = temp[len(own):len(own) + npix] if self.has_prev else np.zeros(0)
+        pad = np.zeros(ps)
+        return np.concatenate(([pad] if self.has_prev else []) + [spat] + ([pad] if self.has_next else [])
+                              + ([prev_row] if self.has_prev else []) + [own])
+
+    def _local(self, full):
+        lo = self.npix if self.has_prev else 0
+        return full[lo:lo + self.ntl * self.npix]
+
+    def tv_weights(self, x, eps, q, out, halo=None):
+        y = self.Le._fwd(self._extended(x, halo))
+        w = (y ** 2 + eps ** 2) ** (q / 2 - 1)
+        ps, npix, ntl = self.ps, self.npix, self.ntl
+        s0 = ps if self.has_prev else 0
+        spat = w[s0:s0 + ntl * ps]
+        temp = w[self.nte * ps:].reshape(self.nte - 1, npix)
+        t0 = 1 if self.has_prev else 0
+        own = temp[t0:t0 + ntl - 1 + int(self.has_next)].reshape(-1)
+        prev_row = temp[0] if self.has_prev else np.zeros(0)
+        out[:self.tv_weights_len].copy_(torch.from_numpy(np.concatenate((spat, own, prev_row)).astype(np.float32)))
+
+    def tv_grad(self, x, w, r_in, lam, out, dot_with=None, dot_out=None, halo=None):
+        from cpu_engine import _put
+        y = self.Le._fwd(self._extended(x, halo))
+        if w is not None:
+            y = y * self._rows(w)
+        g = self._local(self.Le._adj(y))
+        res = (0.0 if r_in is None else r_in.numpy().astype(np.float64)) + lam * g
+        out.copy_(torch.from_numpy(res.astype(np.float32)))
+        if dot_with is not None:
+            _put(dot_out, float(out.double() @ dot_with.double()))
+
+
 def _solve_all(eng):
     """CGLS, GKS and MMGKS on this rank's shard; returns the local slices of the three solutions + info scalars."""
     from cpu_engine import OracleOp
@@ -120,6 +208,20 @@ def _solve_all(eng):
     out["cgls_one_nohist"] = (x.reshape(-1), np.array(info["relResidual"]))
     x, info = S.GKS(F, bl, L, 3, 6, 1e-2, xl)
     out["gks"] = (x.reshape(-1), np.array(info["Residual"]))
+    # the FUSED space-time forms, time-sharded: the kernels' surface of the one-rank solve on every rank, one neighbour exchange per
+    # iteration (counted between a 4- and a 6-iteration solve: the start basis costs exchanges of its own)
+    Lf = FusedShardedSpaceTime(N, nt, eng, st)
+    Lf = _as_fused_operator(Lf, OracleOp(_L, eng))
+    cnt = []
+    for its in (4, 6):
+        h0, c0 = eng.halo_exchanges, 0 if calls is None else calls["allreduce"]
+        x, info = S.GKS(F, bl, Lf, 3, its, 1e-2, xl)
+        cnt.append((eng.halo_exchanges - h0, (0 if calls is None else calls["allreduce"]) - c0))
+    out["gks_fused"] = (x.reshape(-1), np.array(info["Residual"]))
+    out["gks_fused_counts"] = (np.array([(cnt[1][0] - cnt[0][0]) / 2.0, (cnt[1][1] - cnt[0][1]) / 2.0, float(info.get("fused_tv", True))]),
+                               np.zeros(1))
+    x, info = S.MMGKS(F, bl, Lf, 2, 1, 3, 6, 1e-2, xl)
+    out["mmgks_fused"] = (x.reshape(-1), np.array(info["Residual"]))
     x, info = S.MMGKS(F, bl, L, 2, 1, 3, 6, 1e-2, xl)
     out["mmgks"] = (x.reshape(-1), np.array(info["Residual"]))
     x, info = S.Hybrid_LSQR(F, bl, 8, 1e-2, xl)
@@ -171,7 +273,12 @@ def test_sharded_solvers_match_single_process():
         assert np.linalg.norm(p["cgls_x"] - p["cgls_two_x"]) / np.linalg.norm(p["cgls_two_x"]) < 1e-5
         assert np.allclose(p["cgls_s"], p["cgls_two_s"], rtol=1e-5) and np.allclose(p["cgls_relerr_x"], p["cgls_two_relerr_x"], rtol=1e-5)
         assert np.array_equal(p["cgls_one_nohist_x"], p["cgls_x"])
-    for key in ("cgls", "cgls_two", "gks", "mmgks", "lsqr"):
+    # fused space-time forms on ranks: ONE neighbour exchange per GKS iteration, no more all-reduces than the plain form, and the
+    # result of the single-process fused solve
+    for p in parts:
+        assert p["gks_fused_counts_x"][0] == 1.0 and p["gks_fused_counts_x"][2] == 1.0, p["gks_fused_counts_x"]
+        assert p["gks_fused_counts_x"][1] <= 4.0, p["gks_fused_counts_x"]
+    for key in ("cgls", "cgls_two", "gks", "mmgks", "lsqr", "gks_fused", "mmgks_fused"):
         x = np.concatenate([p[f"{key}_x"] for p in parts])
         rx = ref[key][0]
         err = np.linalg.norm(x - rx) / np.linalg.norm(rx)

@@ -3,10 +3,16 @@ box's host; C2 and C4's operator are covered at full size by test_gpu_cgls.py / 
 
 Bars = north_star's 1e-5 on every solution the solvers converge to, with ONE stated exception: iterates 5..19 of Hybrid-LSQR at
 lambda = 1e-2.  There the projected Tikhonov solution x_k = V_k y_k passes through its semi-convergence transient and is
-sensitive to the 6e-8 roundings of ANY fp32-stored iteration: the float64 oracle itself, re-run with nothing changed but its
-operator products rounded to float32 (tools/fp32_floor.py, CPU only), leaves the float64 run by 3.5e-4 at step 9 and returns to
-7.9e-7 by step 20.  The engine: 1.6e-3 at step 7, 2.1e-6 at step 20, <= 8.4e-7 from step 21 on, 1.8e-7 at step 60
-(tools/configs_parity.py on the MI355X, round 3).  The projector itself is within 1e-7 of the oracle (test_gpu_radon_accuracy.py)."""
+sensitive to the 6e-8 roundings of ANY fp32-stored iteration.  Shown, not argued (round 4, profiles/r04/c3_parity_epilogue.txt):
+  * the ENGINE'S OWN arrangement restated in NumPy (Golub-Kahan on unnormalised vectors + damped LSQR's short recurrence:
+    tools/fp32_floor.py c3emul) agrees with the oracle to 9e-8 in float64 arithmetic; with nothing changed but a rounding to
+    float32 where the engine STORES u, v, w, x it leaves the oracle by 3.6e-4 at iterate 9 (5.0e-4 with the operator's output
+    rounded once more), and from iterate 10 on by the very numbers the engine measures (2.9e-4, 1.7e-4, 8.9e-5, 4.1e-5);
+  * the engine: 1.06e-3 at iterate 8 — twice that floor.  Round 3 had 1.57e-3 at iterate 7: the half steps were combined in
+    trk_axpby's fp32 arithmetic (rounded coefficients, the same perturbation in every entry of a Lanczos vector); combined in
+    float64 that iterate is at 3.5e-4.  What is left above the floor is the projector's own fp32 accumulation, which the
+    restatement does not model.
+From iterate 21 on <= 8.4e-7, 1.8e-7 at step 60.  The projector itself is within 1e-7 of the oracle (test_gpu_radon_accuracy.py)."""
 import numpy as np
 import pytest
 
@@ -17,7 +23,7 @@ pytestmark = pytest.mark.gpu
 # bars: set from measurements on the MI355X (tools/configs_parity.py) and the fp32-storage floor of the oracle itself
 # (tools/fp32_floor.py) — see DESIGN.md section 2
 C3_BAR = 1e-5              # final iterate, every iterate from step 21 on, relError of those (measured 1.8e-7 ... 8.4e-7)
-C3_TRANSIENT_BAR = 5e-3    # iterates 1..20: the reference algorithm's own fp32 sensitivity (floor 3.5e-4, measured 1.6e-3)
+C3_TRANSIENT_BAR = 2.5e-3  # iterates 1..20: fp32 storage of this arrangement (NumPy restatement: 5.0e-4; engine 1.06e-3; round 3: 1.6e-3)
 C5_BAR = 1e-5              # measured 6e-8 ... 1.2e-7 on every iterate, relError 3e-9
 C5_RESIDUAL_BAR = 1e-5     # measured 1.9e-7
 

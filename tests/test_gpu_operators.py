@@ -104,7 +104,7 @@ def test_blockdiag_frames():
     assert np.isclose(S.host()[0], float((out.double() ** 2).sum()), rtol=1e-8)
 
 
-# ----------------------------------------------------------------------------------------------- Radon (parity unpinned)
+# ----------------------------------------------------------------------- Radon (convention pinned via the fan-beam images; weights: Joseph)
 @pytest.mark.parametrize("N,na,nd", [(32, 12, 32), (64, 45, 64), (64, 45, 40), (96, 30, 140), (256, 180, 256), (257, 33, 301)])
 def test_radon_vs_oracle_convention(N, na, nd):
     """The HIP projector against the oracle's sparse-matrix Joseph projector on the same inputs.  The oracle itself is
@@ -267,7 +267,7 @@ def test_framelet_operator_matches_reference():
 
 @pytest.mark.parametrize("N,na", [(16, 7), (34, 12), (50, 20), (132, 24)])
 def test_fanbeam_vs_bruteforce_oracle(N, na):
-    """Fan-beam line projector (parity unpinned vs ASTRA): the HIP traversal / gather kernels against the
+    """Fan-beam line projector (pinned to the reference's ASTRA images in the test below): the HIP traversal / gather kernels against the
     oracle's brute-force ray-pixel clipping, plus the geometry defaults of Tomography.define_proj_id."""
     from oracle import cpu_ref as O
     from trips_py_amd.operators import FanBeam2D
@@ -413,6 +413,7 @@ def test_radon_fused_half_step_equals_apply_then_axpby(case):
     S = eng.scalars(8)
     S.set(0, np.array([3.7, 0.61, 0, 0, 0, 0, 0, 0]))
     ca, cb = Coef(1.0, den=S.ref(0), sqrt_den=True), Coef(-1.0, num=S.ref(0), den=S.ref(1), sqrt_num=True, sqrt_den=True)
+    ca_abs, cb_abs = 1.0 / np.sqrt(3.7), np.sqrt(3.7) / np.sqrt(0.61)
     for tr, xin, z in ((False, x, zy), (True, y, zx)):
         nout = n if tr else m
         t, want, got = eng.empty(nout), eng.empty(nout), eng.empty(nout)
@@ -420,9 +421,12 @@ def test_radon_fused_half_step_equals_apply_then_axpby(case):
         for zz, bb in ((z, cb), (None, 0.0)):
             eng.axpby(ca, t, bb, zz, want, sumsq=S.ref(2))
             A.apply_axpby(xin, ca, bb, zz, got, transpose=tr, sumsq=S.ref(3))
-            assert torch.equal(got, want), (tr, zz is None)
+            # the projector combines in float64 (one rounding of a Op(x) + b z), trk_axpby in fp32 with rounded coefficients:
+            # equal to a unit in the last place of the larger operand (TRK_RADON_EPI_F32=1: to the bit)
+            tol = 2.0 ** -22 * (float(ca_abs) * t.abs() + (0 if zz is None else float(cb_abs) * zz.abs())) + 1e-30
+            assert bool(((got - want).abs() <= tol).all()), (tr, zz is None, float((got - want).abs().max()))
             s = S.host(2, 4)
-            assert abs(s[0] - s[1]) <= 1e-12 * s[0]
+            assert abs(s[0] - s[1]) <= 1e-6 * s[0]
             A.apply_axpby(xin, ca, bb, zz, got, transpose=tr, sumsq=S.ref(4))      # run to run: the same bits
             assert S.host(4, 5)[0] == s[1]
     # chain with hints: u1 = A x ; v1 = A^T u1 (records from the forward) ; u2 = A v1 (transposed copy from the adjoint)

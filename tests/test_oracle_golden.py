@@ -284,7 +284,7 @@ def test_regparam_functions():
     assert np.isclose(O.gcv_choose(Qb, np.diag(s), np.eye(k), g["bhat"], "modified", int(g["fullsize"])), float(g["lam_gcv_mod"]), rtol=1e-6)
 
 
-# ------------------------------------------------------------------ Radon: parity unpinned -> invariants
+# ------------------------------------------------------------------ Radon: invariants (its convention is pinned further down)
 def test_radon_oracle_invariants():
     N = 32
     ang = np.linspace(0, np.pi, 12, endpoint=False)
@@ -320,7 +320,7 @@ def test_oneshot_solvers():
 
 
 def test_fanbeam_oracle_invariants():
-    """Fan-beam oracle (parity unpinned): exact adjoint by construction; every ray's weights sum to its chord through the
+    """Fan-beam oracle (pinned to the reference's ASTRA images in test_fanbeam_oracle_matches_the_reference_demo_images): exact adjoint by construction; every ray's weights sum to its chord through the
     image square; geometry defaults of Tomography.define_proj_id (Tomography.py:48-60)."""
     N = 16
     A = O.FanBeam2D(N, np.linspace(0, np.pi, 6, endpoint=False))

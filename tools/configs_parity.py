@@ -9,7 +9,13 @@ sys.path.insert(0, REPO)
 sys.path.insert(0, os.path.join(REPO, "tests"))
 import test_gpu_configs_fullsize as T  # noqa: E402
 
-for name, fn, its in (("c3", T.c3_numbers, (20, 60)), ("c5", T.c5_numbers, (8, 20))):
+which = sys.argv[1:] or ["c3", "c5"]          # e.g. `configs_parity.py c3:60` for one case
+jobs = []
+for w in which:
+    name, _, k = w.partition(":")
+    fn, dflt = {"c3": (T.c3_numbers, (20, 60)), "c5": (T.c5_numbers, (8, 20))}[name]
+    jobs.append((name, fn, (int(k),) if k else dflt))
+for name, fn, its in jobs:
     for k in its:
         m = fn(k)
         m["iterates_max"] = max(m["iterates"])

@@ -163,6 +163,7 @@ SIGNATURES = {
     "trk_isotv_weights": (c_int, [c_f32p, c_int, c_int, c_f32p, c_i64, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_tv_weights": (c_int, [c_op, c_f32p, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_tv_grad": (c_int, [c_op, c_f32p, c_f32p, c_f32p, c_dbl, c_f32p, c_stream]),
+    "trk_tv_halo": (c_int, [c_op, c_f32p, c_f32p]),
     "trk_tv_grad_dot": (c_int, [c_op, c_f32p, c_f32p, c_f32p, c_dbl, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_mm_weights": (c_int, [c_i64, c_f32p, c_f32p, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_cgls_update_xr": (c_int, [c_i64, c_i64, c_f64p, c_f64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_stream]),
@@ -248,6 +249,7 @@ SIGNATURES = {
     "trk_comm_destroy": (c_int, [ctypes.c_void_p]),
     "trk_allreduce_f64": (c_int, [ctypes.c_void_p, c_f64p, c_int, c_stream]),
     "trk_halo_exchange": (c_int, [ctypes.c_void_p, c_f32p, c_int, c_f32p, c_int, c_i64, c_stream]),
+    "trk_halo_exchange2": (c_int, [ctypes.c_void_p, c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_stream]),
     "trk_dot_pair": (c_int, [c_f32p, c_f32p, c_i64, c_f64p, c_stream]),
     "trk_cgls_sharded_update": (c_int, [c_i64, c_i64, c_f64p, c_f64p, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p,
                                         c_f32p, c_f32p, c_f64p, c_f64p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),

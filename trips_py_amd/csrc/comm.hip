@@ -180,4 +180,35 @@ int trk_halo_exchange(trk_comm* c, const float* send, int send_to, float* recv, 
   return TRK_OK;
 }
 
+// Both neighbours in ONE group: what a fused space-time stencil needs of a time-sharded vector is its two boundary frames
+// (operators.py:39-45 couples frame t with t+1 only) — one exchange per vector instead of one per direction of L.
+int trk_halo_exchange2(trk_comm* c, const float* send_prev, float* recv_prev, const float* send_next, float* recv_next, int64_t count,
+                       trk_stream st) {
+  TRK_REQUIRE(c && count >= 0, "trk_halo_exchange2: bad argument");
+  const bool hp = c->rank > 0, hn = c->rank < c->world - 1;
+  TRK_REQUIRE((!hp || (send_prev && recv_prev)) && (!hn || (send_next && recv_next)), "trk_halo_exchange2: NULL buffer for an existing neighbour");
+  if (count == 0 || (!hp && !hn)) return TRK_OK;
+  TRK_NCCL(g_rccl.GroupStart());
+  ncclResult_t first = ncclSuccess;
+  const char* what = "";
+  auto step = [&](ncclResult_t r, const char* w) {
+    if (first == ncclSuccess && r != ncclSuccess) {
+      first = r;
+      what = w;
+    }
+  };
+  if (hp) {
+    step(g_rccl.Send(send_prev, (size_t)count, ncclFloat32, c->rank - 1, c->comm, (hipStream_t)st), "ncclSend");
+    if (first == ncclSuccess) step(g_rccl.Recv(recv_prev, (size_t)count, ncclFloat32, c->rank - 1, c->comm, (hipStream_t)st), "ncclRecv");
+  }
+  if (hn && first == ncclSuccess) {
+    step(g_rccl.Send(send_next, (size_t)count, ncclFloat32, c->rank + 1, c->comm, (hipStream_t)st), "ncclSend");
+    if (first == ncclSuccess) step(g_rccl.Recv(recv_next, (size_t)count, ncclFloat32, c->rank + 1, c->comm, (hipStream_t)st), "ncclRecv");
+  }
+  step(g_rccl.GroupEnd(), "ncclGroupEnd");        // always ended: an open group would swallow every later collective of the process
+  if (first != ncclSuccess)
+    return fail(TRK_ENCCL, "trk_halo_exchange2: %s -> %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(first) : "RCCL error");
+  return TRK_OK;
+}
+
 }  // extern "C"

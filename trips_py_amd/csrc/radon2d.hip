@@ -1,9 +1,10 @@
 // radon2d.hip — parallel-beam Radon transform (Joseph / linear-interpolation projector) and its matched adjoint.
 //
 // Replaces astra.OpTomo over create_proj_geom('parallel', 1, N, theta) + create_projector('linear', ...) and the
-// 1/N scaling of trips/utilities/io.py:392-399.  PARITY UNPINNED: astra-toolbox is not installable in the build image
-// and the reference holds no reproducible output at that boundary; the convention below is the one recorded in
-// oracle/cpu_ref.py (Radon2D) and is pinned by the adjoint identity and analytic line integrals.
+// 1/N scaling of trips/utilities/io.py:392-399.  astra-toolbox is not installable in the build image; the convention below
+// (oracle/cpu_ref.py, Radon2D) is pinned to the ASTRA outputs the reference holds as images — through the fan-beam operator whose
+// far-source limit this one is (tests/test_oracle_golden.py, tests/test_gpu_operators.py) — and by the adjoint identity, analytic
+// line integrals and the axis-aligned views; the interpolation weights are Joseph's published kernel.
 //
 // Geometry: pixel (i,j) centre (x,y) = (j - h, h - i), h = (N-1)/2; detector bin d at s = d - (n_det-1)/2 along
 // (cos t, sin t); rays run along (sin t, -cos t).  Per angle one of two marching modes:
@@ -154,20 +155,33 @@ __device__ __forceinline__ double coef_eval_pend(const Coef& k, const double* ta
   return v;
 }
 // both coefficients of the epilogue (uniform over the grid; ends with every thread past a barrier when a norm is pending)
-__device__ __forceinline__ void epi_coefs(const Epi& e, bool first_block, double* lds1, float& ca, float& cb, double* total_out = nullptr) {
+__device__ __forceinline__ void epi_coefs(const Epi& e, bool first_block, double* lds1, float& ca, float& cb, double* total_out = nullptr,
+                                          double* cad = nullptr, double* cbd = nullptr) {
   ca = 1.f;
   cb = 0.f;
-  if (!e.on) return;
-  if (e.pend_target) {
-    const double total = pend_total(e, lds1);
-    if (total_out) *total_out = total;
-    ca = (float)coef_eval_pend(e.a, e.pend_target, total);
-    if (e.z) cb = (float)coef_eval_pend(e.b, e.pend_target, total);
-    if (first_block && threadIdx.x == 0) *e.pend_target = total;
-  } else {
-    ca = (float)coef_eval(e.a);
-    if (e.z) cb = (float)coef_eval(e.b);
+  double da = 1.0, db = 0.0;
+  if (e.on) {
+    if (e.pend_target) {
+      const double total = pend_total(e, lds1);
+      if (total_out) *total_out = total;
+      da = coef_eval_pend(e.a, e.pend_target, total);
+      if (e.z) db = coef_eval_pend(e.b, e.pend_target, total);
+      if (first_block && threadIdx.x == 0) *e.pend_target = total;
+    } else {
+      da = coef_eval(e.a);
+      if (e.z) db = coef_eval(e.b);
+    }
+    ca = (float)da;
+    cb = (float)db;
   }
+  if (cad) *cad = da;
+  if (cbd) *cbd = db;
+}
+// the epilogue's arithmetic: e.on == 2 (default) float64 coefficients and products, one rounding of the result; e.on == 1
+// (TRK_RADON_EPI_F32=1) that of trk_axpby — fp32 coefficients, one FMA: the fused half step equals apply + trk_axpby to the bit
+__device__ __forceinline__ float epi_combine(int on, float ca, float cb, double cad, double cbd, float o, float z, bool has_z) {
+  if (on == 2) return (float)(has_z ? fma(cad, (double)o, cbd * (double)z) : cad * (double)o);
+  return has_z ? fmaf(ca, o, cb * z) : ca * o;
 }
 
 // ---------------------------------------------------------------------------------------- transpose (LDS tile 32x33)
@@ -1026,8 +1040,9 @@ __global__ __launch_bounds__(256) void k_radon_bands_post(const float* __restric
     a32 = A32[row * ndp + e];
   }
   float ca, cb;
-  epi_coefs(epi, blockIdx.x == 0, &lds[0], ca, cb);
-  auto fin = [&](const Raw& v) -> float { return epi.on ? (epi.z ? fmaf(ca, v.o, cb * v.z) : ca * v.o) : v.o; };
+  double cad, cbd;
+  epi_coefs(epi, blockIdx.x == 0, &lds[0], ca, cb, nullptr, &cad, &cbd);
+  auto fin = [&](const Raw& v) -> float { return epi.on ? epi_combine(epi.on, ca, cb, cad, cbd, v.o, v.z, epi.z != nullptr) : v.o; };
   const bool inr = valid && d >= 0 && d < nd;
   const float v0 = inr ? fin(r0) : 0.f;
   if (inr) sino[row * nd + d] = v0;
@@ -1400,15 +1415,15 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
     lr[k] = (in && epi.lq.ref) ? epi.lq.ref[g] : 0.f;
   }
   float ca, cb;
-  double pend_sum = 0.0;
-  epi_coefs(epi, blockIdx.x == 0 && blockIdx.y == 0, &lds[0], ca, cb, &pend_sum);
+  double pend_sum = 0.0, cad, cbd;
+  epi_coefs(epi, blockIdx.x == 0 && blockIdx.y == 0, &lds[0], ca, cb, &pend_sum, &cad, &cbd);
   if (xT_out) xT_out += (int64_t)frame * N * N;
 #pragma unroll
   for (int k = 0; k < PX; ++k) {
     const int i = i0 + r1 + k * TS, j = j0 + c1;
     float o = (accB[k] + (anB[k][0] + anB[k][1])) + (PX > 1 ? xch[r1 + k * TS][c1] : accA[k] + (anA[k][0] + anA[k][1]));
     if (i < N && j < N) {
-      if (epi.on) o = epi.z ? fmaf(ca, o, cb * zv[k]) : ca * o;
+      if (epi.on) o = epi_combine(epi.on, ca, cb, cad, cbd, o, zv[k], epi.z != nullptr);
       img[(int64_t)i * N + j] = o;
       if (xT_out) xT_out[(int64_t)j * N + i] = o;
       q += (double)o * o;
@@ -1788,7 +1803,13 @@ int radon_apply_axpby(trk_op* op, int tr, const float* x, Coef a, Coef b, const 
     if (int rc = radon_run(op, tr, x, op->rows, out, op->cols, 1, nullptr, Epi{}, 0, s)) return rc;
     return trk_axpby(op->cols, a.c, a.num, a.den, a.flags, out, b.c, b.num, b.den, b.flags, z, out, sumsq, (trk_stream)s);
   }
-  return radon_run(op, tr, x, tr ? op->rows : op->cols, out, tr ? op->cols : op->rows, 1, sumsq, Epi{1, a, b, z, nullptr, nullptr, 0}, hints, s);
+  // The half step's combination a Op(x) + b z in float64 (coefficients as they are, one rounding of the result) — not in trk_axpby's
+  // fp32 arithmetic, whose rounded coefficients perturb EVERY entry of a Golub-Kahan vector the same way: un-reorthogonalised
+  // Lanczos amplified that 4.5 x at C3's semi-convergence transient (iterate 7 of Hybrid-LSQR at 512^2 x 180 against the float64
+  // oracle: 1.57e-3 -> 3.5e-4; profiles/r04/c3_parity_epilogue.txt).  The kernels that write the output are far from the vector
+  // unit's float64 rate.  TRK_RADON_EPI_F32=1 restores apply + trk_axpby to the bit.
+  static const int epi_mode = getenv("TRK_RADON_EPI_F32") ? 1 : 2;
+  return radon_run(op, tr, x, tr ? op->rows : op->cols, out, tr ? op->cols : op->rows, 1, sumsq, Epi{epi_mode, a, b, z, nullptr, nullptr, 0}, hints, s);
 }
 
 void radon_destroy(trk_op* op) {

@@ -173,23 +173,37 @@ __global__ __launch_bounds__(NT) void k_tv_weights(const float* __restrict__ x, 
   d2_fwd_body<false, true>(x + blockIdx.z * npix, w + blockIdx.z * ps, N, eps2, e, special, unused);
 }
 
-// temporal rows of the space-time operator: w_t = ((x_t - x_{t+1})^2 + eps^2)^e, t < nt - 1 (blockIdx.y = t)
-__global__ __launch_bounds__(NT) void k_tvt_weights(const float* __restrict__ x, int64_t npix, float eps2, float e, int special,
-                                                    float* __restrict__ wt) {
-  const float* a = x + (int64_t)blockIdx.y * npix;
-  float* o = wt + (int64_t)blockIdx.y * npix;
+// temporal rows of the space-time operator: w_t = ((x_t - x_{t+1})^2 + eps^2)^e (blockIdx.y = row).  Rows t < nt - 1 are inside the
+// rank's frames; with a time-sharded vector row nt - 1 (has_next) takes x_{t+1} from the next rank's first frame, and ONE more row —
+// the weight of the row the PREVIOUS rank owns, (its last frame) - x_0, which this rank's k_tv_grad needs for frame 0 — is
+// recomputed here from the halo: the same expression on the same two floats, the same bits as on the rank that owns it.
+__global__ __launch_bounds__(NT) void k_tvt_weights(const float* __restrict__ x, int64_t npix, int nt, float eps2, float e, int special,
+                                                    float* __restrict__ wt, const float* __restrict__ xprev,
+                                                    const float* __restrict__ xnext) {
+  const int r = blockIdx.y;
+  const float* a;
+  const float* b;
+  if (r < nt - 1) { a = x + (int64_t)r * npix; b = a + npix; }
+  else if (r == nt - 1 && xnext) { a = x + (int64_t)r * npix; b = xnext; }
+  else { a = xprev; b = x; }                                       // the previous rank's boundary row
+  float* o = wt + (int64_t)r * npix;
   for (int64_t idx = (int64_t)blockIdx.x * NT + threadIdx.x; idx < npix; idx += (int64_t)gridDim.x * NT)
-    o[idx] = mm_w(a[idx] - a[idx + npix], eps2, e, special);
+    o[idx] = mm_w(a[idx] - b[idx], eps2, e, special);
 }
 
-// nt > 1: the space-time operator (single rank).  blockIdx.z = frame; w = [nt x 2N(N-1) spatial | (nt-1) x N^2 temporal] as the rows
-// of L; the temporal part adds wt_t (x_t - x_{t+1}) - wt_{t-1} (x_{t-1} - x_t) to frame t.
+// nt > 1 or halos: the space-time operator.  blockIdx.z = frame; w = [nt x 2N(N-1) spatial | temporal rows x N^2] as the rows of L;
+// the temporal part adds wt_t (x_t - x_{t+1}) - wt_{t-1} (x_{t-1} - x_t) to frame t.  A time-sharded vector brings its neighbours'
+// boundary frames (xprev: the previous rank's last frame, xnext: the next rank's first; trk_tv_halo): frame 0 / nt - 1 then have
+// their temporal neighbours like any inner frame, and the rank forms ITS pixels of L^T (w .* L x) completely — the same kernel as on
+// one rank, no exchange of rows of L x.  Temporal weights: rows 0 .. nt-2 (+ row nt-1 with xnext), then the previous rank's
+// boundary row (with xprev), as k_tvt_weights lays them out.
 // DOT: also the block partial of <out, dotv> (GKS: r . L^T L r for the Gram row of the next basis vector, GKS.py:92-96 through the
 // Gram form — no pass over the two vectors of its own); every thread then stays to the end (the block sum's barriers).
 template <bool W, bool RIN, bool DOT = false>
 __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, const float* __restrict__ w,
                                                 const float* __restrict__ rin, float lam, float* __restrict__ out, int N, int nt,
-                                                const float* __restrict__ dotv = nullptr, double* __restrict__ dot_part = nullptr) {
+                                                const float* __restrict__ dotv = nullptr, double* __restrict__ dot_part = nullptr,
+                                                const float* __restrict__ xprev = nullptr, const float* __restrict__ xnext = nullptr) {
 #pragma clang fp contract(off)       // products and sums as written (HIP's __fmul_rn is a plain `*`): the same bits in every instantiation
   __shared__ double dred[DOT ? NT / 64 : 1];
   double dacc = 0.0;
@@ -198,7 +212,7 @@ __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, con
   const float* __restrict__ xf = x + f * npix;
   const float* __restrict__ wh = W ? w + f * ps : nullptr;
   const float* __restrict__ wv = W ? wh + (int64_t)N * (N - 1) : nullptr;
-  const float* __restrict__ wt = (W && nt > 1) ? w + nt * ps : nullptr;      // temporal weights, row t at wt + t npix
+  const float* __restrict__ wt = (W && (nt > 1 || xprev || xnext)) ? w + nt * ps : nullptr;      // temporal weights, row t at wt + t npix
   rin = RIN ? rin + f * npix : rin;
   out += f * npix;
   if (DOT) dotv += f * npix;
@@ -207,7 +221,13 @@ __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, con
   if (!DOT && !live) return;
   const int j = live ? jraw : N - 1;                             // (DOT: a thread beyond the image works on the last column, stores nothing)
   const bool hr = j < N - 1, hl = j > 0;
-  const bool tnext = nt > 1 && f < nt - 1, tprev = nt > 1 && f > 0;
+  // the frames after / before this one: inside the rank's block, or the neighbour rank's boundary frame
+  const float* __restrict__ xnf = (f < nt - 1) ? xf + npix : xnext;
+  const float* __restrict__ xpf = (f > 0) ? xf - npix : xprev;
+  const bool tnext = xnf != nullptr, tprev = xpf != nullptr;
+  // weight rows: row f couples f with f + 1; the row before frame 0 is the previous rank's, kept behind the rank's own rows
+  const int ntemp = nt - 1 + (xnext ? 1 : 0);
+  const int64_t wrow_prev = (f > 0) ? (int64_t)(f - 1) * npix : (int64_t)ntemp * npix;
   for (int i0 = blockIdx.y * RB; i0 < N; i0 += gridDim.y * RB) {
     const int64_t o0 = (int64_t)i0 * N + j;
     const int64_t h0 = (int64_t)i0 * (N - 1) + j;
@@ -231,10 +251,10 @@ __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, con
       wc[t] = W ? ((in && hr) ? wh[hb] : 0.f) : 1.f;
       wp[t] = W ? ((in && hl) ? wh[hb - 1] : 0.f) : 1.f;
       rr[t] = (RIN && in) ? rin[o] : 0.f;
-      xn[t] = (in && tnext) ? xf[o + npix] : 0.f;
-      xp[t] = (in && tprev) ? xf[o - npix] : 0.f;
+      xn[t] = (in && tnext) ? xnf[o] : 0.f;
+      xp[t] = (in && tprev) ? xpf[o] : 0.f;
       wn[t] = W ? ((in && tnext) ? wt[(int64_t)f * npix + o] : 0.f) : 1.f;
-      wq[t] = W ? ((in && tprev) ? wt[(int64_t)(f - 1) * npix + o] : 0.f) : 1.f;
+      wq[t] = W ? ((in && tprev) ? wt[wrow_prev + o] : 0.f) : 1.f;
     }
 #pragma unroll
     for (int t = 0; t < RB; ++t) {
@@ -315,6 +335,8 @@ struct STImpl {
   int N, nt, has_next, has_prev;
   const float* halo_next;  // first frame of the next rank (forward)
   const float* halo_prev;  // last temporal block of the previous rank (transpose)
+  const float* xh_prev;    // fused forms (trk_tv_halo): the previous rank's LAST frame of the vector the next fused call takes
+  const float* xh_next;    // ... and the next rank's FIRST frame
 };
 
 int st_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
@@ -372,42 +394,62 @@ int trk_deriv2d_create(int N, trk_op** out) {
 
 int trk_spacetime_create(int N, int nt_local, int has_next, int has_prev, trk_op** out) {
   TRK_REQUIRE(out && N >= 2 && nt_local >= 1, "trk_spacetime_create: need N >= 2 and nt_local >= 1");
-  auto* im = new STImpl{N, nt_local, has_next ? 1 : 0, has_prev ? 1 : 0, nullptr, nullptr};
+  auto* im = new STImpl{N, nt_local, has_next ? 1 : 0, has_prev ? 1 : 0, nullptr, nullptr, nullptr, nullptr};
   const int64_t npix = (int64_t)N * N, ps = 2 * (int64_t)N * (N - 1);
   const int ntemp = nt_local - 1 + (has_next ? 1 : 0);
   *out = new trk_op{4, (int64_t)nt_local * ps + (int64_t)ntemp * npix, (int64_t)nt_local * npix, im, st_apply, st_destroy, nullptr, 0};
   return TRK_OK;
 }
 
-// N and the frame count of a first-difference regulariser the fused TV forms serve: the 2-D operator, or the space-time operator
-// of one rank that owns the whole time axis (no halos)
-static int tv_geometry(trk_op* L, const char* who, int* N, int* nt) {
+// N and the frame count of a first-difference regulariser the fused TV forms serve: the 2-D operator or the space-time operator.
+// A time-sharded space-time handle needs the neighbours' boundary frames of the operand (trk_tv_halo, consumed by this call).
+struct TvGeo {
+  int N, nt;
+  const float *xprev, *xnext;
+};
+static int tv_geometry(trk_op* L, const char* who, TvGeo* g) {
+  g->xprev = g->xnext = nullptr;
   if (L->kind == 3) {
-    *N = static_cast<D2Impl*>(L->impl)->N;
-    *nt = 1;
+    g->N = static_cast<D2Impl*>(L->impl)->N;
+    g->nt = 1;
     return TRK_OK;
   }
   if (L->kind == 4) {
     auto* im = static_cast<STImpl*>(L->impl);
-    if (im->has_next || im->has_prev) return fail(TRK_EUNSUPPORTED, "%s: the time axis is sharded over ranks (halo rows): use the operator's apply", who);
-    *N = im->N;
-    *nt = im->nt;
+    if ((im->has_prev && !im->xh_prev) || (im->has_next && !im->xh_next))
+      return fail(TRK_EINVAL, "%s: the time axis is sharded over ranks: give the operand's boundary frames of the neighbour ranks with trk_tv_halo first", who);
+    g->N = im->N;
+    g->nt = im->nt;
+    g->xprev = im->has_prev ? im->xh_prev : nullptr;
+    g->xnext = im->has_next ? im->xh_next : nullptr;
+    im->xh_prev = im->xh_next = nullptr;             // they belong to ONE operand
     return TRK_OK;
   }
   return fail(TRK_EINVAL, "%s: L must come from trk_deriv2d_create or trk_spacetime_create", who);
 }
 
+int trk_tv_halo(trk_op* L, const float* x_prev_last, const float* x_next_first) {
+  TRK_REQUIRE(L && L->kind == 4, "trk_tv_halo: not a space-time operator");
+  auto* im = static_cast<STImpl*>(L->impl);
+  TRK_REQUIRE((!im->has_prev || x_prev_last) && (!im->has_next || x_next_first), "trk_tv_halo: NULL frame for an existing neighbour");
+  im->xh_prev = x_prev_last;
+  im->xh_next = x_next_first;
+  return TRK_OK;
+}
+
 int trk_tv_weights(trk_op* L, const float* x, double eps, double q, float* w, trk_stream st) {
   TRK_REQUIRE(L && x && w, "trk_tv_weights: NULL argument");
-  int N = 0, nt = 0;
-  if (int rc = tv_geometry(L, "trk_tv_weights", &N, &nt)) return rc;
+  TvGeo g;
+  if (int rc = tv_geometry(L, "trk_tv_weights", &g)) return rc;
+  const int N = g.N, nt = g.nt;
   const float e = (float)(q / 2.0 - 1.0), eps2 = (float)(eps * eps);
   const int special = (q == 2.0) ? 1 : (q == 1.0) ? 2 : 0;
   hipLaunchKernelGGL(k_tv_weights, grid2(N, nt, false).g, dim3(NT), 0, (hipStream_t)st, x, N, eps2, e, special, w);
-  if (nt > 1) {
+  const int rows = nt - 1 + (g.xnext ? 1 : 0) + (g.xprev ? 1 : 0);
+  if (rows > 0) {
     const int64_t npix = (int64_t)N * N;
-    hipLaunchKernelGGL(k_tvt_weights, dim3(grid_for(npix), nt - 1), dim3(NT), 0, (hipStream_t)st, x, npix, eps2, e, special,
-                       w + (int64_t)nt * 2 * N * (N - 1));
+    hipLaunchKernelGGL(k_tvt_weights, dim3(grid_for(npix), rows), dim3(NT), 0, (hipStream_t)st, x, npix, nt, eps2, e, special,
+                       w + (int64_t)nt * 2 * N * (N - 1), g.xprev, g.xnext);
   }
   TRK_LAUNCH_CHECK();
   return TRK_OK;
@@ -416,11 +458,12 @@ int trk_tv_weights(trk_op* L, const float* x, double eps, double q, float* w, tr
 int trk_tv_grad(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, trk_stream st) {
   TRK_REQUIRE(L && x && out, "trk_tv_grad: NULL argument");
   TRK_REQUIRE(out != x && out != r_in, "trk_tv_grad: out must not alias x or r_in");
-  int N = 0, nt = 0;
-  if (int rc = tv_geometry(L, "trk_tv_grad", &N, &nt)) return rc;
+  TvGeo gg;
+  if (int rc = tv_geometry(L, "trk_tv_grad", &gg)) return rc;
+  const int N = gg.N, nt = gg.nt;
   const dim3 g = grid2(N, nt, false).g;
   hipStream_t s = (hipStream_t)st;
-#define TG(W, R) hipLaunchKernelGGL((k_tv_grad<W, R>), g, dim3(NT), 0, s, x, w, r_in, (float)lam, out, N, nt)
+#define TG(W, R) hipLaunchKernelGGL((k_tv_grad<W, R>), g, dim3(NT), 0, s, x, w, r_in, (float)lam, out, N, nt, (const float*)nullptr, (double*)nullptr, gg.xprev, gg.xnext)
   if (w) { if (r_in) TG(true, true); else TG(true, false); }
   else   { if (r_in) TG(false, true); else TG(false, false); }
 #undef TG
@@ -432,14 +475,15 @@ int trk_tv_grad_dot(trk_op* L, const float* x, const float* w, const float* r_in
                     double* dot_out, trk_stream st) {
   TRK_REQUIRE(L && x && out && dotv && dot_out, "trk_tv_grad_dot: NULL argument");
   TRK_REQUIRE(out != x && out != r_in && out != dotv, "trk_tv_grad_dot: out must not alias x, r_in or dotv");
-  int N = 0, nt = 0;
-  if (int rc = tv_geometry(L, "trk_tv_grad_dot", &N, &nt)) return rc;
+  TvGeo gg;
+  if (int rc = tv_geometry(L, "trk_tv_grad_dot", &gg)) return rc;
+  const int N = gg.N, nt = gg.nt;
   const Grid2 g2 = grid2(N, nt, true);
   const int nblk = g2.per_frame * nt;
   hipStream_t s = (hipStream_t)st;
   double* part = nullptr;
   if (int rc = scratch_doubles(s, (size_t)nblk, &part)) return rc;
-#define TGD(W, R) hipLaunchKernelGGL((k_tv_grad<W, R, true>), g2.g, dim3(NT), 0, s, x, w, r_in, (float)lam, out, N, nt, dotv, part)
+#define TGD(W, R) hipLaunchKernelGGL((k_tv_grad<W, R, true>), g2.g, dim3(NT), 0, s, x, w, r_in, (float)lam, out, N, nt, dotv, part, gg.xprev, gg.xnext)
   if (w) { if (r_in) TGD(true, true); else TGD(true, false); }
   else   { if (r_in) TGD(false, true); else TGD(false, false); }
 #undef TGD

@@ -3,7 +3,8 @@ CPU tests).  The hot path has exactly two kinds of exchange when a dynamic probl
 
   * all-reduce(sum) of a handful of float64 scalars (inner products, Gram rows): latency-bound, so reductions of one
     synchronisation point share one call (SURVEY §8e);
-  * a one-frame halo shift between time-neighbours for the temporal rows of the space-time regulariser.
+  * the boundary frames of a vector between time-neighbours for the temporal rows of the space-time regulariser: ONE two-sided
+    exchange per operand of a fused stencil (`exchange2`), or a one-frame shift per direction of a plain L / L^T apply (`shift`).
 
 Everything else (operator applies, axpys, weights) is local to a rank's frames.
 """
@@ -49,6 +50,26 @@ class TorchComm:
                 req.wait()
         if do_recv and stage:
             recv.copy_(rbuf)
+
+    def exchange2(self, send_prev, recv_prev, send_next, recv_next):
+        """Both time-neighbours in ONE batch: send_prev -> rank-1 / recv_prev <- rank-1 (rank > 0), send_next -> rank+1 /
+        recv_next <- rank+1 (rank < world-1).  The boundary frames a fused space-time stencil needs of a sharded vector."""
+        hp, hn = self.rank > 0, self.rank < self.world - 1
+        pairs = ([(send_prev, recv_prev, self.rank - 1)] if hp else []) + ([(send_next, recv_next, self.rank + 1)] if hn else [])
+        ops, back = [], []
+        for snd, rcv, peer in pairs:
+            stage = self.host_staging and (snd.is_cuda or rcv.is_cuda)
+            sbuf = snd.detach().to("cpu") if stage else snd.contiguous()
+            rbuf = torch.empty(rcv.shape, dtype=rcv.dtype) if stage else rcv
+            ops.append(dist.P2POp(dist.isend, sbuf, self._global(peer), self.group))
+            ops.append(dist.P2POp(dist.irecv, rbuf, self._global(peer), self.group))
+            if stage:
+                back.append((rcv, rbuf))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+        for rcv, rbuf in back:
+            rcv.copy_(rbuf)
 
     def _global(self, group_rank):
         return group_rank if self.group is None else dist.get_global_rank(self.group, group_rank)
@@ -110,6 +131,19 @@ class RcclComm:
                                         None if recv is None else recv.data_ptr(), -1 if recv_from is None else int(recv_from),
                                         count, self._stream(ref))
         _lib.check(rc, "trk_halo_exchange")
+
+    def exchange2(self, send_prev, recv_prev, send_next, recv_next):
+        from . import _lib
+        hp, hn = self.rank > 0, self.rank < self.world - 1
+        if not (hp or hn):
+            return
+        ref = send_prev if hp else send_next
+        sp = send_prev.contiguous() if hp else None
+        sn = send_next.contiguous() if hn else None
+        rc = self.lib.trk_halo_exchange2(self._h, None if sp is None else sp.data_ptr(), recv_prev.data_ptr() if hp else None,
+                                         None if sn is None else sn.data_ptr(), recv_next.data_ptr() if hn else None,
+                                         ref.numel(), self._stream(ref))
+        _lib.check(rc, "trk_halo_exchange2")
 
     def barrier(self):
         if dist.is_initialized():

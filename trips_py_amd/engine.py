@@ -277,6 +277,7 @@ class HipEngine:
         self.world = 1 if comm is None else comm.world
         self.rank = 0 if comm is None else comm.rank
         self.reduction_points = 0           # calls of allreduce() (+ the all-reduces a C iteration loop enqueues itself)
+        self.halo_exchanges = 0             # neighbour exchanges of the time-sharded space-time regulariser (counted on one rank too)
 
     # ------------------------------------------------------------------ memory
     def empty(self, n):

@@ -296,9 +296,15 @@ class FirstDerivative2D(_FusedTV, _HandleOperator):
 
 
 class SpaceTimeDerivative(_FusedTV, _HandleOperator):
-    """Space-time first differences over this rank's `nt_local` frames.  With a sharded time axis the engine's
-    communicator moves one frame to the neighbour before each apply (forward: first frame of the next rank;
-    transpose: last temporal block of the previous rank)."""
+    """Space-time first differences over this rank's `nt_local` frames (trips/utilities/operators.py:39-45).
+
+    Time-sharded (engine.world > 1), two ways to meet the rows x_t - x_{t+1} that cross a rank boundary:
+      * the fused forms `tv_weights` / `tv_grad` (what GKS / MMGKS use; the kernels one rank runs): the operand's two boundary
+        frames of the neighbour ranks — `halo_frames(x)`, ONE two-sided exchange — and the rank forms its own pixels of
+        L^T (w .* L x) completely.  `halo=` takes frames the caller already has (GKS derives them for x = V y and v_new from the
+        basis vectors' halos: one exchange per iteration);
+      * plain `L @ x` / `L.T @ y`: one frame moves to the neighbour before each apply (forward: first frame of the next rank;
+        transpose: last temporal block of the previous rank)."""
 
     def __init__(self, N, nt, engine=None):
         engine = engine if engine is not None else default_engine()
@@ -313,17 +319,49 @@ class SpaceTimeDerivative(_FusedTV, _HandleOperator):
                    "trk_spacetime_create")
         super().__init__(h, engine)
         npix = self.N * self.N
+        self.npix = npix
         self._halo_next = engine.empty(npix) if self.has_next else None
         self._halo_prev = engine.empty(npix) if self.has_prev else None
+        self._xh = engine.empty(2 * npix) if w > 1 else None       # [previous rank's last frame | next rank's first frame]
         self._ps = 2 * self.N * (self.N - 1)
-        self.streaming = w == 1                        # sharded: every apply also pays a halo exchange
-        self.fused_tv = w == 1                         # ... and the fused forms have no halo rows
+        self.sharded = w > 1
+        self.streaming = True
+        self.fused_tv = True
+        # weights of the fused forms: the rows of L, plus (has_prev) the previous rank's boundary row recomputed here
+        self.tv_weights_len = self.shape[0] + (npix if self.has_prev else 0)
+
+    # ---- fused forms over a time-sharded vector
+    def halo_frames(self, x, out=None):
+        """The neighbour ranks' boundary frames of the time-sharded vector x, [prev's last | next's first] (2 N^2 floats; a half
+        without a neighbour is left as it is): ONE two-sided exchange."""
+        eng, npix = self.engine, self.npix
+        out = self._xh if out is None else out
+        eng.halo_exchanges += 1
+        if eng.world > 1:
+            eng.comm.exchange2(x[:npix], out[:npix], x[(self.nt_local - 1) * npix:self.nt_local * npix], out[npix:2 * npix])
+        return out
+
+    def _give_halo(self, x, halo):
+        if not self.sharded:
+            return
+        hf = self.halo_frames(x) if halo is None else halo
+        _lib.check(self.engine.lib.trk_tv_halo(self._h, hf.data_ptr() if self.has_prev else None,
+                                               hf[self.npix:].data_ptr() if self.has_next else None), "trk_tv_halo")
+
+    def tv_weights(self, x, eps, q, out, halo=None):
+        self._give_halo(x, halo)
+        super().tv_weights(x, eps, q, out)
+
+    def tv_grad(self, x, w, r_in, lam, out, dot_with=None, dot_out=None, halo=None):
+        self._give_halo(x, halo)
+        super().tv_grad(x, w, r_in, lam, out, dot_with=dot_with, dot_out=dot_out)
 
     def _apply(self, x2, y2, transpose, sumsq):
         eng = self.engine
         if eng.world > 1:
             if x2.shape[0] != 1:
                 raise NotImplementedError("sharded space-time operator applies one vector at a time")
+            eng.halo_exchanges += 1
             spacetime_halo_exchange(eng, x2[0], transpose, self.N, self.nt_local, self._halo_next, self._halo_prev)
             _lib.check(eng.lib.trk_spacetime_set_halo(self._h, None if self._halo_next is None else self._halo_next.data_ptr(),
                                                       None if self._halo_prev is None else self._halo_prev.data_ptr()),

@@ -24,6 +24,46 @@ import os as _os
 _TVDOT = _os.environ.get("TRK_GKS_TVDOT", "1") != "0"       # r . L^T L r from the pass that forms L^T L r (trk_tv_grad_dot)
 
 
+class _HaloTrack:
+    """Time-sharded space-time regulariser: the neighbour ranks' boundary frames ("halo", [prev's last | next's first]) of every
+    basis vector.  The fused stencil L^T L x needs them of its operand (operators.SpaceTimeDerivative.tv_grad, trk_tv_halo);
+    everything the solver hands to it is a combination of vectors whose halos are known here:
+        x = V y            ->  halo(x) = VH y                       (a 2 N^2-long combination, no exchange)
+        r (the residual)   ->  ONE two-sided exchange per iteration  (`of_residual`)
+        v_new = (r - V c) / rho  ->  halo(v_new) = (halo(r) - VH c) / rho   (`push_from_sweep`)
+    so a GKS iteration costs one exchange (GKS.py:81-96; operators.py:39-45 couple frame t with t+1 only)."""
+
+    def __init__(self, L, V, kmax):
+        from ..krylov import DeviceBasis
+        self.L, self.eng = L, L.engine
+        n2 = 2 * L.npix
+        self.VH = DeviceBasis(self.eng, n2, kmax)
+        self.VH.data.zero_()                      # the half of a rank without that neighbour is never exchanged — and never read
+        self.xh, self.rh = self.eng.zeros(n2), self.eng.zeros(n2)
+        for j in range(V.k):
+            self.push_exchanged(V[j])
+
+    def push_exchanged(self, v):
+        self.L.halo_frames(v, out=self.VH.next_slot())
+        self.VH.commit()
+
+    def of_iterate(self, k, y):
+        self.eng.gemv_n(self.VH.data, k, y, self.xh)
+        return self.xh
+
+    def of_residual(self, r):
+        return self.L.halo_frames(r, out=self.rh)
+
+    def push_from_sweep(self, k, c, rho2):
+        slot = self.VH.next_slot()
+        self.eng.gemv_n(self.VH.data, k, c, slot, a=1.0, base=self.rh, s=-1.0)
+        self.eng.scale(Coef(1.0, den=rho2, sqrt_den=True), slot, slot)
+        self.VH.commit()
+
+    def __getitem__(self, j):
+        return self.VH[j]
+
+
 class _ProjectedBases:
     """V and the incrementally maintained Gram data  G_A = (AV)^T AV, G_L = (LV)^T LV, c = (AV)^T b.
 
@@ -62,6 +102,9 @@ class _ProjectedBases:
         self.GL = np.zeros((kmax, kmax))
         self.c = np.zeros(kmax)
         self.S = eng.scalars(2 * kmax + 8)
+        # time-sharded fused L: the basis vectors' boundary frames of the neighbour ranks (one exchange per start vector here)
+        self.halo = _HaloTrack(L, V0, kmax) if (self.from_v_L and self.tL is None and getattr(L, "sharded", False)) else None
+        self.r_halo = None
         for j in range(V0.k):
             self._push_images(j)
 
@@ -90,7 +133,8 @@ class _ProjectedBases:
             pass
         elif self.from_v_L:
             if self.tL is None:
-                self.L.tv_grad(v, None, None, 1.0, out=self.zL)           # z_L = L^T L v in one stencil pass
+                hk = {} if self.halo is None else {"halo": self.halo[j]}
+                self.L.tv_grad(v, None, None, 1.0, out=self.zL, **hk)     # z_L = L^T L v in one stencil pass
             else:
                 self.L.apply(v, out=self.tL)
                 self.L.apply(self.tL, out=self.zL, transpose=True)
@@ -155,11 +199,12 @@ class _ProjectedBases:
             eng.dot(r, self.atb, S.ref(2))
             extra.append(self.zA)
         if self.from_v_L:
+            hk = {} if self.halo is None else {"halo": self.r_halo}
             if self.tL is None and hasattr(getattr(eng, "lib", None), "trk_tv_grad_dot") and _TVDOT:
-                self.L.tv_grad(r, None, None, 1.0, out=self.zL, dot_with=r, dot_out=S.ref(1))   # z_L = L^T L r and r . z_L, one pass
+                self.L.tv_grad(r, None, None, 1.0, out=self.zL, dot_with=r, dot_out=S.ref(1), **hk)   # z_L = L^T L r and r . z_L, one pass
             else:
                 if self.tL is None:
-                    self.L.tv_grad(r, None, None, 1.0, out=self.zL)
+                    self.L.tv_grad(r, None, None, 1.0, out=self.zL, **hk)
                 else:
                     self.L.apply(r, out=self.tL)
                     self.L.apply(self.tL, out=self.zL, transpose=True)
@@ -277,8 +322,12 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
             eng.gemv_n(pb.AV.data, k, Y.ref(0), tm, a=-1.0, base=bv, s=1.0)
         A.apply(tm, out=r, transpose=True)
         if fusedL:
-            L.tv_grad(x_dev, None, r, float(lam), out=rb)                            # r + lam L^T L x in one stencil pass
+            # time-sharded: the iterate's boundary frames of the neighbour ranks are the same combination of the basis vectors' (no exchange)
+            hk = {} if pb.halo is None else {"halo": pb.halo.of_iterate(k, Y.ref(0))}
+            L.tv_grad(x_dev, None, r, float(lam), out=rb, **hk)                      # r + lam L^T L x in one stencil pass
             r, rb = rb, r
+            if pb.halo is not None:
+                pb.r_halo = pb.halo.of_residual(r)                                   # the ONE neighbour exchange of the iteration
         else:
             if dL:
                 L.apply(x_dev, out=tp)
@@ -289,22 +338,30 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         vn = pb.V.next_slot()
         merged = (on_dev and gs_gram is not None and pb.from_v_L and hasattr(eng, "gram_row_from_sweep")
                   and gs_gram.in_G == k - 1 and kwargs.get("gram_rows_from_sweep", True))
+        cc = None
         if merged:
             # the sweep's pass over V also takes V^T (A^T A r), V^T (L^T L r): the next vector's Gram rows need no pass of their own
             cc = gs_gram.sweep(k, r, 3, vn, sumsq=R.ref(ii), extra=pb.sweep_operands(r))
         elif gs_gram is not None:
-            gs_gram.sweep(k, r, 3, vn, sumsq=R.ref(ii))                              # (:86-88) three sweeps, ||r||^2 fused
+            cc = gs_gram.sweep(k, r, 3, vn, sumsq=R.ref(ii))                         # (:86-88) three sweeps, ||r||^2 fused
         else:
             orthogonalize(eng, pb.V, k, r, H, 0, passes=3, out=vn, sumsq=R.ref(ii))
         eng.allreduce(R, ii, ii + 1)
         eng.scale(Coef(1.0, den=R.ref(ii), sqrt_den=True), vn, vn)                   # vn = r/||r|| (:89-91)
         pb.V.commit()
+        if pb.halo is not None:                                                      # the new vector's boundary frames: from the
+            if cc is not None and pb.r_halo is not None:                             # residual's and the sweep's coefficients
+                pb.halo.push_from_sweep(k, cc, R.ref(ii))
+            else:
+                pb.halo.push_exchanged(pb.V[k])
         if merged:
             pb.append_from_sweep(gs_gram, k, cc, R.ref(ii))
         else:
             pb.append()                                                              # AV, LV, Gram rows (:92-96)
     info = {"xHistory": Hs.collect(fmt, n_iter), "regParam": lam, "regParam_history": lams,
             "Residual": list(np.sqrt(R.host(0, n_iter))), "its": n_iter - 1}
+    if getattr(L, "sharded", False):
+        info["fused_tv"] = bool(fusedL)                 # engine-only: the kernels of the one-rank solve ran on every rank
     if xt is not None:
         if err_fused:
             eng.finalize_batched(EP.ref(0), n_ep, 1, n_iter, E.ref(2), 1)

@@ -136,7 +136,8 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     E = eng.scalars(n_iter + 3)
     Rn = eng.scalars(n_iter + 1)
     ax, tm, wf = eng.empty(m), eng.empty(m), eng.empty(m)
-    lx, tp, wr = eng.empty(p_rows), eng.empty(p_rows), eng.empty(p_rows)
+    # (a time-sharded fused L keeps one more weight row: the previous rank's boundary row, operators.SpaceTimeDerivative)
+    lx, tp, wr = eng.empty(p_rows), eng.empty(p_rows), eng.empty(max(p_rows, getattr(L, "tv_weights_len", p_rows)))
     r, rb = eng.empty(n), eng.empty(n)
     if xt is not None:
         eng.nrm2sq(xt, E.ref(0))
@@ -152,6 +153,8 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     # the two Gram-Schmidt sweeps per iteration by Gram matrix (two passes over V instead of three / four)
     gs_gram = GramSchmidtByGram(eng, V, kmax) if (hasattr(eng, "cgs_coeffs") and kwargs.get("gram_sweeps", True)) else None
     lams, res, lam, x_dev, its = [], [], None, None, 0
+    xh_mm = None
+    xh_buf = eng.zeros(2 * L.npix) if (fusedL and getattr(L, "sharded", False)) else None
     unit_wf = (pnorm == 2)
     if unit_wf:
         wf.fill_(1.0)
@@ -175,9 +178,11 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             eng.group_weights(gs_d, gs_rows, gs_nt_x, float(np.exp(2)), qnorm / 2 - 1, gs_nt_x, wr)   # exp(2): sic (:87)
         elif fusedL:
             if not gram_ahead:
-                L.tv_weights(x_cur if x_dev is None else x_dev, epsilon, qnorm, wr)
+                # time-sharded: the iterate's boundary frames were exchanged for the residual of the previous iteration already
+                hk = {"halo": xh_mm} if (xh_mm is not None and x_dev is not None) else {}
+                L.tv_weights(x_cur if x_dev is None else x_dev, epsilon, qnorm, wr, **hk)
         else:
-            eng.mm_weights(lx, None, epsilon, qnorm, wr)
+            eng.mm_weights(lx, None, epsilon, qnorm, wr[:p_rows])
         # weighted Gram matrices and projected right-hand sides
         if pbA is None:
             eng.wgram(AV.data, k, wf, bv, G.ref(0), G.ref(2 * kk), G.ref(2 * kk + k))
@@ -187,7 +192,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             else:
                 eng.wgram_tv(V.data, k, L.N, wr, G.ref(kk))
         else:
-            eng.wgram(LV.data, k, wr, None, G.ref(kk))
+            eng.wgram(LV.data, k, wr[:p_rows], None, G.ref(kk))          # (the rows of L: a sharded fused L keeps one weight row more)
         nred = 2 * kk + 2 * k
         if pbA is not None:
             eng.allreduce(G, kk, 2 * kk)
@@ -244,7 +249,11 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             eng.mul_diff(wf, res_a, bv, tm)
         A.apply(tm, out=r, transpose=True)
         if fusedL:
-            L.tv_grad(x_dev, wr, r, float(lam), out=rb)                               # r + lam L^T (wr * (L x)), one pass
+            hk = {}
+            if getattr(L, "sharded", False):
+                xh_mm = L.halo_frames(x_dev, out=xh_buf)                              # ONE exchange: this residual and the next weights
+                hk = {"halo": xh_mm}
+            L.tv_grad(x_dev, wr, r, float(lam), out=rb, **hk)                         # r + lam L^T (wr * (L x)), one pass
             r, rb = rb, r
         else:
             if dL:
@@ -255,7 +264,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
                 res_l = tp
                 if not last:
                     L.apply(x_dev, out=lx)                                            # for the next weights (:60)
-            eng.mul(wr, res_l, tp)
+            eng.mul(wr[:p_rows], res_l, tp)
             L.apply(tp, out=rb, transpose=True)
             eng.axpby(1.0, r, float(lam), rb, r)
         vn = V.next_slot()
@@ -278,7 +287,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             if tv_gram and fuse_passes and not last:
                 # the new Gram row V^T (A^T A v_new) and the NEXT iteration's re-weighted Gram of L V both sweep V (now k + 1 vectors):
                 # one pass (trk_wgram_tv_z).  The weights of the next iteration depend on x_dev only, which is final.
-                L.tv_weights(x_dev, epsilon, qnorm, wr)
+                L.tv_weights(x_dev, epsilon, qnorm, wr, **({"halo": xh_mm} if xh_mm is not None else {}))
                 k1 = V.k
                 gram_ahead = pbA.append(v_pass=lambda zz, out: eng.wgram_tv(V.data, k1, L.N, wr, G.ref(k1 * k1), z=zz, h=out))
             else:
