@@ -307,6 +307,36 @@ def run_blur_cgls(args, rank, world, json_fd=1):
                      "cgls_alg_bytes_per_iter": 44.0 * n,
                      "cgls_effective_GBps": round(44.0 * n * K / elapsed / 1e9, 1)}}
 
+    # solver rates "history off and on", and what a reference-style call sees from idle.  Whole CGLS() calls of 100
+    # iterations (CGLS.py:16 semantics, tol = 0, device tensors in and out), wall clock around the call, synchronised both ends:
+    #   history off / on (the reference keeps every iterate, CGLS.py:66: here 100 rows of 67 MB on the device), after a warm call;
+    #   cold: ONE call after two seconds of an idle GPU, no run-in — the ~100-iteration clock / cache ramp of RUN_IN_ITERS is inside.
+    try:
+        from trips_py_amd.solvers import CGLS as _CGLS
+        solves = {}
+        for tag, hist in (("history_off", False), ("history_on", True)):
+            _CGLS(A, b, x0, 100, 0, history=hist)
+            torch.cuda.synchronize()
+            barrier(world)
+            ts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                _CGLS(A, b, x0, 100, 0, history=hist)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            solves[f"{tag}_iters_per_sec"] = round(world * 100 / max_over_ranks(float(np.median(ts)), world), 1)
+            torch.cuda.empty_cache()
+        time.sleep(2.0)
+        barrier(world)
+        t0 = time.perf_counter()
+        _CGLS(A, b, x0, 100, 0, history=False)
+        torch.cuda.synchronize()
+        solves["cold_100_iter_solve_iters_per_sec"] = round(world * 100 / max_over_ranks(time.perf_counter() - t0, world), 1)
+        solves["note"] = "whole CGLS() calls of 100 iterations at this size (constructor, loop, final norms, result), median of 3; cold: one call after 2 s idle"
+        res["extra"]["cgls_100_iter_solves"] = solves
+    except Exception as exc:          # noqa: BLE001
+        res["extra"]["cgls_100_iter_solves"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
     # Host baselines run AFTER every GPU measurement of this process: NumPy / SciPy work on the host wakes BLAS thread pools whose
     # idle spinning can exhaust the container's CPU quota, and the kernel then parks every thread for the rest of the period — a
     # solver loop enqueueing microsecond kernels stops for ~100 ms (seen here as C4 at 170 instead of 540
@@ -667,10 +697,14 @@ def extra_c5_dynamic(rank, world, cpu_jobs=None):
     out["gks_iters_per_sec"] = round(reps * 50 / dt, 1)
     cnt = []
     for its in (10, 30):
-        c0 = eng.reduction_points
-        GKS(F, bl, L, 3, its, 1e-2, history=False)
-        cnt.append(eng.reduction_points - c0)
-    out["gks_reduction_points_per_iteration"] = round((cnt[1] - cnt[0]) / 20.0, 3)
+        c0, h0 = eng.reduction_points, eng.halo_exchanges
+        _, ginfo = GKS(F, bl, L, 3, its, 1e-2, history=False)
+        cnt.append((eng.reduction_points - c0, eng.halo_exchanges - h0))
+    out["gks_reduction_points_per_iteration"] = round((cnt[1][0] - cnt[0][0]) / 20.0, 3)
+    # ranks > 1: the fused space-time stencil takes the neighbours' boundary frames (trk_tv_halo); the iterate's and the new basis
+    # vector's come from the basis vectors' (solvers/GKS._HaloTrack), the residual's from ONE two-sided exchange per iteration
+    out["gks_halo_exchanges_per_iteration"] = round((cnt[1][1] - cnt[0][1]) / 20.0, 3) if world > 1 else "1 on ranks > 1; none on one rank"
+    out["gks_fused_tv_kernels_on_every_rank"] = bool(ginfo.get("fused_tv", True)) and bool(getattr(L, "fused_tv", False))
     if cpu_jobs is not None:
         bh = bl.detach().to("cpu")
 

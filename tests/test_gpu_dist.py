@@ -1,6 +1,7 @@
 """The sharded (time-frames over ranks) path with the REAL HIP kernels, world_size = 2, on one GPU: both ranks use cuda:0
 and talk over gloo with host staging (RCCL refuses two ranks on one device).  Exercises HipEngine + TorchComm, the
-per-iteration all-reduces of the solvers and the space-time halo exchange feeding trk_spacetime_set_halo.
+per-iteration all-reduces of the solvers, the two-sided halo exchange feeding the fused space-time stencil (trk_tv_halo:
+GKS / MMGKS) and the one-frame shifts feeding trk_spacetime_set_halo (plain L / L^T applies).
 Each rank's slice must equal the single-process solve of the whole problem."""
 import os
 import socket
@@ -53,8 +54,17 @@ def _solve(eng, nt=4, N=32):
         bl = F.apply(xl)
         x, info = S.CGLS(F, bl, torch.zeros(F.shape[1], device=eng.device), 10, 0)
         out[f"{tag}_cgls"] = (x.reshape(-1).cpu().numpy(), np.array(info["relResidual"]))
-        x, info = S.GKS(F, bl, L, 3, 5, 1e-2)
+        # GKS on ranks runs the kernels of the one-rank solve (fused space-time stencil with the neighbours' boundary frames,
+        # trk_tv_halo): ONE halo exchange and at most 4 all-reduces per iteration — counted between a 3- and a 5-iteration solve
+        assert L.fused_tv and L.streaming
+        cnt = []
+        for its in (3, 5):
+            h0, r0 = eng.halo_exchanges, eng.reduction_points
+            x, info = S.GKS(F, bl, L, 3, its, 1e-2)
+            cnt.append((eng.halo_exchanges - h0, eng.reduction_points - r0))
+        assert info.get("fused_tv", eng.world == 1)
         out[f"{tag}_gks"] = (x.reshape(-1).cpu().numpy(), np.array(info["Residual"]))
+        out[f"{tag}_gks_counts"] = (np.array([(cnt[1][0] - cnt[0][0]) / 2.0, (cnt[1][1] - cnt[0][1]) / 2.0]), np.zeros(1))
         x, info = S.MMGKS(F, bl, L, 2, 1, 3, 5, 1e-2)
         out[f"{tag}_mmgks"] = (x.reshape(-1).cpu().numpy(), np.array(info["Residual"]))
         # Golub-Kahan with the half steps inside the projector's output pass (tomo: trk_op_apply_axpby, norms all-reduced
@@ -88,7 +98,13 @@ def test_sharded_hip_path_matches_single_process():
     with tempfile.TemporaryDirectory() as d:
         mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
         parts = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
+    for tag in ("blur", "tomo"):
+        for p in parts:
+            per_it = p[f"{tag}_gks_counts_x"]
+            assert per_it[0] == 1.0 and per_it[1] <= 4.0, (tag, per_it)
     for key in ref:
+        if key.endswith("_counts"):
+            continue
         x = np.concatenate([p[f"{key}_x"] for p in parts])
         err = np.linalg.norm(x - ref[key][0]) / np.linalg.norm(ref[key][0])
         assert err < 2e-5, (key, err)

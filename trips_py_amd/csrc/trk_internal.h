@@ -185,11 +185,15 @@ inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 // Bits 6, 7: the basis rows read by k_gemv_t / k_gemv_n (k x 4n bytes streamed once per kernel; hinted, they stop evicting
 // the vector every row tile re-reads): 4096^2 GKS 343 -> 372, Hybrid-GMRES 907 -> 1001, MMGKS 331 -> 342 iterations/s.
 // TRK_NT=<mask> overrides (tuning).
+// Bit 8 (TRK_REV=1, an experiment — DESIGN.md 4.1b): the two CGLS update kernels sweep their vectors from the END: each then meets
+// the rows its producer (a blur launch, sweeping forward) wrote last first, while they can still be in the 256 MB memory-side cache,
+// and leaves its own output so that the next blur launch meets ITS first rows last-written.
 inline int stream_nontemporal(int64_t n) {
   static const int env = getenv("TRK_NT") ? atoi(getenv("TRK_NT")) : -1;
-  if (env >= 0) return env;
-  if (n >= kNontemporalLoadsMinFloats) return 51 | 192;
-  return n >= kNontemporalMinFloats ? (3 | 192) : 0;
+  static const int rev = (getenv("TRK_REV") && atoi(getenv("TRK_REV"))) ? 256 : 0;
+  if (env >= 0) return env | rev;
+  if (n >= kNontemporalLoadsMinFloats) return 51 | 192 | rev;
+  return (n >= kNontemporalMinFloats ? (3 | 192) : 0) | rev;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

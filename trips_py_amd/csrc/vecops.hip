@@ -302,7 +302,8 @@ __global__ __launch_bounds__(NT) void k_cgls_update(int64_t n, int64_t m, Scalar
         s2 += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
       }
     }
-    for (int64_t i = tid; i < m4; i += nth) {
+    for (int64_t i0 = tid; i0 < m4; i0 += nth) {
+      const int64_t i = (nt & 256) ? m4 - 1 - i0 : i0;      // TRK_REV: last-written rows of the producer first (Infinity-Cache experiment)
       float4 rv = ld4(r, i);
       const float4 wv = ld4(w, i);
       rv.x = fmaf(-step, wv.x, rv.x);
@@ -388,7 +389,8 @@ __global__ __launch_bounds__(NT) void k_cgls_r_update(int64_t m, const double* g
   if (VEC) {
     const int64_t m4 = m >> 2;
     tail0 = m4 << 2;
-    for (int64_t i = tid; i < m4; i += nth) {
+    for (int64_t i0 = tid; i0 < m4; i0 += nth) {
+      const int64_t i = (nt & 256) ? m4 - 1 - i0 : i0;      // TRK_REV: last-written rows of the producer first (Infinity-Cache experiment)
       float4 rv = ld4(r, i);
       const float4 wv = ld4(w, i);
       rv.x = fmaf(-step, wv.x, rv.x);
@@ -424,7 +426,8 @@ __global__ __launch_bounds__(NT) void k_cgls_xp_update(int64_t n, const double* 
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
   const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
   const int64_t n4 = n >> 2;
-  for (int64_t i = tid; i < n4; i += nth) {
+  for (int64_t i0 = tid; i0 < n4; i0 += nth) {
+    const int64_t i = (nt & 256) ? n4 - 1 - i0 : i0;        // TRK_REV (see k_cgls_r_update)
     const float4 xv = (nt & 16) ? ld4_nt(x, i) : ld4(x, i), pv = ld4(p, i), tv = (nt & 32) ? ld4_nt(t, i) : ld4(t, i);
     const float4 d = make_float4(step * pv.x, step * pv.y, step * pv.z, step * pv.w);
     const float4 xn = make_float4(xv.x + d.x, xv.y + d.y, xv.z + d.z, xv.w + d.w);
