@@ -628,11 +628,26 @@ def extra_c5_dynamic(rank, world, cpu_jobs=None):
         import torch.distributed as dist
         comm = None
         if dist.get_backend() == "nccl" and os.environ.get("TRK_COMM", "rccl") == "rccl":
+            # trk_comm_init is collective: a rank that cannot even load librccl must say so BEFORE the others enter it, or they
+            # wait there forever.  Every rank probes on its own (trk_comm_unique_id: loads the library, no communication) and the
+            # ranks agree on the outcome first.
+            probe_ok, why = 1.0, ""
             try:
-                from trips_py_amd.dist import RcclComm
-                comm, comm_kind = RcclComm(), "libtrk RCCL communicator (trk_comm_init / trk_allreduce_f64 / trk_halo_exchange)"
+                from trips_py_amd import _lib as _trk_lib
+                _buf = (ctypes.c_char * 128)()
+                _trk_lib.check(_trk_lib.load().trk_comm_unique_id(_buf), "trk_comm_unique_id")
             except Exception as exc:      # noqa: BLE001
-                comm_kind = f"torch.distributed ({type(exc).__name__} from trk_comm_init: {exc})"[:200]
+                probe_ok, why = 0.0, f"{type(exc).__name__}: {exc}"
+            flag = torch.tensor([probe_ok], device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if float(flag.item()) < 1.0:
+                comm_kind = f"torch.distributed (librccl not usable through libtrk on some rank{': ' + why if why else ''})"[:200]
+            else:
+                try:
+                    from trips_py_amd.dist import RcclComm
+                    comm, comm_kind = RcclComm(), "libtrk RCCL communicator (trk_comm_init / trk_allreduce_f64 / trk_halo_exchange2)"
+                except Exception as exc:      # noqa: BLE001
+                    comm_kind = f"torch.distributed ({type(exc).__name__} from trk_comm_init: {exc})"[:200]
             # every rank must end up on the same communicator: if one could not make its own, all use torch.distributed
             ok = torch.tensor([1.0 if comm is not None else 0.0], device="cuda")
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)

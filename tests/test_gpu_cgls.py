@@ -258,3 +258,20 @@ def test_radon_cgls_raw_partials_form_equals_finalized_form(case):
     for k in range(its):
         assert relerr(raw.X[k].cpu().numpy(), fin.X[k].cpu().numpy()) < 5e-6, k
     assert relerr(raw.X[its - 1].cpu().numpy(), fin.X[its - 1].cpu().numpy()) < 5e-6
+
+
+def test_carried_vectors_of_the_recurrence_forms_do_not_drift_over_long_solves():
+    """the default arrangements advance w = A p (and r) by fp32 recurrences and never refresh them from a real product
+    (tiled form 2 on one rank: w_k = A t + beta w_{k-1}; the one-all-reduce form on ranks: w_k = q + beta w_{k-1}).  Over the longest
+    solves anything here runs (bench: 100 iterations; this test: 1000 and 400) the carried vectors stay at rounding distance from
+    b - A x and A p — measured on the MI355X (tools/cgls_drift.py): r 3.4e-7 |b| after 1000 iterations (the form that forms A p every
+    iteration: 2.7e-7), w 2.8e-6 |A p|; sharded form after 400: 7.7e-8 / 8.3e-7.  No periodic refresh is needed below these counts;
+    `tiled=1` / `one_reduction=False` select the arrangements that do refresh."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import cgls_drift as D
+    dr, dw = D.blur_case(256, 1000, 2)
+    assert dr < 2e-6 and dw < 2e-5, (dr, dw)
+    dr, dw = D.sharded_case(400)
+    assert dr < 1e-6 and dw < 1e-5, (dr, dw)

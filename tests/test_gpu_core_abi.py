@@ -286,8 +286,7 @@ def gks(c, A, L, b, d, iters, lam, weights=None, eps=0.1, q=1.0):               
         A.apply(tm, r, True)
         c.combine(LV, k, y, tp)
         if weights:
-            c.mul(wr, tp, tp)
-            c.mul(wr, tp, tp)                                                         # the weights enter SQUARED through the weighted QR (:94-95,116)
+            c.mul(wr, tp, tp)                                                         # to the FIRST power here (MMGKS.py:116), squared in the QR (:94-95)
         L.apply(tp, rb, True)
         c.axpby(1.0, r, lam, rb, r)
         for _ in range(2 if weights else 3):                                          # (:86-88 / MMGKS.py:119-120)

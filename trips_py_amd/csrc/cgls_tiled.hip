@@ -515,8 +515,11 @@ int tiled_geom(trk_op* A, TiledGeom* g, int* ntiles) {
   if (!blur_separable_params(A, &nx, &ny, &kh, &kw, &sf, &st)) return 0;
   if (kh > 9 || kw > 9 || nx < 16 || ny < 16) return 0;
   float hf[18], ht[18];
-  if (hipMemcpy(hf, sf, sizeof(float) * (kw + kh), hipMemcpyDeviceToHost) != hipSuccess) return 0;
-  if (hipMemcpy(ht, st, sizeof(float) * (kw + kh), hipMemcpyDeviceToHost) != hipSuccess) return 0;
+  if (hipMemcpy(hf, sf, sizeof(float) * (kw + kh), hipMemcpyDeviceToHost) != hipSuccess ||
+      hipMemcpy(ht, st, sizeof(float) * (kw + kh), hipMemcpyDeviceToHost) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;                                      // a HIP error, not an answer about the operator: the caller must not cache it
+  }
   for (int o = 0; o < 9; ++o) g->rwf[o] = g->cwf[o] = g->rwt[o] = g->cwt[o] = 0.f;
   const int T = kh - 1 - kh / 2, L = kw - 1 - kw / 2;        // y[i][j] = sum c[a][b] x~[i - T + a][j - L + b]
   for (int b = 0; b < kw; ++b) {
@@ -539,14 +542,23 @@ int tiled_geom(trk_op* A, TiledGeom* g, int* ntiles) {
 extern "C" {
 
 // the tile geometry of a handle (two small device-to-host copies: blocking) once per handle, kept in A->aux; ntiles = 0 records
-// "not a separable blur <= 9 x 9 on an image >= 16 x 16" so that the question is not asked of the device again either
+// "not a separable blur <= 9 x 9 on an image >= 16 x 16" so that the question is not asked of the device again either.  Only
+// that STRUCTURAL "no" is cached: a failed copy returns NULL with the error string set and is asked again next time.
 struct TiledCache { TiledGeom g; int ntiles; };
 static const TiledCache* tiled_cache(trk_op* A) {
   if (!A->aux) {
     TiledCache c{};
-    if (!tiled_geom(A, &c.g, &c.ntiles)) c.ntiles = 0;
+    const int have = tiled_geom(A, &c.g, &c.ntiles);
+    if (have < 0) {
+      (void)fail(TRK_EHIP, "tiled CGLS: could not read the blur's separable factors from the device");
+      return nullptr;
+    }
+    if (!have) c.ntiles = 0;
     A->aux = malloc(sizeof(TiledCache));
-    if (!A->aux) return nullptr;
+    if (!A->aux) {
+      (void)fail(TRK_ENOMEM, "tiled CGLS: out of memory");
+      return nullptr;
+    }
     memcpy(A->aux, &c, sizeof(TiledCache));
   }
   return static_cast<const TiledCache*>(A->aux);
@@ -555,7 +567,9 @@ static const TiledCache* tiled_cache(trk_op* A) {
 int trk_cgls_tiled_caps(trk_op* A, int np_capacity_blocks, int pcap, int* can) {
   TRK_REQUIRE(A && can, "trk_cgls_tiled_caps: NULL argument");
   const TiledCache* c = tiled_cache(A);                    // (asked by every CGLS() call: must not touch the device after the first)
-  *can = (c && c->ntiles > 0 && c->ntiles <= np_capacity_blocks && c->ntiles <= pcap) ? 1 : 0;
+  *can = 0;
+  if (!c) return TRK_EHIP;                                 // the error string is set; nothing was cached: the next call asks again
+  *can = (c->ntiles > 0 && c->ntiles <= np_capacity_blocks && c->ntiles <= pcap) ? 1 : 0;
   return TRK_OK;
 }
 
@@ -567,7 +581,7 @@ int trk_cgls_iterate_tiled(trk_op* A, int k_first, int n_iters, float* P, int64_
               "trk_cgls_iterate_tiled: NULL argument");
   TRK_REQUIRE(k_first >= 1 && n_iters >= 0, "trk_cgls_iterate_tiled: need k_first >= 1, n_iters >= 0");
   const TiledCache* tc = tiled_cache(A);
-  if (!tc) return fail(TRK_ENOMEM, "trk_cgls_iterate_tiled: out of memory");
+  if (!tc) return TRK_EHIP;                                // (message set by tiled_cache)
   if (tc->ntiles <= 0) return fail(TRK_EUNSUPPORTED, "trk_cgls_iterate_tiled: needs a separable blur <= 9x9 on an image >= 16x16");
   const TiledGeom g = tc->g;
   const int ntiles = tc->ntiles;
@@ -607,7 +621,7 @@ int trk_cgls_iterate_tiled2(trk_op* A, int k_first, int n_iters, float* p, float
               "trk_cgls_iterate_tiled2: NULL argument");
   TRK_REQUIRE(k_first >= 1 && n_iters >= 0, "trk_cgls_iterate_tiled2: need k_first >= 1, n_iters >= 0");
   const TiledCache* tc = tiled_cache(A);
-  if (!tc) return fail(TRK_ENOMEM, "trk_cgls_iterate_tiled2: out of memory");
+  if (!tc) return TRK_EHIP;
   if (tc->ntiles <= 0) return fail(TRK_EUNSUPPORTED, "trk_cgls_iterate_tiled2: needs a separable blur <= 9x9 on an image >= 16x16");
   const TiledGeom g = tc->g;
   const int ntiles = tc->ntiles;

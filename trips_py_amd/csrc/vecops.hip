@@ -1948,12 +1948,12 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, do
   hipStream_t s = (hipStream_t)st;
   const int grid = stream_grid(n);
   double* part = nullptr;
-  if (sumsq)
-    if (int rc = scratch_doubles(s, (size_t)cu_count() * 16, &part)) return rc;
   const bool vec = aligned16(V) && aligned16(out) && (ld % 4 == 0) && (!base || aligned16(base));
   static const int U = env_int("TRK_GEMVN_UNROLL", 8);        // measured, tools/gemv_micro.py: 4 -> 5.4-5.8 TB/s, 8 (+ 8 blocks per CU) -> 6.2-6.4
   static const int gmul = env_int("TRK_GEMVN_GRID", 8);          // blocks per CU (0: stream_grid's 4)
   const int grid_n = gmul > 0 ? (int)std::min<int64_t>((n + (int64_t)NT * 4 - 1) / ((int64_t)NT * 4), (int64_t)cu_count() * gmul) : grid;
+  if (sumsq)                                                     // one partial per workgroup of the grid actually launched
+    if (int rc = scratch_doubles(s, (size_t)(grid_n > grid ? grid_n : grid), &part)) return rc;
 #define GN(HB, SS, VC)                                                                                                            \
   do {                                                                                                                            \
     if (U >= 16) hipLaunchKernelGGL((k_gemv_n<HB, SS, VC, false, 16>), dim3(grid_n), dim3(NT), 0, s, YPtr{y}, V, ld, k, n, a, base, sc, out, part, (const float*)nullptr, stream_nontemporal(n)); \

@@ -84,16 +84,7 @@ class DevScalars:
         if eng is not None:
             # trk_mailbox: one hipMemcpyAsync + one hipEventRecord; the tensor-copy + Event-object route below costs the host
             # ~12 us per download, a tenth of a Hybrid-LSQR iteration at 512^2
-            if self._mb is None:
-                import weakref
-                # borrowed from the engine's pool and handed back when this block dies: pinned memory is never freed while the
-                # engine lives (hipHostFree synchronises the device and takes milliseconds — run by the garbage collector in the
-                # middle of somebody else's solve it cost the bench's C5 CGLS 85 ms)
-                cap = 64
-                while cap < self.t.numel():
-                    cap *= 2
-                self._mb, self._mb_np = eng._mailbox_take(cap, self.MAILBOX_SLOTS)
-                weakref.finalize(self, eng._mailbox_give, cap, self._mb, self._mb_np)
+            self._ensure_mailbox()
             slot = self._mb_slot
             self._mb_slot = (slot + 1) % self.MAILBOX_SLOTS
             _lib.check(eng.lib.trk_mailbox_post(self._mb, slot, self.base + 8 * i, int(i), int(j - i), eng.stream()), "trk_mailbox_post")
@@ -105,13 +96,26 @@ class DevScalars:
         ev.record()
         return _Pending(ev, self._pin, i, j)
 
+    def _ensure_mailbox(self):
+        """This block's mailbox, taken from the engine's pool on first use — nothing is posted and nothing is waited for."""
+        if self._mb is None:
+            import weakref
+            # borrowed from the engine's pool and handed back when this block dies: pinned memory is never freed while the
+            # engine lives (hipHostFree synchronises the device and takes milliseconds — run by the garbage collector in the
+            # middle of somebody else's solve it cost the bench's C5 CGLS 85 ms)
+            eng = self._eng
+            cap = 64
+            while cap < self.t.numel():
+                cap *= 2
+            self._mb, self._mb_np = eng._mailbox_take(cap, self.MAILBOX_SLOTS)
+            weakref.finalize(self, eng._mailbox_give, cap, self._mb, self._mb_np)
+
     def host_later_sum(self, i, j, partials, n_partials, at):
         """host_later(i, j) that also publishes the sum of `n_partials` block partials (device address `partials`) as scalar `at`
         of this block (outside [i, j)), on the device and on the host, with the same launch (trk_mailbox_post_sum).
         Returns two handles: the copied range and the one summed value."""
         eng = self._eng
-        if self._mb is None:
-            self.host_later(i, j).get()        # (creates the mailbox; the extra post only on the first call)
+        self._ensure_mailbox()                 # (no post, no wait: a hidden host synchronisation per solve otherwise)
         slot = self._mb_slot
         self._mb_slot = (slot + 1) % self.MAILBOX_SLOTS
         _lib.check(eng.lib.trk_mailbox_post_sum(self._mb, slot, self.base + 8 * i, int(i), int(j - i), _ptr(partials), int(n_partials),
@@ -123,8 +127,7 @@ class DevScalars:
         (trk_gk_step_post), and the handles to collect it with: ((mailbox, slot, src, offset, count, partials, n, sum_dev,
         sum_offset), range handle, sum handle or None)."""
         eng = self._eng
-        if self._mb is None:
-            self.host_later(i, j).get()        # (creates the mailbox; the extra post only on the first call)
+        self._ensure_mailbox()
         slot = self._mb_slot
         self._mb_slot = (slot + 1) % self.MAILBOX_SLOTS
         args = (self._mb, slot, self.base + 8 * i, int(i), int(j - i), _ptr(partials), int(n_partials),

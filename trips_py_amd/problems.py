@@ -4,10 +4,16 @@
   gauss_psf(dim, spread)              <- Deblurring2D.Gauss            trips/test_problems/Deblurring2D.py:48-64
   gauss_psf_1d(n, sigma)              <- Deblurring1D.Gauss1D          trips/test_problems/Deblurring1D.py:63-69
   Deblurring2D().forward_Op(...)      <- Deblurring2D.forward_Op       :66-73   (returns a trips_py_amd Blur2D)
-  synthetic_image / add_noise         seeded versions of the data recipe (:141-146)
+  synthetic_image / add_noise         seeded versions of the data recipe (:141-146): what bench.py / smoke() / the tests use
+
+In scope here: the PSF and the operator constructors.  The demos' host-side data preparation — gen_xtrue,
+gen_data, the classes' unseeded add_noise (OUT OF SCOPE) — lives in trips_py_amd/demo_helpers.py and is
+only inherited, so that a demo keeps running with these classes swapped in; nothing in the engine, the solvers, the tests of the
+hot path or the bench depends on it.
 """
 import numpy as np
 
+from . import demo_helpers as _demo
 from .operators import Blur1D, Blur2D, BlockDiagOp, FanBeam2D, Radon2DParallel
 
 
@@ -33,8 +39,9 @@ def gauss_psf_1d(n, sigma):
     return psf / psf.sum()
 
 
-class Deblurring2D:
-    """Operator-constructor subset of trips.test_problems.Deblurring2D (same method names)."""
+class Deblurring2D(_demo.Deblurring2DData):
+    """Operator-constructor subset of trips.test_problems.Deblurring2D (same method names); the demos' host-side data helpers
+    (gen_data, add_noise: OUT of the hot-path scope) are inherited from trips_py_amd.demo_helpers."""
 
     def __init__(self, **kwargs):
         self.nx = self.ny = None
@@ -49,43 +56,8 @@ class Deblurring2D:
         psf, _ = self.Gauss(dim, spread)
         return Blur2D(psf, nx, ny, engine=engine)
 
-    # The two data-generation helpers of the demos, on the HOST (one-time data preparation, not the hot path): same
-    # arithmetic as Deblurring2D.py:123-159 so that a demo keeps working with this class swapped in.  Images come from the
-    # caller (the reference's gen_true reads ./data/image_data/*.mat: dataset handling is out of scope).
-    def gen_data(self, x):
-        """b = blurred x.  CommitCrime=False (:125-137): blur on a zero-padded 2nx x 2ny canvas with 'constant' boundary and cut
-        the centre out (the data then do not come from the reflective operator); True: the operator's own convolution."""
-        from scipy.ndimage import convolve
-        psf, _ = gauss_psf(self.dim, self.spread)
-        im = np.asarray(x, dtype=np.float64).reshape((self.nx, self.ny))
-        if self.CommitCrime is False:
-            big = np.zeros((2 * self.nx, 2 * self.ny))
-            i0, j0 = self.nx // 2, self.ny // 2
-            big[i0:i0 + self.nx, j0:j0 + self.ny] = im
-            b = convolve(big, psf, mode="constant")[i0:i0 + self.nx, j0:j0 + self.ny]
-        else:
-            b = convolve(im, psf, mode="reflect")
-        return b.reshape((-1, 1))
 
-    def add_noise(self, b_true, opt, noise_level):
-        """(b_meas as an nx x ny image, delta) — :141-159 (unseeded, like the reference; seeded variant: problems.add_noise)."""
-        b_true = np.asarray(b_true, dtype=np.float64)
-        if opt == "Gaussian":
-            e = np.random.randn(self.nx * self.ny, 1)
-            sig = noise_level * np.linalg.norm(b_true) / np.linalg.norm(e)
-            b_meas, delta = b_true + sig * e, np.linalg.norm(sig * e)
-        elif opt == "Poisson":
-            b_meas, delta = np.random.poisson(lam=b_true + 1), 0.0
-        elif opt == "Laplace":
-            e = np.random.laplace(self.nx * self.ny, 1)
-            sig = noise_level * np.linalg.norm(b_true) / np.linalg.norm(e)
-            b_meas, delta = b_true + sig * e, np.linalg.norm(sig * e)
-        else:
-            raise ValueError(f"unknown noise option {opt!r}")
-        return np.asarray(b_meas).reshape((self.nx, self.ny)), delta
-
-
-class Deblurring1D:
+class Deblurring1D(_demo.Deblurring1DData):
     """trips.test_problems.Deblurring1D: the operator constructor on the engine plus the demo's host-side data helpers
     (Deblurring1D.py:63-69, 104-143, 144-197, 199-216) — BASELINE config C1 (n = 256, 'curve0', sigma = 3)."""
 
@@ -105,69 +77,8 @@ class Deblurring1D:
         self.PSF, self.center = self.Gauss1D(nx, parameter)
         return Blur1D(self.PSF, nx, engine=engine)
 
-    def gen_xtrue(self, N, test):
-        """The test signals of :144-197."""
-        self.grid_points, self.ny = N, 1
-        if test == "sigma":
-            x = np.linspace(-2.5, 2.5, N)
-            return np.piecewise(x, [x < 0, x >= 0], [-1, 1])
-        if test == "piecewise":
-            xx = np.linspace(0, 1, N)
-            edges = [0, 0.10, 0.15, 0.20, 0.25, 0.35, 0.38, 0.45, 0.55, 0.75, 0.8]
-            values = [0, 1, 0, 0, 0, 0, 0, 0.25, 0, 1, 0]
-            conds = [(edges[i] <= xx) & (xx < edges[i + 1]) for i in range(10)] + [(0.8 <= xx) & (xx <= 1)]
-            return np.piecewise(xx, conds, values)
-        if test == "curve0":
-            h = np.pi / N
-            t = -np.pi / 2 + np.arange(0.5, N, 1) * h
-            return 2 * np.exp(-6 * (t - 0.8) ** 2) + np.exp(-2 * (t + 0.5) ** 2)
-        h = 1.0 / N
-        sqh = np.sqrt(h)
-        i = np.arange(N, dtype=np.float64)
-        if test == "curve1":
-            return (h * sqh * (i + 0.5)).reshape(-1, 1)
-        if test == "curve2":
-            return ((np.exp((i + 1) * h) - np.exp(i * h)) / sqh).reshape(-1, 1)
-        if test == "curve3":
-            d = (((i + 1) * h) ** 2 - (i * h) ** 2) / 2
-            first = np.arange(N) < int(N / 2 + 1)
-            return (np.where(first, d, h - d) / sqh).reshape(-1, 1)
-        raise ValueError(f"unknown test signal {test!r}")
 
-    def gen_data(self, x, **kwargs):
-        """b = blurred x (:104-143): on a zero-padded 2N grid unless CommitCrime; parameter defaults to 0.3 as in the reference."""
-        from scipy.ndimage import convolve1d
-        if "parameter" in kwargs:
-            self.parameter, self.boundary_condition = kwargs["parameter"], "reflect"
-        elif self.parameter is None:
-            self.parameter = 0.3
-            self.boundary_condition = kwargs.get("boundary_condition", self.boundary_condition or "reflect")
-        n = self.grid_points
-        self.PSF, self.center = self.Gauss1D(n, self.parameter)
-        if self.CommitCrime is False:
-            pad = np.zeros((2 * n, 1))
-            pad[n // 2:n // 2 + n, :] = np.asarray(x, dtype=np.float64).reshape((n, 1))
-            b = convolve1d(pad, self.PSF, mode=self.boundary_condition)      # (axis -1 of an (2n, 1) array, as the reference)
-            return b[n // 2:n // 2 + n, :].reshape((-1, 1))
-        return convolve1d(np.asarray(x, dtype=np.float64), self.PSF, mode=self.boundary_condition).reshape((-1, 1))
-
-    def add_noise(self, b_true, opt, noise_level):
-        """(b_meas, delta) — :199-216 (unseeded, like the reference)."""
-        b_true = np.asarray(b_true, dtype=np.float64)
-        if opt == "Gaussian":
-            e = np.random.randn(self.grid_points, 1)
-            sig = noise_level * np.linalg.norm(b_true) / np.linalg.norm(e)
-            return b_true + sig * e, np.linalg.norm(sig * e)
-        if opt == "Poisson":
-            return np.random.poisson(lam=b_true + 1), 0
-        if opt == "Laplace":
-            e = np.random.laplace(self.grid_points)
-            sig = noise_level * np.linalg.norm(b_true) / np.linalg.norm(e)
-            return b_true + sig * e, np.linalg.norm(sig * e)
-        raise ValueError(f"unknown noise option {opt!r}")
-
-
-class Tomography:
+class Tomography(_demo.TomographyData):
     """Operator-constructor subset of trips.test_problems.Tomography (same method name and return convention)."""
 
     def __init__(self, **kwargs):
@@ -184,31 +95,6 @@ class Tomography:
             A_mis = FanBeam2D(nx, angles=A.angles + 1e-8, engine=engine)
             return A, A, A_mis
         return A, A
-
-    def gen_data(self, x, nx, ny, views, engine=None):
-        """(A, b, p, q, AforMatrixOperation) of Tomography.py:153-168: b from the angle-shifted operator unless CommitCrime;
-        NOTE the reference then overwrites p with `views` and q with rows / views (:166-167); reproduced."""
-        ops = self.forward_Op(nx, ny, views, engine=engine)
-        xv = np.asarray(x, dtype=np.float64).reshape(-1)
-        b = np.asarray((ops[2] if not self.CommitCrime else ops[0]) @ xv).reshape((-1, 1))
-        self.p = views
-        self.q = int(b.shape[0] / views)
-        return ops[0], b, self.p, self.q, ops[1]
-
-    def add_noise(self, b_true, opt, noise_level):
-        """(b_meas as a p x q array, delta) — Tomography.py:203-227 (unseeded like the reference)."""
-        b_true = np.asarray(b_true, dtype=np.float64)
-        if opt == "Gaussian":
-            noise = np.random.randn(b_true.shape[0]).reshape((-1, 1))
-            e = noise_level * np.linalg.norm(b_true) / np.linalg.norm(noise) * noise
-            b_meas, delta = b_true.reshape((-1, 1)) + e, np.linalg.norm(e)
-        elif opt == "Poisson":
-            b_meas, delta = np.random.poisson(lam=b_true + 1), 0
-        else:
-            e = np.random.laplace(self.p * self.q)
-            sig = noise_level * np.linalg.norm(b_true) / np.linalg.norm(e)
-            b_meas, delta = b_true + sig * e, np.linalg.norm(sig * e)
-        return np.asarray(b_meas).reshape((self.p, self.q)), delta
 
 
 def parallel_beam_frames(N, angle_sets, engine=None):

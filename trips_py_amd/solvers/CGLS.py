@@ -183,8 +183,11 @@ class CGLSRun:
 class CGLSRunSharded(CGLSRun):
     """The recurrence with ONE all-reduce per iteration, for unknowns spread over ranks (frames of a dynamic problem, io.py:420)
     and tol = 0.  The reference's two global sums per iteration (CGLS.py:61 ||A p||^2, :70 ||A^T r||^2; the second waits for the
-    first) become one exchange of three doubles: with q = A t_{k-1} formed explicitly, w_k = A p_k = q + beta w_{k-1} and
-    delta_k = ||q||^2 + 2 beta <q, w_{k-1}> + beta^2 delta_{k-1} (include/trk.h, csrc/cgls_sharded.hip).  The three norms the
+    first) become one exchange of FOUR doubles {gamma_{k-1}, ||q||^2, <q, w_{k-1}>, ||w_{k-1}||^2}: with q = A t_{k-1} formed
+    explicitly, w_k = A p_k = q + beta w_{k-1} and delta_k = ||q||^2 + 2 beta <q, w_{k-1}> + beta^2 ||w_{k-1}||^2, the last norm
+    taken from the stored vector rather than carried as beta^2 delta_{k-1} (include/trk.h, csrc/cgls_sharded.hip).
+    `one_reduction=False` selects the two-reduction recurrence as written on ranks; `tiled=1` the four-blur tiled form on one
+    rank — the two arrangements that refresh w = A p from a real product every iteration.  The three norms the
     reference records per iterate are only reported, so each rank keeps its share and they are summed over the ranks once, in
     `rows()`.  With libtrk's own communicator (dist.RcclComm) — or on one rank — the whole stretch is one library call
     (trk_cgls_iterate_sharded: the all-reduces are enqueued from C); with torch's communicator the same kernels are stepped from
@@ -464,7 +467,9 @@ def CGLS(A, b, x0, max_iter, tol, x_true=None, **kwargs):
         (want if want is not None else CGLSRunFused.auto(A.shape[1]))
     tiled = (not sync_each) and want is None and kwargs.get("tiled", True) and CGLSRunFused.tiled_usable(A, A.engine)
     if tiled:
-        tiled = int(kwargs.get("tiled", CGLSRunFused.TILED_DEFAULT))       # 1: four blurs per iteration, 2: two (w by recurrence)
+        # tiled=True (what earlier versions took) means "the default tiled form", not form 1
+        tk = kwargs.get("tiled", True)
+        tiled = CGLSRunFused.TILED_DEFAULT if tk is True else int(tk)       # 1: four blurs per iteration, 2: two (w by recurrence)
     # unknowns spread over ranks, tol = 0: the one-all-reduce form (one_reduction=False keeps the two reductions of the recurrence
     # as written; one_reduction=True also selects it on a single rank, where it is the same arithmetic without the exchange)
     one_red = kwargs.get("one_reduction", None)

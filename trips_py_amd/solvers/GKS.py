@@ -12,6 +12,7 @@ What moved where
 """
 import numpy as np
 
+from .. import _trace
 from .._io import Formatter, History, as_operator
 from ..engine import Coef
 from ..decompositions import golub_kahan_device
@@ -289,8 +290,9 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     err_fused = xt is not None and hasattr(eng, "gemv_n_err") and kwargs.get("fused_error_norm", True)
     EP_CAP = 2048
     EP, n_ep = (eng.scalars(EP_CAP * max(1, n_iter)) if err_fused else None), 0
-    for ii in range(n_iter):
+    for ii in _trace.progress(range(n_iter), "running GKS...", kwargs.get("progress")):       # (GKS.py:42)
         k = pb.V.k
+        _trace.mark("GKS: projected problem")
         if on_dev:
             lam = regparam
             lams.append(lam)
@@ -305,6 +307,7 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
             lams.append(lam)
             y = tikhonov_lstsq(R_A, R_L, lam, rhs)
             Y.set(0, y)
+        _trace.mark("GKS: iterate x = V y")
         x_dev = Hs.row(ii)
         if err_fused:      # x = V y (:76) with ||x - x_true||^2 as block partials of the same pass, summed once after the loop
             n_ep = eng.gemv_n_err(pb.V.data, k, Y.ref(0), x_dev, xt, EP.ref(n_ep * ii), EP_CAP)
@@ -315,6 +318,7 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
             eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
         # r = A^T (A x - b) + lam L^T (L x), A x = (AV) y and L x = (LV) y in the reference (:81-85); stencil operators
         # form them directly from x (8n-12n bytes instead of k basis vectors)
+        _trace.mark("GKS: residual")
         if dA:
             A.apply(x_dev, out=tm)
             eng.axpby(1.0, tm, -1.0, bv, tm)
@@ -335,6 +339,7 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
                 eng.gemv_n(pb.LV.data, k, Y.ref(0), tp)
             L.apply(tp, out=rb, transpose=True)
             eng.axpby(1.0, r, float(lam), rb, r)
+        _trace.mark("GKS: orthogonalise, new basis vector")
         vn = pb.V.next_slot()
         merged = (on_dev and gs_gram is not None and pb.from_v_L and hasattr(eng, "gram_row_from_sweep")
                   and gs_gram.in_G == k - 1 and kwargs.get("gram_rows_from_sweep", True))
@@ -354,10 +359,12 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
                 pb.halo.push_from_sweep(k, cc, R.ref(ii))
             else:
                 pb.halo.push_exchanged(pb.V[k])
+        _trace.mark("GKS: Gram rows")
         if merged:
             pb.append_from_sweep(gs_gram, k, cc, R.ref(ii))
         else:
             pb.append()                                                              # AV, LV, Gram rows (:92-96)
+    _trace.mark(None)
     info = {"xHistory": Hs.collect(fmt, n_iter), "regParam": lam, "regParam_history": lams,
             "Residual": list(np.sqrt(R.host(0, n_iter))), "its": n_iter - 1}
     if getattr(L, "sharded", False):

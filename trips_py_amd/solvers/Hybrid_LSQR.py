@@ -8,6 +8,7 @@ whole solve is enqueued asynchronously.
 import numpy as np
 import scipy.linalg as sla
 
+from .. import _trace
 from .._io import Formatter, History, as_operator
 from ..krylov import GKState
 from ..reg_param._bidiag import bidiag_svd_first_row, bidiag_svd_project
@@ -180,7 +181,8 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             eng.diff_nrm2sq(x_dev, xt, E.ref(nx_done))
 
     try:
-        for ii in range(n_iter):
+        for ii in _trace.progress(range(n_iter), "running Golub-Kahan bidiagonalization algorithm...", kwargs.get("progress")):   # (Hybrid_LSQR.py:73)
+            _trace.mark("Hybrid_LSQR: Golub-Kahan step, projected problem, iterate")
             k = ii + 1
             rode = False
             if on_host:
@@ -280,6 +282,7 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             form_iterate(waiting, lam)
         clean = True
     finally:
+        _trace.mark(None)
         if searcher is not None:
             if clean:
                 searcher.give_back()

@@ -12,6 +12,7 @@ uses: (AV*wf)^T b for the least-squares solve (sic: unweighted b, :106) and (AV*
 """
 import numpy as np
 
+from .. import _trace
 from .._io import Formatter, History, as_operator
 from ..engine import Coef
 from ..decompositions import golub_kahan_device
@@ -163,9 +164,10 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     err_fused = xt is not None and hasattr(eng, "gemv_n_err") and kwargs.get("fused_error_norm", True)
     EP_CAP = 2048
     EP, n_ep = (eng.scalars(EP_CAP * max(1, n_iter)) if err_fused else None), 0
-    for ii in range(n_iter):
+    for ii in _trace.progress(range(n_iter), "running MMGKS...", kwargs.get("progress")):     # (MMGKS.py:55)
         its = ii
         k = V.k
+        _trace.mark("MMGKS: weights, Gram matrices, projected problem")
         kk = k * k
         # weights from the current iterate (:56-57, :60, :93); ax = A x, lx = L x of it
         # (pnorm = 2: wf = ((A x - b)^2 + eps^2)^0 is 1.0 exactly in every entry, every iteration — set once, before the loop)
@@ -223,6 +225,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             lams.append(lam)
             y = tikhonov_lstsq(R_A, R_L, lam, rhs_b)
             Y.set(0, y)
+        _trace.mark("MMGKS: iterate x = V y")
         x_dev = Hs.row(ii)
         if err_fused:      # x = V y (:107) with ||x - x_true||^2 as block partials of the same pass, summed once after the loop
             n_ep = eng.gemv_n_err(V.data, k, Y.ref(0), x_dev, xt, EP.ref(n_ep * ii), EP_CAP)
@@ -234,6 +237,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         if ii >= k:                                                                   # `ii >= R_L.shape[0]` (:109-110)
             break
         last = ii == n_iter - 1
+        _trace.mark("MMGKS: residual")
         # r = A^T (wf * (A x - b)) + lam L^T (wr * (L x))                              (:114-118)
         if dA:
             A.apply(x_dev, out=ax)
@@ -267,6 +271,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             eng.mul(wr[:p_rows], res_l, tp)
             L.apply(tp, out=rb, transpose=True)
             eng.axpby(1.0, r, float(lam), rb, r)
+        _trace.mark("MMGKS: orthogonalise, new basis vector, images")
         vn = V.next_slot()
         # (GKS takes that row from the sweep's own pass over V; here r is NOT orthogonal to V — the residual carries the weights to
         #  the first power, the projected problem to the second — so the coefficients c are not small and the row's algebra
@@ -294,6 +299,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
                 pbA.append()
         push_images(V.k - 1)
         res.append(ii)
+    _trace.mark(None)
     nres = len(res)
     info = {"xHistory": Hs.collect(fmt, its + 1), "regParam": lam, "regParam_history": lams,
             "Residual": list(np.sqrt(Rn.host(0, nres))), "its": its}
