@@ -240,10 +240,13 @@ def test_separate_tv_kernels_path_matches_the_golden_too(solver):
     assert relerr(out[True], out[False]) < 5e-6
 
 
-@pytest.mark.parametrize("N,na", [(64, 30), (512, 180)])
-def test_golub_kahan_fused_half_steps_equal_the_separate_kernels(N, na):
+def _gk_paths_agree(N, na, strict):
     """GKState on the Radon projector: the three-launch step (forward, band reduction with epilogue + records, tile gather
-    with epilogue + transposed copy) against apply / axpby / reduce as separate launches: same U, V, alpha, beta."""
+    with epilogue + transposed copy) against apply / axpby / reduce as separate launches: same U, V, alpha, beta.
+    strict: the process runs with TRK_RADON_EPI_F32=1 — the fused half step then combines in trk_axpby's fp32 arithmetic like the
+    separate kernels and all twelve vectors agree to rounding.  Otherwise (the default: one rounding of a Op(x) + b z formed in
+    float64) the two paths differ by a unit in the last place per step, which un-reorthogonalised Golub-Kahan on noise-free data
+    amplifies ~5 x per step (measured 1.2e-5 at the third vector, 2.8e-3 at the sixth): only the first two steps are comparable."""
     from trips_py_amd.krylov import GKState
     from trips_py_amd.operators import Radon2DParallel
     A = Radon2DParallel(N, np.linspace(0, np.pi, na, endpoint=False))
@@ -255,19 +258,31 @@ def test_golub_kahan_fused_half_steps_equal_the_separate_kernels(N, na):
         st_f.step(sync=False)
         st_s.step(sync=False)
         st_d.step(sync=False, defer=True)        # beta^2 finished by the next step's adjoint kernel / the flush in _sync
+    # deferred and immediate forms of the SAME arithmetic: the norms are summed over different workgroup partitions (equal to fp64
+    # rounding), the vectors equal to fp32 rounding
     assert np.allclose(st_d.alphas, st_f.alphas, rtol=1e-9) and np.allclose(st_d.betas, st_f.betas, rtol=1e-9)
     assert relerr(st_d.V.data[11].cpu().numpy(), st_f.V.data[11].cpu().numpy()) < 5e-6
-    # (the norms are summed over different workgroup partitions: equal to fp64 rounding.)  The vectors: the fused half step
-    # combines a Op(x) + b z in float64 with one rounding (round 4), the separate kernels in trk_axpby's fp32 arithmetic with
-    # rounded coefficients — one unit in the last place per step, which un-reorthogonalised Golub-Kahan amplifies step by step
-    # (measured 1.2e-5 at the third vector, 512^2 x 180).  TRK_RADON_EPI_F32=1 makes the two paths agree to 5e-6 on all twelve.
-    # What is pinned here: the first two steps to fp32 rounding, the rest to the recurrence's own sensitivity; the deferred and the
-    # immediate forms of the SAME arithmetic (above) to 5e-6 on the last vector.
-    for k in range(12):
-        bar = 5e-6 if k < 2 else 2e-3
-        assert relerr(st_f.V.data[k].cpu().numpy(), st_s.V.data[k].cpu().numpy()) < bar, k
-        assert relerr(st_f.U.data[k + 1].cpu().numpy(), st_s.U.data[k + 1].cpu().numpy()) < bar, k
-    assert np.allclose(st_f.alphas, st_s.alphas, rtol=1e-4) and np.allclose(st_f.betas, st_s.betas, rtol=1e-4)
+    for k in range(12 if strict else 2):
+        assert relerr(st_f.V.data[k].cpu().numpy(), st_s.V.data[k].cpu().numpy()) < 5e-6, k
+        assert relerr(st_f.U.data[k + 1].cpu().numpy(), st_s.U.data[k + 1].cpu().numpy()) < 5e-6, k
+    if strict:
+        assert np.allclose(st_f.alphas, st_s.alphas, rtol=1e-6) and np.allclose(st_f.betas, st_s.betas, rtol=1e-6)
+    else:
+        assert np.allclose(st_f.alphas[:2], st_s.alphas[:2], rtol=1e-6) and np.allclose(st_f.betas[:2], st_s.betas[:2], rtol=1e-6)
+
+
+@pytest.mark.parametrize("N,na", [(64, 30), (512, 180)])
+def test_golub_kahan_fused_half_steps_equal_the_separate_kernels(N, na):
+    _gk_paths_agree(N, na, strict=False)
+    # ... and to rounding on all twelve steps when both paths use the same arithmetic (the switch is read once per process)
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, "-c", f"import sys; sys.path[:0] = [{here!r}, {os.path.dirname(here)!r}]; "
+                        f"import test_gpu_solvers as T; T._gk_paths_agree({N}, {na}, True); print('strict ok')"],
+                       env=dict(os.environ, TRK_RADON_EPI_F32="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "strict ok" in r.stdout, r.stderr[-1500:]
 
 
 @pytest.mark.parametrize("N,its", [(32, 20), (128, 100)])
