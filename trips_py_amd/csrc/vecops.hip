@@ -1442,8 +1442,10 @@ struct TvRow {
 template <int T, bool Z, int D>
 __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 2)) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
                                                     const float* __restrict__ w, int nbands, int band_rows,
-                                                    double* __restrict__ partials, const float* __restrict__ z, int lockstep) {
+                                                    double* __restrict__ partials, const float* __restrict__ z, int lockstep_in) {
   constexpr int NP = T * (T + 1) / 2;
+  const int lockstep = lockstep_in & 1;
+  const bool no_xcd_map = (lockstep_in & 2) != 0;                // TRK_WGRAM_TV_NO_XCD=1: the round-robin unit order (A/B)
   __shared__ double red[3][4][64];
   __shared__ __attribute__((aligned(16))) float wl[NT / 64][Z ? 96 : 64];
   // lockstep (the launcher's choice when the workgroup's four waves always own four neighbouring strips of one band): the pixel
@@ -1476,7 +1478,28 @@ __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 
   float* __restrict__ my = wl[wave];
   const int up16 = ((lane + 16) & 63) << 2;                      // ds_bpermute address of lane l + 16
 
-  for (int64_t u = gw; u < units; u += nw) {
+  // Which XCD's L2 meets which strips (round 4).  The pixel right of a workgroup's four strips is one dword of a line that the
+  // workgroup owning the next four strips fetches as its own data: with workgroups dealt round-robin to the eight XCDs the two
+  // sit behind different L2s and the line crosses the fabric twice — 1.33 x the operand bytes at 4096^2 (FETCH_SIZE,
+  // profiles/r04/traffic_c4_before_xcd_map.txt).  Workgroups b and b + 8 share an XCD (placement is speed only, never correctness),
+  // so each XCD is given a CONTIGUOUS eighth of every band's strip groups: the neighbour line is then in its own L2 except at the
+  // eight seams.  Needs the groups of a band to divide by 8 (N a multiple of 1024) and a grid that is a multiple of 8.
+  const int groups = strips / (NT / 64);
+  const bool xcd_map = strips % (NT / 64) == 0 && (groups & 7) == 0 && (gridDim.x & 7) == 0 && !no_xcd_map;   // (uniform)
+  for (int64_t it = 0;; ++it) {
+    int64_t u;
+    if (xcd_map) {
+      const int64_t U = (int64_t)blockIdx.x + it * gridDim.x;
+      if (U >= units / (NT / 64)) break;
+      const int per = groups >> 3;
+      const int64_t q = U >> 3;
+      const int64_t bnd = q / per;
+      const int grp = (int)(U & 7) * per + (int)(q - bnd * per);
+      u = (bnd * groups + grp) * (NT / 64) + wave;
+    } else {
+      u = gw + it * nw;
+      if (u >= units) break;
+    }
     const int band = (int)(u / strips), strip = (int)(u - (int64_t)band * strips);
     const int i0 = band * band_rows, i1 = (i0 + band_rows < N) ? i0 + band_rows : N;
     const int cs = 32 * strip;
@@ -2120,7 +2143,8 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   double* part = nullptr;
   const int nv = k * k + (z ? k : 0);
   if (int rc = scratch_doubles(s, (size_t)bx * nv, &part)) return rc;
-#define WTV(TT, ZZ) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock)
+  static const int no_xcd = env_int("TRK_WGRAM_TV_NO_XCD", 0) ? 2 : 0;
+#define WTV(TT, ZZ) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd)
   if (z && T16 == 3) {
     // three tiles AND the dots do not fit the register file (108 spilled registers): two passes for 33 <= k <= 48
     WTV(3, false);
