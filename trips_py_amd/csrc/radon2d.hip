@@ -747,7 +747,7 @@ struct QuadParam {
 
 __device__ __forceinline__ unsigned lds_off(const void* p) { return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p; }
 
-template <int DUMMY = 0>
+template <int NBUF>
 __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restrict__ img, const float* __restrict__ imgT,
                                                         float* __restrict__ out, int N, int nd,
                                                         const QuadParam* __restrict__ quads, int nq_per_frame, int ngrp_per_frame,
@@ -756,7 +756,7 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restri
                                                         const unsigned* __restrict__ B32q, int npad,
                                                         const AngleParam* __restrict__ ang, const unsigned* __restrict__ A32,
                                                         const unsigned* __restrict__ B32) {
-  __shared__ __attribute__((aligned(16))) float tile[2][2 * QD_REGION];
+  __shared__ __attribute__((aligned(16))) float tile[NBUF][2 * QD_REGION];
   __shared__ float ext[4][QD_MAXCH][2];
   __shared__ int chinfo[QD_MAXCH][2];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -841,7 +841,7 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restri
   const int uF = 2 * wv + sr, uM = 2 * (QD_R / 2 - 1 - wv) + 1 - sr;
   auto stage = [&](int ch, int cs) {
     const int tb = t0 + ch * QD_R, te = (tb + QD_R < t1) ? tb + QD_R : t1;
-    float* __restrict__ T = tile[ch & 1];
+    float* __restrict__ T = tile[ch % NBUF];
     const unsigned rowbase = (unsigned)tb * (unsigned)N * 4u;
     const int colF = cs + sk, colM = (N - cs - QD_W) + sk;
     const bool okF = ((unsigned)colF < (unsigned)N) && (tb + uF < te), okM = ((unsigned)colM < (unsigned)N) && (tb + uM < te);
@@ -859,19 +859,42 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restri
   };
 
   f2v acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-  int cs_cur = nch > 0 ? __builtin_amdgcn_readfirstlane(chinfo[0][0]) : 0;
-  int st_cur = nch > 0 ? __builtin_amdgcn_readfirstlane(chinfo[0][1]) : 2;
-  if (st_cur == 1) stage(0, cs_cur);
+  // Every chunk's window in a register (lane ch holds chunk ch): inside the loop nothing the COMPILER sees touches LDS, so it has no
+  // reason to drain the direct-to-LDS loads (it orders every LDS access it knows of behind all of them), and chunks can be
+  // staged NBUF - 1 ahead.  A workgroup's chunks form a dependent chain — barrier, wait for a tile, march 8 rows — and at small
+  // images (few workgroups per CU) the chain is bound by the latency of ONE staging round trip per chunk (512^2: 16 chunks x
+  // 1.7 us); with three chunks in flight the round trips overlap.
+  const int cs_all = lane < nch ? chinfo[lane][0] : 0, st_all = lane < nch ? chinfo[lane][1] : 2;
+  const int per_stage = __builtin_popcount(smask & 15);          // wave-level load instructions one staged chunk issues
+  auto st_of = [&](int c) { return c < nch ? __builtin_amdgcn_readlane(st_all, c) : 2; };
+  auto cs_of = [&](int c) { return c < nch ? __builtin_amdgcn_readlane(cs_all, c) : 0; };
+  auto wait_loads = [&](int later) {                             // until at most `later` of this wave's loads are outstanding
+    switch (later) {
+      case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+      case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+      case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+      case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+      case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+      case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+      case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+      default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+  };
+#pragma unroll
+  for (int c = 0; c < NBUF - 1; ++c)
+    if (st_of(c) == 1) stage(c, cs_of(c));
   for (int ch = 0; ch < nch; ++ch) {
     const int tb = t0 + ch * QD_R, te = (tb + QD_R < t1) ? tb + QD_R : t1;
-    const float* __restrict__ T = tile[ch & 1];
-    __syncthreads();                                               // (waits for this wave's loads) chunk ch is in LDS; the other buffer is free
-    const int cs = cs_cur, st = st_cur;
-    if (ch + 1 < nch) {                                            // the next chunk's window: read BEFORE its loads are issued (a C++
-      cs_cur = __builtin_amdgcn_readfirstlane(chinfo[ch + 1][0]);  // LDS read after them would wait for them)
-      st_cur = __builtin_amdgcn_readfirstlane(chinfo[ch + 1][1]);
-      if (st_cur == 1) stage(ch + 1, cs_cur);
-    }
+    const float* __restrict__ T = tile[ch % NBUF];
+    const int cs = cs_of(ch), st = st_of(ch);
+    // this wave's loads of chunk ch have landed (those of the chunks staged after it may still fly), then the workgroup meets:
+    // chunk ch is complete in LDS and everybody has left the buffer chunk ch + NBUF - 1 goes into
+    int later = 0;
+#pragma unroll
+    for (int c = 1; c < NBUF - 1; ++c) later += (st_of(ch + c) == 1) ? per_stage : 0;
+    wait_loads(later);
+    asm volatile("s_barrier" ::: "memory");
+    if (st_of(ch + NBUF - 1) == 1) stage(ch + NBUF - 1, cs_of(ch + NBUF - 1));
     const bool full = (te - tb == QD_R);
     if (st == 1 && any) {
       const unsigned* __restrict__ Brow = static_cast<const unsigned*>(__builtin_assume_aligned(Ball + tb, 32));
@@ -1702,8 +1725,18 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
         if (fp.quad) {
           const int nwq = ceil_div(N + im->band + 4, QD_WO), ngq = ceil_div(im->nq, 4);
           dim3 gq(8 * ceil_div(nwq, 8) * ngq * nt, nb, 1);           // windows dealt to the XCDs in contiguous eighths (see the kernel)
-          hipLaunchKernelGGL(k_radon_fwd_quad<0>, gq, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->quad_dev, im->nq, ngq, na, nwq, bs, im->band,
-                             im->fidx, im->A32q, im->B32q, im->npad, im->ang_dev, im->A32, im->B32);
+          // tiles in flight per workgroup: 2 where the chip is full of workgroups anyway (four per CU hide each other's staging round
+          // trips), 4 where it is not (the chain of a workgroup's chunks is then bound by ONE round trip per chunk: see the kernel)
+          static const int qbuf_env = getenv("TRK_RADON_QBUF") ? atoi(getenv("TRK_RADON_QBUF")) : 0;
+          const int64_t wgs = (int64_t)nwq * ngq * nt * nb;
+          // (measured: deeper staging does not pay at any size — the extra LDS costs resident workgroups, 512^2: 40 -> 60 us with four
+          //  tiles in flight, 4096^2: 0.76 -> 1.34 ms; the knob stays for experiments)
+          (void)wgs;
+          const int qbuf = qbuf_env ? qbuf_env : 2;
+#define QUAD(NB) hipLaunchKernelGGL(k_radon_fwd_quad<NB>, gq, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->quad_dev, im->nq, ngq, na, nwq, bs, im->band, \
+                                    im->fidx, im->A32q, im->B32q, im->npad, im->ang_dev, im->A32, im->B32)
+          if (qbuf >= 4) QUAD(4); else if (qbuf == 3) QUAD(3); else QUAD(2);
+#undef QUAD
         } else {
           const int nwin = ceil_div(N + 2 * im->band + 16, 61);
           dim3 gw(nwin * ngrp * nt, nb, 1);
