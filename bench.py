@@ -307,35 +307,38 @@ def run_blur_cgls(args, rank, world, json_fd=1):
                      "cgls_alg_bytes_per_iter": 44.0 * n,
                      "cgls_effective_GBps": round(44.0 * n * K / elapsed / 1e9, 1)}}
 
-    # solver rates "history off and on", and what a reference-style call sees from idle.  Whole CGLS() calls of 100
-    # iterations (CGLS.py:16 semantics, tol = 0, device tensors in and out), wall clock around the call, synchronised both ends:
-    #   history off / on (the reference keeps every iterate, CGLS.py:66: here 100 rows of 67 MB on the device), after a warm call;
-    #   cold: ONE call after two seconds of an idle GPU, no run-in — the ~100-iteration clock / cache ramp of RUN_IN_ITERS is inside.
-    try:
-        from trips_py_amd.solvers import CGLS as _CGLS
-        solves = {}
-        for tag, hist in (("history_off", False), ("history_on", True)):
-            _CGLS(A, b, x0, 100, 0, history=hist)
-            torch.cuda.synchronize()
-            barrier(world)
-            ts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
+    def solves_leg():
+        """solver rates "history off and on", and what a reference-style call sees from idle.  Whole CGLS() calls of
+        100 iterations (CGLS.py:16 semantics, tol = 0, device tensors in and out), wall clock around the call, synchronised both ends:
+        history off / on (the reference keeps every iterate, CGLS.py:66: here 100 rows of 67 MB on the device), after a warm call;
+        cold: ONE call after two seconds of an idle GPU, no run-in — the ~100-iteration clock / cache ramp of RUN_IN_ITERS is inside.
+        Runs LAST of the GPU legs: the idle period it needs costs whatever is measured next its clocks (C2 at 512^2 read 53 k
+        instead of 70 k iterations/s right behind it)."""
+        try:
+            from trips_py_amd.solvers import CGLS as _CGLS
+            solves = {}
+            for tag, hist in (("history_off", False), ("history_on", True)):
                 _CGLS(A, b, x0, 100, 0, history=hist)
                 torch.cuda.synchronize()
-                ts.append(time.perf_counter() - t0)
-            solves[f"{tag}_iters_per_sec"] = round(world * 100 / max_over_ranks(float(np.median(ts)), world), 1)
-            torch.cuda.empty_cache()
-        time.sleep(2.0)
-        barrier(world)
-        t0 = time.perf_counter()
-        _CGLS(A, b, x0, 100, 0, history=False)
-        torch.cuda.synchronize()
-        solves["cold_100_iter_solve_iters_per_sec"] = round(world * 100 / max_over_ranks(time.perf_counter() - t0, world), 1)
-        solves["note"] = "whole CGLS() calls of 100 iterations at this size (constructor, loop, final norms, result), median of 3; cold: one call after 2 s idle"
-        res["extra"]["cgls_100_iter_solves"] = solves
-    except Exception as exc:          # noqa: BLE001
-        res["extra"]["cgls_100_iter_solves"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+                barrier(world)
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    _CGLS(A, b, x0, 100, 0, history=hist)
+                    torch.cuda.synchronize()
+                    ts.append(time.perf_counter() - t0)
+                solves[f"{tag}_iters_per_sec"] = round(world * 100 / max_over_ranks(float(np.median(ts)), world), 1)
+                torch.cuda.empty_cache()
+            time.sleep(2.0)
+            barrier(world)
+            t0 = time.perf_counter()
+            _CGLS(A, b, x0, 100, 0, history=False)
+            torch.cuda.synchronize()
+            solves["cold_100_iter_solve_iters_per_sec"] = round(world * 100 / max_over_ranks(time.perf_counter() - t0, world), 1)
+            solves["note"] = "whole CGLS() calls of 100 iterations at this size (constructor, loop, final norms, result), median of 3; cold: one call after 2 s idle"
+            return solves
+        except Exception as exc:          # noqa: BLE001
+            return {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     # Host baselines run AFTER every GPU measurement of this process: NumPy / SciPy work on the host wakes BLAS thread pools whose
     # idle spinning can exhaust the container's CPU quota, and the kernel then parks every thread for the rest of the period — a
@@ -373,6 +376,7 @@ def run_blur_cgls(args, rank, world, json_fd=1):
             except Exception as exc:          # noqa: BLE001
                 res["extra"][name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
             barrier(world)
+        res["extra"]["cgls_100_iter_solves"] = solves_leg()
         for put, job in cpu_jobs:             # every GPU number is in: now the host legs, each guarded
             put(guarded(job))
         watchdog.cancel()
@@ -549,13 +553,19 @@ def extra_c3_tomo(world, cpu_jobs=None):
             Hybrid_LSQR(R, bt, 100, reg, x_true=xt, history=False, **kw)
         barrier(world)
         reps = 5
+        each = []
         with no_gc():
             t0 = time.perf_counter()
             for _ in range(reps):
+                t1 = time.perf_counter()
                 _, info = Hybrid_LSQR(R, bt, 100, reg, x_true=xt, history=False, **kw)
+                each.append(time.perf_counter() - t1)
             barrier(world)
             dt = max_over_ranks(time.perf_counter() - t0, world)
         out[f"hybrid_lsqr{tag}_iters_per_sec_all_ranks"] = round(world * reps * 100 / dt, 1)
+        # the automatic selectors search on a host thread: one solve in eight is a third slower when the host stalls
+        # (tools/hybrid_selector_rates.py); the median solve beside the mean
+        out[f"hybrid_lsqr{tag}_median_solve_iters_per_sec"] = round(world * 100 / max_over_ranks(float(np.median(each)), world), 1)
         out[f"hybrid_lsqr{tag}_relError_last"] = float(info["relError"][-1])
     if cpu_jobs is not None:
         bh = bt.detach().to("cpu")
