@@ -440,7 +440,7 @@ class GramSchmidtByGram:
             eng.cgs_coeffs(self.G.ref(0), self.kmax, None, self.W.ref(0), j + 1, 0, None)
         self.in_G = V.k
 
-    def sweep(self, k, w, passes, out, sumsq=None, c_out=None, extra=()):
+    def sweep(self, k, w, passes, out, sumsq=None, c_out=None, extra=(), tail=0):
         """out = w orthogonalised against V[0..k) by `passes` sweeps; LOCAL sum(out^2) into `sumsq` (fused).  Returns the
         DevScalars reference of the k combined coefficients.  extra: one or two more vectors z whose products V^T z ride on
         the same pass over the basis (trk_gemv_tn); they are left at `self.extra_ref(q, k)`."""
@@ -452,7 +452,10 @@ class GramSchmidtByGram:
             if self.in_G != k - 1 or len(extra) > 2:
                 raise RuntimeError("GramSchmidtByGram: extra right-hand sides ride on the sweep that installs the newest vector's row")
             eng.gemv_tn(V.data, k, [w, V[k - 1]] + list(extra), W.ref(0))
-            eng.allreduce(W, 0, (2 + len(extra)) * k)
+            # tail: scalars the caller has put right behind the products (GKS: r . A^T A r, r . L^T L r, r . A^T b) share the exchange
+            if (2 + len(extra)) * k + tail > 4 * K:
+                raise ValueError("GramSchmidtByGram: no room behind the sweep's products")
+            eng.allreduce(W, 0, (2 + len(extra)) * k + tail)
             eng.cgs_coeffs(self.G.ref(0), K, W.ref(0), W.ref(k), k, passes, c)
             self.in_G = k
         elif self.in_G == k - 1:                      # the newest vector's Gram row rides along with h

@@ -190,36 +190,43 @@ class _ProjectedBases:
     # The new vector is v_k = (r - V c)/rho; G[i][k] = v_i . M v_k follows from a = V^T (M r), which rides on the sweep that
     # orthogonalises r (krylov.GramSchmidtByGram.sweep(extra=...), trk_gemv_tn), and from c, r . M r, rho^2
     # (trk_gram_row_from_sweep).  Per iteration GKS then passes over V three times (x = V y, the sweep, r - V c), not four.
-    def sweep_operands(self, r):
-        """The vectors whose V^T products the sweep must also take, and the scalars r . M r (and r . A^T b): call before the sweep."""
-        eng, S = self.eng, self.S
+    def sweep_operands(self, r, scal=None, off=0):
+        """The vectors whose V^T products the sweep must also take, and the scalars r . M r (and r . A^T b): call before the sweep.
+        scal / off: put the three scalars at scal[off .. off + 3) and leave their sum over ranks to the caller (GKS puts them right
+        behind the sweep's own products, so that ONE all-reduce carries both: three exchanges per iteration on ranks, not four)."""
+        eng = self.eng
+        own = scal is None
+        S, o = (self.S, 0) if own else (scal, int(off))
+        self._sw = (S, o)
         extra = []
         if self.from_v_A:
-            self.A.apply(r, out=self.tA, sumsq=S.ref(0))                  # ||A r||^2 = r . A^T A r
+            self.A.apply(r, out=self.tA, sumsq=S.ref(o))                  # ||A r||^2 = r . A^T A r
             self.A.apply(self.tA, out=self.zA, transpose=True)
-            eng.dot(r, self.atb, S.ref(2))
+            eng.dot(r, self.atb, S.ref(o + 2))
             extra.append(self.zA)
         if self.from_v_L:
             hk = {} if self.halo is None else {"halo": self.r_halo}
             if self.tL is None and hasattr(getattr(eng, "lib", None), "trk_tv_grad_dot") and _TVDOT:
-                self.L.tv_grad(r, None, None, 1.0, out=self.zL, dot_with=r, dot_out=S.ref(1), **hk)   # z_L = L^T L r and r . z_L, one pass
+                self.L.tv_grad(r, None, None, 1.0, out=self.zL, dot_with=r, dot_out=S.ref(o + 1), **hk)   # z_L = L^T L r and r . z_L, one pass
             else:
                 if self.tL is None:
                     self.L.tv_grad(r, None, None, 1.0, out=self.zL, **hk)
                 else:
                     self.L.apply(r, out=self.tL)
                     self.L.apply(self.tL, out=self.zL, transpose=True)
-                eng.dot(r, self.zL, S.ref(1))                             # r . L^T L r
+                eng.dot(r, self.zL, S.ref(o + 1))                         # r . L^T L r
             extra.append(self.zL)
-        eng.allreduce(S, 0, 3)
+        if own:
+            eng.allreduce(S, 0, 3)
         return extra
 
     def append_from_sweep(self, gs, k, c, rho2):
         """After the sweep over k vectors (coefficients c, rho^2 = ||r - V c||^2) and the commit of v_k: rows k of the Gram data."""
         eng, S = self.eng, self.S
+        Sw, so = getattr(self, "_sw", (self.S, 0))                          # where sweep_operands left r . M r
         q = 0
         if self.from_v_A:
-            eng.gram_row_from_sweep(self.GA_d.ref(0), self.kmax, k, gs.extra_ref(q, k), c, S.ref(0), rho2, rhs=self.c_d.ref(0), tb=S.ref(2))
+            eng.gram_row_from_sweep(self.GA_d.ref(0), self.kmax, k, gs.extra_ref(q, k), c, Sw.ref(so), rho2, rhs=self.c_d.ref(0), tb=Sw.ref(so + 2))
             q += 1
         else:                                                             # the images of A are kept (small m): as in _push_images
             av = self.AV.next_slot()
@@ -241,7 +248,7 @@ class _ProjectedBases:
                 eng.gemv_t(self.AV.data, k + 1, av, S.ref(4))
             eng.cgs_coeffs(self.GA_d.ref(0), self.kmax, None, S.ref(4), k + 1, 0, None)
         if self.from_v_L:
-            eng.gram_row_from_sweep(self.GL_d.ref(0), self.kmax, k, gs.extra_ref(q, k), c, S.ref(1), rho2)
+            eng.gram_row_from_sweep(self.GL_d.ref(0), self.kmax, k, gs.extra_ref(q, k), c, Sw.ref(so + 1), rho2)
 
 
 @small_host_blas
@@ -346,7 +353,10 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         cc = None
         if merged:
             # the sweep's pass over V also takes V^T (A^T A r), V^T (L^T L r): the next vector's Gram rows need no pass of their own
-            cc = gs_gram.sweep(k, r, 3, vn, sumsq=R.ref(ii), extra=pb.sweep_operands(r))
+            # (the three scalars r . M r ride behind the sweep's products: one all-reduce for both)
+            n_extra = int(pb.from_v_A) + int(pb.from_v_L)
+            off = (2 + n_extra) * k
+            cc = gs_gram.sweep(k, r, 3, vn, sumsq=R.ref(ii), extra=pb.sweep_operands(r, scal=gs_gram.W, off=off), tail=3)
         elif gs_gram is not None:
             cc = gs_gram.sweep(k, r, 3, vn, sumsq=R.ref(ii))                         # (:86-88) three sweeps, ||r||^2 fused
         else:
