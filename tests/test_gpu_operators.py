@@ -167,6 +167,42 @@ def test_radon_shared_window_forward_vs_oracle(case):
     assert abs(dd[0] - dd[1]) <= 1e-6 * float(torch.linalg.norm(Rx.double()) * torch.linalg.norm(yd.double()))
 
 
+@pytest.mark.parametrize("N,na,nd", [(200, 90, 200), (256, 180, 256), (288, 60, 410), (512, 180, 512), (800, 40, 800)])
+def test_radon_adjoint_with_the_angles_of_a_tile_split_over_workgroups(N, na, nd):
+    """Small images, many angles: the adjoint runs 32 x 32 tiles whose angles are split over 4 or 8 workgroups; the partial tiles
+    meet in the workgroup that takes the last ticket (k_radon_adj_tile, nsplit > 1).  (a) Against the float64 oracle at 1e-5, at
+    sizes with ragged tiles (200, 288, 800 are not multiples of 32) and angle counts that do not divide evenly; (b) the hand-off
+    between workgroups (write-through stores, ticket, loads past the L1) under load: 40 applies interleaved with forward applies
+    and a different sinogram in between, every result bit-identical to the first — a stale partial tile would differ."""
+    from oracle import cpu_ref as O
+    from trips_py_amd.operators import Radon2DParallel
+    rng = np.random.default_rng(N + na)
+    ang = np.linspace(0, np.pi, na, endpoint=False)
+    R, Ro = Radon2DParallel(N, ang, n_det=nd), O.Radon2D(N, ang, n_det=nd)
+    y = rng.standard_normal(Ro.shape[0]).astype(np.float32)
+    ref = Ro.T @ y.astype(np.float64)
+    eng = R.engine
+    yd = torch.from_numpy(y).to(eng.device)
+    y2 = torch.from_numpy(rng.standard_normal(Ro.shape[0]).astype(np.float32)).to(eng.device)
+    first = R.apply(yd, transpose=True).clone()
+    assert relerr(first.cpu().numpy().astype(np.float64), ref) < 1e-5
+    out, tmp, sino = torch.empty_like(first), torch.empty_like(first), torch.empty_like(yd)
+    for k in range(40):
+        R.apply(y2, out=tmp, transpose=True)          # other partial tiles in the same buffers
+        if k % 3 == 0:
+            R.apply(tmp, out=sino)
+        R.apply(yd, out=out, transpose=True)
+        assert torch.equal(out, first), k
+    # the fused half step on the same path: a * A^T y + b * z with its norm
+    z = torch.from_numpy(rng.standard_normal(N * N).astype(np.float32)).to(eng.device)
+    S = eng.scalars(1)
+    o2 = torch.empty_like(first)
+    R.apply_axpby(yd, 1.0, -0.5, z, o2, transpose=True, sumsq=S.ref(0))
+    want = first.double() - 0.5 * z.double()
+    assert relerr(o2.double().cpu().numpy(), want.cpu().numpy()) < 1e-6
+    assert abs(S.host()[0] - float((o2.double() ** 2).sum())) <= 1e-9 * float((o2.double() ** 2).sum())
+
+
 @pytest.mark.parametrize("N,na", [(64, 20), (512, 180), (1500, 24)])
 def test_radon_invariants(N, na):
     """What pins the Radon operator: exact-adjoint identity, axis-aligned views = column / row sums, mass conservation,

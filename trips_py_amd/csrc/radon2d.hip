@@ -84,6 +84,10 @@ struct RadonImpl {
   int4* adj_pos;     // [nt*na]: angle row (caller's order) -> {its sorted row (the inverse of adj_ang[].orig), that row's
                      // adjoint weight (bits), its flip flag, 0}: one load where the record writer chased three
   int n_bands, band;
+  // adjoint with the angles of a tile split over `nsplit` workgroups (small images): partial tiles and one counter per tile
+  float* adj_part;
+  unsigned* adj_cnt;
+  int64_t adj_part_cap, adj_cnt_cap;
   // quads: groups of up to four symmetric angles served by one wave of k_radon_fwd_quad (nq per frame, padded with empty ones)
   QuadParam* quad_dev;
   unsigned* A32q;   // [nt*nq][nd + 4]  base tables
@@ -1198,7 +1202,8 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
                                                         const AdjAngle* __restrict__ ang, const float* __restrict__ wgt,
                                                         const unsigned* __restrict__ A32, const int* __restrict__ n_mode0,
                                                         const uint2* __restrict__ CB, int npad, int tiles_x,
-                                                        double* __restrict__ ssq_part, Epi epi, float* __restrict__ xT_out) {
+                                                        double* __restrict__ ssq_part, Epi epi, float* __restrict__ xT_out,
+                                                        int nsplit, float* __restrict__ part_img, unsigned* __restrict__ tile_cnt) {
   __shared__ __attribute__((aligned(16))) uint4 ring[2][AB][64];
   __shared__ __attribute__((aligned(16))) uint2 cbs[2][AB][T];
   __shared__ float xch[PX > 1 ? T : 1][T + 1];
@@ -1207,19 +1212,30 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int frame = blockIdx.y;
-  const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+  // nsplit > 1 (small images: too few tiles to fill the chip with 32 x 32 tiles): workgroup (part, tile) gathers the sorted
+  // angles [a_lo, a_hi) of the frame for its tile; the partial tiles meet in the workgroup that finishes LAST (below).  Parts of
+  // one tile are ntiles workgroups apart: the same XCD when ntiles % 8 == 0 (speed only)
+  const int ntiles = tiles_x * tiles_x;
+  const int part = nsplit > 1 ? blockIdx.x / ntiles : 0;
+  const int tile_id = blockIdx.x - part * ntiles;
+  const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
   const int i0 = ty * T, j0 = tx * T;
   const int ndp = nd + 2 * A32_PAD;
-  ang += (int64_t)frame * na;
-  wgt += (int64_t)frame * na;
+  const int a_lo = nsplit > 1 ? (int)(((int64_t)part * na) / nsplit) : 0;
+  const int a_hi = nsplit > 1 ? (int)(((int64_t)(part + 1) * na) / nsplit) : na;
   sino += (int64_t)frame * na * nd;
-  rec += (int64_t)frame * na * ndp;
   A32 += (int64_t)frame * na * ndp;
-  const auto rrec = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, (unsigned)((int64_t)na * ndp * 16), 0x00020000);
   CB += (int64_t)frame * na * npad;
-  const int n0 = n_mode0[frame];
+  int n0 = n_mode0[frame] - a_lo;
+  ang += (int64_t)frame * na + a_lo;                   // from here on `na` is the part's angle count and angle 0 its first
+  wgt += (int64_t)frame * na + a_lo;
+  rec += ((int64_t)frame * na + a_lo) * ndp;
+  const int na_frame = na;
+  na = a_hi - a_lo;
+  n0 = n0 < 0 ? 0 : (n0 > na ? na : n0);
+  const auto rrec = __builtin_amdgcn_make_buffer_rsrc((void*)rec, 0, (unsigned)((int64_t)na * ndp * 16), 0x00020000);
   const float sdh = 0.5f * (float)(nd - 1);
-  const auto rcb = __builtin_amdgcn_make_buffer_rsrc((void*)CB, 0, (unsigned)((int64_t)na * npad * 8), 0x00020000);
+  const auto rcb = __builtin_amdgcn_make_buffer_rsrc((void*)CB, 0, (unsigned)((int64_t)na_frame * npad * 8), 0x00020000);
 
   // thread -> pixels.  mode 0 (marching index = row): row r0, columns c0 + k T/PX;  mode 1 (= column): column c1, rows
   // r1 + k T/PX, k < PX (PX = 1: the same pixel in both).  Neighbouring lanes hold NEIGHBOURING pixels, so the 16 lanes of a
@@ -1416,6 +1432,53 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
     for (int k = 0; k < PX; ++k) xch[r0][c0 + k * TS] = accA[k] + (anA[k][0] + anA[k][1]);
     __syncthreads();
   }
+  float oraw[PX];
+#pragma unroll
+  for (int k = 0; k < PX; ++k)
+    oraw[k] = (accB[k] + (anB[k][0] + anB[k][1])) + (PX > 1 ? xch[r1 + k * TS][c1] : accA[k] + (anA[k][0] + anA[k][1]));
+  if (PX == 4 && nsplit > 1) {                                     // (the host splits only the 32 x 32 form)
+    // The parts of a tile meet: every workgroup leaves its partial tile (thread-major, 16 bytes per lane), then takes a ticket; the
+    // one that draws the LAST ticket adds the partial tiles in part order (the same bits whoever comes last) and carries the
+    // epilogue.  The parts may have run on different XCDs, whose L2s are not coherent: the bytes are stored WRITE-THROUGH (sc1) and
+    // loaded past the L1 (sc1), every storing wave drains its stores before the workgroup's one ticket (an agent-scope atomic add),
+    // and the loads are issued only after the add has returned and the workgroup has met (MI355X_MICROARCH.md, inter-workgroup
+    // visibility: the "workgroup whose add came last" hand-off).  A release / acquire fence pair per workgroup instead
+    // (__threadfence) writes back and invalidates whole caches: 512^2 x 180 ran 130 us instead of 33.
+    constexpr int MAXSPLIT = 8;
+    const int64_t pstride = (int64_t)gridDim.y * ntiles * (T * T);
+    float* P = part_img + ((int64_t)frame * ntiles + tile_id) * (T * T) + tid * PX;     // (not __restrict__: the other parts write it too)
+    {
+      f4r v = {oraw[0], oraw[PX > 1 ? 1 : 0], oraw[PX > 2 ? 2 : 0], oraw[PX > 3 ? 3 : 0]};
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(P + part * pstride), "v"(v) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    __shared__ unsigned ticket;
+    unsigned* cnt = tile_cnt + (int64_t)frame * ntiles + tile_id;
+    if (tid == 0) ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (ticket != (unsigned)(nsplit - 1)) return;
+    if (tid == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
+    f4r pv[MAXSPLIT];
+#pragma unroll
+    for (int s = 0; s < MAXSPLIT; ++s) {
+      // straight-line code (parts beyond nsplit re-read part 0 and are not added): a branch around an inline-assembly load would
+      // let the compiler copy its destination at the join, before the data has arrived
+      const float* src = P + (s < nsplit ? s : 0) * pstride;
+      asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(pv[s]) : "v"(src) : "memory");
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int s = 0; s < MAXSPLIT; ++s) asm volatile("" : "+v"(pv[s]));
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+      float t = pv[0][k];
+#pragma unroll
+      for (int s = 1; s < MAXSPLIT; ++s) t = s < nsplit ? t + pv[s][k] : t;
+      oraw[k] = t;
+    }
+  }
+  const bool lead = tile_id == 0 && blockIdx.y == 0;               // the workgroup that carries the once-per-launch duties
   double q = 0.0;
   img += (int64_t)frame * N * N;
   // epilogue (trk_op_apply_axpby): out = a * (A^T s) + b * z; xT_out: also the transposed image the next forward apply wants
@@ -1439,12 +1502,12 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
   }
   float ca, cb;
   double pend_sum = 0.0, cad, cbd;
-  epi_coefs(epi, blockIdx.x == 0 && blockIdx.y == 0, &lds[0], ca, cb, &pend_sum, &cad, &cbd);
+  epi_coefs(epi, lead, &lds[0], ca, cb, &pend_sum, &cad, &cbd);
   if (xT_out) xT_out += (int64_t)frame * N * N;
 #pragma unroll
   for (int k = 0; k < PX; ++k) {
     const int i = i0 + r1 + k * TS, j = j0 + c1;
-    float o = (accB[k] + (anB[k][0] + anB[k][1])) + (PX > 1 ? xch[r1 + k * TS][c1] : accA[k] + (anA[k][0] + anA[k][1]));
+    float o = oraw[k];
     if (i < N && j < N) {
       if (epi.on) o = epi_combine(epi.on, ca, cb, cad, cbd, o, zv[k], epi.z != nullptr);
       img[(int64_t)i * N + j] = o;
@@ -1454,9 +1517,9 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
   }
   if (ssq_part) {                                                 // uniform over the grid
     q = block_sum<256>(q, lds);
-    if (tid == 0) ssq_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = q;
+    if (tid == 0) ssq_part[(size_t)blockIdx.y * ntiles + tile_id] = q;
   }
-  if (epi.pq.on && blockIdx.x == 0 && blockIdx.y == 0 && tid < 64) {
+  if (epi.pq.on && lead && tid < 64) {
     // the mailbox post of the step before (k_mailbox_post / k_mailbox_post_sum, core.hip): its scalars are final here — the
     // deferred one is `pend_sum`, which this workgroup has just stored — and the host polls the sequence word
     const PostReq& Q = epi.pq;
@@ -1500,7 +1563,7 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
       lcf[0] = 1.0 / alpha;
       lcf[1] = tw;
       lcf[2] = cs * phibar / rho;
-      if (blockIdx.x == 0 && blockIdx.y == 0) {
+      if (lead) {
         L.st_out[0] = cs;
         L.st_out[1] = sn;
         L.st_out[2] = rho;
@@ -1528,7 +1591,7 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
     }
     if (L.ref) {
       acc = block_sum<256>(acc, lds);
-      if (tid == 0) L.err_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = acc;
+      if (tid == 0) L.err_part[(size_t)blockIdx.y * ntiles + tile_id] = acc;
     }
   }
 }
@@ -1646,7 +1709,19 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   static const int tile_env = getenv("TRK_RADON_ADJ_TILE") ? atoi(getenv("TRK_RADON_ADJ_TILE")) : 0;
   // measured: 512^2 x 180 (one frame: 256 / 1024 tiles) 51 vs 42 us; 32 frames x 256^2 x 15 (2048 / 8192 tiles) 21 vs 34 us
   const int64_t tiles32 = (int64_t)ceil_div(N, 32) * ceil_div(N, 32) * nt;
-  const int tile_T = tile_env ? tile_env : (tiles32 >= 1024 ? 32 : 16);
+  // Too few 32 x 32 tiles to fill the chip, many angles: the angles of a tile are SPLIT over nsplit workgroups whose partial tiles
+  // meet in the one that finishes last (k_radon_adj_tile) — the instructions per pixel and angle of the 32 x 32 form (10.25 against
+  // 14.5 for 16 x 16 tiles with one pixel per thread, where the staging of a batch is shared by a quarter of the pixels) at the
+  // same number of waves.  TRK_RADON_ADJ_SPLIT: 1 = off, 2 / 4 / 8 forces.
+  static const int split_env = getenv("TRK_RADON_ADJ_SPLIT") ? atoi(getenv("TRK_RADON_ADJ_SPLIT")) : 0;
+  int nsplit = 1;
+  // measured (us per apply, 180 angles; 16 x 16 tiles -> split 2 / 4 / 8): 256^2 24.1 -> 32.6 / 21.4 / 16.3, 512^2 32.9 -> 36.5 / 29.8 /
+  // 29.8, 768^2 63.2 -> 54.8 / 50.4 / 50.9; 1024^2 (1024 tiles: 32 x 32 unsplit already) 83 with or without
+  if (tile && !tile_env && batch == 1 && tiles32 < (split_env > 1 ? 4096 : 1024) && na > 32 && N >= 64) {
+    nsplit = split_env ? split_env : (tiles32 <= 128 ? 8 : 4);
+    nsplit = nsplit >= 8 ? 8 : (nsplit >= 4 ? 4 : (nsplit >= 2 ? 2 : 1));
+  }
+  const int tile_T = tile_env ? tile_env : ((tiles32 >= 1024 || nsplit > 1) ? 32 : 16);
   static const int ab_env = getenv("TRK_RADON_ADJ_AB") ? atoi(getenv("TRK_RADON_ADJ_AB")) : 0;
   const int tiles_x = ceil_div(N, tile_T);
   const int64_t adj_blocks = tile ? (int64_t)tiles_x * tiles_x : (int64_t)ceil_div((int64_t)N * N, 256);
@@ -1777,10 +1852,28 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
       }
       static const bool no_xt_out = getenv("TRK_RADON_NO_XT_OUT") != nullptr;
       float* xT_out = ((hints & HINT_OUT_FEEDS_OPPOSITE) && tile && im->n_mode1 > 0 && batch == 1 && !no_xt_out) ? im->xT : nullptr;
+      if (nsplit > 1) {
+        const int64_t need = (int64_t)nsplit * nt * adj_blocks * 1024, need_c = (int64_t)nt * adj_blocks;
+        if (im->adj_part_cap < need) {
+          if (im->adj_part) hipFree(im->adj_part);
+          im->adj_part = nullptr;
+          im->adj_part_cap = 0;
+          if (hipMalloc((void**)&im->adj_part, sizeof(float) * (size_t)need) != hipSuccess) return fail(TRK_EHIP, "radon: hipMalloc (adjoint partial tiles) failed");
+          im->adj_part_cap = need;
+        }
+        if (im->adj_cnt_cap < need_c) {
+          if (im->adj_cnt) hipFree(im->adj_cnt);
+          im->adj_cnt = nullptr;
+          im->adj_cnt_cap = 0;
+          if (hipMalloc((void**)&im->adj_cnt, sizeof(unsigned) * (size_t)need_c) != hipSuccess) return fail(TRK_EHIP, "radon: hipMalloc (adjoint tile counters) failed");
+          if (hipMemsetAsync(im->adj_cnt, 0, sizeof(unsigned) * (size_t)need_c, s) != hipSuccess) return fail(TRK_EHIP, "radon: hipMemsetAsync failed");
+          im->adj_cnt_cap = need_c;
+        }
+      }
 #define ADJ_TILE(TT, PP, BB, PR)                                                                                              \
-  hipLaunchKernelGGL((k_radon_adj_tile<TT, PP, BB, PR>), dim3((unsigned)adj_blocks, nt), dim3(256), 0, s, xb, im->rec,          \
+  hipLaunchKernelGGL((k_radon_adj_tile<TT, PP, BB, PR>), dim3((unsigned)(adj_blocks * nsplit), nt), dim3(256), 0, s, xb, im->rec, \
                      y + (int64_t)b * ldy, N, nd, na, im->adj_ang, im->adj_wgt, im->A32, im->adj_n0, im->CB, im->npad, tiles_x, \
-                     ssq_part, epi, xT_out)
+                     ssq_part, epi, xT_out, nsplit, im->adj_part, im->adj_cnt)
       if (tile && tile_T == 32) {
         if (adj_prep) ADJ_TILE(32, 4, 8, true); else ADJ_TILE(32, 4, 8, false);
       } else if (tile && (ab_env ? ab_env == 16 : na > 32)) {
@@ -1847,7 +1940,7 @@ int radon_apply_axpby(trk_op* op, int tr, const float* x, Coef a, Coef b, const 
 
 void radon_destroy(trk_op* op) {
   auto* im = static_cast<RadonImpl*>(op->impl);
-  void* ptrs[] = {im->quad_dev, im->A32q, im->B32q, im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec, im->adj_pos, im->pend_buf[0], im->pend_buf[1]};
+  void* ptrs[] = {im->quad_dev, im->A32q, im->B32q, im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec, im->adj_pos, im->pend_buf[0], im->pend_buf[1], im->adj_part, im->adj_cnt};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete im;
