@@ -9,6 +9,6 @@ for N, views in ((256, 90), (512, 180), (1024, 180)):
         fn(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(5): fn()
+        for _ in range(20): fn()
         e1.record(); torch.cuda.synchronize()
-        print(f"fanbeam {N}^2 x {views} views x {R.n_det} det {name}: {e0.elapsed_time(e1)/5:9.3f} ms")
+        print(f"fanbeam {N}^2 x {views} views x {R.n_det} det {name}: {e0.elapsed_time(e1)/20:9.3f} ms")

@@ -1,0 +1,16 @@
+"""Fan-beam forward / adjoint applies at one size (default 512^2 x 180 views): the program behind tools/gpu_pmc_cmd.sh / gpu_prof_cmd.sh."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from trips_py_amd.operators import FanBeam2D
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
+views = int(sys.argv[2]) if len(sys.argv) > 2 else 180
+R = FanBeam2D(N, views=views)
+x = torch.rand(N * N, device="cuda"); y = torch.empty(R.shape[0], device="cuda"); z = torch.empty(N * N, device="cuda")
+for name, fn in (("fwd", lambda: R.apply(x, out=y)), ("adj", lambda: R.apply(y, out=z, transpose=True))):
+    fn(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20): fn()
+    e1.record(); torch.cuda.synchronize()
+    print(f"fanbeam {N}^2 x {views} views x {R.n_det} det {name}: {e0.elapsed_time(e1) / 20 * 1e3:9.1f} us")

@@ -65,29 +65,46 @@ struct FanImpl {
 // The position is a 64-bit integer X0 + tt * M in units of 2^-30 — in fp32 it carried 6e-8 N of error, 1.5e-5 relative on white
 // noise in the adjoint at N = 132 already and growing with N; like this every weight is within 2^-24 of its exact value whatever
 // N, and the forward and the adjoint evaluate the very same integers.
+// The fraction of a step's segment that lies in its first column: the interval [lo, lo + |M|) reaches the next integer, `dist` away,
+// when |M| >= dist and is split there at dist / |M|; otherwise all of it lies in the first column.  Both cases are ONE multiply with
+// the hardware clamp to [0, 1] (dist / |M| > 1 exactly when the integer is not reached; |M| = 0 comes with a reciprocal of 2^-2,
+// dist >= 4): the compare / min / select form was five of the ~20 vector instructions of a marching step.
+// `frac32` is the position's fraction in units of 2^-32 (the 30 fraction bits of the tables, shifted up by two: then the carry of a
+// 32-bit add IS the step into the next column); dist = 2^32 - frac32 = ~frac32 + 1 — the NOT in the integer unit (2^32 itself does
+// not fit a register), the + 1 inside the FMA: f = clamp((float)(~frac32) * inv32 + inv32), exact for small distances, where it
+// matters.  `inv32` = 1 / (|M| in units of 2^-32); |M| = 0: 1.0 (any distance then clamps to 1).  The forward and the adjoint both
+// call this: the same bits on the same integers.
+__device__ __forceinline__ float fan_split(unsigned frac32, float inv32) {
+  float f;
+  const float fd = (float)(~frac32);
+  asm("v_fma_f32 %0, %1, %2, %2 clamp" : "=v"(f) : "v"(fd), "v"(inv32));
+  return f;
+}
+
 struct FanRayRegs {
   long long x0;      // low bit cleared
-  int m, mneg, absm;
-  float inv_absm;
+  int m, mneg;
+  float inv32;       // 1 / (|M| in units of 2^-32); |M| = 0: 1.0 (fan_split)
   bool shallow;
 };
+__device__ __forceinline__ float fan_inv32(int m) {
+  const int absm = m < 0 ? -m : m;
+  return absm > 0 ? 0.25f * __builtin_amdgcn_rcpf((float)absm) : 1.0f;
+}
 __device__ __forceinline__ FanRayRegs fan_ray_regs(const FanRay& q) {
   FanRayRegs r;
   r.shallow = (q.x0_lo & 1u) != 0u;
   r.x0 = ((long long)q.x0_hi << 32) | (long long)(q.x0_lo & ~1u);
   r.m = q.m;
   r.mneg = q.m < 0 ? q.m : 0;
-  r.absm = q.m < 0 ? -q.m : q.m;
-  r.inv_absm = __builtin_amdgcn_rcpf((float)(r.absm > 0 ? r.absm : 1));
+  r.inv32 = fan_inv32(q.m);
   return r;
 }
 // the step whose interval starts at `lo` (= X0 + tt M + min(M, 0), 64-bit fixed point)
 __device__ __forceinline__ void fan_step_at(long long lo, const FanRayRegs& r, int& cl, float& w0, float& w1) {
   cl = (int)(lo >> FAN_Q);
-  const int dist = (1 << FAN_Q) - (int)((unsigned)lo & ((1u << FAN_Q) - 1u));         // to the next integer, in (0, 2^30]
-  const float f = (r.absm >= dist) ? fminf((float)dist * r.inv_absm, 1.f) : 1.f;      // the interval reaches it: split there
-  w0 = f;
-  w1 = 1.f - f;
+  w0 = fan_split((unsigned)lo << (32 - FAN_Q), r.inv32);
+  w1 = 1.f - w0;
 }
 __device__ __forceinline__ void fan_step(int tt, const FanRayRegs& r, int& cl, float& w0, float& w1) {
   fan_step_at(r.x0 + (long long)tt * (long long)r.m + (long long)r.mneg, r, cl, w0, w1);
@@ -117,7 +134,7 @@ typedef float fan_f2 __attribute__((ext_vector_type(2)));
 
 // gridDim.y > 1: the march is cut into that many bands of `band` steps, band b leaving its sum (without the ray's length) in
 // part[b][ray] for k_fan_bands_sum — one thread per ray is 2 waves per SIMD at 512^2 x 180 x 724, too few to hide the gathers.
-__global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__ P0, const float* __restrict__ P1,
+__global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__ P0, int64_t padded,
                                                        float* __restrict__ sino, int N, int64_t nrays,
                                                        const FanRay* __restrict__ rays, int band, float* __restrict__ part) {
   const int64_t ray = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -125,25 +142,40 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
   const FanRay gq = rays[ray];
   const FanRayRegs g = fan_ray_regs(gq);
   const int W = N + 2 * FAN_PAD;
-  const float* __restrict__ I = (g.shallow ? P1 : P0) + FAN_PAD;
+  // both padded copies behind ONE buffer resource (they are one allocation: P1 = P0 + padded): the step's address is then
+  //   [scalar]  row (t0 + u) W 4   +   [vector]  4 clamp(cl) + (the ray's copy, the pad)   — one v_lshl_add per step
+  // where pointer arithmetic took a 64-bit add for the row and a sign extension + 64-bit add for the column
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)P0, 0, (unsigned)(2 * padded * 4), 0x00020000);
+  const unsigned lane_base = (g.shallow ? (unsigned)(padded * 4) : 0u) + FAN_PAD * 4u;
   float acc0 = 0.f, acc1 = 0.f;
   int t0 = blockIdx.y * band;
   const int t_end = (t0 + band < N) ? t0 + band : N;
+  const int Nimg = N;
   N = t_end;                                             // (the march below runs to N)
-  long long pos = g.x0 + (long long)g.mneg + (long long)t0 * (long long)g.m;   // exact integers: stepping by M accumulates nothing
-  const float* __restrict__ row = I + (int64_t)t0 * W;   // (one 64-bit add per step instead of a 64-bit multiply-add)
-  const int Nimg = W - 2 * FAN_PAD;
+  // the position as column + fraction in units of 2^-32: stepping by M is a 32-bit add whose carry moves the column (exact integers:
+  // nothing accumulates); M = mi + mf with mi = floor(M) in {-1, 0, 1}, mf in [0, 1)
+  const long long pos0 = g.x0 + (long long)g.mneg + (long long)t0 * (long long)g.m;
+  int col = (int)(pos0 >> FAN_Q);
+  unsigned frac = (unsigned)pos0 << (32 - FAN_Q);
+  const int mi = g.m >> FAN_Q;
+  const unsigned mf = (unsigned)g.m << (32 - FAN_Q);
   for (; t0 + 8 <= N; t0 += 8) {
     float w0[8], w1[8];
     fan_f2 v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
+      w0[u] = fan_split(frac, g.inv32);
+      w1[u] = 1.f - w0[u];
       int cl;
-      fan_step_at(pos, g, cl, w0[u], w1[u]);
-      pos += g.m;
-      cl = cl < -FAN_PAD ? -FAN_PAD : (cl > Nimg ? Nimg : cl);
-      v[u] = *reinterpret_cast<const fan_f2*>(row + cl);                             // 4-byte aligned 8-byte load
-      row += W;
+      asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cl) : "v"(col), "n"(-FAN_PAD), "s"(Nimg));
+      int rowoff = (t0 + u) * W * 4;                     // wave-uniform: a scalar
+      asm("" : "+s"(rowoff));
+      unsigned off;
+      asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(off) : "v"(cl), "v"(lane_base));
+      v[u] = __builtin_bit_cast(fan_f2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off, rowoff, 0));
+      const unsigned nf = frac + mf;
+      col += mi + (nf < frac ? 1 : 0);
+      frac = nf;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -157,7 +189,7 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
     float w0, w1;
     fan_step(t0, g, cl, w0, w1);
     cl = cl < -FAN_PAD ? -FAN_PAD : (cl > Nimg ? Nimg : cl);
-    const float* q = I + (int64_t)t0 * W + cl;
+    const fan_f2 q = __builtin_bit_cast(fan_f2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(((unsigned)cl << 2) + lane_base), t0 * W * 4, 0));
     acc0 = fmaf(w0, q[0], acc0);
     acc1 = fmaf(w1, q[1], acc1);
   }
@@ -182,7 +214,7 @@ __global__ __launch_bounds__(256) void k_fan_bands_sum(const float* __restrict__
 // the reciprocal per candidate were a third of the adjoint's instructions.
 struct FanRec {
   unsigned x0_lo;    // as FanRay (bit 0: class)
-  float inv_absm;    // the float fan_ray_regs() computes from M — the same bits as the forward uses
+  float inv32;       // the float fan_ray_regs() computes from M — the same bits as the forward uses
   int m;
   float len_s;       // len * S[a][d]
 };
@@ -195,7 +227,7 @@ __global__ __launch_bounds__(256) void k_fan_adj_prep(const float* __restrict__ 
   const FanRay q = rays[i];
   FanRec o;
   o.x0_lo = q.x0_lo;
-  o.inv_absm = fan_ray_regs(q).inv_absm;
+  o.inv32 = fan_inv32(q.m);
   o.m = q.m;
   o.len_s = q.len * sino[(int64_t)blockIdx.y * ld_sino + i];
   recs[(int64_t)blockIdx.y * nrays + i] = o;
@@ -235,9 +267,7 @@ __global__ __launch_bounds__(256) void k_fan_adj_march(float* __restrict__ img,
     // fan_step_at() on the position relative to the pixel, modulo 4 columns: rel = X0 + tt M + min(M, 0) - want   (2^-30 units)
     const unsigned rel = (q.x0_lo & ~1u) + tt * (unsigned)q.m + (unsigned)(q.m < 0 ? q.m : 0) - (want << FAN_Q);
     const int sel = (int)rel >> FAN_Q;                                     // cl - want: 0 the ray's first column, -1 its second
-    const int dist = (1 << FAN_Q) - (int)(rel & ((1u << FAN_Q) - 1u));
-    const int absm = q.m < 0 ? -q.m : q.m;
-    const float f = (absm >= dist) ? fminf((float)dist * q.inv_absm, 1.f) : 1.f;
+    const float f = fan_split(rel << (32 - FAN_Q), q.inv32);
     return ((sel == 0) ? f : ((sel == -1) ? 1.f - f : 0.f)) * q.len_s;
   };
   const FanRec* __restrict__ R0 = recs + (int64_t)blockIdx.y * na * nd;
@@ -410,7 +440,7 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
     float* part = reinterpret_cast<float*>(im->recs);
     for (int b = 0; b < batch; ++b) {                                      // one pair of padded copies per handle: columns go one by one
       hipLaunchKernelGGL(k_fan_pad_copies, dim3(nb, nb, 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->xT, im->xT + padded, im->N);
-      hipLaunchKernelGGL(k_fan_fwd_march, grid, dim3(256), 0, s, im->xT, im->xT + padded, y + (int64_t)b * ldy, im->N,
+      hipLaunchKernelGGL(k_fan_fwd_march, grid, dim3(256), 0, s, im->xT, padded, y + (int64_t)b * ldy, im->N,
                          nrays, im->rays, band, part);
       if (nbands > 1)
         hipLaunchKernelGGL(k_fan_bands_sum, dim3(ceil_div(nrays, 256)), dim3(256), 0, s, part, nbands, nrays, im->rays, y + (int64_t)b * ldy);
