@@ -39,6 +39,8 @@ struct FanAngle {
   float d0x, d0y;    // centre of detector pixel 0
   float ux, uy;      // detector pixel pitch vector
   float nx, ny;      // unit normal source -> detector centre
+  float ex, ey;      // source - centre of detector pixel 0 (the adjoint's locator)
+  float uxs, uys;    // pitch vector / pitch^2: a point of the detector line -> detector coordinate
 };
 
 struct FanRay {      // row-march form of one ray (index coordinates; see the header), fixed point with FAN_Q fraction bits
@@ -55,7 +57,7 @@ struct FanImpl {
   float pitch;
   FanAngle* ang_dev;
   FanRay* rays;      // [na * nd], NULL: general fallback kernels
-  FanRay* recs;      // [na * nd] per apply (adjoint): the same with len * sinogram value in place of len
+  FanRay* recs;      // [na][nd + 4] FanRec per apply (adjoint); the forward's band partials in between
   float* xT;         // two padded copies of the image (forward: as it is / transposed), owned by the handle
   float reach;       // half width, in detector pixels per unit magnification, of the detector interval a pixel can touch
   int max_cand;      // most detectors that interval can hold anywhere in the image
@@ -131,6 +133,7 @@ __global__ __launch_bounds__(256) void k_fan_pad_copies(const float* __restrict_
 }
 
 typedef float fan_f2 __attribute__((ext_vector_type(2)));
+typedef unsigned u4f __attribute__((ext_vector_type(4)));
 
 // gridDim.y > 1: the march is cut into that many bands of `band` steps, band b leaving its sum (without the ray's length) in
 // part[b][ray] for k_fan_bands_sum — one thread per ray is 2 waves per SIMD at 512^2 x 180 x 724, too few to hide the gathers.
@@ -207,105 +210,138 @@ __global__ __launch_bounds__(256) void k_fan_bands_sum(const float* __restrict__
   sino[ray] = rays[ray].len * t;
 }
 
-// records of one apply: the ray table with len * S in place of len (one gather per candidate ray in the adjoint instead of two) and
-// 1/|M| in place of the high word of X0: a pixel weighs a candidate ray by the ray's position RELATIVE to the pixel, which lies
-// within +-1.1 columns for every candidate (the interval is the pixel's half diagonal plus 2 %), so the low 32 bits of the 2^-30
-// fixed-point position — a range of 4 columns — decide it exactly; the 64-bit multiply-add of the forward's absolute position and
-// the reciprocal per candidate were a third of the adjoint's instructions.
+// Records of one apply: per view a row of nd + 2 FAN_RP records, FAN_RP zero records either side (a candidate index outside the
+// detector then needs no test: it weighs nothing).  A record is the ray's table entry prepared for the pixel's side of the
+// computation: a pixel weighs a candidate ray by the ray's position RELATIVE to the pixel, which lies within +-1.5 columns for every
+// candidate, so the low 32 bits of the 2^-30 fixed-point position — a range of 4 columns — decide it exactly (the 64-bit
+// multiply-add of the forward's absolute position and the reciprocal per candidate were a third of the adjoint's instructions):
+//   x0m   = (X0 + min(M, 0)) mod 2^32   (the start of the step's interval at marching index 0; even: X0's class bit cleared)
+//   inv32 = fan_inv32(M), NEGATIVE for a shallow ray (the class: one float compare; the weight takes |inv32|)
+//   m, len_s = len * S[a][d]
+constexpr int FAN_RP = 2;
 struct FanRec {
-  unsigned x0_lo;    // as FanRay (bit 0: class)
-  float inv32;       // the float fan_ray_regs() computes from M — the same bits as the forward uses
+  unsigned x0m;
+  float inv32;
   int m;
-  float len_s;       // len * S[a][d]
+  float len_s;
 };
 static_assert(sizeof(FanRec) == sizeof(FanRay), "the record array doubles as the forward's band partials: 16 bytes per ray");
 
 __global__ __launch_bounds__(256) void k_fan_adj_prep(const float* __restrict__ sino, int64_t ld_sino, const FanRay* __restrict__ rays,
-                                                      FanRec* __restrict__ recs, int64_t nrays) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= nrays) return;
-  const FanRay q = rays[i];
-  FanRec o;
-  o.x0_lo = q.x0_lo;
-  o.inv32 = fan_inv32(q.m);
-  o.m = q.m;
-  o.len_s = q.len * sino[(int64_t)blockIdx.y * ld_sino + i];
-  recs[(int64_t)blockIdx.y * nrays + i] = o;
+                                                      FanRec* __restrict__ recs, int nd, int na) {
+  const int ndp = nd + 2 * FAN_RP;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over na x ndp
+  if (i >= (int64_t)na * ndp) return;
+  const int a = (int)(i / ndp), d = (int)(i - (int64_t)a * ndp) - FAN_RP;
+  FanRec o{0u, 1.0f, 0, 0.f};
+  if (d >= 0 && d < nd) {
+    const int64_t k = (int64_t)a * nd + d;
+    const FanRay q = rays[k];
+    o.x0m = (q.x0_lo & ~1u) + (unsigned)(q.m < 0 ? q.m : 0);
+    const float iv = fan_inv32(q.m);
+    o.inv32 = (q.x0_lo & 1u) ? -iv : iv;
+    o.m = q.m;
+    o.len_s = q.len * sino[(int64_t)blockIdx.y * ld_sino + k];
+  }
+  recs[(int64_t)blockIdx.y * na * ndp + i] = o;
 }
 
-// NC = 2: the geometry admits two candidate rays per pixel and angle nearly everywhere (decided at creation; the reference's: three
-// only next to the source) — the first two are always fetched and weighed, invalid ones with weight 0, further ones in a rare loop, and the angle loop is unrolled so that the gathers of several
-// angles are in flight together: with the candidate loop of the general form (NC = 0) every angle waited for its own gather,
-// ~0.9 us per angle and wave at four waves per SIMD.
+// One thread per pixel.  Per view: the detector coordinate uc of the pixel centre's projection and the half width w of the detector
+// interval a ray must lie in to touch the pixel give the candidates dlo = ceil(uc - w) .. floor(uc + w): one or two nearly
+// everywhere (NC = 2, decided at creation: three only next to the source) — the first two are always fetched (16-byte records
+// through a buffer resource: view row in the scalar offset, 16 dlo in the vector offset, the second 16 bytes on) and weighed, the
+// second with weight 0 when it is not in the interval (it may lie more than two columns away, where the 32-bit relative position
+// would alias), further ones in a rare loop; the view loop is unrolled by four so that the gathers of several views are in flight
+// together (with a candidate loop every view waited for its own gather: 0.9 us per view and wave at four waves per SIMD).
+// The kernel is bound by vector-instruction issue (PMC: 96 % busy): 76 instructions per pixel and view in round 3's form, ~58 here.
 template <int NC>
 __global__ __launch_bounds__(256) void k_fan_adj_march(float* __restrict__ img,
-                                                       int64_t ld_img, int N, int nd, int na, float dsd, float inv_pitch, float reach,
+                                                       int64_t ld_img, int N, int nd, int na, float dsd, float reach,
                                                        const FanAngle* __restrict__ ang, const FanRec* __restrict__ recs) {
   const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (int64_t)N * N) return;
   const int r = (int)(idx / N), c = (int)(idx - (int64_t)r * N);
   const float half = 0.5f * (float)N;
   const float px = (float)c + 0.5f - half, py = half - (float)r - 0.5f;     // pixel centre
+  const int ndp = nd + 2 * FAN_RP;
+  const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(recs + (int64_t)blockIdx.y * na * ndp), 0, (unsigned)((int64_t)na * ndp * 16), 0x00020000);
+  // marching index / picked index by class, the picked one already negated and shifted (rel = x0m + tt M - (want << 30))
+  const unsigned nw_steep = 0u - ((unsigned)c << FAN_Q), nw_shallow = 0u - ((unsigned)r << FAN_Q);
+  const float dsd_reach = dsd * reach;
   float acc = 0.f;
-  auto interval = [&](const FanAngle& g, int& dlo, int& dhi) {
-    // detector coordinate of the centre's projection, and how far to either side a ray can still touch the pixel
+  struct Iv { float clo, hi; int dlo; };
+  auto interval = [&](const FanAngle& g) -> Iv {
     // (only the candidate interval hangs on these numbers — every candidate is then weighed exactly — so the hardware reciprocal
     // does: 1 ulp against the 2 % + 0.01 of slack in `reach`)
     const float vx = px - g.sx, vy = py - g.sy;
-    const float mag = dsd * __builtin_amdgcn_rcpf(fmaf(vx, g.nx, vy * g.ny));
-    const float hx = fmaf(mag, vx, g.sx - g.d0x), hy = fmaf(mag, vy, g.sy - g.d0y);
-    const float uc = fmaf(hx, g.ux, hy * g.uy) * (inv_pitch * inv_pitch);
-    const float w = fmaf(reach, mag, 0.01f);
-    dlo = (int)ceilf(uc - w);
-    dhi = (int)floorf(uc + w);
-    dlo = dlo < 0 ? 0 : dlo;
-    dhi = dhi > nd - 1 ? nd - 1 : dhi;
+    const float rden = __builtin_amdgcn_rcpf(fmaf(vx, g.nx, vy * g.ny));
+    const float mag = dsd * rden;
+    const float hx = fmaf(mag, vx, g.ex), hy = fmaf(mag, vy, g.ey);
+    const float uc = fmaf(hx, g.uxs, hy * g.uys);
+    const float w = fmaf(dsd_reach, rden, 0.01f);
+    Iv v;
+    v.clo = ceilf(uc - w);
+    v.hi = uc + w;
+    int dlo = (int)v.clo;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(v.dlo) : "v"(dlo), "n"(-FAN_RP), "s"(nd));     // dlo and dlo + 1 stay inside the padded row
+    return v;
   };
   auto weigh = [&](const FanRec& q) -> float {
-    const bool shallow = (q.x0_lo & 1u) != 0u;
-    const unsigned tt = shallow ? c : r, want = shallow ? r : c;           // marching index / the index the ray picks per step
+    const bool shallow = q.inv32 < 0.f;
+    const unsigned tt = shallow ? (unsigned)c : (unsigned)r;                // marching index
+    const unsigned nwant = shallow ? nw_shallow : nw_steep;
     // fan_step_at() on the position relative to the pixel, modulo 4 columns: rel = X0 + tt M + min(M, 0) - want   (2^-30 units)
-    const unsigned rel = (q.x0_lo & ~1u) + tt * (unsigned)q.m + (unsigned)(q.m < 0 ? q.m : 0) - (want << FAN_Q);
-    const int sel = (int)rel >> FAN_Q;                                     // cl - want: 0 the ray's first column, -1 its second
-    const float f = fan_split(rel << (32 - FAN_Q), q.inv32);
-    return ((sel == 0) ? f : ((sel == -1) ? 1.f - f : 0.f)) * q.len_s;
+    const unsigned rel = q.x0m + tt * (unsigned)q.m + nwant;
+    float f;
+    {
+      const float fd = (float)(~(rel << (32 - FAN_Q)));                     // fan_split with |inv32| (the sign is the class)
+      asm("v_fma_f32 %0, %1, |%2|, |%2| clamp" : "=v"(f) : "v"(fd), "v"(q.inv32));
+    }
+    // rel in [0, 2^30): the pixel is the ray's first column of the step (weight f); in [-2^30, 0): its second (1 - f); else none
+    const float s = (int)rel >= 0 ? f : 1.f - f;
+    const bool touches = (rel + (1u << FAN_Q)) < (2u << FAN_Q);
+    return touches ? s * q.len_s : 0.f;
   };
-  const FanRec* __restrict__ R0 = recs + (int64_t)blockIdx.y * na * nd;
+  auto fetch = [&](int a, int d) -> FanRec {
+    const u4f t = __builtin_bit_cast(u4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, (d + FAN_RP) << 4, a * ndp * 16, 0));
+    // (elements copied to scalars first: __builtin_bit_cast(float, t[k]) on an ext-vector ELEMENT reads element 0 whatever k is —
+    //  hipcc / ROCm 7.2, met before in radon2d.hip's adj_gather)
+    const unsigned t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+    return FanRec{t0, __builtin_bit_cast(float, t1), (int)t2, __builtin_bit_cast(float, t3)};
+  };
   if (NC == 2) {
     constexpr int UA = 4;
     int a = 0;
     for (; a + UA <= na; a += UA) {
       FanRec q[UA][2];
-      bool ok[UA][2];
+      bool ok1[UA];
 #pragma unroll
       for (int u = 0; u < UA; ++u) {
-        int dlo, dhi;
-        interval(ang[a + u], dlo, dhi);
-        const FanRec* __restrict__ Ra = R0 + (int64_t)(a + u) * nd;
-        ok[u][0] = dlo <= dhi;
-        ok[u][1] = dlo + 1 <= dhi;
-        q[u][0] = Ra[ok[u][0] ? dlo : 0];
-        q[u][1] = Ra[ok[u][1] ? dlo + 1 : 0];
-        for (int d = dlo + 2; d <= dhi; ++d) acc += weigh(Ra[d]);          // a third candidate and beyond: rare (pixels near the source)
+        const Iv v = interval(ang[a + u]);
+        ok1[u] = v.clo + 1.f <= v.hi;
+        q[u][0] = fetch(a + u, v.dlo);
+        q[u][1] = fetch(a + u, v.dlo + 1);
+        if (v.clo + 2.f <= v.hi) {                                          // a third candidate and beyond: rare (pixels near the source)
+          const int dhi = min((int)floorf(v.hi), nd - 1);
+          for (int d = max((int)v.clo + 2, 0); d <= dhi; ++d) acc += weigh(fetch(a + u, d));
+        }
       }
 #pragma unroll
       for (int u = 0; u < UA; ++u) {
-        acc += ok[u][0] ? weigh(q[u][0]) : 0.f;
-        acc += ok[u][1] ? weigh(q[u][1]) : 0.f;
+        acc += weigh(q[u][0]);
+        acc += ok1[u] ? weigh(q[u][1]) : 0.f;
       }
     }
     for (; a < na; ++a) {
-      int dlo, dhi;
-      interval(ang[a], dlo, dhi);
-      const FanRec* __restrict__ Ra = R0 + (int64_t)a * nd;
-      for (int d = dlo; d <= dhi; ++d) acc += weigh(Ra[d]);
+      const Iv v = interval(ang[a]);
+      const int dhi = min((int)floorf(v.hi), nd - 1);
+      for (int d = max((int)v.clo, 0); d <= dhi; ++d) acc += weigh(fetch(a, d));
     }
   } else {
     for (int a = 0; a < na; ++a) {
-      int dlo, dhi;
-      interval(ang[a], dlo, dhi);
-      const FanRec* __restrict__ Ra = R0 + (int64_t)a * nd;
-      for (int d = dlo; d <= dhi; ++d) acc += weigh(Ra[d]);                // one 16-byte gather: {X0 (64 bits), M, len * S[a][d]}
+      const Iv v = interval(ang[a]);
+      const int dhi = min((int)floorf(v.hi), nd - 1);
+      for (int d = max((int)v.clo, 0); d <= dhi; ++d) acc += weigh(fetch(a, d));
     }
   }
   img[(int64_t)blockIdx.y * ld_img + idx] = acc;
@@ -452,13 +488,14 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
     const int64_t nrays = (int64_t)im->na * im->nd;
     dim3 grid(ceil_div((int64_t)im->N * im->N, 256), 1);
     for (int b = 0; b < batch; ++b) {                                      // one record array per handle: columns go one by one
-      hipLaunchKernelGGL(k_fan_adj_prep, dim3(ceil_div(nrays, 256), 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->rays, reinterpret_cast<FanRec*>(im->recs), nrays);
+      hipLaunchKernelGGL(k_fan_adj_prep, dim3(ceil_div((int64_t)im->na * (im->nd + 2 * FAN_RP), 256), 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx,
+                         im->rays, reinterpret_cast<FanRec*>(im->recs), im->nd, im->na);
       if (im->max_cand <= 3)
         hipLaunchKernelGGL(k_fan_adj_march<2>, grid, dim3(256), 0, s, y + (int64_t)b * ldy, ldy, im->N, im->nd, im->na, im->dsd,
-                           1.0f / im->pitch, im->reach, im->ang_dev, reinterpret_cast<const FanRec*>(im->recs));
+                           im->reach, im->ang_dev, reinterpret_cast<const FanRec*>(im->recs));
       else
         hipLaunchKernelGGL(k_fan_adj_march<0>, grid, dim3(256), 0, s, y + (int64_t)b * ldy, ldy, im->N, im->nd, im->na, im->dsd,
-                           1.0f / im->pitch, im->reach, im->ang_dev, reinterpret_cast<const FanRec*>(im->recs));
+                           im->reach, im->ang_dev, reinterpret_cast<const FanRec*>(im->recs));
     }
   } else {
     dim3 grid(ceil_div((int64_t)im->N * im->N, 256), batch);
@@ -503,6 +540,10 @@ extern "C" int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double s
     g.d0y = (float)(dcy - 0.5 * (n_det - 1) * det_pitch * st);
     g.nx = (float)(-st);
     g.ny = (float)(ct);
+    g.ex = g.sx - g.d0x;                                 // (fp32 differences of the fp32 fields: what the kernel used to form itself)
+    g.ey = g.sy - g.d0y;
+    g.uxs = (float)(ct / det_pitch);
+    g.uys = (float)(st / det_pitch);
     h[a] = g;
   }
   auto* im = new FanImpl{N, n_det, n_ang, (float)(sod + odd), (float)det_pitch, nullptr, nullptr, nullptr, nullptr, 0.f, 1 << 30};
@@ -542,7 +583,7 @@ extern "C" int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double s
     }
     e = hipMalloc(&im->rays, sizeof(FanRay) * rt.size());
     if (e == hipSuccess) e = hipMemcpy(im->rays, rt.data(), sizeof(FanRay) * rt.size(), hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMalloc(&im->recs, sizeof(FanRay) * rt.size());
+    if (e == hipSuccess) e = hipMalloc(&im->recs, sizeof(FanRay) * (size_t)n_ang * (n_det + 2 * 2));   // rows padded for the adjoint (FAN_RP)
     const size_t padded = (size_t)N * (N + 2 * FAN_PAD);                 // two padded copies; the pad columns stay zero for good
     if (e == hipSuccess) e = hipMalloc(&im->xT, sizeof(float) * 2 * padded);
     if (e == hipSuccess) e = hipMemset(im->xT, 0, sizeof(float) * 2 * padded);
