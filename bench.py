@@ -370,7 +370,8 @@ def run_blur_cgls(args, rank, world, json_fd=1):
                          ("c2_blur512_cgls", lambda: extra_c2_blur512(world, cpu_jobs if cpu else None)),
                          ("c3_tomo512_hybrid_lsqr", lambda: extra_c3_tomo(world, cpu_jobs if cpu else None)),
                          ("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world, cpu_jobs if cpu else None, psf)),
-                         ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world, cpu_jobs if cpu else None))):
+                         ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world, cpu_jobs if cpu else None)),
+                         ("next_fanbeam512_matvec", lambda: extra_fanbeam(world))):
             try:
                 res["extra"][name] = fn()
             except Exception as exc:          # noqa: BLE001
@@ -571,6 +572,32 @@ def extra_c3_tomo(world, cpu_jobs=None):
         bh = bt.detach().to("cpu")
         cpu_jobs.append((lambda v: out.__setitem__("cpu_baseline", v),
                          lambda: cpu_c3(Nt, np.linspace(0, np.pi, na, endpoint=False), bh)))
+    return out
+
+
+def extra_fanbeam(world):
+    """SURVEY 8f "next" row, rank 1 (not a BASELINE config): the fan-beam 'line_fanflat' projector of Tomography.py:53-88 at the demo
+    geometry scaled to 512^2 (180 views, int(sqrt(2) N) = 724 detectors): time per forward / adjoint apply, ray-steps per second."""
+    from trips_py_amd.operators import FanBeam2D
+    N, views = 512, 180
+    R = FanBeam2D(N, views=views)
+    dev = R.engine.device
+    x = torch.rand(N * N, device=dev)
+    y, z = torch.empty(R.shape[0], device=dev), torch.empty(N * N, device=dev)
+    out = {"geometry": f"{N}x{N}, {views} views, {R.n_det} detectors, source 3N / detector N from the centre", "ray_steps_per_apply": float(views) * R.n_det * N}
+    for name, fn in (("fwd", lambda: R.apply(x, out=y)), ("adj", lambda: R.apply(y, out=z, transpose=True))):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        out[f"{name}_us"] = round(us, 1)
+        out[f"{name}_Gsteps_per_s"] = round(out["ray_steps_per_apply"] / us * 1e-3, 1)
+    out["bound"] = "forward: texture addresser (one scattered 8-byte gather per ray-step: 16.6 cycles per wave-load); adjoint: vector-instruction issue (profiles/r04/fanbeam.txt)"
     return out
 
 
