@@ -144,6 +144,11 @@ int trk_diff_nrm2sq(const float* x, const float* y, int64_t n, double* out_dev, 
 int trk_axpby(int64_t n, double ca, const double* a_num, const double* a_den, int a_flags, const float* x,
               double cb, const double* b_num, const double* b_den, int b_flags, const float* y, float* out,
               double* sumsq_dev, trk_stream stream);
+/* out = A*x and *dot_dev = <out, z> in the same pass (out may alias x): the new basis vector v = r / ||r|| (MMGKS.py:121-123,
+ * GKS.py:92-96) together with c_j = v_j . (A^T b), the entry of the projected right-hand side it adds — optional fused path,
+ * the same results as trk_axpby followed by trk_dot. */
+int trk_scale_dot(int64_t n, double ca, const double* a_num, const double* a_den, int a_flags, const float* x, float* out,
+                  const float* z, double* dot_dev, trk_stream stream);
 /* out = x * y (element-wise; MMGKS.py:114,116 `wf * (...)`, `wr * (...)`). */
 int trk_mul(int64_t n, const float* x, const float* y, float* out, trk_stream stream);
 /* out = w * (x - y) in one pass (the weighted residual `wf * (AV@y - b)` of MMGKS.py:114); out may alias any input. */

@@ -80,6 +80,33 @@ def test_axpby_with_device_coefficients(eng, n):
     assert np.allclose(dy.cpu().numpy(), ref + 2 * f32(y), rtol=3e-7, atol=1e-6)
 
 
+@pytest.mark.parametrize("n", [1, 5, 4096, 100_003, 1_000_001])
+def test_scale_with_the_dot_of_its_output(eng, n):
+    """trk_scale_dot: out = a x (in place as the solvers call it) and <out, z> in one pass — the same floats as scale, the dot of
+    exactly those floats (MMGKS.py:121-123 with the new entry v . A^T b of the projected right-hand side)."""
+    from trips_py_amd.engine import Coef
+    rng = np.random.default_rng(n)
+    x, z = rng.standard_normal(n), rng.standard_normal(n)
+    dx, dz = dev(eng, x), dev(eng, z)
+    for view in (slice(None), slice(1, None)):                          # 16-byte aligned and not
+        a, b = dx[view].clone() if view.start else dx.clone(), dz[view]
+        if view.start:
+            buf = eng.empty(n + 3)
+            a = buf[1:n]
+            a.copy_(dx[view])
+        if a.numel() == 0:
+            continue
+        S = eng.scalars(2)
+        S[0] = 16.0
+        want = a.clone()
+        eng.scale(Coef(1.0, den=S[0:1], sqrt_den=True), want, want)
+        eng.scale_dot(Coef(1.0, den=S[0:1], sqrt_den=True), a, a, b, S[1:2])
+        assert torch.equal(a, want)
+        ref = float(np.dot(a.cpu().numpy().astype(np.float64), b.cpu().numpy().astype(np.float64)))
+        got = float(eng.to_host(S)[1])
+        assert abs(got - ref) <= 1e-12 * float(np.linalg.norm(a.cpu().numpy().astype(np.float64)) * np.linalg.norm(b.cpu().numpy().astype(np.float64))) + 1e-300
+
+
 @pytest.mark.parametrize("p,eps", [(1.0, 0.1), (2.0, 0.1), (0.5, 0.01), (1.5, 0.3)])
 def test_mm_weights_and_mul(eng, p, eps):
     rng = np.random.default_rng(3)

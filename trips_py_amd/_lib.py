@@ -157,6 +157,7 @@ SIGNATURES = {
     "trk_nrm2sq": (c_int, [c_f32p, c_i64, c_f64p, c_stream]),
     "trk_diff_nrm2sq": (c_int, [c_f32p, c_f32p, c_i64, c_f64p, c_stream]),
     "trk_axpby": (c_int, [c_i64, c_dbl, c_f64p, c_f64p, c_int, c_f32p, c_dbl, c_f64p, c_f64p, c_int, c_f32p, c_f32p, c_f64p, c_stream]),
+    "trk_scale_dot": (c_int, [c_i64, c_dbl, c_f64p, c_f64p, c_int, c_f32p, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_mul": (c_int, [c_i64, c_f32p, c_f32p, c_f32p, c_stream]),
     "trk_mul_diff": (c_int, [c_i64, c_f32p, c_f32p, c_f32p, c_f32p, c_stream]),
     "trk_group_weights": (c_int, [c_f32p, c_i64, c_int, c_dbl, c_dbl, c_int, c_f32p, c_stream]),

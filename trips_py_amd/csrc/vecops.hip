@@ -157,6 +157,38 @@ __global__ __launch_bounds__(NT) void k_axpby(int64_t n, Coef ca, const float* x
   }
 }
 
+// ------------------------------------------------------------------ out = a*x with <out, z> (the new basis vector and c_j = v_j . A^T b)
+template <bool VEC>
+__global__ __launch_bounds__(NT) void k_scale_dot(int64_t n, Coef ca, const float* x, float* out, const float* __restrict__ z,
+                                                  double* __restrict__ partials) {
+  __shared__ double lds[NT / 64];
+  const float a = (float)coef_eval(ca);
+  double acc = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      const float4 v = ld4(x, i), w = ld4(z, i);
+      float4 o;
+      o.x = a * v.x;
+      o.y = a * v.y;
+      o.z = a * v.z;
+      o.w = a * v.w;
+      st4(out, i, o);
+      acc += (double)o.x * w.x + (double)o.y * w.y + (double)o.z * w.z + (double)o.w * w.w;
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) {
+    const float o = a * x[i];
+    out[i] = o;
+    acc += (double)o * z[i];
+  }
+  acc = block_sum<NT>(acc, lds);
+  if (threadIdx.x == 0) partials[blockIdx.x] = acc;
+}
+
 // ------------------------------------------------------------------ out = x*y ; MM weights
 template <bool VEC>
 __global__ __launch_bounds__(NT) void k_mul(int64_t n, const float* x, const float* y, float* out) {
@@ -1767,6 +1799,22 @@ int trk_axpby(int64_t n, double ca, const double* a_num, const double* a_den, in
   TRK_LAUNCH_CHECK();
   if (sumsq) return finalize_sums(part, grid, 1, 1, sumsq, s);
   return TRK_OK;
+}
+
+int trk_scale_dot(int64_t n, double ca, const double* a_num, const double* a_den, int a_flags, const float* x, float* out,
+                  const float* z, double* dot_out, trk_stream st) {
+  TRK_REQUIRE(x && out && z && dot_out && n >= 0, "trk_scale_dot: NULL argument or n < 0");
+  hipStream_t s = (hipStream_t)st;
+  const Coef A{ca, a_num, a_den, a_flags};
+  const int grid = stream_grid(n);
+  double* part = nullptr;
+  if (int rc = scratch_doubles(s, grid, &part)) return rc;
+  if (aligned16(x) && aligned16(out) && aligned16(z))
+    hipLaunchKernelGGL((k_scale_dot<true>), dim3(grid), dim3(NT), 0, s, n, A, x, out, z, part);
+  else
+    hipLaunchKernelGGL((k_scale_dot<false>), dim3(grid), dim3(NT), 0, s, n, A, x, out, z, part);
+  TRK_LAUNCH_CHECK();
+  return finalize_sums(part, grid, 1, 1, dot_out, s);
 }
 
 int trk_mul(int64_t n, const float* x, const float* y, float* out, trk_stream st) {

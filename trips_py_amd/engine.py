@@ -397,6 +397,14 @@ class HipEngine:
     def scale(self, a, x, out, sumsq=None):
         self.axpby(a, x, 0.0, None, out, sumsq)
 
+    def scale_dot(self, a, x, out, z, dot_out):
+        """out = a*x and dot_out = <out, z> in one pass (trk_scale_dot: the new basis vector with its entry of the projected
+        right-hand side)."""
+        a = _as_coef(a)
+        rc = self.lib.trk_scale_dot(x.numel(), a.c, a.num, a.den, a.flags, x.data_ptr(), out.data_ptr(), z.data_ptr(), _ptr(dot_out),
+                                    self.stream())
+        _lib.check(rc, "trk_scale_dot")
+
     def copy(self, x, out):
         out.copy_(x)
 

@@ -121,7 +121,8 @@ class _ProjectedBases:
         if self.from_v_A:
             self.A.apply(v, out=self.tA)
             self.A.apply(self.tA, out=self.zA, transpose=True)            # z_A = A^T A v
-            eng.dot(v, self.atb, c_out)                                   # c_j = (A v_j) . b = v_j . (A^T b)
+            if getattr(self, "_c_ready", -1) != j:                        # (else: left by normalise_new, with the scaling pass)
+                eng.dot(v, self.atb, c_out)                               # c_j = (A v_j) . b = v_j . (A^T b)
         else:
             av = self.AV.next_slot()
             self.A.apply(v, out=av)
@@ -180,6 +181,18 @@ class _ProjectedBases:
         self.GA[j, :k] = self.GA[:k, j] = h[:k]
         self.GL[j, :k] = self.GL[:k, j] = h[k:2 * k]
         self.c[j] = h[2 * k]
+
+    def normalise_new(self, coef, vn):
+        """vn <- coef * vn for the basis vector about to be committed (v = r / ||r||).  Where c_j = v_j . (A^T b) is a dot of its
+        own (A-side Gram from V, one rank, scalars on the device) it rides this pass (trk_scale_dot): one launch and one read of
+        v less per iteration; the same bits as scale followed by dot up to the order of the block sums."""
+        eng = self.eng
+        j = self.V.k
+        if self.from_v_A and self.on_device and eng.world == 1 and hasattr(eng, "scale_dot"):
+            eng.scale_dot(coef, vn, vn, self.atb, self.c_d.ref(j))
+            self._c_ready = j
+        else:
+            eng.scale(coef, vn, vn)
 
     def append(self, v_pass=None):
         """The caller has written the new basis vector into V.next_slot() and committed it."""
@@ -362,7 +375,10 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         else:
             orthogonalize(eng, pb.V, k, r, H, 0, passes=3, out=vn, sumsq=R.ref(ii))
         eng.allreduce(R, ii, ii + 1)
-        eng.scale(Coef(1.0, den=R.ref(ii), sqrt_den=True), vn, vn)                   # vn = r/||r|| (:89-91)
+        if merged:
+            eng.scale(Coef(1.0, den=R.ref(ii), sqrt_den=True), vn, vn)               # vn = r/||r|| (:89-91)
+        else:
+            pb.normalise_new(Coef(1.0, den=R.ref(ii), sqrt_den=True), vn)
         pb.V.commit()
         if pb.halo is not None:                                                      # the new vector's boundary frames: from the
             if cc is not None and pb.r_halo is not None:                             # residual's and the sweep's coefficients

@@ -284,7 +284,10 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         else:
             orthogonalize(eng, V, k, r, H, 0, passes=2, out=vn, sumsq=Rn.ref(ii))
         eng.allreduce(Rn, ii, ii + 1)
-        eng.scale(Coef(1.0, den=Rn.ref(ii), sqrt_den=True), vn, vn)                  # vn = r / ||r|| (:121-123)
+        if pbA is not None and not merged:
+            pbA.normalise_new(Coef(1.0, den=Rn.ref(ii), sqrt_den=True), vn)          # vn = r / ||r|| (:121-123), with c_j = v_j . A^T b
+        else:
+            eng.scale(Coef(1.0, den=Rn.ref(ii), sqrt_den=True), vn, vn)              # vn = r / ||r|| (:121-123)
         V.commit()
         if merged:
             pbA.append_from_sweep(gs_gram, k, cc, Rn.ref(ii))
