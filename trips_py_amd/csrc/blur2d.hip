@@ -265,11 +265,19 @@ struct SlideFuse {
   ScalarSrc num, den;
 };
 
-template <int KH, int KW, int D, bool SUMSQ, bool FUSE>
+// EPI: the output is combined on its way out,  y = a * (A x) + b * z  (trk_op_apply_axpby: MMGKS's A x - b, a Golub-Kahan half
+// step) — trk_axpby's arithmetic on the finished row, fmaf(a, o, b * z), so the result equals apply followed by trk_axpby to the
+// bit; z's rows travel D outputs ahead of their use like the operand's.  SUMSQ then sums the combined output.
+struct SlideEpi {
+  const float* z;      // NULL: y = a * (A x)
+  Coef a, b;
+};
+
+template <int KH, int KW, int D, bool SUMSQ, bool FUSE, bool EPI = false>
 __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
                                                    int64_t ldy, int nx, int ny, const float* __restrict__ wts,
                                                    double* __restrict__ partials, int spans_x, int nbands,
-                                                   int rows_per_band, SlideFuse fz, int nt_store) {
+                                                   int rows_per_band, SlideFuse fz, int nt_store, SlideEpi ep = SlideEpi{}) {
   constexpr int T = KH - 1 - KH / 2;
   constexpr int Lh = KW - 1 - KW / 2;
   constexpr int OFFC = 4 - Lh;          // v[] index of tap 0 of output column 0
@@ -353,6 +361,23 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
   };
 #pragma unroll
   for (int d = 0; d < D; ++d) issue(d, d);
+  // EPI: coefficients (device scalars, wave-uniform) and the ring of z rows, output o in slot o % D
+  float ea = 1.f, eb = 0.f;
+  f4 zq[EPI ? D : 1];
+  const auto rz = __builtin_amdgcn_make_buffer_rsrc((void*)((EPI && ep.z) ? ep.z : x), 0, img_bytes, 0x00020000);
+  const bool has_z = EPI && ep.z != nullptr;
+  auto issue_z = [&](int o, int slot) {
+    const int oc = o < band_rows - 1 ? o : band_rows - 1;                 // (beyond the band: any valid row, never used)
+    zq[slot] = __builtin_bit_cast(f4, __builtin_amdgcn_raw_buffer_load_b128(rz, vc, (ofirst + dir * oc) * rowbytes, 0));
+  };
+  if (EPI) {
+    ea = (float)coef_eval(ep.a);
+    eb = has_z ? (float)coef_eval(ep.b) : 0.f;
+    if (has_z) {
+#pragma unroll
+      for (int d = 0; d < D; ++d) issue_z(d, d);
+    }
+  }
 
   f2 acc[KH][2];
   double ss = 0.0;
@@ -408,7 +433,19 @@ __global__ __launch_bounds__(64) void k_blur_slide(const float* __restrict__ x, 
       const int o = t - (KH - 1);
       if (!GUARD || (o >= 0 && o < band_rows)) {        // uniform
         const int kd = pmod(u - (KH - 1), KH);
-        const f4 out = (f4){acc[kd][0][0], acc[kd][0][1], acc[kd][1][0], acc[kd][1][1]};
+        f4 out = (f4){acc[kd][0][0], acc[kd][0][1], acc[kd][1][0], acc[kd][1][1]};
+        if (EPI) {
+          const int zs = pmod(u - (KH - 1), D);                             // = o % D: U is a multiple of D
+          if (has_z) {                                                       // grid-uniform
+            const f4 zv = zq[zs];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[e] = fmaf(ea, out[e], eb * zv[e]);
+            issue_z(o + D, zs);
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[e] = ea * out[e];
+          }
+        }
         // NOTE the row offset goes into the VGPR offset, not the SGPR soffset: with an SGPR soffset hipcc (ROCm 7.2)
         // emits no wait state between a >64-bit buffer store and a VALU overwrite of its data registers, and on
         // gfx950 the last dword of the store was then observed corrupted (lanes 12-15 of each row of 16).
@@ -499,22 +536,30 @@ int launch_strip(const BlurImpl* im, int tr, const float* x, int64_t ldx, float*
 template <int K, int D>
 int launch_slide(const BlurImpl* im, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch,
                  double* part, int spans_x, int nbands, int rows_per_band, hipStream_t s, hipEvent_t ev0, hipEvent_t ev1,
-                 const SlideFuse* fuse = nullptr) {
+                 const SlideFuse* fuse = nullptr, const SlideEpi* epi = nullptr) {
   dim3 grid(spans_x * nbands, batch), block(64);
   const float* w = im->sep_dev[tr];
   const int nts = stream_nontemporal((int64_t)im->nx * im->ny);
   if (fuse) {   // fused-operand form: always with the sum of squares (raw partials)
-    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, true, true>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band, *fuse, nts);
+    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, true, true>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band, *fuse, nts, SlideEpi{});
     TRK_LAUNCH_CHECK();
     return TRK_OK;
   }
   const SlideFuse nofuse{nullptr, nullptr, 0.0, {nullptr, 0}, {nullptr, 0}};
+  if (epi) {
+    if (part)
+      hipExtLaunchKernelGGL((k_blur_slide<K, K, D, true, false, true>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band, nofuse, nts, *epi);
+    else
+      hipExtLaunchKernelGGL((k_blur_slide<K, K, D, false, false, true>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band, nofuse, nts, *epi);
+    TRK_LAUNCH_CHECK();
+    return TRK_OK;
+  }
   // hipExtLaunchKernelGGL attaches the (optional) events to the dispatch itself: their timestamps are the kernel's own
   // begin / end, the same quantity rocprofv3's kernel trace reports.
   if (part)
-    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, true, false>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band, nofuse, nts);
+    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, true, false>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band, nofuse, nts, SlideEpi{});
   else
-    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, false, false>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band, nofuse, nts);
+    hipExtLaunchKernelGGL((k_blur_slide<K, K, D, false, false>), grid, block, 0, s, ev0, ev1, 0, x, ldx, y, ldy, im->nx, im->ny, w, part, spans_x, nbands, rows_per_band, nofuse, nts, SlideEpi{});
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }
@@ -671,6 +716,38 @@ int blur_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_
   return TRK_OK;
 }
 
+// out = a * Op(x) + b * z (+ ||out||^2) in the sliding kernel's store (trk_op_apply_axpby on a blur handle; caps stay 0)
+int blur_apply_axpby_plain(trk_op* op, int tr, const float* x, Coef a, Coef b, const float* z, float* out, double* sumsq,
+                           hipStream_t s) {
+  auto* im = static_cast<BlurImpl*>(op->impl);
+  if (!slide_shape_ok(im) || !aligned16(x) || !aligned16(out) || (z && !aligned16(z))) return TRK_EUNSUPPORTED;
+  int spans_x, nbands, rpb;
+  const int Usel = (im->kh == 9) ? 9 : (im->kh == 7) ? 7 : (im->kh == 5) ? 5 : 6;
+  slide_grid(im->nx, im->ny, 1, im->kh, Usel, &spans_x, &nbands, &rpb);
+  const int nblk = spans_x * nbands;
+  double* part = nullptr;
+  if (sumsq)
+    if (int rc = scratch_doubles(s, (size_t)nblk, &part)) return rc;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  if (trk_timer* t = op->timer)
+    if ((op->timer_which == 2 || op->timer_which == tr) && t->used < t->cap) {
+      ev0 = t->ev[2 * t->used];
+      ev1 = t->ev[2 * t->used + 1];
+      ++t->used;
+    }
+  const SlideEpi ep{z, a, b};
+  int rc;
+  switch (im->kh) {
+    case 3: rc = launch_slide<3, 6>(im, tr, x, 0, out, 0, 1, part, spans_x, nbands, rpb, s, ev0, ev1, nullptr, &ep); break;
+    case 5: rc = launch_slide<5, 5>(im, tr, x, 0, out, 0, 1, part, spans_x, nbands, rpb, s, ev0, ev1, nullptr, &ep); break;
+    case 7: rc = launch_slide<7, 7>(im, tr, x, 0, out, 0, 1, part, spans_x, nbands, rpb, s, ev0, ev1, nullptr, &ep); break;
+    default: rc = launch_slide<9, 9>(im, tr, x, 0, out, 0, 1, part, spans_x, nbands, rpb, s, ev0, ev1, nullptr, &ep); break;
+  }
+  if (rc) return rc;
+  if (sumsq) return finalize_sums(part, nblk, 1, 1, sumsq, s);
+  return TRK_OK;
+}
+
 void blur_destroy(trk_op* op) {
   auto* im = static_cast<BlurImpl*>(op->impl);
   for (int t = 0; t < 2; ++t) {
@@ -766,6 +843,7 @@ extern "C" int trk_blur2d_create(const double* psf, int kh, int kw, int nx, int 
   const int64_t n = (int64_t)nx * ny;
   auto* op = new trk_op{1, n, n, im, blur_apply, blur_destroy, nullptr, 0};
   if (slide_shape_ok(im)) op->apply_fused = blur_apply_fused;
+  if (slide_shape_ok(im)) op->apply_axpby_plain = blur_apply_axpby_plain;
   *out = op;
   return TRK_OK;
 }

@@ -251,6 +251,11 @@ int trk_op_apply_axpby(trk_op* op, int transpose, const float* x, double ca, con
   if (op->apply_axpby)
     return op->apply_axpby(op, tr, x, Coef{ca, a_num, a_den, a_flags}, Coef{cb, b_num, b_den, b_flags}, z, out, sumsq, hints,
                            (hipStream_t)stream);
+  if (op->apply_axpby_plain) {
+    const int rc = op->apply_axpby_plain(op, tr, x, Coef{ca, a_num, a_den, a_flags}, Coef{cb, b_num, b_den, b_flags}, z, out, sumsq,
+                                         (hipStream_t)stream);
+    if (rc != TRK_EUNSUPPORTED) return rc;
+  }
   // any operator: the plain apply into `out`, then the vector kernel in place
   const int64_t nin = tr ? op->rows : op->cols, nout = tr ? op->cols : op->rows;
   if (int rc = op->apply(op, tr, x, nin, out, nout, 1, nullptr, (hipStream_t)stream)) return rc;

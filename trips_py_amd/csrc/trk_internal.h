@@ -288,6 +288,11 @@ struct trk_op {
   // optional: out = a * Op(x) + b * z (+ ||out||^2) inside the operator's own output pass (trk_op_apply_axpby); hints: TRK_HINT_*
   int (*apply_axpby)(trk_op*, int transpose, const float* x, trk::Coef a, trk::Coef b, const float* z, float* out,
                      double* sumsq, int hints, hipStream_t s) = nullptr;
+  // optional: the same combination for operators WITHOUT the hinted chains of apply_axpby (trk_op_axpby_caps stays 0: the solvers'
+  // Golub-Kahan chains do not change): trk_op_apply_axpby takes it instead of apply + trk_axpby.  May return TRK_EUNSUPPORTED for
+  // shapes / alignments its kernel does not take — the caller then falls back.
+  int (*apply_axpby_plain)(trk_op*, int transpose, const float* x, trk::Coef a, trk::Coef b, const float* z, float* out,
+                           double* sumsq, hipStream_t s) = nullptr;
   // optional: finish what a TRK_HINT_SUMSQ_DEFERRED apply left unfinished (trk_op_flush)
   int (*flush)(trk_op*, hipStream_t s) = nullptr;
   // set for the duration of one trk_gk_step_proj call: the forward half step's output pass also leaves the block partials of

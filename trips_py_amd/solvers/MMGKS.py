@@ -239,7 +239,11 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         last = ii == n_iter - 1
         _trace.mark("MMGKS: residual")
         # r = A^T (wf * (A x - b)) + lam L^T (wr * (L x))                              (:114-118)
-        if dA:
+        fused_res = dA and unit_wf and hasattr(A, "apply_axpby") and kwargs.get("fused_residual", True)
+        if fused_res:
+            A.apply_axpby(x_dev, 1.0, -1.0, bv, tm)                                   # A x - b in the operator's own output pass
+            res_a = None
+        elif dA:
             A.apply(x_dev, out=ax)
             res_a = ax
         else:
@@ -247,7 +251,9 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             res_a = tm
             if not last:
                 A.apply(x_dev, out=ax)                                                # for the next weights (:56)
-        if unit_wf:
+        if fused_res:
+            pass
+        elif unit_wf:
             eng.axpby(1.0, res_a, -1.0, bv, tm)                                       # wf = 1: the same bits as 1.0 * (A x - b)
         else:
             eng.mul_diff(wf, res_a, bv, tm)
