@@ -334,6 +334,17 @@ class GKState:
                 self.U.commit()
                 self._chained = True
                 return self._finish_step(k, sync)
+            if getattr(A, "_h", None) and hasattr(A, "apply_axpby"):
+                # a handle without the hinted chains: the half steps still go through trk_op_apply_axpby — apply + trk_axpby inside the
+                # library for most operators, the operator's own store where it has one (separable blurs: k_blur_slide<.., EPI>); the
+                # same bits either way, no temporary, one call per half step
+                A.apply_axpby(u, ca_v, 0.0 if k == 0 else cb_v, None if k == 0 else self.V[k - 1], v, transpose=True, sumsq=a2)
+                eng.allreduce(AB, 2 * k + 1, 2 * k + 2)
+                self.V.commit()
+                A.apply_axpby(v, ca_u, cb_u, u, self.U.next_slot(), sumsq=b2)
+                eng.allreduce(AB, 2 * k + 2, 2 * k + 3)
+                self.U.commit()
+                return self._finish_step(k, sync)
             A.apply(u, out=self.tmp_n, transpose=True)
             if k == 0:
                 eng.scale(ca_v, self.tmp_n, v, sumsq=a2)
