@@ -233,13 +233,14 @@ def test_radon_invariants(N, na):
     assert np.all(np.abs(sd[:, N // 2 - 1:N // 2 + 1].mean(axis=1) - 2 * rad) < 1.5)
 
 
-def test_dynamic_radon_equals_blockdiag_of_frames():
+@pytest.mark.parametrize("N,nt,na", [(48, 5, 9), (96, 3, 40)])
+def test_dynamic_radon_equals_blockdiag_of_frames(N, nt, na):
     """BlockDiagOp of same-geometry Radon frames runs as ONE handle (trk_radon2d_dynamic_create): identical to applying the
-    per-frame operators one by one, and to the oracle's block-diagonal operator."""
+    per-frame operators one by one, and to the oracle's block-diagonal operator.  (96, 3, 40): many angles per small frame — the
+    adjoint with a tile's angles split over workgroups, frames in the grid's second dimension."""
     from oracle import cpu_ref as O
     from trips_py_amd.operators import BlockDiagOp, Radon2DParallel
-    N, nt, na = 48, 5, 9
-    angs = [np.deg2rad(t + 20.0 * np.arange(na)) for t in range(nt)]
+    angs = [np.deg2rad(t + (180.0 / na) * np.arange(na)) for t in range(nt)]
     frames = [Radon2DParallel(N, a) for a in angs]
     F = BlockDiagOp(frames)
     rng = np.random.default_rng(3)
