@@ -146,14 +146,17 @@ __device__ __forceinline__ double pend_total(const Epi& e, double* lds1) {
   __syncthreads();
   return *lds1;
 }
-__device__ __forceinline__ double coef_eval_pend(const Coef& k, const double* target, double total) {
+// (num_v / den_v: the scalars *k.num / *k.den as fetched BEFORE the pending sum was formed — behind its barrier they were one more
+//  exposed round trip at the end of every workgroup of the band reduction and of the adjoint's finishers; a value that is the
+//  pending target itself is stale there and not used)
+__device__ __forceinline__ double coef_eval_pend(const Coef& k, const double* target, double total, double num_v, double den_v) {
   double v = k.c;
   if (k.num) {
-    const double t = (k.num == target) ? total : *k.num;
+    const double t = (k.num == target) ? total : num_v;
     v *= (k.flags & TRK_SQRT_NUM) ? sqrt(t) : t;
   }
   if (k.den) {
-    const double t = (k.den == target) ? total : *k.den;
+    const double t = (k.den == target) ? total : den_v;
     v /= (k.flags & TRK_SQRT_DEN) ? sqrt(t) : t;
   }
   return v;
@@ -166,10 +169,12 @@ __device__ __forceinline__ void epi_coefs(const Epi& e, bool first_block, double
   double da = 1.0, db = 0.0;
   if (e.on) {
     if (e.pend_target) {
+      const double an = e.a.num ? *e.a.num : 0.0, ad = e.a.den ? *e.a.den : 0.0;
+      const double bn = (e.z && e.b.num) ? *e.b.num : 0.0, bd = (e.z && e.b.den) ? *e.b.den : 0.0;
       const double total = pend_total(e, lds1);
       if (total_out) *total_out = total;
-      da = coef_eval_pend(e.a, e.pend_target, total);
-      if (e.z) db = coef_eval_pend(e.b, e.pend_target, total);
+      da = coef_eval_pend(e.a, e.pend_target, total, an, ad);
+      if (e.z) db = coef_eval_pend(e.b, e.pend_target, total, bn, bd);
       if (first_block && threadIdx.x == 0) *e.pend_target = total;
     } else {
       da = coef_eval(e.a);
