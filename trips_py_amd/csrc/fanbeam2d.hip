@@ -140,8 +140,9 @@ typedef unsigned u4f __attribute__((ext_vector_type(4)));
 __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__ P0, int64_t padded,
                                                        float* __restrict__ sino, int N, int64_t nrays,
                                                        const FanRay* __restrict__ rays, int band, float* __restrict__ part) {
-  const int64_t ray = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (ray >= nrays) return;
+  const int64_t ray_raw = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live_ray = ray_raw < nrays;                 // (the lane stays: the wave takes a minimum / maximum over its rays below)
+  const int64_t ray = live_ray ? ray_raw : nrays - 1;
   const FanRay gq = rays[ray];
   const FanRayRegs g = fan_ray_regs(gq);
   const int W = N + 2 * FAN_PAD;
@@ -152,8 +153,45 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
   const unsigned lane_base = (g.shallow ? (unsigned)(padded * 4) : 0u) + FAN_PAD * 4u;
   float acc0 = 0.f, acc1 = 0.f;
   int t0 = blockIdx.y * band;
-  const int t_end = (t0 + band < N) ? t0 + band : N;
+  int t_end = (t0 + band < N) ? t0 + band : N;
   const int Nimg = N;
+  // Rows in which NONE of the wave's 64 rays touches the image are skipped: outside columns [-2, N] both taps read the zero padding,
+  // so those steps add exact zeros.  With 1.41 N detectors over the image's diagonal a quarter of the rays of an axis-aligned view
+  // miss the square altogether, and oblique rays enter and leave through its sides.  Per ray the row interval comes from the fp32
+  // line X(t) = X0 + t M with four columns of margin (the estimate is good to a small fraction of one); the wave marches the union.
+  {
+    const float x0f = (float)((double)(g.x0 + (long long)g.mneg) * (1.0 / 1073741824.0));
+    const float mff = (float)g.m * (1.0f / 1073741824.0f);
+    const float lo = -6.f - x0f, hi = (float)Nimg + 5.f - x0f;                     // lo <= t M <= hi
+    float ta_f, tb_f;
+    if (fabsf(mff) < 1e-6f) {
+      const bool in = lo <= 0.f && hi >= 0.f;
+      ta_f = in ? -1e9f : 1e9f;
+      tb_f = in ? 1e9f : -1e9f;
+    } else {
+      const float r = __builtin_amdgcn_rcpf(mff), u1 = lo * r, u2 = hi * r;
+      ta_f = fminf(u1, u2) - 2.f;
+      tb_f = fmaxf(u1, u2) + 3.f;
+    }
+    int ta = (int)fminf(fmaxf(floorf(ta_f), -1e9f), 1e9f), tb = (int)fminf(fmaxf(ceilf(tb_f), -1e9f), 1e9f);   // rows [ta, tb)
+    if (!live_ray) { ta = 0x7fffffff; tb = -0x7fffffff; }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      ta = min(ta, __shfl_xor(ta, off, 64));
+      tb = max(tb, __shfl_xor(tb, off, 64));
+    }
+    ta = __builtin_amdgcn_readfirstlane(ta);             // (every lane holds the wave's value: a scalar for the row offsets below)
+    tb = __builtin_amdgcn_readfirstlane(tb);
+    ta = ta > t0 ? ta : t0;
+    tb = tb < t_end ? tb : t_end;
+    if (ta >= tb) {
+      t0 = t_end;                                        // nothing to march: the sum is zero
+    } else {
+      t0 += (ta - t0) & ~7;                              // whole blocks of eight steps from the band's first row
+      const int te = t0 + ((tb - t0 + 7) & ~7);
+      t_end = te < t_end ? te : t_end;
+    }
+  }
   N = t_end;                                             // (the march below runs to N)
   // the position as column + fraction in units of 2^-32: stepping by M is a 32-bit add whose carry moves the column (exact integers:
   // nothing accumulates); M = mi + mf with mi = floor(M) in {-1, 0, 1}, mf in [0, 1)
@@ -196,6 +234,7 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
     acc0 = fmaf(w0, q[0], acc0);
     acc1 = fmaf(w1, q[1], acc1);
   }
+  if (!live_ray) return;
   if (gridDim.y == 1) sino[ray] = gq.len * (acc0 + acc1);
   else part[(int64_t)blockIdx.y * nrays + ray] = acc0 + acc1;
 }
