@@ -406,6 +406,9 @@ __global__ __launch_bounds__(256) void k_radon_fwd_lds(const float* __restrict__
     // column range of all taps of the chunk (q is monotone in tt as well): wave-uniform
     const float ta = (float)tb * p.dq, tz = (float)(te - 1) * p.dq;
     const float qlo = blo + fminf(ta, tz), qhi = bhi + fmaxf(ta, tz);
+    // a chunk in which every tap of the wave lies outside the image (oblique views: the corners the detector overhangs) adds exact
+    // zeros: skipped (two columns of margin for the fp32 estimate)
+    if (__builtin_amdgcn_readfirstlane((qhi < -2.f || qlo > (float)N + 1.f) ? 1 : 0)) continue;
     // (readfirstlane: the values are wave-uniform but were computed in vector registers)
     const int cs = __builtin_amdgcn_readfirstlane(((int)floorf(qlo) - 1) & ~3);   // one column of slack for the fp32 estimate
     const bool fits = (__builtin_amdgcn_readfirstlane((int)floorf(qhi)) + 2 - cs) < LDS_W;
