@@ -248,6 +248,12 @@ int trk_mailbox_post_sum(trk_mailbox* mb, int slot, const double* src_dev, int o
  * (single rank: the next chained apply finishes them). */
 int trk_gk_step(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
                 int defer_alpha, int defer_beta, trk_stream stream);
+/* One Arnoldi step on one rank (decompositions.py:207-228; Hybrid_GMRES.py:61-63, GMRES.py): w = A V[k-1], orthogonalised against
+ * V[0..k) by two Gram-Schmidt sweeps in their Gram-matrix form (trk_gemv_t2 / trk_cgs_coeffs / trk_gemv_n), V[k] = the normalised
+ * result.  V: rows of ld floats (row k is written), w: n floats of scratch, G: the basis' Gram matrix so far (ldg x ldg doubles, rows
+ * 0..k-2 installed; row k-1 is installed here), W: 2k doubles of scratch, S: S[0] = h_{k+1,k}^2, S[1..1+k) = column k of H above it.
+ * Optional: the same five calls in one. */
+int trk_arnoldi_step(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S, trk_stream stream);
 /* trk_gk_step (optionally with the projection of trk_gk_step_proj: proj != NULL) that also carries a mailbox post — the copy of
  * `count` (<= 8) device doubles src_dev[0..count) to host[offset ..] of `mb`, optionally the sum of n_sum block partials to *sum_dev and
  * host[sum_offset], and the publication of `slot` (trk_mailbox_post / trk_mailbox_post_sum): on the projector the first workgroup of

@@ -702,3 +702,29 @@ def test_arnoldi_orthogonality_by_gram_vs_sweeps():
     assert loss_s < 2e-6, loss_s
     assert loss_g < 1e-5, loss_g
     assert np.abs(Hg - Hs).max() / np.abs(Hs).max() < 1e-5
+
+
+def test_arnoldi_step_in_one_library_call_equals_the_five_calls():
+    """trk_arnoldi_step (apply, the sweep's two passes over the basis, its k x k recurrence, the normalisation — enqueued by one call)
+    against the same five calls made from Python: the same basis and the same Hessenberg matrix, bit for bit."""
+    from oracle import cpu_ref as O
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.krylov import ArnoldiState
+    psf, _ = O.gauss_psf((9, 9), (2, 2))
+    N = 96
+    A = Blur2D(psf, N, N)
+    eng = A.engine
+    b = torch.rand(N * N, device=eng.device, generator=torch.Generator(device=eng.device).manual_seed(3))
+    one = ArnoldiState(A, b, 24)
+    for _ in range(24):
+        one.step()
+    eng.arnoldi_step, keep = None, eng.arnoldi_step                     # the instance attribute shadows the method: Python's five calls
+    try:
+        five = ArnoldiState(A, b, 24)
+        for _ in range(24):
+            five.step()
+    finally:
+        del eng.arnoldi_step
+    assert keep is not None and eng.arnoldi_step is not None
+    assert np.array_equal(one.H(), five.H())
+    assert torch.equal(one.V.data[:25], five.V.data[:25])

@@ -499,6 +499,23 @@ int trk_gk_step(trk_op* op, int k, const float* u_k, const float* v_prev, float*
                             feeds | takes | (defer_beta ? later : 0), stream);
 }
 
+// ------------------------------------------------------------------ one Arnoldi step (decompositions.py:207-228), one rank
+// w = A V[k-1]; the two Gram-Schmidt sweeps against V[0..k) by Gram matrix (one pair of passes over the basis: trk_gemv_t2 with the
+// newest vector's Gram row riding along, trk_cgs_coeffs, trk_gemv_n with the fused ||.||^2); V[k] = the result, normalised.
+// The five library calls the Python step made, enqueued by one: on the 512^2 blur the host was the bound (65 % device-busy).
+int trk_arnoldi_step(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S, trk_stream stream) {
+  TRK_REQUIRE(op && V && w && G && W && S && k >= 1 && ldg >= k, "trk_arnoldi_step: bad argument");
+  TRK_REQUIRE(op->rows == op->cols && ld >= op->rows, "trk_arnoldi_step: square operator, ld >= n");
+  const int64_t n = op->rows;
+  const float* vk1 = V + (int64_t)(k - 1) * ld;
+  float* vk = V + (int64_t)k * ld;
+  if (int rc = trk_op_apply(op, 0, vk1, n, w, n, 1, nullptr, stream)) return rc;
+  if (int rc = trk_gemv_t2(V, ld, k, n, w, vk1, W, stream)) return rc;                   // h = V^T w | Gram row of V[k-1]
+  if (int rc = trk_cgs_coeffs(G, ldg, W, W + k, k, 2, S + 1, stream)) return rc;         // column k of H (without its last entry) at S[1..1+k)
+  if (int rc = trk_gemv_n(V, ld, k, n, S + 1, 1.0, w, -1.0, vk, S, stream)) return rc;   // V[k] = w - V c, S[0] = ||.||^2
+  return trk_axpby(n, 1.0, nullptr, S, TRK_SQRT_DEN, vk, 0.0, nullptr, nullptr, 0, nullptr, vk, nullptr, stream);
+}
+
 int trk_gk_step_proj(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,
                      int defer_alpha, int defer_beta, const float* proj, double* partials, int cap, int* n_partials,
                      trk_stream stream) {

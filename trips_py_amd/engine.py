@@ -397,6 +397,12 @@ class HipEngine:
     def scale(self, a, x, out, sumsq=None):
         self.axpby(a, x, 0.0, None, out, sumsq)
 
+    def arnoldi_step(self, op_handle, V, k, w, G, ldg, W, S):
+        """One Arnoldi step enqueued by one call (trk_arnoldi_step: apply, the sweep's two passes, the normalisation)."""
+        rc = self.lib.trk_arnoldi_step(op_handle, V.data_ptr(), V.stride(0), int(k), w.data_ptr(), _ptr(G), int(ldg), _ptr(W), _ptr(S),
+                                       self.stream())
+        _lib.check(rc, "trk_arnoldi_step")
+
     def scale_dot(self, a, x, out, z, dot_out):
         """out = a*x and dot_out = <out, z> in one pass (trk_scale_dot: the new basis vector with its entry of the projected
         right-hand side)."""

@@ -518,12 +518,20 @@ class ArnoldiState:
         k = V.k
         if len(S) < 2 * k + 2:
             self.S = S = eng.scalars(4 * k + 2)
-        A.apply(V[k - 1], out=self.w)
         slot = V.next_slot()
         # two Gram-Schmidt sweeps (= the reference's modified Gram-Schmidt to rounding), written straight into the next slot with
         # ||.||^2 in S[0]: by Gram matrix (two passes over the basis) where the engine has the kernels, else sweep by sweep
         if self.gram is None and self.by_gram and hasattr(eng, "cgs_coeffs") and self.capacity is not None:
             self.gram = GramSchmidtByGram(eng, V, self.capacity + 1)
+        if (self.gram is not None and self.gram.in_G == k - 1 and getattr(eng, "world", 1) == 1
+                and getattr(eng, "arnoldi_step", None) is not None and getattr(A, "_h", None) and V.data.stride(0) >= A.shape[0]):
+            # the whole step in one call of the library (trk_arnoldi_step: the very calls below, same arguments, same results; the
+            # Python side of a step was a third of a Hybrid-GMRES iteration on the 512^2 blur)
+            eng.arnoldi_step(A._h, V.data, k, self.w, self.gram.G.ref(0), self.gram.kmax, self.gram.W.ref(0), S.ref(0))
+            self.gram.in_G = k
+            V.commit()
+            return k
+        A.apply(V[k - 1], out=self.w)
         if self.gram is not None:
             # the combined coefficients of both sweeps go to S[1 .. 1+k) (column k of H); S[1+k .. 1+2k) stays zero
             self.gram.sweep(k, self.w, 2, slot, sumsq=S.ref(0), c_out=S.ref(1))
