@@ -371,6 +371,7 @@ def run_blur_cgls(args, rank, world, json_fd=1):
                          ("c3_tomo512_hybrid_lsqr", lambda: extra_c3_tomo(world, cpu_jobs if cpu else None)),
                          ("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world, cpu_jobs if cpu else None, psf)),
                          ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world, cpu_jobs if cpu else None)),
+                         ("hybrid_gmres_and_lsqr_blur512", lambda: extra_hybrid_blur(world)),
                          ("next_fanbeam512_matvec", lambda: extra_fanbeam(world))):
             try:
                 res["extra"][name] = fn()
@@ -572,6 +573,37 @@ def extra_c3_tomo(world, cpu_jobs=None):
         bh = bt.detach().to("cpu")
         cpu_jobs.append((lambda v: out.__setitem__("cpu_baseline", v),
                          lambda: cpu_c3(Nt, np.linspace(0, np.pi, na, endpoint=False), bh)))
+    return out
+
+
+def extra_hybrid_blur(world):
+    """The two hybrid loops of the path on the reference's own deblurring size (512^2, 9 x 9 Gaussian PSF, 1 % noise): Hybrid-GMRES
+    (Hybrid_GMRES.py: Arnoldi + projected Tikhonov; no BASELINE config of its own) and Hybrid-LSQR on the same operator, 60-iteration
+    solves with x_true, fixed lambda and GCV.  Replicas across ranks."""
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import gauss_psf
+    from trips_py_amd.solvers import Hybrid_GMRES, Hybrid_LSQR
+    N = 512
+    A = Blur2D(gauss_psf((9, 9), (3, 3))[0], N, N)
+    dev = A.engine.device
+    x = torch.rand(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
+    b = A.apply(x)
+    e = torch.randn(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
+    b = b + e * (0.01 * float(b.norm()) / e.norm())
+    out = {"problem": "512x512 Gaussian blur 9x9 sigma 3, 1% noise, 60 iterations per solve, x_true given"}
+    for name, solver in (("hybrid_gmres", Hybrid_GMRES), ("hybrid_lsqr", Hybrid_LSQR)):
+        for reg in (1e-2, "gcv"):
+            solver(A, b, 5, reg, x)
+            solver(A, b, 60, reg, x)
+            torch.cuda.synchronize()
+            barrier(world)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                solver(A, b, 60, reg, x)
+            torch.cuda.synchronize()
+            barrier(world)
+            dt = max_over_ranks(time.perf_counter() - t0, world) / 3
+            out[f"{name}_{'fixed_lambda' if reg != 'gcv' else 'gcv'}_iters_per_sec_all_ranks"] = round(world * 60 / dt, 1)
     return out
 
 
