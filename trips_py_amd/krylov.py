@@ -10,6 +10,14 @@ import numpy as np
 from .engine import Coef
 
 
+
+def _plain_handle_apply(A):
+    """True when applying A is nothing but the library call on its handle (operators whose Python `_apply` does more — the
+    time-sharded space-time operator exchanges halos first — must keep going through it)."""
+    from .operators import _HandleOperator
+    return isinstance(A, _HandleOperator) and type(A)._apply is _HandleOperator._apply
+
+
 class DeviceBasis:
     """k vectors of length n stored row-per-vector in one [capacity, n] fp32 device tensor.
 
@@ -334,7 +342,7 @@ class GKState:
                 self.U.commit()
                 self._chained = True
                 return self._finish_step(k, sync)
-            if getattr(A, "_h", None) and hasattr(A, "apply_axpby"):
+            if getattr(A, "_h", None) and hasattr(A, "apply_axpby") and _plain_handle_apply(A):
                 # a handle without the hinted chains: the half steps still go through trk_op_apply_axpby — apply + trk_axpby inside the
                 # library for most operators, the operator's own store where it has one (separable blurs: k_blur_slide<.., EPI>); the
                 # same bits either way, no temporary, one call per half step
@@ -524,7 +532,7 @@ class ArnoldiState:
         if self.gram is None and self.by_gram and hasattr(eng, "cgs_coeffs") and self.capacity is not None:
             self.gram = GramSchmidtByGram(eng, V, self.capacity + 1)
         if (self.gram is not None and self.gram.in_G == k - 1 and getattr(eng, "world", 1) == 1
-                and getattr(eng, "arnoldi_step", None) is not None and getattr(A, "_h", None) and V.data.stride(0) >= A.shape[0]):
+                and getattr(eng, "arnoldi_step", None) is not None and getattr(A, "_h", None) and _plain_handle_apply(A) and V.data.stride(0) >= A.shape[0]):
             # the whole step in one call of the library (trk_arnoldi_step: the very calls below, same arguments, same results; the
             # Python side of a step was a third of a Hybrid-GMRES iteration on the 512^2 blur)
             eng.arnoldi_step(A._h, V.data, k, self.w, self.gram.G.ref(0), self.gram.kmax, self.gram.W.ref(0), S.ref(0))

@@ -16,7 +16,7 @@ from .. import _trace
 from .._io import Formatter, History, as_operator
 from ..engine import Coef
 from ..decompositions import golub_kahan_device
-from ..krylov import DeviceBasis, GramSchmidtByGram, orthogonalize
+from ..krylov import _plain_handle_apply, DeviceBasis, GramSchmidtByGram, orthogonalize
 from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq, small_host_blas
 
 
@@ -239,7 +239,7 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         last = ii == n_iter - 1
         _trace.mark("MMGKS: residual")
         # r = A^T (wf * (A x - b)) + lam L^T (wr * (L x))                              (:114-118)
-        fused_res = dA and unit_wf and hasattr(A, "apply_axpby") and kwargs.get("fused_residual", True)
+        fused_res = dA and unit_wf and hasattr(A, "apply_axpby") and _plain_handle_apply(A) and kwargs.get("fused_residual", True)
         if fused_res:
             A.apply_axpby(x_dev, 1.0, -1.0, bv, tm)                                   # A x - b in the operator's own output pass
             res_a = None
