@@ -5,9 +5,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from trips_py_amd.operators import Blur2D
 from trips_py_amd.solvers import Hybrid_LSQR
-from oracle import cpu_ref as O
+from trips_py_amd.problems import gauss_psf
 for N in (512, 2048):
-    psf, _ = O.gauss_psf((9, 9), (3, 3))
+    psf, _ = gauss_psf((9, 9), (3, 3))
     A = Blur2D(psf, N, N)
     x = torch.rand(N * N, device="cuda"); b = A.apply(x)
     b = b + 0.01 * torch.randn_like(b) * b.norm() / b.numel() ** 0.5
