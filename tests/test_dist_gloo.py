@@ -1,4 +1,4 @@
-"""world_size = 2 runs over gloo (CPU): the sharded dynamic problem of BASELINE config C5 in miniature.
+"""world_size = 2 / 4 / 8 runs over gloo (CPU): the sharded dynamic problem of BASELINE config C5 in miniature.
 
 Frames are sharded over ranks (frame-major x, b; block-diagonal forward operator), every inner product is all-reduced
 through trips_py_amd.dist.TorchComm (the same class that drives RCCL on GPUs), and the temporal rows of the space-time
@@ -175,17 +175,18 @@ class FusedShardedSpaceTime:
             _put(dot_out, float(out.double() @ dot_with.double()))
 
 
-def _solve_all(eng):
+def _solve_all(eng, nt=4, N=12):
     """CGLS, GKS and MMGKS on this rank's shard; returns the local slices of the three solutions + info scalars."""
     from cpu_engine import OracleOp
     from oracle import cpu_ref as O
     from trips_py_amd import solvers as S
     from trips_py_amd.dist import frame_range
-    psfs, x_true, b, nt, N = _problem()
+    psfs, x_true, b, nt, N = _problem(nt, N)
     lo, hi = frame_range(nt, eng.world, eng.rank)
     npix = N * N
     F = OracleOp(O.BlockDiag([O.Blur2D(psfs[t], N, N) for t in range(lo, hi)]), eng)
     st = ShardedSpaceTime(N, nt, eng)
+    out_sides = np.array([float(st.has_prev), float(st.has_next)])
 
     class _L:                                           # minimal oracle-like wrapper for OracleOp
         shape = st.shape
@@ -226,10 +227,11 @@ def _solve_all(eng):
     out["mmgks"] = (x.reshape(-1), np.array(info["Residual"]))
     x, info = S.Hybrid_LSQR(F, bl, 8, 1e-2, xl)
     out["lsqr"] = (x.reshape(-1), np.array(info["regParam_history"], dtype=float))
+    out["sides"] = (out_sides, np.zeros(1))
     return out, (lo, hi, npix)
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, nt, N):
     sys.path.insert(0, REPO)
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -249,22 +251,28 @@ def _worker(rank, world, port, outdir):
                 return super().allreduce_sum_(t)
 
         eng = CpuEngine(comm=CountingComm())
-        out, (lo, hi, npix) = _solve_all(eng)
+        out, (lo, hi, npix) = _solve_all(eng, nt, N)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), lo=lo, hi=hi, npix=npix,
                  **{f"{k}_x": v[0] for k, v in out.items()}, **{f"{k}_s": v[1] for k, v in out.items()})
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(300)
-def test_sharded_solvers_match_single_process():
+# (world, frames, N): two ranks (each has ONE neighbour); four ranks x two frames and four ranks x ONE frame (ranks 1, 2 have both
+# neighbours; with one frame per rank a rank has no temporal row of its own); C5's real partition, eight ranks x four frames
+# (ranks 1..6 interior) at a reduced frame size
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,nt,N", [(2, 4, 12), (4, 8, 12), (4, 4, 12), (8, 32, 64)])
+def test_sharded_solvers_match_single_process(world, nt, N):
     sys.path.insert(0, HERE)
     from cpu_engine import CpuEngine
-    ref, _ = _solve_all(CpuEngine())                     # single process, all frames
-    world = 2
+    ref, _ = _solve_all(CpuEngine(), nt, N)               # single process, all frames
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), d, nt, N), nprocs=world, join=True)
         parts = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
+    # the two-neighbour branch really ran: every interior rank reports both sides
+    sides = [tuple(p["sides_x"]) for p in parts]
+    assert sides[0] == (0.0, 1.0) and sides[-1] == (1.0, 0.0) and all(s == (1.0, 1.0) for s in sides[1:-1]), sides
     # CGLS over ranks: one all-reduce per iteration (12 iterations + the one after the solve for the reported norms) against
     # 1 + 2 per iteration for the recurrence as written; iterates of the two forms within 1e-5, identical reported scalars
     for p in parts:
@@ -279,6 +287,7 @@ def test_sharded_solvers_match_single_process():
         assert p["gks_fused_counts_x"][0] == 1.0 and p["gks_fused_counts_x"][2] == 1.0, p["gks_fused_counts_x"]
         assert p["gks_fused_counts_x"][1] <= 4.0, p["gks_fused_counts_x"]
     for key in ("cgls", "cgls_two", "gks", "mmgks", "lsqr", "gks_fused", "mmgks_fused"):
+        assert [int(p["lo"]) for p in parts] == [r * nt // world for r in range(world)]
         x = np.concatenate([p[f"{key}_x"] for p in parts])
         rx = ref[key][0]
         err = np.linalg.norm(x - rx) / np.linalg.norm(rx)

@@ -1,4 +1,4 @@
-"""The sharded (time-frames over ranks) path with the REAL HIP kernels, world_size = 2, on one GPU: both ranks use cuda:0
+"""The sharded (time-frames over ranks) path with the REAL HIP kernels, world_size = 2 and 4, on one GPU: all ranks use cuda:0
 and talk over gloo with host staging (RCCL refuses two ranks on one device).  Exercises HipEngine + TorchComm, the
 per-iteration all-reduces of the solvers, the two-sided halo exchange feeding the fused space-time stencil (trk_tv_halo:
 GKS / MMGKS) and the one-frame shifts feeding trk_spacetime_set_halo (plain L / L^T applies).
@@ -74,7 +74,7 @@ def _solve(eng, nt=4, N=32):
     return out
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, nt, N):
     sys.path.insert(0, REPO)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -83,20 +83,22 @@ def _worker(rank, world, port, outdir):
     try:
         from trips_py_amd.dist import TorchComm
         from trips_py_amd.engine import HipEngine
-        out = _solve(HipEngine(comm=TorchComm()))
+        out = _solve(HipEngine(comm=TorchComm()), nt, N)
         np.savez(os.path.join(outdir, f"rank{rank}.npz"), **{f"{k}_x": v[0] for k, v in out.items()},
                  **{f"{k}_s": v[1] for k, v in out.items()})
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.timeout(600)
-def test_sharded_hip_path_matches_single_process():
+# world 4: ranks 1 and 2 have BOTH time-neighbours (trk_tv_halo with two halo frames, exchange2's two-sided branch, the
+# has_prev & has_next form of SpaceTimeDerivative) — with two frames per rank and with ONE frame per rank (no temporal row inside a rank)
+@pytest.mark.timeout(900)
+@pytest.mark.parametrize("world,nt,N", [(2, 4, 32), (4, 8, 32), (4, 4, 32)])
+def test_sharded_hip_path_matches_single_process(world, nt, N):
     from trips_py_amd.engine import HipEngine
-    ref = _solve(HipEngine())
-    world = 2
+    ref = _solve(HipEngine(), nt, N)
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, _free_port(), d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, _free_port(), d, nt, N), nprocs=world, join=True)
         parts = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
     for tag in ("blur", "tomo"):
         for p in parts:
