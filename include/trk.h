@@ -473,6 +473,30 @@ int trk_lsqr_damped_update(const float* vk, float* w, const float* x_in, float* 
                            double* err_partials, int capacity_blocks, int* n_blocks, const double* alpha_sq,
                            const double* beta_next_sq, const double* beta0_sq, double damp, const double* state_in,
                            double* state_out, int first, trk_stream stream);
+/* ---- The float64 instrument (csrc/ref64.hip): the Golub-Kahan / damped-LSQR chain instantiated on the element type ----
+ * Diagnostics (hard part 2): not a fast path.  A parallel-beam handle's operator evaluated with float64 arithmetic
+ * on vectors of `elem_bytes` = 4 (float) or 8 (double); `weights` 0: interpolation weights from the geometry in float64 (the
+ * oracle's numbers, trips/utilities/io.py:392-399 as oracle/cpu_ref.py Radon2D restates it), 1: the product kernels' fixed-point
+ * tables (24 fractional bits) — the product operator's own weights, summed in float64. */
+int trk_radon2d_apply_ref(trk_op* op, int transpose, int elem_bytes, int weights, const void* x, void* y, trk_stream stream);
+/* The arithmetic every apply of a parallel-beam handle runs in from now on: 0 the product's kernels (default); 1 float64 geometry
+ * and sums, 2 table weights with float64 sums — both on the usual fp32 vectors, through trk_op_apply / trk_op_apply_axpby /
+ * trk_gk_step* unchanged (the fused riders are then run in launches of their own).  For experiments that separate what fp32
+ * STORAGE costs a solver from what the projector's own arithmetic adds. */
+int trk_radon2d_set_arithmetic(trk_op* op, int mode);
+/* out = a x + b z on float / double vectors with the coefficients of trk_axpby: float64 coefficients and products, ONE rounding
+ * to the element type (the arithmetic of the projector's fused half step), *sumsq = sum out^2 (may be NULL).  x may alias out. */
+int trk_ref_axpby(int elem_bytes, int64_t n, double ca, const double* a_num, const double* a_den, int a_flags, const void* x,
+                  double cb, const double* b_num, const double* b_den, int b_flags, const void* z, void* out, double* sumsq,
+                  trk_stream stream);
+/* Hybrid-LSQR at a fixed lambda in the engine's own arrangement (Golub-Kahan on unnormalised vectors, decompositions.py:230-255;
+ * the iterate by damped LSQR's short recurrence, Hybrid_LSQR.py:104-105) on vectors of elem_bytes, n_iter steps enqueued by one
+ * call.  b: rows elements.  x_hist: n_iter rows of cols elements, row k = the iterate after k + 1 steps (the reference reports rows
+ * 1 .. n_iter - 1).  work: 2 rows + 3 cols elements.  AB: 2 n_iter + 1 device doubles (beta0^2, alpha_1^2, beta_2^2, ...).
+ * state8: 8 device doubles. */
+int trk_gk_lsqr_chain(trk_op* op, int elem_bytes, int weights, const void* b, int n_iter, double lambda, void* x_hist, void* work,
+                      double* AB, double* state8, trk_stream stream);
+
 /* The weighted Gram of L V for the 2-D first-difference operator L = [D_h; D_v] of an N x N image, formed from V itself:
  *   G[a][b] = sum_e w_e^2 (L v_a)_e (L v_b)_e ,   w = [w_h: N rows of N-1 | w_v: N-1 rows of N]  (what trk_tv_weights writes).
  * Same result as trk_wgram over the stored images L v_j (MMGKS.py:94-95 through its Gram matrix) for half the bytes — n floats per

@@ -360,6 +360,49 @@ class SpaceTimeDerivative(_Op):
         return out.reshape(-1)
 
 
+def framelet_filters_1d(n, lev):
+    """The three n x n filter matrices of one framelet level (operators.py:50-85): taps (1, 2, 1)/4, (-1, 0, 1)*sqrt(2)/4 and
+    (-1, 2, -1)/4 at offsets (-lev, 0, +lev); the corrections of :57-59, :67-69, :79-81 are the half-sample-symmetric
+    reflection of the taps that fall off either end (index -1-j -> j, n+j -> n-1-j)."""
+    taps = (((1.0, 2.0, 1.0), 0.25), ((-1.0, 0.0, 1.0), np.sqrt(2.0) / 4.0), ((-1.0, 2.0, -1.0), 0.25))
+    out = []
+    for coef, scale in taps:
+        H = np.zeros((n, n))
+        for i in range(n):
+            for off, c in zip((-lev, 0, lev), coef):
+                H[i, reflect_index(i + off, n)] += c
+        out.append(H * scale)
+    return out
+
+
+def framelet_analysis_1d(n, l):
+    """operators.py:88-103, recursion included as written: the deepest level returns its three filters WITHOUT the product of
+    the low-pass filters above it (:90-91 returns before `* w`); every other level is vstack(deeper, H1, H2) * w with w the
+    low-pass filter of the level above (w = 1 at the top)."""
+    def rec(level, w):
+        H0, H1, H2 = framelet_filters_1d(n, level)
+        if level == l:
+            return np.vstack((H0, H1, H2))
+        return np.vstack((rec(level + 1, H0), H1, H2)) @ w
+    return rec(1, np.eye(n))
+
+
+class Framelet2D(_Op):
+    """create_framelet_operator(n, m, l) (operators.py:105-113): x -> W_n X W_m^H with COLUMN-major reshapes of x (n x m)
+    and of the result (n(2l+1) x m(2l+1))."""
+
+    def __init__(self, n, m, l):
+        self.n, self.m = int(n), int(m)
+        self.Wn, self.Wm = framelet_analysis_1d(self.n, l), framelet_analysis_1d(self.m, l)
+        self.shape = (self.Wn.shape[0] * self.Wm.shape[0], self.n * self.m)
+
+    def _fwd(self, x):
+        return (self.Wn @ (x.reshape(self.n, self.m, order="F") @ self.Wm.T)).reshape(-1, order="F")
+
+    def _adj(self, y):
+        return (self.Wn.T @ (y.reshape(self.Wn.shape[0], self.Wm.shape[0], order="F") @ self.Wm)).reshape(-1, order="F")
+
+
 # =====================================================================================
 # a13 MM weights                                           trips/utilities/weights.py:66-68
 # =====================================================================================

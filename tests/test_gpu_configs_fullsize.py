@@ -16,7 +16,7 @@ From iterate 21 on <= 8.4e-7, 1.8e-7 at step 60.  The projector itself is within
 import numpy as np
 import pytest
 
-from conftest import relerr
+from conftest import bar, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -26,6 +26,7 @@ C3_BAR = 1e-5              # final iterate, every iterate from step 21 on, relEr
 C3_TRANSIENT_BAR = 2.5e-3  # iterates 1..20: fp32 storage of this arrangement (NumPy restatement: 5.0e-4; engine 1.06e-3; round 3: 1.6e-3)
 C5_BAR = 1e-5              # measured 6e-8 ... 1.2e-7 on every iterate, relError 3e-9
 C5_RESIDUAL_BAR = 1e-5     # measured 1.9e-7
+C4_1024_BAR = 5e-5         # provisional
 
 
 def c3_numbers(its=20):
@@ -145,7 +146,7 @@ def test_c4_mmgks_tv_1024_vs_oracle_and_4096_path_equivalence():
     x, info = S.MMGKS(Blur2D(psf, N, N), b, FirstDerivative2D(N), 2, 1, 3, 6, 1e-2, xt, epsilon=0.1)
     xo, io = O.mmgks(Ao, b.reshape(-1, 1), O.FirstDerivative2D(N), 2, 1, 3, 6, 1e-2, xt.reshape(-1, 1), epsilon=0.1)
     assert info["its"] == io["its"]
-    assert relerr(x, xo.reshape(-1)) < 5e-5, relerr(x, xo.reshape(-1))
+    bar("c4_1024_vs_oracle.x", relerr(x, xo.reshape(-1)), C4_1024_BAR)
     assert np.allclose(info["relError"], io["relError"], rtol=2e-4)
     N = 4096
     A, L = Blur2D(psf, N, N), FirstDerivative2D(N)

@@ -5,11 +5,19 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, relerr
+from conftest import bar, load_golden, maxrel, relerr
 from test_oracle_golden import lam_close
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
+# Automatic-lambda bars (gcv / dp / l_curve): (relError history, x), each = 2 x the deviation MEASURED on the MI355X against the
+# reference's golden run (profiles/r05/bars.txt).  The selectors' minima are flat: the reference moves
+# itself by 3-4e-3 between fp32 and fp64 inputs — what is held here is the engine's own distance.
+PROVISIONAL = (5e-2, 5e-2)
+AUTO_BAR = {"gks-gcv": PROVISIONAL, "gks-dp": PROVISIONAL, "gks-lcurve": PROVISIONAL, "mmgks-gcv": PROVISIONAL, "mmgks-lcurve": PROVISIONAL,
+            "mmgks_gs-gcv": PROVISIONAL, "mmgks_isotv-gcv": PROVISIONAL, "gks_framelet-gcv": PROVISIONAL, "mmgks_framelet-gcv": PROVISIONAL}
+HYBRID_AUTO_BAR = {("Hybrid_LSQR", "gcv"): 1e-4, ("Hybrid_LSQR", "dp"): 1e-4, ("Hybrid_GMRES", "gcv"): 1e-4, ("Hybrid_GMRES", "dp"): 1e-4,
+                   ("Hybrid_LSQR", "lcurve"): 1e-4, ("Hybrid_GMRES", "lcurve"): 1e-4}
 
 
 def blur(g):
@@ -60,7 +68,7 @@ def test_hybrid(solver, tag):
     assert info["its"] == int(g["its"]) and len(info["xHistory"]) == int(g["n_hist"])
     assert lam_close(info["regParam_history"], g["regParam_history"], 2e-3)
     assert np.allclose(info["relError"], g["relError"], rtol=2e-4)
-    assert relerr(x, g["x"]) < (1e-4 if tag != "lam1e-2" else TOL), relerr(x, g["x"])
+    bar(f"hybrid[{solver}-{tag}].x", relerr(x, g["x"]), HYBRID_AUTO_BAR[(solver, tag)] if tag != "lam1e-2" else TOL)
     assert relerr(info["xHistory"][0], g["x_it1"]) < TOL
     if solver == "Hybrid_GMRES":
         assert np.allclose(info["relResidual"], g["relResidual"], rtol=1e-4)
@@ -82,7 +90,8 @@ def test_gks(tag):
         assert np.allclose(info["relError"], g["relError"], rtol=1e-4)
         assert np.allclose(info["Residual"], g["Residual"], rtol=1e-3)
     else:
-        assert np.allclose(info["relError"], g["relError"], rtol=5e-2) and relerr(x, g["x"]) < 5e-2
+        bar(f"gks[{tag}].relError", maxrel(info["relError"], g["relError"]), AUTO_BAR[f"gks-{tag}"][0])
+        bar(f"gks[{tag}].x", relerr(x, g["x"]), AUTO_BAR[f"gks-{tag}"][1])
 
 
 @pytest.mark.parametrize("tag,p,q,rp,eps", [("p2q1_lam1e-2", 2, 1, 1e-2, 0.1), ("p1q1_lam1e-2", 1, 1, 1e-2, 0.1),
@@ -100,7 +109,66 @@ def test_mmgks(tag, p, q, rp, eps):
         assert np.allclose(info["relError"], g["relError"], rtol=2e-4)
         assert np.allclose(info["Residual"], g["Residual"], rtol=2e-3)
     else:
-        assert np.allclose(info["relError"], g["relError"], rtol=5e-2) and relerr(x, g["x"]) < 5e-2
+        bar("mmgks[p2q1_gcv].relError", maxrel(info["relError"], g["relError"]), AUTO_BAR["mmgks-gcv"][0])
+        bar("mmgks[p2q1_gcv].x", relerr(x, g["x"]), AUTO_BAR["mmgks-gcv"][1])
+
+
+@pytest.mark.parametrize("solver", ["Hybrid_LSQR", "Hybrid_GMRES", "GKS", "MMGKS"])
+def test_lcurve_through_the_solvers(solver):
+    """regparam = 'l_curve' end to end against the reference's own runs (Hybrid_LSQR.py:94-98, Hybrid_GMRES.py:67-71,
+    GKS.py:67-68, MMGKS.py:100-101)."""
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import FirstDerivative2D
+    g = load_golden({"GKS": "gks_blur32_lcurve", "MMGKS": "mmgks_blur32_p2q1_lcurve"}.get(solver, f"{solver.lower()}_blur32_lcurve"))
+    N = int(g["N"])
+    if solver.startswith("Hybrid"):
+        x, info = getattr(S, solver)(blur(g), g["b"], int(g["n_iter"]), "l_curve", g["x_true"])
+        assert len(info["xHistory"]) == int(g["n_hist"])
+        bar(f"lcurve[{solver}].x", relerr(x, g["x"]), HYBRID_AUTO_BAR[(solver, "lcurve")])
+        key = None
+    elif solver == "GKS":
+        x, info = S.GKS(blur(g), g["b"], FirstDerivative2D(N), 3, int(g["n_iter"]), "l_curve", g["x_true"])
+        key = "gks-lcurve"
+    else:
+        x, info = S.MMGKS(blur(g), g["b"], FirstDerivative2D(N), 2, 1, 3, int(g["n_iter"]), "l_curve", g["x_true"])
+        key = "mmgks-lcurve"
+    assert info["its"] == int(g["its"])
+    lam, lam_ref = np.array(info["regParam_history"], dtype=float), g["regParam_history"]
+    nz = lam_ref != 0                                    # (Hybrid-GMRES reports 0 for its first step)
+    bar(f"lcurve[{solver}].lambda", maxrel(lam[nz], lam_ref[nz]), 1e-3)
+    if key is not None:
+        bar(f"lcurve[{solver}].relError", maxrel(info["relError"], g["relError"]), AUTO_BAR[key][0])
+        bar(f"lcurve[{solver}].x", relerr(x, g["x"]), AUTO_BAR[key][1])
+    else:
+        bar(f"lcurve[{solver}].relError", maxrel(info["relError"], g["relError"]), 2e-4)
+
+
+@pytest.mark.parametrize("tag", ["lam1e-2", "gcv"])
+@pytest.mark.parametrize("solver", ["GKS", "MMGKS"])
+def test_framelet_regulariser_through_the_solvers(solver, tag):
+    """GKS / MMGKS with L = create_framelet_operator(32, 32, 2) — the regulariser of the reference's large-scale demos
+    (demos/demo_2D_Deblurring_large_scale.ipynb:403, demo_Tomo_large_scale.ipynb:687; operators.py:50-113) — against its own runs."""
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import create_framelet_operator
+    g = load_golden("gks_blur32_framelet_" + tag if solver == "GKS" else "mmgks_blur32_framelet_p2q1_" + tag)
+    N = int(g["N"])
+    W = create_framelet_operator(N, N, int(g["level"]))
+    rp = 1e-2 if tag == "lam1e-2" else "gcv"
+    if solver == "GKS":
+        x, info = S.GKS(blur(g), g["b"], W, 3, int(g["n_iter"]), rp, g["x_true"])
+    else:
+        x, info = S.MMGKS(blur(g), g["b"], W, 2, 1, 3, int(g["n_iter"]), rp, g["x_true"])
+    assert info["its"] == int(g["its"]) and len(info["xHistory"]) == int(g["n_iter"])
+    if tag == "lam1e-2":
+        bar(f"framelet[{solver}-lam].x", relerr(x, g["x"]), TOL)
+        bar(f"framelet[{solver}-lam].x_it1", relerr(info["xHistory"][0], g["x_it1"]), TOL)
+        bar(f"framelet[{solver}-lam].relError", maxrel(info["relError"], g["relError"]), 1e-4)
+        bar(f"framelet[{solver}-lam].Residual", maxrel(info["Residual"], g["Residual"]), 2e-3)
+    else:
+        assert lam_close(info["regParam_history"], g["regParam_history"], 5e-2)
+        key = "gks_framelet-gcv" if solver == "GKS" else "mmgks_framelet-gcv"
+        bar(f"framelet[{solver}-gcv].relError", maxrel(info["relError"], g["relError"]), AUTO_BAR[key][0])
+        bar(f"framelet[{solver}-gcv].x", relerr(x, g["x"]), AUTO_BAR[key][1])
 
 
 def test_dynamic_blockdiag_spacetime():
@@ -135,7 +203,8 @@ def test_mmgks_group_sparsity_branch(tag, q, rp):
         assert relerr(x, g["x"]) < 5e-5 and np.allclose(info["relError"], g["relError"], rtol=2e-4)
         assert np.allclose(info["Residual"], g["Residual"], rtol=2e-3)
     else:
-        assert np.allclose(info["relError"], g["relError"], rtol=5e-2) and relerr(x, g["x"]) < 5e-2
+        bar("mmgks_gs[gcv].relError", maxrel(info["relError"], g["relError"]), AUTO_BAR["mmgks_gs-gcv"][0])
+        bar("mmgks_gs[gcv].x", relerr(x, g["x"]), AUTO_BAR["mmgks_gs-gcv"][1])
     with pytest.raises(TypeError):
         S.MMGKS(F, g["b"], SpaceTimeDerivative(N, nt), 2, q, 3, 2, 1e-2, GS="GS")
 
@@ -159,7 +228,8 @@ def test_mmgks_isotv_branch(tag, q, rp):
         assert relerr(x, g["x"]) < 5e-5 and np.allclose(info["relError"], g["relError"], rtol=2e-4)
         assert np.allclose(info["Residual"], g["Residual"], rtol=2e-3)
     else:
-        assert np.allclose(info["relError"], g["relError"], rtol=5e-2) and relerr(x, g["x"]) < 5e-2
+        bar("mmgks_isotv[gcv].relError", maxrel(info["relError"], g["relError"]), AUTO_BAR["mmgks_isotv-gcv"][0])
+        bar("mmgks_isotv[gcv].x", relerr(x, g["x"]), AUTO_BAR["mmgks_isotv-gcv"][1])
     with pytest.raises(TypeError):
         S.MMGKS(F, g["b"], L, 2, q, 3, 2, 1e-2, isoTV="isoTV")
 

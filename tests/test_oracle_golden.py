@@ -386,3 +386,51 @@ def test_discrepancy_principle_corner_branches():
     for dpt in ("tsvd", "tgsvd"):
         for tag, dl in (("", delta), ("_big", 6.0 * delta), ("_small", 0.05 * delta)):
             assert O.discrepancy_truncation(Qtb, 6, dl, dptype=dpt) == int(g[f"{dpt}{tag}"]), (dpt, tag)
+
+
+@pytest.mark.parametrize("solver", ["hybrid_lsqr", "hybrid_gmres", "gks", "mmgks"])
+def test_lcurve_through_the_solvers(solver):
+    """regparam = 'l_curve' end to end (Hybrid_LSQR.py:94-98, Hybrid_GMRES.py:67-71, GKS.py:67-68, MMGKS.py:100-101)."""
+    g = load_golden({"gks": "gks_blur32_lcurve", "mmgks": "mmgks_blur32_p2q1_lcurve"}.get(solver, f"{solver}_blur32_lcurve"))
+    N = int(g["N"])
+    A = O.Blur2D(g["psf"], N, N)
+    if solver.startswith("hybrid"):
+        x, info = getattr(O, solver)(A, g["b"], int(g["n_iter"]), "l_curve", g["x_true"])
+        assert len(info["xHistory"]) == int(g["n_hist"]) and relerr(info["xHistory"][1], g["x_it2"]) < 1e-8
+    elif solver == "gks":
+        x, info = O.gks(A, g["b"], O.FirstDerivative2D(N), 3, int(g["n_iter"]), "l_curve", g["x_true"])
+    else:
+        x, info = O.mmgks(A, g["b"], O.FirstDerivative2D(N), 2, 1, 3, int(g["n_iter"]), "l_curve", g["x_true"])
+    assert info["its"] == int(g["its"])
+    assert np.allclose(np.array(info["regParam_history"], dtype=float), g["regParam_history"], rtol=1e-5)
+    assert np.allclose(info["relError"], g["relError"], rtol=1e-6) and relerr(x, g["x"]) < 1e-6
+
+
+def test_framelet_operator_restatement():
+    """oracle.Framelet2D against create_framelet_operator's own matrix and actions (operators.py:50-113)."""
+    g = load_golden("framelet_ops")
+    W = O.Framelet2D(8, 6, 2)
+    assert np.abs(np.column_stack([W._fwd(e) for e in np.eye(48)]) - g["dense_8_6_2"]).max() < 1e-14
+    for (n, m, l) in ((8, 6, 2), (12, 12, 1), (16, 10, 3)):
+        W = O.Framelet2D(n, m, l)
+        assert W.shape == (n * (2 * l + 1) * m * (2 * l + 1), n * m)
+        assert np.abs(W._fwd(g[f"x_{n}_{m}_{l}"]) - g[f"Wx_{n}_{m}_{l}"]).max() < 1e-13
+        assert np.abs(W._adj(g[f"y_{n}_{m}_{l}"]) - g[f"WTy_{n}_{m}_{l}"]).max() < 1e-13
+
+
+@pytest.mark.parametrize("tag", ["lam1e-2", "gcv"])
+@pytest.mark.parametrize("solver", ["gks", "mmgks"])
+def test_framelet_regulariser_through_the_solvers(solver, tag):
+    """GKS / MMGKS with L = create_framelet_operator(32, 32, 2): the large-scale demos' regulariser."""
+    g = load_golden("gks_blur32_framelet_" + tag if solver == "gks" else "mmgks_blur32_framelet_p2q1_" + tag)
+    N = int(g["N"])
+    A, W = O.Blur2D(g["psf"], N, N), O.Framelet2D(N, N, int(g["level"]))
+    rp = 1e-2 if tag == "lam1e-2" else "gcv"
+    if solver == "gks":
+        x, info = O.gks(A, g["b"], W, 3, int(g["n_iter"]), rp, g["x_true"])
+    else:
+        x, info = O.mmgks(A, g["b"], W, 2, 1, 3, int(g["n_iter"]), rp, g["x_true"])
+    assert info["its"] == int(g["its"])
+    assert lam_close(info["regParam_history"], g["regParam_history"], 1e-3 if tag == "gcv" else 1e-6)
+    assert np.allclose(info["relError"], g["relError"], rtol=1e-6) and relerr(x, g["x"]) < 1e-6
+    assert np.allclose(info["Residual"], g["Residual"], rtol=1e-4)

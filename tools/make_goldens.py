@@ -19,6 +19,9 @@ Fixture families:
   G4 hybrid_lsqr_*, hybrid_gmres_*                        (Hybrid_LSQR.py:25, Hybrid_GMRES.py:23)
   G5 gks_*, mmgks_*                                       (GKS.py:27, MMGKS.py:28)
   G5b mmgks_*_isotv_*, isotv_weights                     (MMGKS.py:61-77 over the shim's FirstDerivative)
+  G4c/G5c *_lcurve       regparam='l_curve' through the four projection solvers (Hybrid_LSQR.py:94-98, Hybrid_GMRES.py:67-71,
+                         GKS.py:67-68, MMGKS.py:100-101)
+  G5d *_framelet_*       GKS / MMGKS with L = create_framelet_operator(32, 32, 2) (operators.py:50-113; the large-scale demos' regulariser)
   G6 deriv_ops                                            (operators.py:24-45)
   G7 regparam_fn                                          (gcv.py, discrepancy_principle.py, l_curve.py)
   G8 deblur1d_cgls                                        (Deblurring1D.py + CGLS: BASELINE config C1)
@@ -291,6 +294,49 @@ def g5_gks():
              relError=info["relError"], Residual=info["Residual"], its=info["its"])
 
 
+# ----------------------------------------------------------------------------------------- G4c / G5c / G5d
+def g45_lcurve():
+    """regparam = 'l_curve' end to end: Hybrid_LSQR.py:94-98, Hybrid_GMRES.py:67-71, GKS.py:67-68, MMGKS.py:100-101."""
+    print("G4c/G5c l_curve through the solvers")
+    N = 32
+    A, PSF, x_true, b, delta = blur_problem(N, 31)
+    for name, fn in (("hybrid_lsqr", Hybrid_LSQR), ("hybrid_gmres", Hybrid_GMRES)):
+        x, info = quiet(fn, A, b, 12, "l_curve", x_true)
+        save(name + "_blur32_lcurve", psf=PSF, N=N, b=b, x_true=x_true, n_iter=12, delta=delta,
+             x=x, regParam=info["regParam"], regParam_history=np.array(info["regParam_history"], dtype=float),
+             relError=info["relError"], relResidual=np.array(info["relResidual"], dtype=float), its=info["its"],
+             n_hist=len(info["xHistory"]), x_it1=info["xHistory"][0], x_it2=info["xHistory"][1])
+    A, PSF, x_true, b, delta = blur_problem(N, 41)
+    L = refops.gen_first_derivative_operator_2D(N, N)
+    x, info = quiet(GKS, A, b, L, 3, 10, "l_curve", x_true)
+    save("gks_blur32_lcurve", psf=PSF, N=N, b=b, x_true=x_true, projection_dim=3, n_iter=10, delta=delta,
+         x=x, regParam=info["regParam"], regParam_history=np.array(info["regParam_history"], dtype=float),
+         relError=info["relError"], Residual=info["Residual"], its=info["its"], x_it1=info["xHistory"][0])
+    x, info = quiet(MMGKS, A, b, L, 2, 1, 3, 10, "l_curve", x_true)
+    save("mmgks_blur32_p2q1_lcurve", psf=PSF, N=N, b=b, x_true=x_true, pnorm=2, qnorm=1, projection_dim=3, n_iter=10,
+         epsilon=0.1, x=x, regParam=info["regParam"], regParam_history=np.array(info["regParam_history"], dtype=float),
+         relError=info["relError"], Residual=info["Residual"], its=info["its"], x_it1=info["xHistory"][0])
+
+
+def g5d_framelet():
+    """GKS / MMGKS with the framelet analysis operator as regulariser — what demos/demo_2D_Deblurring_large_scale.ipynb:403 and
+    demo_Tomo_large_scale.ipynb:687 run (operators.py:50-113)."""
+    print("G5d GKS / MMGKS with the framelet regulariser")
+    N = 32
+    A, PSF, x_true, b, delta = blur_problem(N, 41)
+    W = refops.create_framelet_operator(N, N, 2)
+    for tag, rp in (("lam1e-2", 1e-2), ("gcv", "gcv")):
+        x, info = quiet(GKS, A, b, W, 3, 10, rp, x_true)
+        save("gks_blur32_framelet_" + tag, psf=PSF, N=N, level=2, b=b, x_true=x_true, projection_dim=3, n_iter=10, delta=delta,
+             x=x, regParam=info["regParam"], regParam_history=np.array(info["regParam_history"], dtype=float),
+             relError=info["relError"], Residual=info["Residual"], its=info["its"], x_it1=info["xHistory"][0])
+        x, info = quiet(MMGKS, A, b, W, 2, 1, 3, 10, rp, x_true)
+        save("mmgks_blur32_framelet_p2q1_" + tag, psf=PSF, N=N, level=2, b=b, x_true=x_true, pnorm=2, qnorm=1, projection_dim=3,
+             n_iter=10, epsilon=0.1, x=x, regParam=info["regParam"],
+             regParam_history=np.array(info["regParam_history"], dtype=float),
+             relError=info["relError"], Residual=info["Residual"], its=info["its"], x_it1=info["xHistory"][0])
+
+
 # ----------------------------------------------------------------------------------------- G5b
 def g5b_isotv():
     """MMGKS isoTV branch (MMGKS.py:61-77) with the operators_old.py PyLops-built regulariser.  NOTE: PyLops is absent, so
@@ -446,6 +492,8 @@ if __name__ == "__main__":
     g4_hybrid()
     g4b_oneshot()
     g5_gks()
+    g45_lcurve()
+    g5d_framelet()
     g5b_isotv()
     g6_derivs()
     g7_regparam()

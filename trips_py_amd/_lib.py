@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 LIB_PATH = os.path.join(CSRC, "libtrk.so")
-SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip", "spmv.hip", "fanbeam2d.hip", "projected.hip", "cgls_loop.hip", "comm.hip", "cgls_tiled.hip", "cgls_sharded.hip"]
+SOURCES = ["core.hip", "vecops.hip", "blur2d.hip", "tvops.hip", "radon2d.hip", "spmv.hip", "fanbeam2d.hip", "projected.hip", "cgls_loop.hip", "comm.hip", "cgls_tiled.hip", "cgls_sharded.hip", "ref64.hip"]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-I" + INCLUDE, "-I" + CSRC]
 
 
@@ -241,6 +241,12 @@ SIGNATURES = {
     "trk_gemv_n_hosty": (c_int, [c_f32p, c_i64, c_int, c_i64, ctypes.c_void_p, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int),
                                  c_stream]),
     "trk_gk_step": (c_int, [c_op, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_stream]),
+    "trk_radon2d_apply_ref": (c_int, [c_op, c_int, c_int, c_int, ctypes.c_void_p, ctypes.c_void_p, c_stream]),
+    "trk_radon2d_set_arithmetic": (c_int, [c_op, c_int]),
+    "trk_ref_axpby": (c_int, [c_int, c_i64, c_dbl, c_f64p, c_f64p, c_int, ctypes.c_void_p, c_dbl, c_f64p, c_f64p, c_int, ctypes.c_void_p,
+                              ctypes.c_void_p, c_f64p, c_stream]),
+    "trk_gk_lsqr_chain": (c_int, [c_op, c_int, c_int, ctypes.c_void_p, c_int, c_dbl, ctypes.c_void_p, ctypes.c_void_p, c_f64p, c_f64p,
+                                  c_stream]),
     "trk_lsqr_damped_update": (c_int, [c_f32p, c_f32p, c_f32p, c_f32p, c_i64, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int),
                                        c_f64p, c_f64p, c_f64p, c_dbl, c_f64p, c_f64p, c_int, c_stream]),
     "trk_gemv_n": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_dbl, c_f32p, c_dbl, c_f32p, c_f64p, c_stream]),

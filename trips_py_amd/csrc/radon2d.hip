@@ -105,6 +105,11 @@ struct RadonImpl {
   double* pend_target;
   const double* pend_part;
   int pend_n;
+  // the float64 instrument (ref64.hip): the angles in float64, and the arithmetic this handle's applies run in —
+  // 0 the product's kernels; 1 float64 geometry and sums (fp32 vectors); 2 the fixed-point tables' weights, float64 sums
+  RadonRefAngle* ref_ang;
+  int ref_mode;
+  float* ref_tmp;     // max(rows, cols) floats: Op(x) before the half step's combination (ref_mode != 0 only)
 };
 
 // Optional epilogue of the kernel that writes an apply's output (trk_op_apply_axpby): out = a * Op(x) + b * z.
@@ -1911,8 +1916,31 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   return TRK_OK;
 }
 
+// ref_mode != 0 (trk_radon2d_set_arithmetic): every apply of the handle through ref64.hip's float64-arithmetic kernels
+int radon_ref_geom_of(RadonImpl* im, RadonRefGeom* g) {
+  *g = RadonRefGeom{im->N, im->nd, im->na, im->nt, im->npad, im->ref_ang, im->A32, im->B32};
+  return TRK_OK;
+}
+int radon_apply_refmode(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq, hipStream_t s) {
+  auto* im = static_cast<RadonImpl*>(op->impl);
+  if (int rc = radon_flush(op, s)) return rc;
+  im->rec_src = nullptr;
+  im->xT_src = nullptr;
+  RadonRefGeom g;
+  radon_ref_geom_of(im, &g);
+  for (int bi = 0; bi < batch; ++bi)
+    if (int rc = radon_ref_apply_f32(g, tr, im->ref_mode - 1, x + (int64_t)bi * ldx, y + (int64_t)bi * ldy, s)) return rc;
+  if (sumsq) {
+    const int64_t nout = tr ? op->cols : op->rows;
+    if (batch == 1 || ldy == nout) return trk_nrm2sq(y, nout * batch, sumsq, (trk_stream)s);
+    return fail(TRK_EUNSUPPORTED, "radon: fused sum of squares needs contiguous batch outputs");
+  }
+  return TRK_OK;
+}
+
 int radon_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
                 hipStream_t s) {
+  if (static_cast<RadonImpl*>(op->impl)->ref_mode) return radon_apply_refmode(op, tr, x, ldx, y, ldy, batch, sumsq, s);
   return radon_run(op, tr, x, ldx, y, ldy, batch, sumsq, Epi{}, 0, s);
 }
 
@@ -1923,6 +1951,10 @@ int radon_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, doub
                       double* partials, int cap, int* n_partials, hipStream_t s) {
   if (x2) return fail(TRK_EUNSUPPORTED, "radon: the two-operand fused apply is not available (trk_op_fused_caps reports 2)");
   if (cap < 1) return fail(TRK_EINVAL, "radon: fused apply needs room for at least one partial");
+  if (static_cast<RadonImpl*>(op->impl)->ref_mode) {          // the instrument: one finished partial
+    if (n_partials) *n_partials = 1;
+    return radon_apply_refmode(op, tr, x1, tr ? op->rows : op->cols, y, tr ? op->cols : op->rows, 1, partials, s);
+  }
   return radon_run(op, tr, x1, tr ? op->rows : op->cols, y, tr ? op->cols : op->rows, 1, nullptr, Epi{}, 0, s, partials, cap,
                    n_partials);
 }
@@ -1932,6 +1964,18 @@ int radon_apply_fused(trk_op* op, int tr, const float* x1, const float* x2, doub
 int radon_apply_axpby(trk_op* op, int tr, const float* x, Coef a, Coef b, const float* z, float* out, double* sumsq, int hints,
                       hipStream_t s) {
   auto* im = static_cast<RadonImpl*>(op->impl);
+  if (im->ref_mode) {
+    // the instrument: Op(x) by the float64-arithmetic kernels, then the half step's combination as the product's epilogue forms
+    // it (float64 coefficients and products, one rounding) with the norm finished at once; the riders of trk_gk_step_* are not
+    // taken (their callers run them in launches of their own)
+    const int64_t nout = tr ? op->cols : op->rows;
+    if (!im->ref_tmp) {
+      const int64_t cap = op->rows > op->cols ? op->rows : op->cols;
+      TRK_HIP(hipMalloc((void**)&im->ref_tmp, sizeof(float) * (size_t)cap));
+    }
+    if (int rc = radon_apply_refmode(op, tr, x, tr ? op->rows : op->cols, im->ref_tmp, nout, 1, nullptr, s)) return rc;
+    return ref_axpby_f32(nout, a, im->ref_tmp, b, z, out, sumsq, s);
+  }
   const bool tile = getenv("TRK_RADON_ADJ_SIMPLE") == nullptr && im->N >= 16;
   if (tr && !tile) {
     if (int rc = radon_run(op, tr, x, op->rows, out, op->cols, 1, nullptr, Epi{}, 0, s)) return rc;
@@ -1948,7 +1992,7 @@ int radon_apply_axpby(trk_op* op, int tr, const float* x, Coef a, Coef b, const 
 
 void radon_destroy(trk_op* op) {
   auto* im = static_cast<RadonImpl*>(op->impl);
-  void* ptrs[] = {im->quad_dev, im->A32q, im->B32q, im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec, im->adj_pos, im->pend_buf[0], im->pend_buf[1], im->adj_part, im->adj_cnt};
+  void* ptrs[] = {im->ref_ang, im->ref_tmp, im->quad_dev, im->A32q, im->B32q, im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec, im->adj_pos, im->pend_buf[0], im->pend_buf[1], im->adj_part, im->adj_cnt};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete im;
@@ -1967,6 +2011,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
   if ((int64_t)na * ndp * 16 >= ((int64_t)1 << 31) || (int64_t)na * npad * 8 >= ((int64_t)1 << 31))
     return fail(TRK_EUNSUPPORTED, "radon2d: %d angles x %d detectors per frame exceed the 2 GiB record addressing of the adjoint", na, n_det);
   std::vector<AngleParam> h(n_ang);
+  std::vector<RadonRefAngle> href(n_ang);
   std::vector<float> wadj(n_ang);
   std::vector<unsigned> a32((size_t)n_ang * ndp), b32((size_t)n_ang * npad);
   std::vector<uint2> cb((size_t)n_ang * npad);
@@ -1987,6 +2032,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
       inv = -1.0 / st; dq = ct / st; k0 = half - half * ct / st; w = scale / std::fabs(st); rinv = -st;
       ++n1;
     }
+    href[a] = RadonRefAngle{inv, dq, k0, w, p.mode, 0};
     p.inv = (float)inv; p.dq = (float)dq; p.k0 = (float)k0; p.rinv = (float)rinv;
     p.wgt = (float)(w / 4294967296.0);        // the forward kernels' weights are in units of 2^-32
     h[a] = p;
@@ -2117,6 +2163,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     if (e == hipSuccess && src) e = hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice);
   };
   up((void**)&im->ang_dev, h.data(), sizeof(AngleParam) * n_ang);
+  up((void**)&im->ref_ang, href.data(), sizeof(RadonRefAngle) * n_ang);
   if (n1 > 0) up((void**)&im->xT, nullptr, sizeof(float) * (size_t)nt * N * N);
   up((void**)&im->part, nullptr, sizeof(float) * (size_t)nb * n_ang * n_det);   // nb = 1: used by the fused epilogue form
   {
@@ -2173,6 +2220,25 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
   (*out)->flush = radon_flush;
   (*out)->apply_fused = radon_apply_fused;
   (*out)->fused_caps = 2;                  // raw block partials only, no two-operand form
+  return TRK_OK;
+}
+
+namespace trk {
+bool radon_ref_geometry(trk_op* op, RadonRefGeom* g) {
+  if (!op || op->kind != 2 || op->apply != radon_apply) return false;
+  radon_ref_geom_of(static_cast<RadonImpl*>(op->impl), g);
+  return true;
+}
+}  // namespace trk
+
+extern "C" int trk_radon2d_set_arithmetic(trk_op* op, int mode) {
+  TRK_REQUIRE(op && op->kind == 2 && op->apply == radon_apply, "trk_radon2d_set_arithmetic: not a parallel-beam handle");
+  TRK_REQUIRE(mode >= 0 && mode <= 2, "trk_radon2d_set_arithmetic: mode 0 (product), 1 (float64 geometry and sums) or 2 (table weights, float64 sums)");
+  auto* im = static_cast<RadonImpl*>(op->impl);
+  if (im->pend_target) return fail(TRK_EINVAL, "trk_radon2d_set_arithmetic: a deferred norm is pending (trk_op_flush first)");
+  im->ref_mode = mode;
+  im->rec_src = nullptr;
+  im->xT_src = nullptr;
   return TRK_OK;
 }
 

@@ -229,6 +229,26 @@ struct TimerScope {
 
 struct trk_op;
 namespace trk {
+// ---- the float64 instrument (ref64.hip) ----
+// radon2d.hip: one angle of a parallel-beam handle in float64 (q(d, tt) = (d - (nd-1)/2) inv + k0 + tt dq, weight w = scale / |cos|
+// or / |sin|, mode 1 = marching columns) and the handle's sizes + fixed-point tables
+struct RadonRefAngle {
+  double inv, dq, k0, w;
+  int mode, pad_;
+};
+struct RadonRefGeom {
+  int N, nd, na, nt, npad;          // na = angles per frame, nt frames
+  const RadonRefAngle* ang;         // nt * na, frame-major (device)
+  const unsigned* A32;              // [nt*na][nd + 4]
+  const unsigned* B32;              // [nt*na][npad]
+};
+bool radon_ref_geometry(trk_op* op, RadonRefGeom* g);
+int radon_ref_apply_f32(const RadonRefGeom& g, int transpose, int weights, const float* x, float* y, hipStream_t s);
+int ref_axpby_f32(int64_t n, Coef a, const float* x, Coef b, const float* z, float* out, double* sumsq, hipStream_t s);
+// vecops.hip: k_lsqr_damped_update<T, ..> for T = float (elem_bytes 4) / double (8), no error partials
+int lsqr_damped_update_any(size_t elem_bytes, const void* vk, void* w, const void* x_in, void* x_out, int64_t n, const double* alpha_sq,
+                           const double* beta_next_sq, const double* beta0_sq, double damp, const double* state_in, double* state_out,
+                           int first, hipStream_t s);
 // blur2d.hip: sizes and device pointers to the separable weights [kw row weights | kh column weights] of a blur handle
 bool blur_separable_params(trk_op* op, int* nx, int* ny, int* kh, int* kw, const float** sep_fwd, const float** sep_adj);
 }  // namespace trk

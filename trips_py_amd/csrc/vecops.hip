@@ -866,9 +866,11 @@ __global__ __launch_bounds__(NT) void k_gemv_n(const YS y, const float* __restri
 // the damping, one against beta_{k+1}) are recomputed by thread 0 of every workgroup from alpha_k^2, beta_{k+1}^2 and the
 // four doubles the previous step left in st_in = {cs, sn, rho, phibar}; workgroup 0 leaves this step's in st_out (the caller
 // alternates two slots).  vk is alpha_k v_k as GKState(normalized=False) stores it.
-template <bool VEC>
-__global__ __launch_bounds__(NT) void k_lsqr_damped_update(const float* __restrict__ vk, float* w, const float* x_in, float* x_out,
-                                                           const float* __restrict__ ref, double* __restrict__ err_part, int64_t n,
+// Templated on the element type T of the vectors (float: the product; double: the float64 instrument of ref64.hip — the same
+// statements with one type changed); VEC (16-byte accesses) exists for float only.
+template <class T, bool VEC>
+__global__ __launch_bounds__(NT) void k_lsqr_damped_update(const T* __restrict__ vk, T* w, const T* x_in, T* x_out,
+                                                           const T* __restrict__ ref, double* __restrict__ err_part, int64_t n,
                                                            const double* __restrict__ a2, const double* __restrict__ b2,
                                                            const double* __restrict__ beta0_sq, double damp,
                                                            const double* __restrict__ st_in, double* __restrict__ st_out, int first) {
@@ -903,12 +905,13 @@ __global__ __launch_bounds__(NT) void k_lsqr_damped_update(const float* __restri
   const double ia = cf[0], tw = cf[1], px = cf[2];
   double acc = 0.0;
   const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
-  auto one = [&](float v, float wo, float xo, float& wn, float& xn) {
-    wn = (float)(ia * (double)v - (first ? 0.0 : tw * (double)wo));
-    xn = (float)((x_in ? (double)xo : 0.0) + px * (double)wn);
+  auto one = [&](T v, T wo, T xo, T& wn, T& xn) {
+    wn = (T)(ia * (double)v - (first ? 0.0 : tw * (double)wo));
+    xn = (T)((x_in ? (double)xo : 0.0) + px * (double)wn);
   };
   int64_t tail0 = 0;
-  if (VEC) {
+  if constexpr (VEC) {
+    static_assert(std::is_same<T, float>::value, "16-byte accesses: float only");
     const int64_t n4 = n >> 2;
     tail0 = n4 << 2;
     for (int64_t i = tid; i < n4; i += nth) {
@@ -930,12 +933,12 @@ __global__ __launch_bounds__(NT) void k_lsqr_damped_update(const float* __restri
     }
   }
   for (int64_t i = tail0 + tid; i < n; i += nth) {
-    float wn, xn;
-    one(vk[i], first ? 0.f : w[i], x_in ? x_in[i] : 0.f, wn, xn);
+    T wn, xn;
+    one(vk[i], first ? (T)0 : w[i], x_in ? x_in[i] : (T)0, wn, xn);
     w[i] = wn;
     x_out[i] = xn;
     if (ref) {
-      const double e = (double)xn - ref[i];
+      const double e = (double)xn - (double)ref[i];
       acc += e * e;
     }
   }
@@ -2157,10 +2160,10 @@ int trk_lsqr_damped_update(const float* vk, float* w, const float* x_in, float* 
   hipStream_t s = (hipStream_t)st;
   const bool vec = aligned16(vk) && aligned16(w) && aligned16(x_out) && (!x_in || aligned16(x_in)) && (!ref || aligned16(ref));
   if (vec)
-    hipLaunchKernelGGL((k_lsqr_damped_update<true>), dim3(grid), dim3(NT), 0, s, vk, w, x_in, x_out, ref, err_partials, n, alpha_sq,
+    hipLaunchKernelGGL((k_lsqr_damped_update<float, true>), dim3(grid), dim3(NT), 0, s, vk, w, x_in, x_out, ref, err_partials, n, alpha_sq,
                        beta_next_sq, beta0_sq, damp, state_in, state_out, first);
   else
-    hipLaunchKernelGGL((k_lsqr_damped_update<false>), dim3(grid), dim3(NT), 0, s, vk, w, x_in, x_out, ref, err_partials, n, alpha_sq,
+    hipLaunchKernelGGL((k_lsqr_damped_update<float, false>), dim3(grid), dim3(NT), 0, s, vk, w, x_in, x_out, ref, err_partials, n, alpha_sq,
                        beta_next_sq, beta0_sq, damp, state_in, state_out, first);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
@@ -2352,3 +2355,22 @@ int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, cons
 }
 
 }  // extern "C"
+
+// the damped-LSQR update on float or double vectors (ref64.hip's chain): the scalar-access instantiation of the production template
+namespace trk {
+int lsqr_damped_update_any(size_t elem_bytes, const void* vk, void* w, const void* x_in, void* x_out, int64_t n, const double* alpha_sq,
+                           const double* beta_next_sq, const double* beta0_sq, double damp, const double* state_in, double* state_out,
+                           int first, hipStream_t s) {
+  const int grid = stream_grid(n);
+  if (elem_bytes == 8)
+    hipLaunchKernelGGL((k_lsqr_damped_update<double, false>), dim3(grid), dim3(NT), 0, s, (const double*)vk, (double*)w, (const double*)x_in,
+                       (double*)x_out, (const double*)nullptr, (double*)nullptr, n, alpha_sq, beta_next_sq, beta0_sq, damp, state_in,
+                       state_out, first);
+  else
+    hipLaunchKernelGGL((k_lsqr_damped_update<float, false>), dim3(grid), dim3(NT), 0, s, (const float*)vk, (float*)w, (const float*)x_in,
+                       (float*)x_out, (const float*)nullptr, (double*)nullptr, n, alpha_sq, beta_next_sq, beta0_sq, damp, state_in,
+                       state_out, first);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+}  // namespace trk

@@ -236,6 +236,28 @@ class Radon2DParallel(_HandleOperator):
         _lib.check(engine.lib.trk_radon2d_create(self.N, self.n_det, p, len(self.angles), self.scale, ctypes.byref(h)), "trk_radon2d_create")
         super().__init__(h, engine)
 
+    # ---- the float64 instrument (csrc/ref64.hip; diagnostics, not a fast path) ----
+    ARITHMETIC = {"product": 0, "float64": 1, "tables64": 2}
+
+    def set_arithmetic(self, mode):
+        """The arithmetic every apply of this operator runs in (trk_radon2d_set_arithmetic): 'product' — the fast kernels;
+        'float64' — interpolation weights from the geometry in float64, float64 sums; 'tables64' — the fast kernels' fixed-point
+        weights, float64 sums.  Vectors stay fp32; solvers work unchanged (fused riders run in launches of their own)."""
+        _lib.check(self.engine.lib.trk_radon2d_set_arithmetic(self._h, self.ARITHMETIC[mode]), "trk_radon2d_set_arithmetic")
+        return self
+
+    def apply_ref(self, x, transpose=False, weights="float64"):
+        """Op(x) by the float64-arithmetic kernels on a float32 OR float64 device vector (trk_radon2d_apply_ref)."""
+        if x.dtype not in (torch.float32, torch.float64) or not x.is_contiguous():
+            raise ValueError("apply_ref: contiguous float32 / float64 device vector expected")
+        nin, nout = (self.shape[0], self.shape[1]) if transpose else (self.shape[1], self.shape[0])
+        if x.numel() != nin:
+            raise ValueError(f"dimension mismatch: operator expects {nin}, got {x.numel()}")
+        y = torch.empty(nout, dtype=x.dtype, device=x.device)
+        _lib.check(self.engine.lib.trk_radon2d_apply_ref(self._h, int(bool(transpose)), x.element_size(), {"float64": 0, "tables64": 1}[weights],
+                                                         x.data_ptr(), y.data_ptr(), self.engine.stream()), "trk_radon2d_apply_ref")
+        return y
+
 
 class FanBeam2D(_HandleOperator):
     """Fan-beam flat-detector line projector with the geometry defaults of Tomography.define_proj_id

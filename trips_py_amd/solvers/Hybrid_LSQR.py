@@ -90,6 +90,8 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     Engine-only kwarg: history (True, False, a stride, 'host' or a .npy path: _io.History)."""
     A = as_operator(A)
     delta = check_delta(regparam, kwargs)
+    if kwargs.get("dtype") is not None and np.dtype(kwargs["dtype"]) != np.dtype("float32"):
+        return _hybrid_lsqr_float64(A, b, int(n_iter), regparam, x_true, kwargs)
     if kwargs.get("dp_stop", False):
         # the reference's dp_stop branch multiplies V[:, :-1] (k-1 columns) by a k-vector and raises (:87-93 / :60-66)
         raise NotImplementedError("dp_stop=True: the reference branch is shape-inconsistent; not reproduced")
@@ -302,6 +304,44 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         e = E.host(0, nx_done + 1)
         info["relError"] = list(np.sqrt(e[1:] / e[0]))
     return fmt.vec(x_dev), info
+
+
+def _hybrid_lsqr_float64(A, b, n_iter, regparam, x_true, kwargs):
+    """Hybrid_LSQR(..., dtype='float64'): the float64 INSTRUMENT (csrc/ref64.hip, trk_gk_lsqr_chain) — the engine's own arrangement
+    of the solver (Golub-Kahan on unnormalised vectors, the iterate by damped LSQR's short recurrence) with its vectors stored in
+    float64 and the projector's weights and sums in float64.  For checking the fast path against, not for speed: a numeric
+    `regparam` and a parallel-beam operator only.  kwargs: storage ('float64' | 'float32': the element type of the vectors; the
+    arithmetic stays float64), weights ('float64' | 'tables64': see Radon2DParallel.set_arithmetic)."""
+    import torch
+    from .. import _lib
+    from ..operators import Radon2DParallel
+    if np.dtype(kwargs["dtype"]) != np.dtype("float64"):
+        raise ValueError("Hybrid_LSQR: dtype must be 'float32' (the engine) or 'float64' (the instrument)")
+    if isinstance(regparam, str) or not isinstance(A, Radon2DParallel):
+        raise NotImplementedError("Hybrid_LSQR(dtype='float64') is the diagnostic chain: numeric regparam, Radon2DParallel operator")
+    if n_iter < 2:
+        raise UnboundLocalError("Hybrid_LSQR with n_iter < 2 forms no iterate (the reference fails the same way, Hybrid_LSQR.py:114)")
+    eng = A.engine
+    m, n = A.shape
+    tdt = torch.float64 if kwargs.get("storage", "float64") == "float64" else torch.float32
+    fmt = Formatter(b)
+    bv = torch.as_tensor(np.asarray(b, dtype=np.float64).reshape(-1) if not isinstance(b, torch.Tensor) else b.reshape(-1)).to(device=eng.device, dtype=tdt)
+    if bv.numel() != m:
+        raise ValueError(f"dimension mismatch: b has {bv.numel()} entries, the operator {m} rows")
+    X = torch.empty((n_iter, n), dtype=tdt, device=eng.device)
+    work = torch.empty(2 * m + 3 * n, dtype=tdt, device=eng.device)
+    AB = torch.zeros(2 * n_iter + 1, dtype=torch.float64, device=eng.device)
+    st = torch.zeros(8, dtype=torch.float64, device=eng.device)
+    rc = eng.lib.trk_gk_lsqr_chain(A._h, bv.element_size(), {"float64": 0, "tables64": 1}[kwargs.get("weights", "float64")], bv.data_ptr(),
+                                   n_iter, float(regparam), X.data_ptr(), work.data_ptr(), AB.data_ptr(), st.data_ptr(), eng.stream())
+    _lib.check(rc, "trk_gk_lsqr_chain")
+    hist = [X[k].to("cpu").numpy().astype(np.float64).reshape(-1, 1) for k in range(1, n_iter)]   # none at the first step (:77-78)
+    info = {"xHistory": hist, "regParam": regparam, "regParam_history": [regparam] * (n_iter - 1), "relResidual": [],
+            "its": n_iter - 1, "B_squared": AB.to("cpu").numpy()}
+    if x_true is not None:
+        xt = (x_true.detach().to("cpu").numpy() if isinstance(x_true, torch.Tensor) else np.asarray(x_true)).astype(np.float64).reshape(-1, 1)
+        info["relError"] = [float(np.linalg.norm(h - xt) / np.linalg.norm(xt)) for h in hist]
+    return (hist[-1] if fmt.numpy else X[n_iter - 1].clone().reshape(-1, 1)), info
 
 
 @atexit.register
