@@ -182,7 +182,9 @@ int trk_tv_weights(trk_op* L, const float* x, double eps, double q, float* w, tr
  * LAST frame and the next rank's FIRST frame of the same vector, N*N floats each, NULL where there is no neighbour — and the rank
  * forms its own pixels of L^T (w .* L x) completely with the same kernel one rank runs: one two-sided exchange of x
  * (trk_halo_exchange2) per operand instead of one exchange of rows of L x per direction of L.  The frames must stay valid until
- * that call has completed on its stream; the call consumes them.  Weight layout of a sharded handle (trk_tv_weights out,
+ * that call has completed on its stream; the call consumes them on every exit path (a call that fails its argument checks
+ * disarms them too).  The handle holds ONE armed operand: not for concurrent fused calls from two threads / streams.  Weight layout
+ * of a sharded handle (trk_tv_weights out,
  * trk_tv_grad in): nt_local * 2N(N-1) spatial | rows 0 .. nt_local-2 | row nt_local-1 (has_next) | the previous rank's boundary
  * row (has_prev: recomputed from the halo, the same bits as on the rank that owns it), N*N floats each. */
 int trk_tv_halo(trk_op* L, const float* x_prev_last_dev, const float* x_next_first_dev);
@@ -484,6 +486,11 @@ int trk_radon2d_apply_ref(trk_op* op, int transpose, int elem_bytes, int weights
  * trk_gk_step* unchanged (the fused riders are then run in launches of their own).  For experiments that separate what fp32
  * STORAGE costs a solver from what the projector's own arithmetic adds. */
 int trk_radon2d_set_arithmetic(trk_op* op, int mode);
+/* The instrument's kernels with EMULATED fp32 partial sums (what separates the product kernels from exact arithmetic): the forward
+ * adds its products in fp32 and moves the sum into a float64 total every chunk_fwd marching steps, the adjoint every chunk_adj
+ * angles, and the angle's weight is applied in fp32; 0 (default) = float64 sums.  Applies to trk_radon2d_apply_ref,
+ * trk_gk_lsqr_chain and the arithmetic modes 1 / 2 above. */
+int trk_radon2d_set_ref_sums(trk_op* op, int chunk_fwd, int chunk_adj);
 /* out = a x + b z on float / double vectors with the coefficients of trk_axpby: float64 coefficients and products, ONE rounding
  * to the element type (the arithmetic of the projector's fused half step), *sumsq = sum out^2 (may be NULL).  x may alias out. */
 int trk_ref_axpby(int elem_bytes, int64_t n, double ca, const double* a_num, const double* a_den, int a_flags, const void* x,

@@ -554,6 +554,31 @@ def test_half_step_entry_point_serves_any_operator():
         A.apply_axpby(x, 1.0, 1.0, z, x)
 
 
+@pytest.mark.parametrize("N,pitch,nd", [(64, 4.0, 24), (64, 3.0, 40), (96, 2.5, 60), (64, 1.2, 90)])
+def test_fanbeam_coarse_detector_adjoint_is_matched(N, pitch, nd):
+    """A detector pitch coarser than a pixel's footprint (2 w < 1): most pixels see NO ray of a view, and the adjoint's candidate
+    interval is empty there — the ray next to it may lie several columns away and must weigh nothing (the guard on
+    the first candidate).  The adjoint against the oracle's brute-force matrix and the adjoint identity."""
+    from oracle import cpu_ref as O
+    from trips_py_amd.operators import FanBeam2D
+    na = 36
+    ang = np.linspace(0, np.pi, na, endpoint=False) + 0.01
+    A = FanBeam2D(N, angles=ang, n_det=nd, det_pitch=pitch)
+    Ao = O.FanBeam2D(N, ang, n_det=nd, pitch=pitch)
+    rng = np.random.default_rng(N + nd)
+    x, y = rng.random(N * N), rng.standard_normal(A.shape[0])
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    assert relerr(A @ x, Ao @ f(x)) < 1e-5 and relerr(A.T @ y, Ao.T @ f(y)) < 1e-5, (relerr(A @ x, Ao @ f(x)), relerr(A.T @ y, Ao.T @ f(y)))
+    Ax, ATy = A @ x, A.T @ y
+    assert abs(Ax @ y - x @ ATy) <= 2e-6 * np.linalg.norm(Ax) * np.linalg.norm(y)
+    # pixels no ray touches get exactly nothing
+    untouched = np.asarray(abs(Ao.matrix()).sum(axis=0)).reshape(-1) == 0
+    if pitch >= 2.5:
+        assert untouched.any()
+    back = A.T @ np.abs(y)
+    assert np.all(back[untouched] <= 1e-6 * back.max())
+
+
 @pytest.mark.parametrize("N,views", [(256, 90), (512, 180), (1000, 50)])
 def test_fanbeam_matched_pair_at_demo_sizes(N, views):
     """Row-march fan-beam pair at the sizes the tomography demos use: <A x, y> = <x, A^T y> to fp32 summation error (the adjoint

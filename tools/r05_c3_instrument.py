@@ -71,16 +71,28 @@ def main():
                     ("chain32/tab", dict(storage="float32", weights="tables64")), ("chain64/tab", dict(storage="float64", weights="tables64"))):
         x, info = S.Hybrid_LSQR(R, b, its, 1e-2, xt, dtype="float64", **kw)
         runs[tag] = info["xHistory"]
-    for tag, mode in (("solver/w64", "float64"), ("solver/tab", "tables64"), ("product", "product")):
+    # (chunk_fwd, chunk_adj): the instrument's kernels with EMULATED fp32 partial sums — which of the product's sums matter?
+    sums = {"solver/w64": ("float64", 0, 0), "solver/tab": ("tables64", 0, 0), "tab/f16,a180": ("tables64", 16, 180),
+            "tab/f16,a0": ("tables64", 16, 0), "tab/f0,a180": ("tables64", 0, 180), "tab/f4,a32": ("tables64", 4, 32),
+            "tab/f8,a16": ("tables64", 8, 16), "product": ("product", 0, 0)}
+    for tag, (mode, cf, ca) in sums.items():
         R.set_arithmetic(mode)
+        R.set_ref_sums(cf, ca)
+        if mode != "product":
+            v32 = torch.from_numpy(rng.standard_normal(N * N).astype(np.float32)).to(dev)
+            u32 = torch.from_numpy(rng.standard_normal(na * N).astype(np.float32)).to(dev)
+            ef = relerr(R.apply(v32).cpu().numpy(), Ro @ v32.cpu().numpy().astype(np.float64))
+            ea = relerr(R.apply(u32, transpose=True).cpu().numpy(), Ro.T @ u32.cpu().numpy().astype(np.float64))
+            print(f"# {tag:14s}: A noise {ef:.2e}   A^T noise {ea:.2e}")
         x, info = S.Hybrid_LSQR(R, b, its, 1e-2, xt)
         runs[tag] = info["xHistory"]
     R.set_arithmetic("product")
+    R.set_ref_sums(0, 0)
     tags = list(runs)
-    print("# iterate " + " ".join(f"{t:>12s}" for t in tags))
+    print("# iterate " + " ".join(f"{t:>13s}" for t in tags))
     d = {t: [relerr(h, ho) for h, ho in zip(runs[t], io["xHistory"])] for t in tags}
     for k in range(len(io["xHistory"])):
-        print(f"{k + 1:9d} " + " ".join(f"{d[t][k]:12.3e}" for t in tags))
+        print(f"{k + 1:9d} " + " ".join(f"{d[t][k]:13.3e}" for t in tags))
     print("# max over iterates 1..20 " + " ".join(f"{t}={max(d[t][:20]):.3e}" for t in tags))
     print("# max over iterates 21..  " + " ".join(f"{t}={max(d[t][20:]):.3e}" for t in tags))
     print("# final iterate           " + " ".join(f"{t}={d[t][-1]:.3e}" for t in tags))

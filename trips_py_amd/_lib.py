@@ -243,6 +243,7 @@ SIGNATURES = {
     "trk_gk_step": (c_int, [c_op, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_stream]),
     "trk_radon2d_apply_ref": (c_int, [c_op, c_int, c_int, c_int, ctypes.c_void_p, ctypes.c_void_p, c_stream]),
     "trk_radon2d_set_arithmetic": (c_int, [c_op, c_int]),
+    "trk_radon2d_set_ref_sums": (c_int, [c_op, c_int, c_int]),
     "trk_ref_axpby": (c_int, [c_int, c_i64, c_dbl, c_f64p, c_f64p, c_int, ctypes.c_void_p, c_dbl, c_f64p, c_f64p, c_int, ctypes.c_void_p,
                               ctypes.c_void_p, c_f64p, c_stream]),
     "trk_gk_lsqr_chain": (c_int, [c_op, c_int, c_int, ctypes.c_void_p, c_int, c_dbl, ctypes.c_void_p, ctypes.c_void_p, c_f64p, c_f64p,

@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256) void k_fan_adj_prep(const float* __restrict__ 
 // One thread per pixel.  Per view: the detector coordinate uc of the pixel centre's projection and the half width w of the detector
 // interval a ray must lie in to touch the pixel give the candidates dlo = ceil(uc - w) .. floor(uc + w): one or two nearly
 // everywhere (NC = 2, decided at creation: three only next to the source) — the first two are always fetched (16-byte records
-// through a buffer resource: view row in the scalar offset, 16 dlo in the vector offset, the second 16 bytes on) and weighed, the
-// second with weight 0 when it is not in the interval (it may lie more than two columns away, where the 32-bit relative position
+// through a buffer resource: view row in the scalar offset, 16 dlo in the vector offset, the second 16 bytes on) and weighed, each
+// with weight 0 when it is not in the interval (it may lie more than two columns away, where the 32-bit relative position
 // would alias), further ones in a rare loop; the view loop is unrolled by four so that the gathers of several views are in flight
 // together (with a candidate loop every view waited for its own gather: 0.9 us per view and wave at four waves per SIMD).
 // The kernel is bound by vector-instruction issue (PMC: 96 % busy): 76 instructions per pixel and view in round 3's form, ~58 here.
@@ -353,10 +353,13 @@ __global__ __launch_bounds__(256) void k_fan_adj_march(float* __restrict__ img,
     int a = 0;
     for (; a + UA <= na; a += UA) {
       FanRec q[UA][2];
-      bool ok1[UA];
+      bool ok0[UA], ok1[UA];
 #pragma unroll
       for (int u = 0; u < UA; ++u) {
         const Iv v = interval(ang[a + u]);
+        // an EMPTY interval (2 w < 1: detector pitch coarser than a pixel's footprint) has no candidate at all: the ray at
+        // ceil(uc - w) may then lie several columns away, where the 32-bit relative position of weigh() would alias
+        ok0[u] = v.clo <= v.hi;
         ok1[u] = v.clo + 1.f <= v.hi;
         q[u][0] = fetch(a + u, v.dlo);
         q[u][1] = fetch(a + u, v.dlo + 1);
@@ -367,7 +370,7 @@ __global__ __launch_bounds__(256) void k_fan_adj_march(float* __restrict__ img,
       }
 #pragma unroll
       for (int u = 0; u < UA; ++u) {
-        acc += weigh(q[u][0]);
+        acc += ok0[u] ? weigh(q[u][0]) : 0.f;
         acc += ok1[u] ? weigh(q[u][1]) : 0.f;
       }
     }

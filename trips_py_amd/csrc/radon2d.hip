@@ -109,6 +109,7 @@ struct RadonImpl {
   // 0 the product's kernels; 1 float64 geometry and sums (fp32 vectors); 2 the fixed-point tables' weights, float64 sums
   RadonRefAngle* ref_ang;
   int ref_mode;
+  int ref_chunk_fwd, ref_chunk_adj;   // emulated fp32 partial sums of the instrument (0: float64 sums)
   float* ref_tmp;     // max(rows, cols) floats: Op(x) before the half step's combination (ref_mode != 0 only)
 };
 
@@ -1918,7 +1919,7 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
 
 // ref_mode != 0 (trk_radon2d_set_arithmetic): every apply of the handle through ref64.hip's float64-arithmetic kernels
 int radon_ref_geom_of(RadonImpl* im, RadonRefGeom* g) {
-  *g = RadonRefGeom{im->N, im->nd, im->na, im->nt, im->npad, im->ref_ang, im->A32, im->B32};
+  *g = RadonRefGeom{im->N, im->nd, im->na, im->nt, im->npad, im->ref_ang, im->A32, im->B32, im->ref_chunk_fwd, im->ref_chunk_adj};
   return TRK_OK;
 }
 int radon_apply_refmode(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq, hipStream_t s) {
@@ -2239,6 +2240,15 @@ extern "C" int trk_radon2d_set_arithmetic(trk_op* op, int mode) {
   im->ref_mode = mode;
   im->rec_src = nullptr;
   im->xT_src = nullptr;
+  return TRK_OK;
+}
+
+extern "C" int trk_radon2d_set_ref_sums(trk_op* op, int chunk_fwd, int chunk_adj) {
+  TRK_REQUIRE(op && op->kind == 2 && op->apply == radon_apply, "trk_radon2d_set_ref_sums: not a parallel-beam handle");
+  TRK_REQUIRE(chunk_fwd >= 0 && chunk_adj >= 0, "trk_radon2d_set_ref_sums: chunks must be >= 0 (0 = float64 sums)");
+  auto* im = static_cast<RadonImpl*>(op->impl);
+  im->ref_chunk_fwd = chunk_fwd;
+  im->ref_chunk_adj = chunk_adj;
   return TRK_OK;
 }
 

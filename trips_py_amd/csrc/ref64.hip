@@ -60,6 +60,27 @@ __global__ __launch_bounds__(NT) void k_ref_radon_fwd(const T* __restrict__ img,
   const T* __restrict__ I = img + (int64_t)(a / g.na) * g.N * g.N;
   const int N = g.N;
   double acc = 0.0;
+  if (g.chunk_fwd > 0) {
+    // the product kernels' arithmetic, emulated: fp32 FMAs into one accumulator per tap side, moved to the float64 total every
+    // chunk_fwd steps; the angle's weight applied to the fp32-rounded total in fp32
+    float a0 = 0.f, a1 = 0.f;
+    for (int tt = 0; tt < N; ++tt) {
+      int c;
+      double f;
+      ref_tap<WEIGHTS>(p, g, a, d, tt, c, f);
+      float v0 = 0.f, v1 = 0.f;
+      if ((unsigned)c < (unsigned)N) v0 = (float)(p.mode ? I[(int64_t)c * N + tt] : I[(int64_t)tt * N + c]);
+      if ((unsigned)(c + 1) < (unsigned)N) v1 = (float)(p.mode ? I[(int64_t)(c + 1) * N + tt] : I[(int64_t)tt * N + c + 1]);
+      a0 = fmaf((float)(1.0 - f), v0, a0);
+      a1 = fmaf((float)f, v1, a1);
+      if ((tt + 1) % g.chunk_fwd == 0 || tt == N - 1) {
+        acc += (double)(a0 + a1);
+        a0 = a1 = 0.f;
+      }
+    }
+    sino[ray] = (T)((float)p.w * (float)acc);
+    return;
+  }
   for (int tt = 0; tt < N; ++tt) {
     int c;
     double f;
@@ -81,6 +102,7 @@ __global__ __launch_bounds__(NT) void k_ref_radon_adj(const T* __restrict__ sino
   const int i = (int)(pix / N), j = (int)(pix - (int64_t)i * N);
   const double sdh = 0.5 * (double)(g.nd - 1);
   double acc = 0.0;
+  float af32[4] = {0.f, 0.f, 0.f, 0.f};                      // chunk_adj > 0: fp32 accumulators by candidate position (the product: 3)
   for (int af = 0; af < g.na; ++af) {
     const int a = frame * g.na + af;
     const RadonRefAngle p = g.ang[a];
@@ -94,10 +116,23 @@ __global__ __launch_bounds__(NT) void k_ref_radon_adj(const T* __restrict__ sino
       int c;
       double f;
       ref_tap<WEIGHTS>(p, g, a, d, tt, c, f);
-      if (c == col) s += (1.0 - f) * (double)sino[(int64_t)a * g.nd + d];
-      else if (c + 1 == col) s += f * (double)sino[(int64_t)a * g.nd + d];
+      const double wt = (c == col) ? 1.0 - f : (c + 1 == col) ? f : 0.0;
+      if (wt == 0.0) continue;
+      if (g.chunk_adj > 0) {
+        const float ws = (float)p.w * (float)sino[(int64_t)a * g.nd + d];        // the record's pre-weighted sample
+        af32[d - d0 + 1] = fmaf((float)wt, ws, af32[d - d0 + 1]);
+      } else {
+        s += wt * (double)sino[(int64_t)a * g.nd + d];
+      }
     }
-    acc += p.w * s;
+    if (g.chunk_adj > 0) {
+      if ((af + 1) % g.chunk_adj == 0 || af == g.na - 1) {
+        acc += (double)((af32[0] + af32[1]) + (af32[2] + af32[3]));
+        af32[0] = af32[1] = af32[2] = af32[3] = 0.f;
+      }
+    } else {
+      acc += p.w * s;
+    }
   }
   img[(int64_t)frame * N * N + pix] = (T)acc;
 }

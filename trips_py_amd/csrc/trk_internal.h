@@ -241,6 +241,9 @@ struct RadonRefGeom {
   const RadonRefAngle* ang;         // nt * na, frame-major (device)
   const unsigned* A32;              // [nt*na][nd + 4]
   const unsigned* B32;              // [nt*na][npad]
+  // emulation of fp32 partial sums (0: float64 sums): the forward adds its products in fp32 and moves the sum to a float64 total
+  // every chunk_fwd marching steps, the adjoint every chunk_adj angles; the angle's weight is then applied in fp32 as well
+  int chunk_fwd, chunk_adj;
 };
 bool radon_ref_geometry(trk_op* op, RadonRefGeom* g);
 int radon_ref_apply_f32(const RadonRefGeom& g, int transpose, int weights, const float* x, float* y, hipStream_t s);

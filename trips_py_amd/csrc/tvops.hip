@@ -438,9 +438,11 @@ int trk_tv_halo(trk_op* L, const float* x_prev_last, const float* x_next_first) 
 }
 
 int trk_tv_weights(trk_op* L, const float* x, double eps, double q, float* w, trk_stream st) {
-  TRK_REQUIRE(L && x && w, "trk_tv_weights: NULL argument");
+  TRK_REQUIRE(L, "trk_tv_weights: NULL operator");
   TvGeo g;
-  if (int rc = tv_geometry(L, "trk_tv_weights", &g)) return rc;
+  const int rcg = tv_geometry(L, "trk_tv_weights", &g);      // first: the frames trk_tv_halo parked are consumed on EVERY exit path
+  TRK_REQUIRE(x && w, "trk_tv_weights: NULL argument");
+  if (rcg) return rcg;
   const int N = g.N, nt = g.nt;
   const float e = (float)(q / 2.0 - 1.0), eps2 = (float)(eps * eps);
   const int special = (q == 2.0) ? 1 : (q == 1.0) ? 2 : 0;
@@ -456,10 +458,12 @@ int trk_tv_weights(trk_op* L, const float* x, double eps, double q, float* w, tr
 }
 
 int trk_tv_grad(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, trk_stream st) {
-  TRK_REQUIRE(L && x && out, "trk_tv_grad: NULL argument");
-  TRK_REQUIRE(out != x && out != r_in, "trk_tv_grad: out must not alias x or r_in");
+  TRK_REQUIRE(L, "trk_tv_grad: NULL operator");
   TvGeo gg;
-  if (int rc = tv_geometry(L, "trk_tv_grad", &gg)) return rc;
+  const int rcg = tv_geometry(L, "trk_tv_grad", &gg);        // first: see trk_tv_weights
+  TRK_REQUIRE(x && out, "trk_tv_grad: NULL argument");
+  TRK_REQUIRE(out != x && out != r_in, "trk_tv_grad: out must not alias x or r_in");
+  if (rcg) return rcg;
   const int N = gg.N, nt = gg.nt;
   const dim3 g = grid2(N, nt, false).g;
   hipStream_t s = (hipStream_t)st;
@@ -473,10 +477,12 @@ int trk_tv_grad(trk_op* L, const float* x, const float* w, const float* r_in, do
 
 int trk_tv_grad_dot(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, const float* dotv,
                     double* dot_out, trk_stream st) {
-  TRK_REQUIRE(L && x && out && dotv && dot_out, "trk_tv_grad_dot: NULL argument");
-  TRK_REQUIRE(out != x && out != r_in && out != dotv, "trk_tv_grad_dot: out must not alias x, r_in or dotv");
+  TRK_REQUIRE(L, "trk_tv_grad_dot: NULL operator");
   TvGeo gg;
-  if (int rc = tv_geometry(L, "trk_tv_grad_dot", &gg)) return rc;
+  const int rcg = tv_geometry(L, "trk_tv_grad_dot", &gg);    // first: see trk_tv_weights
+  TRK_REQUIRE(x && out && dotv && dot_out, "trk_tv_grad_dot: NULL argument");
+  TRK_REQUIRE(out != x && out != r_in && out != dotv, "trk_tv_grad_dot: out must not alias x, r_in or dotv");
+  if (rcg) return rcg;
   const int N = gg.N, nt = gg.nt;
   const Grid2 g2 = grid2(N, nt, true);
   const int nblk = g2.per_frame * nt;

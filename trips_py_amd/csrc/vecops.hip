@@ -1488,8 +1488,22 @@ __device__ __forceinline__ void bf16_split8(const float (&d)[8], bf8v& hi, bf8v&
     lo[c] = (__bf16)(d[c] - (float)hi[c]);
   }
 }
-template <int T, bool Z, int D, bool BF = true>
-__global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 2)) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
+// BF = 3 (round 5): THREE bf16 pieces per operand — hi + mid + lo is the fp32 value exactly — and the six partial products down to
+// 2^-16 of the largest (hi hi, hi mid, mid hi, mid mid, hi lo, lo hi; what is dropped is 2^-24 and below, the fp32 accumulator's own
+// resolution).  Two pieces lose up to 2^-16 of EACH operand; on noisy data the residuals average out (measured 5e-9 against the
+// fp32-pipe Gram), on piecewise-constant or repeated values they are all the same number and do not: a Gram entry was then off by
+// up to 3e-5 of itself (tests/test_gpu_kernels.py::test_wgram_tv_split_products_on_adversarial_images).
+__device__ __forceinline__ void bf16_split8x3(const float (&d)[8], bf8v& hi, bf8v& mid, bf8v& lo) {
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    hi[c] = (__bf16)d[c];
+    const float r1 = d[c] - (float)hi[c];
+    mid[c] = (__bf16)r1;
+    lo[c] = (__bf16)(r1 - (float)mid[c]);
+  }
+}
+template <int T, bool Z, int D, int BF = 3, int MINB = (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 2)>
+__global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
                                                     const float* __restrict__ w, int nbands, int band_rows,
                                                     double* __restrict__ partials, const float* __restrict__ z, int lockstep_in) {
   constexpr int NP = T * (T + 1) / 2;
@@ -1643,7 +1657,28 @@ __global__ __launch_bounds__(NT, (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 
         dv[t][7] = (b.w - d.w) * wv1.w;
       }
       int p = 0;
-      if constexpr (BF) {
+      if constexpr (BF == 3) {
+        // one direction at a time (its three pieces die before the other direction's are made: the register file is the limit here)
+        auto dir = [&](const float (&dd)[T][8]) {
+          bf8v ph[T], pm[T], pl[T];
+#pragma unroll
+          for (int t = 0; t < T; ++t) bf16_split8x3(dd[t], ph[t], pm[t], pl[t]);
+          int pp = 0;
+#pragma unroll
+          for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+            for (int tb = ta; tb < T; ++tb, ++pp) {
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[ta], pl[tb], acc[pp], 0, 0, 0);      // smallest terms first
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[ta], ph[tb], acc[pp], 0, 0, 0);
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm[ta], pm[tb], acc[pp], 0, 0, 0);
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[ta], pm[tb], acc[pp], 0, 0, 0);
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm[ta], ph[tb], acc[pp], 0, 0, 0);
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[ta], ph[tb], acc[pp], 0, 0, 0);
+            }
+        };
+        dir(dh);
+        dir(dv);
+      } else if constexpr (BF == 2) {
         bf8v hh[T], hl[T], vh[T], vl[T];
 #pragma unroll
         for (int t = 0; t < T; ++t) {
@@ -2232,10 +2267,14 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   if (int rc = scratch_doubles(s, (size_t)bx * nv, &part)) return rc;
   static const int no_xcd = env_int("TRK_WGRAM_TV_NO_XCD", 0) ? 2 : 0;
   static const int f32_pipe = env_int("TRK_WGRAM_TV_F32", 0);       // 1: the products through v_mfma_f32_16x16x4_f32 as in round 3 (A/B)
+  static const int pieces = env_int("TRK_WGRAM_TV_PIECES", 3);      // 2: round 4's two-piece split (A/B; accuracy contract: trk.h)
+  static const int occ2 = env_int("TRK_WGRAM_TV_OCC2", 0);          // two tiles, three pieces: 256 registers (no spills), 2 workgroups per CU
 #define WTV(TT, ZZ)                                                                                                                                   \
   do {                                                                                                                                                \
-    if (f32_pipe) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, false>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd); \
-    else hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, true>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd);           \
+    if (f32_pipe) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 0>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd); \
+    else if (pieces == 2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd); \
+    else if (TT == 2 && !ZZ && occ2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd); \
+    else hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd);           \
   } while (0)
   if (z && T16 == 3) {
     // three tiles AND the dots do not fit the register file (108 spilled registers): two passes for 33 <= k <= 48

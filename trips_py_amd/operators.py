@@ -239,6 +239,12 @@ class Radon2DParallel(_HandleOperator):
     # ---- the float64 instrument (csrc/ref64.hip; diagnostics, not a fast path) ----
     ARITHMETIC = {"product": 0, "float64": 1, "tables64": 2}
 
+    def set_ref_sums(self, chunk_fwd=0, chunk_adj=0):
+        """The instrument's kernels with emulated fp32 partial sums (trk_radon2d_set_ref_sums): fp32 running sums moved to a float64
+        total every chunk_fwd marching steps (forward) / chunk_adj angles (adjoint); 0 = float64 sums."""
+        _lib.check(self.engine.lib.trk_radon2d_set_ref_sums(self._h, int(chunk_fwd), int(chunk_adj)), "trk_radon2d_set_ref_sums")
+        return self
+
     def set_arithmetic(self, mode):
         """The arithmetic every apply of this operator runs in (trk_radon2d_set_arithmetic): 'product' — the fast kernels;
         'float64' — interpolation weights from the geometry in float64, float64 sums; 'tables64' — the fast kernels' fixed-point
@@ -371,10 +377,15 @@ class SpaceTimeDerivative(_FusedTV, _HandleOperator):
                                                hf[self.npix:].data_ptr() if self.has_next else None), "trk_tv_halo")
 
     def tv_weights(self, x, eps, q, out, halo=None):
+        if out.numel() < self.tv_weights_len:
+            # (a rank with a previous neighbour also writes that neighbour's boundary row: N^2 more than L has rows)
+            raise ValueError(f"tv_weights: out holds {out.numel()} floats, this operator writes tv_weights_len = {self.tv_weights_len}")
         self._give_halo(x, halo)
         super().tv_weights(x, eps, q, out)
 
     def tv_grad(self, x, w, r_in, lam, out, dot_with=None, dot_out=None, halo=None):
+        if w is not None and w.numel() < self.tv_weights_len:
+            raise ValueError(f"tv_grad: w holds {w.numel()} floats, this operator reads tv_weights_len = {self.tv_weights_len}")
         self._give_halo(x, halo)
         super().tv_grad(x, w, r_in, lam, out, dot_with=dot_with, dot_out=dot_out)
 
