@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import relerr
+from conftest import bar, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -280,6 +280,84 @@ def test_wgram_tv_from_v_equals_the_gram_of_the_stored_images(eng, N, k):
         LVo = (Ls @ V.double().cpu().numpy().T).T
         refo = (LVo * w.double().cpu().numpy() ** 2) @ LVo.T
         assert np.allclose(a, refo, rtol=2e-6, atol=1e-6 * scale)
+
+
+def _adversarial_basis(kind, k, N, dev):
+    """Rows that make the roundings of a split-operand product CORRELATED: the same few values over and
+    over, so that whatever a bf16 split drops is the same number in millions of terms."""
+    g = torch.Generator(device=dev).manual_seed(7 * k + N)
+    if kind == "piecewise8":
+        # piecewise-constant images of <= 8 distinct values on a coarse block grid (what a TV-regularised iterate looks like)
+        levels = torch.tensor([0.0, 0.2137, 0.3931, 0.5009, 0.6877, 0.8113, 0.9371, 1.0], device=dev)
+        V = torch.empty(k, N * N, device=dev)
+        for j in range(k):
+            bs = 32 * (1 + j % 4)
+            idx = torch.randint(0, 8, (N // bs + 1, N // bs + 1), device=dev, generator=g)
+            img = levels[idx].repeat_interleave(bs, 0).repeat_interleave(bs, 1)[:N, :N]
+            V[j] = img.reshape(-1) * (1.0 + 0.01 * j)
+        return V
+    if kind == "constant_steps":
+        # every difference is one of two numbers: a ramp in x times a ramp in y with steps just above a bf16 rounding boundary
+        step = 1.0 + 2.0 ** -8 + 2.0 ** -16 + 2.0 ** -17 + 2.0 ** -22      # bf16 keeps 8 bits, two pieces 16: the rest is dropped
+        ii = torch.arange(N, device=dev, dtype=torch.float64)
+        V = torch.empty(k, N * N, device=dev)
+        for j in range(k):
+            a, b = step * (1 + j % 3), step * (1 + (j // 3) % 4)
+            V[j] = ((a * ii)[:, None] * 2.0 ** -12 + (b * ii)[None, :] * 2.0 ** -12).float().reshape(-1)
+        return V
+    if kind == "constant":
+        V = torch.ones(k, N * N, device=dev) * torch.linspace(0.3, 1.7, k, device=dev)[:, None]
+        V[:, ::N] += 0.5004883                                                # one step per row, the same everywhere
+        return V
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize("kind", ["piecewise8", "constant_steps", "constant"])
+@pytest.mark.parametrize("with_z", [False, True])
+@pytest.mark.parametrize("mode,limit", [("bf16x2", 1.2e-5), ("bf16x3", 1e-6), ("fp32", 1e-6)])
+def test_wgram_tv_split_products_on_adversarial_images(eng, kind, with_z, mode, limit):
+    """trk_wgram_tv(_z) — Gram tiles through the bf16 matrix pipe with split operands — on images whose differences repeat a few
+    values millions of times, unit weights and the weights trk_tv_weights makes of such an image: every entry within 1e-6 of the
+    float64 Gram relative to sqrt(G_aa G_bb), in the three arithmetic modes of trk_wgram_tv_precision — the accuracy contract of
+    include/trk.h: the default two-piece split loses up to 2^-16 of each operand, all of one sign on such images (measured 5.8e-6 on
+    `constant_steps`; bar 2 x that), three pieces or the fp32 pipe stay within 1e-6 (measured 4.7e-7)."""
+    from trips_py_amd.operators import FirstDerivative2D
+    N, k = 2048, 24
+    dev = eng.device
+    L = FirstDerivative2D(N, engine=eng)
+    n, p = N * N, 2 * N * (N - 1)
+    V = _adversarial_basis(kind, k, N, dev)
+    ws = [torch.ones(p, device=dev)]
+    wt = torch.empty(p, device=dev)
+    L.tv_weights(V[0].contiguous(), 0.1, 1.0, wt)                             # ((L x)^2 + eps^2)^(-1/2) of a piecewise image
+    ws.append(wt)
+    z = torch.randn(n, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    G = eng.scalars(k * k + k)
+    worst = 0.0
+    was = eng.wgram_tv_precision(mode)
+    for w in ws:
+        if with_z:
+            eng.wgram_tv(V, k, N, w, G[0:k * k], z=z, h=G[k * k:k * k + k])
+        else:
+            eng.wgram_tv(V, k, N, w, G[0:k * k])
+        got = eng.to_host(G)[:k * k].reshape(k, k)
+        # float64 reference from the fp32 operands as the kernel forms them: d = fl32(fl32(x_i - x_j) * w)
+        ref = torch.zeros(k, k, dtype=torch.float64, device=dev)
+        for lo in range(0, N, 256):                                            # row blocks: 24 x 2048 x 256 doubles at a time
+            hi = min(lo + 256, N)
+            X = V.reshape(k, N, N)[:, lo:min(hi + 1, N), :]
+            dh = ((X[:, :hi - lo, :-1] - X[:, :hi - lo, 1:]) * w[:N * (N - 1)].reshape(N, N - 1)[lo:hi]).double().reshape(k, -1)
+            ref += dh @ dh.T
+            nv = min(hi, N - 1) - lo
+            if nv > 0:
+                dv = ((X[:, :nv, :] - X[:, 1:nv + 1, :]) * w[N * (N - 1):].reshape(N - 1, N)[lo:lo + nv]).double().reshape(k, -1)
+                ref += dv @ dv.T
+        ref = ref.cpu().numpy()
+        dg = np.sqrt(np.abs(np.diag(ref)))
+        scale = np.maximum(np.outer(dg, dg), 1e-300)
+        worst = max(worst, float(np.max(np.abs(got - ref) / scale)))
+    assert eng.wgram_tv_precision(was) == mode
+    bar(f"wgram_tv.adversarial[{kind}{'-z' if with_z else ''}-{mode}]", worst, limit)
 
 
 @pytest.mark.gpu

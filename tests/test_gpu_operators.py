@@ -571,11 +571,12 @@ def test_fanbeam_coarse_detector_adjoint_is_matched(N, pitch, nd):
     assert relerr(A @ x, Ao @ f(x)) < 1e-5 and relerr(A.T @ y, Ao.T @ f(y)) < 1e-5, (relerr(A @ x, Ao @ f(x)), relerr(A.T @ y, Ao.T @ f(y)))
     Ax, ATy = A @ x, A.T @ y
     assert abs(Ax @ y - x @ ATy) <= 2e-6 * np.linalg.norm(Ax) * np.linalg.norm(y)
-    # pixels no ray touches get exactly nothing
-    untouched = np.asarray(abs(Ao.matrix()).sum(axis=0)).reshape(-1) == 0
+    # ... view by view (a single view of a coarse detector leaves most pixels untouched: they must get exactly nothing from it)
+    A1, A1o = FanBeam2D(N, angles=ang[:1], n_det=nd, det_pitch=pitch), O.FanBeam2D(N, ang[:1], n_det=nd, pitch=pitch)
+    untouched = np.asarray(abs(A1o.matrix()).sum(axis=0)).reshape(-1) == 0
+    back = A1.T @ np.ones(nd)
     if pitch >= 2.5:
         assert untouched.any()
-    back = A.T @ np.abs(y)
     assert np.all(back[untouched] <= 1e-6 * back.max())
 
 

