@@ -372,7 +372,8 @@ def run_blur_cgls(args, rank, world, json_fd=1):
                          ("c4_mmgks_tv_4096", lambda: extra_c4_mmgks(A, b, N, world, cpu_jobs if cpu else None, psf)),
                          ("c5_dynamic_tomo_sharded", lambda: extra_c5_dynamic(rank, world, cpu_jobs if cpu else None)),
                          ("hybrid_gmres_and_lsqr_blur512", lambda: extra_hybrid_blur(world)),
-                         ("next_fanbeam512_matvec", lambda: extra_fanbeam(world))):
+                         ("next_fanbeam512_matvec", lambda: extra_fanbeam(world)),
+                         ("next_sparse_dynamic", lambda: extra_sparse_dynamic(world, cpu_jobs if cpu else None))):
             try:
                 res["extra"][name] = fn()
             except Exception as exc:          # noqa: BLE001
@@ -633,6 +634,108 @@ def extra_fanbeam(world):
     return out
 
 
+def joseph_block_matrix(Nf, angle_sets, n_det):
+    """blkdiag over frames of the parallel-beam Joseph matrix (two linear-interpolation taps per marching step, scale 1 / Nf: the
+    convention of trips_py_amd.operators.Radon2DParallel) as scipy.sparse CSR — the build's own stand-in for the sparse forward
+    matrix the reference's real-data loaders read from disk (io.py:197-229; the Zenodo files are not reachable offline)."""
+    import scipy.sparse as sp
+    half, sdh = 0.5 * (Nf - 1), 0.5 * (n_det - 1)
+    k = np.arange(Nf)
+    s = np.arange(n_det) - sdh
+    blocks = []
+    for angles in angle_sets:
+        rows, cols, vals = [], [], []
+        for a, th in enumerate(angles):
+            ct, st = np.cos(th), np.sin(th)
+            if abs(ct) >= abs(st):
+                q = (s[:, None] - (half - k)[None, :] * st) / ct + half
+                w = 1.0 / abs(ct)
+            else:
+                q = half - (s[:, None] - (k - half)[None, :] * ct) / st
+                w = 1.0 / abs(st)
+            q0 = np.floor(q)
+            f = q - q0
+            for off, wt in ((0, 1.0 - f), (1, f)):
+                t = (q0 + off).astype(np.int64)
+                ok = (t >= 0) & (t < Nf) & (wt > 0)
+                lin = (k[None, :] * Nf + t) if abs(ct) >= abs(st) else (t * Nf + k[None, :])
+                d_idx = np.broadcast_to(np.arange(n_det)[:, None], t.shape)
+                rows.append((a * n_det + d_idx)[ok])
+                cols.append(lin[ok])
+                vals.append((w * wt / Nf)[ok])
+        blocks.append(sp.csr_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(len(angles) * n_det, Nf * Nf)))
+    return blocks
+
+
+def extra_sparse_dynamic(world, cpu_jobs=None):
+    """SURVEY 8f "next" row, rank 4 (not a BASELINE config): the sparse-forward-matrix dynamic path of io.py:197-229 — frames cut out
+    of one sparse matrix, applied as ONE CSR operator (csrc/spmv.hip).  (i) CrossPhantom-like: 16 frames of 128^2, 700 rays per frame
+    (demos/2_demo_dynamic_CrossPhantom.ipynb): Hybrid-LSQR iterations/s.  (ii) the SpMV's roofline on a ~2e7-non-zero block-diagonal
+    matrix (16 frames of 256^2, 10 angles x 256 detectors): algorithmic bytes 8 nnz + 4 (m + n) per apply against the HBM peak."""
+    from trips_py_amd.operators import SparseBlockDiag
+    from trips_py_amd.solvers import Hybrid_LSQR
+    out = {}
+    # (ii) first: the big matrix is freed before the solver leg
+    T, Nf, na, nd = 16, 256, 10, 256
+    blocks = joseph_block_matrix(Nf, [np.deg2rad(t + 18.0 * np.arange(na)) for t in range(T)], nd)
+    D = SparseBlockDiag(blocks)
+    dev = D.engine.device
+    m, n, nnz = D.shape[0], D.shape[1], int(D.matrix.nnz)
+    x = torch.rand(n, device=dev, generator=torch.Generator(device=dev).manual_seed(11))
+    y, z = torch.empty(m, device=dev), torch.empty(n, device=dev)
+    alg = 8.0 * nnz + 4.0 * (m + n)
+    roof = {"matrix": f"blkdiag of {T} frames, {m} x {n}, {nnz} non-zeros (Joseph weights, {na} angles x {nd} detectors per {Nf}x{Nf} frame)",
+            "alg_bytes_per_apply": alg, "alg_bytes_formula": "8 nnz + 4 (m + n)", "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
+    for name, fn in (("fwd", lambda: D.apply(x, out=y)), ("adj", lambda: D.apply(y, out=z, transpose=True))):
+        for _ in range(3):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(20):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / 20 * 1e3
+        roof[f"{name}_us"] = round(us, 1)
+        roof[f"{name}_achieved"] = round(alg / us * 1e-3, 1)
+        roof[f"{name}_frac"] = round(alg / us * 1e-3 / HBM_PEAK_GBPS, 4)
+    roof["note"] = ("the matrix (170 MB) fits the 256 MB memory-side cache: repeated applies may be served from it, the figure is the "
+                    "kernel's streaming rate against the HBM peak; timed by events on the stream the applies are enqueued on")
+    out["roofline_spmv"] = roof
+    del D, x, y, z
+    torch.cuda.empty_cache()
+    # (i) the CrossPhantom-like problem through Hybrid-LSQR (the demo's cell 15), fixed lambda, whole solves
+    T, Nf, na, nd = 16, 128, 5, 140
+    blocks = joseph_block_matrix(Nf, [np.deg2rad(t + 36.0 * np.arange(na)) for t in range(T)], nd)
+    F = SparseBlockDiag(blocks)
+    xt = torch.zeros(T, Nf, Nf, device=dev)
+    for t in range(T):
+        xt[t, 30 + 2 * t:70 + 2 * t, 20:90] = 1.0
+        xt[t, 80:110, 10 + 4 * t:40 + 4 * t] = 0.5
+    xt = xt.reshape(-1)
+    b = F.apply(xt)
+    e = torch.randn(b.numel(), device=dev, generator=torch.Generator(device=dev).manual_seed(12))
+    b = b + e * (0.01 * torch.linalg.norm(b) / torch.linalg.norm(e))
+    its = 50
+    Hybrid_LSQR(F, b, its, 1e-2, xt, history=False)
+    barrier(world)
+    reps = 5
+    with no_gc():
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            xs, info = Hybrid_LSQR(F, b, its, 1e-2, xt, history=False)
+        barrier(world)
+        dt = max_over_ranks(time.perf_counter() - t0, world)
+    out.update({"problem": f"{T} frames of {Nf}x{Nf}, {na * nd} rays per frame, {int(F.matrix.nnz)} non-zeros in one CSR handle",
+                "solver": f"Hybrid_LSQR(n_iter={its}, regparam=1e-2, x_true)", "iters_per_sec_all_ranks": round(world * reps * its / dt, 1),
+                "ms_per_solve": round(dt / reps * 1e3, 3), "relError_last": float(info["relError"][-1])})
+    if cpu_jobs is not None:
+        Fm, bh = F.matrix.astype(np.float64), b.detach().to("cpu")
+        cpu_jobs.append((lambda v: out.__setitem__("cpu_baseline", v), lambda: cpu_sparse_dynamic(Fm, bh)))
+    return out
+
+
 def extra_c4_mmgks(A, b, N, world, cpu_jobs=None, psf=None):
     """BASELINE config C4: blur 4096^2, MMGKS + TV (pnorm=2, qnorm=1, projection_dim=3, n_iter=30, lambda=1e-2).
     Replicas across ranks (a static image does not shard)."""
@@ -854,6 +957,16 @@ def cpu_c3(Nt, angles, b_dev, sample=8):
     v, t = cpu_iteration_rate(Ro, lambda k: O.hybrid_lsqr(Ro, bh, k, 1e-2), sample)
     return cpu_leg(v, t, f"iterations 2..{sample + 1} of Hybrid_LSQR(regparam=1e-2) on the same {Nt}x{Nt}, {len(angles)}-angle data "
                          "(the reference's cost per iteration grows with the basis: V y, hstack copies); SpMV single-threaded")
+
+
+def cpu_sparse_dynamic(Fm, b_dev, sample=20):
+    """The sparse dynamic problem on the host: the oracle's Hybrid-LSQR over the same scipy.sparse matrix (what the reference runs:
+    demos/2_demo_dynamic_CrossPhantom.ipynb cell 15 hands the loader's scipy matrix straight to Hybrid_LSQR)."""
+    from oracle import cpu_ref as O
+    Fo = O.MatrixOp(Fm)
+    bh = b_dev.detach().cpu().numpy().astype(np.float64).reshape(-1, 1)
+    v, t = cpu_iteration_rate(Fo, lambda k: O.hybrid_lsqr(Fo, bh, k, 1e-2), sample)
+    return cpu_leg(v, t, f"iterations 2..{sample + 1} of Hybrid_LSQR(regparam=1e-2) on the same sparse matrix; scipy CSR SpMV is single-threaded")
 
 
 def cpu_c4(psf, N, b_dev):

@@ -293,6 +293,17 @@ class BlockDiag(_Op):
         return np.concatenate([o._adj(y[self._ro[t]:self._ro[t + 1]]) for t, o in enumerate(self.ops)])
 
 
+def dynamic_frame_blocks(A, b, nt, rows_per_frame, cols_per_frame):
+    """The per-frame blocks the reference's loaders cut out of a dynamic problem's sparse forward matrix and data
+    (io.py:223-225 generate_crossPhantom, :160-162 generate_emoji): AA[ii] = A[r ii : r (ii+1), c ii : c (ii+1)], B[ii] = b[r ii : r (ii+1)]."""
+    A = sp.csr_matrix(A)
+    b = np.asarray(b).reshape(-1)
+    r, c = int(rows_per_frame), int(cols_per_frame)
+    AA = [A[r * ii:r * (ii + 1), c * ii:c * (ii + 1)] for ii in range(int(nt))]
+    B = [b[r * ii:r * (ii + 1)] for ii in range(int(nt))]
+    return AA, B
+
+
 # =====================================================================================
 # a14 derivative regularisers (as sparse matrices)         trips/utilities/operators.py:24-45
 # =====================================================================================

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden, relerr
+from conftest import bar, load_golden, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -288,6 +288,62 @@ def test_sparse_operator_and_reference_built_regularisers():
     A = Blur2D(g["psf"], N, N)
     x, info = S.GKS(A, g["b"], O.first_derivative_2d(N, N), 3, int(g["n_iter"]), 1e-2, g["x_true"])   # scipy.sparse L
     assert relerr(x, g["x"]) < 1e-5
+
+
+@pytest.mark.parametrize("shape,density", [((1000, 3000), 0.001), ((512, 512), 0.012), ((300, 4000), 0.05), ((64, 9000), 0.3), ((7, 5), 0.5),
+                                           ((2000, 50), 0.02)])
+def test_csr_group_kernel_every_group_size(shape, density):
+    """k_csr_group<G> for every lanes-per-row choice (mean row lengths 3 .. 2700: G = 4 .. 64; and empty rows, rows longer than
+    2 G, a matrix with fewer rows than a wave has groups), both directions, against scipy on the fp32-rounded operands."""
+    import scipy.sparse as sp
+    from trips_py_amd.operators import SparseOp
+    M = sp.random(shape[0], shape[1], density=density, random_state=shape[0] + shape[1], format="csr")
+    M.data = np.round(M.data * 64) / 64 + 1 / 64
+    Op = SparseOp(M)
+    rng = np.random.default_rng(shape[1])
+    f = lambda a: a.astype(np.float32).astype(np.float64)
+    x, y = rng.standard_normal(shape[1]), rng.standard_normal(shape[0])
+    assert relerr(Op @ x, M @ f(x)) < 5e-7 and relerr(Op.T @ y, M.T @ f(y)) < 5e-7
+    X = rng.standard_normal((shape[1], 3))
+    assert np.array_equal((Op @ X)[:, 2], Op @ X[:, 2])
+
+
+def test_sparse_dynamic_path_vs_the_reference_loader_and_solvers():
+    """the real-data dynamic problems ship one sparse forward matrix that the reference's loader slices into
+    per-frame blocks (io.py:197-229).  Fixture: generate_crossPhantom ITSELF run on a synthetic stand-in file, and the reference's
+    CGLS / Hybrid_LSQR / MMGKS / GKS on what it returned (tools/make_goldens.py g9).  Here: the whole matrix as ONE CSR handle, the
+    block-diagonal of its frames as ONE CSR handle (SparseBlockDiag.from_matrix, BlockDiagOp of SparseOps), and the solvers."""
+    from test_oracle_golden import sparse_dynamic_golden, sparse_dynamic_vectors
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import BlockDiagOp, FirstDerivative2D, SparseBlockDiag, SparseOp, SpaceTimeDerivative, slice_dynamic_frames
+    g, F = sparse_dynamic_golden()
+    T, N, rpf = int(g["T"]), int(g["N"]), int(g["rows_per_frame"])
+    npix = N * N
+    xr, yr = sparse_dynamic_vectors(T * npix, T * rpf)
+    Fop = SparseOp(F)
+    assert relerr(Fop @ xr, g["F_fwd"]) < 1e-6 and relerr((Fop.T @ yr)[::37], g["F_adj_s"]) < 1e-6
+    # the block-diagonal of the loader's frames: what is outside the blocks is gone, one handle for all frames
+    D = SparseBlockDiag.from_matrix(F, T, rpf, npix)
+    assert D.shape == F.shape and D.matrix.nnz == int(g["block_nnz"].sum()) < F.nnz
+    assert relerr(D @ xr, g["blk_fwd"]) < 1e-6 and relerr((D.T @ yr)[::37], g["blk_adj_s"]) < 1e-6
+    AA, B = slice_dynamic_frames(F, g["b"], T, rpf, npix)
+    D2 = BlockDiagOp([SparseOp(a) for a in AA])                     # merged into one CSR handle, not T launches
+    assert hasattr(D2, "matrix") and np.array_equal(D2 @ xr, D @ xr)
+    # the solvers of the demo (2_demo_dynamic_CrossPhantom.ipynb cells 5, 15, 23) on the loader's outputs
+    x, info = S.Hybrid_LSQR(F, g["b"], 10, 1e-2)                                    # a scipy.sparse matrix straight in
+    assert info["its"] == int(g["lsqr_its"])
+    bar("sparse_dynamic.lsqr.x", relerr(x.reshape(-1)[::16], g["lsqr_x_s"]), 1e-5)
+    assert abs(np.linalg.norm(x) / float(g["lsqr_x_norm"]) - 1) < 1e-5
+    x, info = S.CGLS(Fop, g["b"], np.zeros(T * npix), 12, 0)
+    bar("sparse_dynamic.cgls.x", relerr(x.reshape(-1)[::16], g["cgls_x_s"]), 1e-5)
+    assert np.allclose(info["relResidual"], g["cgls_relResidual"], rtol=1e-4)
+    tf = int(g["frame"])
+    x, info = S.MMGKS(AA[tf], B[tf], FirstDerivative2D(N), 2, 1, 1, 6, 1e-2, None, epsilon=0.1)
+    bar("sparse_dynamic.mmgks_frame.x", relerr(x, g["mmgks_frame_x"]), 5e-5)
+    assert np.allclose(info["Residual"], g["mmgks_frame_Residual"], rtol=2e-3)
+    x, info = S.GKS(Fop, g["b"], SpaceTimeDerivative(N, T), 2, 4, 1e-2, None)
+    bar("sparse_dynamic.gks.x", relerr(x.reshape(-1)[::16], g["gks_x_s"]), 1e-5)
+    assert np.allclose(info["Residual"], g["gks_Residual"], rtol=1e-3)
 
 
 def test_framelet_operator_matches_reference():

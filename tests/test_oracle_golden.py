@@ -434,3 +434,56 @@ def test_framelet_regulariser_through_the_solvers(solver, tag):
     assert lam_close(info["regParam_history"], g["regParam_history"], 1e-3 if tag == "gcv" else 1e-6)
     assert np.allclose(info["relError"], g["relError"], rtol=1e-6) and relerr(x, g["x"]) < 1e-6
     assert np.allclose(info["Residual"], g["Residual"], rtol=1e-4)
+
+
+def sparse_dynamic_vectors(n, m):
+    """The probe vectors of tools/make_goldens.py g9_sparse_dynamic (formulas, not stored)."""
+    return np.sin(0.37 * np.arange(n)) + 0.25 * np.cos(0.011 * np.arange(n)), np.cos(0.53 * np.arange(m)) - 0.1
+
+
+def sparse_dynamic_golden():
+    import scipy.sparse as sp
+    g = load_golden("sparse_dynamic_crossphantom_like")
+    F = sp.csr_matrix((g["F_data"].astype(np.float64), g["F_indices"], g["F_indptr"]), shape=tuple(g["F_shape"]))
+    return g, F
+
+
+def test_sparse_dynamic_frame_slicing_and_solvers():
+    """The sparse-forward-matrix dynamic path against the reference's own loader and solvers run on a synthetic
+    stand-in file (make_goldens g9): frame blocks as io.py:223-225 cuts them (the entries outside the blocks dropped), then CGLS /
+    Hybrid_LSQR on the whole matrix, MMGKS on one frame's block, GKS with the space-time regulariser."""
+    g, F = sparse_dynamic_golden()
+    T, N, rpf = int(g["T"]), int(g["N"]), int(g["rows_per_frame"])
+    npix = N * N
+    AA, B = O.dynamic_frame_blocks(F, g["b"], T, rpf, npix)
+    assert np.array_equal(np.array([a.nnz for a in AA]), g["block_nnz"]) and F.nnz > sum(a.nnz for a in AA)
+    assert np.array_equal(np.concatenate(B), g["B_concat"])
+    xr, yr = sparse_dynamic_vectors(T * npix, T * rpf)
+    assert np.allclose(np.concatenate([AA[t] @ xr[t * npix:(t + 1) * npix] for t in range(T)]), g["blk_fwd"], rtol=1e-13, atol=1e-13)
+    assert np.allclose(np.concatenate([AA[t].T @ yr[t * rpf:(t + 1) * rpf] for t in range(T)])[::37], g["blk_adj_s"], rtol=1e-13, atol=1e-13)
+    Fo = O.MatrixOp(F)
+    assert np.allclose(Fo @ xr, g["F_fwd"], rtol=1e-13, atol=1e-13) and np.allclose((Fo.T @ yr)[::37], g["F_adj_s"], rtol=1e-13, atol=1e-13)
+    bv = g["b"].reshape(-1, 1)
+    x, info = O.hybrid_lsqr(Fo, bv, 10, 1e-2)
+    assert info["its"] == int(g["lsqr_its"]) and relerr(x.reshape(-1)[::16], g["lsqr_x_s"]) < 1e-8
+    assert abs(np.linalg.norm(x) / float(g["lsqr_x_norm"]) - 1) < 1e-9
+    x, info = O.cgls(Fo, bv, np.zeros((T * npix, 1)), 12, 0)
+    assert relerr(x.reshape(-1)[::16], g["cgls_x_s"]) < 1e-9 and np.allclose(info["relResidual"], g["cgls_relResidual"], rtol=1e-8)
+    tf = int(g["frame"])
+    x, info = O.mmgks(O.MatrixOp(AA[tf]), B[tf].reshape(-1, 1), O.FirstDerivative2D(N), 2, 1, 1, 6, 1e-2, None, epsilon=0.1)
+    assert relerr(x, g["mmgks_frame_x"]) < 1e-7 and np.allclose(info["Residual"], g["mmgks_frame_Residual"], rtol=1e-6)
+    x, info = O.gks(Fo, bv, O.SpaceTimeDerivative(N, T), 2, 4, 1e-2, None)
+    assert relerr(x.reshape(-1)[::16], g["gks_x_s"]) < 1e-8 and np.allclose(info["Residual"], g["gks_Residual"], rtol=1e-7)
+
+
+def test_product_slicing_helper_without_gpu():
+    """trips_py_amd.operators.slice_dynamic_frames (host-side, scipy only) = the reference's blocks."""
+    from trips_py_amd.operators import slice_dynamic_frames
+    g, F = sparse_dynamic_golden()
+    T, N, rpf = int(g["T"]), int(g["N"]), int(g["rows_per_frame"])
+    AA, B = slice_dynamic_frames(F, g["b"], T, rpf, N * N)
+    assert np.array_equal(np.array([a.nnz for a in AA]), g["block_nnz"]) and np.array_equal(np.concatenate(B), g["B_concat"])
+    xr, _ = sparse_dynamic_vectors(T * N * N, T * rpf)
+    assert np.allclose(np.concatenate([AA[t] @ xr[t * N * N:(t + 1) * N * N] for t in range(T)]), g["blk_fwd"], rtol=1e-13, atol=1e-13)
+    with pytest.raises(ValueError):
+        slice_dynamic_frames(F, g["b"], T + 1, rpf, N * N)

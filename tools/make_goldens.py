@@ -24,6 +24,7 @@ Fixture families:
   G5d *_framelet_*       GKS / MMGKS with L = create_framelet_operator(32, 32, 2) (operators.py:50-113; the large-scale demos' regulariser)
   G6 deriv_ops                                            (operators.py:24-45)
   G7 regparam_fn                                          (gcv.py, discrepancy_principle.py, l_curve.py)
+  G9 sparse_dynamic_*    generate_crossPhantom on a synthetic stand-in file + CGLS / Hybrid_LSQR / GKS / MMGKS on its outputs (io.py:187-229)
   G8 deblur1d_cgls                                        (Deblurring1D.py + CGLS: BASELINE config C1)
 """
 import io
@@ -480,6 +481,94 @@ def g8_deblur1d():
          x=x, relResidual=info["relResidual"], relError=info["relError"], its=info["its"])
 
 
+# ----------------------------------------------------------------------------------------- G9
+def sparse_dynamic_vectors(n, m):
+    """Deterministic probe vectors (formulas, so that the fixture need not hold them)."""
+    return np.sin(0.37 * np.arange(n)) + 0.25 * np.cos(0.011 * np.arange(n)), np.cos(0.53 * np.arange(m)) - 0.1
+
+
+def g9_sparse_dynamic():
+    """The sparse-forward-matrix dynamic path: the reference's OWN loader generate_crossPhantom (io.py:187-229) run on a synthetic
+    stand-in for the Zenodo file it downloads (same keys, same layout: A of (mm nn) x (16 128^2), sinogram mm x nn), then its
+    solvers on what the loader returns — F = A_small whole (demos/2_demo_dynamic_CrossPhantom.ipynb cell 15, 23) and one frame's
+    block Aseq[t] (cell 5).  T = 16, 700 rows and 16384 columns per frame are hard-coded in the loader (:203, :223)."""
+    print("G9 sparse dynamic path through generate_crossPhantom")
+    import tempfile
+    import scipy.io as spio
+    from trips.utilities import io as rio
+    T, Nf, mm, nn = 16, 128, 140, 240                 # nn / 3 = 80 kept sinogram columns x 140 rays = 11200 = 16 x 700 rows
+    npix = Nf * Nf
+    rng = np.random.default_rng(91)
+    nrows = mm * nn
+    rows, cols, vals = [], [], []
+    for r in range(nrows):
+        col, t = divmod(r, mm)                        # sinogram column, ray
+        kept, ii = (col % 3 == 0), col // 3
+        f = (ii * mm + t) // 700 if kept else rng.integers(0, T)     # the frame the loader will file this row under
+        # a short "ray": 4 pixels of a line through frame f, and one entry OUTSIDE the frame's block (the loader must drop it)
+        i0, j0 = rng.integers(8, Nf - 8, size=2)
+        di, dj = rng.integers(-2, 3, size=2)
+        for k in range(4):
+            rows.append(r)
+            cols.append(f * npix + (i0 + k * di) * Nf + (j0 + k * dj))
+            vals.append(rng.integers(8, 64) / 64.0)
+        rows.append(r)
+        cols.append(((f + 1 + rng.integers(0, T - 1)) % T) * npix + rng.integers(0, npix))
+        vals.append(rng.integers(1, 8) / 64.0)
+    A = _sps.csc_matrix((np.array(vals), (np.array(rows), np.array(cols))), shape=(nrows, T * npix))
+    xs = []
+    for t in range(T):
+        img = np.zeros((Nf, Nf))
+        img[30 + 2 * t:70 + 2 * t, 20:90] = 1.0
+        img[80:110, 10 + 4 * t:40 + 4 * t] = 0.5
+        xs.append(img.reshape(-1))
+    x_true = np.concatenate(xs)
+    sino = np.asarray(A @ x_true).reshape(mm, nn, order="F")
+    here = os.getcwd()
+    with tempfile.TemporaryDirectory() as d:
+        os.makedirs(os.path.join(d, "data", "crossphantom_data"))
+        spio.savemat(os.path.join(d, "data", "crossphantom_data", "DataDynamic_128x15.mat"), {"A": A, "sinogram": sino})
+        os.chdir(d)
+        # (scipy.io.loadmat of SciPy >= 1.15 hands a MATLAB sparse matrix over as COO, which cannot be indexed: the loader's
+        #  `A[ind, :]` (:209) was written against the CSC that older SciPy returned — restored here, nothing else touched)
+        real_loadmat = rio.spio.loadmat
+
+        def loadmat_csc(*a, **k):
+            f = real_loadmat(*a, **k)
+            return {key: (_sps.csc_matrix(v) if _sps.issparse(v) else v) for key, v in f.items()}
+        rio.spio.loadmat = loadmat_csc
+        try:
+            F, b, Aseq, B, nx, ny, nt = quiet(rio.generate_crossPhantom, 15)
+        finally:
+            rio.spio.loadmat = real_loadmat
+            os.chdir(here)
+    F = _sps.csr_matrix(F)
+    F.sum_duplicates()
+    F.sort_indices()
+    assert (nx, ny, nt) == (Nf, Nf, T) and F.shape == (T * 700, T * npix) and len(Aseq) == T
+    xr, yr = sparse_dynamic_vectors(T * npix, T * 700)
+    blk_fwd = np.concatenate([np.asarray(Aseq[t] @ xr[t * npix:(t + 1) * npix]).reshape(-1) for t in range(T)])
+    blk_adj = np.concatenate([np.asarray(Aseq[t].T @ yr[t * 700:(t + 1) * 700]).reshape(-1) for t in range(T)])
+    out = dict(T=T, N=Nf, rows_per_frame=700, F_data=F.data.astype(np.float32), F_indices=F.indices.astype(np.int32),
+               F_indptr=F.indptr.astype(np.int32), F_shape=np.array(F.shape), b=np.asarray(b).reshape(-1),
+               B_concat=np.concatenate([np.asarray(v).reshape(-1) for v in B]), block_nnz=np.array([a.nnz for a in Aseq]),
+               blk_fwd=blk_fwd, blk_adj_s=blk_adj[::37], F_fwd=np.asarray(F @ xr).reshape(-1), F_adj_s=np.asarray(F.T @ yr).reshape(-1)[::37])
+    # the solvers on what the loader returned
+    bv = np.asarray(b).reshape(-1, 1)
+    x, info = quiet(Hybrid_LSQR, F, bv, 10, 1e-2)
+    out.update(lsqr_x_s=np.asarray(x).reshape(-1)[::16], lsqr_x_norm=np.linalg.norm(x), lsqr_its=info["its"])
+    x, info = quiet(CGLS, F, bv, np.zeros((T * npix, 1)), 12, 0)
+    out.update(cgls_x_s=np.asarray(x).reshape(-1)[::16], cgls_x_norm=np.linalg.norm(x), cgls_relResidual=info["relResidual"])
+    tf = 5
+    L2 = refops.gen_first_derivative_operator_2D(Nf, Nf)
+    x, info = quiet(MMGKS, Aseq[tf], np.asarray(B[tf]).reshape(-1, 1), L2, 2, 1, 1, 6, 1e-2, None, epsilon=0.1)
+    out.update(frame=tf, mmgks_frame_x=np.asarray(x).reshape(-1), mmgks_frame_Residual=info["Residual"])
+    Lst = refops.gen_spacetime_derivative_operator(Nf, Nf, T)
+    x, info = quiet(GKS, F, bv, Lst, 2, 4, 1e-2, None)
+    out.update(gks_x_s=np.asarray(x).reshape(-1)[::16], gks_x_norm=np.linalg.norm(x), gks_Residual=info["Residual"])
+    save("sparse_dynamic_crossphantom_like", **out)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:                      # python tools/make_goldens.py g5b_isotv [...]: only the named families
         for name in sys.argv[1:]:
@@ -499,4 +588,5 @@ if __name__ == "__main__":
     g7_regparam()
     g7b_dp_corners()
     g8_deblur1d()
+    g9_sparse_dynamic()
     print("done ->", OUT)

@@ -1,13 +1,21 @@
 // spmv.hip — general sparse operator (CSR SpMV), for operators given as matrices: the reference builds its
 // regularisers as scipy.sparse matrices (trips/utilities/operators.py:24-45 derivative operators, :50-113 framelet
-// analysis operators) and the real-data dynamic problems ship a precomputed sparse forward matrix sliced into per-frame
-// blocks (trips/utilities/io.py:132-135,197-229).  y = A x uses the CSR of A; y = A^T x uses the CSR of A^T (built once
-// by the host) — both directions are gathers (no atomics).
-//   * short rows (derivative / framelet rows: 2..9 non-zeros): one thread per row;
-//   * long rows  (tomography rays: ~N non-zeros): one wave per row, lanes stride the row's non-zeros (coalesced value /
-//     index loads), wave64 shuffle reduction.
-// fp32 values and vectors, fp64 row accumulation.  HBM-bound: 8 bytes per non-zero (value + column index) + the gathers of x.
+// analysis operators) and the real-data dynamic problems ship a precomputed sparse forward matrix, used whole (F) and sliced
+// into per-frame blocks (trips/utilities/io.py:132-135,197-229; demos/2_demo_dynamic_CrossPhantom.ipynb).  y = A x uses the CSR
+// of A; y = A^T x uses the CSR of A^T (built once by the host) — both directions are gathers (no atomics).
+//
+// One kernel, k_csr_group<G>: a GROUP of G = 2 .. 64 neighbouring lanes owns a row (G = the power of two at or above the mean row
+// length: 2 for first-difference rows, 8 for framelet rows, 64 for tomography rays), the wave's 64 / G groups own neighbouring
+// rows — so the wave's loads of `vals` and `indices` are contiguous runs whatever the row length (round 4's one-thread-per-row
+// kernel read rows of 2 .. 9 non-zeros with a stride of the row length across lanes) — every lane keeps two fp32 FMA chains,
+// and float64 appears only in the reduction across the group (round 4: a float64 FMA per non-zero).  Row pointers are 32-bit on
+// the device (nnz < 2^31): 4 bytes per row next to the 8 per non-zero.
+// HBM-bound: 8 bytes per non-zero (value + column index) + 4 (m + n) for the vectors + 4 m row pointers; the gathers of x hit L2
+// (a 256^2 frame is 256 KB).  Measured: profiles/r05/spmv.txt, DESIGN.md section 4.
 #include "trk_internal.h"
+
+#include <cstdlib>
+#include <vector>
 
 using namespace trk;
 
@@ -17,52 +25,40 @@ constexpr int NT = 256;
 
 struct Csr {
   int64_t nrows, ncols, nnz;
-  int64_t* indptr;
+  unsigned* indptr;      // nrows + 1 row pointers
   int* indices;
   float* vals;
-  bool long_rows;
+  int group;             // lanes per row
 };
 
 struct SpImpl {
   Csr a, at;
 };
 
-template <bool SUMSQ>
-__global__ __launch_bounds__(NT) void k_csr_thread(int64_t nrows, const int64_t* __restrict__ indptr,
-                                                   const int* __restrict__ indices, const float* __restrict__ vals,
-                                                   const float* __restrict__ x, float* __restrict__ y,
-                                                   double* __restrict__ partials) {
+template <int G, bool SUMSQ>
+__global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned* __restrict__ indptr,
+                                                  const int* __restrict__ indices, const float* __restrict__ vals,
+                                                  const float* __restrict__ x, float* __restrict__ y,
+                                                  double* __restrict__ partials) {
   __shared__ double red[NT / 64];
+  const int g = threadIdx.x & (G - 1);
+  const int64_t grp0 = ((int64_t)blockIdx.x * NT + threadIdx.x) / G, ngrp = (int64_t)gridDim.x * (NT / G);
   double ss = 0.0;
-  for (int64_t r = (int64_t)blockIdx.x * NT + threadIdx.x; r < nrows; r += (int64_t)gridDim.x * NT) {
-    const int64_t p0 = indptr[r], p1 = indptr[r + 1];
-    double acc = 0.0;
-    for (int64_t p = p0; p < p1; ++p) acc = fma((double)vals[p], (double)x[indices[p]], acc);
-    const float o = (float)acc;
-    y[r] = o;
-    if (SUMSQ) ss += (double)o * o;
-  }
-  if (SUMSQ) {
-    ss = block_sum<NT>(ss, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = ss;
-  }
-}
-
-template <bool SUMSQ>
-__global__ __launch_bounds__(NT) void k_csr_wave(int64_t nrows, const int64_t* __restrict__ indptr,
-                                                 const int* __restrict__ indices, const float* __restrict__ vals,
-                                                 const float* __restrict__ x, float* __restrict__ y,
-                                                 double* __restrict__ partials) {
-  __shared__ double red[NT / 64];
-  const int lane = threadIdx.x & 63;
-  const int64_t wave0 = ((int64_t)blockIdx.x * NT + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * NT) >> 6;
-  double ss = 0.0;
-  for (int64_t r = wave0; r < nrows; r += nwaves) {
-    const int64_t p0 = indptr[r], p1 = indptr[r + 1];
-    double acc = 0.0;
-    for (int64_t p = p0 + lane; p < p1; p += 64) acc = fma((double)vals[p], (double)x[indices[p]], acc);
-    acc = wave_sum(acc);
-    if (lane == 0) {
+  for (int64_t r = grp0; r < nrows; r += ngrp) {
+    const unsigned p0 = indptr[r], p1 = indptr[r + 1];
+    float a0 = 0.f, a1 = 0.f;
+    unsigned p = p0 + g;
+    for (; p + G < p1; p += 2 * G) {                 // two loads of each stream in flight per lane, two independent chains
+      const float v0 = vals[p], v1 = vals[p + G];
+      const int c0 = indices[p], c1 = indices[p + G];
+      a0 = fmaf(v0, x[c0], a0);
+      a1 = fmaf(v1, x[c1], a1);
+    }
+    if (p < p1) a0 = fmaf(vals[p], x[indices[p]], a0);
+    double acc = (double)a0 + (double)a1;
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (g == 0) {
       const float o = (float)acc;
       y[r] = o;
       if (SUMSQ) ss += (double)o * o;
@@ -74,12 +70,20 @@ __global__ __launch_bounds__(NT) void k_csr_wave(int64_t nrows, const int64_t* _
   }
 }
 
+template <int G>
+void launch_group(const Csr& M, int grid, const float* xb, float* yb, double* pb, hipStream_t s) {
+  if (pb) hipLaunchKernelGGL((k_csr_group<G, true>), dim3(grid), dim3(NT), 0, s, M.nrows, M.indptr, M.indices, M.vals, xb, yb, pb);
+  else hipLaunchKernelGGL((k_csr_group<G, false>), dim3(grid), dim3(NT), 0, s, M.nrows, M.indptr, M.indices, M.vals, xb, yb, pb);
+}
+
 int sp_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
              hipStream_t s) {
   auto* im = static_cast<SpImpl*>(op->impl);
   const Csr& M = tr ? im->at : im->a;
-  int64_t want = M.long_rows ? (M.nrows + 3) / 4 : (M.nrows + NT - 1) / NT;
-  if (want > kMaxPartialBlocks) want = kMaxPartialBlocks;
+  // one pass of groups over the rows where that fits the grid cap, grid-stride beyond (a reduction leaves <= kMaxPartialBlocks partials)
+  int64_t want = (M.nrows * M.group + NT - 1) / NT;
+  const int64_t cap = sumsq ? kMaxPartialBlocks : (int64_t)cu_count() * 16;
+  if (want > cap) want = cap;
   const int grid = (int)(want < 1 ? 1 : want);
   double* part = nullptr;
   if (sumsq)
@@ -89,10 +93,14 @@ int sp_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t 
     const float* xb = x + (int64_t)b * ldx;
     float* yb = y + (int64_t)b * ldy;
     double* pb = part ? part + (size_t)b * grid : nullptr;
-#define SP(K, SS) hipLaunchKernelGGL((K<SS>), dim3(grid), dim3(NT), 0, s, M.nrows, M.indptr, M.indices, M.vals, xb, yb, pb)
-    if (M.long_rows) { if (sumsq) SP(k_csr_wave, true); else SP(k_csr_wave, false); }
-    else             { if (sumsq) SP(k_csr_thread, true); else SP(k_csr_thread, false); }
-#undef SP
+    switch (M.group) {
+      case 2: launch_group<2>(M, grid, xb, yb, pb, s); break;
+      case 4: launch_group<4>(M, grid, xb, yb, pb, s); break;
+      case 8: launch_group<8>(M, grid, xb, yb, pb, s); break;
+      case 16: launch_group<16>(M, grid, xb, yb, pb, s); break;
+      case 32: launch_group<32>(M, grid, xb, yb, pb, s); break;
+      default: launch_group<64>(M, grid, xb, yb, pb, s); break;
+    }
   }
   tm.stop();
   TRK_LAUNCH_CHECK();
@@ -115,11 +123,26 @@ void sp_destroy(trk_op* op) {
 
 int csr_upload(Csr& c, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* indptr, const int* indices,
                const float* vals) {
-  c = Csr{nrows, ncols, nnz, nullptr, nullptr, nullptr, nnz > 16 * nrows};
-  TRK_HIP(hipMalloc(&c.indptr, sizeof(int64_t) * (size_t)(nrows + 1)));
+  // lanes per row: the power of two at or above the mean row length, 2 .. 64 (TRK_CSR_GROUP overrides: tuning)
+  int group = 2;
+  while (group < 64 && (int64_t)group * nrows < nnz) group *= 2;
+  if (const char* e = getenv("TRK_CSR_GROUP")) {
+    const int v = atoi(e);
+    if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) group = v;
+  }
+  c = Csr{nrows, ncols, nnz, nullptr, nullptr, nullptr, group};
+  std::vector<unsigned> ip32((size_t)nrows + 1);
+  for (int64_t r = 0; r <= nrows; ++r) {
+    if (indptr[r] < 0 || indptr[r] > nnz || (r > 0 && indptr[r] < indptr[r - 1]))
+      return fail(TRK_EINVAL, "trk_csr_create: row pointers must be non-decreasing inside [0, nnz]");
+    ip32[(size_t)r] = (unsigned)indptr[r];
+  }
+  for (int64_t p = 0; p < nnz; ++p)
+    if (indices[p] < 0 || indices[p] >= ncols) return fail(TRK_EINVAL, "trk_csr_create: column index %d outside [0, %lld)", indices[p], (long long)ncols);
+  TRK_HIP(hipMalloc(&c.indptr, sizeof(unsigned) * (size_t)(nrows + 1)));
   TRK_HIP(hipMalloc(&c.indices, sizeof(int) * (size_t)(nnz > 0 ? nnz : 1)));
   TRK_HIP(hipMalloc(&c.vals, sizeof(float) * (size_t)(nnz > 0 ? nnz : 1)));
-  TRK_HIP(hipMemcpy(c.indptr, indptr, sizeof(int64_t) * (size_t)(nrows + 1), hipMemcpyHostToDevice));
+  TRK_HIP(hipMemcpy(c.indptr, ip32.data(), sizeof(unsigned) * (size_t)(nrows + 1), hipMemcpyHostToDevice));
   if (nnz > 0) {
     TRK_HIP(hipMemcpy(c.indices, indices, sizeof(int) * (size_t)nnz, hipMemcpyHostToDevice));
     TRK_HIP(hipMemcpy(c.vals, vals, sizeof(float) * (size_t)nnz, hipMemcpyHostToDevice));
@@ -133,8 +156,8 @@ extern "C" int trk_csr_create(int64_t nrows, int64_t ncols, int64_t nnz, const i
                               const float* values_host, const int64_t* t_indptr_host, const int* t_indices_host,
                               const float* t_values_host, trk_op** out) {
   TRK_REQUIRE(out && indptr_host && t_indptr_host, "trk_csr_create: NULL argument");
-  TRK_REQUIRE(nrows >= 1 && ncols >= 1 && nnz >= 0 && ncols < ((int64_t)1 << 31) && nrows < ((int64_t)1 << 31),
-              "trk_csr_create: bad sizes");
+  TRK_REQUIRE(nrows >= 1 && ncols >= 1 && nnz >= 0 && ncols < ((int64_t)1 << 31) && nrows < ((int64_t)1 << 31) && nnz < ((int64_t)1 << 31),
+              "trk_csr_create: bad sizes (rows, columns and non-zeros must each be below 2^31)");
   TRK_REQUIRE(nnz == 0 || (indices_host && values_host && t_indices_host && t_values_host), "trk_csr_create: NULL arrays");
   TRK_REQUIRE(indptr_host[nrows] == nnz && t_indptr_host[ncols] == nnz, "trk_csr_create: indptr does not end at nnz");
   auto* im = new SpImpl{};

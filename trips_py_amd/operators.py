@@ -432,7 +432,14 @@ class BlockDiagOp(_HandleOperator):
         first = self.ops[0]
         same_radon = all(isinstance(o, Radon2DParallel) and o.N == first.N and o.n_det == first.n_det
                          and o.scale == first.scale and len(o.angles) == len(first.angles) for o in self.ops)
-        if same_radon and len(self.ops) > 1:
+        if len(self.ops) > 1 and all(type(o) is SparseOp for o in self.ops):
+            # frames given as sparse matrices (the blocks io.py:223-225 cuts out of the real data's forward matrix): ONE CSR of the
+            # block-diagonal matrix, one launch per apply whatever the number of frames
+            import scipy.sparse as sp
+            merged = SparseOp(sp.block_diag([o.matrix for o in self.ops], format="csr"), engine=engine)
+            self.matrix = merged.matrix
+            h, merged._h = merged._h, None
+        elif same_radon and len(self.ops) > 1:
             # frames of one dynamic tomography problem: a single handle runs all frames per launch
             ang = np.concatenate([o.angles for o in self.ops])
             arr, p = _dbl_array(ang)
@@ -468,6 +475,44 @@ class SparseOp(_HandleOperator):
         _lib.check(engine.lib.trk_csr_create(A.shape[0], A.shape[1], A.nnz, ip.ctypes.data, ix.ctypes.data, dv.ctypes.data,
                                              tp.ctypes.data, tx.ctypes.data, tv.ctypes.data, ctypes.byref(h)), "trk_csr_create")
         super().__init__(h, engine)
+
+
+def slice_dynamic_frames(A, b, nt, rows_per_frame, cols_per_frame):
+    """The per-frame blocks of a dynamic problem's forward matrix and data, exactly as the reference's loaders cut them
+    (trips/utilities/io.py:223-225, generate_crossPhantom: `AA[ii] = A_small[700*ii:700*(ii+1), 16384*ii:16384*(ii+1)]`,
+    `B[ii] = b[700*ii:700*(ii+1)]`; io.py:160-162 does the same for the emoji data): frame ii owns rows
+    [ii rows_per_frame, (ii+1) rows_per_frame) and columns [ii cols_per_frame, (ii+1) cols_per_frame); whatever the matrix
+    holds outside those blocks is dropped.  Returns (list of scipy.sparse CSR blocks, list of data blocks)."""
+    import scipy.sparse as sp
+    A = sp.csr_matrix(A)
+    nt, rpf, cpf = int(nt), int(rows_per_frame), int(cols_per_frame)
+    if A.shape[0] < nt * rpf or A.shape[1] < nt * cpf:
+        raise ValueError(f"slice_dynamic_frames: a {A.shape[0]} x {A.shape[1]} matrix has no {nt} blocks of {rpf} x {cpf}")
+    bb = None if b is None else np.asarray(b).reshape(-1)
+    AA = [A[rpf * ii:rpf * (ii + 1), cpf * ii:cpf * (ii + 1)].tocsr() for ii in range(nt)]
+    B = None if bb is None else [bb[rpf * ii:rpf * (ii + 1)] for ii in range(nt)]
+    return AA, B
+
+
+class SparseBlockDiag(SparseOp):
+    """F = blkdiag(A_0 .. A_{T-1}) of sparse frame matrices as ONE CSR operator on the device: x and b frame-major, one launch per
+    apply (pylops.BlockDiag over per-frame matrices, io.py:420, for the sparse real-data problems of io.py:197-229).  On several
+    ranks every rank holds the blocks of its own frames (dist.frame_range)."""
+
+    def __init__(self, blocks, engine=None):
+        import scipy.sparse as sp
+        self.blocks = [sp.csr_matrix(B) for B in blocks]
+        super().__init__(sp.block_diag(self.blocks, format="csr"), engine=engine)
+
+    @classmethod
+    def from_matrix(cls, A, nt, rows_per_frame, cols_per_frame, engine=None):
+        """From the whole forward matrix, sliced as the reference slices it (slice_dynamic_frames); with engine.world > 1 only this
+        rank's frames are kept."""
+        from .dist import frame_range
+        engine = engine if engine is not None else default_engine()
+        AA, _ = slice_dynamic_frames(A, None, nt, rows_per_frame, cols_per_frame)
+        lo, hi = frame_range(int(nt), getattr(engine, "world", 1), getattr(engine, "rank", 0))
+        return cls(AA[lo:hi], engine=engine)
 
 
 def create_framelet_operator(n, m, l, engine=None):
