@@ -463,8 +463,12 @@ def test_fanbeam_invariants_and_problem_class():
     assert relerr(A_mis @ disc.reshape(-1), sd.reshape(-1)) < 1e-4
     Ac, Ac2 = Tomography(CommitCrime=True).forward_Op(N, N, views)
     assert Ac.shape == A.shape and Ac2 is Ac
-    # the demos' data helpers (Tomography.py:153-168, 203-227)
-    T = Tomography(CommitCrime=False)
+    # the demos' data helpers (Tomography.py:153-168, 203-227): tools/demo_helpers.py, outside the package
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from demo_helpers import demo_classes
+    T = demo_classes()[2](CommitCrime=False)
     xr = rng.random(N * N)
     Aop, b, p, q, Amat = T.gen_data(xr, N, N, views)
     assert b.shape == (A.shape[0], 1) and (p, q) == (views, A.shape[0] // views) and Amat is Aop

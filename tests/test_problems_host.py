@@ -1,8 +1,17 @@
-"""Host-side data helpers of trips_py_amd.problems (the demos' gen_data / add_noise, Deblurring2D.py:123-159): no GPU."""
+"""The demos' host-side data helpers (gen_data / add_noise, Deblurring2D.py:123-159) — tools/demo_helpers.py, outside the package and
+outside the hot-path scope — still follow the reference's recipes: no GPU."""
+import os
+import sys
+import types
+
 import numpy as np
 from scipy.ndimage import convolve
 
-from trips_py_amd import problems as P
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+from demo_helpers import demo_classes  # noqa: E402
+
+_D1, _D2, _T = demo_classes()
+P = types.SimpleNamespace(Deblurring1D=_D1, Deblurring2D=_D2, Tomography=_T)
 
 
 def test_gen_data_and_add_noise_follow_the_reference_recipe():

@@ -1,16 +1,25 @@
-"""Demo conveniences — OUT OF THE HOT-PATH SCOPE.
+"""Demo conveniences — OUT OF THE HOT-PATH SCOPE, and since round 5 OUT OF THE PACKAGE (tools/).
 
 Host-side, one-time data preparation of the reference's demo classes (test signals, blurred data on a padded canvas, unseeded
 noise: trips/test_problems/Deblurring1D.py:104-216, Deblurring2D.py:123-159, Tomography.py:153-227), restated so that a notebook
 keeps running when `trips_py_amd.problems.{Deblurring1D, Deblurring2D, Tomography}` replace the reference's classes.  Not GPU
 code, not benchmarked, not part of the parity claims of the path; the engine, the solvers and bench.py never import anything from
-here (they use the seeded `problems.synthetic_image` / `problems.add_noise`).  Mixins: the classes in problems.py inherit them.
+here (they use the seeded `problems.synthetic_image` / `problems.add_noise`).  Mixins: `demo_classes()` below combines them with the
+operator-constructor classes of trips_py_amd.problems for a notebook that wants the reference's whole class surface:
+
+    sys.path.insert(0, "<repo>/tools"); from demo_helpers import demo_classes
+    Deblurring1D, Deblurring2D, Tomography = demo_classes()
 """
+import os
+import sys
+
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def _gauss_psf(dim, spread):
-    from .problems import gauss_psf
+    from trips_py_amd.problems import gauss_psf
     return gauss_psf(dim, spread)
 
 
@@ -138,3 +147,19 @@ class TomographyData:
             sig = noise_level * np.linalg.norm(b_true) / np.linalg.norm(e)
             b_meas, delta = b_true + sig * e, np.linalg.norm(sig * e)
         return np.asarray(b_meas).reshape((self.p, self.q)), delta
+
+
+def demo_classes():
+    """(Deblurring1D, Deblurring2D, Tomography): trips_py_amd.problems' operator constructors + the demo data helpers above."""
+    from trips_py_amd import problems as P
+
+    class Deblurring1D(P.Deblurring1D, Deblurring1DData):
+        pass
+
+    class Deblurring2D(P.Deblurring2D, Deblurring2DData):
+        pass
+
+    class Tomography(P.Tomography, TomographyData):
+        pass
+
+    return Deblurring1D, Deblurring2D, Tomography

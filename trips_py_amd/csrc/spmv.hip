@@ -4,10 +4,10 @@
 // into per-frame blocks (trips/utilities/io.py:132-135,197-229; demos/2_demo_dynamic_CrossPhantom.ipynb).  y = A x uses the CSR
 // of A; y = A^T x uses the CSR of A^T (built once by the host) — both directions are gathers (no atomics).
 //
-// One kernel, k_csr_group<G>: a GROUP of G = 2 .. 64 neighbouring lanes owns a row (G = the power of two at or above the mean row
+// One kernel, k_csr_group<G>: a GROUP of G = 2 .. 64 neighbouring lanes owns a row (G = the largest power of two not above the mean row
 // length: 2 for first-difference rows, 8 for framelet rows, 64 for tomography rays), the wave's 64 / G groups own neighbouring
 // rows — so the wave's loads of `vals` and `indices` are contiguous runs whatever the row length (round 4's one-thread-per-row
-// kernel read rows of 2 .. 9 non-zeros with a stride of the row length across lanes) — every lane keeps two fp32 FMA chains,
+// kernel read rows of 2 .. 9 non-zeros with a stride of the row length across lanes) — every lane keeps four fp32 FMA chains,
 // and float64 appears only in the reduction across the group (round 4: a float64 FMA per non-zero).  Row pointers are 32-bit on
 // the device (nnz < 2^31): 4 bytes per row next to the 8 per non-zero.
 // HBM-bound: 8 bytes per non-zero (value + column index) + 4 (m + n) for the vectors + 4 m row pointers; the gathers of x hit L2
@@ -35,7 +35,12 @@ struct SpImpl {
   Csr a, at;
 };
 
-template <int G, bool SUMSQ>
+// the matrix is streamed once per apply (nothing of it is re-read): non-temporal loads keep it from evicting x, the one operand
+// the gathers want cached
+template <bool NTL> __device__ __forceinline__ float ldm(const float* p) { return NTL ? __builtin_nontemporal_load(p) : *p; }
+template <bool NTL> __device__ __forceinline__ int ldm(const int* p) { return NTL ? __builtin_nontemporal_load(p) : *p; }
+
+template <int G, bool SUMSQ, bool NTL>
 __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned* __restrict__ indptr,
                                                   const int* __restrict__ indices, const float* __restrict__ vals,
                                                   const float* __restrict__ x, float* __restrict__ y,
@@ -46,16 +51,27 @@ __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned*
   double ss = 0.0;
   for (int64_t r = grp0; r < nrows; r += ngrp) {
     const unsigned p0 = indptr[r], p1 = indptr[r + 1];
-    float a0 = 0.f, a1 = 0.f;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
     unsigned p = p0 + g;
-    for (; p + G < p1; p += 2 * G) {                 // two loads of each stream in flight per lane, two independent chains
-      const float v0 = vals[p], v1 = vals[p + G];
-      const int c0 = indices[p], c1 = indices[p + G];
+    // four loads of each stream in flight per lane, four independent fp32 chains (long rows: a wave streams 2 KB per trip)
+    for (; p + 3 * G < p1; p += 4 * G) {
+      const float v0 = ldm<NTL>(vals + p), v1 = ldm<NTL>(vals + p + G), v2 = ldm<NTL>(vals + p + 2 * G), v3 = ldm<NTL>(vals + p + 3 * G);
+      const int c0 = ldm<NTL>(indices + p), c1 = ldm<NTL>(indices + p + G), c2 = ldm<NTL>(indices + p + 2 * G), c3 = ldm<NTL>(indices + p + 3 * G);
       a0 = fmaf(v0, x[c0], a0);
       a1 = fmaf(v1, x[c1], a1);
+      a2 = fmaf(v2, x[c2], a2);
+      a3 = fmaf(v3, x[c3], a3);
     }
-    if (p < p1) a0 = fmaf(vals[p], x[indices[p]], a0);
-    double acc = (double)a0 + (double)a1;
+    // up to three more, issued together (predicated: a row's tail, or the whole of a short row)
+    {
+      const bool h0 = p < p1, h1 = p + G < p1, h2 = p + 2 * G < p1;
+      const float v0 = h0 ? ldm<NTL>(vals + p) : 0.f, v1 = h1 ? ldm<NTL>(vals + p + G) : 0.f, v2 = h2 ? ldm<NTL>(vals + p + 2 * G) : 0.f;
+      const int c0 = h0 ? ldm<NTL>(indices + p) : 0, c1 = h1 ? ldm<NTL>(indices + p + G) : 0, c2 = h2 ? ldm<NTL>(indices + p + 2 * G) : 0;
+      a0 = fmaf(v0, h0 ? x[c0] : 0.f, a0);
+      a1 = fmaf(v1, h1 ? x[c1] : 0.f, a1);
+      a2 = fmaf(v2, h2 ? x[c2] : 0.f, a2);
+    }
+    double acc = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
 #pragma unroll
     for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (g == 0) {
@@ -72,17 +88,23 @@ __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned*
 
 template <int G>
 void launch_group(const Csr& M, int grid, const float* xb, float* yb, double* pb, hipStream_t s) {
-  if (pb) hipLaunchKernelGGL((k_csr_group<G, true>), dim3(grid), dim3(NT), 0, s, M.nrows, M.indptr, M.indices, M.vals, xb, yb, pb);
-  else hipLaunchKernelGGL((k_csr_group<G, false>), dim3(grid), dim3(NT), 0, s, M.nrows, M.indptr, M.indices, M.vals, xb, yb, pb);
+  static const bool ntl = getenv("TRK_CSR_NT") && atoi(getenv("TRK_CSR_NT")) != 0;
+#define CG(SS, NN) hipLaunchKernelGGL((k_csr_group<G, SS, NN>), dim3(grid), dim3(NT), 0, s, M.nrows, M.indptr, M.indices, M.vals, xb, yb, pb)
+  if (pb) { if (ntl) CG(true, true); else CG(true, false); }
+  else    { if (ntl) CG(false, true); else CG(false, false); }
+#undef CG
 }
 
 int sp_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
              hipStream_t s) {
   auto* im = static_cast<SpImpl*>(op->impl);
   const Csr& M = tr ? im->at : im->a;
-  // one pass of groups over the rows where that fits the grid cap, grid-stride beyond (a reduction leaves <= kMaxPartialBlocks partials)
+  // one group per row where that fits (every row's load chain then starts at once: a grid-stride loop over rows of ~17 non-zeros was
+  // one dependent chain of indptr -> vals / indices -> x per row and lane group, 83 us for 141 MB); a reduction keeps its partials
+  // within 8 k blocks
   int64_t want = (M.nrows * M.group + NT - 1) / NT;
-  const int64_t cap = sumsq ? kMaxPartialBlocks : (int64_t)cu_count() * 16;
+  static const int64_t cap_env = getenv("TRK_CSR_GRID_PER_CU") ? atoll(getenv("TRK_CSR_GRID_PER_CU")) * cu_count() : 0;
+  const int64_t cap = cap_env > 0 ? cap_env : (sumsq ? 8 * (int64_t)kMaxPartialBlocks : ((int64_t)1 << 22));
   if (want > cap) want = cap;
   const int grid = (int)(want < 1 ? 1 : want);
   double* part = nullptr;
@@ -123,12 +145,14 @@ void sp_destroy(trk_op* op) {
 
 int csr_upload(Csr& c, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* indptr, const int* indices,
                const float* vals) {
-  // lanes per row: the power of two at or above the mean row length, 2 .. 64 (TRK_CSR_GROUP overrides: tuning)
+  // lanes per row: the largest power of two not above the mean row length, 2 .. 64 — idle lanes cost more than a second trip
+  // (mean 16.8: 16 lanes, not 32) (TRK_CSR_GROUP overrides: tuning)
   int group = 2;
-  while (group < 64 && (int64_t)group * nrows < nnz) group *= 2;
+  while (group < 64 && (int64_t)2 * group * nrows <= nnz) group *= 2;
   if (const char* e = getenv("TRK_CSR_GROUP")) {
     const int v = atoi(e);
     if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) group = v;
+    if (v < 0 && group > 2 && -v <= 3) group = group >> (-v) < 2 ? 2 : group >> (-v);     // -1 / -2: half / quarter of the rule's choice
   }
   c = Csr{nrows, ncols, nnz, nullptr, nullptr, nullptr, group};
   std::vector<unsigned> ip32((size_t)nrows + 1);

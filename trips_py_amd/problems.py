@@ -7,13 +7,11 @@
   synthetic_image / add_noise         seeded versions of the data recipe (:141-146): what bench.py / smoke() / the tests use
 
 In scope here: the PSF and the operator constructors.  The demos' host-side data preparation — gen_xtrue,
-gen_data, the classes' unseeded add_noise (OUT OF SCOPE) — lives in trips_py_amd/demo_helpers.py and is
-only inherited, so that a demo keeps running with these classes swapped in; nothing in the engine, the solvers, the tests of the
-hot path or the bench depends on it.
+gen_data, the classes' unseeded add_noise (OUT OF SCOPE) — is not part of the package: tools/demo_helpers.py
+holds it as mixins (`demo_classes()`), for a notebook that wants the reference's whole class surface.
 """
 import numpy as np
 
-from . import demo_helpers as _demo
 from .operators import Blur1D, Blur2D, BlockDiagOp, FanBeam2D, Radon2DParallel
 
 
@@ -39,9 +37,8 @@ def gauss_psf_1d(n, sigma):
     return psf / psf.sum()
 
 
-class Deblurring2D(_demo.Deblurring2DData):
-    """Operator-constructor subset of trips.test_problems.Deblurring2D (same method names); the demos' host-side data helpers
-    (gen_data, add_noise: OUT of the hot-path scope) are inherited from trips_py_amd.demo_helpers."""
+class Deblurring2D:
+    """Operator-constructor subset of trips.test_problems.Deblurring2D (same method names)."""
 
     def __init__(self, **kwargs):
         self.nx = self.ny = None
@@ -57,9 +54,9 @@ class Deblurring2D(_demo.Deblurring2DData):
         return Blur2D(psf, nx, ny, engine=engine)
 
 
-class Deblurring1D(_demo.Deblurring1DData):
-    """trips.test_problems.Deblurring1D: the operator constructor on the engine plus the demo's host-side data helpers
-    (Deblurring1D.py:63-69, 104-143, 144-197, 199-216) — BASELINE config C1 (n = 256, 'curve0', sigma = 3)."""
+class Deblurring1D:
+    """trips.test_problems.Deblurring1D: the operator constructor on the engine (Deblurring1D.py:63-69, 93-102) — BASELINE config C1
+    (n = 256, sigma = 3)."""
 
     def __init__(self, **kwargs):
         self.grid_points = self.ny = self.parameter = self.boundary_condition = None
@@ -78,7 +75,7 @@ class Deblurring1D(_demo.Deblurring1DData):
         return Blur1D(self.PSF, nx, engine=engine)
 
 
-class Tomography(_demo.TomographyData):
+class Tomography:
     """Operator-constructor subset of trips.test_problems.Tomography (same method name and return convention)."""
 
     def __init__(self, **kwargs):

@@ -80,38 +80,25 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             hy = (Hh[:k + 1, :k] @ Yh[ii, :k]).reshape(-1, 1)
             res.append(float(np.linalg.norm(bhat.reshape(1, -1) - hy)))    # the reference's broadcast quirk (:80), as below
     pend = ar.step_prefetch() if (n_iter > 0 and not on_dev) else None
-    for ii in range(0 if not on_dev else n_iter, n_iter):
-        k = ii + 1
-        ar.absorb(pend)                      # column k of H; step k+1 runs while the host works on the projected problem
-        pend = ar.step_prefetch() if k < n_iter else None
-        H = ar.H()[:k + 1, :k]
+
+    def projected(k, H, first):
+        """Everything the host owes iterate k once H_k is known — lambda_k, y_k, the reference's relResidual — as a function of H_k
+        alone: the Arnoldi steps do not depend on it, so several k are worked on AT ONCE by a small thread pool (LAPACK releases
+        the interpreter lock) while the main thread keeps the device fed.  The SVD of a 61 x 60 H costs 0.45 ms on a host core,
+        0.17 ms on average over a 60-step solve, against 66 us of kernels per iteration (round 4: 5.2 k iterations/s with gcv,
+        15.2 k with a number)."""
         bhat = np.zeros(k + 1)
         bhat[0] = ar.beta0
         svd = None
-        if ii == 0:
+        if first:
             lam = 0
-        elif isinstance(regparam, str) and regparam in ("gcv", "l_curve"):
-            Qh, s, Vh = sla.svd(H, full_matrices=False)
+        elif regparam in ("gcv", "l_curve"):
+            Qh, sv, Vh = sla.svd(H, full_matrices=False, check_finite=False)
             qb = Qh.T @ bhat
-            lam = choose_lambda(regparam, np.diag(s), np.eye(k), qb, 0.0, kwargs)   # 'standard' GCV here (:58)
-            svd = (s, Vh, qb)
-        elif isinstance(regparam, str) and regparam == "dp":
-            eng.gemv_t(ar.V.data, k + 1, bv, P.ref(0))
-            eng.allreduce(P, 0, k + 1)
-            if kwargs.get("solve_by_svd", True):
-                # the SVD discrepancy_principle() takes of H (discrepancy_principle.py:68-70), taken here so that the Tikhonov
-                # solve below can share it
-                from ..reg_param.discrepancy_principle import discrepancy_principle
-                Uf, s, Vh = sla.svd(H)
-                extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
-                lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
-                                            spectrum=(s, Uf.T @ P.host(0, k + 1).reshape(-1, 1), (k + 1, k)), **extra)
-                svd = (s, Vh, Uf[:, :k].T @ bhat)
-            else:
-                lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=H, dp_bproj=P.host(0, k + 1))
+            lam = choose_lambda(regparam, np.diag(sv), np.eye(k), qb, 0.0, kwargs)   # 'standard' GCV here (:58)
+            svd = (sv, Vh, qb)
         else:
             lam = regparam
-        lams.append(lam)
         if svd is not None and lam > 0 and kwargs.get("solve_by_svd", True):
             # the Tikhonov minimiser of (:76) from the SVD the selector needed anyway: y = V diag(s / (s^2 + lam)) U^T bhat — O(k^2)
             # where the stacked least-squares problem is another O(k^3) factorisation per iteration
@@ -119,6 +106,15 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             y = Vh.T @ ((sv / (sv * sv + lam)) * qb)
         else:
             y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
+        # reference quirk (:80): `bhat - H@y` broadcasts a (k+1,) against a (k+1,1) -> Frobenius norm of a matrix
+        hy = (H @ y).reshape(-1, 1)
+        return lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy))
+
+    def form(ii, lam, y, r):
+        nonlocal n_ep, x_dev
+        k = ii + 1
+        lams.append(lam)
+        res.append(r)
         Y.set(0, y)
         x_dev = Hs.row(ii)
         if err_fused:
@@ -126,11 +122,65 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
         else:
             eng.gemv_n(ar.V.data, k, Y.ref(0), x_dev)                  # x = V[:, :-1] @ y (:77)
         Hs.pushed(ii)
-        # reference quirk (:80): `bhat - H@y` broadcasts a (k+1,) against a (k+1,1) -> Frobenius norm of a matrix
-        hy = (H @ y).reshape(-1, 1)
-        res.append(float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
         if xt is not None and not err_fused:
             eng.diff_nrm2sq(x_dev, xt, E.ref(ii + 1))
+
+    is_dp = isinstance(regparam, str) and regparam == "dp"
+    workers = int(kwargs.get("host_workers", 4)) if (isinstance(regparam, str) and not is_dp and not on_dev) else 0
+    pool, inflight = None, []
+    if workers > 1 and n_iter > 2:
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(max_workers=workers)
+    try:
+        for ii in range(0 if not on_dev else n_iter, n_iter):
+            k = ii + 1
+            ar.absorb(pend)                      # column k of H; step k+1 runs while the host works on the projected problem
+            pend = ar.step_prefetch() if k < n_iter else None
+            H = ar.H()[:k + 1, :k]
+            if is_dp:
+                bhat = np.zeros(k + 1)
+                bhat[0] = ar.beta0
+                svd = None
+                if ii == 0:
+                    lam = 0
+                else:
+                    eng.gemv_t(ar.V.data, k + 1, bv, P.ref(0))
+                    eng.allreduce(P, 0, k + 1)
+                    if kwargs.get("solve_by_svd", True):
+                        # the SVD discrepancy_principle() takes of H (discrepancy_principle.py:68-70), taken here so that the
+                        # Tikhonov solve below can share it
+                        from ..reg_param.discrepancy_principle import discrepancy_principle
+                        Uf, sv, Vh = sla.svd(H)
+                        extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
+                        lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
+                                                    spectrum=(sv, Uf.T @ P.host(0, k + 1).reshape(-1, 1), (k + 1, k)), **extra)
+                        svd = (sv, Vh, Uf[:, :k].T @ bhat)
+                    else:
+                        lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=H, dp_bproj=P.host(0, k + 1))
+                if svd is not None and lam > 0 and kwargs.get("solve_by_svd", True):
+                    sv, Vh, qb = svd
+                    y = Vh.T @ ((sv / (sv * sv + lam)) * qb)
+                else:
+                    y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
+                hy = (H @ y).reshape(-1, 1)
+                form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
+                continue
+            if pool is None:
+                form(ii, *projected(k, H, ii == 0))
+                continue
+            inflight.append((ii, pool.submit(projected, k, np.array(H, copy=True), ii == 0)))
+            # iterates are formed in order, as soon as their lambda is there; the host never runs more than `workers` steps ahead
+            while inflight and (inflight[0][1].done() or len(inflight) > workers):
+                j, fut = inflight.pop(0)
+                form(j, *fut.result())
+        for j, fut in inflight:
+            form(j, *fut.result())
+        inflight = []
+    finally:
+        if pool is not None:
+            pool.shutdown(wait=True, cancel_futures=True)
+    if lams:
+        lam = lams[-1]
     if x_dev is None:
         raise UnboundLocalError("Hybrid_GMRES with n_iter < 1 forms no iterate")
     info = {"xHistory": Hs.collect(fmt, n_iter), "regParam": lam, "regParam_history": lams,
