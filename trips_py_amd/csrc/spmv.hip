@@ -4,8 +4,8 @@
 // into per-frame blocks (trips/utilities/io.py:132-135,197-229; demos/2_demo_dynamic_CrossPhantom.ipynb).  y = A x uses the CSR
 // of A; y = A^T x uses the CSR of A^T (built once by the host) — both directions are gathers (no atomics).
 //
-// One kernel, k_csr_group<G>: a GROUP of G = 2 .. 64 neighbouring lanes owns a row (G = the largest power of two not above the mean row
-// length: 2 for first-difference rows, 8 for framelet rows, 64 for tomography rays), the wave's 64 / G groups own neighbouring
+// One kernel, k_csr_group<G>: a GROUP of G = 2 .. 64 neighbouring lanes owns a row (G = the largest power of two not above a quarter of the
+// mean row length, 2 .. 16: 2 for first-difference and framelet rows, 16 for tomography rays), the wave's 64 / G groups own neighbouring
 // rows — so the wave's loads of `vals` and `indices` are contiguous runs whatever the row length (round 4's one-thread-per-row
 // kernel read rows of 2 .. 9 non-zeros with a stride of the row length across lanes) — every lane keeps four fp32 FMA chains,
 // and float64 appears only in the reduction across the group (round 4: a float64 FMA per non-zero).  Row pointers are 32-bit on
@@ -35,8 +35,8 @@ struct SpImpl {
   Csr a, at;
 };
 
-// the matrix is streamed once per apply (nothing of it is re-read): non-temporal loads keep it from evicting x, the one operand
-// the gathers want cached
+// (non-temporal loads of the matrix streams — nothing of them is re-read within an apply — LOSE: 38 -> 59 us on the Joseph matrix;
+//  TRK_CSR_NT=1 keeps the variant for measurements)
 template <bool NTL> __device__ __forceinline__ float ldm(const float* p) { return NTL ? __builtin_nontemporal_load(p) : *p; }
 template <bool NTL> __device__ __forceinline__ int ldm(const int* p) { return NTL ? __builtin_nontemporal_load(p) : *p; }
 
@@ -99,12 +99,12 @@ int sp_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t 
              hipStream_t s) {
   auto* im = static_cast<SpImpl*>(op->impl);
   const Csr& M = tr ? im->at : im->a;
-  // one group per row where that fits (every row's load chain then starts at once: a grid-stride loop over rows of ~17 non-zeros was
-  // one dependent chain of indptr -> vals / indices -> x per row and lane group, 83 us for 141 MB); a reduction keeps its partials
-  // within 8 k blocks
+  // groups cover the rows once up to 16 workgroups per CU, grid-stride beyond (first differences of a 2048^2 image, 8.4 M rows of 2:
+  // 55 us with one group per row, 46 with the cap; longer rows: no difference); a reduction leaves <= kMaxPartialBlocks partials
   int64_t want = (M.nrows * M.group + NT - 1) / NT;
   static const int64_t cap_env = getenv("TRK_CSR_GRID_PER_CU") ? atoll(getenv("TRK_CSR_GRID_PER_CU")) * cu_count() : 0;
-  const int64_t cap = cap_env > 0 ? cap_env : (sumsq ? 8 * (int64_t)kMaxPartialBlocks : ((int64_t)1 << 22));
+  int64_t cap = cap_env > 0 ? cap_env : (int64_t)cu_count() * 16;
+  if (sumsq && cap > kMaxPartialBlocks) cap = kMaxPartialBlocks;
   if (want > cap) want = cap;
   const int grid = (int)(want < 1 ? 1 : want);
   double* part = nullptr;
@@ -145,14 +145,17 @@ void sp_destroy(trk_op* op) {
 
 int csr_upload(Csr& c, int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* indptr, const int* indices,
                const float* vals) {
-  // lanes per row: the largest power of two not above the mean row length, 2 .. 64 — idle lanes cost more than a second trip
-  // (mean 16.8: 16 lanes, not 32) (TRK_CSR_GROUP overrides: tuning)
+  // lanes per row: the largest power of two not above a QUARTER of the mean row length, 2 .. 16.  Measured (profiles/r05/spmv.txt,
+  // us per apply): rows of 17 (Joseph transpose, 17.7 M non-zeros) 16 / 8 / 4 lanes -> 68.8 / 42.8 / 30.6; rows of 431 (Joseph)
+  // 64 / 32 / 16 -> 38.4 / 36.7 / 36.2; rows of 169 (framelet transpose) 64 / 32 / 16 -> 162 / 134 / 112; rows of 7 (framelets)
+  // 4 / 2 -> 139 / 108: many short chains per wave keep more loads in flight than one long coalesced one.
+  // TRK_CSR_GROUP=<2..64> forces it, -1 / -2 halve / quarter the rule's choice (tuning).
   int group = 2;
-  while (group < 64 && (int64_t)2 * group * nrows <= nnz) group *= 2;
+  while (group < 16 && (int64_t)8 * group * nrows <= nnz) group *= 2;
   if (const char* e = getenv("TRK_CSR_GROUP")) {
     const int v = atoi(e);
     if (v == 2 || v == 4 || v == 8 || v == 16 || v == 32 || v == 64) group = v;
-    if (v < 0 && group > 2 && -v <= 3) group = group >> (-v) < 2 ? 2 : group >> (-v);     // -1 / -2: half / quarter of the rule's choice
+    if (v < 0 && group > 2 && -v <= 3) group = group >> (-v) < 2 ? 2 : group >> (-v);
   }
   c = Csr{nrows, ncols, nnz, nullptr, nullptr, nullptr, group};
   std::vector<unsigned> ip32((size_t)nrows + 1);

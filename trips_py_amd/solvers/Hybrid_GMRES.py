@@ -83,10 +83,10 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
 
     def projected(k, H, first):
         """Everything the host owes iterate k once H_k is known — lambda_k, y_k, the reference's relResidual — as a function of H_k
-        alone: the Arnoldi steps do not depend on it, so several k are worked on AT ONCE by a small thread pool (LAPACK releases
-        the interpreter lock) while the main thread keeps the device fed.  The SVD of a 61 x 60 H costs 0.45 ms on a host core,
-        0.17 ms on average over a 60-step solve, against 66 us of kernels per iteration (round 4: 5.2 k iterations/s with gcv,
-        15.2 k with a number)."""
+        alone.  (Round 5 measured the obvious next step — several k at once on a small thread pool, LAPACK releasing the interpreter
+        lock — and it LOSES: 3.3 k iterations/s against 5.2 k on the 512^2 blur, the hand-over of the interpreter lock between the
+        pool and the enqueueing thread costs more than the SVDs overlap.  The SVD of a 61 x 60 H is 0.45 ms on a host core, 0.17 ms on
+        average over a 60-step solve, against 66 us of kernels per iteration: that is the 5.2 k with gcv against 15.4 k with a number.)"""
         bhat = np.zeros(k + 1)
         bhat[0] = ar.beta0
         svd = None
@@ -126,59 +126,40 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             eng.diff_nrm2sq(x_dev, xt, E.ref(ii + 1))
 
     is_dp = isinstance(regparam, str) and regparam == "dp"
-    workers = int(kwargs.get("host_workers", 4)) if (isinstance(regparam, str) and not is_dp and not on_dev) else 0
-    pool, inflight = None, []
-    if workers > 1 and n_iter > 2:
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(max_workers=workers)
-    try:
-        for ii in range(0 if not on_dev else n_iter, n_iter):
-            k = ii + 1
-            ar.absorb(pend)                      # column k of H; step k+1 runs while the host works on the projected problem
-            pend = ar.step_prefetch() if k < n_iter else None
-            H = ar.H()[:k + 1, :k]
-            if is_dp:
-                bhat = np.zeros(k + 1)
-                bhat[0] = ar.beta0
-                svd = None
-                if ii == 0:
-                    lam = 0
+    for ii in range(0 if not on_dev else n_iter, n_iter):
+        k = ii + 1
+        ar.absorb(pend)                      # column k of H; step k+1 runs while the host works on the projected problem
+        pend = ar.step_prefetch() if k < n_iter else None
+        H = ar.H()[:k + 1, :k]
+        if is_dp:
+            bhat = np.zeros(k + 1)
+            bhat[0] = ar.beta0
+            svd = None
+            if ii == 0:
+                lam = 0
+            else:
+                eng.gemv_t(ar.V.data, k + 1, bv, P.ref(0))
+                eng.allreduce(P, 0, k + 1)
+                if kwargs.get("solve_by_svd", True):
+                    # the SVD discrepancy_principle() takes of H (discrepancy_principle.py:68-70), taken here so that the
+                    # Tikhonov solve below can share it
+                    from ..reg_param.discrepancy_principle import discrepancy_principle
+                    Uf, sv, Vh = sla.svd(H)
+                    extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
+                    lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
+                                                spectrum=(sv, Uf.T @ P.host(0, k + 1).reshape(-1, 1), (k + 1, k)), **extra)
+                    svd = (sv, Vh, Uf[:, :k].T @ bhat)
                 else:
-                    eng.gemv_t(ar.V.data, k + 1, bv, P.ref(0))
-                    eng.allreduce(P, 0, k + 1)
-                    if kwargs.get("solve_by_svd", True):
-                        # the SVD discrepancy_principle() takes of H (discrepancy_principle.py:68-70), taken here so that the
-                        # Tikhonov solve below can share it
-                        from ..reg_param.discrepancy_principle import discrepancy_principle
-                        Uf, sv, Vh = sla.svd(H)
-                        extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
-                        lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
-                                                    spectrum=(sv, Uf.T @ P.host(0, k + 1).reshape(-1, 1), (k + 1, k)), **extra)
-                        svd = (sv, Vh, Uf[:, :k].T @ bhat)
-                    else:
-                        lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=H, dp_bproj=P.host(0, k + 1))
-                if svd is not None and lam > 0 and kwargs.get("solve_by_svd", True):
-                    sv, Vh, qb = svd
-                    y = Vh.T @ ((sv / (sv * sv + lam)) * qb)
-                else:
-                    y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
-                hy = (H @ y).reshape(-1, 1)
-                form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
-                continue
-            if pool is None:
-                form(ii, *projected(k, H, ii == 0))
-                continue
-            inflight.append((ii, pool.submit(projected, k, np.array(H, copy=True), ii == 0)))
-            # iterates are formed in order, as soon as their lambda is there; the host never runs more than `workers` steps ahead
-            while inflight and (inflight[0][1].done() or len(inflight) > workers):
-                j, fut = inflight.pop(0)
-                form(j, *fut.result())
-        for j, fut in inflight:
-            form(j, *fut.result())
-        inflight = []
-    finally:
-        if pool is not None:
-            pool.shutdown(wait=True, cancel_futures=True)
+                    lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=H, dp_bproj=P.host(0, k + 1))
+            if svd is not None and lam > 0 and kwargs.get("solve_by_svd", True):
+                sv, Vh, qb = svd
+                y = Vh.T @ ((sv / (sv * sv + lam)) * qb)
+            else:
+                y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
+            hy = (H @ y).reshape(-1, 1)
+            form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
+            continue
+        form(ii, *projected(k, H, ii == 0))
     if lams:
         lam = lams[-1]
     if x_dev is None:
