@@ -570,6 +570,17 @@ def extra_c3_tomo(world, cpu_jobs=None):
         # (tools/hybrid_selector_rates.py); the median solve beside the mean
         out[f"hybrid_lsqr{tag}_median_solve_iters_per_sec"] = round(world * 100 / max_over_ranks(float(np.median(each)), world), 1)
         out[f"hybrid_lsqr{tag}_relError_last"] = float(info["relError"][-1])
+    # the float64 INSTRUMENT beside the product (Hybrid_LSQR(..., dtype='float64'): csrc/ref64.hip — one thread per ray / per pixel,
+    # float64 arithmetic and storage; what the fast path is checked against on the hardware, not a fast path itself)
+    try:
+        Hybrid_LSQR(R, bt, 10, 1e-2, dtype="float64")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        Hybrid_LSQR(R, bt, 30, 1e-2, dtype="float64")
+        torch.cuda.synchronize()
+        out["hybrid_lsqr_float64_instrument_iters_per_sec"] = round(30 / (time.perf_counter() - t0), 1)
+    except Exception as exc:      # noqa: BLE001
+        out["hybrid_lsqr_float64_instrument_iters_per_sec"] = f"error: {exc}"[:200]
     if cpu_jobs is not None:
         bh = bt.detach().to("cpu")
         cpu_jobs.append((lambda v: out.__setitem__("cpu_baseline", v),
