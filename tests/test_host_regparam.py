@@ -253,3 +253,37 @@ def test_host_projected_solve_of_the_bidiagonal_problem(k):
             assert rc == 0
             assert np.allclose(y * (al if over else 1.0), want, rtol=1e-9, atol=1e-12 * np.abs(want).max())
     assert lib.trk_host_bidiag_tikhonov(al.ctypes.data, be.ctypes.data, k, 1.0, -1.0, 0, y.ctypes.data) != 0      # mu < 0
+
+
+def test_hessenberg_bidiagonal_form_equals_the_svd_route():
+    """Hybrid-GMRES's projected problem through reg_param/_bidiag.HessenbergBidiag (LAPACK dgebrd on [bhat | H], then the O(k) forms of
+    the Golub-Kahan path) against the SVD route of Hybrid_GMRES.py:54-77: same singular values, same GCV minimiser where the minimum
+    is interior (two evaluations of one smooth function a rounding apart: 3e-8), same Tikhonov solution to 1e-13."""
+    import scipy.linalg as sla
+    from trips_py_amd.reg_param._bidiag import HessenbergBidiag, bidiag_tikhonov_host
+    from trips_py_amd.reg_param.gcv import fminbound_gcv_bidiag
+    from trips_py_amd.solvers._common import choose_lambda
+    if not HessenbergBidiag.available():
+        pytest.skip("SciPy without the cython_lapack capsule table")
+    rng = np.random.default_rng(0)
+    for k in (1, 2, 5, 12, 30, 60):
+        H = np.triu(rng.standard_normal((k + 1, k)), -1) * np.logspace(0, -3, k)[None, :]
+        H[np.arange(1, k + 1), np.arange(k)] = np.abs(H[np.arange(1, k + 1), np.arange(k)]) + 0.1
+        beta0 = 3.7
+        bhat = np.zeros(k + 1)
+        bhat[0] = beta0
+        hb = HessenbergBidiag(H, beta0)
+        B = np.zeros((k + 1, k))
+        B[np.arange(k), np.arange(k)], B[np.arange(1, k + 1), np.arange(k)] = hb.alphas, hb.betas
+        assert abs(hb.beta0) == pytest.approx(beta0, rel=1e-15)
+        assert np.allclose(sla.svdvals(B), sla.svdvals(H), rtol=1e-12, atol=1e-14)
+        Qh, sv, Vh = sla.svd(H, full_matrices=False)
+        qb = Qh.T @ bhat
+        lam_svd = choose_lambda("gcv", np.diag(sv), np.eye(k), qb, 0.0, {})
+        lam_bd = fminbound_gcv_bidiag(hb.alphas, hb.betas, hb.beta0, k)
+        if k >= 12:                                   # interior minima (below: the objective is flat, any lambda is a minimiser)
+            assert lam_bd == pytest.approx(lam_svd, rel=1e-6)
+        for lam in (lam_svd, 1e-3, 2.0):
+            y_svd = Vh.T @ ((sv / (sv * sv + lam)) * qb)
+            y_bd = hb.back(bidiag_tikhonov_host(hb.alphas, hb.betas, hb.beta0, np.sqrt(lam)))
+            assert np.linalg.norm(y_bd - y_svd) <= 1e-12 * np.linalg.norm(y_svd)

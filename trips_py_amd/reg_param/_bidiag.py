@@ -75,3 +75,95 @@ def bidiag_svd_project(alphas, betas, row=None):
     if info.value != 0:
         raise np.linalg.LinAlgError(f"dbdsqr: info = {info.value}")
     return d[:k], u
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# Hybrid-GMRES: the projected problem  min || H y - beta0 e1 ||^2 + lam || y ||^2  (H the (k+1) x k Arnoldi Hessenberg matrix,
+# Hybrid_GMRES.py:54-77) brought to the Golub-Kahan form the LSQR path already solves without an SVD.
+# LAPACK's dgebrd on the (k+1) x (k+1) matrix M = [beta0 e1 | H]:  M = Q B P^T, B upper bidiagonal (d, e).  The first column of M is
+# a multiple of e1, so the first left reflector is the identity and Q^T (beta0 e1) = d[0] e1; P = diag(1, P') acts on H's columns only.
+# Hence  H = Q B[:, 1:] P'^T  with  B[:, 1:]  LOWER bidiagonal (k+1) x k, diagonal e[0..k), sub-diagonal d[1..k], and with y = P' z:
+#     || H y - beta0 e1 || = || B[:, 1:] z - d[0] e1 || ,   || y || = || z ||
+# — the same singular values and the same products u_i . bhat as the SVD of H gives, so GCV ('standard': fullsize k + 1,
+# Hybrid_GMRES.py:58), the discrepancy principle and the Tikhonov minimiser follow from (e, d) in O(k) per evaluation, and the one
+# O(k^3) step per iteration is the bidiagonalisation (a third of the dense SVD's cost: no vectors, no iteration).
+_gebrd = None
+
+
+def _bind_gebrd():
+    global _gebrd
+    if _gebrd is None:
+        try:
+            import scipy.linalg.cython_lapack as cl
+            api = ctypes.pythonapi
+            api.PyCapsule_GetName.restype, api.PyCapsule_GetName.argtypes = ctypes.c_char_p, [ctypes.py_object]
+            api.PyCapsule_GetPointer.restype = ctypes.c_void_p
+            api.PyCapsule_GetPointer.argtypes = [ctypes.py_object, ctypes.c_char_p]
+
+            def fn(name, *argtypes):
+                cap = cl.__pyx_capi__[name]
+                return ctypes.CFUNCTYPE(None, *argtypes)(api.PyCapsule_GetPointer(cap, api.PyCapsule_GetName(cap)))
+            # dgebrd(m, n, a, lda, d, e, tauq, taup, work, lwork, info); dormbr(vect, side, trans, m, n, k, a, lda, tau, c, ldc, work, lwork, info)
+            _gebrd = (fn("dgebrd", _INT_P, _INT_P, _DBL_P, _INT_P, _DBL_P, _DBL_P, _DBL_P, _DBL_P, _DBL_P, _INT_P, _INT_P),
+                      fn("dormbr", ctypes.c_char_p, ctypes.c_char_p, ctypes.c_char_p, _INT_P, _INT_P, _INT_P, _DBL_P, _INT_P, _DBL_P,
+                         _DBL_P, _INT_P, _DBL_P, _INT_P, _INT_P))
+        except Exception:                     # noqa: BLE001  (no capsule table in this SciPy build)
+            _gebrd = False
+    return _gebrd or None
+
+
+class HessenbergBidiag:
+    """The reduction above for one H: `.alphas`, `.betas`, `.beta0` (the Golub-Kahan triple of B[:, 1:] and Q^T bhat) and `.back(z)`
+    = P' z.  `available()` is False when SciPy's LAPACK capsule table is missing (callers keep their SVD path)."""
+
+    @staticmethod
+    def available():
+        return _bind_gebrd() is not None
+
+    def __init__(self, H, beta0):
+        gebrd, self._ormbr = _bind_gebrd()
+        H = np.asarray(H, dtype=np.float64)
+        k = H.shape[1]
+        n = k + 1
+        M = np.zeros((n, n), order="F")
+        M[0, 0] = beta0
+        M[:, 1:] = H
+        d, e, tq, tp = np.empty(n), np.empty(max(1, n - 1)), np.empty(n), np.empty(n)
+        lwork = 64 * n
+        work = np.empty(lwork)
+        ci = ctypes.c_int
+        nn, lw, info = ci(n), ci(lwork), ci(0)
+        p = lambda a: a.ctypes.data_as(_DBL_P)      # noqa: E731
+        gebrd(ctypes.byref(nn), ctypes.byref(nn), p(M), ctypes.byref(nn), p(d), p(e), p(tq), p(tp), p(work), ctypes.byref(lw),
+              ctypes.byref(info))
+        if info.value != 0:
+            raise RuntimeError(f"dgebrd failed (info = {info.value})")
+        self.k, self._M, self._tp, self._work = k, M, tp, work
+        self.alphas, self.betas, self.beta0 = e[:k].copy(), d[1:n].copy(), float(d[0])
+
+    def back(self, z):
+        """y = P' z (k-vector)."""
+        n = self.k + 1
+        c = np.zeros(n)
+        c[1:] = z
+        ci = ctypes.c_int
+        nn, one, lw, info = ci(n), ci(1), ci(self._work.size), ci(0)
+        p = lambda a: a.ctypes.data_as(_DBL_P)      # noqa: E731
+        self._ormbr(b"P", b"L", b"N", ctypes.byref(nn), ctypes.byref(one), ctypes.byref(nn), p(self._M), ctypes.byref(nn), p(self._tp),
+                    p(c), ctypes.byref(nn), p(self._work), ctypes.byref(lw), ctypes.byref(info))
+        if info.value != 0:
+            raise RuntimeError(f"dormbr failed (info = {info.value})")
+        return c[1:].copy()
+
+
+def bidiag_tikhonov_host(alphas, betas, beta0, mu):
+    """argmin || [B; mu I] z - beta0 e1 || for B lower bidiagonal (diagonal alphas, sub-diagonal betas), on the host in O(k)
+    (libtrk's trk_host_bidiag_tikhonov: Givens recurrence + back substitution; no GPU involved)."""
+    from .. import _lib
+    lib = _lib.load()
+    al = np.ascontiguousarray(alphas, dtype=np.float64)
+    be = np.ascontiguousarray(betas, dtype=np.float64)
+    z = np.empty(al.size, dtype=np.float64)
+    rc = lib.trk_host_bidiag_tikhonov(al.ctypes.data, be.ctypes.data, int(al.size), float(beta0), float(mu), 0, z.ctypes.data)
+    _lib.check(rc, "trk_host_bidiag_tikhonov")
+    return z

@@ -7,7 +7,13 @@ import scipy.linalg as sla
 
 from .._io import Formatter, History, as_operator
 from ..krylov import ArnoldiState
+from ..reg_param._bidiag import HessenbergBidiag, bidiag_tikhonov_host
+from ..reg_param.gcv import fminbound_gcv_bidiag
 from ._common import check_delta, choose_lambda, tikhonov_lstsq, small_host_blas
+
+# basis size from which Hybrid-GMRES's GCV goes through the bidiagonal form instead of the dense SVD (below it the SVD is the
+# cheaper call: 20 us at k = 10 against 25-60 us of ctypes and NumPy overhead around dgebrd)
+BIDIAG_FROM_K = 12
 
 
 @small_host_blas
@@ -92,6 +98,16 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
         svd = None
         if first:
             lam = 0
+        elif regparam == "gcv" and k >= BIDIAG_FROM_K and kwargs.get("gcv_by_bidiag", True) and HessenbergBidiag.available():
+            # no SVD: [bhat | H] bidiagonalised once (LAPACK dgebrd, a third of the dense SVD's cost), then the O(k)-per-evaluation
+            # GCV search and the O(k) Tikhonov solve of the Golub-Kahan form (reg_param/_bidiag.HessenbergBidiag); 'standard' GCV
+            # on the k x k diag(s) of (:58) = fullsize k.  Same singular values, same products with bhat: lambda agrees with the
+            # SVD route to ~3e-8 at an interior minimum (two evaluations of one smooth function a rounding apart), y to 1e-14.
+            hb = HessenbergBidiag(H, ar.beta0)
+            lam = fminbound_gcv_bidiag(hb.alphas, hb.betas, hb.beta0, k)
+            y = hb.back(bidiag_tikhonov_host(hb.alphas, hb.betas, hb.beta0, np.sqrt(lam)))
+            hy = (H @ y).reshape(-1, 1)
+            return lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy))
         elif regparam in ("gcv", "l_curve"):
             Qh, sv, Vh = sla.svd(H, full_matrices=False, check_finite=False)
             qb = Qh.T @ bhat
