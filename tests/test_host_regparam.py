@@ -287,3 +287,23 @@ def test_hessenberg_bidiagonal_form_equals_the_svd_route():
             y_svd = Vh.T @ ((sv / (sv * sv + lam)) * qb)
             y_bd = hb.back(bidiag_tikhonov_host(hb.alphas, hb.betas, hb.beta0, np.sqrt(lam)))
             assert np.linalg.norm(y_bd - y_svd) <= 1e-12 * np.linalg.norm(y_svd)
+
+
+def test_hessenberg_bidiagonal_form_serves_the_discrepancy_principle():
+    """... and the discrepancy principle: V^T b taken into the left Golub-Kahan basis (HessenbergBidiag.left_t), the same Newton
+    iteration as on the SVD of H (discrepancy_principle.py:68-99): lambda to 1e-12."""
+    import scipy.linalg as sla
+    from trips_py_amd.reg_param._bidiag import HessenbergBidiag
+    from trips_py_amd.reg_param.discrepancy_principle import discrepancy_principle_bidiag
+    if not HessenbergBidiag.available():
+        pytest.skip("SciPy without the cython_lapack capsule table")
+    rng = np.random.default_rng(1)
+    for k in (3, 12, 30, 60):
+        H = np.triu(rng.standard_normal((k + 1, k)), -1) * np.logspace(0, -2, k)[None, :]
+        pvec = H @ rng.standard_normal(k) + 0.05 * rng.standard_normal(k + 1)
+        delta = 0.05 * np.sqrt(k + 1)
+        Uf, sv, _ = sla.svd(H)
+        lam_svd = discrepancy_principle(None, None, None, 0.0, delta=delta, L_is_identity=True, spectrum=(sv, Uf.T @ pvec.reshape(-1, 1), (k + 1, k)))
+        hb = HessenbergBidiag(H, 5.0)
+        assert np.linalg.norm(hb.left_t(pvec)) == pytest.approx(np.linalg.norm(pvec), rel=1e-14)
+        assert discrepancy_principle_bidiag(hb.alphas, hb.betas, hb.left_t(pvec), delta=delta) == pytest.approx(lam_svd, rel=1e-12)

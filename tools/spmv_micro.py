@@ -38,8 +38,11 @@ def time_op(name, D):
     print("   ".join(row), flush=True)
 
 
+only = sys.argv[1] if len(sys.argv) > 1 else None       # "joseph": the 17.7 M non-zero matrix alone (for rocprofv3 runs)
 T, Nf, na, nd = 16, 256, 10, 256
 time_op("joseph 16 x 256^2", SparseBlockDiag(bench.joseph_block_matrix(Nf, [np.deg2rad(t + 18.0 * np.arange(na)) for t in range(T)], nd)))
+if only == "joseph":
+    sys.exit(0)
 time_op("crossphantom-like 16 x 128^2", SparseBlockDiag(bench.joseph_block_matrix(128, [np.deg2rad(t + 36.0 * np.arange(5)) for t in range(16)], 140)))
 time_op("first differences 2048^2", SparseOp(O.first_derivative_2d(2048, 2048)))
 time_op("space-time differences 16 x 256^2", SparseOp(O.spacetime_derivative(256, 256, 16)))

@@ -138,7 +138,7 @@ class HessenbergBidiag:
               ctypes.byref(info))
         if info.value != 0:
             raise RuntimeError(f"dgebrd failed (info = {info.value})")
-        self.k, self._M, self._tp, self._work = k, M, tp, work
+        self.k, self._M, self._tp, self._tq, self._work = k, M, tp, tq, work
         self.alphas, self.betas, self.beta0 = e[:k].copy(), d[1:n].copy(), float(d[0])
 
     def back(self, z):
@@ -154,6 +154,22 @@ class HessenbergBidiag:
         if info.value != 0:
             raise RuntimeError(f"dormbr failed (info = {info.value})")
         return c[1:].copy()
+
+    def left_t(self, p_vec):
+        """Q^T p for a (k+1)-vector p in the Arnoldi basis' coordinates (e.g. V_{k+1}^T b of the discrepancy principle): its
+        coordinates in the left Golub-Kahan basis of the bidiagonal form."""
+        n = self.k + 1
+        c = np.array(p_vec, dtype=np.float64).reshape(-1).copy()
+        if c.size != n:
+            raise ValueError(f"left_t: expected {n} entries")
+        ci = ctypes.c_int
+        nn, one, lw, info = ci(n), ci(1), ci(self._work.size), ci(0)
+        p = lambda a: a.ctypes.data_as(_DBL_P)      # noqa: E731
+        self._ormbr(b"Q", b"L", b"T", ctypes.byref(nn), ctypes.byref(one), ctypes.byref(nn), p(self._M), ctypes.byref(nn), p(self._tq),
+                    p(c), ctypes.byref(nn), p(self._work), ctypes.byref(lw), ctypes.byref(info))
+        if info.value != 0:
+            raise RuntimeError(f"dormbr failed (info = {info.value})")
+        return c
 
 
 def bidiag_tikhonov_host(alphas, betas, beta0, mu):

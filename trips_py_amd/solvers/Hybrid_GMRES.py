@@ -156,6 +156,21 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             else:
                 eng.gemv_t(ar.V.data, k + 1, bv, P.ref(0))
                 eng.allreduce(P, 0, k + 1)
+                hb = None
+                if k >= BIDIAG_FROM_K and kwargs.get("dp_by_bidiag", True) and HessenbergBidiag.available() and "explicitProj" not in kwargs:
+                    # the same Newton iteration on the bidiagonal form of [bhat | H] (as 'gcv' above): V^T b in the left basis'
+                    # coordinates; lambda agrees with the SVD route to 1e-15 (tests/test_host_regparam.py)
+                    from ..reg_param.discrepancy_principle import discrepancy_principle_bidiag
+                    hb = HessenbergBidiag(H, ar.beta0)
+                    extra = {key: kwargs[key] for key in ("eta",) if key in kwargs}
+                    lam = discrepancy_principle_bidiag(hb.alphas, hb.betas, hb.left_t(P.host(0, k + 1)), delta=kwargs.get("delta"), **extra)
+                    if lam is None or not lam > 0:
+                        hb = None
+                if hb is not None:
+                    y = hb.back(bidiag_tikhonov_host(hb.alphas, hb.betas, hb.beta0, np.sqrt(lam)))
+                    hy = (H @ y).reshape(-1, 1)
+                    form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
+                    continue
                 if kwargs.get("solve_by_svd", True):
                     # the SVD discrepancy_principle() takes of H (discrepancy_principle.py:68-70), taken here so that the
                     # Tikhonov solve below can share it
