@@ -510,17 +510,24 @@ int trk_gk_lsqr_chain(trk_op* op, int elem_bytes, int weights, const void* b, in
  * basis vector instead of 2n — and L V is never stored.  1 <= k <= 48, N a multiple of 32, rows of V 16-byte aligned. */
 int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, double* G, trk_stream stream);
 /* ACCURACY CONTRACT of trk_wgram_tv / trk_wgram_tv_z, and the switch.  The 16 x 16 tile products go through the matrix cores; `mode`:
- *   2 (default)  each weighted difference split into TWO bf16 pieces, all four partial products: what is lost is each operand's third
- *                piece, <= 2^-16 of it.  On data whose roundings are uncorrelated (noisy images, Krylov vectors) the Gram is within
- *                5e-9 of the fp32-pipe one; on images that repeat a few values millions of times the residuals are all the same
- *                number and an entry may be off by up to 1.2e-5 of sqrt(G_aa G_bb) (measured 5.8e-6,
- *                tests/test_gpu_kernels.py::test_wgram_tv_split_products_on_adversarial_images);
+ *   1 (default)  AUTO: two bf16 pieces unless the data says otherwise.  Every call first measures, on a sample (128 image rows, four
+ *                of the k basis vectors), what the two-piece split would lose — max |S' - S| / sqrt(S_aa S_bb) of the sampled Gram with
+ *                and without the split, in float64 — and the verdict, left on the DEVICE, lets one launch of a pair run: the two-piece
+ *                form below 1e-6, the fp32 pipe above (nothing visits the host; three near-empty launches and 17 MB of reads at
+ *                4096^2 per call).  <= 1e-6 per entry relative to sqrt(G_aa G_bb) on data the sample represents; the piecewise-
+ *                constant / repeated-value images of tests/test_gpu_kernels.py trip it, noisy images and Krylov vectors do not.
+ *   2            each weighted difference split into TWO bf16 pieces, all four partial products: what is lost is each operand's third
+ *                piece, <= 2^-16 of it.  On data whose roundings are uncorrelated the Gram is within 5e-9 of the fp32-pipe one; on
+ *                images that repeat a few values millions of times an entry may be off by up to 1.2e-5 (measured 5.8e-6);
  *   3            THREE bf16 pieces (the fp32 value exactly), six partial products: <= 1e-6 on those images (measured 4.7e-7), at
  *                1.1-1.5 x the time for 17 <= k <= 32;
  *   0            the fp32 matrix pipe (v_mfma_f32_16x16x4_f32): fp32 products, <= 1e-6 likewise, 0.51-0.57 ms at 4096^2 whatever k.
  * Returns the mode in force before the call; mode -1 only queries.  Process-wide (not per stream); environment TRK_WGRAM_TV_F32=1 /
- * TRK_WGRAM_TV_PIECES=3 set the default. */
+ * TRK_WGRAM_TV_PIECES=2|3 set the default. */
 int trk_wgram_tv_precision(int mode);
+/* Diagnostics: {verdict (0 two pieces ran, 1 the fp32 pipe ran), the sampled deviation} of the LAST call in mode 1, copied to two host
+ * doubles after a device synchronisation; {-1, -1} before the first such call. */
+int trk_wgram_tv_last_probe(double* verdict_and_deviation_host);
 /* The same pass also taking h[j] = V[j] . z for one more image z (n floats, 16-byte aligned): MMGKS forms the new Gram row
  * V^T (A^T A v_new) of the fidelity term (MMGKS.py:58 through its Gram matrix) and the re-weighted Gram of the regulariser for the
  * next iteration in ONE sweep over the basis. */

@@ -314,13 +314,14 @@ def _adversarial_basis(kind, k, N, dev):
 
 @pytest.mark.parametrize("kind", ["piecewise8", "constant_steps", "constant"])
 @pytest.mark.parametrize("with_z", [False, True])
-@pytest.mark.parametrize("mode,limit", [("bf16x2", 1.2e-5), ("bf16x3", 1e-6), ("fp32", 1e-6)])
+@pytest.mark.parametrize("mode,limit", [("auto", 1e-6), ("bf16x2", 1.2e-5), ("bf16x3", 1e-6), ("fp32", 1e-6)])
 def test_wgram_tv_split_products_on_adversarial_images(eng, kind, with_z, mode, limit):
     """trk_wgram_tv(_z) — Gram tiles through the bf16 matrix pipe with split operands — on images whose differences repeat a few
     values millions of times, unit weights and the weights trk_tv_weights makes of such an image: every entry within 1e-6 of the
-    float64 Gram relative to sqrt(G_aa G_bb), in the three arithmetic modes of trk_wgram_tv_precision — the accuracy contract of
-    include/trk.h: the default two-piece split loses up to 2^-16 of each operand, all of one sign on such images (measured 5.8e-6 on
-    `constant_steps`; bar 2 x that), three pieces or the fp32 pipe stay within 1e-6 (measured 4.7e-7)."""
+    float64 Gram relative to sqrt(G_aa G_bb), in the four arithmetic modes of trk_wgram_tv_precision — the accuracy contract of
+    include/trk.h: the two-piece split loses up to 2^-16 of each operand, all of one sign on such images (measured 5.8e-6 on
+    `constant_steps`; bar 2 x that), three pieces or the fp32 pipe stay within 1e-6 (measured 4.7e-7); the default, 'auto', measures
+    the loss on a sample per call and runs the fp32 pipe where it exceeds 1e-6 (it does on every image of this test that needs it)."""
     from trips_py_amd.operators import FirstDerivative2D
     N, k = 2048, 24
     dev = eng.device
@@ -356,8 +357,49 @@ def test_wgram_tv_split_products_on_adversarial_images(eng, kind, with_z, mode, 
         dg = np.sqrt(np.abs(np.diag(ref)))
         scale = np.maximum(np.outer(dg, dg), 1e-300)
         worst = max(worst, float(np.max(np.abs(got - ref) / scale)))
+    verdict, sampled = eng.wgram_tv_last_probe() if mode == "auto" else (None, None)
     assert eng.wgram_tv_precision(was) == mode
     bar(f"wgram_tv.adversarial[{kind}{'-z' if with_z else ''}-{mode}]", worst, limit)
+    if mode == "auto":
+        # (the probe's estimate of the last call — the weights of trk_tv_weights — next to what the two-piece split really loses)
+        assert verdict in (0, 1) and sampled >= 0.0
+        if verdict == 0:
+            assert sampled <= 1e-6
+
+
+def test_wgram_tv_auto_mode_keeps_the_two_piece_form_on_noisy_data(eng):
+    """'auto' on the data the solvers meet (Krylov vectors: noise-like): the probe's sampled deviation is ~1e-9, the verdict 0, and
+    the Gram is the two-piece Gram to the bit — the probe costs three near-empty launches, not accuracy or the matrix pipe's speed."""
+    from trips_py_amd.operators import FirstDerivative2D
+    N, k = 1024, 20
+    n, p = N * N, 2 * N * (N - 1)
+    g = torch.Generator(device=eng.device).manual_seed(3)
+    V = torch.randn(k, n, device=eng.device, generator=g)
+    w = torch.rand(p, device=eng.device, generator=g) + 0.25
+    z = torch.randn(n, device=eng.device, generator=g)
+    G = eng.scalars(2 * (k * k + k))
+    was = eng.wgram_tv_precision("auto")
+    try:
+        eng.wgram_tv(V, k, N, w, G[0:k * k], z=z, h=G[k * k:k * k + k])
+        verdict, sampled = eng.wgram_tv_last_probe()
+        eng.wgram_tv_precision("bf16x2")
+        eng.wgram_tv(V, k, N, w, G[k * k + k:2 * k * k + k], z=z, h=G[2 * k * k + k:2 * k * k + 2 * k])
+    finally:
+        eng.wgram_tv_precision(was)
+    got = eng.to_host(G)
+    assert verdict == 0 and sampled < 1e-7, (verdict, sampled)
+    assert np.array_equal(got[:k * k + k], got[k * k + k:])
+    # ... and a constant-step image flips it (the verdict is per call, nothing sticks)
+    V2 = _adversarial_basis("constant_steps", k, N, eng.device)
+    eng.wgram_tv_precision("auto")
+    try:
+        eng.wgram_tv(V2, k, N, torch.ones(p, device=eng.device), G[0:k * k])
+        verdict2, sampled2 = eng.wgram_tv_last_probe()
+        eng.wgram_tv(V, k, N, w, G[0:k * k])
+        verdict3, _ = eng.wgram_tv_last_probe()
+    finally:
+        eng.wgram_tv_precision(was)
+    assert verdict2 == 1 and sampled2 > 1e-6 and verdict3 == 0, (verdict2, sampled2, verdict3)
 
 
 @pytest.mark.gpu

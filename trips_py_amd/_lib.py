@@ -242,6 +242,7 @@ SIGNATURES = {
                                  c_stream]),
     "trk_gk_step": (c_int, [c_op, c_int, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_int, c_int, c_int, c_stream]),
     "trk_wgram_tv_precision": (c_int, [c_int]),
+    "trk_wgram_tv_last_probe": (c_int, [ctypes.POINTER(c_dbl)]),
     "trk_radon2d_apply_ref": (c_int, [c_op, c_int, c_int, c_int, ctypes.c_void_p, ctypes.c_void_p, c_stream]),
     "trk_radon2d_set_arithmetic": (c_int, [c_op, c_int]),
     "trk_radon2d_set_ref_sums": (c_int, [c_op, c_int, c_int]),

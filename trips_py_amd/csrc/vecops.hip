@@ -1505,7 +1505,11 @@ __device__ __forceinline__ void bf16_split8x3(const float (&d)[8], bf8v& hi, bf8
 template <int T, bool Z, int D, int BF = 3, int MINB = (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 2)>
 __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
                                                     const float* __restrict__ w, int nbands, int band_rows,
-                                                    double* __restrict__ partials, const float* __restrict__ z, int lockstep_in) {
+                                                    double* __restrict__ partials, const float* __restrict__ z, int lockstep_in,
+                                                    const double* __restrict__ gate, int want) {
+  // 'auto' arithmetic (trk_wgram_tv_precision): the launch is one of a pair — two bf16 pieces / the fp32 pipe — of which the probe's
+  // verdict (gate[0], written by k_wgram_tv_gate earlier on the stream) lets exactly one run; the other leaves at once
+  if (gate && ((gate[0] != 0.0) != (want != 0))) return;
   constexpr int NP = T * (T + 1) / 2;
   const int lockstep = lockstep_in & 1;
   const bool no_xcd_map = (lockstep_in & 2) != 0;                // TRK_WGRAM_TV_NO_XCD=1: the round-robin unit order (A/B)
@@ -1782,6 +1786,108 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
       const double t = ((red[0][0][row] + red[0][1][row]) + red[0][2][row]) + red[0][3][row];
       if (row < k) out[(size_t)k * k + row] = t;
     }
+  }
+}
+
+// ------------------------------------------------------------------ the probe of the 'auto' arithmetic of trk_wgram_tv
+// What two bf16 pieces per operand lose is each operand's third piece (<= 2^-16 of it).  On noisy data those residuals average out; on
+// data that repeats a few values they are one number, millions of times (tests/test_gpu_kernels.py: 5.8e-6 per entry).  Whether the
+// data at hand is of that kind is MEASURED per call on a sample: 128 image rows (every N/128-th), four of the k basis vectors; for
+// their weighted differences d the kernel forms both  S_ab = sum d_a d_b  and  S'_ab = sum t_a t_b , t = the two-piece value of d,
+// in float64 — S' - S is exactly what the split loses on the sample.  k_wgram_tv_gate turns the partials into
+//     gate[1] = max_ab |S'_ab - S_ab| / sqrt(S_aa S_bb) ,   gate[0] = gate[1] > threshold ,
+// and the pair of Gram launches behind it reads gate[0]: the bf16 form runs when it is 0, the fp32 pipe when it is 1 — decided on the
+// device, nothing visits the host.  Cost: 4 N^2 / (N / 128) floats read (17 MB at 4096^2) + three near-empty launches.
+constexpr int PROBE_V = 4, PROBE_P = PROBE_V * (PROBE_V + 1) / 2, PROBE_ROWS = 128;
+__device__ __forceinline__ float two_piece(float d) {
+  const float hi = (float)(__bf16)d;
+  return hi + (float)(__bf16)(d - hi);
+}
+__global__ __launch_bounds__(NT) void k_wgram_tv_probe(const float* __restrict__ V, int64_t ld, int k, int N, const float* __restrict__ w,
+                                                       int row_step, double* __restrict__ part) {
+  __shared__ double lds[(NT / 64) * 2 * PROBE_P];
+  const int i = blockIdx.x * row_step;                           // the sampled image row (grid = sampled rows)
+  int pr[PROBE_V];
+#pragma unroll
+  for (int a = 0; a < PROBE_V; ++a) pr[a] = (int)(((int64_t)a * (k - 1)) / (PROBE_V - 1));
+  const float* __restrict__ wh = w;
+  const float* __restrict__ wv = w + (int64_t)N * (N - 1);
+  double acc[2 * PROBE_P];
+#pragma unroll
+  for (int q = 0; q < 2 * PROBE_P; ++q) acc[q] = 0.0;
+  if (i < N) {
+    for (int c = threadIdx.x; c < N; c += NT) {
+      const float whc = c < N - 1 ? wh[(int64_t)i * (N - 1) + c] : 0.f;
+      const float wvc = i < N - 1 ? wv[(int64_t)i * N + c] : 0.f;
+      float dh[PROBE_V], dv[PROBE_V], th[PROBE_V], tv[PROBE_V];
+#pragma unroll
+      for (int a = 0; a < PROBE_V; ++a) {
+        const float* __restrict__ row = V + (int64_t)pr[a] * ld + (int64_t)i * N;
+        const float x = row[c];
+        const float xr = c < N - 1 ? row[c + 1] : x;
+        const float xb = i < N - 1 ? row[c + N] : x;
+        dh[a] = (x - xr) * whc;
+        dv[a] = (x - xb) * wvc;
+        th[a] = two_piece(dh[a]);
+        tv[a] = two_piece(dv[a]);
+      }
+      int q = 0;
+#pragma unroll
+      for (int a = 0; a < PROBE_V; ++a)
+#pragma unroll
+        for (int b = a; b < PROBE_V; ++b, ++q) {
+          acc[q] += (double)dh[a] * (double)dh[b] + (double)dv[a] * (double)dv[b];
+          acc[PROBE_P + q] += (double)th[a] * (double)th[b] + (double)tv[a] * (double)tv[b];
+        }
+    }
+  }
+  const double t = block_sum_many<NT, 2 * PROBE_P>(acc, lds);
+  if (threadIdx.x < 2 * PROBE_P) part[(size_t)blockIdx.x * 2 * PROBE_P + threadIdx.x] = t;
+}
+__global__ __launch_bounds__(64) void k_wgram_tv_gate(const double* __restrict__ part, int nblocks, double threshold, double* __restrict__ gate) {
+  __shared__ double S[2 * PROBE_P];
+  if (threadIdx.x < 2 * PROBE_P) {
+    double v = 0.0;
+    for (int b = 0; b < nblocks; ++b) v += part[(size_t)b * 2 * PROBE_P + threadIdx.x];      // fixed order
+    S[threadIdx.x] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double diag[PROBE_V], worst = 0.0;
+    int q = 0;
+    for (int a = 0; a < PROBE_V; ++a)
+      for (int b = a; b < PROBE_V; ++b, ++q)
+        if (a == b) diag[a] = S[q];
+    q = 0;
+    for (int a = 0; a < PROBE_V; ++a)
+      for (int b = a; b < PROBE_V; ++b, ++q) {
+        const double sc = sqrt(fabs(diag[a] * diag[b]));
+        if (sc > 0.0) worst = fmax(worst, fabs(S[PROBE_P + q] - S[q]) / sc);
+      }
+    gate[1] = worst;
+    gate[0] = worst > threshold ? 1.0 : 0.0;
+  }
+}
+// k_finalize / k_finalize_split of core.hip for one launch of such a pair (outputs from nsplit on go to out2)
+__global__ __launch_bounds__(256) void k_finalize_gated(const double* __restrict__ partials, int nblocks, int stride, double* __restrict__ out,
+                                                        int nsplit, double* __restrict__ out2, const double* __restrict__ gate, int want) {
+  if ((gate[0] != 0.0) != (want != 0)) return;
+  __shared__ double lds[4];
+  const int o = blockIdx.x;
+  const double* __restrict__ p = partials + o;
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  int b = threadIdx.x;
+  for (; b + 768 < nblocks; b += 1024) {
+    v0 += p[(size_t)b * stride];
+    v1 += p[(size_t)(b + 256) * stride];
+    v2 += p[(size_t)(b + 512) * stride];
+    v3 += p[(size_t)(b + 768) * stride];
+  }
+  for (; b < nblocks; b += 256) v0 += p[(size_t)b * stride];
+  const double v = block_sum<256>((v0 + v1) + (v2 + v3), lds);
+  if (threadIdx.x == 0) {
+    if (o < nsplit) out[o] = v;
+    else out2[o - nsplit] = v;
   }
 }
 
@@ -2223,16 +2329,28 @@ int trk_gemv_nt(const float* V, int64_t ld, int k, int64_t n, const double* h, c
   return finalize_sums(part, bx, k, k, g, s);
 }
 
-static int g_wgram_tv_mode = -1;       // -1: not chosen yet (environment, else 2)
+static int g_wgram_tv_mode = -1;       // -1: not chosen yet (environment, else 1 = auto)
+static double* g_wgram_gate = nullptr; // {verdict, worst sampled deviation} of the last 'auto' call (device; process-wide like the mode)
 static int wgram_tv_mode() {
-  if (g_wgram_tv_mode < 0) g_wgram_tv_mode = env_int("TRK_WGRAM_TV_F32", 0) ? 0 : (env_int("TRK_WGRAM_TV_PIECES", 2) == 3 ? 3 : 2);
+  if (g_wgram_tv_mode < 0) {
+    const int pcs = env_int("TRK_WGRAM_TV_PIECES", 0);
+    g_wgram_tv_mode = env_int("TRK_WGRAM_TV_F32", 0) ? 0 : (pcs == 3 ? 3 : pcs == 2 ? 2 : 1);
+  }
   return g_wgram_tv_mode;
 }
 int trk_wgram_tv_precision(int mode) {
-  TRK_REQUIRE(mode == -1 || mode == 0 || mode == 2 || mode == 3, "trk_wgram_tv_precision: mode 0 (fp32 pipe), 2 or 3 (bf16 pieces), -1 (query)");
+  TRK_REQUIRE(mode >= -1 && mode <= 3, "trk_wgram_tv_precision: mode 1 (auto), 0 (fp32 pipe), 2 or 3 (bf16 pieces), -1 (query)");
   const int was = wgram_tv_mode();
   if (mode >= 0) g_wgram_tv_mode = mode;
   return was;
+}
+int trk_wgram_tv_last_probe(double* verdict_and_deviation_host) {
+  TRK_REQUIRE(verdict_and_deviation_host, "trk_wgram_tv_last_probe: NULL argument");
+  verdict_and_deviation_host[0] = verdict_and_deviation_host[1] = -1.0;
+  if (!g_wgram_gate) return TRK_OK;                              // no 'auto' call yet
+  TRK_HIP(hipDeviceSynchronize());
+  TRK_HIP(hipMemcpy(verdict_and_deviation_host, g_wgram_gate, 2 * sizeof(double), hipMemcpyDeviceToHost));
+  return TRK_OK;
 }
 static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w, double* G, const float* z, double* h, trk_stream st);
 
@@ -2277,36 +2395,61 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   if ((int64_t)bx * (NT / 64) > units) bx = (int)((units + NT / 64 - 1) / (NT / 64));
   double* part = nullptr;
   const int nv = k * k + (z ? k : 0);
-  if (int rc = scratch_doubles(s, (size_t)bx * nv, &part)) return rc;
+  if (int rc = scratch_doubles(s, (size_t)bx * nv + (size_t)PROBE_ROWS * 2 * PROBE_P, &part)) return rc;
+  double* probe_part = part + (size_t)bx * nv;
   static const int no_xcd = env_int("TRK_WGRAM_TV_NO_XCD", 0) ? 2 : 0;
-  // Which arithmetic forms the tile products (trk_wgram_tv_precision; environment TRK_WGRAM_TV_F32=1 / TRK_WGRAM_TV_PIECES=3 set the
-  // process default): 0 fp32 matrix pipe, 2 two bf16 pieces (default), 3 three bf16 pieces
+  // Which arithmetic forms the tile products (trk_wgram_tv_precision; environment TRK_WGRAM_TV_F32=1 / TRK_WGRAM_TV_PIECES=2|3 set the
+  // process default): 1 auto (default: two bf16 pieces unless the probe finds the data's roundings correlated, then the fp32 pipe),
+  // 0 fp32 matrix pipe, 2 two bf16 pieces, 3 three bf16 pieces
   const int mode = wgram_tv_mode();
-  const int f32_pipe = mode == 0, pieces = mode == 3 ? 3 : 2;
   // two tiles, three pieces: 256 registers (no spills) at 2 workgroups per CU is the faster form (532 / 605 us at k = 17 / 32 against
   // 648 / 781 with 32 spilled registers at 3: profiles/r05/wgram_tv_pieces.txt)
   static const int occ2 = env_int("TRK_WGRAM_TV_OCC2", 1);
-#define WTV(TT, ZZ)                                                                                                                                   \
-  do {                                                                                                                                                \
-    if (f32_pipe) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 0>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd); \
-    else if (pieces == 2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd); \
-    else if (TT == 2 && !ZZ && occ2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd); \
-    else hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd);           \
-  } while (0)
-  if (z && T16 == 3) {
-    // three tiles AND the dots do not fit the register file (108 spilled registers): two passes for 33 <= k <= 48
-    WTV(3, false);
+  const double* gate = nullptr;
+  if (mode == 1) {
+    if (!g_wgram_gate) TRK_HIP(hipMalloc((void**)&g_wgram_gate, 2 * sizeof(double)));
+    static const double thr = getenv("TRK_WGRAM_TV_PROBE_THRESHOLD") ? atof(getenv("TRK_WGRAM_TV_PROBE_THRESHOLD")) : 1e-6;
+    const int row_step = N / PROBE_ROWS > 0 ? N / PROBE_ROWS : 1;
+    const int prows = (N + row_step - 1) / row_step < PROBE_ROWS ? (N + row_step - 1) / row_step : PROBE_ROWS;
+    hipLaunchKernelGGL(k_wgram_tv_probe, dim3(prows), dim3(NT), 0, s, V, ld, k, N, w, row_step, probe_part);
+    hipLaunchKernelGGL(k_wgram_tv_gate, dim3(1), dim3(64), 0, s, probe_part, prows, thr, g_wgram_gate);
     TRK_LAUNCH_CHECK();
-    if (int rc = finalize_sums(part, bx, k * k, k * k, G, s)) return rc;
-    return launch_gemv_t(V, ld, k, (int64_t)N * N, z, nullptr, 0, h, s);
+    gate = g_wgram_gate;
   }
-  if (z) { if (T16 == 1) WTV(1, true); else WTV(2, true); }
-  else   { if (T16 == 1) WTV(1, false); else if (T16 == 2) WTV(2, false); else WTV(3, false); }
-#undef WTV
-  TRK_LAUNCH_CHECK();
-  if (z) return finalize_sums_split(part, bx, nv, nv, G, k * k, h, s);
-  return finalize_sums(part, bx, k * k, k * k, G, s);
+  // arith: 0 fp32 pipe, 2 / 3 bf16 pieces; (gate, want): NULL = run; else run iff the probe's verdict equals want
+#define WTV(TT, ZZ, ARITH, WANT)                                                                                                                      \
+  do {                                                                                                                                                \
+    if ((ARITH) == 0) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 0>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, gate, WANT); \
+    else if ((ARITH) == 2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, gate, WANT); \
+    else if (TT == 2 && !ZZ && occ2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, gate, WANT); \
+    else hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, gate, WANT);           \
+  } while (0)
+  // one pass of the chosen arithmetic: the kernel and the sum of its block partials
+  auto pass = [&](int arith, int want) -> int {
+    const bool two_pass = z && T16 == 3;     // three tiles AND the dots do not fit the register file (108 spilled registers): the dots
+    if (two_pass) WTV(3, false, arith, want);   // of 33 <= k <= 48 in a pass of their own, below
+    else if (z) { if (T16 == 1) WTV(1, true, arith, want); else WTV(2, true, arith, want); }
+    else { if (T16 == 1) WTV(1, false, arith, want); else if (T16 == 2) WTV(2, false, arith, want); else WTV(3, false, arith, want); }
+    TRK_LAUNCH_CHECK();
+    const int nout = two_pass ? k * k : nv;
+    if (gate) {
+      hipLaunchKernelGGL(k_finalize_gated, dim3(nout), dim3(256), 0, s, part, bx, nout, G, k * k, h, gate, want);
+      TRK_LAUNCH_CHECK();
+      return TRK_OK;
+    }
+    if (z && !two_pass) return finalize_sums_split(part, bx, nv, nv, G, k * k, h, s);
+    return finalize_sums(part, bx, k * k, k * k, G, s);
+  };
+  if (mode == 1) {
+    if (int rc = pass(2, 0)) return rc;
+    if (int rc = pass(0, 1)) return rc;
+  } else {
+    if (int rc = pass(mode, 0)) return rc;
+  }
+  if (z && T16 == 3) return launch_gemv_t(V, ld, k, (int64_t)N * N, z, nullptr, 0, h, s);
+  return TRK_OK;
 }
+#undef WTV
 
 int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G, double* c1,
               double* c2, trk_stream st) {

@@ -771,15 +771,22 @@ class HipEngine:
 
     WGRAM_TV_MAX_K = 48
 
-    WGRAM_TV_MODES = {"bf16x2": 2, "bf16x3": 3, "fp32": 0}
+    WGRAM_TV_MODES = {"auto": 1, "bf16x2": 2, "bf16x3": 3, "fp32": 0}
 
     def wgram_tv_precision(self, mode=None):
-        """The arithmetic of trk_wgram_tv's tile products (accuracy contract: include/trk.h): 'bf16x2' (default: fastest; up to 1.2e-5
-        per entry on images that repeat a few values), 'bf16x3' or 'fp32' (<= 1e-6 on any image).  Process-wide.  Returns the name
+        """The arithmetic of trk_wgram_tv's tile products (accuracy contract: include/trk.h): 'auto' (default: two bf16 pieces unless a
+        per-call probe finds the data's roundings correlated, then the fp32 pipe — decided on the device), 'bf16x2' (fastest; up to
+        1.2e-5 per entry on images that repeat a few values), 'bf16x3' or 'fp32' (<= 1e-6 on any image).  Process-wide.  Returns the name
         in force before the call; None only queries."""
         code = -1 if mode is None else self.WGRAM_TV_MODES[mode]
         was = self.lib.trk_wgram_tv_precision(code)
         return {v: n for n, v in self.WGRAM_TV_MODES.items()}[was]
+
+    def wgram_tv_last_probe(self):
+        """(verdict, sampled deviation) of the last 'auto' call of wgram_tv (synchronises; diagnostics)."""
+        out = (ctypes.c_double * 2)()
+        _lib.check(self.lib.trk_wgram_tv_last_probe(out), "trk_wgram_tv_last_probe")
+        return int(out[0]), float(out[1])
 
     def wgram_tv(self, V, k, N, w, G, z=None, h=None):
         """G = (L V) diag(w^2) (L V)^T for the 2-D first-difference L of an N x N image, from V itself (trk_wgram_tv: N % 32 == 0,

@@ -33,7 +33,7 @@ def _old_first_derivative_2d_matrix(nx, ny):
 @small_host_blas
 def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv", x_true=None, **kwargs):
     """Returns (x, info); info keys xHistory, regParam, regParam_history, relError (if x_true), Residual, its.
-    Engine-only kwargs: history (True, False, a stride, 'host' or a .npy path: _io.History); gram_precision ('bf16x2' default |
+    Engine-only kwargs: history (True, False, a stride, 'host' or a .npy path: _io.History); gram_precision ('auto' default | 'bf16x2' |
     'bf16x3' | 'fp32': the arithmetic of the re-weighted TV Gram's tile products for this solve, engine.wgram_tv_precision —
     choose one of the last two for iterates that repeat a few values exactly, e.g. synthetic piecewise-constant data)."""
     A = as_operator(A)
