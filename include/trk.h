@@ -513,7 +513,7 @@ int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, doubl
  *   1 (default)  AUTO: two bf16 pieces unless the data says otherwise.  Every call first measures, on a sample (128 image rows, four
  *                of the k basis vectors), what the two-piece split would lose — max |S' - S| / sqrt(S_aa S_bb) of the sampled Gram with
  *                and without the split, in float64 — and the verdict, left on the DEVICE, lets one launch of a pair run: the two-piece
- *                form below 1e-6, the fp32 pipe above (nothing visits the host; three near-empty launches and 17 MB of reads at
+ *                form below 3e-7, the fp32 pipe above (nothing visits the host; three near-empty launches and 17 MB of reads at
  *                4096^2 per call).  <= 1e-6 per entry relative to sqrt(G_aa G_bb) on data the sample represents; the piecewise-
  *                constant / repeated-value images of tests/test_gpu_kernels.py trip it, noisy images and Krylov vectors do not.
  *   2            each weighted difference split into TWO bf16 pieces, all four partial products: what is lost is each operand's third
