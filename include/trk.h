@@ -510,11 +510,11 @@ int trk_gk_lsqr_chain(trk_op* op, int elem_bytes, int weights, const void* b, in
  * basis vector instead of 2n — and L V is never stored.  1 <= k <= 48, N a multiple of 32, rows of V 16-byte aligned. */
 int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, double* G, trk_stream stream);
 /* ACCURACY CONTRACT of trk_wgram_tv / trk_wgram_tv_z, and the switch.  The 16 x 16 tile products go through the matrix cores; `mode`:
- *   1 (default)  AUTO: two bf16 pieces unless the data says otherwise.  Every call first measures, on a sample (128 image rows, four
- *                of the k basis vectors), what the two-piece split would lose — max |S' - S| / sqrt(S_aa S_bb) of the sampled Gram with
+ *   1 (default)  AUTO: two bf16 pieces unless the data says otherwise.  Every call first measures, on a sample (runs of 1024 pixels in 256 image
+ *                rows, four of the k basis vectors), what the two-piece split would lose — max |S' - S| / sqrt(S_aa S_bb) of the sampled Gram with
  *                and without the split, in float64 — and the verdict, left on the DEVICE, lets one launch of a pair run: the two-piece
- *                form below 3e-7, the fp32 pipe above (nothing visits the host; three near-empty launches and 17 MB of reads at
- *                4096^2 per call).  <= 1e-6 per entry relative to sqrt(G_aa G_bb) on data the sample represents; the piecewise-
+ *                form below 3e-7, the fp32 pipe above (nothing visits the host; a probe of ~12 MB of reads whatever the image size and the idle
+ *                launches of the pair per call).  <= 1e-6 per entry relative to sqrt(G_aa G_bb) on data the sample represents; the piecewise-
  *                constant / repeated-value images of tests/test_gpu_kernels.py trip it, noisy images and Krylov vectors do not.
  *   2            each weighted difference split into TWO bf16 pieces, all four partial products: what is lost is each operand's third
  *                piece, <= 2^-16 of it.  On data whose roundings are uncorrelated the Gram is within 5e-9 of the fp32-pipe one; on

@@ -1480,6 +1480,35 @@ struct TvRow {
 // v_mfma_f32_16x16x32_bf16 takes a lane's eight weighted differences of a step in ONE instruction: 4 x 16 cycles per tile pair and
 // direction where eight v_mfma_f32_16x16x4_f32 took 256 — the fp32 matrix pipe, at the vector unit's own rate, was this kernel's
 // bound at two tiles (k = 17 .. 32: 0.51-0.57 ms whatever k; 48 MFMAs x 32 cycles per 32 pixels), now the rows' traffic is.
+// The verdict of trk_wgram_tv's 'auto' arithmetic (the probe is further down: k_wgram_tv_probe): sums = the probe's 2 x 10 finished
+// sums {S_ab, S'_ab}; worst = max_ab |S' - S| / sqrt(S_aa S_bb); verdict = worst > threshold.  Every workgroup of the pair of Gram
+// launches evaluates it (20 scalar loads, the same bits everywhere); the first one of the bf16 launch also records it in `record`.
+struct ProbeGate {
+  const double* sums;     // NULL: no gating
+  double threshold;
+  int want;               // this launch runs iff verdict == want
+  double* record;         // {verdict, worst} for trk_wgram_tv_last_probe
+};
+__device__ __forceinline__ int probe_verdict(const ProbeGate& pg, bool record) {
+  constexpr int PV = 4, PP = 10;
+  double worst = 0.0;
+  int q = 0;
+#pragma unroll
+  for (int a = 0; a < PV; ++a)
+#pragma unroll
+    for (int b = a; b < PV; ++b, ++q) {
+      // (the diagonal entries of the upper-triangle order: a = 0 -> 0, 1 -> 4, 2 -> 7, 3 -> 9)
+      const int qa = a == 0 ? 0 : a == 1 ? 4 : a == 2 ? 7 : 9, qb = b == 0 ? 0 : b == 1 ? 4 : b == 2 ? 7 : 9;
+      const double sc = sqrt(fabs(pg.sums[qa] * pg.sums[qb]));
+      if (sc > 0.0) worst = fmax(worst, fabs(pg.sums[PP + q] - pg.sums[q]) / sc);
+    }
+  const int verdict = worst > pg.threshold ? 1 : 0;
+  if (record && pg.want == 0 && pg.record) {
+    pg.record[0] = (double)verdict;
+    pg.record[1] = worst;
+  }
+  return verdict;
+}
 typedef __bf16 bf8v __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void bf16_split8(const float (&d)[8], bf8v& hi, bf8v& lo) {
 #pragma unroll
@@ -1506,10 +1535,10 @@ template <int T, bool Z, int D, int BF = 3, int MINB = (D > 3 ? 1 : T == 1 ? 4 :
 __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
                                                     const float* __restrict__ w, int nbands, int band_rows,
                                                     double* __restrict__ partials, const float* __restrict__ z, int lockstep_in,
-                                                    const double* __restrict__ gate, int want) {
+                                                    ProbeGate pg) {
   // 'auto' arithmetic (trk_wgram_tv_precision): the launch is one of a pair — two bf16 pieces / the fp32 pipe — of which the probe's
-  // verdict (gate[0], written by k_wgram_tv_gate earlier on the stream) lets exactly one run; the other leaves at once
-  if (gate && ((gate[0] != 0.0) != (want != 0))) return;
+  // verdict (worked out by every workgroup from the probe's 20 finished sums: no launch for it) lets exactly one run; the other leaves at once
+  if (pg.sums && probe_verdict(pg, blockIdx.x == 0 && threadIdx.x == 0) != pg.want) return;
   constexpr int NP = T * (T + 1) / 2;
   const int lockstep = lockstep_in & 1;
   const bool no_xcd_map = (lockstep_in & 2) != 0;                // TRK_WGRAM_TV_NO_XCD=1: the round-robin unit order (A/B)
@@ -1792,30 +1821,36 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
 // ------------------------------------------------------------------ the probe of the 'auto' arithmetic of trk_wgram_tv
 // What two bf16 pieces per operand lose is each operand's third piece (<= 2^-16 of it).  On noisy data those residuals average out; on
 // data that repeats a few values they are one number, millions of times (tests/test_gpu_kernels.py: 5.8e-6 per entry).  Whether the
-// data at hand is of that kind is MEASURED per call on a sample: 128 image rows (one per N/128, jittered), four of the k basis vectors; for
+// data at hand is of that kind is MEASURED per call on a sample: runs of 1024 pixels in 256 image rows (jittered), four of the k basis vectors; for
 // their weighted differences d the kernel forms both  S_ab = sum d_a d_b  and  S'_ab = sum t_a t_b , t = the two-piece value of d,
 // in float64 — S' - S is exactly what the split loses on the sample.  k_wgram_tv_gate turns the partials into
 //     gate[1] = max_ab |S'_ab - S_ab| / sqrt(S_aa S_bb) ,   gate[0] = gate[1] > threshold (3e-7) ,
 // and the pair of Gram launches behind it reads gate[0]: the bf16 form runs when it is 0, the fp32 pipe when it is 1 — decided on the
-// device, nothing visits the host.  Cost: 4 N^2 / (N / 128) floats read (17 MB at 4096^2) + three near-empty launches.
-constexpr int PROBE_V = 4, PROBE_P = PROBE_V * (PROBE_V + 1) / 2, PROBE_ROWS = 128, PROBE_SEG = 1024;
+// device, nothing visits the host.  Cost: ~12 MB of reads whatever N, the probe and its 20-sum finalize, and the two launches of the
+// pair that does not run (measured at 4096^2: see profiles/r05/wgram_tv_auto.txt).
+constexpr int PROBE_V = 4, PROBE_P = PROBE_V * (PROBE_V + 1) / 2, PROBE_ROWS = 256, PROBE_SEG = 1024;
 __device__ __forceinline__ float two_piece(float d) {
   const float hi = (float)(__bf16)d;
   return hi + (float)(__bf16)(d - hi);
 }
-// the j-th sampled image row: one per stride, at a pseudo-random place inside it (a regular comb would never meet the block edges of
-// a piecewise-constant image whose blocks are multiples of the stride — measured: such an image passed the first version's probe)
-__device__ __forceinline__ int probe_row(int j, int row_step, int N) {
-  unsigned h = (unsigned)j * 2654435761u;
+// the j-th sample: one image row per stride, at a pseudo-random place inside it, and of that row one pseudo-random run of PROBE_SEG
+// columns (a regular comb would never meet the block edges of a piecewise-constant image whose blocks are multiples of the stride —
+// measured: such an image passed the first version's probe).  262 144 pixels whatever N: the probe's cost does not grow with the image.
+__device__ __forceinline__ unsigned probe_hash(unsigned j) {
+  unsigned h = j * 2654435761u;
   h ^= h >> 15;
-  const int i = j * row_step + (int)(h % (unsigned)row_step);
-  return i < N ? i : N - 1;
+  h *= 2246822519u;
+  return h ^ (h >> 13);
 }
-// grid = (column segments of PROBE_SEG, sampled rows): a thread takes every 256th column of its segment
 __global__ __launch_bounds__(NT) void k_wgram_tv_probe(const float* __restrict__ V, int64_t ld, int k, int N, const float* __restrict__ w,
                                                        int row_step, double* __restrict__ part) {
   __shared__ double lds[(NT / 64) * 2 * PROBE_P];
-  const int i = probe_row(blockIdx.y, row_step, N);
+  const unsigned h = probe_hash(blockIdx.x);
+  int i = blockIdx.x * row_step + (int)(h % (unsigned)row_step);
+  i = i < N ? i : N - 1;
+  const int span = N > PROBE_SEG ? N - PROBE_SEG : 0;
+  const int cbeg = span > 0 ? (int)((h >> 8) % (unsigned)(span + 1)) : 0;
+  const int c_end = cbeg + PROBE_SEG < N ? cbeg + PROBE_SEG : N;
   int pr[PROBE_V];
 #pragma unroll
   for (int a = 0; a < PROBE_V; ++a) pr[a] = (int)(((int64_t)a * (k - 1)) / (PROBE_V - 1));
@@ -1824,8 +1859,7 @@ __global__ __launch_bounds__(NT) void k_wgram_tv_probe(const float* __restrict__
   double acc[2 * PROBE_P];
 #pragma unroll
   for (int q = 0; q < 2 * PROBE_P; ++q) acc[q] = 0.0;
-  const int c_end = (blockIdx.x + 1) * PROBE_SEG < N ? (blockIdx.x + 1) * PROBE_SEG : N;
-  for (int c = blockIdx.x * PROBE_SEG + threadIdx.x; c < c_end; c += NT) {
+  for (int c = cbeg + threadIdx.x; c < c_end; c += NT) {
     const float whc = c < N - 1 ? wh[(int64_t)i * (N - 1) + c] : 0.f;
     const float wvc = i < N - 1 ? wv[(int64_t)i * N + c] : 0.f;
     float dh[PROBE_V], dv[PROBE_V], th[PROBE_V], tv[PROBE_V];
@@ -1850,46 +1884,12 @@ __global__ __launch_bounds__(NT) void k_wgram_tv_probe(const float* __restrict__
       }
   }
   const double t = block_sum_many<NT, 2 * PROBE_P>(acc, lds);
-  if (threadIdx.x < 2 * PROBE_P) part[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 2 * PROBE_P + threadIdx.x] = t;
-}
-// one workgroup: the 2 PROBE_P sums over the probe's block partials (12 threads per sum, fixed order), then the verdict
-__global__ __launch_bounds__(NT) void k_wgram_tv_gate(const double* __restrict__ part, int nblocks, double threshold, double* __restrict__ gate) {
-  constexpr int NS = 2 * PROBE_P, PER = NT / NS;                 // 20 sums, 12 threads each (16 threads idle)
-  __shared__ double sh[NS][PER];
-  __shared__ double S[NS];
-  const int q = threadIdx.x / PER, r = threadIdx.x - q * PER;
-  if (q < NS) {
-    double v = 0.0;
-    for (int b = r; b < nblocks; b += PER) v += part[(size_t)b * NS + q];
-    sh[q][r] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x < NS) {
-    double v = 0.0;
-    for (int j = 0; j < PER; ++j) v += sh[threadIdx.x][j];
-    S[threadIdx.x] = v;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double diag[PROBE_V], worst = 0.0;
-    int qq = 0;
-    for (int a = 0; a < PROBE_V; ++a)
-      for (int b = a; b < PROBE_V; ++b, ++qq)
-        if (a == b) diag[a] = S[qq];
-    qq = 0;
-    for (int a = 0; a < PROBE_V; ++a)
-      for (int b = a; b < PROBE_V; ++b, ++qq) {
-        const double sc = sqrt(fabs(diag[a] * diag[b]));
-        if (sc > 0.0) worst = fmax(worst, fabs(S[PROBE_P + qq] - S[qq]) / sc);
-      }
-    gate[1] = worst;
-    gate[0] = worst > threshold ? 1.0 : 0.0;
-  }
+  if (threadIdx.x < 2 * PROBE_P) part[(size_t)blockIdx.x * 2 * PROBE_P + threadIdx.x] = t;
 }
 // k_finalize / k_finalize_split of core.hip for one launch of such a pair (outputs from nsplit on go to out2)
 __global__ __launch_bounds__(256) void k_finalize_gated(const double* __restrict__ partials, int nblocks, int stride, double* __restrict__ out,
-                                                        int nsplit, double* __restrict__ out2, const double* __restrict__ gate, int want) {
-  if ((gate[0] != 0.0) != (want != 0)) return;
+                                                        int nsplit, double* __restrict__ out2, ProbeGate pg) {
+  if (probe_verdict(pg, false) != pg.want) return;
   __shared__ double lds[4];
   const int o = blockIdx.x;
   const double* __restrict__ p = partials + o;
@@ -2396,7 +2396,7 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   // 366, k <= 10 equal; with the dots of _z (218 registers, two workgroups per CU at two tiles): k = 18 / 26 / 32: 640 / 649 / 676 vs
   // 598 / 666 / 791 — from k = 25 on.
   static const int ls_env = env_int("TRK_WGRAM_TV_LOCKSTEP", -1);
-  const bool ls_pays = T16 == 1 ? k >= 12 : T16 == 2 ? (z ? k >= 25 : true) : false;
+  const bool ls_pays = T16 == 1 ? k >= 12 : T16 == 2 ? (z ? k >= 22 : true) : false;      // (round 5, two bf16 pieces, _z: k = 20 455 vs 464 us, k = 24 540 vs 478)
   const int lock = (strips % (NT / 64) == 0 && (ls_env < 0 ? ls_pays : ls_env != 0)) ? 1 : 0;
   // workgroups per CU: what the registers let be resident while the matrix pipe is the bound; without the lockstep exchange fewer
   // once the rows' traffic is (k = 32 plain: 762 / 744 / 683 us with 4 / 2 / 1 — more waves, more row streams open at once)
@@ -2413,9 +2413,9 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   if ((int64_t)bx * (NT / 64) > units) bx = (int)((units + NT / 64 - 1) / (NT / 64));
   double* part = nullptr;
   const int nv = k * k + (z ? k : 0);
-  const int psegs = (N + PROBE_SEG - 1) / PROBE_SEG;
-  if (int rc = scratch_doubles(s, (size_t)bx * nv + ((size_t)PROBE_ROWS * psegs + 1) * 2 * PROBE_P, &part)) return rc;
+  if (int rc = scratch_doubles(s, (size_t)bx * nv + ((size_t)PROBE_ROWS + 1) * 2 * PROBE_P, &part)) return rc;
   double* probe_part = part + (size_t)bx * nv;
+  double* probe_sums = probe_part + (size_t)PROBE_ROWS * 2 * PROBE_P;
   static const int no_xcd = env_int("TRK_WGRAM_TV_NO_XCD", 0) ? 2 : 0;
   // Which arithmetic forms the tile products (trk_wgram_tv_precision; environment TRK_WGRAM_TV_F32=1 / TRK_WGRAM_TV_PIECES=2|3 set the
   // process default): 1 auto (default: two bf16 pieces unless the probe finds the data's roundings correlated, then the fp32 pipe),
@@ -2424,26 +2424,25 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   // two tiles, three pieces: 256 registers (no spills) at 2 workgroups per CU is the faster form (532 / 605 us at k = 17 / 32 against
   // 648 / 781 with 32 spilled registers at 3: profiles/r05/wgram_tv_pieces.txt)
   static const int occ2 = env_int("TRK_WGRAM_TV_OCC2", 1);
-  const double* gate = nullptr;
+  ProbeGate pg{nullptr, 0.0, 0, nullptr};
   if (mode == 1) {
     if (!g_wgram_gate) TRK_HIP(hipMalloc((void**)&g_wgram_gate, 2 * sizeof(double)));
     // verdict threshold on the SAMPLED deviation: a third of the 1e-6 the contract promises (the sample is an estimate)
     static const double thr = getenv("TRK_WGRAM_TV_PROBE_THRESHOLD") ? atof(getenv("TRK_WGRAM_TV_PROBE_THRESHOLD")) : 3e-7;
     const int row_step = N / PROBE_ROWS > 0 ? N / PROBE_ROWS : 1;
     const int prows = (N + row_step - 1) / row_step < PROBE_ROWS ? (N + row_step - 1) / row_step : PROBE_ROWS;
-    hipLaunchKernelGGL(k_wgram_tv_probe, dim3(psegs, prows), dim3(NT), 0, s, V, ld, k, N, w, row_step, probe_part);
+    hipLaunchKernelGGL(k_wgram_tv_probe, dim3(prows), dim3(NT), 0, s, V, ld, k, N, w, row_step, probe_part);
     TRK_LAUNCH_CHECK();
-    hipLaunchKernelGGL(k_wgram_tv_gate, dim3(1), dim3(NT), 0, s, probe_part, prows * psegs, thr, g_wgram_gate);
-    TRK_LAUNCH_CHECK();
-    gate = g_wgram_gate;
+    if (int rc = finalize_sums(probe_part, prows, 2 * PROBE_P, 2 * PROBE_P, probe_sums, s)) return rc;
+    pg = ProbeGate{probe_sums, thr, 0, g_wgram_gate};
   }
-  // arith: 0 fp32 pipe, 2 / 3 bf16 pieces; (gate, want): NULL = run; else run iff the probe's verdict equals want
+  // arith: 0 fp32 pipe, 2 / 3 bf16 pieces; want: with a probe, the launch runs iff the probe's verdict equals it
 #define WTV(TT, ZZ, ARITH, WANT)                                                                                                                      \
   do {                                                                                                                                                \
-    if ((ARITH) == 0) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 0>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, gate, WANT); \
-    else if ((ARITH) == 2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, gate, WANT); \
-    else if (TT == 2 && !ZZ && occ2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, gate, WANT); \
-    else hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, gate, WANT);           \
+    if ((ARITH) == 0) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 0>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record}); \
+    else if ((ARITH) == 2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record}); \
+    else if (TT == 2 && !ZZ && occ2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record}); \
+    else hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record});           \
   } while (0)
   // one pass of the chosen arithmetic: the kernel and the sum of its block partials
   auto pass = [&](int arith, int want) -> int {
@@ -2453,8 +2452,8 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
     else { if (T16 == 1) WTV(1, false, arith, want); else if (T16 == 2) WTV(2, false, arith, want); else WTV(3, false, arith, want); }
     TRK_LAUNCH_CHECK();
     const int nout = two_pass ? k * k : nv;
-    if (gate) {
-      hipLaunchKernelGGL(k_finalize_gated, dim3(nout), dim3(256), 0, s, part, bx, nout, G, k * k, h, gate, want);
+    if (pg.sums) {
+      hipLaunchKernelGGL(k_finalize_gated, dim3(nout), dim3(256), 0, s, part, bx, nout, G, k * k, h, ProbeGate{pg.sums, pg.threshold, want, nullptr});
       TRK_LAUNCH_CHECK();
       return TRK_OK;
     }
