@@ -270,3 +270,22 @@ def test_history_modes_on_the_cpu_engine(eng, spec, tmp_path):
     assert np.array_equal(xc0, xc1)
     for j, k in enumerate(ic1["xHistory"].iterations):
         assert np.array_equal(ic1["xHistory"][j], ic0["xHistory"][k])
+
+
+def test_hybrid_gmres_gcv_routes_agree(eng):
+    """Hybrid_GMRES(regparam='gcv') through the bidiagonal form of [bhat | H] — with the search on the library's worker thread one
+    iteration behind (default) or in line — and through the SVD of H as the reference writes it (Hybrid_GMRES.py:54-60): the two
+    bidiagonal forms are the same computation (identical histories), the SVD route agrees on x to 1e-6 (lambda itself moves by up
+    to a few 1e-3 where the GCV minimum is flat: two evaluations of one function a rounding apart)."""
+    g = load_golden("hybrid_gmres_blur32_gcv")
+    A = blur(eng, g)
+    rng = np.random.default_rng(0)
+    b = g["b"] + 0.05 * np.linalg.norm(g["b"]) / np.sqrt(g["b"].size) * rng.standard_normal(g["b"].shape)   # interior GCV minima
+    x1, i1 = S.Hybrid_GMRES(A, b, 40, "gcv", g["x_true"])
+    x2, i2 = S.Hybrid_GMRES(A, b, 40, "gcv", g["x_true"], async_search=False)
+    x3, i3 = S.Hybrid_GMRES(A, b, 40, "gcv", g["x_true"], gcv_by_bidiag=False)
+    assert np.array_equal(x1, x2) and i1["regParam_history"] == i2["regParam_history"] and i1["relResidual"] == i2["relResidual"]
+    assert i1["regParam"] == i1["regParam_history"][-1] and len(i1["xHistory"]) == 40
+    assert relerr(x1, x3) < 1e-6 and np.allclose(i1["relError"], i3["relError"], rtol=1e-6)
+    l1, l3 = np.array(i1["regParam_history"][1:], dtype=float), np.array(i3["regParam_history"][1:], dtype=float)
+    assert np.max(np.abs(l1 / l3 - 1)) < 2e-2

@@ -142,55 +142,102 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             eng.diff_nrm2sq(x_dev, xt, E.ref(ii + 1))
 
     is_dp = isinstance(regparam, str) and regparam == "dp"
-    for ii in range(0 if not on_dev else n_iter, n_iter):
-        k = ii + 1
-        ar.absorb(pend)                      # column k of H; step k+1 runs while the host works on the projected problem
-        pend = ar.step_prefetch() if k < n_iter else None
-        H = ar.H()[:k + 1, :k]
-        if is_dp:
-            bhat = np.zeros(k + 1)
-            bhat[0] = ar.beta0
-            svd = None
-            if ii == 0:
-                lam = 0
-            else:
-                eng.gemv_t(ar.V.data, k + 1, bv, P.ref(0))
-                eng.allreduce(P, 0, k + 1)
-                hb = None
-                if k >= BIDIAG_FROM_K and kwargs.get("dp_by_bidiag", True) and HessenbergBidiag.available() and "explicitProj" not in kwargs:
-                    # the same Newton iteration on the bidiagonal form of [bhat | H] (as 'gcv' above): V^T b in the left basis'
-                    # coordinates; lambda agrees with the SVD route to 1e-15 (tests/test_host_regparam.py)
-                    from ..reg_param.discrepancy_principle import discrepancy_principle_bidiag
-                    hb = HessenbergBidiag(H, ar.beta0)
-                    extra = {key: kwargs[key] for key in ("eta",) if key in kwargs}
-                    lam = discrepancy_principle_bidiag(hb.alphas, hb.betas, hb.left_t(P.host(0, k + 1)), delta=kwargs.get("delta"), **extra)
-                    if lam is None or not lam > 0:
-                        hb = None
-                if hb is not None:
-                    y = hb.back(bidiag_tikhonov_host(hb.alphas, hb.betas, hb.beta0, np.sqrt(lam)))
-                    hy = (H @ y).reshape(-1, 1)
-                    form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
-                    continue
-                if kwargs.get("solve_by_svd", True):
-                    # the SVD discrepancy_principle() takes of H (discrepancy_principle.py:68-70), taken here so that the
-                    # Tikhonov solve below can share it
-                    from ..reg_param.discrepancy_principle import discrepancy_principle
-                    Uf, sv, Vh = sla.svd(H)
-                    extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
-                    lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
-                                                spectrum=(sv, Uf.T @ P.host(0, k + 1).reshape(-1, 1), (k + 1, k)), **extra)
-                    svd = (sv, Vh, Uf[:, :k].T @ bhat)
+    # gcv through the bidiagonal form: the search itself on the library's worker thread, one iteration behind (kwarg async_search)
+    async_gcv = (regparam == "gcv" and not on_dev and kwargs.get("gcv_by_bidiag", True) and kwargs.get("async_search", True)
+                 and HessenbergBidiag.available() and n_iter > BIDIAG_FROM_K)
+    searcher, waiting = None, None
+    if async_gcv:
+        from .. import _lib
+        from .Hybrid_LSQR import _Searcher
+        searcher = _Searcher.borrow(_lib.load())           # (host-only entry points: no GPU involved)
+
+    def finish_waiting():
+        nonlocal waiting
+        jj, hbw, Hw = waiting
+        waiting = None
+        lam_w = searcher.collect()
+        kw_ = jj + 1
+        y = hbw.back(bidiag_tikhonov_host(hbw.alphas, hbw.betas, hbw.beta0, np.sqrt(lam_w)))
+        bh = np.zeros(kw_ + 1)
+        bh[0] = ar.beta0
+        hy = (Hw @ y).reshape(-1, 1)
+        form(jj, lam_w, y, float(np.linalg.norm(bh.reshape(1, -1) - hy)))
+
+    def host_loop():
+        nonlocal pend, waiting, lam
+        for ii in range(0 if not on_dev else n_iter, n_iter):
+            k = ii + 1
+            ar.absorb(pend)                      # column k of H; step k+1 runs while the host works on the projected problem
+            pend = ar.step_prefetch() if k < n_iter else None
+            H = ar.H()[:k + 1, :k]
+            if is_dp:
+                bhat = np.zeros(k + 1)
+                bhat[0] = ar.beta0
+                svd = None
+                if ii == 0:
+                    lam = 0
                 else:
-                    lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=H, dp_bproj=P.host(0, k + 1))
-            if svd is not None and lam > 0 and kwargs.get("solve_by_svd", True):
-                sv, Vh, qb = svd
-                y = Vh.T @ ((sv / (sv * sv + lam)) * qb)
+                    eng.gemv_t(ar.V.data, k + 1, bv, P.ref(0))
+                    eng.allreduce(P, 0, k + 1)
+                    hb = None
+                    if k >= BIDIAG_FROM_K and kwargs.get("dp_by_bidiag", True) and HessenbergBidiag.available() and "explicitProj" not in kwargs:
+                        # the same Newton iteration on the bidiagonal form of [bhat | H] (as 'gcv' above): V^T b in the left basis'
+                        # coordinates; lambda agrees with the SVD route to 1e-15 (tests/test_host_regparam.py)
+                        from ..reg_param.discrepancy_principle import discrepancy_principle_bidiag
+                        hb = HessenbergBidiag(H, ar.beta0)
+                        extra = {key: kwargs[key] for key in ("eta",) if key in kwargs}
+                        lam = discrepancy_principle_bidiag(hb.alphas, hb.betas, hb.left_t(P.host(0, k + 1)), delta=kwargs.get("delta"), **extra)
+                        if lam is None or not lam > 0:
+                            hb = None
+                    if hb is not None:
+                        y = hb.back(bidiag_tikhonov_host(hb.alphas, hb.betas, hb.beta0, np.sqrt(lam)))
+                        hy = (H @ y).reshape(-1, 1)
+                        form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
+                        continue
+                    if kwargs.get("solve_by_svd", True):
+                        # the SVD discrepancy_principle() takes of H (discrepancy_principle.py:68-70), taken here so that the
+                        # Tikhonov solve below can share it
+                        from ..reg_param.discrepancy_principle import discrepancy_principle
+                        Uf, sv, Vh = sla.svd(H)
+                        extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
+                        lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
+                                                    spectrum=(sv, Uf.T @ P.host(0, k + 1).reshape(-1, 1), (k + 1, k)), **extra)
+                        svd = (sv, Vh, Uf[:, :k].T @ bhat)
+                    else:
+                        lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=H, dp_bproj=P.host(0, k + 1))
+                if svd is not None and lam > 0 and kwargs.get("solve_by_svd", True):
+                    sv, Vh, qb = svd
+                    y = Vh.T @ ((sv / (sv * sv + lam)) * qb)
+                else:
+                    y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
+                hy = (H @ y).reshape(-1, 1)
+                form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
+                continue
+            if async_gcv and k >= BIDIAG_FROM_K:
+                # lambda_k is searched on the library's worker thread (trk_host_worker_*, as Hybrid-LSQR does) while this thread finishes
+                # iterate k - 1 — its Tikhonov solve, back-transformation and the launch that forms x_{k-1} — and waits for step k + 1
+                hb = HessenbergBidiag(np.array(H, copy=True), ar.beta0)
+                if waiting is not None:
+                    finish_waiting()
+                searcher.post_gcv(hb.alphas, hb.betas, hb.beta0, k)
+                waiting = (ii, hb, np.array(H, copy=True))
+                continue
+            if waiting is not None:
+                finish_waiting()
+            form(ii, *projected(k, H, ii == 0))
+        if waiting is not None:
+            finish_waiting()
+
+    clean = False
+    try:
+        host_loop()
+        clean = True
+    finally:
+        if searcher is not None:
+            if clean:
+                searcher.give_back()
             else:
-                y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
-            hy = (H @ y).reshape(-1, 1)
-            form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
-            continue
-        form(ii, *projected(k, H, ii == 0))
+                searcher.close()             # (a job may still be posted: destroy waits for it)
     if lams:
         lam = lams[-1]
     if x_dev is None:
