@@ -1538,7 +1538,13 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
                                                     ProbeGate pg) {
   // 'auto' arithmetic (trk_wgram_tv_precision): the launch is one of a pair — two bf16 pieces / the fp32 pipe — of which the probe's
   // verdict (worked out by every workgroup from the probe's 20 finished sums: no launch for it) lets exactly one run; the other leaves at once
-  if (pg.sums && probe_verdict(pg, blockIdx.x == 0 && threadIdx.x == 0) != pg.want) return;
+  // BF == 4: ONE launch holds both arithmetics and the verdict picks per launch (uniform branch in the step) — no idle launches
+  bool use_f32 = false;
+  if constexpr (BF == 4) {
+    use_f32 = pg.sums && probe_verdict(pg, blockIdx.x == 0 && threadIdx.x == 0) != 0;
+  } else {
+    if (pg.sums && probe_verdict(pg, blockIdx.x == 0 && threadIdx.x == 0) != pg.want) return;
+  }
   constexpr int NP = T * (T + 1) / 2;
   const int lockstep = lockstep_in & 1;
   const bool no_xcd_map = (lockstep_in & 2) != 0;                // TRK_WGRAM_TV_NO_XCD=1: the round-robin unit order (A/B)
@@ -1582,6 +1588,11 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
   // eight seams.  Needs the groups of a band to divide by 8 (N a multiple of 1024) and a grid that is a multiple of 8.
   const int groups = strips / (NT / 64);
   const bool xcd_map = strips % (NT / 64) == 0 && (groups & 7) == 0 && (gridDim.x & 7) == 0 && !no_xcd_map;   // (uniform)
+  // The whole sweep once per arithmetic AR (0 fp32 pipe, 2 / 3 bf16 pieces).  BF == 4 ('auto') instantiates it twice under ONE uniform
+  // branch on the probe's verdict: both forms in one launch, each with its own register allocation (a branch inside the step made
+  // the allocator keep both forms' operands live: 34-99 spilled registers).
+  auto run = [&](auto arith_tag) {
+  constexpr int AR = decltype(arith_tag)::value;
   for (int64_t it = 0;; ++it) {
     int64_t u;
     if (xcd_map) {
@@ -1690,7 +1701,7 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
         dv[t][7] = (b.w - d.w) * wv1.w;
       }
       int p = 0;
-      if constexpr (BF == 3) {
+      if constexpr (AR == 3) {
         // one direction at a time (its three pieces die before the other direction's are made: the register file is the limit here)
         auto dir = [&](const float (&dd)[T][8]) {
           bf8v ph[T], pm[T], pl[T];
@@ -1711,38 +1722,46 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
         };
         dir(dh);
         dir(dv);
-      } else if constexpr (BF == 2) {
-        bf8v hh[T], hl[T], vh[T], vl[T];
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          bf16_split8(dh[t], hh[t], hl[t]);
-          bf16_split8(dv[t], vh[t], vl[t]);
-        }
-#pragma unroll
-        for (int ta = 0; ta < T; ++ta)
-#pragma unroll
-          for (int tb = ta; tb < T; ++tb, ++p) {
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[ta], hl[tb], acc[p], 0, 0, 0);      // smallest terms first
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[ta], vl[tb], acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[ta], hl[tb], acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[ta], hh[tb], acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ta], vl[tb], acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[ta], vh[tb], acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[ta], hh[tb], acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ta], vh[tb], acc[p], 0, 0, 0);
-          }
       } else {
+        auto two_pieces = [&]() {
+          bf8v hh[T], hl[T], vh[T], vl[T];
 #pragma unroll
-      for (int ta = 0; ta < T; ++ta)
-#pragma unroll
-        for (int tb = ta; tb < T; ++tb, ++p) {
-#pragma unroll
-          for (int c = 0; c < 8; ++c) {
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[ta][c], dh[tb][c], acc[p], 0, 0, 0);
-            acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[ta][c], dv[tb][c], acc[p], 0, 0, 0);
+          for (int t = 0; t < T; ++t) {
+            bf16_split8(dh[t], hh[t], hl[t]);
+            bf16_split8(dv[t], vh[t], vl[t]);
           }
-        }
+          int pp = 0;
+#pragma unroll
+          for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+            for (int tb = ta; tb < T; ++tb, ++pp) {
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[ta], hl[tb], acc[pp], 0, 0, 0);      // smallest terms first
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[ta], vl[tb], acc[pp], 0, 0, 0);
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[ta], hl[tb], acc[pp], 0, 0, 0);
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[ta], hh[tb], acc[pp], 0, 0, 0);
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ta], vl[tb], acc[pp], 0, 0, 0);
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[ta], vh[tb], acc[pp], 0, 0, 0);
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[ta], hh[tb], acc[pp], 0, 0, 0);
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ta], vh[tb], acc[pp], 0, 0, 0);
+            }
+        };
+        auto fp32_pipe = [&]() {
+          int pp = 0;
+#pragma unroll
+          for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+            for (int tb = ta; tb < T; ++tb, ++pp) {
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {
+                acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[ta][c], dh[tb][c], acc[pp], 0, 0, 0);
+                acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[ta][c], dv[tb][c], acc[pp], 0, 0, 0);
+              }
+            }
+        };
+        if constexpr (AR == 2) two_pieces();
+        else fp32_pipe();
       }
+      (void)p;
 #pragma unroll
       for (int p2 = 0; p2 < NP; ++p2)
 #pragma unroll
@@ -1771,6 +1790,13 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
         step(P[j], P[(j + 1) % D], i + j);
       }
     }
+  }
+  };
+  if constexpr (BF == 4) {
+    if (use_f32) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 2>{});
+  } else {
+    run(std::integral_constant<int, BF>{});
   }
   // combine the 4 waves (fixed order) and write the block partial in matrix order (16x16 C/D map: lane (r, sl), register q
   // holds D[4 sl + q][r])
@@ -2439,7 +2465,8 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   // arith: 0 fp32 pipe, 2 / 3 bf16 pieces; want: with a probe, the launch runs iff the probe's verdict equals it
 #define WTV(TT, ZZ, ARITH, WANT)                                                                                                                      \
   do {                                                                                                                                                \
-    if ((ARITH) == 0) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 0>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record}); \
+    if ((ARITH) == 4) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 4>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, 0, pg.record}); \
+    else if ((ARITH) == 0) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 0>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record}); \
     else if ((ARITH) == 2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record}); \
     else if (TT == 2 && !ZZ && occ2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record}); \
     else hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record});           \
@@ -2452,7 +2479,7 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
     else { if (T16 == 1) WTV(1, false, arith, want); else if (T16 == 2) WTV(2, false, arith, want); else WTV(3, false, arith, want); }
     TRK_LAUNCH_CHECK();
     const int nout = two_pass ? k * k : nv;
-    if (pg.sums) {
+    if (pg.sums && arith != 4) {
       hipLaunchKernelGGL(k_finalize_gated, dim3(nout), dim3(256), 0, s, part, bx, nout, G, k * k, h, ProbeGate{pg.sums, pg.threshold, want, nullptr});
       TRK_LAUNCH_CHECK();
       return TRK_OK;
@@ -2460,9 +2487,12 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
     if (z && !two_pass) return finalize_sums_split(part, bx, nv, nv, G, k * k, h, s);
     return finalize_sums(part, bx, k * k, k * k, G, s);
   };
-  if (mode == 1) {
+  static const int auto_pair = env_int("TRK_WGRAM_TV_AUTO_PAIR", 0);     // 1: the gated pair of launches instead of one launch with both forms (A/B)
+  if (mode == 1 && auto_pair) {
     if (int rc = pass(2, 0)) return rc;
     if (int rc = pass(0, 1)) return rc;
+  } else if (mode == 1) {
+    if (int rc = pass(4, 0)) return rc;
   } else {
     if (int rc = pass(mode, 0)) return rc;
   }
