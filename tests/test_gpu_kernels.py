@@ -245,7 +245,10 @@ def test_gemv_t_with_one_more_row(eng, k, n):
 
 @pytest.mark.parametrize("N,k", [(32, 1), (32, 5), (64, 16), (64, 17), (96, 7), (96, 32), (160, 33), (128, 48), (512, 20), (1024, 3),
                                  # a multiple of four strips: the workgroup's waves in step, the right-neighbour column through LDS
-                                 (128, 16), (256, 13), (384, 30), (256, 25)])
+                                 (128, 16), (256, 13), (384, 30), (256, 25),
+                                 # 256-column tiles staged through LDS (k_wgram_tv_lds: N a multiple of 256 from 2048 on, k <= 32):
+                                 # one and two tiles of vectors, tile counts that do and do not deal evenly to the XCDs; 33: the register-fed kernel
+                                 (2048, 5), (2048, 16), (2048, 17), (2048, 24), (2048, 32), (2304, 20), (2048, 33)])
 def test_wgram_tv_from_v_equals_the_gram_of_the_stored_images(eng, N, k):
     """trk_wgram_tv (the weighted Gram of L V formed from V, L the 2-D first difference) against (i) the float64 definition on the
     oracle's L and (ii) trk_wgram over the stored images L v_j: all tile counts, bands that do not divide N, the image's right

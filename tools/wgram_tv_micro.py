@@ -2,6 +2,10 @@
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+if os.environ.get("TRK_EXPERIMENT_LIB"):          # a library built with experiment macros (tools/r05_wgram_exp.sh): timing only
+    from trips_py_amd import _lib as _L
+    _L.LIB_PATH = os.environ["TRK_EXPERIMENT_LIB"]
+    _L._stale = lambda: False
 from trips_py_amd.engine import default_engine
 from trips_py_amd.operators import FirstDerivative2D
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096

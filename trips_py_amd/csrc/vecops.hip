@@ -1531,6 +1531,108 @@ __device__ __forceinline__ void bf16_split8x3(const float (&d)[8], bf8v& hi, bf8
     lo[c] = (__bf16)(r1 - (float)mid[c]);
   }
 }
+// The arithmetic of one image row of a 32-column strip (k_wgram_tv and k_wgram_tv_lds): lane (r, sl) holds, per 16-vector tile t, the eight
+// pixels Px[t] of image row i and Qx[t] of the row below, nbr[t] = the pixel right of the strip (used by the last quarter only), and the
+// row's weights for its eight columns; the weighted differences' tile products in the arithmetic AR (0 fp32 pipe, 2 / 3 bf16 pieces),
+// flushed into the float64 accumulators.
+template <int T, int AR>
+__device__ __forceinline__ void tv_row_products(const float4 (&Px)[T][2], const float4 (&Qx)[T][2], const float (&nbr)[T], int up16, int sl,
+                                                const float4& wh0, const float4& wh1, const float4& wv0, const float4& wv1,
+                                                double (&accd)[T * (T + 1) / 2][4]) {
+  constexpr int NP = T * (T + 1) / 2;
+    f4v acc[NP];
+#pragma unroll
+    for (int p = 0; p < NP; ++p) acc[p] = (f4v){0.f, 0.f, 0.f, 0.f};
+    float dh[T][8], dv[T][8];
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      const float4 a = Px[t][0], b = Px[t][1], c = Qx[t][0], d = Qx[t][1];
+      // the pixel right of this lane's eight: lane l + 16 holds it as its first, the last quarter takes the next strip's
+      float right = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(up16, __builtin_bit_cast(int, a.x)));
+      right = sl == 3 ? nbr[t] : right;
+      dh[t][0] = (a.x - a.y) * wh0.x;
+      dh[t][1] = (a.y - a.z) * wh0.y;
+      dh[t][2] = (a.z - a.w) * wh0.z;
+      dh[t][3] = (a.w - b.x) * wh0.w;
+      dh[t][4] = (b.x - b.y) * wh1.x;
+      dh[t][5] = (b.y - b.z) * wh1.y;
+      dh[t][6] = (b.z - b.w) * wh1.z;
+      dh[t][7] = (b.w - right) * wh1.w;
+      dv[t][0] = (a.x - c.x) * wv0.x;
+      dv[t][1] = (a.y - c.y) * wv0.y;
+      dv[t][2] = (a.z - c.z) * wv0.z;
+      dv[t][3] = (a.w - c.w) * wv0.w;
+      dv[t][4] = (b.x - d.x) * wv1.x;
+      dv[t][5] = (b.y - d.y) * wv1.y;
+      dv[t][6] = (b.z - d.z) * wv1.z;
+      dv[t][7] = (b.w - d.w) * wv1.w;
+    }
+    if constexpr (AR == 3) {
+      // one direction at a time (its three pieces die before the other direction's are made: the register file is the limit here)
+      auto dir = [&](const float (&dd)[T][8]) {
+        bf8v ph[T], pm[T], pl[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) bf16_split8x3(dd[t], ph[t], pm[t], pl[t]);
+        int pp = 0;
+#pragma unroll
+        for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+          for (int tb = ta; tb < T; ++tb, ++pp) {
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[ta], pl[tb], acc[pp], 0, 0, 0);      // smallest terms first
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[ta], ph[tb], acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm[ta], pm[tb], acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[ta], pm[tb], acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm[ta], ph[tb], acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[ta], ph[tb], acc[pp], 0, 0, 0);
+          }
+      };
+      dir(dh);
+      dir(dv);
+    } else {
+      auto two_pieces = [&]() {
+        bf8v hh[T], hl[T], vh[T], vl[T];
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          bf16_split8(dh[t], hh[t], hl[t]);
+          bf16_split8(dv[t], vh[t], vl[t]);
+        }
+        int pp = 0;
+#pragma unroll
+        for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+          for (int tb = ta; tb < T; ++tb, ++pp) {
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[ta], hl[tb], acc[pp], 0, 0, 0);      // smallest terms first
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[ta], vl[tb], acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[ta], hl[tb], acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[ta], hh[tb], acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ta], vl[tb], acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[ta], vh[tb], acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[ta], hh[tb], acc[pp], 0, 0, 0);
+            acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ta], vh[tb], acc[pp], 0, 0, 0);
+          }
+      };
+      auto fp32_pipe = [&]() {
+        int pp = 0;
+#pragma unroll
+        for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+          for (int tb = ta; tb < T; ++tb, ++pp) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[ta][c], dh[tb][c], acc[pp], 0, 0, 0);
+              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[ta][c], dv[tb][c], acc[pp], 0, 0, 0);
+            }
+          }
+      };
+      if constexpr (AR == 2) two_pieces();
+      else fp32_pipe();
+    }
+#pragma unroll
+    for (int p2 = 0; p2 < NP; ++p2)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) accd[p2][q] += (double)acc[p2][q];
+}
+
 template <int T, bool Z, int D, int BF = 3, int MINB = (D > 3 ? 1 : T == 1 ? 4 : (T == 2 && !Z) ? 3 : 2)>
 __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__ V, int64_t ld, int k, int N,
                                                     const float* __restrict__ w, int nbands, int band_rows,
@@ -1548,6 +1650,13 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
   constexpr int NP = T * (T + 1) / 2;
   const int lockstep = lockstep_in & 1;
   const bool no_xcd_map = (lockstep_in & 2) != 0;                // TRK_WGRAM_TV_NO_XCD=1: the round-robin unit order (A/B)
+#ifdef TRK_WGRAM_TV_EXPERIMENT
+  // timing experiments only (tools/r05_wgram_exp.sh builds a separate library with this macro; the product never defines it and
+  // the results are WRONG with either bit): 4 = no wave fetches the column right of its strips, 8 = the loads alone, no arithmetic
+  const bool x_nohalo = (lockstep_in & 4) != 0, x_loadonly = (lockstep_in & 8) != 0;
+#else
+  constexpr bool x_nohalo = false, x_loadonly = false;
+#endif
   __shared__ double red[3][4][64];
   __shared__ __attribute__((aligned(16))) float wl[NT / 64][Z ? 96 : 64];
   // lockstep (the launcher's choice when the workgroup's four waves always own four neighbouring strips of one band): the pixel
@@ -1613,7 +1722,7 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
     const int c0 = cs + 8 * sl;
     const bool last_strip = cs + 32 >= N;                        // (uniform) no pixel right of this strip
     const int nxo = last_strip ? 31 : 32;                        // clamped: a valid address, met by a zero weight
-    const bool need_nx = !lockstep || wave == NT / 64 - 1;       // (uniform per wave)
+    const bool need_nx = (!lockstep || wave == NT / 64 - 1) && !x_nohalo;   // (uniform per wave)
 
     // every load is unconditional (clamped addresses, zeroed weights instead of branches): all loads of a row are in flight together
     auto load = [&](TvRow<T>& P, int i) {
@@ -1636,6 +1745,11 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
       }
     };
     auto step = [&](const TvRow<T>& P, const TvRow<T>& Q, int i) {   // P: image row i, Q: the one below
+      if (x_loadonly) {
+#pragma unroll
+        for (int t = 0; t < T; ++t) accz[t] += (double)(P.x[t][0].x + P.x[t][1].w + P.nx[t] + P.w + (Z ? P.z : 0.f));
+        return;
+      }
       float nbr[T];
 #pragma unroll
       for (int t = 0; t < T; ++t) nbr[t] = P.nx[t];
@@ -1673,99 +1787,7 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
                      (double)b.x * z1.x + (double)b.y * z1.y + (double)b.z * z1.z + (double)b.w * z1.w;
         }
       }
-      f4v acc[NP];
-#pragma unroll
-      for (int p = 0; p < NP; ++p) acc[p] = (f4v){0.f, 0.f, 0.f, 0.f};
-      float dh[T][8], dv[T][8];
-#pragma unroll
-      for (int t = 0; t < T; ++t) {
-        const float4 a = P.x[t][0], b = P.x[t][1], c = Q.x[t][0], d = Q.x[t][1];
-        // the pixel right of this lane's eight: lane l + 16 holds it as its first, the last quarter takes the next strip's
-        float right = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(up16, __builtin_bit_cast(int, a.x)));
-        right = sl == 3 ? nbr[t] : right;
-        dh[t][0] = (a.x - a.y) * wh0.x;
-        dh[t][1] = (a.y - a.z) * wh0.y;
-        dh[t][2] = (a.z - a.w) * wh0.z;
-        dh[t][3] = (a.w - b.x) * wh0.w;
-        dh[t][4] = (b.x - b.y) * wh1.x;
-        dh[t][5] = (b.y - b.z) * wh1.y;
-        dh[t][6] = (b.z - b.w) * wh1.z;
-        dh[t][7] = (b.w - right) * wh1.w;
-        dv[t][0] = (a.x - c.x) * wv0.x;
-        dv[t][1] = (a.y - c.y) * wv0.y;
-        dv[t][2] = (a.z - c.z) * wv0.z;
-        dv[t][3] = (a.w - c.w) * wv0.w;
-        dv[t][4] = (b.x - d.x) * wv1.x;
-        dv[t][5] = (b.y - d.y) * wv1.y;
-        dv[t][6] = (b.z - d.z) * wv1.z;
-        dv[t][7] = (b.w - d.w) * wv1.w;
-      }
-      int p = 0;
-      if constexpr (AR == 3) {
-        // one direction at a time (its three pieces die before the other direction's are made: the register file is the limit here)
-        auto dir = [&](const float (&dd)[T][8]) {
-          bf8v ph[T], pm[T], pl[T];
-#pragma unroll
-          for (int t = 0; t < T; ++t) bf16_split8x3(dd[t], ph[t], pm[t], pl[t]);
-          int pp = 0;
-#pragma unroll
-          for (int ta = 0; ta < T; ++ta)
-#pragma unroll
-            for (int tb = ta; tb < T; ++tb, ++pp) {
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[ta], pl[tb], acc[pp], 0, 0, 0);      // smallest terms first
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pl[ta], ph[tb], acc[pp], 0, 0, 0);
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm[ta], pm[tb], acc[pp], 0, 0, 0);
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[ta], pm[tb], acc[pp], 0, 0, 0);
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pm[ta], ph[tb], acc[pp], 0, 0, 0);
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ph[ta], ph[tb], acc[pp], 0, 0, 0);
-            }
-        };
-        dir(dh);
-        dir(dv);
-      } else {
-        auto two_pieces = [&]() {
-          bf8v hh[T], hl[T], vh[T], vl[T];
-#pragma unroll
-          for (int t = 0; t < T; ++t) {
-            bf16_split8(dh[t], hh[t], hl[t]);
-            bf16_split8(dv[t], vh[t], vl[t]);
-          }
-          int pp = 0;
-#pragma unroll
-          for (int ta = 0; ta < T; ++ta)
-#pragma unroll
-            for (int tb = ta; tb < T; ++tb, ++pp) {
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[ta], hl[tb], acc[pp], 0, 0, 0);      // smallest terms first
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[ta], vl[tb], acc[pp], 0, 0, 0);
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[ta], hl[tb], acc[pp], 0, 0, 0);
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hl[ta], hh[tb], acc[pp], 0, 0, 0);
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ta], vl[tb], acc[pp], 0, 0, 0);
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vl[ta], vh[tb], acc[pp], 0, 0, 0);
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(hh[ta], hh[tb], acc[pp], 0, 0, 0);
-              acc[pp] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vh[ta], vh[tb], acc[pp], 0, 0, 0);
-            }
-        };
-        auto fp32_pipe = [&]() {
-          int pp = 0;
-#pragma unroll
-          for (int ta = 0; ta < T; ++ta)
-#pragma unroll
-            for (int tb = ta; tb < T; ++tb, ++pp) {
-#pragma unroll
-              for (int c = 0; c < 8; ++c) {
-                acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(dh[ta][c], dh[tb][c], acc[pp], 0, 0, 0);
-                acc[pp] = __builtin_amdgcn_mfma_f32_16x16x4f32(dv[ta][c], dv[tb][c], acc[pp], 0, 0, 0);
-              }
-            }
-        };
-        if constexpr (AR == 2) two_pieces();
-        else fp32_pipe();
-      }
-      (void)p;
-#pragma unroll
-      for (int p2 = 0; p2 < NP; ++p2)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) accd[p2][q] += (double)acc[p2][q];
+      tv_row_products<T, AR>(P.x, Q.x, nbr, up16, sl, wh0, wh1, wv0, wv1, accd);
     };
 
     TvRow<T> P[D];                                               // a ring: row i sits in P[(i - i0) % D]; indices are compile-time below
@@ -1839,6 +1861,301 @@ __global__ __launch_bounds__(NT, MINB) void k_wgram_tv(const float* __restrict__
     if (threadIdx.x < 16 * T) {
       const int row = threadIdx.x;
       const double t = ((red[0][0][row] + red[0][1][row]) + red[0][2][row]) + red[0][3][row];
+      if (row < k) out[(size_t)k * k + row] = t;
+    }
+  }
+}
+
+// ------------------------------------------------------------------ the same pass, the rows of V through LDS in FULL lines (round 5)
+// k_wgram_tv's loads are fragment-shaped: one wave-instruction touches 16 basis vectors x 64 bytes, a workgroup 512 contiguous bytes
+// per (vector, image row) — the loads ALONE take the kernel's whole time (tools/r05_wgram_exp.sh: k = 32 at 4096^2 576 us with the
+// arithmetic removed, 545 with it; 3.9 TB/s where the plain streams of k_gemv_n run at 5.9).  Here a workgroup of 8 waves owns 256
+// image columns: every (vector, image row) of its tile is ONE 1 KiB global_load_lds_dwordx4 (a whole wave reading 1 KiB of one
+// row of one basis vector) straight into an LDS stage, four stages deep — two image rows in flight per CU without a register held
+// for them — and the waves take their MFMA operands from LDS.  The LDS image of a (vector, row) piece has its 16-byte slots XOR-ed with
+// the vector's index mod 16 (applied to the per-lane SOURCE address of the load: the LDS side of such a load is lane-linear): the four
+// 16-lane groups of a ds_read_b128 — {0-3, 12-15, 20-27}, .. — then meet 16 different slots (padding the rows to 260 floats does
+// not do it: 61 % of the LDS cycles were bank conflicts, SQ_LDS_BANK_CONFLICT).  The pixel right of a wave's strip is the next strip's first pixel in the same stage; the column right
+// of the TILE comes with the stage as one dword per vector.  The row's weights and the row of z arrive the same way (no load of the
+// loop has a register destination: one vmcnt queue, counted by hand, raw barriers — a __syncthreads() would drain it).
+// Arithmetic, block partials and their order: exactly k_wgram_tv's (tv_row_products).  N a multiple of 256, k <= 32.
+constexpr int LW_NW = 8, LW_NT = 64 * LW_NW, LW_COLS = 32 * LW_NW, LW_RS = LW_COLS, LW_S = 4;
+constexpr int LW_WH = 0, LW_WV = 256, LW_Z = 512, LW_HALO = 768, LW_XF = 832;      // the extras of a stage, in floats after its rows
+__device__ __forceinline__ void glds16(const float* g, unsigned lds) {              // lane l: 16 bytes at g -> LDS byte lds + 16 l
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+__device__ __forceinline__ void glds4(const float* g, unsigned lds) {               // lane l: 4 bytes at g -> LDS byte lds + 4 l
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(g), "s"(lds) : "memory");
+}
+// LDS reads the compiler may not take apart (it split the float4 reads of a row into b64 / b32 / read2_b32 pieces: 18 LDS instructions
+// per step instead of 12, most of them on the 32-bank paths): issued as written, waited for by hand (lds_wait), and the values tied to
+// the wait (lds_tie) so that no use is scheduled before it.
+__device__ __forceinline__ f4v lds_r128(const float* p) {
+  f4v v;
+  asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const float*)p) : "memory");
+  return v;
+}
+__device__ __forceinline__ float lds_r32(const float* p) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const float*)p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+template <class X>
+__device__ __forceinline__ void lds_tie(X& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ float4 as_float4(const f4v& v) { return make_float4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void wait_vm_le(int n) {                                 // (n: wave-uniform, <= 10)
+  switch (n) {
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+  }
+}
+template <int T>
+struct LwRow {
+  float4 x[T][2];      // lane (r, sl): 8 pixels of vector 16 t + r at columns 32 wave + 8 sl ..
+  float nx[T];         // the pixel right of the wave's strip
+};
+template <int T, bool Z, int BF>
+__global__ __launch_bounds__(LW_NT, T == 1 ? 4 : 2) void k_wgram_tv_lds(const float* __restrict__ V, int64_t ld, int k, int N,
+                                                           const float* __restrict__ w, int nbands, int band_rows,
+                                                           double* __restrict__ partials, const float* __restrict__ z, int flags,
+                                                           ProbeGate pg) {
+  bool use_f32 = false;
+  if constexpr (BF == 4) {
+    use_f32 = pg.sums && probe_verdict(pg, blockIdx.x == 0 && threadIdx.x == 0) != 0;
+  } else {
+    if (pg.sums && probe_verdict(pg, blockIdx.x == 0 && threadIdx.x == 0) != pg.want) return;
+  }
+  constexpr int NP = T * (T + 1) / 2, NV = 16 * T, SF = NV * LW_RS + LW_XF;
+  __shared__ __attribute__((aligned(16))) float smem[LW_S * SF];                  // (ALL of the kernel's LDS: the sums at the end alias it)
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63, r = lane & 15, sl = lane >> 4;
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) float*)smem;
+  const float* __restrict__ wh = w;
+  const float* __restrict__ wv = w + (int64_t)N * (N - 1);
+  const int up16 = ((lane + 16) & 63) << 2;
+  // rows of vectors beyond the basis are never loaded: zero in every stage (their Gram entries are never stored; finite all the same)
+  for (int s = 0; s < LW_S; ++s)
+    for (int v = k; v < NV; ++v)
+      for (int c = threadIdx.x; c < LW_RS; c += LW_NT) smem[s * SF + v * LW_RS + c] = 0.f;
+  // this wave's pieces of a stage: the vectors wave, wave + 8, .. below k, and one of the extras
+  int nv_mine = 0;
+#pragma unroll
+  for (int j = 0; j < 2 * T; ++j) nv_mine += (wave + 8 * j < k) ? 1 : 0;
+  const bool has_extra = wave <= 4 || (wave == 5 && Z) || wave == 6;
+  const int npw = nv_mine + (has_extra ? 1 : 0);
+  double accd[NP][4];
+#pragma unroll
+  for (int p = 0; p < NP; ++p)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) accd[p][q] = 0.0;
+  double accz[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) accz[t] = 0.0;
+  const int tiles = N / LW_COLS;
+  const int64_t units = (int64_t)tiles * nbands;
+  const bool xcd_map = (tiles & 7) == 0 && (gridDim.x & 7) == 0 && (flags & 2) == 0;      // (uniform) as in k_wgram_tv: an XCD's tiles are neighbours
+  __syncthreads();
+
+  auto run = [&](auto arith_tag) {
+  constexpr int AR = decltype(arith_tag)::value;
+  for (int64_t U = blockIdx.x; U < units; U += gridDim.x) {
+    int band, tile;
+    if (xcd_map) {
+      const int per = tiles >> 3;
+      const int64_t q = U >> 3;
+      band = (int)(q / per);
+      tile = (int)(U & 7) * per + (int)(q - (int64_t)band * per);
+    } else {
+      band = (int)(U / tiles);
+      tile = (int)(U - (int64_t)band * tiles);
+    }
+    const int i0 = band * band_rows, i1 = (i0 + band_rows < N) ? i0 + band_rows : N;
+    const int c0 = LW_COLS * tile;
+    const bool last_tile = c0 + LW_COLS >= N;                    // (uniform)
+    const int halo_col = last_tile ? N - 1 : c0 + LW_COLS;       // clamped: a valid address, met by a zero weight
+
+    auto issue = [&](int i) {                                    // image row i -> stage i & 3
+      const int ic = i < N ? i : N - 1;
+      const int64_t e = (int64_t)ic * N;
+      const int iv = ic < N - 1 ? ic : N - 2;
+      const unsigned sb = lds0 + (unsigned)((i & (LW_S - 1)) * SF) * 4u;
+#pragma unroll
+      for (int j = 0; j < 2 * T; ++j) {
+        const int v = wave + 8 * j;
+        if (v < k) glds16(V + (int64_t)v * ld + e + c0 + 4 * (lane ^ (v & 15)), sb + (unsigned)(v * LW_RS) * 4u);
+      }
+      const unsigned xb = sb + (unsigned)(NV * LW_RS) * 4u;
+      if (wave < 4) glds4(wh + (int64_t)ic * (N - 1) + c0 + 64 * wave + lane, xb + (unsigned)(LW_WH + 64 * wave) * 4u);
+      else if (wave == 4) glds16(wv + (int64_t)iv * N + c0 + 4 * lane, xb + LW_WV * 4u);
+      else if (wave == 5) { if (Z) glds16(z + e + c0 + 4 * lane, xb + LW_Z * 4u); }
+      else if (wave == 6) {
+        const int hv = (lane & (NV - 1)) < k ? (lane & (NV - 1)) : 0;
+        glds4(V + (int64_t)hv * ld + e + halo_col, xb + LW_HALO * 4u);
+      }
+    };
+    // RAW: the reads as hand-issued ds_read_b128 (every value used only after lds_wait + lds_tie).  Measured per form: without the dots
+    // the compiler takes the float4 reads apart (18 LDS instructions per step, 53 % of the LDS cycles bank conflicts; raw reads 415 us
+    // against 428 at k = 24); with them it keeps them whole and schedules around its own waits better than one lds_wait does (435 us
+    // against 463).
+    constexpr bool RAW = !Z;
+    auto fetch_raw = [&](f4v (&x)[T][2], float (&nx)[T], int i) {   // the wave's operands of image row i, from its stage
+      const float* S = smem + (i & (LW_S - 1)) * SF;
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        const float* row = S + (16 * t + r) * LW_RS;             // slot q of the row sits at slot q ^ r
+        const int q = 8 * wave + 2 * sl;
+        const float* np = wave < LW_NW - 1 ? row + 4 * ((8 * wave + 8) ^ r) : S + NV * LW_RS + LW_HALO + 16 * t + r;
+        if constexpr (RAW) {
+          x[t][0] = lds_r128(row + 4 * (q ^ r));
+          x[t][1] = lds_r128(row + 4 * ((q + 1) ^ r));
+          nx[t] = lds_r32(np);
+        } else {
+          x[t][0] = *reinterpret_cast<const f4v*>(row + 4 * (q ^ r));
+          x[t][1] = *reinterpret_cast<const f4v*>(row + 4 * ((q + 1) ^ r));
+          nx[t] = *np;
+        }
+      }
+    };
+    auto settle = [&](LwRow<T>& R, f4v (&x)[T][2], float (&nx)[T]) {
+#pragma unroll
+      for (int t = 0; t < T; ++t) {
+        if constexpr (RAW) {
+          lds_tie(x[t][0]);
+          lds_tie(x[t][1]);
+          lds_tie(nx[t]);
+        }
+        R.x[t][0] = as_float4(x[t][0]);
+        R.x[t][1] = as_float4(x[t][1]);
+        R.nx[t] = nx[t];
+      }
+    };
+    auto step = [&](const LwRow<T>& P, LwRow<T>& Q, int i) {     // P: image row i (held), Q: the row below (fetched here)
+      wait_vm_le(i + 2 <= i1 ? npw : 0);                         // row i + 1 has landed (this wave's pieces); row i + 2 may be in flight
+      __builtin_amdgcn_s_barrier();                              // ... everybody's; and everybody has left step i - 1
+      if (i + 3 <= i1) issue(i + 3);                             // into the stage of row i - 1
+      const float* X = smem + (i & (LW_S - 1)) * SF + NV * LW_RS + 32 * wave + 8 * sl;
+      f4v rwh0, rwh1, rwv0, rwv1, rz0 = {0.f, 0.f, 0.f, 0.f}, rz1 = rz0;
+      if constexpr (RAW) {
+        rwh0 = lds_r128(X + LW_WH), rwh1 = lds_r128(X + LW_WH + 4), rwv0 = lds_r128(X + LW_WV), rwv1 = lds_r128(X + LW_WV + 4);
+      } else {
+        rwh0 = *reinterpret_cast<const f4v*>(X + LW_WH), rwh1 = *reinterpret_cast<const f4v*>(X + LW_WH + 4);
+        rwv0 = *reinterpret_cast<const f4v*>(X + LW_WV), rwv1 = *reinterpret_cast<const f4v*>(X + LW_WV + 4);
+        if (Z) {
+          rz0 = *reinterpret_cast<const f4v*>(X + LW_Z);
+          rz1 = *reinterpret_cast<const f4v*>(X + LW_Z + 4);
+        }
+      }
+      f4v qx[T][2];
+      float qn[T];
+      fetch_raw(qx, qn, i + 1);
+      if constexpr (RAW) {
+        lds_wait();
+        lds_tie(rwh0); lds_tie(rwh1); lds_tie(rwv0); lds_tie(rwv1);
+      }
+      settle(Q, qx, qn);
+      float4 wh0 = as_float4(rwh0), wh1 = as_float4(rwh1), wv0 = as_float4(rwv0), wv1 = as_float4(rwv1);
+      if (last_tile && wave == LW_NW - 1 && sl == 3) wh1.w = 0.f;      // column N - 1 has no right neighbour
+      if (i >= N - 1) {                                                // row N - 1 has none below
+        wv0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        wv1 = wv0;
+      }
+      if (Z) {
+        const float4 z0 = as_float4(rz0), z1 = as_float4(rz1);
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const float4 a = P.x[t][0], b = P.x[t][1];
+          accz[t] += (double)a.x * z0.x + (double)a.y * z0.y + (double)a.z * z0.z + (double)a.w * z0.w +
+                     (double)b.x * z1.x + (double)b.y * z1.y + (double)b.z * z1.z + (double)b.w * z1.w;
+        }
+      }
+      tv_row_products<T, AR>(P.x, Q.x, P.nx, up16, sl, wh0, wh1, wv0, wv1, accd);
+    };
+
+    LwRow<T> A, B;
+    __builtin_amdgcn_s_barrier();                                // the previous unit's last rows have been read
+    issue(i0);
+    issue(i0 + 1);
+    issue(i0 + 2);
+    wait_vm_le(2 * npw);
+    __builtin_amdgcn_s_barrier();
+    {
+      f4v ax[T][2];
+      float an[T];
+      fetch_raw(ax, an, i0);
+      if constexpr (RAW) lds_wait();
+      settle(A, ax, an);
+    }
+    int i = i0;
+    for (; i + 2 <= i1; i += 2) {                                // roles alternate: no register copies
+      step(A, B, i);
+      step(B, A, i + 1);
+    }
+    if (i < i1) step(A, B, i);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");             // (rows past a band shorter than the prologue's three)
+  }
+  };
+  if constexpr (BF == 4) {
+    if (use_f32) run(std::integral_constant<int, 0>{});
+    else run(std::integral_constant<int, 2>{});
+  } else {
+    run(std::integral_constant<int, BF>{});
+  }
+  // combine the 8 waves (fixed order) and write the block partial in matrix order, as k_wgram_tv does
+  __syncthreads();
+  double* red = reinterpret_cast<double*>(smem);                 // [7][4][64]
+  double* __restrict__ out = partials + (size_t)blockIdx.x * (k * k + (Z ? k : 0));
+  int p = 0;
+#pragma unroll
+  for (int ta = 0; ta < T; ++ta)
+#pragma unroll
+    for (int tb = ta; tb < T; ++tb, ++p) {
+      if (wave > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) red[((wave - 1) * 4 + q) * 64 + lane] = accd[p][q];
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          double t = accd[p][q];
+#pragma unroll
+          for (int ww = 0; ww < LW_NW - 1; ++ww) t += red[(ww * 4 + q) * 64 + lane];
+          const int row = 16 * ta + 4 * sl + q, col = 16 * tb + r;
+          if (row < k && col < k && (ta != tb || row <= col)) {
+            out[(size_t)row * k + col] = t;
+            if (row != col) out[(size_t)col * k + row] = t;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  if (Z) {
+#pragma unroll
+    for (int t = 0; t < T; ++t) {
+      double v = accz[t];
+      const double v1 = __shfl(v, r + 16, 64), v2 = __shfl(v, r + 32, 64), v3 = __shfl(v, r + 48, 64);
+      v = ((__shfl(v, r, 64) + v1) + v2) + v3;
+      if (lane < 16) red[wave * 64 + 16 * t + lane] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16 * T) {
+      const int row = threadIdx.x;
+      double t = red[row];
+#pragma unroll
+      for (int ww = 1; ww < LW_NW; ++ww) t += red[ww * 64 + row];
       if (row < k) out[(size_t)k * k + row] = t;
     }
   }
@@ -2433,16 +2750,35 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   int bx = cu_count() * per_cu;
   // (strip, band) units, band-major: the waves in flight together then work on a few neighbouring image rows of every basis vector
   static const int band_env = env_int("TRK_WGRAM_TV_BAND", 64);
-  const int band_rows = band_env < N ? (band_env > 0 ? band_env : 16) : N;
-  const int nbands = (N + band_rows - 1) / band_rows;
+  int band_rows = band_env < N ? (band_env > 0 ? band_env : 16) : N;
+  int nbands = (N + band_rows - 1) / band_rows;
   const int64_t units = (int64_t)strips * nbands;
   if ((int64_t)bx * (NT / 64) > units) bx = (int)((units + NT / 64 - 1) / (NT / 64));
+  // Large images, at most two tiles of vectors: the rows of V staged through LDS in full lines (k_wgram_tv_lds): 256-column tiles,
+  // one workgroup of 8 waves per CU (two at one tile of vectors).  TRK_WGRAM_TV_LDS=0: the register-fed kernel everywhere (A/B).
+  static const int lds_env = env_int("TRK_WGRAM_TV_LDS", 1);
+  static const int lds_band_env = env_int("TRK_WGRAM_TV_LDS_BAND", 64);
+  static const int lds_pc_env = env_int("TRK_WGRAM_TV_LDS_PER_CU", 0);
+  const bool use_lds = lds_env != 0 && T16 <= 2 && N % LW_COLS == 0 && N >= 2048;
+  if (use_lds) {
+    band_rows = lds_band_env >= 4 && lds_band_env < N ? lds_band_env : 64;
+    while (N % band_rows) band_rows >>= 1;                      // (N is a multiple of 256: a power of two <= 256 divides it)
+    nbands = N / band_rows;
+    const int64_t lunits = (int64_t)(N / LW_COLS) * nbands;
+    bx = cu_count() * (lds_pc_env > 0 ? (lds_pc_env > 2 ? 2 : lds_pc_env) : (T16 == 1 ? 2 : 1));
+    if (T16 == 2 && bx > cu_count()) bx = cu_count();
+    if (bx > lunits) bx = (int)lunits;
+  }
   double* part = nullptr;
   const int nv = k * k + (z ? k : 0);
   if (int rc = scratch_doubles(s, (size_t)bx * nv + ((size_t)PROBE_ROWS + 1) * 2 * PROBE_P, &part)) return rc;
   double* probe_part = part + (size_t)bx * nv;
   double* probe_sums = probe_part + (size_t)PROBE_ROWS * 2 * PROBE_P;
+#ifdef TRK_WGRAM_TV_EXPERIMENT
+  static const int no_xcd = (env_int("TRK_WGRAM_TV_NO_XCD", 0) ? 2 : 0) | (env_int("TRK_WGRAM_TV_X", 0) & 12);
+#else
   static const int no_xcd = env_int("TRK_WGRAM_TV_NO_XCD", 0) ? 2 : 0;
+#endif
   // Which arithmetic forms the tile products (trk_wgram_tv_precision; environment TRK_WGRAM_TV_F32=1 / TRK_WGRAM_TV_PIECES=2|3 set the
   // process default): 1 auto (default: two bf16 pieces unless the probe finds the data's roundings correlated, then the fp32 pipe),
   // 0 fp32 matrix pipe, 2 two bf16 pieces, 3 three bf16 pieces
@@ -2472,8 +2808,20 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
     else hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record});           \
   } while (0)
   // one pass of the chosen arithmetic: the kernel and the sum of its block partials
+#define WTVL1(TT, ZZ, BFV, WANT) hipLaunchKernelGGL((k_wgram_tv_lds<TT, ZZ, BFV>), dim3(bx), dim3(LW_NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, (int)no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record})
+#define WTVL(TT, ZZ, ARITH, WANT)                                \
+  do {                                                           \
+    if ((ARITH) == 4) WTVL1(TT, ZZ, 4, 0);                       \
+    else if ((ARITH) == 0) WTVL1(TT, ZZ, 0, WANT);               \
+    else if ((ARITH) == 2) WTVL1(TT, ZZ, 2, WANT);               \
+    else WTVL1(TT, ZZ, 3, WANT);                                 \
+  } while (0)
   auto pass = [&](int arith, int want) -> int {
     const bool two_pass = z && T16 == 3;     // three tiles AND the dots do not fit the register file (108 spilled registers): the dots
+    if (use_lds) {
+      if (z) { if (T16 == 1) WTVL(1, true, arith, want); else WTVL(2, true, arith, want); }
+      else { if (T16 == 1) WTVL(1, false, arith, want); else WTVL(2, false, arith, want); }
+    } else
     if (two_pass) WTV(3, false, arith, want);   // of 33 <= k <= 48 in a pass of their own, below
     else if (z) { if (T16 == 1) WTV(1, true, arith, want); else WTV(2, true, arith, want); }
     else { if (T16 == 1) WTV(1, false, arith, want); else if (T16 == 2) WTV(2, false, arith, want); else WTV(3, false, arith, want); }
@@ -2500,6 +2848,8 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   return TRK_OK;
 }
 #undef WTV
+#undef WTVL
+#undef WTVL1
 
 int trk_wgram(const float* W, int64_t ld, int k, int64_t m, const float* w, const float* b1, double* G, double* c1,
               double* c2, trk_stream st) {
