@@ -394,6 +394,17 @@ int trk_host_worker_post_gcv_bidiag(trk_host_worker* w, const double* alpha, con
 int trk_host_worker_post_dp_bidiag(trk_host_worker* w, const double* alpha, const double* beta_sub, int k, const double* bproj,
                                    double target, double extra);
 int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int* have_out);
+/* Hybrid-GMRES (Hybrid_GMRES.py:54-80): the WHOLE projected problem of iterate k as one job.  H: the (k+1) x k Arnoldi Hessenberg
+ * matrix on the host, element (i, j) at H[i * h_row_stride + j * h_col_stride] (copied at post); beta0 = ||b||.  The job
+ * bidiagonalises [beta0 e1 | H] with the CALLER's LAPACK (trk_host_worker_set_lapack: pointers to dgebrd and dormbr with the C
+ * signatures of scipy.linalg.cython_lapack — every argument by reference, no hidden string lengths; libtrk links no LAPACK),
+ * chooses lambda by 'standard' GCV on the bidiagonal form (trk_host_gcv_bidiag with m_eff; gcv.py:94-95), solves the Tikhonov
+ * problem there (trk_host_bidiag_tikhonov) and maps back: collect_vec returns lambda, y (k doubles) and the reference's
+ * relResidual of that iterate (:80, the Frobenius norm of its broadcast). */
+int trk_host_worker_set_lapack(trk_host_worker* w, void* dgebrd, void* dormbr);
+int trk_host_worker_post_hess_gcv(trk_host_worker* w, const double* H, int64_t h_row_stride, int64_t h_col_stride, int k,
+                                  double beta0, double m_eff, double x1, double x2, double xatol, int maxfun);
+int trk_host_worker_collect_vec(trk_host_worker* w, double* lam_out, int* have_out, double* y, int k, double* resid_out);
 
 /* n_iters consecutive CGLS iterations (numbers k_first .. k_first + n_iters - 1, 1-based) enqueued by one call: the loop
  * body of trips/solvers/CGLS.py:56-80 with tol = 0, i.e. nothing is read back between iterations.  Same kernels, scalar

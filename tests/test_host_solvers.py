@@ -284,7 +284,9 @@ def test_hybrid_gmres_gcv_routes_agree(eng):
     x1, i1 = S.Hybrid_GMRES(A, b, 40, "gcv", g["x_true"])
     x2, i2 = S.Hybrid_GMRES(A, b, 40, "gcv", g["x_true"], async_search=False)
     x3, i3 = S.Hybrid_GMRES(A, b, 40, "gcv", g["x_true"], gcv_by_bidiag=False)
-    assert np.array_equal(x1, x2) and i1["regParam_history"] == i2["regParam_history"] and i1["relResidual"] == i2["relResidual"]
+    # (the worker forms the reference's relResidual — a Frobenius norm of a broadcast — in closed form: equal to rounding, not to the bit)
+    assert np.array_equal(x1, x2) and i1["regParam_history"] == i2["regParam_history"]
+    assert np.allclose(i1["relResidual"], i2["relResidual"], rtol=1e-12, atol=0)
     assert i1["regParam"] == i1["regParam_history"][-1] and len(i1["xHistory"]) == 40
     assert relerr(x1, x3) < 1e-6 and np.allclose(i1["relError"], i3["relError"], rtol=1e-6)
     l1, l3 = np.array(i1["regParam_history"][1:], dtype=float), np.array(i3["regParam_history"][1:], dtype=float)

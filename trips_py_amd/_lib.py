@@ -223,6 +223,10 @@ SIGNATURES = {
                                                 c_dbl, c_int]),
     "trk_host_worker_post_dp_bidiag": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_int, ctypes.c_void_p, c_dbl, c_dbl]),
     "trk_host_worker_collect": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
+    "trk_host_worker_set_lapack": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "trk_host_worker_post_hess_gcv": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64, c_i64, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int]),
+    "trk_host_worker_collect_vec": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.c_void_p, c_int,
+                                            ctypes.POINTER(c_dbl)]),
     "trk_scalars_put": (c_int, [c_f64p, ctypes.c_void_p, c_int, c_stream]),
     "trk_mailbox_create": (c_int, [c_int, c_int, ctypes.POINTER(ctypes.c_void_p)]),
     "trk_mailbox_destroy": (c_int, [ctypes.c_void_p]),

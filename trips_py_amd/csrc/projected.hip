@@ -853,9 +853,55 @@ struct trk_host_worker {
   int maxfun = 0;
   double lam = 0.0;
   int have = 0, rc = 0;
+  // kind 2 (Hybrid-GMRES): the whole projected problem of one iterate — bidiagonalisation of [beta0 e1 | H] by the caller's LAPACK
+  // (dgebrd / dormbr: plain C pointers, every argument by reference), the GCV search, the Tikhonov solve, y = P' z, the residual
+  void* gebrd = nullptr;
+  void* ormbr = nullptr;
+  std::vector<double> M, H, d, e, tq, tp, work, y;
+  double resid = 0.0;
 };
 
 namespace {
+typedef void (*gebrd_fn)(int*, int*, double*, int*, double*, double*, double*, double*, double*, int*, int*);
+typedef void (*ormbr_fn)(char*, char*, char*, int*, int*, int*, double*, int*, double*, double*, int*, double*, int*, int*);
+
+// Hybrid_GMRES.py:54-80 for one k, from H_k ((k+1) x k, column-major, ld = k+1) and beta0: M = [beta0 e1 | H] = Q B P^T (dgebrd; the
+// first column is a multiple of e1, so Q^T (beta0 e1) = d[0] e1 and P = diag(1, P')): H = Q B[:, 1:] P'^T with B[:, 1:] LOWER bidiagonal,
+// diagonal e[0..k), sub-diagonal d[1..k].  lambda by 'standard' GCV on that triple (fullsize k: the k x k diag(s) of :58), z the
+// Tikhonov minimiser, y = P' z, and the reference's relResidual (:80: a (k+1,) minus a (k+1, 1) — the Frobenius norm of a matrix).
+int hess_gcv_job(trk_host_worker* w) {
+  const int k = w->k, n = k + 1;
+  w->M.assign((size_t)n * n, 0.0);
+  w->M[0] = w->p[0];
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < n; ++i) w->M[(size_t)(j + 1) * n + i] = w->H[(size_t)j * n + i];
+  w->d.resize(n); w->e.resize(n); w->tq.resize(n); w->tp.resize(n);
+  int lwork = 64 * n, info = 0, nn = n, one = 1;
+  w->work.resize(lwork);
+  ((gebrd_fn)w->gebrd)(&nn, &nn, w->M.data(), &nn, w->d.data(), w->e.data(), w->tq.data(), w->tp.data(), w->work.data(), &lwork, &info);
+  if (info != 0) return ::trk::fail(TRK_EINVAL, "trk_host_worker (hess_gcv): dgebrd failed (info = %d)", info);
+  const double* alpha = w->e.data();
+  const double* beta = w->d.data() + 1;
+  const double b0 = w->d[0];
+  double lam = 0.0;
+  if (int rc = trk_host_gcv_bidiag(alpha, beta, k, b0, w->p[1], w->p[2], w->p[3], w->p[4], w->maxfun, &lam, nullptr, nullptr)) return rc;
+  w->lam = lam;
+  w->have = 1;
+  w->y.assign(n, 0.0);
+  if (int rc = trk_host_bidiag_tikhonov(alpha, beta, k, b0, sqrt(lam), 0, w->y.data() + 1)) return rc;
+  char vect = 'P', side = 'L', trans = 'N';
+  ((ormbr_fn)w->ormbr)(&vect, &side, &trans, &nn, &one, &nn, w->M.data(), &nn, w->tp.data(), w->y.data(), &nn, w->work.data(), &lwork, &info);
+  if (info != 0) return ::trk::fail(TRK_EINVAL, "trk_host_worker (hess_gcv): dormbr failed (info = %d)", info);
+  double r2 = 0.0;
+  for (int i = 0; i < n; ++i) {
+    double hy = 0.0;
+    for (int j = 0; j < k; ++j) hy += w->H[(size_t)j * n + i] * w->y[1 + j];
+    r2 += (w->p[0] - hy) * (w->p[0] - hy) + (double)k * hy * hy;
+  }
+  w->resid = sqrt(r2);
+  return TRK_OK;
+}
+
 void host_worker_main(trk_host_worker* w) {
   for (;;) {
     // spin briefly (jobs arrive every ~70 us inside a solve), then sleep
@@ -870,6 +916,8 @@ void host_worker_main(trk_host_worker* w) {
       w->have = 1;
       w->rc = trk_host_gcv_bidiag(w->a.data(), w->b.data(), w->k, w->p[0], w->p[1], w->p[2], w->p[3], w->p[4], w->maxfun, &w->lam,
                                   nullptr, nullptr);
+    } else if (w->kind == 2) {
+      w->rc = hess_gcv_job(w);
     } else {
       w->rc = trk_host_dp_bidiag(w->a.data(), w->b.data(), w->k, w->c.data(), w->p[0], w->p[1], &w->lam, &w->have, nullptr, nullptr);
     }
@@ -935,6 +983,41 @@ extern "C" int trk_host_worker_post_dp_bidiag(trk_host_worker* w, const double* 
   w->k = k;
   w->p[0] = target; w->p[1] = extra;
   return host_worker_post(w, 1);
+}
+
+extern "C" int trk_host_worker_set_lapack(trk_host_worker* w, void* dgebrd, void* dormbr) {
+  TRK_REQUIRE(w && dgebrd && dormbr, "trk_host_worker_set_lapack: NULL argument");
+  TRK_REQUIRE(w->state.load() != 1, "trk_host_worker_set_lapack: a job is running");
+  w->gebrd = dgebrd;
+  w->ormbr = dormbr;
+  return TRK_OK;
+}
+
+extern "C" int trk_host_worker_post_hess_gcv(trk_host_worker* w, const double* H, int64_t h_row_stride, int64_t h_col_stride, int k,
+                                             double beta0, double m_eff, double x1, double x2, double xatol, int maxfun) {
+  TRK_REQUIRE(w && H && k >= 1, "trk_host_worker_post_hess_gcv: bad argument");
+  TRK_REQUIRE(w->gebrd && w->ormbr, "trk_host_worker_post_hess_gcv: trk_host_worker_set_lapack first");
+  TRK_REQUIRE(w->state.load() != 1, "trk_host_worker_post_hess_gcv: a job is still running (collect it first)");
+  const int n = k + 1;
+  w->H.resize((size_t)n * k);
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < n; ++i) w->H[(size_t)j * n + i] = H[i * h_row_stride + j * h_col_stride];
+  w->k = k;
+  w->p[0] = beta0; w->p[1] = m_eff; w->p[2] = x1; w->p[3] = x2; w->p[4] = xatol;
+  w->maxfun = maxfun;
+  return host_worker_post(w, 2);
+}
+
+extern "C" int trk_host_worker_collect_vec(trk_host_worker* w, double* lam_out, int* have_out, double* y, int k, double* resid_out) {
+  TRK_REQUIRE(w && lam_out && have_out && y && resid_out, "trk_host_worker_collect_vec: NULL argument");
+  TRK_REQUIRE(w->state.load() != 0, "trk_host_worker_collect_vec: nothing was posted");
+  TRK_REQUIRE(w->kind == 2 && k == w->k, "trk_host_worker_collect_vec: the posted job is not a Hessenberg job of this size");
+  const int rc = trk_host_worker_collect(w, lam_out, have_out);
+  if (rc == TRK_OK) {
+    for (int j = 0; j < k; ++j) y[j] = w->y[1 + j];
+    *resid_out = w->resid;
+  }
+  return rc;
 }
 
 extern "C" int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int* have_out) {

@@ -513,6 +513,7 @@ class ArnoldiState:
         self.w = eng.empty(n)
         self.S = eng.scalars(2 * (capacity + 1) + 2)
         self.Hcols = []
+        self._Hfull, self._Hn = np.zeros((int(capacity) + 2, int(capacity) + 1)), 0      # the columns absorbed so far, in place (H_view)
         self.gram, self.capacity = None, int(capacity)
         bv = eng.to_vec(b, n)
         eng.nrm2sq(bv, self.S.ref(0))
@@ -555,6 +556,9 @@ class ArnoldiState:
         col[:k] = h[1:1 + k] + h[1 + k:1 + 2 * k]
         col[k] = np.sqrt(h[0])
         self.Hcols.append(col)
+        if getattr(self, "_Hfull", None) is not None and self._Hn == k - 1 and k < self._Hfull.shape[1]:
+            self._Hfull[:k + 1, k - 1] = col
+            self._Hn = k
         return col
 
     def step(self):
@@ -570,6 +574,16 @@ class ArnoldiState:
     def absorb(self, pending):
         k, handle = pending
         return self._column(k, handle.get())
+
+    def H_view(self):
+        """H_k as a read-only VIEW of the array the steps fill in place (Hybrid-GMRES looks at H_k every iteration: rebuilding it from
+        its columns was O(k) Python statements per iteration); falls back to H() when the columns were set from outside."""
+        k = len(self.Hcols)
+        if getattr(self, "_Hfull", None) is None or self._Hn != k:
+            return self.H()
+        v = self._Hfull[:k + 1, :k]
+        v.flags.writeable = False
+        return v
 
     def H(self):
         k = len(self.Hcols)

@@ -112,6 +112,14 @@ def _bind_gebrd():
     return _gebrd or None
 
 
+def lapack_pointers():
+    """(dgebrd, dormbr) as plain C addresses for libtrk's worker thread (trk_host_worker_set_lapack), or None."""
+    fns = _bind_gebrd()
+    if fns is None:
+        return None
+    return tuple(ctypes.cast(f, ctypes.c_void_p).value for f in fns)
+
+
 class HessenbergBidiag:
     """The reduction above for one H: `.alphas`, `.betas`, `.beta0` (the Golub-Kahan triple of B[:, 1:] and Q^T bhat) and `.back(z)`
     = P' z.  `available()` is False when SciPy's LAPACK capsule table is missing (callers keep their SVD path)."""

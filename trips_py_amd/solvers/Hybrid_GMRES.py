@@ -151,17 +151,11 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
         from .Hybrid_LSQR import _Searcher
         searcher = _Searcher.borrow(_lib.load())           # (host-only entry points: no GPU involved)
 
-    def finish_waiting():
+    def collect_waiting():
         nonlocal waiting
-        jj, hbw, Hw = waiting
+        jj = waiting
         waiting = None
-        lam_w = searcher.collect()
-        kw_ = jj + 1
-        y = hbw.back(bidiag_tikhonov_host(hbw.alphas, hbw.betas, hbw.beta0, np.sqrt(lam_w)))
-        bh = np.zeros(kw_ + 1)
-        bh[0] = ar.beta0
-        hy = (Hw @ y).reshape(-1, 1)
-        form(jj, lam_w, y, float(np.linalg.norm(bh.reshape(1, -1) - hy)))
+        return (jj,) + searcher.collect_vec(jj + 1)
 
     def host_loop():
         nonlocal pend, waiting, lam
@@ -169,7 +163,7 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             k = ii + 1
             ar.absorb(pend)                      # column k of H; step k+1 runs while the host works on the projected problem
             pend = ar.step_prefetch() if k < n_iter else None
-            H = ar.H()[:k + 1, :k]
+            H = ar.H_view()
             if is_dp:
                 bhat = np.zeros(k + 1)
                 bhat[0] = ar.beta0
@@ -214,19 +208,20 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
                 form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
                 continue
             if async_gcv and k >= BIDIAG_FROM_K:
-                # lambda_k is searched on the library's worker thread (trk_host_worker_*, as Hybrid-LSQR does) while this thread finishes
-                # iterate k - 1 — its Tikhonov solve, back-transformation and the launch that forms x_{k-1} — and waits for step k + 1
-                hb = HessenbergBidiag(np.array(H, copy=True), ar.beta0)
-                if waiting is not None:
-                    finish_waiting()
-                searcher.post_gcv(hb.alphas, hb.betas, hb.beta0, k)
-                waiting = (ii, hb, np.array(H, copy=True))
+                # iterate k's whole projected problem — bidiagonalisation of [bhat | H_k], the GCV search, the Tikhonov solve, y = P' z —
+                # is ONE job of the library's worker thread (trk_host_worker_post_hess_gcv), collected one iteration later: this thread
+                # only absorbs a step, enqueues the next and launches x_{k-1} = V y_{k-1} while the worker and the device run
+                done = collect_waiting() if waiting is not None else None
+                searcher.post_hess_gcv(H, ar.beta0, k)           # (H is copied before this returns)
+                waiting = ii
+                if done is not None:
+                    form(*done)
                 continue
             if waiting is not None:
-                finish_waiting()
+                form(*collect_waiting())
             form(ii, *projected(k, H, ii == 0))
         if waiting is not None:
-            finish_waiting()
+            form(*collect_waiting())
 
     clean = False
     try:

@@ -49,6 +49,29 @@ class _Searcher:
                                                    float((eta * delta) ** 2), 0.0) != 0:
             raise RuntimeError("trk_host_worker_post_dp_bidiag failed")
 
+    def post_hess_gcv(self, H, beta0, k, x1=1e-9, x2=1e2, xtol=1e-12, maxfun=1000):
+        """Hybrid-GMRES: the whole projected problem of iterate k (bidiagonalisation, GCV, Tikhonov solve, back-transformation) as one
+        job; H: a float64 array view of the (k+1) x k Hessenberg matrix (any strides: copied by the library before this returns)."""
+        if not getattr(self, "_lapack", False):
+            from ..reg_param._bidiag import lapack_pointers
+            ptrs = lapack_pointers()
+            if ptrs is None or self.lib.trk_host_worker_set_lapack(self.h, ptrs[0], ptrs[1]) != 0:
+                raise RuntimeError("trk_host_worker_set_lapack failed")
+            self._lapack = True
+        if H.dtype != np.float64 or H.shape != (k + 1, k):
+            raise ValueError("post_hess_gcv: H must be a float64 (k+1) x k array")
+        if self.lib.trk_host_worker_post_hess_gcv(self.h, H.ctypes.data, H.strides[0] // 8, H.strides[1] // 8, int(k), float(beta0),
+                                                  float(k), float(x1), float(x2), float(xtol), int(maxfun)) != 0:
+            raise RuntimeError("trk_host_worker_post_hess_gcv failed")
+
+    def collect_vec(self, k):
+        lam, have, r = self._ct.c_double(0.0), self._ct.c_int(0), self._ct.c_double(0.0)
+        y = np.empty(k, dtype=np.float64)
+        if self.lib.trk_host_worker_collect_vec(self.h, self._ct.byref(lam), self._ct.byref(have), y.ctypes.data, int(k),
+                                                self._ct.byref(r)) != 0:
+            raise RuntimeError("the projected problem failed on the worker thread")
+        return lam.value, y, r.value
+
     def collect(self):
         lam, have = self._ct.c_double(0.0), self._ct.c_int(0)
         if self.lib.trk_host_worker_collect(self.h, self._ct.byref(lam), self._ct.byref(have)) != 0:
