@@ -404,6 +404,12 @@ int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int* have_out);
 int trk_host_worker_set_lapack(trk_host_worker* w, void* dgebrd, void* dormbr);
 int trk_host_worker_post_hess_gcv(trk_host_worker* w, const double* H, int64_t h_row_stride, int64_t h_col_stride, int k,
                                   double beta0, double m_eff, double x1, double x2, double xatol, int maxfun);
+/* ... and with the discrepancy principle instead of GCV (discrepancy_principle.py:68-99 on the same bidiagonal form; bproj = V_{k+1}^T b,
+ * k + 1 host doubles, copied at post; target = (eta delta)^2, extra as trk_host_dp_bidiag): y and the residual are formed only when
+ * the Newton iteration returns a positive lambda (*have_out = 1 and *lam_out > 0); otherwise the caller takes the reference's other
+ * branches itself. */
+int trk_host_worker_post_hess_dp(trk_host_worker* w, const double* H, int64_t h_row_stride, int64_t h_col_stride, int k,
+                                 double beta0, const double* bproj, double target, double extra);
 int trk_host_worker_collect_vec(trk_host_worker* w, double* lam_out, int* have_out, double* y, int k, double* resid_out);
 
 /* n_iters consecutive CGLS iterations (numbers k_first .. k_first + n_iters - 1, 1-based) enqueued by one call: the loop

@@ -291,3 +291,23 @@ def test_hybrid_gmres_gcv_routes_agree(eng):
     assert relerr(x1, x3) < 1e-6 and np.allclose(i1["relError"], i3["relError"], rtol=1e-6)
     l1, l3 = np.array(i1["regParam_history"][1:], dtype=float), np.array(i3["regParam_history"][1:], dtype=float)
     assert np.max(np.abs(l1 / l3 - 1)) < 2e-2
+
+
+def test_hybrid_gmres_dp_routes_agree(eng):
+    """Hybrid_GMRES(regparam='dp') with the projected problem of an iterate as one job of the library's worker thread (default), in
+    this thread on the bidiagonal form, and through the SVD of H as the reference writes it (Hybrid_GMRES.py:61-76,
+    discrepancy_principle.py:68-99): one Newton iteration on one function — the same lambdas to 1e-10, the same iterates."""
+    g = load_golden("hybrid_gmres_blur32_gcv")
+    A = blur(eng, g)
+    rng = np.random.default_rng(1)
+    noise = 0.05 * np.linalg.norm(g["b"]) / np.sqrt(g["b"].size) * rng.standard_normal(g["b"].shape)
+    b = g["b"] + noise
+    delta = float(np.linalg.norm(noise))
+    x1, i1 = S.Hybrid_GMRES(A, b, 30, "dp", g["x_true"], delta=delta)
+    x2, i2 = S.Hybrid_GMRES(A, b, 30, "dp", g["x_true"], delta=delta, async_search=False)
+    x3, i3 = S.Hybrid_GMRES(A, b, 30, "dp", g["x_true"], delta=delta, dp_by_bidiag=False)
+    l1, l2, l3 = (np.array(i["regParam_history"], dtype=float) for i in (i1, i2, i3))
+    assert l1.shape == l2.shape == l3.shape == (30,) and np.any(l1[12:] > 0)          # the worker's branch was taken
+    assert np.allclose(l1, l2, rtol=1e-10, atol=0) and np.allclose(l1, l3, rtol=1e-8, atol=0)
+    assert relerr(x1, x2) < 1e-10 and relerr(x1, x3) < 1e-8
+    assert np.allclose(i1["relResidual"], i2["relResidual"], rtol=1e-10) and np.allclose(i1["relError"], i3["relError"], rtol=1e-7)

@@ -225,6 +225,7 @@ SIGNATURES = {
     "trk_host_worker_collect": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
     "trk_host_worker_set_lapack": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "trk_host_worker_post_hess_gcv": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64, c_i64, c_int, c_dbl, c_dbl, c_dbl, c_dbl, c_dbl, c_int]),
+    "trk_host_worker_post_hess_dp": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64, c_i64, c_int, c_dbl, ctypes.c_void_p, c_dbl, c_dbl]),
     "trk_host_worker_collect_vec": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl), ctypes.POINTER(c_int), ctypes.c_void_p, c_int,
                                             ctypes.POINTER(c_dbl)]),
     "trk_scalars_put": (c_int, [c_f64p, ctypes.c_void_p, c_int, c_stream]),

@@ -869,7 +869,7 @@ typedef void (*ormbr_fn)(char*, char*, char*, int*, int*, int*, double*, int*, d
 // first column is a multiple of e1, so Q^T (beta0 e1) = d[0] e1 and P = diag(1, P')): H = Q B[:, 1:] P'^T with B[:, 1:] LOWER bidiagonal,
 // diagonal e[0..k), sub-diagonal d[1..k].  lambda by 'standard' GCV on that triple (fullsize k: the k x k diag(s) of :58), z the
 // Tikhonov minimiser, y = P' z, and the reference's relResidual (:80: a (k+1,) minus a (k+1, 1) — the Frobenius norm of a matrix).
-int hess_gcv_job(trk_host_worker* w) {
+int hess_job(trk_host_worker* w, bool dp) {
   const int k = w->k, n = k + 1;
   w->M.assign((size_t)n * n, 0.0);
   w->M[0] = w->p[0];
@@ -884,12 +884,24 @@ int hess_gcv_job(trk_host_worker* w) {
   const double* beta = w->d.data() + 1;
   const double b0 = w->d[0];
   double lam = 0.0;
-  if (int rc = trk_host_gcv_bidiag(alpha, beta, k, b0, w->p[1], w->p[2], w->p[3], w->p[4], w->maxfun, &lam, nullptr, nullptr)) return rc;
-  w->lam = lam;
-  w->have = 1;
+  char vect = 'P', side = 'L', trans = 'N';
+  if (dp) {
+    // the discrepancy principle (discrepancy_principle.py:68-99) wants V_{k+1}^T b in the left basis of the bidiagonal form: Q^T bproj
+    vect = 'Q'; trans = 'T';
+    ((ormbr_fn)w->ormbr)(&vect, &side, &trans, &nn, &one, &nn, w->M.data(), &nn, w->tq.data(), w->c.data(), &nn, w->work.data(), &lwork, &info);
+    if (info != 0) return ::trk::fail(TRK_EINVAL, "trk_host_worker (hess_dp): dormbr failed (info = %d)", info);
+    w->have = 0;
+    if (int rc = trk_host_dp_bidiag(alpha, beta, k, w->c.data(), w->p[1], w->p[2], &lam, &w->have, nullptr, nullptr)) return rc;
+    w->lam = lam;
+    if (!w->have || !(lam > 0.0)) return TRK_OK;              // the caller's in-line branches (unassigned / not reachable yet)
+    vect = 'P'; trans = 'N';
+  } else {
+    if (int rc = trk_host_gcv_bidiag(alpha, beta, k, b0, w->p[1], w->p[2], w->p[3], w->p[4], w->maxfun, &lam, nullptr, nullptr)) return rc;
+    w->lam = lam;
+    w->have = 1;
+  }
   w->y.assign(n, 0.0);
   if (int rc = trk_host_bidiag_tikhonov(alpha, beta, k, b0, sqrt(lam), 0, w->y.data() + 1)) return rc;
-  char vect = 'P', side = 'L', trans = 'N';
   ((ormbr_fn)w->ormbr)(&vect, &side, &trans, &nn, &one, &nn, w->M.data(), &nn, w->tp.data(), w->y.data(), &nn, w->work.data(), &lwork, &info);
   if (info != 0) return ::trk::fail(TRK_EINVAL, "trk_host_worker (hess_gcv): dormbr failed (info = %d)", info);
   double r2 = 0.0;
@@ -916,8 +928,8 @@ void host_worker_main(trk_host_worker* w) {
       w->have = 1;
       w->rc = trk_host_gcv_bidiag(w->a.data(), w->b.data(), w->k, w->p[0], w->p[1], w->p[2], w->p[3], w->p[4], w->maxfun, &w->lam,
                                   nullptr, nullptr);
-    } else if (w->kind == 2) {
-      w->rc = hess_gcv_job(w);
+    } else if (w->kind == 2 || w->kind == 3) {
+      w->rc = hess_job(w, w->kind == 3);
     } else {
       w->rc = trk_host_dp_bidiag(w->a.data(), w->b.data(), w->k, w->c.data(), w->p[0], w->p[1], &w->lam, &w->have, nullptr, nullptr);
     }
@@ -1008,12 +1020,27 @@ extern "C" int trk_host_worker_post_hess_gcv(trk_host_worker* w, const double* H
   return host_worker_post(w, 2);
 }
 
+extern "C" int trk_host_worker_post_hess_dp(trk_host_worker* w, const double* H, int64_t h_row_stride, int64_t h_col_stride, int k,
+                                            double beta0, const double* bproj, double target, double extra) {
+  TRK_REQUIRE(w && H && bproj && k >= 1, "trk_host_worker_post_hess_dp: bad argument");
+  TRK_REQUIRE(w->gebrd && w->ormbr, "trk_host_worker_post_hess_dp: trk_host_worker_set_lapack first");
+  TRK_REQUIRE(w->state.load() != 1, "trk_host_worker_post_hess_dp: a job is still running (collect it first)");
+  const int n = k + 1;
+  w->H.resize((size_t)n * k);
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < n; ++i) w->H[(size_t)j * n + i] = H[i * h_row_stride + j * h_col_stride];
+  w->c.assign(bproj, bproj + n);
+  w->k = k;
+  w->p[0] = beta0; w->p[1] = target; w->p[2] = extra;
+  return host_worker_post(w, 3);
+}
+
 extern "C" int trk_host_worker_collect_vec(trk_host_worker* w, double* lam_out, int* have_out, double* y, int k, double* resid_out) {
   TRK_REQUIRE(w && lam_out && have_out && y && resid_out, "trk_host_worker_collect_vec: NULL argument");
   TRK_REQUIRE(w->state.load() != 0, "trk_host_worker_collect_vec: nothing was posted");
-  TRK_REQUIRE(w->kind == 2 && k == w->k, "trk_host_worker_collect_vec: the posted job is not a Hessenberg job of this size");
+  TRK_REQUIRE((w->kind == 2 || w->kind == 3) && k == w->k, "trk_host_worker_collect_vec: the posted job is not a Hessenberg job of this size");
   const int rc = trk_host_worker_collect(w, lam_out, have_out);
-  if (rc == TRK_OK) {
+  if (rc == TRK_OK && *have_out && (w->kind == 2 || *lam_out > 0.0)) {
     for (int j = 0; j < k; ++j) y[j] = w->y[1 + j];
     *resid_out = w->resid;
   }

@@ -151,61 +151,102 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
         from .Hybrid_LSQR import _Searcher
         searcher = _Searcher.borrow(_lib.load())           # (host-only entry points: no GPU involved)
 
+    # dp the same way: V_{k+1}^T b grows by ONE entry per step (the earlier basis vectors do not change): one dot per step, enqueued
+    # behind the step and downloaded with it, instead of a sweep over the whole basis and a blocking read per iteration
+    dp_async = (is_dp and not on_dev and kwargs.get("dp_by_bidiag", True) and kwargs.get("async_search", True)
+                and "explicitProj" not in kwargs and HessenbergBidiag.available() and n_iter > BIDIAG_FROM_K)
+    if dp_async and searcher is None:
+        from .. import _lib
+        from .Hybrid_LSQR import _Searcher
+        searcher = _Searcher.borrow(_lib.load())
+    Ph = np.zeros(n_iter + 2)
+
+    def enqueue_proj(j0, j1):
+        for j in range(j0, j1):
+            eng.dot(ar.V[j], bv, P.ref(j))
+        eng.allreduce(P, j0, j1)
+        return j0, j1, P.host_later(j0, j1)
+
+    ppend = enqueue_proj(0, 2) if (is_dp and pend is not None) else None
+
     def collect_waiting():
         nonlocal waiting
         jj = waiting
         waiting = None
         return (jj,) + searcher.collect_vec(jj + 1)
 
+    def dp_inline(ii, k, H, Pk):
+        """Iterate k with the discrepancy principle in this thread (the first steps, and whatever the worker hands back: the
+        reference's unassigned / not-reachable-yet branches)."""
+        bhat = np.zeros(k + 1)
+        bhat[0] = ar.beta0
+        svd = None
+        if ii == 0:
+            lam = 0
+        else:
+            hb = None
+            if k >= BIDIAG_FROM_K and kwargs.get("dp_by_bidiag", True) and HessenbergBidiag.available() and "explicitProj" not in kwargs:
+                # the same Newton iteration on the bidiagonal form of [bhat | H] (as 'gcv' above): V^T b in the left basis'
+                # coordinates; lambda agrees with the SVD route to 1e-15 (tests/test_host_regparam.py)
+                from ..reg_param.discrepancy_principle import discrepancy_principle_bidiag
+                hb = HessenbergBidiag(np.array(H, copy=True), ar.beta0)
+                extra = {key: kwargs[key] for key in ("eta",) if key in kwargs}
+                lam = discrepancy_principle_bidiag(hb.alphas, hb.betas, hb.left_t(Pk), delta=kwargs.get("delta"), **extra)
+                if lam is None or not lam > 0:
+                    hb = None
+            if hb is not None:
+                y = hb.back(bidiag_tikhonov_host(hb.alphas, hb.betas, hb.beta0, np.sqrt(lam)))
+                hy = (H @ y).reshape(-1, 1)
+                form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
+                return
+            if kwargs.get("solve_by_svd", True):
+                # the SVD discrepancy_principle() takes of H (discrepancy_principle.py:68-70), taken here so that the
+                # Tikhonov solve below can share it
+                from ..reg_param.discrepancy_principle import discrepancy_principle
+                Uf, sv, Vh = sla.svd(H)
+                extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
+                lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
+                                            spectrum=(sv, Uf.T @ np.array(Pk).reshape(-1, 1), (k + 1, k)), **extra)
+                svd = (sv, Vh, Uf[:, :k].T @ bhat)
+            else:
+                lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=H, dp_bproj=np.array(Pk))
+        if svd is not None and lam > 0 and kwargs.get("solve_by_svd", True):
+            sv, Vh, qb = svd
+            y = Vh.T @ ((sv / (sv * sv + lam)) * qb)
+        else:
+            y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
+        hy = (H @ y).reshape(-1, 1)
+        form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
+
+    def finish_dp(done):
+        jj, lam_w, y, r = done
+        if lam_w is not None and lam_w > 0:
+            form(jj, lam_w, y, r)
+        else:
+            dp_inline(jj, jj + 1, ar.H_view()[:jj + 2, :jj + 1], Ph[:jj + 2])
+
     def host_loop():
-        nonlocal pend, waiting, lam
+        nonlocal pend, ppend, waiting, lam
         for ii in range(0 if not on_dev else n_iter, n_iter):
             k = ii + 1
             ar.absorb(pend)                      # column k of H; step k+1 runs while the host works on the projected problem
+            if ppend is not None:
+                j0, j1, hnd = ppend
+                Ph[j0:j1] = hnd.get()
             pend = ar.step_prefetch() if k < n_iter else None
+            ppend = enqueue_proj(k + 1, k + 2) if (is_dp and pend is not None) else None
             H = ar.H_view()
             if is_dp:
-                bhat = np.zeros(k + 1)
-                bhat[0] = ar.beta0
-                svd = None
-                if ii == 0:
-                    lam = 0
-                else:
-                    eng.gemv_t(ar.V.data, k + 1, bv, P.ref(0))
-                    eng.allreduce(P, 0, k + 1)
-                    hb = None
-                    if k >= BIDIAG_FROM_K and kwargs.get("dp_by_bidiag", True) and HessenbergBidiag.available() and "explicitProj" not in kwargs:
-                        # the same Newton iteration on the bidiagonal form of [bhat | H] (as 'gcv' above): V^T b in the left basis'
-                        # coordinates; lambda agrees with the SVD route to 1e-15 (tests/test_host_regparam.py)
-                        from ..reg_param.discrepancy_principle import discrepancy_principle_bidiag
-                        hb = HessenbergBidiag(H, ar.beta0)
-                        extra = {key: kwargs[key] for key in ("eta",) if key in kwargs}
-                        lam = discrepancy_principle_bidiag(hb.alphas, hb.betas, hb.left_t(P.host(0, k + 1)), delta=kwargs.get("delta"), **extra)
-                        if lam is None or not lam > 0:
-                            hb = None
-                    if hb is not None:
-                        y = hb.back(bidiag_tikhonov_host(hb.alphas, hb.betas, hb.beta0, np.sqrt(lam)))
-                        hy = (H @ y).reshape(-1, 1)
-                        form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
-                        continue
-                    if kwargs.get("solve_by_svd", True):
-                        # the SVD discrepancy_principle() takes of H (discrepancy_principle.py:68-70), taken here so that the
-                        # Tikhonov solve below can share it
-                        from ..reg_param.discrepancy_principle import discrepancy_principle
-                        Uf, sv, Vh = sla.svd(H)
-                        extra = {key: kwargs[key] for key in ("eta", "explicitProj") if key in kwargs}
-                        lam = discrepancy_principle(None, None, None, 0.0, delta=kwargs.get("delta"), L_is_identity=True,
-                                                    spectrum=(sv, Uf.T @ P.host(0, k + 1).reshape(-1, 1), (k + 1, k)), **extra)
-                        svd = (sv, Vh, Uf[:, :k].T @ bhat)
-                    else:
-                        lam = choose_lambda("dp", None, None, None, 0.0, kwargs, L_is_identity=True, dp_A=H, dp_bproj=P.host(0, k + 1))
-                if svd is not None and lam > 0 and kwargs.get("solve_by_svd", True):
-                    sv, Vh, qb = svd
-                    y = Vh.T @ ((sv / (sv * sv + lam)) * qb)
-                else:
-                    y = tikhonov_lstsq(H, np.eye(k), lam, bhat)
-                hy = (H @ y).reshape(-1, 1)
-                form(ii, lam, y, float(np.linalg.norm(bhat.reshape(1, -1) - hy)))
+                if dp_async and ii > 0 and k >= BIDIAG_FROM_K:
+                    done = collect_waiting() if waiting is not None else None
+                    searcher.post_hess_dp(H, ar.beta0, k, Ph[:k + 1], kwargs.get("delta"), kwargs.get("eta", 1.01))
+                    waiting = ii
+                    if done is not None:
+                        finish_dp(done)
+                    continue
+                if waiting is not None:
+                    finish_dp(collect_waiting())
+                dp_inline(ii, k, H, Ph[:k + 1])
                 continue
             if async_gcv and k >= BIDIAG_FROM_K:
                 # iterate k's whole projected problem — bidiagonalisation of [bhat | H_k], the GCV search, the Tikhonov solve, y = P' z —
@@ -221,7 +262,10 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
                 form(*collect_waiting())
             form(ii, *projected(k, H, ii == 0))
         if waiting is not None:
-            form(*collect_waiting())
+            if is_dp:
+                finish_dp(collect_waiting())
+            else:
+                form(*collect_waiting())
 
     clean = False
     try:

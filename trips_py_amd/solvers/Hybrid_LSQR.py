@@ -52,25 +52,39 @@ class _Searcher:
     def post_hess_gcv(self, H, beta0, k, x1=1e-9, x2=1e2, xtol=1e-12, maxfun=1000):
         """Hybrid-GMRES: the whole projected problem of iterate k (bidiagonalisation, GCV, Tikhonov solve, back-transformation) as one
         job; H: a float64 array view of the (k+1) x k Hessenberg matrix (any strides: copied by the library before this returns)."""
-        if not getattr(self, "_lapack", False):
-            from ..reg_param._bidiag import lapack_pointers
-            ptrs = lapack_pointers()
-            if ptrs is None or self.lib.trk_host_worker_set_lapack(self.h, ptrs[0], ptrs[1]) != 0:
-                raise RuntimeError("trk_host_worker_set_lapack failed")
-            self._lapack = True
+        self._need_lapack()
         if H.dtype != np.float64 or H.shape != (k + 1, k):
             raise ValueError("post_hess_gcv: H must be a float64 (k+1) x k array")
         if self.lib.trk_host_worker_post_hess_gcv(self.h, H.ctypes.data, H.strides[0] // 8, H.strides[1] // 8, int(k), float(beta0),
                                                   float(k), float(x1), float(x2), float(xtol), int(maxfun)) != 0:
             raise RuntimeError("trk_host_worker_post_hess_gcv failed")
 
+    def _need_lapack(self):
+        if not getattr(self, "_lapack", False):
+            from ..reg_param._bidiag import lapack_pointers
+            ptrs = lapack_pointers()
+            if ptrs is None or self.lib.trk_host_worker_set_lapack(self.h, ptrs[0], ptrs[1]) != 0:
+                raise RuntimeError("trk_host_worker_set_lapack failed")
+            self._lapack = True
+
+    def post_hess_dp(self, H, beta0, k, bproj, delta, eta=1.01):
+        """The same job with the discrepancy principle: bproj = V_{k+1}^T b (k + 1 values, copied)."""
+        self._need_lapack()
+        bp = np.ascontiguousarray(np.asarray(bproj, dtype=np.float64).reshape(-1))
+        if H.dtype != np.float64 or H.shape != (k + 1, k) or bp.size != k + 1:
+            raise ValueError("post_hess_dp: H must be a float64 (k+1) x k array, bproj k + 1 values")
+        if self.lib.trk_host_worker_post_hess_dp(self.h, H.ctypes.data, H.strides[0] // 8, H.strides[1] // 8, int(k), float(beta0),
+                                                 bp.ctypes.data, float((eta * delta) ** 2), 0.0) != 0:
+            raise RuntimeError("trk_host_worker_post_hess_dp failed")
+
     def collect_vec(self, k):
+        """(lambda or None, y, relResidual); y and the residual are meaningful only for a positive lambda."""
         lam, have, r = self._ct.c_double(0.0), self._ct.c_int(0), self._ct.c_double(0.0)
         y = np.empty(k, dtype=np.float64)
         if self.lib.trk_host_worker_collect_vec(self.h, self._ct.byref(lam), self._ct.byref(have), y.ctypes.data, int(k),
                                                 self._ct.byref(r)) != 0:
             raise RuntimeError("the projected problem failed on the worker thread")
-        return lam.value, y, r.value
+        return (lam.value if have.value else None), y, r.value
 
     def collect(self):
         lam, have = self._ct.c_double(0.0), self._ct.c_int(0)
