@@ -729,17 +729,22 @@ def extra_sparse_dynamic(world, cpu_jobs=None):
     e = torch.randn(b.numel(), device=dev, generator=torch.Generator(device=dev).manual_seed(12))
     b = b + e * (0.01 * torch.linalg.norm(b) / torch.linalg.norm(e))
     its = 50
-    Hybrid_LSQR(F, b, its, 1e-2, xt, history=False)
+    for _ in range(2):                       # (as C3: the first solve allocates, the second still pays first-use costs of the host side)
+        Hybrid_LSQR(F, b, its, 1e-2, xt, history=False)
     barrier(world)
-    reps = 5
+    reps = 10
+    each = []
     with no_gc():
         t0 = time.perf_counter()
         for _ in range(reps):
+            t1 = time.perf_counter()
             xs, info = Hybrid_LSQR(F, b, its, 1e-2, xt, history=False)
+            each.append(time.perf_counter() - t1)
         barrier(world)
         dt = max_over_ranks(time.perf_counter() - t0, world)
     out.update({"problem": f"{T} frames of {Nf}x{Nf}, {na * nd} rays per frame, {int(F.matrix.nnz)} non-zeros in one CSR handle",
                 "solver": f"Hybrid_LSQR(n_iter={its}, regparam=1e-2, x_true)", "iters_per_sec_all_ranks": round(world * reps * its / dt, 1),
+                "median_solve_iters_per_sec": round(world * its / max_over_ranks(float(np.median(each)), world), 1),
                 "ms_per_solve": round(dt / reps * 1e3, 3), "relError_last": float(info["relError"][-1])})
     if cpu_jobs is not None:
         Fm, bh = F.matrix.astype(np.float64), b.detach().to("cpu")
