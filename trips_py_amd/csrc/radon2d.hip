@@ -84,6 +84,7 @@ struct RadonImpl {
   int4* adj_pos;     // [nt*na]: angle row (caller's order) -> {its sorted row (the inverse of adj_ang[].orig), that row's
                      // adjoint weight (bits), its flip flag, 0}: one load where the record writer chased three
   int n_bands, band;
+  int band_res;     // forward by k_radon_fwd_band: 64-row bands resident in LDS (small images)
   // adjoint with the angles of a tile split over `nsplit` workgroups (small images): partial tiles and one counter per tile
   float* adj_part;
   unsigned* adj_cnt;
@@ -1032,6 +1033,167 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restri
 // also writes the adjoint's record {w S[d -], w S[d +], w S[d], A32[d]} of every position (what k_radon_adj_prep would
 // make from the finished sinogram; the neighbours come through LDS, the two at the block's edges are recomputed).
 // ssq_part != NULL: sum(out^2) of this block's outputs in ssq_part[blockIdx.x].
+// ---------------------------------------------------------------------------------------- forward, band-resident (small images; round 5)
+// At 512^2 (C3) k_radon_fwd_lds spends 45 % of its vector instructions on staging a window per wave and 16 rows (addresses of 7
+// loads, window bookkeeping, the wait for the loads), and its 2 160 workgroups of four waves run in 1.7 rounds.  A band of 64 rows of a
+// 512-wide image is 130 KB: it FITS the LDS of one CU.  Here a workgroup of 16 waves loads its band once — rows of the image for the
+// row-driven angles, rows of the transposed image for the column-driven ones, zero columns either side — and every wave then marches
+// (angle, 64 detectors) tasks through all 64 rows with no staging, no barrier and no load left in the loop: per 16 rows one window
+// start (the tables know the column mod 256), then the seven instructions of a step.  Chunks of 16 rows in fp32, flushed to float64,
+// as k_radon_fwd_lds sums them; the band partials go to the same array (64-row bands).  Grid: frames x {row bands, column bands} x
+// slices of that mode's angle list (adj_ang: the angles sorted by mode), about one workgroup per CU.
+constexpr int BR_ROWS = 64, BR_NW = 16, BR_NT = 64 * BR_NW, BR_PAD = 4, BR_NMAX = 512;
+__global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __restrict__ img, const float* __restrict__ imgT,
+                                                             float* __restrict__ part, int N, int nd,
+                                                             const AngleParam* __restrict__ ang, int na,
+                                                             const AdjAngle* __restrict__ sorted, const int* __restrict__ n_mode0,
+                                                             int nslice, int64_t band_stride,
+                                                             const unsigned* __restrict__ A32, const unsigned* __restrict__ B32, int npad,
+                                                             int have_xT) {
+  extern __shared__ __attribute__((aligned(16))) float band[];   // BR_ROWS x (N + 2 BR_PAD) floats, then the task counter
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int nbands = N / BR_ROWS;
+  const int nw = (int)(blockDim.x >> 6), nthr = (int)blockDim.x;   // 16 waves (one workgroup per CU) or 8 (narrow images: two per CU)
+  int& next_task = *reinterpret_cast<int*>(band + BR_ROWS * (N + 2 * BR_PAD));
+  // blockIdx.x = ((frame * 2 + mode) * nbands + b) * nslice + slice
+  int bid = blockIdx.x;
+  const int slice = bid % nslice; bid /= nslice;
+  const int b = bid % nbands; bid /= nbands;
+  const int mode = bid & 1, frame = bid >> 1;
+  const int n0 = n_mode0[frame];
+  const int cnt = mode ? na - n0 : n0;                           // angles of this mode in the frame
+  const int ndblk = (nd + 63) / 64;
+  // the mode's (angle, 64 detectors) tasks in list order, dealt to the slices in equal contiguous shares
+  const int all_tasks = cnt * ndblk;
+  const int task0 = (int)((int64_t)all_tasks * slice / nslice), task1 = (int)((int64_t)all_tasks * (slice + 1) / nslice);
+  if (task1 <= task0) return;
+  const int RS = N + 2 * BR_PAD;                                 // row stride in floats (a multiple of 4)
+  if (mode && !have_xT) {
+    // no transposed copy at hand: the band of the transposed image is 64 COLUMNS of the image — a wave-load takes 16 image rows x 16
+    // columns (whole 64-byte sectors), a lane's four values go to four rows of the band (consecutive lanes: consecutive addresses)
+    const float* __restrict__ X = img + (int64_t)frame * N * N + (int64_t)b * BR_ROWS;
+    const int r = lane & 15, jq = lane >> 4;
+    const int pieces = (N / 16) * 4;                               // (16-row group, 16-column group)
+    for (int p0 = wv; p0 < pieces; p0 += 4 * nw) {
+      f4r v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pc = p0 + u * nw;
+        const int rg = pc >> 2, cg = pc & 3;
+        v[u] = pc < pieces ? *reinterpret_cast<const f4r*>(X + (int64_t)(16 * rg + r) * N + 16 * cg + 4 * jq) : (f4r){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pc = p0 + u * nw;
+        if (pc < pieces) {
+          const int rg = pc >> 2, cg = pc & 3;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) band[(16 * cg + 4 * jq + e) * RS + BR_PAD + 16 * rg + r] = v[u][e];
+        }
+      }
+    }
+  } else {
+    // the band: 64 rows x N floats as float4, 8 (N = 512) per thread in flight
+    const float* __restrict__ I = (mode ? imgT : img) + (int64_t)frame * N * N + (int64_t)b * BR_ROWS * N;
+    const int q4 = N / 4, tot = BR_ROWS * q4;
+    for (int i0 = threadIdx.x; i0 < tot; i0 += 8 * nthr) {
+      f4r v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + u * nthr;
+        v[u] = idx < tot ? *reinterpret_cast<const f4r*>(I + 4 * (int64_t)idx) : (f4r){0.f, 0.f, 0.f, 0.f};   // (row * N + 4 c4 = 4 idx)
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + u * nthr;
+        if (idx < tot) {
+          const int row = idx / q4, c4 = idx - row * q4;
+          *reinterpret_cast<f4r*>(&band[row * RS + BR_PAD + 4 * c4]) = v[u];
+        }
+      }
+    }
+  }
+  // the pads are zeros
+  if (threadIdx.x < BR_ROWS * 2) {
+    const int row = threadIdx.x >> 1, side = threadIdx.x & 1;
+    *reinterpret_cast<f4r*>(&band[row * RS + (side ? BR_PAD + N : 0)]) = (f4r){0.f, 0.f, 0.f, 0.f};
+  }
+  if (threadIdx.x == 0) next_task = task0 + nw;
+  __syncthreads();
+  float two32 = 4294967296.0f;
+  asm("" : "+s"(two32));
+  const int t0 = b * BR_ROWS;
+  const float sdh = 0.5f * (float)(nd - 1);
+  const int ndp = nd + 2 * A32_PAD;
+  // a wave takes the next task when it has finished one (tasks at the image's edge and beside it cost differently)
+  for (int task = task0 + wv; task < task1;) {
+    const int ai = task / ndblk, dblk = task - ai * ndblk;
+    const int a = frame * na + sorted[frame * na + (mode ? n0 : 0) + ai].orig;                    // (scalar loads)
+    const AngleParam p = ang[a];
+    const int nlive = (nd - dblk * 64 < 64) ? nd - dblk * 64 : 64;
+    const bool live = lane < nlive;
+    const int d = dblk * 64 + lane;
+    const unsigned A = A32[(int64_t)a * ndp + (live ? d : nd - 1) + A32_PAD];      // dead lanes repeat the last ray; never stored
+    const unsigned* __restrict__ Ball = B32 + (int64_t)a * npad;
+    const float b0 = fmaf((float)(dblk * 64) - sdh, p.inv, p.k0), b1 = fmaf((float)(dblk * 64 + nlive - 1) - sdh, p.inv, p.k0);
+    const float blo = fminf(b0, b1), bhi = fmaxf(b0, b1);
+    double total = 0.0;
+#pragma unroll 1
+    for (int c = 0; c < BR_ROWS / 16; ++c) {
+      const int tb = t0 + 16 * c;
+      const float ta = (float)tb * p.dq, tz = (float)(tb + 15) * p.dq;
+      const float qlo = blo + fminf(ta, tz), qhi = bhi + fmaxf(ta, tz);
+      if (__builtin_amdgcn_readfirstlane((qhi < -2.f || qlo > (float)N + 1.f) ? 1 : 0)) continue;      // nothing of the wave touches the image here
+      const int cs = __builtin_amdgcn_readfirstlane((int)floorf(qlo) - 1);
+      const int ce = __builtin_amdgcn_readfirstlane((int)floorf(qhi) + 2);
+      const unsigned* __restrict__ Brow = static_cast<const unsigned*>(__builtin_assume_aligned(Ball + tb, 64));
+      const unsigned Ac = A - ((unsigned)cs << QF);              // column relative to cs (mod 256: the window is < 256 wide)
+      const char* rowp = reinterpret_cast<const char*>(band) + (16 * c) * RS * 4;
+      f2v acc2 = {0.f, 0.f};
+      if (cs >= 0 && ce <= N - 1) {
+        // every tap of the wave inside the image: address = row (scalar) + 4 (cs + pad) (scalar) + 4 * relative column
+        f2v w[16], t2[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const unsigned Q = Ac + Brow[u];
+          const float f1 = (float)(Q << 8);
+          w[u][1] = f1;
+          w[u][0] = two32 - f1;
+          int off = u * RS * 4 + (cs + BR_PAD) * 4;
+          asm("" : "+s"(off));
+          const float* tp = reinterpret_cast<const float*>(rowp + off + ((Q >> QF) << 2));
+          t2[u] = (f2v){tp[0], tp[1]};
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc2 = __builtin_elementwise_fma(w[u], t2[u], acc2);
+      } else {
+        // the window overhangs the image: columns clamped into the zero pads ([-2, N]: both taps of a clamped step read zeros)
+        f2v w[16], t2[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+          const unsigned Q = Ac + Brow[u];
+          const float f1 = (float)(Q << 8);
+          w[u][1] = f1;
+          w[u][0] = two32 - f1;
+          int col = cs + (int)(Q >> QF);
+          asm("v_med3_i32 %0, %1, -2, %2" : "=v"(col) : "v"(col), "s"(N));
+          int off = u * RS * 4 + BR_PAD * 4;
+          asm("" : "+s"(off));
+          const float* tp = reinterpret_cast<const float*>(rowp + off + (col << 2));
+          t2[u] = (f2v){tp[0], tp[1]};
+        }
+#pragma unroll
+        for (int u = 0; u < 16; ++u) acc2 = __builtin_elementwise_fma(w[u], t2[u], acc2);
+      }
+      total += (double)(acc2[0] + acc2[1]);
+    }
+    if (live) part[(int64_t)b * band_stride + (int64_t)a * nd + d] = (float)total;
+    int nx = 0;
+    if (lane == 0) nx = atomicAdd(&next_task, 1);
+    task = __builtin_amdgcn_readfirstlane(nx);
+  }
+}
+
 template <bool REC>
 __global__ __launch_bounds__(256) void k_radon_bands_post(const float* __restrict__ part, int nb, int64_t band_stride,
                                                           float* __restrict__ sino, int nd, const AngleParam* __restrict__ ang,
@@ -1792,8 +1954,9 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
       // the adjoint that produced xb may have left its transpose in xT already (hinted chain): then the copy costs nothing and the
       // kernel without the transposing staging is the faster one (512^2 x 180 inside Golub-Kahan: 24.5 vs 27.6 us)
       const bool have_xT = im->n_mode1 > 0 && (hints & HINT_INPUT_FROM_OPPOSITE) && im->xT_src == xb;
-      const int direct1 = (fp.direct1 && !have_xT) ? 1 : 0;
-      if (im->n_mode1 > 0 && !direct1) {
+      const bool band_res = im->band_res && !fp.win && lds;
+      const int direct1 = (fp.direct1 && !have_xT && !band_res) ? 1 : 0;
+      if (im->n_mode1 > 0 && !direct1 && !band_res) {
         if (have_xT) {
         } else {
           dim3 g(ceil_div(N, 32), ceil_div(N, 32), nt);
@@ -1808,7 +1971,24 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
       static const bool no_rec_out = getenv("TRK_RADON_NO_REC_OUT") != nullptr;     // tuning knobs: the producer side of the hints off
       const bool want_rec = (hints & HINT_OUT_FEEDS_OPPOSITE) && tile && adj_prep && batch == 1 && !no_rec_out;
       // measured: 512^2 35 us (shared) vs 32 us (per-wave windows); 2048^2 0.256 vs 0.277 ms; 4096^2 0.96 vs 1.11 ms
-      if (fp.win) {
+      if (band_res) {
+        const int nbr = N / BR_ROWS;
+        static const int slice_env = getenv("TRK_RADON_BANDRES_SLICES") ? atoi(getenv("TRK_RADON_BANDRES_SLICES")) : 0;
+        // one workgroup of 16 waves per CU whatever the width (measured at 32 frames of 256^2: two workgroups of 8 waves per CU, which the
+        // narrower band's LDS would allow, 18.4 us against 16.5)
+        const size_t lds_bytes = sizeof(float) * (size_t)BR_ROWS * (N + 2 * BR_PAD) + 16;
+        static const int per_cu_env = getenv("TRK_RADON_BANDRES_PER_CU") ? atoi(getenv("TRK_RADON_BANDRES_PER_CU")) : 1;
+        const int per_cu = (per_cu_env >= 2 && 2 * (lds_bytes + 512) <= 160 * 1024) ? 2 : 1;
+        int nslice = slice_env > 0 ? slice_env : (cu_count() * per_cu + nt * 2 * nbr / 2) / (nt * 2 * nbr);
+        if (nslice < 1) nslice = 1;
+        static bool attr_set = false;
+        if (!attr_set) {
+          TRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_radon_fwd_band), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(k_radon_fwd_band, dim3((unsigned)(nt * 2 * nbr * nslice)), dim3(per_cu >= 2 ? BR_NT / 2 : BR_NT), lds_bytes, s, xb, im->xT, im->part, N, nd, im->ang_dev,
+                           na, im->adj_ang, im->adj_n0, nslice, bs, im->A32, im->B32, im->npad, have_xT ? 1 : 0);
+      } else if (fp.win) {
         // window-sharing kernel: band partials of rays no window owns must read as zero
         if (hipMemsetAsync(im->part, 0, sizeof(float) * (size_t)nb * bs, s) != hipSuccess) return fail(TRK_EHIP, "radon: hipMemsetAsync failed");
         if (fp.quad) {
@@ -2151,6 +2331,9 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     const int64_t wgs128 = (int64_t)((n_det + 63) / 64) * ((na + 3) / 4) * ((N + RADON_BAND - 1) / RADON_BAND);
     if (wgs128 < 64 && N > 64) band = 64;
   }
+  // small images: a 64-row band of the image fits the LDS of a CU (k_radon_fwd_band).  TRK_RADON_NO_BANDRES=1: the per-wave windows
+  const bool band_res = N % BR_ROWS == 0 && N >= 2 * BR_ROWS && N <= BR_NMAX && getenv("TRK_RADON_NO_BANDRES") == nullptr;
+  if (band_res) band = BR_ROWS;
   if (const char* e = getenv("TRK_RADON_BAND")) {               // tuning knob; kept a positive multiple of RADON_CHUNK
     band = atoi(e);
     band = band < RADON_CHUNK ? RADON_CHUNK : (band / RADON_CHUNK) * RADON_CHUNK;
@@ -2158,6 +2341,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
   const int nb = (N + band - 1) / band;
   auto* im = new RadonImpl{};
   im->N = N; im->nd = n_det; im->na = na; im->nt = nt; im->n_mode1 = n1; im->npad = npad; im->n_bands = nb; im->band = band;
+  im->band_res = (band_res && band == BR_ROWS) ? 1 : 0;
   hipError_t e = hipSuccess;
   auto up = [&](void** dst, const void* src, size_t bytes) {
     if (e == hipSuccess) e = hipMalloc(dst, bytes);
