@@ -2,6 +2,10 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+if os.environ.get("TRK_EXPERIMENT_LIB"):          # a library built with experiment macros (tools/r05_band_exp.sh): timing only
+    from trips_py_amd import _lib as _L
+    _L.LIB_PATH = os.environ["TRK_EXPERIMENT_LIB"]
+    _L._stale = lambda: False
 from trips_py_amd.operators import Radon2DParallel
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 R = Radon2DParallel(N, np.linspace(0, np.pi, 180, endpoint=False))

@@ -1068,6 +1068,13 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
   const int task0 = (int)((int64_t)all_tasks * slice / nslice), task1 = (int)((int64_t)all_tasks * (slice + 1) / nslice);
   if (task1 <= task0) return;
   const int RS = N + 2 * BR_PAD;                                 // row stride in floats (a multiple of 4)
+#ifdef TRK_RADON_BAND_EXPERIMENT
+  // timing experiments only (tools/r05_band_exp.sh builds a separate library; results are wrong with either bit): have_xT & 2 = the
+  // band load alone, & 4 = the march alone (over whatever the LDS holds)
+  const bool x_loadonly = (have_xT & 2) != 0, x_noload = (have_xT & 4) != 0;
+  have_xT &= 1;
+  if (!x_noload)
+#endif
   if (mode && !have_xT) {
     // no transposed copy at hand: the band of the transposed image is 64 COLUMNS of the image — a wave-load takes 16 image rows x 16
     // columns (whole 64-byte sectors), a lane's four values go to four rows of the band (consecutive lanes: consecutive addresses)
@@ -1120,12 +1127,20 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
   }
   if (threadIdx.x == 0) next_task = task0 + nw;
   __syncthreads();
+#ifdef TRK_RADON_BAND_EXPERIMENT
+  if (x_loadonly) {
+    if (threadIdx.x == 0) part[blockIdx.x] = band[blockIdx.x & 1023];
+    return;
+  }
+#endif
   float two32 = 4294967296.0f;
   asm("" : "+s"(two32));
   const int t0 = b * BR_ROWS;
   const float sdh = 0.5f * (float)(nd - 1);
   const int ndp = nd + 2 * A32_PAD;
-  // a wave takes the next task when it has finished one (tasks at the image's edge and beside it cost differently)
+  // a wave takes the next task when it has finished one (tasks at the image's edge and beside it cost differently).  (Fetching the
+  // NEXT task's angle constants and table entries while the current one is marched, and the four chunks' windows at once, one per lane:
+  // measured 21.8 us against 20.4 — not kept.)
   for (int task = task0 + wv; task < task1;) {
     const int ai = task / ndblk, dblk = task - ai * ndblk;
     const int a = frame * na + sorted[frame * na + (mode ? n0 : 0) + ai].orig;                    // (scalar loads)
@@ -1987,7 +2002,12 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
           attr_set = true;
         }
         hipLaunchKernelGGL(k_radon_fwd_band, dim3((unsigned)(nt * 2 * nbr * nslice)), dim3(per_cu >= 2 ? BR_NT / 2 : BR_NT), lds_bytes, s, xb, im->xT, im->part, N, nd, im->ang_dev,
-                           na, im->adj_ang, im->adj_n0, nslice, bs, im->A32, im->B32, im->npad, have_xT ? 1 : 0);
+                           na, im->adj_ang, im->adj_n0, nslice, bs, im->A32, im->B32, im->npad,
+#ifdef TRK_RADON_BAND_EXPERIMENT
+                           (have_xT ? 1 : 0) | (getenv("TRK_RADON_BAND_X") ? atoi(getenv("TRK_RADON_BAND_X")) & 6 : 0));
+#else
+                           have_xT ? 1 : 0);
+#endif
       } else if (fp.win) {
         // window-sharing kernel: band partials of rays no window owns must read as zero
         if (hipMemsetAsync(im->part, 0, sizeof(float) * (size_t)nb * bs, s) != hipSuccess) return fail(TRK_EHIP, "radon: hipMemsetAsync failed");
@@ -2069,6 +2089,7 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
                      y + (int64_t)b * ldy, N, nd, na, im->adj_ang, im->adj_wgt, im->A32, im->adj_n0, im->CB, im->npad, tiles_x, \
                      ssq_part, epi, xT_out, nsplit, im->adj_part, im->adj_cnt)
       if (tile && tile_T == 32) {
+        // (16 angles per batch — half the barriers, twice the rings — measured at 512^2 x 180: 34.7 us against 29.9; not instantiated)
         if (adj_prep) ADJ_TILE(32, 4, 8, true); else ADJ_TILE(32, 4, 8, false);
       } else if (tile && (ab_env ? ab_env == 16 : na > 32)) {
         if (adj_prep) ADJ_TILE(16, 1, 16, true); else ADJ_TILE(16, 1, 16, false);
