@@ -203,6 +203,47 @@ def test_radon_adjoint_with_the_angles_of_a_tile_split_over_workgroups(N, na, nd
     assert abs(S.host()[0] - float((o2.double() ** 2).sum())) <= 1e-9 * float((o2.double() ** 2).sum())
 
 
+@pytest.mark.parametrize("N,na,nd,nt", [(128, 7, 100, 1), (192, 33, 300, 1), (320, 50, 453, 1), (512, 180, 724, 1), (256, 15, 364, 5),
+                                        (448, 3, 700, 2)])
+def test_radon_forward_with_the_band_resident_in_lds(N, na, nd, nt, monkeypatch):
+    """Small images (N a multiple of 64 up to 512): the forward projector keeps a 64-row band of the image — of the transposed image
+    for the column-driven angles — resident in LDS (k_radon_fwd_band).  (a) Against the float64 oracle; (b) against the per-wave-window
+    kernel it replaces (TRK_RADON_NO_BANDRES=1 at create: same tables, same weights, other partial sums: 1e-6); (c) both ways the
+    column bands are filled — transposed while loading (a plain apply) and from the transposed copy the adjoint leaves in a chain
+    (trk_op_apply_axpby with the hints of a Golub-Kahan step): the same bits; (d) angle sets of ONE marching mode, detectors that are not
+    a multiple of 64, several frames in one launch."""
+    from oracle import cpu_ref as O
+    from trips_py_amd.operators import Radon2DParallel, BlockDiagOp
+    rng = np.random.default_rng(N + na)
+    frames = [np.linspace(0.05 * f, np.pi + 0.05 * f, na, endpoint=False) for f in range(nt)]
+    if na == 3:
+        frames = [np.array([0.1, 0.2, 2.9]) + 0.01 * f for f in range(nt)]                   # row-driven angles only
+    def make():
+        ops = [Radon2DParallel(N, a, n_det=nd) for a in frames]
+        return ops[0] if nt == 1 else BlockDiagOp(ops)
+    R = make()
+    monkeypatch.setenv("TRK_RADON_NO_BANDRES", "1")
+    Rw = make()
+    monkeypatch.delenv("TRK_RADON_NO_BANDRES")
+    eng = R.engine
+    x = rng.standard_normal(nt * N * N).astype(np.float32)
+    xd = torch.from_numpy(x).to(eng.device)
+    got, old = R.apply(xd).clone(), Rw.apply(xd).clone()
+    ref = np.concatenate([O.Radon2D(N, a, n_det=nd) @ x[f * N * N:(f + 1) * N * N].astype(np.float64) for f, a in enumerate(frames)])
+    assert relerr(got.double().cpu().numpy(), ref) < 2e-6
+    assert relerr(got.double().cpu().numpy(), old.double().cpu().numpy()) < 1e-6
+    assert not torch.equal(got, old) or N == 128          # (another kernel: other partial sums — equal only by accident)
+    # in a chain: x = A^T y leaves its transpose behind, the forward apply that follows reads it
+    y = torch.from_numpy(rng.standard_normal(R.shape[0]).astype(np.float32)).to(eng.device)
+    xa = torch.empty_like(xd)
+    z = torch.zeros_like(xd)
+    R.apply_axpby(y, 1.0, 0.0, z, xa, transpose=True, hints=1)                               # TRK_HINT_OUT_FEEDS_OPPOSITE
+    chained = torch.empty_like(got)
+    R.apply_axpby(xa, 1.0, 0.0, torch.zeros_like(got), chained, hints=2)                     # TRK_HINT_INPUT_FROM_OPPOSITE
+    plain = R.apply(xa.clone()).clone()
+    assert torch.equal(plain, chained)
+
+
 @pytest.mark.parametrize("N,na", [(64, 20), (512, 180), (1500, 24)])
 def test_radon_invariants(N, na):
     """What pins the Radon operator: exact-adjoint identity, axis-aligned views = column / row sums, mass conservation,
