@@ -232,7 +232,7 @@ def test_radon_forward_with_the_band_resident_in_lds(N, na, nd, nt, monkeypatch)
     ref = np.concatenate([O.Radon2D(N, a, n_det=nd) @ x[f * N * N:(f + 1) * N * N].astype(np.float64) for f, a in enumerate(frames)])
     assert relerr(got.double().cpu().numpy(), ref) < 2e-6
     assert relerr(got.double().cpu().numpy(), old.double().cpu().numpy()) < 1e-6
-    assert not torch.equal(got, old) or N == 128          # (another kernel: other partial sums — equal only by accident)
+    # (where the per-wave-window kernel runs 64-row bands too — few workgroups — the two kernels agree to the bit: same chunks, same sums)
     # in a chain: x = A^T y leaves its transpose behind, the forward apply that follows reads it
     y = torch.from_numpy(rng.standard_normal(R.shape[0]).astype(np.float32)).to(eng.device)
     xa = torch.empty_like(xd)
