@@ -1387,28 +1387,37 @@ __device__ __forceinline__ void adj_gather(const u4r r, unsigned B, unsigned neg
   acc0 = fmaf(w0, __builtin_bit_cast(float, s0), acc0);
 }
 
-template <int T, int PX, int AB, bool PREP>
-__global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict__ sino, const uint4* __restrict__ rec,
+// G > 1 (round 5; a 512^2 image: 256 tiles = one per CU): the parts of a tile are G groups of four waves of ONE workgroup of 1024 threads —
+// the same angle ranges, the same batches, their own rings — whose partial tiles meet in LDS in part order: the same bits as the
+// split over workgroups, without write-through partial tiles, tickets and a finisher that starts when everybody else is done.
+template <int T, int PX, int AB, bool PREP, int G = 1>
+__global__ __launch_bounds__(256 * G) void k_radon_adj_tile(const float* __restrict__ sino, const uint4* __restrict__ rec,
                                                         float* __restrict__ img, int N, int nd, int na,
                                                         const AdjAngle* __restrict__ ang, const float* __restrict__ wgt,
                                                         const unsigned* __restrict__ A32, const int* __restrict__ n_mode0,
                                                         const uint2* __restrict__ CB, int npad, int tiles_x,
                                                         double* __restrict__ ssq_part, Epi epi, float* __restrict__ xT_out,
                                                         int nsplit, float* __restrict__ part_img, unsigned* __restrict__ tile_cnt) {
-  __shared__ __attribute__((aligned(16))) uint4 ring[2][AB][64];
-  __shared__ __attribute__((aligned(16))) uint2 cbs[2][AB][T];
-  __shared__ float xch[PX > 1 ? T : 1][T + 1];
+  __shared__ __attribute__((aligned(16))) uint4 ring_all[G][2][AB][64];
+  __shared__ __attribute__((aligned(16))) uint2 cbs_all[G][2][AB][T];
+  __shared__ float xch_all[G][PX > 1 ? T : 1][T + 1];
   static_assert(T * T == 256 * PX && (T == 16 || T == 32), "256 threads x PX pixels cover the T x T tile");
+  static_assert(G == 1 || (PX == 4 && T == 32), "groups: the 32 x 32 form only");
   __shared__ double lds[4];
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int tid = G > 1 ? (int)(threadIdx.x & 255) : (int)threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = G > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8)) : 0;
+  auto& ring = ring_all[grp];
+  auto& cbs = cbs_all[grp];
+  auto& xch = xch_all[grp];
   const int frame = blockIdx.y;
   // nsplit > 1 (small images: too few tiles to fill the chip with 32 x 32 tiles): workgroup (part, tile) gathers the sorted
   // angles [a_lo, a_hi) of the frame for its tile; the partial tiles meet in the workgroup that finishes LAST (below).  Parts of
   // one tile are ntiles workgroups apart: the same XCD when ntiles % 8 == 0 (speed only)
   const int ntiles = tiles_x * tiles_x;
-  const int part = nsplit > 1 ? blockIdx.x / ntiles : 0;
-  const int tile_id = blockIdx.x - part * ntiles;
+  if (G > 1) nsplit = G;
+  const int part = G > 1 ? grp : (nsplit > 1 ? blockIdx.x / ntiles : 0);
+  const int tile_id = G > 1 ? (int)blockIdx.x : (int)blockIdx.x - part * ntiles;
   const int ty = tile_id / tiles_x, tx = tile_id - ty * tiles_x;
   const int i0 = ty * T, j0 = tx * T;
   const int ndp = nd + 2 * A32_PAD;
@@ -1458,6 +1467,16 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
   asm("" : "+s"(nsc));
 
   const int nbatch = (na + AB - 1) / AB;
+  // groups: every group meets every barrier — the batches of the LARGEST part (a part may hold one angle more than another)
+  int nbatch_all = nbatch;
+  if (G > 1) {
+    nbatch_all = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int sz = (int)(((int64_t)(g + 1) * na_frame) / G) - (int)(((int64_t)g * na_frame) / G);
+      nbatch_all = (sz + AB - 1) / AB > nbatch_all ? (sz + AB - 1) / AB : nbatch_all;
+    }
+  }
   // Staging of batch b into buffer b & 1: wave w takes the rings of angles w, w + 4, ... of the batch, lane l the detector whose
   // ring slot is l.  PREP: the records {w S[d -], w S[d +], w S[d], A32[d]} were written by k_radon_adj_prep and go straight
   // to LDS (one 16-byte direct-to-LDS load per lane and angle).  !PREP: they are made here from the sinogram itself — four
@@ -1550,10 +1569,11 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
 
   stage_load(0);
   stage_store(0);
-  for (int b = 0; b < nbatch; ++b) {
+  for (int b = 0; b < nbatch_all; ++b) {
     const int buf = b & 1;
     __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): this wave's share of batch b has landed
     __syncthreads();                                 // batch b complete; everyone is done with the other buffer
+    if (G > 1 && b >= nbatch) continue;              // (a smaller part of the workgroup: only the barrier)
     if (b + 1 < nbatch) stage_load(b + 1);           // in flight while batch b is gathered
     const int nal = (na - b * AB < AB) ? na - b * AB : AB;
     // the batch's mode-0 angles come first (the angles are sorted by mode): two loops without a mode test inside, unrolled so
@@ -1627,7 +1647,23 @@ __global__ __launch_bounds__(256) void k_radon_adj_tile(const float* __restrict_
 #pragma unroll
   for (int k = 0; k < PX; ++k)
     oraw[k] = (accB[k] + (anB[k][0] + anB[k][1])) + (PX > 1 ? xch[r1 + k * TS][c1] : accA[k] + (anA[k][0] + anA[k][1]));
-  if (PX == 4 && nsplit > 1) {                                     // (the host splits only the 32 x 32 form)
+  if (G > 1) {
+    // the groups' partial tiles meet in LDS, added in part order by the first group, which carries the epilogue alone
+    __shared__ float red[G > 1 ? G - 1 : 1][256][PX];
+    if (grp > 0) {
+#pragma unroll
+      for (int k = 0; k < PX; ++k) red[grp - 1][tid][k] = oraw[k];
+    }
+    __syncthreads();
+    if (grp > 0) return;
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+      float t = oraw[k];
+#pragma unroll
+      for (int s = 1; s < G; ++s) t += red[s - 1][tid][k];
+      oraw[k] = t;
+    }
+  } else if (PX == 4 && nsplit > 1) {                              // (the host splits only the 32 x 32 form)
     // The parts of a tile meet: every workgroup leaves its partial tile (thread-major, 16 bytes per lane), then takes a ticket; the
     // one that draws the LAST ticket adds the partial tiles in part order (the same bits whoever comes last) and carries the
     // epilogue.  The parts may have run on different XCDs, whose L2s are not coherent: the bytes are stored WRITE-THROUGH (sc1) and
@@ -2088,7 +2124,17 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   hipLaunchKernelGGL((k_radon_adj_tile<TT, PP, BB, PR>), dim3((unsigned)(adj_blocks * nsplit), nt), dim3(256), 0, s, xb, im->rec, \
                      y + (int64_t)b * ldy, N, nd, na, im->adj_ang, im->adj_wgt, im->A32, im->adj_n0, im->CB, im->npad, tiles_x, \
                      ssq_part, epi, xT_out, nsplit, im->adj_part, im->adj_cnt)
-      if (tile && tile_T == 32) {
+      // the parts of a tile as groups of ONE workgroup where that gives about one workgroup per CU (512^2: 256 tiles)
+      static const int grp_env = getenv("TRK_RADON_ADJ_GROUPS") ? atoi(getenv("TRK_RADON_ADJ_GROUPS")) : 1;
+      const bool groups = grp_env != 0 && tile && tile_T == 32 && nsplit == 4 && adj_blocks * nt <= cu_count() && adj_blocks * nt * 4 >= 3 * cu_count();
+      if (groups) {
+        if (adj_prep) hipLaunchKernelGGL((k_radon_adj_tile<32, 4, 8, true, 4>), dim3((unsigned)adj_blocks, nt), dim3(1024), 0, s, xb, im->rec,
+                                         y + (int64_t)b * ldy, N, nd, na, im->adj_ang, im->adj_wgt, im->A32, im->adj_n0, im->CB, im->npad, tiles_x,
+                                         ssq_part, epi, xT_out, 1, im->adj_part, im->adj_cnt);
+        else hipLaunchKernelGGL((k_radon_adj_tile<32, 4, 8, false, 4>), dim3((unsigned)adj_blocks, nt), dim3(1024), 0, s, xb, im->rec,
+                                y + (int64_t)b * ldy, N, nd, na, im->adj_ang, im->adj_wgt, im->A32, im->adj_n0, im->CB, im->npad, tiles_x,
+                                ssq_part, epi, xT_out, 1, im->adj_part, im->adj_cnt);
+      } else if (tile && tile_T == 32) {
         // (16 angles per batch — half the barriers, twice the rings — measured at 512^2 x 180: 34.7 us against 29.9; not instantiated)
         if (adj_prep) ADJ_TILE(32, 4, 8, true); else ADJ_TILE(32, 4, 8, false);
       } else if (tile && (ab_env ? ab_env == 16 : na > 32)) {
