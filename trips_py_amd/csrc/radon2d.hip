@@ -1231,12 +1231,12 @@ __global__ __launch_bounds__(256) void k_radon_bands_post(const float* __restric
     if (dd < 0 || dd >= nd) return Raw{0.f, 0.f};
     const int64_t k = r * nd + dd;
     double t = 0.0;
-    for (int b0 = 0; b0 < nb; b0 += 4) {           // four band partials in flight, added in band order
-      float pv[4];
+    for (int b0 = 0; b0 < nb; b0 += 8) {           // eight band partials in flight (all of a 512-row image's 64-row bands), added in band order
+      float pv[8];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) pv[u] = (b0 + u < nb) ? part[(int64_t)(b0 + u) * band_stride + k] : 0.f;
+      for (int u = 0; u < 8; ++u) pv[u] = (b0 + u < nb) ? part[(int64_t)(b0 + u) * band_stride + k] : 0.f;
 #pragma unroll
-      for (int u = 0; u < 4; ++u) t += (double)pv[u];
+      for (int u = 0; u < 8; ++u) t += (double)pv[u];
     }
     return Raw{ang[r].wgt * (float)t, (epi.on && epi.z) ? epi.z[k] : 0.f};
   };
