@@ -61,6 +61,10 @@ struct FanImpl {
   float* xT;         // two padded copies of the image (forward: as it is / transposed), owned by the handle
   float reach;       // half width, in detector pixels per unit magnification, of the detector interval a pixel can touch
   int max_cand;      // most detectors that interval can hold anywhere in the image
+  // band-resident forward (small images): the rays by class (steep first), and band partials of their own
+  int* cls_list;     // [na * nd] ray indices: the n_steep steep rays in table order, then the shallow ones
+  int n_steep;
+  float* band_part;  // [N / 64][na * nd]
 };
 
 // One marching step of a ray: column (row) cl and its right neighbour, with their weights as fractions of the segment length.
@@ -237,6 +241,162 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
   if (!live_ray) return;
   if (gridDim.y == 1) sino[ray] = gq.len * (acc0 + acc1);
   else part[(int64_t)blockIdx.y * nrays + ray] = acc0 + acc1;
+}
+
+// Band-resident forward march (small images; round 5, as k_radon_fwd_band of radon2d.hip): a 64-row band of a 512-wide image is
+// 130 KB and fits the LDS of one CU.  k_fan_fwd_march takes its two taps per step with one scattered 8-byte load per lane, and the
+// texture addresser's rate for such loads (16.6 cycles per wave-load) IS its time (28 of 37 us at 512^2 x 180 x 724), behind a launch
+// that makes two padded copies of the image.  Here a workgroup of 16 waves loads its band once — rows of the image for the steep rays,
+// 64 COLUMNS transposed while loading for the shallow ones, zero columns either side: no padded copies — and every wave marches
+// tasks of 64 rays of the band's class (neighbours in the table) through the band's rows with LDS taps: the same integers, the same
+// weights (fan_split), the same skipping of rows no ray of the wave touches.  Band partials [band][ray] for k_fan_bands_sum.
+constexpr int FB_ROWS = 64, FB_NT = 1024, FB_PAD = 4, FB_NMAX = 512;
+__global__ __launch_bounds__(FB_NT, 4) void k_fan_fwd_band(const float* __restrict__ img, float* __restrict__ part, int N, int64_t nrays,
+                                                           const FanRay* __restrict__ rays, const int* __restrict__ cls_list, int n_steep,
+                                                           int nslice) {
+  extern __shared__ __attribute__((aligned(16))) float fband[];   // FB_ROWS x (N + 2 FB_PAD) floats, then the task counter
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
+  const int nw = (int)(blockDim.x >> 6), nthr = (int)blockDim.x;
+  const int nbands = N / FB_ROWS;
+  const int RS = N + 2 * FB_PAD;
+  int& next_task = *reinterpret_cast<int*>(fband + FB_ROWS * RS);
+  int bid = blockIdx.x;
+  const int slice = bid % nslice; bid /= nslice;
+  const int b = bid % nbands;
+  const int cls = bid / nbands;                                    // 0: steep rays (march over rows), 1: shallow (over columns)
+  const int cnt = cls ? (int)nrays - n_steep : n_steep;
+  const int* __restrict__ list = cls_list + (cls ? n_steep : 0);
+  const int all_tasks = (cnt + 63) / 64;
+  const int task0 = (int)((int64_t)all_tasks * slice / nslice), task1 = (int)((int64_t)all_tasks * (slice + 1) / nslice);
+  if (task1 <= task0) return;
+  typedef float f4b __attribute__((ext_vector_type(4)));
+  if (cls) {
+    // the band of the transposed image = 64 columns of the image: a wave-load takes 16 image rows x 16 columns (whole 64-byte
+    // sectors), a lane's four values go to four rows of the band (consecutive lanes: consecutive addresses)
+    const float* __restrict__ X = img + (int64_t)b * FB_ROWS;
+    const int r = lane & 15, jq = lane >> 4;
+    const int pieces = (N / 16) * 4;
+    for (int p0 = wv; p0 < pieces; p0 += 4 * nw) {
+      f4b v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pc = p0 + u * nw;
+        const int rg = pc >> 2, cg = pc & 3;
+        v[u] = pc < pieces ? *reinterpret_cast<const f4b*>(X + (int64_t)(16 * rg + r) * N + 16 * cg + 4 * jq) : (f4b){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pc = p0 + u * nw;
+        if (pc < pieces) {
+          const int rg = pc >> 2, cg = pc & 3;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) fband[(16 * cg + 4 * jq + e) * RS + FB_PAD + 16 * rg + r] = v[u][e];
+        }
+      }
+    }
+  } else {
+    const float* __restrict__ I = img + (int64_t)b * FB_ROWS * N;
+    const int q4 = N / 4, tot = FB_ROWS * q4;
+    for (int i0 = threadIdx.x; i0 < tot; i0 += 8 * nthr) {
+      f4b v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + u * nthr;
+        v[u] = idx < tot ? *reinterpret_cast<const f4b*>(I + 4 * (int64_t)idx) : (f4b){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int idx = i0 + u * nthr;
+        if (idx < tot) {
+          const int row = idx / q4, c4 = idx - row * q4;
+          *reinterpret_cast<f4b*>(&fband[row * RS + FB_PAD + 4 * c4]) = v[u];
+        }
+      }
+    }
+  }
+  if (threadIdx.x < FB_ROWS * 2) {
+    const int row = threadIdx.x >> 1, side = threadIdx.x & 1;
+    *reinterpret_cast<f4b*>(&fband[row * RS + (side ? FB_PAD + N : 0)]) = (f4b){0.f, 0.f, 0.f, 0.f};
+  }
+  if (threadIdx.x == 0) next_task = task0 + nw;
+  __syncthreads();
+  const int band0 = b * FB_ROWS;
+  for (int task = task0 + wv; task < task1;) {
+    const int li = task * 64 + lane;
+    const bool live_ray = li < cnt;
+    const int ray = list[live_ray ? li : cnt - 1];
+    const FanRay gq = rays[ray];
+    const FanRayRegs g = fan_ray_regs(gq);
+    float acc0 = 0.f, acc1 = 0.f;
+    int t0 = band0, t_end = band0 + FB_ROWS;
+    {
+      // the rows in which any ray of the wave can touch the image (k_fan_fwd_march: the same estimate, the same margins)
+      const float x0f = (float)((double)(g.x0 + (long long)g.mneg) * (1.0 / 1073741824.0));
+      const float mff = (float)g.m * (1.0f / 1073741824.0f);
+      const float lo = -6.f - x0f, hi = (float)N + 5.f - x0f;
+      float ta_f, tb_f;
+      if (fabsf(mff) < 1e-6f) {
+        const bool in = lo <= 0.f && hi >= 0.f;
+        ta_f = in ? -1e9f : 1e9f;
+        tb_f = in ? 1e9f : -1e9f;
+      } else {
+        const float r = __builtin_amdgcn_rcpf(mff), u1 = lo * r, u2 = hi * r;
+        ta_f = fminf(u1, u2) - 2.f;
+        tb_f = fmaxf(u1, u2) + 3.f;
+      }
+      int ta = (int)fminf(fmaxf(floorf(ta_f), -1e9f), 1e9f), tb = (int)fminf(fmaxf(ceilf(tb_f), -1e9f), 1e9f);
+      if (!live_ray) { ta = 0x7fffffff; tb = -0x7fffffff; }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        ta = min(ta, __shfl_xor(ta, off, 64));
+        tb = max(tb, __shfl_xor(tb, off, 64));
+      }
+      ta = __builtin_amdgcn_readfirstlane(ta);
+      tb = __builtin_amdgcn_readfirstlane(tb);
+      ta = ta > t0 ? ta : t0;
+      tb = tb < t_end ? tb : t_end;
+      if (ta >= tb) {
+        t0 = t_end;
+      } else {
+        t0 += (ta - t0) & ~7;
+        const int te = t0 + ((tb - t0 + 7) & ~7);
+        t_end = te < t_end ? te : t_end;
+      }
+    }
+    const long long pos0 = g.x0 + (long long)g.mneg + (long long)t0 * (long long)g.m;
+    int col = (int)(pos0 >> FAN_Q);
+    unsigned frac = (unsigned)pos0 << (32 - FAN_Q);
+    const int mi = g.m >> FAN_Q;
+    const unsigned mf = (unsigned)g.m << (32 - FAN_Q);
+    const char* base = reinterpret_cast<const char*>(fband) + FB_PAD * 4;
+    for (; t0 + 8 <= t_end; t0 += 8) {                             // (bands and the skipped prefix are multiples of eight rows)
+      float w0[8], w1[8];
+      fan_f2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        w0[u] = fan_split(frac, g.inv32);
+        w1[u] = 1.f - w0[u];
+        int cl;
+        asm("v_med3_i32 %0, %1, %2, %3" : "=v"(cl) : "v"(col), "n"(-2), "s"(N));
+        int rowoff = (t0 - band0 + u) * RS * 4;                  // wave-uniform: a scalar
+        asm("" : "+s"(rowoff));
+        const float* tp = reinterpret_cast<const float*>(base + rowoff + (cl << 2));
+        v[u] = (fan_f2){tp[0], tp[1]};
+        const unsigned nf = frac + mf;
+        col += mi + (nf < frac ? 1 : 0);
+        frac = nf;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        acc0 = fmaf(w0[u], v[u][0], acc0);
+        acc1 = fmaf(w1[u], v[u][1], acc1);
+      }
+    }
+    if (live_ray) part[(int64_t)b * nrays + ray] = acc0 + acc1;
+    int nx = 0;
+    if (lane == 0) nx = atomicAdd(&next_task, 1);
+    task = __builtin_amdgcn_readfirstlane(nx);
+  }
 }
 
 // sino[ray] = len * (the bands' sums, added in band order)
@@ -516,6 +676,24 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
     nbands = ceil_div(im->N, band);
     dim3 grid(ceil_div(nrays, 256), nbands);
     float* part = reinterpret_cast<float*>(im->recs);
+    static const bool no_bandres = getenv("TRK_FAN_NO_BANDRES") != nullptr;
+    if (im->band_part && !no_bandres && ldx >= (int64_t)im->N * im->N && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (batch == 1 || ldx % 4 == 0)) {
+      // small images: 64-row bands resident in LDS (k_fan_fwd_band), no padded copies
+      const int nbr = im->N / FB_ROWS;
+      const size_t lds_bytes = sizeof(float) * (size_t)FB_ROWS * (im->N + 2 * FB_PAD) + 16;
+      int nslice = (cu_count() + nbr) / (2 * nbr);
+      if (nslice < 1) nslice = 1;
+      static bool attr_set = false;
+      if (!attr_set) {
+        TRK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_fan_fwd_band), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+      for (int b = 0; b < batch; ++b) {
+        hipLaunchKernelGGL(k_fan_fwd_band, dim3((unsigned)(2 * nbr * nslice)), dim3(FB_NT), lds_bytes, s, x + (int64_t)b * ldx, im->band_part,
+                           im->N, nrays, im->rays, im->cls_list, im->n_steep, nslice);
+        hipLaunchKernelGGL(k_fan_bands_sum, dim3(ceil_div(nrays, 256)), dim3(256), 0, s, im->band_part, nbr, nrays, im->rays, y + (int64_t)b * ldy);
+      }
+    } else
     for (int b = 0; b < batch; ++b) {                                      // one pair of padded copies per handle: columns go one by one
       hipLaunchKernelGGL(k_fan_pad_copies, dim3(nb, nb, 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->xT, im->xT + padded, im->N);
       hipLaunchKernelGGL(k_fan_fwd_march, grid, dim3(256), 0, s, im->xT, padded, y + (int64_t)b * ldy, im->N,
@@ -559,6 +737,8 @@ void fan_destroy(trk_op* op) {
   if (im->rays) (void)hipFree(im->rays);
   if (im->recs) (void)hipFree(im->recs);
   if (im->xT) (void)hipFree(im->xT);
+  if (im->cls_list) (void)hipFree(im->cls_list);
+  if (im->band_part) (void)hipFree(im->band_part);
   delete im;
 }
 
@@ -588,7 +768,7 @@ extern "C" int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double s
     g.uys = (float)(st / det_pitch);
     h[a] = g;
   }
-  auto* im = new FanImpl{N, n_det, n_ang, (float)(sod + odd), (float)det_pitch, nullptr, nullptr, nullptr, nullptr, 0.f, 1 << 30};
+  auto* im = new FanImpl{N, n_det, n_ang, (float)(sod + odd), (float)det_pitch, nullptr, nullptr, nullptr, nullptr, 0.f, 1 << 30, nullptr, 0, nullptr};
   hipError_t e = hipMalloc(&im->ang_dev, sizeof(FanAngle) * n_ang);
   if (e == hipSuccess) e = hipMemcpy(im->ang_dev, h.data(), sizeof(FanAngle) * n_ang, hipMemcpyHostToDevice);
   // row-march table: needs every ray to cross the whole image, i.e. source and detector outside its circumscribed circle
@@ -625,6 +805,17 @@ extern "C" int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double s
     }
     e = hipMalloc(&im->rays, sizeof(FanRay) * rt.size());
     if (e == hipSuccess) e = hipMemcpy(im->rays, rt.data(), sizeof(FanRay) * rt.size(), hipMemcpyHostToDevice);
+    if (e == hipSuccess && N % FB_ROWS == 0 && N >= 2 * FB_ROWS && N <= FB_NMAX) {
+      // the band-resident forward: rays by class, in table order
+      std::vector<int> lst;
+      lst.reserve(rt.size());
+      for (size_t i = 0; i < rt.size(); ++i) if (!(rt[i].x0_lo & 1u)) lst.push_back((int)i);
+      im->n_steep = (int)lst.size();
+      for (size_t i = 0; i < rt.size(); ++i) if (rt[i].x0_lo & 1u) lst.push_back((int)i);
+      e = hipMalloc(&im->cls_list, sizeof(int) * lst.size());
+      if (e == hipSuccess) e = hipMemcpy(im->cls_list, lst.data(), sizeof(int) * lst.size(), hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc(&im->band_part, sizeof(float) * (size_t)(N / FB_ROWS) * rt.size());
+    }
     if (e == hipSuccess) e = hipMalloc(&im->recs, sizeof(FanRay) * (size_t)n_ang * (n_det + 2 * 2));   // rows padded for the adjoint (FAN_RP)
     const size_t padded = (size_t)N * (N + 2 * FAN_PAD);                 // two padded copies; the pad columns stay zero for good
     if (e == hipSuccess) e = hipMalloc(&im->xT, sizeof(float) * 2 * padded);
