@@ -1042,19 +1042,21 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restri
 // start (the tables know the column mod 256), then the seven instructions of a step.  Chunks of 16 rows in fp32, flushed to float64,
 // as k_radon_fwd_lds sums them; the band partials go to the same array (64-row bands).  Grid: frames x {row bands, column bands} x
 // slices of that mode's angle list (adj_ang: the angles sorted by mode), about one workgroup per CU.
-constexpr int BR_ROWS = 64, BR_NW = 16, BR_NT = 64 * BR_NW, BR_PAD = 4, BR_NMAX = 512;
+constexpr int BR_ROWS = 64, BR_NW = 16, BR_NT = 64 * BR_NW, BR_PAD = 4, BR_NMAX = 1024;
+// rows per band: 64 where 64 x (N + 8) floats fit (N <= 512), else 32 (N <= 1024: 132 KB)
+inline int br_rows(int N) { return (size_t)BR_ROWS * (N + 2 * BR_PAD) * 4 <= 150 * 1024 ? BR_ROWS : BR_ROWS / 2; }
 __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __restrict__ img, const float* __restrict__ imgT,
                                                              float* __restrict__ part, int N, int nd,
                                                              const AngleParam* __restrict__ ang, int na,
                                                              const AdjAngle* __restrict__ sorted, const int* __restrict__ n_mode0,
                                                              int nslice, int64_t band_stride,
                                                              const unsigned* __restrict__ A32, const unsigned* __restrict__ B32, int npad,
-                                                             int have_xT) {
-  extern __shared__ __attribute__((aligned(16))) float band[];   // BR_ROWS x (N + 2 BR_PAD) floats, then the task counter
+                                                             int have_xT, int rows) {
+  extern __shared__ __attribute__((aligned(16))) float band[];   // rows x (N + 2 BR_PAD) floats, then the task counter
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
-  const int nbands = N / BR_ROWS;
+  const int nbands = N / rows;
   const int nw = (int)(blockDim.x >> 6), nthr = (int)blockDim.x;   // 16 waves (one workgroup per CU) or 8 (narrow images: two per CU)
-  int& next_task = *reinterpret_cast<int*>(band + BR_ROWS * (N + 2 * BR_PAD));
+  int& next_task = *reinterpret_cast<int*>(band + rows * (N + 2 * BR_PAD));
   // blockIdx.x = ((frame * 2 + mode) * nbands + b) * nslice + slice
   int bid = blockIdx.x;
   const int slice = bid % nslice; bid /= nslice;
@@ -1078,22 +1080,22 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
   if (mode && !have_xT) {
     // no transposed copy at hand: the band of the transposed image is 64 COLUMNS of the image — a wave-load takes 16 image rows x 16
     // columns (whole 64-byte sectors), a lane's four values go to four rows of the band (consecutive lanes: consecutive addresses)
-    const float* __restrict__ X = img + (int64_t)frame * N * N + (int64_t)b * BR_ROWS;
+    const float* __restrict__ X = img + (int64_t)frame * N * N + (int64_t)b * rows;
     const int r = lane & 15, jq = lane >> 4;
-    const int pieces = (N / 16) * 4;                               // (16-row group, 16-column group)
+    const int cgs = rows / 16, pieces = (N / 16) * cgs;            // (16-row group, 16-column group)
     for (int p0 = wv; p0 < pieces; p0 += 4 * nw) {
       f4r v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pc = p0 + u * nw;
-        const int rg = pc >> 2, cg = pc & 3;
+        const int rg = pc / cgs, cg = pc - rg * cgs;
         v[u] = pc < pieces ? *reinterpret_cast<const f4r*>(X + (int64_t)(16 * rg + r) * N + 16 * cg + 4 * jq) : (f4r){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pc = p0 + u * nw;
         if (pc < pieces) {
-          const int rg = pc >> 2, cg = pc & 3;
+          const int rg = pc / cgs, cg = pc - rg * cgs;
 #pragma unroll
           for (int e = 0; e < 4; ++e) band[(16 * cg + 4 * jq + e) * RS + BR_PAD + 16 * rg + r] = v[u][e];
         }
@@ -1101,8 +1103,8 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
     }
   } else {
     // the band: 64 rows x N floats as float4, 8 (N = 512) per thread in flight
-    const float* __restrict__ I = (mode ? imgT : img) + (int64_t)frame * N * N + (int64_t)b * BR_ROWS * N;
-    const int q4 = N / 4, tot = BR_ROWS * q4;
+    const float* __restrict__ I = (mode ? imgT : img) + (int64_t)frame * N * N + (int64_t)b * rows * N;
+    const int q4 = N / 4, tot = rows * q4;
     for (int i0 = threadIdx.x; i0 < tot; i0 += 8 * nthr) {
       f4r v[8];
 #pragma unroll
@@ -1121,7 +1123,7 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
     }
   }
   // the pads are zeros
-  if (threadIdx.x < BR_ROWS * 2) {
+  if (threadIdx.x < rows * 2) {
     const int row = threadIdx.x >> 1, side = threadIdx.x & 1;
     *reinterpret_cast<f4r*>(&band[row * RS + (side ? BR_PAD + N : 0)]) = (f4r){0.f, 0.f, 0.f, 0.f};
   }
@@ -1135,7 +1137,7 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
 #endif
   float two32 = 4294967296.0f;
   asm("" : "+s"(two32));
-  const int t0 = b * BR_ROWS;
+  const int t0 = b * rows;
   const float sdh = 0.5f * (float)(nd - 1);
   const int ndp = nd + 2 * A32_PAD;
   // a wave takes the next task when it has finished one (tasks at the image's edge and beside it cost differently).  (Fetching the
@@ -1155,7 +1157,7 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
     const float blo = fminf(b0, b1), bhi = fmaxf(b0, b1);
     double total = 0.0;
 #pragma unroll 1
-    for (int c = 0; c < BR_ROWS / 16; ++c) {
+    for (int c = 0; c < rows / 16; ++c) {
       const int tb = t0 + 16 * c;
       const float ta = (float)tb * p.dq, tz = (float)(tb + 15) * p.dq;
       const float qlo = blo + fminf(ta, tz), qhi = bhi + fmaxf(ta, tz);
@@ -1884,7 +1886,7 @@ FwdPath fwd_path(const RadonImpl* im, const float* xb) {
   f.dma = dma;
   // measured: 512^2 35 us (shared) vs 32 us (per-wave windows); 2048^2 0.256 vs 0.277 ms; 4096^2 0.96 vs 1.11 ms
   static const int win_min = getenv("TRK_RADON_WIN_MIN") ? atoi(getenv("TRK_RADON_WIN_MIN")) : 1024;     // tuning knob
-  f.win = im->n_bands > 1 && im->N >= win_min && f.lds && dma && !no_win && im->band <= WIN_R * WIN_MAXCH;
+  f.win = im->n_bands > 1 && im->N >= win_min && f.lds && dma && !no_win && im->band <= WIN_R * WIN_MAXCH && !im->band_res;
   f.direct1 = f.lds && !f.win && !no_direct1;
   // four symmetric angles per wave, conflict-free half-wave windows (k_radon_fwd_quad): 4096^2 x 180 0.94 -> see DESIGN.md 4.4
   static const bool no_quad = getenv("TRK_RADON_NO_QUAD") != nullptr;
@@ -2024,11 +2026,11 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
       const bool want_rec = (hints & HINT_OUT_FEEDS_OPPOSITE) && tile && adj_prep && batch == 1 && !no_rec_out;
       // measured: 512^2 35 us (shared) vs 32 us (per-wave windows); 2048^2 0.256 vs 0.277 ms; 4096^2 0.96 vs 1.11 ms
       if (band_res) {
-        const int nbr = N / BR_ROWS;
+        const int rows = im->band, nbr = N / rows;
         static const int slice_env = getenv("TRK_RADON_BANDRES_SLICES") ? atoi(getenv("TRK_RADON_BANDRES_SLICES")) : 0;
         // one workgroup of 16 waves per CU whatever the width (measured at 32 frames of 256^2: two workgroups of 8 waves per CU, which the
         // narrower band's LDS would allow, 18.4 us against 16.5)
-        const size_t lds_bytes = sizeof(float) * (size_t)BR_ROWS * (N + 2 * BR_PAD) + 16;
+        const size_t lds_bytes = sizeof(float) * (size_t)rows * (N + 2 * BR_PAD) + 16;
         static const int per_cu_env = getenv("TRK_RADON_BANDRES_PER_CU") ? atoi(getenv("TRK_RADON_BANDRES_PER_CU")) : 1;
         const int per_cu = (per_cu_env >= 2 && 2 * (lds_bytes + 512) <= 160 * 1024) ? 2 : 1;
         int nslice = slice_env > 0 ? slice_env : (cu_count() * per_cu + nt * 2 * nbr / 2) / (nt * 2 * nbr);
@@ -2041,9 +2043,9 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
         hipLaunchKernelGGL(k_radon_fwd_band, dim3((unsigned)(nt * 2 * nbr * nslice)), dim3(per_cu >= 2 ? BR_NT / 2 : BR_NT), lds_bytes, s, xb, im->xT, im->part, N, nd, im->ang_dev,
                            na, im->adj_ang, im->adj_n0, nslice, bs, im->A32, im->B32, im->npad,
 #ifdef TRK_RADON_BAND_EXPERIMENT
-                           (have_xT ? 1 : 0) | (getenv("TRK_RADON_BAND_X") ? atoi(getenv("TRK_RADON_BAND_X")) & 6 : 0));
+                           (have_xT ? 1 : 0) | (getenv("TRK_RADON_BAND_X") ? atoi(getenv("TRK_RADON_BAND_X")) & 6 : 0), rows);
 #else
-                           have_xT ? 1 : 0);
+                           have_xT ? 1 : 0, rows);
 #endif
       } else if (fp.win) {
         // window-sharing kernel: band partials of rays no window owns must read as zero
@@ -2401,7 +2403,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
   }
   // small images: a 64-row band of the image fits the LDS of a CU (k_radon_fwd_band).  TRK_RADON_NO_BANDRES=1: the per-wave windows
   const bool band_res = N % BR_ROWS == 0 && N >= 2 * BR_ROWS && N <= BR_NMAX && getenv("TRK_RADON_NO_BANDRES") == nullptr;
-  if (band_res) band = BR_ROWS;
+  if (band_res) band = br_rows(N);
   if (const char* e = getenv("TRK_RADON_BAND")) {               // tuning knob; kept a positive multiple of RADON_CHUNK
     band = atoi(e);
     band = band < RADON_CHUNK ? RADON_CHUNK : (band / RADON_CHUNK) * RADON_CHUNK;
@@ -2409,7 +2411,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
   const int nb = (N + band - 1) / band;
   auto* im = new RadonImpl{};
   im->N = N; im->nd = n_det; im->na = na; im->nt = nt; im->n_mode1 = n1; im->npad = npad; im->n_bands = nb; im->band = band;
-  im->band_res = (band_res && band == BR_ROWS) ? 1 : 0;
+  im->band_res = (band_res && band == br_rows(N)) ? 1 : 0;
   hipError_t e = hipSuccess;
   auto up = [&](void** dst, const void* src, size_t bytes) {
     if (e == hipSuccess) e = hipMalloc(dst, bytes);
