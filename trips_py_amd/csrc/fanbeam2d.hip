@@ -250,16 +250,18 @@ __global__ __launch_bounds__(256) void k_fan_fwd_march(const float* __restrict__
 // 64 COLUMNS transposed while loading for the shallow ones, zero columns either side: no padded copies — and every wave marches
 // tasks of 64 rays of the band's class (neighbours in the table) through the band's rows with LDS taps: the same integers, the same
 // weights (fan_split), the same skipping of rows no ray of the wave touches.  Band partials [band][ray] for k_fan_bands_sum.
-constexpr int FB_ROWS = 64, FB_NT = 1024, FB_PAD = 4, FB_NMAX = 512;
+constexpr int FB_ROWS = 64, FB_NT = 1024, FB_PAD = 4, FB_NMAX = 1024;
+// rows per band: 64 where 64 x (N + 8) floats fit the LDS (N <= 512), else 32 (N <= 1024: 132 KB)
+inline int fb_rows(int N) { return (size_t)FB_ROWS * (N + 2 * FB_PAD) * 4 <= 150 * 1024 ? FB_ROWS : FB_ROWS / 2; }
 __global__ __launch_bounds__(FB_NT, 4) void k_fan_fwd_band(const float* __restrict__ img, float* __restrict__ part, int N, int64_t nrays,
                                                            const FanRay* __restrict__ rays, const int* __restrict__ cls_list, int n_steep,
-                                                           int nslice) {
-  extern __shared__ __attribute__((aligned(16))) float fband[];   // FB_ROWS x (N + 2 FB_PAD) floats, then the task counter
+                                                           int nslice, int rows) {
+  extern __shared__ __attribute__((aligned(16))) float fband[];   // rows x (N + 2 FB_PAD) floats, then the task counter
   const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63;
   const int nw = (int)(blockDim.x >> 6), nthr = (int)blockDim.x;
-  const int nbands = N / FB_ROWS;
+  const int nbands = N / rows;
   const int RS = N + 2 * FB_PAD;
-  int& next_task = *reinterpret_cast<int*>(fband + FB_ROWS * RS);
+  int& next_task = *reinterpret_cast<int*>(fband + rows * RS);
   int bid = blockIdx.x;
   const int slice = bid % nslice; bid /= nslice;
   const int b = bid % nbands;
@@ -273,30 +275,30 @@ __global__ __launch_bounds__(FB_NT, 4) void k_fan_fwd_band(const float* __restri
   if (cls) {
     // the band of the transposed image = 64 columns of the image: a wave-load takes 16 image rows x 16 columns (whole 64-byte
     // sectors), a lane's four values go to four rows of the band (consecutive lanes: consecutive addresses)
-    const float* __restrict__ X = img + (int64_t)b * FB_ROWS;
+    const float* __restrict__ X = img + (int64_t)b * rows;
     const int r = lane & 15, jq = lane >> 4;
-    const int pieces = (N / 16) * 4;
+    const int cgs = rows / 16, pieces = (N / 16) * cgs;
     for (int p0 = wv; p0 < pieces; p0 += 4 * nw) {
       f4b v[4];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pc = p0 + u * nw;
-        const int rg = pc >> 2, cg = pc & 3;
+        const int rg = pc / cgs, cg = pc - rg * cgs;
         v[u] = pc < pieces ? *reinterpret_cast<const f4b*>(X + (int64_t)(16 * rg + r) * N + 16 * cg + 4 * jq) : (f4b){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int pc = p0 + u * nw;
         if (pc < pieces) {
-          const int rg = pc >> 2, cg = pc & 3;
+          const int rg = pc / cgs, cg = pc - rg * cgs;
 #pragma unroll
           for (int e = 0; e < 4; ++e) fband[(16 * cg + 4 * jq + e) * RS + FB_PAD + 16 * rg + r] = v[u][e];
         }
       }
     }
   } else {
-    const float* __restrict__ I = img + (int64_t)b * FB_ROWS * N;
-    const int q4 = N / 4, tot = FB_ROWS * q4;
+    const float* __restrict__ I = img + (int64_t)b * rows * N;
+    const int q4 = N / 4, tot = rows * q4;
     for (int i0 = threadIdx.x; i0 < tot; i0 += 8 * nthr) {
       f4b v[8];
 #pragma unroll
@@ -314,13 +316,13 @@ __global__ __launch_bounds__(FB_NT, 4) void k_fan_fwd_band(const float* __restri
       }
     }
   }
-  if (threadIdx.x < FB_ROWS * 2) {
+  if (threadIdx.x < rows * 2) {
     const int row = threadIdx.x >> 1, side = threadIdx.x & 1;
     *reinterpret_cast<f4b*>(&fband[row * RS + (side ? FB_PAD + N : 0)]) = (f4b){0.f, 0.f, 0.f, 0.f};
   }
   if (threadIdx.x == 0) next_task = task0 + nw;
   __syncthreads();
-  const int band0 = b * FB_ROWS;
+  const int band0 = b * rows;
   for (int task = task0 + wv; task < task1;) {
     const int li = task * 64 + lane;
     const bool live_ray = li < cnt;
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(FB_NT, 4) void k_fan_fwd_band(const float* __restri
     const FanRay gq = rays[ray];
     const FanRayRegs g = fan_ray_regs(gq);
     float acc0 = 0.f, acc1 = 0.f;
-    int t0 = band0, t_end = band0 + FB_ROWS;
+    int t0 = band0, t_end = band0 + rows;
     {
       // the rows in which any ray of the wave can touch the image (k_fan_fwd_march: the same estimate, the same margins)
       const float x0f = (float)((double)(g.x0 + (long long)g.mneg) * (1.0 / 1073741824.0));
@@ -679,8 +681,8 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
     static const bool no_bandres = getenv("TRK_FAN_NO_BANDRES") != nullptr;
     if (im->band_part && !no_bandres && ldx >= (int64_t)im->N * im->N && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (batch == 1 || ldx % 4 == 0)) {
       // small images: 64-row bands resident in LDS (k_fan_fwd_band), no padded copies
-      const int nbr = im->N / FB_ROWS;
-      const size_t lds_bytes = sizeof(float) * (size_t)FB_ROWS * (im->N + 2 * FB_PAD) + 16;
+      const int rows = fb_rows(im->N), nbr = im->N / rows;
+      const size_t lds_bytes = sizeof(float) * (size_t)rows * (im->N + 2 * FB_PAD) + 16;
       int nslice = (cu_count() + nbr) / (2 * nbr);
       if (nslice < 1) nslice = 1;
       static bool attr_set = false;
@@ -690,7 +692,7 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
       }
       for (int b = 0; b < batch; ++b) {
         hipLaunchKernelGGL(k_fan_fwd_band, dim3((unsigned)(2 * nbr * nslice)), dim3(FB_NT), lds_bytes, s, x + (int64_t)b * ldx, im->band_part,
-                           im->N, nrays, im->rays, im->cls_list, im->n_steep, nslice);
+                           im->N, nrays, im->rays, im->cls_list, im->n_steep, nslice, rows);
         hipLaunchKernelGGL(k_fan_bands_sum, dim3(ceil_div(nrays, 256)), dim3(256), 0, s, im->band_part, nbr, nrays, im->rays, y + (int64_t)b * ldy);
       }
     } else
@@ -814,7 +816,7 @@ extern "C" int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double s
       for (size_t i = 0; i < rt.size(); ++i) if (rt[i].x0_lo & 1u) lst.push_back((int)i);
       e = hipMalloc(&im->cls_list, sizeof(int) * lst.size());
       if (e == hipSuccess) e = hipMemcpy(im->cls_list, lst.data(), sizeof(int) * lst.size(), hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = hipMalloc(&im->band_part, sizeof(float) * (size_t)(N / FB_ROWS) * rt.size());
+      if (e == hipSuccess) e = hipMalloc(&im->band_part, sizeof(float) * (size_t)(N / fb_rows(N)) * rt.size());
     }
     if (e == hipSuccess) e = hipMalloc(&im->recs, sizeof(FanRay) * (size_t)n_ang * (n_det + 2 * 2));   // rows padded for the adjoint (FAN_RP)
     const size_t padded = (size_t)N * (N + 2 * FAN_PAD);                 // two padded copies; the pad columns stay zero for good
