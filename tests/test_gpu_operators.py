@@ -655,6 +655,33 @@ def test_half_step_entry_point_serves_any_operator():
         A.apply_axpby(x, 1.0, 1.0, z, x)
 
 
+@pytest.mark.parametrize("N,na", [(128, 24), (192, 31), (512, 45), (640, 20)])
+def test_fanbeam_forward_with_the_band_resident_in_lds(N, na, monkeypatch):
+    """Images up to 1024 wide (N a multiple of 64): the fan-beam forward marches its rays through 64-row (32-row beyond 512 columns)
+    bands held in LDS (k_fan_fwd_band) instead of gathering two taps per step through the texture path from padded copies.  The same
+    integers and weights, other partial sums: against the gather march (TRK_FAN_NO_BANDRES=1) at 1e-6, against the brute-force float64
+    oracle at the small size, and the pair stays matched."""
+    from oracle import cpu_ref as O
+    from trips_py_amd.operators import FanBeam2D
+    ang = np.linspace(0.0, 2 * np.pi, na, endpoint=False) + 0.013
+    A = FanBeam2D(N, angles=ang)
+    eng = A.engine
+    g = torch.Generator(device=eng.device).manual_seed(N + na)
+    x = torch.randn(N * N, device=eng.device, generator=g)
+    got = A.apply(x).clone()
+    monkeypatch.setenv("TRK_FAN_NO_BANDRES", "1")
+    old = A.apply(x).clone()
+    monkeypatch.delenv("TRK_FAN_NO_BANDRES")
+    assert relerr(got.double().cpu().numpy(), old.double().cpu().numpy()) < 1e-6
+    assert torch.equal(A.apply(x), got)                                   # (and back on the band-resident path: the same bits every time)
+    if N <= 128:
+        Ao = O.FanBeam2D(N, ang)
+        assert relerr(got.double().cpu().numpy(), Ao @ x.double().cpu().numpy()) < 1e-5
+    y = torch.randn(A.shape[0], device=eng.device, generator=g)
+    lhs, rhs = float(got.double() @ y.double()), float(x.double() @ A.apply(y, transpose=True).double())
+    assert abs(lhs - rhs) <= 2e-6 * float(torch.linalg.norm(got.double()) * torch.linalg.norm(y.double()))
+
+
 @pytest.mark.parametrize("N,pitch,nd", [(64, 4.0, 24), (64, 3.0, 40), (96, 2.5, 60), (64, 1.2, 90)])
 def test_fanbeam_coarse_detector_adjoint_is_matched(N, pitch, nd):
     """A detector pitch coarser than a pixel's footprint (2 w < 1): most pixels see NO ray of a view, and the adjoint's candidate

@@ -678,7 +678,7 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
     nbands = ceil_div(im->N, band);
     dim3 grid(ceil_div(nrays, 256), nbands);
     float* part = reinterpret_cast<float*>(im->recs);
-    static const bool no_bandres = getenv("TRK_FAN_NO_BANDRES") != nullptr;
+    const bool no_bandres = getenv("TRK_FAN_NO_BANDRES") != nullptr;       // (read per call: tests switch it)
     if (im->band_part && !no_bandres && ldx >= (int64_t)im->N * im->N && (reinterpret_cast<uintptr_t>(x) & 15u) == 0 && (batch == 1 || ldx % 4 == 0)) {
       // small images: 64-row bands resident in LDS (k_fan_fwd_band), no padded copies
       const int rows = fb_rows(im->N), nbr = im->N / rows;
