@@ -529,9 +529,11 @@ int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, doubl
 /* ACCURACY CONTRACT of trk_wgram_tv / trk_wgram_tv_z, and the switch.  The 16 x 16 tile products go through the matrix cores; `mode`:
  *   1 (default)  AUTO: two bf16 pieces unless the data says otherwise.  Every call first measures, on a sample (runs of 1024 pixels in 256 image
  *                rows, four of the k basis vectors), what the two-piece split would lose — max |S' - S| / sqrt(S_aa S_bb) of the sampled Gram with
- *                and without the split, in float64 — and the verdict, left on the DEVICE, lets one launch of a pair run: the two-piece
- *                form below 3e-7, the fp32 pipe above (nothing visits the host; a probe of ~12 MB of reads whatever the image size and the idle
- *                launches of the pair per call).  <= 1e-6 per entry relative to sqrt(G_aa G_bb) on data the sample represents; the piecewise-
+ *                and without the split, in float64 — and the verdict stays on the DEVICE: ONE Gram launch holds both arithmetic forms, every
+ *                workgroup works the verdict out from the probe's sums in its prologue and takes the sweep of the form it names — two pieces
+ *                below 3e-7, the fp32 pipe above (nothing visits the host; the probe reads ~12 MB whatever the image size).  TRK_WGRAM_TV_AUTO_PAIR=1
+ *                selects the older A/B arrangement instead (a gated PAIR of launches, one of which returns at once).
+ *                <= 1e-6 per entry relative to sqrt(G_aa G_bb) on data the sample represents; the piecewise-
  *                constant / repeated-value images of tests/test_gpu_kernels.py trip it, noisy images and Krylov vectors do not.
  *   2            each weighted difference split into TWO bf16 pieces, all four partial products: what is lost is each operand's third
  *                piece, <= 2^-16 of it.  On data whose roundings are uncorrelated the Gram is within 5e-9 of the fp32-pipe one; on
@@ -539,11 +541,14 @@ int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, doubl
  *   3            THREE bf16 pieces (the fp32 value exactly), six partial products: <= 1e-6 on those images (measured 4.7e-7), at
  *                1.1-1.5 x the time for 17 <= k <= 32;
  *   0            the fp32 matrix pipe (v_mfma_f32_16x16x4_f32): fp32 products, <= 1e-6 likewise, 0.51-0.57 ms at 4096^2 whatever k.
- * Returns the mode in force before the call; mode -1 only queries.  Process-wide (not per stream); environment TRK_WGRAM_TV_F32=1 /
+ * Returns the mode in force before the call; mode -1 only queries.  PROCESS-WIDE and NOT THREAD-SAFE: one plain global read by every
+ * trk_wgram_tv* call on any stream — a caller that switches it around a solve (MMGKS(gram_precision=)) must not run another solve on
+ * another thread meanwhile (the engine's model is one process per GPU, one solve at a time).  Environment TRK_WGRAM_TV_F32=1 /
  * TRK_WGRAM_TV_PIECES=2|3 set the default. */
 int trk_wgram_tv_precision(int mode);
 /* Diagnostics: {verdict (0 two pieces ran, 1 the fp32 pipe ran), the sampled deviation} of the LAST call in mode 1, copied to two host
- * doubles after a device synchronisation; {-1, -1} before the first such call. */
+ * doubles after a device synchronisation; {-1, -1} before the first such call.  (The record is written by workgroup 0 of the Gram launch
+ * alone — every workgroup derives the same verdict from the same sums, one of them reports it.) */
 int trk_wgram_tv_last_probe(double* verdict_and_deviation_host);
 /* The same pass also taking h[j] = V[j] . z for one more image z (n floats, 16-byte aligned): MMGKS forms the new Gram row
  * V^T (A^T A v_new) of the fidelity term (MMGKS.py:58 through its Gram matrix) and the re-weighted Gram of the regulariser for the

@@ -167,6 +167,41 @@ def test_radon_shared_window_forward_vs_oracle(case):
     assert abs(dd[0] - dd[1]) <= 1e-6 * float(torch.linalg.norm(Rx.double()) * torch.linalg.norm(yd.double()))
 
 
+@pytest.mark.parametrize("case", ["deg180", "quads", "signs", "scattered", "ragged1028", "wide_detector", "dynamic"])
+def test_radon_lean_quad_kernel_equals_the_round4_kernel_bit_for_bit(case, monkeypatch):
+    """Round 6: k_radon_fwd_quadf (the march alone, its bookkeeping from a per-operator plan: k_radon_quad_plan) serves the workgroups
+    the plan allows, k_radon_fwd_quad the listed rest.  Both own the same rays and add the same products in the same order, so the
+    sinogram must not change by a bit against the all-k_radon_fwd_quad run (TRK_RADON_NO_QUADF=1) — on full 1-degree sets (every
+    workgroup lean but ragged ones), incomplete quads, scattered angles (windows that do not fit: listed), an image whose bands are
+    ragged, a detector wider than the image and a dynamic operator (frames of few angles)."""
+    from trips_py_amd.operators import Radon2DParallel
+    N = 1028 if case == "ragged1028" else 1024
+    ang = {"deg180": np.linspace(0, np.pi, 180, endpoint=False),
+           "quads": np.deg2rad([10.0, 80.0, 100.0, 170.0, 11.0, 79.0, 101.0, 169.0, 12.0, 78.0, 13.0]),
+           "signs": np.deg2rad([20.0, 160.0, -20.0, 200.0, 70.0, 110.0, -70.0, 250.0, 290.0, 340.0, -160.0, 21.0]),
+           "scattered": np.array([0.1, 2.0, 0.8, 2.9, 1.3, 0.05]),
+           "ragged1028": np.linspace(0, np.pi, 60, endpoint=False),
+           "wide_detector": np.linspace(0, np.pi, 36, endpoint=False),
+           "dynamic": np.deg2rad(np.arange(2)[:, None] * 7.0 + 12.0 * np.arange(15)[None, :])}[case]
+    nd = 1500 if case == "wide_detector" else N
+    if case == "dynamic":                            # two frames of 15 angles each: ONE handle, one launch (BlockDiagOp)
+        from trips_py_amd.operators import BlockDiagOp
+        R = BlockDiagOp([Radon2DParallel(N, a, n_det=nd) for a in ang])
+    else:
+        R = Radon2DParallel(N, ang, n_det=nd)
+    eng = R.engine
+    g = torch.Generator(device=eng.device).manual_seed(5)
+    x = torch.rand(R.shape[1], device=eng.device, generator=g)
+    y_lean = R.apply(x).clone()
+    monkeypatch.setenv("TRK_RADON_NO_QUADF", "1")
+    y_old = R.apply(x).clone()
+    monkeypatch.delenv("TRK_RADON_NO_QUADF")
+    y_again = R.apply(x)
+    assert torch.equal(y_lean, y_old), float((y_lean - y_old).abs().max())
+    assert torch.equal(y_lean, y_again)
+    assert float(y_lean.abs().max()) > 0.0
+
+
 @pytest.mark.parametrize("N,na,nd", [(200, 90, 200), (256, 180, 256), (288, 60, 410), (512, 180, 512), (800, 40, 800)])
 def test_radon_adjoint_with_the_angles_of_a_tile_split_over_workgroups(N, na, nd):
     """Small images, many angles: the adjoint runs 32 x 32 tiles whose angles are split over 4 or 8 workgroups; the partial tiles
@@ -345,8 +380,13 @@ def test_csr_group_kernel_every_group_size(shape, density):
     f = lambda a: a.astype(np.float32).astype(np.float64)
     x, y = rng.standard_normal(shape[1]), rng.standard_normal(shape[0])
     assert relerr(Op @ x, M @ f(x)) < 5e-7 and relerr(Op.T @ y, M.T @ f(y)) < 5e-7
-    X = rng.standard_normal((shape[1], 3))
-    assert np.array_equal((Op @ X)[:, 2], Op @ X[:, 2])
+    # the k-column form (round 6: `A @ V` in passes of 8 / 4 / 2 / 1 columns, each pass reading the matrix once): every column
+    # carries the single-vector kernel's chains and summation order, so it equals y = A x of that column to the bit — both directions
+    X, Y = rng.standard_normal((shape[1], 15)), rng.standard_normal((shape[0], 15))
+    AX, ATY = Op @ X, Op.T @ Y
+    for j in range(15):
+        assert np.array_equal(AX[:, j], Op @ X[:, j]), j
+        assert np.array_equal(ATY[:, j], Op.T @ Y[:, j]), j
 
 
 def test_sparse_dynamic_path_vs_the_reference_loader_and_solvers():

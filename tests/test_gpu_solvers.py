@@ -10,20 +10,21 @@ from test_oracle_golden import lam_close
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
-# Automatic-lambda bars (gcv / dp / l_curve): (relError history, x).  Rule: bar = max(2 x the deviation MEASURED on the MI355X against
-# the reference's golden run, 1e-5 = north_star's bar for a fixed lambda) — measured values beside each (profiles/r05/bars.txt;
-# VERDICT round 4 item 3a; round 4 had 5e-2 everywhere).  The selectors' minima are flat — the reference moves itself by 3-4e-3
-# between fp32 and fp64 inputs — but on these problems the engine's fp32 bases move lambda by < 6e-6.
-AUTO_BAR = {"gks-gcv": (4e-5, 2e-5),            # measured 1.7e-5, 8.0e-6
-            "gks-dp": (1e-5, 1e-5),             # 2.8e-6, 3.3e-6
+# Automatic-lambda bars (gcv / dp / l_curve): (relError history, x).  Rule (round 6): bar = max(8 x the deviation MEASURED on
+# one MI355X against the reference's golden run, 1e-5 = north_star's bar for a fixed lambda) — measured values beside each
+# (profiles/r05/bars.txt; the record is still logged with TRK_BARS_LOG).  Round 5 had 2 x measured: the order of the partial sums
+# depends on the CU count (grid sizes of the sparse, band and Gram kernels) and the selectors' minima are flat — the reference moves
+# itself by 3-4e-3 between fp32 and fp64 inputs — so a tight multiple would flake on another part or ROCm.
+AUTO_BAR = {"gks-gcv": (1.4e-4, 6.4e-5),        # measured 1.7e-5, 8.0e-6
+            "gks-dp": (2.3e-5, 2.7e-5),         # 2.8e-6, 3.3e-6
             "gks-lcurve": (1e-5, 1e-5),         # 3.1e-7, 1.1e-7
-            "mmgks-gcv": (1e-5, 1e-5),          # 1.5e-6, 4.2e-6
-            "mmgks-lcurve": (1e-5, 1e-5),       # 7.8e-7, 2.4e-6
+            "mmgks-gcv": (1.2e-5, 3.4e-5),      # 1.5e-6, 4.2e-6
+            "mmgks-lcurve": (1e-5, 2e-5),       # 7.8e-7, 2.4e-6
             "mmgks_gs-gcv": (1e-5, 1e-5),       # 1.1e-7, 2.5e-7
-            "mmgks_isotv-gcv": (1e-5, 1e-5),    # 4.3e-6, 2.8e-6
+            "mmgks_isotv-gcv": (3.5e-5, 2.3e-5),  # 4.3e-6, 2.8e-6
             "gks_framelet-gcv": (1e-5, 1e-5),   # 3.6e-7, 2.6e-7
             "mmgks_framelet-gcv": (1e-5, 1e-5)}  # 1.1e-7, 5.0e-7
-HYBRID_AUTO_BAR = {("Hybrid_LSQR", "gcv"): 1e-5, ("Hybrid_LSQR", "dp"): 1.2e-5, ("Hybrid_GMRES", "gcv"): 1e-5, ("Hybrid_GMRES", "dp"): 1e-5,
+HYBRID_AUTO_BAR = {("Hybrid_LSQR", "gcv"): 1e-5, ("Hybrid_LSQR", "dp"): 4.5e-5, ("Hybrid_GMRES", "gcv"): 1e-5, ("Hybrid_GMRES", "dp"): 1e-5,
                    ("Hybrid_LSQR", "lcurve"): 1e-5, ("Hybrid_GMRES", "lcurve"): 1e-5}   # measured 2.8e-7, 5.6e-6, 3.9e-7, 2.0e-7, 7.4e-8, 6.3e-8
 
 

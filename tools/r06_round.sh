@@ -1,0 +1,51 @@
+#!/bin/bash
+# Round 6 GPU visit: ONE script, steps by name.  usage: tools/r06_round.sh <out-subdir> [steps...]
+# steps: test (whole -m gpu suite, bars logged) | tradon (projector tests) | radon (4096^2 / 2048^2 / 1024^2 / 512^2 projector rates) |
+#        pmc_radon (counters of the 4096^2 pair) | smoke | drv | bench | prof | c3 (C3 instrument) | py:<script> [runs tools/<script>] |
+#        mb:<name> (builds + runs tools/microbench/<name>.hip)
+R=$GRAFT_REPO_ROOT
+O=$R/gpurun_out/$1; shift
+STEPS=${@:-test}
+mkdir -p $O
+export TMPDIR=/tmp
+cd $R
+python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1; echo "build rc=$?"
+for s in $STEPS; do case $s in
+test)
+  rm -f $O/bars.txt
+  TRK_BARS_LOG=$O/bars.txt timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest_gpu.log ;;
+tradon)
+  timeout 1500 python -m pytest tests/test_gpu_radon_accuracy.py tests/test_gpu_operators.py tests/test_gpu_ref64.py -m gpu -x -q > $O/pytest_radon.log 2>&1; echo "pytest radon rc=$?"; tail -6 $O/pytest_radon.log ;;
+radon)
+  timeout 600 python3 tools/radon_micro.py 4096 2048 1024 512 > $O/radon_micro.txt 2>&1; echo "radon rc=$?"; cat $O/radon_micro.txt ;;
+pmc_radon)
+  timeout 1500 bash tools/gpu_pmc_cmd.sh k_radon tools/radon_one.py 4096 > $O/radon_4096_pmc.txt 2>&1; echo "pmc rc=$?"; grep -A40 "fwd_quad" $O/radon_4096_pmc.txt | head -60 ;;
+smoke)
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke rc=$?"; tail -2 $O/smoke.log ;;
+drv)
+  for i in 1 2 3; do
+    timeout 300 python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/drv_$i.json 2> $O/drv_$i.err
+    python3 -c "
+import json
+r = json.load(open('$O/drv_$i.json'))
+print('drv $i:', r['value'], {k: r['roofline'][k] for k in ('frac', 'avg_kernel_us', 'median_kernel_us', 'min_kernel_us', 'max_kernel_us')})"
+  done ;;
+bench)
+  timeout 1200 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err; echo "bench rc=$?"; cat $O/bench_driver_flags.json ;;
+prof)
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_drv -- python3 $R/bench.py --gpus 1 --steps 20 --warmup 5 --no-extras --no-cpu-baseline > $O/prof_drv.json 2> $O/prof_drv.err); echo "prof drv rc=$?"
+  f=$(ls -t $O/prof_drv/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/bench_driver_flags_kernel_stats.csv
+  head -c 1200 $O/prof_drv.json; echo
+  head -8 $O/bench_driver_flags_kernel_stats.csv ;;
+c3)
+  timeout 1200 python3 tools/r05_c3_instrument.py 100 > $O/c3_instrument.txt 2> $O/c3_instrument.err; echo "instr rc=$?"; head -40 $O/c3_instrument.txt; tail -3 $O/c3_instrument.err ;;
+py:*)
+  n=${s#py:}; a=${n//,/ }; f=${a%% *}
+  timeout 1500 python3 tools/$a > $O/${f%.py}.txt 2>&1; echo "$f rc=$?"; tail -40 $O/${f%.py}.txt ;;
+mb:*)
+  n=${s#mb:}
+  hipcc -O3 --offload-arch=gfx950 -std=c++17 -o /tmp/$n tools/microbench/$n.hip > $O/$n.build.log 2>&1 && timeout 900 /tmp/$n > $O/$n.txt 2>&1; echo "$n rc=$?"; tail -60 $O/$n.txt ;;
+esac; done
+find $O -name "*kernel_trace.csv" -delete 2>/dev/null
+find $O -name "*.db" -delete 2>/dev/null
+du -sh $O | tail -1

@@ -63,6 +63,7 @@ struct AdjAngle {           // the adjoint's per-angle constants, sorted by marc
 };
 
 struct QuadParam;
+struct QuadPlan;
 
 struct RadonImpl {
   int N, nd, na;   // na = angles PER FRAME
@@ -94,6 +95,12 @@ struct RadonImpl {
   unsigned* A32q;   // [nt*nq][nd + 4]  base tables
   unsigned* B32q;   // [nt*nq][npad]
   int nq;
+  // round 6: the quad kernel's per-workgroup bookkeeping made once per operator (k_radon_quad_plan) and the compact list of the
+  // workgroups the lean kernel (k_radon_fwd_quadf) does not serve
+  struct QuadPlan* qplan;
+  int* qslow;       // [0] = count, then the workgroup ids (band * grid_x + block) k_radon_fwd_quad still runs
+  int qslow_n;      // host copy of the count
+  int qplan_gx, qplan_nb;   // the grid the plan was made for
   // what the side buffers currently hold, when a fused apply left them behind for the next apply of the other direction
   // (trk_op_apply_axpby hints): rec = the records of the sinogram at rec_src, xT = the transpose of the image at xT_src
   const float* rec_src;
@@ -774,16 +781,19 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restri
                                                         const float* __restrict__ fidx, const unsigned* __restrict__ A32q,
                                                         const unsigned* __restrict__ B32q, int npad,
                                                         const AngleParam* __restrict__ ang, const unsigned* __restrict__ A32,
-                                                        const unsigned* __restrict__ B32) {
+                                                        const unsigned* __restrict__ B32, const int* __restrict__ wg_list, int grid_x) {
   __shared__ __attribute__((aligned(16))) float tile[NBUF][2 * QD_REGION];
   __shared__ float ext[4][QD_MAXCH][2];
   __shared__ int chinfo[QD_MAXCH][2];
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  // wg_list (round 6): this launch runs only the workgroups of the full grid that k_radon_fwd_quadf leaves to it
+  const int wg_id = wg_list ? wg_list[1 + blockIdx.x] : 0;
+  const int blk_y = wg_list ? wg_id / grid_x : (int)blockIdx.y, blk_x = wg_list ? wg_id - blk_y * grid_x : (int)blockIdx.x;
   // workgroups b and b + 8 run on the same XCD (round-robin placement: speed only, never correctness): give every XCD one
   // contiguous eighth of the windows, for all quad groups — its L2 then holds an eighth of the band (and the mirrored eighth)
   // instead of every fourth window of all of it
   const int nw8 = (nwin + 7) >> 3;
-  const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+  const int xcd = blk_x & 7, bidx = blk_x >> 3;
   const int grp = bidx / nw8, jj = xcd * nw8 + (bidx - grp * nw8);
   if (jj >= nwin) return;
   const int frame = grp / ngrp_per_frame;
@@ -792,7 +802,7 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restri
   const QuadParam* __restrict__ qg = quads + (int64_t)frame * nq_per_frame + q0;
   int smask = 0;                                                    // slots any of the workgroup's quads uses: what gets staged
   for (int w = 0; w < nval; ++w) smask |= qg[w].mask;
-  const int t0 = blockIdx.y * bh, t1 = (t0 + bh < N) ? t0 + bh : N;
+  const int t0 = blk_y * bh, t1 = (t0 + bh < N) ? t0 + bh : N;
   const int OFFS = bh + 4;
   const bool valid = wv < nval;
   const QuadParam p = qg[valid ? wv : 0];
@@ -906,6 +916,12 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restri
     const int tb = t0 + ch * QD_R, te = (tb + QD_R < t1) ? tb + QD_R : t1;
     const float* __restrict__ T = tile[ch % NBUF];
     const int cs = cs_of(ch), st = st_of(ch);
+    // The chunk's eight B32 entries in ONE scalar load, requested BEFORE the barrier (round 6).  Fetched one by one inside the march
+    // (as rounds 4-5 had it: `Ac + Brow[u]` next to the reads) every entry came with `s_waitcnt lgkmcnt(0)` — scalar loads return
+    // out of order, so a wait for one is a wait for everything counted in lgkmcnt, the LDS reads included: every step drained the
+    // three steps of reads "in flight", and the waves issued 38 % of their resident time (profiles/r05/radon_4096_pmc.txt).
+    typedef unsigned u8v __attribute__((ext_vector_type(8)));
+    const u8v Bv = *reinterpret_cast<const u8v*>(__builtin_assume_aligned(Ball + tb, 32));
     // this wave's loads of chunk ch have landed (those of the chunks staged after it may still fly), then the workgroup meets:
     // chunk ch is complete in LDS and everybody has left the buffer chunk ch + NBUF - 1 goes into
     int later = 0;
@@ -916,7 +932,6 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restri
     if (st_of(ch + NBUF - 1) == 1) stage(ch + NBUF - 1, cs_of(ch + NBUF - 1));
     const bool full = (te - tb == QD_R);
     if (st == 1 && any) {
-      const unsigned* __restrict__ Brow = static_cast<const unsigned*>(__builtin_assume_aligned(Ball + tb, 32));
       const unsigned Ac = A_m - ((unsigned)cs << QF);
       const unsigned Toff = lds_off(T);
       unsigned Cm = 2u * Toff + 4u * (unsigned)(QD_REGION + (QD_R / 2 - 1) * QD_PAIR + QD_W + (QD_W - 2));
@@ -928,7 +943,7 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restri
         // weights and addresses of a step are made three steps ahead of their use, just before its reads are issued: the vector
         // work of step u + 3 runs while the reads of steps u .. u + 2 are in flight, and few of these registers are live at once
         auto prep = [&](int u) {
-          const unsigned Q = Ac + Brow[u];
+          const unsigned Q = Ac + Bv[u];
           float f1 = (float)(Q << 8);                             // the 24 fraction bits, in units of 2^-32 (exact)
           float f0 = two32v - f1;
           if (!FULL) {
@@ -1019,6 +1034,251 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quad(const float* __restri
     }
   }
   if (owned) {
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      if (!((p.mask >> m) & 1)) continue;
+      const int dm = ((p.flip >> m) & 1) ? nd - 1 - d : d;
+      out[(int64_t)blk_y * band_stride + ((int64_t)frame * na_per_frame + p.am[m]) * nd + dm] = (float)total[m];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------- forward, quads: plan + lean kernel (round 6)
+// Counters of k_radon_fwd_quad at 4096^2 x 180 (profiles/r05/radon_4096_pmc.txt, r06): 241 M vector instructions of which the march
+// itself is 134 M; 150 M scalar; the vector unit 68 % busy and the waves stalled at issue — the kernel is bound by its instruction
+// count, and 44 % of it is bookkeeping that depends on the GEOMETRY only: which detector a lane owns, the column range of every chunk
+// (two barriers and an LDS round per workgroup), whether a window fits, the clamps of partial chunks, four march variants, and
+// scalar registers spilled to vector lanes by all of it.  k_radon_quad_plan works that out ONCE per operator, per workgroup of the grid
+// (the same arithmetic, statement for statement, as k_radon_fwd_quad's prologue: the two kernels own the same rays), and
+// k_radon_fwd_quadf is the march alone: whole chunks of eight rows, all four members, one window start per chunk from the plan.
+// Workgroups it cannot serve (a window that does not fit, a ragged band, groups of mostly single angles) are LISTED by the plan and
+// run by k_radon_fwd_quad as before; both write the same band partials, the same bits.
+constexpr int QD_NONE = INT32_MIN;
+struct QuadPlan {
+  int cs[QD_MAXCH];              // window start of every chunk; QD_NONE: no wave owns a ray there
+  int dfirst[4][2];              // [wave][half]: the detector of lane li = 0 of that half (lane li: + li)
+  unsigned omask_lo[4], omask_hi[4];   // the lanes that own a ray
+  int fast;                      // 1: k_radon_fwd_quadf; 0: k_radon_fwd_quad (listed); 2: nothing to do
+  int pad[64 - QD_MAXCH - 8 - 8 - 1];
+};
+static_assert(sizeof(QuadPlan) == 256, "one plan entry = 256 bytes");
+
+__global__ __launch_bounds__(256) void k_radon_quad_plan(int N, int nd, const QuadParam* __restrict__ quads, int nq_per_frame,
+                                                         int ngrp_per_frame, int nwin, int bh, const float* __restrict__ fidx,
+                                                         int have_xT, QuadPlan* __restrict__ plan, int* __restrict__ slow) {
+  __shared__ float ext[4][QD_MAXCH][2];
+  __shared__ int nfit;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  QuadPlan& P = plan[(int64_t)blockIdx.y * gridDim.x + blockIdx.x];
+  const int nw8 = (nwin + 7) >> 3;
+  const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+  const int grp = bidx / nw8, jj = xcd * nw8 + (bidx - grp * nw8);
+  if (jj >= nwin) {
+    if (threadIdx.x == 0) P.fast = 2;
+    return;
+  }
+  const int frame = grp / ngrp_per_frame;
+  const int q0 = (grp - frame * ngrp_per_frame) * 4;
+  const int nval = (nq_per_frame - q0 < 4) ? nq_per_frame - q0 : 4;
+  const QuadParam* __restrict__ qg = quads + (int64_t)frame * nq_per_frame + q0;
+  int members = 0;
+  for (int w = 0; w < nval; ++w) members += __builtin_popcount(qg[w].mask & 15);
+  const int t0 = blockIdx.y * bh, t1 = (t0 + bh < N) ? t0 + bh : N;
+  const int OFFS = bh + 4;
+  const bool valid = wv < nval;
+  const QuadParam p = qg[valid ? wv : 0];
+  const float sdh = 0.5f * (float)(nd - 1);
+  // ---- k_radon_fwd_quad's ownership, statement for statement
+  const int hw = lane >> 5, li = lane & 31;
+  const float qa = (float)(jj * QD_WO - OFFS + QD_HALF * hw), qb = qa + (float)QD_HALF;
+  const float t0f = fidx[t0];
+  const float offs = fmaf(t0f, p.dq, p.k0);
+  const float dA = (qa - offs) * p.rinv + sdh;
+  const int d0 = (int)ceilf(dA - 0.05f);
+  const float qt0 = fmaf(t0f, p.dq, fmaf((float)d0 - sdh, p.inv, p.k0));
+  const int dl0 = d0 + (qt0 < qa ? 1 : 0);
+  const int d = dl0 + li;
+  const float base = fmaf((float)d - sdh, p.inv, p.k0);
+  const float qtop = fmaf(t0f, p.dq, base);
+  const bool owned = valid && p.mask != 0 && (unsigned)d < (unsigned)nd && qtop >= qa && qtop < qb;
+  const unsigned long long omask = __builtin_amdgcn_ballot_w64(owned);
+  const bool any = omask != 0ull;
+  const int l_first = any ? __builtin_ctzll(omask) : 0, l_last = any ? 63 - __builtin_clzll(omask) : 0;
+  const float blo = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, base), l_first));
+  const float bhi = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, base), l_last));
+  const int nch = (t1 - t0 + QD_R - 1) / QD_R;
+  if (lane < nch) {
+    const int tb = t0 + lane * QD_R, te = (tb + QD_R < t1) ? tb + QD_R : t1;
+    ext[wv][lane][0] = any ? blo + (float)tb * p.dq : 3.0e38f;
+    ext[wv][lane][1] = any ? bhi + (float)(te - 1) * p.dq : -3.0e38f;
+  }
+  if (threadIdx.x == 0) nfit = 0;
+  __syncthreads();
+  if (li == 0) P.dfirst[wv][hw] = dl0;
+  if (lane == 0) {
+    P.omask_lo[wv] = (unsigned)omask;
+    P.omask_hi[wv] = (unsigned)(omask >> 32);
+  }
+  if (wv == 0 && lane < QD_MAXCH) {
+    int csv = QD_NONE;
+    if (lane < nch) {
+      const float ulo = fminf(fminf(ext[0][lane][0], ext[1][lane][0]), fminf(ext[2][lane][0], ext[3][lane][0]));
+      const float uhi = fmaxf(fmaxf(ext[0][lane][1], ext[1][lane][1]), fmaxf(ext[2][lane][1], ext[3][lane][1]));
+      const bool nobody = ulo > uhi;
+      const int cs = nobody ? 0 : (((int)floorf(ulo) - 1) & ~3);
+      const bool fits = !nobody && ((int)floorf(nobody ? 0.f : uhi) + 2 - cs) < QD_W;
+      if (!nobody) {
+        csv = cs;
+        if (!fits) atomicAdd(&nfit, 1);
+      }
+    }
+    P.cs[lane] = csv;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const bool whole = (t1 - t0) % QD_R == 0;
+    const bool fast = have_xT && whole && nfit == 0 && 4 * members >= 3 * 4 * nval;
+    P.fast = fast ? 1 : 0;
+    if (!fast) {
+      const int k = atomicAdd(&slow[0], 1);
+      slow[1 + k] = blockIdx.y * gridDim.x + blockIdx.x;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256, 4) void k_radon_fwd_quadf(const float* __restrict__ img, const float* __restrict__ imgT,
+                                                            float* __restrict__ out, int N, int nd,
+                                                            const QuadParam* __restrict__ quads, int nq_per_frame, int ngrp_per_frame,
+                                                            int na_per_frame, int nwin, int64_t band_stride, int bh,
+                                                            const unsigned* __restrict__ A32q, const unsigned* __restrict__ B32q, int npad,
+                                                            const QuadPlan* __restrict__ plan) {
+  __shared__ __attribute__((aligned(16))) float tile[2][2 * QD_REGION];
+  const QuadPlan& P = plan[(int64_t)blockIdx.y * gridDim.x + blockIdx.x];
+  if (P.fast != 1) return;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int nw8 = (nwin + 7) >> 3;
+  const int xcd = blockIdx.x & 7, bidx = blockIdx.x >> 3;
+  const int grp = bidx / nw8;
+  const int frame = grp / ngrp_per_frame;
+  const int q0 = (grp - frame * ngrp_per_frame) * 4;
+  const int nval = (nq_per_frame - q0 < 4) ? nq_per_frame - q0 : 4;
+  const bool valid = wv < nval;
+  const int qrow = frame * nq_per_frame + q0 + (valid ? wv : 0);
+  const int t0 = blockIdx.y * bh;
+  const int nch = ((t0 + bh < N ? bh : N - t0)) / QD_R;              // whole chunks only (the plan's condition)
+  const int ndp = nd + 2 * A32_PAD;
+  const unsigned img_bytes = (unsigned)N * (unsigned)N * 4u;
+  const auto rsrc0 = __builtin_amdgcn_make_buffer_rsrc((void*)(img + (int64_t)frame * N * N), 0, img_bytes, 0x00020000);
+  const auto rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)(imgT + (int64_t)frame * N * N), 0, img_bytes, 0x00020000);
+  const int hw = lane >> 5, li = lane & 31;
+  const int d = P.dfirst[wv][hw] + li;
+  const unsigned om_lo = P.omask_lo[wv], om_hi = P.omask_hi[wv];
+  const bool any = (om_lo | om_hi) != 0u;
+  const bool owned = (((hw ? om_hi : om_lo) >> li) & 1u) != 0u;
+  const int dcl = d < 0 ? 0 : (d >= nd ? nd - 1 : d);
+  const unsigned A = A32q[(int64_t)qrow * ndp + dcl + A32_PAD];
+  // lanes without a ray follow the first owned ray of their half (of the other half if theirs owns none): a broadcast, inside the tile
+  const int lf0 = om_lo ? __builtin_ctz(om_lo) : (om_hi ? 32 + __builtin_ctz(om_hi) : 0);
+  const int lf1 = om_hi ? 32 + __builtin_ctz(om_hi) : lf0;
+  const unsigned A_f0 = (unsigned)__builtin_amdgcn_readlane((int)A, lf0), A_f1 = (unsigned)__builtin_amdgcn_readlane((int)A, lf1);
+  const unsigned A_m = owned ? A : (hw ? A_f1 : A_f0);
+  const unsigned* __restrict__ Ball = B32q + (int64_t)qrow * npad + t0;
+  float two32v = 4294967296.0f;                    // in a VECTOR register: an SGPR operand would make the subtraction a 4-cycle issue
+  asm volatile("" : "+v"(two32v));
+  const int cs_all = lane < QD_MAXCH ? P.cs[lane] : QD_NONE;
+  // staging: wave wv fills row pair wv of region F and of region M, one load per source (lanes 0-59: row in pair = lane / 30, four
+  // columns from 4 (lane % 30)); columns outside the image arrive as zeros (offset out of range).  Per chunk: the window start times
+  // four plus a per-lane constant, and a range test — nothing else
+  const int sr = lane >= 30 ? 1 : 0, sk = (lane - 30 * sr) << 2;
+  const int cF = sk, cM = N - QD_W + sk;                                                  // column = cs + cF / cM - cs
+  const int oF = ((2 * wv + sr) * N + sk) * 4, oM = ((2 * (QD_R / 2 - 1 - wv) + 1 - sr) * N + (N - QD_W + sk)) * 4;
+  const unsigned row8 = (unsigned)QD_R * (unsigned)N * 4u;
+  unsigned rowbase = (unsigned)t0 * (unsigned)N * 4u + row8;                              // of the chunk being staged (chunk 1 first)
+  auto stage = [&](int buf, int cs, unsigned rb) {
+    float* __restrict__ T = tile[buf];
+    const int cs4 = cs << 2;
+    const int voffF = ((unsigned)(cs + cF) < (unsigned)N) ? cs4 + oF : (int)img_bytes;
+    const int voffM = ((unsigned)(cM - cs) < (unsigned)N) ? oM - cs4 : (int)img_bytes;
+    auto* dF = (__attribute__((address_space(3))) void*)(T + wv * QD_PAIR);
+    auto* dFt = (__attribute__((address_space(3))) void*)(T + wv * QD_PAIR + QD_SRC);
+    auto* dM = (__attribute__((address_space(3))) void*)(T + QD_REGION + wv * QD_PAIR);
+    auto* dMt = (__attribute__((address_space(3))) void*)(T + QD_REGION + wv * QD_PAIR + QD_SRC);
+    if (lane < 60) {
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, dF, 16, voffF, rb, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, dFt, 16, voffF, rb, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc0, dM, 16, voffM, rb, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, dMt, 16, voffM, rb, 0, 0);
+    }
+  };
+  f2v acc[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+  double total[4] = {0.0, 0.0, 0.0, 0.0};
+  int cs = __builtin_amdgcn_readlane(cs_all, 0);
+  if (cs != QD_NONE) stage(0, cs, rowbase - row8);
+  typedef unsigned u8v __attribute__((ext_vector_type(8)));
+  for (int ch = 0; ch < nch; ++ch) {
+    const int cs_nx = ch + 1 < nch ? __builtin_amdgcn_readlane(cs_all, ch + 1) : QD_NONE;
+    // the chunk's eight B32 entries: one scalar load, requested before the barrier
+    const u8v Bv = *reinterpret_cast<const u8v*>(__builtin_assume_aligned(Ball + ch * QD_R, 32));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's share of chunk ch has landed ...
+    asm volatile("s_barrier" ::: "memory");                          // ... everybody's; and everybody has left the other buffer
+    if (cs_nx != QD_NONE) stage((ch + 1) & 1, cs_nx, rowbase);
+    rowbase += row8;
+    if (cs != QD_NONE && any) {
+      const unsigned Ac = A_m - ((unsigned)cs << QF);
+      const unsigned Toff = lds_off(tile[ch & 1]);
+      unsigned Cm = 2u * Toff + 4u * (unsigned)(QD_REGION + (QD_R / 2 - 1) * QD_PAIR + QD_W + (QD_W - 2));
+      asm volatile("" : "+v"(Cm));
+      f2v w[QD_R];
+      unsigned a0[QD_R], a1[QD_R];
+      auto prep = [&](int u) {
+        const unsigned Q = Ac + Bv[u];
+        const float f1 = (float)(Q << 8);                           // the 24 fraction bits, in units of 2^-32 (exact)
+        const float f0 = two32v - f1;
+        w[u] = (f2v){f0, f1};
+        int rowoff = (int)Toff + ((u >> 1) * QD_PAIR + (u & 1) * QD_W) * 4;
+        asm("" : "+s"(rowoff));
+        a0[u] = ((Q >> QF) << 2) + (unsigned)rowoff;
+        a1[u] = Cm - a0[u];
+      };
+      f2v tA[QD_R], tB[QD_R], tC[QD_R], tD[QD_R];
+      auto issue = [&](int u) {
+        asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(tA[u]) : "v"(a0[u]));
+        asm volatile("ds_read2_b32 %0, %1 offset0:240 offset1:241" : "=v"(tB[u]) : "v"(a0[u]));
+        asm volatile("ds_read2_b32 %0, %1 offset1:1" : "=v"(tC[u]) : "v"(a1[u]));
+        asm volatile("ds_read2_b32 %0, %1 offset0:240 offset1:241" : "=v"(tD[u]) : "v"(a1[u]));
+      };
+      prep(0);
+      issue(0);
+      prep(1);
+      issue(1);
+      prep(2);
+      issue(2);
+#pragma unroll
+      for (int u = 0; u < QD_R; ++u) {
+        if (u + 3 < QD_R) prep(u + 3);
+        if (u <= QD_R - 3) asm volatile("s_waitcnt lgkmcnt(8)" ::: "memory");
+        else if (u == QD_R - 2) asm volatile("s_waitcnt lgkmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        asm volatile("" : "+v"(tA[u]), "+v"(tB[u]), "+v"(tC[u]), "+v"(tD[u]));
+        if (u + 3 < QD_R) issue(u + 3);
+        acc[0] = __builtin_elementwise_fma(w[u], tA[u], acc[0]);
+        acc[2] = __builtin_elementwise_fma(w[u], tB[u], acc[2]);
+        // mirrored windows: the pair read at the mirrored address is (tap c+1, tap c): the weights swap halves
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[1]) : "v"(w[u]), "v"(tC[u]));
+        asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(acc[3]) : "v"(w[u]), "v"(tD[u]));
+      }
+    }
+    if ((ch & 1) || ch == nch - 1) {                               // fp32 partial sums over 16 rows, then fp64 (as the other forward kernels)
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        total[m] += (double)(acc[m][0] + acc[m][1]);
+        acc[m] = (f2v){0.f, 0.f};
+      }
+    }
+    cs = cs_nx;
+  }
+  if (owned) {
+    const QuadParam p = quads[qrow];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       if (!((p.mask >> m) & 1)) continue;
@@ -2062,9 +2322,38 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
           //  tiles in flight, 4096^2: 0.76 -> 1.34 ms; the knob stays for experiments)
           (void)wgs;
           const int qbuf = qbuf_env ? qbuf_env : 2;
-#define QUAD(NB) hipLaunchKernelGGL(k_radon_fwd_quad<NB>, gq, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->quad_dev, im->nq, ngq, na, nwq, bs, im->band, \
-                                    im->fidx, im->A32q, im->B32q, im->npad, im->ang_dev, im->A32, im->B32)
-          if (qbuf >= 4) QUAD(4); else if (qbuf == 3) QUAD(3); else QUAD(2);
+          // round 6: the lean kernel for the workgroups its plan allows, k_radon_fwd_quad for the listed rest (TRK_RADON_NO_QUADF=1: all
+          // of them, as rounds 4-5).  The plan depends on the geometry and the grid only: made at the first apply, kept with the handle
+          const bool no_quadf = getenv("TRK_RADON_NO_QUADF") != nullptr;      // read per call: the tests switch it
+          dim3 gslow = gq;
+          const int* wg_list = nullptr;
+          if (!no_quadf && qbuf == 2) {
+            if (!im->qplan || im->qplan_gx != (int)gq.x || im->qplan_nb != nb) {
+              if (im->qplan) (void)hipFree(im->qplan);
+              if (im->qslow) (void)hipFree(im->qslow);
+              im->qplan = nullptr;
+              im->qslow = nullptr;
+              const size_t nwg = (size_t)gq.x * nb;
+              TRK_HIP(hipMalloc((void**)&im->qplan, sizeof(QuadPlan) * nwg));
+              TRK_HIP(hipMalloc((void**)&im->qslow, sizeof(int) * (nwg + 1)));
+              TRK_HIP(hipMemsetAsync(im->qslow, 0, sizeof(int), s));
+              hipLaunchKernelGGL(k_radon_quad_plan, gq, dim3(256), 0, s, N, nd, im->quad_dev, im->nq, ngq, nwq, im->band, im->fidx,
+                                 im->xT ? 1 : 0, im->qplan, im->qslow);
+              TRK_HIP(hipMemcpyAsync(&im->qslow_n, im->qslow, sizeof(int), hipMemcpyDeviceToHost, s));
+              TRK_HIP(hipStreamSynchronize(s));
+              im->qplan_gx = (int)gq.x;
+              im->qplan_nb = nb;
+            }
+            hipLaunchKernelGGL(k_radon_fwd_quadf, gq, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->quad_dev, im->nq, ngq, na, nwq, bs, im->band,
+                               im->A32q, im->B32q, im->npad, im->qplan);
+            gslow = dim3((unsigned)im->qslow_n, 1, 1);
+            wg_list = im->qslow;
+          }
+#define QUAD(NB) hipLaunchKernelGGL(k_radon_fwd_quad<NB>, gslow, dim3(256), 0, s, xb, im->xT, im->part, N, nd, im->quad_dev, im->nq, ngq, na, nwq, bs, im->band, \
+                                    im->fidx, im->A32q, im->B32q, im->npad, im->ang_dev, im->A32, im->B32, wg_list, (int)gq.x)
+          if (gslow.x > 0) {
+            if (qbuf >= 4) QUAD(4); else if (qbuf == 3) QUAD(3); else QUAD(2);
+          }
 #undef QUAD
         } else {
           const int nwin = ceil_div(N + 2 * im->band + 16, 61);
@@ -2244,7 +2533,7 @@ int radon_apply_axpby(trk_op* op, int tr, const float* x, Coef a, Coef b, const 
 
 void radon_destroy(trk_op* op) {
   auto* im = static_cast<RadonImpl*>(op->impl);
-  void* ptrs[] = {im->ref_ang, im->ref_tmp, im->quad_dev, im->A32q, im->B32q, im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec, im->adj_pos, im->pend_buf[0], im->pend_buf[1], im->adj_part, im->adj_cnt};
+  void* ptrs[] = {im->ref_ang, im->ref_tmp, im->quad_dev, im->A32q, im->B32q, im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec, im->adj_pos, im->pend_buf[0], im->pend_buf[1], im->adj_part, im->adj_cnt, im->qplan, im->qslow};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete im;

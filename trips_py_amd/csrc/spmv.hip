@@ -40,59 +40,102 @@ struct SpImpl {
 template <bool NTL> __device__ __forceinline__ float ldm(const float* p) { return NTL ? __builtin_nontemporal_load(p) : *p; }
 template <bool NTL> __device__ __forceinline__ int ldm(const int* p) { return NTL ? __builtin_nontemporal_load(p) : *p; }
 
-template <int G, bool SUMSQ, bool NTL>
+// Accumulator type of the per-lane chains: float64 for G == 2 (rows of 2 .. 9 non-zeros: first differences, framelets — at most two
+// products per chain, so float64 costs nothing measurable there and the framelet residuals stop carrying fp32 product roundings:
+// ADVICE round 5), fp32 for the long tomography rows (four chains per lane, float64 only across the group).
+template <int G> struct ChainT { typedef float type; };
+template <> struct ChainT<2> { typedef double type; };
+__device__ __forceinline__ float chain_fma(float v, float x, float a) { return fmaf(v, x, a); }
+__device__ __forceinline__ double chain_fma(float v, float x, double a) { return fma((double)v, (double)x, a); }
+
+// KB right-hand sides per pass (KB = 1: y = A x; KB = 2 / 4 / 8: Y[:, b] = A X[:, b], columns ldx / ldy apart — `A @ V` on an (n, k)
+// block, GKS.py:37 / MMGKS.py:44): the matrix streams (8 bytes per non-zero) are read ONCE for the KB columns; each column keeps
+// the single-vector kernel's chains and summation order, so its result is bit-identical to a y = A x of that column alone.
+template <int G, int KB, bool SUMSQ, bool NTL>
 __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned* __restrict__ indptr,
                                                   const int* __restrict__ indices, const float* __restrict__ vals,
-                                                  const float* __restrict__ x, float* __restrict__ y,
-                                                  double* __restrict__ partials) {
+                                                  const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
+                                                  double* __restrict__ partials, int pstride) {
+  typedef typename ChainT<G>::type acc_t;
   __shared__ double red[NT / 64];
   const int g = threadIdx.x & (G - 1);
   const int64_t grp0 = ((int64_t)blockIdx.x * NT + threadIdx.x) / G, ngrp = (int64_t)gridDim.x * (NT / G);
-  double ss = 0.0;
+  double ss[KB];
+#pragma unroll
+  for (int b = 0; b < KB; ++b) ss[b] = 0.0;
   for (int64_t r = grp0; r < nrows; r += ngrp) {
     const unsigned p0 = indptr[r], p1 = indptr[r + 1];
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    acc_t a0[KB], a1[KB], a2[KB], a3[KB];
+#pragma unroll
+    for (int b = 0; b < KB; ++b) a0[b] = a1[b] = a2[b] = a3[b] = (acc_t)0;
     unsigned p = p0 + g;
-    // four loads of each stream in flight per lane, four independent fp32 chains (long rows: a wave streams 2 KB per trip)
+    // four loads of each stream in flight per lane, four independent chains per column (long rows: a wave streams 2 KB per trip)
     for (; p + 3 * G < p1; p += 4 * G) {
       const float v0 = ldm<NTL>(vals + p), v1 = ldm<NTL>(vals + p + G), v2 = ldm<NTL>(vals + p + 2 * G), v3 = ldm<NTL>(vals + p + 3 * G);
       const int c0 = ldm<NTL>(indices + p), c1 = ldm<NTL>(indices + p + G), c2 = ldm<NTL>(indices + p + 2 * G), c3 = ldm<NTL>(indices + p + 3 * G);
-      a0 = fmaf(v0, x[c0], a0);
-      a1 = fmaf(v1, x[c1], a1);
-      a2 = fmaf(v2, x[c2], a2);
-      a3 = fmaf(v3, x[c3], a3);
+#pragma unroll
+      for (int b = 0; b < KB; ++b) {
+        const float* __restrict__ xb = x + (int64_t)b * ldx;
+        a0[b] = chain_fma(v0, xb[c0], a0[b]);
+        a1[b] = chain_fma(v1, xb[c1], a1[b]);
+        a2[b] = chain_fma(v2, xb[c2], a2[b]);
+        a3[b] = chain_fma(v3, xb[c3], a3[b]);
+      }
     }
     // up to three more, issued together (predicated: a row's tail, or the whole of a short row)
     {
       const bool h0 = p < p1, h1 = p + G < p1, h2 = p + 2 * G < p1;
       const float v0 = h0 ? ldm<NTL>(vals + p) : 0.f, v1 = h1 ? ldm<NTL>(vals + p + G) : 0.f, v2 = h2 ? ldm<NTL>(vals + p + 2 * G) : 0.f;
       const int c0 = h0 ? ldm<NTL>(indices + p) : 0, c1 = h1 ? ldm<NTL>(indices + p + G) : 0, c2 = h2 ? ldm<NTL>(indices + p + 2 * G) : 0;
-      a0 = fmaf(v0, h0 ? x[c0] : 0.f, a0);
-      a1 = fmaf(v1, h1 ? x[c1] : 0.f, a1);
-      a2 = fmaf(v2, h2 ? x[c2] : 0.f, a2);
-    }
-    double acc = ((double)a0 + (double)a1) + ((double)a2 + (double)a3);
 #pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
-    if (g == 0) {
-      const float o = (float)acc;
-      y[r] = o;
-      if (SUMSQ) ss += (double)o * o;
+      for (int b = 0; b < KB; ++b) {
+        const float* __restrict__ xb = x + (int64_t)b * ldx;
+        a0[b] = chain_fma(v0, h0 ? xb[c0] : 0.f, a0[b]);
+        a1[b] = chain_fma(v1, h1 ? xb[c1] : 0.f, a1[b]);
+        a2[b] = chain_fma(v2, h2 ? xb[c2] : 0.f, a2[b]);
+      }
+    }
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+      double acc = ((double)a0[b] + (double)a1[b]) + ((double)a2[b] + (double)a3[b]);
+#pragma unroll
+      for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+      if (g == 0) {
+        const float o = (float)acc;
+        y[(int64_t)b * ldy + r] = o;
+        if (SUMSQ) ss[b] += (double)o * o;
+      }
     }
   }
   if (SUMSQ) {
-    ss = block_sum<NT>(ss, red);
-    if (threadIdx.x == 0) partials[blockIdx.x] = ss;
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+      const double t = block_sum<NT>(ss[b], red);
+      if (threadIdx.x == 0) partials[(size_t)b * pstride + blockIdx.x] = t;
+      if (KB > 1) __syncthreads();
+    }
   }
 }
 
-template <int G>
-void launch_group(const Csr& M, int grid, const float* xb, float* yb, double* pb, hipStream_t s) {
+template <int G, int KB>
+void launch_group(const Csr& M, int grid, const float* xb, int64_t ldx, float* yb, int64_t ldy, double* pb, hipStream_t s) {
   static const bool ntl = getenv("TRK_CSR_NT") && atoi(getenv("TRK_CSR_NT")) != 0;
-#define CG(SS, NN) hipLaunchKernelGGL((k_csr_group<G, SS, NN>), dim3(grid), dim3(NT), 0, s, M.nrows, M.indptr, M.indices, M.vals, xb, yb, pb)
+#define CG(SS, NN) hipLaunchKernelGGL((k_csr_group<G, KB, SS, NN>), dim3(grid), dim3(NT), 0, s, M.nrows, M.indptr, M.indices, M.vals, xb, ldx, yb, ldy, pb, grid)
   if (pb) { if (ntl) CG(true, true); else CG(true, false); }
   else    { if (ntl) CG(false, true); else CG(false, false); }
 #undef CG
+}
+
+template <int KB>
+void launch_cols(const Csr& M, int grid, const float* xb, int64_t ldx, float* yb, int64_t ldy, double* pb, hipStream_t s) {
+  switch (M.group) {
+    case 2: launch_group<2, KB>(M, grid, xb, ldx, yb, ldy, pb, s); break;
+    case 4: launch_group<4, KB>(M, grid, xb, ldx, yb, ldy, pb, s); break;
+    case 8: launch_group<8, KB>(M, grid, xb, ldx, yb, ldy, pb, s); break;
+    case 16: launch_group<16, KB>(M, grid, xb, ldx, yb, ldy, pb, s); break;
+    case 32: launch_group<32, KB>(M, grid, xb, ldx, yb, ldy, pb, s); break;
+    default: launch_group<64, KB>(M, grid, xb, ldx, yb, ldy, pb, s); break;
+  }
 }
 
 int sp_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t ldy, int batch, double* sumsq,
@@ -110,19 +153,19 @@ int sp_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t 
   double* part = nullptr;
   if (sumsq)
     if (int rc = scratch_doubles(s, (size_t)grid * batch, &part)) return rc;
+  // columns per pass (round 6): a batch — `A @ V`, GKS.py:37 / MMGKS.py:44 — goes through in passes of 8 / 4 / 2 columns, each pass
+  // reading the matrix once; TRK_CSR_COLS=1 restores one launch per column (A/B runs)
+  static const int max_cols = getenv("TRK_CSR_COLS") ? atoi(getenv("TRK_CSR_COLS")) : 8;
   TimerScope tm(op->timer, op->timer_which, tr, s);
-  for (int b = 0; b < batch; ++b) {
+  for (int b = 0; b < batch;) {
     const float* xb = x + (int64_t)b * ldx;
     float* yb = y + (int64_t)b * ldy;
     double* pb = part ? part + (size_t)b * grid : nullptr;
-    switch (M.group) {
-      case 2: launch_group<2>(M, grid, xb, yb, pb, s); break;
-      case 4: launch_group<4>(M, grid, xb, yb, pb, s); break;
-      case 8: launch_group<8>(M, grid, xb, yb, pb, s); break;
-      case 16: launch_group<16>(M, grid, xb, yb, pb, s); break;
-      case 32: launch_group<32>(M, grid, xb, yb, pb, s); break;
-      default: launch_group<64>(M, grid, xb, yb, pb, s); break;
-    }
+    const int left = batch - b;
+    if (left >= 8 && max_cols >= 8) { launch_cols<8>(M, grid, xb, ldx, yb, ldy, pb, s); b += 8; }
+    else if (left >= 4 && max_cols >= 4) { launch_cols<4>(M, grid, xb, ldx, yb, ldy, pb, s); b += 4; }
+    else if (left >= 2 && max_cols >= 2) { launch_cols<2>(M, grid, xb, ldx, yb, ldy, pb, s); b += 2; }
+    else { launch_cols<1>(M, grid, xb, ldx, yb, ldy, pb, s); b += 1; }
   }
   tm.stop();
   TRK_LAUNCH_CHECK();

@@ -2045,6 +2045,7 @@ __global__ __launch_bounds__(LW_NT, T == 1 ? 4 : 2) void k_wgram_tv_lds(const fl
     auto step = [&](const LwRow<T>& P, LwRow<T>& Q, int i) {     // P: image row i (held), Q: the row below (fetched here)
       wait_vm_le(i + 2 <= i1 ? npw : 0);                         // row i + 1 has landed (this wave's pieces); row i + 2 may be in flight
       __builtin_amdgcn_s_barrier();                              // ... everybody's; and everybody has left step i - 1
+      asm volatile("" ::: "memory");                            // (the raw barrier is IntrNoMem: nothing else keeps the plain LDS reads of the Z form below it)
       if (i + 3 <= i1) issue(i + 3);                             // into the stage of row i - 1
       const float* X = smem + (i & (LW_S - 1)) * SF + NV * LW_RS + 32 * wave + 8 * sl;
       f4v rwh0, rwh1, rwv0, rwv1, rz0 = {0.f, 0.f, 0.f, 0.f}, rz1 = rz0;
@@ -2086,11 +2087,13 @@ __global__ __launch_bounds__(LW_NT, T == 1 ? 4 : 2) void k_wgram_tv_lds(const fl
 
     LwRow<T> A, B;
     __builtin_amdgcn_s_barrier();                                // the previous unit's last rows have been read
+    asm volatile("" ::: "memory");
     issue(i0);
     issue(i0 + 1);
     issue(i0 + 2);
     wait_vm_le(2 * npw);
     __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
     {
       f4v ax[T][2];
       float an[T];

@@ -35,9 +35,12 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     """Returns (x, info); info keys xHistory, regParam, regParam_history, relError (if x_true), Residual, its.
     Engine-only kwargs: history (True, False, a stride, 'host' or a .npy path: _io.History); gram_precision ('auto' default | 'bf16x2' |
     'bf16x3' | 'fp32': the arithmetic of the re-weighted TV Gram's tile products for this solve, engine.wgram_tv_precision —
-    choose one of the last two for iterates that repeat a few values exactly, e.g. synthetic piecewise-constant data)."""
+    choose one of the last two for iterates that repeat a few values exactly, e.g. synthetic piecewise-constant data).  The switch is
+    process-wide for the duration of the call (trk.h, trk_wgram_tv_precision): not for two solves on two threads at once."""
     A = as_operator(A)
-    if kwargs.get("gram_precision") is not None and hasattr(A.engine, "wgram_tv_precision"):
+    if kwargs.get("gram_precision") is not None:
+        if not hasattr(A.engine, "wgram_tv_precision"):
+            raise TypeError(f"MMGKS(gram_precision=...): the operator's engine ({type(A.engine).__name__}) has no TV-Gram arithmetic to select")
         kw = dict(kwargs)
         was = A.engine.wgram_tv_precision(kw.pop("gram_precision"))
         try:
