@@ -202,6 +202,51 @@ def test_radon_lean_quad_kernel_equals_the_round4_kernel_bit_for_bit(case, monke
     assert float(y_lean.abs().max()) > 0.0
 
 
+@pytest.mark.parametrize("case", ["deg180", "quads", "signs", "wide_detector", "two_frames"])
+def test_radon_adjoint_by_mirrored_tile_pairs(case, monkeypatch):
+    """Round 6: k_radon_adj_quad — a workgroup owns the orbit of a 32 x 32 tile under the two mirrors of the grid and evaluates the BASE
+    geometry of a quad once for two members (the column-mirrored pair shares slots 0 / 1, the row-mirrored pair slots 2 / 3).  Same taps,
+    same fixed-point weights as k_radon_adj_tile, another summation order: against that kernel (TRK_RADON_NO_ADJQ=1) at fp32 summation
+    noise, against the float64 oracle at 1e-5, the adjoint identity with the forward, and run to run to the bit."""
+    from oracle import cpu_ref as O
+    from trips_py_amd.operators import BlockDiagOp, Radon2DParallel
+    N = 1024
+    monkeypatch.setenv("TRK_RADON_ADJQ_MIN", "1024")       # (the product takes this kernel from 2048^2 on: read when the handle is made)
+    ang = {"deg180": np.linspace(0, np.pi, 180, endpoint=False),
+           "quads": np.deg2rad([10.0, 80.0, 100.0, 170.0, 11.0, 79.0, 101.0, 169.0, 12.0, 78.0, 102.0, 13.0]),
+           "signs": np.deg2rad([20.0, 160.0, -20.0, 200.0, 70.0, 110.0, -70.0, 250.0, 290.0, 340.0, -160.0, 21.0, 69.0, 111.0, 159.0]),
+           "wide_detector": np.linspace(0, np.pi, 36, endpoint=False),
+           "two_frames": np.deg2rad(np.arange(2)[:, None] * 0.5 + 5.0 * np.arange(36)[None, :])}[case]
+    nd = 1500 if case == "wide_detector" else N
+    if case == "two_frames":
+        R = BlockDiagOp([Radon2DParallel(N, a, n_det=nd) for a in ang])
+    else:
+        R = Radon2DParallel(N, ang, n_det=nd)
+    eng = R.engine
+    g = torch.Generator(device=eng.device).manual_seed(7)
+    y = torch.randn(R.shape[0], device=eng.device, generator=g)
+    z_new = R.apply(y, transpose=True).clone()
+    monkeypatch.setenv("TRK_RADON_NO_ADJQ", "1")
+    z_old = R.apply(y, transpose=True).clone()
+    monkeypatch.delenv("TRK_RADON_NO_ADJQ")
+    z_again = R.apply(y, transpose=True)
+    assert torch.equal(z_new, z_again)
+    scale = float(z_old.abs().max())
+    dev = float((z_new - z_old).abs().max()) / scale
+    assert dev < 2e-6, dev                                          # another summation order: the same sums
+    assert float(torch.linalg.norm((z_new - z_old).double()) / torch.linalg.norm(z_old.double())) < 3e-7
+    if case in ("quads", "wide_detector"):                          # the oracle's sparse matrix at 1024^2: the small angle sets only
+        Ro = O.Radon2D(N, ang, n_det=nd)
+        yh = y.cpu().numpy().astype(np.float64)
+        assert relerr(z_new.cpu().numpy().astype(np.float64), Ro.T @ yh) < 1e-5
+    x = torch.randn(R.shape[1], device=eng.device, generator=g)
+    S = eng.scalars(2)
+    eng.dot(R.apply(x), y, S.ref(0))
+    eng.dot(x, z_new, S.ref(1))
+    dd = S.host()
+    assert abs(dd[0] - dd[1]) <= 1e-6 * float(torch.linalg.norm(R.apply(x).double()) * torch.linalg.norm(y.double()))
+
+
 @pytest.mark.parametrize("N,na,nd", [(200, 90, 200), (256, 180, 256), (288, 60, 410), (512, 180, 512), (800, 40, 800)])
 def test_radon_adjoint_with_the_angles_of_a_tile_split_over_workgroups(N, na, nd):
     """Small images, many angles: the adjoint runs 32 x 32 tiles whose angles are split over 4 or 8 workgroups; the partial tiles
@@ -567,6 +612,17 @@ def _radon_case(name):
         return Radon2DParallel(512, np.linspace(0, np.pi, 180, endpoint=False))
     if name == "static1030":        # shared-window forward kernel (N >= 1024), 32 x 32 tiles
         return Radon2DParallel(1030, np.linspace(0, np.pi, 36, endpoint=False), n_det=1100)
+    if name == "static1024":        # round 6: the lean quad forward and the adjoint by mirrored tile pairs (whole 64 x 64 super-tiles, full quads)
+        import os
+        was = os.environ.get("TRK_RADON_ADJQ_MIN")
+        os.environ["TRK_RADON_ADJQ_MIN"] = "1024"       # (the product takes the mirrored-pair adjoint from 2048^2 on; read at create)
+        try:
+            return Radon2DParallel(1024, np.linspace(0, np.pi, 60, endpoint=False))
+        finally:
+            if was is None:
+                del os.environ["TRK_RADON_ADJQ_MIN"]
+            else:
+                os.environ["TRK_RADON_ADJQ_MIN"] = was
     if name == "dynamic":           # BASELINE C5 structure: frames in one handle, 15 angles per frame (records made in the tile kernel)
         return BlockDiagOp([Radon2DParallel(128, np.deg2rad(3.0 * t + 12.0 * np.arange(15))) for t in range(6)])
     if name == "tiny":              # N < 16: no tiled adjoint -> apply + axpby inside the C entry point
@@ -574,7 +630,7 @@ def _radon_case(name):
     raise KeyError(name)
 
 
-@pytest.mark.parametrize("case", ["static64", "static512", "static1030", "dynamic", "tiny"])
+@pytest.mark.parametrize("case", ["static64", "static512", "static1030", "static1024", "dynamic", "tiny"])
 def test_radon_fused_half_step_equals_apply_then_axpby(case):
     """trk_op_apply_axpby (out = a Op(x) + b z and ||out||^2 in the projector's own output pass: band reduction of the
     forward, tile gather of the adjoint; norm finished by the last workgroup) against trk_op_apply + trk_axpby, both

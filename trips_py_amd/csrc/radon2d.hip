@@ -64,6 +64,9 @@ struct AdjAngle {           // the adjoint's per-angle constants, sorted by marc
 
 struct QuadParam;
 struct QuadPlan;
+struct AdjQuad {            // base geometry of a quad for the adjoint: c1 = 1 - inv (<= 0), rinv = cos(beta), dq = tan(beta), k0 = h (1 - dq)
+  float c1, rinv, dq, k0;   // ({c1, rinv} is read as ONE scalar pair, as AdjAngle's)
+};
 
 struct RadonImpl {
   int N, nd, na;   // na = angles PER FRAME
@@ -97,6 +100,13 @@ struct RadonImpl {
   int nq;
   // round 6: the quad kernel's per-workgroup bookkeeping made once per operator (k_radon_quad_plan) and the compact list of the
   // workgroups the lean kernel (k_radon_fwd_quadf) does not serve
+  // round 6, adjoint by mirrored tile pairs (k_radon_adj_quad): per quad {c1, rinv, dq, k0} of the BASE geometry, {C, B32} of the base per
+  // marching index, the members' weights; recq = per-apply records indexed by (quad, slot, BASE detector)
+  struct AdjQuad* adjq;
+  uint2* CBq;        // [nt*nq][npad]
+  float* wq;         // [nt*nq][4]
+  uint4* recq;       // [nt*nq][4][nd + 4]
+  int adjq_ok;
   struct QuadPlan* qplan;
   int* qslow;       // [0] = count, then the workgroup ids (band * grid_x + block) k_radon_fwd_quad still runs
   int qslow_n;      // host copy of the count
@@ -1428,7 +1438,10 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
       const unsigned* __restrict__ Brow = static_cast<const unsigned*>(__builtin_assume_aligned(Ball + tb, 64));
       const unsigned Ac = A - ((unsigned)cs << QF);              // column relative to cs (mod 256: the window is < 256 wide)
       const char* rowp = reinterpret_cast<const char*>(band) + (16 * c) * RS * 4;
-      f2v acc2 = {0.f, 0.f};
+      // fp32 sums of FOUR rows, then float64 (round 6; rounds 2-5: of sixteen).  The float64 instrument (profiles/r05/c3_instrument.txt)
+      // showed what the longer fp32 chains cost where the solver amplifies roundings — iterates 5-7 of C3's transient sat 44-90 x
+      // above the fp32-storage floor with 16-row sums and on it with 4-row sums (R.set_ref_sums(4, 32))
+      f2v acc2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
       if (cs >= 0 && ce <= N - 1) {
         // every tap of the wave inside the image: address = row (scalar) + 4 (cs + pad) (scalar) + 4 * relative column
         f2v w[16], t2[16];
@@ -1444,7 +1457,7 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
           t2[u] = (f2v){tp[0], tp[1]};
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc2 = __builtin_elementwise_fma(w[u], t2[u], acc2);
+        for (int u = 0; u < 16; ++u) acc2[u >> 2] = __builtin_elementwise_fma(w[u], t2[u], acc2[u >> 2]);
       } else {
         // the window overhangs the image: columns clamped into the zero pads ([-2, N]: both taps of a clamped step read zeros)
         f2v w[16], t2[16];
@@ -1462,9 +1475,10 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
           t2[u] = (f2v){tp[0], tp[1]};
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc2 = __builtin_elementwise_fma(w[u], t2[u], acc2);
+        for (int u = 0; u < 16; ++u) acc2[u >> 2] = __builtin_elementwise_fma(w[u], t2[u], acc2[u >> 2]);
       }
-      total += (double)(acc2[0] + acc2[1]);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) total += (double)(acc2[g4][0] + acc2[g4][1]);
     }
     if (live) part[(int64_t)b * band_stride + (int64_t)a * nd + d] = (float)total;
     int nx = 0;
@@ -1664,7 +1678,7 @@ __global__ __launch_bounds__(256 * G) void k_radon_adj_tile(const float* __restr
                                                         int nsplit, float* __restrict__ part_img, unsigned* __restrict__ tile_cnt) {
   __shared__ __attribute__((aligned(16))) uint4 ring_all[G][2][AB][64];
   __shared__ __attribute__((aligned(16))) uint2 cbs_all[G][2][AB][T];
-  __shared__ float xch_all[G][PX > 1 ? T : 1][T + 1];
+  __shared__ double xch_all[G][PX > 1 ? T : 1][T + 1];     // (float64 since round 6: the two modes' totals meet unrounded)
   static_assert(T * T == 256 * PX && (T == 16 || T == 32), "256 threads x PX pixels cover the T x T tile");
   static_assert(G == 1 || (PX == 4 && T == 32), "groups: the 32 x 32 form only");
   __shared__ double lds[4];
@@ -1720,10 +1734,16 @@ __global__ __launch_bounds__(256 * G) void k_radon_adj_tile(const float* __restr
   }
   f2v anA[PX], anB[PX];
   float accA[PX], accB[PX];
+  // fp32 sums over at most ADJ_FLUSH angles, then float64 (round 6; rounds 1-5: fp32 over all angles of the part).  The float64
+  // instrument (profiles/r05/c3_instrument.txt) put the 180-angle fp32 sum one amplification step (x 6.5 per iteration of C3's
+  // transient) above the fp32-storage floor, a 32-angle cadence on it (R.set_ref_sums(4, 32))
+  constexpr int ADJ_FLUSH = 32;
+  double totA[PX], totB[PX];
 #pragma unroll
   for (int k = 0; k < PX; ++k) {
     accA[k] = accB[k] = 0.f;
     anA[k] = anB[k] = (f2v){0.f, 0.f};
+    totA[k] = totB[k] = 0.0;
   }
   f2v sc2 = {5.9604644775390625e-8f, 5.9604644775390625e-8f};          // 2^-24, kept in an (aligned) VGPR pair
   float nsc = -5.9604644775390625e-8f;
@@ -1899,18 +1919,37 @@ __global__ __launch_bounds__(256 * G) void k_radon_adj_tile(const float* __restr
     };
     angles(0, nm0, fcolA, colA, r0, anA, accA);
     angles(nm0, nal, fcolB, colB, c1, anB, accB);
+    if (((b + 1) * AB) % ADJ_FLUSH == 0) {           // wave-uniform; only the batch where the modes change flushes both
+      if (nm0 > 0) {
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+          totA[k] += (double)(accA[k] + (anA[k][0] + anA[k][1]));
+          accA[k] = 0.f;
+          anA[k] = (f2v){0.f, 0.f};
+        }
+      }
+      if (nm0 < nal) {
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+          totB[k] += (double)(accB[k] + (anB[k][0] + anB[k][1]));
+          accB[k] = 0.f;
+          anB[k] = (f2v){0.f, 0.f};
+        }
+      }
+    }
     if (b + 1 < nbatch) stage_store(b + 1);          // the other buffer: nobody reads it before the next barrier
   }
   // the two partial images meet: mode-0 sums go through LDS to the thread that holds the pixel in the mode-1 layout
   if (PX > 1) {
 #pragma unroll
-    for (int k = 0; k < PX; ++k) xch[r0][c0 + k * TS] = accA[k] + (anA[k][0] + anA[k][1]);
+    for (int k = 0; k < PX; ++k) xch[r0][c0 + k * TS] = totA[k] + (double)(accA[k] + (anA[k][0] + anA[k][1]));
     __syncthreads();
   }
   float oraw[PX];
 #pragma unroll
   for (int k = 0; k < PX; ++k)
-    oraw[k] = (accB[k] + (anB[k][0] + anB[k][1])) + (PX > 1 ? xch[r1 + k * TS][c1] : accA[k] + (anA[k][0] + anA[k][1]));
+    oraw[k] = (float)((totB[k] + (double)(accB[k] + (anB[k][0] + anB[k][1]))) +
+                      (PX > 1 ? xch[r1 + k * TS][c1] : totA[k] + (double)(accA[k] + (anA[k][0] + anA[k][1]))));
   if (G > 1) {
     // the groups' partial tiles meet in LDS, added in part order by the first group, which carries the epilogue alone
     __shared__ float red[G > 1 ? G - 1 : 1][256][PX];
@@ -2087,6 +2126,266 @@ __global__ __launch_bounds__(256 * G) void k_radon_adj_tile(const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------------------- adjoint by mirrored tile pairs (round 6)
+// The symmetry that carries the forward's quads (k_radon_fwd_quad) applied to the adjoint.  With the BASE geometry of a quad — beta in
+// [0, 45 deg], q_b(d, tt) = (A_b[d] + B_b[tt]) 2^-24 — one evaluation of {nearest base detector d0, t0 = q_b(d0, tt) - col, the three hat
+// weights} at (tt, col) serves
+//     slot 0 (rows of x):            pixel (tt, col)            slot 1 (rows of x, mirrored):  pixel (tt, N-1-col)
+//     slot 2 (rows of x^T):          pixel (col, tt)            slot 3 (rows of x^T, mirrored): pixel (N-1-col, tt)
+// each with ITS member's sinogram values at the base detectors d0 - 1, d0, d0 + 1 (a mirrored member sees t = -t0: the hat is even; a
+// flipped member's detector index runs the other way: the record array recq is written per (quad, slot, BASE detector) by
+// k_radon_adj_prepq, so that one ring slot index serves all slots).  A pixel's four members need four different geometries, so the
+// sharing is between MIRRORED PIXELS: (tt, col) and (tt, N-1-col) exchange slots 0 / 1, (col, tt) and (N-1-col, tt) slots 2 / 3.  A
+// workgroup therefore owns the orbit of a 32 x 32 tile under the two mirrors — tiles (a, b), (a, b~), (a~, b), (a~, b~) — and runs four
+// sub-phases over all quads: rows of a / rows of a~ (slots 0 and 1, the column-mirrored pair of tiles each), columns of b / columns
+// of b~ (slots 2 and 3, the row-mirrored pair each).  Per geometry: 8 shared vector instructions + 2 per member (k_radon_adj_tile: 10.25
+// per pixel and angle; here 6), one ds_read_b128 per pixel and angle as before.  The four sums of a pixel (two sub-phases, two members
+// each) meet in LDS; the tiles leave through one coalesced pass that carries the epilogue (a * A^T s + b * z, the norm partials,
+// the transposed copy for the next forward apply).  Same taps and weights as k_radon_adj_tile, another summation order: tested
+// against the float64 oracle and against that kernel.
+__global__ __launch_bounds__(256) void k_radon_adj_prepq(const float* __restrict__ sino, uint4* __restrict__ recq, int nd, int na, int nq,
+                                                         const QuadParam* __restrict__ quads, const float* __restrict__ wq,
+                                                         const unsigned* __restrict__ A32q) {
+  const int ndp = nd + 2 * A32_PAD;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;      // over (quad of the frame, slot) x ndp; blockIdx.y = frame
+  const int64_t r = idx / ndp;
+  if (r >= (int64_t)nq * 4) return;
+  const int e = (int)(idx - r * ndp), q = (int)(r >> 2), m = (int)(r & 3);
+  const int64_t qr = (int64_t)blockIdx.y * nq + q;
+  const QuadParam p = quads[qr];
+  const int am = m == 0 ? p.am[0] : (m == 1 ? p.am[1] : (m == 2 ? p.am[2] : p.am[3]));
+  const bool flip = ((p.flip >> m) & 1) != 0;
+  const float w = wq[qr * 4 + m];
+  const int d = e - A32_PAD;
+  const float* __restrict__ S = sino + ((int64_t)blockIdx.y * na + (am < 0 ? 0 : am)) * nd;
+  auto val = [&](int db) -> float {                                 // the member's sample at BASE detector db
+    const int dm = flip ? nd - 1 - db : db;
+    return (am >= 0 && db >= 0 && db < nd) ? w * S[dm] : 0.f;
+  };
+  uint4 o;
+  o.x = __builtin_bit_cast(unsigned, val(d - 1));                   // the base ray at t0 - inv (inv > 0)
+  o.y = __builtin_bit_cast(unsigned, val(d + 1));                   // the base ray at t0 + inv
+  o.z = __builtin_bit_cast(unsigned, val(d));
+  o.w = A32q[qr * ndp + e];
+  recq[(qr * 4 + m) * ndp + e] = o;
+}
+
+template <int QB>
+__global__ __launch_bounds__(256) void k_radon_adj_quad(const uint4* __restrict__ recq, float* __restrict__ img, int N, int nd, int nq,
+                                                        const AdjQuad* __restrict__ aq, const uint2* __restrict__ CBq, int npad,
+                                                        int tiles_h, double* __restrict__ ssq_part, Epi epi,
+                                                        float* __restrict__ xT_out) {
+  constexpr int T = 32, PX = 4, TS = 8;
+  __shared__ __attribute__((aligned(16))) uint4 ring[2][QB][4][64];   // [buffer][quad of the batch][base tile 0: slot A, slot B; base tile 1: A, B]
+  __shared__ __attribute__((aligned(16))) uint2 cbs[2][QB][T];        // {C, B32} of the base at the sub-phase's 32 marching indices
+  __shared__ float sum[4][T][T + 1];                                   // the orbit's four tiles: [2 (row >= N/2) + (col >= N/2)]
+  __shared__ double lds[4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int frame = blockIdx.y;
+  const int ta = blockIdx.x / tiles_h, tb = blockIdx.x - ta * tiles_h;
+  const int i0 = ta * T, j0 = tb * T;                                  // tile (a, b); its mirrors start at N - T - i0 / N - T - j0
+  const int ndp = nd + 2 * A32_PAD;
+  aq += (int64_t)frame * nq;
+  CBq += (int64_t)frame * nq * npad;
+  recq += (int64_t)frame * nq * 4 * ndp;
+  const auto rrec = __builtin_amdgcn_make_buffer_rsrc((void*)recq, 0, (unsigned)((int64_t)nq * 4 * ndp * 16), 0x00020000);
+  const auto rcb = __builtin_amdgcn_make_buffer_rsrc((void*)CBq, 0, (unsigned)((int64_t)nq * npad * 8), 0x00020000);
+  const float sdh = 0.5f * (float)(nd - 1);
+  f2v sc2 = {5.9604644775390625e-8f, 5.9604644775390625e-8f};          // 2^-24, kept in an (aligned) VGPR pair
+  float nsc = -5.9604644775390625e-8f;
+  asm("" : "+v"(sc2));
+  asm("" : "+s"(nsc));
+  const int nbatch = (nq + QB - 1) / QB;
+  const int r0 = tid / TS, c0 = tid % TS;                              // sub-phases 0, 1: row r0, columns c0 + 8 k
+  int nqm1;
+  asm("s_add_i32 %0, %1, -1" : "=s"(nqm1) : "s"(nq) : "scc");
+
+#pragma unroll 1
+  for (int sp = 0; sp < 4; ++sp) {
+    // the sub-phase's geometry: marching index tt (fixed per thread), interpolated coordinates col_k and their mirrors N-1-col_k
+    const bool colmode = sp >= 2;
+    const int u0 = colmode ? j0 : i0, v0 = colmode ? i0 : j0;          // marching tile start / interpolated tile start (unmirrored)
+    const int tl = colmode ? tid / TS : r0;                            // marching index within the tile
+    const int cl = colmode ? tid % TS : c0;                            // first interpolated index within the tile
+    const bool mir_t = (sp & 1) != 0;                                  // sub-phases 1, 3: the mirrored marching tile
+    const int tt0 = mir_t ? N - T - u0 : u0;                           // its first marching index (ascending table order)
+    const int tt = mir_t ? N - 1 - (u0 + tl) : u0 + tl;
+    const int ttl = tt - tt0;
+    const int slotA = colmode ? 2 : 0;
+    float fcol[2][PX];
+    unsigned ncol[2][PX];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+      const int c = v0 + cl + k * TS;
+      fcol[0][k] = (float)c;
+      ncol[0][k] = 0u - ((unsigned)c << QF);
+      fcol[1][k] = (float)(N - 1 - c);
+      ncol[1][k] = 0u - ((unsigned)(N - 1 - c) << QF);
+    }
+    // centres of the two base tiles (the interpolated tile and its mirror) for the ring bases
+    const float tt_c = (float)tt0 + 0.5f * (float)(T - 1);
+    const float co_c0 = (float)v0 + 0.5f * (float)(T - 1), co_c1 = (float)(N - T - v0) + 0.5f * (float)(T - 1);
+    f2v an[2][PX];
+    float ac[2][PX];
+#pragma unroll
+    for (int k = 0; k < PX; ++k) {
+      an[0][k] = an[1][k] = (f2v){0.f, 0.f};
+      ac[0][k] = ac[1][k] = 0.f;
+    }
+    // staging of batch b into buffer b & 1: wave w takes rings w, w + 4, ... of the batch's 4 QB (ring = quad * 4 + 2 * base tile + slot
+    // B), lane l the base detector whose ring slot is l; threads 0 .. 16 QB - 1 the {C, B32} pairs (16 bytes = two indices each)
+    float nx_rinv, nx_dq, nx_k0;
+    auto fetch_quads = [&](int b) {
+      int q = b * QB + (lane & (QB - 1));
+      q = q < nq ? q : nq - 1;
+      nx_rinv = aq[q].rinv;
+      nx_dq = aq[q].dq;
+      nx_k0 = aq[q].k0;
+    };
+    fetch_quads(0);
+    auto stage_load = [&](int b) {
+      // lane (q, base tile) = (lane & (QB-1), (lane / QB) & 1) works out one ring base; handed out by v_readlane (no scalar float unit)
+      int dbase_l;
+      {
+        const float co_c = ((lane / QB) & 1) ? co_c1 : co_c0;
+        dbase_l = (int)floorf(fmaf(co_c - fmaf(tt_c, nx_dq, nx_k0), nx_rinv, sdh)) - 32;
+      }
+      if (b + 1 < nbatch) fetch_quads(b + 1);
+#pragma unroll
+      for (int h = 0; h < QB; ++h) {
+        const int rr = wv + 4 * h;                                     // ring of the batch: quad rr / 4, base tile (rr / 2) & 1, slot A + (rr & 1)
+        const int ql = rr >> 2, bt = (rr >> 1) & 1;
+        int q;
+        asm("s_min_i32 %0, %1, %2" : "=s"(q) : "s"(b * QB + ql), "s"(nqm1) : "scc");
+        const int row = (q * 4 + slotA + (rr & 1)) * ndp;
+        const int dbase = __builtin_amdgcn_readlane(dbase_l, ql + QB * bt);
+        const int d = dbase + ((lane - dbase) & 63);
+        int e;
+        asm("v_med3_i32 %0, %1, 0, %2" : "=v"(e) : "v"(d + A32_PAD), "s"(ndp - 1));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rrec, (__attribute__((address_space(3))) void*)&ring[b & 1][ql][rr & 3][0], 16, (row + e) * 16, 0, 0, 0);
+      }
+      if (tid < QB * T / 2) {
+        const int ql = tid / (T / 2), pr = tid - ql * (T / 2);
+        int q = b * QB + ql;
+        q = q < nq ? q : nq - 1;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rcb, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(&cbs[b & 1][0][0]) + wv * 1024), 16,
+                                                 (q * npad + tt0 + 2 * pr) * 8, 0, 0, 0);
+      }
+    };
+    stage_load(0);
+    for (int b = 0; b < nbatch; ++b) {
+      const int buf = b & 1;
+      __builtin_amdgcn_s_waitcnt(0x0F70);            // vmcnt(0): this wave's share of batch b has landed
+      __syncthreads();                               // batch b complete; everyone is done with the other buffer
+      if (b + 1 < nbatch) stage_load(b + 1);
+      const int nql = (nq - b * QB < QB) ? nq - b * QB : QB;
+      const unsigned rbase = __builtin_amdgcn_readfirstlane(lds_offset(&ring[buf][0][0][0]));
+#pragma unroll 1
+      for (int ql = 0; ql < nql; ++ql) {
+        const AdjQuad p = aq[b * QB + ql];           // wave-uniform: scalar loads
+        f2v cr = {p.c1, p.rinv};
+        asm("" : "+s"(cr));
+        const uint2 cb = cbs[buf][ql][ttl];
+        const float C = __builtin_bit_cast(float, cb.x);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {                // the interpolated tile, then its mirror
+          u4r ra[PX], rb[PX];
+          const unsigned rb_h = rbase + (unsigned)(ql * 4 + 2 * h) * 1024u;
+#pragma unroll
+          for (int k = 0; k < PX; ++k) {
+            const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[h][k], p.rinv, C) + RND_MAGIC);
+            unsigned addr;
+            const unsigned slot = bits & 63u;
+            asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(slot), "s"(rb_h));
+            asm volatile("ds_read_b128 %0, %1" : "=v"(ra[k]) : "v"(addr) : "memory");
+            asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(rb[k]) : "v"(addr) : "memory");
+          }
+          ring_wait();
+#pragma unroll
+          for (int k = 0; k < PX; ++k) {
+            ring_tie(ra[k]);
+            ring_tie(rb[k]);
+            // slot A's member sees the pixel of this geometry, slot B's its mirror: tile set h / 1 - h
+            const unsigned slo = ra[k][0], shi = ra[k][1], s0 = ra[k][2], a32 = ra[k][3];
+            const unsigned mlo = rb[k][0], mhi = rb[k][1], m0 = rb[k][2];
+            unsigned ti;
+            asm("v_add3_u32 %0, %1, %2, %3" : "=v"(ti) : "v"(a32), "v"(cb.y), "v"(ncol[h][k]));
+            const float tf = (float)(int)ti;
+            f2v t2;
+            t2[0] = tf;
+            f2v wn;
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,0] neg_hi:[0,1,0] clamp" : "=v"(wn) : "v"(t2), "v"(sc2), "s"(cr));
+            float w0;
+            asm("v_fma_f32 %0, |%1|, %2, 1.0" : "=v"(w0) : "v"(tf), "s"(nsc));
+            const f2v sn = {__builtin_bit_cast(float, slo), __builtin_bit_cast(float, shi)};
+            const f2v mn = {__builtin_bit_cast(float, mlo), __builtin_bit_cast(float, mhi)};
+            an[h][k] = __builtin_elementwise_fma(wn, sn, an[h][k]);
+            ac[h][k] = fmaf(w0, __builtin_bit_cast(float, s0), ac[h][k]);
+            an[1 - h][k] = __builtin_elementwise_fma(wn, mn, an[1 - h][k]);
+            ac[1 - h][k] = fmaf(w0, __builtin_bit_cast(float, m0), ac[1 - h][k]);
+          }
+        }
+      }
+    }
+    // the sub-phase's sums meet the other one's in LDS: pixel (row, col) of tile set h, interpolated index col_k (h = 0) or its mirror
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int k = 0; k < PX; ++k) {
+        const int c = h ? N - 1 - (v0 + cl + k * TS) : v0 + cl + k * TS;
+        const int row = colmode ? c : tt, col = colmode ? tt : c;
+        float* dst = &sum[2 * (row >= N / 2 ? 1 : 0) + (col >= N / 2 ? 1 : 0)][row & (T - 1)][col & (T - 1)];
+        const float v = ac[h][k] + (an[h][k][0] + an[h][k][1]);
+        *dst = colmode ? *dst + v : v;
+      }
+    __syncthreads();
+  }
+
+  // ---- the four tiles leave: rows of 32 contiguous pixels per quarter-wave, the epilogue of trk_op_apply_axpby on the way
+  const bool lead = blockIdx.x == 0 && blockIdx.y == 0;
+  float ca, cb;
+  double pend_sum = 0.0, cad, cbd;
+  img += (int64_t)frame * N * N;
+  const int pc = tid & 31, pr = tid >> 5;
+  float zv[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = ((t >> 1) ? N - T - i0 : i0) + pr + 8 * k, j = ((t & 1) ? N - T - j0 : j0) + pc;
+      zv[t][k] = (epi.on && epi.z) ? epi.z[((int64_t)frame * N + i) * N + j] : 0.f;
+    }
+  epi_coefs(epi, lead, &lds[0], ca, cb, &pend_sum, &cad, &cbd);
+  double q = 0.0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = ((t >> 1) ? N - T - i0 : i0) + pr + 8 * k, j = ((t & 1) ? N - T - j0 : j0) + pc;
+      float o = sum[t][pr + 8 * k][pc];
+      if (epi.on) o = epi_combine(epi.on, ca, cb, cad, cbd, o, zv[t][k], epi.z != nullptr);
+      img[(int64_t)i * N + j] = o;
+      if (xT_out) sum[t][pr + 8 * k][pc] = o;
+      q += (double)o * o;
+    }
+  if (xT_out) {
+    xT_out += (int64_t)frame * N * N;
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int i = ((t >> 1) ? N - T - i0 : i0) + pc, j = ((t & 1) ? N - T - j0 : j0) + pr + 8 * k;
+        xT_out[(int64_t)j * N + i] = sum[t][pc][pr + 8 * k];
+      }
+  }
+  if (ssq_part) {
+    q = block_sum<256>(q, lds);
+    if (tid == 0) ssq_part[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = q;
+  }
+}
+
 // The same arithmetic without LDS (one thread per pixel, records and table pairs read from memory): the reference form the
 // tiled kernel is tested against (TRK_RADON_ADJ_SIMPLE=1 selects it) and the path for frames too small to tile.
 __global__ __launch_bounds__(256) void k_radon_adj_simple(const uint4* __restrict__ rec, float* __restrict__ img, int N, int nd, int na,
@@ -2218,13 +2517,20 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   const int64_t adj_blocks = tile ? (int64_t)tiles_x * tiles_x : (int64_t)ceil_div((int64_t)N * N, 256);
   const int ndp = nd + 2 * A32_PAD;
   const bool adj_prep = !tile || na > 32;            // few angles per frame: the tile kernel makes its records itself
+  // round 6: the adjoint by mirrored tile pairs (k_radon_adj_quad) where the handle allows it (whole 64 x 64 super-tiles, mostly
+  // complete quads) and no rider travels on the epilogue (the damped-LSQR update and the mailbox post stay with k_radon_adj_tile);
+  // TRK_RADON_NO_ADJQ=1: k_radon_adj_tile everywhere (read per call: the tests switch it)
+  const bool adjq_riders = epi.on && (op->post.on || op->lsqr.on);
+  const bool adjq = tr && tile && im->adjq_ok && tile_T == 32 && nsplit == 1 && !adjq_riders && getenv("TRK_RADON_NO_ADJQ") == nullptr;
+  const int adjq_th = N / 64;
+  const int64_t adjq_blocks = (int64_t)adjq_th * adjq_th;
   if (epi.on && (batch != 1 || (tr && !tile))) return fail(TRK_EUNSUPPORTED, "radon: fused epilogue needs batch 1 and the tiled adjoint");
   // the forward's band reduction carries the epilogue / the fused norm / the adjoint's records
   const bool post = epi.on || im->n_bands > 1 || ext_part;
   if (ext_part) sumsq = ext_part;          // where a finished value goes when the partials do not fit / no kernel makes any
   const bool fuse_ssq = sumsq && batch == 1 && (tr ? tile : post);
   const int64_t post_blocks = ceil_div((int64_t)nt * na * ndp, 256);
-  const int64_t n_part = tr ? adj_blocks * nt : post_blocks;
+  const int64_t n_part = tr ? (adjq ? adjq_blocks : adj_blocks) * nt : post_blocks;
   epi.pq = PostReq{};
   if (tr && tile && batch == 1 && epi.on && op->post.on) {
     epi.pq = op->post;                         // trk_gk_step_post: the mailbox post on the adjoint kernel's first workgroup
@@ -2284,7 +2590,9 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
       dim3 grid(ndblk * ngrp * nt, nb, 1);
       float* yb = y + (int64_t)b * ldy;
       static const bool no_rec_out = getenv("TRK_RADON_NO_REC_OUT") != nullptr;     // tuning knobs: the producer side of the hints off
-      const bool want_rec = (hints & HINT_OUT_FEEDS_OPPOSITE) && tile && adj_prep && batch == 1 && !no_rec_out;
+      // (the mirrored-pair adjoint reads records of its own kind, made by its own pre-pass: nothing to leave behind for it)
+      const bool want_rec = (hints & HINT_OUT_FEEDS_OPPOSITE) && tile && adj_prep && batch == 1 && !no_rec_out &&
+                            !(im->adjq_ok && tiles32 >= 1024 && getenv("TRK_RADON_NO_ADJQ") == nullptr);
       // measured: 512^2 35 us (shared) vs 32 us (per-wave windows); 2048^2 0.256 vs 0.277 ms; 4096^2 0.96 vs 1.11 ms
       if (band_res) {
         const int rows = im->band, nbr = N / rows;
@@ -2387,6 +2695,23 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   } else {
     for (int b = 0; b < batch; ++b) {            // the record array is per vector
       const float* xb = x + (int64_t)b * ldx;
+      if (adjq) {
+        static const bool no_xt_out_q = getenv("TRK_RADON_NO_XT_OUT") != nullptr;
+        float* xT_out = ((hints & HINT_OUT_FEEDS_OPPOSITE) && im->n_mode1 > 0 && batch == 1 && !no_xt_out_q) ? im->xT : nullptr;
+        hipLaunchKernelGGL(k_radon_adj_prepq, dim3(ceil_div((int64_t)im->nq * 4 * ndp, 256), nt), dim3(256), 0, s, xb, im->recq, nd, na, im->nq,
+                           im->quad_dev, im->wq, im->A32q);
+        im->rec_src = nullptr;
+        static const int qb_env = getenv("TRK_RADON_ADJQ_QB") ? atoi(getenv("TRK_RADON_ADJQ_QB")) : 0;
+        if (qb_env == 2)
+          hipLaunchKernelGGL(k_radon_adj_quad<2>, dim3((unsigned)adjq_blocks, nt), dim3(256), 0, s, im->recq, y + (int64_t)b * ldy, N, nd, im->nq,
+                             im->adjq, im->CBq, im->npad, adjq_th, ssq_part, epi, xT_out);
+        else
+          hipLaunchKernelGGL(k_radon_adj_quad<4>, dim3((unsigned)adjq_blocks, nt), dim3(256), 0, s, im->recq, y + (int64_t)b * ldy, N, nd, im->nq,
+                             im->adjq, im->CBq, im->npad, adjq_th, ssq_part, epi, xT_out);
+        if (xT_out) im->xT_src = y + (int64_t)b * ldy;
+        TRK_LAUNCH_CHECK();
+        continue;
+      }
       if (adj_prep) {
         if (!((hints & HINT_INPUT_FROM_OPPOSITE) && im->rec_src == xb))   // else: the forward that produced xb left its records
           hipLaunchKernelGGL(k_radon_adj_prep, dim3(ceil_div((int64_t)na * ndp, 256), nt), dim3(256), 0, s, xb, im->rec, nd, na,
@@ -2533,7 +2858,7 @@ int radon_apply_axpby(trk_op* op, int tr, const float* x, Coef a, Coef b, const 
 
 void radon_destroy(trk_op* op) {
   auto* im = static_cast<RadonImpl*>(op->impl);
-  void* ptrs[] = {im->ref_ang, im->ref_tmp, im->quad_dev, im->A32q, im->B32q, im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec, im->adj_pos, im->pend_buf[0], im->pend_buf[1], im->adj_part, im->adj_cnt, im->qplan, im->qslow};
+  void* ptrs[] = {im->ref_ang, im->ref_tmp, im->quad_dev, im->A32q, im->B32q, im->ang_dev, im->xT, im->part, im->fidx, im->A32, im->B32, im->CB, im->adj_ang, im->adj_wgt, im->adj_n0, im->rec, im->adj_pos, im->pend_buf[0], im->pend_buf[1], im->adj_part, im->adj_cnt, im->qplan, im->qslow, im->adjq, im->CBq, im->wq, im->recq};
   for (void* q : ptrs)
     if (q) (void)hipFree(q);
   delete im;
@@ -2597,6 +2922,10 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
   //   plain: A_m[e] = A_b[e'], B_m = B_b;   mirrored: A_m[e] = (N-1) 2^24 - A_b[e'], B_m = -B_b   (e' = e, or ndp-1-e when flipped).
   std::vector<QuadParam> quads;
   std::vector<unsigned> a32q, b32q;
+  std::vector<AdjQuad> adjq_h;
+  std::vector<uint2> cbq_h;
+  std::vector<float> wq_h;
+  bool adjq_mostly_full = false;
   int nq = 0;
   {
     struct Cand { double beta, ctb, t; int a, slot, flip; };
@@ -2682,6 +3011,27 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
       for (size_t k = per_frame[f].size(); k < (size_t)nq; ++k)
         for (int m = 0; m < 4; ++m) quads[(size_t)f * nq + k].am[m] = -1;
     }
+    // the adjoint by mirrored tile pairs (k_radon_adj_quad): base geometry per quad, its locator offsets and the members' weights
+    adjq_h.assign((size_t)nt * nq, AdjQuad{0.f, 1.f, 0.f, 0.f});
+    cbq_h.assign((size_t)nt * nq * npad, uint2{0u, 0u});
+    wq_h.assign((size_t)nt * nq * 4, 0.f);
+    int64_t members = 0;
+    for (int f = 0; f < nt; ++f)
+      for (size_t k = 0; k < per_frame[f].size(); ++k) {
+        const size_t qr = (size_t)f * nq + k;
+        const double ctb = geo[f][k].first, t = geo[f][k].second, k0 = half - half * t;
+        adjq_h[qr] = AdjQuad{(float)(1.0 - 1.0 / ctb), (float)ctb, (float)t, (float)k0};
+        for (int tt = 0; tt < npad; ++tt) {
+          const float C = (float)(sdh - (k0 + (double)tt * t) * ctb);
+          cbq_h[qr * npad + tt] = uint2{__builtin_bit_cast(unsigned, C), b32q[qr * npad + tt]};
+        }
+        for (int m = 0; m < 4; ++m)
+          if (quads[qr].am[m] >= 0) {
+            wq_h[qr * 4 + m] = wadj[(size_t)f * na + quads[qr].am[m]];
+            ++members;
+          }
+      }
+    adjq_mostly_full = 4 * members >= 3 * 4 * (int64_t)nt * nq;
   }
   int band = RADON_BAND;
   {
@@ -2691,6 +3041,9 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     const int64_t wgs128 = (int64_t)((n_det + 63) / 64) * ((na + 3) / 4) * ((N + RADON_BAND - 1) / RADON_BAND);
     if (wgs128 < 64 && N > 64) band = 64;
   }
+  // large images (the quad kernels): 256-row bands — half the band partials to clear, write and add up (4096^2 x 180: 94 -> 47 MB each
+  // way; measured per apply 0.760 -> 0.725 ms with k_radon_fwd_quad, round 6), the four quads of a workgroup still inside one window
+  if (N >= 2048 && N % QD_R == 0) band = 2 * RADON_BAND;
   // small images: a 64-row band of the image fits the LDS of a CU (k_radon_fwd_band).  TRK_RADON_NO_BANDRES=1: the per-wave windows
   const bool band_res = N % BR_ROWS == 0 && N >= 2 * BR_ROWS && N <= BR_NMAX && getenv("TRK_RADON_NO_BANDRES") == nullptr;
   if (band_res) band = br_rows(N);
@@ -2723,6 +3076,17 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
   up((void**)&im->quad_dev, quads.data(), sizeof(QuadParam) * quads.size());
   up((void**)&im->A32q, a32q.data(), sizeof(unsigned) * a32q.size());
   up((void**)&im->B32q, b32q.data(), sizeof(unsigned) * b32q.size());
+  // the mirrored-pair adjoint: images of whole 64 x 64 super-tiles, mostly complete quads (single angles would pay for four), from
+  // 2048^2 on (measured per apply, 180 angles, k_radon_adj_tile -> k_radon_adj_quad: 4096^2 1.009 -> 0.794 ms, 2048^2 0.263 -> 0.222,
+  // 1024^2 0.084 -> 0.101: 256 workgroups of four sub-phases leave the chip half empty there).  TRK_RADON_ADJQ_MIN: the tests' knob
+  const int adjq_min = getenv("TRK_RADON_ADJQ_MIN") ? atoi(getenv("TRK_RADON_ADJQ_MIN")) : 2048;
+  im->adjq_ok = (nq > 0 && N % 64 == 0 && N >= adjq_min && adjq_mostly_full && (int64_t)nq * 4 * ndp * 16 < ((int64_t)1 << 31)) ? 1 : 0;
+  if (im->adjq_ok) {
+    up((void**)&im->adjq, adjq_h.data(), sizeof(AdjQuad) * adjq_h.size());
+    up((void**)&im->CBq, cbq_h.data(), sizeof(uint2) * cbq_h.size());
+    up((void**)&im->wq, wq_h.data(), sizeof(float) * wq_h.size());
+    up((void**)&im->recq, nullptr, sizeof(uint4) * (size_t)nt * nq * 4 * ndp);
+  }
   {
     // adjoint tables: per frame, the angles with marching mode 0 first
     std::vector<AdjAngle> aa(n_ang);
