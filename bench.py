@@ -531,11 +531,11 @@ def extra_c3_tomo(world, cpu_jobs=None):
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for _ in range(3):
+            for _ in range(10):
                 fn()
             e1.record()
             torch.cuda.synchronize()
-            ms = e0.elapsed_time(e1) / 3
+            ms = e0.elapsed_time(e1) / 10
             big[f"{name}_ms"] = round(ms, 3)
             big[f"{name}_Gtaps_per_s"] = round(big["taps_per_apply"] / ms / 1e6, 1)
             big[f"{name}_alg_GBps"] = round(big["alg_bytes_per_apply"] / ms / 1e6, 2)
@@ -546,16 +546,22 @@ def extra_c3_tomo(world, cpu_jobs=None):
         #   forward (k_radon_fwd_quad): four symmetric angles share the taps' arithmetic, so a wave-step serves 256
         #   ray-steps with 4 ds_read2_b32 (16 LDS cycles per CU: the binding pipe, conflict-free by construction) and
         #   8 shared + 4 packed-FMA vector instructions (38.5 cycles on one of the CU's four SIMDs);
-        #   adjoint (k_radon_adj_tile): 10.25 vector instructions per pixel and angle, its mix at 4 cycles each.
+        #   adjoint (round 6, k_radon_adj_quad: mirrored tile pairs share the base geometry's weights): 6 vector instructions per
+        #   pixel and angle at 4 cycles each (k_radon_adj_tile: 10.25), one ds_read_b128 per pixel and angle (4 LDS cycles per wave).
+        # `fwd_ms` / `adj_ms` are whole applies (forward: transpose + clear + k_radon_fwd_quadf + band reduction; adjoint: record
+        # pre-pass + k_radon_adj_quad); the kernels alone are in profiles/r06 (rocprofv3).
         steps = float(Nb) * Nb * na
         lds_floor_ms = steps / 256.0 * 16.0 / (256 * 2.4e9) * 1e3
         valu_floor_ms = steps / 256.0 * 38.5 / (1024 * 2.4e9) * 1e3
-        big["fwd_roofline"] = {"bound": "lds_gather", "lds_cycles_per_256_ray_steps": 16.0, "units": steps, "floor_ms": round(lds_floor_ms, 4),
+        big["fwd_roofline"] = {"bound": "lds_gather", "kernel": "k_radon_fwd_quadf (+ k_transpose, clear, k_radon_bands_post in fwd_ms)",
+                               "lds_cycles_per_256_ray_steps": 16.0, "units": steps, "floor_ms": round(lds_floor_ms, 4),
                                "frac": round(lds_floor_ms / big["fwd_ms"], 4), "valu_floor_ms": round(valu_floor_ms, 4),
                                "valu_cycles_per_256_ray_steps_per_simd": 38.5}
-        floor_ms = steps * 10.25 / 64.0 * 4.0 / (1024 * 2.4e9) * 1e3
-        big["adj_roofline"] = {"bound": "valu_issue", "instr_per_unit": 10.25, "cycles_per_instr": 4.0, "units": steps,
-                               "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / big["adj_ms"], 4)}
+        floor_ms = steps * 6.0 / 64.0 * 4.0 / (1024 * 2.4e9) * 1e3
+        adj_lds_floor_ms = steps / 64.0 * 4.0 / (256 * 2.4e9) * 1e3
+        big["adj_roofline"] = {"bound": "valu_issue", "kernel": "k_radon_adj_quad (+ k_radon_adj_prepq in adj_ms)", "instr_per_unit": 6.0,
+                               "cycles_per_instr": 4.0, "units": steps, "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / big["adj_ms"], 4),
+                               "lds_floor_ms": round(adj_lds_floor_ms, 4), "round5_kernel_floor_ms": round(steps * 10.25 / 64.0 * 4.0 / (1024 * 2.4e9) * 1e3, 4)}
         out["radon_4096x180"] = big
         del Rb, xb, yb, zb
     except Exception as exc:      # noqa: BLE001
@@ -710,22 +716,60 @@ def extra_sparse_dynamic(world, cpu_jobs=None):
     alg = 8.0 * nnz + 4.0 * (m + n)
     roof = {"matrix": f"blkdiag of {T} frames, {m} x {n}, {nnz} non-zeros (Joseph weights, {na} angles x {nd} detectors per {Nf}x{Nf} frame)",
             "alg_bytes_per_apply": alg, "alg_bytes_formula": "8 nnz + 4 (m + n)", "bound": "hbm", "peak": HBM_PEAK_GBPS, "unit": "GB/s"}
-    for name, fn in (("fwd", lambda: D.apply(x, out=y)), ("adj", lambda: D.apply(y, out=z, transpose=True))):
-        for _ in range(3):
-            fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(20):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        us = e0.elapsed_time(e1) / 20 * 1e3
-        roof[f"{name}_us"] = round(us, 1)
-        roof[f"{name}_achieved"] = round(alg / us * 1e-3, 1)
-        roof[f"{name}_frac"] = round(alg / us * 1e-3 / HBM_PEAK_GBPS, 4)
-    roof["note"] = ("the matrix (170 MB) fits the 256 MB memory-side cache: repeated applies may be served from it, the figure is the "
-                    "kernel's streaming rate against the HBM peak; timed by events on the stream the applies are enqueued on")
+    # COLD (round 6): three handles holding copies of the matrix and their own vectors take turns, so that every
+    # apply streams its 170 MB from HBM (3 x 170 MB per direction do not fit the 256 MB memory-side cache); `*_frac` is this
+    # number.  WARM (one handle, back to back: round 5's figure, the matrix served by the memory-side cache) stays beside it.
+    Ds = [D, SparseBlockDiag(blocks), SparseBlockDiag(blocks)]
+    xs = [x] + [x.clone() for _ in range(2)]
+    ys = [y] + [torch.empty_like(y) for _ in range(2)]
+    zs = [z] + [torch.empty_like(z) for _ in range(2)]
+    for name in ("fwd", "adj"):
+        for mode, nh in (("", 3), ("_warm", 1)):
+            def fn(i, name=name, nh=nh):
+                h = i % nh
+                if name == "fwd":
+                    Ds[h].apply(xs[h], out=ys[h])
+                else:
+                    Ds[h].apply(ys[h], out=zs[h], transpose=True)
+            for i in range(6):
+                fn(i)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(30):
+                fn(i)
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / 30 * 1e3
+            roof[f"{name}_us{mode}"] = round(us, 1)
+            roof[f"{name}_achieved{mode}"] = round(alg / us * 1e-3, 1)
+            roof[f"{name}_frac{mode}"] = round(alg / us * 1e-3 / HBM_PEAK_GBPS, 4)
+    # A @ V on an (n, k) block (GKS.py:37 / MMGKS.py:44): k = 8 columns in ONE pass over the matrix (k_csr_group<G, 8>) against 8 passes
+    try:
+        k = 8
+        X = torch.rand(k, n, device=dev, generator=torch.Generator(device=dev).manual_seed(13))
+        Y = torch.empty(k, m, device=dev)
+        for tag, call in (("block8", lambda h: Ds[h].apply(X, out=Y)),
+                          ("eight_single", lambda h: [Ds[h].apply(X[j], out=Y[j]) for j in range(k)])):
+            for i in range(3):
+                call(i % 3)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for i in range(12):
+                call(i % 3)
+            e1.record()
+            torch.cuda.synchronize()
+            roof[f"fwd_{tag}_us"] = round(e0.elapsed_time(e1) / 12 * 1e3, 1)
+        roof["fwd_block8_alg_bytes"] = 8.0 * nnz + 4.0 * k * (m + n)
+        roof["fwd_block8_achieved"] = round(roof["fwd_block8_alg_bytes"] / roof["fwd_block8_us"] * 1e-3, 1)
+        del X, Y
+    except Exception as exc:      # noqa: BLE001
+        roof["fwd_block8_error"] = f"{type(exc).__name__}: {exc}"[:200]
+    roof["note"] = ("fwd / adj: COLD — three copies of the 170 MB matrix (and of the vectors) in rotation, every apply streams from HBM; "
+                    "*_warm: one copy back to back (it fits the 256 MB memory-side cache: round 5's figure); timed by events on the stream "
+                    "the applies are enqueued on")
+    del Ds, xs, ys, zs
     out["roofline_spmv"] = roof
     del D, x, y, z
     torch.cuda.empty_cache()

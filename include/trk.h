@@ -506,7 +506,10 @@ int trk_radon2d_set_arithmetic(trk_op* op, int mode);
 /* The instrument's kernels with EMULATED fp32 partial sums (what separates the product kernels from exact arithmetic): the forward
  * adds its products in fp32 and moves the sum into a float64 total every chunk_fwd marching steps, the adjoint every chunk_adj
  * angles, and the angle's weight is applied in fp32; 0 (default) = float64 sums.  Applies to trk_radon2d_apply_ref,
- * trk_gk_lsqr_chain and the arithmetic modes 1 / 2 above. */
+ * trk_gk_lsqr_chain and the arithmetic modes 1 / 2 above.  chunk_adj = -1 / -2 (round 6, table weights only): float64 sums, but the
+ * two NEIGHBOUR rays of a pixel weighed the way the product's gather adjoint weighs them — from the nearest ray's exact t0 and the
+ * angle's detector spacing, clamp(1 - |inv| -+ t0), instead of from their own table entries — with 1 - |inv| in float64 (-1) or
+ * rounded to fp32 as the product holds it (-2): what the adjoint's weight rule alone costs a solver, sums and storage apart. */
 int trk_radon2d_set_ref_sums(trk_op* op, int chunk_fwd, int chunk_adj);
 /* out = a x + b z on float / double vectors with the coefficients of trk_axpby: float64 coefficients and products, ONE rounding
  * to the element type (the arithmetic of the projector's fused half step), *sumsq = sum out^2 (may be NULL).  x may alias out. */

@@ -16,7 +16,18 @@ c3_instrument.txt) measured there on the MI355X, the same 100 iterations in twel
     arithmetics to three digits) or iterate 9;  the product: 1.06e-3 at iterate 8.
 So every iterate is held to  max(1e-5, the larger of the reference's own steps into and out of that iterate) — "within 1e-5, or
 closer to the reference's iterate than the reference's neighbouring iterates are" — and the float64 instantiation of the chain to
-1e-9 outside the transient and to the same envelope inside it."""
+1e-9 outside the transient and to the same envelope inside it.
+
+Round 6 (profiles/r06/c3_instrument.txt): the product's iterates 5-8 sat 44-90 x above the fp32-storage floor (chain32/tab), and the
+instrument's emulations said why — not the length of the kernels' fp32 sums (both directions summed in fp32 at the product's old
+cadence: on the floor) but a MISMATCH between A and A^T that is the same for every entry of an angle: any arithmetic that rounded the
+angle's weight in one direction only sat where the product sat.  The product's mismatch of that kind was the adjoint's neighbour-weight
+constant 1 - |inv|: formed from the fp32 inv (off by up to 7e-8 for every neighbour weight of the angle), then rounded again inside the
+fp32 FMA that forms the weights.  Now it lies on the 2^-24 grid of the fixed-point tables (the FMA is exact) and which grid neighbour
+an angle takes is chosen by error diffusion over the angles (radon2d.hip, radon_create_impl): iterates 5 / 6 / 7 / 8 at 3.2e-7 /
+2.0e-6 / 1.2e-5 / 6.9e-5 against the floor's 1.2e-7 / 6.5e-7 / 3.9e-6 / 2.0e-5 (round 5: 6.4e-6 / 4.5e-5 / 3.6e-4 / 1.06e-3).  The
+criterion is therefore tightened: 1e-5 outright on iterates 1-6 and from 21 on, and inside the transient within SIX times the floor
+measured in the same test (and still inside round 5's envelope)."""
 import functools
 
 import numpy as np
@@ -27,7 +38,7 @@ from conftest import bar, relerr
 pytestmark = pytest.mark.gpu
 
 # bars: set from measurements on the MI355X (tools/r05_c3_instrument.py, tools/configs_parity.py)
-C3_BAR = 1e-5              # final iterate, the first four, every iterate from step 21 on (measured 9e-8 ... 8.4e-7)
+C3_BAR = 1e-5              # final iterate, the first six, every iterate from step 21 on (measured 8e-8 ... 2.0e-6)
 C3_ITS = 100
 C5_BAR = 1e-5              # measured 6e-8 ... 1.2e-7 on every iterate, relError 3e-9
 C5_RESIDUAL_BAR = 1e-5     # measured 1.9e-7
@@ -71,11 +82,20 @@ def test_c3_tomo512_hybrid_lsqr_fullsize():
     d, env = m["iterates"], m["envelope"]
     bar("c3.final_x", m["x"], C3_BAR)
     bar("c3.relError_final", m["relError"][-1], C3_BAR)
-    bar("c3.first_four", max(d[:4]), C3_BAR)
+    bar("c3.first_six", max(d[:6]), C3_BAR)                                     # round 6 (rounds 3-5: the first four; iterate 6 was 4.5e-5)
     bar("c3.from_21_on", max(d[20:]), C3_BAR)
-    bar("c3.transient_max", max(d[:20]), 2e-3)                                  # recorded: 1.06e-3 at iterate 8 (= the envelope there)
-    for k in range(len(d)):                                                     # THE criterion, iterate by iterate
-        assert d[k] < max(C3_BAR, env[k]), (k + 1, d[k], env[k])
+    bar("c3.transient_max", max(d[:20]), 1e-3)                                  # recorded: 6.3e-4 at iterate 9 (round 5: 1.06e-3 at iterate 8)
+    # THE criterion, iterate by iterate (round 6): within 1e-5, or within SIX times what fp32 storage alone costs that iterate — the
+    # same arrangement on fp32 vectors with the float64-arithmetic projector on the product's table weights (chain32/tab of
+    # profiles/r06/c3_instrument.txt), run here beside the product — and never further than the oracle's own steps (round 5's envelope).
+    # Measured product / floor: <= 3.4 (iterates 5-9: 3.2e-7 / 2.0e-6 / 1.2e-5 / 6.9e-5 / 6.3e-4 against 1.2e-7 / 6.5e-7 / 3.9e-6 / 2.0e-5 /
+    # 2.9e-4); round 5's kernels sat 44-90 x above it there and passed through the envelope alone.
+    floor = c3_numbers(lambda N, ang, xt, b: S.Hybrid_LSQR(Radon2DParallel(N, ang), b, C3_ITS, 1e-2, xt, dtype="float64", storage="float32",
+                                                           weights="tables64"))["iterates"]
+    bar("c3.over_the_fp32_storage_floor", max(d[k] / max(floor[k], 1e-7) for k in range(20)), 6.0)
+    for k in range(len(d)):
+        lim = max(C3_BAR, min(env[k], 6.0 * floor[k]))
+        assert d[k] < lim, (k + 1, d[k], floor[k], env[k])
         assert m["relError"][k] < max(C3_BAR, env[k]), (k + 1, m["relError"][k], env[k])
 
 

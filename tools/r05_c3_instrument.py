@@ -74,7 +74,11 @@ def main():
     # (chunk_fwd, chunk_adj): the instrument's kernels with EMULATED fp32 partial sums — which of the product's sums matter?
     sums = {"solver/w64": ("float64", 0, 0), "solver/tab": ("tables64", 0, 0), "tab/f16,a180": ("tables64", 16, 180),
             "tab/f16,a0": ("tables64", 16, 0), "tab/f0,a180": ("tables64", 0, 180), "tab/f4,a32": ("tables64", 4, 32),
-            "tab/f8,a16": ("tables64", 8, 16), "product": ("product", 0, 0)}
+            "tab/f8,a16": ("tables64", 8, 16),
+            # round 6: float64 sums, table weights, but the adjoint's two NEIGHBOUR rays weighed by the product's rule (from the nearest
+            # ray's t0 and the detector spacing) with 1 - |inv| in float64 / in fp32: what the weight rule alone costs
+            "tab/nbr64": ("tables64", 0, -1), "tab/nbr32": ("tables64", 0, -2),
+            "product": ("product", 0, 0)}
     for tag, (mode, cf, ca) in sums.items():
         R.set_arithmetic(mode)
         R.set_ref_sums(cf, ca)

@@ -2,7 +2,7 @@
 # Round 6 GPU visit: ONE script, steps by name.  usage: tools/r06_round.sh <out-subdir> [steps...]
 # steps: test (whole -m gpu suite, bars logged) | tradon (projector tests) | radon (4096^2 / 2048^2 / 1024^2 / 512^2 projector rates) |
 #        pmc_radon (counters of the 4096^2 pair) | smoke | drv | bench | prof | c3 (C3 instrument) | py:<script> [runs tools/<script>] |
-#        mb:<name> (builds + runs tools/microbench/<name>.hip)
+#        mb:<name> (builds + runs tools/microbench/<name>.hip) | traffic:<tag>,<script>[,args] | stats:<tag>,<script>[,args]
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$1; shift
 STEPS=${@:-test}
@@ -39,6 +39,19 @@ prof)
   head -8 $O/bench_driver_flags_kernel_stats.csv ;;
 c3)
   timeout 1200 python3 tools/r05_c3_instrument.py 100 > $O/c3_instrument.txt 2> $O/c3_instrument.err; echo "instr rc=$?"; head -40 $O/c3_instrument.txt; tail -3 $O/c3_instrument.err ;;
+traffic:*)
+  # HBM-side bytes per launch of tools/<script> (separate FETCH_SIZE / WRITE_SIZE passes): traffic:<tag>,<script>[,args]
+  n=${s#traffic:}; tag=${n%%,*}; rest=${n#*,}; a=${rest//,/ }
+  for ctr in FETCH_SIZE WRITE_SIZE; do
+    (cd /tmp && timeout 600 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/pmc_${tag}_$ctr -- python3 $R/tools/$a > /dev/null 2>&1); echo "pmc $tag $ctr rc=$?"
+  done
+  python3 $R/tools/traffic_summary.py $O > $O/traffic_$tag.txt 2>&1; cut -c1-175 $O/traffic_$tag.txt | head -12
+  find $O -name "*counter_collection.csv" -delete ;;
+stats:*)
+  # rocprofv3 --kernel-trace --stats of tools/<script>: stats:<tag>,<script>[,args]
+  n=${s#stats:}; tag=${n%%,*}; rest=${n#*,}; a=${rest//,/ }
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $R/tools/$a > $O/prof_$tag.log 2>&1); echo "stats $tag rc=$?"
+  f=$(ls -t $O/prof_$tag/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/${tag}_kernel_stats.csv; head -12 $O/${tag}_kernel_stats.csv | cut -c1-160 ;;
 py:*)
   n=${s#py:}; a=${n//,/ }; f=${a%% *}
   timeout 1500 python3 tools/$a > $O/${f%.py}.txt 2>&1; echo "$f rc=$?"; tail -40 $O/${f%.py}.txt ;;

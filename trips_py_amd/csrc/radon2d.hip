@@ -55,17 +55,23 @@ struct AngleParam {
   float rinv;               // ~1/inv
 };
 
-struct AdjAngle {           // the adjoint's per-angle constants, sorted by marching mode per frame
-  float c1, rinv, dq, k0;   // c1 = 1 - |inv| (<= 0): a neighbouring ray at distance |inv| weighs clamp(c1 -+ t0).  {c1, rinv} is
-                            // read as ONE scalar pair whose low half is the packed FMA's addend (adj_gather)
+struct alignas(8) AdjAngle { // the adjoint's per-angle constants, sorted by marching mode per frame
+  float c1m, c1p;           // 1 - |inv| (<= 0) ON THE 2^-24 GRID, for the neighbour on the smaller-q / larger-q side: a neighbouring ray at
+                            // distance |inv| weighs clamp(c1m + t0) / clamp(c1p - t0).  Read as ONE scalar pair: the packed FMA's
+                            // addend (adj_gather).  Which grid neighbours of the real 1 - |inv| the two hold is chosen when the handle is
+                            // made (radon_create_impl: error diffusion over the angles)
+  float rinv, dq, k0;
   int orig;                 // index of the angle within its frame
   int flip;                 // inv < 0: the ray on the larger-q side is d0 - 1 (the records store neighbours by side)
+  int pad_;
 };
 
 struct QuadParam;
 struct QuadPlan;
-struct AdjQuad {            // base geometry of a quad for the adjoint: c1 = 1 - inv (<= 0), rinv = cos(beta), dq = tan(beta), k0 = h (1 - dq)
-  float c1, rinv, dq, k0;   // ({c1, rinv} is read as ONE scalar pair, as AdjAngle's)
+struct alignas(8) AdjQuad {  // base geometry of a quad for the adjoint: c1m / c1p = 1 - inv (<= 0) on the 2^-24 grid (as AdjAngle's),
+  float c1m, c1p;           // rinv = cos(beta), dq = tan(beta), k0 = h (1 - dq)
+  float rinv, dq, k0;
+  int pad_;
 };
 
 struct RadonImpl {
@@ -1636,6 +1642,17 @@ __device__ __forceinline__ u4r ring_read(unsigned ring_base, unsigned bits) {
   asm volatile("ds_read_b128 %0, %1" : "=v"(r) : "v"(addr) : "memory");
   return r;
 }
+// a {C, B32} pair by inline assembly, for the same reason (a C++ LDS load in the angle loop was given `s_waitcnt vmcnt(0)`: the wait
+// for the NEXT batch's direct-to-LDS loads).  The caller waits (ring_wait) and ties (pair_tie) before using OR COPYING it: the data
+// lands after the instruction has issued, so nothing may touch the destination registers in between — no conditional assignment
+// (a join would copy them), no element-wise repacking
+typedef unsigned u2r __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ u2r pair_read(const void* p) {
+  u2r r;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(r) : "v"(lds_offset(p)) : "memory");
+  return r;
+}
+__device__ __forceinline__ void pair_tie(u2r& r) { asm volatile("" : "+v"(r)); }
 // all of this wave's LDS reads have returned; ring_tie makes a record's uses depend on the wait (volatile asm keeps its order)
 __device__ __forceinline__ void ring_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ void ring_tie(u4r& r) { asm volatile("" : "+v"(r)); }
@@ -1649,7 +1666,7 @@ __device__ __forceinline__ void adj_gather(const u4r r, unsigned B, unsigned neg
   unsigned ti;                                                   // t_int = A32 + B32 - (col << 24), wrap-around mod 2^32 is the point
   asm("v_add3_u32 %0, %1, %2, %3" : "=v"(ti) : "v"(a32), "v"(B), "v"(negcol24));
   const float tf = (float)(int)ti;                               // t0 in units of 2^-24, exact
-  // {clamp(c1 + t0), clamp(c1 - t0)} in one packed FMA: both lanes read the LOW half of every source (op_sel_hi 0), the high
+  // {clamp(c1m + t0), clamp(c1p - t0)} in one packed FMA: both lanes read the LOW half of t2 and of the scale (op_sel_hi 0), each its own half of the addend; the high
   // lane negates the scale 2^-24.  64-bit operands must sit in even-aligned register pairs, hence the two-element carriers
   // whose high halves are never read.  The one scalar operand an instruction may have is the angle's {c1, rinv} pair as it came
   // from the scalar load (the scale, loop-invariant, lives in a vector pair): with c1 as the vector operand every angle paid a
@@ -1657,7 +1674,7 @@ __device__ __forceinline__ void adj_gather(const u4r r, unsigned B, unsigned neg
   f2v t2;
   t2[0] = tf;
   f2v wn;
-  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,0] neg_hi:[0,1,0] clamp" : "=v"(wn) : "v"(t2), "v"(sc2), "s"(cr));
+  asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1] neg_hi:[0,1,0] clamp" : "=v"(wn) : "v"(t2), "v"(sc2), "s"(cr));
   float w0;                                                      // 1 - |t0|: exact (t0 is a multiple of 2^-24)
   asm("v_fma_f32 %0, |%1|, %2, 1.0" : "=v"(w0) : "v"(tf), "s"(nsc));
   const f2v sn = {__builtin_bit_cast(float, slo), __builtin_bit_cast(float, shi)};
@@ -1890,30 +1907,45 @@ __global__ __launch_bounds__(256 * G) void k_radon_adj_tile(const float* __restr
           for (int u = 0; u < 4; ++u) ring_tie(rr[u]);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            f2v cr = {p[u].c1, p[u].rinv};           // the packed clamp-FMA takes its addend from this scalar pair (low half read)
+            f2v cr = {p[u].c1m, p[u].c1p};           // the packed clamp-FMA takes its addend from this scalar pair
             asm("" : "+s"(cr));
             adj_gather(rr[u], cb[u].y, ncol[0], sc2, nsc, cr, an[0], ac[0]);
           }
         }
       }
-#pragma unroll 2
-      for (; al < al_hi; ++al) {
-        const AdjAngle p = ang[a0 + al];             // wave-uniform: scalar loads
-        f2v cr = {p.c1, p.rinv};
-        asm("" : "+s"(cr));
-        const uint2 cb = cbs[buf][al][cbrow];
-        const float C = __builtin_bit_cast(float, cb.x);
-        u4r rr[PX];
-#pragma unroll
-        for (int k = 0; k < PX; ++k) {
-          const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[k], p.rinv, C) + RND_MAGIC);
-          rr[k] = ring_read(rbase0 + al * 1024, bits);
-        }
+      // (round 6) the NEXT angle's constants and {C, B32} pair are requested right behind this angle's record reads, so that one wait
+      // covers both: angle by angle the loop had two exposed round trips (scalar + LDS for the pair, then LDS for the records)
+      if (al < al_hi) {
+        float pn_c1 = ang[a0 + al].c1m, pn_c1p = ang[a0 + al].c1p, pn_rinv = ang[a0 + al].rinv;     // wave-uniform: scalar loads
+        u2r cbn = pair_read(&cbs[buf][al][cbrow]);
         ring_wait();
+        pair_tie(cbn);
+#pragma unroll 2
+        for (; al < al_hi; ++al) {
+          const float p_rinv = pn_rinv;
+          f2v cr = {pn_c1, pn_c1p};
+          asm("" : "+s"(cr));
+          const u2r cbv = cbn;                       // (a copy made AFTER the tie)
+          const float C = __builtin_bit_cast(float, (unsigned)cbv[0]);
+          const unsigned cb_y = cbv[1];
+          u4r rr[PX];
 #pragma unroll
-        for (int k = 0; k < PX; ++k) {
-          ring_tie(rr[k]);
-          adj_gather(rr[k], cb.y, ncol[k], sc2, nsc, cr, an[k], ac[k]);
+          for (int k = 0; k < PX; ++k) {
+            const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[k], p_rinv, C) + RND_MAGIC);
+            rr[k] = ring_read(rbase0 + al * 1024, bits);
+          }
+          const int aln = al + 1 < al_hi ? al + 1 : al;      // (the last angle re-reads itself: unconditional, no join)
+          pn_c1 = ang[a0 + aln].c1m;
+          pn_c1p = ang[a0 + aln].c1p;
+          pn_rinv = ang[a0 + aln].rinv;
+          cbn = pair_read(&cbs[buf][aln][cbrow]);
+          ring_wait();
+          pair_tie(cbn);
+#pragma unroll
+          for (int k = 0; k < PX; ++k) {
+            ring_tie(rr[k]);
+            adj_gather(rr[k], cb_y, ncol[k], sc2, nsc, cr, an[k], ac[k]);
+          }
         }
       }
     };
@@ -2281,27 +2313,41 @@ __global__ __launch_bounds__(256) void k_radon_adj_quad(const uint4* __restrict_
       if (b + 1 < nbatch) stage_load(b + 1);
       const int nql = (nq - b * QB < QB) ? nq - b * QB : QB;
       const unsigned rbase = __builtin_amdgcn_readfirstlane(lds_offset(&ring[buf][0][0][0]));
+      // the next quad's constants and {C, B32} pair travel behind this quad's record reads: one wait covers both
+      float pn_c1 = aq[b * QB].c1m, pn_c1p = aq[b * QB].c1p, pn_rinv = aq[b * QB].rinv;     // wave-uniform: scalar loads
+      u2r cbn = pair_read(&cbs[buf][0][ttl]);
+      ring_wait();
+      pair_tie(cbn);
 #pragma unroll 1
       for (int ql = 0; ql < nql; ++ql) {
-        const AdjQuad p = aq[b * QB + ql];           // wave-uniform: scalar loads
-        f2v cr = {p.c1, p.rinv};
+        const float p_rinv = pn_rinv;
+        f2v cr = {pn_c1, pn_c1p};
         asm("" : "+s"(cr));
-        const uint2 cb = cbs[buf][ql][ttl];
-        const float C = __builtin_bit_cast(float, cb.x);
+        const u2r cbv = cbn;                         // (a copy made AFTER the tie)
+        const float C = __builtin_bit_cast(float, (unsigned)cbv[0]);
+        const unsigned cb_y = cbv[1];
+        const int qln = ql + 1 < nql ? ql + 1 : ql;  // (the last quad re-reads itself: unconditional, no join)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {                // the interpolated tile, then its mirror
           u4r ra[PX], rb[PX];
           const unsigned rb_h = rbase + (unsigned)(ql * 4 + 2 * h) * 1024u;
 #pragma unroll
           for (int k = 0; k < PX; ++k) {
-            const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[h][k], p.rinv, C) + RND_MAGIC);
+            const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[h][k], p_rinv, C) + RND_MAGIC);
             unsigned addr;
             const unsigned slot = bits & 63u;
             asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(slot), "s"(rb_h));
             asm volatile("ds_read_b128 %0, %1" : "=v"(ra[k]) : "v"(addr) : "memory");
             asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(rb[k]) : "v"(addr) : "memory");
           }
+          if (h == 1) {                              // (compile-time: the h loop is unrolled)
+            pn_c1 = aq[b * QB + qln].c1m;
+            pn_c1p = aq[b * QB + qln].c1p;
+            pn_rinv = aq[b * QB + qln].rinv;
+            cbn = pair_read(&cbs[buf][qln][ttl]);
+          }
           ring_wait();
+          pair_tie(cbn);
 #pragma unroll
           for (int k = 0; k < PX; ++k) {
             ring_tie(ra[k]);
@@ -2310,12 +2356,12 @@ __global__ __launch_bounds__(256) void k_radon_adj_quad(const uint4* __restrict_
             const unsigned slo = ra[k][0], shi = ra[k][1], s0 = ra[k][2], a32 = ra[k][3];
             const unsigned mlo = rb[k][0], mhi = rb[k][1], m0 = rb[k][2];
             unsigned ti;
-            asm("v_add3_u32 %0, %1, %2, %3" : "=v"(ti) : "v"(a32), "v"(cb.y), "v"(ncol[h][k]));
+            asm("v_add3_u32 %0, %1, %2, %3" : "=v"(ti) : "v"(a32), "v"(cb_y), "v"(ncol[h][k]));
             const float tf = (float)(int)ti;
             f2v t2;
             t2[0] = tf;
             f2v wn;
-            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,0] neg_hi:[0,1,0] clamp" : "=v"(wn) : "v"(t2), "v"(sc2), "s"(cr));
+            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1] neg_hi:[0,1,0] clamp" : "=v"(wn) : "v"(t2), "v"(sc2), "s"(cr));
             float w0;
             asm("v_fma_f32 %0, |%1|, %2, 1.0" : "=v"(w0) : "v"(tf), "s"(nsc));
             const f2v sn = {__builtin_bit_cast(float, slo), __builtin_bit_cast(float, shi)};
@@ -2416,7 +2462,7 @@ __global__ __launch_bounds__(256) void k_radon_adj_simple(const uint4* __restric
     int e = d0 + A32_PAD;
     e = e < 0 ? 0 : (e > ndp - 1 ? ndp - 1 : e);
     const uint4 rr = rec[(int64_t)a * ndp + e];
-    f2v cr = {p.c1, p.rinv};
+    f2v cr = {p.c1m, p.c1p};
     asm("" : "+s"(cr));
     adj_gather((u4r){rr.x, rr.y, rr.z, rr.w}, cb.y, 0u - ((unsigned)col << QF), sc2, nsc, cr, accn, acc0);
   }
@@ -3012,15 +3058,19 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
         for (int m = 0; m < 4; ++m) quads[(size_t)f * nq + k].am[m] = -1;
     }
     // the adjoint by mirrored tile pairs (k_radon_adj_quad): base geometry per quad, its locator offsets and the members' weights
-    adjq_h.assign((size_t)nt * nq, AdjQuad{0.f, 1.f, 0.f, 0.f});
+    adjq_h.assign((size_t)nt * nq, AdjQuad{0.f, 0.f, 1.f, 0.f, 0.f, 0});
     cbq_h.assign((size_t)nt * nq * npad, uint2{0u, 0u});
     wq_h.assign((size_t)nt * nq * 4, 0.f);
     int64_t members = 0;
-    for (int f = 0; f < nt; ++f)
+    for (int f = 0; f < nt; ++f) {
+      double carry = 0.0;                             // c1 on the 2^-24 grid, its rounding diffused over the quads in order of beta (see adj_ang below)
       for (size_t k = 0; k < per_frame[f].size(); ++k) {
         const size_t qr = (size_t)f * nq + k;
         const double ctb = geo[f][k].first, t = geo[f][k].second, k0 = half - half * t;
-        adjq_h[qr] = AdjQuad{(float)(1.0 - 1.0 / ctb), (float)ctb, (float)t, (float)k0};
+        const double c1x = (1.0 - 1.0 / ctb) * one, c1lo = std::floor(c1x), c1hi = std::ceil(c1x);
+        const double cm = std::fabs(carry + (c1lo - c1x)) <= std::fabs(carry + (c1hi - c1x)) ? c1lo : c1hi, cp = cm;
+        carry += cm - c1x;
+        adjq_h[qr] = AdjQuad{(float)(cm / one), (float)(cp / one), (float)ctb, (float)t, (float)k0, 0};
         for (int tt = 0; tt < npad; ++tt) {
           const float C = (float)(sdh - (k0 + (double)tt * t) * ctb);
           cbq_h[qr * npad + tt] = uint2{__builtin_bit_cast(unsigned, C), b32q[qr * npad + tt]};
@@ -3031,6 +3081,7 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
             ++members;
           }
       }
+    }
     adjq_mostly_full = 4 * members >= 3 * 4 * (int64_t)nt * nq;
   }
   int band = RADON_BAND;
@@ -3093,13 +3144,43 @@ static int radon_create_impl(int N, int n_det, const double* angles, int nt, int
     std::vector<int> n0(nt);
     std::vector<float> wg(n_ang);
     std::vector<int4> pos_of(n_ang);
+    // What is left of that mismatch is rounding again, and again one value per angle.  The neighbour weights are formed as
+    // clamp(c1 -+ t0 2^-24) by ONE fp32 FMA: t0 2^-24 lies on the 2^-24 grid, so whatever c1 holds below that grid is rounded away in
+    // the result (exactly so for the weights in [0.5, 1), the ones that matter) — always the same way for an angle.  The float64
+    // instrument separates it (profiles/r06/c3_instrument.txt: the product's neighbour RULE with unrounded weights sits on the fp32-
+    // storage floor, the product 6-10 x above it).  So c1 is put ON the grid — the FMA is then exact, no rounding at all — and WHICH of
+    // its two grid neighbours an angle gets is chosen by error diffusion over the angles in order of their direction: neighbouring
+    // views back-project nearly the same field, so their biases (< 6e-8, alternating) cancel instead of adding up over 180 views.
+    // (The kernels take the addend per SIDE — c1m for the neighbour on the smaller-q side, c1p for the other — so that a split
+    //  {floor, ceil} with half the mean bias could be dealt as a third level.  Measured on C3, distance of iterates 5 / 6 / 7 / 8 from
+    //  the float64 oracle: fp32 c1 from the fp32 inv 6.4e-6 / 4.5e-5 / 3.6e-4 / 1.06e-3 (round 5), fp32 c1 from the float64 inv
+    //  7.9e-7 / 5.5e-6 / 3.3e-5 / 2.3e-4, on the grid with diffusion 3.2e-7 / 2.0e-6 / 1.2e-5 / 6.9e-5, with the split levels 3.8e-7 /
+    //  2.5e-6 / 1.5e-5 / 8.9e-5; the fp32-storage floor 1.2e-7 / 6.5e-7 / 3.9e-6 / 2.0e-5 — so both sides get the same value.)
+    std::vector<float> c1m_d(n_ang), c1p_d(n_ang);
+    for (int f = 0; f < nt; ++f) {
+      std::vector<int> order(na);
+      for (int a = 0; a < na; ++a) order[a] = a;
+      auto dir = [&](int a) { double t = std::fmod(angles[(size_t)f * na + a], M_PI); return t < 0 ? t + M_PI : t; };
+      std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return dir(x) < dir(y); });
+      double carry = 0.0;
+      for (int a : order) {
+        const double exact = (1.0 - std::fabs(href[(size_t)f * na + a].inv)) * one;       // in units of 2^-24 (<= 0)
+        const double lo = std::floor(exact), hi = std::ceil(exact);
+        const double pick = std::fabs(carry + (lo - exact)) <= std::fabs(carry + (hi - exact)) ? lo : hi;
+        carry += pick - exact;
+        c1m_d[(size_t)f * na + a] = c1p_d[(size_t)f * na + a] = (float)(pick / one);        // |pick| < 2^23: exact
+      }
+    }
     for (int f = 0; f < nt; ++f) {
       int pos = 0;
       for (int pass = 0; pass < 2; ++pass) {
         for (int a = 0; a < na; ++a) {
           const AngleParam& q = h[(size_t)f * na + a];
           if (q.mode != pass) continue;
-          aa[(size_t)f * na + pos] = AdjAngle{1.0f - fabsf(q.inv), q.rinv, q.dq, q.k0, a, q.inv < 0.f ? 1 : 0};
+          // c1 = 1 - |inv| from the float64 inv (round 6).  Formed from the fp32-rounded inv it was off by up to 7e-8 — the same
+          // amount for EVERY neighbour weight of the angle, while the forward's weights are exact: a systematic mismatch between A
+          // and A^T of the size the float64 instrument showed to cost C3's transient iterates 50 x (profiles/r06/c3_instrument.txt)
+          aa[(size_t)f * na + pos] = AdjAngle{c1m_d[(size_t)f * na + a], c1p_d[(size_t)f * na + a], q.rinv, q.dq, q.k0, a, q.inv < 0.f ? 1 : 0, 0};
           wg[(size_t)f * na + pos] = wadj[(size_t)f * na + a];
           const float wa = wadj[(size_t)f * na + a];
           const int wbits = __builtin_bit_cast(int, wa);
@@ -3153,7 +3234,7 @@ extern "C" int trk_radon2d_set_arithmetic(trk_op* op, int mode) {
 
 extern "C" int trk_radon2d_set_ref_sums(trk_op* op, int chunk_fwd, int chunk_adj) {
   TRK_REQUIRE(op && op->kind == 2 && op->apply == radon_apply, "trk_radon2d_set_ref_sums: not a parallel-beam handle");
-  TRK_REQUIRE(chunk_fwd >= 0 && chunk_adj >= 0, "trk_radon2d_set_ref_sums: chunks must be >= 0 (0 = float64 sums)");
+  TRK_REQUIRE(chunk_fwd >= 0 && chunk_adj >= -2, "trk_radon2d_set_ref_sums: chunk_fwd >= 0, chunk_adj >= 0 (0 = float64 sums) or -1 / -2 (the product's neighbour rule)");
   auto* im = static_cast<RadonImpl*>(op->impl);
   im->ref_chunk_fwd = chunk_fwd;
   im->ref_chunk_adj = chunk_adj;

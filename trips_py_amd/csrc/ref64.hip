@@ -111,6 +111,27 @@ __global__ __launch_bounds__(NT) void k_ref_radon_adj(const T* __restrict__ sino
     const double dstar = ((double)col - p.k0 - (double)tt * p.dq) / p.inv + sdh;
     const int d0 = (int)floor(dstar);
     double s = 0.0;
+    if (WEIGHTS == 1 && g.chunk_adj < 0) {
+      // the product's rule (k_radon_adj_tile): the nearest ray dn by its own table entry (exact t0), its two neighbours at t0 -+ |inv|
+      int dn = 0;
+      bool found = false;
+      long long tbest = 0;
+      for (int d = d0 - 1; d <= d0 + 2; ++d) {
+        if (d < -A32_PAD || d >= g.nd + A32_PAD) continue;
+        const unsigned Q = g.A32[(int64_t)a * (g.nd + 2 * A32_PAD) + d + A32_PAD] + g.B32[(int64_t)a * g.npad + tt] - ((unsigned)col << QF);
+        const long long t = (long long)(int)Q;
+        if (!found || llabs(t) < llabs(tbest)) { dn = d; tbest = t; found = true; }
+      }
+      if (!found) continue;
+      const double t0 = (double)tbest * (1.0 / 16777216.0);
+      const double c1 = g.chunk_adj == -2 ? (double)(float)(1.0 - fabs(p.inv)) : 1.0 - fabs(p.inv);
+      const int sg = p.inv < 0.0 ? -1 : 1;                           // the ray on the larger-q side is dn + sg
+      auto smp = [&](int d) -> double { return (d >= 0 && d < g.nd) ? (double)sino[(int64_t)a * g.nd + d] : 0.0; };
+      const double wm = fmin(fmax(c1 + t0, 0.0), 1.0), wp = fmin(fmax(c1 - t0, 0.0), 1.0);
+      s = (1.0 - fabs(t0)) * smp(dn) + wm * smp(dn - sg) + wp * smp(dn + sg);
+      acc += p.w * s;
+      continue;
+    }
     for (int d = d0 - 1; d <= d0 + 2; ++d) {
       if (d < 0 || d >= g.nd) continue;
       int c;

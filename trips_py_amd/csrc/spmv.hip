@@ -59,11 +59,19 @@ __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned*
   typedef typename ChainT<G>::type acc_t;
   __shared__ double red[NT / 64];
   const int g = threadIdx.x & (G - 1);
-  const int64_t grp0 = ((int64_t)blockIdx.x * NT + threadIdx.x) / G, ngrp = (int64_t)gridDim.x * (NT / G);
+  // Rows in CONTIGUOUS spans per workgroup, the spans dealt to the XCDs in contiguous eighths (round 6; workgroups b and b + 8 share an
+  // XCD under round-robin placement: speed only).  A block-diagonal matrix of frames (io.py:223-225) then has every XCD's L2 gather
+  // from its own frames' slice of x instead of all of x: the grid-stride form fetched 192.8 MB for 145.7 MB of algorithmic bytes on
+  // the 16-frame Joseph matrix (profiles/r05/traffic_spmv.txt), the gathers of x leaving L2 once per XCD and stride.
+  const int nb = gridDim.x;
+  const int bid = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+  constexpr int RPT = NT / G;                                        // rows per trip of a workgroup
+  const int64_t span = ((nrows + nb - 1) / nb + RPT - 1) / RPT * RPT;
+  const int64_t r_end = (bid + 1) * span < nrows ? (bid + 1) * span : nrows;
   double ss[KB];
 #pragma unroll
   for (int b = 0; b < KB; ++b) ss[b] = 0.0;
-  for (int64_t r = grp0; r < nrows; r += ngrp) {
+  for (int64_t r = bid * span + threadIdx.x / G; r < r_end; r += RPT) {
     const unsigned p0 = indptr[r], p1 = indptr[r + 1];
     acc_t a0[KB], a1[KB], a2[KB], a3[KB];
 #pragma unroll
