@@ -77,6 +77,30 @@ __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned*
 #pragma unroll
     for (int b = 0; b < KB; ++b) a0[b] = a1[b] = a2[b] = a3[b] = (acc_t)0;
     unsigned p = p0 + g;
+    // one right-hand side, long rows: EIGHT loads of each stream in flight per lane (round 6).  From HBM — the matrix of a real dynamic
+    // problem does not fit the memory-side cache — a trip is one memory round trip plus one gather round trip, and a row of 431 non-zeros
+    // over 16 lanes was seven dependent trips of four: 46 us cold against 33 us warm on the 16-frame Joseph matrix.  Same four chains,
+    // the second four products behind the first four.
+    if (KB == 1) {
+      for (; p + 7 * G < p1; p += 8 * G) {
+        float v[8], xv[8];
+        int c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ldm<NTL>(vals + p + u * G);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = ldm<NTL>(indices + p + u * G);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];
+        a0[0] = chain_fma(v[0], xv[0], a0[0]);
+        a1[0] = chain_fma(v[1], xv[1], a1[0]);
+        a2[0] = chain_fma(v[2], xv[2], a2[0]);
+        a3[0] = chain_fma(v[3], xv[3], a3[0]);
+        a0[0] = chain_fma(v[4], xv[4], a0[0]);
+        a1[0] = chain_fma(v[5], xv[5], a1[0]);
+        a2[0] = chain_fma(v[6], xv[6], a2[0]);
+        a3[0] = chain_fma(v[7], xv[7], a3[0]);
+      }
+    }
     // four loads of each stream in flight per lane, four independent chains per column (long rows: a wave streams 2 KB per trip)
     for (; p + 3 * G < p1; p += 4 * G) {
       const float v0 = ldm<NTL>(vals + p), v1 = ldm<NTL>(vals + p + G), v2 = ldm<NTL>(vals + p + 2 * G), v3 = ldm<NTL>(vals + p + 3 * G);
