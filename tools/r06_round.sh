@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round 6 GPU visit: ONE script, steps by name.  usage: tools/r06_round.sh <out-subdir> [steps...]
 # steps: test (whole -m gpu suite, bars logged) | tradon (projector tests) | radon (4096^2 / 2048^2 / 1024^2 / 512^2 projector rates) |
-#        pmc_radon (counters of the 4096^2 pair) | smoke | drv | bench | prof | c3 (C3 instrument) | py:<script> [runs tools/<script>] |
+#        pmc_radon (counters of the 4096^2 pair) | smoke | drv | bench | bench2/4/8 (ranks on one GPU over gloo) | prof | c3 (C3 instrument) | py:<script> [runs tools/<script>] |
 #        mb:<name> (builds + runs tools/microbench/<name>.hip) | traffic:<tag>,<script>[,args] | stats:<tag>,<script>[,args]
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$1; shift
@@ -37,6 +37,9 @@ prof)
   f=$(ls -t $O/prof_drv/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/bench_driver_flags_kernel_stats.csv
   head -c 1200 $O/prof_drv.json; echo
   head -8 $O/bench_driver_flags_kernel_stats.csv ;;
+bench2|bench4|bench8)
+  n=${s#bench}
+  TRK_DIST_BACKEND=gloo TRK_SINGLE_DEVICE=1 timeout 900 python -m torch.distributed.run --nnodes=1 --nproc-per-node $n --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus $n --steps 50 --no-cpu-baseline > $O/bench_${n}ranks_one_gpu_gloo.json 2> $O/bench$n.err; echo "bench$n rc=$?"; head -c 2500 $O/bench_${n}ranks_one_gpu_gloo.json; echo; tail -3 $O/bench$n.err ;;
 c3)
   timeout 1200 python3 tools/r05_c3_instrument.py 100 > $O/c3_instrument.txt 2> $O/c3_instrument.err; echo "instr rc=$?"; head -40 $O/c3_instrument.txt; tail -3 $O/c3_instrument.err ;;
 traffic:*)
