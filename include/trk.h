@@ -101,7 +101,9 @@ int trk_spacetime_set_halo(trk_op* op, const float* x_next_dev, const float* y_p
 /* General sparse operator from host CSR arrays of A (nrows x ncols) and of A^T (built by the caller, e.g. scipy's
  * `.T.tocsr()`); all six arrays are copied to the device.  Serves operators the reference holds as scipy.sparse matrices:
  * the derivative regularisers (operators.py:24-45), the framelet analysis operators (:50-113) and the precomputed
- * forward matrices of the real dynamic data sets sliced per frame (io.py:132-135,197-229). */
+ * forward matrices of the real dynamic data sets sliced per frame (io.py:132-135,197-229).  trk_op_apply with batch = k > 1 (`A @ V`
+ * on an (n, k) block: GKS.py:37, MMGKS.py:44) reads the matrix once per pass of 8 / 4 / 2 columns; every column equals its own
+ * single-vector apply to the bit. */
 int trk_csr_create(int64_t nrows, int64_t ncols, int64_t nnz, const int64_t* indptr_host, const int* indices_host,
                    const float* values_host, const int64_t* t_indptr_host, const int* t_indices_host,
                    const float* t_values_host, trk_op** out);

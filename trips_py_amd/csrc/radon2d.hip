@@ -2800,7 +2800,10 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
                                 ssq_part, epi, xT_out, 1, im->adj_part, im->adj_cnt);
       } else if (tile && tile_T == 32) {
         // (16 angles per batch — half the barriers, twice the rings — measured at 512^2 x 180: 34.7 us against 29.9; not instantiated)
-        if (adj_prep) ADJ_TILE(32, 4, 8, true); else ADJ_TILE(32, 4, 8, false);
+        // (TRK_RADON_ADJ_AB=16 — one batch for a 15-angle frame, half the barriers at 180 angles — measured again in round 6 on C5's
+        //  shape, 32 frames of 256^2 x 15 angles: see profiles/r06/adj_ab16.txt)
+        if (ab_env == 16) { if (adj_prep) ADJ_TILE(32, 4, 16, true); else ADJ_TILE(32, 4, 16, false); }
+        else if (adj_prep) ADJ_TILE(32, 4, 8, true); else ADJ_TILE(32, 4, 8, false);
       } else if (tile && (ab_env ? ab_env == 16 : na > 32)) {
         if (adj_prep) ADJ_TILE(16, 1, 16, true); else ADJ_TILE(16, 1, 16, false);
       } else if (tile) {   // few angles per frame (dynamic problems: 15): short batches, so that staging and gathering still overlap
