@@ -2804,7 +2804,9 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
         //  shape, 32 frames of 256^2 x 15 angles: see profiles/r06/adj_ab16.txt)
         if (ab_env == 16) { if (adj_prep) ADJ_TILE(32, 4, 16, true); else ADJ_TILE(32, 4, 16, false); }
         else if (adj_prep) ADJ_TILE(32, 4, 8, true); else ADJ_TILE(32, 4, 8, false);
-      } else if (tile && (ab_env ? ab_env == 16 : na > 32)) {
+      } else if (tile && (ab_env ? ab_env == 16 : (na > 32 || adj_blocks * nt <= 4 * (int64_t)cu_count()))) {
+        // (16 angles per batch also for the few frames of a dynamic problem one rank of eight holds — 4 frames of 256^2 x 15 angles, 1 024
+        //  workgroups: 10.2 -> 9.1 us per apply, profiles/r06/adj_ab16.txt; with more workgroups than that the shorter batches win)
         if (adj_prep) ADJ_TILE(16, 1, 16, true); else ADJ_TILE(16, 1, 16, false);
       } else if (tile) {   // few angles per frame (dynamic problems: 15): short batches, so that staging and gathering still overlap
         if (adj_prep) ADJ_TILE(16, 1, 4, true); else ADJ_TILE(16, 1, 4, false);
