@@ -305,7 +305,16 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise TrkError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
                        "There is no CPU fallback for the engine.")
-    lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_GLOBAL)
+    path = LIB_PATH
+    exp = os.environ.get("TRK_EXPERIMENT_LIB")
+    if exp:
+        # A/B measurements of kernel variants on ONE box (tools/r06_ab_libs.sh builds them with -DTRK_... switches): a library of the same
+        # ABI under another path.  Announced on stderr; never set by the product.
+        if not os.path.exists(exp):
+            raise TrkError(f"TRK_EXPERIMENT_LIB={exp}: no such file")
+        print(f"trips_py_amd: loading the EXPERIMENT library {exp} instead of {LIB_PATH}", file=sys.stderr)
+        path = exp
+    lib = ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError here = header / library mismatch: fail loudly
         fn.restype = res

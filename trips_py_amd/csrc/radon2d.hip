@@ -1319,6 +1319,11 @@ __global__ __launch_bounds__(256, 4) void k_radon_fwd_quadf(const float* __restr
 // as k_radon_fwd_lds sums them; the band partials go to the same array (64-row bands).  Grid: frames x {row bands, column bands} x
 // slices of that mode's angle list (adj_ang: the angles sorted by mode), about one workgroup per CU.
 constexpr int BR_ROWS = 64, BR_NW = 16, BR_NT = 64 * BR_NW, BR_PAD = 4, BR_NMAX = 1024;
+#ifdef TRK_FWD_EXPERIMENT_FLUSH16                      // (A/B build switch: rounds 2-5's fp32 sums of 16 rows)
+constexpr int BR_FLUSH_SHIFT = 4;
+#else
+constexpr int BR_FLUSH_SHIFT = 2;                      // fp32 sums of 4 rows, then float64
+#endif
 // rows per band: 64 where 64 x (N + 8) floats fit (N <= 512), else 32 (N <= 1024: 132 KB)
 inline int br_rows(int N) { return (size_t)BR_ROWS * (N + 2 * BR_PAD) * 4 <= 150 * 1024 ? BR_ROWS : BR_ROWS / 2; }
 __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __restrict__ img, const float* __restrict__ imgT,
@@ -1463,7 +1468,7 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
           t2[u] = (f2v){tp[0], tp[1]};
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc2[u >> 2] = __builtin_elementwise_fma(w[u], t2[u], acc2[u >> 2]);
+        for (int u = 0; u < 16; ++u) acc2[u >> BR_FLUSH_SHIFT] = __builtin_elementwise_fma(w[u], t2[u], acc2[u >> BR_FLUSH_SHIFT]);
       } else {
         // the window overhangs the image: columns clamped into the zero pads ([-2, N]: both taps of a clamped step read zeros)
         f2v w[16], t2[16];
@@ -1481,7 +1486,7 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
           t2[u] = (f2v){tp[0], tp[1]};
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) acc2[u >> 2] = __builtin_elementwise_fma(w[u], t2[u], acc2[u >> 2]);
+        for (int u = 0; u < 16; ++u) acc2[u >> BR_FLUSH_SHIFT] = __builtin_elementwise_fma(w[u], t2[u], acc2[u >> BR_FLUSH_SHIFT]);
       }
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) total += (double)(acc2[g4][0] + acc2[g4][1]);
@@ -1915,6 +1920,28 @@ __global__ __launch_bounds__(256 * G) void k_radon_adj_tile(const float* __restr
       }
       // (round 6) the NEXT angle's constants and {C, B32} pair are requested right behind this angle's record reads, so that one wait
       // covers both: angle by angle the loop had two exposed round trips (scalar + LDS for the pair, then LDS for the records)
+#ifdef TRK_ADJ_EXPERIMENT_NO_PIPELINE                 // (A/B build switch: rounds 2-5's loop, two waits per angle)
+#pragma unroll 2
+      for (; al < al_hi; ++al) {
+        const AdjAngle p = ang[a0 + al];
+        f2v cr = {p.c1m, p.c1p};
+        asm("" : "+s"(cr));
+        const uint2 cb = cbs[buf][al][cbrow];
+        const float C = __builtin_bit_cast(float, cb.x);
+        u4r rr[PX];
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+          const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[k], p.rinv, C) + RND_MAGIC);
+          rr[k] = ring_read(rbase0 + al * 1024, bits);
+        }
+        ring_wait();
+#pragma unroll
+        for (int k = 0; k < PX; ++k) {
+          ring_tie(rr[k]);
+          adj_gather(rr[k], cb.y, ncol[k], sc2, nsc, cr, an[k], ac[k]);
+        }
+      }
+#else
       if (al < al_hi) {
         float pn_c1 = ang[a0 + al].c1m, pn_c1p = ang[a0 + al].c1p, pn_rinv = ang[a0 + al].rinv;     // wave-uniform: scalar loads
         u2r cbn = pair_read(&cbs[buf][al][cbrow]);
@@ -1948,9 +1975,11 @@ __global__ __launch_bounds__(256 * G) void k_radon_adj_tile(const float* __restr
           }
         }
       }
+#endif
     };
     angles(0, nm0, fcolA, colA, r0, anA, accA);
     angles(nm0, nal, fcolB, colB, c1, anB, accB);
+#ifndef TRK_ADJ_EXPERIMENT_NO_F64_TOTALS             // (A/B build switch: tools/r06_ab_libs.sh)
     if (((b + 1) * AB) % ADJ_FLUSH == 0) {           // wave-uniform; only the batch where the modes change flushes both
       if (nm0 > 0) {
 #pragma unroll
@@ -1969,6 +1998,7 @@ __global__ __launch_bounds__(256 * G) void k_radon_adj_tile(const float* __restr
         }
       }
     }
+#endif
     if (b + 1 < nbatch) stage_store(b + 1);          // the other buffer: nobody reads it before the next barrier
   }
   // the two partial images meet: mode-0 sums go through LDS to the thread that holds the pixel in the mode-1 layout
