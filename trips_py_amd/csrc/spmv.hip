@@ -40,11 +40,15 @@ struct SpImpl {
 template <bool NTL> __device__ __forceinline__ float ldm(const float* p) { return NTL ? __builtin_nontemporal_load(p) : *p; }
 template <bool NTL> __device__ __forceinline__ int ldm(const int* p) { return NTL ? __builtin_nontemporal_load(p) : *p; }
 
-// Accumulator type of the per-lane chains: float64 for G == 2 (rows of 2 .. 9 non-zeros: first differences, framelets — at most two
-// products per chain, so float64 costs nothing measurable there and the framelet residuals stop carrying fp32 product roundings:
-// ADVICE round 5), fp32 for the long tomography rows (four chains per lane, float64 only across the group).
+// Accumulator type of the per-lane chains: fp32 (four chains per lane, float64 only across the group).  ADVICE r05 suggested float64 chains
+// for the 2-lane rows (first differences, framelets: at most two products per chain) as "almost free" — measured in round 6
+// (profiles/r06/spmv_ab.txt): first differences 2048^2 forward 48 -> 57 us, transpose 36 -> 45, space-time differences 20 -> 24, framelets
+// 129 -> 138, and the one deviation it was meant for (MMGKS with the framelet regulariser, `Residual` against the reference) 3.2e-4 -> 2.2e-4:
+// the deviation is not the SpMV's.  Not adopted; -DTRK_CSR_EXPERIMENT_F64_CHAINS builds it.
 template <int G> struct ChainT { typedef float type; };
+#ifdef TRK_CSR_EXPERIMENT_F64_CHAINS                // (A/B build switch; see the note above: measured, not adopted)
 template <> struct ChainT<2> { typedef double type; };
+#endif
 __device__ __forceinline__ float chain_fma(float v, float x, float a) { return fmaf(v, x, a); }
 __device__ __forceinline__ double chain_fma(float v, float x, double a) { return fma((double)v, (double)x, a); }
 
@@ -64,6 +68,10 @@ __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned*
   // from its own frames' slice of x instead of all of x: the grid-stride form fetched 192.8 MB for 145.7 MB of algorithmic bytes on
   // the 16-frame Joseph matrix (profiles/r05/traffic_spmv.txt), the gathers of x leaving L2 once per XCD and stride.
   const int nb = gridDim.x;
+  // ... for rows of more than two lanes.  Two-lane rows (2 .. 9 non-zeros: a workgroup's trip is 128 rows = 2 KB of each stream) keep the
+  // grid-stride map — trip t of the whole grid covers one contiguous run of rows: framelets 512^2 forward 110 us against 129 with spans,
+  // first differences the same either way (profiles/r06/spmv_ab.txt).
+  constexpr bool SPANS = G > 2;
   const int bid = (nb & 7) == 0 ? (int)(blockIdx.x & 7) * (nb >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
   constexpr int RPT = NT / G;                                        // rows per trip of a workgroup
   const int64_t span = ((nrows + nb - 1) / nb + RPT - 1) / RPT * RPT;
@@ -71,7 +79,9 @@ __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned*
   double ss[KB];
 #pragma unroll
   for (int b = 0; b < KB; ++b) ss[b] = 0.0;
-  for (int64_t r = bid * span + threadIdx.x / G; r < r_end; r += RPT) {
+  const int64_t r_first = SPANS ? bid * span + threadIdx.x / G : ((int64_t)blockIdx.x * NT + threadIdx.x) / G;
+  const int64_t r_stop = SPANS ? r_end : nrows, r_step = SPANS ? (int64_t)RPT : (int64_t)nb * RPT;
+  for (int64_t r = r_first; r < r_stop; r += r_step) {
     const unsigned p0 = indptr[r], p1 = indptr[r + 1];
     acc_t a0[KB], a1[KB], a2[KB], a3[KB];
 #pragma unroll
@@ -82,23 +92,43 @@ __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned*
     // over 16 lanes was seven dependent trips of four: 46 us cold against 33 us warm on the 16-frame Joseph matrix.  Same four chains,
     // the second four products behind the first four.
     if (KB == 1) {
-      for (; p + 7 * G < p1; p += 8 * G) {
-        float v[8], xv[8];
+      // software-pipelined: the NEXT trip's values and indices are requested behind this trip's gathers, so that a trip costs the longer
+      // of the two round trips (matrix from HBM, x from L2) instead of their sum
+      if (p + 7 * G < p1) {
+        float v[8];
         int c[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) v[u] = ldm<NTL>(vals + p + u * G);
 #pragma unroll
         for (int u = 0; u < 8; ++u) c[u] = ldm<NTL>(indices + p + u * G);
+        for (;;) {
+          float xv[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];
-        a0[0] = chain_fma(v[0], xv[0], a0[0]);
-        a1[0] = chain_fma(v[1], xv[1], a1[0]);
-        a2[0] = chain_fma(v[2], xv[2], a2[0]);
-        a3[0] = chain_fma(v[3], xv[3], a3[0]);
-        a0[0] = chain_fma(v[4], xv[4], a0[0]);
-        a1[0] = chain_fma(v[5], xv[5], a1[0]);
-        a2[0] = chain_fma(v[6], xv[6], a2[0]);
-        a3[0] = chain_fma(v[7], xv[7], a3[0]);
+          for (int u = 0; u < 8; ++u) xv[u] = x[c[u]];
+          const unsigned pn = p + 8 * G;
+          const bool more = pn + 7 * G < p1;                         // (per group; the loads below are predicated, not branched around)
+          float vn[8];
+          int cn[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) vn[u] = more ? ldm<NTL>(vals + pn + u * G) : 0.f;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) cn[u] = more ? ldm<NTL>(indices + pn + u * G) : 0;
+          a0[0] = chain_fma(v[0], xv[0], a0[0]);
+          a1[0] = chain_fma(v[1], xv[1], a1[0]);
+          a2[0] = chain_fma(v[2], xv[2], a2[0]);
+          a3[0] = chain_fma(v[3], xv[3], a3[0]);
+          a0[0] = chain_fma(v[4], xv[4], a0[0]);
+          a1[0] = chain_fma(v[5], xv[5], a1[0]);
+          a2[0] = chain_fma(v[6], xv[6], a2[0]);
+          a3[0] = chain_fma(v[7], xv[7], a3[0]);
+          p = pn;
+          if (!more) break;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            v[u] = vn[u];
+            c[u] = cn[u];
+          }
+        }
       }
     }
     // four loads of each stream in flight per lane, four independent chains per column (long rows: a wave streams 2 KB per trip)
