@@ -2233,7 +2233,7 @@ __global__ __launch_bounds__(256) void k_radon_adj_prepq(const float* __restrict
 }
 
 template <int QB>
-__global__ __launch_bounds__(256) void k_radon_adj_quad(const uint4* __restrict__ recq, float* __restrict__ img, int N, int nd, int nq,
+__global__ __launch_bounds__(256, 3) void k_radon_adj_quad(const uint4* __restrict__ recq, float* __restrict__ img, int N, int nd, int nq,
                                                         const AdjQuad* __restrict__ aq, const uint2* __restrict__ CBq, int npad,
                                                         int tiles_h, double* __restrict__ ssq_part, Epi epi,
                                                         float* __restrict__ xT_out) {
@@ -2343,64 +2343,80 @@ __global__ __launch_bounds__(256) void k_radon_adj_quad(const uint4* __restrict_
       if (b + 1 < nbatch) stage_load(b + 1);
       const int nql = (nq - b * QB < QB) ? nq - b * QB : QB;
       const unsigned rbase = __builtin_amdgcn_readfirstlane(lds_offset(&ring[buf][0][0][0]));
-      // the next quad's constants and {C, B32} pair travel behind this quad's record reads: one wait covers both
-      float pn_c1 = aq[b * QB].c1m, pn_c1p = aq[b * QB].c1p, pn_rinv = aq[b * QB].rinv;     // wave-uniform: scalar loads
-      u2r cbn = pair_read(&cbs[buf][0][ttl]);
+      // Software pipeline over the batch's 2 QB half-quads (round 6, second pass): the eight record reads of half-quad i + 1 are in
+      // flight while half-quad i is weighed — LDS returns in order, so "at most nine younger reads outstanding" means half-quad i has
+      // landed.  No scalar load may be outstanding inside (they return out of order: any wait would have to be lgkmcnt(0)), so the
+      // batch's constants are fetched up front; the {C, B32} pair of the next quad rides between the two halves' reads.
+      float q_c1m[QB], q_c1p[QB], q_rinv[QB];
+#pragma unroll
+      for (int ql = 0; ql < QB; ++ql) {
+        const int qi = b * QB + (ql < nql ? ql : 0);          // wave-uniform: scalar loads
+        q_c1m[ql] = aq[qi].c1m;
+        q_c1p[ql] = aq[qi].c1p;
+        q_rinv[ql] = aq[qi].rinv;
+      }
+      u2r cbq = pair_read(&cbs[buf][0][ttl]);
       ring_wait();
-      pair_tie(cbn);
-#pragma unroll 1
-      for (int ql = 0; ql < nql; ++ql) {
-        const float p_rinv = pn_rinv;
-        f2v cr = {pn_c1, pn_c1p};
-        asm("" : "+s"(cr));
-        const u2r cbv = cbn;                         // (a copy made AFTER the tie)
-        const float C = __builtin_bit_cast(float, (unsigned)cbv[0]);
-        const unsigned cb_y = cbv[1];
-        const int qln = ql + 1 < nql ? ql + 1 : ql;  // (the last quad re-reads itself: unconditional, no join)
+      pair_tie(cbq);
+      u4r ra[2][PX], rb[2][PX];
+      auto issue = [&](int ql, int h, float rinv_q, float C) {
+        const unsigned rb_h = rbase + (unsigned)(ql * 4 + 2 * h) * 1024u;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {                // the interpolated tile, then its mirror
-          u4r ra[PX], rb[PX];
-          const unsigned rb_h = rbase + (unsigned)(ql * 4 + 2 * h) * 1024u;
+        for (int k = 0; k < PX; ++k) {
+          const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[h][k], rinv_q, C) + RND_MAGIC);
+          unsigned addr;
+          const unsigned slot = bits & 63u;
+          asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(slot), "s"(rb_h));
+          asm volatile("ds_read_b128 %0, %1" : "=v"(ra[h][k]) : "v"(addr) : "memory");
+          asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(rb[h][k]) : "v"(addr) : "memory");
+        }
+      };
+      auto weigh = [&](int h, unsigned cb_y, f2v cr) {
 #pragma unroll
-          for (int k = 0; k < PX; ++k) {
-            const unsigned bits = __builtin_bit_cast(unsigned, fmaf(fcol[h][k], p_rinv, C) + RND_MAGIC);
-            unsigned addr;
-            const unsigned slot = bits & 63u;
-            asm("v_lshl_add_u32 %0, %1, 4, %2" : "=v"(addr) : "v"(slot), "s"(rb_h));
-            asm volatile("ds_read_b128 %0, %1" : "=v"(ra[k]) : "v"(addr) : "memory");
-            asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(rb[k]) : "v"(addr) : "memory");
-          }
-          if (h == 1) {                              // (compile-time: the h loop is unrolled)
-            pn_c1 = aq[b * QB + qln].c1m;
-            pn_c1p = aq[b * QB + qln].c1p;
-            pn_rinv = aq[b * QB + qln].rinv;
-            cbn = pair_read(&cbs[buf][qln][ttl]);
-          }
-          ring_wait();
-          pair_tie(cbn);
+        for (int k = 0; k < PX; ++k) {
+          ring_tie(ra[h][k]);
+          ring_tie(rb[h][k]);
+          // slot A's member sees the pixel of this geometry, slot B's its mirror: tile set h / 1 - h
+          const unsigned slo = ra[h][k][0], shi = ra[h][k][1], s0 = ra[h][k][2], a32 = ra[h][k][3];
+          const unsigned mlo = rb[h][k][0], mhi = rb[h][k][1], m0 = rb[h][k][2];
+          unsigned ti;
+          asm("v_add3_u32 %0, %1, %2, %3" : "=v"(ti) : "v"(a32), "v"(cb_y), "v"(ncol[h][k]));
+          const float tf = (float)(int)ti;
+          f2v t2;
+          t2[0] = tf;
+          f2v wn;
+          asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1] neg_hi:[0,1,0] clamp" : "=v"(wn) : "v"(t2), "v"(sc2), "s"(cr));
+          float w0;
+          asm("v_fma_f32 %0, |%1|, %2, 1.0" : "=v"(w0) : "v"(tf), "s"(nsc));
+          const f2v sn = {__builtin_bit_cast(float, slo), __builtin_bit_cast(float, shi)};
+          const f2v mn = {__builtin_bit_cast(float, mlo), __builtin_bit_cast(float, mhi)};
+          an[h][k] = __builtin_elementwise_fma(wn, sn, an[h][k]);
+          ac[h][k] = fmaf(w0, __builtin_bit_cast(float, s0), ac[h][k]);
+          an[1 - h][k] = __builtin_elementwise_fma(wn, mn, an[1 - h][k]);
+          ac[1 - h][k] = fmaf(w0, __builtin_bit_cast(float, m0), ac[1 - h][k]);
+        }
+      };
+      issue(0, 0, q_rinv[0], __builtin_bit_cast(float, (unsigned)cbq[0]));
 #pragma unroll
-          for (int k = 0; k < PX; ++k) {
-            ring_tie(ra[k]);
-            ring_tie(rb[k]);
-            // slot A's member sees the pixel of this geometry, slot B's its mirror: tile set h / 1 - h
-            const unsigned slo = ra[k][0], shi = ra[k][1], s0 = ra[k][2], a32 = ra[k][3];
-            const unsigned mlo = rb[k][0], mhi = rb[k][1], m0 = rb[k][2];
-            unsigned ti;
-            asm("v_add3_u32 %0, %1, %2, %3" : "=v"(ti) : "v"(a32), "v"(cb_y), "v"(ncol[h][k]));
-            const float tf = (float)(int)ti;
-            f2v t2;
-            t2[0] = tf;
-            f2v wn;
-            asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,0,1] neg_hi:[0,1,0] clamp" : "=v"(wn) : "v"(t2), "v"(sc2), "s"(cr));
-            float w0;
-            asm("v_fma_f32 %0, |%1|, %2, 1.0" : "=v"(w0) : "v"(tf), "s"(nsc));
-            const f2v sn = {__builtin_bit_cast(float, slo), __builtin_bit_cast(float, shi)};
-            const f2v mn = {__builtin_bit_cast(float, mlo), __builtin_bit_cast(float, mhi)};
-            an[h][k] = __builtin_elementwise_fma(wn, sn, an[h][k]);
-            ac[h][k] = fmaf(w0, __builtin_bit_cast(float, s0), ac[h][k]);
-            an[1 - h][k] = __builtin_elementwise_fma(wn, mn, an[1 - h][k]);
-            ac[1 - h][k] = fmaf(w0, __builtin_bit_cast(float, m0), ac[1 - h][k]);
+      for (int ql = 0; ql < QB; ++ql) {
+        if (ql < nql) {                                      // wave-uniform
+          const u2r cbv = cbq;                               // (a copy of a pair that has landed and been tied)
+          const float C = __builtin_bit_cast(float, (unsigned)cbv[0]);
+          const unsigned cb_y = cbv[1];
+          f2v cr = {q_c1m[ql], q_c1p[ql]};
+          asm("" : "+s"(cr));
+          issue(ql, 1, q_rinv[ql], C);                       // 8 more reads ...
+          const int qln = ql + 1 < QB ? ql + 1 : ql;         // (the last quad of a batch re-reads its own pair: unconditional, no join)
+          cbq = pair_read(&cbs[buf][qln][ttl]);              // ... and the next quad's pair behind them
+          asm volatile("s_waitcnt lgkmcnt(9)" ::: "memory");  // half 0 of this quad has landed
+          weigh(0, cb_y, cr);
+          ring_wait();                                       // half 1 and the pair have landed (they had half 0's arithmetic to do so)
+          pair_tie(cbq);
+          if (ql + 1 < QB) {                                 // (compile-time; the reads themselves are unconditional — a quad beyond the batch's
+            const bool more = ql + 1 < nql;                  //  last re-reads this one's rings: no join behind an asynchronous read)
+            issue(more ? ql + 1 : ql, 0, more ? q_rinv[ql + 1 < QB ? ql + 1 : ql] : q_rinv[ql], __builtin_bit_cast(float, (unsigned)cbq[0]));
           }
+          weigh(1, cb_y, cr);
         }
       }
     }
