@@ -256,8 +256,13 @@ int trk_gk_step(trk_op* op, int k, const float* u_k, const float* v_prev, float*
  * V[0..k) by two Gram-Schmidt sweeps in their Gram-matrix form (trk_gemv_t2 / trk_cgs_coeffs / trk_gemv_n), V[k] = the normalised
  * result.  V: rows of ld floats (row k is written), w: n floats of scratch, G: the basis' Gram matrix so far (ldg x ldg doubles, rows
  * 0..k-2 installed; row k-1 is installed here), W: 2k doubles of scratch, S: S[0] = h_{k+1,k}^2, S[1..1+k) = column k of H above it.
- * Optional: the same five calls in one. */
+ * Optional: the same five calls in one — same results bit for bit, in five kernels where the five calls launch seven (the two
+ * finalize launches are folded into their consumers; TRK_ARNOLDI_7=1 in the environment keeps the seven). */
 int trk_arnoldi_step(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S, trk_stream stream);
+/* The same step whose last kernel also posts S[offset .. offset + count) to host[offset ..] of `mb` (trk_mailbox_post's contract:
+ * trk_mailbox_wait(mb, slot) returns once they have arrived) — no launch for the post. */
+int trk_arnoldi_step_post(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
+                          trk_mailbox* mb, int slot, int offset, int count, trk_stream stream);
 /* trk_gk_step (optionally with the projection of trk_gk_step_proj: proj != NULL) that also carries a mailbox post — the copy of
  * `count` (<= 8) device doubles src_dev[0..count) to host[offset ..] of `mb`, optionally the sum of n_sum block partials to *sum_dev and
  * host[sum_offset], and the publication of `slot` (trk_mailbox_post / trk_mailbox_post_sum): on the projector the first workgroup of

@@ -2,7 +2,7 @@
 # Round 6 GPU visit: ONE script, steps by name.  usage: tools/r06_round.sh <out-subdir> [steps...]
 # steps: test (whole -m gpu suite, bars logged) | tradon (projector tests) | radon (4096^2 / 2048^2 / 1024^2 / 512^2 projector rates) |
 #        pmc_radon (counters of the 4096^2 pair) | smoke | drv | bench | bench2/4/8 (ranks on one GPU over gloo) | prof | c3 (C3 instrument) | py:<script> [runs tools/<script>] |
-#        mb:<name> (builds + runs tools/microbench/<name>.hip) | traffic:<tag>,<script>[,args] | stats:<tag>,<script>[,args]
+#        mb:<name> (builds + runs tools/microbench/<name>.hip) | traffic:<tag>,<script>[,args] | stats:<tag>,<script>[,args] | gaps:<tag>,<n>,<script>[,args]
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/$1; shift
 STEPS=${@:-test}
@@ -55,12 +55,17 @@ stats:*)
   n=${s#stats:}; tag=${n%%,*}; rest=${n#*,}; a=${rest//,/ }
   (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_$tag -- python3 $R/tools/$a > $O/prof_$tag.log 2>&1); echo "stats $tag rc=$?"
   f=$(ls -t $O/prof_$tag/*/*kernel_stats.csv 2>/dev/null | head -1); [ -n "$f" ] && cp $f $O/${tag}_kernel_stats.csv; head -12 $O/${tag}_kernel_stats.csv | cut -c1-160 ;;
+gaps:*)
+  # busy time / gaps of the last <n> launches of tools/<script> (rocprofv3 --kernel-trace + tools/trace_gaps.py): gaps:<tag>,<n>,<script>[,args]
+  n=${s#gaps:}; tag=${n%%,*}; rest=${n#*,}; cnt=${rest%%,*}; rest=${rest#*,}; a=${rest//,/ }
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d $O/gaps_$tag -- python3 $R/tools/$a > $O/gaps_$tag.log 2>&1); echo "gaps $tag rc=$?"
+  python3 $R/tools/trace_gaps.py $(ls -t $O/gaps_$tag/*/*kernel_trace.csv | head -1) $cnt > $O/gaps_$tag.txt 2>&1; cat $O/gaps_$tag.txt ;;
 py:*)
   n=${s#py:}; a=${n//,/ }; f=${a%% *}
   timeout 1500 python3 tools/$a > $O/${f%.py}.txt 2>&1; echo "$f rc=$?"; tail -40 $O/${f%.py}.txt ;;
 mb:*)
   n=${s#mb:}
-  hipcc -O3 --offload-arch=gfx950 -std=c++17 -o /tmp/$n tools/microbench/$n.hip > $O/$n.build.log 2>&1 && timeout 900 /tmp/$n > $O/$n.txt 2>&1; echo "$n rc=$?"; tail -60 $O/$n.txt ;;
+  hipcc -O3 --offload-arch=gfx950 -std=c++17 -Iinclude -Itrips_py_amd/csrc -o /tmp/$n tools/microbench/$n.hip > $O/$n.build.log 2>&1 && timeout 900 /tmp/$n > $O/$n.txt 2>&1; echo "$n rc=$?"; tail -60 $O/$n.txt ;;
 esac; done
 find $O -name "*kernel_trace.csv" -delete 2>/dev/null
 find $O -name "*.db" -delete 2>/dev/null

@@ -164,6 +164,8 @@ SIGNATURES = {
     "trk_isotv_weights": (c_int, [c_f32p, c_int, c_int, c_f32p, c_i64, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_tv_weights": (c_int, [c_op, c_f32p, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_arnoldi_step": (c_int, [c_op, c_f32p, c_i64, c_int, c_f32p, c_f64p, c_int, c_f64p, c_f64p, c_stream]),
+    "trk_arnoldi_step_post": (c_int, [c_op, c_f32p, c_i64, c_int, c_f32p, c_f64p, c_int, c_f64p, c_f64p, ctypes.c_void_p, c_int, c_int, c_int,
+                                     c_stream]),
     "trk_tv_grad": (c_int, [c_op, c_f32p, c_f32p, c_f32p, c_dbl, c_f32p, c_stream]),
     "trk_tv_halo": (c_int, [c_op, c_f32p, c_f32p]),
     "trk_tv_grad_dot": (c_int, [c_op, c_f32p, c_f32p, c_f32p, c_dbl, c_f32p, c_f32p, c_f64p, c_stream]),

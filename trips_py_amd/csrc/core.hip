@@ -60,6 +60,21 @@ int scratch_doubles(hipStream_t s, size_t count, double** out) {
   return TRK_OK;
 }
 
+static std::map<std::pair<int, hipStream_t>, unsigned*> g_tickets;
+int stream_ticket(hipStream_t s, unsigned** out) {
+  int dev = 0;
+  TRK_HIP(hipGetDevice(&dev));
+  std::lock_guard<std::mutex> lk(g_mu);
+  unsigned*& p = g_tickets[{dev, s}];
+  if (!p) {
+    TRK_HIP(hipMalloc(&p, 256));
+    TRK_HIP(hipMemset(p, 0, 256));
+    TRK_HIP(hipStreamSynchronize(nullptr));  // zero before anything that takes tickets can be enqueued (once per stream)
+  }
+  *out = p;
+  return TRK_OK;
+}
+
 // ---------------------------------------------------------------- finalize: fixed-order sum of block partials
 // One workgroup per output.  Four independent accumulators keep four loads in flight per thread; the association of
 // the sum is a fixed function of (nblocks, thread id), hence bitwise reproducible run to run.
@@ -67,17 +82,7 @@ __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ par
                                                   double* __restrict__ out) {
   __shared__ double lds[4];
   const int o = blockIdx.x;
-  const double* __restrict__ p = partials + o;
-  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
-  int b = threadIdx.x;
-  for (; b + 768 < nblocks; b += 1024) {
-    v0 += p[(size_t)b * stride];
-    v1 += p[(size_t)(b + 256) * stride];
-    v2 += p[(size_t)(b + 512) * stride];
-    v3 += p[(size_t)(b + 768) * stride];
-  }
-  for (; b < nblocks; b += 256) v0 += p[(size_t)b * stride];
-  double v = block_sum<256>((v0 + v1) + (v2 + v3), lds);
+  const double v = finalize_block_256(partials + o, nblocks, stride, lds);
   if (threadIdx.x == 0) out[o] = v;
 }
 
@@ -503,17 +508,59 @@ int trk_gk_step(trk_op* op, int k, const float* u_k, const float* v_prev, float*
 // w = A V[k-1]; the two Gram-Schmidt sweeps against V[0..k) by Gram matrix (one pair of passes over the basis: trk_gemv_t2 with the
 // newest vector's Gram row riding along, trk_cgs_coeffs, trk_gemv_n with the fused ||.||^2); V[k] = the result, normalised.
 // The five library calls the Python step made, enqueued by one: on the 512^2 blur the host was the bound (65 % device-busy).
-int trk_arnoldi_step(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S, trk_stream stream) {
-  TRK_REQUIRE(op && V && w && G && W && S && k >= 1 && ldg >= k, "trk_arnoldi_step: bad argument");
-  TRK_REQUIRE(op->rows == op->cols && ld >= op->rows, "trk_arnoldi_step: square operator, ld >= n");
+// Five kernels (round 6; seven before): the finalize launches of the two reductions are gone — the 2k sums of the sweep are added up
+// by the workgroups of the launch whose last arriver runs the k x k recurrence (k_finalize_cgs), the norm by every workgroup of the
+// normalising pass (k_scale_fin); both in k_finalize's own association: the bits of the seven-kernel form (TRK_ARNOLDI_7=1 keeps it).
+static int arnoldi_step_impl(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
+                             const PostReq& post, hipStream_t s) {
   const int64_t n = op->rows;
   const float* vk1 = V + (int64_t)(k - 1) * ld;
   float* vk = V + (int64_t)k * ld;
-  if (int rc = trk_op_apply(op, 0, vk1, n, w, n, 1, nullptr, stream)) return rc;
-  if (int rc = trk_gemv_t2(V, ld, k, n, w, vk1, W, stream)) return rc;                   // h = V^T w | Gram row of V[k-1]
-  if (int rc = trk_cgs_coeffs(G, ldg, W, W + k, k, 2, S + 1, stream)) return rc;         // column k of H (without its last entry) at S[1..1+k)
-  if (int rc = trk_gemv_n(V, ld, k, n, S + 1, 1.0, w, -1.0, vk, S, stream)) return rc;   // V[k] = w - V c, S[0] = ||.||^2
-  return trk_axpby(n, 1.0, nullptr, S, TRK_SQRT_DEN, vk, 0.0, nullptr, nullptr, 0, nullptr, vk, nullptr, stream);
+  static const bool seven = getenv("TRK_ARNOLDI_7") && atoi(getenv("TRK_ARNOLDI_7"));
+  if (int rc = trk_op_apply(op, 0, vk1, n, w, n, 1, nullptr, s)) return rc;
+  if (seven) {
+    if (int rc = trk_gemv_t2(V, ld, k, n, w, vk1, W, s)) return rc;                   // h = V^T w | Gram row of V[k-1]
+    if (int rc = trk_cgs_coeffs(G, ldg, W, W + k, k, 2, S + 1, s)) return rc;         // column k of H (without its last entry) at S[1..1+k)
+    if (int rc = trk_gemv_n(V, ld, k, n, S + 1, 1.0, w, -1.0, vk, S, s)) return rc;   // V[k] = w - V c, S[0] = ||.||^2
+    if (int rc = trk_axpby(n, 1.0, nullptr, S, TRK_SQRT_DEN, vk, 0.0, nullptr, nullptr, 0, nullptr, vk, nullptr, s)) return rc;
+    if (post.on) {
+      hipLaunchKernelGGL(k_mailbox_post, dim3(1), dim3(64), 0, s, post.src, post.dst, post.count, post.seq, post.value);
+      TRK_LAUNCH_CHECK();
+    }
+    return TRK_OK;
+  }
+  double* part = nullptr;
+  int nblk = 0;
+  if (int rc = gemv_t2_partials(V, ld, k, n, w, vk1, &part, &nblk, s)) return rc;
+  if (int rc = finalize_cgs(part, nblk, k, W, G, ldg, 2, S + 1, s)) return rc;
+  if (int rc = gemv_n_partials(V, ld, k, n, S + 1, 1.0, w, -1.0, vk, &part, &nblk, s)) return rc;
+  return scale_by_partials(n, part, nblk, vk, vk, S, post, s);
+}
+
+int trk_arnoldi_step(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S, trk_stream stream) {
+  TRK_REQUIRE(op && V && w && G && W && S && k >= 1 && ldg >= k, "trk_arnoldi_step: bad argument");
+  TRK_REQUIRE(op->rows == op->cols && ld >= op->rows, "trk_arnoldi_step: square operator, ld >= n");
+  return arnoldi_step_impl(op, V, ld, k, w, G, ldg, W, S, PostReq{}, (hipStream_t)stream);
+}
+
+// the same step with the mailbox post of its scalars S[offset .. offset + count) riding on its last kernel (trk_mailbox_post's
+// contract for `slot`: trk_mailbox_wait(mb, slot) returns when they have arrived)
+int trk_arnoldi_step_post(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
+                          trk_mailbox* mb, int slot, int offset, int count, trk_stream stream) {
+  TRK_REQUIRE(op && V && w && G && W && S && k >= 1 && ldg >= k, "trk_arnoldi_step_post: bad argument");
+  TRK_REQUIRE(op->rows == op->cols && ld >= op->rows, "trk_arnoldi_step_post: square operator, ld >= n");
+  TRK_REQUIRE(mb && slot >= 0 && slot < mb->slots, "trk_arnoldi_step_post: bad mailbox / slot");
+  TRK_REQUIRE(offset >= 0 && count > 0 && offset + count <= mb->n, "trk_arnoldi_step_post: range outside the mailbox");
+  mb->expect[slot] = ++mb->counter;
+  mb->stream[slot] = (hipStream_t)stream;
+  PostReq q;
+  q.on = 1;
+  q.src = S + offset;
+  q.dst = mb->host + offset;
+  q.count = count;
+  q.seq = mb->seq + slot;
+  q.value = mb->expect[slot];
+  return arnoldi_step_impl(op, V, ld, k, w, G, ldg, W, S, q, (hipStream_t)stream);
 }
 
 int trk_gk_step_proj(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,

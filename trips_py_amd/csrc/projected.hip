@@ -393,6 +393,67 @@ __global__ __launch_bounds__(256) void k_cgs_coeffs(double* __restrict__ G, int 
     for (int j = threadIdx.x; j < k; j += blockDim.x) c[j] = cs[j];
 }
 
+// k_finalize over the 2k sums of a trk_gemv_t2 sweep (h = V^T r | the Gram row of the newest vector) and k_cgs_coeffs in ONE launch:
+// workgroup o adds up output o exactly as k_finalize does (finalize_block_256: the same bits) and stores it write-through; the
+// workgroup that draws the last ticket then runs the k x k recurrence on the finished sums, which it loads past its L1 / the other
+// XCDs' stale L2 lines (sc1) — the hand-off of k_radon_adj_tile's split tiles.  An Arnoldi / GKS step is a chain of dependent
+// launches of ~4.5 us each whatever they compute: this takes one out (Hybrid-GMRES on the 512^2 blur: 9 launches per iteration).
+__global__ __launch_bounds__(256) void k_finalize_cgs(const double* __restrict__ partials, int nblocks, double* W, unsigned* cnt,
+                                                      double* __restrict__ G, int ldg, int k, int passes, double* __restrict__ c) {
+  extern __shared__ double sh[];           // c (k) | t (k) | h (k) | g_new (k)
+  __shared__ double lds[4];
+  __shared__ unsigned ticket;
+  const int nout = 2 * k;
+  const int o = blockIdx.x;
+  const double v = finalize_block_256(partials + o, nblocks, nout, lds);
+  if (threadIdx.x == 0) {
+    asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(W + o), "v"(v) : "memory");
+    ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (ticket != (unsigned)(nout - 1)) return;
+  if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
+  double* cs = sh;
+  double* ts = sh + k;
+  double* hs = sh + 2 * k;
+  double* gs = sh + 3 * k;
+  for (int j = threadIdx.x; j < nout; j += blockDim.x) {
+    double t;
+    asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(t) : "v"(W + j) : "memory");
+    hs[j] = t;                             // (hs and gs are adjacent: W = h | g_new)
+  }
+  __syncthreads();
+  // from here on: k_cgs_coeffs with h and g_new in LDS
+  for (int j = threadIdx.x; j < k; j += blockDim.x) {
+    G[(size_t)(k - 1) * ldg + j] = gs[j];
+    G[(size_t)j * ldg + (k - 1)] = gs[j];
+  }
+  __threadfence_block();
+  for (int j = threadIdx.x; j < k; j += blockDim.x) cs[j] = 0.0;
+  __syncthreads();
+  __syncthreads();
+  for (int p = 0; p < passes; ++p) {
+    if (p == 0) {
+      for (int j = threadIdx.x; j < k; j += blockDim.x) ts[j] = hs[j];
+    } else {
+      symv4(G, ldg, k, cs, [&](int i, double a) { ts[i] = hs[i] - a; });
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += blockDim.x) cs[j] += ts[j];
+    __syncthreads();
+  }
+  for (int j = threadIdx.x; j < k; j += blockDim.x) c[j] = cs[j];
+}
+
+int trk::finalize_cgs(const double* part, int nblk, int k, double* W, double* G, int ldg, int passes, double* c, hipStream_t s) {
+  TRK_REQUIRE(part && W && G && c && k >= 1 && k <= 1024 && ldg >= k && passes >= 1 && nblk >= 1, "finalize_cgs: bad argument");
+  unsigned* cnt = nullptr;
+  if (int rc = stream_ticket(s, &cnt)) return rc;
+  hipLaunchKernelGGL(k_finalize_cgs, dim3(2 * k), dim3(256), 4 * (size_t)k * sizeof(double), s, part, nblk, W, cnt, G, ldg, k, passes, c);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
 extern "C" int trk_cgs_coeffs(double* G, int ldg, const double* h, const double* g_new, int k, int passes, double* c,
                               trk_stream st) {
   TRK_REQUIRE(G && k >= 1 && ldg >= k && passes >= 0 && (passes == 0 || (h && c)), "trk_cgs_coeffs: bad argument");

@@ -36,6 +36,10 @@ int finalize_sums(const double* partials, int nblocks, int stride, int nout, dou
 int finalize_sums_split(const double* partials, int nblocks, int stride, int nout, double* out_dev, int nsplit, double* out2_dev,
                         hipStream_t s);
 
+// a zeroed word per (device, stream) for kernels whose LAST workgroup carries a once-per-launch duty (it takes tickets with
+// agent-scope atomic adds and puts the word back to zero): launches on one stream run in order, so one word per stream is enough
+int stream_ticket(hipStream_t s, unsigned** out);
+
 // device facts (cached)
 int cu_count();
 
@@ -61,11 +65,64 @@ __device__ __forceinline__ double coef_eval(const Coef& k) {
 }
 
 // ------------------------------------------------------------------ wave64 / block reductions (fp64)
-__device__ __forceinline__ double wave_sum(double v) {
+__device__ __forceinline__ double wave_sum_trees(double v) {      // (the reference form: six ds_bpermute pairs through the LDS crossbar)
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
   return v;  // lane 0 holds the wave total
 }
+
+// ---- cross-lane moves on the vector unit (gfx950: v_permlane32_swap / v_permlane16_swap; DPP within a row of 16 lanes)
+__device__ __forceinline__ void swap_halves32(double& a, double& b) {      // a's lanes 32-63 <-> b's lanes 0-31
+  unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+  unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+  auto r = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+  alo = r[0]; blo = r[1];
+  r = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+  ahi = r[0]; bhi = r[1];
+  a = __hiloint2double((int)ahi, (int)alo);
+  b = __hiloint2double((int)bhi, (int)blo);
+}
+__device__ __forceinline__ void swap_rows16(double& a, double& b) {        // a's odd rows of 16 lanes <-> b's even rows
+  unsigned alo = (unsigned)__double2loint(a), ahi = (unsigned)__double2hiint(a);
+  unsigned blo = (unsigned)__double2loint(b), bhi = (unsigned)__double2hiint(b);
+  auto r = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+  alo = r[0]; blo = r[1];
+  r = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+  ahi = r[0]; bhi = r[1];
+  a = __hiloint2double((int)ahi, (int)alo);
+  b = __hiloint2double((int)bhi, (int)blo);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xF, 0xF, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xF, 0xF, true);
+  return __hiloint2double(hi, lo);
+}
+// the value of lane ^ OFF (OFF = 8, 4, 2, 1): row_ror:8 | row_half_mirror then the quads reversed | quad_perm [2,3,0,1] | [1,0,3,2]
+template <int OFF>
+__device__ __forceinline__ double lane_xor_f64(double v) {
+  static_assert(OFF == 8 || OFF == 4 || OFF == 2 || OFF == 1, "within a row of 16 lanes");
+  if (OFF == 8) return dpp_f64<0x128>(v);
+  if (OFF == 4) return dpp_f64<0x1B>(dpp_f64<0x141>(v));
+  if (OFF == 2) return dpp_f64<0x4E>(v);
+  return dpp_f64<0xB1>(v);
+}
+// wave_sum_trees' tree (lane l with l + 32, the results with l + 16, ...) on the vector unit: two half / row swaps, then DPP; the same
+// pairs in the same order, the same bits in lane 0 — the only lane either form promises.
+__device__ __forceinline__ double wave_sum(double v) {
+  double t = v, u = v;
+  swap_halves32(t, u);            // u's lanes 0-31 <- v's lanes 32-63
+  v = v + u;
+  t = v; u = v;
+  swap_rows16(t, u);              // u's even rows <- v's odd rows
+  v = v + u;
+  v = v + lane_xor_f64<8>(v);
+  v = v + lane_xor_f64<4>(v);
+  v = v + lane_xor_f64<2>(v);
+  v = v + lane_xor_f64<1>(v);
+  return v;  // lane 0 holds the wave total
+}
+
 
 // MM weight w = (v^2 + eps^2)^(e), e = p/2 - 1 (trips/solvers/MMGKS.py:57,93).  e == -0.5 (q = 1, the TV case) is an
 // rsqrt; e == 0 is 1.
@@ -96,22 +153,90 @@ __device__ __forceinline__ double block_sum(double v, double* lds) {
   return t;
 }
 
+// k_finalize's sum of output `o` (core.hip) by a workgroup of 256 threads: thread t adds the partials of blocks t, t + 256, ... on four
+// accumulators, then block_sum.  One definition for the finalize kernel and for every consumer kernel that adds the partials up itself
+// instead of waiting for a finalize launch (k_finalize_cgs, k_scale_fin): the same association, the same bits.  Valid in thread 0.
+__device__ __forceinline__ double finalize_block_256(const double* __restrict__ p, int nblocks, int stride, double* lds) {
+  double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;
+  int b = threadIdx.x;
+  for (; b + 768 < nblocks; b += 1024) {
+    v0 += p[(size_t)b * stride];
+    v1 += p[(size_t)(b + 256) * stride];
+    v2 += p[(size_t)(b + 512) * stride];
+    v3 += p[(size_t)(b + 768) * stride];
+  }
+  for (; b < nblocks; b += 256) v0 += p[(size_t)b * stride];
+  return block_sum<256>((v0 + v1) + (v2 + v3), lds);
+}
+
 // NV block sums with two barriers instead of 2 NV: every value is reduced within its wave, lane 0 of each wave parks its NV
 // sums in LDS, and thread i < NV adds the NT/64 wave sums of value i — in wave order, the order of block_sum, so the bits are
 // the same.  `lds` holds (NT/64) * NV doubles.  The result of value i is valid in thread i.
 template <int NT, int NV>
-__device__ __forceinline__ double block_sum_many(const double (&v)[NV], double* lds) {
+__device__ __forceinline__ double block_sum_many_trees(const double (&v)[NV], double* lds) {
   constexpr int NW = NT / 64;
   static_assert(NV <= NT, "one thread per value");
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   double w[NV];
 #pragma unroll
-  for (int i = 0; i < NV; ++i) w[i] = wave_sum(v[i]);
+  for (int i = 0; i < NV; ++i) w[i] = wave_sum_trees(v[i]);
   __syncthreads();  // protect lds reuse between consecutive calls
   if (lane == 0) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) lds[wid * NV + i] = w[i];
   }
+  __syncthreads();
+  double t = 0.0;
+  if (threadIdx.x < NV) {
+#pragma unroll
+    for (int q = 0; q < NW; ++q) t += lds[q * NV + threadIdx.x];
+  }
+  return t;
+}
+
+// block_sum_many without the LDS crossbar: the NV wave sums by a TRANSPOSING butterfly.  wave_sum's tree pairs lane l with l + 32, the
+// results with l + 16, ... ; here the lanes of a pair split the values between them at every level — the lower one keeps the first half
+// and receives the partner's first half, the upper one the second — so a level moves half as many values as the one before: NV - 1
+// + log2(64 / NV) exchanged doubles per wave instead of 6 NV, through v_permlane32_swap / v_permlane16_swap (gfx950) and DPP row /
+// quad permutations, no ds_bpermute (k_gemv_t2 on a 512^2 basis is ONE float4 per thread and row, then 16 sums per wave: 192
+// ds_bpermute per wave, a CU's 16 waves queueing on one LDS crossbar).  Same pairs in the same order as wave_sum, and a + b = b + a
+// exactly: the same bits as block_sum_many_trees (tools/microbench/wave_sum_many.hip: bit-identical, 9 x faster at 8, 16 and 32
+// values with a CU full of reducing workgroups).  Any NV <= 32 (padded with zeros to 8, 16 or 32 — values of their own, added to
+// nothing); the result of value i is valid in thread i.
+template <int NV, int N, int OFF>
+__device__ __forceinline__ void butterfly_level(double (&v)[NV], int lane) {
+  if constexpr (N >= 2) {
+#pragma unroll
+    for (int i = 0; i < N / 2; ++i) {
+      if constexpr (OFF == 32) {
+        swap_halves32(v[i], v[i + N / 2]);
+        v[i] = v[i] + v[i + N / 2];
+      } else if constexpr (OFF == 16) {
+        swap_rows16(v[i], v[i + N / 2]);
+        v[i] = v[i] + v[i + N / 2];
+      } else {
+        const bool up = (lane & OFF) != 0;
+        const double keep = up ? v[i + N / 2] : v[i], give = up ? v[i] : v[i + N / 2];
+        v[i] = keep + lane_xor_f64<OFF>(give);
+      }
+    }
+  } else {
+    v[0] = v[0] + lane_xor_f64<OFF>(v[0]);
+  }
+  if constexpr (OFF > 1) butterfly_level<NV, (N >= 2 ? N / 2 : 1), OFF / 2>(v, lane);
+}
+template <int NT, int NV>
+__device__ __forceinline__ double block_sum_many(const double (&vin)[NV], double* lds) {
+  static_assert(NV >= 1 && NV <= 32 && NV <= NT, "at most 32 values, one thread per value");
+  constexpr int P = NV <= 8 ? 8 : (NV <= 16 ? 16 : 32);
+  constexpr int NW = NT / 64, LPV = 64 / P;                      // lanes that end up with the same value
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  double v[P];
+#pragma unroll
+  for (int i = 0; i < P; ++i) v[i] = i < NV ? vin[i < NV ? i : 0] : 0.0;
+  butterfly_level<P, P, 32>(v, lane);                            // v[0]: the wave sum of value lane / LPV
+  __syncthreads();  // protect lds reuse between consecutive calls
+  if ((lane & (LPV - 1)) == 0 && lane / LPV < NV) lds[wid * NV + lane / LPV] = v[0];
   __syncthreads();
   double t = 0.0;
   if (threadIdx.x < NV) {
@@ -228,6 +353,7 @@ struct TimerScope {
 }  // namespace trk
 
 struct trk_op;
+struct PostReq;
 namespace trk {
 // ---- the float64 instrument (ref64.hip) ----
 // radon2d.hip: one angle of a parallel-beam handle in float64 (q(d, tt) = (d - (nd-1)/2) inv + k0 + tt dq, weight w = scale / |cos|
@@ -252,6 +378,16 @@ int ref_axpby_f32(int64_t n, Coef a, const float* x, Coef b, const float* z, flo
 int lsqr_damped_update_any(size_t elem_bytes, const void* vk, void* w, const void* x_in, void* x_out, int64_t n, const double* alpha_sq,
                            const double* beta_next_sq, const double* beta0_sq, double damp, const double* state_in, double* state_out,
                            int first, hipStream_t s);
+// vecops.hip: trk_gemv_t2 / trk_gemv_n without their finalize launch (the block partials stay in the stream's scratch: *part, *nblk),
+// and the normalisation x / sqrt(sum of partials) that adds them up itself (k_finalize's order) and leaves the sum in *sum_out;
+// post.on: workgroup 0 also carries a mailbox post (as the Golub-Kahan adjoint half step does)
+int gemv_t2_partials(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* r2, double** part, int* nblk, hipStream_t s);
+int gemv_n_partials(const float* V, int64_t ld, int k, int64_t n, const double* y, double a, const float* base, double sc, float* out,
+                    double** part, int* nblk, hipStream_t s);
+int scale_by_partials(int64_t n, const double* part, int nblk, const float* x, float* out, double* sum_out, const PostReq& post,
+                      hipStream_t s);
+// projected.hip: finalize of the 2k sums of gemv_t2_partials and trk_cgs_coeffs(G, ldg, W, W + k, k, passes, c) in one launch
+int finalize_cgs(const double* part, int nblk, int k, double* W, double* G, int ldg, int passes, double* c, hipStream_t s);
 // blur2d.hip: sizes and device pointers to the separable weights [kw row weights | kh column weights] of a blur handle
 bool blur_separable_params(trk_op* op, int* nx, int* ny, int* kh, int* kw, const float** sep_fwd, const float** sep_adj);
 }  // namespace trk

@@ -36,7 +36,12 @@ inline int tiled_dot_grid_x(int64_t n, int ntile, int blocks_per_cu) {
   static const int env = env_int("TRK_GEMVT_PER_CU", 0);
   const int64_t total = (int64_t)cu_count() * (env > 0 ? env : blocks_per_cu);
   int64_t bx = total / ntile;
-  const int64_t want = (n + (int64_t)NT * 4 - 1) / ((int64_t)NT * 4);
+  // float4s of a row per thread at least: two on short vectors (512^2: one float4 per thread and row left a workgroup little but its
+  // reduction to do; Hybrid-GMRES 17.0 -> 17.4 k iterations/s, four: 17.0), TRK_GEMVT_F4 overrides
+  static const int env_f4 = env_int("TRK_GEMVT_F4", 0);
+  const int per_thread = env_f4 > 0 ? env_f4 : (n <= ((int64_t)1 << 20) ? 2 : 1);
+  const int64_t chunk = (int64_t)NT * 4 * per_thread;
+  const int64_t want = (n + chunk - 1) / chunk;
   if (bx > want) bx = want;
   if (bx > kMaxPartialBlocks) bx = kMaxPartialBlocks;
   return bx < 1 ? 1 : (int)bx;
@@ -2515,9 +2520,18 @@ int trk_gemv_t_x(const float* V, int64_t ld, int k, int64_t n, const float* r, c
 }
 
 int trk_gemv_t2(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* r2, double* h2k, trk_stream st) {
-  TRK_REQUIRE(V && r && r2 && h2k, "trk_gemv_t2: NULL argument");
+  TRK_REQUIRE(h2k, "trk_gemv_t2: NULL argument");
+  double* part = nullptr;
+  int bx = 0;
+  if (int rc = gemv_t2_partials(V, ld, k, n, r, r2, &part, &bx, (hipStream_t)st)) return rc;
+  return finalize_sums(part, bx, 2 * k, 2 * k, h2k, (hipStream_t)st);
+}
+
+}  // extern "C"
+int trk::gemv_t2_partials(const float* V, int64_t ld, int k, int64_t n, const float* r, const float* r2, double** part_out, int* nblk,
+                          hipStream_t s) {
+  TRK_REQUIRE(V && r && r2, "trk_gemv_t2: NULL argument");
   TRK_REQUIRE(k >= 1 && n >= 0 && ld >= n, "trk_gemv_t2: need k >= 1, n >= 0, ld >= n");
-  hipStream_t s = (hipStream_t)st;
   const int ntile = ceil_div(k, JT);
   static const int occ = resident_blocks_per_cu(k_gemv_t2<true>);
   const int bx = tiled_dot_grid_x(n, ntile, occ);
@@ -2528,8 +2542,11 @@ int trk_gemv_t2(const float* V, int64_t ld, int k, int64_t n, const float* r, co
   if (vec) hipLaunchKernelGGL((k_gemv_t2<true>), grid, dim3(NT), 0, s, V, ld, k, n, r, r2, part, stream_nontemporal(n));
   else hipLaunchKernelGGL((k_gemv_t2<false>), grid, dim3(NT), 0, s, V, ld, k, n, r, r2, part, stream_nontemporal(n));
   TRK_LAUNCH_CHECK();
-  return finalize_sums(part, bx, 2 * k, 2 * k, h2k, s);
+  *part_out = part;
+  *nblk = bx;
+  return TRK_OK;
 }
+extern "C" {
 
 int trk_gemv_tn(const float* V, int64_t ld, int k, int64_t n, const float* const* rhs, int n_rhs, double* out, trk_stream st) {
   TRK_REQUIRE(V && rhs && out, "trk_gemv_tn: NULL argument");
@@ -2560,9 +2577,19 @@ int trk_gemv_tn(const float* V, int64_t ld, int k, int64_t n, const float* const
 
 int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, double a, const float* base, double sc,
                float* out, double* sumsq, trk_stream st) {
+  double* part = nullptr;
+  int nblk = 0;
+  if (int rc = gemv_n_partials(V, ld, k, n, y, a, base, sc, out, sumsq ? &part : nullptr, &nblk, (hipStream_t)st)) return rc;
+  if (sumsq) return finalize_sums(part, nblk, 1, 1, sumsq, (hipStream_t)st);
+  return TRK_OK;
+}
+
+}  // extern "C"
+int trk::gemv_n_partials(const float* V, int64_t ld, int k, int64_t n, const double* y, double a, const float* base, double sc,
+                         float* out, double** part_out, int* nblk, hipStream_t s) {
   TRK_REQUIRE(V && y && out, "trk_gemv_n: NULL argument");
   TRK_REQUIRE(k >= 1 && k <= KMAX_LDS && n >= 0 && ld >= n, "trk_gemv_n: need 1 <= k <= %d, n >= 0, ld >= n", KMAX_LDS);
-  hipStream_t s = (hipStream_t)st;
+  const bool sumsq = part_out != nullptr;
   const int grid = stream_grid(n);
   double* part = nullptr;
   const bool vec = aligned16(V) && aligned16(out) && (ld % 4 == 0) && (!base || aligned16(base));
@@ -2586,9 +2613,63 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y, do
   }
 #undef GN
   TRK_LAUNCH_CHECK();
-  if (sumsq) return finalize_sums(part, grid_n, 1, 1, sumsq, s);
+  if (sumsq) *part_out = part;
+  *nblk = grid_n;
   return TRK_OK;
 }
+
+// out = x / sqrt(S), S = the sum of nblk block partials added up by every workgroup as k_finalize would (finalize_block_256: the same
+// bits as the finalize launch + trk_axpby(1 / sqrt(*S)) pair it replaces); workgroup 0 leaves S in *sum_out and carries the mailbox
+// post, if any (PostReq: its scalars are final here — *sum_out is the last one).
+template <bool VEC>
+__global__ __launch_bounds__(NT) void k_scale_fin(int64_t n, const double* __restrict__ part, int nblk, const float* x, float* out,
+                                                  double* sum_out, const PostReq pq) {
+  __shared__ double lds[NT / 64];
+  __shared__ double bc;
+  const double S = finalize_block_256(part, nblk, 1, lds);
+  if (threadIdx.x == 0) {
+    bc = S;
+    if (blockIdx.x == 0) *sum_out = S;
+  }
+  __syncthreads();
+  double cv = 1.0;
+  cv /= sqrt(bc);                                        // coef_eval(Coef{1.0, nullptr, S, TRK_SQRT_DEN})
+  const float a = (float)cv;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      float4 v = ld4(x, i), o;
+      o.x = a * v.x;
+      o.y = a * v.y;
+      o.z = a * v.z;
+      o.w = a * v.w;
+      st4(out, i, o);
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) out[i] = a * x[i];
+  if (pq.on && blockIdx.x == 0 && threadIdx.x < 64) {          // one wave: its lanes move in step, the publication follows the copies
+    for (int c = threadIdx.x; c < pq.count; c += 64) {
+      const double* sp = pq.src + c;
+      pq.dst[c] = (sp == sum_out) ? bc : *sp;
+    }
+    __threadfence_system();
+    if (threadIdx.x == 0) __hip_atomic_store(pq.seq, pq.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+int trk::scale_by_partials(int64_t n, const double* part, int nblk, const float* x, float* out, double* sum_out, const PostReq& post,
+                           hipStream_t s) {
+  TRK_REQUIRE(part && nblk >= 1 && x && out && sum_out && n >= 0, "scale_by_partials: bad argument");
+  const int grid = stream_grid(n);
+  if (aligned16(x) && aligned16(out)) hipLaunchKernelGGL((k_scale_fin<true>), dim3(grid), dim3(NT), 0, s, n, part, nblk, x, out, sum_out, post);
+  else hipLaunchKernelGGL((k_scale_fin<false>), dim3(grid), dim3(NT), 0, s, n, part, nblk, x, out, sum_out, post);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+extern "C" {
 
 int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y, float* out, const float* ref,
                    double* err_partials, int capacity_blocks, int* n_blocks, trk_stream st) {

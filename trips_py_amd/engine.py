@@ -403,6 +403,13 @@ class HipEngine:
                                        self.stream())
         _lib.check(rc, "trk_arnoldi_step")
 
+    def arnoldi_step_post(self, op_handle, V, k, w, G, ldg, W, S, post):
+        """arnoldi_step whose last kernel carries the mailbox post `post` (DevScalars.rider_post()[0]: trk_arnoldi_step_post)."""
+        mb, slot, _src, offset, count = post[:5]
+        rc = self.lib.trk_arnoldi_step_post(op_handle, V.data_ptr(), V.stride(0), int(k), w.data_ptr(), _ptr(G), int(ldg), _ptr(W), _ptr(S),
+                                            mb, int(slot), int(offset), int(count), self.stream())
+        _lib.check(rc, "trk_arnoldi_step_post")
+
     def scale_dot(self, a, x, out, z, dot_out):
         """out = a*x and dot_out = <out, z> in one pass (trk_scale_dot: the new basis vector with its entry of the projected
         right-hand side)."""

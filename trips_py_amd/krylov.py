@@ -522,7 +522,16 @@ class ArnoldiState:
         self.V.commit()
         self.beta0 = float(np.sqrt(self.S.host(0, 1)[0]))
 
-    def _enqueue(self):
+    def _enqueue(self, post=False):
+        """The next step, enqueued; returns its index k — or, with post=True, (k, handle): the download of S[0 .. 1+2k) started with
+        the step, riding on the step's last kernel where the library's one-call form runs (handle None: the caller posts it)."""
+        if post:
+            self._post_handle = None
+            k = self._enqueue_impl(True)
+            return k, self._post_handle
+        return self._enqueue_impl(False)
+
+    def _enqueue_impl(self, post):
         A, eng, S, V = self.A, self.eng, self.S, self.V
         k = V.k
         if len(S) < 2 * k + 2:
@@ -536,7 +545,11 @@ class ArnoldiState:
                 and getattr(eng, "arnoldi_step", None) is not None and getattr(A, "_h", None) and _plain_handle_apply(A) and V.data.stride(0) >= A.shape[0]):
             # the whole step in one call of the library (trk_arnoldi_step: the very calls below, same arguments, same results; the
             # Python side of a step was a third of a Hybrid-GMRES iteration on the 512^2 blur)
-            eng.arnoldi_step(A._h, V.data, k, self.w, self.gram.G.ref(0), self.gram.kmax, self.gram.W.ref(0), S.ref(0))
+            if post and getattr(eng, "arnoldi_step_post", None) is not None and getattr(S, "rider_post", None) is not None:
+                args, self._post_handle, _ = S.rider_post(0, 1 + 2 * k)
+                eng.arnoldi_step_post(A._h, V.data, k, self.w, self.gram.G.ref(0), self.gram.kmax, self.gram.W.ref(0), S.ref(0), args)
+            else:
+                eng.arnoldi_step(A._h, V.data, k, self.w, self.gram.G.ref(0), self.gram.kmax, self.gram.W.ref(0), S.ref(0))
             self.gram.in_G = k
             V.commit()
             return k
@@ -568,8 +581,8 @@ class ArnoldiState:
     def step_prefetch(self):
         """The step enqueued and the download of its column of H started; `absorb()` waits for that copy only (see
         GKState.step_prefetch).  Absorb a pending step before prefetching the next: both use the same scalars."""
-        k = self._enqueue()
-        return k, self.S.host_later(0, 1 + 2 * k)
+        k, handle = self._enqueue(post=True)
+        return k, (handle if handle is not None else self.S.host_later(0, 1 + 2 * k))
 
     def absorb(self, pending):
         k, handle = pending
