@@ -235,6 +235,8 @@ typedef struct trk_mailbox trk_mailbox;
 int trk_mailbox_create(int n_doubles, int slots, trk_mailbox** out);
 int trk_mailbox_destroy(trk_mailbox* mb);
 int trk_mailbox_host(trk_mailbox* mb, double** host_out);
+int trk_mailbox_doubles(trk_mailbox* mb);   /* the sizes it was created with */
+int trk_mailbox_slots(trk_mailbox* mb);
 int trk_mailbox_post(trk_mailbox* mb, int slot, const double* src_dev, int offset, int count, trk_stream stream);
 int trk_mailbox_wait(trk_mailbox* mb, int slot);
 /* trk_mailbox_post plus one more value published with it: the sum of `n_partials` device doubles (block partials of an inner
@@ -263,6 +265,31 @@ int trk_arnoldi_step(trk_op* op, float* V, int64_t ld, int k, float* w, double* 
  * trk_mailbox_wait(mb, slot) returns once they have arrived) — no launch for the post. */
 int trk_arnoldi_step_post(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
                           trk_mailbox* mb, int slot, int offset, int count, trk_stream stream);
+/* ... to host[host_offset ..] instead (two steps in flight: a region of the mailbox per slot). */
+int trk_arnoldi_step_post_at(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
+                             trk_mailbox* mb, int slot, int offset, int count, int host_offset, trk_stream stream);
+/* Hybrid-GMRES with regparam = 'gcv' (Hybrid_GMRES.py:46-80): the host side of one iteration in one call.  The handle keeps H (host,
+ * column-major), runs the Arnoldi steps ahead on `stream` (trk_arnoldi_step_post into a mailbox of its own), hands iterate k's projected
+ * problem to a worker thread (trk_host_worker_post_hess_gcv; `workers`: n_workers of them, set_lapack done, and `mb`, 2 slots and
+ * 2 (2 capacity + 4) doubles, all the caller's for the life of the handle: nothing in the Arnoldi process waits for a projected
+ * solution, so consecutive iterates' O(k^3) jobs run side by side) and launches x_k = V_k y_k (trk_gemv_n_hosty) when the job is
+ * collected, n_workers calls later.  create: the arguments of
+ * trk_arnoldi_step with V[0] = b / ||b|| in place, beta0 = ||b||, at most `capacity` steps; start: enqueues step 1.  iter (projected.hip):
+ * absorb (wait for the oldest posted step, install its column of H), enqueue_next, x_done != NULL (collect the OLDEST posted job:
+ * *done_ii, its lambda, the reference's relResidual (:80); x_done launched, + ||x - ref||^2 block partials, *done_blocks of them, when
+ * ref != NULL), post_job (iterate = columns - 1; needs a free worker).  H: a view of the columns installed so far, H[i + j * ldh],
+ * for iterates the caller solves itself (the first ones; the SVD route). */
+typedef struct trk_hgmres trk_hgmres;
+typedef struct trk_host_worker trk_host_worker;
+int trk_hgmres_create(trk_op* op, float* V, int64_t ld, int capacity, float* w, double* G, int ldg, double* W, double* S,
+                      trk_mailbox* mb, trk_host_worker* const* workers, int n_workers, double beta0, trk_stream stream, trk_hgmres** out);
+int trk_hgmres_destroy(trk_hgmres* g);
+int trk_hgmres_start(trk_hgmres* g);
+int trk_hgmres_iter(trk_hgmres* g, int absorb, int enqueue_next, int post_job, float* x_done, const float* ref, double* err_partials,
+                    int err_cap, int* done_ii, double* done_lam, double* done_resid, int* done_blocks);
+int trk_hgmres_H(trk_hgmres* g, double** H, int* ldh, int* columns);
+/* host seconds spent so far: waiting for steps | enqueueing steps | waiting for workers | posting jobs | launching x = V y */
+int trk_hgmres_stats(trk_hgmres* g, double* seconds5);
 /* trk_gk_step (optionally with the projection of trk_gk_step_proj: proj != NULL) that also carries a mailbox post — the copy of
  * `count` (<= 8) device doubles src_dev[0..count) to host[offset ..] of `mb`, optionally the sum of n_sum block partials to *sum_dev and
  * host[sum_offset], and the publication of `slot` (trk_mailbox_post / trk_mailbox_post_sum): on the projector the first workgroup of

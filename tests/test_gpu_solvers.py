@@ -389,6 +389,37 @@ def test_hybrid_gmres_device_projected_solve_equals_the_host_one(N, its):
         assert float(torch.linalg.norm(a - c) / torch.linalg.norm(c)) < 1e-5, k
 
 
+@pytest.mark.parametrize("N,its,hist", [(64, 30, True), (128, 45, True), (96, 25, 3), (64, 13, False)])
+def test_hybrid_gmres_gcv_one_library_call_per_iteration_equals_the_python_loop(N, its, hist):
+    """trk_hgmres_iter — absorb the step that ran ahead, enqueue the next, collect the worker's answer for the iterate before, post this
+    one, launch x = V y: the host side of a Hybrid-GMRES iteration with regparam='gcv' in one call — against the Python loop that makes
+    those calls one by one (c_loop=False): the same lambda history (the same job on the same worker: 1e-10), iterates, relError and the
+    reference's relResidual."""
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import gauss_psf
+    from trips_py_amd.solvers import Hybrid_GMRES
+    A = Blur2D(gauss_psf((9, 9), (2, 2))[0], N, N)
+    dev = A.engine.device
+    xt = torch.rand(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    b = A.apply(xt)
+    b = b + 0.01 * torch.randn(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(6)) * b.norm() / N
+    assert hasattr(A.engine.lib, "trk_hgmres_iter")
+    xc, ic = Hybrid_GMRES(A, b, its, "gcv", xt, history=hist)
+    xp, ip = Hybrid_GMRES(A, b, its, "gcv", xt, history=hist, c_loop=False)
+    assert len(ic["regParam_history"]) == len(ip["regParam_history"]) == its and ic["its"] == ip["its"]
+    assert np.allclose(ic["regParam_history"], ip["regParam_history"], rtol=1e-10, atol=0)
+    assert np.allclose(ic["relResidual"], ip["relResidual"], rtol=1e-10)
+    assert np.allclose(ic["relError"], ip["relError"], rtol=1e-6)
+    assert float(torch.linalg.norm(xc - xp) / torch.linalg.norm(xp)) < 1e-6
+    if hist is True:
+        for k in (0, 11, its // 2, its - 1):
+            a, c = ic["xHistory"][k].reshape(-1), ip["xHistory"][k].reshape(-1)
+            assert float(torch.linalg.norm(a - c) / torch.linalg.norm(c)) < 1e-6, k
+    # without x_true (no error partials) the same iterates
+    x2, i2 = Hybrid_GMRES(A, b, its, "gcv", history=False)
+    assert float(torch.linalg.norm(x2 - xc) / torch.linalg.norm(xc)) < 1e-6 and "relError" not in i2
+
+
 def test_gks_gram_rows_from_v_equal_the_stored_images_form():
     """GKS on stencil operators keeps no AV / LV: G_A, G_L rows come from one sweep over V with A^T A v_new and L^T L v_new
     (trk_gemv_t2).  Same iterates and lambda history as the stored-images form, on the reference golden and on a 256^2 problem

@@ -445,6 +445,9 @@ int trk_mailbox_host(trk_mailbox* mb, double** host_out) {
   return TRK_OK;
 }
 
+int trk_mailbox_doubles(trk_mailbox* mb) { return mb ? mb->n : 0; }
+int trk_mailbox_slots(trk_mailbox* mb) { return mb ? mb->slots : 0; }
+
 int trk_mailbox_post(trk_mailbox* mb, int slot, const double* src_dev, int offset, int count, trk_stream stream) {
   TRK_REQUIRE(mb && src_dev && slot >= 0 && slot < mb->slots, "trk_mailbox_post: bad mailbox / slot");
   TRK_REQUIRE(offset >= 0 && count > 0 && offset + count <= mb->n, "trk_mailbox_post: range outside the mailbox");
@@ -547,16 +550,22 @@ int trk_arnoldi_step(trk_op* op, float* V, int64_t ld, int k, float* w, double* 
 // contract for `slot`: trk_mailbox_wait(mb, slot) returns when they have arrived)
 int trk_arnoldi_step_post(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
                           trk_mailbox* mb, int slot, int offset, int count, trk_stream stream) {
+  return trk_arnoldi_step_post_at(op, V, ld, k, w, G, ldg, W, S, mb, slot, offset, count, offset, stream);
+}
+
+// ... to host[host_offset ..] (a caller that keeps two steps in flight gives each slot a region of its own)
+int trk_arnoldi_step_post_at(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
+                             trk_mailbox* mb, int slot, int offset, int count, int host_offset, trk_stream stream) {
   TRK_REQUIRE(op && V && w && G && W && S && k >= 1 && ldg >= k, "trk_arnoldi_step_post: bad argument");
   TRK_REQUIRE(op->rows == op->cols && ld >= op->rows, "trk_arnoldi_step_post: square operator, ld >= n");
   TRK_REQUIRE(mb && slot >= 0 && slot < mb->slots, "trk_arnoldi_step_post: bad mailbox / slot");
-  TRK_REQUIRE(offset >= 0 && count > 0 && offset + count <= mb->n, "trk_arnoldi_step_post: range outside the mailbox");
+  TRK_REQUIRE(offset >= 0 && count > 0 && host_offset >= 0 && host_offset + count <= mb->n, "trk_arnoldi_step_post: range outside the mailbox");
   mb->expect[slot] = ++mb->counter;
   mb->stream[slot] = (hipStream_t)stream;
   PostReq q;
   q.on = 1;
   q.src = S + offset;
-  q.dst = mb->host + offset;
+  q.dst = mb->host + host_offset;
   q.count = count;
   q.seq = mb->seq + slot;
   q.value = mb->expect[slot];

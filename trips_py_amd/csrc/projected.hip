@@ -8,6 +8,9 @@
 // float64 throughout; one lane does the (inherently sequential) recurrence.
 #include "trk_internal.h"
 
+#include <chrono>
+#include <deque>
+
 #include <map>
 #include <mutex>
 
@@ -975,11 +978,24 @@ int hess_job(trk_host_worker* w, bool dp) {
   return TRK_OK;
 }
 
+// poll the worker's state for up to ~0.4 ms before going to sleep on the condition variable: a wake-up through the kernel costs
+// 50-100 us, a job 30-150 us — a caller that arrives a little early (the one-call-per-iteration loop does) must not pay for a sleep
+template <class F>
+void spin_until(trk_host_worker* w, F&& ready) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    for (int i = 0; i < 512; ++i) {
+      if (ready(w->state.load(std::memory_order_acquire))) return;
+      __builtin_ia32_pause();
+    }
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::microseconds(400)) return;
+  }
+}
+
 void host_worker_main(trk_host_worker* w) {
   for (;;) {
-    // spin briefly (jobs arrive every ~70 us inside a solve), then sleep
-    int spins = 0;
-    while (w->state.load(std::memory_order_acquire) != 1 && w->state.load(std::memory_order_acquire) != 3 && spins < 20000) ++spins;
+    // spin for a while (jobs arrive every ~60 us inside a solve), then sleep
+    spin_until(w, [](int st) { return st == 1 || st == 3; });
     if (w->state.load(std::memory_order_acquire) != 1 && w->state.load(std::memory_order_acquire) != 3) {
       std::unique_lock<std::mutex> lk(w->m);
       w->cv.wait(lk, [&] { const int s = w->state.load(std::memory_order_acquire); return s == 1 || s == 3; });
@@ -1111,8 +1127,7 @@ extern "C" int trk_host_worker_collect_vec(trk_host_worker* w, double* lam_out, 
 extern "C" int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int* have_out) {
   TRK_REQUIRE(w && lam_out && have_out, "trk_host_worker_collect: NULL argument");
   TRK_REQUIRE(w->state.load() != 0, "trk_host_worker_collect: nothing was posted");
-  int spins = 0;
-  while (w->state.load(std::memory_order_acquire) != 2 && spins < 20000) ++spins;
+  spin_until(w, [](int st) { return st == 2; });
   if (w->state.load(std::memory_order_acquire) != 2) {
     std::unique_lock<std::mutex> lk(w->m);
     w->cv.wait(lk, [&] { return w->state.load(std::memory_order_acquire) == 2; });
@@ -1122,4 +1137,174 @@ extern "C" int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int*
   const int rc = w->rc;
   w->state.store(0, std::memory_order_release);
   return rc;
+}
+
+// ------------------------------------------------------------------ Hybrid-GMRES: the host side of one iteration in one call
+// Hybrid_GMRES.py:46-80 with regparam = 'gcv' as this library runs it: the Arnoldi steps run ahead on the stream (each posts its column
+// of H from its last kernel), iterate k's projected problem — bidiagonalisation of [beta0 e1 | H_k], the GCV search, the Tikhonov solve —
+// is one job of a worker thread, and x_k = V_k y_k is launched with y_k in the kernel's arguments when the job is collected.  Nothing
+// in the Arnoldi process waits for a projected solution, so the jobs of consecutive iterates run on SEVERAL workers side by side (a job
+// is O(k^3): ~150 us at k = 60 against ~55 us of kernels per step) and are collected in order, `workers` iterations late.  What the
+// interpreter did per iteration (seven library calls, three NumPy temporaries, ~70 us) is one call here.
+struct trk_hgmres {
+  trk_op* op;
+  float* V;
+  int64_t ld;
+  int cap;                 // Arnoldi steps at most (H is (cap + 1) x cap)
+  float* w;
+  double *G, *W, *S;
+  int ldg;
+  trk_mailbox* mb;         // borrowed: 2 slots, a region of 2 cap + 4 doubles each
+  double* mb_host;
+  std::vector<trk_host_worker*> ws;   // borrowed
+  double beta0;
+  std::vector<double> H;   // column-major, column stride ldh
+  int ldh;
+  int k_enq, k_abs;        // steps enqueued / columns of H installed
+  std::deque<int> posted;  // iterates (0-based) whose projected problems the workers hold, oldest first
+  unsigned long long post_seq, collect_seq;
+  std::vector<double> y;
+  hipStream_t stream;
+  double t_wait_step = 0, t_enqueue = 0, t_collect = 0, t_post = 0, t_launch = 0;     // host seconds by phase (trk_hgmres_stats)
+};
+static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+extern "C" int trk_hgmres_stats(trk_hgmres* g, double* seconds5) {
+  TRK_REQUIRE(g && seconds5, "trk_hgmres_stats: NULL argument");
+  seconds5[0] = g->t_wait_step; seconds5[1] = g->t_enqueue; seconds5[2] = g->t_collect; seconds5[3] = g->t_post; seconds5[4] = g->t_launch;
+  return TRK_OK;
+}
+
+extern "C" int trk_hgmres_create(trk_op* op, float* V, int64_t ld, int capacity, float* w, double* G, int ldg, double* W, double* S,
+                                 trk_mailbox* mb, trk_host_worker* const* workers, int n_workers, double beta0, trk_stream stream,
+                                 trk_hgmres** out) {
+  TRK_REQUIRE(op && V && w && G && W && S && out && mb && workers && capacity >= 1 && ldg >= capacity, "trk_hgmres_create: bad argument");
+  TRK_REQUIRE(op->rows == op->cols && ld >= op->rows, "trk_hgmres_create: square operator, ld >= n");
+  TRK_REQUIRE(n_workers >= 1 && n_workers <= 16, "trk_hgmres_create: 1..16 workers");
+  for (int i = 0; i < n_workers; ++i)
+    TRK_REQUIRE(workers[i] && workers[i]->gebrd && workers[i]->ormbr, "trk_hgmres_create: every worker with trk_host_worker_set_lapack done");
+  auto* g = new trk_hgmres{};
+  g->op = op; g->V = V; g->ld = ld; g->cap = capacity; g->w = w; g->G = G; g->W = W; g->S = S; g->ldg = ldg;
+  g->beta0 = beta0; g->ldh = capacity + 2; g->stream = (hipStream_t)stream;
+  g->H.assign((size_t)g->ldh * (size_t)(capacity + 1), 0.0);
+  g->y.assign((size_t)capacity + 1, 0.0);
+  g->ws.assign(workers, workers + n_workers);
+  g->mb = mb;
+  int rc = trk_mailbox_host(mb, &g->mb_host);
+  if (!rc && (trk_mailbox_doubles(mb) < 2 * (2 * capacity + 4) || trk_mailbox_slots(mb) < 2))
+    rc = fail(TRK_EINVAL, "trk_hgmres_create: the mailbox needs 2 slots and 2 (2 capacity + 4) doubles (a region per slot: two steps are in flight)");
+  if (rc) {
+    delete g;
+    return rc;
+  }
+  *out = g;
+  return TRK_OK;
+}
+
+// (the mailbox and the workers are the caller's: pinned memory and threads are pooled above the library — creating and freeing them
+// per solve costs more than the iterations of a short solve)
+extern "C" int trk_hgmres_destroy(trk_hgmres* g) {
+  if (!g) return TRK_OK;
+  if (g->k_enq > g->k_abs) (void)trk_mailbox_wait(g->mb, g->k_enq & 1);              // a posted step still writes to the mailbox
+  while (!g->posted.empty()) {                                                        // jobs nobody collected: the workers go back idle
+    double lam, r;
+    int have;
+    (void)trk_host_worker_collect_vec(g->ws[g->collect_seq % g->ws.size()], &lam, &have, g->y.data(), g->posted.front() + 1, &r);
+    g->posted.pop_front();
+    ++g->collect_seq;
+  }
+  delete g;
+  return TRK_OK;
+}
+
+extern "C" int trk_hgmres_H(trk_hgmres* g, double** H, int* ldh, int* columns) {
+  TRK_REQUIRE(g && H && ldh && columns, "trk_hgmres_H: NULL argument");
+  *H = g->H.data();
+  *ldh = g->ldh;
+  *columns = g->k_abs;
+  return TRK_OK;
+}
+
+// the next Arnoldi step, its scalars posted to slot (k & 1)
+static int hgmres_enqueue(trk_hgmres* g) {
+  const int k = g->k_enq + 1;
+  TRK_REQUIRE(k <= g->cap, "trk_hgmres: more steps than the basis was planned for");
+  if (int rc = trk_arnoldi_step_post_at(g->op, g->V, g->ld, k, g->w, g->G, g->ldg, g->W, g->S, g->mb, k & 1, 0, 1 + 2 * k,
+                                        (k & 1) * (2 * g->cap + 4), g->stream))
+    return rc;
+  g->k_enq = k;
+  return TRK_OK;
+}
+// Two steps ahead of the columns installed: step k + 1 needs nothing from the host, and enqueued only once step k's scalars had
+// arrived it left the device idle for a launch latency per step (S is rewritten by step k + 1 only after step k's last kernel has
+// posted it: stream order)
+static int hgmres_keep_ahead(trk_hgmres* g) {
+  while (g->k_enq < g->cap && g->k_enq < g->k_abs + 2)
+    if (int rc = hgmres_enqueue(g)) return rc;
+  return TRK_OK;
+}
+
+extern "C" int trk_hgmres_start(trk_hgmres* g) {
+  TRK_REQUIRE(g && g->k_enq == 0, "trk_hgmres_start: once, first");
+  return hgmres_keep_ahead(g);
+}
+
+/* One pass of the loop.  absorb: wait for the oldest posted step and install its column of H (column k = the count so far + 1);
+ * enqueue_next: keep two steps on the stream ahead of the columns installed (up to `capacity`); x_done != NULL: collect the OLDEST posted job — *done_ii names its iterate, with its
+ * lambda and the reference's relResidual in *done_lam / *done_resid — and launch x_done = V y (ref != NULL: with the block partials of
+ * ||x - ref||^2 in err_partials, *done_blocks of them); post_job: hand iterate k - 1's projected problem (H_k, gcv) to the worker that
+ * is free (with all of them busy, the caller collects in the same call).  The collect comes before the post, the launch after it. */
+extern "C" int trk_hgmres_iter(trk_hgmres* g, int absorb, int enqueue_next, int post_job, float* x_done, const float* ref,
+                               double* err_partials, int err_cap, int* done_ii, double* done_lam, double* done_resid, int* done_blocks) {
+  TRK_REQUIRE(g && done_ii && done_lam && done_resid && done_blocks, "trk_hgmres_iter: NULL argument");
+  *done_ii = -1;
+  *done_blocks = 0;
+  const size_t nw = g->ws.size();
+  if (absorb) {
+    TRK_REQUIRE(g->k_enq > g->k_abs, "trk_hgmres_iter: no step is pending");
+    const int k = g->k_abs + 1;
+    const double t0 = now_s();
+    if (int rc = trk_mailbox_wait(g->mb, k & 1)) return rc;
+    g->t_wait_step += now_s() - t0;
+    const double* h = g->mb_host + (size_t)(k & 1) * (2 * g->cap + 4);   // S[0] = h_{k+1,k}^2, S[1..1+k) + S[1+k..1+2k) = the column above it
+    double* col = g->H.data() + (size_t)(k - 1) * g->ldh;
+    for (int i = 0; i < k; ++i) col[i] = h[1 + i] + h[1 + k + i];
+    col[k] = sqrt(h[0]);
+    g->k_abs = k;
+  }
+  double t1 = now_s();
+  if (enqueue_next)
+    if (int rc = hgmres_keep_ahead(g)) return rc;
+  g->t_enqueue += now_s() - t1;
+  t1 = now_s();
+  int done = -1;
+  if (x_done) {
+    TRK_REQUIRE(!g->posted.empty(), "trk_hgmres_iter: x_done given but no job is posted");
+    int have = 0;
+    done = g->posted.front();
+    if (int rc = trk_host_worker_collect_vec(g->ws[g->collect_seq % nw], done_lam, &have, g->y.data(), done + 1, done_resid)) return rc;
+    TRK_REQUIRE(have, "trk_hgmres_iter: the worker returned no lambda");
+    g->posted.pop_front();
+    ++g->collect_seq;
+  }
+  g->t_collect += now_s() - t1;
+  t1 = now_s();
+  if (post_job) {
+    TRK_REQUIRE(g->k_abs >= 1 && g->posted.size() < nw, "trk_hgmres_iter: post_job needs a column of H and a free worker (collect first)");
+    const int k = g->k_abs;
+    if (int rc = trk_host_worker_post_hess_gcv(g->ws[g->post_seq % nw], g->H.data(), 1, g->ldh, k, g->beta0, (double)k, 1e-9, 1e2, 1e-12, 1000))
+      return rc;
+    g->posted.push_back(k - 1);
+    ++g->post_seq;
+  }
+  g->t_post += now_s() - t1;
+  t1 = now_s();
+  if (done >= 0) {
+    if (int rc = trk_gemv_n_hosty(g->V, g->ld, done + 1, g->op->rows, g->y.data(), x_done, ref, err_partials, err_cap, done_blocks,
+                                  g->stream))
+      return rc;
+    *done_ii = done;
+  }
+  g->t_launch += now_s() - t1;
+  return TRK_OK;
 }

@@ -290,10 +290,10 @@ __device__ __forceinline__ double scalar_from_wave(const ScalarSrc s, int lane) 
   if (i + 320 < s.n) a5 += s.p[i + 320];
   if (i + 384 < s.n) a6 += s.p[i + 384];
   double v = ((a0 + a1) + (a2 + a3)) + ((a4 + a5) + (a6 + a7));
-  // fixed tree: shfl_down order so that the association does not depend on the caller
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return __shfl(v, 0, 64);
+  // fixed tree (wave_sum: lane l with l + 32, the results with l + 16, ...: the association does not depend on the caller), lane 0's
+  // total to every lane through the scalar unit
+  v = wave_sum(v);
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
 
 inline int ceil_div(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -6,7 +6,7 @@ import numpy as np
 import scipy.linalg as sla
 
 from .._io import Formatter, History, as_operator
-from ..krylov import ArnoldiState
+from ..krylov import ArnoldiState, _plain_handle_apply
 from ..reg_param._bidiag import HessenbergBidiag, bidiag_tikhonov_host
 from ..reg_param.gcv import fminbound_gcv_bidiag
 from ._common import check_delta, choose_lambda, tikhonov_lstsq, small_host_blas
@@ -14,6 +14,10 @@ from ._common import check_delta, choose_lambda, tikhonov_lstsq, small_host_blas
 # basis size from which Hybrid-GMRES's GCV goes through the bidiagonal form instead of the dense SVD (below it the SVD is the
 # cheaper call: 20 us at k = 10 against 25-60 us of ctypes and NumPy overhead around dgebrd)
 BIDIAG_FROM_K = 12
+# (the same threshold in the one-call-per-iteration loop, kwarg worker_from_k: the two routes evaluate one GCV function a rounding
+# apart, and below k ~ 10 its minimum can be flat enough for the two answers to differ visibly — 56 % at one iterate of the 512^2 blur
+# with worker_from_k=2 — so the reference's route, the SVD, keeps the small iterates)
+WORKER_FROM_K = BIDIAG_FROM_K
 
 
 @small_host_blas
@@ -85,8 +89,6 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             bhat[0] = ar.beta0
             hy = (Hh[:k + 1, :k] @ Yh[ii, :k]).reshape(-1, 1)
             res.append(float(np.linalg.norm(bhat.reshape(1, -1) - hy)))    # the reference's broadcast quirk (:80), as below
-    pend = ar.step_prefetch() if (n_iter > 0 and not on_dev) else None
-
     def projected(k, H, first):
         """Everything the host owes iterate k once H_k is known — lambda_k, y_k, the reference's relResidual — as a function of H_k
         alone.  (Round 5 measured the obvious next step — several k at once on a small thread pool, LAPACK releasing the interpreter
@@ -160,6 +162,12 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
         from .Hybrid_LSQR import _Searcher
         searcher = _Searcher.borrow(_lib.load())
     Ph = np.zeros(n_iter + 2)
+    # gcv, one rank, a plain library operator: the host side of an iteration is ONE library call (trk_hgmres_iter: absorb the step that
+    # ran ahead, enqueue the next, collect the worker's answer for the iterate before, post this one, launch x = V y) — kwarg c_loop
+    c_loop = (async_gcv and kwargs.get("c_loop", True) and getattr(eng, "world", 1) == 1 and bool(getattr(A, "_h", None))
+              and _plain_handle_apply(A) and ar.by_gram and hasattr(eng, "cgs_coeffs") and hasattr(eng, "gemv_n_hosty")
+              and hasattr(getattr(eng, "lib", None), "trk_hgmres_create") and ar.V.data.stride(0) >= n and (xt is None or err_fused))
+    pend = ar.step_prefetch() if (n_iter > 0 and not on_dev and not c_loop) else None
 
     def enqueue_proj(j0, j1):
         for j in range(j0, j1):
@@ -267,16 +275,103 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             else:
                 form(*collect_waiting())
 
+    def c_gcv_loop():
+        nonlocal n_ep, x_dev
+        import ctypes as ct
+        from .. import _lib
+        from ..krylov import GramSchmidtByGram
+        lib = eng.lib
+        searcher._need_lapack()
+        ar.gram = GramSchmidtByGram(eng, ar.V, ar.capacity + 1)          # (installs the Gram row of V[0])
+        drv = ct.c_void_p()
+        # worker threads: the projected problems of consecutive iterates side by side (each O(k^3): ~150 us at k = 60 against ~55 us
+        # of kernels per step on the 512^2 blur), collected in order — kwarg search_workers
+        nw = max(1, min(16, int(kwargs.get("search_workers", 2))))
+        from .Hybrid_LSQR import _Searcher
+        while len(more_searchers) < nw - 1:                              # (borrowed like the first one; handed back by the caller)
+            more_searchers.append(_Searcher.borrow(lib))
+        for sx in more_searchers:
+            sx._need_lapack()
+        wh = (ct.c_void_p * nw)(searcher.h, *[sx.h for sx in more_searchers])
+        cap_mb = 64
+        while cap_mb < 2 * (2 * n_iter + 4):
+            cap_mb *= 2
+        mb, mb_view = eng._mailbox_take(cap_mb, 32)                      # pinned memory from the engine's pool
+        try:
+            _lib.check(lib.trk_hgmres_create(A._h, ar.V.data.data_ptr(), ar.V.data.stride(0), n_iter, ar.w.data_ptr(), ar.gram.G.ref(0),
+                                             ar.gram.kmax, ar.gram.W.ref(0), ar.S.ref(0), mb, wh, nw, float(ar.beta0), eng.stream(),
+                                             ct.byref(drv)), "trk_hgmres_create")
+        except Exception:
+            eng._mailbox_give(cap_mb, mb, mb_view)
+            raise
+        try:
+            _lib.check(lib.trk_hgmres_start(drv), "trk_hgmres_start")
+            Hp, ldh, ncol = ct.POINTER(ct.c_double)(), ct.c_int(), ct.c_int()
+            _lib.check(lib.trk_hgmres_H(drv, ct.byref(Hp), ct.byref(ldh), ct.byref(ncol)), "trk_hgmres_H")
+            Ht = np.ctypeslib.as_array(Hp, shape=(n_iter + 1, ldh.value))      # Ht[j, i] = H[i, j]: the library's array, filled as steps arrive
+            d_ii, d_lam, d_res, d_blk = ct.c_int(), ct.c_double(), ct.c_double(), ct.c_int()
+            ref = xt.data_ptr() if xt is not None else None
+            posted = []                                                  # iterates whose jobs the workers hold, oldest first
+            from_k = max(2, int(kwargs.get("worker_from_k", WORKER_FROM_K)))
+
+            def one(absorb, more, post, collect):
+                nonlocal n_ep, x_dev
+                jj = posted.pop(0) if collect else None
+                row = Hs.row(jj) if collect else None
+                ep = EP.ref(n_ep * jj) if (err_fused and collect) else None
+                _lib.check(lib.trk_hgmres_iter(drv, absorb, more, post, None if row is None else row.data_ptr(), ref, ep, 1024,
+                                               ct.byref(d_ii), ct.byref(d_lam), ct.byref(d_res), ct.byref(d_blk)), "trk_hgmres_iter")
+                if collect:
+                    if d_ii.value != jj:
+                        raise RuntimeError("trk_hgmres_iter: the collected iterate is not the oldest one posted")
+                    lams.append(d_lam.value)
+                    res.append(d_res.value)
+                    if err_fused:
+                        n_ep = d_blk.value
+                    x_dev = row
+                    Hs.pushed(jj)
+
+            for ii in range(n_iter):
+                k = ii + 1
+                post = k >= from_k
+                one(1, 1, int(post), post and len(posted) == nw)          # (the library keeps two steps ahead, n_iter in all)
+                if post:
+                    posted.append(ii)
+                if not post:                                             # the first iterates: in this thread (SVD route), as before
+                    lam_k, y, r = projected(k, Ht[:k, :k + 1].T, ii == 0)
+                    lams.append(lam_k)
+                    res.append(r)
+                    x_dev = Hs.row(ii)
+                    yk = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+                    if err_fused:
+                        n_ep = eng.gemv_n_hosty(ar.V.data, k, yk, x_dev, xt, EP.ref(n_ep * ii), 1024)
+                    else:
+                        eng.gemv_n_hosty(ar.V.data, k, yk, x_dev)
+                    Hs.pushed(ii)
+            while posted:
+                one(0, 0, 0, True)
+            if "host_phases" in kwargs:                                  # (a list the caller wants the library's phase timers in)
+                t5 = (ct.c_double * 5)()
+                lib.trk_hgmres_stats(drv, t5)
+                kwargs["host_phases"][:] = list(t5)
+        finally:
+            lib.trk_hgmres_destroy(drv)                                  # (waits for what is still posted: then the mailbox may go back)
+            eng._mailbox_give(cap_mb, mb, mb_view)
+
+    more_searchers = []
     clean = False
     try:
-        host_loop()
+        if c_loop:
+            c_gcv_loop()
+        else:
+            host_loop()
         clean = True
     finally:
-        if searcher is not None:
+        for sx in ([searcher] if searcher is not None else []) + more_searchers:
             if clean:
-                searcher.give_back()
+                sx.give_back()
             else:
-                searcher.close()             # (a job may still be posted: destroy waits for it)
+                sx.close()                   # (a job may still be posted: destroy waits for it)
     if lams:
         lam = lams[-1]
     if x_dev is None:
