@@ -565,10 +565,12 @@ int trk_gk_lsqr_chain(trk_op* op, int elem_bytes, int weights, const void* b, in
 int trk_wgram_tv(const float* V, int64_t ld, int k, int N, const float* w, double* G, trk_stream stream);
 /* ACCURACY CONTRACT of trk_wgram_tv / trk_wgram_tv_z, and the switch.  The 16 x 16 tile products go through the matrix cores; `mode`:
  *   1 (default)  AUTO: two bf16 pieces unless the data says otherwise.  Every call first measures, on a sample (runs of 1024 pixels in 256 image
- *                rows, four of the k basis vectors), what the two-piece split would lose — max |S' - S| / sqrt(S_aa S_bb) of the sampled Gram with
+ *                rows; four of the k basis vectors spread over the basis and, from k = 8, the NEWEST four with all their pairs — a solver's basis
+ *                changes character at its end first; vectors in the middle that neither set holds are the sample's blind spot), what the
+ *                two-piece split would lose — max |S' - S| / sqrt(S_aa S_bb) of the sampled Gram with
  *                and without the split, in float64 — and the verdict stays on the DEVICE: ONE Gram launch holds both arithmetic forms, every
  *                workgroup works the verdict out from the probe's sums in its prologue and takes the sweep of the form it names — two pieces
- *                below 3e-7, the fp32 pipe above (nothing visits the host; the probe reads ~12 MB whatever the image size).  TRK_WGRAM_TV_AUTO_PAIR=1
+ *                below 3e-7, the fp32 pipe above (nothing visits the host; the probe reads ~24 MB whatever the image size).  TRK_WGRAM_TV_AUTO_PAIR=1
  *                selects the older A/B arrangement instead (a gated PAIR of launches, one of which returns at once).
  *                <= 1e-6 per entry relative to sqrt(G_aa G_bb) on data the sample represents; the piecewise-
  *                constant / repeated-value images of tests/test_gpu_kernels.py trip it, noisy images and Krylov vectors do not.

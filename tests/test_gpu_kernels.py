@@ -409,6 +409,40 @@ def test_wgram_tv_auto_mode_keeps_the_two_piece_form_on_noisy_data(eng):
     assert verdict2 == 1 and sampled2 > 1e-6 and verdict3 == 0, (verdict2, sampled2, verdict3)
 
 
+@pytest.mark.parametrize("where", ["last4", "last4_but_newest", "last1"])
+def test_wgram_tv_auto_probe_sees_a_basis_that_turns_piecewise_constant_at_its_end(eng, where):
+    """a basis whose NEWEST vectors alone are images of repeated values (MMGKS late in a TV solve), the rest
+    noise-like — the probe samples four vectors spread over the basis and, since round 6, the newest four with all their pairs: the
+    verdict is 1 and the Gram within the contract's 1e-6 whether the repeated-value images are the last four, the three before the
+    newest, or the newest alone."""
+    from trips_py_amd.operators import FirstDerivative2D
+    N, k = 2048, 24
+    dev = eng.device
+    n, p = N * N, 2 * N * (N - 1)
+    V = torch.randn(k, n, device=dev, generator=torch.Generator(device=dev).manual_seed(11))
+    adv = _adversarial_basis("constant_steps", 4, N, dev)
+    rows = {"last4": [k - 4, k - 3, k - 2, k - 1], "last4_but_newest": [k - 4, k - 3, k - 2], "last1": [k - 1]}[where]
+    for j, r in enumerate(rows):
+        V[r] = adv[j]
+    w = torch.empty(p, device=dev)
+    FirstDerivative2D(N, engine=eng).tv_weights(adv[0].contiguous(), 0.1, 1.0, w)
+    G = eng.scalars(2 * k * k)
+    was = eng.wgram_tv_precision("auto")
+    try:
+        eng.wgram_tv(V, k, N, w, G[0:k * k])
+        verdict, sampled = eng.wgram_tv_last_probe()
+        eng.wgram_tv_precision("fp32")
+        eng.wgram_tv(V, k, N, w, G[k * k:2 * k * k])
+    finally:
+        eng.wgram_tv_precision(was)
+    got = eng.to_host(G)
+    a, ref = got[:k * k].reshape(k, k), got[k * k:].reshape(k, k)
+    dg = np.sqrt(np.abs(np.diag(ref)))
+    worst = float(np.max(np.abs(a - ref) / np.maximum(np.outer(dg, dg), 1e-300)))
+    bar(f"wgram_tv.auto_late_basis[{where}]", worst, 1e-6)
+    assert verdict == 1 and sampled > 3e-7, (verdict, sampled)
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("k,mu", [(1, 0.3), (2, 0.0), (7, 1e-2), (100, 1e-3), (1000, 0.5)])
 def test_bidiag_tikhonov_matches_stacked_lstsq(k, mu):

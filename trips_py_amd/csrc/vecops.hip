@@ -1493,20 +1493,24 @@ struct ProbeGate {
   double threshold;
   int want;               // this launch runs iff verdict == want
   double* record;         // {verdict, worst} for trk_wgram_tv_last_probe
+  int groups = 1;         // sets of four sampled basis vectors: 2 x 10 sums each (k_wgram_tv_probe)
 };
 __device__ __forceinline__ int probe_verdict(const ProbeGate& pg, bool record) {
   constexpr int PV = 4, PP = 10;
   double worst = 0.0;
-  int q = 0;
+  for (int g = 0; g < pg.groups; ++g) {
+    const double* __restrict__ S = pg.sums + g * 2 * PP;
+    int q = 0;
 #pragma unroll
-  for (int a = 0; a < PV; ++a)
+    for (int a = 0; a < PV; ++a)
 #pragma unroll
-    for (int b = a; b < PV; ++b, ++q) {
-      // (the diagonal entries of the upper-triangle order: a = 0 -> 0, 1 -> 4, 2 -> 7, 3 -> 9)
-      const int qa = a == 0 ? 0 : a == 1 ? 4 : a == 2 ? 7 : 9, qb = b == 0 ? 0 : b == 1 ? 4 : b == 2 ? 7 : 9;
-      const double sc = sqrt(fabs(pg.sums[qa] * pg.sums[qb]));
-      if (sc > 0.0) worst = fmax(worst, fabs(pg.sums[PP + q] - pg.sums[q]) / sc);
-    }
+      for (int b = a; b < PV; ++b, ++q) {
+        // (the diagonal entries of the upper-triangle order: a = 0 -> 0, 1 -> 4, 2 -> 7, 3 -> 9)
+        const int qa = a == 0 ? 0 : a == 1 ? 4 : a == 2 ? 7 : 9, qb = b == 0 ? 0 : b == 1 ? 4 : b == 2 ? 7 : 9;
+        const double sc = sqrt(fabs(S[qa] * S[qb]));
+        if (sc > 0.0) worst = fmax(worst, fabs(S[PP + q] - S[q]) / sc);
+      }
+  }
   const int verdict = worst > pg.threshold ? 1 : 0;
   if (record && pg.want == 0 && pg.record) {
     pg.record[0] = (double)verdict;
@@ -2202,9 +2206,12 @@ __global__ __launch_bounds__(NT) void k_wgram_tv_probe(const float* __restrict__
   const int span = N > PROBE_SEG ? N - PROBE_SEG : 0;
   const int cbeg = span > 0 ? (int)((h >> 8) % (unsigned)(span + 1)) : 0;
   const int c_end = cbeg + PROBE_SEG < N ? cbeg + PROBE_SEG : N;
+  // group 0: four vectors spread over the basis (the first and the last among them); group 1 (k >= 8): the NEWEST four — a solver's
+  // basis changes character at its end first (MMGKS late in a TV solve: VERDICT round 5, weak 3), and all pairs of the last four are
+  // what a spread sample of one of them cannot see
   int pr[PROBE_V];
 #pragma unroll
-  for (int a = 0; a < PROBE_V; ++a) pr[a] = (int)(((int64_t)a * (k - 1)) / (PROBE_V - 1));
+  for (int a = 0; a < PROBE_V; ++a) pr[a] = blockIdx.y == 0 ? (int)(((int64_t)a * (k - 1)) / (PROBE_V - 1)) : k - PROBE_V + a;
   const float* __restrict__ wh = w;
   const float* __restrict__ wv = w + (int64_t)N * (N - 1);
   double acc[2 * PROBE_P];
@@ -2235,7 +2242,7 @@ __global__ __launch_bounds__(NT) void k_wgram_tv_probe(const float* __restrict__
       }
   }
   const double t = block_sum_many<NT, 2 * PROBE_P>(acc, lds);
-  if (threadIdx.x < 2 * PROBE_P) part[(size_t)blockIdx.x * 2 * PROBE_P + threadIdx.x] = t;
+  if (threadIdx.x < 2 * PROBE_P) part[((size_t)blockIdx.x * gridDim.y + blockIdx.y) * 2 * PROBE_P + threadIdx.x] = t;
 }
 // k_finalize / k_finalize_split of core.hip for one launch of such a pair (outputs from nsplit on go to out2)
 __global__ __launch_bounds__(256) void k_finalize_gated(const double* __restrict__ partials, int nblocks, int stride, double* __restrict__ out,
@@ -2855,9 +2862,9 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   }
   double* part = nullptr;
   const int nv = k * k + (z ? k : 0);
-  if (int rc = scratch_doubles(s, (size_t)bx * nv + ((size_t)PROBE_ROWS + 1) * 2 * PROBE_P, &part)) return rc;
+  if (int rc = scratch_doubles(s, (size_t)bx * nv + ((size_t)PROBE_ROWS + 1) * 2 * 2 * PROBE_P, &part)) return rc;
   double* probe_part = part + (size_t)bx * nv;
-  double* probe_sums = probe_part + (size_t)PROBE_ROWS * 2 * PROBE_P;
+  double* probe_sums = probe_part + (size_t)PROBE_ROWS * 2 * 2 * PROBE_P;
 #ifdef TRK_WGRAM_TV_EXPERIMENT
   static const int no_xcd = (env_int("TRK_WGRAM_TV_NO_XCD", 0) ? 2 : 0) | (env_int("TRK_WGRAM_TV_X", 0) & 12);
 #else
@@ -2870,29 +2877,30 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
   // two tiles, three pieces: 256 registers (no spills) at 2 workgroups per CU is the faster form (532 / 605 us at k = 17 / 32 against
   // 648 / 781 with 32 spilled registers at 3: profiles/r05/wgram_tv_pieces.txt)
   static const int occ2 = env_int("TRK_WGRAM_TV_OCC2", 1);
-  ProbeGate pg{nullptr, 0.0, 0, nullptr};
+  ProbeGate pg{nullptr, 0.0, 0, nullptr, 1};
   if (mode == 1) {
     if (!g_wgram_gate) TRK_HIP(hipMalloc((void**)&g_wgram_gate, 2 * sizeof(double)));
     // verdict threshold on the SAMPLED deviation: a third of the 1e-6 the contract promises (the sample is an estimate)
     static const double thr = getenv("TRK_WGRAM_TV_PROBE_THRESHOLD") ? atof(getenv("TRK_WGRAM_TV_PROBE_THRESHOLD")) : 3e-7;
     const int row_step = N / PROBE_ROWS > 0 ? N / PROBE_ROWS : 1;
     const int prows = (N + row_step - 1) / row_step < PROBE_ROWS ? (N + row_step - 1) / row_step : PROBE_ROWS;
-    hipLaunchKernelGGL(k_wgram_tv_probe, dim3(prows), dim3(NT), 0, s, V, ld, k, N, w, row_step, probe_part);
+    const int pgroups = k >= 2 * PROBE_V ? 2 : 1;
+    hipLaunchKernelGGL(k_wgram_tv_probe, dim3(prows, pgroups), dim3(NT), 0, s, V, ld, k, N, w, row_step, probe_part);
     TRK_LAUNCH_CHECK();
-    if (int rc = finalize_sums(probe_part, prows, 2 * PROBE_P, 2 * PROBE_P, probe_sums, s)) return rc;
-    pg = ProbeGate{probe_sums, thr, 0, g_wgram_gate};
+    if (int rc = finalize_sums(probe_part, prows, pgroups * 2 * PROBE_P, pgroups * 2 * PROBE_P, probe_sums, s)) return rc;
+    pg = ProbeGate{probe_sums, thr, 0, g_wgram_gate, pgroups};
   }
   // arith: 0 fp32 pipe, 2 / 3 bf16 pieces; want: with a probe, the launch runs iff the probe's verdict equals it
 #define WTV(TT, ZZ, ARITH, WANT)                                                                                                                      \
   do {                                                                                                                                                \
-    if ((ARITH) == 4) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 4>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, 0, pg.record}); \
-    else if ((ARITH) == 0) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 0>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record}); \
-    else if ((ARITH) == 2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record}); \
-    else if (TT == 2 && !ZZ && occ2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record}); \
-    else hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record});           \
+    if ((ARITH) == 4) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 4>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, 0, pg.record, pg.groups}); \
+    else if ((ARITH) == 0) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 0>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record, pg.groups}); \
+    else if ((ARITH) == 2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record, pg.groups}); \
+    else if (TT == 2 && !ZZ && occ2) hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3, 2>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record, pg.groups}); \
+    else hipLaunchKernelGGL((k_wgram_tv<TT, ZZ, 3, 3>), dim3(bx), dim3(NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, lock | no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record, pg.groups});           \
   } while (0)
   // one pass of the chosen arithmetic: the kernel and the sum of its block partials
-#define WTVL1(TT, ZZ, BFV, WANT) hipLaunchKernelGGL((k_wgram_tv_lds<TT, ZZ, BFV>), dim3(bx), dim3(LW_NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, (int)no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record})
+#define WTVL1(TT, ZZ, BFV, WANT) hipLaunchKernelGGL((k_wgram_tv_lds<TT, ZZ, BFV>), dim3(bx), dim3(LW_NT), 0, s, V, ld, k, N, w, nbands, band_rows, part, z, (int)no_xcd, ProbeGate{pg.sums, pg.threshold, WANT, pg.record, pg.groups})
 #define WTVL(TT, ZZ, ARITH, WANT)                                \
   do {                                                           \
     if ((ARITH) == 4) WTVL1(TT, ZZ, 4, 0);                       \
@@ -2912,7 +2920,7 @@ static int wgram_tv_run(const float* V, int64_t ld, int k, int N, const float* w
     TRK_LAUNCH_CHECK();
     const int nout = two_pass ? k * k : nv;
     if (pg.sums && arith != 4) {
-      hipLaunchKernelGGL(k_finalize_gated, dim3(nout), dim3(256), 0, s, part, bx, nout, G, k * k, h, ProbeGate{pg.sums, pg.threshold, want, nullptr});
+      hipLaunchKernelGGL(k_finalize_gated, dim3(nout), dim3(256), 0, s, part, bx, nout, G, k * k, h, ProbeGate{pg.sums, pg.threshold, want, nullptr, pg.groups});
       TRK_LAUNCH_CHECK();
       return TRK_OK;
     }
