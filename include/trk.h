@@ -288,6 +288,8 @@ int trk_hgmres_start(trk_hgmres* g);
 int trk_hgmres_iter(trk_hgmres* g, int absorb, int enqueue_next, int post_job, float* x_done, const float* ref, double* err_partials,
                     int err_cap, int* done_ii, double* done_lam, double* done_resid, int* done_blocks);
 int trk_hgmres_H(trk_hgmres* g, double** H, int* ldh, int* columns);
+/* A numeric regparam: the jobs posted from now on solve with this lambda instead of searching (lam < 0: gcv again). */
+int trk_hgmres_fixed_lambda(trk_hgmres* g, double lam);
 /* host seconds spent so far: waiting for steps | enqueueing steps | waiting for workers | posting jobs | launching x = V y */
 int trk_hgmres_stats(trk_hgmres* g, double* seconds5);
 /* trk_gk_step (optionally with the projection of trk_gk_step_proj: proj != NULL) that also carries a mailbox post — the copy of
@@ -442,6 +444,9 @@ int trk_host_worker_post_hess_gcv(trk_host_worker* w, const double* H, int64_t h
  * k + 1 host doubles, copied at post; target = (eta delta)^2, extra as trk_host_dp_bidiag): y and the residual are formed only when
  * the Newton iteration returns a positive lambda (*have_out = 1 and *lam_out > 0); otherwise the caller takes the reference's other
  * branches itself. */
+/* ... with a lambda the caller names (no search): y, the residual and *lam_out = lam through trk_host_worker_collect_vec. */
+int trk_host_worker_post_hess_fixed(trk_host_worker* w, const double* H, int64_t h_row_stride, int64_t h_col_stride, int k,
+                                    double beta0, double lam);
 int trk_host_worker_post_hess_dp(trk_host_worker* w, const double* H, int64_t h_row_stride, int64_t h_col_stride, int k,
                                  double beta0, const double* bproj, double target, double extra);
 int trk_host_worker_collect_vec(trk_host_worker* w, double* lam_out, int* have_out, double* y, int k, double* resid_out);

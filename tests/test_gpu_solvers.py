@@ -378,15 +378,18 @@ def test_hybrid_gmres_device_projected_solve_equals_the_host_one(N, its):
     xt = torch.rand(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(3))
     b = A.apply(xt)
     b = b + 0.01 * torch.randn(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(4)) * b.norm() / N
-    xd, idv = Hybrid_GMRES(A, b, its, 1e-2, xt)
     xh, ih = Hybrid_GMRES(A, b, its, 1e-2, xt, device_solve=False)
-    assert float(torch.linalg.norm(xd - xh) / torch.linalg.norm(xh)) < 1e-5
-    assert idv["regParam_history"] == ih["regParam_history"] and idv["its"] == ih["its"]
-    assert np.allclose(idv["relError"], ih["relError"], rtol=1e-5)
-    assert np.allclose(idv["relResidual"], ih["relResidual"], rtol=1e-6)
-    for k in (0, its // 2, its - 1):
-        a, c = idv["xHistory"][k].reshape(-1), ih["xHistory"][k].reshape(-1)
-        assert float(torch.linalg.norm(a - c) / torch.linalg.norm(c)) < 1e-5, k
+    # the device kernel (c_loop=False), and the default since round 6: the library's one-call-per-iteration loop with the projected
+    # problems as fixed-lambda jobs of the host worker threads (trk_hgmres_iter + trk_host_worker_post_hess_fixed)
+    for kw in ({"c_loop": False}, {}):
+        xd, idv = Hybrid_GMRES(A, b, its, 1e-2, xt, **kw)
+        assert float(torch.linalg.norm(xd - xh) / torch.linalg.norm(xh)) < 1e-5, kw
+        assert idv["regParam_history"] == ih["regParam_history"] and idv["its"] == ih["its"], kw
+        assert np.allclose(idv["relError"], ih["relError"], rtol=1e-5), kw
+        assert np.allclose(idv["relResidual"], ih["relResidual"], rtol=1e-6), kw
+        for k in (0, its // 2, its - 1):
+            a, c = idv["xHistory"][k].reshape(-1), ih["xHistory"][k].reshape(-1)
+            assert float(torch.linalg.norm(a - c) / torch.linalg.norm(c)) < 1e-5, (k, kw)
 
 
 @pytest.mark.parametrize("N,its,hist", [(64, 30, True), (128, 45, True), (96, 25, 3), (64, 13, False)])

@@ -169,6 +169,7 @@ SIGNATURES = {
                                  ctypes.POINTER(ctypes.c_void_p)]),
     "trk_hgmres_destroy": (c_int, [ctypes.c_void_p]),
     "trk_hgmres_start": (c_int, [ctypes.c_void_p]),
+    "trk_hgmres_fixed_lambda": (c_int, [ctypes.c_void_p, c_dbl]),
     "trk_hgmres_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl)]),
     "trk_hgmres_iter": (c_int, [ctypes.c_void_p, c_int, c_int, c_int, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int),
                                ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),

@@ -933,7 +933,7 @@ typedef void (*ormbr_fn)(char*, char*, char*, int*, int*, int*, double*, int*, d
 // first column is a multiple of e1, so Q^T (beta0 e1) = d[0] e1 and P = diag(1, P')): H = Q B[:, 1:] P'^T with B[:, 1:] LOWER bidiagonal,
 // diagonal e[0..k), sub-diagonal d[1..k].  lambda by 'standard' GCV on that triple (fullsize k: the k x k diag(s) of :58), z the
 // Tikhonov minimiser, y = P' z, and the reference's relResidual (:80: a (k+1,) minus a (k+1, 1) — the Frobenius norm of a matrix).
-int hess_job(trk_host_worker* w, bool dp) {
+int hess_job(trk_host_worker* w, bool dp, bool fixed = false) {
   const int k = w->k, n = k + 1;
   w->M.assign((size_t)n * n, 0.0);
   w->M[0] = w->p[0];
@@ -959,6 +959,10 @@ int hess_job(trk_host_worker* w, bool dp) {
     w->lam = lam;
     if (!w->have || !(lam > 0.0)) return TRK_OK;              // the caller's in-line branches (unassigned / not reachable yet)
     vect = 'P'; trans = 'N';
+  } else if (fixed) {                                           // (kind 4: lambda is the caller's number — no search)
+    lam = w->p[5];
+    w->lam = lam;
+    w->have = 1;
   } else {
     if (int rc = trk_host_gcv_bidiag(alpha, beta, k, b0, w->p[1], w->p[2], w->p[3], w->p[4], w->maxfun, &lam, nullptr, nullptr)) return rc;
     w->lam = lam;
@@ -1005,8 +1009,8 @@ void host_worker_main(trk_host_worker* w) {
       w->have = 1;
       w->rc = trk_host_gcv_bidiag(w->a.data(), w->b.data(), w->k, w->p[0], w->p[1], w->p[2], w->p[3], w->p[4], w->maxfun, &w->lam,
                                   nullptr, nullptr);
-    } else if (w->kind == 2 || w->kind == 3) {
-      w->rc = hess_job(w, w->kind == 3);
+    } else if (w->kind == 2 || w->kind == 3 || w->kind == 4) {
+      w->rc = hess_job(w, w->kind == 3, w->kind == 4);
     } else {
       w->rc = trk_host_dp_bidiag(w->a.data(), w->b.data(), w->k, w->c.data(), w->p[0], w->p[1], &w->lam, &w->have, nullptr, nullptr);
     }
@@ -1097,6 +1101,20 @@ extern "C" int trk_host_worker_post_hess_gcv(trk_host_worker* w, const double* H
   return host_worker_post(w, 2);
 }
 
+extern "C" int trk_host_worker_post_hess_fixed(trk_host_worker* w, const double* H, int64_t h_row_stride, int64_t h_col_stride, int k,
+                                               double beta0, double lam) {
+  TRK_REQUIRE(w && H && k >= 1 && lam >= 0.0, "trk_host_worker_post_hess_fixed: bad argument");
+  TRK_REQUIRE(w->gebrd && w->ormbr, "trk_host_worker_post_hess_fixed: trk_host_worker_set_lapack first");
+  TRK_REQUIRE(w->state.load() != 1, "trk_host_worker_post_hess_fixed: a job is still running (collect it first)");
+  const int n = k + 1;
+  w->H.resize((size_t)n * k);
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < n; ++i) w->H[(size_t)j * n + i] = H[i * h_row_stride + j * h_col_stride];
+  w->k = k;
+  w->p[0] = beta0; w->p[5] = lam;
+  return host_worker_post(w, 4);
+}
+
 extern "C" int trk_host_worker_post_hess_dp(trk_host_worker* w, const double* H, int64_t h_row_stride, int64_t h_col_stride, int k,
                                             double beta0, const double* bproj, double target, double extra) {
   TRK_REQUIRE(w && H && bproj && k >= 1, "trk_host_worker_post_hess_dp: bad argument");
@@ -1115,9 +1133,9 @@ extern "C" int trk_host_worker_post_hess_dp(trk_host_worker* w, const double* H,
 extern "C" int trk_host_worker_collect_vec(trk_host_worker* w, double* lam_out, int* have_out, double* y, int k, double* resid_out) {
   TRK_REQUIRE(w && lam_out && have_out && y && resid_out, "trk_host_worker_collect_vec: NULL argument");
   TRK_REQUIRE(w->state.load() != 0, "trk_host_worker_collect_vec: nothing was posted");
-  TRK_REQUIRE((w->kind == 2 || w->kind == 3) && k == w->k, "trk_host_worker_collect_vec: the posted job is not a Hessenberg job of this size");
+  TRK_REQUIRE((w->kind == 2 || w->kind == 3 || w->kind == 4) && k == w->k, "trk_host_worker_collect_vec: the posted job is not a Hessenberg job of this size");
   const int rc = trk_host_worker_collect(w, lam_out, have_out);
-  if (rc == TRK_OK && *have_out && (w->kind == 2 || *lam_out > 0.0)) {
+  if (rc == TRK_OK && *have_out && (w->kind != 3 || *lam_out > 0.0)) {
     for (int j = 0; j < k; ++j) y[j] = w->y[1 + j];
     *resid_out = w->resid;
   }
@@ -1166,8 +1184,15 @@ struct trk_hgmres {
   std::vector<double> y;
   hipStream_t stream;
   double t_wait_step = 0, t_enqueue = 0, t_collect = 0, t_post = 0, t_launch = 0;     // host seconds by phase (trk_hgmres_stats)
+  double fixed_lam = -1.0;                                                              // >= 0: the jobs solve with this lambda (no search)
 };
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+extern "C" int trk_hgmres_fixed_lambda(trk_hgmres* g, double lam) {
+  TRK_REQUIRE(g, "trk_hgmres_fixed_lambda: NULL handle");
+  g->fixed_lam = lam;                          // (< 0: back to gcv)
+  return TRK_OK;
+}
 
 extern "C" int trk_hgmres_stats(trk_hgmres* g, double* seconds5) {
   TRK_REQUIRE(g && seconds5, "trk_hgmres_stats: NULL argument");
@@ -1292,7 +1317,9 @@ extern "C" int trk_hgmres_iter(trk_hgmres* g, int absorb, int enqueue_next, int 
   if (post_job) {
     TRK_REQUIRE(g->k_abs >= 1 && g->posted.size() < nw, "trk_hgmres_iter: post_job needs a column of H and a free worker (collect first)");
     const int k = g->k_abs;
-    if (int rc = trk_host_worker_post_hess_gcv(g->ws[g->post_seq % nw], g->H.data(), 1, g->ldh, k, g->beta0, (double)k, 1e-9, 1e2, 1e-12, 1000))
+    if (g->fixed_lam >= 0.0) {
+      if (int rc = trk_host_worker_post_hess_fixed(g->ws[g->post_seq % nw], g->H.data(), 1, g->ldh, k, g->beta0, g->fixed_lam)) return rc;
+    } else if (int rc = trk_host_worker_post_hess_gcv(g->ws[g->post_seq % nw], g->H.data(), 1, g->ldh, k, g->beta0, (double)k, 1e-9, 1e2, 1e-12, 1000))
       return rc;
     g->posted.push_back(k - 1);
     ++g->post_seq;

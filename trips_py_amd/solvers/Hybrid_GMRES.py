@@ -55,8 +55,17 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
     # numeric regparam: the projected problem stays on the device (trk_hess_tikhonov appends the new column of H from the
     # sweep's scalars and solves the k x k normal equations) — nothing visits the host inside the loop; H and every y are
     # downloaded once at the end for `relResidual`
+    # ... unless the library's one-call-per-iteration loop runs (below: c_loop): then the projected problems are jobs of the host worker
+    # threads, with the caller's lambda instead of a search, and the device runs nothing but the Arnoldi steps and x = V y (the
+    # ~8 us k_hess_tikhonov left every iteration's critical path: 17-18 k -> 20 k iterations/s on the 512^2 blur)
+    c_ok = (kwargs.get("c_loop", True) and n_iter >= 2 and getattr(eng, "world", 1) == 1 and bool(getattr(A, "_h", None))
+            and _plain_handle_apply(A) and ar.by_gram and hasattr(eng, "cgs_coeffs") and hasattr(eng, "gemv_n_hosty")
+            and hasattr(getattr(eng, "lib", None), "trk_hgmres_create") and ar.V.data.stride(0) >= n
+            and (xt is None or err_fused) and HessenbergBidiag.available())
+    c_fixed = (c_ok and not isinstance(regparam, str) and float(regparam) >= 0.0 and kwargs.get("device_solve", True)
+               and (regparam > 0 or n_iter < eng.GRAM_TIKHONOV_MAX_K))
     on_dev = (not isinstance(regparam, str)) and hasattr(eng, "hess_tikhonov") and hasattr(eng, "cgs_coeffs") \
-        and 0 < n_iter and (regparam > 0 or n_iter < eng.GRAM_TIKHONOV_MAX_K) and kwargs.get("device_solve", True)
+        and 0 < n_iter and (regparam > 0 or n_iter < eng.GRAM_TIKHONOV_MAX_K) and kwargs.get("device_solve", True) and not c_fixed
     if on_dev:
         kmax = n_iter
         Hd = eng.scalars((kmax + 1) * kmax)          # column-major, column stride kmax + 1
@@ -164,9 +173,11 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
     Ph = np.zeros(n_iter + 2)
     # gcv, one rank, a plain library operator: the host side of an iteration is ONE library call (trk_hgmres_iter: absorb the step that
     # ran ahead, enqueue the next, collect the worker's answer for the iterate before, post this one, launch x = V y) — kwarg c_loop
-    c_loop = (async_gcv and kwargs.get("c_loop", True) and getattr(eng, "world", 1) == 1 and bool(getattr(A, "_h", None))
-              and _plain_handle_apply(A) and ar.by_gram and hasattr(eng, "cgs_coeffs") and hasattr(eng, "gemv_n_hosty")
-              and hasattr(getattr(eng, "lib", None), "trk_hgmres_create") and ar.V.data.stride(0) >= n and (xt is None or err_fused))
+    c_loop = (async_gcv and c_ok) or c_fixed
+    if c_fixed and searcher is None:
+        from .. import _lib
+        from .Hybrid_LSQR import _Searcher
+        searcher = _Searcher.borrow(_lib.load())
     pend = ar.step_prefetch() if (n_iter > 0 and not on_dev and not c_loop) else None
 
     def enqueue_proj(j0, j1):
@@ -313,6 +324,9 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             ref = xt.data_ptr() if xt is not None else None
             posted = []                                                  # iterates whose jobs the workers hold, oldest first
             from_k = max(2, int(kwargs.get("worker_from_k", WORKER_FROM_K)))
+            if c_fixed:                                                  # a number: no search, no flat minimum — every iterate but the first
+                from_k = 2
+                _lib.check(lib.trk_hgmres_fixed_lambda(drv, float(regparam)), "trk_hgmres_fixed_lambda")
 
             def one(absorb, more, post, collect):
                 nonlocal n_ep, x_dev
