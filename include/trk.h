@@ -287,7 +287,7 @@ int trk_hgmres_destroy(trk_hgmres* g);
 int trk_hgmres_start(trk_hgmres* g);
 int trk_hgmres_iter(trk_hgmres* g, int absorb, int enqueue_next, int post_job, float* x_done, const float* ref, double* err_partials,
                     int err_cap, int* done_ii, double* done_lam, double* done_resid, int* done_blocks);
-int trk_hgmres_H(trk_hgmres* g, double** H, int* ldh, int* columns);
+int trk_hgmres_hessenberg(trk_hgmres* g, double** H, int* ldh, int* columns);
 /* A numeric regparam: the jobs posted from now on solve with this lambda instead of searching (lam < 0: gcv again). */
 int trk_hgmres_fixed_lambda(trk_hgmres* g, double lam);
 /* host seconds spent so far: waiting for steps | enqueueing steps | waiting for workers | posting jobs | launching x = V y */

@@ -173,7 +173,12 @@ SIGNATURES = {
     "trk_hgmres_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl)]),
     "trk_hgmres_iter": (c_int, [ctypes.c_void_p, c_int, c_int, c_int, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int),
                                ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
-    "trk_hgmres_H": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.POINTER(c_dbl)), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "trk_hgmres_hessenberg": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.POINTER(c_dbl)), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "trk_arnoldi_step_post_at": (c_int, [c_op, c_f32p, c_i64, c_int, c_f32p, c_f64p, c_int, c_f64p, c_f64p, ctypes.c_void_p, c_int, c_int, c_int,
+                                        c_int, c_stream]),
+    "trk_mailbox_doubles": (c_int, [ctypes.c_void_p]),
+    "trk_mailbox_slots": (c_int, [ctypes.c_void_p]),
+    "trk_host_worker_post_hess_fixed": (c_int, [ctypes.c_void_p, ctypes.c_void_p, c_i64, c_i64, c_int, c_dbl, c_dbl]),
     "trk_arnoldi_step_post": (c_int, [c_op, c_f32p, c_i64, c_int, c_f32p, c_f64p, c_int, c_f64p, c_f64p, ctypes.c_void_p, c_int, c_int, c_int,
                                      c_stream]),
     "trk_tv_grad": (c_int, [c_op, c_f32p, c_f32p, c_f32p, c_dbl, c_f32p, c_stream]),

@@ -1242,8 +1242,8 @@ extern "C" int trk_hgmres_destroy(trk_hgmres* g) {
   return TRK_OK;
 }
 
-extern "C" int trk_hgmres_H(trk_hgmres* g, double** H, int* ldh, int* columns) {
-  TRK_REQUIRE(g && H && ldh && columns, "trk_hgmres_H: NULL argument");
+extern "C" int trk_hgmres_hessenberg(trk_hgmres* g, double** H, int* ldh, int* columns) {
+  TRK_REQUIRE(g && H && ldh && columns, "trk_hgmres_hessenberg: NULL argument");
   *H = g->H.data();
   *ldh = g->ldh;
   *columns = g->k_abs;

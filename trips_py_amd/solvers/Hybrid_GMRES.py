@@ -318,7 +318,7 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
         try:
             _lib.check(lib.trk_hgmres_start(drv), "trk_hgmres_start")
             Hp, ldh, ncol = ct.POINTER(ct.c_double)(), ct.c_int(), ct.c_int()
-            _lib.check(lib.trk_hgmres_H(drv, ct.byref(Hp), ct.byref(ldh), ct.byref(ncol)), "trk_hgmres_H")
+            _lib.check(lib.trk_hgmres_hessenberg(drv, ct.byref(Hp), ct.byref(ldh), ct.byref(ncol)), "trk_hgmres_hessenberg")
             Ht = np.ctypeslib.as_array(Hp, shape=(n_iter + 1, ldh.value))      # Ht[j, i] = H[i, j]: the library's array, filled as steps arrive
             d_ii, d_lam, d_res, d_blk = ct.c_int(), ct.c_double(), ct.c_double(), ct.c_int()
             ref = xt.data_ptr() if xt is not None else None
