@@ -185,6 +185,20 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
         searcher = _Searcher.borrow(eng.lib)
     waiting = None                           # the step whose lambda the worker is looking for
     clean = False
+    # B_k's entries (and U^T b in the left basis' scale) as float64 ARRAYS grown in place: the calls below take views of them — the lists
+    # of krylov.GKState converted to arrays four times per iteration were O(k) interpreter work each (20 us of a 70 us iteration at k = 100)
+    al_np, be_np, bp_np = np.empty(n_iter + 1), np.empty(n_iter + 1), np.empty(n_iter + 2)
+    n_ab, n_bp = 0, 0
+
+    def grow_host_arrays():
+        nonlocal n_ab, n_bp
+        while n_ab < len(gk._alphas):
+            al_np[n_ab], be_np[n_ab] = gk._alphas[n_ab], gk._betas[n_ab]
+            n_ab += 1
+        if gk.uproj is not None:
+            while n_bp < len(gk.uproj) and n_bp <= n_ab:                 # rows of U are beta_j u_j (beta_0 := beta0)
+                bp_np[n_bp] = gk.uproj[n_bp] / (gk.beta0 if n_bp == 0 else be_np[n_bp - 1])
+                n_bp += 1
 
     def form_iterate(k, lam):
         nonlocal nx_done, n_ep, x_dev
@@ -197,7 +211,7 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
             # automatic lambda: B_k is on the host already (lambda_k was chosen from it), and so is the projected solve — O(k) on a
             # CPU core, where one GPU lane spent 5-25 us on the dependent square roots and divisions of a recurrence that restarts
             # whenever lambda moves; the k coefficients reach the device in the arguments of the launch that forms x_k
-            yk = eng.host_bidiag_tikhonov(gk._alphas[:k], gk._betas[:k], gk.beta0, np.sqrt(lam), y_over_alpha=True)
+            yk = eng.host_bidiag_tikhonov(al_np[:k], be_np[:k], gk.beta0, np.sqrt(lam), y_over_alpha=True)
             x_dev = H.row(nx_done)
             if xt is not None:
                 n_ep = eng.gemv_n_hosty(gk.V.data, k, yk, x_dev, xt, EP.ref(n_ep * nx_done), 1024)
@@ -229,6 +243,7 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
                 while n_enq < n_iter and len(pending) < ahead:
                     pending.extend(gk.step_prefetch(project=ub_vec, more_follow=n_enq + 1 < n_iter))
                     n_enq += 1
+                grow_host_arrays()
             else:
                 # fixed lambda: nothing on the host needs B_k.  Iterates that nobody looks at are not formed and the step's last norm
                 # stays inside the operator (defer); when every iterate IS formed, step k+1 is enqueued BEFORE x_k — its adjoint kernel
@@ -281,10 +296,11 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
                     lam = searcher.collect()
                 # post the search for lambda_k first, then form the iterate of the step before it
                 if regparam == "gcv":
-                    searcher.post_gcv(gk._alphas[:k], gk._betas[:k], gk.beta0, m)
+                    searcher.post_gcv(al_np[:k], be_np[:k], gk.beta0, m)
                 else:
-                    bproj = np.asarray(gk.uproj[:k + 1]) / np.concatenate(([gk.beta0], gk._betas[:k]))   # rows of U are beta_j u_j
-                    searcher.post_dp(gk._alphas[:k], gk._betas[:k], bproj, kwargs.get("delta"), kwargs.get("eta", 1.01))
+                    if n_bp < k + 1:
+                        raise RuntimeError("Hybrid_LSQR: U^T b is behind the bidiagonal")
+                    searcher.post_dp(al_np[:k], be_np[:k], bp_np[:k + 1], kwargs.get("delta"), kwargs.get("eta", 1.01))
                 if waiting is not None:
                     form_iterate(waiting, lam)
                 waiting = k
