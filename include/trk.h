@@ -430,6 +430,16 @@ int trk_host_worker_post_gcv_bidiag(trk_host_worker* w, const double* alpha, con
 int trk_host_worker_post_dp_bidiag(trk_host_worker* w, const double* alpha, const double* beta_sub, int k, const double* bproj,
                                    double target, double extra);
 int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int* have_out);
+/* Hybrid-LSQR with automatic lambda (Hybrid_LSQR.py:80-110), the host's turn of an iteration in one call: collect the search posted by
+ * the call before (k_done > 0: the step it belongs to), post the search for step k_post (mode 0: trk_host_worker_post_gcv_bidiag with
+ * m_eff, the reference's bounds and tolerance; mode 1: trk_host_worker_post_dp_bidiag with target, extra and bproj), and with x_out != NULL
+ * solve step k_done's projected problem with the collected lambda (trk_host_bidiag_tikhonov, y over alpha) and launch x_out = V y
+ * (trk_gemv_n_hosty; ref, err_partials, err_cap, n_blocks as there).  alphas / betas / bproj: host arrays of B_k's entries, read before the
+ * call returns.  *have_out = 0 when nothing was collected or the search set no lambda (the caller's in-line branches). */
+int trk_hlsqr_select(trk_host_worker* w, int mode, const double* alphas, const double* betas, int k_post, double beta0,
+                     double m_eff_or_target, const double* bproj, double extra, int k_done, const float* V, int64_t ld, int64_t n,
+                     float* x_out, const float* ref, double* err_partials, int err_cap, int* n_blocks, double* lam_out, int* have_out,
+                     trk_stream stream);
 /* Hybrid-GMRES (Hybrid_GMRES.py:54-80): the WHOLE projected problem of iterate k as one job.  H: the (k+1) x k Arnoldi Hessenberg
  * matrix on the host, element (i, j) at H[i * h_row_stride + j * h_col_stride] (copied at post); beta0 = ||b||.  The job
  * bidiagonalises [beta0 e1 | H] with the CALLER's LAPACK (trk_host_worker_set_lapack: pointers to dgebrd and dormbr with the C

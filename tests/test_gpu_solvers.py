@@ -423,6 +423,37 @@ def test_hybrid_gmres_gcv_one_library_call_per_iteration_equals_the_python_loop(
     assert float(torch.linalg.norm(x2 - xc) / torch.linalg.norm(xc)) < 1e-6 and "relError" not in i2
 
 
+@pytest.mark.parametrize("reg", ["gcv", "dp"])
+@pytest.mark.parametrize("hist,with_xt", [(True, True), (False, True), (False, False)])
+def test_hybrid_lsqr_automatic_lambda_host_turn_in_one_library_call(reg, hist, with_xt):
+    """trk_hlsqr_select — collect lambda of the step before, post the search for this step, solve the projected problem and launch the
+    iterate: the host's turn of a Hybrid-LSQR iteration with gcv / the discrepancy principle in one call — against the four calls of the
+    interpreter's loop (one_call=False): the same lambdas to the bit (the same searches on the same worker), the same iterates."""
+    from trips_py_amd.operators import Radon2DParallel
+    from trips_py_amd.solvers import Hybrid_LSQR
+    N, na, its = 96, 40, 30
+    A = Radon2DParallel(N, np.linspace(0, np.pi, na, endpoint=False))
+    dev = A.engine.device
+    g = torch.Generator(device=dev).manual_seed(9)
+    xt = torch.rand(N * N, device=dev, generator=g)
+    b = A.apply(xt)
+    e = torch.randn(b.numel(), device=dev, generator=g)
+    delta = 0.01 * float(b.norm())
+    b = b + e * (delta / e.norm())
+    kw = {"delta": delta} if reg == "dp" else {}
+    assert hasattr(A.engine.lib, "trk_hlsqr_select")
+    x1, i1 = Hybrid_LSQR(A, b, its, reg, xt if with_xt else None, history=hist, **kw)
+    x0, i0 = Hybrid_LSQR(A, b, its, reg, xt if with_xt else None, history=hist, one_call=False, **kw)
+    assert i1["regParam_history"] == i0["regParam_history"] and len(i1["regParam_history"]) == its - 1
+    assert float(torch.linalg.norm(x1 - x0) / torch.linalg.norm(x0)) < 1e-6
+    if with_xt:
+        assert np.allclose(i1["relError"], i0["relError"], rtol=1e-6)
+    if hist is True:
+        for k in (0, its // 2, its - 2):
+            a, c = i1["xHistory"][k].reshape(-1), i0["xHistory"][k].reshape(-1)
+            assert float(torch.linalg.norm(a - c) / torch.linalg.norm(c)) < 1e-6, k
+
+
 def test_gks_gram_rows_from_v_equal_the_stored_images_form():
     """GKS on stencil operators keeps no AV / LV: G_A, G_L rows come from one sweep over V with A^T A v_new and L^T L v_new
     (trk_gemv_t2).  Same iterates and lambda history as the stored-images form, on the reference golden and on a 256^2 problem

@@ -1157,6 +1157,43 @@ extern "C" int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int*
   return rc;
 }
 
+// ------------------------------------------------------------------ Hybrid-LSQR with automatic lambda: the host's turn of an iteration
+// Hybrid_LSQR.py:80-110 as the engine runs it (the search for lambda_k on the worker thread, the iterate of the step before formed when its
+// lambda is collected): collect the search posted by the call before, post the search for step k_post (mode 0: gcv, 1: the discrepancy
+// principle; B_k's entries and U^T b are the caller's host arrays, read before this returns), and — when k_done > 0 and x_out != NULL —
+// solve the projected Tikhonov problem of step k_done with the collected lambda (trk_host_bidiag_tikhonov, y over alpha) and launch
+// x_out = V_{k_done} y with y in the kernel's arguments (trk_gemv_n_hosty; ref != NULL: with the error partials).  Four library calls and
+// three NumPy temporaries of the interpreter's loop in one.  *have_out = 0: nothing was collected (k_done == 0) or the search set no lambda.
+extern "C" int trk_hlsqr_select(trk_host_worker* w, int mode, const double* alphas, const double* betas, int k_post, double beta0,
+                                double m_eff_or_target, const double* bproj, double extra, int k_done, const float* V, int64_t ld,
+                                int64_t n, float* x_out, const float* ref, double* err_partials, int err_cap, int* n_blocks,
+                                double* lam_out, int* have_out, trk_stream stream) {
+  TRK_REQUIRE(w && alphas && betas && lam_out && have_out && n_blocks && k_post >= 0 && k_done >= 0, "trk_hlsqr_select: bad argument");
+  TRK_REQUIRE(mode == 0 || (mode == 1 && (bproj || k_post == 0)), "trk_hlsqr_select: mode 0 (gcv) or 1 (dp, with U^T b)");
+  *have_out = 0;
+  *n_blocks = 0;
+  double lam = 0.0;
+  int have = 0;
+  if (k_done > 0) {
+    if (int rc = trk_host_worker_collect(w, &lam, &have)) return rc;
+    *lam_out = lam;
+    *have_out = have;
+  }
+  if (k_post > 0) {
+    if (mode == 0) {
+      if (int rc = trk_host_worker_post_gcv_bidiag(w, alphas, betas, k_post, beta0, m_eff_or_target, 1e-9, 1e2, 1e-12, 1000)) return rc;
+    } else if (int rc = trk_host_worker_post_dp_bidiag(w, alphas, betas, k_post, bproj, m_eff_or_target, extra)) return rc;
+  }
+  if (k_done > 0 && have && x_out) {
+    TRK_REQUIRE(V && n >= 0 && ld >= n, "trk_hlsqr_select: x_out given without the basis");
+    static thread_local std::vector<double> y;
+    y.resize((size_t)k_done);
+    if (int rc = trk_host_bidiag_tikhonov(alphas, betas, k_done, beta0, sqrt(lam), 1, y.data())) return rc;
+    if (int rc = trk_gemv_n_hosty(V, ld, k_done, n, y.data(), x_out, ref, err_partials, err_cap, n_blocks, stream)) return rc;
+  }
+  return TRK_OK;
+}
+
 // ------------------------------------------------------------------ Hybrid-GMRES: the host side of one iteration in one call
 // Hybrid_GMRES.py:46-80 with regparam = 'gcv' as this library runs it: the Arnoldi steps run ahead on the stream (each posts its column
 // of H from its last kernel), iterate k's projected problem — bidiagonalisation of [beta0 e1 | H_k], the GCV search, the Tikhonov solve —

@@ -189,6 +189,14 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
     # of krylov.GKState converted to arrays four times per iteration were O(k) interpreter work each (20 us of a 70 us iteration at k = 100)
     al_np, be_np, bp_np = np.empty(n_iter + 1), np.empty(n_iter + 1), np.empty(n_iter + 2)
     n_ab, n_bp = 0, 0
+    # kwarg one_call (default on): the host's turn of an iteration as one library call (trk_hlsqr_select)
+    one_call = (searcher is not None and host_y and kwargs.get("one_call", True) and hasattr(getattr(eng, "lib", None), "trk_hlsqr_select")
+                and (regparam == "gcv" or kwargs.get("delta") is not None))
+    if one_call:
+        import ctypes as ct
+        from .. import _lib
+        c_nblk, c_lam, c_have = ct.c_int(0), ct.c_double(0.0), ct.c_int(0)
+        dp_target = float((kwargs.get("eta", 1.01) * kwargs["delta"]) ** 2) if regparam == "dp" else 0.0
 
     def grow_host_arrays():
         nonlocal n_ab, n_bp
@@ -290,6 +298,33 @@ def Hybrid_LSQR(A, b, n_iter=100, regparam="gcv", x_true=None, **kwargs):
                 continue
             if ii == 0:
                 lam = 0
+                continue
+            if searcher is not None and one_call:
+                # collect lambda of the step before, post the search for lambda_k, solve and launch the iterate of the step before: ONE
+                # library call (trk_hlsqr_select) for what the branch below does in four
+                kd = waiting if waiting is not None else 0
+                form = kd > 0 and (keep or xt is not None or kd >= n_iter)
+                row = H.row(nx_done) if form else None
+                if regparam == "dp" and n_bp < k + 1:
+                    raise RuntimeError("Hybrid_LSQR: U^T b is behind the bidiagonal")
+                _lib.check(eng.lib.trk_hlsqr_select(
+                    searcher.h, 0 if regparam == "gcv" else 1, al_np.ctypes.data, be_np.ctypes.data, k, float(gk.beta0),
+                    float(m) if regparam == "gcv" else dp_target, bp_np.ctypes.data, 0.0, kd, gk.V.data.data_ptr(), gk.V.data.stride(0), n,
+                    None if row is None else row.data_ptr(), None if (row is None or xt is None) else xt.data_ptr(),
+                    None if (row is None or xt is None) else EP.ref(n_ep * nx_done), 1024, ct.byref(c_nblk), ct.byref(c_lam), ct.byref(c_have),
+                    eng.stream()), "trk_hlsqr_select")
+                if kd > 0:
+                    if not c_have.value:
+                        raise RuntimeError("Hybrid_LSQR: the search on the worker thread set no lambda")
+                    lam = c_lam.value
+                    lams.append(lam)
+                    if form:
+                        x_dev = row
+                        if xt is not None:
+                            n_ep = c_nblk.value
+                        H.pushed(nx_done)
+                        nx_done += 1
+                waiting = k
                 continue
             if searcher is not None:
                 if waiting is not None:
