@@ -660,7 +660,7 @@ def extra_fanbeam(world):
         us = e0.elapsed_time(e1) / 20 * 1e3
         out[f"{name}_us"] = round(us, 1)
         out[f"{name}_Gsteps_per_s"] = round(out["ray_steps_per_apply"] / us * 1e-3, 1)
-    out["bound"] = "forward: texture addresser (one scattered 8-byte gather per ray-step: 16.6 cycles per wave-load); adjoint: vector-instruction issue (profiles/r04/fanbeam.txt)"
+    out["bound"] = "forward: texture addresser (one scattered 8-byte gather per ray-step: 16.6 cycles per wave-load); adjoint (round 6, k_fan_adj_views: 42 vector instructions per pixel and view, 59 before): the texture data path at 82 % (two scattered 16-byte records per pixel and view) next to the vector unit at 76 % (profiles/r06/fanbeam_adj_pmc.txt)"
     return out
 
 

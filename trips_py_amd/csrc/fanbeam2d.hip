@@ -51,6 +51,16 @@ struct FanRay {      // row-march form of one ray (index coordinates; see the he
 };
 constexpr int FAN_Q = 30;
 
+// The adjoint's per-view constants (round 6: k_fan_adj_views), folded on the host in float64 so that the locator of a pixel (column c,
+// row r) is  den = c nx + r nny + kd ,  lo = (c Ux + r Uy + Uklo) / den + kelo ,  hi = lo + dr2 / den  (+ 0.02 in the comparisons):
+// [lo, hi] = the detector interval whose rays can touch the pixel (uc -+ w of k_fan_adj_march), candidates ceil(lo) .. floor(hi).
+// Pairs {den's, lo's} side by side: one packed FMA forms both.
+struct FanAdjView {
+  float nx, Ux, nny, Uy;
+  float kd, Uklo, kelo, dr2;
+};
+static_assert(sizeof(FanAdjView) == 32, "two 16-byte LDS reads per view");
+
 struct FanImpl {
   int N, nd, na;
   float dsd;         // source-detector distance
@@ -65,6 +75,9 @@ struct FanImpl {
   int* cls_list;     // [na * nd] ray indices: the n_steep steep rays in table order, then the shallow ones
   int n_steep;
   float* band_part;  // [N / 64][na * nd]
+  FanAdjView* views; // [na] (adjoint, round 6)
+  int* view_cls;     // [na] 0: every ray of the view is steep (marching index = the pixel's row), 1: every ray shallow, 2: both kinds
+  int dense;         // 1: no pixel's interval is ever empty (2 w >= 1 everywhere: the reference's geometry)
 };
 
 // One marching step of a ray: column (row) cl and its right neighbour, with their weights as fractions of the segment length.
@@ -138,6 +151,8 @@ __global__ __launch_bounds__(256) void k_fan_pad_copies(const float* __restrict_
 
 typedef float fan_f2 __attribute__((ext_vector_type(2)));
 typedef unsigned u4f __attribute__((ext_vector_type(4)));
+typedef float f2v __attribute__((ext_vector_type(2)));
+typedef float f4r __attribute__((ext_vector_type(4)));
 
 // gridDim.y > 1: the march is cut into that many bands of `band` steps, band b leaving its sum (without the ray's length) in
 // part[b][ray] for k_fan_bands_sum — one thread per ray is 2 waves per SIMD at 512^2 x 180 x 724, too few to hide the gathers.
@@ -428,6 +443,8 @@ struct FanRec {
 };
 static_assert(sizeof(FanRec) == sizeof(FanRay), "the record array doubles as the forward's band partials: 16 bytes per ray");
 
+// NEG (k_fan_adj_views): x0m and m stored as ~x0m and -m — the kernel then forms ~a of its position word a directly (see there)
+template <bool NEG>
 __global__ __launch_bounds__(256) void k_fan_adj_prep(const float* __restrict__ sino, int64_t ld_sino, const FanRay* __restrict__ rays,
                                                       FanRec* __restrict__ recs, int nd, int na) {
   const int ndp = nd + 2 * FAN_RP;
@@ -439,9 +456,10 @@ __global__ __launch_bounds__(256) void k_fan_adj_prep(const float* __restrict__ 
     const int64_t k = (int64_t)a * nd + d;
     const FanRay q = rays[k];
     o.x0m = (q.x0_lo & ~1u) + (unsigned)(q.m < 0 ? q.m : 0);
+    if (NEG) o.x0m = ~o.x0m;
     const float iv = fan_inv32(q.m);
     o.inv32 = (q.x0_lo & 1u) ? -iv : iv;
-    o.m = q.m;
+    o.m = NEG ? -q.m : q.m;
     o.len_s = q.len * sino[(int64_t)blockIdx.y * ld_sino + k];
   }
   recs[(int64_t)blockIdx.y * na * ndp + i] = o;
@@ -547,6 +565,116 @@ __global__ __launch_bounds__(256) void k_fan_adj_march(float* __restrict__ img,
       const int dhi = min((int)floorf(v.hi), nd - 1);
       for (int d = max((int)v.clo, 0); d <= dhi; ++d) acc += weigh(fetch(a, d));
     }
+  }
+  img[(int64_t)blockIdx.y * ld_img + idx] = acc;
+}
+
+// Round 6: the same gather with the per-view work taken off the pixel.  k_fan_adj_march spent ~58 vector instructions per pixel and view
+// (96 % issue-bound): 17 on the locator, and per candidate 3 selects + 1 compare on the ray's class, an exec-mask branch around the
+// weighing (two s_nop and the mask bookkeeping), 2 on the record's address and ~13 on the weight itself.  Here
+//  (i)   the locator's constants are folded per view on the host (FanAdjView) and live in LDS (two broadcast ds_read_b128 per view): the
+//        pixel's {den, lo-numerator} are TWO packed FMAs, then a reciprocal, two FMAs, ceil, a conversion, a difference: 10 instructions;
+//  (ii)  a view's records are fetched through a buffer resource of THAT view's row: anything outside it reads zeros (a record of zeros
+//        weighs nothing), so the detector index needs no clamp;
+//  (iii) 70 % of the views (fan half angle 13 degrees: all but the views within it of a diagonal) hold rays of ONE class: marching index
+//        and wanted index are chosen once per view by a scalar condition, not per candidate;
+//  (iv)  the candidates are weighed without a branch — one outside the pixel's interval has its len_s replaced by 0 — and the weight
+//        enters the sum by one FMA; DENSE geometries (no empty interval) skip the first candidate's test;
+//  (v)   the records hold ~x0m and -m (k_fan_adj_prep<true>): with a = x0m + tt M - (want << 30) + 2^30 the position word of
+//        k_fan_adj_march (first column of the step for a in [2^30, 2^31), second for a in [0, 2^30)), na = ~a comes out of the same
+//        multiply-add, ~(a << 2) = (na << 2) | 3 is one v_lshl_or, "touches" is the sign of na and "second column" na >= 0xC0000000;
+//  (vi)  tt M (32-bit, a quarter-rate v_mul_lo_u32) as two 24-bit multiplies on the halves of M (SDWA word selects) and a shift-add.
+// The weights are k_fan_adj_march's to the bit (the same integers, the same clamped FMA); the sum differs by the FMA.
+template <bool DENSE>
+__global__ __launch_bounds__(256) void k_fan_adj_views(float* __restrict__ img, int64_t ld_img, int N, int nd, int na,
+                                                       const FanAdjView* __restrict__ views, const int* __restrict__ view_cls,
+                                                       const FanRec* __restrict__ recs) {
+  extern __shared__ __attribute__((aligned(16))) float vlds[];              // na x 8 floats
+  for (int i = threadIdx.x; i < 2 * na; i += 256)
+    reinterpret_cast<f4r*>(vlds)[i] = reinterpret_cast<const f4r*>(views)[i];
+  __syncthreads();
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)N * N) return;
+  const int r = (int)(idx / N), c = (int)(idx - (int64_t)r * N);
+  const f2v fc2 = {(float)c, (float)c}, fr2 = {(float)r, (float)r};
+  const int ndp = nd + 2 * FAN_RP;
+  const FanRec* __restrict__ rbase = recs + (int64_t)blockIdx.y * na * ndp;
+  const unsigned nwn_steep = ((unsigned)c - 1u) << FAN_Q, nwn_shallow = ((unsigned)r - 1u) << FAN_Q;     // -((1 - want) << 30)
+  float acc = 0.f;
+  struct Loc { float t, clo, hi; int d; };
+  auto locate = [&](int a) -> Loc {
+    const f4r A = reinterpret_cast<const f4r*>(vlds)[2 * a], K = reinterpret_cast<const f4r*>(vlds)[2 * a + 1];
+    const f2v P = __builtin_elementwise_fma(fc2, (f2v){A[0], A[1]}, __builtin_elementwise_fma(fr2, (f2v){A[2], A[3]}, (f2v){K[0], K[1]}));
+    const float rden = __builtin_amdgcn_rcpf(P[0]);
+    const float lo = fmaf(P[1], rden, K[2]);
+    Loc L;
+    L.clo = ceilf(lo);
+    L.hi = fmaf(K[3], rden, lo);                            // (without the 0.02 of slack: it sits in the comparisons)
+    L.t = L.clo - L.hi;                                     // <= 0.02: ceil(lo) is a candidate, <= -0.98: the next one too, <= -1.98: a third
+    L.d = (int)L.clo;
+    return L;
+  };
+  auto fetch = [&](int a, int d, int more) -> FanRec {
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(rbase + (int64_t)a * ndp), 0, (unsigned)(ndp * 16), 0x00020000);
+    const u4f t = __builtin_bit_cast(u4f, __builtin_amdgcn_raw_buffer_load_b128(rsrc, ((d + FAN_RP) << 4) + more * 16, 0, 0));
+    const unsigned t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3];
+    return FanRec{t0, __builtin_bit_cast(float, t1), (int)t2, __builtin_bit_cast(float, t3)};
+  };
+  // the weight of record q on this pixel times its len_s, added to acc; in: the candidate lies in the pixel's interval
+  auto weigh = [&](const FanRec& q, unsigned tt, unsigned nwn, bool in) {
+    unsigned p0, p1;
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(p0) : "v"(tt), "v"(q.m));
+    asm("v_mul_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(p1) : "v"(tt), "v"(q.m));
+    unsigned na_ = q.x0m + nwn + p0;                                          // ~a, but for the high half of the product
+    asm("v_lshl_add_u32 %0, %1, 16, %0" : "+v"(na_) : "v"(p1));
+    float f;
+    {
+      const float fd = (float)((na_ << (32 - FAN_Q)) | 3u);                   // ~(a << 2): fan_split with |inv32| (the sign is the class)
+      asm("v_fma_f32 %0, %1, |%2|, |%2| clamp" : "=v"(f) : "v"(fd), "v"(q.inv32));
+    }
+    const float s = na_ >= 0xC0000000u ? 1.f - f : f;
+    const float w = (in && (int)na_ < 0) ? q.len_s : 0.f;
+    acc = fmaf(s, w, acc);
+  };
+  auto weigh_any = [&](const FanRec& q, bool in) {                           // the ray's own class
+    const bool shallow = q.inv32 < 0.f;
+    weigh(q, shallow ? (unsigned)c : (unsigned)r, shallow ? nwn_shallow : nwn_steep, in);
+  };
+  constexpr int UA = 4;
+  int a = 0;
+  for (; a + UA <= na; a += UA) {
+    FanRec q[UA][2];
+    float t[UA];
+    int cls[UA];
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const Loc L = locate(a + u);
+      t[u] = L.t;
+      cls[u] = view_cls[a + u];                                               // (scalar load)
+      q[u][0] = fetch(a + u, L.d, 0);
+      q[u][1] = fetch(a + u, L.d, 1);
+      if (L.t <= -1.98f) {                                                    // a third candidate and beyond: rare (pixels near the source)
+        const int dhi = min((int)floorf(L.hi + 0.02f), nd - 1);
+        for (int d = max(L.d + 2, 0); d <= dhi; ++d) weigh_any(fetch(a + u, d, 0), true);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UA; ++u) {
+      const bool in0 = DENSE ? true : t[u] <= 0.02f, in1 = t[u] <= -0.98f;
+      if (cls[u] != 2) {                                                      // one class for the whole view: a scalar choice
+        const unsigned tt = cls[u] ? (unsigned)c : (unsigned)r, nwn = cls[u] ? nwn_shallow : nwn_steep;
+        weigh(q[u][0], tt, nwn, in0);
+        weigh(q[u][1], tt, nwn, in1);
+      } else {
+        weigh_any(q[u][0], in0);
+        weigh_any(q[u][1], in1);
+      }
+    }
+  }
+  for (; a < na; ++a) {
+    const Loc L = locate(a);
+    const int dhi = min((int)floorf(L.hi + 0.02f), nd - 1);
+    for (int d = max(L.d, 0); d <= dhi; ++d) weigh_any(fetch(a, d, 0), true);
   }
   img[(int64_t)blockIdx.y * ld_img + idx] = acc;
 }
@@ -710,9 +838,22 @@ int fan_apply(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
     const int64_t nrays = (int64_t)im->na * im->nd;
     dim3 grid(ceil_div((int64_t)im->N * im->N, 256), 1);
     for (int b = 0; b < batch; ++b) {                                      // one record array per handle: columns go one by one
-      hipLaunchKernelGGL(k_fan_adj_prep, dim3(ceil_div((int64_t)im->na * (im->nd + 2 * FAN_RP), 256), 1), dim3(256), 0, s, x + (int64_t)b * ldx, ldx,
-                         im->rays, reinterpret_cast<FanRec*>(im->recs), im->nd, im->na);
-      if (im->max_cand <= 3)
+      const bool old_form = getenv("TRK_FAN_ADJ_MARCH2") != nullptr;            // round 3-5's kernel, for comparison (read per call: tests switch it)
+      const bool by_views = im->max_cand <= 3 && im->views && !old_form && (size_t)im->na * sizeof(FanAdjView) <= 48 * 1024;
+      const dim3 pgrid(ceil_div((int64_t)im->na * (im->nd + 2 * FAN_RP), 256), 1);
+      if (by_views)
+        hipLaunchKernelGGL(k_fan_adj_prep<true>, pgrid, dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->rays, reinterpret_cast<FanRec*>(im->recs), im->nd, im->na);
+      else
+        hipLaunchKernelGGL(k_fan_adj_prep<false>, pgrid, dim3(256), 0, s, x + (int64_t)b * ldx, ldx, im->rays, reinterpret_cast<FanRec*>(im->recs), im->nd, im->na);
+      if (by_views) {
+        const size_t lds = (size_t)im->na * sizeof(FanAdjView);
+        if (im->dense)
+          hipLaunchKernelGGL(k_fan_adj_views<true>, grid, dim3(256), lds, s, y + (int64_t)b * ldy, ldy, im->N, im->nd, im->na, im->views,
+                             im->view_cls, reinterpret_cast<const FanRec*>(im->recs));
+        else
+          hipLaunchKernelGGL(k_fan_adj_views<false>, grid, dim3(256), lds, s, y + (int64_t)b * ldy, ldy, im->N, im->nd, im->na, im->views,
+                             im->view_cls, reinterpret_cast<const FanRec*>(im->recs));
+      } else if (im->max_cand <= 3)
         hipLaunchKernelGGL(k_fan_adj_march<2>, grid, dim3(256), 0, s, y + (int64_t)b * ldy, ldy, im->N, im->nd, im->na, im->dsd,
                            im->reach, im->ang_dev, reinterpret_cast<const FanRec*>(im->recs));
       else
@@ -741,6 +882,8 @@ void fan_destroy(trk_op* op) {
   if (im->xT) (void)hipFree(im->xT);
   if (im->cls_list) (void)hipFree(im->cls_list);
   if (im->band_part) (void)hipFree(im->band_part);
+  if (im->views) (void)hipFree(im->views);
+  if (im->view_cls) (void)hipFree(im->view_cls);
   delete im;
 }
 
@@ -770,7 +913,8 @@ extern "C" int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double s
     g.uys = (float)(st / det_pitch);
     h[a] = g;
   }
-  auto* im = new FanImpl{N, n_det, n_ang, (float)(sod + odd), (float)det_pitch, nullptr, nullptr, nullptr, nullptr, 0.f, 1 << 30, nullptr, 0, nullptr};
+  auto* im = new FanImpl{N, n_det, n_ang, (float)(sod + odd), (float)det_pitch, nullptr, nullptr, nullptr, nullptr, 0.f, 1 << 30, nullptr, 0, nullptr,
+                         nullptr, nullptr, 0};
   hipError_t e = hipMalloc(&im->ang_dev, sizeof(FanAngle) * n_ang);
   if (e == hipSuccess) e = hipMemcpy(im->ang_dev, h.data(), sizeof(FanAngle) * n_ang, hipMemcpyHostToDevice);
   // row-march table: needs every ray to cross the whole image, i.e. source and detector outside its circumscribed circle
@@ -827,6 +971,38 @@ extern "C" int trk_fanbeam2d_create(int N, int n_det, double det_pitch, double s
     im->reach = (float)(0.7072 / det_pitch * (1.0 + tan_max * tan_max) * 1.02);
     const double mag_max = (sod + odd) / (sod - 0.7072 * N);              // the pixel nearest to the source
     im->max_cand = (int)std::floor(2.0 * ((double)im->reach * mag_max * 1.001 + 0.01)) + 1;
+    // the adjoint's per-view constants (FanAdjView) and whether any pixel's interval can be empty
+    if (e == hipSuccess) {
+      const double dsd = sod + odd, reach = (double)im->reach;
+      std::vector<FanAdjView> vw(n_ang);
+      std::vector<int> vcls(n_ang);
+      for (int a = 0; a < n_ang; ++a) {
+        const double ct = std::cos(angles[a]), st = std::sin(angles[a]);
+        const double sx = sod * st, sy = -sod * ct, nx = -st, ny = ct;
+        const double d0x = -odd * st - 0.5 * (n_det - 1) * det_pitch * ct, d0y = odd * ct - 0.5 * (n_det - 1) * det_pitch * st;
+        const double uxs = ct / det_pitch, uys = st / det_pitch;
+        const double cx = 0.5 - half - sx, cy = half - 0.5 - sy;         // pixel centre minus source = (c + cx, -r + cy)
+        FanAdjView v{};
+        v.nx = (float)nx;
+        v.nny = (float)(-ny);
+        v.kd = (float)(cx * nx + cy * ny);
+        v.Ux = (float)(dsd * uxs);
+        v.Uy = (float)(-dsd * uys);
+        v.Uklo = (float)(dsd * (cx * uxs + cy * uys) - dsd * reach);
+        v.kelo = (float)((sx - d0x) * uxs + (sy - d0y) * uys - 0.01);
+        v.dr2 = (float)(2.0 * dsd * reach);
+        int n_sh = 0;
+        for (int d = 0; d < n_det; ++d) n_sh += (int)(rt[(size_t)a * n_det + d].x0_lo & 1u);
+        vcls[a] = n_sh == 0 ? 0 : (n_sh == n_det ? 1 : 2);
+        vw[a] = v;
+      }
+      const double den_max = sod + 0.7072 * N;                           // the pixel farthest from the source along the central ray
+      im->dense = 2.0 * (dsd * reach / den_max) >= 1.0 ? 1 : 0;          // (+ 0.02 of slack in the kernel's interval on top)
+      e = hipMalloc(&im->views, sizeof(FanAdjView) * n_ang);
+      if (e == hipSuccess) e = hipMemcpy(im->views, vw.data(), sizeof(FanAdjView) * n_ang, hipMemcpyHostToDevice);
+      if (e == hipSuccess) e = hipMalloc(&im->view_cls, sizeof(int) * n_ang);
+      if (e == hipSuccess) e = hipMemcpy(im->view_cls, vcls.data(), sizeof(int) * n_ang, hipMemcpyHostToDevice);
+    }
   }
   if (e != hipSuccess) {
     trk_op tmp{7, 0, 0, im, nullptr, nullptr, nullptr, 0};
