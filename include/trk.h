@@ -268,6 +268,12 @@ int trk_arnoldi_step_post(trk_op* op, float* V, int64_t ld, int k, float* w, dou
 /* ... to host[host_offset ..] instead (two steps in flight: a region of the mailbox per slot). */
 int trk_arnoldi_step_post_at(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
                              trk_mailbox* mb, int slot, int offset, int count, int host_offset, trk_stream stream);
+/* ... and S[dot_index] = <V[k], dotv> formed by the step's normalising pass — a place OUTSIDE [0, 1 + 2 kmax): S[1+k .. 1+2k) must stay zero
+ * for the steps to come — which reaches the host right behind the posted range, host[host_offset + count]: Hybrid-GMRES with the
+ * discrepancy principle wants V_{k+1}^T b, one new entry per step (Hybrid_GMRES.py:64-67 through discrepancy_principle.py:58). */
+int trk_arnoldi_step_post_dot(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
+                              trk_mailbox* mb, int slot, int offset, int count, int host_offset, const float* dotv, int dot_index,
+                              trk_stream stream);
 /* Hybrid-GMRES with regparam = 'gcv' (Hybrid_GMRES.py:46-80): the host side of one iteration in one call.  The handle keeps H (host,
  * column-major), runs the Arnoldi steps ahead on `stream` (trk_arnoldi_step_post into a mailbox of its own), hands iterate k's projected
  * problem to a worker thread (trk_host_worker_post_hess_gcv; `workers`: n_workers of them, set_lapack done, and `mb`, 2 slots and
@@ -290,6 +296,11 @@ int trk_hgmres_iter(trk_hgmres* g, int absorb, int enqueue_next, int post_job, f
 int trk_hgmres_hessenberg(trk_hgmres* g, double** H, int* ldh, int* columns);
 /* A numeric regparam: the jobs posted from now on solve with this lambda instead of searching (lam < 0: gcv again). */
 int trk_hgmres_fixed_lambda(trk_hgmres* g, double lam);
+/* regparam = 'dp': before trk_hgmres_start.  bvec: the right-hand side on the device (every step's normalising pass then takes
+ * <V[k], b>: trk_arnoldi_step_post_dot), bproj0 = <V[0], b>; the jobs are trk_host_worker_post_hess_dp(…, target, extra).  A collected
+ * job that set no positive lambda (the reference's unassigned / not-reachable-yet branches) is handed back: *done_blocks = -1, nothing
+ * launched — the caller solves that iterate itself from H and *bproj_out (V_{k+1}^T b so far, the handle's array). */
+int trk_hgmres_dp(trk_hgmres* g, const float* bvec, double bproj0, double target, double extra, double** bproj_out);
 /* host seconds spent so far: waiting for steps | enqueueing steps | waiting for workers | posting jobs | launching x = V y */
 int trk_hgmres_stats(trk_hgmres* g, double* seconds5);
 /* trk_gk_step (optionally with the projection of trk_gk_step_proj: proj != NULL) that also carries a mailbox post — the copy of

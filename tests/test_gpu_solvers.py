@@ -423,6 +423,35 @@ def test_hybrid_gmres_gcv_one_library_call_per_iteration_equals_the_python_loop(
     assert float(torch.linalg.norm(x2 - xc) / torch.linalg.norm(xc)) < 1e-6 and "relError" not in i2
 
 
+@pytest.mark.parametrize("N,its,noise", [(64, 30, 0.01), (128, 40, 0.05), (96, 20, 0.001)])
+def test_hybrid_gmres_discrepancy_principle_one_library_call_per_iteration(N, its, noise):
+    """regparam='dp' through trk_hgmres_iter: V_{k+1}^T b grows by the dot the step's normalising pass takes (k_scale_fin<DOT>: block
+    partials, the last workgroup adds them up and posts them with the step's scalars), the jobs are trk_host_worker_post_hess_dp, and a
+    job that sets no positive lambda comes back to the interpreter's branches — against the Python loop (c_loop=False): lambda history
+    to 1e-8 (the dots are summed in another order: 1e-16 of them), iterates, relError, relResidual."""
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import gauss_psf
+    from trips_py_amd.solvers import Hybrid_GMRES
+    A = Blur2D(gauss_psf((9, 9), (2, 2))[0], N, N)
+    dev = A.engine.device
+    g = torch.Generator(device=dev).manual_seed(N)
+    xt = torch.rand(N * N, device=dev, generator=g)
+    b = A.apply(xt)
+    e = torch.randn(N * N, device=dev, generator=g)
+    delta = noise * float(b.norm())
+    b = b + e * (delta / e.norm())
+    xc, ic = Hybrid_GMRES(A, b, its, "dp", xt, delta=delta)
+    xp, ip = Hybrid_GMRES(A, b, its, "dp", xt, delta=delta, c_loop=False)
+    assert len(ic["regParam_history"]) == len(ip["regParam_history"]) == its
+    assert np.allclose(ic["regParam_history"], ip["regParam_history"], rtol=1e-8, atol=1e-300)
+    assert np.allclose(ic["relResidual"], ip["relResidual"], rtol=1e-7)
+    assert np.allclose(ic["relError"], ip["relError"], rtol=1e-6)
+    assert float(torch.linalg.norm(xc - xp) / torch.linalg.norm(xp)) < 1e-6
+    for k in (0, 5, its // 2, its - 1):
+        a, c = ic["xHistory"][k].reshape(-1), ip["xHistory"][k].reshape(-1)
+        assert float(torch.linalg.norm(a - c) / torch.linalg.norm(c)) < 1e-6, k
+
+
 @pytest.mark.parametrize("reg", ["gcv", "dp"])
 @pytest.mark.parametrize("hist,with_xt", [(True, True), (False, True), (False, False)])
 def test_hybrid_lsqr_automatic_lambda_host_turn_in_one_library_call(reg, hist, with_xt):

@@ -172,11 +172,14 @@ SIGNATURES = {
                                  ctypes.POINTER(ctypes.c_void_p)]),
     "trk_hgmres_destroy": (c_int, [ctypes.c_void_p]),
     "trk_hgmres_start": (c_int, [ctypes.c_void_p]),
+    "trk_hgmres_dp": (c_int, [ctypes.c_void_p, c_f32p, c_dbl, c_dbl, c_dbl, ctypes.POINTER(ctypes.POINTER(c_dbl))]),
     "trk_hgmres_fixed_lambda": (c_int, [ctypes.c_void_p, c_dbl]),
     "trk_hgmres_stats": (c_int, [ctypes.c_void_p, ctypes.POINTER(c_dbl)]),
     "trk_hgmres_iter": (c_int, [ctypes.c_void_p, c_int, c_int, c_int, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int),
                                ctypes.POINTER(c_dbl), ctypes.POINTER(c_dbl), ctypes.POINTER(c_int)]),
     "trk_hgmres_hessenberg": (c_int, [ctypes.c_void_p, ctypes.POINTER(ctypes.POINTER(c_dbl)), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "trk_arnoldi_step_post_dot": (c_int, [c_op, c_f32p, c_i64, c_int, c_f32p, c_f64p, c_int, c_f64p, c_f64p, ctypes.c_void_p, c_int, c_int, c_int,
+                                         c_int, c_f32p, c_int, c_stream]),
     "trk_arnoldi_step_post_at": (c_int, [c_op, c_f32p, c_i64, c_int, c_f32p, c_f64p, c_int, c_f64p, c_f64p, ctypes.c_void_p, c_int, c_int, c_int,
                                         c_int, c_stream]),
     "trk_mailbox_doubles": (c_int, [ctypes.c_void_p]),

@@ -515,7 +515,7 @@ int trk_gk_step(trk_op* op, int k, const float* u_k, const float* v_prev, float*
 // by the workgroups of the launch whose last arriver runs the k x k recurrence (k_finalize_cgs), the norm by every workgroup of the
 // normalising pass (k_scale_fin); both in k_finalize's own association: the bits of the seven-kernel form (TRK_ARNOLDI_7=1 keeps it).
 static int arnoldi_step_impl(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
-                             const PostReq& post, hipStream_t s) {
+                             const PostReq& post, hipStream_t s, const float* dotv = nullptr, double* dot_out = nullptr) {
   const int64_t n = op->rows;
   const float* vk1 = V + (int64_t)(k - 1) * ld;
   float* vk = V + (int64_t)k * ld;
@@ -526,6 +526,13 @@ static int arnoldi_step_impl(trk_op* op, float* V, int64_t ld, int k, float* w, 
     if (int rc = trk_cgs_coeffs(G, ldg, W, W + k, k, 2, S + 1, s)) return rc;         // column k of H (without its last entry) at S[1..1+k)
     if (int rc = trk_gemv_n(V, ld, k, n, S + 1, 1.0, w, -1.0, vk, S, s)) return rc;   // V[k] = w - V c, S[0] = ||.||^2
     if (int rc = trk_axpby(n, 1.0, nullptr, S, TRK_SQRT_DEN, vk, 0.0, nullptr, nullptr, 0, nullptr, vk, nullptr, s)) return rc;
+    if (dotv) {
+      if (int rc = trk_dot(vk, dotv, n, dot_out, s)) return rc;
+      if (post.on && post.sum_host) {                    // (the seven-kernel form posts the dot by a launch of its own, ahead of the step's)
+        hipLaunchKernelGGL(k_mailbox_post, dim3(1), dim3(64), 0, s, (const double*)dot_out, post.sum_host, 1, post.seq, post.value - 1);
+        TRK_LAUNCH_CHECK();
+      }
+    }
     if (post.on) {
       hipLaunchKernelGGL(k_mailbox_post, dim3(1), dim3(64), 0, s, post.src, post.dst, post.count, post.seq, post.value);
       TRK_LAUNCH_CHECK();
@@ -537,7 +544,7 @@ static int arnoldi_step_impl(trk_op* op, float* V, int64_t ld, int k, float* w, 
   if (int rc = gemv_t2_partials(V, ld, k, n, w, vk1, &part, &nblk, s)) return rc;
   if (int rc = finalize_cgs(part, nblk, k, W, G, ldg, 2, S + 1, s)) return rc;
   if (int rc = gemv_n_partials(V, ld, k, n, S + 1, 1.0, w, -1.0, vk, &part, &nblk, s)) return rc;
-  return scale_by_partials(n, part, nblk, vk, vk, S, post, s);
+  return scale_by_partials(n, part, nblk, vk, vk, S, post, s, dotv, dot_out);
 }
 
 int trk_arnoldi_step(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S, trk_stream stream) {
@@ -556,6 +563,13 @@ int trk_arnoldi_step_post(trk_op* op, float* V, int64_t ld, int k, float* w, dou
 // ... to host[host_offset ..] (a caller that keeps two steps in flight gives each slot a region of its own)
 int trk_arnoldi_step_post_at(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
                              trk_mailbox* mb, int slot, int offset, int count, int host_offset, trk_stream stream) {
+  return trk_arnoldi_step_post_dot(op, V, ld, k, w, G, ldg, W, S, mb, slot, offset, count, host_offset, nullptr, 0, stream);
+}
+
+// ... with S[dot_index] = <V[k], dotv> taken by the normalising pass and posted with the rest (dotv = NULL: no dot)
+int trk_arnoldi_step_post_dot(trk_op* op, float* V, int64_t ld, int k, float* w, double* G, int ldg, double* W, double* S,
+                              trk_mailbox* mb, int slot, int offset, int count, int host_offset, const float* dotv, int dot_index,
+                              trk_stream stream) {
   TRK_REQUIRE(op && V && w && G && W && S && k >= 1 && ldg >= k, "trk_arnoldi_step_post: bad argument");
   TRK_REQUIRE(op->rows == op->cols && ld >= op->rows, "trk_arnoldi_step_post: square operator, ld >= n");
   TRK_REQUIRE(mb && slot >= 0 && slot < mb->slots, "trk_arnoldi_step_post: bad mailbox / slot");
@@ -569,7 +583,14 @@ int trk_arnoldi_step_post_at(trk_op* op, float* V, int64_t ld, int k, float* w, 
   q.count = count;
   q.seq = mb->seq + slot;
   q.value = mb->expect[slot];
-  return arnoldi_step_impl(op, V, ld, k, w, G, ldg, W, S, q, (hipStream_t)stream);
+  if (dotv) {
+    // the dot lives OUTSIDE the step's scalar ranges on the device (S[1+k .. 1+2k) must stay zero for the steps to come) and lands
+    // right behind the posted range on the host
+    TRK_REQUIRE(dot_index >= 0 && host_offset + count + 1 <= mb->n, "trk_arnoldi_step_post_dot: no room behind the posted range for the dot");
+    q.sum_dev = S + dot_index;
+    q.sum_host = mb->host + host_offset + count;
+  }
+  return arnoldi_step_impl(op, V, ld, k, w, G, ldg, W, S, q, (hipStream_t)stream, dotv, dotv ? S + dot_index : nullptr);
 }
 
 int trk_gk_step_proj(trk_op* op, int k, const float* u_k, const float* v_prev, float* v_k, float* u_next, double* AB, int chained,

@@ -1222,12 +1222,27 @@ struct trk_hgmres {
   hipStream_t stream;
   double t_wait_step = 0, t_enqueue = 0, t_collect = 0, t_post = 0, t_launch = 0;     // host seconds by phase (trk_hgmres_stats)
   double fixed_lam = -1.0;                                                              // >= 0: the jobs solve with this lambda (no search)
+  // the discrepancy principle: V_{k+1}^T b grows by one entry per step (taken by the step's normalising pass, posted with its scalars)
+  const float* bvec = nullptr;
+  std::vector<double> bproj;
+  double dp_target = 0.0, dp_extra = 0.0;
 };
 static inline double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 extern "C" int trk_hgmres_fixed_lambda(trk_hgmres* g, double lam) {
   TRK_REQUIRE(g, "trk_hgmres_fixed_lambda: NULL handle");
   g->fixed_lam = lam;                          // (< 0: back to gcv)
+  return TRK_OK;
+}
+
+extern "C" int trk_hgmres_dp(trk_hgmres* g, const float* bvec, double bproj0, double target, double extra, double** bproj_out) {
+  TRK_REQUIRE(g && bvec && g->k_enq == 0, "trk_hgmres_dp: before trk_hgmres_start, with the right-hand side on the device");
+  g->bvec = bvec;
+  g->bproj.assign((size_t)g->cap + 2, 0.0);
+  g->bproj[0] = bproj0;
+  g->dp_target = target;
+  g->dp_extra = extra;
+  if (bproj_out) *bproj_out = g->bproj.data();
   return TRK_OK;
 }
 
@@ -1291,8 +1306,8 @@ extern "C" int trk_hgmres_hessenberg(trk_hgmres* g, double** H, int* ldh, int* c
 static int hgmres_enqueue(trk_hgmres* g) {
   const int k = g->k_enq + 1;
   TRK_REQUIRE(k <= g->cap, "trk_hgmres: more steps than the basis was planned for");
-  if (int rc = trk_arnoldi_step_post_at(g->op, g->V, g->ld, k, g->w, g->G, g->ldg, g->W, g->S, g->mb, k & 1, 0, 1 + 2 * k,
-                                        (k & 1) * (2 * g->cap + 4), g->stream))
+  if (int rc = trk_arnoldi_step_post_dot(g->op, g->V, g->ld, k, g->w, g->G, g->ldg, g->W, g->S, g->mb, k & 1, 0, 1 + 2 * k,
+                                         (k & 1) * (2 * g->cap + 4), g->bvec, 2 * g->cap + 2, g->stream))
     return rc;
   g->k_enq = k;
   return TRK_OK;
@@ -1332,6 +1347,7 @@ extern "C" int trk_hgmres_iter(trk_hgmres* g, int absorb, int enqueue_next, int 
     double* col = g->H.data() + (size_t)(k - 1) * g->ldh;
     for (int i = 0; i < k; ++i) col[i] = h[1 + i] + h[1 + k + i];
     col[k] = sqrt(h[0]);
+    if (g->bvec) g->bproj[k] = h[1 + 2 * k];
     g->k_abs = k;
   }
   double t1 = now_s();
@@ -1345,16 +1361,24 @@ extern "C" int trk_hgmres_iter(trk_hgmres* g, int absorb, int enqueue_next, int 
     int have = 0;
     done = g->posted.front();
     if (int rc = trk_host_worker_collect_vec(g->ws[g->collect_seq % nw], done_lam, &have, g->y.data(), done + 1, done_resid)) return rc;
-    TRK_REQUIRE(have, "trk_hgmres_iter: the worker returned no lambda");
     g->posted.pop_front();
     ++g->collect_seq;
+    if (!have || (g->bvec && !(*done_lam > 0.0))) {        // the discrepancy principle's "unassigned / not reachable yet": the caller's branch
+      TRK_REQUIRE(g->bvec, "trk_hgmres_iter: the worker returned no lambda");
+      *done_ii = done;
+      *done_blocks = -1;
+      done = -1;
+    }
   }
   g->t_collect += now_s() - t1;
   t1 = now_s();
   if (post_job) {
     TRK_REQUIRE(g->k_abs >= 1 && g->posted.size() < nw, "trk_hgmres_iter: post_job needs a column of H and a free worker (collect first)");
     const int k = g->k_abs;
-    if (g->fixed_lam >= 0.0) {
+    if (g->bvec) {
+      if (int rc = trk_host_worker_post_hess_dp(g->ws[g->post_seq % nw], g->H.data(), 1, g->ldh, k, g->beta0, g->bproj.data(), g->dp_target, g->dp_extra))
+        return rc;
+    } else if (g->fixed_lam >= 0.0) {
       if (int rc = trk_host_worker_post_hess_fixed(g->ws[g->post_seq % nw], g->H.data(), 1, g->ldh, k, g->beta0, g->fixed_lam)) return rc;
     } else if (int rc = trk_host_worker_post_hess_gcv(g->ws[g->post_seq % nw], g->H.data(), 1, g->ldh, k, g->beta0, (double)k, 1e-9, 1e2, 1e-12, 1000))
       return rc;

@@ -385,7 +385,7 @@ int gemv_t2_partials(const float* V, int64_t ld, int k, int64_t n, const float* 
 int gemv_n_partials(const float* V, int64_t ld, int k, int64_t n, const double* y, double a, const float* base, double sc, float* out,
                     double** part, int* nblk, hipStream_t s);
 int scale_by_partials(int64_t n, const double* part, int nblk, const float* x, float* out, double* sum_out, const PostReq& post,
-                      hipStream_t s);
+                      hipStream_t s, const float* dotv = nullptr, double* dot_out = nullptr);   // dotv: also *dot_out = <out, dotv>, posted with the rest
 // projected.hip: finalize of the 2k sums of gemv_t2_partials and trk_cgs_coeffs(G, ldg, W, W + k, k, passes, c) in one launch
 int finalize_cgs(const double* part, int nblk, int k, double* W, double* G, int ldg, int passes, double* c, hipStream_t s);
 // blur2d.hip: sizes and device pointers to the separable weights [kw row weights | kh column weights] of a blur handle

@@ -2628,11 +2628,16 @@ int trk::gemv_n_partials(const float* V, int64_t ld, int k, int64_t n, const dou
 // out = x / sqrt(S), S = the sum of nblk block partials added up by every workgroup as k_finalize would (finalize_block_256: the same
 // bits as the finalize launch + trk_axpby(1 / sqrt(*S)) pair it replaces); workgroup 0 leaves S in *sum_out and carries the mailbox
 // post, if any (PostReq: its scalars are final here — *sum_out is the last one).
-template <bool VEC>
+// DOT: the pass also takes <out, dotv> (Hybrid-GMRES with the discrepancy principle wants V_{k+1}^T b, one new entry per step): block
+// partials stored write-through, a ticket per workgroup, and the workgroup that draws the LAST one adds them up (k_finalize's order, loads
+// past the caches), stores the sum in *dot_out and carries the post instead of workgroup 0 — the dot travels with it (PostReq::sum_host).
+template <bool VEC, bool DOT>
 __global__ __launch_bounds__(NT) void k_scale_fin(int64_t n, const double* __restrict__ part, int nblk, const float* x, float* out,
-                                                  double* sum_out, const PostReq pq) {
+                                                  double* sum_out, const PostReq pq, const float* __restrict__ dotv, double* dot_part,
+                                                  unsigned* cnt, double* dot_out) {
   __shared__ double lds[NT / 64];
-  __shared__ double bc;
+  __shared__ double bc, bd;
+  __shared__ unsigned ticket;
   const double S = finalize_block_256(part, nblk, 1, lds);
   if (threadIdx.x == 0) {
     bc = S;
@@ -2644,6 +2649,7 @@ __global__ __launch_bounds__(NT) void k_scale_fin(int64_t n, const double* __res
   const float a = (float)cv;
   const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
   int64_t tail0 = 0;
+  double acc = 0.0;
   if (VEC) {
     const int64_t n4 = n >> 2;
     tail0 = n4 << 2;
@@ -2654,25 +2660,83 @@ __global__ __launch_bounds__(NT) void k_scale_fin(int64_t n, const double* __res
       o.z = a * v.z;
       o.w = a * v.w;
       st4(out, i, o);
+      if (DOT) {
+        const float4 bv = ld4(dotv, i);
+        acc += (double)o.x * bv.x + (double)o.y * bv.y + (double)o.z * bv.z + (double)o.w * bv.w;
+      }
     }
   }
-  for (int64_t i = tail0 + tid; i < n; i += nth) out[i] = a * x[i];
-  if (pq.on && blockIdx.x == 0 && threadIdx.x < 64) {          // one wave: its lanes move in step, the publication follows the copies
+  for (int64_t i = tail0 + tid; i < n; i += nth) {
+    const float o = a * x[i];
+    out[i] = o;
+    if (DOT) acc += (double)o * dotv[i];
+  }
+  bool poster = blockIdx.x == 0;
+  if (DOT) {
+    acc = block_sum<NT>(acc, lds);
+    if (threadIdx.x == 0) {
+      asm volatile("global_store_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" ::"v"(dot_part + blockIdx.x), "v"(acc) : "memory");
+      ticket = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    poster = ticket == gridDim.x - 1;
+    if (!poster) return;
+    if (threadIdx.x == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // for the next launch
+    double v0 = 0.0, v1 = 0.0, v2 = 0.0, v3 = 0.0;        // finalize_block_256's association, the partials loaded past the caches
+    auto ldp = [&](int bb) -> double {
+      double t;
+      asm volatile("global_load_dwordx2 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(t) : "v"(dot_part + bb) : "memory");
+      return t;
+    };
+    int bb = threadIdx.x;
+    const int nb = (int)gridDim.x;
+    for (; bb + 768 < nb; bb += 1024) {
+      v0 += ldp(bb);
+      v1 += ldp(bb + 256);
+      v2 += ldp(bb + 512);
+      v3 += ldp(bb + 768);
+    }
+    for (; bb < nb; bb += 256) v0 += ldp(bb);
+    const double D = block_sum<NT>((v0 + v1) + (v2 + v3), lds);
+    if (threadIdx.x == 0) {
+      bd = D;
+      *dot_out = D;
+    }
+    __syncthreads();
+  }
+  if (pq.on && poster && threadIdx.x < 64) {                    // one wave: its lanes move in step, the publication follows the copies
     for (int c = threadIdx.x; c < pq.count; c += 64) {
       const double* sp = pq.src + c;
       pq.dst[c] = (sp == sum_out) ? bc : *sp;
     }
+    if (DOT && pq.sum_host && threadIdx.x == 0) *pq.sum_host = bd;       // the dot: its own place on the host (PostReq::sum_host)
     __threadfence_system();
     if (threadIdx.x == 0) __hip_atomic_store(pq.seq, pq.value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
 
 int trk::scale_by_partials(int64_t n, const double* part, int nblk, const float* x, float* out, double* sum_out, const PostReq& post,
-                           hipStream_t s) {
-  TRK_REQUIRE(part && nblk >= 1 && x && out && sum_out && n >= 0, "scale_by_partials: bad argument");
+                           hipStream_t s, const float* dotv, double* dot_out) {
+  TRK_REQUIRE(part && nblk >= 1 && x && out && sum_out && n >= 0 && (!dotv || dot_out), "scale_by_partials: bad argument");
   const int grid = stream_grid(n);
-  if (aligned16(x) && aligned16(out)) hipLaunchKernelGGL((k_scale_fin<true>), dim3(grid), dim3(NT), 0, s, n, part, nblk, x, out, sum_out, post);
-  else hipLaunchKernelGGL((k_scale_fin<false>), dim3(grid), dim3(NT), 0, s, n, part, nblk, x, out, sum_out, post);
+  const bool vec = aligned16(x) && aligned16(out) && (!dotv || aligned16(dotv));
+  if (dotv) {
+    unsigned* cnt = nullptr;
+    if (int rc = stream_ticket(s, &cnt)) return rc;
+    // the dot's partials behind the norm's in the stream's scratch (`part` is its start: gemv_n_partials left nblk doubles there)
+    double* base = nullptr;
+    if (int rc = scratch_doubles(s, (size_t)nblk + (size_t)grid, &base)) return rc;
+    TRK_REQUIRE(base == part, "scale_by_partials: the norm's partials are not at the start of the stream's scratch");
+    double* dpart = base + nblk;
+    if (vec) hipLaunchKernelGGL((k_scale_fin<true, true>), dim3(grid), dim3(NT), 0, s, n, part, nblk, x, out, sum_out, post, dotv, dpart, cnt, dot_out);
+    else hipLaunchKernelGGL((k_scale_fin<false, true>), dim3(grid), dim3(NT), 0, s, n, part, nblk, x, out, sum_out, post, dotv, dpart, cnt, dot_out);
+  } else {
+    const float* nof = nullptr;
+    double* nod = nullptr;
+    unsigned* noc = nullptr;
+    if (vec) hipLaunchKernelGGL((k_scale_fin<true, false>), dim3(grid), dim3(NT), 0, s, n, part, nblk, x, out, sum_out, post, nof, nod, noc, nod);
+    else hipLaunchKernelGGL((k_scale_fin<false, false>), dim3(grid), dim3(NT), 0, s, n, part, nblk, x, out, sum_out, post, nof, nod, noc, nod);
+  }
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }

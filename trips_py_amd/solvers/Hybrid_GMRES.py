@@ -142,6 +142,15 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
         k = ii + 1
         lams.append(lam)
         res.append(r)
+        if c_loop:                                 # (the one-call loop: every iterate through the same kernel and partial count)
+            yk = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
+            x_dev = Hs.row(ii)
+            if err_fused:
+                n_ep = eng.gemv_n_hosty(ar.V.data, k, yk, x_dev, xt, EP.ref(n_ep * ii), 1024)
+            else:
+                eng.gemv_n_hosty(ar.V.data, k, yk, x_dev)
+            Hs.pushed(ii)
+            return
         Y.set(0, y)
         x_dev = Hs.row(ii)
         if err_fused:
@@ -173,7 +182,8 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
     Ph = np.zeros(n_iter + 2)
     # gcv, one rank, a plain library operator: the host side of an iteration is ONE library call (trk_hgmres_iter: absorb the step that
     # ran ahead, enqueue the next, collect the worker's answer for the iterate before, post this one, launch x = V y) — kwarg c_loop
-    c_loop = (async_gcv and c_ok) or c_fixed
+    c_dp = c_ok and dp_async and kwargs.get("delta") is not None
+    c_loop = (async_gcv and c_ok) or c_fixed or c_dp
     if c_fixed and searcher is None:
         from .. import _lib
         from .Hybrid_LSQR import _Searcher
@@ -316,7 +326,6 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             eng._mailbox_give(cap_mb, mb, mb_view)
             raise
         try:
-            _lib.check(lib.trk_hgmres_start(drv), "trk_hgmres_start")
             Hp, ldh, ncol = ct.POINTER(ct.c_double)(), ct.c_int(), ct.c_int()
             _lib.check(lib.trk_hgmres_hessenberg(drv, ct.byref(Hp), ct.byref(ldh), ct.byref(ncol)), "trk_hgmres_hessenberg")
             Ht = np.ctypeslib.as_array(Hp, shape=(n_iter + 1, ldh.value))      # Ht[j, i] = H[i, j]: the library's array, filled as steps arrive
@@ -327,6 +336,17 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
             if c_fixed:                                                  # a number: no search, no flat minimum — every iterate but the first
                 from_k = 2
                 _lib.check(lib.trk_hgmres_fixed_lambda(drv, float(regparam)), "trk_hgmres_fixed_lambda")
+            bp = None
+            if c_dp:
+                # V_{k+1}^T b: the first entry here, every further one by the step's own normalising pass (trk_arnoldi_step_post_dot)
+                eng.dot(ar.V[0], bv, P.ref(0))
+                bpp = ct.POINTER(ct.c_double)()
+                _lib.check(lib.trk_hgmres_dp(drv, bv.data_ptr(), float(P.host(0, 1)[0]), float((kwargs.get("eta", 1.01) * kwargs["delta"]) ** 2),
+                                             0.0, ct.byref(bpp)), "trk_hgmres_dp")
+                bp = np.ctypeslib.as_array(bpp, shape=(n_iter + 2,))
+                from_k = BIDIAG_FROM_K
+
+            _lib.check(lib.trk_hgmres_start(drv), "trk_hgmres_start")
 
             def one(absorb, more, post, collect):
                 nonlocal n_ep, x_dev
@@ -338,6 +358,9 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
                 if collect:
                     if d_ii.value != jj:
                         raise RuntimeError("trk_hgmres_iter: the collected iterate is not the oldest one posted")
+                    if d_blk.value < 0:                                  # dp: no positive lambda from the worker — the reference's other branches, here
+                        dp_inline(jj, jj + 1, np.ascontiguousarray(Ht[:jj + 1, :jj + 2].T), bp[:jj + 2].copy())
+                        return
                     lams.append(d_lam.value)
                     res.append(d_res.value)
                     if err_fused:
@@ -352,18 +375,17 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
                 if post:
                     posted.append(ii)
                 if not post:                                             # the first iterates: in this thread (SVD route), as before
-                    lam_k, y, r = projected(k, Ht[:k, :k + 1].T, ii == 0)
-                    lams.append(lam_k)
-                    res.append(r)
-                    x_dev = Hs.row(ii)
-                    yk = np.ascontiguousarray(y, dtype=np.float64).reshape(-1)
-                    if err_fused:
-                        n_ep = eng.gemv_n_hosty(ar.V.data, k, yk, x_dev, xt, EP.ref(n_ep * ii), 1024)
+                    # (row-major copies: the layout the Python loop hands to LAPACK — the discrepancy principle's lambda is ill-conditioned
+                    #  enough at small k for a transposed input's other rounding to show at 1e-6)
+                    Hk = np.ascontiguousarray(Ht[:k, :k + 1].T)
+                    if c_dp:
+                        dp_inline(ii, k, Hk, bp[:k + 1].copy())
                     else:
-                        eng.gemv_n_hosty(ar.V.data, k, yk, x_dev)
-                    Hs.pushed(ii)
+                        form(ii, *projected(k, Hk, ii == 0))
             while posted:
                 one(0, 0, 0, True)
+            if "debug_bproj" in kwargs and bp is not None:
+                kwargs["debug_bproj"][:] = list(bp[:n_iter + 1])
             if "host_phases" in kwargs:                                  # (a list the caller wants the library's phase timers in)
                 t5 = (ct.c_double * 5)()
                 lib.trk_hgmres_stats(drv, t5)
