@@ -344,7 +344,7 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
                 _lib.check(lib.trk_hgmres_dp(drv, bv.data_ptr(), float(P.host(0, 1)[0]), float((kwargs.get("eta", 1.01) * kwargs["delta"]) ** 2),
                                              0.0, ct.byref(bpp)), "trk_hgmres_dp")
                 bp = np.ctypeslib.as_array(bpp, shape=(n_iter + 2,))
-                from_k = BIDIAG_FROM_K
+                from_k = max(2, int(kwargs.get("worker_from_k", BIDIAG_FROM_K)))   # (from 2: measured, no gain — the early iterates come back unassigned)
 
             _lib.check(lib.trk_hgmres_start(drv), "trk_hgmres_start")
 
@@ -384,8 +384,6 @@ def Hybrid_GMRES(A, b, n_iter, regparam="gcv", x_true=None, **kwargs):
                         form(ii, *projected(k, Hk, ii == 0))
             while posted:
                 one(0, 0, 0, True)
-            if "debug_bproj" in kwargs and bp is not None:
-                kwargs["debug_bproj"][:] = list(bp[:n_iter + 1])
             if "host_phases" in kwargs:                                  # (a list the caller wants the library's phase timers in)
                 t5 = (ct.c_double * 5)()
                 lib.trk_hgmres_stats(drv, t5)
