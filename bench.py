@@ -620,21 +620,23 @@ def extra_hybrid_blur(world):
     x = torch.rand(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(0))
     b = A.apply(x)
     e = torch.randn(N * N, device=dev, generator=torch.Generator(device=dev).manual_seed(1))
-    b = b + e * (0.01 * float(b.norm()) / e.norm())
+    delta = 0.01 * float(b.norm())
+    b = b + e * (delta / e.norm())
     out = {"problem": "512x512 Gaussian blur 9x9 sigma 3, 1% noise, 60 iterations per solve, x_true given"}
     for name, solver in (("hybrid_gmres", Hybrid_GMRES), ("hybrid_lsqr", Hybrid_LSQR)):
-        for reg in (1e-2, "gcv"):
-            solver(A, b, 5, reg, x)
-            solver(A, b, 60, reg, x)
+        for reg in (1e-2, "gcv", "dp"):
+            kw = {"delta": delta} if reg == "dp" else {}
+            solver(A, b, 5, reg, x, **kw)
+            solver(A, b, 60, reg, x, **kw)
             torch.cuda.synchronize()
             barrier(world)
             t0 = time.perf_counter()
             for _ in range(3):
-                solver(A, b, 60, reg, x)
+                solver(A, b, 60, reg, x, **kw)
             torch.cuda.synchronize()
             barrier(world)
             dt = max_over_ranks(time.perf_counter() - t0, world) / 3
-            out[f"{name}_{'fixed_lambda' if reg != 'gcv' else 'gcv'}_iters_per_sec_all_ranks"] = round(world * 60 / dt, 1)
+            out[f"{name}_{'fixed_lambda' if not isinstance(reg, str) else reg}_iters_per_sec_all_ranks"] = round(world * 60 / dt, 1)
     return out
 
 
