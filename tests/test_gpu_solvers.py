@@ -392,6 +392,35 @@ def test_hybrid_gmres_device_projected_solve_equals_the_host_one(N, its):
             assert float(torch.linalg.norm(a - c) / torch.linalg.norm(c)) < 1e-5, (k, kw)
 
 
+def test_arnoldi_step_last_arriver_kernels_over_many_runs_at_512():
+    """k_finalize_cgs and k_scale_fin hand partial sums from all workgroups to the one that draws the last ticket (write-through stores,
+    loads past the caches, an agent-scope counter): at 512^2 the sweep's partials come from ~1 000 workgroups on all eight XCDs.  Twenty
+    factorisations of 30 steps, each against the five separate calls of the Python step (finalize launches in between): the same H and
+    the same basis bit for bit, every time — a stale line or a lost ticket would show as a different sum."""
+    from trips_py_amd.operators import Blur2D
+    from trips_py_amd.problems import gauss_psf
+    from trips_py_amd.krylov import ArnoldiState
+    N, steps = 512, 30
+    A = Blur2D(gauss_psf((9, 9), (3, 3))[0], N, N)
+    eng = A.engine
+    b = torch.rand(N * N, device=eng.device, generator=torch.Generator(device=eng.device).manual_seed(21))
+    eng.arnoldi_step, keep = None, eng.arnoldi_step
+    try:
+        five = ArnoldiState(A, b, steps)
+        for _ in range(steps):
+            five.step()
+    finally:
+        del eng.arnoldi_step
+    assert keep is not None
+    Href, Vref = five.H(), five.V.data[:steps + 1].clone()
+    for rep in range(20):
+        one = ArnoldiState(A, b, steps)
+        for _ in range(steps):
+            one.step()
+        assert np.array_equal(one.H(), Href), rep
+        assert torch.equal(one.V.data[:steps + 1], Vref), rep
+
+
 @pytest.mark.parametrize("N,its,hist", [(64, 30, True), (128, 45, True), (96, 25, 3), (64, 13, False)])
 def test_hybrid_gmres_gcv_one_library_call_per_iteration_equals_the_python_loop(N, its, hist):
     """trk_hgmres_iter — absorb the step that ran ahead, enqueue the next, collect the worker's answer for the iterate before, post this
