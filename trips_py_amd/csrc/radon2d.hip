@@ -2251,6 +2251,13 @@ __global__ __launch_bounds__(256, 3) void k_radon_adj_quad(const uint4* __restri
   aq += (int64_t)frame * nq;
   CBq += (int64_t)frame * nq * npad;
   recq += (int64_t)frame * nq * 4 * ndp;
+#ifdef TRK_ADJQ_EXPERIMENT_SPLIT
+  {  // TIMING EXPERIMENT ONLY (wrong results: the splits overwrite each other): blockIdx.z takes a share of the quads
+    const int per = (nq + (int)gridDim.z - 1) / (int)gridDim.z, qs = blockIdx.z * per;
+    aq += qs; CBq += (int64_t)qs * npad; recq += (int64_t)qs * 4 * ndp;
+    nq = nq - qs < per ? (nq - qs < 0 ? 0 : nq - qs) : per;
+  }
+#endif
   const auto rrec = __builtin_amdgcn_make_buffer_rsrc((void*)recq, 0, (unsigned)((int64_t)nq * 4 * ndp * 16), 0x00020000);
   const auto rcb = __builtin_amdgcn_make_buffer_rsrc((void*)CBq, 0, (unsigned)((int64_t)nq * npad * 8), 0x00020000);
   const float sdh = 0.5f * (float)(nd - 1);
@@ -2613,6 +2620,9 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
   // complete quads) and no rider travels on the epilogue (the damped-LSQR update and the mailbox post stay with k_radon_adj_tile);
   // TRK_RADON_NO_ADJQ=1: k_radon_adj_tile everywhere (read per call: the tests switch it)
   const bool adjq_riders = epi.on && (op->post.on || op->lsqr.on);
+#ifdef TRK_ADJQ_EXPERIMENT_SPLIT
+  if (tr && tile && im->adjq_ok && getenv("TRK_ADJQ_SPLIT")) nsplit = 1;      // (timing experiment: the quad kernel splits by itself)
+#endif
   const bool adjq = tr && tile && im->adjq_ok && tile_T == 32 && nsplit == 1 && !adjq_riders && getenv("TRK_RADON_NO_ADJQ") == nullptr;
   const int adjq_th = N / 64;
   const int64_t adjq_blocks = (int64_t)adjq_th * adjq_th;
@@ -2798,8 +2808,13 @@ int radon_run(trk_op* op, int tr, const float* x, int64_t ldx, float* y, int64_t
           hipLaunchKernelGGL(k_radon_adj_quad<2>, dim3((unsigned)adjq_blocks, nt), dim3(256), 0, s, im->recq, y + (int64_t)b * ldy, N, nd, im->nq,
                              im->adjq, im->CBq, im->npad, adjq_th, ssq_part, epi, xT_out);
         else
+#ifdef TRK_ADJQ_EXPERIMENT_SPLIT
+          hipLaunchKernelGGL(k_radon_adj_quad<4>, dim3((unsigned)adjq_blocks, nt, getenv("TRK_ADJQ_SPLIT") ? atoi(getenv("TRK_ADJQ_SPLIT")) : 1), dim3(256), 0, s, im->recq, y + (int64_t)b * ldy, N, nd, im->nq,
+                             im->adjq, im->CBq, im->npad, adjq_th, ssq_part, epi, xT_out);
+#else
           hipLaunchKernelGGL(k_radon_adj_quad<4>, dim3((unsigned)adjq_blocks, nt), dim3(256), 0, s, im->recq, y + (int64_t)b * ldy, N, nd, im->nq,
                              im->adjq, im->CBq, im->npad, adjq_th, ssq_part, epi, xT_out);
+#endif
         if (xT_out) im->xT_src = y + (int64_t)b * ldy;
         TRK_LAUNCH_CHECK();
         continue;
