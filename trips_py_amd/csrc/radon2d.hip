@@ -1347,7 +1347,13 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
   const int cnt = mode ? na - n0 : n0;                           // angles of this mode in the frame
   const int ndblk = (nd + 63) / 64;
   // the mode's (angle, 64 detectors) tasks in list order, dealt to the slices in equal contiguous shares
+#ifdef TRK_BAND_EXPERIMENT_PAIR
+  // TIMING EXPERIMENT ONLY (wrong results): every second angle of the mode's list, each task also summing a MIRRORED ray with the same
+  // weights (what a pair of symmetric angles sharing one march would cost)
+  const int all_tasks = (cnt / 2) * ndblk;
+#else
   const int all_tasks = cnt * ndblk;
+#endif
   const int task0 = (int)((int64_t)all_tasks * slice / nslice), task1 = (int)((int64_t)all_tasks * (slice + 1) / nslice);
   if (task1 <= task0) return;
   const int RS = N + 2 * BR_PAD;                                 // row stride in floats (a multiple of 4)
@@ -1427,7 +1433,12 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
   // two chunks of its first task: 21.9 us.  Nor the row stride as a compile-time constant with the row offsets as immediates of two hand-issued
   // ds_read_b32 per step (no scalar instruction per step: 80 -> 45 per chunk, twice the LDS instructions): 27.3 us per plain apply against 26.2.)
   for (int task = task0 + wv; task < task1;) {
+#ifdef TRK_BAND_EXPERIMENT_PAIR
+    const int ai = 2 * (task / ndblk), dblk = task - (ai / 2) * ndblk;
+    double total_m = 0.0;
+#else
     const int ai = task / ndblk, dblk = task - ai * ndblk;
+#endif
     const int a = frame * na + sorted[frame * na + (mode ? n0 : 0) + ai].orig;                    // (scalar loads)
     const AngleParam p = ang[a];
     const int nlive = (nd - dblk * 64 < 64) ? nd - dblk * 64 : 64;
@@ -1453,9 +1464,15 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
       // showed what the longer fp32 chains cost where the solver amplifies roundings — iterates 5-7 of C3's transient sat 44-90 x
       // above the fp32-storage floor with 16-row sums and on it with 4-row sums (R.set_ref_sums(4, 32))
       f2v acc2[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#ifdef TRK_BAND_EXPERIMENT_PAIR
+      f2v acc2m[4] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+#endif
       if (cs >= 0 && ce <= N - 1) {
         // every tap of the wave inside the image: address = row (scalar) + 4 (cs + pad) (scalar) + 4 * relative column
         f2v w[16], t2[16];
+#ifdef TRK_BAND_EXPERIMENT_PAIR
+        f2v t2m[16];
+#endif
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
           const unsigned Q = Ac + Brow[u];
@@ -1466,9 +1483,19 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
           asm("" : "+s"(off));
           const float* tp = reinterpret_cast<const float*>(rowp + off + ((Q >> QF) << 2));
           t2[u] = (f2v){tp[0], tp[1]};
+#ifdef TRK_BAND_EXPERIMENT_PAIR
+          int offm = u * RS * 4 + (BR_PAD + N - 2 - cs) * 4;
+          asm("" : "+s"(offm));
+          const float* tpm = reinterpret_cast<const float*>(rowp + offm - ((Q >> QF) << 2));
+          t2m[u] = (f2v){tpm[0], tpm[1]};
+#endif
         }
 #pragma unroll
         for (int u = 0; u < 16; ++u) acc2[u >> BR_FLUSH_SHIFT] = __builtin_elementwise_fma(w[u], t2[u], acc2[u >> BR_FLUSH_SHIFT]);
+#ifdef TRK_BAND_EXPERIMENT_PAIR
+#pragma unroll
+        for (int u = 0; u < 16; ++u) asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[0,1,1]" : "+v"(acc2m[u >> BR_FLUSH_SHIFT]) : "v"(w[u]), "v"(t2m[u]));
+#endif
       } else {
         // the window overhangs the image: columns clamped into the zero pads ([-2, N]: both taps of a clamped step read zeros)
         f2v w[16], t2[16];
@@ -1490,8 +1517,15 @@ __global__ __launch_bounds__(BR_NT, 4) void k_radon_fwd_band(const float* __rest
       }
 #pragma unroll
       for (int g4 = 0; g4 < 4; ++g4) total += (double)(acc2[g4][0] + acc2[g4][1]);
+#ifdef TRK_BAND_EXPERIMENT_PAIR
+#pragma unroll
+      for (int g4 = 0; g4 < 4; ++g4) total_m += (double)(acc2m[g4][0] + acc2m[g4][1]);
+#endif
     }
     if (live) part[(int64_t)b * band_stride + (int64_t)a * nd + d] = (float)total;
+#ifdef TRK_BAND_EXPERIMENT_PAIR
+    if (live && ai + 1 < cnt) part[(int64_t)b * band_stride + (int64_t)(frame * na + sorted[frame * na + (mode ? n0 : 0) + ai + 1].orig) * nd + d] = (float)total_m;
+#endif
     int nx = 0;
     if (lane == 0) nx = atomicAdd(&next_task, 1);
     task = __builtin_amdgcn_readfirstlane(nx);
