@@ -81,8 +81,14 @@ def _diagonalise(R_A, R_L, rhs):
     if tri and (d.min() <= 1e-12 * d.max()):
         return None
     try:
-        M = sla.solve_triangular(R_L, R_A.T, trans="T", lower=False).T if tri else sla.solve(R_L.T, R_A.T).T
-        U, sig, _ = sla.svd(M)
+        # (check_finite=False: the same LAPACK calls without SciPy's scans of the operands — NaN / inf surface as a failed SVD or as
+        #  non-finite singular values, both answered with None below; this pair of calls runs once per GKS / MMGKS iteration with the
+        #  device idle)
+        if not (np.all(np.isfinite(R_A)) and np.all(np.isfinite(R_L))):
+            return None
+        M = (sla.solve_triangular(R_L, R_A.T, trans="T", lower=False, check_finite=False).T if tri
+             else sla.solve(R_L.T, R_A.T, check_finite=False).T)
+        U, sig, _ = sla.svd(M, check_finite=False)
     except (sla.LinAlgError, ValueError):
         return None
     if not np.all(np.isfinite(sig)):
