@@ -852,6 +852,14 @@ def extra_c4_mmgks(A, b, N, world, cpu_jobs=None, psf=None):
                                           "fused_separate_grams_frac": round(gbps / HBM_PEAK_GBPS, 4),
                                           "reference_sweep_passes_(32k+192)n_frac": round(alg_ref / dt / 1e9 / HBM_PEAK_GBPS, 4)},
                          "timed": "whole solve, wall clock incl. the host's projected problems"}}
+    # the reference's DEFAULT regparam ('gcv': MMGKS.py:24): lambda chosen on the host every iteration (trk_host_gram_gcv)
+    MMGKS(A, b, L, 2, 1, 3, 30, "gcv", history=False)
+    barrier(world)
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        MMGKS(A, b, L, 2, 1, 3, 30, "gcv", history=False)
+    barrier(world)
+    out["gcv_iters_per_sec_all_ranks"] = round(world * 30 / (max_over_ranks(time.perf_counter() - t0, world) / reps), 2)
     if cpu_jobs is not None:
         bh = b.detach().to("cpu")
         cpu_jobs.append((lambda v: out.__setitem__("cpu_baseline", v), lambda: cpu_c4(psf, N, bh)))
@@ -960,6 +968,16 @@ def extra_c5_dynamic(rank, world, cpu_jobs=None):
         barrier(world)
         dt = max_over_ranks(time.perf_counter() - t0, world)
     out["gks_iters_per_sec"] = round(reps * 50 / dt, 1)
+    # the reference's DEFAULT regparam ('gcv': GKS.py:23): the projected problem visits the host every iteration (trk_host_gram_gcv)
+    GKS(F, bl, L, 3, 50, "gcv", history=False)
+    barrier(world)
+    with no_gc():
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            GKS(F, bl, L, 3, 50, "gcv", history=False)
+        barrier(world)
+        dt = max_over_ranks(time.perf_counter() - t0, world)
+    out["gks_gcv_iters_per_sec"] = round(reps * 50 / dt, 1)
     cnt = []
     for its in (10, 30):
         c0, h0 = eng.reduction_points, eng.halo_exchanges

@@ -307,3 +307,37 @@ def test_hessenberg_bidiagonal_form_serves_the_discrepancy_principle():
         hb = HessenbergBidiag(H, 5.0)
         assert np.linalg.norm(hb.left_t(pvec)) == pytest.approx(np.linalg.norm(pvec), rel=1e-14)
         assert discrepancy_principle_bidiag(hb.alphas, hb.betas, hb.left_t(pvec), delta=delta) == pytest.approx(lam_svd, rel=1e-12)
+
+
+@pytest.mark.parametrize("k", [1, 2, 5, 17, 30, 53])
+def test_gram_gcv_in_one_library_call_equals_the_scipy_sequence(k):
+    """trk_host_gram_gcv — Cholesky factors of the projected Gram matrices, Q_A^T b, GCV through the SVD of R_A R_L^-1, the stacked
+    least-squares solve, with SciPy's own LAPACK routines handed over as C pointers — against the sequence gram_factor / project_rhs /
+    choose_lambda('gcv') / tikhonov_lstsq it replaces in GKS and MMGKS (GKS.py:54-74, MMGKS.py:94-106): the same lambda and y (the same
+    LAPACK calls on the same numbers: identical or within rounding), also with a selector right-hand side that differs from the solve's
+    (MMGKS's weighted / unweighted pair); and None where a Gram matrix is not positive definite."""
+    from trips_py_amd.solvers._common import choose_lambda, gram_factor, gram_gcv_host, project_rhs, tikhonov_lstsq
+    rng = np.random.default_rng(100 + k)
+    W = rng.standard_normal((300, k)) * np.logspace(0, -3, k)
+    Lw = rng.standard_normal((500, k))
+    GA, GL = W.T @ W, Lw.T @ Lw
+    c, c2 = W.T @ rng.standard_normal(300), W.T @ rng.standard_normal(300)
+    one = gram_gcv_host(GA, GL, c2, c)
+    if one is None:
+        pytest.skip("SciPy's LAPACK capsule table is not available in this build")
+    R_A, R_L = gram_factor(GA), gram_factor(GL)
+    rhs, rhs2 = project_rhs(R_A, c), project_rhs(R_A, c2)
+    lam = choose_lambda("gcv", R_A, R_L, rhs2, 0.0, {})
+    y = tikhonov_lstsq(R_A, R_L, lam, rhs)
+    assert abs(one[0] - lam) <= 1e-6 * lam
+    assert np.linalg.norm(one[1] - y) <= 1e-6 * np.linalg.norm(y)
+    # a view with a row stride (GKS hands slices of its kmax x kmax mirrors)
+    big = np.zeros((2, k + 3, k + 3))
+    big[0, :k, :k], big[1, :k, :k] = GA, GL
+    two = gram_gcv_host(big[0, :k, :k], big[1, :k, :k], c2, c)
+    assert two is not None and two[0] == one[0] and np.array_equal(two[1], one[1])
+    # a semi-definite Gram matrix: the call declines (the caller's eigen-factor branch takes over)
+    if k >= 2:
+        Gneg = GA.copy()
+        Gneg[0, 0] = -1.0
+        assert gram_gcv_host(Gneg, GL, c, c) is None

@@ -1157,6 +1157,124 @@ extern "C" int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int*
   return rc;
 }
 
+// ------------------------------------------------------------------ GKS / MMGKS with regparam = 'gcv': the host's projected problem in one call
+// GKS.py:54-74 / MMGKS.py:94-106 as the engine runs them on the host (the reference's DEFAULT regparam): from the Gram data
+// G_A = (AV)^T AV, G_L = (LV)^T LV, c = (AV)^T b — R_A, R_L by Cholesky (the economic QRs' R up to row signs), Q_A^T b = R_A^-T c,
+// GCV on (R_A, R_L) brought to (diag(s), I) by the SVD of R_A R_L^-1, the Tikhonov minimiser by the stacked least-squares problem.
+// The interpreter's version of this sequence (SciPy wrappers around the same LAPACK calls) was 250-300 us per iteration WITH THE
+// DEVICE IDLE — the next basis vector needs x = V y — of which the LAPACK calls are a third.  The caller hands the LAPACK routines
+// (SciPy's, as plain C pointers: dpotrf, dtrtrs, dgesdd, dgelsy).  *ok_out = 0: a factor failed (semi-definite Gram matrix, singular
+// R_L, SVD not converged) — the caller's own branches take over.
+namespace {
+typedef void (*potrf_fn)(char*, int*, double*, int*, int*);
+typedef void (*trtrs_fn)(char*, char*, char*, int*, int*, double*, int*, double*, int*, int*);
+typedef void (*gesdd_fn)(char*, int*, int*, double*, int*, double*, double*, int*, double*, int*, double*, int*, int*, int*);
+typedef void (*gelsy_fn)(int*, int*, int*, double*, int*, double*, int*, int*, double*, int*, double*, int*, int*);
+}  // namespace
+
+extern "C" int trk_host_gram_gcv(void* dpotrf, void* dtrtrs, void* dgesdd, void* dgelsy, const double* GA, const double* GL, int ldg,
+                                 const double* c_select, const double* c_solve, int k, double m_eff, double* lam_out, double* y_out,
+                                 int* ok_out) {
+  TRK_REQUIRE(dpotrf && dtrtrs && dgesdd && dgelsy && GA && GL && c_select && c_solve && lam_out && y_out && ok_out && k >= 1 && ldg >= k,
+              "trk_host_gram_gcv: bad argument");
+  *ok_out = 0;
+  static thread_local std::vector<double> buf, wk;
+  static thread_local std::vector<int> ibuf;
+  const size_t kk = (size_t)k * k;
+  buf.resize(9 * kk + 16 * (size_t)k + 64);
+  ibuf.resize(9 * (size_t)k + 8);
+  double* RA = buf.data();
+  double* RL = RA + kk;
+  double* X = RL + kk;           // R_L^-T R_A^T, then M = X^T
+  double* M = X + kk;
+  double* U = M + kk;
+  double* VT = U + kk;
+  double* ST = VT + kk;          // stacked [R_A; sqrt(lam) R_L], 2k x k
+  double* sv = ST + 2 * kk;
+  double* rs = sv + k;           // R_A^-T c_select
+  double* rb = rs + k;           // R_A^-T c_solve
+  double* q = rb + k;
+  double* b2 = q + k;            // 2k
+  int n = k, one = 1, info = 0;
+  char U_ = 'U', T_ = 'T', N_ = 'N', A_ = 'A';
+  // column-major copies of the symmetrised Gram matrices (symmetric: the layout does not matter), upper Cholesky factors
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < k; ++i) {
+      RA[i + (size_t)j * k] = 0.5 * (GA[(size_t)i * ldg + j] + GA[(size_t)j * ldg + i]);
+      RL[i + (size_t)j * k] = 0.5 * (GL[(size_t)i * ldg + j] + GL[(size_t)j * ldg + i]);
+    }
+  ((potrf_fn)dpotrf)(&U_, &n, RA, &n, &info);
+  if (info != 0) return TRK_OK;
+  ((potrf_fn)dpotrf)(&U_, &n, RL, &n, &info);
+  if (info != 0) return TRK_OK;
+  for (int j = 0; j < k; ++j)
+    for (int i = j + 1; i < k; ++i) RA[i + (size_t)j * k] = RL[i + (size_t)j * k] = 0.0;      // (dpotrf leaves the other triangle as it was)
+  double dmin = fabs(RL[0]), dmax = dmin;
+  for (int i = 1; i < k; ++i) {
+    const double d = fabs(RL[i + (size_t)i * k]);
+    dmin = d < dmin ? d : dmin;
+    dmax = d > dmax ? d : dmax;
+  }
+  if (dmin <= 1e-12 * dmax) return TRK_OK;                                                       // (gcv._diagonalise's test)
+  for (int i = 0; i < k; ++i) {
+    rs[i] = c_select[i];
+    rb[i] = c_solve[i];
+  }
+  ((trtrs_fn)dtrtrs)(&U_, &T_, &N_, &n, &one, RA, &n, rs, &n, &info);                            // Q_A^T b = R_A^-T c
+  if (info != 0) return TRK_OK;
+  ((trtrs_fn)dtrtrs)(&U_, &T_, &N_, &n, &one, RA, &n, rb, &n, &info);
+  if (info != 0) return TRK_OK;
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < k; ++i) X[i + (size_t)j * k] = RA[j + (size_t)i * k];                    // R_A^T
+  ((trtrs_fn)dtrtrs)(&U_, &T_, &N_, &n, &n, RL, &n, X, &n, &info);                               // R_L^T X = R_A^T
+  if (info != 0) return TRK_OK;
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < k; ++i) M[i + (size_t)j * k] = X[j + (size_t)i * k];                     // M = R_A R_L^-1
+  double wq = 0.0;
+  int lwork = -1;
+  ((gesdd_fn)dgesdd)(&A_, &n, &n, M, &n, sv, U, &n, VT, &n, &wq, &lwork, ibuf.data(), &info);
+  if (info != 0) return TRK_OK;
+  lwork = (int)wq + 1;
+  if ((int)wk.size() < lwork) wk.resize(lwork);
+  ((gesdd_fn)dgesdd)(&A_, &n, &n, M, &n, sv, U, &n, VT, &n, wk.data(), &lwork, ibuf.data(), &info);
+  if (info != 0) return TRK_OK;
+  for (int i = 0; i < k; ++i) {
+    if (!std::isfinite(sv[i])) return TRK_OK;
+    double a = 0.0;
+    for (int r = 0; r < k; ++r) a += U[r + (size_t)i * k] * rs[r];
+    q[i] = a;
+  }
+  double lam = 0.0;
+  if (int rc = trk_host_gcv_fminbound(sv, q, k, m_eff, 1e-9, 1e2, 1e-12, 1000, &lam, nullptr, nullptr)) return rc;
+  // y = argmin || R_A y - Q_A^T b ||^2 + lam || R_L y ||^2: the stacked least-squares problem, pivoted QR (SciPy's gelsy, rcond = eps)
+  const int m2 = 2 * k;
+  const double sl = sqrt(lam);
+  for (int j = 0; j < k; ++j)
+    for (int i = 0; i < k; ++i) {
+      ST[i + (size_t)j * m2] = RA[i + (size_t)j * k];
+      ST[k + i + (size_t)j * m2] = sl * RL[i + (size_t)j * k];
+    }
+  for (int i = 0; i < k; ++i) {
+    b2[i] = rb[i];
+    b2[k + i] = 0.0;
+  }
+  int* jpvt = ibuf.data();
+  for (int i = 0; i < k; ++i) jpvt[i] = 0;
+  double rcond = 2.220446049250313e-16;
+  int rank = 0, mm = m2;
+  lwork = -1;
+  ((gelsy_fn)dgelsy)(&mm, &n, &one, ST, &mm, b2, &mm, jpvt, &rcond, &rank, &wq, &lwork, &info);
+  if (info != 0) return TRK_OK;
+  lwork = (int)wq + 1;
+  if ((int)wk.size() < lwork) wk.resize(lwork);
+  ((gelsy_fn)dgelsy)(&mm, &n, &one, ST, &mm, b2, &mm, jpvt, &rcond, &rank, wk.data(), &lwork, &info);
+  if (info != 0) return TRK_OK;
+  for (int i = 0; i < k; ++i) y_out[i] = b2[i];
+  *lam_out = lam;
+  *ok_out = 1;
+  return TRK_OK;
+}
+
 // ------------------------------------------------------------------ Hybrid-LSQR with automatic lambda: the host's turn of an iteration
 // Hybrid_LSQR.py:80-110 as the engine runs it (the search for lambda_k on the worker thread, the iterate of the step before formed when its
 // lambda is collected): collect the search posted by the call before, post the search for step k_post (mode 0: gcv, 1: the discrepancy

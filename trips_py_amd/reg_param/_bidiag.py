@@ -112,6 +112,25 @@ def _bind_gebrd():
     return _gebrd or None
 
 
+_raw_ptrs = {}
+
+
+def lapack_pointer(name):
+    """SciPy's LAPACK routine `name` (scipy.linalg.cython_lapack's capsule table) as a plain C address, or None."""
+    if name not in _raw_ptrs:
+        try:
+            import scipy.linalg.cython_lapack as cl
+            api = ctypes.pythonapi
+            api.PyCapsule_GetName.restype, api.PyCapsule_GetName.argtypes = ctypes.c_char_p, [ctypes.py_object]
+            api.PyCapsule_GetPointer.restype = ctypes.c_void_p
+            api.PyCapsule_GetPointer.argtypes = [ctypes.py_object, ctypes.c_char_p]
+            cap = cl.__pyx_capi__[name]
+            _raw_ptrs[name] = api.PyCapsule_GetPointer(cap, api.PyCapsule_GetName(cap))
+        except Exception:                     # noqa: BLE001  (no capsule table in this SciPy build)
+            _raw_ptrs[name] = None
+    return _raw_ptrs[name]
+
+
 def lapack_pointers():
     """(dgebrd, dormbr) as plain C addresses for libtrk's worker thread (trk_host_worker_set_lapack), or None."""
     fns = _bind_gebrd()

@@ -18,7 +18,7 @@ from ..engine import Coef
 from ..decompositions import golub_kahan_device
 from ..krylov import DeviceBasis, GramSchmidtByGram, orthogonalize
 from ..operators import is_identity
-from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq, small_host_blas
+from ._common import check_delta, choose_lambda, gram_factor, gram_gcv_host, project_rhs, tikhonov_lstsq, small_host_blas
 
 
 import os as _os
@@ -321,11 +321,16 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
                               Minv=Minv, ldm=kmax, k_from=k_inv)
             k_inv = k
         else:
-            R_A, R_L = gram_factor(pb.GA[:k, :k]), gram_factor(pb.GL[:k, :k])
-            rhs = project_rhs(R_A, pb.c[:k])
-            lam = choose_lambda(regparam, R_A, R_L, rhs, max(b2 - float(rhs @ rhs), 0.0), kwargs)
-            lams.append(lam)
-            y = tikhonov_lstsq(R_A, R_L, lam, rhs)
+            one = gram_gcv_host(pb.GA[:k, :k], pb.GL[:k, :k], pb.c[:k], pb.c[:k]) if (regparam == "gcv" and kwargs.get("host_solve_in_c", True)) else None
+            if one is not None:                   # the whole projected problem in one library call (trk_host_gram_gcv)
+                lam, y = one
+                lams.append(lam)
+            else:
+                R_A, R_L = gram_factor(pb.GA[:k, :k]), gram_factor(pb.GL[:k, :k])
+                rhs = project_rhs(R_A, pb.c[:k])
+                lam = choose_lambda(regparam, R_A, R_L, rhs, max(b2 - float(rhs @ rhs), 0.0), kwargs)
+                lams.append(lam)
+                y = tikhonov_lstsq(R_A, R_L, lam, rhs)
             Y.set(0, y)
         _trace.mark("GKS: iterate x = V y")
         x_dev = Hs.row(ii)

@@ -17,7 +17,7 @@ from .._io import Formatter, History, as_operator
 from ..engine import Coef
 from ..decompositions import golub_kahan_device
 from ..krylov import _plain_handle_apply, DeviceBasis, GramSchmidtByGram, orthogonalize
-from ._common import check_delta, choose_lambda, gram_factor, project_rhs, tikhonov_lstsq, small_host_blas
+from ._common import check_delta, choose_lambda, gram_factor, gram_gcv_host, project_rhs, tikhonov_lstsq, small_host_blas
 
 
 def _old_first_derivative_2d_matrix(nx, ny):
@@ -226,16 +226,23 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
                 nred += 1
             eng.allreduce(G, 0, nred)
             g = G.host(0, nred)
-            R_A, R_L = gram_factor(g[:kk].reshape(k, k)), gram_factor(g[kk:2 * kk].reshape(k, k))
-            rhs_b = project_rhs(R_A, g[2 * kk:2 * kk + k])            # Q_A^T b          (:106)
-            rhs_wb = project_rhs(R_A, g[2 * kk + k:2 * kk + 2 * k])   # Q_A^T (wf*b)     (:97-99)
-            resid2 = max(float(g[-1]) - float(rhs_wb @ rhs_wb), 0.0) if need_wb2 else 0.0
-            if isinstance(regparam, str) and regparam == "l_curve":
-                lam = choose_lambda("l_curve", R_A, R_L, rhs_b, 0.0, kwargs)           # l_curve(R_A, R_L, Q_A.T@b) (:101)
+            one = None
+            if isinstance(regparam, str) and regparam == "gcv" and kwargs.get("host_solve_in_c", True):
+                # the whole projected problem in one library call (trk_host_gram_gcv): lambda from Q_A^T (wf*b), y from Q_A^T b (:97-106)
+                one = gram_gcv_host(g[:kk].reshape(k, k), g[kk:2 * kk].reshape(k, k), g[2 * kk + k:2 * kk + 2 * k], g[2 * kk:2 * kk + k])
+            if one is not None:
+                lam, y = one
             else:
-                lam = choose_lambda(regparam, R_A, R_L, rhs_wb, resid2, kwargs)
+                R_A, R_L = gram_factor(g[:kk].reshape(k, k)), gram_factor(g[kk:2 * kk].reshape(k, k))
+                rhs_b = project_rhs(R_A, g[2 * kk:2 * kk + k])            # Q_A^T b          (:106)
+                rhs_wb = project_rhs(R_A, g[2 * kk + k:2 * kk + 2 * k])   # Q_A^T (wf*b)     (:97-99)
+                resid2 = max(float(g[-1]) - float(rhs_wb @ rhs_wb), 0.0) if need_wb2 else 0.0
+                if isinstance(regparam, str) and regparam == "l_curve":
+                    lam = choose_lambda("l_curve", R_A, R_L, rhs_b, 0.0, kwargs)           # l_curve(R_A, R_L, Q_A.T@b) (:101)
+                else:
+                    lam = choose_lambda(regparam, R_A, R_L, rhs_wb, resid2, kwargs)
+                y = tikhonov_lstsq(R_A, R_L, lam, rhs_b)
             lams.append(lam)
-            y = tikhonov_lstsq(R_A, R_L, lam, rhs_b)
             Y.set(0, y)
         _trace.mark("MMGKS: iterate x = V y")
         x_dev = Hs.row(ii)
