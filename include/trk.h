@@ -444,13 +444,14 @@ int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int* have_out);
 /* HOST function: the projected problem of GKS / MMGKS with regparam = 'gcv' — the reference's default — from the Gram data of the
  * projected operators, in one call (GKS.py:54-74, MMGKS.py:94-106): R_A, R_L = the Cholesky factors of G_A = (AV)^T AV, G_L = (LV)^T LV
  * (k x k, row stride ldg; what the economic QRs of AV, LV give up to row signs), Q_A^T b = R_A^-T c, lambda by GCV on (R_A, R_L) reduced
- * to (diag(s), I) through the SVD of R_A R_L^-1 (gcv.py:25-95: 'standard' form, m_eff = k), y by the stacked least-squares problem
+ * to (diag(s), I) through M = R_A R_L^-1 (gcv.py:25-95: 'standard' form, m_eff = k) — s and U^T rhs of M's SVD by bidiagonalisation
+ * and a bidiagonal SVD that rotates the one vector, no singular vectors formed — y by the stacked least-squares problem
  * [R_A; sqrt(lam) R_L] y = [Q_A^T b; 0].  c_select / c_solve: the right-hand side the selector sees and the one the solve uses (MMGKS
- * hands the weighted and the unweighted one, MMGKS.py:97-106; GKS the same array twice).  dpotrf, dtrtrs, dgesdd, dgelsy: the
- * caller's LAPACK as plain C pointers (Fortran calling convention).  *ok_out = 0: a factorisation failed (semi-definite Gram matrix,
- * singular R_L, no convergence) and nothing was written: the caller's own branches take over. */
-int trk_host_gram_gcv(void* dpotrf, void* dtrtrs, void* dgesdd, void* dgelsy, const double* GA, const double* GL, int ldg,
-                      const double* c_select, const double* c_solve, int k, double m_eff, double* lam_out, double* y_out, int* ok_out);
+ * hands the weighted and the unweighted one, MMGKS.py:97-106; GKS the same array twice).  lapack: {dpotrf, dtrtrs, dgebrd, dormbr,
+ * dbdsqr, dgelsy}, the caller's LAPACK as plain C pointers (Fortran calling convention).  *ok_out = 0: a factorisation failed
+ * (semi-definite Gram matrix, singular R_L, no convergence) and nothing was written: the caller's own branches take over. */
+int trk_host_gram_gcv(void* const* lapack, const double* GA, const double* GL, int ldg, const double* c_select, const double* c_solve,
+                      int k, double m_eff, double* lam_out, double* y_out, int* ok_out);
 /* Hybrid-LSQR with automatic lambda (Hybrid_LSQR.py:80-110), the host's turn of an iteration in one call: collect the search posted by
  * the call before (k_done > 0: the step it belongs to), post the search for step k_post (mode 0: trk_host_worker_post_gcv_bidiag with
  * m_eff, the reference's bounds and tolerance; mode 1: trk_host_worker_post_dp_bidiag with target, extra and bproj), and with x_out != NULL

@@ -164,8 +164,8 @@ SIGNATURES = {
     "trk_isotv_weights": (c_int, [c_f32p, c_int, c_int, c_f32p, c_i64, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_tv_weights": (c_int, [c_op, c_f32p, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_arnoldi_step": (c_int, [c_op, c_f32p, c_i64, c_int, c_f32p, c_f64p, c_int, c_f64p, c_f64p, c_stream]),
-    "trk_host_gram_gcv": (c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, c_int,
-                                 ctypes.c_void_p, ctypes.c_void_p, c_int, c_dbl, ctypes.POINTER(c_dbl), ctypes.c_void_p, ctypes.POINTER(c_int)]),
+    "trk_host_gram_gcv": (c_int, [ctypes.POINTER(ctypes.c_void_p), ctypes.c_void_p, ctypes.c_void_p, c_int, ctypes.c_void_p, ctypes.c_void_p,
+                                 c_int, c_dbl, ctypes.POINTER(c_dbl), ctypes.c_void_p, ctypes.POINTER(c_int)]),
     "trk_hlsqr_select": (c_int, [ctypes.c_void_p, c_int, ctypes.c_void_p, ctypes.c_void_p, c_int, c_dbl, c_dbl, ctypes.c_void_p, c_dbl, c_int,
                                 c_f32p, c_i64, c_i64, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_dbl),
                                 ctypes.POINTER(c_int), c_stream]),

@@ -1160,52 +1160,60 @@ extern "C" int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int*
 // ------------------------------------------------------------------ GKS / MMGKS with regparam = 'gcv': the host's projected problem in one call
 // GKS.py:54-74 / MMGKS.py:94-106 as the engine runs them on the host (the reference's DEFAULT regparam): from the Gram data
 // G_A = (AV)^T AV, G_L = (LV)^T LV, c = (AV)^T b — R_A, R_L by Cholesky (the economic QRs' R up to row signs), Q_A^T b = R_A^-T c,
-// GCV on (R_A, R_L) brought to (diag(s), I) by the SVD of R_A R_L^-1, the Tikhonov minimiser by the stacked least-squares problem.
-// The interpreter's version of this sequence (SciPy wrappers around the same LAPACK calls) was 250-300 us per iteration WITH THE
-// DEVICE IDLE — the next basis vector needs x = V y — of which the LAPACK calls are a third.  The caller hands the LAPACK routines
-// (SciPy's, as plain C pointers: dpotrf, dtrtrs, dgesdd, dgelsy).  *ok_out = 0: a factor failed (semi-definite Gram matrix, singular
-// R_L, SVD not converged) — the caller's own branches take over.
+// GCV on (R_A, R_L) brought to (diag(s), I) through M = R_A R_L^-1 = U diag(s) W^T, the Tikhonov minimiser by the stacked
+// least-squares problem.  The interpreter's version of this sequence (SciPy wrappers around LAPACK) was 250-300 us per iteration WITH
+// THE DEVICE IDLE — the next basis vector needs x = V y.  GCV sees M only through s and U^T rhs: M is bidiagonalised (dgebrd), Q^T is
+// applied to rhs (dormbr) and the bidiagonal's singular values are found with the left rotations applied to that ONE vector (dbdsqr,
+// ncc = 1) — no singular vectors are formed (the dense SVD with both vector sets, what sla.svd computes, is ~5 x the work).  The caller
+// hands the LAPACK routines (SciPy's, as plain C pointers).  *ok_out = 0: a factor failed (semi-definite Gram matrix, singular R_L, no
+// convergence) — the caller's own branches take over.
 namespace {
 typedef void (*potrf_fn)(char*, int*, double*, int*, int*);
 typedef void (*trtrs_fn)(char*, char*, char*, int*, int*, double*, int*, double*, int*, int*);
-typedef void (*gesdd_fn)(char*, int*, int*, double*, int*, double*, double*, int*, double*, int*, double*, int*, int*, int*);
+typedef void (*bdsqr_fn)(char*, int*, int*, int*, int*, double*, double*, double*, int*, double*, int*, double*, int*, double*, int*);
 typedef void (*gelsy_fn)(int*, int*, int*, double*, int*, double*, int*, int*, double*, int*, double*, int*, int*);
 }  // namespace
 
-extern "C" int trk_host_gram_gcv(void* dpotrf, void* dtrtrs, void* dgesdd, void* dgelsy, const double* GA, const double* GL, int ldg,
-                                 const double* c_select, const double* c_solve, int k, double m_eff, double* lam_out, double* y_out,
-                                 int* ok_out) {
-  TRK_REQUIRE(dpotrf && dtrtrs && dgesdd && dgelsy && GA && GL && c_select && c_solve && lam_out && y_out && ok_out && k >= 1 && ldg >= k,
-              "trk_host_gram_gcv: bad argument");
+// lapack: {dpotrf, dtrtrs, dgebrd, dormbr, dbdsqr, dgelsy}
+extern "C" int trk_host_gram_gcv(void* const* lapack, const double* GA, const double* GL, int ldg, const double* c_select,
+                                 const double* c_solve, int k, double m_eff, double* lam_out, double* y_out, int* ok_out) {
+  TRK_REQUIRE(lapack && GA && GL && c_select && c_solve && lam_out && y_out && ok_out && k >= 1 && ldg >= k, "trk_host_gram_gcv: bad argument");
+  for (int i = 0; i < 6; ++i) TRK_REQUIRE(lapack[i], "trk_host_gram_gcv: six LAPACK routines (dpotrf, dtrtrs, dgebrd, dormbr, dbdsqr, dgelsy)");
+  const potrf_fn dpotrf = (potrf_fn)lapack[0];
+  const trtrs_fn dtrtrs = (trtrs_fn)lapack[1];
+  const gebrd_fn dgebrd = (gebrd_fn)lapack[2];
+  const ormbr_fn dormbr = (ormbr_fn)lapack[3];
+  const bdsqr_fn dbdsqr = (bdsqr_fn)lapack[4];
+  const gelsy_fn dgelsy = (gelsy_fn)lapack[5];
   *ok_out = 0;
   static thread_local std::vector<double> buf, wk;
   static thread_local std::vector<int> ibuf;
   const size_t kk = (size_t)k * k;
-  buf.resize(9 * kk + 16 * (size_t)k + 64);
-  ibuf.resize(9 * (size_t)k + 8);
+  buf.resize(6 * kk + 16 * (size_t)k + 64);
+  ibuf.resize((size_t)k + 8);
   double* RA = buf.data();
   double* RL = RA + kk;
-  double* X = RL + kk;           // R_L^-T R_A^T, then M = X^T
-  double* M = X + kk;
-  double* U = M + kk;
-  double* VT = U + kk;
-  double* ST = VT + kk;          // stacked [R_A; sqrt(lam) R_L], 2k x k
-  double* sv = ST + 2 * kk;
-  double* rs = sv + k;           // R_A^-T c_select
+  double* X = RL + kk;           // R_L^-T R_A^T
+  double* M = X + kk;            // M = X^T = R_A R_L^-1, overwritten by its bidiagonal form
+  double* ST = M + kk;           // stacked [R_A; sqrt(lam) R_L], 2k x k
+  double* sv = ST + 2 * kk;      // d of the bidiagonal form, then the singular values
+  double* e = sv + k;
+  double* tq = e + k;
+  double* tp = tq + k;
+  double* rs = tp + k;           // R_A^-T c_select, then Q^T of it, then U^T of it
   double* rb = rs + k;           // R_A^-T c_solve
-  double* q = rb + k;
-  double* b2 = q + k;            // 2k
-  int n = k, one = 1, info = 0;
-  char U_ = 'U', T_ = 'T', N_ = 'N', A_ = 'A';
+  double* b2 = rb + k;           // 2k
+  int n = k, one = 1, zero = 0, info = 0;
+  char U_ = 'U', T_ = 'T', N_ = 'N', Q_ = 'Q', L_ = 'L';
   // column-major copies of the symmetrised Gram matrices (symmetric: the layout does not matter), upper Cholesky factors
   for (int j = 0; j < k; ++j)
     for (int i = 0; i < k; ++i) {
       RA[i + (size_t)j * k] = 0.5 * (GA[(size_t)i * ldg + j] + GA[(size_t)j * ldg + i]);
       RL[i + (size_t)j * k] = 0.5 * (GL[(size_t)i * ldg + j] + GL[(size_t)j * ldg + i]);
     }
-  ((potrf_fn)dpotrf)(&U_, &n, RA, &n, &info);
+  dpotrf(&U_, &n, RA, &n, &info);
   if (info != 0) return TRK_OK;
-  ((potrf_fn)dpotrf)(&U_, &n, RL, &n, &info);
+  dpotrf(&U_, &n, RL, &n, &info);
   if (info != 0) return TRK_OK;
   for (int j = 0; j < k; ++j)
     for (int i = j + 1; i < k; ++i) RA[i + (size_t)j * k] = RL[i + (size_t)j * k] = 0.0;      // (dpotrf leaves the other triangle as it was)
@@ -1220,32 +1228,33 @@ extern "C" int trk_host_gram_gcv(void* dpotrf, void* dtrtrs, void* dgesdd, void*
     rs[i] = c_select[i];
     rb[i] = c_solve[i];
   }
-  ((trtrs_fn)dtrtrs)(&U_, &T_, &N_, &n, &one, RA, &n, rs, &n, &info);                            // Q_A^T b = R_A^-T c
+  dtrtrs(&U_, &T_, &N_, &n, &one, RA, &n, rs, &n, &info);                                        // Q_A^T b = R_A^-T c
   if (info != 0) return TRK_OK;
-  ((trtrs_fn)dtrtrs)(&U_, &T_, &N_, &n, &one, RA, &n, rb, &n, &info);
+  dtrtrs(&U_, &T_, &N_, &n, &one, RA, &n, rb, &n, &info);
   if (info != 0) return TRK_OK;
   for (int j = 0; j < k; ++j)
     for (int i = 0; i < k; ++i) X[i + (size_t)j * k] = RA[j + (size_t)i * k];                    // R_A^T
-  ((trtrs_fn)dtrtrs)(&U_, &T_, &N_, &n, &n, RL, &n, X, &n, &info);                               // R_L^T X = R_A^T
+  dtrtrs(&U_, &T_, &N_, &n, &n, RL, &n, X, &n, &info);                                           // R_L^T X = R_A^T
   if (info != 0) return TRK_OK;
   for (int j = 0; j < k; ++j)
     for (int i = 0; i < k; ++i) M[i + (size_t)j * k] = X[j + (size_t)i * k];                     // M = R_A R_L^-1
-  double wq = 0.0;
-  int lwork = -1;
-  ((gesdd_fn)dgesdd)(&A_, &n, &n, M, &n, sv, U, &n, VT, &n, &wq, &lwork, ibuf.data(), &info);
-  if (info != 0) return TRK_OK;
-  lwork = (int)wq + 1;
+  // s and U^T rhs without singular vectors: M = Q B P^T (dgebrd), w = Q^T rhs (dormbr), B = U_B diag(s) V_B^T with w <- U_B^T w (dbdsqr)
+  int lwork = 64 * k + 64;
   if ((int)wk.size() < lwork) wk.resize(lwork);
-  ((gesdd_fn)dgesdd)(&A_, &n, &n, M, &n, sv, U, &n, VT, &n, wk.data(), &lwork, ibuf.data(), &info);
+  dgebrd(&n, &n, M, &n, sv, e, tq, tp, wk.data(), &lwork, &info);
   if (info != 0) return TRK_OK;
-  for (int i = 0; i < k; ++i) {
-    if (!std::isfinite(sv[i])) return TRK_OK;
-    double a = 0.0;
-    for (int r = 0; r < k; ++r) a += U[r + (size_t)i * k] * rs[r];
-    q[i] = a;
+  dormbr(&Q_, &L_, &T_, &n, &one, &n, M, &n, tq, rs, &n, wk.data(), &lwork, &info);
+  if (info != 0) return TRK_OK;
+  {
+    double dummy = 0.0;
+    if ((int)wk.size() < 4 * k + 8) wk.resize(4 * k + 8);
+    dbdsqr(&U_, &n, &zero, &zero, &one, sv, e, &dummy, &one, &dummy, &one, rs, &n, wk.data(), &info);
+    if (info != 0) return TRK_OK;
   }
+  for (int i = 0; i < k; ++i)
+    if (!std::isfinite(sv[i]) || !std::isfinite(rs[i])) return TRK_OK;
   double lam = 0.0;
-  if (int rc = trk_host_gcv_fminbound(sv, q, k, m_eff, 1e-9, 1e2, 1e-12, 1000, &lam, nullptr, nullptr)) return rc;
+  if (int rc = trk_host_gcv_fminbound(sv, rs, k, m_eff, 1e-9, 1e2, 1e-12, 1000, &lam, nullptr, nullptr)) return rc;
   // y = argmin || R_A y - Q_A^T b ||^2 + lam || R_L y ||^2: the stacked least-squares problem, pivoted QR (SciPy's gelsy, rcond = eps)
   const int m2 = 2 * k;
   const double sl = sqrt(lam);
@@ -1260,14 +1269,14 @@ extern "C" int trk_host_gram_gcv(void* dpotrf, void* dtrtrs, void* dgesdd, void*
   }
   int* jpvt = ibuf.data();
   for (int i = 0; i < k; ++i) jpvt[i] = 0;
-  double rcond = 2.220446049250313e-16;
+  double rcond = 2.220446049250313e-16, wq = 0.0;
   int rank = 0, mm = m2;
   lwork = -1;
-  ((gelsy_fn)dgelsy)(&mm, &n, &one, ST, &mm, b2, &mm, jpvt, &rcond, &rank, &wq, &lwork, &info);
+  dgelsy(&mm, &n, &one, ST, &mm, b2, &mm, jpvt, &rcond, &rank, &wq, &lwork, &info);
   if (info != 0) return TRK_OK;
   lwork = (int)wq + 1;
   if ((int)wk.size() < lwork) wk.resize(lwork);
-  ((gelsy_fn)dgelsy)(&mm, &n, &one, ST, &mm, b2, &mm, jpvt, &rcond, &rank, wk.data(), &lwork, &info);
+  dgelsy(&mm, &n, &one, ST, &mm, b2, &mm, jpvt, &rcond, &rank, wk.data(), &lwork, &info);
   if (info != 0) return TRK_OK;
   for (int i = 0; i < k; ++i) y_out[i] = b2[i];
   *lam_out = lam;

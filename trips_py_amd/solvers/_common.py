@@ -97,7 +97,7 @@ _GRAM_GCV = None
 
 def gram_gcv_host(GA, GL, c_select, c_solve):
     """(lambda, y) of GKS / MMGKS's projected problem with regparam='gcv' from the Gram data, in ONE library call
-    (trk_host_gram_gcv: Cholesky factors, Q_A^T b, GCV through the SVD of R_A R_L^-1, the stacked least-squares solve — the sequence
+    (trk_host_gram_gcv: Cholesky factors, Q_A^T b, GCV through the singular values of R_A R_L^-1, the stacked least-squares solve — the sequence
     gram_factor / project_rhs / choose_lambda / tikhonov_lstsq runs through SciPy's wrappers with the device idle), or None where the
     library, SciPy's LAPACK capsules or a factorisation are not to be had — the caller then runs that sequence."""
     global _GRAM_GCV
@@ -107,8 +107,8 @@ def gram_gcv_host(GA, GL, c_select, c_solve):
             from .. import _lib
             from ..reg_param._bidiag import lapack_pointer
             lib = _lib.load()
-            ptrs = [lapack_pointer(nm) for nm in ("dpotrf", "dtrtrs", "dgesdd", "dgelsy")]
-            _GRAM_GCV = (lib, ptrs) if (all(ptrs) and hasattr(lib, "trk_host_gram_gcv")) else False
+            ptrs = [lapack_pointer(nm) for nm in ("dpotrf", "dtrtrs", "dgebrd", "dormbr", "dbdsqr", "dgelsy")]
+            _GRAM_GCV = (lib, (ctypes.c_void_p * 6)(*ptrs)) if (all(ptrs) and hasattr(lib, "trk_host_gram_gcv")) else False
         except Exception:                     # noqa: BLE001
             _GRAM_GCV = False
     if not _GRAM_GCV:
@@ -123,7 +123,7 @@ def gram_gcv_host(GA, GL, c_select, c_solve):
     cb = cs if c_solve is c_select else np.ascontiguousarray(c_solve, dtype=np.float64).reshape(-1)
     y = np.empty(k)
     lam, ok = ctypes.c_double(0.0), ctypes.c_int(0)
-    rc = lib.trk_host_gram_gcv(ptrs[0], ptrs[1], ptrs[2], ptrs[3], GA.ctypes.data, GL.ctypes.data, GA.strides[0] // 8, cs.ctypes.data,
+    rc = lib.trk_host_gram_gcv(ptrs, GA.ctypes.data, GL.ctypes.data, GA.strides[0] // 8, cs.ctypes.data,
                                cb.ctypes.data, int(k), float(k), ctypes.byref(lam), y.ctypes.data, ctypes.byref(ok))
     if rc != 0 or not ok.value:
         return None
