@@ -923,6 +923,8 @@ struct trk_host_worker {
   void* ormbr = nullptr;
   std::vector<double> M, H, d, e, tq, tp, work, y;
   double resid = 0.0;
+  int dp_solves_zero = 0;         // kind 3: "the discrepancy cannot be reached yet" (lambda = 0) is solved here too (trk_hgmres's workers)
+  int y_valid = 0;                // the last Hessenberg job left y and resid
 };
 
 namespace {
@@ -935,6 +937,7 @@ typedef void (*ormbr_fn)(char*, char*, char*, int*, int*, int*, double*, int*, d
 // Tikhonov minimiser, y = P' z, and the reference's relResidual (:80: a (k+1,) minus a (k+1, 1) — the Frobenius norm of a matrix).
 int hess_job(trk_host_worker* w, bool dp, bool fixed = false) {
   const int k = w->k, n = k + 1;
+  w->y_valid = 0;
   w->M.assign((size_t)n * n, 0.0);
   w->M[0] = w->p[0];
   for (int j = 0; j < k; ++j)
@@ -957,7 +960,8 @@ int hess_job(trk_host_worker* w, bool dp, bool fixed = false) {
     w->have = 0;
     if (int rc = trk_host_dp_bidiag(alpha, beta, k, w->c.data(), w->p[1], w->p[2], &lam, &w->have, nullptr, nullptr)) return rc;
     w->lam = lam;
-    if (!w->have || !(lam > 0.0)) return TRK_OK;              // the caller's in-line branches (unassigned / not reachable yet)
+    // the caller's in-line branches (unassigned / not reachable yet) — unless it asked for the unreachable case's lambda = 0 solve
+    if (!w->have || !(lam > 0.0 || (lam == 0.0 && w->dp_solves_zero))) return TRK_OK;
     vect = 'P'; trans = 'N';
   } else if (fixed) {                                           // (kind 4: lambda is the caller's number — no search)
     lam = w->p[5];
@@ -979,6 +983,7 @@ int hess_job(trk_host_worker* w, bool dp, bool fixed = false) {
     r2 += (w->p[0] - hy) * (w->p[0] - hy) + (double)k * hy * hy;
   }
   w->resid = sqrt(r2);
+  w->y_valid = 1;
   return TRK_OK;
 }
 
@@ -1135,7 +1140,7 @@ extern "C" int trk_host_worker_collect_vec(trk_host_worker* w, double* lam_out, 
   TRK_REQUIRE(w->state.load() != 0, "trk_host_worker_collect_vec: nothing was posted");
   TRK_REQUIRE((w->kind == 2 || w->kind == 3 || w->kind == 4) && k == w->k, "trk_host_worker_collect_vec: the posted job is not a Hessenberg job of this size");
   const int rc = trk_host_worker_collect(w, lam_out, have_out);
-  if (rc == TRK_OK && *have_out && (w->kind != 3 || *lam_out > 0.0)) {
+  if (rc == TRK_OK && *have_out && w->y_valid) {
     for (int j = 0; j < k; ++j) y[j] = w->y[1 + j];
     *resid_out = w->resid;
   }
@@ -1369,6 +1374,7 @@ extern "C" int trk_hgmres_dp(trk_hgmres* g, const float* bvec, double bproj0, do
   g->bproj[0] = bproj0;
   g->dp_target = target;
   g->dp_extra = extra;
+  for (trk_host_worker* w : g->ws) w->dp_solves_zero = 1;      // (reset by trk_hgmres_destroy: the workers are borrowed)
   if (bproj_out) *bproj_out = g->bproj.data();
   return TRK_OK;
 }
@@ -1417,6 +1423,7 @@ extern "C" int trk_hgmres_destroy(trk_hgmres* g) {
     g->posted.pop_front();
     ++g->collect_seq;
   }
+  for (trk_host_worker* w : g->ws) w->dp_solves_zero = 0;
   delete g;
   return TRK_OK;
 }
@@ -1490,7 +1497,7 @@ extern "C" int trk_hgmres_iter(trk_hgmres* g, int absorb, int enqueue_next, int 
     if (int rc = trk_host_worker_collect_vec(g->ws[g->collect_seq % nw], done_lam, &have, g->y.data(), done + 1, done_resid)) return rc;
     g->posted.pop_front();
     ++g->collect_seq;
-    if (!have || (g->bvec && !(*done_lam > 0.0))) {        // the discrepancy principle's "unassigned / not reachable yet": the caller's branch
+    if (!have || (g->bvec && !g->ws[(g->collect_seq - 1) % nw]->y_valid)) {   // the discrepancy principle's "unassigned": the caller's branch
       TRK_REQUIRE(g->bvec, "trk_hgmres_iter: the worker returned no lambda");
       *done_ii = done;
       *done_blocks = -1;
