@@ -105,3 +105,25 @@ def test_solvers_on_a_tiny_problem():
     x, info = S.GKS(A, b, L, 2, 4, 1e-2)
     xo, _ = O.gks(Ao, b.reshape(-1, 1), Lo, 2, 4, 1e-2)
     assert relerr(x, xo.reshape(-1)) < 1e-4
+
+
+def test_scalar_block_download_by_mailbox_equals_the_tensor_copy():
+    """DevScalars.host() goes through the block's pinned mailbox for up to 4096 doubles (one small launch + a poll instead of a
+    staged tensor copy) and through torch beyond: the same numbers either way, for whole blocks, slices, negative and open bounds."""
+    from trips_py_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(5)
+    for n in (1, 7, 64, 1000, 4096, 5000):
+        S = eng.scalars(n)
+        v = rng.standard_normal(n)
+        S.t.copy_(torch.as_tensor(v))
+        ref = S.t.detach().to("cpu").numpy()
+        assert np.array_equal(S.host(), ref)
+        assert np.array_equal(S.host(0, n), ref)
+        if n >= 7:
+            assert np.array_equal(S.host(2, 6), ref[2:6])
+            assert np.array_equal(S.host(3, None), ref[3:])
+            assert np.array_equal(S.host(1, -1), ref[1:-1])
+        a = S.host(0, 1)
+        a[0] = 123.0                                   # a copy: the block is untouched
+        assert S.host(0, 1)[0] == ref[0]
