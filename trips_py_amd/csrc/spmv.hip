@@ -39,6 +39,15 @@ struct SpImpl {
 //  TRK_CSR_NT=1 keeps the variant for measurements)
 template <bool NTL> __device__ __forceinline__ float ldm(const float* p) { return NTL ? __builtin_nontemporal_load(p) : *p; }
 template <bool NTL> __device__ __forceinline__ int ldm(const int* p) { return NTL ? __builtin_nontemporal_load(p) : *p; }
+// four consecutive entries of a stream in one 16-byte load at 4-byte alignment (a row starts wherever indptr says)
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));
+typedef int i4u __attribute__((ext_vector_type(4), aligned(4)));
+template <bool NTL> __device__ __forceinline__ f4u ldm4(const float* p) {
+  return NTL ? __builtin_nontemporal_load(reinterpret_cast<const f4u*>(p)) : *reinterpret_cast<const f4u*>(p);
+}
+template <bool NTL> __device__ __forceinline__ i4u ldm4(const int* p) {
+  return NTL ? __builtin_nontemporal_load(reinterpret_cast<const i4u*>(p)) : *reinterpret_cast<const i4u*>(p);
+}
 
 // Accumulator type of the per-lane chains: fp32 (four chains per lane, float64 only across the group).  ADVICE r05 suggested float64 chains
 // for the 2-lane rows (first differences, framelets: at most two products per chain) as "almost free" — measured in round 6
@@ -55,7 +64,15 @@ __device__ __forceinline__ double chain_fma(float v, float x, double a) { return
 // KB right-hand sides per pass (KB = 1: y = A x; KB = 2 / 4 / 8: Y[:, b] = A X[:, b], columns ldx / ldy apart — `A @ V` on an (n, k)
 // block, GKS.py:37 / MMGKS.py:44): the matrix streams (8 bytes per non-zero) are read ONCE for the KB columns; each column keeps
 // the single-vector kernel's chains and summation order, so its result is bit-identical to a y = A x of that column alone.
-template <int G, int KB, bool SUMSQ, bool NTL>
+// V4 (late round 6; rows of eight lanes and more): the row's non-zeros are dealt to the lanes in QUADS of four consecutive ones — lane g
+// takes quads g, g + G, ... — so that a lane fetches its four values and its four column indices with ONE 16-byte load each, two quads in
+// flight: half the load instructions of the entry-per-lane form (one load per value, one per index, one gather).  Measured on the 16-frame
+// Joseph matrix, same box: forward (431 per row, 16 lanes) cold 44.8 -> 43.2 us, warm 34.1 -> 32.8; the transpose (17 per row, 4 lanes)
+// LOSES with it, 43.8 -> 49.1 cold — hence eight lanes and more.  So the matrix streams' instruction count is not the bound either: what
+// is left is the gathers of x, 17.7 M of them fetching a 64-byte sector each.  A lane's four chains take the four entries of its quads;
+// what is left of a row after its last whole quad (<= 3 entries) goes to lanes 0 .. 2 on their first chain.  Every column of a batch keeps
+// this order: bit-identical to its single apply, as before.
+template <int G, int KB, bool SUMSQ, bool NTL, bool V4>
 __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned* __restrict__ indptr,
                                                   const int* __restrict__ indices, const float* __restrict__ vals,
                                                   const float* __restrict__ x, int64_t ldx, float* __restrict__ y, int64_t ldy,
@@ -87,11 +104,59 @@ __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned*
 #pragma unroll
     for (int b = 0; b < KB; ++b) a0[b] = a1[b] = a2[b] = a3[b] = (acc_t)0;
     unsigned p = p0 + g;
+    if (V4) {
+      const unsigned nq = (p1 - p0) >> 2;
+      unsigned q = g;
+      for (; q + G < nq; q += 2 * G) {                                 // two quads of each stream in flight per lane
+        const unsigned ba = p0 + 4 * q, bb = p0 + 4 * (q + G);
+        const f4u va = ldm4<NTL>(vals + ba), vb = ldm4<NTL>(vals + bb);
+        const i4u ca = ldm4<NTL>(indices + ba), cb = ldm4<NTL>(indices + bb);
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+          const float* __restrict__ xb = x + (int64_t)b * ldx;
+          const float x0 = xb[ca[0]], x1 = xb[ca[1]], x2 = xb[ca[2]], x3 = xb[ca[3]];
+          const float x4 = xb[cb[0]], x5 = xb[cb[1]], x6 = xb[cb[2]], x7 = xb[cb[3]];
+          a0[b] = chain_fma(va[0], x0, a0[b]);
+          a1[b] = chain_fma(va[1], x1, a1[b]);
+          a2[b] = chain_fma(va[2], x2, a2[b]);
+          a3[b] = chain_fma(va[3], x3, a3[b]);
+          a0[b] = chain_fma(vb[0], x4, a0[b]);
+          a1[b] = chain_fma(vb[1], x5, a1[b]);
+          a2[b] = chain_fma(vb[2], x6, a2[b]);
+          a3[b] = chain_fma(vb[3], x7, a3[b]);
+        }
+      }
+      if (q < nq) {
+        const unsigned ba = p0 + 4 * q;
+        const f4u va = ldm4<NTL>(vals + ba);
+        const i4u ca = ldm4<NTL>(indices + ba);
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+          const float* __restrict__ xb = x + (int64_t)b * ldx;
+          a0[b] = chain_fma(va[0], xb[ca[0]], a0[b]);
+          a1[b] = chain_fma(va[1], xb[ca[1]], a1[b]);
+          a2[b] = chain_fma(va[2], xb[ca[2]], a2[b]);
+          a3[b] = chain_fma(va[3], xb[ca[3]], a3[b]);
+        }
+      }
+      {                                                                 // the row's last <= 3 entries: lanes 0 .. 2, first chain
+        const unsigned pt = p0 + 4 * nq + g;
+        const bool ht = g < 3 && pt < p1;
+        const float vt = ht ? ldm<NTL>(vals + pt) : 0.f;
+        const int ct = ht ? ldm<NTL>(indices + pt) : 0;
+#pragma unroll
+        for (int b = 0; b < KB; ++b) {
+          const float* __restrict__ xb = x + (int64_t)b * ldx;
+          a0[b] = chain_fma(vt, ht ? xb[ct] : 0.f, a0[b]);
+        }
+      }
+      p = p1;                                                           // (the entry-per-lane loops below find nothing left)
+    }
     // one right-hand side, long rows: EIGHT loads of each stream in flight per lane (round 6).  From HBM — the matrix of a real dynamic
     // problem does not fit the memory-side cache — a trip is one memory round trip plus one gather round trip, and a row of 431 non-zeros
     // over 16 lanes was seven dependent trips of four: 46 us cold against 33 us warm on the 16-frame Joseph matrix.  Same four chains,
     // the second four products behind the first four.
-    if (KB == 1) {
+    if (KB == 1 && !V4) {
       // software-pipelined: the NEXT trip's values and indices are requested behind this trip's gathers, so that a trip costs the longer
       // of the two round trips (matrix from HBM, x from L2) instead of their sum
       if (p + 7 * G < p1) {
@@ -145,7 +210,7 @@ __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned*
       }
     }
     // up to three more, issued together (predicated: a row's tail, or the whole of a short row)
-    {
+    if (!V4) {
       const bool h0 = p < p1, h1 = p + G < p1, h2 = p + 2 * G < p1;
       const float v0 = h0 ? ldm<NTL>(vals + p) : 0.f, v1 = h1 ? ldm<NTL>(vals + p + G) : 0.f, v2 = h2 ? ldm<NTL>(vals + p + 2 * G) : 0.f;
       const int c0 = h0 ? ldm<NTL>(indices + p) : 0, c1 = h1 ? ldm<NTL>(indices + p + G) : 0, c2 = h2 ? ldm<NTL>(indices + p + 2 * G) : 0;
@@ -182,9 +247,16 @@ __global__ __launch_bounds__(NT) void k_csr_group(int64_t nrows, const unsigned*
 template <int G, int KB>
 void launch_group(const Csr& M, int grid, const float* xb, int64_t ldx, float* yb, int64_t ldy, double* pb, hipStream_t s) {
   static const bool ntl = getenv("TRK_CSR_NT") && atoi(getenv("TRK_CSR_NT")) != 0;
-#define CG(SS, NN) hipLaunchKernelGGL((k_csr_group<G, KB, SS, NN>), dim3(grid), dim3(NT), 0, s, M.nrows, M.indptr, M.indices, M.vals, xb, ldx, yb, ldy, pb, grid)
-  if (pb) { if (ntl) CG(true, true); else CG(true, false); }
-  else    { if (ntl) CG(false, true); else CG(false, false); }
+  static const bool no_v4 = getenv("TRK_CSR_NO_VEC4") && atoi(getenv("TRK_CSR_NO_VEC4")) != 0;     // (the entry-per-lane form everywhere)
+  constexpr bool V = G >= 8;
+#define CG(SS, NN, VV) hipLaunchKernelGGL((k_csr_group<G, KB, SS, NN, VV>), dim3(grid), dim3(NT), 0, s, M.nrows, M.indptr, M.indices, M.vals, xb, ldx, yb, ldy, pb, grid)
+  if (V && !no_v4) {
+    if (pb) { if (ntl) CG(true, true, V); else CG(true, false, V); }
+    else    { if (ntl) CG(false, true, V); else CG(false, false, V); }
+  } else {
+    if (pb) { if (ntl) CG(true, true, false); else CG(true, false, false); }
+    else    { if (ntl) CG(false, true, false); else CG(false, false, false); }
+  }
 #undef CG
 }
 
