@@ -108,12 +108,12 @@ def test_solvers_on_a_tiny_problem():
 
 
 def test_scalar_block_download_by_mailbox_equals_the_tensor_copy():
-    """DevScalars.host() goes through the block's pinned mailbox for up to 4096 doubles (one small launch + a poll instead of a
+    """DevScalars.host() goes through the block's pinned mailbox for up to HOST_BY_MAILBOX_MAX doubles (one small launch + a poll instead of a
     staged tensor copy) and through torch beyond: the same numbers either way, for whole blocks, slices, negative and open bounds."""
     from trips_py_amd.engine import default_engine
     eng = default_engine()
     rng = np.random.default_rng(5)
-    for n in (1, 7, 64, 1000, 4096, 5000):
+    for n in (1, 7, 64, 256, 257, 1000, 5000):
         S = eng.scalars(n)
         v = rng.standard_normal(n)
         S.t.copy_(torch.as_tensor(v))

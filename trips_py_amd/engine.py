@@ -74,7 +74,7 @@ class DevScalars:
     def view(self, i=0, j=None):
         return self.t[i:j]
 
-    HOST_BY_MAILBOX_MAX = 4096
+    HOST_BY_MAILBOX_MAX = 256          # (measured: MMGKS's 2 k^2 + 2 k Gram doubles per iteration travel no faster by mailbox than by tensor copy)
 
     def host(self, i=0, j=None):
         """A blocking download of scalars [i, j) as a float64 array.  Up to HOST_BY_MAILBOX_MAX doubles go through the block's mailbox
