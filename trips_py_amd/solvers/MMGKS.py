@@ -114,7 +114,11 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
     # pnorm = 2: wf = ((A x - b)^2 + eps^2)^0 = 1, the fidelity Gram (AV)^T AV is UNWEIGHTED and only grows — it is kept as in GKS
     # (solvers/GKS._ProjectedBases): new row = V^T (A^T A v_new), one pass over V (n floats per vector) instead of the weighted-Gram
     # pass over the images A v_j, which are not stored; the L side stays re-weighted every iteration (trk_wgram over LV)
-    unit_A = (pnorm == 2 and on_dev and dA and hasattr(eng, "gram_row_from_sweep") and hasattr(eng, "cgs_coeffs")
+    # ... also with regparam='gcv' (the reference's default; late round 6): the projected problem then visits the host, but the fidelity Gram
+    # it needs is the same growing one — downloaded, not re-formed from stored images A v_j by a weighted-Gram pass every iteration
+    # (2048^2: 16 % of the device's time, and kmax x m floats of images)
+    gcv_host = isinstance(regparam, str) and regparam == "gcv" and hasattr(eng, "gram_tikhonov") and kwargs.get("device_solve", True)
+    unit_A = (pnorm == 2 and (on_dev or gcv_host) and dA and hasattr(eng, "gram_row_from_sweep") and hasattr(eng, "cgs_coeffs")
               and kmax <= eng.GRAM_TIKHONOV_MAX_K and kwargs.get("gram_sweeps", True) and kwargs.get("unweighted_fidelity_gram", True))
     AV = None if unit_A else DeviceBasis(eng, m, kmax)
     # the 2-D first-difference L has fused forms (trk_tv_weights / trk_tv_grad): L x is never written out
@@ -208,7 +212,24 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
         else:
             eng.wgram(LV.data, k, wr[:p_rows], None, G.ref(kk))          # (the rows of L: a sharded fused L keeps one weight row more)
         nred = 2 * kk + 2 * k
-        if pbA is not None:
+        if pbA is not None and not on_dev:
+            # regparam='gcv', unit fidelity weights: lambda and y on the host from the growing fidelity Gram, the re-weighted G_L and
+            # c = (AV)^T b (wf = 1: the selector's and the solve's right-hand sides coincide, MMGKS.py:97-106)
+            eng.allreduce(G, kk, 2 * kk)
+            ga = pbA.GA_d.host(0, kmax * kmax).reshape(kmax, kmax)[:k, :k]
+            gl = G.host(kk, 2 * kk).reshape(k, k)
+            cc = pbA.c_d.host(0, k)
+            one = gram_gcv_host(ga, gl, cc, cc) if kwargs.get("host_solve_in_c", True) else None
+            if one is not None:
+                lam, y = one
+            else:
+                R_A, R_L = gram_factor(ga), gram_factor(gl)
+                rhs_b = project_rhs(R_A, cc)
+                lam = choose_lambda(regparam, R_A, R_L, rhs_b, 0.0, kwargs)
+                y = tikhonov_lstsq(R_A, R_L, lam, rhs_b)
+            lams.append(lam)
+            Y.set(0, y)
+        elif pbA is not None:
             eng.allreduce(G, kk, 2 * kk)
             lam = regparam
             lams.append(lam)
