@@ -82,8 +82,17 @@ class _ProjectedBases:
         self.on_device = bool(on_device)
         self.kmax = int(kmax)
         if self.on_device:
-            self.GA_d, self.GL_d = eng.scalars(self.kmax * self.kmax), eng.scalars(self.kmax * self.kmax)
-            self.c_d = eng.scalars(self.kmax)
+            # (one block: an automatic selector downloads G_A, G_L and c with ONE copy per iteration — download_grams)
+            from ..engine import DevScalars
+            kq = self.kmax * self.kmax
+            blk = eng.scalars(2 * kq + self.kmax)
+            if isinstance(blk, DevScalars):
+                self._gram_block = blk
+                self.GA_d, self.GL_d = DevScalars(blk.t[:kq], eng), DevScalars(blk.t[kq:2 * kq], eng)
+                self.c_d = DevScalars(blk.t[2 * kq:], eng)
+            else:                                   # (another engine's scalar blocks — the CPU test engine: three blocks, three downloads)
+                self._gram_block = None
+                self.GA_d, self.GL_d, self.c_d = eng.scalars(kq), eng.scalars(kq), eng.scalars(self.kmax)
         m, n = A.shape
         p = L.shape[0]
         self.V = V0
@@ -181,6 +190,15 @@ class _ProjectedBases:
         self.GA[j, :k] = self.GA[:k, j] = h[:k]
         self.GL[j, :k] = self.GL[:k, j] = h[k:2 * k]
         self.c[j] = h[2 * k]
+
+    def download_grams(self, k):
+        """(G_A[:k, :k], G_L[:k, :k], c[:k]) of the device-resident Gram data as host views of one download (row stride kmax)."""
+        kq = self.kmax * self.kmax
+        if self._gram_block is None:
+            return (self.GA_d.host(0, kq).reshape(self.kmax, self.kmax)[:k, :k], self.GL_d.host(0, kq).reshape(self.kmax, self.kmax)[:k, :k],
+                    self.c_d.host(0, k))
+        h = self._gram_block.host()
+        return (h[:kq].reshape(self.kmax, self.kmax)[:k, :k], h[kq:2 * kq].reshape(self.kmax, self.kmax)[:k, :k], h[2 * kq:2 * kq + k])
 
     def normalise_new(self, coef, vn):
         """vn <- coef * vn for the basis vector about to be committed (v = r / ||r||).  Where c_j = v_j . (A^T b) is a dot of its
@@ -289,7 +307,12 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         and (kmax <= eng.GRAM_TIKHONOV_MAX_K or kwargs.get("border_inverse", True)) and kwargs.get("device_solve", True)
     dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
     from_v = hasattr(eng, "gemv_t2") and kwargs.get("gram_from_v", True)
-    pb = _ProjectedBases(A, L, bv, gk.V, kmax, on_device=on_dev, from_v_A=dA and from_v, from_v_L=dL and from_v)
+    # regparam='gcv' (the reference's default; late round 6): the Gram data is kept on the device all the same — its rows then come from the
+    # orthogonalisation sweep's own pass over V (gram_rows_from_sweep) instead of two sweeps of their own — and the selector downloads it
+    # with one copy per iteration (kwarg device_gram)
+    dev_gram = on_dev or (isinstance(regparam, str) and regparam == "gcv" and hasattr(eng, "gram_tikhonov") and hasattr(eng, "cgs_coeffs")
+                          and kwargs.get("device_solve", True) and kwargs.get("device_gram", True))
+    pb = _ProjectedBases(A, L, bv, gk.V, kmax, on_device=dev_gram, from_v_A=dA and from_v, from_v_L=dL and from_v)
     Hs = History(eng, kwargs.get("history", True), n_iter, n, "GKS xHistory")
     Y = eng.scalars(kmax)
     H = eng.scalars(3 * kmax)
@@ -321,13 +344,14 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
                               Minv=Minv, ldm=kmax, k_from=k_inv)
             k_inv = k
         else:
-            one = gram_gcv_host(pb.GA[:k, :k], pb.GL[:k, :k], pb.c[:k], pb.c[:k]) if (regparam == "gcv" and kwargs.get("host_solve_in_c", True)) else None
+            hGA, hGL, hc = pb.download_grams(k) if dev_gram else (pb.GA[:k, :k], pb.GL[:k, :k], pb.c[:k])
+            one = gram_gcv_host(hGA, hGL, hc, hc) if (regparam == "gcv" and kwargs.get("host_solve_in_c", True)) else None
             if one is not None:                   # the whole projected problem in one library call (trk_host_gram_gcv)
                 lam, y = one
                 lams.append(lam)
             else:
-                R_A, R_L = gram_factor(pb.GA[:k, :k]), gram_factor(pb.GL[:k, :k])
-                rhs = project_rhs(R_A, pb.c[:k])
+                R_A, R_L = gram_factor(hGA), gram_factor(hGL)
+                rhs = project_rhs(R_A, hc)
                 lam = choose_lambda(regparam, R_A, R_L, rhs, max(b2 - float(rhs @ rhs), 0.0), kwargs)
                 lams.append(lam)
                 y = tikhonov_lstsq(R_A, R_L, lam, rhs)
@@ -366,7 +390,7 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
             eng.axpby(1.0, r, float(lam), rb, r)
         _trace.mark("GKS: orthogonalise, new basis vector")
         vn = pb.V.next_slot()
-        merged = (on_dev and gs_gram is not None and pb.from_v_L and hasattr(eng, "gram_row_from_sweep")
+        merged = (dev_gram and gs_gram is not None and pb.from_v_L and hasattr(eng, "gram_row_from_sweep")
                   and gs_gram.in_G == k - 1 and kwargs.get("gram_rows_from_sweep", True))
         cc = None
         if merged:

@@ -216,9 +216,8 @@ def MMGKS(A, b, L, pnorm=2, qnorm=1, projection_dim=3, n_iter=5, regparam="gcv",
             # regparam='gcv', unit fidelity weights: lambda and y on the host from the growing fidelity Gram, the re-weighted G_L and
             # c = (AV)^T b (wf = 1: the selector's and the solve's right-hand sides coincide, MMGKS.py:97-106)
             eng.allreduce(G, kk, 2 * kk)
-            ga = pbA.GA_d.host(0, kmax * kmax).reshape(kmax, kmax)[:k, :k]
+            ga, _, cc = pbA.download_grams(k)
             gl = G.host(kk, 2 * kk).reshape(k, k)
-            cc = pbA.c_d.host(0, k)
             one = gram_gcv_host(ga, gl, cc, cc) if kwargs.get("host_solve_in_c", True) else None
             if one is not None:
                 lam, y = one
