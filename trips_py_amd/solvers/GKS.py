@@ -307,10 +307,10 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         and (kmax <= eng.GRAM_TIKHONOV_MAX_K or kwargs.get("border_inverse", True)) and kwargs.get("device_solve", True)
     dA, dL = bool(getattr(A, "streaming", False)), bool(getattr(L, "streaming", False))
     from_v = hasattr(eng, "gemv_t2") and kwargs.get("gram_from_v", True)
-    # regparam='gcv' (the reference's default; late round 6): the Gram data is kept on the device all the same — its rows then come from the
+    # an automatic regparam ('gcv', the reference's default, 'dp', 'l_curve'; late round 6): the Gram data is kept on the device all the same — its rows then come from the
     # orthogonalisation sweep's own pass over V (gram_rows_from_sweep) instead of two sweeps of their own — and the selector downloads it
     # with one copy per iteration (kwarg device_gram)
-    dev_gram = on_dev or (isinstance(regparam, str) and regparam == "gcv" and hasattr(eng, "gram_tikhonov") and hasattr(eng, "cgs_coeffs")
+    dev_gram = on_dev or (isinstance(regparam, str) and hasattr(eng, "gram_tikhonov") and hasattr(eng, "cgs_coeffs")
                           and kwargs.get("device_solve", True) and kwargs.get("device_gram", True))
     pb = _ProjectedBases(A, L, bv, gk.V, kmax, on_device=dev_gram, from_v_A=dA and from_v, from_v_L=dL and from_v)
     Hs = History(eng, kwargs.get("history", True), n_iter, n, "GKS xHistory")
