@@ -537,6 +537,12 @@ int trk_gemv_t2(const float* V, int64_t ld, int k, int64_t n, const float* r, co
  * passes = 0 only installs.  One workgroup; k x k work. */
 int trk_cgs_coeffs(double* G_dev, int ldg, const double* h_dev, const double* g_new_dev, int k, int passes, double* c_dev,
                    trk_stream stream);
+/* The same (passes >= 1) and, from *rr_dev = r . r, the squared norm of the orthogonalised vector before any pass forms it:
+ * *rho2_dev = || r - V c ||^2 = r.r - 2 c.h + c.(G c).  In GKS / MMGKS r is the residual of the projected normal equations —
+ * orthogonal to V but for rounding, c.h and c.G c are ~1e-14 of r.r — so the value is the computed norm (GKS.py:89) to float64
+ * rounding.  Serves trk_gemv_orth_iterate. */
+int trk_cgs_coeffs_rho(double* G_dev, int ldg, const double* h_dev, const double* g_new_dev, int k, int passes, double* c_dev,
+                       const double* rr_dev, double* rho2_dev, trk_stream stream);
 /* out = a*base + s * sum_j y[j]*V[j]   (y: k device doubles; base may be NULL; out may alias base).
  * (x = V@y: Hybrid_LSQR.py:105, Hybrid_GMRES.py:77, GKS.py:76; r -= V h: GKS.py:86-88) */
 int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y_dev, double a, const float* base,
@@ -546,6 +552,16 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y_dev
  * trk_finalize_batched instead of one reduction-finalize launch per iterate). */
 int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y, float* out, const float* ref,
                    double* err_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
+/* The new basis vector AND the next iterate in one pass over the basis (GKS.py:76 + :86-91, MMGKS.py:108 + :119-122):
+ *   vn = (w - sum_{j<k} c[j] V[j]) / sqrt(*rho2)          (the orthogonalised, normalised direction: V[k] once the caller commits it)
+ *   x_next = sum_{j<k} y_next[j] V[j] + y_next[k] vn       (the iterate of the NEXT iteration, k + 1 coefficients; NULL with y_next: vn only)
+ * c, rho2, y_next: device doubles (rho2 from trk_cgs_coeffs_rho; y_next from the projected problem over k + 1 vectors, whose Gram rows
+ * trk_gram_row_from_sweep derives without v_k).  ref != NULL: block partials of ||x_next - ref||^2 as in trk_gemv_n_err.
+ * chk_sumsq != NULL: *chk_sumsq = ||w - V c||^2 as this pass computes it (what *rho2 stands for; one more finalize launch).
+ * The reference forms x = V y at the top of every iteration and r - V (V^T r) at its bottom: two passes over the basis; here one. */
+int trk_gemv_orth_iterate(const float* V, int64_t ld, int k, int64_t n, const float* w, const double* c_dev, const double* rho2_dev,
+                          const double* y_next_dev, float* vn, float* x_next, const float* ref, double* err_partials,
+                          int capacity_blocks, int* n_blocks, double* chk_sumsq_dev, trk_stream stream);
 /* out = sum_j y_host[j] V[j] with the k coefficients read from HOST memory at the call: they travel in the launch's own arguments
  * (128 per launch; more rows = more launches adding to `out`), so a projected solution computed on the host (x = V y,
  * Hybrid_LSQR.py:105) needs neither an upload nor a kernel of its own.  ref != NULL: block partials of ||out - ref||^2 as in

@@ -555,6 +555,61 @@ def test_gemv_n_err_partials(k, n):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,n,with_x", [(1, 1000, True), (5, 4099, True), (13, 70_001, False), (40, 262_144, True)])
+def test_gemv_orth_iterate_one_pass_for_the_new_vector_and_the_next_iterate(k, n, with_x):
+    """trk_cgs_coeffs_rho + trk_gemv_orth_iterate: rho^2 = ||w - V c||^2 by algebra from the sweep's products, vn = (w - V c)/rho and
+    x' = V y'[:k] + y'[k] vn in ONE pass — against float64 NumPy, against the pass's own computed norm (chk), and x' bit for bit
+    against trk_gemv_n over the k + 1 stored vectors (the sum it replaces, term for term)."""
+    import torch
+    from trips_py_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(100 + k)
+    V = eng.empty_basis(k + 1, n)
+    Q, _ = np.linalg.qr(rng.standard_normal((n, k)))
+    Vh = np.ascontiguousarray(Q.T).astype(np.float32)                 # orthonormal to fp32 rounding
+    V[:k].copy_(torch.from_numpy(Vh))
+    w64 = rng.standard_normal(n)
+    w64 -= Q @ (Q.T @ w64) * (1.0 - 1e-4)                             # nearly orthogonal to V, as the solvers' residuals are
+    w = torch.from_numpy(w64.astype(np.float32)).to(eng.device)
+    wd, Vd = w.cpu().numpy().astype(np.float64), Vh.astype(np.float64)
+    W, G, C, RR = eng.scalars(4 * (k + 1)), eng.scalars((k + 1) * (k + 1)), eng.scalars(k + 1), eng.scalars(3)
+    for j in range(k):                                                # G = V^T V, row by row as GramSchmidtByGram installs it
+        eng.gemv_t(V, j + 1, V[j], W.ref(0))
+        eng.cgs_coeffs(G.ref(0), k + 1, None, W.ref(0), j + 1, 0, None)
+    eng.gemv_t(V, k, w, W.ref(0))
+    eng.nrm2sq(w, RR.ref(0))
+    eng.cgs_coeffs_rho(G.ref(0), k + 1, W.ref(0), None, k, 3, C.ref(0), RR.ref(0), RR.ref(1))
+    c = C.host()[:k]
+    o64 = wd - Vd.T @ c
+    rho2 = RR.host()[1]
+    assert abs(rho2 - float(o64 @ o64)) <= 1e-9 * float(o64 @ o64)
+    yh = rng.standard_normal(k + 1)
+    Y = eng.scalars(k + 1)
+    Y.set(0, yh)
+    ref = torch.from_numpy(rng.standard_normal(n).astype(np.float32)).to(eng.device)
+    x, x2 = eng.empty(n), eng.empty(n)
+    EP, E = eng.scalars(2048), eng.scalars(1)
+    if with_x:
+        nb = eng.gemv_orth_iterate(V, k, w, C.ref(0), RR.ref(1), V[k], y_next=Y.ref(0), x_next=x, ref=ref, partials=EP.ref(0),
+                                   capacity=2048, chk=RR.ref(2))
+        assert 1 <= nb <= 2048
+    else:
+        assert eng.gemv_orth_iterate(V, k, w, C.ref(0), RR.ref(1), V[k], chk=RR.ref(2)) == 0
+    vn = V[k].cpu().numpy().astype(np.float64)
+    want = o64 / np.sqrt(rho2)
+    assert np.abs(vn - want).max() <= 1.2e-7 * np.abs(want).max() + 1e-12
+    assert abs(float(vn @ vn) - 1.0) < 1e-6
+    chk = RR.host()[2]
+    assert abs(chk - rho2) <= 1e-9 * rho2                             # the computed norm and the algebraic one
+    if with_x:
+        eng.gemv_n(V, k + 1, Y.ref(0), x2)
+        assert torch.equal(x, x2)
+        eng.finalize_batched(EP.ref(0), nb, 1, 1, E.ref(0), 1)
+        e = float(np.sum((x.cpu().numpy().astype(np.float64) - ref.cpu().numpy().astype(np.float64)) ** 2))
+        assert abs(E.host()[0] - e) <= 1e-12 * e
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("groups,glen,copies,expo", [(1, 1, 1, -0.5), (37, 3, 3, -0.5), (1000, 7, 2, -0.75), (5000, 32, 1, 0.0)])
 def test_group_weights(groups, glen, copies, expo):
     """trk_group_weights: (sum of squares over each group of consecutive entries + add)^expo, tiled `copies` times."""

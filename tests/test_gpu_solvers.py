@@ -568,6 +568,48 @@ def test_gks_gram_rows_from_the_sweep_equal_the_separate_pass(kind):
         assert float(torch.linalg.norm(u - v) / torch.linalg.norm(v)) < 1e-5, k
 
 
+@pytest.mark.parametrize("kind,rp", [("blur", 1e-2), ("dynamic_tomo", 1e-2), ("blur", "gcv"), ("dynamic_tomo", "gcv"), ("dynamic_tomo", "dp")])
+@pytest.mark.parametrize("hist", [True, False])
+def test_gks_one_pass_for_new_vector_and_next_iterate_equals_the_two_pass_form(kind, rp, hist):
+    """GKS (late round 6): the projected problem of iteration i + 1 solved before r - V c is formed — its Gram rows and rho come from
+    the h-sweep's products — so that ONE pass over the basis leaves the new vector and the next iterate (trk_gemv_orth_iterate); against
+    the form with a pass each (fused_orth_iterate=False): iterates, residual norms, errors and lambdas over 30 iterations, for a stencil
+    A (Gram rows of both sides from V) and for the Radon A that keeps its images (A v_k = (A r - AV c)/rho)."""
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import Blur2D, BlockDiagOp, FirstDerivative2D, Radon2DParallel, SpaceTimeDerivative
+    from trips_py_amd.problems import gauss_psf
+    if kind == "blur":
+        N = 128
+        A = Blur2D(gauss_psf((9, 9), (2, 2))[0], N, N)
+        L = FirstDerivative2D(N)
+    else:
+        N, nt = 64, 4
+        A = BlockDiagOp([Radon2DParallel(N, np.deg2rad(5.0 * t + 12.0 * np.arange(15))) for t in range(nt)])
+        L = SpaceTimeDerivative(N, nt)
+    dev = A.engine.device
+    n = A.shape[1]
+    xt = torch.rand(n, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    b0 = A.apply(xt)
+    e = 0.01 * torch.randn(b0.numel(), device=dev, generator=torch.Generator(device=dev).manual_seed(6)) * b0.norm() / b0.numel() ** 0.5
+    b = b0 + e
+    kw = {"delta": float(e.norm())} if rp == "dp" else {}
+    its = 30
+    xa, ia = S.GKS(A, b, L, 3, its, rp, xt, history=hist, **kw)
+    xb, ib = S.GKS(A, b, L, 3, its, rp, xt, history=hist, fused_orth_iterate=False, **kw)
+    auto = isinstance(rp, str)
+    tol = 2e-3 if auto else 1e-5                                     # an automatic lambda amplifies 1e-7 differences of the Gram data
+    assert float(torch.linalg.norm(xa - xb) / torch.linalg.norm(xb)) < tol
+    assert len(ia["relError"]) == len(ib["relError"]) == its and len(ia["regParam_history"]) == len(ib["regParam_history"]) == its
+    assert np.allclose(ia["relError"], ib["relError"], rtol=1e-2 if auto else 1e-5)
+    assert np.allclose(ia["Residual"], ib["Residual"], rtol=2e-2 if auto else 1e-3)
+    assert np.allclose(ia["regParam_history"], ib["regParam_history"], rtol=5e-2 if auto else 0)
+    assert ia["regParam"] == ia["regParam_history"][-1]
+    if hist:
+        for k in (0, 1, 10, its - 1):
+            u, v = ia["xHistory"][k].reshape(-1), ib["xHistory"][k].reshape(-1)
+            assert float(torch.linalg.norm(u - v) / torch.linalg.norm(v)) < tol, k
+
+
 def test_mmgks_pnorm2_unweighted_fidelity_gram_kept_incrementally():
     """MMGKS with pnorm = 2: wf = 1, so (AV)^T AV is unweighted and only grows — kept as in GKS (row k = V^T (A^T A v_k), no images
     A v_j, no weighted-Gram pass over them) while the L side is re-weighted every iteration.  Same iterates, residual norms and

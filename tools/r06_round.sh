@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6 GPU visit: ONE script, steps by name.  usage: tools/r06_round.sh <out-subdir> [steps...]
-# steps: test (whole -m gpu suite, bars logged) | tradon (projector tests) | radon (4096^2 / 2048^2 / 1024^2 / 512^2 projector rates) |
+# steps: test (whole -m gpu suite, bars logged) | soak (the suite three more times, two of them concurrently) | tradon (projector tests) | radon (4096^2 / 2048^2 / 1024^2 / 512^2 projector rates) |
 #        pmc_radon (counters of the 4096^2 pair) | smoke | drv | bench | bench2/4/8 (ranks on one GPU over gloo) | prof | c3 (C3 instrument) | py:<script> [runs tools/<script>] |
 #        mb:<name> (builds + runs tools/microbench/<name>.hip) | traffic:<tag>,<script>[,args] | stats:<tag>,<script>[,args] | gaps:<tag>,<n>,<script>[,args]
 R=$GRAFT_REPO_ROOT
@@ -14,6 +14,16 @@ for s in $STEPS; do case $s in
 test)
   rm -f $O/bars.txt
   TRK_BARS_LOG=$O/bars.txt timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest_gpu.log ;;
+soak)
+  # the whole -m gpu suite three more times: once alone, then two copies side by side on the one GPU (host threads, mailboxes and worker
+  # pools under contention) — the round-end gate runs this suite on a fresh box, a flaky test there costs the round
+  timeout 1200 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/soak_1.log 2>&1; echo "soak 1 rc=$?"; tail -1 $O/soak_1.log
+  (timeout 1800 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/soak_2a.log 2>&1; echo "soak 2a rc=$?") &
+  p1=$!
+  (timeout 1800 python -m pytest tests -m gpu -x -q -p no:cacheprovider > $O/soak_2b.log 2>&1; echo "soak 2b rc=$?") &
+  p2=$!
+  wait $p1 $p2
+  tail -1 $O/soak_2a.log; tail -1 $O/soak_2b.log ;;
 tradon)
   timeout 1500 python -m pytest tests/test_gpu_radon_accuracy.py tests/test_gpu_operators.py tests/test_gpu_ref64.py -m gpu -x -q > $O/pytest_radon.log 2>&1; echo "pytest radon rc=$?"; tail -6 $O/pytest_radon.log ;;
 radon)

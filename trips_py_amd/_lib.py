@@ -240,6 +240,9 @@ SIGNATURES = {
     "trk_hess_tikhonov": (c_int, [c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_dbl, c_int, c_dbl, c_int, c_f64p,
                                   c_stream]),
     "trk_cgs_coeffs": (c_int, [c_f64p, c_int, c_f64p, c_f64p, c_int, c_int, c_f64p, c_stream]),
+    "trk_cgs_coeffs_rho": (c_int, [c_f64p, c_int, c_f64p, c_f64p, c_int, c_int, c_f64p, c_f64p, c_f64p, c_stream]),
+    "trk_gemv_orth_iterate": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f64p, c_f64p, c_f64p, c_f32p, c_f32p, c_f32p, c_f64p, c_int,
+                                      ctypes.POINTER(c_int), c_f64p, c_stream]),
     "trk_gemv_nt": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_gemv_n_err": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f64p, c_f32p, c_f32p, c_f64p, c_int, ctypes.POINTER(c_int), c_stream]),
     "trk_host_worker_create": (c_int, [ctypes.POINTER(ctypes.c_void_p)]),

@@ -367,9 +367,14 @@ __device__ __forceinline__ void symv4(const double* M, int ld, int k, const doub
 // (sweep p+1 projects the result of sweep p: V^T (r - V c_p) = h - G c_p) — any V, orthonormal or not.  With G kept on the
 // device (one new row per appended vector) the sweeps cost ONE pass over the basis for h and one for r - V c, instead of two
 // per sweep (GKS.py:86-88: three sweeps; MMGKS.py:119-120, decompositions.py:216-218: two).  k x k work, one workgroup.
+// rr != nullptr (*rr = r . r): also *rho2_out = || r - V c ||^2 = r.r - 2 c.h + c.(G c), so that the caller knows the norm of the
+// orthogonalised vector BEFORE the pass that forms it (trk_gemv_orth_iterate; GKS / MMGKS: r is orthogonal to V but for rounding,
+// c.h and c.G c are ~1e-14 of r.r).  Lifted to a tiny positive number should rounding ever drive it to <= 0.
 __global__ __launch_bounds__(256) void k_cgs_coeffs(double* __restrict__ G, int ldg, const double* __restrict__ h,
-                                                    const double* __restrict__ g_new, int k, int passes, double* __restrict__ c) {
+                                                    const double* __restrict__ g_new, int k, int passes, double* __restrict__ c,
+                                                    const double* __restrict__ rr = nullptr, double* __restrict__ rho2_out = nullptr) {
   extern __shared__ double sh[];           // c (k) | t (k)
+  __shared__ double red[2][4];
   double* cs = sh;
   double* ts = sh + k;
   if (g_new) {                             // install the Gram row / column of the newest vector (index k - 1)
@@ -394,6 +399,26 @@ __global__ __launch_bounds__(256) void k_cgs_coeffs(double* __restrict__ G, int 
   }
   if (c)
     for (int j = threadIdx.x; j < k; j += blockDim.x) c[j] = cs[j];
+  if (rr) {
+    double p_ch = 0.0, p_cgc = 0.0;
+    symv4(G, ldg, k, cs, [&](int i, double gc) {
+      p_ch += cs[i] * h[i];
+      p_cgc += cs[i] * gc;
+    });
+    p_ch = wave_sum(p_ch);
+    p_cgc = wave_sum(p_cgc);
+    if ((threadIdx.x & 63) == 0) {
+      red[0][threadIdx.x >> 6] = p_ch;
+      red[1][threadIdx.x >> 6] = p_cgc;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double ch = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+      const double cgc = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+      const double v = *rr - 2.0 * ch + cgc;
+      *rho2_out = v > 0.0 ? v : 1e-300;
+    }
+  }
 }
 
 // k_finalize over the 2k sums of a trk_gemv_t2 sweep (h = V^T r | the Gram row of the newest vector) and k_cgs_coeffs in ONE launch:
@@ -461,7 +486,16 @@ extern "C" int trk_cgs_coeffs(double* G, int ldg, const double* h, const double*
                               trk_stream st) {
   TRK_REQUIRE(G && k >= 1 && ldg >= k && passes >= 0 && (passes == 0 || (h && c)), "trk_cgs_coeffs: bad argument");
   TRK_REQUIRE(k <= 2048, "trk_cgs_coeffs: k <= 2048");
-  hipLaunchKernelGGL(k_cgs_coeffs, dim3(1), dim3(256), 2 * (size_t)k * sizeof(double), (hipStream_t)st, G, ldg, h, g_new, k, passes, c);
+  hipLaunchKernelGGL(k_cgs_coeffs, dim3(1), dim3(256), 2 * (size_t)k * sizeof(double), (hipStream_t)st, G, ldg, h, g_new, k, passes, c, (const double*)nullptr, (double*)nullptr);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+extern "C" int trk_cgs_coeffs_rho(double* G, int ldg, const double* h, const double* g_new, int k, int passes, double* c,
+                                  const double* rr, double* rho2_out, trk_stream st) {
+  TRK_REQUIRE(G && h && c && rr && rho2_out && k >= 1 && ldg >= k && passes >= 1, "trk_cgs_coeffs_rho: bad argument");
+  TRK_REQUIRE(k <= 2048, "trk_cgs_coeffs_rho: k <= 2048");
+  hipLaunchKernelGGL(k_cgs_coeffs, dim3(1), dim3(256), 2 * (size_t)k * sizeof(double), (hipStream_t)st, G, ldg, h, g_new, k, passes, c, rr, rho2_out);
   TRK_LAUNCH_CHECK();
   return TRK_OK;
 }

@@ -863,6 +863,109 @@ __global__ __launch_bounds__(NT) void k_gemv_n(const YS y, const float* __restri
   }
 }
 
+// ------------------------------------------------------------------ the new basis vector AND the next iterate in ONE pass over the basis
+// GKS / MMGKS pass over V three / four times per iteration: x = V y (GKS.py:76), h = V^T r, r - V c (:86-88) [+ the re-weighted Gram].
+// The iterate of the NEXT iteration is x' = V y'[0..k) + y'[k] v_k with v_k = (r - V c) / rho the vector this sweep produces — and y'
+// needs nothing of v_k but its Gram rows, which follow from the products of the h-sweep (trk_gram_row_from_sweep), and rho, which
+// follows from them too (trk_cgs_coeffs_rho: rho^2 = r.r - 2 c.h + c.G c; r is the residual of the projected normal equations, h
+// and c are of rounding size, nothing cancels).  So the projected problem of the next iteration is solved BEFORE this pass and the
+// pass leaves both vectors: one read of the basis less per iteration.
+//   vn = (w - sum_j c[j] V[j]) / sqrt(*rho2)        — the sums of k_gemv_n<HAS_BASE> in its order, ONE rounding to fp32 (after the scaling)
+//   x  = sum_{j<k} y[j] V[j] + y[k] vn              — k_gemv_n's sum over the k + 1 stored vectors, term for term (vn as stored)
+// HAS_REF: block partials of ||x - ref||^2 (trk_gemv_n_err's); chk != nullptr: block partials of ||w - V c||^2 as computed (float64,
+// before the scaling) — what rho^2 stands for, for callers who want to see the two agree.
+template <bool VEC, bool HAS_X, bool HAS_REF, int U>
+__global__ __launch_bounds__(NT) void k_gemv_orth_iter(const float* __restrict__ V, int64_t ld, int k, int64_t n,
+                                                       const float* __restrict__ w, const double* __restrict__ c,
+                                                       const double* __restrict__ rho2, const double* __restrict__ y, float* vn, float* x,
+                                                       const float* __restrict__ ref, double* __restrict__ partials,
+                                                       double* __restrict__ chk, int nt) {
+  __shared__ double2 cy[KMAX_LDS];      // (-c[j], y[j])
+  __shared__ double lds[NT / 64];
+  for (int j = threadIdx.x; j < k; j += NT) cy[j] = make_double2(-c[j], HAS_X ? y[j] : 0.0);
+  const double inv = 1.0 / sqrt(*rho2);
+  const double yk = HAS_X ? y[k] : 0.0;
+  __syncthreads();
+  double acc2 = 0.0, accc = 0.0;
+  const int64_t tid = (int64_t)blockIdx.x * NT + threadIdx.x, nth = (int64_t)gridDim.x * NT;
+  int64_t tail0 = 0;
+  if (VEC) {
+    const int64_t n4 = n >> 2;
+    tail0 = n4 << 2;
+    for (int64_t i = tid; i < n4; i += nth) {
+      const float4 b = ld4(w, i);
+      double o0 = 1.0 * b.x, o1 = 1.0 * b.y, o2 = 1.0 * b.z, o3 = 1.0 * b.w;
+      double x0 = 0, x1 = 0, x2 = 0, x3 = 0;
+      int j = 0;
+      auto group = [&](auto width) {
+        constexpr int W = decltype(width)::value;
+        float4 v[W];
+#pragma unroll
+        for (int u = 0; u < W; ++u) v[u] = (nt & 128) ? ld4_nt(V + (int64_t)(j + u) * ld, i) : ld4(V + (int64_t)(j + u) * ld, i);
+#pragma unroll
+        for (int u = 0; u < W; ++u) {
+          const double2 q = cy[j + u];
+          o0 = fma(q.x, (double)v[u].x, o0);
+          o1 = fma(q.x, (double)v[u].y, o1);
+          o2 = fma(q.x, (double)v[u].z, o2);
+          o3 = fma(q.x, (double)v[u].w, o3);
+          if (HAS_X) {
+            x0 = fma(q.y, (double)v[u].x, x0);
+            x1 = fma(q.y, (double)v[u].y, x1);
+            x2 = fma(q.y, (double)v[u].z, x2);
+            x3 = fma(q.y, (double)v[u].w, x3);
+          }
+        }
+        j += W;
+      };
+      while (j + U <= k) group(std::integral_constant<int, U>{});
+      if (U > 4 && j + 4 <= k) group(std::integral_constant<int, 4>{});
+      while (j < k) group(std::integral_constant<int, 1>{});
+      if (chk) accc += (o0 * o0 + o1 * o1) + (o2 * o2 + o3 * o3);
+      const float4 vo = make_float4((float)(o0 * inv), (float)(o1 * inv), (float)(o2 * inv), (float)(o3 * inv));
+      st4(vn, i, vo);
+      if (HAS_X) {
+        const float4 xo = make_float4((float)fma(yk, (double)vo.x, x0), (float)fma(yk, (double)vo.y, x1), (float)fma(yk, (double)vo.z, x2),
+                                      (float)fma(yk, (double)vo.w, x3));
+        st4(x, i, xo);
+        if (HAS_REF) {
+          const float4 t = ld4(ref, i);
+          const double e0 = (double)xo.x - t.x, e1 = (double)xo.y - t.y, e2 = (double)xo.z - t.z, e3 = (double)xo.w - t.w;
+          acc2 += e0 * e0 + e1 * e1 + e2 * e2 + e3 * e3;
+        }
+      }
+    }
+  }
+  for (int64_t i = tail0 + tid; i < n; i += nth) {
+    double o = 1.0 * w[i], xs = 0.0;
+    for (int j = 0; j < k; ++j) {
+      const double v = (double)V[(int64_t)j * ld + i];
+      o = fma(cy[j].x, v, o);
+      if (HAS_X) xs = fma(cy[j].y, v, xs);
+    }
+    if (chk) accc += o * o;
+    const float vo = (float)(o * inv);
+    vn[i] = vo;
+    if (HAS_X) {
+      const float xo = (float)fma(yk, (double)vo, xs);
+      x[i] = xo;
+      if (HAS_REF) {
+        const double e = (double)xo - ref[i];
+        acc2 += e * e;
+      }
+    }
+  }
+  if (HAS_X && HAS_REF) {
+    acc2 = block_sum<NT>(acc2, lds);
+    if (threadIdx.x == 0) partials[blockIdx.x] = acc2;
+  }
+  if (chk) {                                                      // uniform over the grid
+    __syncthreads();
+    accc = block_sum<NT>(accc, lds);
+    if (threadIdx.x == 0) chk[blockIdx.x] = accc;
+  }
+}
+
 // ------------------------------------------------------------------ damped-LSQR iterate by its short recurrence
 // x_k = V_k y_k with y_k = argmin || [B_k; damp I] y - beta_1 e_1 ||  (Hybrid_LSQR.py:104-105 with a FIXED lambda, damp =
 // sqrt(lambda)) is Paige & Saunders' damped LSQR iterate, which obeys  w_k = v_k - (theta_k / rho_{k-1}) w_{k-1},
@@ -2762,6 +2865,40 @@ int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y
   else
     hipLaunchKernelGGL((k_gemv_n<false, true, false, true>), dim3(grid), dim3(NT), 0, s, YPtr{y}, V, ld, k, n, 1.0, nobase, 1.0, out, err_partials, ref, stream_nontemporal(n));
   TRK_LAUNCH_CHECK();
+  return TRK_OK;
+}
+
+int trk_gemv_orth_iterate(const float* V, int64_t ld, int k, int64_t n, const float* w, const double* c, const double* rho2,
+                          const double* y_next, float* vn, float* x_next, const float* ref, double* err_partials, int capacity_blocks,
+                          int* n_blocks, double* chk_sumsq, trk_stream st) {
+  TRK_REQUIRE(V && w && c && rho2 && vn, "trk_gemv_orth_iterate: NULL argument");
+  TRK_REQUIRE((y_next != nullptr) == (x_next != nullptr), "trk_gemv_orth_iterate: y_next and x_next come together");
+  TRK_REQUIRE(!ref || (x_next && err_partials && n_blocks), "trk_gemv_orth_iterate: ref needs x_next and room for the partials");
+  TRK_REQUIRE(k >= 1 && k < KMAX_LDS && n >= 0 && ld >= n, "trk_gemv_orth_iterate: need 1 <= k < %d, n >= 0, ld >= n", KMAX_LDS);
+  TRK_REQUIRE(vn != w && x_next != w && x_next != vn, "trk_gemv_orth_iterate: the outputs must not alias w or each other");
+  static const int gmul = env_int("TRK_GEMVN_GRID", 8);        // trk_gemv_n_err's launch shape
+  int grid = stream_grid(n);
+  if (gmul > 0) {
+    const int g8 = (int)std::min<int64_t>((n + (int64_t)NT * 4 - 1) / ((int64_t)NT * 4), (int64_t)cu_count() * gmul);
+    if (g8 >= 1 && (!ref || g8 <= capacity_blocks)) grid = g8;
+  }
+  if (ref) {
+    TRK_REQUIRE(grid <= capacity_blocks, "trk_gemv_orth_iterate: partial buffer too small (%d blocks needed)", grid);
+    *n_blocks = grid;
+  }
+  hipStream_t s = (hipStream_t)st;
+  double* chk = nullptr;
+  if (chk_sumsq)
+    if (int rc = scratch_doubles(s, (size_t)grid, &chk)) return rc;
+  const bool vec = aligned16(V) && aligned16(w) && aligned16(vn) && (!x_next || aligned16(x_next)) && (!ref || aligned16(ref)) && (ld % 4 == 0);
+  const int nt = stream_nontemporal(n);
+#define GO(VC, HX, HR) hipLaunchKernelGGL((k_gemv_orth_iter<VC, HX, HR, 8>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, w, c, rho2, y_next, vn, x_next, ref, err_partials, chk, nt)
+  if (!x_next)  { if (vec) GO(true, false, false); else GO(false, false, false); }
+  else if (ref) { if (vec) GO(true, true, true); else GO(false, true, true); }
+  else          { if (vec) GO(true, true, false); else GO(false, true, false); }
+#undef GO
+  TRK_LAUNCH_CHECK();
+  if (chk_sumsq) return finalize_sums(chk, grid, 1, 1, chk_sumsq, s);
   return TRK_OK;
 }
 

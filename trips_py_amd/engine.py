@@ -682,6 +682,23 @@ class HipEngine:
         rc = self.lib.trk_cgs_coeffs(_ptr(G), int(ldg), _ptr(h), _ptr(g_new), int(k), int(passes), _ptr(c), self.stream())
         _lib.check(rc, "trk_cgs_coeffs")
 
+    def cgs_coeffs_rho(self, G, ldg, h, g_new, k, passes, c, rr, rho2):
+        """cgs_coeffs and, from rr = r . r, rho2 = ||r - V c||^2 by algebra (trk_cgs_coeffs_rho): the norm of the vector the next pass forms."""
+        rc = self.lib.trk_cgs_coeffs_rho(_ptr(G), int(ldg), _ptr(h), _ptr(g_new), int(k), int(passes), _ptr(c), _ptr(rr), _ptr(rho2),
+                                         self.stream())
+        _lib.check(rc, "trk_cgs_coeffs_rho")
+
+    def gemv_orth_iterate(self, V, k, w, c, rho2, vn, y_next=None, x_next=None, ref=None, partials=None, capacity=0, chk=None):
+        """vn = (w - V[0..k) c) / sqrt(rho2) and (with y_next, k + 1 device doubles) x_next = V[0..k) y_next[:k] + y_next[k] vn in ONE pass
+        over the basis (trk_gemv_orth_iterate); with `ref`, raw block partials of ||x_next - ref||^2 — returns their count (0 without)."""
+        n = ctypes.c_int(0)
+        rc = self.lib.trk_gemv_orth_iterate(V.data_ptr(), V.stride(0), int(k), vn.numel(), w.data_ptr(), _ptr(c), _ptr(rho2), _ptr(y_next),
+                                            vn.data_ptr(), None if x_next is None else x_next.data_ptr(),
+                                            None if ref is None else ref.data_ptr(), _ptr(partials), int(capacity), ctypes.byref(n),
+                                            _ptr(chk), self.stream())
+        _lib.check(rc, "trk_gemv_orth_iterate")
+        return n.value
+
     def gemv_n_err(self, V, k, y, out, ref, partials, capacity):
         """out = sum_j y[j] V[j]; raw block partials of ||out - ref||^2 into `partials`; returns their count."""
         n = ctypes.c_int(0)

@@ -459,10 +459,12 @@ class GramSchmidtByGram:
             eng.cgs_coeffs(self.G.ref(0), self.kmax, None, self.W.ref(0), j + 1, 0, None)
         self.in_G = V.k
 
-    def sweep(self, k, w, passes, out, sumsq=None, c_out=None, extra=(), tail=0):
+    def sweep(self, k, w, passes, out, sumsq=None, c_out=None, extra=(), tail=0, rr=None, rho2=None):
         """out = w orthogonalised against V[0..k) by `passes` sweeps; LOCAL sum(out^2) into `sumsq` (fused).  Returns the
         DevScalars reference of the k combined coefficients.  extra: one or two more vectors z whose products V^T z ride on
-        the same pass over the basis (trk_gemv_tn); they are left at `self.extra_ref(q, k)`."""
+        the same pass over the basis (trk_gemv_tn); they are left at `self.extra_ref(q, k)`.
+        rr / rho2 (with extra; one rank): rr = w . w on the device -> rho2 = ||w - V c||^2 by algebra (trk_cgs_coeffs_rho) and NO
+        pass forms `out` here (pass out=None): the caller's trk_gemv_orth_iterate forms it together with the next iterate."""
         eng, V, W, K = self.eng, self.V, self.W, self.kmax
         if k > K:
             raise ValueError("GramSchmidtByGram: basis larger than planned")
@@ -475,6 +477,10 @@ class GramSchmidtByGram:
             if (2 + len(extra)) * k + tail > 4 * K:
                 raise ValueError("GramSchmidtByGram: no room behind the sweep's products")
             eng.allreduce(W, 0, (2 + len(extra)) * k + tail)
+            if rr is not None:
+                eng.cgs_coeffs_rho(self.G.ref(0), K, W.ref(0), W.ref(k), k, passes, c, rr, rho2)
+                self.in_G = k
+                return c
             eng.cgs_coeffs(self.G.ref(0), K, W.ref(0), W.ref(k), k, passes, c)
             self.in_G = k
         elif self.in_G == k - 1:                      # the newest vector's Gram row rides along with h

@@ -251,8 +251,10 @@ class _ProjectedBases:
             eng.allreduce(S, 0, 3)
         return extra
 
-    def append_from_sweep(self, gs, k, c, rho2):
-        """After the sweep over k vectors (coefficients c, rho^2 = ||r - V c||^2) and the commit of v_k: rows k of the Gram data."""
+    def append_from_sweep(self, gs, k, c, rho2, r_early=None):
+        """After the sweep over k vectors (coefficients c, rho^2 = ||r - V c||^2) and the commit of v_k: rows k of the Gram data.
+        r_early: v_k = (r - V c) / rho is NOT formed yet (GKS's one-pass form, trk_gemv_orth_iterate) — where the images of A are kept,
+        A v_k = (A r - AV c) / rho comes from one product with r and the same kernel on the m-length images."""
         eng, S = self.eng, self.S
         Sw, so = getattr(self, "_sw", (self.S, 0))                          # where sweep_operands left r . M r
         q = 0
@@ -261,7 +263,13 @@ class _ProjectedBases:
             q += 1
         else:                                                             # the images of A are kept (small m): as in _push_images
             av = self.AV.next_slot()
-            self.A.apply(self.V[k], out=av)
+            if r_early is not None:
+                if getattr(self, "_tA_r", None) is None:
+                    self._tA_r = eng.empty(self.A.shape[0])
+                self.A.apply(r_early, out=self._tA_r)
+                eng.gemv_orth_iterate(self.AV.data, k, self._tA_r, c, rho2, av)
+            else:
+                self.A.apply(self.V[k], out=av)
             self.AV.commit()
             with_row = hasattr(eng, "gemv_t_x")       # c_k = (A v_k) . b from the Gram row's own pass (b as one more row)
             if eng.world > 1:                                             # c_k behind the Gram row: one exchange
@@ -333,9 +341,18 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     err_fused = xt is not None and hasattr(eng, "gemv_n_err") and kwargs.get("fused_error_norm", True)
     EP_CAP = 2048
     EP, n_ep = (eng.scalars(EP_CAP * max(1, n_iter)) if err_fused else None), 0
-    for ii in _trace.progress(range(n_iter), "running GKS...", kwargs.get("progress")):       # (GKS.py:42)
-        k = pb.V.k
-        _trace.mark("GKS: projected problem")
+    # One pass over the basis for the new vector AND the next iterate (late round 6; kwarg fused_orth_iterate): the projected problem of
+    # iteration ii + 1 needs of v_k only its Gram rows and its norm, and both follow from the h-sweep's products — so it is solved
+    # BEFORE r - V c is formed, and that pass leaves x_{ii+1} = V y' as well (trk_gemv_orth_iterate): two passes over V per iteration
+    # instead of three.  One rank, device-resident Gram data whose rows come from the sweep (`merged` below), no halo track.
+    early = (dev_gram and gs_gram is not None and pb.from_v_L and pb.halo is None and getattr(eng, "world", 1) == 1
+             and hasattr(eng, "gemv_orth_iterate") and hasattr(eng, "gram_row_from_sweep") and kmax < 1024
+             and kwargs.get("gram_rows_from_sweep", True) and kwargs.get("fused_orth_iterate", True))
+    RR = eng.scalars(1) if early else None
+    x_ready = False
+
+    def projected_problem(k):
+        nonlocal lam, k_inv
         if on_dev:
             lam = regparam
             lams.append(lam)
@@ -343,28 +360,35 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
             eng.gram_tikhonov(pb.GA_d.ref(0), kmax, pb.GL_d.ref(0), kmax, pb.c_d.ref(0), k, lam, Y.ref(0),
                               Minv=Minv, ldm=kmax, k_from=k_inv)
             k_inv = k
+            return
+        hGA, hGL, hc = pb.download_grams(k) if dev_gram else (pb.GA[:k, :k], pb.GL[:k, :k], pb.c[:k])
+        one = gram_gcv_host(hGA, hGL, hc, hc) if (regparam == "gcv" and kwargs.get("host_solve_in_c", True)) else None
+        if one is not None:                   # the whole projected problem in one library call (trk_host_gram_gcv)
+            lam, y = one
+            lams.append(lam)
         else:
-            hGA, hGL, hc = pb.download_grams(k) if dev_gram else (pb.GA[:k, :k], pb.GL[:k, :k], pb.c[:k])
-            one = gram_gcv_host(hGA, hGL, hc, hc) if (regparam == "gcv" and kwargs.get("host_solve_in_c", True)) else None
-            if one is not None:                   # the whole projected problem in one library call (trk_host_gram_gcv)
-                lam, y = one
-                lams.append(lam)
+            R_A, R_L = gram_factor(hGA), gram_factor(hGL)
+            rhs = project_rhs(R_A, hc)
+            lam = choose_lambda(regparam, R_A, R_L, rhs, max(b2 - float(rhs @ rhs), 0.0), kwargs)
+            lams.append(lam)
+            y = tikhonov_lstsq(R_A, R_L, lam, rhs)
+        Y.set(0, y)
+
+    for ii in _trace.progress(range(n_iter), "running GKS...", kwargs.get("progress")):       # (GKS.py:42)
+        k = pb.V.k
+        if not x_ready:
+            _trace.mark("GKS: projected problem")
+            projected_problem(k)
+            _trace.mark("GKS: iterate x = V y")
+            x_dev = Hs.row(ii)
+            if err_fused:      # x = V y (:76) with ||x - x_true||^2 as block partials of the same pass, summed once after the loop
+                n_ep = eng.gemv_n_err(pb.V.data, k, Y.ref(0), x_dev, xt, EP.ref(n_ep * ii), EP_CAP)
             else:
-                R_A, R_L = gram_factor(hGA), gram_factor(hGL)
-                rhs = project_rhs(R_A, hc)
-                lam = choose_lambda(regparam, R_A, R_L, rhs, max(b2 - float(rhs @ rhs), 0.0), kwargs)
-                lams.append(lam)
-                y = tikhonov_lstsq(R_A, R_L, lam, rhs)
-            Y.set(0, y)
-        _trace.mark("GKS: iterate x = V y")
-        x_dev = Hs.row(ii)
-        if err_fused:      # x = V y (:76) with ||x - x_true||^2 as block partials of the same pass, summed once after the loop
-            n_ep = eng.gemv_n_err(pb.V.data, k, Y.ref(0), x_dev, xt, EP.ref(n_ep * ii), EP_CAP)
-        else:
-            eng.gemv_n(pb.V.data, k, Y.ref(0), x_dev)                               # x = V y (:76)
-        Hs.pushed(ii)
-        if xt is not None and not err_fused:
-            eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
+                eng.gemv_n(pb.V.data, k, Y.ref(0), x_dev)                               # x = V y (:76)
+            Hs.pushed(ii)
+            if xt is not None and not err_fused:
+                eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii))
+        x_ready = False
         # r = A^T (A x - b) + lam L^T (L x), A x = (AV) y and L x = (LV) y in the reference (:81-85); stencil operators
         # form them directly from x (8n-12n bytes instead of k basis vectors)
         _trace.mark("GKS: residual")
@@ -393,6 +417,35 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         merged = (dev_gram and gs_gram is not None and pb.from_v_L and hasattr(eng, "gram_row_from_sweep")
                   and gs_gram.in_G == k - 1 and kwargs.get("gram_rows_from_sweep", True))
         cc = None
+        if merged and early:
+            n_extra = int(pb.from_v_A) + int(pb.from_v_L)
+            eng.nrm2sq(r, RR.ref(0))
+            cc = gs_gram.sweep(k, r, 3, None, extra=pb.sweep_operands(r, scal=gs_gram.W, off=(2 + n_extra) * k), tail=3,
+                               rr=RR.ref(0), rho2=R.ref(ii))                         # (:86-88) h, the Gram rows' products, c, rho^2
+            _trace.mark("GKS: Gram rows")
+            pb.append_from_sweep(gs_gram, k, cc, R.ref(ii), r_early=r)               # rows k of the Gram data, without v_k (:92-96)
+            last = ii + 1 >= n_iter
+            if not last:
+                _trace.mark("GKS: projected problem")
+                projected_problem(k + 1)                                             # (:74 of the NEXT iteration)
+            _trace.mark("GKS: new basis vector and next iterate, one pass")
+            if last:
+                eng.gemv_orth_iterate(pb.V.data, k, r, cc, R.ref(ii), vn)            # v_k = (r - V c)/||.|| (:86-91)
+            else:
+                x_dev = Hs.row(ii + 1)
+                if err_fused:
+                    n_now = eng.gemv_orth_iterate(pb.V.data, k, r, cc, R.ref(ii), vn, y_next=Y.ref(0), x_next=x_dev, ref=xt,
+                                                  partials=EP.ref(n_ep * (ii + 1)), capacity=EP_CAP)
+                    if n_now != n_ep:
+                        raise RuntimeError("GKS: the error partials of the one-pass form do not match trk_gemv_n_err's layout")
+                else:
+                    eng.gemv_orth_iterate(pb.V.data, k, r, cc, R.ref(ii), vn, y_next=Y.ref(0), x_next=x_dev)
+                Hs.pushed(ii + 1)
+                if xt is not None and not err_fused:
+                    eng.diff_nrm2sq(x_dev, xt, E.ref(2 + ii + 1))
+                x_ready = True
+            pb.V.commit()
+            continue
         if merged:
             # the sweep's pass over V also takes V^T (A^T A r), V^T (L^T L r): the next vector's Gram rows need no pass of their own
             # (the three scalars r . M r ride behind the sweep's products: one all-reduce for both)
