@@ -195,6 +195,10 @@ int trk_tv_grad(trk_op* L, const float* x, const float* w, const float* r_in, do
  * z = L^T L r for the Gram row of the next basis vector (GKS.py:92-96 through the Gram form) — no pass over r and z of its own. */
 int trk_tv_grad_dot(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, const float* dotv,
                     double* dot_out, trk_stream stream);
+/* The same with *xsq_out = <x, x> over the rank's own pixels from the same pass (GKS's one-pass form, trk_gemv_orth_iterate: x = dotv = r,
+ * and r . r is what trk_cgs_coeffs_rho turns into the norm of the next basis vector — no pass over r of its own). */
+int trk_tv_grad_dot_xsq(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, const float* dotv,
+                        double* dot_out, double* xsq_out, trk_stream stream);
 
 /* One Golub-Kahan half step in the operator's own output pass (decompositions.py:240-252: v = A^T u - beta v_old, u = A v -
  * alpha u_old, their norms):   out = a * Op(x) + b * z ,  *sumsq = ||out||^2 (if sumsq != NULL)

@@ -225,6 +225,12 @@ def test_tv_grad_with_the_dot_of_its_output(eng, N, nt):
             assert torch.equal(o0, o1)
             want = float(o0.double() @ dv.double())
             assert abs(float(eng.to_host(S)[0]) - want) <= 1e-12 * float(o0.double().norm() * dv.double().norm())
+            # ... and <x, x> behind it (trk_tv_grad_dot_xsq: GKS's one-pass form takes r . r from the pass that forms L^T L r)
+            S2, o2 = eng.scalars(2), eng.empty(n)
+            L.tv_grad(x, ww, rr, 0.7, o2, dot_with=dv, dot_out=S2.ref(0), xsq_out=S2.ref(1))
+            got = eng.to_host(S2)
+            assert torch.equal(o0, o2) and got[0] == float(eng.to_host(S)[0])
+            assert abs(got[1] - float(x.double() @ x.double())) <= 1e-12 * float(x.double() @ x.double())
 
 
 @pytest.mark.parametrize("k,n", [(1, 1000), (7, 10_001), (8, 4096), (9, 70_000), (17, 33_333), (40, 20_000)])

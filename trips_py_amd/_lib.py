@@ -192,6 +192,7 @@ SIGNATURES = {
     "trk_tv_grad": (c_int, [c_op, c_f32p, c_f32p, c_f32p, c_dbl, c_f32p, c_stream]),
     "trk_tv_halo": (c_int, [c_op, c_f32p, c_f32p]),
     "trk_tv_grad_dot": (c_int, [c_op, c_f32p, c_f32p, c_f32p, c_dbl, c_f32p, c_f32p, c_f64p, c_stream]),
+    "trk_tv_grad_dot_xsq": (c_int, [c_op, c_f32p, c_f32p, c_f32p, c_dbl, c_f32p, c_f32p, c_f64p, c_f64p, c_stream]),
     "trk_mm_weights": (c_int, [c_i64, c_f32p, c_f32p, c_dbl, c_dbl, c_f32p, c_stream]),
     "trk_cgls_update_xr": (c_int, [c_i64, c_i64, c_f64p, c_f64p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f32p, c_f64p, c_stream]),
     "trk_op_fused_caps": (c_int, [c_op, ctypes.POINTER(c_int)]),

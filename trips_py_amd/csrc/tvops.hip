@@ -203,10 +203,11 @@ template <bool W, bool RIN, bool DOT = false>
 __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, const float* __restrict__ w,
                                                 const float* __restrict__ rin, float lam, float* __restrict__ out, int N, int nt,
                                                 const float* __restrict__ dotv = nullptr, double* __restrict__ dot_part = nullptr,
-                                                const float* __restrict__ xprev = nullptr, const float* __restrict__ xnext = nullptr) {
+                                                const float* __restrict__ xprev = nullptr, const float* __restrict__ xnext = nullptr,
+                                                int xsq = 0) {
 #pragma clang fp contract(off)       // products and sums as written (HIP's __fmul_rn is a plain `*`): the same bits in every instantiation
   __shared__ double dred[DOT ? NT / 64 : 1];
-  double dacc = 0.0;
+  double dacc = 0.0, xacc = 0.0;       // xsq (DOT only): also the block partial of <x, x> over the rank's own pixels, behind the dot's
   const int f = blockIdx.z;
   const int64_t npix = (int64_t)N * N, ps = 2 * (int64_t)N * (N - 1);
   const float* __restrict__ xf = x + f * npix;
@@ -271,12 +272,23 @@ __global__ __launch_bounds__(NT) void k_tv_grad(const float* __restrict__ x, con
         const float ov = RIN ? __fadd_rn(rr[t], __fmul_rn(lam, acc)) : __fmul_rn(lam, acc);   // (no contraction: the same bits with and without DOT)
         if (!DOT || live) out[o0 + (int64_t)t * N] = ov;
         if (DOT && live) dacc += (double)ov * (double)dotv[o0 + (int64_t)t * N];
+        if (DOT && live && xsq) xacc += (double)c * (double)c;
       }
     }
   }
   if (DOT) {
+    const size_t blk = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     dacc = block_sum<NT>(dacc, dred);
-    if (threadIdx.x == 0) dot_part[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x] = dacc;
+    if (!xsq) {
+      if (threadIdx.x == 0) dot_part[blk] = dacc;
+    } else {
+      __syncthreads();
+      xacc = block_sum<NT>(xacc, dred);
+      if (threadIdx.x == 0) {
+        dot_part[2 * blk] = dacc;
+        dot_part[2 * blk + 1] = xacc;
+      }
+    }
   }
 }
 
@@ -495,6 +507,28 @@ int trk_tv_grad_dot(trk_op* L, const float* x, const float* w, const float* r_in
 #undef TGD
   TRK_LAUNCH_CHECK();
   return finalize_sums(part, nblk, 1, 1, dot_out, s);
+}
+
+int trk_tv_grad_dot_xsq(trk_op* L, const float* x, const float* w, const float* r_in, double lam, float* out, const float* dotv,
+                        double* dot_out, double* xsq_out, trk_stream st) {
+  TRK_REQUIRE(L, "trk_tv_grad_dot_xsq: NULL operator");
+  TvGeo gg;
+  const int rcg = tv_geometry(L, "trk_tv_grad_dot_xsq", &gg);    // first: see trk_tv_weights
+  TRK_REQUIRE(x && out && dotv && dot_out && xsq_out, "trk_tv_grad_dot_xsq: NULL argument");
+  TRK_REQUIRE(out != x && out != r_in && out != dotv, "trk_tv_grad_dot_xsq: out must not alias x, r_in or dotv");
+  if (rcg) return rcg;
+  const int N = gg.N, nt = gg.nt;
+  const Grid2 g2 = grid2(N, nt, true);
+  const int nblk = g2.per_frame * nt;
+  hipStream_t s = (hipStream_t)st;
+  double* part = nullptr;
+  if (int rc = scratch_doubles(s, 2 * (size_t)nblk, &part)) return rc;
+#define TGD(W, R) hipLaunchKernelGGL((k_tv_grad<W, R, true>), g2.g, dim3(NT), 0, s, x, w, r_in, (float)lam, out, N, nt, dotv, part, gg.xprev, gg.xnext, 1)
+  if (w) { if (r_in) TGD(true, true); else TGD(true, false); }
+  else   { if (r_in) TGD(false, true); else TGD(false, false); }
+#undef TGD
+  TRK_LAUNCH_CHECK();
+  return finalize_sums_split(part, nblk, 2, 2, dot_out, 1, xsq_out, s);
 }
 
 int trk_spacetime_set_halo(trk_op* op, const float* x_next, const float* y_prev) {

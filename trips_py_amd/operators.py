@@ -297,9 +297,17 @@ class _FusedTV:
         _lib.check(self.engine.lib.trk_tv_weights(self._h, x.data_ptr(), float(eps), float(q), out.data_ptr(),
                                                   self.engine.stream()), "trk_tv_weights")
 
-    def tv_grad(self, x, w, r_in, lam, out, dot_with=None, dot_out=None):
+    def tv_grad(self, x, w, r_in, lam, out, dot_with=None, dot_out=None, xsq_out=None):
         """out = r_in + lam * L^T (w .* (L x)) (MMGKS.py:116-118); w None: unit weights (GKS.py:81-84); r_in None: 0.
-        dot_with / dot_out: also <out, dot_with> into the device scalar dot_out, from the same pass (trk_tv_grad_dot)."""
+        dot_with / dot_out: also <out, dot_with> into the device scalar dot_out, from the same pass (trk_tv_grad_dot);
+        xsq_out (with them): and <x, x> (trk_tv_grad_dot_xsq)."""
+        if dot_with is not None and xsq_out is not None:
+            rc = self.engine.lib.trk_tv_grad_dot_xsq(self._h, x.data_ptr(), None if w is None else w.data_ptr(),
+                                                     None if r_in is None else r_in.data_ptr(), float(lam), out.data_ptr(),
+                                                     dot_with.data_ptr(), dot_out if isinstance(dot_out, int) else dot_out.data_ptr(),
+                                                     xsq_out if isinstance(xsq_out, int) else xsq_out.data_ptr(), self.engine.stream())
+            _lib.check(rc, "trk_tv_grad_dot_xsq")
+            return
         if dot_with is not None:
             rc = self.engine.lib.trk_tv_grad_dot(self._h, x.data_ptr(), None if w is None else w.data_ptr(),
                                                  None if r_in is None else r_in.data_ptr(), float(lam), out.data_ptr(),
@@ -383,11 +391,11 @@ class SpaceTimeDerivative(_FusedTV, _HandleOperator):
         self._give_halo(x, halo)
         super().tv_weights(x, eps, q, out)
 
-    def tv_grad(self, x, w, r_in, lam, out, dot_with=None, dot_out=None, halo=None):
+    def tv_grad(self, x, w, r_in, lam, out, dot_with=None, dot_out=None, halo=None, xsq_out=None):
         if w is not None and w.numel() < self.tv_weights_len:
             raise ValueError(f"tv_grad: w holds {w.numel()} floats, this operator reads tv_weights_len = {self.tv_weights_len}")
         self._give_halo(x, halo)
-        super().tv_grad(x, w, r_in, lam, out, dot_with=dot_with, dot_out=dot_out)
+        super().tv_grad(x, w, r_in, lam, out, dot_with=dot_with, dot_out=dot_out, xsq_out=xsq_out)
 
     def _apply(self, x2, y2, transpose, sumsq):
         eng = self.engine

@@ -221,15 +221,17 @@ class _ProjectedBases:
     # The new vector is v_k = (r - V c)/rho; G[i][k] = v_i . M v_k follows from a = V^T (M r), which rides on the sweep that
     # orthogonalises r (krylov.GramSchmidtByGram.sweep(extra=...), trk_gemv_tn), and from c, r . M r, rho^2
     # (trk_gram_row_from_sweep).  Per iteration GKS then passes over V three times (x = V y, the sweep, r - V c), not four.
-    def sweep_operands(self, r, scal=None, off=0):
+    def sweep_operands(self, r, scal=None, off=0, rr=False):
         """The vectors whose V^T products the sweep must also take, and the scalars r . M r (and r . A^T b): call before the sweep.
         scal / off: put the three scalars at scal[off .. off + 3) and leave their sum over ranks to the caller (GKS puts them right
-        behind the sweep's own products, so that ONE all-reduce carries both: three exchanges per iteration on ranks, not four)."""
+        behind the sweep's own products, so that ONE all-reduce carries both: three exchanges per iteration on ranks, not four).
+        rr: also r . r at scal[off + 3] (GKS's one-pass form) — from the stencil pass that forms z_L where it can, else a pass of its own."""
         eng = self.eng
         own = scal is None
         S, o = (self.S, 0) if own else (scal, int(off))
         self._sw = (S, o)
         extra = []
+        rr_done = not rr
         if self.from_v_A:
             self.A.apply(r, out=self.tA, sumsq=S.ref(o))                  # ||A r||^2 = r . A^T A r
             self.A.apply(self.tA, out=self.zA, transpose=True)
@@ -237,7 +239,10 @@ class _ProjectedBases:
             extra.append(self.zA)
         if self.from_v_L:
             hk = {} if self.halo is None else {"halo": self.r_halo}
-            if self.tL is None and hasattr(getattr(eng, "lib", None), "trk_tv_grad_dot") and _TVDOT:
+            if self.tL is None and rr and hasattr(getattr(eng, "lib", None), "trk_tv_grad_dot_xsq") and _TVDOT:
+                self.L.tv_grad(r, None, None, 1.0, out=self.zL, dot_with=r, dot_out=S.ref(o + 1), xsq_out=S.ref(o + 3), **hk)
+                rr_done = True
+            elif self.tL is None and hasattr(getattr(eng, "lib", None), "trk_tv_grad_dot") and _TVDOT:
                 self.L.tv_grad(r, None, None, 1.0, out=self.zL, dot_with=r, dot_out=S.ref(o + 1), **hk)   # z_L = L^T L r and r . z_L, one pass
             else:
                 if self.tL is None:
@@ -247,8 +252,10 @@ class _ProjectedBases:
                     self.L.apply(self.tL, out=self.zL, transpose=True)
                 eng.dot(r, self.zL, S.ref(o + 1))                         # r . L^T L r
             extra.append(self.zL)
+        if not rr_done:
+            eng.nrm2sq(r, S.ref(o + 3))
         if own:
-            eng.allreduce(S, 0, 3)
+            eng.allreduce(S, 0, 4 if rr else 3)
         return extra
 
     def append_from_sweep(self, gs, k, c, rho2, r_early=None):
@@ -344,11 +351,10 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
     # One pass over the basis for the new vector AND the next iterate (late round 6; kwarg fused_orth_iterate): the projected problem of
     # iteration ii + 1 needs of v_k only its Gram rows and its norm, and both follow from the h-sweep's products — so it is solved
     # BEFORE r - V c is formed, and that pass leaves x_{ii+1} = V y' as well (trk_gemv_orth_iterate): two passes over V per iteration
-    # instead of three.  One rank, device-resident Gram data whose rows come from the sweep (`merged` below), no halo track.
-    early = (dev_gram and gs_gram is not None and pb.from_v_L and pb.halo is None and getattr(eng, "world", 1) == 1
-             and hasattr(eng, "gemv_orth_iterate") and hasattr(eng, "gram_row_from_sweep") and kmax < 1024
-             and kwargs.get("gram_rows_from_sweep", True) and kwargs.get("fused_orth_iterate", True))
-    RR = eng.scalars(1) if early else None
+    # instead of three.  Device-resident Gram data whose rows come from the sweep (`merged` below); on ranks r . r travels with the sweep's
+    # products (the all-reduce of ||r - V c||^2 is gone) and the new vector's boundary frames come from the residual's, as before.
+    early = (dev_gram and gs_gram is not None and pb.from_v_L and hasattr(eng, "gemv_orth_iterate") and hasattr(eng, "gram_row_from_sweep")
+             and kmax < 1024 and kwargs.get("gram_rows_from_sweep", True) and kwargs.get("fused_orth_iterate", True))
     x_ready = False
 
     def projected_problem(k):
@@ -419,9 +425,12 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
         cc = None
         if merged and early:
             n_extra = int(pb.from_v_A) + int(pb.from_v_L)
-            eng.nrm2sq(r, RR.ref(0))
-            cc = gs_gram.sweep(k, r, 3, None, extra=pb.sweep_operands(r, scal=gs_gram.W, off=(2 + n_extra) * k), tail=3,
-                               rr=RR.ref(0), rho2=R.ref(ii))                         # (:86-88) h, the Gram rows' products, c, rho^2
+            off = (2 + n_extra) * k
+            # (r . r behind the three scalars of sweep_operands: from the stencil pass that forms L^T L r)
+            cc = gs_gram.sweep(k, r, 3, None, extra=pb.sweep_operands(r, scal=gs_gram.W, off=off, rr=True), tail=4,
+                               rr=gs_gram.W.ref(off + 3), rho2=R.ref(ii))            # (:86-88) h, the Gram rows' products, c, rho^2
+            if pb.halo is not None:
+                pb.halo.push_from_sweep(k, cc, R.ref(ii))                            # the new vector's boundary frames
             _trace.mark("GKS: Gram rows")
             pb.append_from_sweep(gs_gram, k, cc, R.ref(ii), r_early=r)               # rows k of the Gram data, without v_k (:92-96)
             last = ii + 1 >= n_iter
