@@ -616,6 +616,39 @@ def test_gemv_orth_iterate_one_pass_for_the_new_vector_and_the_next_iterate(k, n
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("k,n", [(12, 4096), (13, 64), (40, 122_880), (53, 122_880), (100, 262_144), (11, 4096), (40, 122_882)])
+def test_gemv_n_on_short_vectors_rows_split_over_the_waves(k, n):
+    """k_gemv_n_split (a projector's m-length images: few columns, many rows — the four waves of a workgroup take a quarter of the rows
+    each) through trk_gemv_n with and without a base and through trk_gemv_orth_iterate's image form (A v_k = (A r - AV c) / rho), against
+    float64 NumPy to fp32 rounding; the last two shapes fall back to k_gemv_n (k < 12, n % 4 != 0)."""
+    import torch
+    from trips_py_amd.engine import default_engine
+    eng = default_engine()
+    rng = np.random.default_rng(k * 7 + n)
+    V = eng.empty_basis(k + 1, n)
+    Vh = rng.standard_normal((k, n)).astype(np.float32)
+    V[:k].copy_(torch.from_numpy(Vh))
+    yh = rng.standard_normal(k)
+    Y, R2 = eng.scalars(k), eng.scalars(1)
+    Y.set(0, yh)
+    R2.set(0, np.array([7.25]))
+    bh = rng.standard_normal(n).astype(np.float32)
+    b = torch.from_numpy(bh).to(eng.device)
+    out = eng.empty(n)
+    Vd = Vh.astype(np.float64)
+    comb = Vd.T @ yh
+    eng.gemv_n(V, k, Y.ref(0), out)
+    assert np.abs(out.cpu().numpy() - comb).max() <= 1.2e-7 * np.abs(comb).max()
+    eng.gemv_n(V, k, Y.ref(0), out, a=-1.0, base=b, s=1.0)
+    want = comb - bh.astype(np.float64)
+    assert np.abs(out.cpu().numpy() - want).max() <= 1.2e-7 * np.abs(want).max()
+    assert eng.gemv_orth_iterate(V, k, b, Y.ref(0), R2.ref(0), V[k]) == 0
+    want = (bh.astype(np.float64) - comb) / np.sqrt(7.25)
+    assert np.abs(V[k].cpu().numpy() - want).max() <= 1.2e-7 * np.abs(want).max()
+    assert torch.equal(V[:k].cpu(), torch.from_numpy(Vh))                   # the rows read are untouched
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("groups,glen,copies,expo", [(1, 1, 1, -0.5), (37, 3, 3, -0.5), (1000, 7, 2, -0.75), (5000, 32, 1, 0.0)])
 def test_group_weights(groups, glen, copies, expo):
     """trk_group_weights: (sum of squares over each group of consecutive entries + add)^expo, tiled `copies` times."""

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6 GPU visit: ONE script, steps by name.  usage: tools/r06_round.sh <out-subdir> [steps...]
-# steps: test (whole -m gpu suite, bars logged) | soak (the suite three more times, two of them concurrently) | tradon (projector tests) | radon (4096^2 / 2048^2 / 1024^2 / 512^2 projector rates) |
+# steps: none (build only) | test (whole -m gpu suite, bars logged) | soak (the suite three more times, two of them concurrently) | tradon (projector tests) | radon (4096^2 / 2048^2 / 1024^2 / 512^2 projector rates) |
 #        pmc_radon (counters of the 4096^2 pair) | smoke | drv | bench | bench2/4/8 (ranks on one GPU over gloo) | prof | c3 (C3 instrument) | py:<script> [runs tools/<script>] |
 #        mb:<name> (builds + runs tools/microbench/<name>.hip) | traffic:<tag>,<script>[,args] | stats:<tag>,<script>[,args] | gaps:<tag>,<n>,<script>[,args]
 R=$GRAFT_REPO_ROOT
@@ -11,6 +11,7 @@ export TMPDIR=/tmp
 cd $R
 python -c "import __graft_entry__ as g; g.build()" > $O/build.log 2>&1; echo "build rc=$?"
 for s in $STEPS; do case $s in
+none) ;;
 test)
   rm -f $O/bars.txt
   TRK_BARS_LOG=$O/bars.txt timeout 2400 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -5 $O/pytest_gpu.log ;;

@@ -863,6 +863,74 @@ __global__ __launch_bounds__(NT) void k_gemv_n(const YS y, const float* __restri
   }
 }
 
+// ------------------------------------------------------------------ out = (a*base + s * sum_j y[j] V[j]) [/ sqrt(*den2)] for SHORT vectors
+// k_gemv_n gives a thread one 16-byte column of the basis and walks the k rows eight loads at a time: with m-length images of a
+// projector (dynamic tomography, C5: m = 122 880 floats against n = 2 M) the grid is 30 workgroups and every thread waits for k / 8
+// dependent round trips — 11.5 us for k = 40 rows of half a megabyte each.  Here the four waves of a workgroup share 64 columns and take
+// a quarter of the rows each; their partial sums meet in LDS in wave order ((0 + 1) + (2 + 3)).  16-byte aligned operands, n % 4 == 0.
+template <bool HAS_BASE>
+__global__ __launch_bounds__(NT) void k_gemv_n_split(const double* __restrict__ y, const float* __restrict__ V, int64_t ld, int k,
+                                                     int64_t n4, double a, const float* __restrict__ base, double sc, float* out,
+                                                     const double* __restrict__ den2) {
+  __shared__ double ys[KMAX_LDS];
+  __shared__ double part[NT / 64][64][4];
+  for (int j = threadIdx.x; j < k; j += NT) ys[j] = sc * y[j];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const int kq = (k + NT / 64 - 1) / (NT / 64);
+  const int j0 = wv * kq, j1 = (j0 + kq < k) ? j0 + kq : k;
+  double o0 = 0, o1 = 0, o2 = 0, o3 = 0;
+  if (i < n4) {
+    int j = j0;
+    auto group = [&](auto width) {
+      constexpr int W = decltype(width)::value;
+      float4 v[W];
+#pragma unroll
+      for (int u = 0; u < W; ++u) v[u] = ld4(V + (int64_t)(j + u) * ld, i);
+#pragma unroll
+      for (int u = 0; u < W; ++u) {
+        const double c = ys[j + u];
+        o0 = fma(c, (double)v[u].x, o0);
+        o1 = fma(c, (double)v[u].y, o1);
+        o2 = fma(c, (double)v[u].z, o2);
+        o3 = fma(c, (double)v[u].w, o3);
+      }
+      j += W;
+    };
+    while (j + 8 <= j1) group(std::integral_constant<int, 8>{});
+    if (j + 4 <= j1) group(std::integral_constant<int, 4>{});
+    while (j < j1) group(std::integral_constant<int, 1>{});
+  }
+  part[wv][lane][0] = o0;
+  part[wv][lane][1] = o1;
+  part[wv][lane][2] = o2;
+  part[wv][lane][3] = o3;
+  __syncthreads();
+  if (wv != 0 || i >= n4) return;
+  double t[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) t[q] = (part[0][lane][q] + part[1][lane][q]) + (part[2][lane][q] + part[3][lane][q]);
+  if (HAS_BASE) {
+    const float4 b = ld4(base, i);
+    t[0] = fma(a, (double)b.x, t[0]);
+    t[1] = fma(a, (double)b.y, t[1]);
+    t[2] = fma(a, (double)b.z, t[2]);
+    t[3] = fma(a, (double)b.w, t[3]);
+  }
+  if (den2) {
+    const double inv = 1.0 / sqrt(*den2);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) t[q] *= inv;
+  }
+  st4(out, i, make_float4((float)t[0], (float)t[1], (float)t[2], (float)t[3]));
+}
+// whether the short-vector form serves a call (no fused norm, aligned, few columns, enough rows to be worth splitting)
+static bool gemv_n_split_serves(int64_t n, int k, bool vec) {
+  static const int on = env_int("TRK_GEMVN_SPLIT", 1);
+  return on && vec && (n % 4) == 0 && n > 0 && (n >> 2) <= (int64_t)64 * 4 * cu_count() && k >= 12 && k <= KMAX_LDS;
+}
+
 // ------------------------------------------------------------------ the new basis vector AND the next iterate in ONE pass over the basis
 // GKS / MMGKS pass over V three / four times per iteration: x = V y (GKS.py:76), h = V^T r, r - V c (:86-88) [+ the re-weighted Gram].
 // The iterate of the NEXT iteration is x' = V y'[0..k) + y'[k] v_k with v_k = (r - V c) / rho the vector this sweep produces — and y'
@@ -2703,6 +2771,16 @@ int trk::gemv_n_partials(const float* V, int64_t ld, int k, int64_t n, const dou
   const int grid = stream_grid(n);
   double* part = nullptr;
   const bool vec = aligned16(V) && aligned16(out) && (ld % 4 == 0) && (!base || aligned16(base));
+  // short vectors WITH a base (the residual (AV) y - b of a projector's images): rows split over the waves.  The plain combination
+  // x = V y stays with k_gemv_n at every size: trk_gemv_n_err and trk_gemv_orth_iterate are its sum term for term (tested bit for bit)
+  if (!sumsq && base && gemv_n_split_serves(n, k, vec)) {
+    const int64_t n4 = n >> 2;
+    const unsigned g = (unsigned)((n4 + 63) / 64);
+    hipLaunchKernelGGL((k_gemv_n_split<true>), dim3(g), dim3(NT), 0, s, y, V, ld, k, n4, a, base, sc, out, (const double*)nullptr);
+    TRK_LAUNCH_CHECK();
+    *nblk = 0;
+    return TRK_OK;
+  }
   static const int U = env_int("TRK_GEMVN_UNROLL", 8);        // measured, tools/gemv_micro.py: 4 -> 5.4-5.8 TB/s, 8 (+ 8 blocks per CU) -> 6.2-6.4
   static const int gmul = env_int("TRK_GEMVN_GRID", 8);          // blocks per CU (0: stream_grid's 4)
   const int grid_n = gmul > 0 ? (int)std::min<int64_t>((n + (int64_t)NT * 4 - 1) / ((int64_t)NT * 4), (int64_t)cu_count() * gmul) : grid;
@@ -2891,6 +2969,12 @@ int trk_gemv_orth_iterate(const float* V, int64_t ld, int k, int64_t n, const fl
   if (chk_sumsq)
     if (int rc = scratch_doubles(s, (size_t)grid, &chk)) return rc;
   const bool vec = aligned16(V) && aligned16(w) && aligned16(vn) && (!x_next || aligned16(x_next)) && (!ref || aligned16(ref)) && (ld % 4 == 0);
+  if (!x_next && !chk_sumsq && gemv_n_split_serves(n, k, vec)) {  // the image of the new vector, A v_k = (A r - AV c) / rho: short rows
+    const int64_t n4 = n >> 2;
+    hipLaunchKernelGGL((k_gemv_n_split<true>), dim3((unsigned)((n4 + 63) / 64)), dim3(NT), 0, s, c, V, ld, k, n4, 1.0, w, -1.0, vn, rho2);
+    TRK_LAUNCH_CHECK();
+    return TRK_OK;
+  }
   const int nt = stream_nontemporal(n);
 #define GO(VC, HX, HR) hipLaunchKernelGGL((k_gemv_orth_iter<VC, HX, HR, 8>), dim3(grid), dim3(NT), 0, s, V, ld, k, n, w, c, rho2, y_next, vn, x_next, ref, err_partials, chk, nt)
   if (!x_next)  { if (vec) GO(true, false, false); else GO(false, false, false); }
