@@ -556,6 +556,14 @@ int trk_gemv_n(const float* V, int64_t ld, int k, int64_t n, const double* y_dev
  * trk_finalize_batched instead of one reduction-finalize launch per iterate). */
 int trk_gemv_n_err(const float* V, int64_t ld, int k, int64_t n, const double* y, float* out, const float* ref,
                    double* err_partials, int capacity_blocks, int* n_blocks, trk_stream stream);
+/* GKS's one-pass form, the k x k work between the h-sweep and trk_gemv_orth_iterate in ONE launch (one workgroup): row / column k of G_A —
+ * ga_new != NULL: its k + 1 entries as a pass over the kept images left them (trk_gemv_t_x), else from the sweep's products as
+ * trk_gram_row_from_sweep(G_A, ..., a_A, c_sweep, s_A, rho2, c_rhs, tb) — row / column k of G_L from the sweep's products
+ * (a_L, s_L), then y = (G_A + lam G_L)^-1 c_rhs over k + 1 vectors by bordering Minv from k_from (trk_gram_tikhonov's bordering form).
+ * Replaces three launches (GKS.py:92-96 and :74 of the next iteration). */
+int trk_gks_rows_solve(double* GA_dev, double* GL_dev, int ldg, int k, const double* ga_new, const double* a_A, const double* s_A,
+                       const double* tb, const double* a_L, const double* s_L, const double* c_sweep, const double* rho2,
+                       double* c_rhs, double lam, double* Minv, int ldm, int k_from, double* y, trk_stream stream);
 /* The new basis vector AND the next iterate in one pass over the basis (GKS.py:76 + :86-91, MMGKS.py:108 + :119-122):
  *   vn = (w - sum_{j<k} c[j] V[j]) / sqrt(*rho2)          (the orthogonalised, normalised direction: V[k] once the caller commits it)
  *   x_next = sum_{j<k} y_next[j] V[j] + y_next[k] vn       (the iterate of the NEXT iteration, k + 1 coefficients; NULL with y_next: vn only)

@@ -608,6 +608,10 @@ def test_gks_one_pass_for_new_vector_and_next_iterate_equals_the_two_pass_form(k
         for k in (0, 1, 10, its - 1):
             u, v = ia["xHistory"][k].reshape(-1), ib["xHistory"][k].reshape(-1)
             assert float(torch.linalg.norm(u - v) / torch.linalg.norm(v)) < tol, k
+    if not auto:
+        # the k x k work between the sweep and the pass in ONE launch (trk_gks_rows_solve) against its three launches: the same bits
+        xc, ic = S.GKS(A, b, L, 3, its, rp, xt, history=hist, rows_and_solve_in_one=False)
+        assert torch.equal(xa, xc) and ia["Residual"] == ic["Residual"] and ia["relError"] == ic["relError"]
 
 
 def test_mmgks_pnorm2_unweighted_fidelity_gram_kept_incrementally():

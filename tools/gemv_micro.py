@@ -2,7 +2,7 @@
 squares), x = V y (trk_gemv_n), V^T [r, r2] (trk_gemv_t2), V^T [4 right-hand sides] (trk_gemv_tn), V^T r (trk_gemv_t) — time per
 launch and bytes of basis streamed per second, over basis sizes k.  Knobs (environment, read by the library):
 TRK_GEMVN_UNROLL = 4 / 8 / 16 (basis rows requested together), TRK_GEMVN_GRID (blocks per CU), TRK_GEMVT_PER_CU (blocks per CU of the
-transposed family), TRK_NT (cache hints).   usage: python3 tools/gemv_micro.py [N]"""
+transposed family), TRK_NT (cache hints).   usage: [GEMV_MICRO_K=4,8,...] python3 tools/gemv_micro.py [N]"""
 import os
 import sys
 
@@ -15,7 +15,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 n = N * N
 torch.cuda.set_device(0)
 eng = HipEngine()
-KMAX = 33
+KS = tuple(int(v) for v in os.environ.get("GEMV_MICRO_K", "4,8,12,18,24,32").split(","))     # basis sizes (e.g. GEMV_MICRO_K=16,32,52 at C5's n)
+KMAX = max(KS) + 1
 V = eng.empty_basis(KMAX, n)
 V.normal_()
 r, r2, r3, r4, out = (torch.randn(n, device="cuda") for _ in range(5))
@@ -39,7 +40,7 @@ def timeit(fn, reps=10):
 
 print("knobs:", {k: v for k, v in os.environ.items() if k.startswith("TRK_")})
 print(f"{'k':>3} | {'gemv_n base+ss':>16} | {'gemv_n plain':>16} | {'gemv_t2':>16} | {'gemv_tn(4)':>16} | {'gemv_t':>16}   (us, TB/s of 4 k n + vectors)")
-for k in (4, 8, 12, 18, 24, 32):
+for k in KS:
     cells = []
     for name, fn, nbytes in (
             ("n_base", lambda: eng.gemv_n(V, k, y.ref(0), out, a=1.0, base=r, s=-1.0, sumsq=ss.ref(0)), 4.0 * n * (k + 2)),

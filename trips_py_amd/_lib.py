@@ -241,6 +241,8 @@ SIGNATURES = {
     "trk_hess_tikhonov": (c_int, [c_f64p, c_int, c_f64p, c_f64p, c_int, c_f64p, c_f64p, c_f64p, c_dbl, c_int, c_dbl, c_int, c_f64p,
                                   c_stream]),
     "trk_cgs_coeffs": (c_int, [c_f64p, c_int, c_f64p, c_f64p, c_int, c_int, c_f64p, c_stream]),
+    "trk_gks_rows_solve": (c_int, [c_f64p, c_f64p, c_int, c_int, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_f64p, c_dbl,
+                                   c_f64p, c_int, c_int, c_f64p, c_stream]),
     "trk_cgs_coeffs_rho": (c_int, [c_f64p, c_int, c_f64p, c_f64p, c_int, c_int, c_f64p, c_f64p, c_f64p, c_stream]),
     "trk_gemv_orth_iterate": (c_int, [c_f32p, c_i64, c_int, c_i64, c_f32p, c_f64p, c_f64p, c_f64p, c_f32p, c_f32p, c_f32p, c_f64p, c_int,
                                       ctypes.POINTER(c_int), c_f64p, c_stream]),

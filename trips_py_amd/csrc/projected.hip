@@ -562,14 +562,12 @@ __global__ __launch_bounds__(256) void k_gram_tikhonov(const double* __restrict_
 // previous call and is bordered by rows k_from .. k-1 — u = Minv g, s = M[j][j] - g.u, Minv <- [[Minv + u u^T / s, -u / s],
 // [-u^T / s, 1 / s]] — then y = Minv c: O(k^2) per new row instead of the O(k^3) Cholesky from scratch (k = 53: 79 -> ~12 us).
 // k_from = 0 builds the inverse from nothing (the first call, k = projection_dim).
-__global__ __launch_bounds__(256) void k_gram_tikhonov_border(const double* __restrict__ GA, int lda, const double* __restrict__ GL,
-                                                              int ldl, const double* __restrict__ c, int k, int k_from, double lam,
-                                                              double* Minv, int ldm, double* __restrict__ y) {
-  extern __shared__ double sm[];              // g (k) | u (k) | c (k)
-  double* g = sm;
+__device__ __forceinline__ void tikhonov_border_body(const double* GA, int lda, const double* GL, int ldl, const double* c, int k,
+                                                     int k_from, double lam, double* Minv, int ldm, double* __restrict__ y, double* sm,
+                                                     double* red) {
+  double* g = sm;                             // sm: g (k) | u (k) | c (k)
   double* u = sm + k;
   double* cl = sm + 2 * k;
-  __shared__ double red[4];
   for (int i = threadIdx.x; i < k; i += blockDim.x) cl[i] = c[i];
   for (int j = k_from; j < k; ++j) {
     for (int i = threadIdx.x; i <= j; i += blockDim.x) g[i] = GA[(size_t)j * lda + i] + lam * GL[(size_t)j * ldl + i];
@@ -597,6 +595,13 @@ __global__ __launch_bounds__(256) void k_gram_tikhonov_border(const double* __re
   __syncthreads();
   symv4(Minv, ldm, k, cl, [&](int i, double a) { y[i] = a; });
 }
+__global__ __launch_bounds__(256) void k_gram_tikhonov_border(const double* __restrict__ GA, int lda, const double* __restrict__ GL,
+                                                              int ldl, const double* __restrict__ c, int k, int k_from, double lam,
+                                                              double* Minv, int ldm, double* __restrict__ y) {
+  extern __shared__ double sm[];              // g (k) | u (k) | c (k)
+  __shared__ double red[4];
+  tikhonov_border_body(GA, lda, GL, ldl, c, k, k_from, lam, Minv, ldm, y, sm, red);
+}
 
 // GKS: row / column k of a Gram matrix G = V^T M V (M = A^T A or L^T L) for the basis vector v_k = (r - V c) / rho that the sweep
 // has just produced, from what the sweep's own pass over V left behind — a = V^T (M r), the coefficients c, s = r . M r and
@@ -604,11 +609,9 @@ __global__ __launch_bounds__(256) void k_gram_tikhonov_border(const double* __re
 //   G[i][k] = (a_i - (G c)_i) / rho  (i < k),     G[k][k] = (s - 2 c.a + c.(G c)) / rho^2 ;
 // optionally the same for a projected right-hand side  rhs_k = (t - c . rhs[0..k)) / rho  (t = r . (A^T b)).
 // r is the residual of the projected normal equations, so V^T r = 0 but for rounding and c is of rounding size: nothing cancels.
-__global__ __launch_bounds__(256) void k_gram_row_from_sweep(double* G, int ldg, int k, const double* __restrict__ a,
-                                                             const double* __restrict__ c, const double* __restrict__ s_rr,
-                                                             const double* __restrict__ rho2, double* rhs, const double* tb) {
-  extern __shared__ double cl[];              // c (k)
-  __shared__ double red[3][4];
+__device__ __forceinline__ void gram_row_body(double* G, int ldg, int k, const double* __restrict__ a, const double* __restrict__ c,
+                                              const double* __restrict__ s_rr, const double* __restrict__ rho2, double* rhs,
+                                              const double* tb, double* cl, double (*red)[4]) {
   const double rho = sqrt(*rho2);
   for (int i = threadIdx.x; i < k; i += blockDim.x) cl[i] = c[i];
   __syncthreads();
@@ -636,6 +639,55 @@ __global__ __launch_bounds__(256) void k_gram_row_from_sweep(double* G, int ldg,
     G[(size_t)k * ldg + k] = (*s_rr - 2.0 * ca + cgc) / (rho * rho);
     if (rhs) rhs[k] = (*tb - ((red[2][0] + red[2][1]) + (red[2][2] + red[2][3]))) / rho;
   }
+}
+__global__ __launch_bounds__(256) void k_gram_row_from_sweep(double* G, int ldg, int k, const double* __restrict__ a,
+                                                             const double* __restrict__ c, const double* __restrict__ s_rr,
+                                                             const double* __restrict__ rho2, double* rhs, const double* tb) {
+  extern __shared__ double cl[];              // c (k)
+  __shared__ double red[3][4];
+  gram_row_body(G, ldg, k, a, c, s_rr, rho2, rhs, tb, cl, red);
+}
+
+// GKS's one-pass form (trk_gemv_orth_iterate): everything between the h-sweep's products and the pass that needs y' is k x k work of
+// one workgroup — rows k of G_A and G_L, then the bordered inverse over k + 1 vectors and y' — and was three launches of ~6 us each
+// whatever they compute (an install or a row for G_A, a row for G_L, the solve).  One launch: the bodies above, one after the other.
+//   A side: ga_new != NULL — the k + 1 entries of row k as a pass over the kept images left them (the Radon operator) — or a_A != NULL —
+//           from the sweep's products, with the projected right-hand side's entry k (stencil operators);   L side: from the sweep.
+__global__ __launch_bounds__(256) void k_gks_rows_solve(double* GA, double* GL, int ldg, int k, const double* __restrict__ ga_new,
+                                                        const double* __restrict__ a_A, const double* __restrict__ s_A,
+                                                        const double* __restrict__ tb, const double* __restrict__ a_L,
+                                                        const double* __restrict__ s_L, const double* __restrict__ c_sweep,
+                                                        const double* __restrict__ rho2, double* c_rhs, double lam, double* Minv, int ldm,
+                                                        int k_from, double* __restrict__ y) {
+  extern __shared__ double sm[];              // 3 (k + 1) doubles
+  __shared__ double red[3][4];
+  if (ga_new) {
+    for (int j = threadIdx.x; j <= k; j += blockDim.x) {
+      GA[(size_t)k * ldg + j] = ga_new[j];
+      GA[(size_t)j * ldg + k] = ga_new[j];
+    }
+  } else {
+    gram_row_body(GA, ldg, k, a_A, c_sweep, s_A, rho2, c_rhs, tb, sm, red);
+  }
+  __syncthreads();
+  gram_row_body(GL, ldg, k, a_L, c_sweep, s_L, rho2, nullptr, nullptr, sm, red);
+  __threadfence_block();
+  __syncthreads();                            // (one workgroup: its own global writes are visible to it after the barrier)
+  tikhonov_border_body(GA, ldg, GL, ldg, c_rhs, k + 1, k_from, lam, Minv, ldm, y, sm, &red[0][0]);
+}
+
+extern "C" int trk_gks_rows_solve(double* GA, double* GL, int ldg, int k, const double* ga_new, const double* a_A, const double* s_A,
+                                  const double* tb, const double* a_L, const double* s_L, const double* c_sweep, const double* rho2,
+                                  double* c_rhs, double lam, double* Minv, int ldm, int k_from, double* y, trk_stream st) {
+  TRK_REQUIRE(GA && GL && a_L && s_L && c_sweep && rho2 && c_rhs && Minv && y && k >= 1 && ldg >= k + 1 && ldm >= k + 1,
+              "trk_gks_rows_solve: bad argument");
+  TRK_REQUIRE((ga_new != nullptr) != (a_A != nullptr), "trk_gks_rows_solve: the A-side row either as ga_new or from the sweep (a_A, s_A, tb)");
+  TRK_REQUIRE(ga_new || (s_A && tb), "trk_gks_rows_solve: a_A needs s_A = r . A^T A r and tb = r . A^T b");
+  TRK_REQUIRE(k_from >= 0 && k_from <= k + 1 && k + 1 <= 2048, "trk_gks_rows_solve: 0 <= k_from <= k + 1 <= 2048");
+  hipLaunchKernelGGL(k_gks_rows_solve, dim3(1), dim3(256), 3 * (size_t)(k + 1) * sizeof(double), (hipStream_t)st, GA, GL, ldg, k, ga_new, a_A,
+                     s_A, tb, a_L, s_L, c_sweep, rho2, c_rhs, lam, Minv, ldm, k_from, y);
+  TRK_LAUNCH_CHECK();
+  return TRK_OK;
 }
 
 extern "C" int trk_gram_row_from_sweep(double* G, int ldg, int k, const double* a, const double* c, const double* s_rr,

@@ -682,6 +682,15 @@ class HipEngine:
         rc = self.lib.trk_cgs_coeffs(_ptr(G), int(ldg), _ptr(h), _ptr(g_new), int(k), int(passes), _ptr(c), self.stream())
         _lib.check(rc, "trk_cgs_coeffs")
 
+    def gks_rows_solve(self, GA, GL, ldg, k, c_sweep, rho2, c_rhs, lam, Minv, ldm, k_from, y, a_L, s_L, ga_new=None, a_A=None, s_A=None,
+                       tb=None):
+        """Rows k of G_A (installed from ga_new, or from the sweep's products a_A, s_A, tb) and of G_L (a_L, s_L), then the bordered
+        solve over k + 1 vectors, in one launch (trk_gks_rows_solve)."""
+        rc = self.lib.trk_gks_rows_solve(_ptr(GA), _ptr(GL), int(ldg), int(k), _ptr(ga_new), _ptr(a_A), _ptr(s_A), _ptr(tb), _ptr(a_L),
+                                         _ptr(s_L), _ptr(c_sweep), _ptr(rho2), _ptr(c_rhs), float(lam), _ptr(Minv), int(ldm), int(k_from),
+                                         _ptr(y), self.stream())
+        _lib.check(rc, "trk_gks_rows_solve")
+
     def cgs_coeffs_rho(self, G, ldg, h, g_new, k, passes, c, rr, rho2):
         """cgs_coeffs and, from rr = r . r, rho2 = ||r - V c||^2 by algebra (trk_cgs_coeffs_rho): the norm of the vector the next pass forms."""
         rc = self.lib.trk_cgs_coeffs_rho(_ptr(G), int(ldg), _ptr(h), _ptr(g_new), int(k), int(passes), _ptr(c), _ptr(rr), _ptr(rho2),

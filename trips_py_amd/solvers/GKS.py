@@ -258,13 +258,21 @@ class _ProjectedBases:
             eng.allreduce(S, 0, 4 if rr else 3)
         return extra
 
-    def append_from_sweep(self, gs, k, c, rho2, r_early=None):
+    def append_from_sweep(self, gs, k, c, rho2, r_early=None, solve=None):
         """After the sweep over k vectors (coefficients c, rho^2 = ||r - V c||^2) and the commit of v_k: rows k of the Gram data.
         r_early: v_k = (r - V c) / rho is NOT formed yet (GKS's one-pass form, trk_gemv_orth_iterate) — where the images of A are kept,
-        A v_k = (A r - AV c) / rho comes from one product with r and the same kernel on the m-length images."""
+        A v_k = (A r - AV c) / rho comes from one product with r and the same kernel on the m-length images.
+        solve = (lam, Minv, ldm, k_from, Y) (one rank, numeric lambda): the rows AND the projected solve over k + 1 vectors in one launch
+        (trk_gks_rows_solve); returns True when it ran."""
         eng, S = self.eng, self.S
         Sw, so = getattr(self, "_sw", (self.S, 0))                          # where sweep_operands left r . M r
         q = 0
+        one = solve is not None and self.from_v_L and eng.world == 1 and hasattr(eng, "gks_rows_solve")
+        if one and self.from_v_A:
+            lam, Minv, ldm, k_from, Y = solve
+            eng.gks_rows_solve(self.GA_d.ref(0), self.GL_d.ref(0), self.kmax, k, c, rho2, self.c_d.ref(0), lam, Minv, ldm, k_from, Y.ref(0),
+                               gs.extra_ref(1, k), Sw.ref(so + 1), a_A=gs.extra_ref(0, k), s_A=Sw.ref(so), tb=Sw.ref(so + 2))
+            return True
         if self.from_v_A:
             eng.gram_row_from_sweep(self.GA_d.ref(0), self.kmax, k, gs.extra_ref(q, k), c, Sw.ref(so), rho2, rhs=self.c_d.ref(0), tb=Sw.ref(so + 2))
             q += 1
@@ -292,9 +300,15 @@ class _ProjectedBases:
             else:
                 eng.dot(av, self.bv, self.c_d.ref(k))
                 eng.gemv_t(self.AV.data, k + 1, av, S.ref(4))
+            if one:
+                lam, Minv, ldm, k_from, Y = solve
+                eng.gks_rows_solve(self.GA_d.ref(0), self.GL_d.ref(0), self.kmax, k, c, rho2, self.c_d.ref(0), lam, Minv, ldm, k_from,
+                                   Y.ref(0), gs.extra_ref(q, k), Sw.ref(so + 1), ga_new=S.ref(4))
+                return True
             eng.cgs_coeffs(self.GA_d.ref(0), self.kmax, None, S.ref(4), k + 1, 0, None)
         if self.from_v_L:
             eng.gram_row_from_sweep(self.GL_d.ref(0), self.kmax, k, gs.extra_ref(q, k), c, Sw.ref(so + 1), rho2)
+        return False
 
 
 @small_host_blas
@@ -432,9 +446,17 @@ def GKS(A, b, L, projection_dim=3, n_iter=50, regparam="gcv", x_true=None, **kwa
             if pb.halo is not None:
                 pb.halo.push_from_sweep(k, cc, R.ref(ii))                            # the new vector's boundary frames
             _trace.mark("GKS: Gram rows")
-            pb.append_from_sweep(gs_gram, k, cc, R.ref(ii), r_early=r)               # rows k of the Gram data, without v_k (:92-96)
             last = ii + 1 >= n_iter
-            if not last:
+            # rows k of the Gram data, without v_k (:92-96) — with a numeric lambda on one rank together with the solve of the NEXT
+            # iteration's projected problem (:74) in one launch
+            merged_solve = (on_dev and Minv is not None and not last and kwargs.get("rows_and_solve_in_one", True))
+            solved = pb.append_from_sweep(gs_gram, k, cc, R.ref(ii), r_early=r,
+                                          solve=(float(regparam), Minv, kmax, k_inv, Y) if merged_solve else None)
+            if solved:
+                lam = regparam
+                lams.append(lam)
+                k_inv = k + 1
+            elif not last:
                 _trace.mark("GKS: projected problem")
                 projected_problem(k + 1)                                             # (:74 of the NEXT iteration)
             _trace.mark("GKS: new basis vector and next iterate, one pass")
