@@ -449,8 +449,10 @@ int trk_host_worker_collect(trk_host_worker* w, double* lam_out, int* have_out);
  * projected operators, in one call (GKS.py:54-74, MMGKS.py:94-106): R_A, R_L = the Cholesky factors of G_A = (AV)^T AV, G_L = (LV)^T LV
  * (k x k, row stride ldg; what the economic QRs of AV, LV give up to row signs), Q_A^T b = R_A^-T c, lambda by GCV on (R_A, R_L) reduced
  * to (diag(s), I) through M = R_A R_L^-1 (gcv.py:25-95: 'standard' form, m_eff = k) — s and U^T rhs of M's SVD by bidiagonalisation
- * and a bidiagonal SVD that rotates the one vector, no singular vectors formed — y by the stacked least-squares problem
- * [R_A; sqrt(lam) R_L] y = [Q_A^T b; 0].  c_select / c_solve: the right-hand side the selector sees and the one the solve uses (MMGKS
+ * and a bidiagonal SVD that rotates the one vector, no singular vectors formed — y = (G_A + lam G_L)^-1 c by a Cholesky factorisation of
+ * the sum (the normal equations of the stacked problem [R_A; sqrt(lam) R_L] y = [Q_A^T b; 0] the reference hands to lstsq; R_A, R_L being
+ * Cholesky factors of the Gram matrices, both see the same conditioning; the stacked problem by pivoted QR where the sum does not
+ * factor, or with TRK_GRAM_GCV_LSTSQ set).  c_select / c_solve: the right-hand side the selector sees and the one the solve uses (MMGKS
  * hands the weighted and the unweighted one, MMGKS.py:97-106; GKS the same array twice).  lapack: {dpotrf, dtrtrs, dgebrd, dormbr,
  * dbdsqr, dgelsy}, the caller's LAPACK as plain C pointers (Fortran calling convention).  *ok_out = 0: a factorisation failed
  * (semi-definite Gram matrix, singular R_L, no convergence) and nothing was written: the caller's own branches take over. */

@@ -1346,7 +1346,31 @@ extern "C" int trk_host_gram_gcv(void* const* lapack, const double* GA, const do
     if (!std::isfinite(sv[i]) || !std::isfinite(rs[i])) return TRK_OK;
   double lam = 0.0;
   if (int rc = trk_host_gcv_fminbound(sv, rs, k, m_eff, 1e-9, 1e2, 1e-12, 1000, &lam, nullptr, nullptr)) return rc;
-  // y = argmin || R_A y - Q_A^T b ||^2 + lam || R_L y ||^2: the stacked least-squares problem, pivoted QR (SciPy's gelsy, rcond = eps)
+  // y = argmin || R_A y - Q_A^T b ||^2 + lam || R_L y ||^2 = (G_A + lam G_L)^-1 c: by a Cholesky factorisation of the k x k sum — what the
+  // device solves with a numeric lambda (trk_gram_tikhonov); R_A and R_L are Cholesky factors of the Gram matrices themselves, so the
+  // stacked least-squares problem on them (the reference's lstsq, SciPy's gelsy with rcond = eps: 2.7 k^3 flops of pivoted QR, a third of
+  // this call at k = 50) sees the same conditioning.  TRK_GRAM_GCV_LSTSQ=1, or a sum that is not positive definite: the stacked problem.
+  static const bool stacked = getenv("TRK_GRAM_GCV_LSTSQ") != nullptr;
+  if (!stacked) {
+    for (int j = 0; j < k; ++j)
+      for (int i = 0; i < k; ++i)
+        ST[i + (size_t)j * k] = 0.5 * (GA[(size_t)i * ldg + j] + GA[(size_t)j * ldg + i]) +
+                                lam * (0.5 * (GL[(size_t)i * ldg + j] + GL[(size_t)j * ldg + i]));
+    dpotrf(&U_, &n, ST, &n, &info);
+    if (info == 0) {
+      for (int i = 0; i < k; ++i) b2[i] = c_solve[i];
+      dtrtrs(&U_, &T_, &N_, &n, &one, ST, &n, b2, &n, &info);                                    // U^T z = c
+      if (info == 0) dtrtrs(&U_, &N_, &N_, &n, &one, ST, &n, b2, &n, &info);                     // U y = z
+      bool fin = info == 0;
+      for (int i = 0; fin && i < k; ++i) fin = std::isfinite(b2[i]);
+      if (fin) {
+        for (int i = 0; i < k; ++i) y_out[i] = b2[i];
+        *lam_out = lam;
+        *ok_out = 1;
+        return TRK_OK;
+      }
+    }
+  }
   const int m2 = 2 * k;
   const double sl = sqrt(lam);
   for (int j = 0; j < k; ++j)
