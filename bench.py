@@ -860,6 +860,23 @@ def extra_c4_mmgks(A, b, N, world, cpu_jobs=None, psf=None):
         MMGKS(A, b, L, 2, 1, 3, 30, "gcv", history=False)
     barrier(world)
     out["gcv_iters_per_sec_all_ranks"] = round(world * 30 / (max_over_ranks(time.perf_counter() - t0, world) / reps), 2)
+    # GKS on the same problem (GKS.py: the unweighted sibling of this solver): two passes over the basis per iteration (the new vector and
+    # the next iterate share one, trk_gemv_orth_iterate) against the pass each of the reference's order, timed side by side
+    try:
+        from trips_py_amd.solvers import GKS
+        gk = {}
+        for key, kw in (("gks_iters_per_sec_all_ranks", {}), ("gks_a_pass_each_iters_per_sec_all_ranks", {"fused_orth_iterate": False})):
+            GKS(A, b, L, 3, 30, 1e-2, history=False, **kw)
+            barrier(world)
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                GKS(A, b, L, 3, 30, 1e-2, history=False, **kw)
+            barrier(world)
+            gk[key] = round(world * 30 / (max_over_ranks(time.perf_counter() - t0, world) / reps), 2)
+        gk["gks_solver"] = "GKS(projection_dim=3, n_iter=30, regparam=1e-2), same A, b, L"
+        out.update(gk)
+    except Exception as exc:      # noqa: BLE001
+        out["gks_error"] = f"{type(exc).__name__}: {exc}"[:200]
     if cpu_jobs is not None:
         bh = b.detach().to("cpu")
         cpu_jobs.append((lambda v: out.__setitem__("cpu_baseline", v), lambda: cpu_c4(psf, N, bh)))
