@@ -123,3 +123,30 @@ def test_c4_mmgks_fullsize_vs_float64(N, n_iter):
         assert e < 1e-5, (k, e)
     del hist
     torch.cuda.empty_cache()
+
+
+def test_gks_4096_one_pass_form_equals_the_pass_each_form():
+    """GKS on the C4 problem at 4096^2 (the leg bench.py times beside MMGKS): the iteration with ONE pass over the basis for the new vector
+    and the next iterate (trk_gemv_orth_iterate — the next projected problem solved first, from the h-sweep's products) against the
+    reference's order with a pass each, 30 iterations, basis of 3 .. 33 vectors of 67 MB: every 5th iterate, the residual norms and the
+    errors.  (Both forms were held to the float64 oracle at the sizes it reaches: tests/test_gpu_solvers.py, test_gpu_configs_fullsize.py.)"""
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import Blur2D, FirstDerivative2D
+    dev = torch.device("cuda")
+    N = 4096
+    psf, xt, b = make_problem(N, dev)
+    b32, xt32 = b.float(), xt.float()
+    del b, xt
+    A, L = Blur2D(psf, N, N), FirstDerivative2D(N)
+    keep = {}
+    for tag, kw in (("one", {}), ("each", {"fused_orth_iterate": False})):
+        x, info = S.GKS(A, b32, L, 3, 30, 1e-2, xt32, history=5, **kw)
+        keep[tag] = (x.clone(), [h.reshape(-1).clone() for h in info["xHistory"]], np.array(info["Residual"]), np.array(info["relError"]))
+        del x, info
+        torch.cuda.empty_cache()
+    (xa, ha, ra, ea), (xb, hb, rb, eb) = keep["one"], keep["each"]
+    assert float(torch.linalg.norm(xa - xb) / torch.linalg.norm(xb)) < 1e-6
+    assert len(ha) == len(hb) and len(ha) >= 6
+    for u, v in zip(ha, hb):
+        assert float(torch.linalg.norm(u - v) / torch.linalg.norm(v)) < 1e-6
+    assert np.allclose(ra, rb, rtol=1e-4) and np.allclose(ea, eb, rtol=1e-5)
