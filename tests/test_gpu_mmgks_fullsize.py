@@ -150,3 +150,85 @@ def test_gks_4096_one_pass_form_equals_the_pass_each_form():
     for u, v in zip(ha, hb):
         assert float(torch.linalg.norm(u - v) / torch.linalg.norm(v)) < 1e-6
     assert np.allclose(ra, rb, rtol=1e-4) and np.allclose(ea, eb, rtol=1e-5)
+
+
+def gks64(psf, N, b, d, n_iter, lam):
+    """GKS.py:36-96 with a numeric regparam and the 2-D first-derivative L, float64 on the device (the QRs of AV and LV from scratch every
+    iteration, three Gram-Schmidt sweeps :86-88); returns (iterates, residual norms)."""
+    psf_t = torch.from_numpy(psf).to(b.device, torch.float64)
+    A = lambda v: blur64(v.reshape(N, N), psf_t).reshape(-1)
+    AT = lambda v: blur64(v.reshape(N, N), psf_t, flip=True).reshape(-1)
+    u = b / torch.linalg.norm(b)                               # golub_kahan(A, b, d): decompositions.py:118-205 without reorthogonalisation
+    V, beta_prev, v_prev = [], None, None
+    for k in range(d):
+        v = AT(u)
+        if k:
+            v = v - beta_prev * v_prev
+        alpha = torch.linalg.norm(v)
+        v = v / alpha
+        un = A(v) - alpha * u
+        beta_prev = torch.linalg.norm(un)
+        u = un / beta_prev
+        v_prev = v
+        V.append(v)
+    V = torch.stack(V, 1)
+    AV = torch.stack([A(V[:, j]) for j in range(V.shape[1])], 1)
+    LV = torch.stack([d2_fwd(V[:, j], N) for j in range(V.shape[1])], 1)
+    hist, res = [], []
+    for ii in range(n_iter):
+        Q_A, R_A = torch.linalg.qr(AV)
+        _, R_L = torch.linalg.qr(LV)
+        k = R_A.shape[0]
+        M = torch.cat([R_A, np.sqrt(lam) * R_L])
+        rhs = torch.cat([mtv(Q_A, b), torch.zeros(k, dtype=b.dtype, device=b.device)])
+        y = torch.linalg.lstsq(M, rhs[:, None]).solution[:, 0]
+        x = mv(V, y)
+        hist.append(x.clone())
+        r = AT(mv(AV, y) - b) + lam * d2_adj(mv(LV, y), N)     # :81-85
+        for _ in range(3):
+            r = r - mv(V, mtv(V, r))
+        nr = torch.linalg.norm(r)
+        res.append(float(nr))
+        vn = r / nr
+        V = torch.cat([V, vn[:, None]], 1)
+        AV = torch.cat([AV, A(vn)[:, None]], 1)
+        LV = torch.cat([LV, d2_fwd(vn, N)[:, None]], 1)
+    return hist, res
+
+
+def test_torch64_gks_checker_is_the_oracle_at_128():
+    from oracle import cpu_ref as O
+    dev = torch.device("cuda")
+    N = 128
+    psf, xt, b = make_problem(N, dev)
+    hist, res = gks64(psf, N, b, 3, 8, 1e-2)
+    xo, io = O.gks(O.Blur2D(psf, N, N), b.cpu().numpy().reshape(-1, 1), O.FirstDerivative2D(N), 3, 8, 1e-2)
+    assert len(hist) == len(io["xHistory"]) == 8
+    for k in range(8):
+        assert relerr(hist[k].cpu().numpy(), io["xHistory"][k].reshape(-1)) < 1e-9, k
+    assert np.allclose(res, io["Residual"], rtol=1e-9)
+
+
+@pytest.mark.parametrize("N,n_iter", [(1024, 30), (2048, 20)])
+def test_gks_blur_tv_large_vs_float64(N, n_iter):
+    """GKS on the blur with the 2-D first-derivative regulariser at 1024^2 / 2048^2 — the stencil-operator path: no images A v_j, L v_j kept,
+    both Gram matrices' rows from the orthogonalisation sweep's products, the next projected problem solved before the new vector exists and
+    ONE pass over the basis for it and the next iterate (docs/kernels/projected_gks_mmgks.md 4.3c) — against the float64 restatement of
+    GKS.py on the device, pinned to the oracle above: 1e-5 on every iterate (north_star's tolerance at fixed lambda), the residual norms to 1e-3."""
+    from trips_py_amd import solvers as S
+    from trips_py_amd.operators import Blur2D, FirstDerivative2D
+    dev = torch.device("cuda")
+    psf, xt, b = make_problem(N, dev)
+    b32 = b.float()
+    hist, res = gks64(psf, N, b32.double(), 3, n_iter, 1e-2)
+    x, info = S.GKS(Blur2D(psf, N, N), b32, FirstDerivative2D(N), 3, n_iter, 1e-2)
+    assert len(info["xHistory"]) == len(hist) == n_iter
+    worst = 0.0
+    for k in range(n_iter):
+        e = float(torch.linalg.norm(info["xHistory"][k].reshape(-1).double() - hist[k]) / torch.linalg.norm(hist[k]))
+        worst = max(worst, e)
+        assert e < 1e-5, (k, e)
+    assert np.allclose(info["Residual"], res, rtol=1e-3)
+    print(f"GKS {N}^2: worst iterate distance from float64 {worst:.2e}")
+    del hist
+    torch.cuda.empty_cache()
