@@ -75,6 +75,9 @@ def _solve(eng, nt=4, N=32):
         assert info.get("fused_tv", eng.world == 1)
         out[f"{tag}_gks"] = (x.reshape(-1).cpu().numpy(), np.array(info["Residual"]))
         out[f"{tag}_gks_counts"] = (np.array([(cnt[1][0] - cnt[0][0]) / 2.0, (cnt[1][1] - cnt[0][1]) / 2.0]), np.zeros(1))
+        if tag == "tomo":        # the reference's default regparam on ranks: every rank selects the same lambda from the all-reduced Gram data
+            x, info = S.GKS(F, bl, L, 3, 6, "gcv")
+            out["tomo_gksgcv"] = (x.reshape(-1).cpu().numpy(), np.array(info["regParam_history"], dtype=np.float64))
         x, info = S.MMGKS(F, bl, L, 2, 1, 3, 5, 1e-2)
         out[f"{tag}_mmgks"] = (x.reshape(-1).cpu().numpy(), np.array(info["Residual"]))
         # Golub-Kahan with the half steps inside the projector's output pass (tomo: trk_op_apply_axpby, norms all-reduced
@@ -119,9 +122,13 @@ def test_sharded_hip_path_matches_single_process(world, nt, N):
             continue
         x = np.concatenate([p[f"{key}_x"] for p in parts])
         err = np.linalg.norm(x - ref[key][0]) / np.linalg.norm(ref[key][0])
-        assert err < 2e-5, (key, err)
+        auto = key.endswith("gcv")               # an automatic lambda amplifies the 1e-7 differences of the summation orders
+        assert err < (2e-3 if auto else 2e-5), (key, err)
         for p in parts:
-            assert np.allclose(p[f"{key}_s"], ref[key][1], rtol=1e-4), key
+            assert np.allclose(p[f"{key}_s"], ref[key][1], rtol=5e-2 if auto else 1e-4), key
+        if auto:                                 # ... but every rank must have selected the SAME lambdas
+            for p in parts[1:]:
+                assert np.array_equal(p[f"{key}_s"], parts[0][f"{key}_s"]), key
 
 
 _RCCL_ONE_RANK = r"""
